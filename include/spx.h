@@ -1,0 +1,293 @@
+/*
+ * spx.h — C ABI of the MI355X batched Filter/Score engine (libspx.so).
+ *
+ * This is the drop-in boundary for the one hot path of kubernetes-sigs/scheduler-plugins:
+ * the per-pod x per-node Filter()/Score()/NormalizeScore() loops.  A Go plugin keeps its
+ * framework.FilterPlugin / framework.ScorePlugin method signatures and binds these entry
+ * points through cgo (INTEGRATION.md shows the stub).  Reference interfaces replaced:
+ *
+ *   Allocatable.Score / NormalizeScore   pkg/noderesources/allocatable.go:63,143
+ *   TargetLoadPacking.Score              pkg/trimaran/targetloadpacking/targetloadpacking.go:107
+ *   LoadVariationRiskBalancing.Score     pkg/trimaran/loadvariationriskbalancing/loadvariationriskbalancing.go:84
+ *   TopologyMatch.Filter / Score         pkg/noderesourcetopology/filter.go:179, score.go:62
+ *   NetworkOverhead.PreFilter/Filter/Score/NormalizeScore
+ *                                        pkg/networkaware/networkoverhead/networkoverhead.go:174,326,362,389
+ *   TopologicalSort.Less                 pkg/networkaware/topologicalsort/topologicalsort.go:102
+ *   CapacityScheduling.PreFilter         pkg/capacityscheduling/capacity_scheduling.go:208
+ *
+ * Rules of the boundary (cgo-safe):
+ *   - every function returns int: 0 = ok, <0 = error (spx_last_error() gives the text);
+ *   - all tables are flat arrays of fixed-width ints/doubles, caller-owned and only
+ *     borrowed for the duration of the call (no pointer is retained, no pointer-to-pointer);
+ *   - results live in device memory owned by the engine; rows are fetched into
+ *     caller-provided buffers; fetches after spx_sync() are read-only and lock-free, so
+ *     16 concurrent reader goroutines (upstream Parallelizer) may call spx_fetch_* at once;
+ *   - no global state (unlike targetloadpacking.go:49-53): one engine per scheduler profile.
+ *
+ * Two table levels exist:
+ *   "object tables"  (spx_*_objects): a lossless columnar/CSR image of the API objects the
+ *                    reference reads (pods, nodes, watcher metrics, NRT zones, AppGroups ...);
+ *                    this is what the Go shim marshals.
+ *   "SoA tables"     (spx_*_soa): dense per-node / per-pod columns the kernels read from HBM.
+ *   spx_flatten_*() (host C++, part of this library) turns the former into the latter.
+ *
+ * The header is kept in a regular "one field per line" form because the Python ctypes
+ * binding (scheduler-plugins_amd/_abi.py) parses it — it is the single source of truth.
+ */
+#ifndef SPX_H
+#define SPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ constants */
+
+#define SPX_OK 0
+#define SPX_ERR_ARG (-1)
+#define SPX_ERR_HIP (-2)
+#define SPX_ERR_STATE (-3)
+#define SPX_ERR_NOGPU (-4)
+
+/* plugin ids (bit i of a plugin mask = plugin i) */
+#define SPX_PLUGIN_ALLOCATABLE 0
+#define SPX_PLUGIN_TLP 1
+#define SPX_PLUGIN_LVRB 2
+#define SPX_PLUGIN_NRT 3
+#define SPX_PLUGIN_NETOVERHEAD 4
+#define SPX_PLUGIN_CAPACITY 5
+#define SPX_PLUGIN_TOPOSORT 6
+#define SPX_NUM_PLUGINS 7
+
+/* fwk.Status codes (k8s.io/kube-scheduler/framework) */
+#define SPX_STATUS_SUCCESS 0
+#define SPX_STATUS_ERROR 1
+#define SPX_STATUS_UNSCHEDULABLE 2
+
+/* canonical resource ids; quantities are int64 in canonical units:
+ * cpu = millicores (Quantity.MilliValue()), everything else = Quantity.Value() */
+#define SPX_RES_CPU 0
+#define SPX_RES_MEMORY 1
+#define SPX_RES_EPHEMERAL 2
+#define SPX_RES_PODS 3
+#define SPX_RES_STORAGE 4
+#define SPX_RES_FIRST_DYNAMIC 8
+
+/* resource class flags (spx_resource_classes.flags[id]) */
+#define SPX_RC_HUGEPAGE 1   /* v1helper.IsHugePageResourceName  */
+#define SPX_RC_NATIVE 2     /* v1helper.IsNativeResource        */
+#define SPX_RC_SCALAR 4     /* schedutil.IsScalarResourceName   */
+
+/* container kinds */
+#define SPX_CTR_APP 0
+#define SPX_CTR_INIT 1
+#define SPX_CTR_SIDECAR 2 /* init container with restartPolicy Always (pkg/util/sidecar.go) */
+
+/* watcher metric types / operators (paypal/load-watcher v0.2.4 constants, resolved by the shim) */
+#define SPX_MT_CPU 0
+#define SPX_MT_MEMORY 1
+#define SPX_MT_OTHER 2
+#define SPX_MO_AVG 0
+#define SPX_MO_STD 1
+#define SPX_MO_LATEST 2
+#define SPX_MO_EMPTY 3 /* Operator == "" */
+#define SPX_MO_OTHER 4
+
+/* Allocatable modes (apis/config/types.go ModeType) */
+#define SPX_MODE_LEAST 0
+#define SPX_MODE_MOST 1
+
+/* ------------------------------------------------------------------ object tables */
+
+/* class flags per resource id (ids are interned by the caller once per snapshot) */
+typedef struct spx_resource_classes {
+  int32_t n_res;
+  const uint8_t* flags;
+} spx_resource_classes;
+
+/* v1.Pod image.  Containers of pod i are ctr_ptr[i]..ctr_ptr[i+1]-1, init containers first
+ * (spec order) then app containers (spec order) — the order
+ * append(pod.Spec.InitContainers, pod.Spec.Containers...) the reference walks.
+ * Resource lists are CSR: container c requests = req_res/req_qty[req_ptr[c]..req_ptr[c+1]). */
+typedef struct spx_pod_objects {
+  int64_t n_pods;
+  const int32_t* ctr_ptr;
+  const uint8_t* ctr_kind;
+  const int32_t* req_ptr;
+  const int32_t* req_res;
+  const int64_t* req_qty;
+  const int32_t* lim_ptr;
+  const int32_t* lim_res;
+  const int64_t* lim_qty;
+  const int32_t* ovh_ptr;
+  const int32_t* ovh_res;
+  const int64_t* ovh_qty;
+  const int32_t* priority;
+  const int64_t* queue_ts;
+  const int32_t* appgroup;
+  const int32_t* selector;
+  const int32_t* ns;
+} spx_pod_objects;
+
+/* framework.NodeInfo / v1.Node image */
+typedef struct spx_node_objects {
+  int64_t n_nodes;
+  const int64_t* alloc_cpu_milli;
+  const int64_t* alloc_mem;
+  const int64_t* alloc_eph;
+  const int64_t* alloc_pods;
+  const int32_t* scalar_ptr;
+  const int32_t* scalar_res;
+  const int64_t* scalar_qty;
+  const int64_t* cap_cpu_milli;
+  const int32_t* region;
+  const int32_t* zone;
+} spx_node_objects;
+
+/* watcher.WatcherMetrics image (pkg/trimaran/collector.go:110-123) */
+typedef struct spx_metrics_objects {
+  int32_t map_is_nil;
+  int64_t window_end;
+  const uint8_t* node_present;
+  const uint8_t* node_metrics_nil;
+  const int32_t* m_ptr;
+  const uint8_t* m_type;
+  const uint8_t* m_op;
+  const double* m_value;
+} spx_metrics_objects;
+
+/* PodAssignEventHandler.ScheduledPodsCache image (pkg/trimaran/handler.go:47-58):
+ * entries of node n are e_ptr[n]..e_ptr[n+1]-1; e_pod indexes `pods` */
+typedef struct spx_assigned_objects {
+  const int32_t* e_ptr;
+  const int64_t* e_ts_unix;
+  const int32_t* e_pod;
+  const spx_pod_objects* pods;
+} spx_assigned_objects;
+
+/* ------------------------------------------------------------------ plugin params */
+
+typedef struct spx_allocatable_params {
+  int32_t mode;
+  int32_t n_res;
+  const int32_t* res;
+  const int64_t* weight;
+} spx_allocatable_params;
+
+typedef struct spx_tlp_params {
+  int64_t target_utilization;
+  int64_t default_requests_milli;
+  double requests_multiplier;
+} spx_tlp_params;
+
+typedef struct spx_lvrb_params {
+  double safe_variance_margin;
+  double safe_variance_sensitivity;
+} spx_lvrb_params;
+
+/* ------------------------------------------------------------------ SoA tables (what the kernels read) */
+
+/* Allocatable: alloc is [n_res][n_nodes] resource-major, rows in spx_allocatable_params.res order */
+typedef struct spx_alloc_nodes_soa {
+  int64_t n_nodes;
+  int32_t n_res;
+  const int64_t* alloc;
+} spx_alloc_nodes_soa;
+
+/* trimaran node columns (TLP reads Capacity, LVRB reads Allocatable — SURVEY appendix B.6) */
+typedef struct spx_trimaran_nodes_soa {
+  int64_t n_nodes;
+  const int64_t* cap_cpu_milli;
+  const double* tlp_cpu_util;
+  const int64_t* tlp_missing_milli;
+  const uint8_t* tlp_valid;
+  const int64_t* lv_alloc_cpu_milli;
+  const int64_t* lv_alloc_mem;
+  const double* lv_cpu_avg;
+  const double* lv_cpu_std;
+  const double* lv_mem_avg;
+  const double* lv_mem_std;
+  const uint8_t* lv_flags;
+} spx_trimaran_nodes_soa;
+
+#define SPX_LV_HAS_METRICS 1
+#define SPX_LV_CPU_VALID 2
+#define SPX_LV_MEM_VALID 4
+
+typedef struct spx_trimaran_pods_soa {
+  int64_t n_pods;
+  const int64_t* tlp_pod_milli;
+  const int64_t* lv_req_cpu_milli;
+  const int64_t* lv_req_mem;
+} spx_trimaran_pods_soa;
+
+/* ------------------------------------------------------------------ engine */
+
+typedef struct spx_engine spx_engine;
+
+/* create an engine on HIP device `device_id`; fails with SPX_ERR_NOGPU when no device exists
+ * (there is no CPU fallback by design) */
+int spx_create(int device_id, spx_engine** out);
+int spx_destroy(spx_engine* e);
+/* last error text: of engine `e`, or of the failed spx_create when e == NULL (thread-local) */
+const char* spx_last_error(const spx_engine* e);
+/* number of entry points this build exports, and the ABI version */
+int spx_abi_version(void);
+/* run on an externally owned hipStream_t (e.g. torch's current stream); NULL = engine's own */
+int spx_set_stream(spx_engine* e, void* hip_stream);
+/* the stream kernels are launched on (for HIP-event timing by the caller) */
+int spx_get_stream(spx_engine* e, void** hip_stream);
+
+int spx_set_allocatable_params(spx_engine* e, const spx_allocatable_params* p);
+int spx_set_tlp_params(spx_engine* e, const spx_tlp_params* p);
+int spx_set_lvrb_params(spx_engine* e, const spx_lvrb_params* p);
+
+int spx_upload_alloc_nodes(spx_engine* e, const spx_alloc_nodes_soa* t);
+int spx_upload_trimaran_nodes(spx_engine* e, const spx_trimaran_nodes_soa* t);
+int spx_upload_trimaran_pods(spx_engine* e, const spx_trimaran_pods_soa* t);
+
+/* optional per-(pod,node) feasibility mask for normalizing score plugins: uint8 [n_pods][n_nodes],
+ * non-zero = node passed Filter for that pod (upstream scores feasible nodes only).  NULL clears it. */
+int spx_upload_feasible_mask(spx_engine* e, const uint8_t* mask, int64_t n_pods, int64_t n_nodes);
+
+/* evaluate plugins in `plugin_mask` for pod rows [row_begin,row_end) against all nodes;
+ * asynchronous on the engine stream; result tables stay in HBM */
+int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end);
+int spx_sync(spx_engine* e);
+
+/* normalized score row of one pod (n_nodes bytes, 0..100) */
+int spx_fetch_scores(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out);
+/* filter status row of one pod (n_nodes bytes; 0 = pass, else plugin-specific reason code) */
+int spx_fetch_status(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out);
+/* raw int64 Score() row (before NormalizeScore) recomputed for one pod — the parity harness
+ * and direct-call tests observe raw values (e.g. networkoverhead_test.go:803) */
+int spx_fetch_raw(spx_engine* e, int plugin, int which, int64_t pod_row, int64_t* out);
+
+/* device pointer + row stride (bytes) of a plugin's uint8 score table, for RCCL all-gather
+ * by the caller (torch.distributed) or for zero-copy consumers */
+int spx_score_table(spx_engine* e, int plugin, void** dptr, int64_t* row_stride, int64_t* n_rows);
+/* make the engine write a plugin's score table into caller-owned device memory */
+int spx_bind_score_table(spx_engine* e, int plugin, void* dptr, int64_t row_stride, int64_t n_rows);
+
+/* per-pod weighted argmax over the evaluated plugins: best[k] node indices and their
+ * sum_i weight[i]*score_i (upstream selectHost input); infeasible nodes are skipped */
+int spx_set_plugin_weights(spx_engine* e, const int64_t* weights);
+int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end);
+int spx_fetch_best(spx_engine* e, int64_t row_begin, int64_t row_end, int32_t* node_idx, int64_t* weighted_score);
+
+/* duration in ms of the last spx_eval's kernels measured with HIP events on the engine stream */
+int spx_last_eval_ms(spx_engine* e, float* ms);
+
+/* ------------------------------------------------------------------ host flatteners (object -> SoA) */
+
+/* output buffers are caller-allocated with the sizes noted */
+int spx_flatten_alloc_nodes(const spx_node_objects* nodes, const spx_resource_classes* rc, const spx_allocatable_params* p, int64_t* alloc_out);
+int spx_flatten_trimaran_nodes(const spx_node_objects* nodes, const spx_metrics_objects* metrics, const spx_assigned_objects* assigned, const spx_tlp_params* tlp, int64_t* cap_cpu_milli, double* tlp_cpu_util, int64_t* tlp_missing_milli, uint8_t* tlp_valid, int64_t* lv_alloc_cpu_milli, int64_t* lv_alloc_mem, double* lv_cpu_avg, double* lv_cpu_std, double* lv_mem_avg, double* lv_mem_std, uint8_t* lv_flags);
+int spx_flatten_trimaran_pods(const spx_pod_objects* pods, const spx_tlp_params* tlp, int64_t* tlp_pod_milli, int64_t* lv_req_cpu_milli, int64_t* lv_req_mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPX_H */

@@ -1,0 +1,107 @@
+/*
+ * orc_driver.c — batch driver around the per-(pod,node) oracle functions (TEST INFRASTRUCTURE).
+ *
+ * Call structure restated from upstream RunScorePlugins as the reference's own tests and
+ * benchmarks drive it (pkg/noderesources/allocatable_test.go:289-297,
+ * pkg/trimaran/targetloadpacking/targetloadpacking_test.go:369-381): for each pod, Score() on every
+ * (feasible) node, then the plugin's NormalizeScore() over that pod's node list.
+ *
+ * Threads split POD ROWS between workers.  Upstream instead fans one pod's node loop out over 16
+ * goroutines (Parallelizer, copied at targetloadpacking_test.go:386-405) and joins per pod; the row
+ * split used here has no per-pod join and is therefore the more favourable layout for the CPU.
+ */
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "spx_oracle.h"
+
+typedef struct job {
+  const orc_snapshot* s;
+  int plugin;
+  int64_t row_begin, row_end, base;
+  const uint8_t* mask;
+  int64_t* out_raw;
+  int64_t* out_norm;
+  int rc;
+} job;
+
+static int64_t score_one(const orc_snapshot* s, int plugin, int64_t pod, int64_t node) {
+  switch (plugin) {
+    case SPX_PLUGIN_ALLOCATABLE: return orc_allocatable_score(s->nodes, s->rc, s->alloc_params, node);
+    case SPX_PLUGIN_TLP: return orc_tlp_score(s->nodes, s->metrics, s->assigned, s->pods, s->tlp_params, pod, node);
+    case SPX_PLUGIN_LVRB: return orc_lvrb_score(s->nodes, s->metrics, s->pods, s->lvrb_params, pod, node);
+    default: return 0;
+  }
+}
+
+static void* run(void* arg) {
+  job* j = (job*)arg;
+  const int64_t n = j->s->nodes->n_nodes;
+  int64_t* list = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+  int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+  if (!list || !idx) {
+    j->rc = -1;
+    free(list);
+    free(idx);
+    return 0;
+  }
+  for (int64_t pod = j->row_begin; pod < j->row_end; ++pod) {
+    const uint8_t* m = j->mask ? j->mask + (size_t)pod * (size_t)n : 0;
+    int64_t k = 0;
+    for (int64_t node = 0; node < n; ++node) {
+      if (m && !m[node]) continue; /* upstream only scores nodes that passed Filter */
+      list[k] = score_one(j->s, j->plugin, pod, node);
+      idx[k] = node;
+      ++k;
+    }
+    size_t off = (size_t)(pod - j->base) * (size_t)n;
+    if (j->out_raw) {
+      memset(j->out_raw + off, 0, sizeof(int64_t) * (size_t)n);
+      for (int64_t i = 0; i < k; ++i) j->out_raw[off + (size_t)idx[i]] = list[i];
+    }
+    /* NormalizeScore: Allocatable rescales (allocatable.go:143); TLP and LVRB are no-ops
+     * (targetloadpacking.go:193-195, loadvariationriskbalancing.go:134-136) */
+    if (j->plugin == SPX_PLUGIN_ALLOCATABLE) orc_allocatable_normalize(list, k);
+    if (j->out_norm) {
+      memset(j->out_norm + off, 0, sizeof(int64_t) * (size_t)n);
+      for (int64_t i = 0; i < k; ++i) j->out_norm[off + (size_t)idx[i]] = list[i];
+    }
+  }
+  free(list);
+  free(idx);
+  return 0;
+}
+
+int orc_score_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t row_end,
+                   const uint8_t* mask, int threads, int64_t* out_raw, int64_t* out_norm) {
+  if (!s || row_end < row_begin) return -1;
+  if (threads < 1) threads = 1;
+  int64_t rows = row_end - row_begin;
+  if (threads > rows) threads = (int)(rows > 0 ? rows : 1);
+  job* jobs = (job*)calloc((size_t)threads, sizeof(job));
+  pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+  if (!jobs || !th) return -1;
+  int rc = 0;
+  for (int t = 0; t < threads; ++t) {
+    jobs[t].s = s;
+    jobs[t].plugin = plugin;
+    jobs[t].base = row_begin;
+    jobs[t].row_begin = row_begin + rows * t / threads;
+    jobs[t].row_end = row_begin + rows * (t + 1) / threads;
+    jobs[t].mask = mask;
+    jobs[t].out_raw = out_raw;
+    jobs[t].out_norm = out_norm;
+    if (threads == 1)
+      run(&jobs[t]);
+    else
+      pthread_create(&th[t], 0, run, &jobs[t]);
+  }
+  for (int t = 0; t < threads; ++t) {
+    if (threads > 1) pthread_join(th[t], 0);
+    if (jobs[t].rc) rc = jobs[t].rc;
+  }
+  free(jobs);
+  free(th);
+  return rc;
+}

@@ -1,0 +1,77 @@
+/*
+ * spx_oracle.h — CPU restatement of the reference's Filter/Score algorithms (TEST INFRASTRUCTURE).
+ *
+ * This directory is the checker, never the product: only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load liboracle.so.  The product (libspx.so) must not link,
+ * import or call anything here.
+ *
+ * Every function walks the same object tables (include/spx.h, spx_*_objects) the product's
+ * flatteners consume, one (pod, node) pair at a time, in the reference's own call structure,
+ * and cites the reference file:line it restates.  Arithmetic rules restated from Go:
+ * int64 wraps on overflow and `/` truncates toward zero; float64 is IEEE double without
+ * FMA contraction (build with -ffp-contract=off); math.Round is half-away-from-zero;
+ * int64(float64) truncates toward zero.
+ *
+ * Parity pinning: the known-answer tables of the reference's own unit tests are transcribed
+ * as data under tests/golden/ and checked by tests/test_oracle_golden.py.  The reference is Go
+ * and no Go toolchain exists in this image, so it cannot be executed here.
+ */
+#ifndef SPX_ORACLE_H
+#define SPX_ORACLE_H
+
+#include "../include/spx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- noderesources.Allocatable (pkg/noderesources/allocatable.go, resource_allocation.go) */
+int64_t orc_allocatable_score(const spx_node_objects* nodes, const spx_resource_classes* rc,
+                              const spx_allocatable_params* p, int64_t node);
+void orc_allocatable_normalize(int64_t* scores, int64_t n);
+
+/* ---- trimaran.TargetLoadPacking (pkg/trimaran/targetloadpacking/targetloadpacking.go) */
+int64_t orc_tlp_predict_utilisation(const spx_pod_objects* pods, int32_t ctr, const spx_tlp_params* p);
+int64_t orc_tlp_score(const spx_node_objects* nodes, const spx_metrics_objects* metrics,
+                      const spx_assigned_objects* assigned, const spx_pod_objects* pods,
+                      const spx_tlp_params* p, int64_t pod, int64_t node);
+
+/* ---- trimaran.LoadVariationRiskBalancing (.../loadvariationriskbalancing/{loadvariationriskbalancing,analysis}.go,
+ *      pkg/trimaran/resourcestats.go) */
+typedef struct orc_resource_stats {
+  double used_avg;
+  double used_stdev;
+  double req;
+  double capacity;
+} orc_resource_stats;
+double orc_go_pow(double x, double y);
+double orc_lvrb_compute_score(orc_resource_stats* rs, double margin, double sensitivity);
+void orc_get_mu_sigma(const orc_resource_stats* rs, double* mu, double* sigma);
+int orc_get_resource_data(const spx_metrics_objects* metrics, int64_t node, int type, double* avg, double* stdev);
+void orc_get_resource_requested(const spx_pod_objects* pods, int64_t pod, int64_t* milli_cpu, int64_t* memory);
+int64_t orc_lvrb_score(const spx_node_objects* nodes, const spx_metrics_objects* metrics,
+                       const spx_pod_objects* pods, const spx_lvrb_params* p, int64_t pod, int64_t node);
+
+/* ---- batch drivers: for each pod row in [row_begin,row_end): for each node: Score(); then
+ *      NormalizeScore() over that pod's node list (feasible nodes only when `mask` != NULL, as
+ *      upstream RunScorePlugins does).  out_raw / out_norm are [rows][n_nodes] int64 (either may
+ *      be NULL).  `threads` > 1 splits the node loop like upstream's Parallelizer
+ *      (chunked parallel-for copied at targetloadpacking_test.go:386-405). */
+typedef struct orc_snapshot {
+  const spx_node_objects* nodes;
+  const spx_resource_classes* rc;
+  const spx_pod_objects* pods;
+  const spx_metrics_objects* metrics;
+  const spx_assigned_objects* assigned;
+  const spx_allocatable_params* alloc_params;
+  const spx_tlp_params* tlp_params;
+  const spx_lvrb_params* lvrb_params;
+} orc_snapshot;
+
+int orc_score_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t row_end,
+                   const uint8_t* mask, int threads, int64_t* out_raw, int64_t* out_norm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+"""Builds libspx.so (HIP kernels + C-ABI engine + host flatteners) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the tree to the GPU box.
+-ffp-contract=off is load-bearing: the reference's float64 arithmetic (Go, amd64) never fuses
+multiply-add, and the parity bar for Filter/Score is bit-exactness.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+HOST = PKG / "host"
+OBJ = PKG / "_obj"
+LIB = PKG / "libspx.so"
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+          f"-I{ROOT / 'include'}"]
+DEVICE = ["--offload-arch=gfx950"]
+
+
+def _sources():
+    return sorted(CSRC.glob("*.hip")) + sorted(HOST.glob("*.cc"))
+
+
+def _deps_mtime() -> float:
+    hdrs = list(CSRC.glob("*.h")) + list(HOST.glob("*.h")) + list((ROOT / "include").glob("*.h")) + [Path(__file__)]
+    return max(h.stat().st_mtime for h in hdrs)
+
+
+def build(verbose: bool = False, force: bool = False) -> Path:
+    OBJ.mkdir(exist_ok=True)
+    dep_m = _deps_mtime()
+    objs, rebuilt = [], False
+    procs = []
+    for src in _sources():
+        obj = OBJ / (src.name + ".o")
+        objs.append(obj)
+        if not force and obj.exists() and obj.stat().st_mtime >= max(src.stat().st_mtime, dep_m):
+            continue
+        cmd = [HIPCC, *COMMON]
+        if src.suffix == ".hip":
+            cmd += DEVICE
+        else:
+            cmd += ["-x", "c++"]
+        cmd += ["-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        rebuilt = True
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src.name}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    if rebuilt or not LIB.exists() or force:
+        cmd = [HIPCC, "-shared", "-fPIC", *DEVICE, "-o", str(LIB), *map(str, objs)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB
+
+
+def build_oracle(verbose: bool = False) -> Path:
+    """Compiles the CPU oracle (test infrastructure) — building the checker is not using it."""
+    r = subprocess.run(["make", "-C", str(ROOT / "oracle")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"oracle build failed:\n{r.stdout}")
+    if verbose:
+        print(r.stdout)
+    return ROOT / "oracle" / "_build" / "liboracle.so"
+
+
+if __name__ == "__main__":
+    print(build(verbose=True, force="--force" in sys.argv))
+    print(build_oracle(verbose=True))

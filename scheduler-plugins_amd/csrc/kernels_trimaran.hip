@@ -1,0 +1,378 @@
+// kernels_trimaran.hip — gfx950 kernels for NodeResourcesAllocatable + trimaran TargetLoadPacking +
+// LoadVariationRiskBalancing, evaluated as one dense pods x nodes sweep.
+//
+// Work decomposition (one wavefront = one unit of work):
+//   unit = (node tile of 64*NPL nodes) x (chunk of kPodsPerChunk pod rows)
+//   lane l owns NPL consecutive nodes; their per-node parameters are derived ONCE in the wave
+//   prologue and live in VGPRs for the whole chunk, so the steady state reads nothing from memory
+//   except one scalar (wave-uniform) pod record per row and writes NPL result bytes per lane per
+//   plugin as one coalesced vector store (64*NPL contiguous bytes per wave per row).
+//   HBM traffic is therefore the compulsory P*N bytes per plugin of output; node tables (O(N)) are
+//   re-read per unit from L2.  No LDS is needed: there is no cross-lane reuse — every lane's node
+//   state is private — and the only reduction (Allocatable's min/max) is pod-independent.
+//
+// Arithmetic is the reference's, operation for operation, in IEEE double with contraction off
+// (the TU is compiled with -ffp-contract=off): Go on amd64 never fuses a*b+c.
+//   TLP  : pkg/trimaran/targetloadpacking/targetloadpacking.go:146-186
+//   LVRB : pkg/trimaran/loadvariationriskbalancing/analysis.go:34-60, pkg/trimaran/resourcestats.go:45-86
+//   Alloc: pkg/noderesources/allocatable.go:117-168
+#include "spx_internal.h"
+
+namespace spx {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kPodsPerChunk = 64;
+
+__device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int m) {
+  int lo = __shfl_xor(static_cast<int>(v & 0xffffffffLL), m, kWave);
+  int hi = __shfl_xor(static_cast<int>(v >> 32), m, kWave);
+  return (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Allocatable: raw score per node + NormalizeScore over the whole node list (pod independent when
+// no per-row feasibility mask is installed: allocatable.go:118-126 never reads the pod).
+// One block; N is O(10^4).
+__global__ __launch_bounds__(1024) void k_alloc_prepare(AllocPrepArgs a) {
+  __shared__ int64_t s_lo[16];
+  __shared__ int64_t s_hi[16];
+  const int tid = threadIdx.x;
+  uint64_t wsum = 0;
+  for (int r = 0; r < a.n_res; ++r) wsum += static_cast<uint64_t>(a.weight[r]);
+  int64_t lo = INT64_MAX;
+  int64_t hi = -INT64_MAX;
+  for (int64_t i = tid; i < a.n_nodes; i += 1024) {
+    uint64_t acc = 0;  // Go int64 wraps; do the sums in uint64
+    for (int r = 0; r < a.n_res; ++r) {
+      const int64_t v = a.alloc[static_cast<int64_t>(r) * a.n_nodes + i];
+      int64_t sc = 0;
+      if (a.mode == SPX_MODE_LEAST) sc = static_cast<int64_t>(0 - static_cast<uint64_t>(v));
+      else if (a.mode == SPX_MODE_MOST) sc = v;
+      acc += static_cast<uint64_t>(sc) * static_cast<uint64_t>(a.weight[r]);
+    }
+    const int64_t raw = static_cast<int64_t>(acc) / static_cast<int64_t>(wsum);  // truncates toward zero
+    a.raw[i] = raw;
+    lo = raw < lo ? raw : lo;
+    hi = raw > hi ? raw : hi;
+  }
+  for (int m = 32; m >= 1; m >>= 1) {
+    const int64_t olo = shfl_xor_i64(lo, m);
+    const int64_t ohi = shfl_xor_i64(hi, m);
+    lo = olo < lo ? olo : lo;
+    hi = ohi > hi ? ohi : hi;
+  }
+  if ((tid & 63) == 0) {
+    s_lo[tid >> 6] = lo;
+    s_hi[tid >> 6] = hi;
+  }
+  __syncthreads();
+  lo = s_lo[0];
+  hi = s_hi[0];
+  for (int w = 1; w < 16; ++w) {
+    lo = s_lo[w] < lo ? s_lo[w] : lo;
+    hi = s_hi[w] > hi ? s_hi[w] : hi;
+  }
+  const int64_t range = static_cast<int64_t>(static_cast<uint64_t>(hi) - static_cast<uint64_t>(lo));
+  for (int64_t i = tid; i < a.row_stride; i += 1024) {
+    int64_t v = 0;
+    if (i < a.n_nodes && range != 0) {
+      const uint64_t d = static_cast<uint64_t>(a.raw[i]) - static_cast<uint64_t>(lo);
+      v = static_cast<int64_t>(d * 100ull) / range;
+    }
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    a.norm[i] = static_cast<uint8_t>(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-node state held in registers
+
+struct TlpNode {
+  double util_millis;  // (util% / 100) * cap   targetloadpacking.go:147
+  double missing;      // float64(missingCPUUtilMillis)
+  double cap;          // float64(Capacity.Cpu().MilliValue())
+  bool valid;          // metrics != nil && cpuMetricFound
+};
+
+__device__ __forceinline__ double tlp_predicted(const TlpNode& n, double pod_milli) {
+  double predicted = 0.0;
+  if (n.cap != 0.0) predicted = 100.0 * ((n.util_millis + pod_milli) + n.missing) / n.cap;  // :170-173
+  return predicted;
+}
+
+// float64 value the reference rounds; *zero is set when the reference returns MinNodeScore outright
+__device__ __forceinline__ double tlp_unrounded(const TlpNode& n, double pod_milli, double t, bool* zero) {
+  *zero = false;
+  if (!n.valid) {
+    *zero = true;
+    return 0.0;
+  }
+  const double predicted = tlp_predicted(n, pod_milli);
+  if (predicted > t) {  // :174-181
+    if (predicted > 100.0) {
+      *zero = true;
+      return 0.0;
+    }
+    return t * (100.0 - predicted) / (100.0 - t);
+  }
+  return (100.0 - t) * predicted / t + t;  // :183-184
+}
+
+// LVRB per resource: state 0 = metric type absent (CreateResourceStats !ok), 1 = capacity <= 0
+// (computeScore returns 0), 2 = regular
+struct LvRes {
+  double cap;
+  double used_avg;  // clamped to [0, cap]   analysis.go:42
+  double sigma;     // final sigma (pod independent) analysis.go:43-54
+  int state;
+};
+
+// math.Pow as the plugin reaches it (x in [0,1]); exact for y in {0,1,2,0.5,+Inf}; see oracle note.
+__device__ double go_pow01(double x, double y) {
+  if (y == 0.0 || x == 1.0) return 1.0;
+  if (y == 1.0) return x;
+  if (x != x || y != y) return x + y;
+  if (x == 0.0) return y < 0.0 ? __builtin_inf() : 0.0;
+  if (__builtin_isinf(y)) return ((fabs(x) < 1.0) == (y > 0.0)) ? 0.0 : __builtin_inf();
+  if (y == 0.5) return sqrt(x);
+  if (y == -0.5) return 1.0 / sqrt(x);
+  if (y == 2.0) return x * x;
+  return pow(x, y);
+}
+
+__device__ __forceinline__ LvRes lv_make(bool valid, double cap, double util, double sd, double margin, double sens) {
+  LvRes r;
+  r.cap = cap;
+  r.used_avg = 0.0;
+  r.sigma = 0.0;
+  if (!valid) {
+    r.state = 0;
+    return r;
+  }
+  if (cap <= 0.0) {
+    r.state = 1;
+    return r;
+  }
+  r.state = 2;
+  double used_avg = util * cap / 100.0;  // resourcestats.go:68
+  double used_sd = sd * cap / 100.0;     // :69
+  used_avg = fmax(fmin(used_avg, cap), 0.0);
+  used_sd = fmax(fmin(used_sd, cap), 0.0);
+  double sigma = used_sd / cap;
+  sigma = fmax(fmin(sigma, 1.0), 0.0);
+  if (sens >= 0.0) sigma = go_pow01(sigma, 1.0 / sens);
+  sigma *= margin;
+  sigma = fmax(fmin(sigma, 1.0), 0.0);
+  r.used_avg = used_avg;
+  r.sigma = sigma;
+  return r;
+}
+
+__device__ __forceinline__ double lv_res_score(const LvRes& r, double req) {
+  if (r.state != 2) return 0.0;
+  double mu = (r.used_avg + req) / r.cap;
+  mu = fmax(fmin(mu, 1.0), 0.0);
+  const double risk = (mu + r.sigma) / 2.0;
+  return (1.0 - risk) * 100.0;
+}
+
+__device__ __forceinline__ double lv_total(bool has_metrics, const LvRes& c, const LvRes& m, double req_cpu, double req_mem) {
+  if (!has_metrics) return 0.0;
+  const double cs = lv_res_score(c, req_cpu);
+  const double ms = lv_res_score(m, req_mem);
+  return (c.state != 0 && m.state != 0) ? fmin(ms, cs) : fmax(ms, cs);
+}
+
+constexpr double kMega = 1.0 / 1024.0 / 1024.0;  // resourcestats.go:29
+
+__device__ __forceinline__ uint32_t to_u8(double unrounded) {
+  // int64(math.Round(x)) then saturate into the uint8 table cell
+  int v = static_cast<int>(round(unrounded));
+  v = v < 0 ? 0 : (v > 255 ? 255 : v);
+  return static_cast<uint32_t>(v);
+}
+
+template <int NPL>
+struct Vec;
+template <>
+struct Vec<4> { using T = uint32_t; };
+template <>
+struct Vec<8> { using T = uint2; };
+template <>
+struct Vec<16> { using T = uint4; };
+
+template <int NPL>
+__device__ __forceinline__ void store_bytes(uint8_t* dst, const uint32_t (&w)[NPL / 4]) {
+  using V = typename Vec<NPL>::T;
+  V v;
+  __builtin_memcpy(&v, w, sizeof(V));
+  *reinterpret_cast<V*>(dst) = v;
+}
+
+template <int NPL, bool A, bool T, bool L>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_trimaran(TrimaranArgs a, int n_tiles) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+  const int tile = static_cast<int>(unit % n_tiles);
+  const int64_t chunk = unit / n_tiles;
+  const int64_t pod0 = a.row_begin + chunk * kPodsPerChunk;
+  if (pod0 >= a.row_end) return;
+  const int64_t pod1 = (pod0 + kPodsPerChunk < a.row_end) ? pod0 + kPodsPerChunk : a.row_end;
+  const int64_t node0 = (static_cast<int64_t>(tile) * kWave + lane) * NPL;
+  const bool active = node0 < a.row_stride;  // row_stride is a multiple of 16 >= n_nodes
+
+  // ---- prologue: per-node state into registers
+  uint32_t alloc_w[NPL / 4];
+  TlpNode tn[NPL];
+  LvRes lc[NPL], lm[NPL];
+  bool lhas[NPL];
+  if constexpr (A) {
+#pragma unroll
+    for (int j = 0; j < NPL / 4; ++j) alloc_w[j] = active ? reinterpret_cast<const uint32_t*>(a.alloc_norm + node0)[j] : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    const int64_t n = node0 + j;
+    const bool in = n < a.n_nodes;
+    if constexpr (T) {
+      const double cap = in ? static_cast<double>(a.cap_cpu_milli[n]) : 0.0;
+      const double util = in ? a.tlp_cpu_util[n] : 0.0;
+      tn[j].cap = cap;
+      tn[j].util_millis = (util / 100.0) * cap;
+      tn[j].missing = in ? static_cast<double>(a.tlp_missing_milli[n]) : 0.0;
+      tn[j].valid = in && a.tlp_valid[n] != 0;
+    }
+    if constexpr (L) {
+      const uint8_t f = in ? a.lv_flags[n] : 0;
+      lhas[j] = (f & SPX_LV_HAS_METRICS) != 0;
+      const double ccap = in ? static_cast<double>(a.lv_alloc_cpu_milli[n]) : 0.0;
+      double mcap = in ? static_cast<double>(a.lv_alloc_mem[n]) : 0.0;
+      mcap *= kMega;
+      lc[j] = lv_make((f & SPX_LV_CPU_VALID) != 0, ccap, in ? a.lv_cpu_avg[n] : 0.0, in ? a.lv_cpu_std[n] : 0.0,
+                      a.lv_margin, a.lv_sensitivity);
+      lm[j] = lv_make((f & SPX_LV_MEM_VALID) != 0, mcap, in ? a.lv_mem_avg[n] : 0.0, in ? a.lv_mem_std[n] : 0.0,
+                      a.lv_margin, a.lv_sensitivity);
+    }
+  }
+  if (!active) return;
+
+  // ---- steady state: one pod row per iteration
+  for (int64_t pod = pod0; pod < pod1; ++pod) {
+    const int64_t row = pod * a.row_stride + node0;
+    if constexpr (A) store_bytes<NPL>(a.out_alloc + row, alloc_w);
+    if constexpr (T) {
+      const double pod_milli = static_cast<double>(a.tlp_pod_milli[pod]);
+      uint32_t w[NPL / 4];
+#pragma unroll
+      for (int j = 0; j < NPL / 4; ++j) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bool zero;
+          const double x = tlp_unrounded(tn[j * 4 + k], pod_milli, a.tlp_target, &zero);
+          acc |= (zero ? 0u : to_u8(x)) << (8 * k);
+        }
+        w[j] = acc;
+      }
+      store_bytes<NPL>(a.out_tlp + row, w);
+    }
+    if constexpr (L) {
+      const double req_cpu = fmax(static_cast<double>(a.lv_req_cpu_milli[pod]), 0.0);           // analysis.go:41
+      const double req_mem = fmax(static_cast<double>(a.lv_req_mem[pod]) * kMega, 0.0);          // resourcestats.go:64
+      uint32_t w[NPL / 4];
+#pragma unroll
+      for (int j = 0; j < NPL / 4; ++j) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int q = j * 4 + k;
+          acc |= to_u8(lv_total(lhas[q], lc[q], lm[q], req_cpu, req_mem)) << (8 * k);
+        }
+        w[j] = acc;
+      }
+      store_bytes<NPL>(a.out_lvrb + row, w);
+    }
+  }
+}
+
+// raw int64 Score() of one row (parity harness / direct-call tests); one thread per node
+__global__ void k_trimaran_raw(TrimaranArgs a, int plugin, int64_t pod, int64_t* out) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= a.n_nodes) return;
+  double x = 0.0;
+  bool zero = false;
+  if (plugin == SPX_PLUGIN_TLP) {
+    TlpNode t;
+    t.cap = static_cast<double>(a.cap_cpu_milli[n]);
+    t.util_millis = (a.tlp_cpu_util[n] / 100.0) * t.cap;
+    t.missing = static_cast<double>(a.tlp_missing_milli[n]);
+    t.valid = a.tlp_valid[n] != 0;
+    x = tlp_unrounded(t, static_cast<double>(a.tlp_pod_milli[pod]), a.tlp_target, &zero);
+  } else {
+    const uint8_t f = a.lv_flags[n];
+    double mcap = static_cast<double>(a.lv_alloc_mem[n]);
+    mcap *= kMega;
+    const LvRes c = lv_make((f & SPX_LV_CPU_VALID) != 0, static_cast<double>(a.lv_alloc_cpu_milli[n]), a.lv_cpu_avg[n],
+                            a.lv_cpu_std[n], a.lv_margin, a.lv_sensitivity);
+    const LvRes m = lv_make((f & SPX_LV_MEM_VALID) != 0, mcap, a.lv_mem_avg[n], a.lv_mem_std[n], a.lv_margin,
+                            a.lv_sensitivity);
+    const double req_cpu = fmax(static_cast<double>(a.lv_req_cpu_milli[pod]), 0.0);
+    const double req_mem = fmax(static_cast<double>(a.lv_req_mem[pod]) * kMega, 0.0);
+    x = lv_total((f & SPX_LV_HAS_METRICS) != 0, c, m, req_cpu, req_mem);
+  }
+  out[n] = zero ? 0 : static_cast<int64_t>(round(x));
+}
+
+template <int NPL>
+void launch_npl(const TrimaranArgs& a, hipStream_t s) {
+  const int tile_nodes = kWave * NPL;
+  const int n_tiles = static_cast<int>((a.row_stride + tile_nodes - 1) / tile_nodes);
+  const int64_t rows = a.row_end - a.row_begin;
+  const int64_t chunks = (rows + kPodsPerChunk - 1) / kPodsPerChunk;
+  const int64_t units = chunks * n_tiles;
+  const unsigned blocks = static_cast<unsigned>((units + kWavesPerBlock - 1) / kWavesPerBlock);
+  const dim3 block(kWave * kWavesPerBlock);
+  const bool A = a.out_alloc != nullptr, T = a.out_tlp != nullptr, L = a.out_lvrb != nullptr;
+#define SPX_CASE(AA, TT, LL)                                                                      \
+  if (A == AA && T == TT && L == LL) {                                                            \
+    hipLaunchKernelGGL((k_trimaran<NPL, AA, TT, LL>), dim3(blocks), block, 0, s, a, n_tiles);    \
+    return;                                                                                       \
+  }
+  SPX_CASE(true, false, false)
+  SPX_CASE(false, true, false)
+  SPX_CASE(false, false, true)
+  SPX_CASE(true, true, false)
+  SPX_CASE(true, false, true)
+  SPX_CASE(false, true, true)
+  SPX_CASE(true, true, true)
+#undef SPX_CASE
+}
+
+}  // namespace
+
+void launch_alloc_prepare(const AllocPrepArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_alloc_prepare, dim3(1), dim3(1024), 0, s, a);
+}
+
+void launch_trimaran(const TrimaranArgs& a, hipStream_t s) {
+  if (a.row_end <= a.row_begin) return;
+  if (!a.out_alloc && !a.out_tlp && !a.out_lvrb) return;
+  // nodes per lane: wide stores when only TLP state (3 doubles/node) must stay resident,
+  // narrower when LVRB adds 6 more doubles per node
+  const bool L = a.out_lvrb != nullptr;
+  const bool T = a.out_tlp != nullptr;
+  if (L && T) launch_npl<4>(a, s);
+  else if (L) launch_npl<8>(a, s);
+  else launch_npl<16>(a, s);
+}
+
+void launch_trimaran_raw(const TrimaranArgs& a, int plugin, int64_t pod_row, int64_t* out, hipStream_t s) {
+  const unsigned blocks = static_cast<unsigned>((a.n_nodes + 255) / 256);
+  hipLaunchKernelGGL(k_trimaran_raw, dim3(blocks), dim3(256), 0, s, a, plugin, pod_row, out);
+}
+
+}  // namespace spx

@@ -1,0 +1,480 @@
+// spx_engine.hip — the C-ABI engine of libspx.so: device-resident SoA tables, result tables in
+// HBM, kernel dispatch on one HIP stream, row-granular fetch.  See include/spx.h for the contract.
+//
+// There is deliberately no CPU fallback: spx_create() fails with SPX_ERR_NOGPU when no HIP device
+// is usable, and every compute entry point needs an engine.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "spx_internal.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  bool external = false;
+};
+
+}  // namespace
+
+struct spx_engine {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  mutable std::string err;
+
+  int64_t n_nodes = -1;
+  int64_t n_pods = -1;
+  int64_t row_stride = 0;
+
+  // params
+  int32_t alloc_mode = SPX_MODE_LEAST;
+  std::vector<int32_t> alloc_res{SPX_RES_MEMORY, SPX_RES_CPU};
+  std::vector<int64_t> alloc_weight{1, 1 << 20};  // defaultResourcesToWeightMap resource_allocation.go:36
+  spx_tlp_params tlp{40, 1000, 1.5};             // apis/config/v1/defaults.go:51-55
+  spx_lvrb_params lvrb{1.0, 1.0};                // defaults.go:65-67
+  int64_t plugin_weight[SPX_NUM_PLUGINS] = {1, 1, 1, 1, 1, 1, 1};
+
+  // device tables
+  DevBuf d_alloc, d_alloc_w, d_alloc_raw, d_alloc_norm;
+  int32_t alloc_n_res = 0;
+  bool alloc_ready = false;  // raw/norm computed for the current table + params
+  DevBuf d_cap_cpu, d_tlp_util, d_tlp_missing, d_tlp_valid;
+  DevBuf d_lv_acpu, d_lv_amem, d_lv_cavg, d_lv_cstd, d_lv_mavg, d_lv_mstd, d_lv_flags;
+  bool tri_nodes = false;
+  DevBuf d_tlp_pod, d_lv_rcpu, d_lv_rmem;
+  bool tri_pods = false;
+  DevBuf d_raw_row;  // int64 [n_nodes] staging for spx_fetch_raw
+
+  DevBuf score[SPX_NUM_PLUGINS];
+  int64_t score_rows[SPX_NUM_PLUGINS] = {0};
+  int64_t score_stride[SPX_NUM_PLUGINS] = {0};
+  uint32_t evaluated = 0;  // plugins with valid rows
+  int64_t eval_begin = 0, eval_end = 0;
+};
+
+namespace {
+
+int fail(const spx_engine* e, int code, const std::string& msg) {
+  if (e) e->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define SPX_HIP(e, call)                                                                          \
+  do {                                                                                            \
+    hipError_t _st = (call);                                                                      \
+    if (_st != hipSuccess)                                                                        \
+      return fail((e), SPX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_st));          \
+  } while (0)
+
+int ensure(spx_engine* e, DevBuf& b, size_t bytes) {
+  if (b.external) return fail(e, SPX_ERR_STATE, "internal: resize of an externally bound buffer");
+  if (bytes == 0) bytes = 16;
+  if (b.bytes >= bytes) return SPX_OK;
+  if (b.p) SPX_HIP(e, hipFree(b.p));
+  b.p = nullptr;
+  b.bytes = 0;
+  SPX_HIP(e, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return SPX_OK;
+}
+
+int upload(spx_engine* e, DevBuf& b, const void* src, size_t bytes) {
+  if (!src) return fail(e, SPX_ERR_ARG, "NULL column in table");
+  int rc = ensure(e, b, bytes);
+  if (rc) return rc;
+  if (bytes) SPX_HIP(e, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, e->stream));
+  return SPX_OK;
+}
+
+int set_nodes(spx_engine* e, int64_t n) {
+  if (n <= 0) return fail(e, SPX_ERR_ARG, "n_nodes must be positive");
+  if (e->n_nodes != -1 && e->n_nodes != n)
+    return fail(e, SPX_ERR_STATE, "n_nodes differs from tables already uploaded (one snapshot per engine; destroy and re-create to change shape)");
+  e->n_nodes = n;
+  e->row_stride = spx::round_up(n, spx::kRowAlign);
+  return SPX_OK;
+}
+
+int set_pods(spx_engine* e, int64_t p) {
+  if (p <= 0) return fail(e, SPX_ERR_ARG, "n_pods must be positive");
+  if (e->n_pods != -1 && e->n_pods != p)
+    return fail(e, SPX_ERR_STATE, "n_pods differs from tables already uploaded");
+  e->n_pods = p;
+  return SPX_OK;
+}
+
+int ensure_score_table(spx_engine* e, int plugin) {
+  DevBuf& b = e->score[plugin];
+  if (b.external) {
+    if (e->score_rows[plugin] < e->n_pods || e->score_stride[plugin] < e->row_stride)
+      return fail(e, SPX_ERR_STATE, "bound score table is smaller than n_pods x row_stride");
+    return SPX_OK;
+  }
+  int rc = ensure(e, b, static_cast<size_t>(e->n_pods) * static_cast<size_t>(e->row_stride));
+  if (rc) return rc;
+  e->score_rows[plugin] = e->n_pods;
+  e->score_stride[plugin] = e->row_stride;
+  return SPX_OK;
+}
+
+int prepare_alloc(spx_engine* e) {
+  if (e->alloc_ready) return SPX_OK;
+  if (!e->d_alloc.p) return fail(e, SPX_ERR_STATE, "Allocatable: spx_upload_alloc_nodes not called");
+  if (e->alloc_n_res != static_cast<int32_t>(e->alloc_res.size()))
+    return fail(e, SPX_ERR_STATE, "Allocatable: uploaded table has a different resource count than the params");
+  int rc = upload(e, e->d_alloc_w, e->alloc_weight.data(), e->alloc_weight.size() * sizeof(int64_t));
+  if (rc) return rc;
+  if ((rc = ensure(e, e->d_alloc_raw, static_cast<size_t>(e->n_nodes) * sizeof(int64_t)))) return rc;
+  if ((rc = ensure(e, e->d_alloc_norm, static_cast<size_t>(e->row_stride)))) return rc;
+  spx::AllocPrepArgs a{};
+  a.n_nodes = e->n_nodes;
+  a.row_stride = e->row_stride;
+  a.n_res = e->alloc_n_res;
+  a.mode = e->alloc_mode;
+  a.alloc = static_cast<const int64_t*>(e->d_alloc.p);
+  a.weight = static_cast<const int64_t*>(e->d_alloc_w.p);
+  a.raw = static_cast<int64_t*>(e->d_alloc_raw.p);
+  a.norm = static_cast<uint8_t*>(e->d_alloc_norm.p);
+  spx::launch_alloc_prepare(a, e->stream);
+  SPX_HIP(e, hipGetLastError());
+  e->alloc_ready = true;
+  return SPX_OK;
+}
+
+void fill_trimaran(const spx_engine* e, spx::TrimaranArgs& a) {
+  a.n_nodes = e->n_nodes;
+  a.row_stride = e->row_stride;
+  a.alloc_norm = static_cast<const uint8_t*>(e->d_alloc_norm.p);
+  a.cap_cpu_milli = static_cast<const int64_t*>(e->d_cap_cpu.p);
+  a.tlp_cpu_util = static_cast<const double*>(e->d_tlp_util.p);
+  a.tlp_missing_milli = static_cast<const int64_t*>(e->d_tlp_missing.p);
+  a.tlp_valid = static_cast<const uint8_t*>(e->d_tlp_valid.p);
+  a.tlp_pod_milli = static_cast<const int64_t*>(e->d_tlp_pod.p);
+  a.tlp_target = static_cast<double>(e->tlp.target_utilization);
+  a.lv_alloc_cpu_milli = static_cast<const int64_t*>(e->d_lv_acpu.p);
+  a.lv_alloc_mem = static_cast<const int64_t*>(e->d_lv_amem.p);
+  a.lv_cpu_avg = static_cast<const double*>(e->d_lv_cavg.p);
+  a.lv_cpu_std = static_cast<const double*>(e->d_lv_cstd.p);
+  a.lv_mem_avg = static_cast<const double*>(e->d_lv_mavg.p);
+  a.lv_mem_std = static_cast<const double*>(e->d_lv_mstd.p);
+  a.lv_flags = static_cast<const uint8_t*>(e->d_lv_flags.p);
+  a.lv_req_cpu_milli = static_cast<const int64_t*>(e->d_lv_rcpu.p);
+  a.lv_req_mem = static_cast<const int64_t*>(e->d_lv_rmem.p);
+  a.lv_margin = e->lvrb.safe_variance_margin;
+  a.lv_sensitivity = e->lvrb.safe_variance_sensitivity;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spx_abi_version(void) { return 1; }
+
+const char* spx_last_error(const spx_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int spx_create(int device_id, spx_engine** out) {
+  if (!out) return fail(nullptr, SPX_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t st = hipGetDeviceCount(&count);
+  if (st != hipSuccess || count <= 0)
+    return fail(nullptr, SPX_ERR_NOGPU, std::string("no HIP device available (") + hipGetErrorString(st) +
+                                            "); libspx has no CPU fallback");
+  if (device_id < 0 || device_id >= count) return fail(nullptr, SPX_ERR_ARG, "device_id out of range");
+  spx_engine* e = new spx_engine();
+  e->device = device_id;
+  if ((st = hipSetDevice(device_id)) != hipSuccess || (st = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+      (st = hipEventCreate(&e->ev0)) != hipSuccess || (st = hipEventCreate(&e->ev1)) != hipSuccess) {
+    std::string msg = std::string("engine init: ") + hipGetErrorString(st);
+    delete e;
+    return fail(nullptr, SPX_ERR_HIP, msg);
+  }
+  e->stream = e->own_stream;
+  *out = e;
+  return SPX_OK;
+}
+
+int spx_destroy(spx_engine* e) {
+  if (!e) return SPX_OK;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  DevBuf* bufs[] = {&e->d_alloc,   &e->d_alloc_w,  &e->d_alloc_raw, &e->d_alloc_norm, &e->d_cap_cpu, &e->d_tlp_util,
+                    &e->d_tlp_missing, &e->d_tlp_valid, &e->d_lv_acpu, &e->d_lv_amem, &e->d_lv_cavg, &e->d_lv_cstd,
+                    &e->d_lv_mavg, &e->d_lv_mstd,  &e->d_lv_flags,  &e->d_tlp_pod,    &e->d_lv_rcpu, &e->d_lv_rmem,
+                    &e->d_raw_row};
+  for (DevBuf* b : bufs)
+    if (b->p && !b->external) (void)hipFree(b->p);
+  for (int i = 0; i < SPX_NUM_PLUGINS; ++i)
+    if (e->score[i].p && !e->score[i].external) (void)hipFree(e->score[i].p);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e;
+  return SPX_OK;
+}
+
+int spx_set_stream(spx_engine* e, void* hip_stream) {
+  if (!e) return SPX_ERR_ARG;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  e->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
+  return SPX_OK;
+}
+
+int spx_get_stream(spx_engine* e, void** hip_stream) {
+  if (!e || !hip_stream) return SPX_ERR_ARG;
+  *hip_stream = static_cast<void*>(e->stream);
+  return SPX_OK;
+}
+
+int spx_set_allocatable_params(spx_engine* e, const spx_allocatable_params* p) {
+  if (!e || !p) return SPX_ERR_ARG;
+  if (p->mode != SPX_MODE_LEAST && p->mode != SPX_MODE_MOST) return fail(e, SPX_ERR_ARG, "invalid mode");
+  if (p->n_res <= 0) return fail(e, SPX_ERR_ARG, "n_res must be positive");
+  for (int32_t r = 0; r < p->n_res; ++r) {
+    if (p->weight[r] <= 0) {  // validateResources allocatable.go:53-61
+      char buf[160];
+      std::snprintf(buf, sizeof buf, "resource Weight of %d should be a positive value, got %lld", p->res[r],
+                    static_cast<long long>(p->weight[r]));
+      return fail(e, SPX_ERR_ARG, buf);
+    }
+  }
+  e->alloc_mode = p->mode;
+  e->alloc_res.assign(p->res, p->res + p->n_res);
+  e->alloc_weight.assign(p->weight, p->weight + p->n_res);
+  e->alloc_ready = false;
+  return SPX_OK;
+}
+
+int spx_set_tlp_params(spx_engine* e, const spx_tlp_params* p) {
+  if (!e || !p) return SPX_ERR_ARG;
+  e->tlp = *p;
+  return SPX_OK;
+}
+
+int spx_set_lvrb_params(spx_engine* e, const spx_lvrb_params* p) {
+  if (!e || !p) return SPX_ERR_ARG;
+  e->lvrb = *p;
+  return SPX_OK;
+}
+
+int spx_set_plugin_weights(spx_engine* e, const int64_t* weights) {
+  if (!e || !weights) return SPX_ERR_ARG;
+  std::memcpy(e->plugin_weight, weights, sizeof e->plugin_weight);
+  return SPX_OK;
+}
+
+int spx_upload_alloc_nodes(spx_engine* e, const spx_alloc_nodes_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  int rc = set_nodes(e, t->n_nodes);
+  if (rc) return rc;
+  if (t->n_res <= 0) return fail(e, SPX_ERR_ARG, "n_res must be positive");
+  rc = upload(e, e->d_alloc, t->alloc, static_cast<size_t>(t->n_res) * static_cast<size_t>(t->n_nodes) * sizeof(int64_t));
+  if (rc) return rc;
+  e->alloc_n_res = t->n_res;
+  e->alloc_ready = false;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));  // host columns are only borrowed for the call
+  return SPX_OK;
+}
+
+int spx_upload_trimaran_nodes(spx_engine* e, const spx_trimaran_nodes_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  int rc = set_nodes(e, t->n_nodes);
+  if (rc) return rc;
+  const size_t n = static_cast<size_t>(t->n_nodes);
+  if ((rc = upload(e, e->d_cap_cpu, t->cap_cpu_milli, n * 8))) return rc;
+  if ((rc = upload(e, e->d_tlp_util, t->tlp_cpu_util, n * 8))) return rc;
+  if ((rc = upload(e, e->d_tlp_missing, t->tlp_missing_milli, n * 8))) return rc;
+  if ((rc = upload(e, e->d_tlp_valid, t->tlp_valid, n))) return rc;
+  if ((rc = upload(e, e->d_lv_acpu, t->lv_alloc_cpu_milli, n * 8))) return rc;
+  if ((rc = upload(e, e->d_lv_amem, t->lv_alloc_mem, n * 8))) return rc;
+  if ((rc = upload(e, e->d_lv_cavg, t->lv_cpu_avg, n * 8))) return rc;
+  if ((rc = upload(e, e->d_lv_cstd, t->lv_cpu_std, n * 8))) return rc;
+  if ((rc = upload(e, e->d_lv_mavg, t->lv_mem_avg, n * 8))) return rc;
+  if ((rc = upload(e, e->d_lv_mstd, t->lv_mem_std, n * 8))) return rc;
+  if ((rc = upload(e, e->d_lv_flags, t->lv_flags, n))) return rc;
+  e->tri_nodes = true;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  return SPX_OK;
+}
+
+int spx_upload_trimaran_pods(spx_engine* e, const spx_trimaran_pods_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  int rc = set_pods(e, t->n_pods);
+  if (rc) return rc;
+  const size_t p = static_cast<size_t>(t->n_pods);
+  if ((rc = upload(e, e->d_tlp_pod, t->tlp_pod_milli, p * 8))) return rc;
+  if ((rc = upload(e, e->d_lv_rcpu, t->lv_req_cpu_milli, p * 8))) return rc;
+  if ((rc = upload(e, e->d_lv_rmem, t->lv_req_mem, p * 8))) return rc;
+  e->tri_pods = true;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  return SPX_OK;
+}
+
+int spx_upload_feasible_mask(spx_engine* e, const uint8_t* mask, int64_t n_pods, int64_t n_nodes) {
+  if (!e) return SPX_ERR_ARG;
+  (void)mask;
+  (void)n_pods;
+  (void)n_nodes;
+  return fail(e, SPX_ERR_STATE, "feasibility masks are not implemented in this build");
+}
+
+int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end) {
+  if (!e) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  const uint32_t known = (1u << SPX_PLUGIN_ALLOCATABLE) | (1u << SPX_PLUGIN_TLP) | (1u << SPX_PLUGIN_LVRB);
+  if (plugin_mask == 0 || (plugin_mask & ~known)) return fail(e, SPX_ERR_ARG, "plugin mask has unsupported bits");
+  if (e->n_nodes <= 0) return fail(e, SPX_ERR_STATE, "no node table uploaded");
+  const bool A = plugin_mask & (1u << SPX_PLUGIN_ALLOCATABLE);
+  const bool T = plugin_mask & (1u << SPX_PLUGIN_TLP);
+  const bool L = plugin_mask & (1u << SPX_PLUGIN_LVRB);
+  if ((T || L) && !(e->tri_nodes && e->tri_pods)) return fail(e, SPX_ERR_STATE, "trimaran node/pod tables not uploaded");
+  if (e->n_pods <= 0) {
+    if (T || L) return fail(e, SPX_ERR_STATE, "no pod table uploaded");
+    return fail(e, SPX_ERR_STATE, "n_pods unknown: upload a pod table first");
+  }
+  if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
+  int rc;
+  if (A && (rc = prepare_alloc(e))) return rc;
+  for (int p = 0; p < 3; ++p)
+    if ((plugin_mask & (1u << p)) && (rc = ensure_score_table(e, p))) return rc;
+
+  spx::TrimaranArgs a{};
+  fill_trimaran(e, a);
+  a.row_begin = row_begin;
+  a.row_end = row_end;
+  // all three tables share row_stride when engine-owned; bound tables must use it too
+  for (int p = 0; p < 3; ++p)
+    if ((plugin_mask & (1u << p)) && e->score_stride[p] != e->row_stride)
+      return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
+  a.out_alloc = A ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_ALLOCATABLE].p) : nullptr;
+  a.out_tlp = T ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_TLP].p) : nullptr;
+  a.out_lvrb = L ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_LVRB].p) : nullptr;
+  SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
+  spx::launch_trimaran(a, e->stream);
+  SPX_HIP(e, hipGetLastError());
+  SPX_HIP(e, hipEventRecord(e->ev1, e->stream));
+  e->timed = true;
+  e->evaluated |= plugin_mask;
+  e->eval_begin = row_begin;
+  e->eval_end = row_end;
+  return SPX_OK;
+}
+
+int spx_sync(spx_engine* e) {
+  if (!e) return SPX_ERR_ARG;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  return SPX_OK;
+}
+
+int spx_last_eval_ms(spx_engine* e, float* ms) {
+  if (!e || !ms) return SPX_ERR_ARG;
+  if (!e->timed) return fail(e, SPX_ERR_STATE, "no spx_eval has run");
+  SPX_HIP(e, hipEventSynchronize(e->ev1));
+  SPX_HIP(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
+  return SPX_OK;
+}
+
+int spx_fetch_scores(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out) {
+  if (!e || !out) return SPX_ERR_ARG;
+  if (plugin < 0 || plugin >= SPX_NUM_PLUGINS || !(e->evaluated & (1u << plugin)))
+    return fail(e, SPX_ERR_STATE, "plugin has not been evaluated");
+  if (pod_row < 0 || pod_row >= e->n_pods) return fail(e, SPX_ERR_ARG, "pod_row out of range");
+  // plain synchronous D2H copy of one row: safe from concurrent reader threads after spx_sync()
+  const uint8_t* src = static_cast<const uint8_t*>(e->score[plugin].p) + pod_row * e->score_stride[plugin];
+  SPX_HIP(e, hipMemcpy(out, src, static_cast<size_t>(e->n_nodes), hipMemcpyDeviceToHost));
+  return SPX_OK;
+}
+
+int spx_fetch_status(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out) {
+  if (!e || !out) return SPX_ERR_ARG;
+  (void)plugin;
+  (void)pod_row;
+  return fail(e, SPX_ERR_STATE, "plugin has no Filter extension point in this build");
+}
+
+int spx_fetch_raw(spx_engine* e, int plugin, int which, int64_t pod_row, int64_t* out) {
+  if (!e || !out) return SPX_ERR_ARG;
+  (void)which;
+  SPX_HIP(e, hipSetDevice(e->device));
+  if (e->n_nodes <= 0) return fail(e, SPX_ERR_STATE, "no node table uploaded");
+  int rc;
+  const size_t bytes = static_cast<size_t>(e->n_nodes) * sizeof(int64_t);
+  if (plugin == SPX_PLUGIN_ALLOCATABLE) {
+    if ((rc = prepare_alloc(e))) return rc;
+    SPX_HIP(e, hipMemcpyAsync(out, e->d_alloc_raw.p, bytes, hipMemcpyDeviceToHost, e->stream));
+    SPX_HIP(e, hipStreamSynchronize(e->stream));
+    return SPX_OK;
+  }
+  if (plugin != SPX_PLUGIN_TLP && plugin != SPX_PLUGIN_LVRB) return fail(e, SPX_ERR_ARG, "raw rows: unsupported plugin");
+  if (!(e->tri_nodes && e->tri_pods)) return fail(e, SPX_ERR_STATE, "trimaran node/pod tables not uploaded");
+  if (pod_row < 0 || pod_row >= e->n_pods) return fail(e, SPX_ERR_ARG, "pod_row out of range");
+  if ((rc = ensure(e, e->d_raw_row, bytes))) return rc;
+  spx::TrimaranArgs a{};
+  fill_trimaran(e, a);
+  spx::launch_trimaran_raw(a, plugin, pod_row, static_cast<int64_t*>(e->d_raw_row.p), e->stream);
+  SPX_HIP(e, hipGetLastError());
+  SPX_HIP(e, hipMemcpyAsync(out, e->d_raw_row.p, bytes, hipMemcpyDeviceToHost, e->stream));
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  return SPX_OK;
+}
+
+int spx_score_table(spx_engine* e, int plugin, void** dptr, int64_t* row_stride, int64_t* n_rows) {
+  if (!e || plugin < 0 || plugin >= SPX_NUM_PLUGINS) return SPX_ERR_ARG;
+  if (e->n_nodes <= 0 || e->n_pods <= 0) return fail(e, SPX_ERR_STATE, "shape unknown: upload node and pod tables first");
+  int rc = ensure_score_table(e, plugin);
+  if (rc) return rc;
+  if (dptr) *dptr = e->score[plugin].p;
+  if (row_stride) *row_stride = e->score_stride[plugin];
+  if (n_rows) *n_rows = e->score_rows[plugin];
+  return SPX_OK;
+}
+
+int spx_bind_score_table(spx_engine* e, int plugin, void* dptr, int64_t row_stride, int64_t n_rows) {
+  if (!e || plugin < 0 || plugin >= SPX_NUM_PLUGINS) return SPX_ERR_ARG;
+  DevBuf& b = e->score[plugin];
+  if (!dptr) {  // unbind
+    if (b.external) b = DevBuf{};
+    e->score_rows[plugin] = e->score_stride[plugin] = 0;
+    return SPX_OK;
+  }
+  if (row_stride % spx::kRowAlign != 0 || (reinterpret_cast<uintptr_t>(dptr) % spx::kRowAlign) != 0)
+    return fail(e, SPX_ERR_ARG, "bound table must be 16-byte aligned with a 16-byte multiple row stride");
+  if (b.p && !b.external) SPX_HIP(e, hipFree(b.p));
+  b.p = dptr;
+  b.bytes = static_cast<size_t>(row_stride) * static_cast<size_t>(n_rows);
+  b.external = true;
+  e->score_rows[plugin] = n_rows;
+  e->score_stride[plugin] = row_stride;
+  return SPX_OK;
+}
+
+int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end) {
+  (void)plugin_mask;
+  (void)row_begin;
+  (void)row_end;
+  return fail(e, SPX_ERR_STATE, "spx_eval_best is not implemented in this build");
+}
+
+int spx_fetch_best(spx_engine* e, int64_t row_begin, int64_t row_end, int32_t* node_idx, int64_t* weighted_score) {
+  (void)row_begin;
+  (void)row_end;
+  (void)node_idx;
+  (void)weighted_score;
+  return fail(e, SPX_ERR_STATE, "spx_eval_best is not implemented in this build");
+}
+
+}  // extern "C"

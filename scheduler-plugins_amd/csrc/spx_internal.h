@@ -1,0 +1,67 @@
+// spx_internal.h — shared between the engine (host) and the kernel translation units.
+// Not part of the public ABI (that is include/spx.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/spx.h"
+
+namespace spx {
+
+// Score rows are written as 16-byte vectors, so every uint8 result row is padded to this.
+constexpr int64_t kRowAlign = 16;
+
+inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- Allocatable
+struct AllocPrepArgs {
+  int64_t n_nodes;
+  int64_t row_stride;
+  int32_t n_res;
+  int32_t mode;
+  const int64_t* alloc;    // [n_res][n_nodes]
+  const int64_t* weight;   // [n_res] (device)
+  int64_t* raw;            // [n_nodes] out: Allocatable.Score per node
+  uint8_t* norm;           // [row_stride] out: NormalizeScore over the full node list
+};
+void launch_alloc_prepare(const AllocPrepArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- fused Allocatable + TLP + LVRB sweep
+struct TrimaranArgs {
+  int64_t n_nodes;
+  int64_t row_stride;
+  int64_t row_begin;
+  int64_t row_end;
+  // Allocatable: pod-independent normalized row (no per-row feasibility mask)
+  const uint8_t* alloc_norm;
+  // TargetLoadPacking
+  const int64_t* cap_cpu_milli;
+  const double* tlp_cpu_util;
+  const int64_t* tlp_missing_milli;
+  const uint8_t* tlp_valid;
+  const int64_t* tlp_pod_milli;
+  double tlp_target;
+  // LoadVariationRiskBalancing
+  const int64_t* lv_alloc_cpu_milli;
+  const int64_t* lv_alloc_mem;
+  const double* lv_cpu_avg;
+  const double* lv_cpu_std;
+  const double* lv_mem_avg;
+  const double* lv_mem_std;
+  const uint8_t* lv_flags;
+  const int64_t* lv_req_cpu_milli;
+  const int64_t* lv_req_mem;
+  double lv_margin;
+  double lv_sensitivity;
+  // outputs: uint8 [n_pods][row_stride] each (NULL = plugin not evaluated)
+  uint8_t* out_alloc;
+  uint8_t* out_tlp;
+  uint8_t* out_lvrb;
+};
+// evaluates the plugins whose out_* pointer is non-NULL
+void launch_trimaran(const TrimaranArgs& a, hipStream_t s);
+// raw int64 Score() of one pod row for `plugin` (SPX_PLUGIN_TLP / SPX_PLUGIN_LVRB)
+void launch_trimaran_raw(const TrimaranArgs& a, int plugin, int64_t pod_row, int64_t* out, hipStream_t s);
+
+}  // namespace spx

@@ -1,0 +1,191 @@
+"""ctypes wrapper over the spx_* C ABI (include/spx.h).  One Engine == one spx_engine == one
+scheduler profile on one GPU.  Every method is a direct call into libspx.so; errors raise."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from ._abi import Table
+
+PLUGINS = {
+    "NodeResourcesAllocatable": 0,
+    "TargetLoadPacking": 1,
+    "LoadVariationRiskBalancing": 2,
+    "NodeResourceTopologyMatch": 3,
+    "NetworkOverhead": 4,
+    "CapacityScheduling": 5,
+    "TopologicalSort": 6,
+}
+ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY, TOPOSORT = range(7)
+
+
+def mask_of(*plugins: int) -> int:
+    m = 0
+    for p in plugins:
+        m |= 1 << p
+    return m
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        from . import SpxError, header, lib
+
+        self._lib = lib()
+        self._hdr = header()
+        self._err = SpxError
+        self._h = C.POINTER(self._hdr.opaque["spx_engine"])()
+        rc = self._lib.spx_create(device, C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.spx_last_error(None)
+            raise SpxError(rc, msg.decode() if msg else "")
+        self.n_nodes = 0
+        self.n_pods = 0
+        self.alloc_params: Optional[Table] = None
+        self.tlp_params = Table(self._hdr, "spx_tlp_params", target_utilization=40, default_requests_milli=1000,
+                                requests_multiplier=1.5)
+        self.lvrb_params = Table(self._hdr, "spx_lvrb_params", safe_variance_margin=1.0, safe_variance_sensitivity=1.0)
+        self.set_allocatable()
+
+    # ------------------------------------------------------------------ plumbing
+    def _ck(self, rc: int) -> None:
+        if rc != 0:
+            msg = self._lib.spx_last_error(self._h)
+            raise self._err(rc, msg.decode() if msg else "")
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.spx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ------------------------------------------------------------------ params
+    def set_allocatable(self, mode: str = "Least", resources: Optional[Dict[int, int]] = None) -> None:
+        """resources: {resource id: weight}; default = {memory: 1, cpu: 1<<20} (resource_allocation.go:36)."""
+        if resources is None:
+            resources = {1: 1, 0: 1 << 20}
+        self.alloc_params = Table(self._hdr, "spx_allocatable_params", mode={"Least": 0, "Most": 1}[mode],
+                                  n_res=len(resources), res=np.array(list(resources.keys()), dtype=np.int32),
+                                  weight=np.array(list(resources.values()), dtype=np.int64))
+        self._ck(self._lib.spx_set_allocatable_params(self._h, self.alloc_params.ref()))
+
+    def set_tlp(self, target_utilization: int = 40, default_requests_milli: int = 1000, requests_multiplier: float = 1.5):
+        self.tlp_params = Table(self._hdr, "spx_tlp_params", target_utilization=target_utilization,
+                                default_requests_milli=default_requests_milli, requests_multiplier=requests_multiplier)
+        self._ck(self._lib.spx_set_tlp_params(self._h, self.tlp_params.ref()))
+
+    def set_lvrb(self, margin: float = 1.0, sensitivity: float = 1.0):
+        self.lvrb_params = Table(self._hdr, "spx_lvrb_params", safe_variance_margin=margin,
+                                 safe_variance_sensitivity=sensitivity)
+        self._ck(self._lib.spx_set_lvrb_params(self._h, self.lvrb_params.ref()))
+
+    # ------------------------------------------------------------------ flatten (host C++) + upload
+    def flatten_alloc_nodes(self, nodes: Table, rc: Optional[Table]) -> np.ndarray:
+        n = nodes.struct.n_nodes
+        r = self.alloc_params.struct.n_res
+        out = np.zeros((r, n), dtype=np.int64)
+        self._ck(self._lib.spx_flatten_alloc_nodes(nodes.ref(), rc.ref() if rc else None, self.alloc_params.ref(),
+                                                    out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    def flatten_trimaran_nodes(self, nodes: Table, metrics: Table, assigned: Optional[Table]) -> Dict[str, np.ndarray]:
+        n = nodes.struct.n_nodes
+        cols = {
+            "cap_cpu_milli": np.zeros(n, np.int64), "tlp_cpu_util": np.zeros(n, np.float64),
+            "tlp_missing_milli": np.zeros(n, np.int64), "tlp_valid": np.zeros(n, np.uint8),
+            "lv_alloc_cpu_milli": np.zeros(n, np.int64), "lv_alloc_mem": np.zeros(n, np.int64),
+            "lv_cpu_avg": np.zeros(n, np.float64), "lv_cpu_std": np.zeros(n, np.float64),
+            "lv_mem_avg": np.zeros(n, np.float64), "lv_mem_std": np.zeros(n, np.float64),
+            "lv_flags": np.zeros(n, np.uint8),
+        }
+        fn = self._lib.spx_flatten_trimaran_nodes
+        ptrs = [v.ctypes.data_as(t) for v, t in zip(cols.values(), fn.argtypes[4:])]
+        self._ck(fn(nodes.ref(), metrics.ref(), assigned.ref() if assigned else None, self.tlp_params.ref(), *ptrs))
+        return cols
+
+    def flatten_trimaran_pods(self, pods: Table) -> Dict[str, np.ndarray]:
+        p = pods.struct.n_pods
+        cols = {"tlp_pod_milli": np.zeros(p, np.int64), "lv_req_cpu_milli": np.zeros(p, np.int64),
+                "lv_req_mem": np.zeros(p, np.int64)}
+        i64p = C.POINTER(C.c_int64)
+        self._ck(self._lib.spx_flatten_trimaran_pods(pods.ref(), self.tlp_params.ref(),
+                                                      *[v.ctypes.data_as(i64p) for v in cols.values()]))
+        return cols
+
+    def upload_alloc_nodes(self, alloc: np.ndarray) -> None:
+        alloc = np.ascontiguousarray(alloc, dtype=np.int64)
+        t = Table(self._hdr, "spx_alloc_nodes_soa", n_nodes=alloc.shape[1], n_res=alloc.shape[0], alloc=alloc)
+        self._ck(self._lib.spx_upload_alloc_nodes(self._h, t.ref()))
+        self.n_nodes = alloc.shape[1]
+
+    def upload_trimaran_nodes(self, cols: Dict[str, np.ndarray]) -> None:
+        n = len(cols["cap_cpu_milli"])
+        t = Table(self._hdr, "spx_trimaran_nodes_soa", n_nodes=n, **cols)
+        self._ck(self._lib.spx_upload_trimaran_nodes(self._h, t.ref()))
+        self.n_nodes = n
+
+    def upload_trimaran_pods(self, cols: Dict[str, np.ndarray]) -> None:
+        p = len(cols["tlp_pod_milli"])
+        t = Table(self._hdr, "spx_trimaran_pods_soa", n_pods=p, **cols)
+        self._ck(self._lib.spx_upload_trimaran_pods(self._h, t.ref()))
+        self.n_pods = p
+
+    def load_trimaran_objects(self, nodes: Table, rc: Optional[Table], pods: Table, metrics: Table,
+                              assigned: Optional[Table] = None) -> None:
+        """objects -> (host flatten) -> SoA -> HBM, for Allocatable + TLP + LVRB."""
+        self.upload_alloc_nodes(self.flatten_alloc_nodes(nodes, rc))
+        self.upload_trimaran_nodes(self.flatten_trimaran_nodes(nodes, metrics, assigned))
+        self.upload_trimaran_pods(self.flatten_trimaran_pods(pods))
+
+    # ------------------------------------------------------------------ eval / fetch
+    def eval(self, plugin_mask: int, row_begin: int = 0, row_end: Optional[int] = None) -> None:
+        self._ck(self._lib.spx_eval(self._h, plugin_mask, row_begin, self.n_pods if row_end is None else row_end))
+
+    def sync(self) -> None:
+        self._ck(self._lib.spx_sync(self._h))
+
+    def last_eval_ms(self) -> float:
+        ms = C.c_float()
+        self._ck(self._lib.spx_last_eval_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def scores(self, plugin: int, pod_row: int) -> np.ndarray:
+        out = np.empty(self.n_nodes, dtype=np.uint8)
+        self._ck(self._lib.spx_fetch_scores(self._h, plugin, pod_row, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def raw(self, plugin: int, pod_row: int, which: int = 0) -> np.ndarray:
+        out = np.empty(self.n_nodes, dtype=np.int64)
+        self._ck(self._lib.spx_fetch_raw(self._h, plugin, which, pod_row, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    def score_table(self, plugin: int):
+        """(device pointer, row stride in bytes, rows) of a plugin's uint8 table in HBM."""
+        p = C.c_void_p()
+        stride = C.c_int64()
+        rows = C.c_int64()
+        self._ck(self._lib.spx_score_table(self._h, plugin, C.byref(p), C.byref(stride), C.byref(rows)))
+        return p.value, stride.value, rows.value
+
+    def bind_score_table(self, plugin: int, dptr: int, row_stride: int, n_rows: int) -> None:
+        self._ck(self._lib.spx_bind_score_table(self._h, plugin, C.c_void_p(dptr), row_stride, n_rows))
+
+    def set_stream(self, stream: int) -> None:
+        self._ck(self._lib.spx_set_stream(self._h, C.c_void_p(stream)))
+
+    def all_scores(self, plugin: int, row_begin: int = 0, row_end: Optional[int] = None) -> np.ndarray:
+        """[rows][n_nodes] uint8 — convenience for tests (row by row through the ABI)."""
+        row_end = self.n_pods if row_end is None else row_end
+        return np.stack([self.scores(plugin, r) for r in range(row_begin, row_end)])

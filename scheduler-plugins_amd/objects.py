@@ -1,0 +1,234 @@
+"""Builders for the "object tables" of include/spx.h from plain Python descriptions.
+
+This is the Python stand-in for what the Go shim does when it marshals *v1.Pod / NodeInfo /
+watcher.WatcherMetrics into flat C arrays.  Tests use it to write cases the
+way the reference's table-driven tests write them (st.MakePod()..., makeNodeInfo(...)).
+"""
+from __future__ import annotations
+
+from fractions import Fraction
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from ._abi import Header, Table
+
+RES_CPU, RES_MEMORY, RES_EPHEMERAL, RES_PODS, RES_STORAGE = 0, 1, 2, 3, 4
+RES_FIRST_DYNAMIC = 8
+RC_HUGEPAGE, RC_NATIVE, RC_SCALAR = 1, 2, 4
+
+_SUFFIX = {
+    "n": Fraction(1, 10**9), "u": Fraction(1, 10**6), "m": Fraction(1, 1000), "": Fraction(1),
+    "k": Fraction(10**3), "M": Fraction(10**6), "G": Fraction(10**9), "T": Fraction(10**12),
+    "P": Fraction(10**15), "E": Fraction(10**18),
+    "Ki": Fraction(2**10), "Mi": Fraction(2**20), "Gi": Fraction(2**30), "Ti": Fraction(2**40),
+    "Pi": Fraction(2**50), "Ei": Fraction(2**60),
+}
+
+
+def parse_quantity(q) -> Fraction:
+    """resource.MustParse: exact decimal value of a Kubernetes quantity string (or number)."""
+    if isinstance(q, (int, np.integer)):
+        return Fraction(int(q))
+    if isinstance(q, Fraction):
+        return q
+    s = str(q).strip()
+    for suf in sorted(_SUFFIX, key=len, reverse=True):
+        if suf and s.endswith(suf):
+            return Fraction(s[: -len(suf)]) * _SUFFIX[suf]
+    if "e" in s or "E" in s:
+        mant, exp = s.lower().split("e")
+        return Fraction(mant) * Fraction(10) ** int(exp)
+    return Fraction(s)
+
+
+def _ceil(fr: Fraction) -> int:
+    return -((-fr.numerator) // fr.denominator)
+
+
+def is_native_resource(name: str) -> bool:  # v1helper.IsNativeResource
+    return "/" not in name or "kubernetes.io/" in name
+
+
+def is_hugepage(name: str) -> bool:  # v1helper.IsHugePageResourceName
+    return name.startswith("hugepages-")
+
+
+def is_scalar_resource_name(name: str) -> bool:  # schedutil.IsScalarResourceName
+    extended = (not is_native_resource(name)) and not name.startswith("requests.")
+    prefixed_native = "kubernetes.io/" in name
+    attachable = name.startswith("attachable-volumes-")
+    return extended or is_hugepage(name) or prefixed_native or attachable
+
+
+class Resources:
+    """Interns resource names to the canonical int ids of spx.h and keeps their class flags."""
+
+    FIXED = {"cpu": RES_CPU, "memory": RES_MEMORY, "ephemeral-storage": RES_EPHEMERAL, "pods": RES_PODS,
+             "storage": RES_STORAGE}
+
+    def __init__(self):
+        self.ids: Dict[str, int] = dict(self.FIXED)
+        self.names: Dict[int, str] = {v: k for k, v in self.FIXED.items()}
+        self._next = RES_FIRST_DYNAMIC
+
+    def id(self, name: str) -> int:
+        if name not in self.ids:
+            self.ids[name] = self._next
+            self.names[self._next] = name
+            self._next += 1
+        return self.ids[name]
+
+    def canonical(self, name: str, q) -> int:
+        """cpu -> MilliValue() (ceil of milli), everything else -> Value() (ceil)."""
+        fr = parse_quantity(q)
+        return _ceil(fr * 1000) if name == "cpu" else _ceil(fr)
+
+    def flags(self) -> np.ndarray:
+        out = np.zeros(max(self._next, RES_FIRST_DYNAMIC), dtype=np.uint8)
+        for name, i in self.ids.items():
+            f = 0
+            if is_hugepage(name):
+                f |= RC_HUGEPAGE
+            if is_native_resource(name):
+                f |= RC_NATIVE
+            if is_scalar_resource_name(name):
+                f |= RC_SCALAR
+            out[i] = f
+        return out
+
+    def table(self, hdr: Header) -> Table:
+        fl = self.flags()
+        return Table(hdr, "spx_resource_classes", n_res=len(fl), flags=fl)
+
+
+def _csr(lists: Sequence[Sequence]) -> np.ndarray:
+    ptr = np.zeros(len(lists) + 1, dtype=np.int32)
+    for i, l in enumerate(lists):
+        ptr[i + 1] = ptr[i] + len(l)
+    return ptr
+
+
+def _rl(res: Resources, rl: Optional[dict]):
+    """v1.ResourceList -> [(id, canonical qty)] keeping key presence (zero quantities stay)."""
+    if not rl:
+        return []
+    return [(res.id(k), res.canonical(k, v)) for k, v in rl.items()]
+
+
+def container(requests: Optional[dict] = None, limits: Optional[dict] = None, sidecar: bool = False) -> dict:
+    return {"requests": requests or {}, "limits": limits or {}, "sidecar": sidecar}
+
+
+def pod(containers: Iterable[dict] = (), init_containers: Iterable[dict] = (), overhead: Optional[dict] = None,
+        priority: int = 0, queue_ts: int = 0, appgroup: int = -1, selector: int = -1, ns: int = 0) -> dict:
+    return {"containers": list(containers), "init_containers": list(init_containers), "overhead": overhead,
+            "priority": priority, "queue_ts": queue_ts, "appgroup": appgroup, "selector": selector, "ns": ns}
+
+
+def build_pod_objects(hdr: Header, res: Resources, pods: Sequence[dict]) -> Table:
+    kinds, reqs, lims, ovhs, per_pod = [], [], [], [], []
+    for p in pods:
+        ctrs = [(c, 2 if c.get("sidecar") else 1) for c in p.get("init_containers", [])]
+        ctrs += [(c, 0) for c in p.get("containers", [])]
+        per_pod.append(ctrs)
+        for c, k in ctrs:
+            kinds.append(k)
+            reqs.append(_rl(res, c.get("requests")))
+            lims.append(_rl(res, c.get("limits")))
+        ovhs.append(_rl(res, p.get("overhead")))
+    flat = lambda ls, j: [x[j] for l in ls for x in l]
+    return Table(
+        hdr, "spx_pod_objects",
+        n_pods=len(pods),
+        ctr_ptr=_csr(per_pod), ctr_kind=np.array(kinds, dtype=np.uint8),
+        req_ptr=_csr(reqs), req_res=flat(reqs, 0), req_qty=flat(reqs, 1),
+        lim_ptr=_csr(lims), lim_res=flat(lims, 0), lim_qty=flat(lims, 1),
+        ovh_ptr=_csr(ovhs), ovh_res=flat(ovhs, 0), ovh_qty=flat(ovhs, 1),
+        priority=[p.get("priority", 0) for p in pods],
+        queue_ts=[p.get("queue_ts", 0) for p in pods],
+        appgroup=[p.get("appgroup", -1) for p in pods],
+        selector=[p.get("selector", -1) for p in pods],
+        ns=[p.get("ns", 0) for p in pods],
+    )
+
+
+def node(allocatable: Optional[dict] = None, capacity: Optional[dict] = None, region: int = -1, zone: int = -1) -> dict:
+    """allocatable/capacity are v1.ResourceList-like dicts; capacity defaults to allocatable
+    (st.MakeNode().Capacity(...) sets both in the reference's tests)."""
+    allocatable = allocatable or {}
+    return {"allocatable": allocatable, "capacity": capacity if capacity is not None else allocatable,
+            "region": region, "zone": zone}
+
+
+def build_node_objects(hdr: Header, res: Resources, nodes: Sequence[dict]) -> Table:
+    def get(n, key, name):
+        rl = n[key]
+        return res.canonical(name, rl[name]) if name in rl else 0
+
+    scalars = []
+    for n in nodes:
+        sc = []
+        for k, v in n["allocatable"].items():
+            if k in ("cpu", "memory", "ephemeral-storage", "pods"):
+                continue
+            if is_scalar_resource_name(k):  # framework.Resource.Add keeps only scalar names
+                sc.append((res.id(k), res.canonical(k, v)))
+        scalars.append(sc)
+    return Table(
+        hdr, "spx_node_objects",
+        n_nodes=len(nodes),
+        alloc_cpu_milli=[get(n, "allocatable", "cpu") for n in nodes],
+        alloc_mem=[get(n, "allocatable", "memory") for n in nodes],
+        alloc_eph=[get(n, "allocatable", "ephemeral-storage") for n in nodes],
+        alloc_pods=[get(n, "allocatable", "pods") for n in nodes],
+        scalar_ptr=_csr(scalars),
+        scalar_res=[x[0] for l in scalars for x in l],
+        scalar_qty=[x[1] for l in scalars for x in l],
+        cap_cpu_milli=[get(n, "capacity", "cpu") for n in nodes],
+        region=[n.get("region", -1) for n in nodes],
+        zone=[n.get("zone", -1) for n in nodes],
+    )
+
+
+MT = {"CPU": 0, "Memory": 1}
+MO = {"AVG": 0, "STD": 1, "Latest": 2, "": 3}
+
+
+def build_metrics_objects(hdr: Header, n_nodes: int, node_metrics: Optional[Dict[int, Optional[list]]],
+                          window_end: int = 0) -> Table:
+    """node_metrics: None = NodeMetricsMap nil ("404 resp from watcher"); else {node index: [(type, op, value)...]};
+    a node missing from the dict has no entry in the map; a value of None is a nil Metrics slice."""
+    present = np.zeros(n_nodes, dtype=np.uint8)
+    isnil = np.zeros(n_nodes, dtype=np.uint8)
+    lists = [[] for _ in range(n_nodes)]
+    if node_metrics is not None:
+        for i, ms in node_metrics.items():
+            present[i] = 1
+            if ms is None:
+                isnil[i] = 1
+            else:
+                lists[i] = [(MT.get(t, 2), MO.get(o, 4), float(v)) for t, o, v in ms]
+    return Table(
+        hdr, "spx_metrics_objects",
+        map_is_nil=1 if node_metrics is None else 0,
+        window_end=window_end,
+        node_present=present, node_metrics_nil=isnil,
+        m_ptr=_csr(lists),
+        m_type=np.array([x[0] for l in lists for x in l], dtype=np.uint8),
+        m_op=np.array([x[1] for l in lists for x in l], dtype=np.uint8),
+        m_value=np.array([x[2] for l in lists for x in l], dtype=np.float64),
+    )
+
+
+def build_assigned_objects(hdr: Header, res: Resources, n_nodes: int, entries: Dict[int, list]) -> Table:
+    """entries: {node index: [(timestamp_unix, pod dict), ...]} — ScheduledPodsCache image."""
+    pods, ts, per_node = [], [], [[] for _ in range(n_nodes)]
+    for ni in range(n_nodes):  # CSR order: entry index == index into `pods`
+        for t, p in entries.get(ni, []):
+            per_node[ni].append(len(pods))
+            pods.append(p)
+            ts.append(t)
+    ptable = build_pod_objects(hdr, res, pods)
+    return Table(hdr, "spx_assigned_objects", e_ptr=_csr(per_node), e_ts_unix=np.array(ts, dtype=np.int64),
+                 e_pod=np.array([i for l in per_node for i in l], dtype=np.int32), pods=ptable)
