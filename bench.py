@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the batched Filter/Score engine.
+
+Metric (BASELINE.json): pod x node Filter+Score evals/sec.  A "step" is one pass of the hot path
+(one spx_eval of the whole plugin set) over one batch of synthetic pods against the node snapshot,
+with every input table already resident in HBM.  N=1 workload = BASELINE.json configs[1]:
+noderesources.Allocatable + trimaran.TargetLoadPacking, 10k nodes x 100k pods.
+
+N>1 (launched by torch.distributed.run, one rank per GPU): pod rows are the sharded unit — every rank
+evaluates its own 100k-pod batch against the replicated node tables (weak scaling), no data-path
+collective; `value` = all ranks' evals / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+WORKLOADS = {
+    # name: (n_nodes, n_pods per GPU, plugins, algorithmic bytes: node_row, pod_row, out per eval) — SURVEY.md §8d
+    "config2": dict(n_nodes=10_000, n_pods=100_000, plugins=("alloc", "tlp"), node_row=41, pod_row=8, out=2,
+                    desc="noderesources.Allocatable + trimaran.TargetLoadPacking, 10k nodes x 100k pods"),
+    "config2_lvrb": dict(n_nodes=10_000, n_pods=100_000, plugins=("alloc", "tlp", "lvrb"), node_row=90, pod_row=24, out=3,
+                         desc="Allocatable + TargetLoadPacking + LoadVariationRiskBalancing, 10k x 100k"),
+    "small": dict(n_nodes=1_000, n_pods=4_000, plugins=("alloc", "tlp"), node_row=41, pod_row=8, out=2,
+                  desc="plumbing-sized Allocatable + TLP"),
+}
+
+
+def cpu_baseline(spx, snap, e, plugins, budget_s: float):
+    """Times the CPU oracle (C restatement of the reference's per-(pod,node) path — NOT the Go binary)
+    on a bounded sample of the same workload's pod rows, all host cores, rows split across threads."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import pyoracle
+
+    osnap = pyoracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], metrics=snap["metrics"], assigned=snap["assigned"],
+                              alloc_params=e.alloc_params, tlp_params=e.tlp_params, lvrb_params=e.lvrb_params)
+    cores = os.cpu_count() or 1
+    n_nodes = osnap.n_nodes
+
+    def run(rows: int) -> float:
+        t0 = time.perf_counter()
+        for p in plugins:
+            osnap.score_rows(p, 0, rows, threads=cores, want_raw=False, want_norm=True)
+        return time.perf_counter() - t0
+
+    probe_rows = min(osnap.n_pods, 8 * cores)
+    t = run(probe_rows)
+    rate = probe_rows / max(t, 1e-9)
+    rows = int(max(probe_rows, min(osnap.n_pods, rate * budget_s)))
+    t = run(rows)
+    return {
+        "value": rows * n_nodes / t, "unit": "evals/s", "cores": cores, "kind": "port",
+        "sample": f"{rows} pod rows x {n_nodes} nodes of the same snapshot, {len(plugins)} plugins, {t:.2f} s wall; "
+                  "C restatement of the reference CPU path (oracle/), not the Go binary",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL over xGMI
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import scheduler_plugins_amd as spx
+    from scheduler_plugins_amd import synth
+    from scheduler_plugins_amd.engine import ALLOCATABLE, LVRB, TLP, Engine, mask_of
+
+    w = WORKLOADS[args.workload]
+    pid = {"alloc": ALLOCATABLE, "tlp": TLP, "lvrb": LVRB}
+    plugins = [pid[p] for p in w["plugins"]]
+    mask = mask_of(*plugins)
+    n_nodes, n_pods = w["n_nodes"], w["n_pods"]
+
+    hdr = spx.header()
+    # every rank: same node snapshot, its own pod batch (seeded by rank)
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED)
+    if rank:
+        snap["pods"] = synth.synth_pods(hdr, n_pods, seed=synth.SEED + 1000 * rank)
+    e = Engine(local_rank)
+    e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        e.eval(mask)
+    e.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        e.eval(mask)
+    e.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-launch kernel duration with HIP events on the engine's own stream (spx_last_eval_ms), measured in a
+    # separate loop so that event reads do not sit inside the timed region above
+    durs = []
+    for _ in range(max(5, min(args.steps, 20))):
+        e.eval(mask)
+        durs.append(e.last_eval_ms())
+    kern_ms = float(np.mean(durs))
+
+    evals_per_step = n_nodes * n_pods * world
+    value = evals_per_step * args.steps / elapsed
+    algo_bytes = n_nodes * w["node_row"] + n_pods * w["pod_row"] + n_nodes * n_pods * w["out"]
+    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "pod_x_node_filter_score_evals_per_sec",
+        "value": value,
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",  # TLP/LVRB compute in float64 exactly as the reference; Allocatable in int64
+        "data": "synthetic",
+        "config": {"workload": w["desc"], "n_nodes": n_nodes, "n_pods_per_gpu": n_pods, "plugins": list(w["plugins"]),
+                   "sharding": "pod rows per rank, node tables replicated, no data-path collective",
+                   "result_tables": "uint8 [pods][nodes] per plugin, resident in HBM"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "spx::k_trimaran", "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes},
+        "kernel_evals_per_sec": n_nodes * n_pods / (kern_ms * 1e-3),
+    }
+    if rank == 0 and world == 1 and args.cpu_budget > 0:
+        out["cpu_baseline"] = cpu_baseline(spx, snap, e, plugins, args.cpu_budget)
+    e.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,4 +1,4 @@
-"""ctypes view of a C header kept in "one field per line" form (include/spx.h, oracle/spx_oracle.h).
+"""ctypes view of a C header kept in "one field per line" form (include/spx.h).
 
 The headers are the single source of truth for the C ABI; this module parses their struct
 typedefs and function prototypes and builds ctypes Structure classes / argtypes from them, so
@@ -56,7 +56,7 @@ class Header:
 
     def derive(self, *paths: str) -> "Header":
         """A new Header that shares this one's struct classes and parses further headers on top
-        (used by the test-side oracle binding so both libraries see the same ctypes classes)."""
+        (so that two libraries sharing table structs see the same ctypes classes)."""
         h = Header()
         h.structs = dict(self.structs)
         h.opaque = dict(self.opaque)

@@ -69,16 +69,5 @@ def build(verbose: bool = False, force: bool = False) -> Path:
     return LIB
 
 
-def build_oracle(verbose: bool = False) -> Path:
-    """Compiles the CPU oracle (test infrastructure) — building the checker is not using it."""
-    r = subprocess.run(["make", "-C", str(ROOT / "oracle")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"oracle build failed:\n{r.stdout}")
-    if verbose:
-        print(r.stdout)
-    return ROOT / "oracle" / "_build" / "liboracle.so"
-
-
 if __name__ == "__main__":
     print(build(verbose=True, force="--force" in sys.argv))
-    print(build_oracle(verbose=True))

@@ -1,0 +1,48 @@
+"""The C-ABI library loads and exports every symbol include/spx.h declares (CPU: no compute calls)."""
+import ctypes as C
+import re
+
+import pytest
+
+import scheduler_plugins_amd as spx
+
+
+def test_library_exports_every_declared_symbol():
+    lib = spx.lib()
+    src = open(spx.HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = set(re.findall(r"\b(spx_\w+)\s*\(", src))
+    assert len(declared) >= 25
+    parsed = set(spx.header().protos)
+    assert declared == parsed, f"header parser missed {declared ^ parsed}"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libspx.so does not export {name}"
+    assert lib.spx_abi_version() == 1
+
+
+def test_no_torch_types_in_signatures():
+    # plain pointers and sizes only
+    for name, (ret, args) in spx.header().protos.items():
+        for a in [ret] + list(args):
+            assert a is None or a.__module__ in ("ctypes", "scheduler_plugins_amd._abi", "_ctypes"), (name, a)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: no product source may reference oracle/."""
+    import pathlib
+    pkg = pathlib.Path(spx.PKG_DIR)
+    bad = []
+    for f in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.cc")) + list(pkg.rglob("*.h")):
+        txt = f.read_text()
+        if re.search(r"pyoracle|liboracle|spx_oracle\.h|orc_\w+\(", txt):
+            bad.append(str(f))
+    assert not bad, bad
+
+
+def test_create_without_gpu_fails_loudly():
+    try:
+        e = spx.Engine(0)
+    except spx.SpxError as err:
+        assert err.code == -4 and "no CPU fallback" in err.msg
+    else:  # on a GPU box this is simply a working engine
+        e.close()
