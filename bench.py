@@ -68,12 +68,24 @@ def cpu_baseline(spx, snap, e, plugins, budget_s: float):
     }
 
 
+def measured_traffic(workload: str):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN/<workload>_traffic.json;
+    collected by tools/prof1.sh in separate --pmc runs, FETCH_SIZE corrected x2 for gfx950)."""
+    cands = sorted(ROOT.glob(f"profiles/r*/{workload}_traffic.json"))
+    if not cands:
+        return None, None
+    d = json.loads(cands[-1].read_text())
+    return d.get("traffic_bytes_per_launch"), str(cands[-1].relative_to(ROOT))
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--plugins", default="", help="override the workload's plugin set, e.g. alloc or tlp,lvrb (experiments)")
+    ap.add_argument("--round-frac", type=float, default=0.0, help="fraction of nodes with integer-valued metrics (tie stress)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -97,7 +109,10 @@ def main() -> None:
     from scheduler_plugins_amd import synth
     from scheduler_plugins_amd.engine import ALLOCATABLE, LVRB, TLP, Engine, mask_of
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if args.plugins:
+        w["plugins"] = tuple(args.plugins.split(","))
+        w["out"] = len(w["plugins"])
     pid = {"alloc": ALLOCATABLE, "tlp": TLP, "lvrb": LVRB}
     plugins = [pid[p] for p in w["plugins"]]
     mask = mask_of(*plugins)
@@ -105,7 +120,7 @@ def main() -> None:
 
     hdr = spx.header()
     # every rank: same node snapshot, its own pod batch (seeded by rank)
-    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED)
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED, round_frac=args.round_frac)
     if rank:
         snap["pods"] = synth.synth_pods(hdr, n_pods, seed=synth.SEED + 1000 * rank)
     e = Engine(local_rank)
@@ -144,6 +159,7 @@ def main() -> None:
     algo_bytes = n_nodes * w["node_row"] + n_pods * w["pod_row"] + n_nodes * n_pods * w["out"]
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
 
+    traffic, traffic_src = measured_traffic(args.workload) if not args.plugins else (None, None)
     out = {
         "metric": "pod_x_node_filter_score_evals_per_sec",
         "value": value,
@@ -161,8 +177,9 @@ def main() -> None:
                    "sharding": "pod rows per rank, node tables replicated, no data-path collective",
                    "result_tables": "uint8 [pods][nodes] per plugin, resident in HBM"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "spx::k_trimaran", "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "spx::k_tlp_fast2 (Allocatable+TLP) / spx::k_trimaran (with LVRB)", "kernel_ms": kern_ms,
+                     "algorithmic_bytes": algo_bytes, "frac_of_measured_copy_ceiling_6.29TBs": achieved / 6290.0},
         "kernel_evals_per_sec": n_nodes * n_pods / (kern_ms * 1e-3),
     }
     if rank == 0 and world == 1 and args.cpu_budget > 0:

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -102,7 +103,10 @@ int set_nodes(spx_engine* e, int64_t n) {
   if (e->n_nodes != -1 && e->n_nodes != n)
     return fail(e, SPX_ERR_STATE, "n_nodes differs from tables already uploaded (one snapshot per engine; destroy and re-create to change shape)");
   e->n_nodes = n;
-  e->row_stride = spx::round_up(n, spx::kRowAlign);
+  int64_t pad = spx::kRowPad;
+  if (const char* env = getenv("SPX_ROW_ALIGN")) pad = atoll(env);
+  if (pad < spx::kRowAlign || pad % spx::kRowAlign) pad = spx::kRowAlign;
+  e->row_stride = spx::round_up(n, pad);
   return SPX_OK;
 }
 

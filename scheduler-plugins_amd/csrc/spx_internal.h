@@ -11,6 +11,8 @@ namespace spx {
 
 // Score rows are written as 16-byte vectors, so every uint8 result row is padded to this.
 constexpr int64_t kRowAlign = 16;
+// Default row padding of engine-owned tables (rows start on a cache-line boundary).
+constexpr int64_t kRowPad = 128;
 
 inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 

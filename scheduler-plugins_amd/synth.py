@@ -110,7 +110,8 @@ def synth_nodes(hdr: Header, n_nodes: int, seed: int = SEED, device_res: int = -
     )
 
 
-def synth_metrics(hdr: Header, n_nodes: int, seed: int = SEED, window_end: int = 1_700_000_000) -> Table:
+def synth_metrics(hdr: Header, n_nodes: int, seed: int = SEED, window_end: int = 1_700_000_000,
+                  round_frac: float = 0.0) -> Table:
     """Per node up to 6 metric slots in a fixed order that exercises SURVEY appendix B.5:
     [CPU AVG, CPU STD, CPU Latest, Memory AVG, Memory STD, Memory ""].  TLP takes the LAST of
     CPU AVG/Latest, LVRB prefers AVG regardless of order."""
@@ -124,8 +125,9 @@ def synth_metrics(hdr: Header, n_nodes: int, seed: int = SEED, window_end: int =
     mop = np.tile(np.array([0, 1, 2, 0, 1, 3], dtype=np.uint8), (n_nodes, 1))
     val = np.stack([rng.uniform(0, 100, n_nodes), rng.uniform(0, 30, n_nodes), rng.uniform(0, 100, n_nodes),
                     rng.uniform(0, 100, n_nodes), rng.uniform(0, 30, n_nodes), rng.uniform(0, 100, n_nodes)], axis=1)
-    # a slice of round values to land exactly on rounding / threshold boundaries
-    rnd = rng.random(n_nodes) < 0.1
+    # optional slice of round values that land exactly on rounding ties / threshold boundaries (tests);
+    # SURVEY.md §8d's distribution itself is continuous: cpu_util% ~ U[0,100)
+    rnd = rng.random(n_nodes) < round_frac
     val = np.where(rnd.reshape(-1, 1), np.round(val), val)
     ptr, sel = _csr_from_mask(mask)
     return Table(hdr, "spx_metrics_objects", map_is_nil=0, window_end=window_end,
@@ -154,12 +156,12 @@ def resource_classes(hdr: Header, flags: Optional[np.ndarray] = None) -> Table:
     return Table(hdr, "spx_resource_classes", n_res=len(flags), flags=flags)
 
 
-def trimaran_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED) -> Dict[str, Table]:
+def trimaran_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, round_frac: float = 0.0) -> Dict[str, Table]:
     """Object tables for BASELINE.json config #2 (Allocatable + TargetLoadPacking [+ LVRB])."""
     return {
         "nodes": synth_nodes(hdr, n_nodes, seed),
         "pods": synth_pods(hdr, n_pods, seed),
-        "metrics": synth_metrics(hdr, n_nodes, seed),
+        "metrics": synth_metrics(hdr, n_nodes, seed, round_frac=round_frac),
         "assigned": synth_assigned(hdr, n_nodes, seed),
         "rc": resource_classes(hdr),
     }

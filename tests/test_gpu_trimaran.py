@@ -91,7 +91,7 @@ def test_lvrb_compute_score_golden(gpu_required, hdr, case):
 @pytest.mark.parametrize("plugins", [(ALLOCATABLE, TLP), (TLP,), (LVRB,), (ALLOCATABLE,), (ALLOCATABLE, TLP, LVRB), (TLP, LVRB)],
                          ids=lambda p: "+".join(map(str, p)))
 def test_differential(gpu_required, hdr, oracle, n_nodes, n_pods, seed, plugins):
-    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=seed)
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=seed, round_frac=0.1 * (seed % 3))
     tlp = tlp_params(hdr, 40, 1000, 1.5)
     lv = lvrb_params(hdr, 1, 1)
     with _engine(gpu_required) as e:
@@ -129,7 +129,7 @@ def test_lvrb_params_differential(gpu_required, hdr, oracle, margin, sens):
 
 @pytest.mark.parametrize("target,mult,default", [(40, 1.5, 1000), (70, 1.0, 500), (1, 2.25, 0), (99, 1.5, 1000)])
 def test_tlp_params_differential(gpu_required, hdr, oracle, target, mult, default):
-    snap = synth.trimaran_snapshot(hdr, 777, 150, seed=13)
+    snap = synth.trimaran_snapshot(hdr, 777, 150, seed=13, round_frac=0.3)
     with _engine(gpu_required) as e:
         e.set_tlp(target, default, mult)
         e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
@@ -181,7 +181,7 @@ def test_partial_row_ranges_and_reeval(gpu_required, hdr, oracle):
 # ------------------------------------------------------------------ full size (config #2): properties + sampled rows
 def test_config2_full_size_properties(gpu_required, hdr, oracle):
     n_nodes, n_pods = 10_000, 100_000
-    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods)
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, round_frac=0.05)
     with _engine(gpu_required) as e:
         e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
         e.eval(mask_of(ALLOCATABLE, TLP))
