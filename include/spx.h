@@ -167,6 +167,36 @@ typedef struct spx_assigned_objects {
   const spx_pod_objects* pods;
 } spx_assigned_objects;
 
+/* NodeResourceTopology CR image per node plus the NRT cache's verdict for it
+ * (pkg/noderesourcetopology/cache: GetCachedNRTCopy -> (nrt, CachedNRTInfo{Fresh})).
+ * legacy_policy encodes TopologyPolicies[0] (nodeconfig/topologymanager.go:131-162) as
+ * (policy << 1) | scope, -1 when absent/unknown; attr_* are the Attributes overrides (:98-115),
+ * -1 when absent or invalid.  policy: 0 none, 1 best-effort, 2 restricted, 3 single-numa-node;
+ * scope: 0 container, 1 pod.  zone_numa_id / zcost_numa_id = numanode.NameToID(name), -1 on error.
+ * assumed_* is the OverReserve store (cache/store.go:315-356): one resource list per assumed pod. */
+typedef struct spx_nrt_objects {
+  int64_t n_nodes;
+  const uint8_t* has_nrt;
+  const uint8_t* fresh;
+  const int8_t* legacy_policy;
+  const int8_t* attr_scope;
+  const int8_t* attr_policy;
+  const int32_t* attr_max_numa;
+  const int32_t* zone_ptr;
+  const uint8_t* zone_is_node;
+  const int32_t* zone_numa_id;
+  const int32_t* zres_ptr;
+  const int32_t* zres_res;
+  const int64_t* zres_avail;
+  const int32_t* zcost_ptr;
+  const int32_t* zcost_numa_id;
+  const int64_t* zcost_value;
+  const int32_t* assumed_ptr;
+  const int32_t* arl_ptr;
+  const int32_t* arl_res;
+  const int64_t* arl_qty;
+} spx_nrt_objects;
+
 /* ------------------------------------------------------------------ plugin params */
 
 typedef struct spx_allocatable_params {
@@ -186,6 +216,19 @@ typedef struct spx_lvrb_params {
   double safe_variance_margin;
   double safe_variance_sensitivity;
 } spx_lvrb_params;
+
+/* NodeResourceTopologyMatch scoring strategy (apis/config/types.go ScoringStrategyType) */
+#define SPX_NRT_MOST_ALLOCATED 0
+#define SPX_NRT_BALANCED_ALLOCATION 1
+#define SPX_NRT_LEAST_ALLOCATED 2
+#define SPX_NRT_LEAST_NUMA_NODES 3
+
+typedef struct spx_nrt_params {
+  int32_t strategy;
+  int32_t n_weights;
+  const int32_t* weight_res;
+  const int64_t* weight;
+} spx_nrt_params;
 
 /* ------------------------------------------------------------------ SoA tables (what the kernels read) */
 
@@ -223,6 +266,63 @@ typedef struct spx_trimaran_pods_soa {
   const int64_t* lv_req_mem;
 } spx_trimaran_pods_soa;
 
+/* NodeResourceTopologyMatch.  Resources are renumbered into dense "slots" 0..n_res-1 (the union of
+ * what pods request and zones report; slot_res gives the canonical id).  Limits of this build:
+ * n_res <= 8, NUMA zones per node <= 8, containers per pod <= 8 (flatten fails beyond them). */
+#define SPX_NRT_MAX_RES 8
+#define SPX_NRT_MAX_ZONES 8
+#define SPX_NRT_MAX_CTRS 8
+#define SPX_NRT_F_HAS_NRT 1
+#define SPX_NRT_F_FRESH 2
+#define SPX_NRT_F_SINGLE_NUMA 4
+#define SPX_NRT_F_POD_SCOPE 8
+#define SPX_NRT_SLOT_AFFINE 1     /* isNUMAAffineResource  numaresources.go:120-135 */
+#define SPX_NRT_SLOT_HOST_LEVEL 2 /* isHostLevelResource   numaresources.go:105-118 */
+#define SPX_NRT_SLOT_CPU 4        /* quantity is millicores: Value() = ceil(milli/1000) */
+#define SPX_QOS_GUARANTEED 0
+#define SPX_QOS_BURSTABLE 1
+#define SPX_QOS_BESTEFFORT 2
+
+/* filter status reason codes of the NRT status table (0 = pass) and their reference messages */
+#define SPX_NRT_ST_INVALID_TOPOLOGY 1 /* "invalid node topology data"      filter.go:199 */
+#define SPX_NRT_ST_INIT_CONTAINER 2   /* "cannot align init container"     filter.go:55  */
+#define SPX_NRT_ST_SIDECAR_CONTAINER 3/* "cannot align sidecar container"  filter.go:55  */
+#define SPX_NRT_ST_CONTAINER 4        /* "cannot align container"          filter.go:67  */
+#define SPX_NRT_ST_POD 5              /* "cannot align pod"                filter.go:172 */
+
+typedef struct spx_nrt_slots {
+  int32_t n_res;
+  const int32_t* slot_res;
+  const uint8_t* slot_flags;
+  const int64_t* slot_weight;
+} spx_nrt_slots;
+
+typedef struct spx_nrt_nodes_soa {
+  int64_t n_nodes;
+  int32_t n_res;
+  const uint8_t* flags;
+  const int32_t* max_numa;
+  const uint8_t* n_zones;
+  const uint8_t* zone_id;
+  const uint8_t* zone_present;
+  const int64_t* zone_avail;
+  const int32_t* zone_cost;
+  const uint8_t* node_present;
+} spx_nrt_nodes_soa;
+
+typedef struct spx_nrt_pods_soa {
+  int64_t n_pods;
+  int32_t n_res;
+  const uint8_t* qos;
+  const uint8_t* non_native;
+  const uint8_t* n_ctr;
+  const uint8_t* ctr_kind;
+  const uint8_t* ctr_present;
+  const int64_t* ctr_req;
+  const uint8_t* pod_present;
+  const int64_t* pod_req;
+} spx_nrt_pods_soa;
+
 /* ------------------------------------------------------------------ engine */
 
 typedef struct spx_engine spx_engine;
@@ -244,9 +344,14 @@ int spx_set_allocatable_params(spx_engine* e, const spx_allocatable_params* p);
 int spx_set_tlp_params(spx_engine* e, const spx_tlp_params* p);
 int spx_set_lvrb_params(spx_engine* e, const spx_lvrb_params* p);
 
+int spx_set_nrt_params(spx_engine* e, const spx_nrt_params* p);
+
 int spx_upload_alloc_nodes(spx_engine* e, const spx_alloc_nodes_soa* t);
 int spx_upload_trimaran_nodes(spx_engine* e, const spx_trimaran_nodes_soa* t);
 int spx_upload_trimaran_pods(spx_engine* e, const spx_trimaran_pods_soa* t);
+int spx_upload_nrt_slots(spx_engine* e, const spx_nrt_slots* t);
+int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t);
+int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t);
 
 /* optional per-(pod,node) feasibility mask for normalizing score plugins: uint8 [n_pods][n_nodes],
  * non-zero = node passed Filter for that pod (upstream scores feasible nodes only).  NULL clears it. */
@@ -286,6 +391,15 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
 int spx_flatten_alloc_nodes(const spx_node_objects* nodes, const spx_resource_classes* rc, const spx_allocatable_params* p, int64_t* alloc_out);
 int spx_flatten_trimaran_nodes(const spx_node_objects* nodes, const spx_metrics_objects* metrics, const spx_assigned_objects* assigned, const spx_tlp_params* tlp, int64_t* cap_cpu_milli, double* tlp_cpu_util, int64_t* tlp_missing_milli, uint8_t* tlp_valid, int64_t* lv_alloc_cpu_milli, int64_t* lv_alloc_mem, double* lv_cpu_avg, double* lv_cpu_std, double* lv_mem_avg, double* lv_mem_std, uint8_t* lv_flags);
 int spx_flatten_trimaran_pods(const spx_pod_objects* pods, const spx_tlp_params* tlp, int64_t* tlp_pod_milli, int64_t* lv_req_cpu_milli, int64_t* lv_req_mem);
+
+
+/* NRT: builds the dense slot numbering from every resource id pods request or zones report
+ * (slot_res/slot_flags/slot_weight sized SPX_NRT_MAX_RES; *n_res_out receives the count) */
+int spx_flatten_nrt_slots(const spx_pod_objects* pods, const spx_nrt_objects* nrt, const spx_resource_classes* rc, const spx_nrt_params* p, int32_t* n_res_out, int32_t* slot_res, uint8_t* slot_flags, int64_t* slot_weight);
+/* node arrays sized: flags[N], max_numa[N], n_zones[N], zone_id[N*8], zone_present[N*8], zone_avail[N*8*n_res], zone_cost[N*8*8], node_present[N] */
+int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_nrt_slots* slots, uint8_t* flags, int32_t* max_numa, uint8_t* n_zones, uint8_t* zone_id, uint8_t* zone_present, int64_t* zone_avail, int32_t* zone_cost, uint8_t* node_present);
+/* pod arrays sized: qos[P], non_native[P], n_ctr[P], ctr_kind[P*8], ctr_present[P*8], ctr_req[P*8*n_res], pod_present[P], pod_req[P*n_res] */
+int spx_flatten_nrt_pods(const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_nrt_slots* slots, uint8_t* qos, uint8_t* non_native, uint8_t* n_ctr, uint8_t* ctr_kind, uint8_t* ctr_present, int64_t* ctr_req, uint8_t* pod_present, int64_t* pod_req);
 
 #ifdef __cplusplus
 }

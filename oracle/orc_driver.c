@@ -31,6 +31,7 @@ static int64_t score_one(const orc_snapshot* s, int plugin, int64_t pod, int64_t
     case SPX_PLUGIN_ALLOCATABLE: return orc_allocatable_score(s->nodes, s->rc, s->alloc_params, node);
     case SPX_PLUGIN_TLP: return orc_tlp_score(s->nodes, s->metrics, s->assigned, s->pods, s->tlp_params, pod, node);
     case SPX_PLUGIN_LVRB: return orc_lvrb_score(s->nodes, s->metrics, s->pods, s->lvrb_params, pod, node);
+    case SPX_PLUGIN_NRT: return orc_nrt_score(s->nrt, s->rc, s->pods, s->nrt_params, pod, node); /* no NormalizeScore: score.go:104-106 */
     default: return 0;
   }
 }
@@ -104,4 +105,48 @@ int orc_score_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t
   free(jobs);
   free(th);
   return rc;
+}
+
+typedef struct fjob {
+  const orc_snapshot* s;
+  int plugin;
+  int64_t row_begin, row_end, base;
+  uint8_t* out;
+} fjob;
+
+static void* frun(void* arg) {
+  fjob* j = (fjob*)arg;
+  const int64_t n = j->s->nodes->n_nodes;
+  for (int64_t pod = j->row_begin; pod < j->row_end; ++pod)
+    for (int64_t node = 0; node < n; ++node) {
+      int st = 0;
+      if (j->plugin == SPX_PLUGIN_NRT) st = orc_nrt_filter(j->s->nodes, j->s->nrt, j->s->rc, j->s->pods, pod, node);
+      j->out[(size_t)(pod - j->base) * (size_t)n + (size_t)node] = (uint8_t)(st < 0 ? 255 : st);
+    }
+  return 0;
+}
+
+int orc_filter_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t row_end, int threads, uint8_t* out_status) {
+  if (!s || !out_status || row_end < row_begin) return -1;
+  int64_t rows = row_end - row_begin;
+  if (threads < 1) threads = 1;
+  if (threads > rows) threads = (int)(rows > 0 ? rows : 1);
+  fjob* jobs = (fjob*)calloc((size_t)threads, sizeof(fjob));
+  pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+  if (!jobs || !th) return -1;
+  for (int t = 0; t < threads; ++t) {
+    jobs[t].s = s;
+    jobs[t].plugin = plugin;
+    jobs[t].base = row_begin;
+    jobs[t].row_begin = row_begin + rows * t / threads;
+    jobs[t].row_end = row_begin + rows * (t + 1) / threads;
+    jobs[t].out = out_status;
+    if (threads == 1) frun(&jobs[t]);
+    else pthread_create(&th[t], 0, frun, &jobs[t]);
+  }
+  if (threads > 1)
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], 0);
+  free(jobs);
+  free(th);
+  return 0;
 }

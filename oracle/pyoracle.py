@@ -56,10 +56,11 @@ class Snapshot:
 
     def __init__(self, nodes: Table, pods: Table, rc: Optional[Table] = None, metrics: Optional[Table] = None,
                  assigned: Optional[Table] = None, alloc_params: Optional[Table] = None,
-                 tlp_params: Optional[Table] = None, lvrb_params: Optional[Table] = None):
+                 tlp_params: Optional[Table] = None, lvrb_params: Optional[Table] = None,
+                 nrt: Optional[Table] = None, nrt_params: Optional[Table] = None):
         h = header()
         self.keep = dict(nodes=nodes, pods=pods, rc=rc, metrics=metrics, assigned=assigned, alloc_params=alloc_params,
-                         tlp_params=tlp_params, lvrb_params=lvrb_params)
+                         tlp_params=tlp_params, lvrb_params=lvrb_params, nrt=nrt, nrt_params=nrt_params)
         self.struct = h.structs["orc_snapshot"]()
         for k, v in self.keep.items():
             if v is not None:
@@ -84,3 +85,12 @@ class Snapshot:
         if rc != 0:
             raise RuntimeError(f"orc_score_rows failed: {rc}")
         return raw, norm
+
+    def filter_rows(self, plugin: int, row_begin: int = 0, row_end: Optional[int] = None, threads: int = 1) -> np.ndarray:
+        row_end = self.n_pods if row_end is None else row_end
+        out = np.zeros((row_end - row_begin, self.n_nodes), dtype=np.uint8)
+        rc = lib().orc_filter_rows(C.byref(self.struct), plugin, row_begin, row_end, threads,
+                                   out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if rc != 0:
+            raise RuntimeError(f"orc_filter_rows failed: {rc}")
+        return out

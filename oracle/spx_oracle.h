@@ -52,6 +52,18 @@ void orc_get_resource_requested(const spx_pod_objects* pods, int64_t pod, int64_
 int64_t orc_lvrb_score(const spx_node_objects* nodes, const spx_metrics_objects* metrics,
                        const spx_pod_objects* pods, const spx_lvrb_params* p, int64_t pod, int64_t node);
 
+/* ---- NodeResourceTopologyMatch (pkg/noderesourcetopology/{filter,score,least_numa,...}.go) */
+int orc_pod_qos(const spx_pod_objects* pods, int64_t pod);
+int orc_include_non_native(const spx_pod_objects* pods, const spx_resource_classes* rc, int64_t pod);
+/* 0 = pass, SPX_NRT_ST_* = Unschedulable with that message, -1 = Error("inconsistent resource accounting") */
+int orc_nrt_filter(const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_resource_classes* rc,
+                   const spx_pod_objects* pods, int64_t pod, int64_t node);
+int64_t orc_nrt_score(const spx_nrt_objects* nrt, const spx_resource_classes* rc, const spx_pod_objects* pods,
+                      const spx_nrt_params* p, int64_t pod, int64_t node);
+int64_t orc_nrt_normalize_score(int numa_nodes_count, int is_min_avg_distance, int highest_numa_id);
+int orc_nrt_numa_nodes_required(const spx_nrt_objects* nrt, const spx_resource_classes* rc, const spx_pod_objects* pods,
+                                int64_t pod, int64_t node, int qos, uint64_t* bitmask, int* is_min_distance);
+
 /* ---- batch drivers: for each pod row in [row_begin,row_end): for each node: Score(); then
  *      NormalizeScore() over that pod's node list (feasible nodes only when `mask` != NULL, as
  *      upstream RunScorePlugins does).  out_raw / out_norm are [rows][n_nodes] int64 (either may
@@ -66,10 +78,16 @@ typedef struct orc_snapshot {
   const spx_allocatable_params* alloc_params;
   const spx_tlp_params* tlp_params;
   const spx_lvrb_params* lvrb_params;
+  const spx_nrt_objects* nrt;
+  const spx_nrt_params* nrt_params;
 } orc_snapshot;
 
 int orc_score_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t row_end,
                    const uint8_t* mask, int threads, int64_t* out_raw, int64_t* out_norm);
+
+/* Filter() of a filter plugin for pod rows [row_begin,row_end) x all nodes: out_status [rows][n_nodes],
+ * 0 = pass, else the plugin's reason code (255 = fwk.Error) */
+int orc_filter_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t row_end, int threads, uint8_t* out_status);
 
 #ifdef __cplusplus
 }

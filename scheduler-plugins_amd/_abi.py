@@ -14,6 +14,7 @@ import numpy as np
 
 _SCALARS = {
     "int": C.c_int,
+    "int8_t": C.c_int8,
     "int32_t": C.c_int32,
     "int64_t": C.c_int64,
     "uint8_t": C.c_uint8,
@@ -26,6 +27,7 @@ _SCALARS = {
 }
 
 _NP = {
+    C.c_int8: np.int8,
     C.c_int32: np.int32,
     C.c_int64: np.int64,
     C.c_uint8: np.uint8,

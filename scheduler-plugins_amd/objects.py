@@ -232,3 +232,104 @@ def build_assigned_objects(hdr: Header, res: Resources, n_nodes: int, entries: D
     ptable = build_pod_objects(hdr, res, pods)
     return Table(hdr, "spx_assigned_objects", e_ptr=_csr(per_node), e_ts_unix=np.array(ts, dtype=np.int64),
                  e_pod=np.array([i for l in per_node for i in l], dtype=np.int32), pods=ptable)
+
+
+# ------------------------------------------------------------------ NodeResourceTopology
+LEGACY_POLICIES = {  # topologyv1alpha2.TopologyManagerPolicy -> (policy << 1) | scope   nodeconfig/topologymanager.go:141-160
+    "SingleNUMANodeContainerLevel": (3 << 1) | 0, "SingleNUMANodePodLevel": (3 << 1) | 1,
+    "BestEffortContainerLevel": (1 << 1) | 0, "BestEffortPodLevel": (1 << 1) | 1,
+    "RestrictedContainerLevel": (2 << 1) | 0, "RestrictedPodLevel": (2 << 1) | 1,
+}
+TM_POLICY = {"none": 0, "best-effort": 1, "restricted": 2, "single-numa-node": 3}
+TM_SCOPE = {"container": 0, "pod": 1}
+
+
+def numa_name_to_id(name: str) -> int:  # numanode.NameToID: "node-<id>"
+    if not name.startswith("node-"):
+        return -1
+    try:
+        return int(name[len("node-"):])
+    except ValueError:
+        return -1
+
+
+def nrt(zones: Sequence[dict], policies: Sequence[str] = (), attributes: Optional[dict] = None) -> dict:
+    """zones: [{"name": "node-0", "type": "Node", "resources": {name: available} | [(name, capacity, available)],
+    "costs": {"node-1": 12, ...}}]"""
+    return {"zones": list(zones), "policies": list(policies), "attributes": dict(attributes or {})}
+
+
+def build_nrt_objects(hdr: Header, res: Resources, nrts: Sequence[Optional[dict]], fresh: Optional[Sequence[bool]] = None,
+                      assumed: Optional[Dict[int, list]] = None) -> Table:
+    n = len(nrts)
+    legacy, a_scope, a_policy, a_max = [], [], [], []
+    zone_lists, zres, zcost, z_is_node, z_id = [], [], [], [], []
+    for t in nrts:
+        lp, sc, po, mx, zs = -1, -1, -1, -1, []
+        if t is not None:
+            pol = t.get("policies") or []
+            if pol:
+                lp = LEGACY_POLICIES.get(pol[0], -1)
+            for k, v in (t.get("attributes") or {}).items():
+                if k == "topologyManagerScope" and v in TM_SCOPE:
+                    sc = TM_SCOPE[v]
+                elif k == "topologyManagerPolicy" and v in TM_POLICY:
+                    po = TM_POLICY[v]
+                elif k == "topologyManagerMaxNUMANodes":
+                    try:
+                        mx = int(v) if int(v) > 1 else -1
+                    except ValueError:
+                        mx = -1
+            for z in t["zones"]:
+                zs.append(z)
+                z_is_node.append(1 if z.get("type", "Node") == "Node" else 0)
+                z_id.append(numa_name_to_id(z["name"]))
+                rl = z.get("resources") or {}
+                if isinstance(rl, dict):
+                    zres.append([(res.id(k), res.canonical(k, v)) for k, v in rl.items()])
+                else:
+                    zres.append([(res.id(k), res.canonical(k, av)) for k, _cap, av in rl])
+                costs = z.get("costs") or {}
+                items = costs.items() if isinstance(costs, dict) else costs
+                zcost.append([(numa_name_to_id(k), int(v)) for k, v in items])
+        legacy.append(lp), a_scope.append(sc), a_policy.append(po), a_max.append(mx)
+        zone_lists.append(zs)
+    assumed = assumed or {}
+    a_lists, per_node = [], []
+    for i in range(n):
+        lists = [_rl(res, rl) for rl in assumed.get(i, [])]
+        per_node.append(lists)
+        a_lists.extend(lists)
+    return Table(
+        hdr, "spx_nrt_objects", n_nodes=n,
+        has_nrt=np.array([t is not None for t in nrts], dtype=np.uint8),
+        fresh=np.ones(n, dtype=np.uint8) if fresh is None else np.array(fresh, dtype=np.uint8),
+        legacy_policy=np.array(legacy, dtype=np.int8), attr_scope=np.array(a_scope, dtype=np.int8),
+        attr_policy=np.array(a_policy, dtype=np.int8), attr_max_numa=np.array(a_max, dtype=np.int32),
+        zone_ptr=_csr(zone_lists), zone_is_node=np.array(z_is_node, dtype=np.uint8), zone_numa_id=np.array(z_id, dtype=np.int32),
+        zres_ptr=_csr(zres), zres_res=[x[0] for l in zres for x in l], zres_avail=[x[1] for l in zres for x in l],
+        zcost_ptr=_csr(zcost), zcost_numa_id=[x[0] for l in zcost for x in l], zcost_value=[x[1] for l in zcost for x in l],
+        assumed_ptr=_csr(per_node), arl_ptr=_csr(a_lists), arl_res=[x[0] for l in a_lists for x in l],
+        arl_qty=[x[1] for l in a_lists for x in l],
+    )
+
+
+def nrt_params(hdr: Header, res: Resources, strategy: str = "LeastAllocated", weights: Optional[dict] = None) -> Table:
+    strat = {"MostAllocated": 0, "BalancedAllocation": 1, "LeastAllocated": 2, "LeastNUMANodes": 3}[strategy]
+    weights = weights or {}
+    return Table(hdr, "spx_nrt_params", strategy=strat, n_weights=len(weights),
+                 weight_res=np.array([res.id(k) for k in weights], dtype=np.int32),
+                 weight=np.array(list(weights.values()), dtype=np.int64))
+
+
+def node_from_zones(zones: Sequence[dict], extra: Optional[dict] = None) -> dict:
+    """makeResourceListFromZones (objects.go:83-95): node allocatable = Σ zone Available per resource (+extras)."""
+    total: Dict[str, Fraction] = {}
+    for z in zones:
+        rl = z.get("resources") or {}
+        items = rl.items() if isinstance(rl, dict) else [(k, av) for k, _c, av in rl]
+        for k, v in items:
+            total[k] = total.get(k, Fraction(0)) + parse_quantity(v)
+    for k, v in (extra or {}).items():
+        total[k] = parse_quantity(v)
+    return node(total)

@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Transcribes the reference's table-driven Go tests into JSON fixtures (tests/golden/*.json).
+
+Runs only where /root/reference is mounted (the build container); the JSON it writes is committed and is
+what the tests read — nothing under tests/ touches /root/reference at run time.  It reads composite
+literals only (goparse.py); no reference code is executed (there is no Go toolchain here).
+
+usage: python tests/golden/transcribe.py            # rewrites every fixture
+"""
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+from goparse import Call, Func, Ident, line_of, parse_literal_after  # noqa: E402
+
+REF = Path("/root/reference")
+
+NAMES = {  # identifiers used as resource names in the test files (filter_test.go:39-48, score_test.go, least_numa_test.go)
+    "v1.ResourceCPU": "cpu", "v1.ResourceMemory": "memory", "cpu": "cpu", "memory": "memory",
+    "v1.ResourceEphemeralStorage": "ephemeral-storage", "v1.ResourceStorage": "storage", "v1.ResourcePods": "pods",
+    "extended": "namespace/extended", "hugepages2Mi": "hugepages-2Mi", "nicResourceName": "vendor/nic1",
+    "notExistingNICResourceName": "vendor/notexistingnic", "nicResourceNameNoNUMA": "vendor.com/old-nic-model",
+    "gpuResource": "gpu", "gpu": "gpu",  # least_numa_test.go:32, score_test.go:42
+}
+
+
+def const(src: str, name: str) -> str:
+    import re
+    m = re.search(r"\b%s\s*=\s*\"([^\"]+)\"" % name, src)
+    return m.group(1)
+
+
+def rname(k):
+    if isinstance(k, Ident):
+        k = k.name
+    return NAMES.get(k, k)
+
+
+def qty(v):
+    """resource.MustParse("2Gi") -> "2Gi"; *resource.NewQuantity(2, DecimalSI) -> 2; NewMilliQuantity(n) -> "<n>m"."""
+    if isinstance(v, Call):
+        if v.fn == "resource.MustParse":
+            return v.args[0]
+        if v.fn == "resource.NewQuantity":
+            return v.args[0]
+        if v.fn == "resource.NewMilliQuantity":
+            return f"{v.args[0]}m"
+    if isinstance(v, (int, str)):
+        return v
+    raise ValueError(f"cannot read quantity {v!r}")
+
+
+def rlist(d, names):
+    return {names(k): qty(v) for k, v in d.items()}
+
+
+def zones_of(z_list, names):
+    out = []
+    for z in z_list:
+        rs = [[names(c.args[0]), c.args[1], c.args[2]] for c in z.get("Resources", [])]
+        costs = [[c["Name"], c["Value"]] for c in z.get("Costs", [])]
+        out.append({"name": z["Name"], "type": z["Type"], "resources": rs, "costs": costs})
+    return out
+
+
+def nrt_of(n, names):
+    pol = n.get("TopologyPolicies", [])
+    pols = []
+    for p in pol:
+        inner = p.args[0] if isinstance(p, Call) else p
+        pols.append(inner.name.split(".")[-1] if isinstance(inner, Ident) else inner)
+    attrs = {a["Name"]: a["Value"] for a in n.get("Attributes", [])}
+    name = n["ObjectMeta"]["Name"]
+    return {"name": name, "policies": pols, "attributes": attrs, "zones": zones_of(n["Zones"], names)}
+
+
+def pod_of(expr, descs, names):
+    """The pod builders of objects.go:26-140 / filter_test.go:1206-1243."""
+    def resolve(v):
+        if isinstance(v, Call) and v.fn == "findAvailableResourceByName":  # filter_test.go:1197-1204
+            sel = v.args[0]  # nodeTopologyDescs[i].nrt.Zones[j].Resources
+            zi = sel.args[0].args[1]
+            di = sel.args[0].args[0].args[0].args[0].args[1]
+            want = names(v.args[1])
+            for n, _cap, av in descs[di]["zones"][zi]["resources"]:
+                if n == want:
+                    return av
+            raise KeyError(want)
+        return qty(v)
+
+    def rl(d):
+        return {names(k): resolve(v) for k, v in d.items()}
+
+    if isinstance(expr, dict) or (isinstance(expr, list) and not expr):  # &v1.Pod{}
+        return {"containers": []}
+    if expr.fn == "makePodByResourceList":
+        r = rl(expr.args[0])
+        return {"containers": [{"requests": r, "limits": r}]}
+    if expr.fn == "makePodByResourceListWithManyContainers":  # objects.go:104-120
+        r = rl(expr.args[0])
+        return {"containers": [{"requests": r, "limits": r} for _ in range(expr.args[1])]}
+    if expr.fn == "makePodWithReqByResourceList":
+        return {"containers": [{"requests": rl(expr.args[0])}]}
+    if expr.fn == "makePodWithReqAndLimitByResourceList":
+        return {"containers": [{"requests": rl(expr.args[0]), "limits": rl(expr.args[1])}]}
+    if expr.fn == "makePod":
+        pod = {"containers": [], "init_containers": []}
+        for opt in expr.args[1:]:
+            lists = [rl(x) for x in opt.args[0]]
+            if opt.fn == "withMultiContainers":  # requests == limits (filter_test.go:1218-1234)
+                pod["containers"] += [{"requests": r, "limits": r} for r in lists]
+            elif opt.fn == "withMultiInitContainers":
+                pod["init_containers"] += [{"requests": r, "limits": r} for r in lists]
+        return pod
+    raise ValueError(expr)
+
+
+def status_of(v):
+    if isinstance(v, Ident) and v.name == "nil":
+        return None
+    if isinstance(v, Call) and v.fn == "fwk.NewStatus":
+        return {"code": v.args[0].name.split(".")[-1], "message": v.args[1]}
+    raise ValueError(v)
+
+
+def nrt_filter():
+    path = "pkg/noderesourcetopology/filter_test.go"
+    src = (REF / path).read_text()
+    names = rname
+    out = {"source": path, "note": "TestNodeResourceTopology / ...MultiContainerPodScope / ...MultiContainerContainerScope"}
+    descs_raw = parse_literal_after(src, "nodeTopologyDescs := ")
+    descs = []
+    for d in descs_raw:
+        n = nrt_of(d["nrt"], names)
+        n["node_extra"] = rlist(d.get("node", {}), names)
+        descs.append(n)
+    out["nodes"] = descs
+    cases = []
+    pos = src.index("tests := ")
+    for t in parse_literal_after(src, "tests := "):
+        cases.append({"name": t["name"], "line": line_of(src, '"' + t["name"] + '"', pos), "pod": pod_of(t["pod"], descs, names),
+                      "node": t["node"].args[1], "want": status_of(t["wantStatus"])})
+    out["cases"] = cases
+    # pod scope, multi container (filter_test.go:715-941)
+    p2 = src.index("func TestNodeResourceTopologyMultiContainerPodScope")
+    nts = parse_literal_after(src[p2:], "nodeTopologies := ")
+    out["pod_scope_nodes"] = [nrt_of(n, names) for n in nts]
+    ps = []
+    for t in parse_literal_after(src[p2:], "tests := "):
+        ps.append({"name": t["name"], "line": line_of(src, '"' + t["name"] + '"', p2), "pod": pod_of(t["pod"], descs, names),
+                   "node": t["node"].args[1], "want": status_of(t["wantStatus"])})
+    out["pod_scope_cases"] = ps
+    # container scope, tiered cases (filter_test.go:943-1182)
+    p3 = src.index("func TestNodeResourceTopologyMultiContainerContainerScope")
+    nts = parse_literal_after(src[p3:], "nodeTopologies := ")
+    out["container_scope_nodes"] = [nrt_of(n, names) for n in nts]
+    cs = []
+    for t in parse_literal_after(src[p3:], "tue := "):
+        def rls(lst):
+            return [{"requests": {names(k): v for k, v in m.items()}, "limits": {names(k): v for k, v in m.items()}} for m in lst]
+        cs.append({"name": t["description"], "line": line_of(src, '"' + t["description"] + '"', p3),
+                   "pod": {"init_containers": rls(t.get("initCntReq", [])), "containers": rls(t.get("cntReq", []))},
+                   "node": 0, "want": ({"code": "Unschedulable", "message": t["statusErr"]} if t.get("statusErr") else None)})
+    out["container_scope_cases"] = cs
+    return out
+
+
+def nrt_score():
+    path = "pkg/noderesourcetopology/score_test.go"
+    src = (REF / path).read_text()
+    names = rname
+    out = {"source": path}
+    pd = src.index("func defaultNUMANodes")
+    out["default_numa_nodes"] = [nrt_of(n, names) for n in parse_literal_after(src[pd:], "nrts := ")]
+    pf = src.index("func fourNUMANodes")
+    out["four_numa_nodes"] = [nrt_of(n, names) for n in parse_literal_after(src[pf:], "return ")]
+    # TestNodeResourceScorePlugin (:88-195) and TestNodeResourcePartialDataScorePlugin (:484-621)
+    def scen(fn_name):
+        p = src.index("func " + fn_name)
+        reqs = parse_literal_after(src[p:], "pRequests := ")
+        pod = pod_of(reqs[0]["pod"], [], names)
+        res = []
+        for t in parse_literal_after(src[p:], "tests := "):
+            f = t.get("nrtFilter")
+            keep = None
+            if isinstance(f, Func):
+                keep = [] if 'nrt.Name != "Node1"' not in f.src else ["Node1"]
+            res.append({"name": t["name"], "line": line_of(src, '"' + t["name"] + '"', p), "pod": pod,
+                        "strategy": {"mostAllocatedScoreStrategy": "MostAllocated", "leastAllocatedScoreStrategy": "LeastAllocated",
+                                     "balancedAllocationScoreStrategy": "BalancedAllocation"}[t["strategy"].name],
+                        "wanted": t["wantedRes"], "nodes_with_nrt": keep})
+        return res
+    out["strategy_cases"] = scen("TestNodeResourceScorePlugin")
+    out["partial_data_cases"] = scen("TestNodeResourcePartialDataScorePlugin")
+    p = src.index("func TestNodeResourceScorePluginLeastNUMA")
+    ln = []
+    for t in parse_literal_after(src[p:], "testCases := "):
+        nodes = t["nodes"]
+        fixture = {"fn": nodes.fn, "policy": None}
+        if nodes.fn == "defaultNUMANodes":
+            fixture["policy"] = nodes.args[0].args[0].name.split(".")[-1]
+        ln.append({"name": t["name"], "line": line_of(src, '"' + t["name"] + '"', p),
+                   "containers": [{names(k): qty(v) for k, v in rl.items()} for rl in t["podRequests"]],
+                   "wanted": t["wantedRes"], "nodes": fixture})
+    out["least_numa_cases"] = ln
+    return out
+
+
+def nrt_least_numa():
+    path = "pkg/noderesourcetopology/least_numa_test.go"
+    src = (REF / path).read_text()
+    names = rname
+    out = {"source": path}
+    cases = []
+    for t in parse_literal_after(src, "testCases := "):
+        bm = t["expectedBitmask"]
+        cases.append({
+            "name": t["description"], "line": line_of(src, '"' + t["description"] + '"'),
+            "numa_nodes": [{"id": n["NUMAID"], "resources": {names(k): qty(v) for k, v in n.get("Resources", {}).items()},
+                            "costs": {str(k): v for k, v in n.get("Costs", {}).items()}} for n in t["numaNodes"]],
+            "pod_resources": {names(k): qty(v) for k, v in t["podResources"].items()},
+            "bitmask": None if isinstance(bm, Ident) else list(bm.args),
+            "min_distance": t["expectedMinDistance"].name == "true",
+        })
+    out["numa_nodes_required"] = cases
+    p = src.index("func TestNormalizeScore")
+    out["normalize_score"] = [{"name": t["description"], "count": t["score"], "expected": t["expectedScore"],
+                               "optimal": isinstance(t.get("optimalDistance"), Ident) and t["optimalDistance"].name == "true"}
+                              for t in parse_literal_after(src[p:], "tcases := ")]
+    return out
+
+
+FIXTURES = {"nrt_filter.json": nrt_filter, "nrt_score.json": nrt_score, "nrt_least_numa.json": nrt_least_numa}
+
+if __name__ == "__main__":
+    for fname, fn in FIXTURES.items():
+        data = fn()
+        (HERE / fname).write_text(json.dumps(data, indent=1, sort_keys=False) + "\n")
+        print(fname, {k: (len(v) if isinstance(v, list) else "…") for k, v in data.items()})
