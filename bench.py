@@ -34,6 +34,10 @@ WORKLOADS = {
                     desc="noderesources.Allocatable + trimaran.TargetLoadPacking, 10k nodes x 100k pods"),
     "config2_lvrb": dict(n_nodes=10_000, n_pods=100_000, plugins=("alloc", "tlp", "lvrb"), node_row=90, pod_row=24, out=3,
                          desc="Allocatable + TargetLoadPacking + LoadVariationRiskBalancing, 10k x 100k"),
+    "config3": dict(n_nodes=5_000, n_pods=50_000, plugins=("nrt",), node_row=324, pod_row=100, out=2, strategy="LeastAllocated",
+                    desc="noderesourcetopology Filter+Score (LeastAllocated), 5k nodes x 8 NUMA zones x 50k pods"),
+    "config3_leastnuma": dict(n_nodes=5_000, n_pods=50_000, plugins=("nrt",), node_row=324, pod_row=100, out=2, strategy="LeastNUMANodes",
+                              desc="noderesourcetopology Filter+Score (LeastNUMANodes), 5k nodes x 8 NUMA zones x 50k pods"),
     "small": dict(n_nodes=1_000, n_pods=4_000, plugins=("alloc", "tlp"), node_row=41, pod_row=8, out=2,
                   desc="plumbing-sized Allocatable + TLP"),
 }
@@ -45,8 +49,9 @@ def cpu_baseline(spx, snap, e, plugins, budget_s: float):
     sys.path.insert(0, str(ROOT / "oracle"))
     import pyoracle
 
-    osnap = pyoracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], metrics=snap["metrics"], assigned=snap["assigned"],
-                              alloc_params=e.alloc_params, tlp_params=e.tlp_params, lvrb_params=e.lvrb_params)
+    osnap = pyoracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], metrics=snap.get("metrics"), assigned=snap.get("assigned"),
+                              alloc_params=e.alloc_params, tlp_params=e.tlp_params, lvrb_params=e.lvrb_params,
+                              nrt=snap.get("nrt"), nrt_params=snap.get("nrt_params"))
     cores = os.cpu_count() or 1
     n_nodes = osnap.n_nodes
 
@@ -54,6 +59,8 @@ def cpu_baseline(spx, snap, e, plugins, budget_s: float):
         t0 = time.perf_counter()
         for p in plugins:
             osnap.score_rows(p, 0, rows, threads=cores, want_raw=False, want_norm=True)
+            if p == 3:  # NodeResourceTopologyMatch also has a Filter extension point
+                osnap.filter_rows(p, 0, rows, threads=cores)
         return time.perf_counter() - t0
 
     probe_rows = min(osnap.n_pods, 8 * cores)
@@ -107,24 +114,33 @@ def main() -> None:
 
     import scheduler_plugins_amd as spx
     from scheduler_plugins_amd import synth
-    from scheduler_plugins_amd.engine import ALLOCATABLE, LVRB, TLP, Engine, mask_of
+    from scheduler_plugins_amd import objects as O
+    from scheduler_plugins_amd.engine import ALLOCATABLE, LVRB, NRT, TLP, Engine, mask_of
 
     w = dict(WORKLOADS[args.workload])
     if args.plugins:
         w["plugins"] = tuple(args.plugins.split(","))
         w["out"] = len(w["plugins"])
-    pid = {"alloc": ALLOCATABLE, "tlp": TLP, "lvrb": LVRB}
+    pid = {"alloc": ALLOCATABLE, "tlp": TLP, "lvrb": LVRB, "nrt": NRT}
     plugins = [pid[p] for p in w["plugins"]]
     mask = mask_of(*plugins)
     n_nodes, n_pods = w["n_nodes"], w["n_pods"]
 
     hdr = spx.header()
     # every rank: same node snapshot, its own pod batch (seeded by rank)
-    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED, round_frac=args.round_frac)
-    if rank:
-        snap["pods"] = synth.synth_pods(hdr, n_pods, seed=synth.SEED + 1000 * rank)
     e = Engine(local_rank)
-    e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+    if "nrt" in w["plugins"]:
+        snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED)
+        if rank:
+            snap["pods"] = synth.synth_pods(hdr, n_pods, seed=synth.SEED + 1000 * rank, device_res=synth.RES_DEVICE,
+                                            hugepage_res=synth.RES_HUGEPAGES_2MI)
+        snap["nrt_params"] = O.nrt_params(hdr, O.Resources(), w["strategy"])
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], snap["nrt_params"])
+    else:
+        snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED, round_frac=args.round_frac)
+        if rank:
+            snap["pods"] = synth.synth_pods(hdr, n_pods, seed=synth.SEED + 1000 * rank)
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
 
     def barrier():
         if dist is not None:

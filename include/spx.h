@@ -307,6 +307,7 @@ typedef struct spx_nrt_nodes_soa {
   const uint8_t* zone_present;
   const int64_t* zone_avail;
   const int32_t* zone_cost;
+  const float* min_avg_dist;
   const uint8_t* node_present;
 } spx_nrt_nodes_soa;
 
@@ -396,8 +397,8 @@ int spx_flatten_trimaran_pods(const spx_pod_objects* pods, const spx_tlp_params*
 /* NRT: builds the dense slot numbering from every resource id pods request or zones report
  * (slot_res/slot_flags/slot_weight sized SPX_NRT_MAX_RES; *n_res_out receives the count) */
 int spx_flatten_nrt_slots(const spx_pod_objects* pods, const spx_nrt_objects* nrt, const spx_resource_classes* rc, const spx_nrt_params* p, int32_t* n_res_out, int32_t* slot_res, uint8_t* slot_flags, int64_t* slot_weight);
-/* node arrays sized: flags[N], max_numa[N], n_zones[N], zone_id[N*8], zone_present[N*8], zone_avail[N*8*n_res], zone_cost[N*8*8], node_present[N] */
-int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_nrt_slots* slots, uint8_t* flags, int32_t* max_numa, uint8_t* n_zones, uint8_t* zone_id, uint8_t* zone_present, int64_t* zone_avail, int32_t* zone_cost, uint8_t* node_present);
+/* node arrays sized: flags[N], max_numa[N], n_zones[N], zone_id[N*8], zone_present[N*8], zone_avail[N*8*n_res], zone_cost[N*8*8], min_avg_dist[N*8], node_present[N] */
+int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_nrt_slots* slots, uint8_t* flags, int32_t* max_numa, uint8_t* n_zones, uint8_t* zone_id, uint8_t* zone_present, int64_t* zone_avail, int32_t* zone_cost, float* min_avg_dist, uint8_t* node_present);
 /* pod arrays sized: qos[P], non_native[P], n_ctr[P], ctr_kind[P*8], ctr_present[P*8], ctr_req[P*8*n_res], pod_present[P], pod_req[P*n_res] */
 int spx_flatten_nrt_pods(const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_nrt_slots* slots, uint8_t* qos, uint8_t* non_native, uint8_t* n_ctr, uint8_t* ctr_kind, uint8_t* ctr_present, int64_t* ctr_req, uint8_t* pod_present, int64_t* pod_req);
 

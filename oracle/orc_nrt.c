@@ -356,7 +356,18 @@ static int64_t strategy_score(const spx_nrt_params* p, const rlist* requested, c
   if (p->strategy == SPX_NRT_BALANCED_ALLOCATION) { /* balanced_allocation.go:27-54 */
     double fr[ORC_MAXR];
     int n = 0;
-    for (int i = 0; i < requested->n; ++i) {
+    /* Go ranges the map in random order; this restatement fixes ascending resource id so that the
+     * float64 sums below are reproducible (order only matters in the last ulp, and only for n >= 3) */
+    int order[ORC_MAXR];
+    for (int i = 0; i < requested->n; ++i) order[i] = i;
+    for (int i = 1; i < requested->n; ++i)
+      for (int j = i; j > 0 && requested->res[order[j - 1]] > requested->res[order[j]]; --j) {
+        int t = order[j];
+        order[j] = order[j - 1];
+        order[j - 1] = t;
+      }
+    for (int oi = 0; oi < requested->n; ++oi) {
+      int i = order[oi];
       int k = rl_find(allocatable, requested->res[i]);
       int64_t cap_v = k >= 0 ? q_value(requested->res[i], allocatable->qty[k]) : 0;
       double f = cap_v == 0 ? 1.0 : (double)q_value(requested->res[i], requested->qty[i]) / (double)cap_v;

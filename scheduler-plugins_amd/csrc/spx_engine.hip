@@ -56,6 +56,16 @@ struct spx_engine {
   bool tri_pods = false;
   DevBuf d_raw_row;  // int64 [n_nodes] staging for spx_fetch_raw
 
+  // NodeResourceTopologyMatch
+  spx_nrt_params nrt_params{SPX_NRT_LEAST_ALLOCATED, 0, nullptr, nullptr};  // defaults.go:87-90
+  int32_t nrt_n_res = 0;
+  uint8_t nrt_slot_flags[SPX_NRT_MAX_RES] = {0};
+  int64_t nrt_slot_weight[SPX_NRT_MAX_RES] = {0};
+  bool nrt_slots = false, nrt_nodes = false, nrt_pods = false;
+  DevBuf d_nrt_flags, d_nrt_max_numa, d_nrt_nz, d_nrt_zid, d_nrt_zp, d_nrt_avail, d_nrt_cost, d_nrt_minavg, d_nrt_np;
+  DevBuf d_nrt_qos, d_nrt_nn, d_nrt_nctr, d_nrt_ckind, d_nrt_cpres, d_nrt_creq, d_nrt_ppres, d_nrt_preq;
+  DevBuf status[SPX_NUM_PLUGINS];
+
   DevBuf score[SPX_NUM_PLUGINS];
   int64_t score_rows[SPX_NUM_PLUGINS] = {0};
   int64_t score_stride[SPX_NUM_PLUGINS] = {0};
@@ -179,6 +189,46 @@ void fill_trimaran(const spx_engine* e, spx::TrimaranArgs& a) {
   a.lv_sensitivity = e->lvrb.safe_variance_sensitivity;
 }
 
+void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
+  na.n_nodes = e->n_nodes;
+  na.n_pods = e->n_pods;
+  na.row_stride = e->row_stride;
+  na.n_res = e->nrt_n_res;
+  na.strategy = e->nrt_params.strategy;
+  std::memcpy(na.slot_flags, e->nrt_slot_flags, sizeof na.slot_flags);
+  std::memcpy(na.slot_weight, e->nrt_slot_weight, sizeof na.slot_weight);
+  na.flags = static_cast<const uint8_t*>(e->d_nrt_flags.p);
+  na.max_numa = static_cast<const int32_t*>(e->d_nrt_max_numa.p);
+  na.n_zones = static_cast<const uint8_t*>(e->d_nrt_nz.p);
+  na.zone_id = static_cast<const uint8_t*>(e->d_nrt_zid.p);
+  na.zone_present = static_cast<const uint8_t*>(e->d_nrt_zp.p);
+  na.zone_avail = static_cast<const int64_t*>(e->d_nrt_avail.p);
+  na.zone_cost = static_cast<const int32_t*>(e->d_nrt_cost.p);
+  na.min_avg = static_cast<const float*>(e->d_nrt_minavg.p);
+  na.node_present = static_cast<const uint8_t*>(e->d_nrt_np.p);
+  na.qos = static_cast<const uint8_t*>(e->d_nrt_qos.p);
+  na.non_native = static_cast<const uint8_t*>(e->d_nrt_nn.p);
+  na.n_ctr = static_cast<const uint8_t*>(e->d_nrt_nctr.p);
+  na.ctr_kind = static_cast<const uint8_t*>(e->d_nrt_ckind.p);
+  na.ctr_present = static_cast<const uint8_t*>(e->d_nrt_cpres.p);
+  na.ctr_req = static_cast<const int64_t*>(e->d_nrt_creq.p);
+  na.pod_present = static_cast<const uint8_t*>(e->d_nrt_ppres.p);
+  na.pod_req = static_cast<const int64_t*>(e->d_nrt_preq.p);
+}
+
+// host [N][inner] -> device [inner][N] so that lane = node reads coalesce
+template <typename T>
+int upload_transposed(spx_engine* e, DevBuf& b, const T* src, int64_t n, int64_t inner) {
+  if (!src) return fail(e, SPX_ERR_ARG, "NULL column in table");
+  std::vector<T> tmp(static_cast<size_t>(n) * static_cast<size_t>(inner));
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t k = 0; k < inner; ++k) tmp[static_cast<size_t>(k) * n + i] = src[static_cast<size_t>(i) * inner + k];
+  int rc = upload(e, b, tmp.data(), tmp.size() * sizeof(T));
+  if (rc) return rc;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));  // tmp dies at scope exit
+  return SPX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -216,11 +266,15 @@ int spx_destroy(spx_engine* e) {
   DevBuf* bufs[] = {&e->d_alloc,   &e->d_alloc_w,  &e->d_alloc_raw, &e->d_alloc_norm, &e->d_cap_cpu, &e->d_tlp_util,
                     &e->d_tlp_missing, &e->d_tlp_valid, &e->d_lv_acpu, &e->d_lv_amem, &e->d_lv_cavg, &e->d_lv_cstd,
                     &e->d_lv_mavg, &e->d_lv_mstd,  &e->d_lv_flags,  &e->d_tlp_pod,    &e->d_lv_rcpu, &e->d_lv_rmem,
-                    &e->d_raw_row};
+                    &e->d_raw_row,   &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
+                    &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
+                    &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq};
   for (DevBuf* b : bufs)
     if (b->p && !b->external) (void)hipFree(b->p);
-  for (int i = 0; i < SPX_NUM_PLUGINS; ++i)
+  for (int i = 0; i < SPX_NUM_PLUGINS; ++i) {
     if (e->score[i].p && !e->score[i].external) (void)hipFree(e->score[i].p);
+    if (e->status[i].p) (void)hipFree(e->status[i].p);
+  }
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -328,6 +382,71 @@ int spx_upload_trimaran_pods(spx_engine* e, const spx_trimaran_pods_soa* t) {
   return SPX_OK;
 }
 
+int spx_set_nrt_params(spx_engine* e, const spx_nrt_params* p) {
+  if (!e || !p) return SPX_ERR_ARG;
+  if (p->strategy < SPX_NRT_MOST_ALLOCATED || p->strategy > SPX_NRT_LEAST_NUMA_NODES)
+    return fail(e, SPX_ERR_ARG, "illegal scoring strategy found");  // score.go:137-139
+  e->nrt_params.strategy = p->strategy;  // weights travel through the slot table (spx_flatten_nrt_slots)
+  return SPX_OK;
+}
+
+int spx_upload_nrt_slots(spx_engine* e, const spx_nrt_slots* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  if (t->n_res < 0 || t->n_res > SPX_NRT_MAX_RES) return fail(e, SPX_ERR_ARG, "NRT: more resource slots than this build supports");
+  e->nrt_n_res = t->n_res;
+  for (int i = 0; i < t->n_res; ++i) {
+    e->nrt_slot_flags[i] = t->slot_flags[i];
+    e->nrt_slot_weight[i] = t->slot_weight[i];
+  }
+  e->nrt_slots = true;
+  e->nrt_nodes = e->nrt_pods = false;  // tables are laid out by slot count
+  return SPX_OK;
+}
+
+int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  if (!e->nrt_slots || t->n_res != e->nrt_n_res) return fail(e, SPX_ERR_STATE, "NRT: upload the slot table first (n_res mismatch)");
+  int rc = set_nodes(e, t->n_nodes);
+  if (rc) return rc;
+  const int64_t n = t->n_nodes;
+  constexpr int64_t Zm = SPX_NRT_MAX_ZONES;
+  if ((rc = upload(e, e->d_nrt_flags, t->flags, static_cast<size_t>(n)))) return rc;
+  if ((rc = upload(e, e->d_nrt_max_numa, t->max_numa, static_cast<size_t>(n) * 4))) return rc;
+  if ((rc = upload(e, e->d_nrt_nz, t->n_zones, static_cast<size_t>(n)))) return rc;
+  if ((rc = upload(e, e->d_nrt_np, t->node_present, static_cast<size_t>(n)))) return rc;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  if ((rc = upload_transposed(e, e->d_nrt_zid, t->zone_id, n, Zm))) return rc;
+  if ((rc = upload_transposed(e, e->d_nrt_zp, t->zone_present, n, Zm))) return rc;
+  if ((rc = upload_transposed(e, e->d_nrt_avail, t->zone_avail, n, Zm * t->n_res))) return rc;
+  if ((rc = upload_transposed(e, e->d_nrt_cost, t->zone_cost, n, Zm * Zm))) return rc;
+  if ((rc = upload_transposed(e, e->d_nrt_minavg, t->min_avg_dist, n, Zm))) return rc;
+  e->nrt_nodes = true;
+  return SPX_OK;
+}
+
+int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  if (!e->nrt_slots || t->n_res != e->nrt_n_res) return fail(e, SPX_ERR_STATE, "NRT: upload the slot table first (n_res mismatch)");
+  int rc = set_pods(e, t->n_pods);
+  if (rc) return rc;
+  const size_t p = static_cast<size_t>(t->n_pods);
+  const size_t R = static_cast<size_t>(t->n_res);
+  constexpr size_t Cm = SPX_NRT_MAX_CTRS;
+  if ((rc = upload(e, e->d_nrt_qos, t->qos, p))) return rc;
+  if ((rc = upload(e, e->d_nrt_nn, t->non_native, p))) return rc;
+  if ((rc = upload(e, e->d_nrt_nctr, t->n_ctr, p))) return rc;
+  if ((rc = upload(e, e->d_nrt_ckind, t->ctr_kind, p * Cm))) return rc;
+  if ((rc = upload(e, e->d_nrt_cpres, t->ctr_present, p * Cm))) return rc;
+  if ((rc = upload(e, e->d_nrt_creq, t->ctr_req, p * Cm * R * 8))) return rc;
+  if ((rc = upload(e, e->d_nrt_ppres, t->pod_present, p))) return rc;
+  if ((rc = upload(e, e->d_nrt_preq, t->pod_req, p * R * 8))) return rc;
+  e->nrt_pods = true;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  return SPX_OK;
+}
+
 int spx_upload_feasible_mask(spx_engine* e, const uint8_t* mask, int64_t n_pods, int64_t n_nodes) {
   if (!e) return SPX_ERR_ARG;
   (void)mask;
@@ -339,7 +458,7 @@ int spx_upload_feasible_mask(spx_engine* e, const uint8_t* mask, int64_t n_pods,
 int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end) {
   if (!e) return SPX_ERR_ARG;
   SPX_HIP(e, hipSetDevice(e->device));
-  const uint32_t known = (1u << SPX_PLUGIN_ALLOCATABLE) | (1u << SPX_PLUGIN_TLP) | (1u << SPX_PLUGIN_LVRB);
+  const uint32_t known = (1u << SPX_PLUGIN_ALLOCATABLE) | (1u << SPX_PLUGIN_TLP) | (1u << SPX_PLUGIN_LVRB) | (1u << SPX_PLUGIN_NRT);
   if (plugin_mask == 0 || (plugin_mask & ~known)) return fail(e, SPX_ERR_ARG, "plugin mask has unsupported bits");
   if (e->n_nodes <= 0) return fail(e, SPX_ERR_STATE, "no node table uploaded");
   const bool A = plugin_mask & (1u << SPX_PLUGIN_ALLOCATABLE);
@@ -352,9 +471,12 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   }
   if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
   int rc;
+  const bool N = plugin_mask & (1u << SPX_PLUGIN_NRT);
+  if (N && !(e->nrt_slots && e->nrt_nodes && e->nrt_pods)) return fail(e, SPX_ERR_STATE, "NRT slot/node/pod tables not uploaded");
   if (A && (rc = prepare_alloc(e))) return rc;
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < 4; ++p)
     if ((plugin_mask & (1u << p)) && (rc = ensure_score_table(e, p))) return rc;
+  if (N && (rc = ensure(e, e->status[SPX_PLUGIN_NRT], static_cast<size_t>(e->n_pods) * static_cast<size_t>(e->row_stride)))) return rc;
 
   spx::TrimaranArgs a{};
   fill_trimaran(e, a);
@@ -370,6 +492,18 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
   spx::launch_trimaran(a, e->stream);
   SPX_HIP(e, hipGetLastError());
+  if (N) {
+    if (e->score_stride[SPX_PLUGIN_NRT] != e->row_stride)
+      return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
+    spx::NrtArgs na{};
+    fill_nrt(e, na);
+    na.row_begin = row_begin;
+    na.row_end = row_end;
+    na.out_status = static_cast<uint8_t*>(e->status[SPX_PLUGIN_NRT].p);
+    na.out_score = static_cast<uint8_t*>(e->score[SPX_PLUGIN_NRT].p);
+    spx::launch_nrt(na, e->stream);
+    SPX_HIP(e, hipGetLastError());
+  }
   SPX_HIP(e, hipEventRecord(e->ev1, e->stream));
   e->timed = true;
   e->evaluated |= plugin_mask;
@@ -405,9 +539,12 @@ int spx_fetch_scores(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out) {
 
 int spx_fetch_status(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out) {
   if (!e || !out) return SPX_ERR_ARG;
-  (void)plugin;
-  (void)pod_row;
-  return fail(e, SPX_ERR_STATE, "plugin has no Filter extension point in this build");
+  if (plugin < 0 || plugin >= SPX_NUM_PLUGINS || !e->status[plugin].p || !(e->evaluated & (1u << plugin)))
+    return fail(e, SPX_ERR_STATE, "plugin has no evaluated Filter table");
+  if (pod_row < 0 || pod_row >= e->n_pods) return fail(e, SPX_ERR_ARG, "pod_row out of range");
+  const uint8_t* src = static_cast<const uint8_t*>(e->status[plugin].p) + pod_row * e->row_stride;
+  SPX_HIP(e, hipMemcpy(out, src, static_cast<size_t>(e->n_nodes), hipMemcpyDeviceToHost));
+  return SPX_OK;
 }
 
 int spx_fetch_raw(spx_engine* e, int plugin, int which, int64_t pod_row, int64_t* out) {
@@ -420,6 +557,21 @@ int spx_fetch_raw(spx_engine* e, int plugin, int which, int64_t pod_row, int64_t
   if (plugin == SPX_PLUGIN_ALLOCATABLE) {
     if ((rc = prepare_alloc(e))) return rc;
     SPX_HIP(e, hipMemcpyAsync(out, e->d_alloc_raw.p, bytes, hipMemcpyDeviceToHost, e->stream));
+    SPX_HIP(e, hipStreamSynchronize(e->stream));
+    return SPX_OK;
+  }
+  if (plugin == SPX_PLUGIN_NRT) {  // TopologyMatch has no NormalizeScore (score.go:104-106)
+    if (!(e->nrt_slots && e->nrt_nodes && e->nrt_pods)) return fail(e, SPX_ERR_STATE, "NRT slot/node/pod tables not uploaded");
+    if (pod_row < 0 || pod_row >= e->n_pods) return fail(e, SPX_ERR_ARG, "pod_row out of range");
+    if ((rc = ensure(e, e->d_raw_row, bytes))) return rc;
+    spx::NrtArgs na{};
+    fill_nrt(e, na);
+    na.row_begin = pod_row;
+    na.row_end = pod_row + 1;
+    na.out_raw = static_cast<int64_t*>(e->d_raw_row.p);
+    spx::launch_nrt(na, e->stream);
+    SPX_HIP(e, hipGetLastError());
+    SPX_HIP(e, hipMemcpyAsync(out, e->d_raw_row.p, bytes, hipMemcpyDeviceToHost, e->stream));
     SPX_HIP(e, hipStreamSynchronize(e->stream));
     return SPX_OK;
   }

@@ -66,4 +66,40 @@ void launch_trimaran(const TrimaranArgs& a, hipStream_t s);
 // raw int64 Score() of one pod row for `plugin` (SPX_PLUGIN_TLP / SPX_PLUGIN_LVRB)
 void launch_trimaran_raw(const TrimaranArgs& a, int plugin, int64_t pod_row, int64_t* out, hipStream_t s);
 
+// ---------------------------------------------------------------- NodeResourceTopologyMatch
+struct NrtArgs {
+  int64_t n_nodes;
+  int64_t n_pods;
+  int64_t row_stride;
+  int64_t row_begin;
+  int64_t row_end;
+  int32_t n_res;
+  int32_t strategy;
+  uint8_t slot_flags[SPX_NRT_MAX_RES];
+  int64_t slot_weight[SPX_NRT_MAX_RES];
+  // node columns, zone/resource-major so that lane = node loads coalesce
+  const uint8_t* flags;          // [N]
+  const int32_t* max_numa;       // [N]
+  const uint8_t* n_zones;        // [N]
+  const uint8_t* zone_id;        // [Z][N]
+  const uint8_t* zone_present;   // [Z][N]
+  const int64_t* zone_avail;     // [Z][n_res][N]
+  const int32_t* zone_cost;      // [Z][Z][N]
+  const float* min_avg;          // [Z][N]  (subset size k-1)
+  const uint8_t* node_present;   // [N]
+  // pod records (wave-uniform reads)
+  const uint8_t* qos;
+  const uint8_t* non_native;
+  const uint8_t* n_ctr;
+  const uint8_t* ctr_kind;       // [P][8]
+  const uint8_t* ctr_present;    // [P][8]
+  const int64_t* ctr_req;        // [P][8][n_res]
+  const uint8_t* pod_present;    // [P]
+  const int64_t* pod_req;        // [P][n_res]
+  uint8_t* out_status;           // [P][row_stride]
+  uint8_t* out_score;            // [P][row_stride]
+  int64_t* out_raw;              // when set: raw int64 scores of row_begin only, no table writes
+};
+void launch_nrt(const NrtArgs& a, hipStream_t s);
+
 }  // namespace spx

@@ -149,6 +149,49 @@ class Engine:
         self.upload_trimaran_nodes(self.flatten_trimaran_nodes(nodes, metrics, assigned))
         self.upload_trimaran_pods(self.flatten_trimaran_pods(pods))
 
+    # ------------------------------------------------------------------ NodeResourceTopologyMatch
+    def load_nrt_objects(self, nodes: Table, nrt: Table, rc: Optional[Table], pods: Table, params: Table) -> None:
+        """objects -> (host flatten: slots, node zone tables, pod request tables) -> HBM."""
+        L, H = self._lib, self._hdr
+        u8p, i32p, i64p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float)
+        self._ck(L.spx_set_nrt_params(self._h, params.ref()))
+        n_res = C.c_int32()
+        slot_res = np.zeros(8, np.int32)
+        slot_flags = np.zeros(8, np.uint8)
+        slot_weight = np.zeros(8, np.int64)
+        self._ck(L.spx_flatten_nrt_slots(pods.ref(), nrt.ref(), rc.ref() if rc else None, params.ref(), C.byref(n_res),
+                                         slot_res.ctypes.data_as(i32p), slot_flags.ctypes.data_as(u8p),
+                                         slot_weight.ctypes.data_as(i64p)))
+        R = n_res.value
+        slots = Table(H, "spx_nrt_slots", n_res=R, slot_res=slot_res, slot_flags=slot_flags, slot_weight=slot_weight)
+        self._ck(L.spx_upload_nrt_slots(self._h, slots.ref()))
+        N, P = nodes.struct.n_nodes, pods.struct.n_pods
+        nc = dict(flags=np.zeros(N, np.uint8), max_numa=np.zeros(N, np.int32), n_zones=np.zeros(N, np.uint8),
+                  zone_id=np.zeros(N * 8, np.uint8), zone_present=np.zeros(N * 8, np.uint8),
+                  zone_avail=np.zeros(N * 8 * max(R, 1), np.int64), zone_cost=np.zeros(N * 64, np.int32),
+                  min_avg_dist=np.zeros(N * 8, np.float32), node_present=np.zeros(N, np.uint8))
+        fn = L.spx_flatten_nrt_nodes
+        self._ck(fn(nodes.ref(), nrt.ref(), slots.ref(), *[v.ctypes.data_as(t) for v, t in zip(nc.values(), fn.argtypes[3:])]))
+        self._ck(L.spx_upload_nrt_nodes(self._h, Table(H, "spx_nrt_nodes_soa", n_nodes=N, n_res=R, **nc).ref()))
+        pc = dict(qos=np.zeros(P, np.uint8), non_native=np.zeros(P, np.uint8), n_ctr=np.zeros(P, np.uint8),
+                  ctr_kind=np.zeros(P * 8, np.uint8), ctr_present=np.zeros(P * 8, np.uint8),
+                  ctr_req=np.zeros(P * 8 * max(R, 1), np.int64), pod_present=np.zeros(P, np.uint8),
+                  pod_req=np.zeros(P * max(R, 1), np.int64))
+        fn = L.spx_flatten_nrt_pods
+        self._ck(fn(pods.ref(), rc.ref() if rc else None, slots.ref(), *[v.ctypes.data_as(t) for v, t in zip(pc.values(), fn.argtypes[3:])]))
+        self._ck(L.spx_upload_nrt_pods(self._h, Table(H, "spx_nrt_pods_soa", n_pods=P, n_res=R, **pc).ref()))
+        self.n_nodes, self.n_pods = N, P
+        self.nrt_soa = {"slots": slots, "nodes": nc, "pods": pc}
+
+    def status(self, plugin: int, pod_row: int) -> np.ndarray:
+        out = np.empty(self.n_nodes, dtype=np.uint8)
+        self._ck(self._lib.spx_fetch_status(self._h, plugin, pod_row, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def all_status(self, plugin: int, row_begin: int = 0, row_end: Optional[int] = None) -> np.ndarray:
+        row_end = self.n_pods if row_end is None else row_end
+        return np.stack([self.status(plugin, r) for r in range(row_begin, row_end)])
+
     # ------------------------------------------------------------------ eval / fetch
     def eval(self, plugin_mask: int, row_begin: int = 0, row_end: Optional[int] = None) -> None:
         self._ck(self._lib.spx_eval(self._h, plugin_mask, row_begin, self.n_pods if row_end is None else row_end))

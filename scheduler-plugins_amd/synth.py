@@ -27,7 +27,7 @@ def _csr_from_mask(mask: np.ndarray):
 
 
 def synth_pods(hdr: Header, n_pods: int, seed: int = SEED, device_res: int = -1, n_appgroups: int = 0,
-               n_namespaces: int = 100) -> Table:
+               n_namespaces: int = 100, hugepage_res: int = -1) -> Table:
     rng = np.random.default_rng(seed + 1)
     n_app = rng.integers(1, 4, n_pods)
     has_init = rng.random(n_pods) < 0.2
@@ -50,17 +50,20 @@ def synth_pods(hdr: Header, n_pods: int, seed: int = SEED, device_res: int = -1,
     dev = (rng.random(n_pods) < 0.1)[pod_of] & (device_res >= 0) & (kind == 0) & (pos == has_init[pod_of])
     dev_n = rng.integers(1, 3, total)
 
-    # requests: slots (cpu, memory, device)
+    # requests: slots (cpu, memory, device, hugepages)
+    rng_hp = np.random.default_rng(seed + 101)  # separate stream: keeps the other columns identical with/without hugepages
+    hp = (rng_hp.random(total) < 0.15) & (hugepage_res >= 0) & (q != 2)
+    hp_q = rng_hp.integers(0, 65, total).astype(np.int64) * (2 << 20)  # includes explicit zero-quantity requests
     bur_cpu = rng.random(total) < 0.8  # burstable containers may omit one of the two
     bur_mem = rng.random(total) < 0.8
-    req_mask = np.stack([(q == 0) | ((q == 1) & bur_cpu), (q == 0) | ((q == 1) & bur_mem), dev], axis=1)
-    req_res = np.tile(np.array([0, 1, max(device_res, 0)], dtype=np.int32), (total, 1))
-    req_qty = np.stack([cpu, mem, dev_n], axis=1)
+    req_mask = np.stack([(q == 0) | ((q == 1) & bur_cpu), (q == 0) | ((q == 1) & bur_mem), dev, hp], axis=1)
+    req_res = np.tile(np.array([0, 1, max(device_res, 0), max(hugepage_res, 0)], dtype=np.int32), (total, 1))
+    req_qty = np.stack([cpu, mem, dev_n, hp_q], axis=1)
     req_ptr, sel = _csr_from_mask(req_mask)
-    # limits: Guaranteed == requests; Burstable sometimes a larger cpu limit; devices always limit == request
+    # limits: Guaranteed == requests; Burstable sometimes a larger cpu limit; devices/hugepages always limit == request
     bur_lim = (q == 1) & bur_cpu & (rng.random(total) < 0.5)
-    lim_mask = np.stack([(q == 0) | bur_lim, (q == 0), dev], axis=1)
-    lim_qty = np.stack([np.where(q == 0, cpu, cpu * 2), mem, dev_n], axis=1)
+    lim_mask = np.stack([(q == 0) | bur_lim, (q == 0), dev, hp], axis=1)
+    lim_qty = np.stack([np.where(q == 0, cpu, cpu * 2), mem, dev_n, hp_q], axis=1)
     lim_ptr, lsel = _csr_from_mask(lim_mask)
 
     ovh = rng.random(n_pods) < 0.05
@@ -164,4 +167,119 @@ def trimaran_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, 
         "metrics": synth_metrics(hdr, n_nodes, seed, round_frac=round_frac),
         "assigned": synth_assigned(hdr, n_nodes, seed),
         "rc": resource_classes(hdr),
+    }
+
+
+# ------------------------------------------------------------------ NodeResourceTopology (config #3)
+RES_HUGEPAGES_2MI = 8   # "hugepages-2Mi"
+RES_DEVICE = 9          # "example.com/gpu" style extended resource
+
+
+def nrt_resource_classes(hdr: Header) -> Table:
+    flags = np.zeros(10, dtype=np.uint8)
+    flags[[0, 1, 2, 3, 4]] = 2              # native
+    flags[RES_HUGEPAGES_2MI] = 1 | 2 | 4    # hugepage, native, scalar
+    flags[RES_DEVICE] = 4                   # extended: not native, scalar
+    return Table(hdr, "spx_resource_classes", n_res=len(flags), flags=flags)
+
+
+def synth_nrt(hdr: Header, nodes: Table, seed: int = SEED, n_zones: int = 8, vary: bool = True):
+    """NRT objects for the given nodes: Z NUMA zones per node with ids == list positions,
+    per-zone available = alloc/Z x U[0.1,1] for {cpu, memory, hugepages-2Mi, device}; distances 10 on the
+    diagonal and {12,20,32} off it; single-numa-node policy, container scope 70% / pod scope 30%,
+    1% of nodes without NRT, 1% stale.  `vary` adds the ragged cases the reference tests cover: fewer zones,
+    zones that do not report the device, missing cost entries, non-single-numa policies, assumed pods."""
+    rng = np.random.default_rng(seed + 5)
+    N = nodes.struct.n_nodes
+    cpu = nodes.array("alloc_cpu_milli")
+    mem = nodes.array("alloc_mem")
+    has = rng.random(N) >= 0.01
+    fresh = rng.random(N) >= 0.01
+    nz = np.full(N, n_zones)
+    if vary:
+        nz = np.where(rng.random(N) < 0.15, rng.choice(np.array([1, 2, 4]), N), nz)
+    nz = np.where(has, nz, 0)
+    zone_ptr = np.zeros(N + 1, dtype=np.int32)
+    np.cumsum(nz, out=zone_ptr[1:])
+    nzt = int(zone_ptr[-1])
+    node_of = np.repeat(np.arange(N), nz)
+    zpos = np.arange(nzt) - zone_ptr[node_of]
+    frac = rng.uniform(0.1, 1.0, (nzt, 4))
+    z_cpu = (cpu[node_of] / nz[node_of] * frac[:, 0]).astype(np.int64)
+    whole = rng.random(nzt) < 0.5
+    z_cpu = np.where(whole, (z_cpu // 1000) * 1000, z_cpu)
+    z_mem = (mem[node_of] / nz[node_of] * frac[:, 1]).astype(np.int64)
+    z_hp = (rng.integers(0, 513, nzt) * (2 << 20)).astype(np.int64)
+    z_dev = rng.integers(0, 5, nzt).astype(np.int64)
+    node_has_dev = rng.random(N) < 0.6
+    rep_dev = node_has_dev[node_of] & ((rng.random(nzt) < 0.85) if vary else True)
+    rep_hp = (rng.random(N) < 0.8)[node_of]
+    mask = np.stack([np.ones(nzt, bool), np.ones(nzt, bool), rep_hp, rep_dev], axis=1)
+    res = np.tile(np.array([0, 1, RES_HUGEPAGES_2MI, RES_DEVICE], dtype=np.int32), (nzt, 1))
+    qty = np.stack([z_cpu, z_mem, z_hp, z_dev], axis=1)
+    zres_ptr, sel = _csr_from_mask(mask)
+    # costs: full matrix per node, 5% of entries dropped when vary
+    cnt = nz[node_of]
+    cost_ptr = np.zeros(nzt + 1, dtype=np.int32)
+    cmask = np.arange(8)[None, :] < cnt[:, None]
+    if vary:
+        cmask &= rng.random((nzt, 8)) >= 0.05
+    tgt = np.tile(np.arange(8, dtype=np.int32), (nzt, 1))
+    off = rng.choice(np.array([12, 20, 32]), (N, 8, 8))
+    off = np.minimum(off, off.transpose(0, 2, 1))
+    cval = np.where(tgt == zpos[:, None], 10, off[node_of[:, None], np.minimum(zpos, 7)[:, None], tgt])
+    np.cumsum(cmask.sum(axis=1), out=cost_ptr[1:])
+    csel = cmask.reshape(-1)
+    # policies
+    pod_scope = rng.random(N) < 0.3
+    legacy = np.where(pod_scope, (3 << 1) | 1, (3 << 1) | 0).astype(np.int8)
+    attr_scope = np.full(N, -1, dtype=np.int8)
+    attr_policy = np.full(N, -1, dtype=np.int8)
+    attr_max = np.full(N, -1, dtype=np.int32)
+    if vary:
+        other = rng.random(N) < 0.06
+        legacy = np.where(other, rng.choice(np.array([-1, (1 << 1) | 0, (2 << 1) | 1], dtype=np.int8), N), legacy).astype(np.int8)
+        via_attr = rng.random(N) < 0.1   # attributes override the legacy field
+        attr_policy = np.where(via_attr, 3, attr_policy).astype(np.int8)
+        attr_scope = np.where(via_attr, rng.integers(0, 2, N), attr_scope).astype(np.int8)
+        attr_max = np.where(rng.random(N) < 0.1, rng.choice(np.array([4, 8, 16]), N), attr_max).astype(np.int32)
+    # assumed pods (OverReserve): 5% of nodes carry 1-2 assumed pods
+    acnt = np.where((rng.random(N) < 0.05) & has & vary, rng.integers(1, 3, N), 0)
+    assumed_ptr = np.zeros(N + 1, dtype=np.int32)
+    np.cumsum(acnt, out=assumed_ptr[1:])
+    na = int(assumed_ptr[-1])
+    arl_ptr = np.arange(na + 1, dtype=np.int32) * 2
+    arl_res = np.tile(np.array([0, 1], dtype=np.int32), na)
+    arl_qty = np.stack([rng.integers(500, 4000, na), rng.integers(1, 16, na) * GiB], axis=1).reshape(-1)
+    return Table(
+        hdr, "spx_nrt_objects", n_nodes=N, has_nrt=has.astype(np.uint8), fresh=fresh.astype(np.uint8),
+        legacy_policy=legacy, attr_scope=attr_scope, attr_policy=attr_policy, attr_max_numa=attr_max,
+        zone_ptr=zone_ptr, zone_is_node=np.ones(nzt, dtype=np.uint8), zone_numa_id=zpos.astype(np.int32),
+        zres_ptr=zres_ptr, zres_res=res.reshape(-1)[sel], zres_avail=qty.reshape(-1)[sel],
+        zcost_ptr=cost_ptr, zcost_numa_id=tgt.reshape(-1)[csel], zcost_value=cval.reshape(-1)[csel].astype(np.int64),
+        assumed_ptr=assumed_ptr, arl_ptr=arl_ptr, arl_res=arl_res, arl_qty=arl_qty.astype(np.int64),
+    )
+
+
+def nrt_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, vary: bool = True) -> Dict[str, Table]:
+    """Object tables for BASELINE.json config #3 (NRT Filter+Score, 8 NUMA zones)."""
+    nodes = synth_nodes(hdr, n_nodes, seed, device_res=RES_DEVICE)
+    # node-level allocatable must list hugepages too (util.ResourceList key check, filter.go:110-116)
+    rng = np.random.default_rng(seed + 6)
+    N = n_nodes
+    has_hp = rng.random(N) < 0.9
+    has_dev = rng.random(N) < 0.7
+    mask = np.stack([has_hp, has_dev], axis=1)
+    ptr, sel = _csr_from_mask(mask)
+    res = np.tile(np.array([RES_HUGEPAGES_2MI, RES_DEVICE], dtype=np.int32), (N, 1))
+    qty = np.stack([np.full(N, 1 << 30, dtype=np.int64), rng.integers(1, 17, N)], axis=1)
+    nodes = Table(hdr, "spx_node_objects", n_nodes=N, alloc_cpu_milli=nodes.array("alloc_cpu_milli"),
+                  alloc_mem=nodes.array("alloc_mem"), alloc_eph=nodes.array("alloc_eph"), alloc_pods=nodes.array("alloc_pods"),
+                  scalar_ptr=ptr, scalar_res=res.reshape(-1)[sel], scalar_qty=qty.reshape(-1)[sel],
+                  cap_cpu_milli=nodes.array("cap_cpu_milli"), region=nodes.array("region"), zone=nodes.array("zone"))
+    return {
+        "nodes": nodes,
+        "pods": synth_pods(hdr, n_pods, seed, device_res=RES_DEVICE, hugepage_res=RES_HUGEPAGES_2MI),
+        "nrt": synth_nrt(hdr, nodes, seed, vary=vary),
+        "rc": nrt_resource_classes(hdr),
     }
