@@ -38,6 +38,8 @@ WORKLOADS = {
                     desc="noderesourcetopology Filter+Score (LeastAllocated), 5k nodes x 8 NUMA zones x 50k pods"),
     "config3_leastnuma": dict(n_nodes=5_000, n_pods=50_000, plugins=("nrt",), node_row=324, pod_row=100, out=2, strategy="LeastNUMANodes",
                               desc="noderesourcetopology Filter+Score (LeastNUMANodes), 5k nodes x 8 NUMA zones x 50k pods"),
+    "config4": dict(n_nodes=10_000, n_pods=200_000, plugins=("net",), node_row=4, pod_row=48, out=2,
+                    desc="networkaware NetworkOverhead (+TopologicalSort keys), 10k nodes x 3-tier topology x 200k pods"),
     "small": dict(n_nodes=1_000, n_pods=4_000, plugins=("alloc", "tlp"), node_row=41, pod_row=8, out=2,
                   desc="plumbing-sized Allocatable + TLP"),
 }
@@ -51,7 +53,8 @@ def cpu_baseline(spx, snap, e, plugins, budget_s: float):
 
     osnap = pyoracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], metrics=snap.get("metrics"), assigned=snap.get("assigned"),
                               alloc_params=e.alloc_params, tlp_params=e.tlp_params, lvrb_params=e.lvrb_params,
-                              nrt=snap.get("nrt"), nrt_params=snap.get("nrt_params"))
+                              nrt=snap.get("nrt"), nrt_params=snap.get("nrt_params"), appgroups=snap.get("appgroups"),
+                              nettopo=snap.get("nettopo"))
     cores = os.cpu_count() or 1
     n_nodes = osnap.n_nodes
 
@@ -59,7 +62,7 @@ def cpu_baseline(spx, snap, e, plugins, budget_s: float):
         t0 = time.perf_counter()
         for p in plugins:
             osnap.score_rows(p, 0, rows, threads=cores, want_raw=False, want_norm=True)
-            if p == 3:  # NodeResourceTopologyMatch also has a Filter extension point
+            if p in (3, 4):  # NodeResourceTopologyMatch / NetworkOverhead also have a Filter extension point
                 osnap.filter_rows(p, 0, rows, threads=cores)
         return time.perf_counter() - t0
 
@@ -121,7 +124,7 @@ def main() -> None:
     if args.plugins:
         w["plugins"] = tuple(args.plugins.split(","))
         w["out"] = len(w["plugins"])
-    pid = {"alloc": ALLOCATABLE, "tlp": TLP, "lvrb": LVRB, "nrt": NRT}
+    pid = {"alloc": ALLOCATABLE, "tlp": TLP, "lvrb": LVRB, "nrt": NRT, "net": 4}
     plugins = [pid[p] for p in w["plugins"]]
     mask = mask_of(*plugins)
     n_nodes, n_pods = w["n_nodes"], w["n_pods"]
@@ -136,6 +139,9 @@ def main() -> None:
                                             hugepage_res=synth.RES_HUGEPAGES_2MI)
         snap["nrt_params"] = O.nrt_params(hdr, O.Resources(), w["strategy"])
         e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], snap["nrt_params"])
+    elif "net" in w["plugins"]:
+        snap = synth.network_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED + 1000 * rank)
+        e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
     else:
         snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED, round_frac=args.round_frac)
         if rank:
@@ -194,7 +200,8 @@ def main() -> None:
                    "result_tables": "uint8 [pods][nodes] per plugin, resident in HBM"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "spx::k_tlp_fast2 (Allocatable+TLP) / spx::k_trimaran (with LVRB)", "kernel_ms": kern_ms,
+                     "kernel": {"nrt": "spx::k_nrt", "net": "spx::k_net"}.get(w["plugins"][0], "spx::k_tlp_fast2 (Allocatable+TLP) / spx::k_trimaran (with LVRB)"),
+                     "kernel_ms": kern_ms,
                      "algorithmic_bytes": algo_bytes, "frac_of_measured_copy_ceiling_6.29TBs": achieved / 6290.0},
         "kernel_evals_per_sec": n_nodes * n_pods / (kern_ms * 1e-3),
     }

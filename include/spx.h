@@ -197,6 +197,42 @@ typedef struct spx_nrt_objects {
   const int64_t* arl_qty;
 } spx_nrt_objects;
 
+/* diktyo AppGroup CRs (appgroup.diktyo.x-k8s.io v1alpha1) as the network-aware plugins read them.
+ * Group g: Spec.Workloads = wl_ptr[g]..wl_ptr[g+1]-1 with their Dependencies (dep_*), Status.TopologyOrder
+ * (topo_*), and the scheduled list util.GetScheduledList builds from the pod lister (placed_*: pods labelled
+ * with the group that already have a node name; placed_node = index of that node in the snapshot).
+ * Selector ids MUST preserve the lexicographic order of the selector strings: util.FindPodOrder
+ * (pkg/networkaware/util/util.go:138-153) binary-searches TopologyOrder with string comparisons. */
+typedef struct spx_appgroup_objects {
+  int32_t n_groups;
+  const int32_t* wl_ptr;
+  const int32_t* wl_selector;
+  const int32_t* dep_ptr;
+  const int32_t* dep_selector;
+  const int64_t* dep_max_cost;
+  const int32_t* topo_ptr;
+  const int32_t* topo_selector;
+  const int32_t* topo_index;
+  const int32_t* placed_ptr;
+  const int32_t* placed_selector;
+  const int32_t* placed_node;
+} spx_appgroup_objects;
+
+/* NetworkTopology CR (networktopology.diktyo.x-k8s.io v1alpha1), the weights set the plugin was configured
+ * with (no.weightsName), keyed by interned label values: region ids and zone ids are the same id spaces as
+ * spx_node_objects.region / .zone.  Origin o's CostList is the slice [ptr[o], ptr[o+1]) of the dest and cost arrays; later entries
+ * for the same destination override earlier ones (map assignment, networkoverhead.go:467-472). */
+typedef struct spx_nettopo_objects {
+  int32_t n_regions;
+  int32_t n_zones;
+  const int32_t* rc_ptr;
+  const int32_t* rc_dest;
+  const int64_t* rc_cost;
+  const int32_t* zc_ptr;
+  const int32_t* zc_dest;
+  const int64_t* zc_cost;
+} spx_nettopo_objects;
+
 /* ------------------------------------------------------------------ plugin params */
 
 typedef struct spx_allocatable_params {
@@ -324,6 +360,39 @@ typedef struct spx_nrt_pods_soa {
   const int64_t* pod_req;
 } spx_nrt_pods_soa;
 
+/* NetworkOverhead.  A pod's PreFilter state depends only on its (AppGroup, workload selector) "workload
+ * key"; the matched (placed pod, dependency) pairs are flattened once per key. */
+#define SPX_NET_ST_UNSCHEDULABLE 1 /* "Node %v does not meet several network requirements ..." networkoverhead.go:355-357 */
+#define SPX_NET_RAW_COST 0
+#define SPX_NET_RAW_SATISFIED 1
+#define SPX_NET_RAW_VIOLATED 2
+#define SPX_NET_SAME_ZONE 1   /* networkoverhead.go:60  */
+#define SPX_NET_MAX_COST 100  /* networkoverhead.go:63  */
+
+typedef struct spx_net_nodes_soa {
+  int64_t n_nodes;
+  const int32_t* region;
+  const int32_t* zone;
+} spx_net_nodes_soa;
+
+typedef struct spx_net_topo_soa {
+  int32_t n_regions;
+  int32_t n_zones;
+  const int32_t* region_cost;
+  const int32_t* zone_cost;
+} spx_net_topo_soa;
+
+typedef struct spx_net_pods_soa {
+  int64_t n_pods;
+  int32_t n_keys;
+  const int32_t* pod_key;
+  const uint8_t* key_score_equally;
+  const int32_t* pair_ptr;
+  const int32_t* pair_node;
+  const int64_t* pair_max_cost;
+  const int32_t* topo_order;
+} spx_net_pods_soa;
+
 /* ------------------------------------------------------------------ engine */
 
 typedef struct spx_engine spx_engine;
@@ -353,6 +422,9 @@ int spx_upload_trimaran_pods(spx_engine* e, const spx_trimaran_pods_soa* t);
 int spx_upload_nrt_slots(spx_engine* e, const spx_nrt_slots* t);
 int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t);
 int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t);
+int spx_upload_net_nodes(spx_engine* e, const spx_net_nodes_soa* t);
+int spx_upload_net_topo(spx_engine* e, const spx_net_topo_soa* t);
+int spx_upload_net_pods(spx_engine* e, const spx_net_pods_soa* t);
 
 /* optional per-(pod,node) feasibility mask for normalizing score plugins: uint8 [n_pods][n_nodes],
  * non-zero = node passed Filter for that pod (upstream scores feasible nodes only).  NULL clears it. */
@@ -401,6 +473,14 @@ int spx_flatten_nrt_slots(const spx_pod_objects* pods, const spx_nrt_objects* nr
 int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_nrt_slots* slots, uint8_t* flags, int32_t* max_numa, uint8_t* n_zones, uint8_t* zone_id, uint8_t* zone_present, int64_t* zone_avail, int32_t* zone_cost, float* min_avg_dist, uint8_t* node_present);
 /* pod arrays sized: qos[P], non_native[P], n_ctr[P], ctr_kind[P*8], ctr_present[P*8], ctr_req[P*8*n_res], pod_present[P], pod_req[P*n_res] */
 int spx_flatten_nrt_pods(const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_nrt_slots* slots, uint8_t* qos, uint8_t* non_native, uint8_t* n_ctr, uint8_t* ctr_kind, uint8_t* ctr_present, int64_t* ctr_req, uint8_t* pod_present, int64_t* pod_req);
+
+/* NetworkOverhead / TopologicalSort.  region_cost[n_regions*n_regions] and zone_cost[n_zones*n_zones]: -1 = no entry.
+ * spx_flatten_net_keys sizes: *n_keys_out and *n_pairs_out first (pass NULL arrays), then fill
+ * pod_key[P], topo_order[P], key_score_equally[n_keys], pair_ptr[n_keys+1], pair_node/pair_max_cost[n_pairs]. */
+int spx_flatten_net_topo(const spx_nettopo_objects* nt, int32_t* region_cost, int32_t* zone_cost);
+int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int32_t* n_keys_out, int64_t* n_pairs_out, int32_t* pod_key, int32_t* topo_order, uint8_t* key_score_equally, int32_t* pair_ptr, int32_t* pair_node, int64_t* pair_max_cost);
+/* TopologicalSort.Less (topologicalsort.go:102-132) for n pairs of pod indices, from the flattened keys */
+int spx_toposort_less(const spx_pod_objects* pods, const int32_t* topo_order, int64_t n_pairs, const int64_t* a, const int64_t* b, uint8_t* less_out);
 
 #ifdef __cplusplus
 }

@@ -47,11 +47,29 @@ static void* run(void* arg) {
     free(idx);
     return 0;
   }
+  int64_t* nsat = 0;
+  int64_t* nvio = 0;
+  int64_t* ncost = 0;
+  if (j->plugin == SPX_PLUGIN_NETOVERHEAD) {
+    nsat = (int64_t*)malloc(sizeof(int64_t) * 3 * (size_t)(n > 0 ? n : 1));
+    nvio = nsat + n;
+    ncost = nvio + n;
+  }
   for (int64_t pod = j->row_begin; pod < j->row_end; ++pod) {
     const uint8_t* m = j->mask ? j->mask + (size_t)pod * (size_t)n : 0;
     int64_t k = 0;
+    int equally = 0;
+    if (j->plugin == SPX_PLUGIN_NETOVERHEAD) /* PreFilter once per pod (networkoverhead.go:174) */
+      equally = orc_net_prefilter(j->s->nodes, j->s->pods, j->s->appgroups, j->s->nettopo, pod, nsat, nvio, ncost);
     for (int64_t node = 0; node < n; ++node) {
       if (m && !m[node]) continue; /* upstream only scores nodes that passed Filter */
+      if (j->plugin == SPX_PLUGIN_NETOVERHEAD) {
+        if (!equally && nvio[node] > nsat[node]) continue; /* the plugin's own Filter (networkoverhead.go:349-357) */
+        list[k] = equally ? 0 : ncost[node];               /* Score :362-386 */
+        idx[k] = node;
+        ++k;
+        continue;
+      }
       list[k] = score_one(j->s, j->plugin, pod, node);
       idx[k] = node;
       ++k;
@@ -64,6 +82,7 @@ static void* run(void* arg) {
     /* NormalizeScore: Allocatable rescales (allocatable.go:143); TLP and LVRB are no-ops
      * (targetloadpacking.go:193-195, loadvariationriskbalancing.go:134-136) */
     if (j->plugin == SPX_PLUGIN_ALLOCATABLE) orc_allocatable_normalize(list, k);
+    if (j->plugin == SPX_PLUGIN_NETOVERHEAD) orc_net_normalize(list, k);
     if (j->out_norm) {
       memset(j->out_norm + off, 0, sizeof(int64_t) * (size_t)n);
       for (int64_t i = 0; i < k; ++i) j->out_norm[off + (size_t)idx[i]] = list[i];
@@ -71,6 +90,7 @@ static void* run(void* arg) {
   }
   free(list);
   free(idx);
+  free(nsat);
   return 0;
 }
 
@@ -117,6 +137,20 @@ typedef struct fjob {
 static void* frun(void* arg) {
   fjob* j = (fjob*)arg;
   const int64_t n = j->s->nodes->n_nodes;
+  if (j->plugin == SPX_PLUGIN_NETOVERHEAD) {
+    int64_t* buf = (int64_t*)malloc(sizeof(int64_t) * 3 * (size_t)(n > 0 ? n : 1));
+    for (int64_t pod = j->row_begin; pod < j->row_end; ++pod) {
+      int eq = orc_net_prefilter(j->s->nodes, j->s->pods, j->s->appgroups, j->s->nettopo, pod, buf, buf + n, buf + 2 * n);
+      for (int64_t node = 0; node < n; ++node) {
+        uint8_t st = 0;
+        if (eq < 0) st = 255;
+        else if (!eq && buf[n + node] > buf[node]) st = SPX_NET_ST_UNSCHEDULABLE;
+        j->out[(size_t)(pod - j->base) * (size_t)n + (size_t)node] = st;
+      }
+    }
+    free(buf);
+    return 0;
+  }
   for (int64_t pod = j->row_begin; pod < j->row_end; ++pod)
     for (int64_t node = 0; node < n; ++node) {
       int st = 0;

@@ -57,10 +57,11 @@ class Snapshot:
     def __init__(self, nodes: Table, pods: Table, rc: Optional[Table] = None, metrics: Optional[Table] = None,
                  assigned: Optional[Table] = None, alloc_params: Optional[Table] = None,
                  tlp_params: Optional[Table] = None, lvrb_params: Optional[Table] = None,
-                 nrt: Optional[Table] = None, nrt_params: Optional[Table] = None):
+                 nrt: Optional[Table] = None, nrt_params: Optional[Table] = None,
+                 appgroups: Optional[Table] = None, nettopo: Optional[Table] = None):
         h = header()
         self.keep = dict(nodes=nodes, pods=pods, rc=rc, metrics=metrics, assigned=assigned, alloc_params=alloc_params,
-                         tlp_params=tlp_params, lvrb_params=lvrb_params, nrt=nrt, nrt_params=nrt_params)
+                         tlp_params=tlp_params, lvrb_params=lvrb_params, nrt=nrt, nrt_params=nrt_params, appgroups=appgroups, nettopo=nettopo)
         self.struct = h.structs["orc_snapshot"]()
         for k, v in self.keep.items():
             if v is not None:

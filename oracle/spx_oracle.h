@@ -64,6 +64,13 @@ int64_t orc_nrt_normalize_score(int numa_nodes_count, int is_min_avg_distance, i
 int orc_nrt_numa_nodes_required(const spx_nrt_objects* nrt, const spx_resource_classes* rc, const spx_pod_objects* pods,
                                 int64_t pod, int64_t node, int qos, uint64_t* bitmask, int* is_min_distance);
 
+/* ---- networkaware NetworkOverhead + TopologicalSort (pkg/networkaware/...) */
+int orc_net_prefilter(const spx_node_objects* nodes, const spx_pod_objects* pods, const spx_appgroup_objects* ag,
+                      const spx_nettopo_objects* nt, int64_t pod, int64_t* sat, int64_t* vio, int64_t* cost);
+void orc_net_normalize(int64_t* scores, int64_t n);
+int32_t orc_find_pod_order(const spx_appgroup_objects* ag, int32_t g, int32_t selector);
+int orc_toposort_less(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int64_t p1, int64_t p2);
+
 /* ---- batch drivers: for each pod row in [row_begin,row_end): for each node: Score(); then
  *      NormalizeScore() over that pod's node list (feasible nodes only when `mask` != NULL, as
  *      upstream RunScorePlugins does).  out_raw / out_norm are [rows][n_nodes] int64 (either may
@@ -80,6 +87,8 @@ typedef struct orc_snapshot {
   const spx_lvrb_params* lvrb_params;
   const spx_nrt_objects* nrt;
   const spx_nrt_params* nrt_params;
+  const spx_appgroup_objects* appgroups;
+  const spx_nettopo_objects* nettopo;
 } orc_snapshot;
 
 int orc_score_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t row_end,

@@ -5,6 +5,7 @@
 // is usable, and every compute entry point needs an engine.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -65,6 +66,12 @@ struct spx_engine {
   DevBuf d_nrt_flags, d_nrt_max_numa, d_nrt_nz, d_nrt_zid, d_nrt_zp, d_nrt_avail, d_nrt_cost, d_nrt_minavg, d_nrt_np;
   DevBuf d_nrt_qos, d_nrt_nn, d_nrt_nctr, d_nrt_ckind, d_nrt_cpres, d_nrt_creq, d_nrt_ppres, d_nrt_preq;
   DevBuf status[SPX_NUM_PLUGINS];
+
+  // NetworkOverhead / TopologicalSort
+  bool net_nodes = false, net_topo = false, net_pods = false;
+  int32_t net_n_regions = 0, net_n_zones = 0, net_n_classes = 0;
+  DevBuf d_net_region, d_net_zone, d_net_class, d_net_cls_region, d_net_cls_zone, d_net_rcost, d_net_zcost;
+  DevBuf d_net_pod_key, d_net_key_flag, d_net_pair_ptr, d_net_pair_node, d_net_pair_max;
 
   DevBuf score[SPX_NUM_PLUGINS];
   int64_t score_rows[SPX_NUM_PLUGINS] = {0};
@@ -216,6 +223,26 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   na.pod_req = static_cast<const int64_t*>(e->d_nrt_preq.p);
 }
 
+void fill_net(const spx_engine* e, spx::NetArgs& g) {
+  g.n_nodes = e->n_nodes;
+  g.row_stride = e->row_stride;
+  g.n_regions = e->net_n_regions;
+  g.n_zones = e->net_n_zones;
+  g.n_classes = e->net_n_classes;
+  g.region = static_cast<const int32_t*>(e->d_net_region.p);
+  g.zone = static_cast<const int32_t*>(e->d_net_zone.p);
+  g.node_class = static_cast<const int32_t*>(e->d_net_class.p);
+  g.cls_region = static_cast<const int32_t*>(e->d_net_cls_region.p);
+  g.cls_zone = static_cast<const int32_t*>(e->d_net_cls_zone.p);
+  g.region_cost = static_cast<const int32_t*>(e->d_net_rcost.p);
+  g.zone_cost = static_cast<const int32_t*>(e->d_net_zcost.p);
+  g.pod_key = static_cast<const int32_t*>(e->d_net_pod_key.p);
+  g.key_flag = static_cast<const uint8_t*>(e->d_net_key_flag.p);
+  g.pair_ptr = static_cast<const int32_t*>(e->d_net_pair_ptr.p);
+  g.pair_node = static_cast<const int32_t*>(e->d_net_pair_node.p);
+  g.pair_max = static_cast<const int64_t*>(e->d_net_pair_max.p);
+}
+
 // host [N][inner] -> device [inner][N] so that lane = node reads coalesce
 template <typename T>
 int upload_transposed(spx_engine* e, DevBuf& b, const T* src, int64_t n, int64_t inner) {
@@ -268,7 +295,10 @@ int spx_destroy(spx_engine* e) {
                     &e->d_lv_mavg, &e->d_lv_mstd,  &e->d_lv_flags,  &e->d_tlp_pod,    &e->d_lv_rcpu, &e->d_lv_rmem,
                     &e->d_raw_row,   &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
-                    &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq};
+                    &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
+                    &e->d_net_region, &e->d_net_zone, &e->d_net_class, &e->d_net_cls_region, &e->d_net_cls_zone,
+                    &e->d_net_rcost, &e->d_net_zcost, &e->d_net_pod_key, &e->d_net_key_flag, &e->d_net_pair_ptr,
+                    &e->d_net_pair_node, &e->d_net_pair_max};
   for (DevBuf* b : bufs)
     if (b->p && !b->external) (void)hipFree(b->p);
   for (int i = 0; i < SPX_NUM_PLUGINS; ++i) {
@@ -447,6 +477,80 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
   return SPX_OK;
 }
 
+int spx_upload_net_nodes(spx_engine* e, const spx_net_nodes_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  int rc = set_nodes(e, t->n_nodes);
+  if (rc) return rc;
+  if (!t->region || !t->zone) return fail(e, SPX_ERR_ARG, "NULL column in table");
+  const int64_t n = t->n_nodes;
+  // topology classes: nodes with identical (region, zone) labels are interchangeable for every pair that is
+  // not hosted on them
+  std::vector<int32_t> cls(static_cast<size_t>(n)), cr, cz;
+  {
+    std::vector<std::pair<int64_t, int32_t>> seen;  // sorted (packed label pair -> class)
+    std::vector<int64_t> keys(static_cast<size_t>(n));
+    for (int64_t i = 0; i < n; ++i) keys[i] = (static_cast<int64_t>(t->region[i]) << 32) ^ static_cast<uint32_t>(t->zone[i]);
+    std::vector<int64_t> uniq(keys);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    for (int64_t i = 0; i < n; ++i)
+      cls[i] = static_cast<int32_t>(std::lower_bound(uniq.begin(), uniq.end(), keys[i]) - uniq.begin());
+    cr.resize(uniq.size());
+    cz.resize(uniq.size());
+    for (int64_t i = 0; i < n; ++i) {
+      cr[cls[i]] = t->region[i];
+      cz[cls[i]] = t->zone[i];
+    }
+  }
+  int32_t n_classes = static_cast<int32_t>(cr.size());
+  if (spx::net_lds_bytes(n_classes, n) > 60 * 1024) n_classes = 0;  // too many label pairs for LDS: exact path only
+  e->net_n_classes = n_classes;
+  if ((rc = upload(e, e->d_net_region, t->region, static_cast<size_t>(n) * 4))) return rc;
+  if ((rc = upload(e, e->d_net_zone, t->zone, static_cast<size_t>(n) * 4))) return rc;
+  if ((rc = upload(e, e->d_net_class, cls.data(), static_cast<size_t>(n) * 4))) return rc;
+  if ((rc = upload(e, e->d_net_cls_region, cr.data(), cr.size() * 4))) return rc;
+  if ((rc = upload(e, e->d_net_cls_zone, cz.data(), cz.size() * 4))) return rc;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  e->net_nodes = true;
+  return SPX_OK;
+}
+
+int spx_upload_net_topo(spx_engine* e, const spx_net_topo_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  if (t->n_regions < 0 || t->n_zones < 0) return fail(e, SPX_ERR_ARG, "negative topology size");
+  int rc;
+  if ((rc = upload(e, e->d_net_rcost, t->region_cost ? static_cast<const void*>(t->region_cost) : static_cast<const void*>(&rc),
+                   static_cast<size_t>(t->n_regions) * t->n_regions * 4)))
+    return rc;
+  if ((rc = upload(e, e->d_net_zcost, t->zone_cost ? static_cast<const void*>(t->zone_cost) : static_cast<const void*>(&rc),
+                   static_cast<size_t>(t->n_zones) * t->n_zones * 4)))
+    return rc;
+  e->net_n_regions = t->n_regions;
+  e->net_n_zones = t->n_zones;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  e->net_topo = true;
+  return SPX_OK;
+}
+
+int spx_upload_net_pods(spx_engine* e, const spx_net_pods_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  int rc = set_pods(e, t->n_pods);
+  if (rc) return rc;
+  if (t->n_keys <= 0 || !t->pair_ptr) return fail(e, SPX_ERR_ARG, "net pods: key table missing");
+  const size_t pairs = static_cast<size_t>(t->pair_ptr[t->n_keys]);
+  if ((rc = upload(e, e->d_net_pod_key, t->pod_key, static_cast<size_t>(t->n_pods) * 4))) return rc;
+  if ((rc = upload(e, e->d_net_key_flag, t->key_score_equally, static_cast<size_t>(t->n_keys)))) return rc;
+  if ((rc = upload(e, e->d_net_pair_ptr, t->pair_ptr, static_cast<size_t>(t->n_keys + 1) * 4))) return rc;
+  if ((rc = upload(e, e->d_net_pair_node, pairs ? static_cast<const void*>(t->pair_node) : static_cast<const void*>(&rc), pairs * 4))) return rc;
+  if ((rc = upload(e, e->d_net_pair_max, pairs ? static_cast<const void*>(t->pair_max_cost) : static_cast<const void*>(&rc), pairs * 8))) return rc;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  e->net_pods = true;
+  return SPX_OK;
+}
+
 int spx_upload_feasible_mask(spx_engine* e, const uint8_t* mask, int64_t n_pods, int64_t n_nodes) {
   if (!e) return SPX_ERR_ARG;
   (void)mask;
@@ -458,7 +562,8 @@ int spx_upload_feasible_mask(spx_engine* e, const uint8_t* mask, int64_t n_pods,
 int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end) {
   if (!e) return SPX_ERR_ARG;
   SPX_HIP(e, hipSetDevice(e->device));
-  const uint32_t known = (1u << SPX_PLUGIN_ALLOCATABLE) | (1u << SPX_PLUGIN_TLP) | (1u << SPX_PLUGIN_LVRB) | (1u << SPX_PLUGIN_NRT);
+  const uint32_t known = (1u << SPX_PLUGIN_ALLOCATABLE) | (1u << SPX_PLUGIN_TLP) | (1u << SPX_PLUGIN_LVRB) | (1u << SPX_PLUGIN_NRT) |
+                         (1u << SPX_PLUGIN_NETOVERHEAD);
   if (plugin_mask == 0 || (plugin_mask & ~known)) return fail(e, SPX_ERR_ARG, "plugin mask has unsupported bits");
   if (e->n_nodes <= 0) return fail(e, SPX_ERR_STATE, "no node table uploaded");
   const bool A = plugin_mask & (1u << SPX_PLUGIN_ALLOCATABLE);
@@ -474,9 +579,12 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   const bool N = plugin_mask & (1u << SPX_PLUGIN_NRT);
   if (N && !(e->nrt_slots && e->nrt_nodes && e->nrt_pods)) return fail(e, SPX_ERR_STATE, "NRT slot/node/pod tables not uploaded");
   if (A && (rc = prepare_alloc(e))) return rc;
-  for (int p = 0; p < 4; ++p)
+  const bool W = plugin_mask & (1u << SPX_PLUGIN_NETOVERHEAD);
+  if (W && !(e->net_nodes && e->net_topo && e->net_pods)) return fail(e, SPX_ERR_STATE, "NetworkOverhead node/topology/pod tables not uploaded");
+  for (int p = 0; p < 5; ++p)
     if ((plugin_mask & (1u << p)) && (rc = ensure_score_table(e, p))) return rc;
   if (N && (rc = ensure(e, e->status[SPX_PLUGIN_NRT], static_cast<size_t>(e->n_pods) * static_cast<size_t>(e->row_stride)))) return rc;
+  if (W && (rc = ensure(e, e->status[SPX_PLUGIN_NETOVERHEAD], static_cast<size_t>(e->n_pods) * static_cast<size_t>(e->row_stride)))) return rc;
 
   spx::TrimaranArgs a{};
   fill_trimaran(e, a);
@@ -502,6 +610,20 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     na.out_status = static_cast<uint8_t*>(e->status[SPX_PLUGIN_NRT].p);
     na.out_score = static_cast<uint8_t*>(e->score[SPX_PLUGIN_NRT].p);
     spx::launch_nrt(na, e->stream);
+    SPX_HIP(e, hipGetLastError());
+  }
+  if (W) {
+    if (e->score_stride[SPX_PLUGIN_NETOVERHEAD] != e->row_stride)
+      return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
+    spx::NetArgs g{};
+    fill_net(e, g);
+    g.row_begin = row_begin;
+    g.row_end = row_end;
+    // upstream scores only nodes that passed every Filter plugin: with NRT in the same eval its status table is the mask
+    g.feasible = nullptr;
+    g.out_status = static_cast<uint8_t*>(e->status[SPX_PLUGIN_NETOVERHEAD].p);
+    g.out_score = static_cast<uint8_t*>(e->score[SPX_PLUGIN_NETOVERHEAD].p);
+    spx::launch_net(g, e->stream);
     SPX_HIP(e, hipGetLastError());
   }
   SPX_HIP(e, hipEventRecord(e->ev1, e->stream));
@@ -549,7 +671,6 @@ int spx_fetch_status(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out) {
 
 int spx_fetch_raw(spx_engine* e, int plugin, int which, int64_t pod_row, int64_t* out) {
   if (!e || !out) return SPX_ERR_ARG;
-  (void)which;
   SPX_HIP(e, hipSetDevice(e->device));
   if (e->n_nodes <= 0) return fail(e, SPX_ERR_STATE, "no node table uploaded");
   int rc;
@@ -570,6 +691,23 @@ int spx_fetch_raw(spx_engine* e, int plugin, int which, int64_t pod_row, int64_t
     na.row_end = pod_row + 1;
     na.out_raw = static_cast<int64_t*>(e->d_raw_row.p);
     spx::launch_nrt(na, e->stream);
+    SPX_HIP(e, hipGetLastError());
+    SPX_HIP(e, hipMemcpyAsync(out, e->d_raw_row.p, bytes, hipMemcpyDeviceToHost, e->stream));
+    SPX_HIP(e, hipStreamSynchronize(e->stream));
+    return SPX_OK;
+  }
+  if (plugin == SPX_PLUGIN_NETOVERHEAD) {  // raw accumulated cost / satisfied / violated (PreFilterState maps)
+    if (!(e->net_nodes && e->net_topo && e->net_pods)) return fail(e, SPX_ERR_STATE, "NetworkOverhead tables not uploaded");
+    if (pod_row < 0 || pod_row >= e->n_pods) return fail(e, SPX_ERR_ARG, "pod_row out of range");
+    if (which < SPX_NET_RAW_COST || which > SPX_NET_RAW_VIOLATED) return fail(e, SPX_ERR_ARG, "which: 0 cost, 1 satisfied, 2 violated");
+    if ((rc = ensure(e, e->d_raw_row, bytes))) return rc;
+    spx::NetArgs g{};
+    fill_net(e, g);
+    g.row_begin = pod_row;
+    g.row_end = pod_row + 1;
+    g.out_raw = static_cast<int64_t*>(e->d_raw_row.p);
+    g.raw_which = which;
+    spx::launch_net(g, e->stream);
     SPX_HIP(e, hipGetLastError());
     SPX_HIP(e, hipMemcpyAsync(out, e->d_raw_row.p, bytes, hipMemcpyDeviceToHost, e->stream));
     SPX_HIP(e, hipStreamSynchronize(e->stream));

@@ -102,4 +102,35 @@ struct NrtArgs {
 };
 void launch_nrt(const NrtArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- NetworkOverhead
+struct NetArgs {
+  int64_t n_nodes;
+  int64_t row_stride;
+  int64_t row_begin;
+  int64_t row_end;
+  int32_t n_regions;
+  int32_t n_zones;
+  int32_t n_classes;            // 0 = no class table: every node takes the exact per-pair path
+  const int32_t* region;        // [N] interned topology.kubernetes.io/region label, -1 = unset
+  const int32_t* zone;          // [N]
+  const int32_t* node_class;    // [N] index into cls_*
+  const int32_t* cls_region;    // [n_classes]
+  const int32_t* cls_zone;      // [n_classes]
+  const int32_t* region_cost;   // [n_regions^2], -1 = no entry
+  const int32_t* zone_cost;     // [n_zones^2]
+  const int32_t* pod_key;       // [P]
+  const uint8_t* key_flag;      // [K] 0 evaluate, 1 scoreEqually, 2 PreFilter error
+  const int32_t* pair_ptr;      // [K+1]
+  const int32_t* pair_node;
+  const int64_t* pair_max;
+  const uint8_t* feasible;      // optional [P][feasible_stride] mask from the other Filter plugins
+  int64_t feasible_stride;
+  uint8_t* out_status;
+  uint8_t* out_score;
+  int64_t* out_raw;             // when set: raw row (row_begin only), no table writes
+  int32_t raw_which;
+};
+void launch_net(const NetArgs& g, hipStream_t s);
+size_t net_lds_bytes(int n_classes, int64_t n_nodes);
+
 }  // namespace spx

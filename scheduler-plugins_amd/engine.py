@@ -183,6 +183,47 @@ class Engine:
         self.n_nodes, self.n_pods = N, P
         self.nrt_soa = {"slots": slots, "nodes": nc, "pods": pc}
 
+    # ------------------------------------------------------------------ NetworkOverhead / TopologicalSort
+    def load_network_objects(self, nodes: Table, pods: Table, appgroups: Table, nettopo: Table) -> None:
+        L, H = self._lib, self._hdr
+        i32p, i64p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)
+        N, P = nodes.struct.n_nodes, pods.struct.n_pods
+        self._ck(L.spx_upload_net_nodes(self._h, Table(H, "spx_net_nodes_soa", n_nodes=N, region=nodes.array("region"),
+                                                        zone=nodes.array("zone")).ref()))
+        rg, zc = nettopo.struct.n_regions, nettopo.struct.n_zones
+        rcost = np.full(max(rg * rg, 1), -1, np.int32)
+        zcost = np.full(max(zc * zc, 1), -1, np.int32)
+        self._ck(L.spx_flatten_net_topo(nettopo.ref(), rcost.ctypes.data_as(i32p), zcost.ctypes.data_as(i32p)))
+        self._ck(L.spx_upload_net_topo(self._h, Table(H, "spx_net_topo_soa", n_regions=rg, n_zones=zc, region_cost=rcost,
+                                                       zone_cost=zcost).ref()))
+        nk, npairs = C.c_int32(), C.c_int64()
+        self._ck(L.spx_flatten_net_keys(pods.ref(), appgroups.ref(), C.byref(nk), C.byref(npairs), None, None, None, None, None, None))
+        cols = dict(pod_key=np.zeros(P, np.int32), topo_order=np.zeros(P, np.int32), key_score_equally=np.zeros(nk.value, np.uint8),
+                    pair_ptr=np.zeros(nk.value + 1, np.int32), pair_node=np.zeros(max(npairs.value, 1), np.int32),
+                    pair_max_cost=np.zeros(max(npairs.value, 1), np.int64))
+        self._ck(L.spx_flatten_net_keys(pods.ref(), appgroups.ref(), C.byref(nk), C.byref(npairs),
+                                        cols["pod_key"].ctypes.data_as(i32p), cols["topo_order"].ctypes.data_as(i32p),
+                                        cols["key_score_equally"].ctypes.data_as(u8p), cols["pair_ptr"].ctypes.data_as(i32p),
+                                        cols["pair_node"].ctypes.data_as(i32p), cols["pair_max_cost"].ctypes.data_as(i64p)))
+        self._ck(L.spx_upload_net_pods(self._h, Table(H, "spx_net_pods_soa", n_pods=P, n_keys=nk.value, **cols).ref()))
+        self.n_nodes, self.n_pods = N, P
+        self.net_soa = cols
+
+    def toposort_less(self, pods: Table, a: Sequence[int], b: Sequence[int]) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        b = np.ascontiguousarray(b, dtype=np.int64)
+        out = np.zeros(len(a), np.uint8)
+        i64p = C.POINTER(C.c_int64)
+        self._ck_static(self._lib.spx_toposort_less(pods.ref(), self.net_soa["topo_order"].ctypes.data_as(C.POINTER(C.c_int32)), len(a),
+                                                    a.ctypes.data_as(i64p), b.ctypes.data_as(i64p),
+                                                    out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out.astype(bool)
+
+    @staticmethod
+    def _ck_static(rc: int) -> None:
+        if rc != 0:
+            raise RuntimeError(f"spx host call failed: {rc}")
+
     def status(self, plugin: int, pod_row: int) -> np.ndarray:
         out = np.empty(self.n_nodes, dtype=np.uint8)
         self._ck(self._lib.spx_fetch_status(self._h, plugin, pod_row, out.ctypes.data_as(C.POINTER(C.c_uint8))))

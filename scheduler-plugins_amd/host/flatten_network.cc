@@ -1,0 +1,140 @@
+// flatten_network.cc — object tables -> SoA for the network-aware plugins (host side, once per snapshot).
+//
+// Hoisted out of NetworkOverhead.PreFilter, which the reference runs once per pod and which itself loops
+// over every node (networkoverhead.go:174-298):
+//   CR fetch + sort + per-node costMap rebuild (sort.Sort + binary searches)     :438-497
+//   GetDependencyList / GetScheduledList                                         util.go:194-232
+//   the (scheduled pod x dependency) selector join                               :516-522, :590-594
+// A pod's PreFilter state depends only on its (AppGroup, workload selector): the join is done once per such
+// "workload key" and pods carry the key.  TopologicalSort's per-comparison CR Get + two binary searches
+// (topologicalsort.go:118-127) become one FindPodOrder per pod.
+#include <cstdint>
+#include <cstddef>
+#include <map>
+#include <utility>
+#include <vector>
+
+#include "../../include/spx.h"
+
+namespace {
+
+// util.FindPodOrder (util.go:138-153): binary search of Status.TopologyOrder by selector
+int32_t find_pod_order(const spx_appgroup_objects* ag, int32_t g, int32_t selector) {
+  const int32_t base = ag->topo_ptr[g];
+  int low = 0, high = ag->topo_ptr[g + 1] - base - 1;
+  while (low <= high) {
+    const int mid = (low + high) / 2;
+    const int32_t s = ag->topo_selector[base + mid];
+    if (s == selector) return ag->topo_index[base + mid];
+    if (s < selector) low = mid + 1;
+    else high = mid - 1;
+  }
+  return -1;
+}
+
+}  // namespace
+
+extern "C" int spx_flatten_net_topo(const spx_nettopo_objects* nt, int32_t* region_cost, int32_t* zone_cost) {
+  if (!nt || !region_cost || !zone_cost) return SPX_ERR_ARG;
+  const int64_t rg = nt->n_regions, zc = nt->n_zones;
+  for (int64_t i = 0; i < rg * rg; ++i) region_cost[i] = -1;
+  for (int64_t i = 0; i < zc * zc; ++i) zone_cost[i] = -1;
+  for (int32_t o = 0; o < nt->n_regions; ++o)
+    for (int32_t k = nt->rc_ptr[o]; k < nt->rc_ptr[o + 1]; ++k) {
+      const int32_t d = nt->rc_dest[k];
+      if (d < 0 || d >= nt->n_regions) continue;
+      if (nt->rc_cost[k] < 0 || nt->rc_cost[k] > INT32_MAX) return SPX_ERR_ARG;  // costs are small non-negative ints
+      region_cost[static_cast<int64_t>(o) * rg + d] = static_cast<int32_t>(nt->rc_cost[k]);
+    }
+  for (int32_t o = 0; o < nt->n_zones; ++o)
+    for (int32_t k = nt->zc_ptr[o]; k < nt->zc_ptr[o + 1]; ++k) {
+      const int32_t d = nt->zc_dest[k];
+      if (d < 0 || d >= nt->n_zones) continue;
+      if (nt->zc_cost[k] < 0 || nt->zc_cost[k] > INT32_MAX) return SPX_ERR_ARG;
+      zone_cost[static_cast<int64_t>(o) * zc + d] = static_cast<int32_t>(nt->zc_cost[k]);
+    }
+  return SPX_OK;
+}
+
+extern "C" int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int32_t* n_keys_out,
+                                    int64_t* n_pairs_out, int32_t* pod_key, int32_t* topo_order, uint8_t* key_score_equally,
+                                    int32_t* pair_ptr, int32_t* pair_node, int64_t* pair_max_cost) {
+  if (!pods || !ag || !n_keys_out || !n_pairs_out) return SPX_ERR_ARG;
+  const bool fill = pod_key && topo_order && key_score_equally && pair_ptr && pair_node && pair_max_cost;
+  std::map<std::pair<int32_t, int32_t>, int32_t> keys;
+  std::vector<std::pair<int32_t, int32_t>> order;
+  // key 0: "Pod does not belong to an AppGroup" -> scoreEqually (networkoverhead.go:187-190)
+  keys[{-1, -1}] = 0;
+  order.push_back({-1, -1});
+  for (int64_t p = 0; p < pods->n_pods; ++p) {
+    int32_t g = pods->appgroup[p];
+    std::pair<int32_t, int32_t> k{-1, -1};
+    if (g >= 0 && g < ag->n_groups) k = {g, pods->selector[p]};
+    auto it = keys.find(k);
+    if (it == keys.end()) {
+      it = keys.emplace(k, static_cast<int32_t>(order.size())).first;
+      order.push_back(k);
+    }
+    if (fill) {
+      pod_key[p] = it->second;
+      topo_order[p] = k.first >= 0 ? find_pod_order(ag, k.first, k.second) : -1;
+    }
+  }
+  int64_t n_pairs = 0;
+  if (fill) pair_ptr[0] = 0;
+  for (std::size_t ki = 0; ki < order.size(); ++ki) {
+    const int32_t g = order[ki].first, sel = order[ki].second;
+    uint8_t flag = 1;  // scoreEqually
+    const int64_t first = n_pairs;
+    if (g >= 0) {
+      // dependencyList: Dependencies of every workload whose selector matches (util.go:203-209)
+      bool any_dep = false;
+      for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w)
+        if (ag->wl_selector[w] == sel && ag->dep_ptr[w + 1] > ag->dep_ptr[w]) any_dep = true;
+      const bool any_placed = ag->placed_ptr[g + 1] > ag->placed_ptr[g];
+      if (any_dep && any_placed) {
+        flag = 0;
+        for (int32_t s = ag->placed_ptr[g]; s < ag->placed_ptr[g + 1]; ++s)      // for each pod already allocated
+          for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w) {            //   for each dependency
+            if (ag->wl_selector[w] != sel) continue;
+            for (int32_t d = ag->dep_ptr[w]; d < ag->dep_ptr[w + 1]; ++d) {
+              if (ag->placed_selector[s] != ag->dep_selector[d]) continue;
+              if (ag->placed_node[s] < 0) flag = 2;  // host not in the snapshot: PreFilter returns Error (:258, :274)
+              if (fill) {
+                pair_node[n_pairs] = ag->placed_node[s];
+                pair_max_cost[n_pairs] = ag->dep_max_cost[d];
+              }
+              ++n_pairs;
+            }
+          }
+      }
+    }
+    (void)first;
+    if (fill) {
+      key_score_equally[ki] = flag;
+      pair_ptr[ki + 1] = static_cast<int32_t>(n_pairs);
+    }
+  }
+  *n_keys_out = static_cast<int32_t>(order.size());
+  *n_pairs_out = n_pairs;
+  return SPX_OK;
+}
+
+extern "C" int spx_toposort_less(const spx_pod_objects* pods, const int32_t* topo_order, int64_t n_pairs, const int64_t* a,
+                                 const int64_t* b, uint8_t* less_out) {
+  if (!pods || !topo_order || !a || !b || !less_out) return SPX_ERR_ARG;
+  for (int64_t i = 0; i < n_pairs; ++i) {
+    const int64_t p1 = a[i], p2 = b[i];
+    if (p1 < 0 || p2 < 0 || p1 >= pods->n_pods || p2 >= pods->n_pods) return SPX_ERR_ARG;
+    const int32_t g1 = pods->appgroup[p1], g2 = pods->appgroup[p2];
+    bool less;
+    if (g1 != g2 || g1 < 0) {  // queuesort.PrioritySort: priority desc, then queue timestamp asc (topologicalsort.go:109-113)
+      less = pods->priority[p1] > pods->priority[p2] ||
+             (pods->priority[p1] == pods->priority[p2] && pods->queue_ts[p1] < pods->queue_ts[p2]);
+    } else {
+      less = topo_order[p1] <= topo_order[p2];  // "Lower is better" :131
+    }
+    less_out[i] = less ? 1 : 0;
+  }
+  return SPX_OK;
+}

@@ -333,3 +333,68 @@ def node_from_zones(zones: Sequence[dict], extra: Optional[dict] = None) -> dict
     for k, v in (extra or {}).items():
         total[k] = parse_quantity(v)
     return node(total)
+
+
+# ------------------------------------------------------------------ network-aware CRs
+class Interner:
+    """String -> dense id; `sorted_ids()` re-numbers so that id order == lexicographic order (needed for
+    AppGroup workload selectors, which util.FindPodOrder compares as strings)."""
+
+    def __init__(self, names: Iterable[str] = ()):
+        self.ids: Dict[str, int] = {}
+        for n in names:
+            self.id(n)
+
+    def id(self, name: Optional[str]) -> int:
+        if name is None or name == "":
+            return -1
+        if name not in self.ids:
+            self.ids[name] = len(self.ids)
+        return self.ids[name]
+
+    def freeze_sorted(self) -> None:
+        self.ids = {n: i for i, n in enumerate(sorted(self.ids))}
+
+    def __len__(self):
+        return len(self.ids)
+
+
+def build_appgroup_objects(hdr: Header, selectors: Interner, groups: Sequence[dict], node_index: Dict[str, int]) -> Table:
+    """groups: [{"workloads": [{"selector": s, "dependencies": [(selector, max_network_cost), ...]}],
+    "topology_order": [(selector, index)], "placed": [(selector, hostname)]}]; selectors must be frozen-sorted."""
+    wl, deps, topo, placed = [], [], [], []
+    for g in groups:
+        ws = g.get("workloads", [])
+        wl.append([selectors.ids[w["selector"]] for w in ws])
+        for w in ws:
+            deps.append([(selectors.ids[s], int(c)) for s, c in w.get("dependencies", [])])
+        topo.append([(selectors.ids[s], int(i)) for s, i in g.get("topology_order", [])])
+        placed.append([(selectors.ids.get(s, -1), node_index.get(h, -1)) for s, h in g.get("placed", []) if h])
+    return Table(
+        hdr, "spx_appgroup_objects", n_groups=len(groups),
+        wl_ptr=_csr(wl), wl_selector=[x for l in wl for x in l],
+        dep_ptr=_csr(deps), dep_selector=[x[0] for l in deps for x in l], dep_max_cost=[x[1] for l in deps for x in l],
+        topo_ptr=_csr(topo), topo_selector=[x[0] for l in topo for x in l], topo_index=[x[1] for l in topo for x in l],
+        placed_ptr=_csr(placed), placed_selector=[x[0] for l in placed for x in l], placed_node=[x[1] for l in placed for x in l],
+    )
+
+
+def build_nettopo_objects(hdr: Header, regions: Interner, zones: Interner, region_costs: Dict[str, list], zone_costs: Dict[str, list]) -> Table:
+    """region_costs / zone_costs: {origin: [(destination, cost), ...]} of the configured weights set."""
+    for o, l in list(region_costs.items()):
+        regions.id(o)
+        for d, _ in l:
+            regions.id(d)
+    for o, l in list(zone_costs.items()):
+        zones.id(o)
+        for d, _ in l:
+            zones.id(d)
+    rc = [[] for _ in range(len(regions))]
+    zc = [[] for _ in range(len(zones))]
+    for o, l in region_costs.items():
+        rc[regions.ids[o]] += [(regions.ids[d], int(c)) for d, c in l]
+    for o, l in zone_costs.items():
+        zc[zones.ids[o]] += [(zones.ids[d], int(c)) for d, c in l]
+    return Table(hdr, "spx_nettopo_objects", n_regions=len(regions), n_zones=len(zones),
+                 rc_ptr=_csr(rc), rc_dest=[x[0] for l in rc for x in l], rc_cost=[x[1] for l in rc for x in l],
+                 zc_ptr=_csr(zc), zc_dest=[x[0] for l in zc for x in l], zc_cost=[x[1] for l in zc for x in l])

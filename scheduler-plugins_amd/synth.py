@@ -283,3 +283,59 @@ def nrt_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, vary:
         "nrt": synth_nrt(hdr, nodes, seed, vary=vary),
         "rc": nrt_resource_classes(hdr),
     }
+
+
+# ------------------------------------------------------------------ network-aware (config #4)
+def synth_network(hdr: Header, nodes: Table, n_groups: int, seed: int = SEED, n_regions: int = 8, zones_per_region: int = 8,
+                  placed_per_group: int = 10):
+    """AppGroup + NetworkTopology objects: AppGroups of 11 workloads shaped like onlineboutique
+    (networkoverhead_test.go:226-307) with D in [0,7] dependencies each and MaxNetworkCost in {5,10,20,50,100};
+    10 already-placed pods per group on random nodes (as the reference benchmarks, :359-370); a 3-tier topology:
+    dense zone->zone costs in [1,50] inside a region with 5% of entries missing, region->region in [20,100]."""
+    rng = np.random.default_rng(seed + 7)
+    N = nodes.struct.n_nodes
+    W = 11
+    G = n_groups
+    n_wl = G * W
+    wl_ptr = np.arange(G + 1, dtype=np.int32) * W
+    wl_selector = np.tile(np.arange(W, dtype=np.int32), G)
+    nd = rng.integers(0, 8, n_wl)
+    nd = np.where(rng.random(n_wl) < 0.5, 0, nd)  # most workloads of onlineboutique have no dependencies
+    dep_ptr = np.zeros(n_wl + 1, dtype=np.int32)
+    np.cumsum(nd, out=dep_ptr[1:])
+    n_dep = int(dep_ptr[-1])
+    dep_selector = rng.integers(0, W, n_dep).astype(np.int32)
+    dep_max = rng.choice(np.array([5, 10, 20, 50, 100], dtype=np.int64), n_dep)
+    topo_ptr = wl_ptr.copy()
+    topo_selector = wl_selector.copy()  # sorted by selector, as the controller writes it
+    topo_index = (np.argsort(rng.random((G, W)), axis=1) + 1).astype(np.int32).reshape(-1)
+    S = placed_per_group
+    placed_ptr = np.arange(G + 1, dtype=np.int32) * S
+    placed_selector = rng.integers(0, W, G * S).astype(np.int32)
+    placed_node = rng.integers(0, N, G * S).astype(np.int32)
+    ag = Table(hdr, "spx_appgroup_objects", n_groups=G, wl_ptr=wl_ptr, wl_selector=wl_selector, dep_ptr=dep_ptr,
+               dep_selector=dep_selector, dep_max_cost=dep_max, topo_ptr=topo_ptr, topo_selector=topo_selector,
+               topo_index=topo_index, placed_ptr=placed_ptr, placed_selector=placed_selector, placed_node=placed_node)
+    Rg, Zc = n_regions, n_regions * zones_per_region
+    rmask = ~np.eye(Rg, dtype=bool)
+    rc_ptr, rsel = _csr_from_mask(rmask)
+    rdest = np.tile(np.arange(Rg, dtype=np.int32), (Rg, 1))
+    rcost = rng.integers(20, 101, (Rg, Rg))
+    same_region = (np.arange(Zc)[:, None] // zones_per_region) == (np.arange(Zc)[None, :] // zones_per_region)
+    zmask = same_region & ~np.eye(Zc, dtype=bool) & (rng.random((Zc, Zc)) >= 0.05)
+    zc_ptr, zsel = _csr_from_mask(zmask)
+    zdest = np.tile(np.arange(Zc, dtype=np.int32), (Zc, 1))
+    zcost = rng.integers(1, 51, (Zc, Zc))
+    nt = Table(hdr, "spx_nettopo_objects", n_regions=Rg, n_zones=Zc, rc_ptr=rc_ptr, rc_dest=rdest.reshape(-1)[rsel],
+               rc_cost=rcost.reshape(-1)[rsel].astype(np.int64), zc_ptr=zc_ptr, zc_dest=zdest.reshape(-1)[zsel],
+               zc_cost=zcost.reshape(-1)[zsel].astype(np.int64))
+    return ag, nt
+
+
+def network_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, pods_per_group: int = 100) -> Dict[str, Table]:
+    """Object tables for BASELINE.json config #4 (NetworkOverhead + TopologicalSort)."""
+    nodes = synth_nodes(hdr, n_nodes, seed)
+    n_groups = max(1, n_pods // pods_per_group)
+    ag, nt = synth_network(hdr, nodes, n_groups, seed)
+    return {"nodes": nodes, "pods": synth_pods(hdr, n_pods, seed, n_appgroups=n_groups), "appgroups": ag, "nettopo": nt,
+            "rc": resource_classes(hdr)}
