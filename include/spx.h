@@ -233,6 +233,32 @@ typedef struct spx_nettopo_objects {
   const int64_t* zc_cost;
 } spx_nettopo_objects;
 
+/* CapacityScheduling: ElasticQuotaInfos + nominated pods (pkg/capacityscheduling/elasticquota.go:62-68,
+ * capacity_scheduling.go:231-253).  A framework.Resource is a vector of SPX_QUOTA_SLOTS int64:
+ * [0] MilliCPU [1] Memory [2] EphemeralStorage [3] AllowedPodNumber [4..7] ScalarResources by slot
+ * (quota_scalar_res gives the canonical resource id of each scalar slot); *_present bit s (4..7) = the
+ * scalar key exists in that Resource's map.  Quotas are indexed by namespace id (spx_pod_objects.ns). */
+#define SPX_QUOTA_SLOTS 8
+#define SPX_QUOTA_ST_OVER_MAX 1 /* "...is rejected in PreFilter because ElasticQuota %v is more than Max"      capacity_scheduling.go:276 */
+#define SPX_QUOTA_ST_OVER_MIN 2 /* "...is rejected in PreFilter because total ElasticQuota used is more than min" :280 */
+typedef struct spx_quota_objects {
+  int32_t n_namespaces;
+  int32_t n_scalar_slots;
+  const int32_t* scalar_res;
+  const uint8_t* has_quota;
+  const int64_t* min;
+  const uint8_t* min_present;
+  const int64_t* max;
+  const uint8_t* max_present;
+  const int64_t* used;
+  const uint8_t* used_present;
+  int64_t n_nominated;
+  const int32_t* nom_ns;
+  const int32_t* nom_priority;
+  const int64_t* nom_pending_index;
+  const spx_pod_objects* nom_pods;
+} spx_quota_objects;
+
 /* ------------------------------------------------------------------ plugin params */
 
 typedef struct spx_allocatable_params {
@@ -393,6 +419,32 @@ typedef struct spx_net_pods_soa {
   const int32_t* topo_order;
 } spx_net_pods_soa;
 
+/* CapacityScheduling.PreFilter: per-pod request vectors and per-namespace nominated lists (CSR, any order) */
+typedef struct spx_quota_soa {
+  int64_t n_pods;
+  int32_t n_namespaces;
+  const int32_t* pod_ns;
+  const int32_t* pod_priority;
+  const int64_t* pod_req;
+  const uint8_t* pod_req_present;
+  const uint8_t* has_quota;
+  const int64_t* used;
+  const uint8_t* used_present;
+  const int64_t* max;
+  const uint8_t* max_present;
+  const int64_t* agg_used;
+  const uint8_t* agg_used_present;
+  const int64_t* agg_min;
+  const uint8_t* agg_min_present;
+  const int64_t* other_nominated;
+  const uint8_t* other_nominated_present;
+  const int32_t* nom_ptr;
+  const int32_t* nom_priority;
+  const int64_t* nom_pending_index;
+  const int64_t* nom_req;
+  const uint8_t* nom_req_present;
+} spx_quota_soa;
+
 /* ------------------------------------------------------------------ engine */
 
 typedef struct spx_engine spx_engine;
@@ -425,6 +477,9 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t);
 int spx_upload_net_nodes(spx_engine* e, const spx_net_nodes_soa* t);
 int spx_upload_net_topo(spx_engine* e, const spx_net_topo_soa* t);
 int spx_upload_net_pods(spx_engine* e, const spx_net_pods_soa* t);
+int spx_upload_quota(spx_engine* e, const spx_quota_soa* t);
+/* CapacityScheduling.PreFilter status per pod (n_pods bytes: 0 Success, SPX_QUOTA_ST_*); valid after spx_eval with the CAPACITY bit */
+int spx_fetch_prefilter(spx_engine* e, int plugin, int64_t row_begin, int64_t row_end, uint8_t* out);
 
 /* optional per-(pod,node) feasibility mask for normalizing score plugins: uint8 [n_pods][n_nodes],
  * non-zero = node passed Filter for that pod (upstream scores feasible nodes only).  NULL clears it. */
@@ -481,6 +536,12 @@ int spx_flatten_net_topo(const spx_nettopo_objects* nt, int32_t* region_cost, in
 int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int32_t* n_keys_out, int64_t* n_pairs_out, int32_t* pod_key, int32_t* topo_order, uint8_t* key_score_equally, int32_t* pair_ptr, int32_t* pair_node, int64_t* pair_max_cost);
 /* TopologicalSort.Less (topologicalsort.go:102-132) for n pairs of pod indices, from the flattened keys */
 int spx_toposort_less(const spx_pod_objects* pods, const int32_t* topo_order, int64_t n_pairs, const int64_t* a, const int64_t* b, uint8_t* less_out);
+
+/* CapacityScheduling: sizes are pod_req[P*8], pod_req_present[P]; the per-namespace arrays [NS*8] / [NS];
+ * agg_*[8] / [1]; other_nominated[NS*8]: nominated requests of OTHER namespaces whose quota is not over min
+ * (capacity_scheduling.go:248-250), i.e. total minus the namespace's own share; nom_* are the nominated pods
+ * grouped by namespace (nom_ptr[NS+1]); n_nominated entries. */
+int spx_flatten_quota(const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_quota_objects* q, int32_t* pod_ns, int32_t* pod_priority, int64_t* pod_req, uint8_t* pod_req_present, int64_t* agg_used, uint8_t* agg_used_present, int64_t* agg_min, uint8_t* agg_min_present, int64_t* other_nominated, uint8_t* other_nominated_present, int32_t* nom_ptr, int32_t* nom_priority, int64_t* nom_pending_index, int64_t* nom_req, uint8_t* nom_req_present);
 
 #ifdef __cplusplus
 }

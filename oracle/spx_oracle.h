@@ -71,6 +71,10 @@ void orc_net_normalize(int64_t* scores, int64_t n);
 int32_t orc_find_pod_order(const spx_appgroup_objects* ag, int32_t g, int32_t selector);
 int orc_toposort_less(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int64_t p1, int64_t p2);
 
+/* ---- CapacityScheduling.PreFilter (pkg/capacityscheduling/{capacity_scheduling,elasticquota}.go) */
+int orc_quota_cmp2(const int64_t* x1, uint8_t x1_present, const int64_t* x2, const int64_t* y, uint8_t y_present, int64_t bound);
+int orc_capacity_prefilter(const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_quota_objects* q, int64_t pod);
+
 /* ---- batch drivers: for each pod row in [row_begin,row_end): for each node: Score(); then
  *      NormalizeScore() over that pod's node list (feasible nodes only when `mask` != NULL, as
  *      upstream RunScorePlugins does).  out_raw / out_norm are [rows][n_nodes] int64 (either may

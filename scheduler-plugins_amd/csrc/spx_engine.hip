@@ -73,6 +73,14 @@ struct spx_engine {
   DevBuf d_net_region, d_net_zone, d_net_class, d_net_cls_region, d_net_cls_zone, d_net_rcost, d_net_zcost;
   DevBuf d_net_pod_key, d_net_key_flag, d_net_pair_ptr, d_net_pair_node, d_net_pair_max;
 
+  // CapacityScheduling.PreFilter
+  bool quota = false;
+  int32_t q_n_namespaces = 0;
+  int64_t q_agg_used[SPX_QUOTA_SLOTS] = {0}, q_agg_min[SPX_QUOTA_SLOTS] = {0};
+  uint32_t q_agg_used_present = 0, q_agg_min_present = 0;
+  DevBuf d_q_pod_ns, d_q_pod_prio, d_q_pod_req, d_q_pod_reqp, d_q_has, d_q_used, d_q_max, d_q_maxp, d_q_other, d_q_otherp;
+  DevBuf d_q_nom_ptr, d_q_nom_prio, d_q_nom_idx, d_q_nom_req, d_q_nom_reqp, d_q_status;
+
   DevBuf score[SPX_NUM_PLUGINS];
   int64_t score_rows[SPX_NUM_PLUGINS] = {0};
   int64_t score_stride[SPX_NUM_PLUGINS] = {0};
@@ -298,7 +306,9 @@ int spx_destroy(spx_engine* e) {
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
                     &e->d_net_region, &e->d_net_zone, &e->d_net_class, &e->d_net_cls_region, &e->d_net_cls_zone,
                     &e->d_net_rcost, &e->d_net_zcost, &e->d_net_pod_key, &e->d_net_key_flag, &e->d_net_pair_ptr,
-                    &e->d_net_pair_node, &e->d_net_pair_max};
+                    &e->d_net_pair_node, &e->d_net_pair_max, &e->d_q_pod_ns, &e->d_q_pod_prio, &e->d_q_pod_req, &e->d_q_pod_reqp,
+                    &e->d_q_has, &e->d_q_used, &e->d_q_max, &e->d_q_maxp, &e->d_q_other, &e->d_q_otherp, &e->d_q_nom_ptr,
+                    &e->d_q_nom_prio, &e->d_q_nom_idx, &e->d_q_nom_req, &e->d_q_nom_reqp, &e->d_q_status};
   for (DevBuf* b : bufs)
     if (b->p && !b->external) (void)hipFree(b->p);
   for (int i = 0; i < SPX_NUM_PLUGINS; ++i) {
@@ -551,6 +561,52 @@ int spx_upload_net_pods(spx_engine* e, const spx_net_pods_soa* t) {
   return SPX_OK;
 }
 
+int spx_upload_quota(spx_engine* e, const spx_quota_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  int rc = set_pods(e, t->n_pods);
+  if (rc) return rc;
+  if (t->n_namespaces < 0 || !t->nom_ptr) return fail(e, SPX_ERR_ARG, "quota: namespace tables missing");
+  const size_t P = static_cast<size_t>(t->n_pods), NS = static_cast<size_t>(t->n_namespaces), S = SPX_QUOTA_SLOTS;
+  const size_t nn = static_cast<size_t>(t->nom_ptr[t->n_namespaces]);
+  const int64_t dummy[SPX_QUOTA_SLOTS] = {0};
+  auto col = [&](const void* p) { return p ? p : static_cast<const void*>(dummy); };
+  if ((rc = upload(e, e->d_q_pod_ns, t->pod_ns, P * 4))) return rc;
+  if ((rc = upload(e, e->d_q_pod_prio, t->pod_priority, P * 4))) return rc;
+  if ((rc = upload(e, e->d_q_pod_req, t->pod_req, P * S * 8))) return rc;
+  if ((rc = upload(e, e->d_q_pod_reqp, t->pod_req_present, P))) return rc;
+  if ((rc = upload(e, e->d_q_has, col(t->has_quota), NS))) return rc;
+  if ((rc = upload(e, e->d_q_used, col(t->used), NS * S * 8))) return rc;
+  if ((rc = upload(e, e->d_q_max, col(t->max), NS * S * 8))) return rc;
+  if ((rc = upload(e, e->d_q_maxp, col(t->max_present), NS))) return rc;
+  if ((rc = upload(e, e->d_q_other, col(t->other_nominated), NS * S * 8))) return rc;
+  if ((rc = upload(e, e->d_q_otherp, col(t->other_nominated_present), NS))) return rc;
+  if ((rc = upload(e, e->d_q_nom_ptr, t->nom_ptr, (NS + 1) * 4))) return rc;
+  if ((rc = upload(e, e->d_q_nom_prio, col(t->nom_priority), nn * 4))) return rc;
+  if ((rc = upload(e, e->d_q_nom_idx, col(t->nom_pending_index), nn * 8))) return rc;
+  if ((rc = upload(e, e->d_q_nom_req, col(t->nom_req), nn * S * 8))) return rc;
+  if ((rc = upload(e, e->d_q_nom_reqp, col(t->nom_req_present), nn))) return rc;
+  if (!t->agg_used || !t->agg_min || !t->agg_used_present || !t->agg_min_present) return fail(e, SPX_ERR_ARG, "quota: aggregate vectors missing");
+  std::memcpy(e->q_agg_used, t->agg_used, sizeof e->q_agg_used);
+  std::memcpy(e->q_agg_min, t->agg_min, sizeof e->q_agg_min);
+  e->q_agg_used_present = *t->agg_used_present;
+  e->q_agg_min_present = *t->agg_min_present;
+  e->q_n_namespaces = t->n_namespaces;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  e->quota = true;
+  return SPX_OK;
+}
+
+int spx_fetch_prefilter(spx_engine* e, int plugin, int64_t row_begin, int64_t row_end, uint8_t* out) {
+  if (!e || !out) return SPX_ERR_ARG;
+  if (plugin != SPX_PLUGIN_CAPACITY || !(e->evaluated & (1u << SPX_PLUGIN_CAPACITY)))
+    return fail(e, SPX_ERR_STATE, "CapacityScheduling.PreFilter has not been evaluated");
+  if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
+  SPX_HIP(e, hipMemcpy(out, static_cast<const uint8_t*>(e->d_q_status.p) + row_begin, static_cast<size_t>(row_end - row_begin),
+                       hipMemcpyDeviceToHost));
+  return SPX_OK;
+}
+
 int spx_upload_feasible_mask(spx_engine* e, const uint8_t* mask, int64_t n_pods, int64_t n_nodes) {
   if (!e) return SPX_ERR_ARG;
   (void)mask;
@@ -563,9 +619,11 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (!e) return SPX_ERR_ARG;
   SPX_HIP(e, hipSetDevice(e->device));
   const uint32_t known = (1u << SPX_PLUGIN_ALLOCATABLE) | (1u << SPX_PLUGIN_TLP) | (1u << SPX_PLUGIN_LVRB) | (1u << SPX_PLUGIN_NRT) |
-                         (1u << SPX_PLUGIN_NETOVERHEAD);
+                         (1u << SPX_PLUGIN_NETOVERHEAD) | (1u << SPX_PLUGIN_CAPACITY);
   if (plugin_mask == 0 || (plugin_mask & ~known)) return fail(e, SPX_ERR_ARG, "plugin mask has unsupported bits");
-  if (e->n_nodes <= 0) return fail(e, SPX_ERR_STATE, "no node table uploaded");
+  const bool Q = plugin_mask & (1u << SPX_PLUGIN_CAPACITY);
+  if (Q && !e->quota) return fail(e, SPX_ERR_STATE, "CapacityScheduling quota tables not uploaded");
+  if (e->n_nodes <= 0 && plugin_mask != (1u << SPX_PLUGIN_CAPACITY)) return fail(e, SPX_ERR_STATE, "no node table uploaded");
   const bool A = plugin_mask & (1u << SPX_PLUGIN_ALLOCATABLE);
   const bool T = plugin_mask & (1u << SPX_PLUGIN_TLP);
   const bool L = plugin_mask & (1u << SPX_PLUGIN_LVRB);
@@ -598,6 +656,35 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   a.out_tlp = T ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_TLP].p) : nullptr;
   a.out_lvrb = L ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_LVRB].p) : nullptr;
   SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
+  if (Q) {
+    if ((rc = ensure(e, e->d_q_status, static_cast<size_t>(e->n_pods)))) return rc;
+    spx::QuotaArgs qa{};
+    qa.row_begin = row_begin;
+    qa.row_end = row_end;
+    qa.n_namespaces = e->q_n_namespaces;
+    qa.pod_ns = static_cast<const int32_t*>(e->d_q_pod_ns.p);
+    qa.pod_priority = static_cast<const int32_t*>(e->d_q_pod_prio.p);
+    qa.pod_req = static_cast<const int64_t*>(e->d_q_pod_req.p);
+    qa.pod_req_present = static_cast<const uint8_t*>(e->d_q_pod_reqp.p);
+    qa.has_quota = static_cast<const uint8_t*>(e->d_q_has.p);
+    qa.used = static_cast<const int64_t*>(e->d_q_used.p);
+    qa.max = static_cast<const int64_t*>(e->d_q_max.p);
+    qa.max_present = static_cast<const uint8_t*>(e->d_q_maxp.p);
+    std::memcpy(qa.agg_used, e->q_agg_used, sizeof qa.agg_used);
+    std::memcpy(qa.agg_min, e->q_agg_min, sizeof qa.agg_min);
+    qa.agg_used_present = e->q_agg_used_present;
+    qa.agg_min_present = e->q_agg_min_present;
+    qa.other_nominated = static_cast<const int64_t*>(e->d_q_other.p);
+    qa.other_nominated_present = static_cast<const uint8_t*>(e->d_q_otherp.p);
+    qa.nom_ptr = static_cast<const int32_t*>(e->d_q_nom_ptr.p);
+    qa.nom_priority = static_cast<const int32_t*>(e->d_q_nom_prio.p);
+    qa.nom_pending_index = static_cast<const int64_t*>(e->d_q_nom_idx.p);
+    qa.nom_req = static_cast<const int64_t*>(e->d_q_nom_req.p);
+    qa.nom_req_present = static_cast<const uint8_t*>(e->d_q_nom_reqp.p);
+    qa.out_status = static_cast<uint8_t*>(e->d_q_status.p);
+    spx::launch_quota(qa, e->stream);
+    SPX_HIP(e, hipGetLastError());
+  }
   spx::launch_trimaran(a, e->stream);
   SPX_HIP(e, hipGetLastError());
   if (N) {

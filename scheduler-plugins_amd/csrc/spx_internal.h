@@ -133,4 +133,32 @@ struct NetArgs {
 void launch_net(const NetArgs& g, hipStream_t s);
 size_t net_lds_bytes(int n_classes, int64_t n_nodes);
 
+// ---------------------------------------------------------------- CapacityScheduling.PreFilter
+struct QuotaArgs {
+  int64_t row_begin;
+  int64_t row_end;
+  int32_t n_namespaces;
+  const int32_t* pod_ns;
+  const int32_t* pod_priority;
+  const int64_t* pod_req;          // [P][8]
+  const uint8_t* pod_req_present;
+  const uint8_t* has_quota;        // [NS]
+  const int64_t* used;             // [NS][8]
+  const int64_t* max;              // [NS][8]
+  const uint8_t* max_present;
+  int64_t agg_used[SPX_QUOTA_SLOTS];
+  uint32_t agg_used_present;
+  int64_t agg_min[SPX_QUOTA_SLOTS];
+  uint32_t agg_min_present;
+  const int64_t* other_nominated;  // [NS][8]
+  const uint8_t* other_nominated_present;
+  const int32_t* nom_ptr;          // [NS+1]
+  const int32_t* nom_priority;
+  const int64_t* nom_pending_index;
+  const int64_t* nom_req;          // [n_nominated][8]
+  const uint8_t* nom_req_present;
+  uint8_t* out_status;             // [P]
+};
+void launch_quota(const QuotaArgs& a, hipStream_t s);
+
 }  // namespace spx

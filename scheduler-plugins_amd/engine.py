@@ -224,6 +224,31 @@ class Engine:
         if rc != 0:
             raise RuntimeError(f"spx host call failed: {rc}")
 
+    # ------------------------------------------------------------------ CapacityScheduling.PreFilter
+    def load_quota_objects(self, pods: Table, rc: Optional[Table], quota: Table) -> None:
+        L, H = self._lib, self._hdr
+        P, NS = pods.struct.n_pods, quota.struct.n_namespaces
+        nn = max(int(quota.struct.n_nominated), 1)
+        cols = dict(pod_ns=np.zeros(P, np.int32), pod_priority=np.zeros(P, np.int32), pod_req=np.zeros(P * 8, np.int64),
+                    pod_req_present=np.zeros(P, np.uint8), agg_used=np.zeros(8, np.int64), agg_used_present=np.zeros(1, np.uint8),
+                    agg_min=np.zeros(8, np.int64), agg_min_present=np.zeros(1, np.uint8),
+                    other_nominated=np.zeros(max(NS, 1) * 8, np.int64), other_nominated_present=np.zeros(max(NS, 1), np.uint8),
+                    nom_ptr=np.zeros(NS + 1, np.int32), nom_priority=np.zeros(nn, np.int32), nom_pending_index=np.zeros(nn, np.int64),
+                    nom_req=np.zeros(nn * 8, np.int64), nom_req_present=np.zeros(nn, np.uint8))
+        fn = L.spx_flatten_quota
+        self._ck_static(fn(pods.ref(), rc.ref() if rc else None, quota.ref(),
+                           *[v.ctypes.data_as(t) for v, t in zip(cols.values(), fn.argtypes[3:])]))
+        t = Table(H, "spx_quota_soa", n_pods=P, n_namespaces=NS, has_quota=quota.array("has_quota"), used=quota.array("used"),
+                  used_present=quota.array("used_present"), max=quota.array("max"), max_present=quota.array("max_present"), **cols)
+        self._ck(L.spx_upload_quota(self._h, t.ref()))
+        self.n_pods = P
+
+    def prefilter(self, plugin: int, row_begin: int = 0, row_end: Optional[int] = None) -> np.ndarray:
+        row_end = self.n_pods if row_end is None else row_end
+        out = np.zeros(row_end - row_begin, np.uint8)
+        self._ck(self._lib.spx_fetch_prefilter(self._h, plugin, row_begin, row_end, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
     def status(self, plugin: int, pod_row: int) -> np.ndarray:
         out = np.empty(self.n_nodes, dtype=np.uint8)
         self._ck(self._lib.spx_fetch_status(self._h, plugin, pod_row, out.ctypes.data_as(C.POINTER(C.c_uint8))))

@@ -398,3 +398,76 @@ def build_nettopo_objects(hdr: Header, regions: Interner, zones: Interner, regio
     return Table(hdr, "spx_nettopo_objects", n_regions=len(regions), n_zones=len(zones),
                  rc_ptr=_csr(rc), rc_dest=[x[0] for l in rc for x in l], rc_cost=[x[1] for l in rc for x in l],
                  zc_ptr=_csr(zc), zc_dest=[x[0] for l in zc for x in l], zc_cost=[x[1] for l in zc for x in l])
+
+
+# ------------------------------------------------------------------ CapacityScheduling (ElasticQuota)
+QUOTA_SLOTS = 8
+UPPER_BOUND_OF_MAX = (1 << 63) - 1  # elasticquota.go:29
+
+
+def _resource_vec(res: Resources, scalar_slots: List[int], rl):
+    """framework.NewResource(rl) over the quota slot vector.  `rl` may be a ResourceList-like dict, or a dict
+    with the framework.Resource field names the reference's tests use (MilliCPU, Memory, ..., ScalarResources)."""
+    v = [0] * QUOTA_SLOTS
+    present = 0
+    if rl is None:
+        return v, present
+    if any(k in rl for k in ("MilliCPU", "Memory", "EphemeralStorage", "AllowedPodNumber", "ScalarResources")):
+        v[0], v[1], v[2], v[3] = (int(rl.get(k, 0)) for k in ("MilliCPU", "Memory", "EphemeralStorage", "AllowedPodNumber"))
+        items = [(k, int(q)) for k, q in (rl.get("ScalarResources") or {}).items()]
+    else:
+        items = []
+        for k, q in rl.items():
+            if k == "cpu":
+                v[0] += res.canonical(k, q)
+            elif k == "memory":
+                v[1] += res.canonical(k, q)
+            elif k == "ephemeral-storage":
+                v[2] += res.canonical(k, q)
+            elif k == "pods":
+                v[3] += res.canonical(k, q)
+            elif is_scalar_resource_name(k):
+                items.append((k, res.canonical(k, q)))
+    for k, q in items:
+        rid = res.id(k)
+        if rid not in scalar_slots:
+            scalar_slots.append(rid)
+        s = 4 + scalar_slots.index(rid)
+        if s >= QUOTA_SLOTS:
+            raise ValueError("more scalar resources than quota slots")
+        v[s] += q
+        present |= 1 << s
+    return v, present
+
+
+def build_quota_objects(hdr: Header, res: Resources, namespaces: Sequence[Optional[dict]], nominated: Sequence[tuple] = ()) -> Table:
+    """namespaces[i] = None (no ElasticQuota) or {"min": rl|None, "max": rl|None, "used": rl};
+    nominated = [(namespace index, priority, pending pod index or -1, pod dict)].
+    A nil Min/Max is replaced like newElasticQuotaInfo does (elasticquota.go:70-76)."""
+    slots: List[int] = []
+    has, mins, maxs, useds, mp, xp, up = [], [], [], [], [], [], []
+    bound_min = {"cpu": "0", "memory": 0, "ephemeral-storage": 0}
+    for ns in namespaces:
+        has.append(1 if ns is not None else 0)
+        ns = ns or {}
+        mn, mnp = _resource_vec(res, slots, ns.get("min") if ns.get("min") is not None else bound_min)
+        if ns.get("max") is not None:
+            mx, mxp = _resource_vec(res, slots, ns["max"])
+        else:
+            mx, mxp = [UPPER_BOUND_OF_MAX, UPPER_BOUND_OF_MAX, UPPER_BOUND_OF_MAX, 0, 0, 0, 0, 0], 0
+        us, usp = _resource_vec(res, slots, ns.get("used"))
+        mins.append(mn), maxs.append(mx), useds.append(us), mp.append(mnp), xp.append(mxp), up.append(usp)
+    nom_pods = build_pod_objects(hdr, res, [n[3] for n in nominated] or [pod()])
+    for n in nominated:  # scalar requests of nominated pods need slots too
+        for c in list(n[3].get("containers", [])) + list(n[3].get("init_containers", [])):
+            _resource_vec(res, slots, c.get("requests"))
+    return Table(
+        hdr, "spx_quota_objects", n_namespaces=len(namespaces), n_scalar_slots=len(slots),
+        scalar_res=np.array(slots + [0] * (4 - len(slots)), dtype=np.int32), has_quota=np.array(has, dtype=np.uint8),
+        min=np.array(mins, dtype=np.int64).reshape(-1), min_present=np.array(mp, dtype=np.uint8),
+        max=np.array(maxs, dtype=np.int64).reshape(-1), max_present=np.array(xp, dtype=np.uint8),
+        used=np.array(useds, dtype=np.int64).reshape(-1), used_present=np.array(up, dtype=np.uint8),
+        n_nominated=len(nominated), nom_ns=np.array([n[0] for n in nominated], dtype=np.int32),
+        nom_priority=np.array([n[1] for n in nominated], dtype=np.int32),
+        nom_pending_index=np.array([n[2] for n in nominated], dtype=np.int64), nom_pods=nom_pods,
+    )

@@ -339,3 +339,48 @@ def network_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, p
     ag, nt = synth_network(hdr, nodes, n_groups, seed)
     return {"nodes": nodes, "pods": synth_pods(hdr, n_pods, seed, n_appgroups=n_groups), "appgroups": ag, "nettopo": nt,
             "rc": resource_classes(hdr)}
+
+
+# ------------------------------------------------------------------ CapacityScheduling (config #5's PreFilter gate)
+def synth_quota(hdr: Header, pods: Table, seed: int = SEED, n_namespaces: int = 100, n_nominated: int = 300, device_res: int = -1) -> Table:
+    """ElasticQuotas for Q namespaces (Q=100): 85% of namespaces carry a quota; Used is drawn
+    around Min so that both PreFilter gates fire for a visible share of pods; nominated pods with priorities in
+    {0,100,1000}, a few of them being pending pods themselves (the uid exclusion, capacity_scheduling.go:239)."""
+    rng = np.random.default_rng(seed + 8)
+    NS, S = n_namespaces, 8
+    has = rng.random(NS) < 0.85
+    mn = np.zeros((NS, S), dtype=np.int64)
+    mx = np.zeros((NS, S), dtype=np.int64)
+    us = np.zeros((NS, S), dtype=np.int64)
+    mn[:, 0] = rng.integers(50, 400, NS) * 1000
+    mn[:, 1] = rng.integers(100, 2000, NS) * GiB
+    mn[:, 2] = rng.integers(0, 100, NS) * GiB
+    mx[:, :3] = (mn[:, :3] * rng.uniform(1.0, 2.0, (NS, 3))).astype(np.int64)
+    no_max = rng.random(NS) < 0.1
+    mx[no_max, :3] = (1 << 63) - 1
+    us[:, :3] = (mn[:, :3] * rng.uniform(0.2, 1.3, (NS, 3))).astype(np.int64)
+    present = np.zeros(NS, dtype=np.uint8)
+    n_scalar = 0
+    scalar_res = np.zeros(4, dtype=np.int32)
+    if device_res >= 0:
+        n_scalar = 1
+        scalar_res[0] = device_res
+        mn[:, 4] = rng.integers(0, 64, NS)
+        mx[:, 4] = mn[:, 4] + rng.integers(0, 64, NS)
+        us[:, 4] = rng.integers(0, 80, NS)
+        present[:] = 1 << 4
+    min_present = np.where(rng.random(NS) < 0.9, present, 0).astype(np.uint8)  # some quotas do not list the device in Min
+    P = pods.struct.n_pods
+    nom_ns = rng.integers(0, NS, n_nominated).astype(np.int32)
+    nom_prio = rng.choice(np.array([0, 100, 1000], dtype=np.int32), n_nominated)
+    nom_pods = synth_pods(hdr, max(n_nominated, 1), seed=seed + 99, device_res=device_res, n_namespaces=NS)
+    pend = np.full(n_nominated, -1, dtype=np.int64)
+    k = min(n_nominated // 10, P)
+    if k:
+        idx = rng.choice(P, k, replace=False)
+        pend[:k] = idx
+        nom_ns[:k] = pods.array("ns")[idx]  # the same pod lives in the same namespace
+    return Table(hdr, "spx_quota_objects", n_namespaces=NS, n_scalar_slots=n_scalar, scalar_res=scalar_res,
+                 has_quota=has.astype(np.uint8), min=mn.reshape(-1), min_present=min_present, max=mx.reshape(-1),
+                 max_present=present, used=us.reshape(-1), used_present=present, n_nominated=n_nominated, nom_ns=nom_ns,
+                 nom_priority=nom_prio, nom_pending_index=pend, nom_pods=nom_pods)

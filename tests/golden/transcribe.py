@@ -234,7 +234,34 @@ def nrt_least_numa():
     return out
 
 
-FIXTURES = {"nrt_filter.json": nrt_filter, "nrt_score.json": nrt_score, "nrt_least_numa.json": nrt_least_numa}
+def capacity():
+    """pkg/capacityscheduling/elasticquota_test.go: TestUsedOverMinWith (:133), TestUsedOverMaxWith (:265), TestUsedOverMin (:397)"""
+    path = "pkg/capacityscheduling/elasticquota_test.go"
+    src = (REF / path).read_text()
+
+    def fres(d):
+        if d is None or isinstance(d, Ident):
+            return None
+        out = {k: v for k, v in d.items() if k != "ScalarResources"}
+        if "ScalarResources" in d:
+            out["ScalarResources"] = {("nvidia.com/gpu" if k == "ResourceGPU" else k): v for k, v in d["ScalarResources"].items()}
+        return out
+
+    out = {"source": path}
+    for fn, key, bound in (("TestUsedOverMinWith", "used_over_min_with", "Min"), ("TestUsedOverMaxWith", "used_over_max_with", "Max"),
+                           ("TestUsedOverMin", "used_over_min", "Min")):
+        p = src.index("func " + fn + "(")
+        cases = []
+        for t in parse_literal_after(src[p:], "tests := "):
+            b = t["before"]
+            cases.append({"name": t["name"], "line": line_of(src, '"' + t["name"] + '"', p), "used": fres(b.get("Used")),
+                          "bound": fres(b.get(bound)), "pod_request": fres(t.get("podRequest")),
+                          "expected": t["expected"].name == "true"})
+        out[key] = cases
+    return out
+
+
+FIXTURES = {"capacity.json": capacity, "nrt_filter.json": nrt_filter, "nrt_score.json": nrt_score, "nrt_least_numa.json": nrt_least_numa}
 
 if __name__ == "__main__":
     for fname, fn in FIXTURES.items():
