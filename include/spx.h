@@ -508,7 +508,10 @@ int spx_bind_score_table(spx_engine* e, int plugin, void* dptr, int64_t row_stri
  * sum_i weight[i]*score_i (upstream selectHost input); infeasible nodes are skipped */
 int spx_set_plugin_weights(spx_engine* e, const int64_t* weights);
 int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end);
-int spx_fetch_best(spx_engine* e, int64_t row_begin, int64_t row_end, int32_t* node_idx, int64_t* weighted_score);
+/* per pod in [row_begin,row_end): best node (lowest index among ties, -1 when no node is feasible or the pod
+ * failed CapacityScheduling.PreFilter), its weighted score, how many nodes tie for it, how many were feasible;
+ * n_ties / n_feasible may be NULL */
+int spx_fetch_best(spx_engine* e, int64_t row_begin, int64_t row_end, int32_t* node_idx, int64_t* weighted_score, int32_t* n_ties, int32_t* n_feasible);
 
 /* duration in ms of the last spx_eval's kernels measured with HIP events on the engine stream */
 int spx_last_eval_ms(spx_engine* e, float* ms);

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(64) void k_net(NetArgs g) {
   const int lo = g.pair_ptr[key], hi = g.pair_ptr[key + 1];
   const int64_t n_words = (g.n_nodes + 31) / 32;
   const bool use_cls = g.n_classes > 0;
-  const uint8_t* mask_row = g.feasible ? g.feasible + pod * g.feasible_stride : nullptr;
+  const uint8_t* other0 = g.other_status[0] ? g.other_status[0] + pod * g.row_stride : nullptr;
+  const uint8_t* other1 = g.other_status[1] ? g.other_status[1] + pod * g.row_stride : nullptr;
   const int64_t tiles = (g.row_stride + 64 * kNpl - 1) / (64 * kNpl);
 
   if (flag != 0) {
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(64) void k_net(NetArgs g) {
       const int64_t n = n0 + j;
       if (n >= g.n_nodes) continue;
       const Acc a = eval(n);
-      const bool feasible = !(a.vio > a.sat) && (!mask_row || mask_row[n] != 0);
+      const bool feasible = !(a.vio > a.sat) && (!other0 || other0[n] == 0) && (!other1 || other1[n] == 0);
       if (feasible) {
         mn = a.cost < mn ? a.cost : mn;
         mx = a.cost > mx ? a.cost : mx;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(64) void k_net(NetArgs g) {
       if (n >= g.n_nodes) continue;
       const Acc a = eval(n);
       const bool pass = !(a.vio > a.sat);
-      const bool feasible = pass && (!mask_row || mask_row[n] != 0);
+      const bool feasible = pass && (!other0 || other0[n] == 0) && (!other1 || other1[n] == 0);
       int score = 0;
       if (feasible) {
         if (mn == 0 && mx == 0) score = a.cost;                            // all minimum: untouched (== 0)

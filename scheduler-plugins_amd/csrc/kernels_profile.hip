@@ -1,0 +1,140 @@
+// kernels_profile.hip — profile-level passes over the per-plugin tables: feasibility-aware NormalizeScore for
+// NodeResourcesAllocatable, and the per-pod weighted argmax ("selectHost" input).
+//
+// Upstream runs Score/NormalizeScore only on the nodes that passed every Filter plugin and then sums
+// plugin_weight x score ("upstream framework runtime").  When a Filter plugin (NRT,
+// NetworkOverhead) or a caller mask is part of the evaluation, Allocatable's min/max must run over each pod's
+// feasible set (allocatable.go:143-168 normalises the list it is handed), so its rows stop being identical.
+// One wavefront per pod row; the row is read twice (status bytes, raw scores from L2) and written once.
+#include "spx_internal.h"
+
+namespace spx {
+
+namespace {
+
+constexpr int kNpl = 4;
+
+__device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int m) {
+  const int lo = __shfl_xor(static_cast<int>(v & 0xffffffffLL), m, 64);
+  const int hi = __shfl_xor(static_cast<int>(v >> 32), m, 64);
+  return (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+}
+
+__device__ __forceinline__ bool feasible_at(const ProfileArgs& a, int64_t pod, int64_t n) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (a.status[k]) ok &= a.status[k][pod * a.row_stride + n] == 0;
+  return ok;
+}
+
+// floor(num / den) for num <= 101 * den
+__device__ __forceinline__ uint64_t div_le100(uint64_t num, uint64_t den) {
+  const float qf = static_cast<float>(num) * __frcp_rn(static_cast<float>(den));
+  uint64_t q = static_cast<uint64_t>(static_cast<uint32_t>(qf));
+  const uint64_t prod = q * den;
+  if (prod > num) --q;
+  else if (num - prod >= den) ++q;
+  return q;
+}
+
+__global__ __launch_bounds__(64) void k_alloc_masked(ProfileArgs a) {
+  const int lane = threadIdx.x;
+  const int64_t pod = a.row_begin + blockIdx.x;
+  if (pod >= a.row_end) return;
+  const int64_t tiles = (a.row_stride + 64 * kNpl - 1) / (64 * kNpl);
+  int64_t lo = INT64_MAX, hi = -INT64_MAX;
+  for (int64_t t = 0; t < tiles; ++t) {
+    const int64_t n0 = (t * 64 + lane) * kNpl;
+#pragma unroll
+    for (int j = 0; j < kNpl; ++j) {
+      const int64_t n = n0 + j;
+      if (n >= a.n_nodes || !feasible_at(a, pod, n)) continue;
+      const int64_t s = a.alloc_raw[n];
+      lo = s < lo ? s : lo;
+      hi = s > hi ? s : hi;
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const int64_t olo = shfl_xor_i64(lo, m), ohi = shfl_xor_i64(hi, m);
+    lo = olo < lo ? olo : lo;
+    hi = ohi > hi ? ohi : hi;
+  }
+  const uint64_t range = static_cast<uint64_t>(hi) - static_cast<uint64_t>(lo);
+  for (int64_t t = 0; t < tiles; ++t) {
+    const int64_t n0 = (t * 64 + lane) * kNpl;
+    if (n0 >= a.row_stride) continue;
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < kNpl; ++j) {
+      const int64_t n = n0 + j;
+      if (n >= a.n_nodes || !feasible_at(a, pod, n) || range == 0) continue;  // infeasible cells hold 0
+      const uint64_t d = static_cast<uint64_t>(a.alloc_raw[n]) - static_cast<uint64_t>(lo);
+      uint64_t v = div_le100(d * 100ull, range);
+      v = v > 255 ? 255 : v;
+      w |= static_cast<uint32_t>(v) << (8 * j);
+    }
+    *reinterpret_cast<uint32_t*>(a.out_alloc + pod * a.row_stride + n0) = w;
+  }
+}
+
+// per pod: argmax over feasible nodes of Σ_plugin weight x score; ties resolved to the lowest node index, the
+// tie count is returned so that callers can compare tie SETS (upstream selectHost picks randomly among them)
+__global__ __launch_bounds__(64) void k_best(ProfileArgs a) {
+  const int lane = threadIdx.x;
+  const int64_t pod = a.row_begin + blockIdx.x;
+  if (pod >= a.row_end) return;
+  int64_t best = INT64_MIN;
+  int best_n = -1, ties = 0, feas = 0;
+  const bool pod_ok = !a.prefilter || a.prefilter[pod] == 0;
+  for (int64_t n = lane; n < a.n_nodes && pod_ok; n += 64) {
+    if (!feasible_at(a, pod, n)) continue;
+    ++feas;
+    int64_t total = 0;
+#pragma unroll
+    for (int k = 0; k < SPX_NUM_PLUGINS; ++k)
+      if (a.score[k]) total += a.weight[k] * static_cast<int64_t>(a.score[k][pod * a.row_stride + n]);
+    if (total > best) {
+      best = total;
+      best_n = static_cast<int>(n);
+      ties = 1;
+    } else if (total == best) {
+      ++ties;
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const int64_t ob = shfl_xor_i64(best, m);
+    const int on = __shfl_xor(best_n, m, 64);
+    const int ot = __shfl_xor(ties, m, 64);
+    feas += __shfl_xor(feas, m, 64);
+    if (ob > best || (ob == best && on >= 0 && (best_n < 0 || on < best_n))) {
+      ties = ob > best ? ot : ties + ot;
+      best = ob;
+      best_n = on;
+    } else if (ob == best && on >= 0) {
+      ties += ot;
+    }
+  }
+  if (lane == 0) {
+    a.best_node[pod] = best_n;
+    a.best_score[pod] = best_n >= 0 ? best : 0;
+    a.best_ties[pod] = best_n >= 0 ? ties : 0;
+    a.best_feasible[pod] = feas;
+  }
+}
+
+}  // namespace
+
+void launch_alloc_masked(const ProfileArgs& a, hipStream_t s) {
+  if (a.row_end <= a.row_begin) return;
+  hipLaunchKernelGGL(k_alloc_masked, dim3(static_cast<unsigned>(a.row_end - a.row_begin)), dim3(64), 0, s, a);
+}
+
+void launch_best(const ProfileArgs& a, hipStream_t s) {
+  if (a.row_end <= a.row_begin) return;
+  hipLaunchKernelGGL(k_best, dim3(static_cast<unsigned>(a.row_end - a.row_begin)), dim3(64), 0, s, a);
+}
+
+}  // namespace spx

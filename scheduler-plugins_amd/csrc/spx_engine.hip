@@ -73,6 +73,12 @@ struct spx_engine {
   DevBuf d_net_region, d_net_zone, d_net_class, d_net_cls_region, d_net_cls_zone, d_net_rcost, d_net_zcost;
   DevBuf d_net_pod_key, d_net_key_flag, d_net_pair_ptr, d_net_pair_node, d_net_pair_max;
 
+  // profile-level state
+  DevBuf d_ext_status;  // caller's feasibility mask, stored as a status table (0 = feasible)
+  bool ext_mask = false;
+  DevBuf d_best_node, d_best_score, d_best_ties, d_best_feas;
+  bool best_valid = false;
+
   // CapacityScheduling.PreFilter
   bool quota = false;
   int32_t q_n_namespaces = 0;
@@ -308,7 +314,8 @@ int spx_destroy(spx_engine* e) {
                     &e->d_net_rcost, &e->d_net_zcost, &e->d_net_pod_key, &e->d_net_key_flag, &e->d_net_pair_ptr,
                     &e->d_net_pair_node, &e->d_net_pair_max, &e->d_q_pod_ns, &e->d_q_pod_prio, &e->d_q_pod_req, &e->d_q_pod_reqp,
                     &e->d_q_has, &e->d_q_used, &e->d_q_max, &e->d_q_maxp, &e->d_q_other, &e->d_q_otherp, &e->d_q_nom_ptr,
-                    &e->d_q_nom_prio, &e->d_q_nom_idx, &e->d_q_nom_req, &e->d_q_nom_reqp, &e->d_q_status};
+                    &e->d_q_nom_prio, &e->d_q_nom_idx, &e->d_q_nom_req, &e->d_q_nom_reqp, &e->d_q_status, &e->d_ext_status,
+                    &e->d_best_node, &e->d_best_score, &e->d_best_ties, &e->d_best_feas};
   for (DevBuf* b : bufs)
     if (b->p && !b->external) (void)hipFree(b->p);
   for (int i = 0; i < SPX_NUM_PLUGINS; ++i) {
@@ -609,10 +616,22 @@ int spx_fetch_prefilter(spx_engine* e, int plugin, int64_t row_begin, int64_t ro
 
 int spx_upload_feasible_mask(spx_engine* e, const uint8_t* mask, int64_t n_pods, int64_t n_nodes) {
   if (!e) return SPX_ERR_ARG;
-  (void)mask;
-  (void)n_pods;
-  (void)n_nodes;
-  return fail(e, SPX_ERR_STATE, "feasibility masks are not implemented in this build");
+  SPX_HIP(e, hipSetDevice(e->device));
+  if (!mask) {  // clear
+    e->ext_mask = false;
+    return SPX_OK;
+  }
+  int rc = set_nodes(e, n_nodes);
+  if (rc) return rc;
+  if ((rc = set_pods(e, n_pods))) return rc;
+  // stored like a Filter plugin's status table: 0 = passed, so that every consumer treats filters uniformly
+  std::vector<uint8_t> st(static_cast<size_t>(n_pods) * static_cast<size_t>(e->row_stride), 1);
+  for (int64_t p = 0; p < n_pods; ++p)
+    for (int64_t n = 0; n < n_nodes; ++n) st[static_cast<size_t>(p * e->row_stride + n)] = mask[p * n_nodes + n] ? 0 : 1;
+  if ((rc = upload(e, e->d_ext_status, st.data(), st.size()))) return rc;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  e->ext_mask = true;
+  return SPX_OK;
 }
 
 int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end) {
@@ -652,7 +671,9 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   for (int p = 0; p < 3; ++p)
     if ((plugin_mask & (1u << p)) && e->score_stride[p] != e->row_stride)
       return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
-  a.out_alloc = A ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_ALLOCATABLE].p) : nullptr;
+  // Allocatable's NormalizeScore runs over each pod's feasible nodes as soon as any Filter is in play
+  const bool masked = N || W || e->ext_mask;
+  a.out_alloc = (A && !masked) ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_ALLOCATABLE].p) : nullptr;
   a.out_tlp = T ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_TLP].p) : nullptr;
   a.out_lvrb = L ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_LVRB].p) : nullptr;
   SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
@@ -685,8 +706,6 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     spx::launch_quota(qa, e->stream);
     SPX_HIP(e, hipGetLastError());
   }
-  spx::launch_trimaran(a, e->stream);
-  SPX_HIP(e, hipGetLastError());
   if (N) {
     if (e->score_stride[SPX_PLUGIN_NRT] != e->row_stride)
       return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
@@ -706,15 +725,33 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     fill_net(e, g);
     g.row_begin = row_begin;
     g.row_end = row_end;
-    // upstream scores only nodes that passed every Filter plugin: with NRT in the same eval its status table is the mask
-    g.feasible = nullptr;
+    // upstream scores only nodes that passed every Filter plugin
+    g.other_status[0] = N ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NRT].p) : nullptr;
+    g.other_status[1] = e->ext_mask ? static_cast<const uint8_t*>(e->d_ext_status.p) : nullptr;
     g.out_status = static_cast<uint8_t*>(e->status[SPX_PLUGIN_NETOVERHEAD].p);
     g.out_score = static_cast<uint8_t*>(e->score[SPX_PLUGIN_NETOVERHEAD].p);
     spx::launch_net(g, e->stream);
     SPX_HIP(e, hipGetLastError());
   }
+  spx::launch_trimaran(a, e->stream);
+  SPX_HIP(e, hipGetLastError());
+  if (A && masked) {
+    spx::ProfileArgs pa{};
+    pa.n_nodes = e->n_nodes;
+    pa.row_stride = e->row_stride;
+    pa.row_begin = row_begin;
+    pa.row_end = row_end;
+    pa.status[0] = N ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NRT].p) : nullptr;
+    pa.status[1] = W ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NETOVERHEAD].p) : nullptr;
+    pa.status[2] = e->ext_mask ? static_cast<const uint8_t*>(e->d_ext_status.p) : nullptr;
+    pa.alloc_raw = static_cast<const int64_t*>(e->d_alloc_raw.p);
+    pa.out_alloc = static_cast<uint8_t*>(e->score[SPX_PLUGIN_ALLOCATABLE].p);
+    spx::launch_alloc_masked(pa, e->stream);
+    SPX_HIP(e, hipGetLastError());
+  }
   SPX_HIP(e, hipEventRecord(e->ev1, e->stream));
   e->timed = true;
+  e->best_valid = false;
   e->evaluated |= plugin_mask;
   e->eval_begin = row_begin;
   e->eval_end = row_end;
@@ -844,18 +881,56 @@ int spx_bind_score_table(spx_engine* e, int plugin, void* dptr, int64_t row_stri
 }
 
 int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end) {
-  (void)plugin_mask;
-  (void)row_begin;
-  (void)row_end;
-  return fail(e, SPX_ERR_STATE, "spx_eval_best is not implemented in this build");
+  if (!e) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  if ((plugin_mask & ~e->evaluated) != 0) return fail(e, SPX_ERR_STATE, "spx_eval_best: plugin in the mask has not been evaluated");
+  if (e->n_nodes <= 0 || e->n_pods <= 0) return fail(e, SPX_ERR_STATE, "shape unknown");
+  if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
+  int rc;
+  const size_t P = static_cast<size_t>(e->n_pods);
+  if ((rc = ensure(e, e->d_best_node, P * 4))) return rc;
+  if ((rc = ensure(e, e->d_best_score, P * 8))) return rc;
+  if ((rc = ensure(e, e->d_best_ties, P * 4))) return rc;
+  if ((rc = ensure(e, e->d_best_feas, P * 4))) return rc;
+  spx::ProfileArgs pa{};
+  pa.n_nodes = e->n_nodes;
+  pa.row_stride = e->row_stride;
+  pa.row_begin = row_begin;
+  pa.row_end = row_end;
+  pa.status[0] = (plugin_mask & (1u << SPX_PLUGIN_NRT)) ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NRT].p) : nullptr;
+  pa.status[1] = (plugin_mask & (1u << SPX_PLUGIN_NETOVERHEAD)) ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NETOVERHEAD].p) : nullptr;
+  pa.status[2] = e->ext_mask ? static_cast<const uint8_t*>(e->d_ext_status.p) : nullptr;
+  pa.prefilter = (plugin_mask & (1u << SPX_PLUGIN_CAPACITY)) ? static_cast<const uint8_t*>(e->d_q_status.p) : nullptr;
+  for (int k = 0; k < SPX_NUM_PLUGINS; ++k) {
+    const bool has_score = k <= SPX_PLUGIN_NETOVERHEAD;
+    if ((plugin_mask & (1u << k)) && has_score) {
+      if (e->score_stride[k] != e->row_stride) return fail(e, SPX_ERR_STATE, "score table stride differs from the engine row stride");
+      pa.score[k] = static_cast<const uint8_t*>(e->score[k].p);
+    }
+    pa.weight[k] = e->plugin_weight[k];
+  }
+  pa.best_node = static_cast<int32_t*>(e->d_best_node.p);
+  pa.best_score = static_cast<int64_t*>(e->d_best_score.p);
+  pa.best_ties = static_cast<int32_t*>(e->d_best_ties.p);
+  pa.best_feasible = static_cast<int32_t*>(e->d_best_feas.p);
+  spx::launch_best(pa, e->stream);
+  SPX_HIP(e, hipGetLastError());
+  e->best_valid = true;
+  return SPX_OK;
 }
 
-int spx_fetch_best(spx_engine* e, int64_t row_begin, int64_t row_end, int32_t* node_idx, int64_t* weighted_score) {
-  (void)row_begin;
-  (void)row_end;
-  (void)node_idx;
-  (void)weighted_score;
-  return fail(e, SPX_ERR_STATE, "spx_eval_best is not implemented in this build");
+int spx_fetch_best(spx_engine* e, int64_t row_begin, int64_t row_end, int32_t* node_idx, int64_t* weighted_score, int32_t* n_ties,
+                   int32_t* n_feasible) {
+  if (!e || !node_idx || !weighted_score) return SPX_ERR_ARG;
+  if (!e->best_valid) return fail(e, SPX_ERR_STATE, "spx_eval_best has not run since the last spx_eval");
+  if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
+  const size_t n = static_cast<size_t>(row_end - row_begin);
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  SPX_HIP(e, hipMemcpy(node_idx, static_cast<const int32_t*>(e->d_best_node.p) + row_begin, n * 4, hipMemcpyDeviceToHost));
+  SPX_HIP(e, hipMemcpy(weighted_score, static_cast<const int64_t*>(e->d_best_score.p) + row_begin, n * 8, hipMemcpyDeviceToHost));
+  if (n_ties) SPX_HIP(e, hipMemcpy(n_ties, static_cast<const int32_t*>(e->d_best_ties.p) + row_begin, n * 4, hipMemcpyDeviceToHost));
+  if (n_feasible) SPX_HIP(e, hipMemcpy(n_feasible, static_cast<const int32_t*>(e->d_best_feas.p) + row_begin, n * 4, hipMemcpyDeviceToHost));
+  return SPX_OK;
 }
 
 }  // extern "C"

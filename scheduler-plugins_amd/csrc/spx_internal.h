@@ -123,8 +123,7 @@ struct NetArgs {
   const int32_t* pair_ptr;      // [K+1]
   const int32_t* pair_node;
   const int64_t* pair_max;
-  const uint8_t* feasible;      // optional [P][feasible_stride] mask from the other Filter plugins
-  int64_t feasible_stride;
+  const uint8_t* other_status[2];  // other Filter plugins' status tables [P][row_stride] (0 = passed), NULL = unused
   uint8_t* out_status;
   uint8_t* out_score;
   int64_t* out_raw;             // when set: raw row (row_begin only), no table writes
@@ -160,5 +159,25 @@ struct QuotaArgs {
   uint8_t* out_status;             // [P]
 };
 void launch_quota(const QuotaArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- profile-level passes
+struct ProfileArgs {
+  int64_t n_nodes;
+  int64_t row_stride;
+  int64_t row_begin;
+  int64_t row_end;
+  const uint8_t* status[3];                // filter status tables in play (0 = passed); NULL = unused
+  const uint8_t* prefilter;                // [P] CapacityScheduling.PreFilter status, NULL = unused
+  const int64_t* alloc_raw;                // [N] Allocatable raw scores
+  uint8_t* out_alloc;
+  const uint8_t* score[SPX_NUM_PLUGINS];   // score tables to sum (NULL = not in the profile)
+  int64_t weight[SPX_NUM_PLUGINS];
+  int32_t* best_node;                      // [P]
+  int64_t* best_score;
+  int32_t* best_ties;
+  int32_t* best_feasible;
+};
+void launch_alloc_masked(const ProfileArgs& a, hipStream_t s);
+void launch_best(const ProfileArgs& a, hipStream_t s);
 
 }  // namespace spx

@@ -291,6 +291,34 @@ class Engine:
     def bind_score_table(self, plugin: int, dptr: int, row_stride: int, n_rows: int) -> None:
         self._ck(self._lib.spx_bind_score_table(self._h, plugin, C.c_void_p(dptr), row_stride, n_rows))
 
+    def upload_feasible_mask(self, mask: Optional[np.ndarray]) -> None:
+        """[n_pods][n_nodes] uint8, non-zero = the node passed the caller's other Filter plugins; None clears it."""
+        if mask is None:
+            self._ck(self._lib.spx_upload_feasible_mask(self._h, None, 0, 0))
+            return
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._ck(self._lib.spx_upload_feasible_mask(self._h, mask.ctypes.data_as(C.POINTER(C.c_uint8)), mask.shape[0], mask.shape[1]))
+
+    def set_plugin_weights(self, weights: Dict[int, int]) -> None:
+        w = np.ones(7, dtype=np.int64)
+        for k, v in weights.items():
+            w[k] = v
+        self._ck(self._lib.spx_set_plugin_weights(self._h, w.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    def eval_best(self, plugin_mask: int, row_begin: int = 0, row_end: Optional[int] = None) -> None:
+        self._ck(self._lib.spx_eval_best(self._h, plugin_mask, row_begin, self.n_pods if row_end is None else row_end))
+
+    def best(self, row_begin: int = 0, row_end: Optional[int] = None):
+        """(best node, weighted score, ties, feasible count) per pod row."""
+        row_end = self.n_pods if row_end is None else row_end
+        n = row_end - row_begin
+        node, score = np.zeros(n, np.int32), np.zeros(n, np.int64)
+        ties, feas = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        i32p = C.POINTER(C.c_int32)
+        self._ck(self._lib.spx_fetch_best(self._h, row_begin, row_end, node.ctypes.data_as(i32p), score.ctypes.data_as(C.POINTER(C.c_int64)),
+                                          ties.ctypes.data_as(i32p), feas.ctypes.data_as(i32p)))
+        return node, score, ties, feas
+
     def set_stream(self, stream: int) -> None:
         self._ck(self._lib.spx_set_stream(self._h, C.c_void_p(stream)))
 

@@ -342,7 +342,8 @@ def network_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, p
 
 
 # ------------------------------------------------------------------ CapacityScheduling (config #5's PreFilter gate)
-def synth_quota(hdr: Header, pods: Table, seed: int = SEED, n_namespaces: int = 100, n_nominated: int = 300, device_res: int = -1) -> Table:
+def synth_quota(hdr: Header, pods: Table, seed: int = SEED, n_namespaces: int = 100, n_nominated: int = 300, device_res: int = -1,
+                hugepage_res: int = -1) -> Table:
     """ElasticQuotas for Q namespaces (Q=100): 85% of namespaces carry a quota; Used is drawn
     around Min so that both PreFilter gates fire for a visible share of pods; nominated pods with priorities in
     {0,100,1000}, a few of them being pending pods themselves (the uid exclusion, capacity_scheduling.go:239)."""
@@ -369,11 +370,14 @@ def synth_quota(hdr: Header, pods: Table, seed: int = SEED, n_namespaces: int = 
         mx[:, 4] = mn[:, 4] + rng.integers(0, 64, NS)
         us[:, 4] = rng.integers(0, 80, NS)
         present[:] = 1 << 4
+    if hugepage_res >= 0:  # pods may request hugepages: a scalar resource the quotas do not bound (no key in Min/Max)
+        scalar_res[n_scalar] = hugepage_res
+        n_scalar += 1
     min_present = np.where(rng.random(NS) < 0.9, present, 0).astype(np.uint8)  # some quotas do not list the device in Min
     P = pods.struct.n_pods
     nom_ns = rng.integers(0, NS, n_nominated).astype(np.int32)
     nom_prio = rng.choice(np.array([0, 100, 1000], dtype=np.int32), n_nominated)
-    nom_pods = synth_pods(hdr, max(n_nominated, 1), seed=seed + 99, device_res=device_res, n_namespaces=NS)
+    nom_pods = synth_pods(hdr, max(n_nominated, 1), seed=seed + 99, device_res=device_res, hugepage_res=hugepage_res, n_namespaces=NS)
     pend = np.full(n_nominated, -1, dtype=np.int64)
     k = min(n_nominated // 10, P)
     if k:
@@ -384,3 +388,20 @@ def synth_quota(hdr: Header, pods: Table, seed: int = SEED, n_namespaces: int = 
                  has_quota=has.astype(np.uint8), min=mn.reshape(-1), min_present=min_present, max=mx.reshape(-1),
                  max_present=present, used=us.reshape(-1), used_present=present, n_nominated=n_nominated, nom_ns=nom_ns,
                  nom_priority=nom_prio, nom_pending_index=pend, nom_pods=nom_pods)
+
+
+# ------------------------------------------------------------------ full profile (config #5)
+def full_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, pods_per_group: int = 100,
+                  n_namespaces: int = 100) -> Dict[str, Table]:
+    """One snapshot carrying every table of the full profile: CapacityScheduling PreFilter + Allocatable + NRT +
+    trimaran + network-aware (BASELINE.json config #5)."""
+    snap = nrt_snapshot(hdr, n_nodes, n_pods, seed)  # nodes (with hugepages/devices), NRT, rc
+    n_groups = max(1, n_pods // pods_per_group)
+    snap["pods"] = synth_pods(hdr, n_pods, seed, device_res=RES_DEVICE, hugepage_res=RES_HUGEPAGES_2MI, n_appgroups=n_groups,
+                              n_namespaces=n_namespaces)
+    snap["metrics"] = synth_metrics(hdr, n_nodes, seed)
+    snap["assigned"] = synth_assigned(hdr, n_nodes, seed)
+    snap["appgroups"], snap["nettopo"] = synth_network(hdr, snap["nodes"], n_groups, seed)
+    snap["quota"] = synth_quota(hdr, snap["pods"], seed, n_namespaces=n_namespaces, device_res=RES_DEVICE,
+                                hugepage_res=RES_HUGEPAGES_2MI)
+    return snap

@@ -1,0 +1,94 @@
+"""Full profile on the GPU (CapacityScheduling PreFilter + Allocatable + NRT + trimaran + network-aware):
+Filter plugins feed the feasibility set of the normalising Score plugins exactly as upstream's framework does
+(Score/NormalizeScore run on nodes that passed every Filter), and the per-pod weighted argmax."""
+import numpy as np
+import pytest
+
+from helpers import ALLOCATABLE, CAPACITY, LVRB, NETOVERHEAD, NRT, TLP, lvrb_params, tlp_params
+from scheduler_plugins_amd import objects as O
+from scheduler_plugins_amd import synth
+from scheduler_plugins_amd.engine import Engine, mask_of
+
+pytestmark = pytest.mark.gpu
+
+ALL = (ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY)
+
+
+def load_all(e, hdr, snap, strategy="LeastAllocated"):
+    params = O.nrt_params(hdr, O.Resources(), strategy)
+    e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+    e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+    e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+    e.load_quota_objects(snap["pods"], snap["rc"], snap["quota"])
+    return params
+
+
+@pytest.mark.parametrize("n_nodes,n_pods,seed", [(300, 200, 1), (65, 33, 2)])
+def test_full_profile(gpu_required, hdr, oracle, n_nodes, n_pods, seed):
+    snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=seed, pods_per_group=20, n_namespaces=20)
+    weights = {ALLOCATABLE: 1, TLP: 2, LVRB: 1, NRT: 3, NETOVERHEAD: 2}
+    with Engine(0) as e:
+        params = load_all(e, hdr, snap)
+        e.set_plugin_weights(weights)
+        e.eval(mask_of(*ALL))
+        e.eval_best(mask_of(*ALL))
+        e.sync()
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], metrics=snap["metrics"], assigned=snap["assigned"],
+                                alloc_params=e.alloc_params, tlp_params=tlp_params(hdr), lvrb_params=lvrb_params(hdr),
+                                nrt=snap["nrt"], nrt_params=params, appgroups=snap["appgroups"], nettopo=snap["nettopo"])
+        nrt_status = osnap.filter_rows(NRT)
+        net_status = osnap.filter_rows(NETOVERHEAD)
+        assert np.array_equal(e.all_status(NRT), nrt_status)
+        assert np.array_equal(e.all_status(NETOVERHEAD), net_status)
+        # non-normalising plugins: every cell
+        want = {}
+        for p in (TLP, LVRB, NRT):
+            want[p] = osnap.score_rows(p, want_norm=False)[0].clip(0, 255)
+            assert np.array_equal(e.all_scores(p).astype(np.int64), want[p]), p
+        # NetworkOverhead normalises over nodes that passed NRT's Filter and its own
+        _, want[NETOVERHEAD] = osnap.score_rows(NETOVERHEAD, mask=(nrt_status == 0).astype(np.uint8))
+        assert np.array_equal(e.all_scores(NETOVERHEAD).astype(np.int64), want[NETOVERHEAD])
+        # Allocatable normalises over nodes that passed both Filters
+        feasible = (nrt_status == 0) & (net_status == 0)
+        _, want[ALLOCATABLE] = osnap.score_rows(ALLOCATABLE, mask=feasible.astype(np.uint8))
+        got_a = e.all_scores(ALLOCATABLE).astype(np.int64)
+        assert np.array_equal(got_a, want[ALLOCATABLE])
+        assert len({tuple(r) for r in got_a}) > 1  # rows are no longer identical
+        # CapacityScheduling.PreFilter
+        pre = np.array([oracle.lib().orc_capacity_prefilter(snap["pods"].ref(), snap["rc"].ref(), snap["quota"].ref(), i)
+                        for i in range(n_pods)], dtype=np.uint8)
+        assert np.array_equal(e.prefilter(CAPACITY), pre)
+        # weighted argmax over feasible nodes, ties as sets
+        total = sum(weights[p] * want[p] for p in weights)
+        node, score, ties, feas = e.best()
+        for i in range(n_pods):
+            f = feasible[i]
+            if pre[i] != 0 or not f.any():
+                assert node[i] == -1 and ties[i] == 0, i
+                continue
+            best = total[i][f].max()
+            tie_set = np.nonzero(f & (total[i] == best))[0]
+            assert score[i] == best and ties[i] == len(tie_set) and node[i] == tie_set[0] and feas[i] == f.sum(), i
+
+
+def test_external_mask_drives_allocatable_normalisation(gpu_required, hdr, oracle):
+    snap = synth.trimaran_snapshot(hdr, 257, 64, seed=4)
+    rng = np.random.default_rng(0)
+    mask = (rng.random((64, 257)) < 0.6).astype(np.uint8)
+    mask[3] = 0   # a pod with no feasible node at all
+    mask[5] = 0
+    mask[5, 17] = 1  # a single feasible node: range == 0 -> MinNodeScore
+    with Engine(0) as e:
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        e.upload_feasible_mask(mask)
+        e.eval(mask_of(ALLOCATABLE, TLP))
+        e.sync()
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], metrics=snap["metrics"], assigned=snap["assigned"],
+                                alloc_params=e.alloc_params, tlp_params=tlp_params(hdr))
+        _, norm = osnap.score_rows(ALLOCATABLE, mask=mask)
+        assert np.array_equal(e.all_scores(ALLOCATABLE).astype(np.int64), norm)
+        assert np.array_equal(e.all_scores(TLP).astype(np.int64), osnap.score_rows(TLP)[0])
+        e.upload_feasible_mask(None)
+        e.eval(mask_of(ALLOCATABLE))
+        e.sync()
+        assert np.array_equal(e.all_scores(ALLOCATABLE).astype(np.int64), osnap.score_rows(ALLOCATABLE)[1])
