@@ -40,6 +40,9 @@ WORKLOADS = {
                               desc="noderesourcetopology Filter+Score (LeastNUMANodes), 5k nodes x 8 NUMA zones x 50k pods"),
     "config4": dict(n_nodes=10_000, n_pods=200_000, plugins=("net",), node_row=4, pod_row=48, out=2,
                     desc="networkaware NetworkOverhead (+TopologicalSort keys), 10k nodes x 3-tier topology x 200k pods"),
+    "config5": dict(n_nodes=20_000, n_pods=62_500, plugins=("cap", "alloc", "tlp", "lvrb", "nrt", "net"), node_row=405, pod_row=188, out=7,
+                    strategy="LeastAllocated",
+                    desc="full profile: CapacityScheduling PreFilter + Allocatable + TLP + LVRB + NRT + NetworkOverhead, 20k nodes x 62.5k pods per GPU (500k pods on 8)"),
     "small": dict(n_nodes=1_000, n_pods=4_000, plugins=("alloc", "tlp"), node_row=41, pod_row=8, out=2,
                   desc="plumbing-sized Allocatable + TLP"),
 }
@@ -61,9 +64,12 @@ def cpu_baseline(spx, snap, e, plugins, budget_s: float):
     def run(rows: int) -> float:
         t0 = time.perf_counter()
         for p in plugins:
+            if p == 5:  # CapacityScheduling.PreFilter is per pod, not per (pod,node): negligible, not part of the CPU sample
+                continue
             osnap.score_rows(p, 0, rows, threads=cores, want_raw=False, want_norm=True)
             if p in (3, 4):  # NodeResourceTopologyMatch / NetworkOverhead also have a Filter extension point
                 osnap.filter_rows(p, 0, rows, threads=cores)
+        return time.perf_counter() - t0
         return time.perf_counter() - t0
 
     probe_rows = min(osnap.n_pods, 8 * cores)
@@ -96,6 +102,8 @@ def main() -> None:
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--plugins", default="", help="override the workload's plugin set, e.g. alloc or tlp,lvrb (experiments)")
     ap.add_argument("--round-frac", type=float, default=0.0, help="fraction of nodes with integer-valued metrics (tie stress)")
+    ap.add_argument("--gather", default="best", choices=["none", "best", "table"],
+                    help="N>1 only, measured OUTSIDE the timed region: all-gather of per-pod decisions and (table) of one score slab")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -124,7 +132,7 @@ def main() -> None:
     if args.plugins:
         w["plugins"] = tuple(args.plugins.split(","))
         w["out"] = len(w["plugins"])
-    pid = {"alloc": ALLOCATABLE, "tlp": TLP, "lvrb": LVRB, "nrt": NRT, "net": 4}
+    pid = {"alloc": ALLOCATABLE, "tlp": TLP, "lvrb": LVRB, "nrt": NRT, "net": 4, "cap": 5}
     plugins = [pid[p] for p in w["plugins"]]
     mask = mask_of(*plugins)
     n_nodes, n_pods = w["n_nodes"], w["n_pods"]
@@ -132,7 +140,14 @@ def main() -> None:
     hdr = spx.header()
     # every rank: same node snapshot, its own pod batch (seeded by rank)
     e = Engine(local_rank)
-    if "nrt" in w["plugins"]:
+    if "cap" in w["plugins"]:
+        snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED + 1000 * rank)
+        snap["nrt_params"] = O.nrt_params(hdr, O.Resources(), w["strategy"])
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], snap["nrt_params"])
+        e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+        e.load_quota_objects(snap["pods"], snap["rc"], snap["quota"])
+    elif "nrt" in w["plugins"]:
         snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED)
         if rank:
             snap["pods"] = synth.synth_pods(hdr, n_pods, seed=synth.SEED + 1000 * rank, device_res=synth.RES_DEVICE,
@@ -176,6 +191,35 @@ def main() -> None:
         durs.append(e.last_eval_ms())
     kern_ms = float(np.mean(durs))
 
+    # the exchange step of the sharded path, reported separately: per-pod decisions, optionally one table
+    gather_info = None
+    if dist is not None and args.gather != "none":
+        try:
+            from scheduler_plugins_amd import shard
+            score_mask = mask & ~(1 << 6)
+            e.eval_best(score_mask)
+            node, score, ties, feas = e.best()
+            barrier()
+            t1 = time.perf_counter()
+            shard.gather_best(dist, torch.device("cuda", local_rank), node, score, ties, feas, n_pods * world)
+            barrier()
+            gather_info = {"best_ms": (time.perf_counter() - t1) * 1e3, "bytes_per_rank": int(n_pods) * 32}
+            if args.gather == "table":
+                p0 = plugins[-1] if plugins[-1] <= 4 else plugins[0]
+                ptr, stride, rows = e.score_table(p0)
+                slab = torch.empty((rows, stride), dtype=torch.uint8, device=f"cuda:{local_rank}")
+                e.bind_score_table(p0, slab.data_ptr(), stride, rows)
+                e.eval(1 << p0)
+                e.sync()
+                barrier()
+                t1 = time.perf_counter()
+                full = shard.gather_table(dist, slab)
+                barrier()
+                gather_info.update({"table_ms": (time.perf_counter() - t1) * 1e3, "table_bytes": int(full.numel())})
+                del full
+        except Exception as ex:  # never lose the bench line to the optional exchange measurement
+            gather_info = {"error": repr(ex)[:200]}
+
     evals_per_step = n_nodes * n_pods * world
     value = evals_per_step * args.steps / elapsed
     algo_bytes = n_nodes * w["node_row"] + n_pods * w["pod_row"] + n_nodes * n_pods * w["out"]
@@ -205,6 +249,8 @@ def main() -> None:
                      "algorithmic_bytes": algo_bytes, "frac_of_measured_copy_ceiling_6.29TBs": achieved / 6290.0},
         "kernel_evals_per_sec": n_nodes * n_pods / (kern_ms * 1e-3),
     }
+    if gather_info is not None:
+        out["gather"] = gather_info
     if rank == 0 and world == 1 and args.cpu_budget > 0:
         out["cpu_baseline"] = cpu_baseline(spx, snap, e, plugins, args.cpu_budget)
     e.close()
