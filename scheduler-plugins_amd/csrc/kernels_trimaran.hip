@@ -539,6 +539,147 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LoadVariationRiskBalancing fast path (bit-exact by construction, same scheme as k_tlp_fast2).
+//
+// For a resource in its regular state the reference's score is affine in the pod's request between two clamps:
+//     score_r = (1 - (mu + sigma)/2) * 100 = A - clamp(B*(usedAvg + req), 0, 50),   A = 100 - 50*sigma, B = 50/cap
+// A, B and C = B*usedAvg are per-node constants (sigma includes math.Pow / margin, evaluated once per node in
+// float64); per cell the kernel evaluates two float32 fma + v_med3, min/max, rndne and a tie test.  Non-regular
+// states (metric absent, capacity <= 0) are encoded as A = B = C = 0 (score_r = 0), and "both resources valid"
+// (min instead of max, loadvariationriskbalancing.go:112-116) is one bit per node.
+// |x' - x| <= 50*2.4e-7 + ulp32(100) <= 2e-5; cells within kTolLv of a rounding tie are recomputed exactly
+// (lv_total) from the node's original columns.
+constexpr float kTolLv = 6e-5f;
+
+// per-node exact LVRB state {cap, usedAvg, sigma, state} x {cpu, memory} + has_metrics, computed once per launch so
+// that the per-cell exact fallback is two loads and one division per resource instead of the full lv_make
+__global__ void k_lvrb_prepare(TrimaranArgs a) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= a.n_nodes) return;
+  const uint8_t f = a.lv_flags[n];
+  double mcap = static_cast<double>(a.lv_alloc_mem[n]);
+  mcap *= kMega;
+  const LvRes c = lv_make((f & SPX_LV_CPU_VALID) != 0, static_cast<double>(a.lv_alloc_cpu_milli[n]), a.lv_cpu_avg[n], a.lv_cpu_std[n],
+                          a.lv_margin, a.lv_sensitivity);
+  const LvRes m = lv_make((f & SPX_LV_MEM_VALID) != 0, mcap, a.lv_mem_avg[n], a.lv_mem_std[n], a.lv_margin, a.lv_sensitivity);
+  double* o = a.lv_exact + n * 8;
+  o[0] = c.cap; o[1] = c.used_avg; o[2] = c.sigma; o[3] = static_cast<double>(c.state);
+  o[4] = m.cap; o[5] = m.used_avg; o[6] = m.sigma; o[7] = static_cast<double>(m.state + ((f & SPX_LV_HAS_METRICS) ? 8 : 0));
+}
+
+template <int NPL, bool A>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArgs a, int n_tiles) {
+  static_assert(kPodsPerChunk == kWave, "one pod record per lane");
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+  const int tile = static_cast<int>(unit % n_tiles);
+  const int64_t chunk = unit / n_tiles;
+  const int64_t pod0 = a.row_begin + chunk * kPodsPerChunk;
+  if (pod0 >= a.row_end) return;
+  const int n_rows = static_cast<int>((pod0 + kPodsPerChunk < a.row_end) ? kPodsPerChunk : a.row_end - pod0);
+  const int64_t node0 = (static_cast<int64_t>(tile) * kWave + lane) * NPL;
+  const bool active = node0 < a.row_stride;
+
+  // one pod record per lane: requests as float32 (cpu millicores; memory in MiB like the reference), and whether
+  // the row must take the exact path (negative or huge requests)
+  float my_cpu = 0.0f, my_mem = 0.0f;
+  int my_bad = 0;
+  if (lane < n_rows) {
+    const double rc = static_cast<double>(a.lv_req_cpu_milli[pod0 + lane]);
+    const double rm = static_cast<double>(a.lv_req_mem[pod0 + lane]) * kMega;
+    my_cpu = static_cast<float>(rc);
+    my_mem = static_cast<float>(rm);
+    my_bad = (!(rc >= 0.0) || !(rm >= 0.0) || !(rc < 1e15) || !(rm < 1e15)) ? 1 : 0;
+  }
+  const int cpu_bits = __float_as_int(my_cpu), mem_bits = __float_as_int(my_mem);
+
+  uint32_t alloc_w[NPL / 4];
+  float ca[NPL], cb[NPL], cc[NPL], ma[NPL], mb[NPL], mc[NPL];
+  uint32_t both_bits = 0;
+  if constexpr (A) {
+#pragma unroll
+    for (int j = 0; j < NPL / 4; ++j) alloc_w[j] = active ? reinterpret_cast<const uint32_t*>(a.alloc_norm + node0)[j] : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    const int64_t n = node0 + j;
+    const bool in = n < a.n_nodes;
+    const uint8_t f = in ? a.lv_flags[n] : 0;
+    const bool has = (f & SPX_LV_HAS_METRICS) != 0;
+    double mcap = in ? static_cast<double>(a.lv_alloc_mem[n]) : 0.0;
+    mcap *= kMega;
+    const LvRes c = lv_make(has && (f & SPX_LV_CPU_VALID), in ? static_cast<double>(a.lv_alloc_cpu_milli[n]) : 0.0,
+                            in ? a.lv_cpu_avg[n] : 0.0, in ? a.lv_cpu_std[n] : 0.0, a.lv_margin, a.lv_sensitivity);
+    const LvRes m = lv_make(has && (f & SPX_LV_MEM_VALID), mcap, in ? a.lv_mem_avg[n] : 0.0, in ? a.lv_mem_std[n] : 0.0,
+                            a.lv_margin, a.lv_sensitivity);
+    auto consts = [](const LvRes& r, float* fa, float* fb, float* fc) {
+      if (r.state != 2) {
+        *fa = *fb = *fc = 0.0f;
+        return;
+      }
+      const double b = 50.0 / r.cap;
+      *fa = static_cast<float>(100.0 - 50.0 * r.sigma);
+      *fb = static_cast<float>(b);
+      *fc = static_cast<float>(b * r.used_avg);
+    };
+    consts(c, &ca[j], &cb[j], &cc[j]);
+    consts(m, &ma[j], &mb[j], &mc[j]);
+    both_bits |= (has && c.state != 0 && m.state != 0) ? (1u << j) : 0u;
+  }
+  if (!active) return;
+  constexpr float kHalf = 0.5f - kTolLv;
+
+  for (int r = 0; r < n_rows; ++r) {
+    const int64_t row = (pod0 + r) * a.row_stride + node0;
+    if constexpr (A) store_bytes<NPL>(a.out_alloc + row, alloc_w);
+    const float req_cpu = __int_as_float(__builtin_amdgcn_readlane(cpu_bits, r));
+    const float req_mem = __int_as_float(__builtin_amdgcn_readlane(mem_bits, r));
+    const bool row_bad = __builtin_amdgcn_readlane(my_bad, r) != 0;
+    bool amb[NPL];
+    bool any = row_bad;
+    uint32_t w[NPL / 4];
+#pragma unroll
+    for (int j = 0; j < NPL / 4; ++j) {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = j * 4 + q;
+        const float xc = ca[i] - __builtin_amdgcn_fmed3f(__builtin_fmaf(cb[i], req_cpu, cc[i]), 0.0f, 50.0f);
+        const float xm = ma[i] - __builtin_amdgcn_fmed3f(__builtin_fmaf(mb[i], req_mem, mc[i]), 0.0f, 50.0f);
+        const float x = ((both_bits >> i) & 1u) ? __builtin_fminf(xm, xc) : __builtin_fmaxf(xm, xc);
+        const float rr = __builtin_rintf(x);
+        amb[i] = !(__builtin_fabsf(x - rr) < kHalf);
+        any |= amb[i];
+        acc = __builtin_amdgcn_cvt_pk_u8_f32(rr, q, acc);
+      }
+      w[j] = acc;
+    }
+    if (__builtin_expect(any, 0)) {
+      const double req_cpu_d = fmax(static_cast<double>(a.lv_req_cpu_milli[pod0 + r]), 0.0);
+      const double req_mem_d = fmax(static_cast<double>(a.lv_req_mem[pod0 + r]) * kMega, 0.0);
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        if (amb[i] || row_bad) {  // exact re-evaluation of this cell from the original node columns
+          const int64_t n = node0 + i;
+          uint32_t b = 0;
+          if (n < a.n_nodes) {
+            const double* o = a.lv_exact + n * 8;
+            const int ms = static_cast<int>(o[7]);
+            const LvRes c{o[0], o[1], o[2], static_cast<int>(o[3])};
+            const LvRes m{o[4], o[5], o[6], ms & 7};
+            b = to_u8(lv_total((ms & 8) != 0, c, m, req_cpu_d, req_mem_d));
+          }
+          const int sh = (i & 3) * 8;
+          w[i >> 2] = (w[i >> 2] & ~(0xffu << sh)) | (b << sh);
+        }
+      }
+    }
+    store_bytes<NPL>(a.out_lvrb + row, w);
+  }
+}
+
 // raw int64 Score() of one row (parity harness / direct-call tests); one thread per node
 __global__ void k_trimaran_raw(TrimaranArgs a, int plugin, int64_t pod, int64_t* out) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -621,12 +762,37 @@ void launch_tlp_fast(const TrimaranArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_tlp_fast2<NPL, false>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2);
 }
 
+template <int NPL>
+void launch_lvrb_fast(const TrimaranArgs& a, hipStream_t s) {
+  const int tile_nodes = kWave * NPL;
+  const int n_tiles = static_cast<int>((a.row_stride + tile_nodes - 1) / tile_nodes);
+  const int64_t chunks = (a.row_end - a.row_begin + kPodsPerChunk - 1) / kPodsPerChunk;
+  const unsigned blocks = static_cast<unsigned>((chunks * n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  hipLaunchKernelGGL(k_lvrb_prepare, dim3(static_cast<unsigned>((a.n_nodes + 255) / 256)), dim3(256), 0, s, a);
+  if (a.out_alloc)
+    hipLaunchKernelGGL((k_lvrb_fast<NPL, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles);
+  else
+    hipLaunchKernelGGL((k_lvrb_fast<NPL, false>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles);
+}
+
 void launch_trimaran(const TrimaranArgs& a, hipStream_t s) {
   if (a.row_end <= a.row_begin) return;
   if (!a.out_alloc && !a.out_tlp && !a.out_lvrb) return;
   static const bool exact_only = getenv("SPX_EXACT_ONLY") != nullptr;
-  if (a.out_tlp && !a.out_lvrb && !exact_only && a.tlp_target >= 1.0 && a.tlp_target <= 99.0) {
-    launch_tlp_fast<16>(a, s);
+  const bool tlp_fast_ok = a.tlp_target >= 1.0 && a.tlp_target <= 99.0;
+  if (!exact_only && (a.out_tlp || a.out_lvrb) && (!a.out_tlp || tlp_fast_ok) && (!a.out_lvrb || a.lv_exact)) {
+    // one bit-exact fast kernel per plugin; Allocatable's broadcast row rides with the first of them
+    TrimaranArgs t = a;
+    if (a.out_tlp) {
+      t.out_lvrb = nullptr;
+      launch_tlp_fast<16>(t, s);
+    }
+    if (a.out_lvrb) {
+      t = a;
+      t.out_tlp = nullptr;
+      if (a.out_tlp) t.out_alloc = nullptr;
+      launch_lvrb_fast<8>(t, s);
+    }
     return;
   }
   // nodes per lane: wide stores when only TLP state (3 doubles/node) must stay resident,

@@ -56,6 +56,7 @@ struct spx_engine {
   DevBuf d_tlp_pod, d_lv_rcpu, d_lv_rmem;
   bool tri_pods = false;
   DevBuf d_raw_row;  // int64 [n_nodes] staging for spx_fetch_raw
+  DevBuf d_lv_exact; // double [n_nodes][8] scratch of the LVRB fast kernel
 
   // NodeResourceTopologyMatch
   spx_nrt_params nrt_params{SPX_NRT_LEAST_ALLOCATED, 0, nullptr, nullptr};  // defaults.go:87-90
@@ -307,7 +308,7 @@ int spx_destroy(spx_engine* e) {
   DevBuf* bufs[] = {&e->d_alloc,   &e->d_alloc_w,  &e->d_alloc_raw, &e->d_alloc_norm, &e->d_cap_cpu, &e->d_tlp_util,
                     &e->d_tlp_missing, &e->d_tlp_valid, &e->d_lv_acpu, &e->d_lv_amem, &e->d_lv_cavg, &e->d_lv_cstd,
                     &e->d_lv_mavg, &e->d_lv_mstd,  &e->d_lv_flags,  &e->d_tlp_pod,    &e->d_lv_rcpu, &e->d_lv_rmem,
-                    &e->d_raw_row,   &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
+                    &e->d_raw_row,   &e->d_lv_exact, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
                     &e->d_net_region, &e->d_net_zone, &e->d_net_class, &e->d_net_cls_region, &e->d_net_cls_zone,
@@ -676,6 +677,10 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   a.out_alloc = (A && !masked) ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_ALLOCATABLE].p) : nullptr;
   a.out_tlp = T ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_TLP].p) : nullptr;
   a.out_lvrb = L ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_LVRB].p) : nullptr;
+  if (L) {
+    if ((rc = ensure(e, e->d_lv_exact, static_cast<size_t>(e->n_nodes) * 8 * sizeof(double)))) return rc;
+    a.lv_exact = static_cast<double*>(e->d_lv_exact.p);
+  }
   SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
   if (Q) {
     if ((rc = ensure(e, e->d_q_status, static_cast<size_t>(e->n_pods)))) return rc;

@@ -56,6 +56,7 @@ struct TrimaranArgs {
   const int64_t* lv_req_mem;
   double lv_margin;
   double lv_sensitivity;
+  double* lv_exact;  // scratch [n_nodes][8]: per-node exact LVRB state for the fast kernel's fallback
   // outputs: uint8 [n_pods][row_stride] each (NULL = plugin not evaluated)
   uint8_t* out_alloc;
   uint8_t* out_tlp;
