@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Copies the judged summaries out of gpurun_out/prof_<workload>/ into profiles/<round>/ :
+kernel stats CSV, a PMC summary per kernel, the bench line printed under rocprofv3, and a traffic JSON
+(WRITE_SIZE + 2*FETCH_SIZE per launch of the dominant kernel, per MI355X_MICROARCH.md's gfx950 correction)."""
+import collections
+import csv
+import json
+import shutil
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = ROOT / "profiles" / rnd
+out.mkdir(parents=True, exist_ok=True)
+for d in sorted((ROOT / "gpurun_out").glob("prof_*")):
+    w = d.name[len("prof_"):]
+    stats = d / "trace" / "t_kernel_stats.csv"
+    if not stats.exists():
+        continue
+    shutil.copy(stats, out / f"{w}_kernel_stats.csv")
+    rows = list(csv.DictReader(open(stats)))
+    dom = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    bench_line = [l for l in open(d / "trace.log") if l.startswith("{")]
+    summ = {"workload": w, "dominant_kernel": dom["Name"], "rocprof_avg_ns": float(dom["AverageNs"]), "calls": int(dom["Calls"])}
+    if bench_line:
+        b = json.loads(bench_line[-1])
+        summ["bench_kernel_ms_under_rocprof"] = b["roofline"]["kernel_ms"]
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for pm in sorted(d.glob("pmc*/p_counter_collection.csv")):
+        for r in csv.DictReader(open(pm)):
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    key = dom["Name"]
+    counters = {c: sum(v) / len(v) for c, v in acc.get(key, {}).items()}
+    summ["pmc_mean_per_dispatch"] = counters
+    if "WRITE_SIZE" in counters and "FETCH_SIZE" in counters:
+        summ["write_bytes"] = counters["WRITE_SIZE"] * 1024
+        summ["fetch_bytes_corrected"] = counters["FETCH_SIZE"] * 1024 * 2
+        summ["traffic_bytes_per_launch"] = summ["write_bytes"] + summ["fetch_bytes_corrected"]
+        summ["note"] = ("WRITE_SIZE/FETCH_SIZE are KiB per dispatch from separate --pmc passes; FETCH_SIZE doubled per "
+                        "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)")
+    (out / f"{w}_traffic.json").write_text(json.dumps(summ, indent=1) + "\n")
+    print(w, dom["Name"][:60], f"avg {float(dom['AverageNs'])/1e6:.3f} ms", "traffic", summ.get("traffic_bytes_per_launch"))

@@ -1,0 +1,15 @@
+# collects rocprofv3 kernel-trace stats + PMC (separate passes) for the bench workloads -> gpurun_out/prof_<workload>/
+set -u
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+for W in "$@"; do
+  OUT=$R/gpurun_out/prof_$W
+  mkdir -p $OUT
+  cd /tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py --workload $W --cpu-budget 0 --steps 10 --warmup 2 > $OUT/trace.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc1 -o p -- python $R/bench.py --workload $W --cpu-budget 0 --steps 3 --warmup 1 > $OUT/pmc1.log 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_LDS --output-format csv -d $OUT/pmc2 -o p -- python $R/bench.py --workload $W --cpu-budget 0 --steps 3 --warmup 1 > $OUT/pmc2.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc3 -o p -- python $R/bench.py --workload $W --cpu-budget 0 --steps 3 --warmup 1 > $OUT/pmc3.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc4 -o p -- python $R/bench.py --workload $W --cpu-budget 0 --steps 3 --warmup 1 > $OUT/pmc4.log 2>&1
+  tail -1 $OUT/trace.log | cut -c1-200
+done
