@@ -97,8 +97,8 @@ def measured_traffic(workload: str):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--plugins", default="", help="override the workload's plugin set, e.g. alloc or tlp,lvrb (experiments)")
     ap.add_argument("--round-frac", type=float, default=0.0, help="fraction of nodes with integer-valued metrics (tie stress)")
@@ -168,13 +168,20 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the engine launches on torch's current stream so that torch.cuda.Event brackets exactly its kernels
+    tstream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(tstream)
+    e.set_stream(tstream.cuda_stream)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(args.warmup):
         e.eval(mask)
     e.sync()
     barrier()
     t0 = time.perf_counter()
+    ev0.record(tstream)
     for _ in range(args.steps):
         e.eval(mask)
+    ev1.record(tstream)
     e.sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -182,14 +189,9 @@ def main() -> None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    # per-launch kernel duration with HIP events on the engine's own stream (spx_last_eval_ms), measured in a
-    # separate loop so that event reads do not sit inside the timed region above
-    durs = []
-    for _ in range(max(5, min(args.steps, 20))):
-        e.eval(mask)
-        durs.append(e.last_eval_ms())
-    kern_ms = float(np.mean(durs))
+    # average launch duration of the sweep measured with HIP events over the timed region itself (back-to-back
+    # launches, sustained clocks); a plugin set evaluated by more than one kernel counts all of them as one launch
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
 
     # the exchange step of the sharded path, reported separately: per-pod decisions, optionally one table
     gather_info = None
