@@ -19,7 +19,8 @@ OBJ = PKG / "_obj"
 LIB = PKG / "libspx.so"
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+EXTRA = os.environ.get("SPX_EXTRA_CFLAGS", "").split()
+COMMON = [*EXTRA, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
           f"-I{ROOT / 'include'}"]
 DEVICE = ["--offload-arch=gfx950"]
 

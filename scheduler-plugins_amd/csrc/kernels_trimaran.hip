@@ -197,21 +197,23 @@ __device__ __forceinline__ uint32_t to_u8(double unrounded) {
   return static_cast<uint32_t>(v);
 }
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int NPL>
 struct Vec;
 template <>
 struct Vec<4> { using T = uint32_t; };
 template <>
-struct Vec<8> { using T = uint2; };
+struct Vec<8> { using T = u32x2; };
 template <>
-struct Vec<16> { using T = uint4; };
+struct Vec<16> { using T = u32x4; };
 
 template <int NPL>
 __device__ __forceinline__ void store_bytes(uint8_t* dst, const uint32_t (&w)[NPL / 4]) {
   using V = typename Vec<NPL>::T;
   V v;
   __builtin_memcpy(&v, w, sizeof(V));
-  *reinterpret_cast<V*>(dst) = v;
+  *reinterpret_cast<V*>(dst) = v;  // non-temporal stores measured: no gain (0.457 vs 0.464 ms on config #2)
 }
 
 template <int NPL, bool A, bool T, bool L>
@@ -423,9 +425,10 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast(TrimaranArgs
 // With u = (util_millis + missing - T*cap/100) + pod   [millicores above the target line]
 //      pred - T = k*u,  k = 100/cap, and the reference's two branches become
 //      u > 0 :  x = T   - (c1*k)*u          u <= 0 :  x = 100 + (c2*k)*u
-// u needs float64 (1.3e5 millicores with a fractional part) but x in [-1,101] does not: once u is
-// formed (ONE v_add_f64: u = b2 + pod, b2 per node), everything after it runs in float32:
-// cvt, select(coef, off), fma, rndne, tie test, v_cvt_pk_u8_f32 (convert+clamp+pack in one op).
+// u is ~1e5 millicores with a fractional part, but pod is an integer and b2 is a per-node constant: with
+// b2 = b2h + b2l (b2h integer-valued, |b2l| <= 0.5) the sum u = (pod + b2h) + b2l costs two float32 adds, the first
+// exact, the second rounding once — no float64 op is left in the per-cell path.  After it:
+// select(coef, off), fma, rndne, tie test, v_cvt_pk_u8_f32 (convert+clamp+pack in one op).
 // |x' - x| <= |coef*u| * 1.2e-7 + ulp32(100)/2 <= 1.7e-5 for x >= -1 (for x < -1 only the sign
 // matters and it cannot flip), so lanes with |frac(x') - .5| >= kTol32 = 4e-5 and |u| >= 1e-6 are
 // provably the exact result; the others ("ambiguous", ~8e-5 of cells on continuous inputs) are
@@ -448,12 +451,14 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
   const int64_t node0 = (static_cast<int64_t>(tile) * kWave + lane) * NPL;
   const bool active = node0 < a.row_stride;
 
-  // one pod record per lane, converted once
-  const double my_pod = (lane < n_rows) ? static_cast<double>(a.tlp_pod_milli[pod0 + lane]) : 0.0;
-  const int pod_lo = __double2loint(my_pod), pod_hi = __double2hiint(my_pod);
+  // one pod record per lane: predicted millicores as float32 (exact below 2^23; larger or negative values send
+  // the whole row to the exact path)
+  const int64_t my_pod_i = (lane < n_rows) ? a.tlp_pod_milli[pod0 + lane] : 0;
+  const int pod_bits = __float_as_int(static_cast<float>(my_pod_i));
+  const int pod_bad = (my_pod_i < 0 || my_pod_i >= (1 << 23)) ? 1 : 0;
 
   uint32_t alloc_w[NPL / 4];
-  double b2[NPL];
+  float b2h[NPL], b2l[NPL];  // b2 = b2h + b2l, b2h integer-valued with |b2h| < 2^23, |b2l| <= 0.5
   float kc1[NPL], kc2[NPL];
   const double t = a.tlp_target;
   if constexpr (A) {
@@ -466,6 +471,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
     const bool in = n < a.n_nodes;
     double b = 1e30;       // invalid / padding: u huge -> x' = T - u -> cvt_pk_u8 gives 0, never ambiguous
     float f1 = -1.0f, f2 = 0.0f;
+    bool split = false;
     if (in && a.tlp_valid[n] != 0) {
       const double cap = static_cast<double>(a.cap_cpu_milli[n]);
       const double um = (a.tlp_cpu_util[n] / 100.0) * cap;
@@ -480,22 +486,32 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
         b = (um + miss) - t * cap / 100.0;
         f1 = static_cast<float>(-c1 * k);
         f2 = static_cast<float>(c2 * k);
+        split = __builtin_fabs(b) < 8388607.0;
+        if (!split) b = __builtin_nan("");  // beyond the exact float32 integer range: always the exact path
       }
     }
-    b2[j] = b;
+    // u = (pod + b2h) + b2l: the first add is exact (two integers below 2^23), the second rounds once — the same
+    // single float32 rounding a float64 add followed by a conversion would make, without the two float64-rate ops
+    const double bh = split ? __builtin_rint(b) : b;
+    b2h[j] = static_cast<float>(bh);
+    b2l[j] = split ? static_cast<float>(b - bh) : 0.0f;
     kc1[j] = f1;
     kc2[j] = f2;
   }
-  if (!active) return;
+  // no early exit for lanes past the row: every lane stays live so that the v_readlane broadcasts below always read
+  // registers that were written under a full exec mask (stores are guarded by `active` instead)
   const float tf = static_cast<float>(t);
   constexpr float kHalf = 0.5f - kTol32;
 
   for (int r = 0; r < n_rows; ++r) {
     const int64_t row = (pod0 + r) * a.row_stride + node0;
-    if constexpr (A) store_bytes<NPL>(a.out_alloc + row, alloc_w);
-    const double pod_milli = __hiloint2double(__builtin_amdgcn_readlane(pod_hi, r), __builtin_amdgcn_readlane(pod_lo, r));
+    if constexpr (A) {
+      if (active) store_bytes<NPL>(a.out_alloc + row, alloc_w);
+    }
+    const float pod_f = __int_as_float(__builtin_amdgcn_readlane(pod_bits, r));
+    const bool row_bad = __builtin_amdgcn_readlane(pod_bad, r) != 0;
     bool amb[NPL];
-    bool any = !(pod_milli >= 0.0) || !(pod_milli < 1e15);
+    bool any = row_bad;
     uint32_t w[NPL / 4];
 #pragma unroll
     for (int j = 0; j < NPL / 4; ++j) {
@@ -503,7 +519,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = j * 4 + q;
-        const float u = static_cast<float>(b2[i] + pod_milli);
+        const float u = (pod_f + b2h[i]) + b2l[i];
         const bool gt = __float_as_int(u) > 0;  // u > 0 on the float's bit pattern (NaN is caught by the tie test)
         const float x = __builtin_fmaf(gt ? kc1[i] : kc2[i], u, gt ? tf : 100.0f);
         const float rr = __builtin_rintf(x);
@@ -514,7 +530,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
       w[j] = acc;
     }
     if (__builtin_expect(any, 0)) {
-      const bool row_bad = !(pod_milli >= 0.0) || !(pod_milli < 1e15);
+      const double pod_milli = static_cast<double>(a.tlp_pod_milli[pod0 + r]);
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
         if (amb[i] || row_bad) {  // exact re-evaluation of this cell from the original node columns
@@ -535,7 +551,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
         }
       }
     }
-    store_bytes<NPL>(a.out_tlp + row, w);
+    if (active) store_bytes<NPL>(a.out_tlp + row, w);
   }
 }
 
@@ -628,12 +644,13 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
     consts(m, &ma[j], &mb[j], &mc[j]);
     both_bits |= (has && c.state != 0 && m.state != 0) ? (1u << j) : 0u;
   }
-  if (!active) return;
-  constexpr float kHalf = 0.5f - kTolLv;
+  constexpr float kHalf = 0.5f - kTolLv;  // (no early exit: see k_tlp_fast2)
 
   for (int r = 0; r < n_rows; ++r) {
     const int64_t row = (pod0 + r) * a.row_stride + node0;
-    if constexpr (A) store_bytes<NPL>(a.out_alloc + row, alloc_w);
+    if constexpr (A) {
+      if (active) store_bytes<NPL>(a.out_alloc + row, alloc_w);
+    }
     const float req_cpu = __int_as_float(__builtin_amdgcn_readlane(cpu_bits, r));
     const float req_mem = __int_as_float(__builtin_amdgcn_readlane(mem_bits, r));
     const bool row_bad = __builtin_amdgcn_readlane(my_bad, r) != 0;
@@ -676,7 +693,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
         }
       }
     }
-    store_bytes<NPL>(a.out_lvrb + row, w);
+    if (active) store_bytes<NPL>(a.out_lvrb + row, w);
   }
 }
 
