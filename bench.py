@@ -193,6 +193,27 @@ def main() -> None:
     # launches, sustained clocks); a plugin set evaluated by more than one kernel counts all of them as one launch
     kern_ms = ev0.elapsed_time(ev1) / args.steps
 
+    # SURVEY §8d(ii) "full-cycle ms": snapshot delta (host flatten + H2D of the SoA columns) + sweep + device-side
+    # per-row argmax + D2H of the per-pod decisions — measured once, outside the timed region, wall clock
+    full_cycle = None
+    if args.workload.startswith("config2") and not args.plugins:
+        try:
+            barrier()
+            c0 = time.perf_counter()
+            e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+            c1 = time.perf_counter()
+            e.eval(mask)
+            e.eval_best(mask)
+            e.sync()
+            c2 = time.perf_counter()
+            e.best()
+            c3 = time.perf_counter()
+            full_cycle = {"ms": (c3 - c0) * 1e3, "flatten_upload_ms": (c1 - c0) * 1e3, "eval_argmax_ms": (c2 - c1) * 1e3,
+                          "fetch_decisions_ms": (c3 - c2) * 1e3,
+                          "what": "objects->SoA flatten + H2D, sweep, per-row weighted argmax, D2H of 32 B/pod decisions"}
+        except Exception as ex:
+            full_cycle = {"error": repr(ex)[:200]}
+
     # the exchange step of the sharded path, reported separately: per-pod decisions, optionally one table
     gather_info = None
     if dist is not None and args.gather != "none":
@@ -251,6 +272,8 @@ def main() -> None:
                      "algorithmic_bytes": algo_bytes, "frac_of_measured_copy_ceiling_6.29TBs": achieved / 6290.0},
         "kernel_evals_per_sec": n_nodes * n_pods / (kern_ms * 1e-3),
     }
+    if full_cycle is not None:
+        out["full_cycle"] = full_cycle
     if gather_info is not None:
         out["gather"] = gather_info
     if rank == 0 and world == 1 and args.cpu_budget > 0:

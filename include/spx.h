@@ -516,6 +516,11 @@ int spx_fetch_best(spx_engine* e, int64_t row_begin, int64_t row_end, int32_t* n
 /* duration in ms of the last spx_eval's kernels measured with HIP events on the engine stream */
 int spx_last_eval_ms(spx_engine* e, float* ms);
 
+/* which formulation of a plugin's sweep the uploaded tables select: 0 = generic (reference arithmetic, operation for
+ * operation), 1 = fast formulation (same results; see DESIGN.md for each kernel's preconditions); <0 on error.
+ * Tests use it to make sure both formulations are exercised. */
+int spx_kernel_path(const spx_engine* e, int plugin);
+
 /* ------------------------------------------------------------------ host flatteners (object -> SoA) */
 
 /* output buffers are caller-allocated with the sizes noted */

@@ -15,6 +15,8 @@
 //
 // Reference: pkg/noderesourcetopology/filter.go:42-258, score.go:62-191, least_numa.go:35-233,
 // least_allocated.go, most_allocated.go, balanced_allocation.go, numaresources.go:105-215.
+#include <cstdlib>
+
 #include "spx_internal.h"
 
 namespace spx {
@@ -470,6 +472,8 @@ __global__ __launch_bounds__(256, 2) void k_nrt(NrtArgs a, int n_tiles) {
 
 void launch_nrt(const NrtArgs& a, hipStream_t s) {
   if (a.row_end <= a.row_begin) return;
+  static const bool generic_only = getenv("SPX_NRT_GENERIC") != nullptr;  // experiments / differential tests
+  if (!generic_only && launch_nrt_fast(a, s)) return;
   const int n_tiles = static_cast<int>((a.n_nodes + 63) / 64);
   const int64_t chunks = (a.row_end - a.row_begin + kPodsPerUnit - 1) / kPodsPerUnit;
   const unsigned blocks = static_cast<unsigned>((chunks * n_tiles + 3) / 4);

@@ -66,6 +66,10 @@ struct spx_engine {
   bool nrt_slots = false, nrt_nodes = false, nrt_pods = false;
   DevBuf d_nrt_flags, d_nrt_max_numa, d_nrt_nz, d_nrt_zid, d_nrt_zp, d_nrt_avail, d_nrt_cost, d_nrt_minavg, d_nrt_np;
   DevBuf d_nrt_qos, d_nrt_nn, d_nrt_nctr, d_nrt_ckind, d_nrt_cpres, d_nrt_creq, d_nrt_ppres, d_nrt_preq;
+  // float64 formulation of the NRT sweep (kernels_nrt_fast.hip): derived tables + whether its preconditions hold
+  DevBuf d_nrt_fav, d_nrt_frc, d_nrt_fcpu, d_nrt_frep, d_nrt_cq2, d_nrt_pq2, d_nrt_wtab, d_nrt_phdr;
+  bool nrt_fast_slots = false, nrt_fast_nodes = false, nrt_fast_pods = false;
+  int32_t nrt_cpu_slot = -1;
   DevBuf status[SPX_NUM_PLUGINS];
 
   // NetworkOverhead / TopologicalSort
@@ -236,7 +240,25 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   na.ctr_req = static_cast<const int64_t*>(e->d_nrt_creq.p);
   na.pod_present = static_cast<const uint8_t*>(e->d_nrt_ppres.p);
   na.pod_req = static_cast<const int64_t*>(e->d_nrt_preq.p);
+  na.fast = e->nrt_fast_slots && e->nrt_fast_nodes && e->nrt_fast_pods;
+  na.cpu_slot = e->nrt_cpu_slot;
+  for (int i = 0; i < SPX_NRT_MAX_RES; ++i) na.slot_weight_f[i] = static_cast<double>(e->nrt_slot_weight[i]);
+  na.f_av = static_cast<const double*>(e->d_nrt_fav.p);
+  na.f_rc = static_cast<const double*>(e->d_nrt_frc.p);
+  na.f_cpu = static_cast<const double*>(e->d_nrt_fcpu.p);
+  na.f_rep = static_cast<const uint8_t*>(e->d_nrt_frep.p);
+  na.ctr_q2 = static_cast<const double*>(e->d_nrt_cq2.p);
+  na.pod_q2 = static_cast<const double*>(e->d_nrt_pq2.p);
+  na.wtab = static_cast<const double*>(e->d_nrt_wtab.p);
+  na.pod_hdr = static_cast<const uint32_t*>(e->d_nrt_phdr.p);
 }
+
+// quantities the float64 NRT kernel may hold exactly, with room for x100 and the reciprocal trick
+constexpr int64_t kNrtFastLimit = int64_t{1} << 42;
+inline bool nrt_fast_qty(int64_t v) { return v >= 0 && v < kNrtFastLimit; }
+// RN(1/v) * (1 + 2^-49): floor(num * rc) == num / v for 0 <= num <= 101 * v, 0 < v < 2^42 (kernels_nrt_fast.hip)
+inline double nrt_biased_rcp(double v) { return v > 0.0 ? (1.0 / v) * (1.0 + 0x1p-49) : 0.0; }
+inline int64_t nrt_value_of(bool is_cpu, int64_t q) { return is_cpu ? (q + 999) / 1000 : q; }
 
 void fill_net(const spx_engine* e, spx::NetArgs& g) {
   g.n_nodes = e->n_nodes;
@@ -311,6 +333,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_raw_row,   &e->d_lv_exact, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
+                    &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_cq2,   &e->d_nrt_pq2, &e->d_nrt_wtab, &e->d_nrt_phdr,
                     &e->d_net_region, &e->d_net_zone, &e->d_net_class, &e->d_net_cls_region, &e->d_net_cls_zone,
                     &e->d_net_rcost, &e->d_net_zcost, &e->d_net_pod_key, &e->d_net_key_flag, &e->d_net_pair_ptr,
                     &e->d_net_pair_node, &e->d_net_pair_max, &e->d_q_pod_ns, &e->d_q_pod_prio, &e->d_q_pod_req, &e->d_q_pod_reqp,
@@ -448,6 +471,29 @@ int spx_upload_nrt_slots(spx_engine* e, const spx_nrt_slots* t) {
   }
   e->nrt_slots = true;
   e->nrt_nodes = e->nrt_pods = false;  // tables are laid out by slot count
+  // float64 formulation: weight-subset table, cpu slot, weight range
+  SPX_HIP(e, hipSetDevice(e->device));
+  e->nrt_cpu_slot = -1;
+  e->nrt_fast_slots = true;
+  int64_t wtotal = 0;
+  for (int i = 0; i < t->n_res; ++i) {
+    if (t->slot_flags[i] & SPX_NRT_SLOT_CPU) e->nrt_cpu_slot = i;
+    if (t->slot_weight[i] < 0 || t->slot_weight[i] >= kNrtFastLimit / 128) e->nrt_fast_slots = false;
+    else wtotal += t->slot_weight[i];
+  }
+  if (wtotal >= kNrtFastLimit / 128) e->nrt_fast_slots = false;
+  std::vector<double> wtab(static_cast<size_t>(2) << t->n_res, 0.0);
+  if (e->nrt_fast_slots)
+    for (unsigned m = 0; m < (1u << t->n_res); ++m) {
+      int64_t w = 0;
+      for (int i = 0; i < t->n_res; ++i)
+        if ((m >> i) & 1u) w += t->slot_weight[i];
+      wtab[2 * m] = static_cast<double>(w);
+      wtab[2 * m + 1] = nrt_biased_rcp(static_cast<double>(w));
+    }
+  int rc = upload(e, e->d_nrt_wtab, wtab.data(), wtab.size() * sizeof(double));
+  if (rc) return rc;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
   return SPX_OK;
 }
 
@@ -469,6 +515,36 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
   if ((rc = upload_transposed(e, e->d_nrt_avail, t->zone_avail, n, Zm * t->n_res))) return rc;
   if ((rc = upload_transposed(e, e->d_nrt_cost, t->zone_cost, n, Zm * Zm))) return rc;
   if ((rc = upload_transposed(e, e->d_nrt_minavg, t->min_avg_dist, n, Zm))) return rc;
+  {  // float64 formulation: derived columns + precondition check
+    const int64_t R = t->n_res;
+    std::vector<double> av(static_cast<size_t>(Zm * R * n), -1.0), rcp(static_cast<size_t>(Zm * R * n), 0.0),
+        cpuv(static_cast<size_t>(Zm * n), 0.0);
+    std::vector<uint8_t> rep(static_cast<size_t>((R > 0 ? R : 1) * n), 0);
+    bool ok = true;
+    for (int64_t i = 0; i < n; ++i) {
+      const int nz = t->n_zones[i];
+      for (int z = 0; z < nz && z < Zm; ++z) {
+        if (t->zone_id[i * Zm + z] != z) ok = false;  // "lowest NUMA id" must be "lowest list position"
+        for (int64_t r = 0; r < R; ++r) {
+          if (!((t->zone_present[i * Zm + z] >> r) & 1u)) continue;
+          const int64_t cap = t->zone_avail[(i * Zm + z) * R + r];
+          if (!nrt_fast_qty(cap)) ok = false;
+          const bool is_cpu = r == e->nrt_cpu_slot;
+          const double cap_v = static_cast<double>(nrt_value_of(is_cpu, cap));
+          av[static_cast<size_t>((z * R + r) * n + i)] = static_cast<double>(cap);
+          rcp[static_cast<size_t>((z * R + r) * n + i)] = nrt_biased_rcp(cap_v);
+          if (is_cpu) cpuv[static_cast<size_t>(z * n + i)] = cap_v;
+          rep[static_cast<size_t>(r * n + i)] |= static_cast<uint8_t>(1u << z);
+        }
+      }
+    }
+    e->nrt_fast_nodes = ok;
+    if ((rc = upload(e, e->d_nrt_fav, av.data(), av.size() * sizeof(double)))) return rc;
+    if ((rc = upload(e, e->d_nrt_frc, rcp.data(), rcp.size() * sizeof(double)))) return rc;
+    if ((rc = upload(e, e->d_nrt_fcpu, cpuv.data(), cpuv.size() * sizeof(double)))) return rc;
+    if ((rc = upload(e, e->d_nrt_frep, rep.data(), rep.size()))) return rc;
+    SPX_HIP(e, hipStreamSynchronize(e->stream));
+  }
   e->nrt_nodes = true;
   return SPX_OK;
 }
@@ -490,6 +566,37 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
   if ((rc = upload(e, e->d_nrt_creq, t->ctr_req, p * Cm * R * 8))) return rc;
   if ((rc = upload(e, e->d_nrt_ppres, t->pod_present, p))) return rc;
   if ((rc = upload(e, e->d_nrt_preq, t->pod_req, p * R * 8))) return rc;
+  {  // float64 formulation: (request, Value(request)) pairs + precondition check
+    std::vector<double> cq(p * Cm * R * 2), pq(p * R * 2);
+    bool ok = true;
+    for (size_t i = 0; i < p * Cm * R; ++i) {
+      const int64_t q = t->ctr_req[i];
+      if (!nrt_fast_qty(q)) ok = false;
+      cq[2 * i] = static_cast<double>(q);
+      cq[2 * i + 1] = static_cast<double>(nrt_value_of(static_cast<int32_t>(i % R) == e->nrt_cpu_slot, q));
+    }
+    for (size_t i = 0; i < p * R; ++i) {
+      const int64_t q = t->pod_req[i];
+      if (!nrt_fast_qty(q)) ok = false;
+      pq[2 * i] = static_cast<double>(q);
+      pq[2 * i + 1] = static_cast<double>(nrt_value_of(static_cast<int32_t>(i % R) == e->nrt_cpu_slot, q));
+    }
+    std::vector<uint32_t> hdr(p * 8, 0u);
+    for (size_t i = 0; i < p; ++i) {
+      uint32_t* w = &hdr[i * 8];
+      w[0] = t->qos[i] | (static_cast<uint32_t>(t->non_native[i] != 0) << 8) | (static_cast<uint32_t>(t->n_ctr[i]) << 16) |
+             (static_cast<uint32_t>(t->pod_present[i]) << 24);
+      for (size_t c = 0; c < Cm; ++c) {
+        w[1 + c / 4] |= static_cast<uint32_t>(t->ctr_kind[i * Cm + c]) << (8 * (c % 4));
+        w[3 + c / 4] |= static_cast<uint32_t>(t->ctr_present[i * Cm + c]) << (8 * (c % 4));
+      }
+    }
+    if ((rc = upload(e, e->d_nrt_phdr, hdr.data(), hdr.size() * sizeof(uint32_t)))) return rc;
+    e->nrt_fast_pods = ok;
+    if ((rc = upload(e, e->d_nrt_cq2, cq.data(), cq.size() * sizeof(double)))) return rc;
+    if ((rc = upload(e, e->d_nrt_pq2, pq.data(), pq.size() * sizeof(double)))) return rc;
+    SPX_HIP(e, hipStreamSynchronize(e->stream));
+  }
   e->nrt_pods = true;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   return SPX_OK;
@@ -767,6 +874,17 @@ int spx_sync(spx_engine* e) {
   if (!e) return SPX_ERR_ARG;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   return SPX_OK;
+}
+
+int spx_kernel_path(const spx_engine* e, int plugin) {
+  if (!e) return SPX_ERR_ARG;
+  if (plugin == SPX_PLUGIN_NRT)
+    return (e->nrt_fast_slots && e->nrt_fast_nodes && e->nrt_fast_pods && e->nrt_params.strategy != SPX_NRT_LEAST_NUMA_NODES &&
+            getenv("SPX_NRT_GENERIC") == nullptr)
+               ? 1
+               : 0;
+  if (plugin == SPX_PLUGIN_TLP) return (e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && getenv("SPX_EXACT_ONLY") == nullptr) ? 1 : 0;
+  return 0;
 }
 
 int spx_last_eval_ms(spx_engine* e, float* ms) {

@@ -100,8 +100,22 @@ struct NrtArgs {
   uint8_t* out_status;           // [P][row_stride]
   uint8_t* out_score;            // [P][row_stride]
   int64_t* out_raw;              // when set: raw int64 scores of row_begin only, no table writes
+  // float64 formulation (kernels_nrt_fast.hip); `fast` is set only when the engine verified its preconditions
+  int32_t fast;
+  int32_t cpu_slot;              // slot whose quantities are millicores (-1: none)
+  double slot_weight_f[SPX_NRT_MAX_RES];
+  const double* f_av;            // [Z][n_res][N] reported ? available : -1
+  const double* f_rc;            // [Z][n_res][N] biased reciprocal of Value(capacity)
+  const double* f_cpu;           // [Z][N] Value() of the cpu capacity
+  const uint8_t* f_rep;          // [n_res][N] mask of the zones reporting the resource
+  const double* ctr_q2;          // [P][8][n_res][2] (request, Value(request))
+  const double* pod_q2;          // [P][n_res][2]
+  const uint32_t* pod_hdr;       // [P][8] packed qos / non_native / n_ctr / pod_present / ctr_kind[8] / ctr_present[8]
+  const double* wtab;            // [2^n_res][2] (sum of weights of the resource subset, its biased reciprocal)
 };
 void launch_nrt(const NrtArgs& a, hipStream_t s);
+// returns false when the float64 kernel does not apply (preconditions, LeastNUMANodes)
+bool launch_nrt_fast(const NrtArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- NetworkOverhead
 struct NetArgs {

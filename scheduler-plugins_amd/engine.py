@@ -265,6 +265,10 @@ class Engine:
     def sync(self) -> None:
         self._ck(self._lib.spx_sync(self._h))
 
+    def kernel_path(self, plugin: int) -> int:
+        """0 = generic sweep kernel, 1 = fast formulation (same results)."""
+        return int(self._lib.spx_kernel_path(self._h, plugin))
+
     def last_eval_ms(self) -> float:
         ms = C.c_float()
         self._ck(self._lib.spx_last_eval_ms(self._h, C.byref(ms)))

@@ -102,6 +102,8 @@ def test_differential(gpu_required, hdr, oracle, strategy, n_nodes, n_pods, seed
     params = O.nrt_params(hdr, res, strategy, {"cpu": 2} if seed == 4 else None)
     with Engine(0) as e:
         e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+        # synthetic snapshots satisfy the float64 kernel's preconditions; LeastNUMANodes always runs the generic kernel
+        assert e.kernel_path(NRT) == (0 if strategy == "LeastNUMANodes" else 1)
         e.eval(mask_of(NRT))
         e.sync()
         osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
@@ -116,6 +118,70 @@ def test_differential(gpu_required, hdr, oracle, strategy, n_nodes, n_pods, seed
         assert bad.size == 0, f"score: {len(bad)} mismatches, first {[(int(p), int(n), int(got_score[p, n]), int(want_score[p, n])) for p, n in bad[:5]]}"
         for r in sorted({0, n_pods // 2, n_pods - 1}):
             assert np.array_equal(e.raw(NRT, r), want_score[r])
+
+
+@pytest.mark.parametrize("strategy", ["LeastAllocated", "MostAllocated", "BalancedAllocation"])
+@pytest.mark.parametrize("how", ["huge_zone_quantity", "huge_request", "permuted_numa_ids"])
+def test_differential_generic_kernel(gpu_required, hdr, oracle, strategy, how):
+    """snapshots that break a precondition of the float64 formulation must select the generic int64 kernel and
+    still match the oracle bit for bit"""
+    snap = synth.nrt_snapshot(hdr, 150, 70, seed=11)
+    if how == "huge_zone_quantity":
+        q = snap["nrt"].array("zres_avail")
+        q[np.flatnonzero(snap["nrt"].array("zres_res") == 1)[3]] = 1 << 45
+    elif how == "huge_request":
+        q = snap["pods"].array("req_qty")
+        i = np.flatnonzero(snap["pods"].array("req_res") == 1)[5]
+        q[i] = 1 << 50
+        # the matching limit is left alone: that pod's QoS class changes, identically for the engine and the oracle
+    else:
+        ids = snap["nrt"].array("zone_numa_id")
+        ptr = snap["nrt"].array("zone_ptr")
+        for n in range(0, 150, 7):  # reverse the ids of some nodes: lowest id != lowest list position
+            ids[ptr[n]:ptr[n + 1]] = ids[ptr[n]:ptr[n + 1]][::-1].copy()
+    res = O.Resources()
+    params = O.nrt_params(hdr, res, strategy)
+    with Engine(0) as e:
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+        assert e.kernel_path(NRT) == 0
+        e.eval(mask_of(NRT))
+        e.sync()
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
+        assert np.array_equal(e.all_status(NRT), osnap.filter_rows(NRT))
+        assert np.array_equal(e.all_scores(NRT).astype(np.int64), osnap.score_rows(NRT, want_norm=False)[0].clip(0, 255))
+
+
+def test_float64_kernel_boundaries(gpu_required, hdr, oracle):
+    """quantities at the edge of the float64 formulation's range (just under 2^42) and exact-multiple / off-by-one
+    quotients: floor(num * biased_rcp) must equal the int64 division everywhere"""
+    snap = synth.nrt_snapshot(hdr, 128, 64, seed=12, vary=False)
+    q = snap["nrt"].array("zres_avail")
+    r = snap["nrt"].array("zres_res")
+    mem = np.flatnonzero(r == 1)
+    rng = np.random.default_rng(5)
+    big = (1 << 42) - 1 - rng.integers(0, 1000, mem.size)
+    q[mem] = np.where(rng.random(mem.size) < 0.5, big, q[mem])
+    pq, pr = snap["pods"].array("req_qty"), snap["pods"].array("req_res")
+    lq, lr = snap["pods"].array("lim_qty"), snap["pods"].array("lim_res")
+    # rewrite a third of the memory quantities as a function of the old value, so that request == limit survives
+    # (Guaranteed pods stay Guaranteed)
+    # (a pod's effective request sums up to 4 containers and must stay below 2^42 as well)
+    vals = np.concatenate([big[:8] // 4 - 1, big[:8] // 4, big[:8] // 8, big[:8] // 400 * 37, [1, 2, 3, 1 << 39]])
+    for which, arr in ((pr, pq), (lr, lq)):
+        idx = np.flatnonzero(which == 1)
+        old = arr[idx] >> 20  # MiB
+        arr[idx] = np.where(old % 3 == 0, vals[old % vals.size], arr[idx])
+    res = O.Resources()
+    for strategy in ("LeastAllocated", "MostAllocated"):
+        params = O.nrt_params(hdr, res, strategy)
+        with Engine(0) as e:
+            e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+            assert e.kernel_path(NRT) == 1
+            e.eval(mask_of(NRT))
+            e.sync()
+            osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
+            assert np.array_equal(e.all_status(NRT), osnap.filter_rows(NRT))
+            assert np.array_equal(e.all_scores(NRT).astype(np.int64), osnap.score_rows(NRT, want_norm=False)[0].clip(0, 255))
 
 
 def test_partial_rows_and_mixed_plugins(gpu_required, hdr, oracle):
