@@ -517,7 +517,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
   if ((rc = upload_transposed(e, e->d_nrt_minavg, t->min_avg_dist, n, Zm))) return rc;
   {  // float64 formulation: derived columns + precondition check
     const int64_t R = t->n_res;
-    std::vector<double> av(static_cast<size_t>(Zm * R * n), -1.0), rcp(static_cast<size_t>(Zm * R * n), 0.0),
+    std::vector<double> av(static_cast<size_t>(Zm * R * n), -1.0), rcp(static_cast<size_t>(Zm * R * n), spx::kNrtNoCap),
         cpuv(static_cast<size_t>(Zm * n), 0.0);
     std::vector<uint8_t> rep(static_cast<size_t>((R > 0 ? R : 1) * n), 0);
     bool ok = true;
@@ -532,7 +532,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
           const bool is_cpu = r == e->nrt_cpu_slot;
           const double cap_v = static_cast<double>(nrt_value_of(is_cpu, cap));
           av[static_cast<size_t>((z * R + r) * n + i)] = static_cast<double>(cap);
-          rcp[static_cast<size_t>((z * R + r) * n + i)] = nrt_biased_rcp(cap_v);
+          rcp[static_cast<size_t>((z * R + r) * n + i)] = cap_v > 0.0 ? 100.0 / cap_v : spx::kNrtNoCap;
           if (is_cpu) cpuv[static_cast<size_t>(z * n + i)] = cap_v;
           rep[static_cast<size_t>(r * n + i)] |= static_cast<uint8_t>(1u << z);
         }
@@ -581,15 +581,44 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
       pq[2 * i] = static_cast<double>(q);
       pq[2 * i + 1] = static_cast<double>(nrt_value_of(static_cast<int32_t>(i % R) == e->nrt_cpu_slot, q));
     }
-    std::vector<uint32_t> hdr(p * 8, 0u);
+    // nrt_pod_header: 16 dwords per pod, read by the float64 kernel with one scalar load
+    //   w0      qos | non_native << 8 | n_ctr << 16 | last app container << 24 (0xff: none)
+    //   w1,w2   ctr_kind[0..7]
+    //   w3,w4   per container: requested slots            w5,w6   ...compared per zone (non-zero, not "always")
+    //   w7,w8   ...any reporting zone suits (non-zero, non-Guaranteed pod, NUMA-affine resource)
+    //   w9,w10  ...explicit zero quantities                w11     the same four sets for the pod-level request
+    std::vector<uint32_t> hdr(p * 16, 0u);
+    const uint32_t slot_mask = (1u << R) - 1u;
     for (size_t i = 0; i < p; ++i) {
-      uint32_t* w = &hdr[i * 8];
-      w[0] = t->qos[i] | (static_cast<uint32_t>(t->non_native[i] != 0) << 8) | (static_cast<uint32_t>(t->n_ctr[i]) << 16) |
-             (static_cast<uint32_t>(t->pod_present[i]) << 24);
+      uint32_t* w = &hdr[i * 16];
+      const bool non_g = t->qos[i] != SPX_QOS_GUARANTEED;
+      uint32_t last_app = 0xffu;
+      auto sets = [&](uint32_t present, const int64_t* req, uint32_t out[4]) {
+        out[0] = present & slot_mask;
+        out[1] = out[2] = out[3] = 0;
+        for (size_t r = 0; r < R; ++r) {
+          if (!((out[0] >> r) & 1u)) continue;
+          if (req[r] == 0) out[3] |= 1u << r;
+          else if (non_g && (e->nrt_slot_flags[r] & SPX_NRT_SLOT_AFFINE)) out[2] |= 1u << r;
+          else out[1] |= 1u << r;
+        }
+      };
       for (size_t c = 0; c < Cm; ++c) {
-        w[1 + c / 4] |= static_cast<uint32_t>(t->ctr_kind[i * Cm + c]) << (8 * (c % 4));
-        w[3 + c / 4] |= static_cast<uint32_t>(t->ctr_present[i * Cm + c]) << (8 * (c % 4));
+        const uint32_t kind = t->ctr_kind[i * Cm + c];
+        if (c < t->n_ctr[i] && kind == SPX_CTR_APP) last_app = static_cast<uint32_t>(c);
+        uint32_t st[4];
+        sets(t->ctr_present[i * Cm + c], t->ctr_req + (i * Cm + c) * R, st);
+        const unsigned sh = 8 * (c % 4);
+        w[1 + c / 4] |= kind << sh;
+        w[3 + c / 4] |= st[0] << sh;
+        w[5 + c / 4] |= st[1] << sh;
+        w[7 + c / 4] |= st[2] << sh;
+        w[9 + c / 4] |= st[3] << sh;
       }
+      uint32_t st[4];
+      sets(t->pod_present[i], t->pod_req + i * R, st);
+      w[11] = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
+      w[0] = t->qos[i] | (static_cast<uint32_t>(t->non_native[i] != 0) << 8) | (static_cast<uint32_t>(t->n_ctr[i]) << 16) | (last_app << 24);
     }
     if ((rc = upload(e, e->d_nrt_phdr, hdr.data(), hdr.size() * sizeof(uint32_t)))) return rc;
     e->nrt_fast_pods = ok;

@@ -105,14 +105,15 @@ struct NrtArgs {
   int32_t cpu_slot;              // slot whose quantities are millicores (-1: none)
   double slot_weight_f[SPX_NRT_MAX_RES];
   const double* f_av;            // [Z][n_res][N] reported ? available : -1
-  const double* f_rc;            // [Z][n_res][N] biased reciprocal of Value(capacity)
+  const double* f_rc;            // [Z][n_res][N] RN(100 / Value(capacity)), kNrtNoCap when the capacity is not positive
   const double* f_cpu;           // [Z][N] Value() of the cpu capacity
   const uint8_t* f_rep;          // [n_res][N] mask of the zones reporting the resource
   const double* ctr_q2;          // [P][8][n_res][2] (request, Value(request))
   const double* pod_q2;          // [P][n_res][2]
-  const uint32_t* pod_hdr;       // [P][8] packed qos / non_native / n_ctr / pod_present / ctr_kind[8] / ctr_present[8]
+  const uint32_t* pod_hdr;       // [P][16] packed pod header (layout: spx_engine.hip nrt_pod_header)
   const double* wtab;            // [2^n_res][2] (sum of weights of the resource subset, its biased reciprocal)
 };
+constexpr double kNrtNoCap = 1e200;
 void launch_nrt(const NrtArgs& a, hipStream_t s);
 // returns false when the float64 kernel does not apply (preconditions, LeastNUMANodes)
 bool launch_nrt_fast(const NrtArgs& a, hipStream_t s);
