@@ -176,8 +176,9 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
         double rs;
         if constexpr (SG == kSgLeast) {
           // (cap_v - req_v) * 100 / cap_v == 100 - req_v * (100 / cap_v); see the header for why the floor is exact
-          if ((st.zero >> r) & 1u) rs = ns.b[z][r] < kNoCap ? 100.0 : 0.0;
-          else rs = __builtin_fmax(__builtin_floor(__builtin_fma(-q[r].value, ns.b[z][r], 100.0 + 0x1p-43)), 0.0);
+          // cells without capacity hold b = +inf: -v * inf is -inf (v > 0) or NaN (explicit zero request), and
+          // max(., 0) turns both into the reference's 0
+          rs = __builtin_fmax(__builtin_floor(__builtin_fma(-q[r].value, ns.b[z][r], 100.0 + 0x1p-43)), 0.0);
         } else {
           const double t = __builtin_floor((q[r].value * (1.0 + 0x1p-49)) * ns.b[z][r]);
           rs = q[r].raw <= ns.av[z][r] ? t : 0.0;
@@ -194,7 +195,7 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
 __constant__ uint32_t kInv16[kC + 1] = {0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192};  // ceil(2^16 / n)
 
 template <int RM, int SG>
-__global__ __launch_bounds__(256, RM == 4 ? 2 : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
+__global__ __launch_bounds__(256, RM == 4 ? 3 : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t unit = static_cast<int64_t>(blockIdx.x) * 4 + wave;
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(256, RM == 4 ? 2 : 1) void k_nrt_fast(NrtArgs a, in
     for (int r = 0; r < RM; ++r) {
       const int64_t i = (static_cast<int64_t>(z) * R + r) * a.n_nodes + n;
       ns.av[z][r] = (in && r < R) ? a.f_av[i] : -1.0;
-      ns.b[z][r] = (SG != kSgBalanced && in && r < R) ? a.f_rc[i] : kNoCap;
+      const double b = (SG != kSgBalanced && in && r < R) ? a.f_rc[i] : kNoCap;
+      ns.b[z][r] = (SG == kSgLeast && b == kNoCap) ? __builtin_inf() : b;
     }
   }
   const bool fresh = flags & SPX_NRT_F_FRESH;
