@@ -15,6 +15,8 @@
 //   phase 4  same sweep again, now normalising (100 - 100*(s-min)/(max-min)) and storing one dword of
 //            status bytes and one dword of score bytes per lane (256 contiguous bytes per wave per table).
 // Output-write bound: 2 B per (pod,node); inputs are 8 B per node, a few bytes per pod, cost matrices in L2.
+#include <cstdlib>
+
 #include "spx_internal.h"
 
 namespace spx {
@@ -212,6 +214,172 @@ __global__ __launch_bounds__(64) void k_net(NetArgs g) {
   }
 }
 
+
+// ---------------------------------------------------------------- table sweep through the class table
+//
+// k_net above evaluates every node on its own (class lookup + host test + three LDS reads, twice).  For whole
+// tables the per-node work shrinks to one 16-bit class id and one LDS read of a finished byte pair:
+//   phase 1  lanes = classes: (cost, Filter verdict) per class into LDS                       [as above]
+//   phase 2  host bitmap; distinct hosts counted per class
+//   phase 3  min/max of the cost over the pod's feasible nodes:
+//              no other Filter plugin in the evaluation: over classes that keep at least one non-host node, plus
+//              the (<= pairs) host nodes evaluated exactly — no pass over the nodes at all;
+//              otherwise one pass over the nodes with dword loads of the other plugins' status bytes
+//   phase 3b lanes = classes: NormalizeScore per class -> (status << 8 | score) in LDS
+//   phase 4  lanes = 4 consecutive nodes: one 8-byte load of class ids, 4 LDS reads, host nodes (rare) patched
+//            exactly, one dword store per table.
+__device__ __forceinline__ int norm_cost(int cost, int mn, int mx) {
+  // networkoverhead.go:389-418; 100*d/r is never within 1e-6 of an integer from below, so int64(float) == integer division
+  if (mn == 0 && mx == 0) return cost;
+  const int range = mx - mn;
+  return range != 0 ? 100 - (100 * (cost - mn)) / range : 100 - (cost - mn);
+}
+
+__global__ __launch_bounds__(64) void k_net_cls(NetArgs g) {
+  extern __shared__ __align__(16) int lds[];
+  const int C = g.n_classes;
+  int* cls_word = lds;                                            // cost | (Filter fails) << 31
+  int* cls_hosts = lds + C;                                       // distinct host nodes of the class
+  uint32_t* cls_fin = reinterpret_cast<uint32_t*>(lds + 2 * C);   // status << 8 | normalised score
+  unsigned* host_bits = reinterpret_cast<unsigned*>(lds + 3 * C);
+  const int lane = threadIdx.x;
+  const int64_t pod = g.row_begin + blockIdx.x;
+  if (pod >= g.row_end) return;
+  const int key = g.pod_key[pod];
+  const int flag = g.key_flag[key];
+  const int lo = g.pair_ptr[key], hi = g.pair_ptr[key + 1];
+  const int64_t n_words = (g.n_nodes + 31) / 32;
+  const uint8_t* other0 = g.other_status[0] ? g.other_status[0] + pod * g.row_stride : nullptr;
+  const uint8_t* other1 = g.other_status[1] ? g.other_status[1] + pod * g.row_stride : nullptr;
+  const int64_t tiles = (g.row_stride + 64 * kNpl - 1) / (64 * kNpl);
+  uint8_t* out_st = g.out_status + pod * g.row_stride;
+  uint8_t* out_sc = g.out_score + pod * g.row_stride;
+
+  if (flag != 0) {  // scoreEqually / PreFilter error, as in k_net
+    const uint32_t st = flag == 2 ? 0xffffffffu : 0u;
+    for (int64_t t = 0; t < tiles; ++t) {
+      const int64_t n0 = (t * 64 + lane) * kNpl;
+      if (n0 >= g.row_stride) continue;
+      *reinterpret_cast<uint32_t*>(out_st + n0) = st;
+      *reinterpret_cast<uint32_t*>(out_sc + n0) = 0u;
+    }
+    return;
+  }
+
+  // ---- phase 1 + 2
+  for (int c = lane; c < C; c += 64) {
+    Acc a{0, 0, 0};
+    const int region = g.cls_region[c], zone = g.cls_zone[c];
+    for (int i = lo; i < hi; ++i) {
+      const int host = g.pair_node[i];  // wave-uniform
+      add_pair(a, g, region, zone, g.region[host], g.zone[host], g.pair_max[i]);
+    }
+    cls_word[c] = a.cost | (a.vio > a.sat ? static_cast<int>(0x80000000u) : 0);
+    cls_hosts[c] = 0;
+  }
+  for (int64_t w = lane; w < n_words; w += 64) host_bits[w] = 0u;
+  __syncthreads();
+  for (int i = lo + lane; i < hi; i += 64) {
+    const int host = g.pair_node[i];
+    const unsigned bit = 1u << (host & 31);
+    if (!(atomicOr(&host_bits[host >> 5], bit) & bit)) atomicAdd(&cls_hosts[g.node_class16[host]], 1);
+  }
+  __syncthreads();
+
+  auto other4 = [&](int64_t n0) -> uint32_t {  // non-zero byte: another Filter plugin rejected the node
+    uint32_t w = 0;
+    if (other0) w |= *reinterpret_cast<const uint32_t*>(other0 + n0);
+    if (other1) w |= *reinterpret_cast<const uint32_t*>(other1 + n0);
+    return w;
+  };
+  auto classes4 = [&](int64_t n0) -> uint64_t {
+    const uint2 v = *reinterpret_cast<const uint2*>(g.node_class16 + n0);
+    return v.x | (static_cast<uint64_t>(v.y) << 32);
+  };
+
+  // ---- phase 3
+  int mn = INT32_MAX, mx = INT32_MIN;
+  if (!other0 && !other1) {
+    for (int c = lane; c < C; c += 64) {
+      const int w = cls_word[c];
+      if (w >= 0 && g.cls_size[c] - cls_hosts[c] > 0) {
+        mn = w < mn ? w : mn;
+        mx = w > mx ? w : mx;
+      }
+    }
+    for (int i = lo + lane; i < hi; i += 64) {
+      const Acc a = direct_eval(g, g.pair_node[i], lo, hi);
+      if (!(a.vio > a.sat)) {
+        mn = a.cost < mn ? a.cost : mn;
+        mx = a.cost > mx ? a.cost : mx;
+      }
+    }
+  } else {
+    for (int64_t t = 0; t < tiles; ++t) {
+      const int64_t n0 = (t * 64 + lane) * kNpl;
+      if (n0 >= g.n_nodes) continue;
+      const uint32_t oth = other4(n0);
+      const uint64_t cw = classes4(n0);
+      const unsigned hb = (host_bits[n0 >> 5] >> (n0 & 31)) & 0xfu;
+#pragma unroll
+      for (int j = 0; j < kNpl; ++j) {
+        if (n0 + j >= g.n_nodes || ((oth >> (8 * j)) & 0xffu)) continue;
+        int w;
+        if ((hb >> j) & 1u) {
+          const Acc a = direct_eval(g, n0 + j, lo, hi);
+          w = a.cost | (a.vio > a.sat ? static_cast<int>(0x80000000u) : 0);
+        } else {
+          w = cls_word[(cw >> (16 * j)) & 0xffffu];
+        }
+        if (w >= 0) {
+          mn = w < mn ? w : mn;
+          mx = w > mx ? w : mx;
+        }
+      }
+    }
+  }
+  mn = wave_min(mn);
+  mx = wave_max(mx);
+
+  // ---- phase 3b
+  for (int c = lane; c < C; c += 64) {
+    const int w = cls_word[c];
+    int score = w >= 0 ? norm_cost(w, mn, mx) : 0;
+    score = score < 0 ? 0 : (score > 255 ? 255 : score);
+    cls_fin[c] = static_cast<uint32_t>(score) | (w < 0 ? static_cast<uint32_t>(SPX_NET_ST_UNSCHEDULABLE) << 8 : 0u);
+  }
+  __syncthreads();
+
+  // ---- phase 4
+  for (int64_t t = 0; t < tiles; ++t) {
+    const int64_t n0 = (t * 64 + lane) * kNpl;
+    if (n0 >= g.row_stride) continue;
+    uint32_t st_w = 0, sc_w = 0;
+    if (n0 < g.n_nodes) {
+      const uint32_t oth = (other0 || other1) ? other4(n0) : 0u;
+      const uint64_t cw = classes4(n0);
+      const unsigned hb = (host_bits[n0 >> 5] >> (n0 & 31)) & 0xfu;
+#pragma unroll
+      for (int j = 0; j < kNpl; ++j) {
+        uint32_t fin = cls_fin[(cw >> (16 * j)) & 0xffffu];
+        if ((hb >> j) & 1u) {  // a host of one of the pod's pairs: exact
+          const Acc a = direct_eval(g, n0 + j, lo, hi);
+          const bool pass = !(a.vio > a.sat);
+          int score = pass ? norm_cost(a.cost, mn, mx) : 0;
+          score = score < 0 ? 0 : (score > 255 ? 255 : score);
+          fin = static_cast<uint32_t>(score) | (pass ? 0u : static_cast<uint32_t>(SPX_NET_ST_UNSCHEDULABLE) << 8);
+        }
+        if ((oth >> (8 * j)) & 0xffu) fin &= 0xff00u;  // rejected elsewhere: not scored
+        if (n0 + j >= g.n_nodes) fin = 0;
+        sc_w |= (fin & 0xffu) << (8 * j);
+        st_w |= (fin >> 8) << (8 * j);
+      }
+    }
+    *reinterpret_cast<uint32_t*>(out_st + n0) = st_w;
+    *reinterpret_cast<uint32_t*>(out_sc + n0) = sc_w;
+  }
+}
+
 }  // namespace
 
 size_t net_lds_bytes(int n_classes, int64_t n_nodes) {
@@ -222,7 +390,11 @@ void launch_net(const NetArgs& g, hipStream_t s) {
   if (g.row_end <= g.row_begin) return;
   const unsigned blocks = static_cast<unsigned>(g.row_end - g.row_begin);
   const size_t lds = g.n_classes > 0 ? net_lds_bytes(g.n_classes, g.n_nodes) : 16;
-  hipLaunchKernelGGL(k_net, dim3(blocks), dim3(64), lds, s, g);
+  const bool generic_only = getenv("SPX_NET_GENERIC") != nullptr;  // experiments / differential tests (read per launch)
+  if (!generic_only && !g.out_raw && g.n_classes > 0 && g.n_classes <= 65535 && g.node_class16)
+    hipLaunchKernelGGL(k_net_cls, dim3(blocks), dim3(64), lds, s, g);
+  else
+    hipLaunchKernelGGL(k_net, dim3(blocks), dim3(64), lds, s, g);
 }
 
 }  // namespace spx

@@ -38,6 +38,17 @@ __device__ __forceinline__ uint64_t div_le100(uint64_t num, uint64_t den) {
   return q;
 }
 
+// OR of the Filter status bytes of nodes n0..n0+3 (one dword per table): a non-zero byte marks an infeasible node.
+// Rows are 128-byte aligned and n0 is a multiple of 4; bytes past n_nodes are never written by the sweeps and
+// must be ignored by the caller.
+__device__ __forceinline__ uint32_t infeasible4(const ProfileArgs& a, int64_t pod, int64_t n0) {
+  uint32_t w = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (a.status[k]) w |= *reinterpret_cast<const uint32_t*>(a.status[k] + pod * a.row_stride + n0);
+  return w;
+}
+
 __global__ __launch_bounds__(64) void k_alloc_masked(ProfileArgs a) {
   const int lane = threadIdx.x;
   const int64_t pod = a.row_begin + blockIdx.x;
@@ -46,10 +57,12 @@ __global__ __launch_bounds__(64) void k_alloc_masked(ProfileArgs a) {
   int64_t lo = INT64_MAX, hi = -INT64_MAX;
   for (int64_t t = 0; t < tiles; ++t) {
     const int64_t n0 = (t * 64 + lane) * kNpl;
+    if (n0 >= a.n_nodes) continue;
+    const uint32_t bad = infeasible4(a, pod, n0);
 #pragma unroll
     for (int j = 0; j < kNpl; ++j) {
       const int64_t n = n0 + j;
-      if (n >= a.n_nodes || !feasible_at(a, pod, n)) continue;
+      if (n >= a.n_nodes || ((bad >> (8 * j)) & 0xffu)) continue;
       const int64_t s = a.alloc_raw[n];
       lo = s < lo ? s : lo;
       hi = s > hi ? s : hi;
@@ -62,18 +75,32 @@ __global__ __launch_bounds__(64) void k_alloc_masked(ProfileArgs a) {
     hi = ohi > hi ? ohi : hi;
   }
   const uint64_t range = static_cast<uint64_t>(hi) - static_cast<uint64_t>(lo);
+  // (s - lo) * 100 / range with a wave-uniform range: below 2^42 the quotient is floor(d * b) for
+  // b = RN(100 / range) * (1 + 2^-49) — the float64 product lies in [x, x + 2^-42) and frac(x) <= 1 - 1/range, so the
+  // floor is exact (same argument as kernels_nrt_fast.hip); wider ranges keep the int64 division
+  const bool small = hi >= lo && range < (1ull << 42);
+  const double b = small && range ? (100.0 / static_cast<double>(range)) * (1.0 + 0x1p-49) : 0.0;
   for (int64_t t = 0; t < tiles; ++t) {
     const int64_t n0 = (t * 64 + lane) * kNpl;
     if (n0 >= a.row_stride) continue;
     uint32_t w = 0;
+    if (n0 < a.n_nodes && range != 0 && hi >= lo) {
+      const uint32_t bad = infeasible4(a, pod, n0);
 #pragma unroll
-    for (int j = 0; j < kNpl; ++j) {
-      const int64_t n = n0 + j;
-      if (n >= a.n_nodes || !feasible_at(a, pod, n) || range == 0) continue;  // infeasible cells hold 0
-      const uint64_t d = static_cast<uint64_t>(a.alloc_raw[n]) - static_cast<uint64_t>(lo);
-      uint64_t v = div_le100(d * 100ull, range);
-      v = v > 255 ? 255 : v;
-      w |= static_cast<uint32_t>(v) << (8 * j);
+      for (int j = 0; j < kNpl; ++j) {
+        const int64_t n = n0 + j;
+        if (n >= a.n_nodes || ((bad >> (8 * j)) & 0xffu)) continue;  // infeasible cells hold 0
+        const uint64_t d = static_cast<uint64_t>(a.alloc_raw[n]) - static_cast<uint64_t>(lo);
+        uint32_t v;
+        if (small) {
+          const double df = __builtin_fma(static_cast<double>(static_cast<uint32_t>(d >> 32)), 0x1p32, static_cast<double>(static_cast<uint32_t>(d)));
+          v = static_cast<uint32_t>(df * b);
+        } else {
+          const uint64_t q = div_le100(d * 100ull, range);
+          v = q > 255 ? 255u : static_cast<uint32_t>(q);
+        }
+        w |= v << (8 * j);
+      }
     }
     *reinterpret_cast<uint32_t*>(a.out_alloc + pod * a.row_stride + n0) = w;
   }

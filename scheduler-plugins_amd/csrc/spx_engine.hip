@@ -75,7 +75,8 @@ struct spx_engine {
   // NetworkOverhead / TopologicalSort
   bool net_nodes = false, net_topo = false, net_pods = false;
   int32_t net_n_regions = 0, net_n_zones = 0, net_n_classes = 0;
-  DevBuf d_net_region, d_net_zone, d_net_class, d_net_cls_region, d_net_cls_zone, d_net_rcost, d_net_zcost;
+  DevBuf d_net_region, d_net_zone, d_net_class, d_net_class16, d_net_cls_size, d_net_cls_region, d_net_cls_zone, d_net_rcost, d_net_zcost;
+  bool net_class16 = false;
   DevBuf d_net_pod_key, d_net_key_flag, d_net_pair_ptr, d_net_pair_node, d_net_pair_max;
 
   // profile-level state
@@ -269,6 +270,8 @@ void fill_net(const spx_engine* e, spx::NetArgs& g) {
   g.region = static_cast<const int32_t*>(e->d_net_region.p);
   g.zone = static_cast<const int32_t*>(e->d_net_zone.p);
   g.node_class = static_cast<const int32_t*>(e->d_net_class.p);
+  g.node_class16 = e->net_class16 ? static_cast<const uint16_t*>(e->d_net_class16.p) : nullptr;
+  g.cls_size = static_cast<const int32_t*>(e->d_net_cls_size.p);
   g.cls_region = static_cast<const int32_t*>(e->d_net_cls_region.p);
   g.cls_zone = static_cast<const int32_t*>(e->d_net_cls_zone.p);
   g.region_cost = static_cast<const int32_t*>(e->d_net_rcost.p);
@@ -334,7 +337,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
                     &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_cq2,   &e->d_nrt_pq2, &e->d_nrt_wtab, &e->d_nrt_phdr,
-                    &e->d_net_region, &e->d_net_zone, &e->d_net_class, &e->d_net_cls_region, &e->d_net_cls_zone,
+                    &e->d_net_region, &e->d_net_zone, &e->d_net_class, &e->d_net_class16, &e->d_net_cls_size, &e->d_net_cls_region, &e->d_net_cls_zone,
                     &e->d_net_rcost, &e->d_net_zcost, &e->d_net_pod_key, &e->d_net_key_flag, &e->d_net_pair_ptr,
                     &e->d_net_pair_node, &e->d_net_pair_max, &e->d_q_pod_ns, &e->d_q_pod_prio, &e->d_q_pod_req, &e->d_q_pod_reqp,
                     &e->d_q_has, &e->d_q_used, &e->d_q_max, &e->d_q_maxp, &e->d_q_other, &e->d_q_otherp, &e->d_q_nom_ptr,
@@ -663,6 +666,18 @@ int spx_upload_net_nodes(spx_engine* e, const spx_net_nodes_soa* t) {
   if ((rc = upload(e, e->d_net_region, t->region, static_cast<size_t>(n) * 4))) return rc;
   if ((rc = upload(e, e->d_net_zone, t->zone, static_cast<size_t>(n) * 4))) return rc;
   if ((rc = upload(e, e->d_net_class, cls.data(), static_cast<size_t>(n) * 4))) return rc;
+  {
+    std::vector<uint16_t> c16(static_cast<size_t>(spx::round_up(n, 4)), 0);
+    std::vector<int32_t> size(cr.size() ? cr.size() : 1, 0);
+    e->net_class16 = cr.size() <= 65535;
+    for (int64_t i = 0; i < n; ++i) {
+      c16[static_cast<size_t>(i)] = static_cast<uint16_t>(cls[static_cast<size_t>(i)]);
+      ++size[static_cast<size_t>(cls[static_cast<size_t>(i)])];
+    }
+    if ((rc = upload(e, e->d_net_class16, c16.data(), c16.size() * 2))) return rc;
+    if ((rc = upload(e, e->d_net_cls_size, size.data(), size.size() * 4))) return rc;
+    SPX_HIP(e, hipStreamSynchronize(e->stream));
+  }
   if ((rc = upload(e, e->d_net_cls_region, cr.data(), cr.size() * 4))) return rc;
   if ((rc = upload(e, e->d_net_cls_zone, cz.data(), cz.size() * 4))) return rc;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
@@ -912,6 +927,7 @@ int spx_kernel_path(const spx_engine* e, int plugin) {
             getenv("SPX_NRT_GENERIC") == nullptr)
                ? 1
                : 0;
+  if (plugin == SPX_PLUGIN_NETOVERHEAD) return (e->net_nodes && e->net_class16 && e->net_n_classes > 0 && getenv("SPX_NET_GENERIC") == nullptr) ? 1 : 0;
   if (plugin == SPX_PLUGIN_TLP) return (e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && getenv("SPX_EXACT_ONLY") == nullptr) ? 1 : 0;
   return 0;
 }

@@ -134,6 +134,8 @@ struct NetArgs {
   const int32_t* cls_zone;      // [n_classes]
   const int32_t* region_cost;   // [n_regions^2], -1 = no entry
   const int32_t* zone_cost;     // [n_zones^2]
+  const uint16_t* node_class16; // [round_up(N, 4)] the same class ids, 16 bit (table sweep); NULL when they do not fit
+  const int32_t* cls_size;      // [n_classes] nodes per class
   const int32_t* pod_key;       // [P]
   const uint8_t* key_flag;      // [K] 0 evaluate, 1 scoreEqually, 2 PreFilter error
   const int32_t* pair_ptr;      // [K+1]
