@@ -30,6 +30,7 @@ namespace {
 constexpr int kZ = SPX_NRT_MAX_ZONES;
 constexpr int kC = SPX_NRT_MAX_CTRS;
 constexpr int kPodsPerUnit = 32;
+constexpr int kWindow = 256;  // nodes per block (4 wavefronts)
 constexpr int kSgLeast = 0;
 constexpr int kSgMost = 1;
 constexpr int kSgBalanced = 2;
@@ -47,11 +48,6 @@ struct FastNode {
   __device__ __forceinline__ uint32_t fillmask(int r) const { return (fill[r >> 2] >> (8 * (r & 3))) & 0xffu; }
 };
 
-struct Q2 {
-  double raw;    // the request as written (cpu in millicores)
-  double value;  // Quantity.Value(): cpu rounded up to whole cores
-};
-
 // Wave-uniform read of immutable input through the constant address space: the backend may then use scalar
 // loads (s_load_dwordxN into SGPRs).  Through a plain global pointer it cannot — the kernel's own table stores
 // might alias — and every pod-record access becomes a vector load with a uniform address (measured: 54 VMEM
@@ -62,36 +58,66 @@ __device__ __forceinline__ T uload(const T* p) {
   return *reinterpret_cast<CT*>(reinterpret_cast<uintptr_t>(p));
 }
 
-// per-pod header, 16 dwords (one s_load_dwordx16), built by the engine at upload (spx_engine.hip: nrt_pod_header)
-typedef uint32_t PodHdr __attribute__((ext_vector_type(16)));
-typedef double F64x2 __attribute__((ext_vector_type(2)));
-
-// the request subsets of one container (or of the pod), precomputed per pod on the host from the QoS class,
-// the slot flags and which quantities are zero
-struct Sets {
-  uint32_t used;    // requested resources (Score iterates these)
-  uint32_t fit;     // non-zero requests compared per zone:            available >= quantity
-  uint32_t always;  // non-zero requests of a non-Guaranteed pod for a NUMA-affine resource: any reporting zone suits
-  uint32_t zero;    // explicit zero-quantity requests
+// The pod record stream (built by the engine at upload, spx_engine.hip: nrt_pod_items): per pod 10 items of IW
+// dwords — item 0 the header, item 1 the pod-level request, items 2..9 the containers in order (init containers
+// first).  One item is one scalar load; the next one is requested before the current one is processed, so the
+// SMEM latency (the kernel's main stall once the arithmetic is cheap) overlaps with the VALU work.
+template <int RM>
+struct ItemWords;
+template <>
+struct ItemWords<4> {
+  typedef uint32_t T __attribute__((ext_vector_type(16)));
 };
+template <>
+struct ItemWords<8> {
+  typedef uint32_t T __attribute__((ext_vector_type(32)));
+};
+constexpr int kItemsPerPod = 2 + kC;
+
+template <int RM>
+struct Item {
+  double raw[RM];  // requests as written (cpu in millicores); 0 for absent slots
+  double cpu_v;    // Quantity.Value() of the cpu request (whole cores, rounded up)
+  double wsum;     // sum of the weights of the requested slots
+  double wrc;      // its biased reciprocal
+  uint32_t used;   // requested slots (Score iterates these)
+  uint32_t fit;    // non-zero requests compared per zone: available >= quantity
+  uint32_t always; // non-zero requests of a non-Guaranteed pod for a NUMA-affine resource: any reporting zone suits
+  uint32_t kind;   // SPX_CTR_*
+};
+
+template <int RM>
+__device__ __forceinline__ Item<RM> decode_item(const typename ItemWords<RM>::T& w) {
+  Item<RM> it;
+#pragma unroll
+  for (int r = 0; r < RM; ++r) it.raw[r] = __hiloint2double(static_cast<int>(w[2 * r + 1]), static_cast<int>(w[2 * r]));
+  it.cpu_v = __hiloint2double(static_cast<int>(w[2 * RM + 1]), static_cast<int>(w[2 * RM]));
+  it.wsum = __hiloint2double(static_cast<int>(w[2 * RM + 3]), static_cast<int>(w[2 * RM + 2]));
+  it.wrc = __hiloint2double(static_cast<int>(w[2 * RM + 5]), static_cast<int>(w[2 * RM + 4]));
+  const uint32_t s = w[2 * RM + 6];
+  it.used = s & 0xffu;
+  it.fit = (s >> 8) & 0xffu;
+  it.always = (s >> 16) & 0xffu;
+  it.kind = s >> 24;
+  return it;
+}
 
 // resourcesAvailableInAnyNUMANodes filter.go:93-163 with ids == positions
 template <int RM>
-__device__ __forceinline__ bool fits_fast(const FastNode<RM>& ns, const Sets& st, const Q2* __restrict__ q2, uint32_t* pos) {
-  const uint32_t need = st.fit | st.always;
+__device__ __forceinline__ bool fits_fast(const FastNode<RM>& ns, const Item<RM>& it, uint32_t* pos) {
+  const uint32_t need = it.fit | it.always;
   const bool ok = (need & ~ns.node_present) == 0;  // requested but not reported at node level -> cannot meet request
   uint32_t mask = 0xffu;
 #pragma unroll
   for (int r = 0; r < RM; ++r) {
     if (!((need >> r) & 1u)) continue;  // uniform
     uint32_t rb;
-    if ((st.always >> r) & 1u) {
+    if ((it.always >> r) & 1u) {
       rb = ns.repmask(r);
     } else {
-      const double q = uload(&q2[r].raw);
       rb = 0;
 #pragma unroll
-      for (int z = 0; z < kZ; ++z) rb |= ns.av[z][r] >= q ? (1u << z) : 0u;
+      for (int z = 0; z < kZ; ++z) rb |= ns.av[z][r] >= it.raw[r] ? (1u << z) : 0u;
     }
     mask &= rb | ns.fillmask(r);
   }
@@ -102,17 +128,16 @@ __device__ __forceinline__ bool fits_fast(const FastNode<RM>& ns, const Sets& st
 // subtractResourcesFromNUMANodeList numaresources.go:145-182 (sign -1) / its inverse (+1).  Unreported cells
 // hold a negative value and stay negative, which is all any reader tests.
 template <int RM>
-__device__ __forceinline__ void adjust_fast(FastNode<RM>& ns, const Sets& st, const Q2* __restrict__ q2, uint32_t pos,
-                                            bool apply, double sign) {
+__device__ __forceinline__ void adjust_fast(FastNode<RM>& ns, const Item<RM>& it, uint32_t pos, bool apply, double sign) {
+  if (it.fit == 0) return;  // uniform
   double sel[kZ];
 #pragma unroll
   for (int z = 0; z < kZ; ++z) sel[z] = (apply && pos == static_cast<uint32_t>(z)) ? sign : 0.0;
 #pragma unroll
   for (int r = 0; r < RM; ++r) {
-    if (!((st.fit >> r) & 1u)) continue;
-    const double q = uload(&q2[r].raw);
+    if (!((it.fit >> r) & 1u)) continue;
 #pragma unroll
-    for (int z = 0; z < kZ; ++z) ns.av[z][r] = __builtin_fma(sel[z], q, ns.av[z][r]);
+    for (int z = 0; z < kZ; ++z) ns.av[z][r] = __builtin_fma(sel[z], it.raw[r], ns.av[z][r]);
   }
 }
 
@@ -120,16 +145,13 @@ __device__ __forceinline__ void adjust_fast(FastNode<RM>& ns, const Sets& st, co
 // reference's running rule `min == 0 || (s != 0 && s < min)` is order-independent).  Zones past the node's
 // count hold no capacity and score 0 under Least/MostAllocated, so they drop out by themselves.
 template <int RM, int SG>
-__device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const NrtArgs& a, const Sets& st,
-                                               const Q2* __restrict__ q2, const double* __restrict__ cpu_v) {
-  const uint32_t used = st.used;
+__device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const NrtArgs& a, const Item<RM>& it,
+                                               const double* __restrict__ cpu_v) {
+  const uint32_t used = it.used;
   uint32_t m = 0xffffffffu;  // min over zones of (score - 1) as unsigned: a zero score wraps to the maximum
-  Q2 q[RM];
+  double value[RM];
 #pragma unroll
-  for (int r = 0; r < RM; ++r) {
-    const F64x2 v = ((used >> r) & 1u) ? uload(reinterpret_cast<const F64x2*>(q2 + r)) : F64x2{0.0, 0.0};
-    q[r] = Q2{v.x, v.y};
-  }
+  for (int r = 0; r < RM; ++r) value[r] = r == a.cpu_slot ? it.cpu_v : it.raw[r];
   if constexpr (SG == kSgBalanced) {
     const double n = static_cast<double>(__builtin_popcount(used));
 #pragma unroll
@@ -142,7 +164,7 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
         if (!((used >> r) & 1u)) continue;
         const double cap = ns.av[z][r];
         const double cap_v = r == a.cpu_slot ? cpu_v[z] : cap;
-        const double f = cap > 0.0 ? q[r].value / cap_v : 1.0;  // fractionOfCapacity balanced_allocation.go:49-54
+        const double f = cap > 0.0 ? value[r] / cap_v : 1.0;  // fractionOfCapacity balanced_allocation.go:49-54
         over |= f > 1.0;
         fr[r] = f;
       }
@@ -164,9 +186,7 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
       m = s1 < m ? s1 : m;
     }
   } else {
-    const double wsum = uload(a.wtab + 2 * used);
-    const double wrc = uload(a.wtab + 2 * used + 1);
-    if (__double_as_longlong(wsum) == 0) return 0;
+    if (__double_as_longlong(it.wsum) == 0) return 0;
 #pragma unroll
     for (int z = 0; z < kZ; ++z) {
       double acc = 0.0;
@@ -175,38 +195,51 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
         if (!((used >> r) & 1u)) continue;
         double rs;
         if constexpr (SG == kSgLeast) {
-          // (cap_v - req_v) * 100 / cap_v == 100 - req_v * (100 / cap_v); see the header for why the floor is exact
-          // cells without capacity hold b = +inf: -v * inf is -inf (v > 0) or NaN (explicit zero request), and
+          // (cap_v - req_v) * 100 / cap_v == 100 - req_v * (100 / cap_v); see the header for why the floor is exact.
+          // Cells without capacity hold b = +inf: -v * inf is -inf (v > 0) or NaN (explicit zero request), and
           // max(., 0) turns both into the reference's 0
-          rs = __builtin_fmax(__builtin_floor(__builtin_fma(-q[r].value, ns.b[z][r], 100.0 + 0x1p-43)), 0.0);
+          rs = __builtin_fmax(__builtin_floor(__builtin_fma(-value[r], ns.b[z][r], 100.0 + 0x1p-43)), 0.0);
         } else {
-          const double t = __builtin_floor((q[r].value * (1.0 + 0x1p-49)) * ns.b[z][r]);
-          rs = q[r].raw <= ns.av[z][r] ? t : 0.0;
+          const double t = __builtin_floor((value[r] * (1.0 + 0x1p-49)) * ns.b[z][r]);
+          rs = it.raw[r] <= ns.av[z][r] ? t : 0.0;
         }
         acc = __builtin_fma(rs, a.slot_weight_f[r], acc);
       }
-      const uint32_t s1 = static_cast<uint32_t>(static_cast<int>(acc * wrc)) - 1u;  // floor(acc / wsum) in 0..100
+      const uint32_t s1 = static_cast<uint32_t>(static_cast<int>(acc * it.wrc)) - 1u;  // floor(acc / wsum) in 0..100
       m = s1 < m ? s1 : m;
     }
   }
   return static_cast<int>(m + 1u);
 }
 
-__constant__ uint32_t kInv16[kC + 1] = {0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192};  // ceil(2^16 / n)
-
 template <int RM, int SG>
-__global__ __launch_bounds__(256, RM == 4 ? 3 : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
+__global__ __launch_bounds__(256, RM == 4 ? (SG == kSgBalanced ? 2 : 3) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
+  typedef typename ItemWords<RM>::T Words;
+  // A block owns a window of 256 consecutive nodes and a chunk of pod rows.  Inside the window the engine has
+  // ordered the nodes by (aligned, scope) — perm[] — so that a wavefront's 64 nodes mostly share one code path
+  // (measured before: 49 % of the VALU lanes active, pod-scope and container-scope nodes being interleaved).
+  // Results are staged in LDS at the nodes' original positions and leave as whole 256-byte row segments.
+  __shared__ __align__(16) uint8_t stage[2][kPodsPerUnit][kWindow];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t unit = static_cast<int64_t>(blockIdx.x) * 4 + wave;
-  const int tile = static_cast<int>(unit % n_tiles);
-  const int64_t chunk = unit / n_tiles;
+  const int n_windows = n_tiles;  // (the launch passes the window count)
+  const int window = static_cast<int>(blockIdx.x % n_windows);
+  const int64_t chunk = blockIdx.x / n_windows;
   const int64_t pod0 = a.row_begin + chunk * kPodsPerUnit;
-  if (pod0 >= a.row_end) return;
+  if (pod0 >= a.row_end) return;  // block-uniform
   const int64_t pod1 = pod0 + kPodsPerUnit < a.row_end ? pod0 + kPodsPerUnit : a.row_end;
-  const int64_t n = static_cast<int64_t>(tile) * 64 + lane;
-  const bool in = n < a.n_nodes;
+  const int64_t base = static_cast<int64_t>(window) * kWindow;
+  const int32_t pn = a.perm[base + threadIdx.x];
+  const bool in = pn >= 0;
+  const int64_t n = in ? pn : 0;
+  const int pos = in ? static_cast<int>(n - base) : 0;
   const int R = a.n_res;
+  if (a.out_raw == nullptr) {
+    uint4* z = reinterpret_cast<uint4*>(&stage[0][0][0]) + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < static_cast<int>(sizeof(stage) / 16 / 256); ++i) z[i * 256] = uint4{0, 0, 0, 0};
+    __syncthreads();
+  }
 
   FastNode<RM> ns;
   double cpu_v[kZ];
@@ -237,88 +270,108 @@ __global__ __launch_bounds__(256, RM == 4 ? 3 : 1) void k_nrt_fast(NrtArgs a, in
   const bool has_nrt = flags & SPX_NRT_F_HAS_NRT;
   const bool single = flags & SPX_NRT_F_SINGLE_NUMA;
   const bool pod_scope = flags & SPX_NRT_F_POD_SCOPE;
+  const bool aligned = fresh && has_nrt && single;  // the node's NUMA table decides Filter and Score
 
+  const Words* items = reinterpret_cast<const Words*>(a.pod_items);
+  Words hw = uload(items + pod0 * kItemsPerPod);
   for (int64_t pod = pod0; pod < pod1; ++pod) {
-    // ---- wave-uniform pod record
-    const PodHdr h = uload(reinterpret_cast<const PodHdr*>(a.pod_hdr) + pod);
-    const int qos = h[0] & 0xffu;
-    const bool non_native = ((h[0] >> 8) & 0xffu) != 0;
-    const int n_ctr = (h[0] >> 16) & 0xffu;
-    const int last_app = static_cast<int>(h[0] >> 24) == 0xff ? -1 : static_cast<int>(h[0] >> 24);
-    const uint64_t kinds = h[1] | (static_cast<uint64_t>(h[2]) << 32);
-    const uint64_t w_used = h[3] | (static_cast<uint64_t>(h[4]) << 32);
-    const uint64_t w_fit = h[5] | (static_cast<uint64_t>(h[6]) << 32);
-    const uint64_t w_always = h[7] | (static_cast<uint64_t>(h[8]) << 32);
-    const uint64_t w_zero = h[9] | (static_cast<uint64_t>(h[10]) << 32);
-    const Sets pod_sets{h[11] & 0xffu, (h[11] >> 8) & 0xffu, (h[11] >> 16) & 0xffu, h[11] >> 24};
-    const Q2* __restrict__ preq = reinterpret_cast<const Q2*>(a.pod_q2) + pod * R;
-    const Q2* __restrict__ creq = reinterpret_cast<const Q2*>(a.ctr_q2) + pod * kC * R;
-    auto ckind_of = [&](int c) { return static_cast<uint32_t>(kinds >> (8 * c)) & 0xffu; };
-    auto sets_of = [&](int c) {
-      return Sets{static_cast<uint32_t>(w_used >> (8 * c)) & 0xffu, static_cast<uint32_t>(w_fit >> (8 * c)) & 0xffu,
-                  static_cast<uint32_t>(w_always >> (8 * c)) & 0xffu, static_cast<uint32_t>(w_zero >> (8 * c)) & 0xffu};
-    };
+    // ---- wave-uniform pod record: this pod's request items now, the next pod's header for the next iteration
+    const Words* pi = items + pod * kItemsPerPod;
+    const Words pw = uload(pi + 1);
+    Words cw = uload(pi + 2);
+    const Words hnext = uload(items + (pod + 1 < pod1 ? pod + 1 : pod) * kItemsPerPod);
+    const int qos = hw[0] & 0xffu;
+    const bool non_native = ((hw[0] >> 8) & 0xffu) != 0;
+    const int n_ctr = (hw[0] >> 16) & 0xffu;
+    const int last_app = static_cast<int>(hw[0] >> 24) == 0xff ? -1 : static_cast<int>(hw[0] >> 24);
+    const uint32_t inv_n = hw[1];  // ceil(2^16 / n_ctr)
     const bool non_g = qos != SPX_QOS_GUARANTEED;
+    const bool filtered = !(qos == SPX_QOS_BESTEFFORT && !non_native);  // filter.go:186-190
 
-    // ================= Filter (filter.go:179-245)
-    uint32_t status = 0;
-    if (!(qos == SPX_QOS_BESTEFFORT && !non_native)) {  // uniform
-      if (!fresh) {
-        status = SPX_NRT_ST_INVALID_TOPOLOGY;
-      } else if (has_nrt && single) {
-        if (pod_scope) {  // singleNUMAPodLevelHandler
+    uint32_t status = (filtered && !fresh) ? SPX_NRT_ST_INVALID_TOPOLOGY : 0u;
+    int score = non_g ? 100 : 0;
+    const bool want_filter = filtered && aligned;
+    const bool want_score = !non_g && aligned;
+
+    if ((want_filter || want_score) && pod_scope) {  // singleNUMAPodLevelHandler / podScopeScore
+      const Item<RM> it = decode_item<RM>(pw);
+      if (want_filter) {
+        uint32_t pos;
+        if (!fits_fast(ns, it, &pos)) status = SPX_NRT_ST_POD;
+      }
+      if (want_score) score = score_each_fast<RM, SG>(ns, a, it, cpu_v);
+    }
+    if ((want_filter || want_score) && !pod_scope) {  // singleNUMAContainerLevelHandler / containerScopeScore
+      // One pass in container order (init containers come first — checked at upload): an init container must fit
+      // and is never subtracted; an app container is placed on the lowest fitting zone and subtracted from it.
+      // Least/MostAllocated's zone scores do not read the mutable table under Least (only b), so Least scores in
+      // the same pass; the other strategies score after the undo.
+      uint32_t chosen = 0;  // list position picked per app container (for the undo), 4 bits each
+      uint32_t placed = 0;  // bit c: container c was subtracted on this lane
+      int sum = 0;
+      for (int c = 0; c < n_ctr; ++c) {
+        const Words nw = uload(pi + 2 + (c + 1 < kC ? c + 1 : c));  // prefetch the next container's item
+        const Item<RM> it = decode_item<RM>(cw);
+        if (want_filter) {
           uint32_t pos;
-          if (!fits_fast(ns, pod_sets, preq, &pos)) status = SPX_NRT_ST_POD;
-        } else {  // singleNUMAContainerLevelHandler
-          for (int c = 0; c < n_ctr; ++c) {  // init containers: must fit, never subtracted
-            if (ckind_of(c) == SPX_CTR_APP) continue;
-            uint32_t pos;
-            const bool ok = fits_fast(ns, sets_of(c), creq + c * R, &pos);
-            if (status == 0 && !ok) status = ckind_of(c) == SPX_CTR_SIDECAR ? SPX_NRT_ST_SIDECAR_CONTAINER : SPX_NRT_ST_INIT_CONTAINER;
-          }
-          uint32_t chosen = 0;  // list position picked per app container (for the undo), 4 bits each
-          uint32_t placed = 0;  // bit c: container c was subtracted on this lane
-          for (int c = 0; c <= last_app; ++c) {
-            if (ckind_of(c) != SPX_CTR_APP) continue;
-            const Sets st = sets_of(c);
-            uint32_t pos;
-            const bool ok = fits_fast(ns, st, creq + c * R, &pos);
-            const bool live = status == 0;
+          const bool ok = fits_fast(ns, it, &pos);
+          const bool live = status == 0;
+          if (it.kind != SPX_CTR_APP) {
+            if (live && !ok) status = it.kind == SPX_CTR_SIDECAR ? SPX_NRT_ST_SIDECAR_CONTAINER : SPX_NRT_ST_INIT_CONTAINER;
+          } else {
             if (live && !ok) status = SPX_NRT_ST_CONTAINER;
-            if (c == last_app) break;  // nothing reads the table after the last app container
-            const bool apply = live && ok;
-            adjust_fast(ns, st, creq + c * R, pos, apply, -1.0);
-            chosen |= (apply ? pos : 0u) << (4 * c);
-            placed |= (apply ? 1u : 0u) << c;
+            if (c != last_app) {  // nothing reads the table after the last app container
+              const bool apply = live && ok;
+              adjust_fast(ns, it, pos, apply, -1.0);
+              chosen |= (apply ? pos : 0u) << (4 * c);
+              placed |= (apply ? 1u : 0u) << c;
+            }
           }
-          for (int c = 0; c < last_app; ++c) {  // undo: Filter works on a private copy in the reference
-            if (ckind_of(c) != SPX_CTR_APP) continue;
-            adjust_fast(ns, sets_of(c), creq + c * R, (chosen >> (4 * c)) & 0xfu, (placed >> c) & 1u, 1.0);
+        }
+        if constexpr (SG == kSgLeast) {
+          if (want_score) sum += score_each_fast<RM, SG>(ns, a, it, cpu_v);
+        }
+        cw = nw;
+      }
+      if (want_filter && last_app > 0) {  // undo: Filter works on a private copy in the reference
+        cw = uload(pi + 2);
+        for (int c = 0; c < last_app; ++c) {
+          const Words nw = uload(pi + 2 + c + 1);
+          const Item<RM> it = decode_item<RM>(cw);
+          if (it.kind == SPX_CTR_APP) adjust_fast(ns, it, (chosen >> (4 * c)) & 0xfu, (placed >> c) & 1u, 1.0);
+          cw = nw;
+        }
+      }
+      if constexpr (SG != kSgLeast) {
+        if (want_score) {
+          cw = uload(pi + 2);
+          for (int c = 0; c < n_ctr; ++c) {
+            const Words nw = uload(pi + 2 + (c + 1 < kC ? c + 1 : c));
+            sum += score_each_fast<RM, SG>(ns, a, decode_item<RM>(cw), cpu_v);
+            cw = nw;
           }
         }
       }
-    }
-
-    // ================= Score (score.go:62-102)
-    int score;
-    if (non_g) {
-      score = 100;
-    } else if (!fresh || !has_nrt || !single) {
-      score = 0;
-    } else if (pod_scope) {
-      score = score_each_fast<RM, SG>(ns, a, pod_sets, preq, cpu_v);
-    } else {  // containerScopeScore: int64(mean) over init + app containers
-      int sum = 0;
-      for (int c = 0; c < n_ctr; ++c) sum += score_each_fast<RM, SG>(ns, a, sets_of(c), creq + c * R, cpu_v);
-      score = static_cast<int>((static_cast<uint32_t>(sum) * kInv16[n_ctr]) >> 16);  // sum / n_ctr for sum <= 800
+      if (want_score) score = static_cast<int>((static_cast<uint32_t>(sum) * inv_n) >> 16);  // int64(mean): sum / n_ctr, sum <= 800
     }
 
     if (in && a.out_raw != nullptr) {
       a.out_raw[n] = score;
     } else if (in) {
-      const int64_t cell = pod * a.row_stride + n;
-      a.out_status[cell] = static_cast<uint8_t>(status);
-      a.out_score[cell] = static_cast<uint8_t>(score > 255 ? 255 : score);
+      stage[0][pod - pod0][pos] = static_cast<uint8_t>(status);
+      stage[1][pod - pod0][pos] = static_cast<uint8_t>(score > 255 ? 255 : score);
+    }
+    hw = hnext;
+  }
+  if (a.out_raw != nullptr) return;
+  __syncthreads();
+  const int rows = static_cast<int>(pod1 - pod0);
+  const int64_t col = base + lane * 4;
+  if (col < a.row_stride) {
+    for (int i = wave; i < 2 * rows; i += 4) {
+      const int p = i >> 1, tbl = i & 1;
+      uint8_t* out = (tbl ? a.out_score : a.out_status) + (pod0 + p) * a.row_stride + col;
+      *reinterpret_cast<uint32_t*>(out) = *reinterpret_cast<const uint32_t*>(&stage[tbl][p][lane * 4]);
     }
   }
 }
@@ -327,9 +380,9 @@ __global__ __launch_bounds__(256, RM == 4 ? 3 : 1) void k_nrt_fast(NrtArgs a, in
 
 bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   if (!a.fast || a.strategy == SPX_NRT_LEAST_NUMA_NODES) return false;
-  const int n_tiles = static_cast<int>((a.n_nodes + 63) / 64);
+  const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);  // windows of 256 nodes
   const int64_t chunks = (a.row_end - a.row_begin + kPodsPerUnit - 1) / kPodsPerUnit;
-  const unsigned blocks = static_cast<unsigned>((chunks * n_tiles + 3) / 4);
+  const unsigned blocks = static_cast<unsigned>(chunks * n_tiles);
   const int sg = a.strategy == SPX_NRT_BALANCED_ALLOCATION ? kSgBalanced : (a.strategy == SPX_NRT_LEAST_ALLOCATED ? kSgLeast : kSgMost);
 #define SPX_NRTF_CASE(RMV, SGV)                                                              \
   if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                           \

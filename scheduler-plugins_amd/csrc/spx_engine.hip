@@ -67,7 +67,8 @@ struct spx_engine {
   DevBuf d_nrt_flags, d_nrt_max_numa, d_nrt_nz, d_nrt_zid, d_nrt_zp, d_nrt_avail, d_nrt_cost, d_nrt_minavg, d_nrt_np;
   DevBuf d_nrt_qos, d_nrt_nn, d_nrt_nctr, d_nrt_ckind, d_nrt_cpres, d_nrt_creq, d_nrt_ppres, d_nrt_preq;
   // float64 formulation of the NRT sweep (kernels_nrt_fast.hip): derived tables + whether its preconditions hold
-  DevBuf d_nrt_fav, d_nrt_frc, d_nrt_fcpu, d_nrt_frep, d_nrt_cq2, d_nrt_pq2, d_nrt_wtab, d_nrt_phdr;
+  DevBuf d_nrt_fav, d_nrt_frc, d_nrt_fcpu, d_nrt_frep, d_nrt_items, d_nrt_perm;
+  std::vector<double> nrt_wtab;  // [2^n_res][2]: sum of the weights of a slot subset, its biased reciprocal
   bool nrt_fast_slots = false, nrt_fast_nodes = false, nrt_fast_pods = false;
   int32_t nrt_cpu_slot = -1;
   DevBuf status[SPX_NUM_PLUGINS];
@@ -248,10 +249,8 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   na.f_rc = static_cast<const double*>(e->d_nrt_frc.p);
   na.f_cpu = static_cast<const double*>(e->d_nrt_fcpu.p);
   na.f_rep = static_cast<const uint8_t*>(e->d_nrt_frep.p);
-  na.ctr_q2 = static_cast<const double*>(e->d_nrt_cq2.p);
-  na.pod_q2 = static_cast<const double*>(e->d_nrt_pq2.p);
-  na.wtab = static_cast<const double*>(e->d_nrt_wtab.p);
-  na.pod_hdr = static_cast<const uint32_t*>(e->d_nrt_phdr.p);
+  na.pod_items = static_cast<const uint32_t*>(e->d_nrt_items.p);
+  na.perm = static_cast<const int32_t*>(e->d_nrt_perm.p);
 }
 
 // quantities the float64 NRT kernel may hold exactly, with room for x100 and the reciprocal trick
@@ -336,7 +335,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_raw_row,   &e->d_lv_exact, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
-                    &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_cq2,   &e->d_nrt_pq2, &e->d_nrt_wtab, &e->d_nrt_phdr,
+                    &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm,
                     &e->d_net_region, &e->d_net_zone, &e->d_net_class, &e->d_net_class16, &e->d_net_cls_size, &e->d_net_cls_region, &e->d_net_cls_zone,
                     &e->d_net_rcost, &e->d_net_zcost, &e->d_net_pod_key, &e->d_net_key_flag, &e->d_net_pair_ptr,
                     &e->d_net_pair_node, &e->d_net_pair_max, &e->d_q_pod_ns, &e->d_q_pod_prio, &e->d_q_pod_req, &e->d_q_pod_reqp,
@@ -494,9 +493,7 @@ int spx_upload_nrt_slots(spx_engine* e, const spx_nrt_slots* t) {
       wtab[2 * m] = static_cast<double>(w);
       wtab[2 * m + 1] = nrt_biased_rcp(static_cast<double>(w));
     }
-  int rc = upload(e, e->d_nrt_wtab, wtab.data(), wtab.size() * sizeof(double));
-  if (rc) return rc;
-  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  e->nrt_wtab = std::move(wtab);
   return SPX_OK;
 }
 
@@ -542,6 +539,22 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
       }
     }
     e->nrt_fast_nodes = ok;
+    // window-local node order: inside each run of 256 nodes, group the nodes by the code path their flags select
+    // (not aligned / pod scope / container scope) so that wavefronts are mostly homogeneous
+    const int64_t n_slots = spx::round_up(n, 256);
+    std::vector<int32_t> perm(static_cast<size_t>(n_slots), -1);
+    for (int64_t w0 = 0; w0 < n; w0 += 256) {
+      const int64_t w1 = std::min<int64_t>(w0 + 256, n);
+      int64_t k = w0;
+      for (int cls = 0; cls < 3; ++cls)
+        for (int64_t i = w0; i < w1; ++i) {
+          const uint8_t f = t->flags[i];
+          const bool aligned = (f & SPX_NRT_F_FRESH) && (f & SPX_NRT_F_HAS_NRT) && (f & SPX_NRT_F_SINGLE_NUMA);
+          const int c = !aligned ? 0 : ((f & SPX_NRT_F_POD_SCOPE) ? 1 : 2);
+          if (c == cls) perm[static_cast<size_t>(k++)] = static_cast<int32_t>(i);
+        }
+    }
+    if ((rc = upload(e, e->d_nrt_perm, perm.data(), perm.size() * sizeof(int32_t)))) return rc;
     if ((rc = upload(e, e->d_nrt_fav, av.data(), av.size() * sizeof(double)))) return rc;
     if ((rc = upload(e, e->d_nrt_frc, rcp.data(), rcp.size() * sizeof(double)))) return rc;
     if ((rc = upload(e, e->d_nrt_fcpu, cpuv.data(), cpuv.size() * sizeof(double)))) return rc;
@@ -569,64 +582,62 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
   if ((rc = upload(e, e->d_nrt_creq, t->ctr_req, p * Cm * R * 8))) return rc;
   if ((rc = upload(e, e->d_nrt_ppres, t->pod_present, p))) return rc;
   if ((rc = upload(e, e->d_nrt_preq, t->pod_req, p * R * 8))) return rc;
-  {  // float64 formulation: (request, Value(request)) pairs + precondition check
-    std::vector<double> cq(p * Cm * R * 2), pq(p * R * 2);
-    bool ok = true;
-    for (size_t i = 0; i < p * Cm * R; ++i) {
-      const int64_t q = t->ctr_req[i];
-      if (!nrt_fast_qty(q)) ok = false;
-      cq[2 * i] = static_cast<double>(q);
-      cq[2 * i + 1] = static_cast<double>(nrt_value_of(static_cast<int32_t>(i % R) == e->nrt_cpu_slot, q));
-    }
-    for (size_t i = 0; i < p * R; ++i) {
-      const int64_t q = t->pod_req[i];
-      if (!nrt_fast_qty(q)) ok = false;
-      pq[2 * i] = static_cast<double>(q);
-      pq[2 * i + 1] = static_cast<double>(nrt_value_of(static_cast<int32_t>(i % R) == e->nrt_cpu_slot, q));
-    }
-    // nrt_pod_header: 16 dwords per pod, read by the float64 kernel with one scalar load
-    //   w0      qos | non_native << 8 | n_ctr << 16 | last app container << 24 (0xff: none)
-    //   w1,w2   ctr_kind[0..7]
-    //   w3,w4   per container: requested slots            w5,w6   ...compared per zone (non-zero, not "always")
-    //   w7,w8   ...any reporting zone suits (non-zero, non-Guaranteed pod, NUMA-affine resource)
-    //   w9,w10  ...explicit zero quantities                w11     the same four sets for the pod-level request
-    std::vector<uint32_t> hdr(p * 16, 0u);
+  {  // float64 formulation: the pod record stream + precondition check
+    // nrt_pod_items: per pod 10 items of IW dwords (IW = 16 for <= 4 resource slots, else 32), RM = 4 or 8 slots:
+    //   item 0   header: w0 = qos | non_native << 8 | n_ctr << 16 | last app container << 24 (0xff: none),
+    //                    w1 = ceil(2^16 / n_ctr)
+    //   item 1   the pod-level effective request;  items 2..9  the containers, in order
+    //   request item: doubles raw[RM] (dwords 0..2RM-1), Value() of the cpu request (2RM), sum of the weights of the
+    //                 requested slots (2RM+2) and its biased reciprocal (2RM+4); dword 2RM+6 =
+    //                 requested slots | compared slots << 8 | "any reporting zone suits" slots << 16 | kind << 24
+    const int RMs = R <= 4 ? 4 : 8;
+    const size_t IW = R <= 4 ? 16 : 32;
+    std::vector<uint32_t> items(p * 10 * IW, 0u);
     const uint32_t slot_mask = (1u << R) - 1u;
+    bool ok = e->nrt_wtab.size() == (static_cast<size_t>(2) << R);
+    auto put_f64 = [](uint32_t* w, double v) { std::memcpy(w, &v, sizeof v); };
+    auto fill = [&](uint32_t* w, uint32_t present, const int64_t* req, bool non_g, uint32_t kind) {
+      const uint32_t used = present & slot_mask;
+      uint32_t fit = 0, always = 0;
+      for (size_t r = 0; r < R; ++r) {
+        if (!nrt_fast_qty(req[r])) ok = false;
+        put_f64(w + 2 * r, static_cast<double>(req[r]));
+        if (!((used >> r) & 1u) || req[r] == 0) continue;  // "ignoring zero-qty resource request" filter.go:103-106
+        if (non_g && (e->nrt_slot_flags[r] & SPX_NRT_SLOT_AFFINE)) always |= 1u << r;
+        else fit |= 1u << r;
+      }
+      const int64_t cpu_q = e->nrt_cpu_slot >= 0 ? req[e->nrt_cpu_slot] : 0;
+      put_f64(w + 2 * RMs, static_cast<double>(nrt_value_of(true, cpu_q)));
+      if (ok) {
+        put_f64(w + 2 * RMs + 2, e->nrt_wtab[2 * used]);
+        put_f64(w + 2 * RMs + 4, e->nrt_wtab[2 * used + 1]);
+      }
+      w[2 * RMs + 6] = used | (fit << 8) | (always << 16) | (kind << 24);
+    };
     for (size_t i = 0; i < p; ++i) {
-      uint32_t* w = &hdr[i * 16];
+      uint32_t* w = &items[i * 10 * IW];
       const bool non_g = t->qos[i] != SPX_QOS_GUARANTEED;
+      const uint32_t n_ctr = t->n_ctr[i];
       uint32_t last_app = 0xffu;
-      auto sets = [&](uint32_t present, const int64_t* req, uint32_t out[4]) {
-        out[0] = present & slot_mask;
-        out[1] = out[2] = out[3] = 0;
-        for (size_t r = 0; r < R; ++r) {
-          if (!((out[0] >> r) & 1u)) continue;
-          if (req[r] == 0) out[3] |= 1u << r;
-          else if (non_g && (e->nrt_slot_flags[r] & SPX_NRT_SLOT_AFFINE)) out[2] |= 1u << r;
-          else out[1] |= 1u << r;
-        }
-      };
+      bool seen_app = false;
       for (size_t c = 0; c < Cm; ++c) {
         const uint32_t kind = t->ctr_kind[i * Cm + c];
-        if (c < t->n_ctr[i] && kind == SPX_CTR_APP) last_app = static_cast<uint32_t>(c);
-        uint32_t st[4];
-        sets(t->ctr_present[i * Cm + c], t->ctr_req + (i * Cm + c) * R, st);
-        const unsigned sh = 8 * (c % 4);
-        w[1 + c / 4] |= kind << sh;
-        w[3 + c / 4] |= st[0] << sh;
-        w[5 + c / 4] |= st[1] << sh;
-        w[7 + c / 4] |= st[2] << sh;
-        w[9 + c / 4] |= st[3] << sh;
+        if (c < n_ctr) {
+          if (kind == SPX_CTR_APP) {
+            last_app = static_cast<uint32_t>(c);
+            seen_app = true;
+          } else if (seen_app) {
+            ok = false;  // the single-pass Filter needs init containers listed before app containers
+          }
+        }
+        fill(w + (2 + c) * IW, t->ctr_present[i * Cm + c], t->ctr_req + (i * Cm + c) * R, non_g, kind);
       }
-      uint32_t st[4];
-      sets(t->pod_present[i], t->pod_req + i * R, st);
-      w[11] = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
-      w[0] = t->qos[i] | (static_cast<uint32_t>(t->non_native[i] != 0) << 8) | (static_cast<uint32_t>(t->n_ctr[i]) << 16) | (last_app << 24);
+      fill(w + IW, t->pod_present[i], t->pod_req + i * R, non_g, 0);
+      w[0] = t->qos[i] | (static_cast<uint32_t>(t->non_native[i] != 0) << 8) | (n_ctr << 16) | (last_app << 24);
+      w[1] = n_ctr ? (65536u + n_ctr - 1u) / n_ctr : 0u;
     }
-    if ((rc = upload(e, e->d_nrt_phdr, hdr.data(), hdr.size() * sizeof(uint32_t)))) return rc;
+    if ((rc = upload(e, e->d_nrt_items, items.data(), items.size() * sizeof(uint32_t)))) return rc;
     e->nrt_fast_pods = ok;
-    if ((rc = upload(e, e->d_nrt_cq2, cq.data(), cq.size() * sizeof(double)))) return rc;
-    if ((rc = upload(e, e->d_nrt_pq2, pq.data(), pq.size() * sizeof(double)))) return rc;
     SPX_HIP(e, hipStreamSynchronize(e->stream));
   }
   e->nrt_pods = true;

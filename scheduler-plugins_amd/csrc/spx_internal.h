@@ -108,10 +108,8 @@ struct NrtArgs {
   const double* f_rc;            // [Z][n_res][N] RN(100 / Value(capacity)), kNrtNoCap when the capacity is not positive
   const double* f_cpu;           // [Z][N] Value() of the cpu capacity
   const uint8_t* f_rep;          // [n_res][N] mask of the zones reporting the resource
-  const double* ctr_q2;          // [P][8][n_res][2] (request, Value(request))
-  const double* pod_q2;          // [P][n_res][2]
-  const uint32_t* pod_hdr;       // [P][16] packed pod header (layout: spx_engine.hip nrt_pod_header)
-  const double* wtab;            // [2^n_res][2] (sum of weights of the resource subset, its biased reciprocal)
+  const int32_t* perm;           // [ceil(N/256)*256] node index per slot, windows of 256 ordered by code path; -1 = empty
+  const uint32_t* pod_items;     // [P][10][16 or 32] pod record stream (layout: spx_engine.hip nrt_pod_items)
 };
 constexpr double kNrtNoCap = 1e200;
 void launch_nrt(const NrtArgs& a, hipStream_t s);
