@@ -197,6 +197,7 @@ __device__ __forceinline__ uint32_t to_u8(double unrounded) {
   return static_cast<uint32_t>(v);
 }
 
+typedef float F32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int NPL>
@@ -458,8 +459,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
   const int pod_bad = (my_pod_i < 0 || my_pod_i >= (1 << 23)) ? 1 : 0;
 
   uint32_t alloc_w[NPL / 4];
-  float b2h[NPL], b2l[NPL];  // b2 = b2h + b2l, b2h integer-valued with |b2h| < 2^23, |b2l| <= 0.5
-  float kc1[NPL], kc2[NPL];
+  // b2 = b2h + b2l, b2h integer-valued with |b2h| < 2^23, |b2l| <= 0.5 — kept as pairs of nodes so that the two adds
+  // of u run as v_pk_add_f32; kc = (coefficient of the u > 0 branch, coefficient of the u <= 0 branch) per node so that
+  // both branches come out of one v_pk_fma_f32
+  F32x2 b2h[NPL / 2], b2l[NPL / 2];
+  F32x2 kc[NPL];
+  bool lane_nan = false;  // one of this lane's nodes always takes the exact path
   const double t = a.tlp_target;
   if constexpr (A) {
 #pragma unroll
@@ -493,10 +498,10 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
     // u = (pod + b2h) + b2l: the first add is exact (two integers below 2^23), the second rounds once — the same
     // single float32 rounding a float64 add followed by a conversion would make, without the two float64-rate ops
     const double bh = split ? __builtin_rint(b) : b;
-    b2h[j] = static_cast<float>(bh);
-    b2l[j] = split ? static_cast<float>(b - bh) : 0.0f;
-    kc1[j] = f1;
-    kc2[j] = f2;
+    lane_nan |= bh != bh;
+    b2h[j >> 1][j & 1] = static_cast<float>(bh);
+    b2l[j >> 1][j & 1] = split ? static_cast<float>(b - bh) : 0.0f;
+    kc[j] = F32x2{f1, f2};
   }
   // no early exit for lanes past the row: every lane stays live so that the v_readlane broadcasts below always read
   // registers that were written under a full exec mask (stores are guarded by `active` instead)
@@ -510,30 +515,54 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
     }
     const float pod_f = __int_as_float(__builtin_amdgcn_readlane(pod_bits, r));
     const bool row_bad = __builtin_amdgcn_readlane(pod_bad, r) != 0;
-    bool amb[NPL];
     bool any = row_bad;
     uint32_t w[NPL / 4];
+    const F32x2 pod2{pod_f, pod_f};
+    const F32x2 off2{tf, 100.0f};
+    // one cell: rounded float32 score and whether it is provably the reference's result
+    auto cell = [&](int i, const F32x2& pod2, float* rr) -> bool {
+      const F32x2 u2 = (pod2 + b2h[i >> 1]) + b2l[i >> 1];  // shared by the two cells of the pair
+      const float u = u2[i & 1];
+      const bool gt = __float_as_int(u) > 0;  // u > 0 on the float's bit pattern (NaN is caught by the tie test)
+      const F32x2 x12 = __builtin_elementwise_fma(kc[i], F32x2{u, u}, off2);
+      const float x = gt ? x12.x : x12.y;
+      *rr = __builtin_rintf(x);
+      return !(__builtin_fabsf(x - *rr) < kHalf) || !(__builtin_fabsf(u) > kTolU);
+    };
+    // the row's worst rounding margin and smallest |u| as running float max/min (v_max3/v_min3: half an instruction per
+    // cell) instead of 32 compares and a chain of lane-mask ORs; NaN cells (nodes outside the float32 range) are
+    // invisible to max/min and are flagged per lane by lane_nan
+    float worst = 0.0f, minu = 1e30f;
 #pragma unroll
     for (int j = 0; j < NPL / 4; ++j) {
       uint32_t acc = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = j * 4 + q;
-        const float u = (pod_f + b2h[i]) + b2l[i];
-        const bool gt = __float_as_int(u) > 0;  // u > 0 on the float's bit pattern (NaN is caught by the tie test)
-        const float x = __builtin_fmaf(gt ? kc1[i] : kc2[i], u, gt ? tf : 100.0f);
+        const F32x2 u2 = (pod2 + b2h[i >> 1]) + b2l[i >> 1];
+        const float u = u2[i & 1];
+        const bool gt = __float_as_int(u) > 0;
+        const F32x2 x12 = __builtin_elementwise_fma(kc[i], F32x2{u, u}, off2);
+        const float x = gt ? x12.x : x12.y;
         const float rr = __builtin_rintf(x);
-        amb[i] = !(__builtin_fabsf(x - rr) < kHalf) || !(__builtin_fabsf(u) > kTolU);
-        any |= amb[i];
+        worst = __builtin_fmaxf(worst, __builtin_fabsf(x - rr));
+        minu = __builtin_fminf(minu, __builtin_fabsf(u));
         acc = __builtin_amdgcn_cvt_pk_u8_f32(rr, q, acc);
       }
       w[j] = acc;
     }
+    any |= lane_nan || !(worst < kHalf) || !(minu > kTolU);
     if (__builtin_expect(any, 0)) {
+      // rare (~8e-5 of cells on continuous inputs): find the ambiguous cells again and re-evaluate them exactly from
+      // the original node columns.  Recomputing the flags here is cheaper than carrying 16 of them across the branch.
       const double pod_milli = static_cast<double>(a.tlp_pod_milli[pod0 + r]);
+      float pf = pod_f;
+      asm volatile("" : "+v"(pf));  // opaque copy: keeps the compiler from carrying the 16 flags across the branch instead
+      const F32x2 pod2s{pf, pf};
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
-        if (amb[i] || row_bad) {  // exact re-evaluation of this cell from the original node columns
+        float rr;
+        if (cell(i, pod2s, &rr) || row_bad) {
           const int64_t n = node0 + i;
           uint32_t b = 0;
           if (n < a.n_nodes) {
