@@ -115,19 +115,31 @@ __global__ __launch_bounds__(64) void k_best(ProfileArgs a) {
   int64_t best = INT64_MIN;
   int best_n = -1, ties = 0, feas = 0;
   const bool pod_ok = !a.prefilter || a.prefilter[pod] == 0;
-  for (int64_t n = lane; n < a.n_nodes && pod_ok; n += 64) {
-    if (!feasible_at(a, pod, n)) continue;
-    ++feas;
-    int64_t total = 0;
+  const int64_t tiles = pod_ok ? (a.n_nodes + 64 * kNpl - 1) / (64 * kNpl) : 0;
+  for (int64_t t = 0; t < tiles; ++t) {  // 4 consecutive nodes per lane: one dword per table
+    const int64_t n0 = (t * 64 + lane) * kNpl;
+    if (n0 >= a.n_nodes) continue;
+    const uint32_t bad = infeasible4(a, pod, n0);
+    uint32_t sc[SPX_NUM_PLUGINS];
 #pragma unroll
     for (int k = 0; k < SPX_NUM_PLUGINS; ++k)
-      if (a.score[k]) total += a.weight[k] * static_cast<int64_t>(a.score[k][pod * a.row_stride + n]);
-    if (total > best) {
-      best = total;
-      best_n = static_cast<int>(n);
-      ties = 1;
-    } else if (total == best) {
-      ++ties;
+      sc[k] = a.score[k] ? *reinterpret_cast<const uint32_t*>(a.score[k] + pod * a.row_stride + n0) : 0u;
+#pragma unroll
+    for (int j = 0; j < kNpl; ++j) {
+      const int64_t n = n0 + j;
+      if (n >= a.n_nodes || ((bad >> (8 * j)) & 0xffu)) continue;
+      ++feas;
+      int64_t total = 0;
+#pragma unroll
+      for (int k = 0; k < SPX_NUM_PLUGINS; ++k)
+        if (a.score[k]) total += a.weight[k] * static_cast<int64_t>((sc[k] >> (8 * j)) & 0xffu);
+      if (total > best) {  // a lane walks its nodes in increasing order: `>` keeps the lowest index among equals
+        best = total;
+        best_n = static_cast<int>(n);
+        ties = 1;
+      } else if (total == best) {
+        ++ties;
+      }
     }
   }
 #pragma unroll

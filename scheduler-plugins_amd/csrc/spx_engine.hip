@@ -83,7 +83,9 @@ struct spx_engine {
   // profile-level state
   DevBuf d_ext_status;  // caller's feasibility mask, stored as a status table (0 = feasible)
   bool ext_mask = false;
-  DevBuf d_best_node, d_best_score, d_best_ties, d_best_feas;
+  DevBuf d_best;              // [score int64 P | node int32 P | ties int32 P | feasible int32 P], one allocation
+  void* h_best = nullptr;     // pinned staging of the same layout: one D2H per spx_fetch_best
+  size_t h_best_bytes = 0;
   bool best_valid = false;
 
   // CapacityScheduling.PreFilter
@@ -341,7 +343,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_net_pair_node, &e->d_net_pair_max, &e->d_q_pod_ns, &e->d_q_pod_prio, &e->d_q_pod_req, &e->d_q_pod_reqp,
                     &e->d_q_has, &e->d_q_used, &e->d_q_max, &e->d_q_maxp, &e->d_q_other, &e->d_q_otherp, &e->d_q_nom_ptr,
                     &e->d_q_nom_prio, &e->d_q_nom_idx, &e->d_q_nom_req, &e->d_q_nom_reqp, &e->d_q_status, &e->d_ext_status,
-                    &e->d_best_node, &e->d_best_score, &e->d_best_ties, &e->d_best_feas};
+                    &e->d_best};
   for (DevBuf* b : bufs)
     if (b->p && !b->external) (void)hipFree(b->p);
   for (int i = 0; i < SPX_NUM_PLUGINS; ++i) {
@@ -350,6 +352,7 @@ int spx_destroy(spx_engine* e) {
   }
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->h_best) (void)hipHostFree(e->h_best);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
   return SPX_OK;
@@ -1067,10 +1070,7 @@ int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_
   if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
   int rc;
   const size_t P = static_cast<size_t>(e->n_pods);
-  if ((rc = ensure(e, e->d_best_node, P * 4))) return rc;
-  if ((rc = ensure(e, e->d_best_score, P * 8))) return rc;
-  if ((rc = ensure(e, e->d_best_ties, P * 4))) return rc;
-  if ((rc = ensure(e, e->d_best_feas, P * 4))) return rc;
+  if ((rc = ensure(e, e->d_best, P * 20))) return rc;
   spx::ProfileArgs pa{};
   pa.n_nodes = e->n_nodes;
   pa.row_stride = e->row_stride;
@@ -1088,10 +1088,10 @@ int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_
     }
     pa.weight[k] = e->plugin_weight[k];
   }
-  pa.best_node = static_cast<int32_t*>(e->d_best_node.p);
-  pa.best_score = static_cast<int64_t*>(e->d_best_score.p);
-  pa.best_ties = static_cast<int32_t*>(e->d_best_ties.p);
-  pa.best_feasible = static_cast<int32_t*>(e->d_best_feas.p);
+  pa.best_score = static_cast<int64_t*>(e->d_best.p);
+  pa.best_node = reinterpret_cast<int32_t*>(pa.best_score + P);
+  pa.best_ties = pa.best_node + P;
+  pa.best_feasible = pa.best_ties + P;
   spx::launch_best(pa, e->stream);
   SPX_HIP(e, hipGetLastError());
   e->best_valid = true;
@@ -1104,11 +1104,23 @@ int spx_fetch_best(spx_engine* e, int64_t row_begin, int64_t row_end, int32_t* n
   if (!e->best_valid) return fail(e, SPX_ERR_STATE, "spx_eval_best has not run since the last spx_eval");
   if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
   const size_t n = static_cast<size_t>(row_end - row_begin);
+  const size_t P = static_cast<size_t>(e->n_pods);
+  // one D2H of the whole decision block into pinned memory, then scatter into the caller's arrays
+  if (e->h_best_bytes < P * 20) {
+    if (e->h_best) SPX_HIP(e, hipHostFree(e->h_best));
+    e->h_best = nullptr;
+    e->h_best_bytes = 0;
+    SPX_HIP(e, hipHostMalloc(&e->h_best, P * 20, hipHostMallocDefault));
+    e->h_best_bytes = P * 20;
+  }
+  SPX_HIP(e, hipMemcpyAsync(e->h_best, e->d_best.p, P * 20, hipMemcpyDeviceToHost, e->stream));
   SPX_HIP(e, hipStreamSynchronize(e->stream));
-  SPX_HIP(e, hipMemcpy(node_idx, static_cast<const int32_t*>(e->d_best_node.p) + row_begin, n * 4, hipMemcpyDeviceToHost));
-  SPX_HIP(e, hipMemcpy(weighted_score, static_cast<const int64_t*>(e->d_best_score.p) + row_begin, n * 8, hipMemcpyDeviceToHost));
-  if (n_ties) SPX_HIP(e, hipMemcpy(n_ties, static_cast<const int32_t*>(e->d_best_ties.p) + row_begin, n * 4, hipMemcpyDeviceToHost));
-  if (n_feasible) SPX_HIP(e, hipMemcpy(n_feasible, static_cast<const int32_t*>(e->d_best_feas.p) + row_begin, n * 4, hipMemcpyDeviceToHost));
+  const int64_t* hs = static_cast<const int64_t*>(e->h_best);
+  const int32_t* hn = reinterpret_cast<const int32_t*>(hs + P);
+  std::memcpy(weighted_score, hs + row_begin, n * 8);
+  std::memcpy(node_idx, hn + row_begin, n * 4);
+  if (n_ties) std::memcpy(n_ties, hn + P + row_begin, n * 4);
+  if (n_feasible) std::memcpy(n_feasible, hn + 2 * P + row_begin, n * 4);
   return SPX_OK;
 }
 
