@@ -20,7 +20,7 @@ LIB = PKG / "libspx.so"
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA = os.environ.get("SPX_EXTRA_CFLAGS", "").split()
-COMMON = [*EXTRA, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+COMMON = [*EXTRA, "-O3", "-std=c++17", "-fPIC", "-pthread", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
           f"-I{ROOT / 'include'}"]
 DEVICE = ["--offload-arch=gfx950"]
 
@@ -30,7 +30,7 @@ def _sources():
 
 
 def _deps_mtime() -> float:
-    hdrs = list(CSRC.glob("*.h")) + list(HOST.glob("*.h")) + list((ROOT / "include").glob("*.h")) + [Path(__file__)]
+    hdrs = list(CSRC.glob("*.h")) + list(HOST.glob("*.h")) + list(HOST.glob("*.hpp")) + list((ROOT / "include").glob("*.h")) + [Path(__file__)]
     return max(h.stat().st_mtime for h in hdrs)
 
 
@@ -61,7 +61,7 @@ def build(verbose: bool = False, force: bool = False) -> Path:
         if verbose and out.strip():
             print(out)
     if rebuilt or not LIB.exists() or force:
-        cmd = [HIPCC, "-shared", "-fPIC", *DEVICE, "-o", str(LIB), *map(str, objs)]
+        cmd = [HIPCC, "-shared", "-fPIC", "-pthread", *DEVICE, "-o", str(LIB), *map(str, objs)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

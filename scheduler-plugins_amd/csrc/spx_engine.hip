@@ -12,7 +12,10 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+
 #include "spx_internal.h"
+#include "../host/parallel.hpp"
 
 namespace {
 
@@ -597,7 +600,7 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
     const size_t IW = R <= 4 ? 16 : 32;
     std::vector<uint32_t> items(p * 10 * IW, 0u);
     const uint32_t slot_mask = (1u << R) - 1u;
-    bool ok = e->nrt_wtab.size() == (static_cast<size_t>(2) << R);
+    std::atomic<bool> ok{e->nrt_wtab.size() == (static_cast<size_t>(2) << R)};
     auto put_f64 = [](uint32_t* w, double v) { std::memcpy(w, &v, sizeof v); };
     auto fill = [&](uint32_t* w, uint32_t present, const int64_t* req, bool non_g, uint32_t kind) {
       const uint32_t used = present & slot_mask;
@@ -611,13 +614,14 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
       }
       const int64_t cpu_q = e->nrt_cpu_slot >= 0 ? req[e->nrt_cpu_slot] : 0;
       put_f64(w + 2 * RMs, static_cast<double>(nrt_value_of(true, cpu_q)));
-      if (ok) {
+      if (ok.load(std::memory_order_relaxed)) {
         put_f64(w + 2 * RMs + 2, e->nrt_wtab[2 * used]);
         put_f64(w + 2 * RMs + 4, e->nrt_wtab[2 * used + 1]);
       }
       w[2 * RMs + 6] = used | (fit << 8) | (always << 16) | (kind << 24);
     };
-    for (size_t i = 0; i < p; ++i) {
+    spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
+    for (size_t i = static_cast<size_t>(row0); i < static_cast<size_t>(row1); ++i) {
       uint32_t* w = &items[i * 10 * IW];
       const bool non_g = t->qos[i] != SPX_QOS_GUARANTEED;
       const uint32_t n_ctr = t->n_ctr[i];
@@ -639,8 +643,9 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
       w[0] = t->qos[i] | (static_cast<uint32_t>(t->non_native[i] != 0) << 8) | (n_ctr << 16) | (last_app << 24);
       w[1] = n_ctr ? (65536u + n_ctr - 1u) / n_ctr : 0u;
     }
+    }, 4096);
     if ((rc = upload(e, e->d_nrt_items, items.data(), items.size() * sizeof(uint32_t)))) return rc;
-    e->nrt_fast_pods = ok;
+    e->nrt_fast_pods = ok.load();
     SPX_HIP(e, hipStreamSynchronize(e->stream));
   }
   e->nrt_pods = true;

@@ -12,7 +12,10 @@
 #include <cstring>
 #include <vector>
 
+#include <atomic>
+
 #include "../../include/spx.h"
+#include "parallel.hpp"
 
 namespace {
 
@@ -219,10 +222,15 @@ extern "C" int spx_flatten_nrt_pods(const spx_pod_objects* pods, const spx_resou
   std::memset(ctr_present, 0, static_cast<size_t>(P) * CM);
   std::memset(ctr_req, 0, static_cast<size_t>(P) * CM * R * sizeof(int64_t));
   std::memset(pod_req, 0, static_cast<size_t>(P) * R * sizeof(int64_t));
+  std::atomic<int> err{SPX_OK};
+  spx_host::parallel_rows(P, [&](int64_t row0, int64_t row1) {
   std::vector<KV> init_res, res;
-  for (int64_t i = 0; i < P; ++i) {
+  for (int64_t i = row0; i < row1; ++i) {
     const int32_t c0 = pods->ctr_ptr[i], c1 = pods->ctr_ptr[i + 1];
-    if (c1 - c0 > CM) return SPX_ERR_ARG;
+    if (c1 - c0 > CM) {
+      err = SPX_ERR_ARG;
+      return;
+    }
     qos[i] = static_cast<uint8_t>(pod_qos(pods, i));
     bool nn = false;
     n_ctr[i] = static_cast<uint8_t>(c1 - c0);
@@ -232,7 +240,10 @@ extern "C" int spx_flatten_nrt_pods(const spx_pod_objects* pods, const spx_resou
       uint8_t present = 0;
       for (int32_t k = pods->req_ptr[c]; k < pods->req_ptr[c + 1]; ++k) {
         const int s = slot_of(slots, pods->req_res[k]);
-        if (s < 0) return SPX_ERR_ARG;
+        if (s < 0) {
+          err = SPX_ERR_ARG;
+          return;
+        }
         present |= static_cast<uint8_t>(1u << s);
         ctr_req[slot_base * R + s] = pods->req_qty[k];
         if (!rc_has(rc, pods->req_res[k], SPX_RC_NATIVE)) nn = true;
@@ -275,11 +286,15 @@ extern "C" int spx_flatten_nrt_pods(const spx_pod_objects* pods, const spx_resou
     uint8_t pp = 0;
     for (const KV& e : res) {
       const int s = slot_of(slots, e.res);
-      if (s < 0) return SPX_ERR_ARG;
+      if (s < 0) {
+        err = SPX_ERR_ARG;
+        return;
+      }
       pp |= static_cast<uint8_t>(1u << s);
       pod_req[i * R + s] = e.qty;
     }
     pod_present[i] = pp;
   }
-  return SPX_OK;
+  }, 4096);
+  return err.load();
 }

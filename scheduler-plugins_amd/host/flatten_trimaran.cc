@@ -14,6 +14,7 @@
 #include <cstdint>
 
 #include "../../include/spx.h"
+#include "parallel.hpp"
 
 namespace {
 
@@ -153,7 +154,8 @@ extern "C" int spx_flatten_trimaran_nodes(const spx_node_objects* nodes, const s
 extern "C" int spx_flatten_trimaran_pods(const spx_pod_objects* pods, const spx_tlp_params* tlp,
                                          int64_t* tlp_pod_milli_out, int64_t* lv_req_cpu_milli, int64_t* lv_req_mem) {
   if (!pods || !tlp) return SPX_ERR_ARG;
-  for (int64_t i = 0; i < pods->n_pods; ++i) {
+  spx_host::parallel_rows(pods->n_pods, [&](int64_t row0, int64_t row1) {
+  for (int64_t i = row0; i < row1; ++i) {
     if (tlp_pod_milli_out) tlp_pod_milli_out[i] = tlp_pod_milli(pods, i, tlp);
     int64_t cpu = 0, mem = 0, q;
     for (int32_t c = pods->ctr_ptr[i]; c < pods->ctr_ptr[i + 1]; ++c) {
@@ -173,5 +175,6 @@ extern "C" int spx_flatten_trimaran_pods(const spx_pod_objects* pods, const spx_
     if (lv_req_cpu_milli) lv_req_cpu_milli[i] = cpu;
     if (lv_req_mem) lv_req_mem[i] = mem;
   }
+  });
   return SPX_OK;
 }
