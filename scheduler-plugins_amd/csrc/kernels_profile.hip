@@ -49,11 +49,68 @@ __device__ __forceinline__ uint32_t infeasible4(const ProfileArgs& a, int64_t po
   return w;
 }
 
+// compact path: raw scores as uint32 offsets from the global minimum (k_alloc_prepare) — 4 B instead of 8 B per node
+// read from L2 per row and pass, 32-bit min/max, and the quotient as one float64 multiply (range < 2^32 < 2^42).
+// The first pass leaves each lane's 4 feasibility bits per tile in LDS (one byte), so the status tables — whose rows
+// do not survive in L2 between the passes at full occupancy — are read from HBM once.
+__device__ __forceinline__ void alloc_masked_compact(const ProfileArgs& a, int64_t pod, int lane, int64_t tiles, uint8_t* feas) {
+  uint32_t lo = 0xffffffffu, hi = 0u;
+  bool any = false;
+#pragma unroll 4
+  for (int64_t t = 0; t < tiles; ++t) {
+    const int64_t n0 = (t * 64 + lane) * kNpl;
+    uint32_t ok = 0;
+    if (n0 < a.n_nodes) {
+      const uint32_t bad = infeasible4(a, pod, n0);
+      const uint4 r4 = *reinterpret_cast<const uint4*>(a.alloc_rel + n0);
+      const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+      for (int j = 0; j < kNpl; ++j) {
+        if (n0 + j >= a.n_nodes || ((bad >> (8 * j)) & 0xffu)) continue;
+        lo = r[j] < lo ? r[j] : lo;
+        hi = r[j] > hi ? r[j] : hi;
+        ok |= 1u << j;
+      }
+    }
+    any |= ok != 0;
+    feas[t * 64 + lane] = static_cast<uint8_t>(ok);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const uint32_t olo = __shfl_xor(lo, m, 64), ohi = __shfl_xor(hi, m, 64);
+    lo = olo < lo ? olo : lo;
+    hi = ohi > hi ? ohi : hi;
+  }
+  const bool some = __ballot(any) != 0;
+  const uint32_t range = some ? hi - lo : 0u;
+  const double b = range ? (100.0 / static_cast<double>(range)) * (1.0 + 0x1p-49) : 0.0;
+#pragma unroll 4
+  for (int64_t t = 0; t < tiles; ++t) {
+    const int64_t n0 = (t * 64 + lane) * kNpl;
+    if (n0 >= a.row_stride) continue;
+    uint32_t w = 0;
+    const uint32_t ok = feas[t * 64 + lane];  // written by this lane
+    if (ok != 0 && range != 0) {
+      const uint4 r4 = *reinterpret_cast<const uint4*>(a.alloc_rel + n0);
+      const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+      for (int j = 0; j < kNpl; ++j)
+        if ((ok >> j) & 1u) w |= static_cast<uint32_t>(static_cast<double>(r[j] - lo) * b) << (8 * j);  // infeasible cells hold 0
+    }
+    *reinterpret_cast<uint32_t*>(a.out_alloc + pod * a.row_stride + n0) = w;
+  }
+}
+
 __global__ __launch_bounds__(64) void k_alloc_masked(ProfileArgs a) {
   const int lane = threadIdx.x;
   const int64_t pod = a.row_begin + blockIdx.x;
   if (pod >= a.row_end) return;
   const int64_t tiles = (a.row_stride + 64 * kNpl - 1) / (64 * kNpl);
+  extern __shared__ uint8_t feas[];  // [tiles][64]
+  if (a.alloc_rel != nullptr && a.alloc_rel[a.row_stride] != 0u) {  // wave-uniform
+    alloc_masked_compact(a, pod, lane, tiles, feas);
+    return;
+  }
   int64_t lo = INT64_MAX, hi = -INT64_MAX;
   for (int64_t t = 0; t < tiles; ++t) {
     const int64_t n0 = (t * 64 + lane) * kNpl;
@@ -168,7 +225,8 @@ __global__ __launch_bounds__(64) void k_best(ProfileArgs a) {
 
 void launch_alloc_masked(const ProfileArgs& a, hipStream_t s) {
   if (a.row_end <= a.row_begin) return;
-  hipLaunchKernelGGL(k_alloc_masked, dim3(static_cast<unsigned>(a.row_end - a.row_begin)), dim3(64), 0, s, a);
+  const size_t tiles = static_cast<size_t>((a.row_stride + 64 * kNpl - 1) / (64 * kNpl));
+  hipLaunchKernelGGL(k_alloc_masked, dim3(static_cast<unsigned>(a.row_end - a.row_begin)), dim3(64), tiles * 64, s, a);
 }
 
 void launch_best(const ProfileArgs& a, hipStream_t s) {

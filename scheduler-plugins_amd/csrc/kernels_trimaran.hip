@@ -86,7 +86,11 @@ __global__ __launch_bounds__(1024) void k_alloc_prepare(AllocPrepArgs a) {
     }
     v = v < 0 ? 0 : (v > 255 ? 255 : v);
     a.norm[i] = static_cast<uint8_t>(v);
+    // compact form for the per-row masked normalisation (k_alloc_masked): offsets from the global minimum as
+    // uint32 (valid when the global range fits; the flag sits behind the last padded entry)
+    if (a.rel) a.rel[i] = i < a.n_nodes ? static_cast<uint32_t>(static_cast<uint64_t>(a.raw[i]) - static_cast<uint64_t>(lo)) : 0u;
   }
+  if (a.rel && tid == 0) a.rel[a.row_stride] = static_cast<uint64_t>(range) < (1ull << 32) ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -50,7 +50,7 @@ struct spx_engine {
   int64_t plugin_weight[SPX_NUM_PLUGINS] = {1, 1, 1, 1, 1, 1, 1};
 
   // device tables
-  DevBuf d_alloc, d_alloc_w, d_alloc_raw, d_alloc_norm;
+  DevBuf d_alloc, d_alloc_w, d_alloc_raw, d_alloc_norm, d_alloc_rel;
   int32_t alloc_n_res = 0;
   bool alloc_ready = false;  // raw/norm computed for the current table + params
   DevBuf d_cap_cpu, d_tlp_util, d_tlp_missing, d_tlp_valid;
@@ -183,6 +183,7 @@ int prepare_alloc(spx_engine* e) {
   int rc = upload(e, e->d_alloc_w, e->alloc_weight.data(), e->alloc_weight.size() * sizeof(int64_t));
   if (rc) return rc;
   if ((rc = ensure(e, e->d_alloc_raw, static_cast<size_t>(e->n_nodes) * sizeof(int64_t)))) return rc;
+  if ((rc = ensure(e, e->d_alloc_rel, static_cast<size_t>(e->row_stride + 4) * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(e, e->d_alloc_norm, static_cast<size_t>(e->row_stride)))) return rc;
   spx::AllocPrepArgs a{};
   a.n_nodes = e->n_nodes;
@@ -192,6 +193,7 @@ int prepare_alloc(spx_engine* e) {
   a.alloc = static_cast<const int64_t*>(e->d_alloc.p);
   a.weight = static_cast<const int64_t*>(e->d_alloc_w.p);
   a.raw = static_cast<int64_t*>(e->d_alloc_raw.p);
+  a.rel = static_cast<uint32_t*>(e->d_alloc_rel.p);
   a.norm = static_cast<uint8_t*>(e->d_alloc_norm.p);
   spx::launch_alloc_prepare(a, e->stream);
   SPX_HIP(e, hipGetLastError());
@@ -334,7 +336,7 @@ int spx_destroy(spx_engine* e) {
   if (!e) return SPX_OK;
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
-  DevBuf* bufs[] = {&e->d_alloc,   &e->d_alloc_w,  &e->d_alloc_raw, &e->d_alloc_norm, &e->d_cap_cpu, &e->d_tlp_util,
+  DevBuf* bufs[] = {&e->d_alloc,   &e->d_alloc_w,  &e->d_alloc_raw, &e->d_alloc_norm, &e->d_alloc_rel, &e->d_cap_cpu, &e->d_tlp_util,
                     &e->d_tlp_missing, &e->d_tlp_valid, &e->d_lv_acpu, &e->d_lv_amem, &e->d_lv_cavg, &e->d_lv_cstd,
                     &e->d_lv_mavg, &e->d_lv_mstd,  &e->d_lv_flags,  &e->d_tlp_pod,    &e->d_lv_rcpu, &e->d_lv_rmem,
                     &e->d_raw_row,   &e->d_lv_exact, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
@@ -920,6 +922,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     pa.status[1] = W ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NETOVERHEAD].p) : nullptr;
     pa.status[2] = e->ext_mask ? static_cast<const uint8_t*>(e->d_ext_status.p) : nullptr;
     pa.alloc_raw = static_cast<const int64_t*>(e->d_alloc_raw.p);
+    pa.alloc_rel = static_cast<const uint32_t*>(e->d_alloc_rel.p);
     pa.out_alloc = static_cast<uint8_t*>(e->score[SPX_PLUGIN_ALLOCATABLE].p);
     spx::launch_alloc_masked(pa, e->stream);
     SPX_HIP(e, hipGetLastError());

@@ -26,6 +26,7 @@ struct AllocPrepArgs {
   const int64_t* weight;   // [n_res] (device)
   int64_t* raw;            // [n_nodes] out: Allocatable.Score per node
   uint8_t* norm;           // [row_stride] out: NormalizeScore over the full node list
+  uint32_t* rel;           // [row_stride + 1] out: raw - global min as uint32, then a flag: 1 when that form is exact
 };
 void launch_alloc_prepare(const AllocPrepArgs& a, hipStream_t s);
 
@@ -185,6 +186,7 @@ struct ProfileArgs {
   const uint8_t* status[3];                // filter status tables in play (0 = passed); NULL = unused
   const uint8_t* prefilter;                // [P] CapacityScheduling.PreFilter status, NULL = unused
   const int64_t* alloc_raw;                // [N] Allocatable raw scores
+  const uint32_t* alloc_rel;               // [row_stride + 1] compact form (AllocPrepArgs.rel)
   uint8_t* out_alloc;
   const uint8_t* score[SPX_NUM_PLUGINS];   // score tables to sum (NULL = not in the profile)
   int64_t weight[SPX_NUM_PLUGINS];
