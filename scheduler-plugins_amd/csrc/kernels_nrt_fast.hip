@@ -21,6 +21,8 @@
 //
 // Reference: pkg/noderesourcetopology/filter.go:42-245, score.go:62-191, least_allocated.go:25-55,
 // most_allocated.go:25-54, balanced_allocation.go:27-54, numaresources.go:105-182.
+#include <cstdlib>
+
 #include "spx_internal.h"
 
 namespace spx {
@@ -212,8 +214,12 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
   return static_cast<int>(m + 1u);
 }
 
-template <int RM, int SG>
-__global__ __launch_bounds__(256, RM == 4 ? (SG == kSgBalanced ? 2 : 3) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
+// PH: 0 = Filter and Score in one launch; 1 = Filter only, 2 = Score only (LeastAllocated: its Score reads only b, the
+// Filter only the mutable table, so each half keeps 64 instead of 128 state registers and runs at higher occupancy)
+constexpr int kPhBoth = 0, kPhFilter = 1, kPhScore = 2;
+
+template <int RM, int SG, int PH>
+__global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? 5 : (PH == kPhFilter ? 4 : (SG == kSgBalanced ? 2 : 3))) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
   typedef typename ItemWords<RM>::T Words;
   // A block owns a window of 256 consecutive nodes and a chunk of pod rows.  Inside the window the engine has
   // ordered the nodes by (aligned, scope) — perm[] — so that a wavefront's 64 nodes mostly share one code path
@@ -290,16 +296,20 @@ __global__ __launch_bounds__(256, RM == 4 ? (SG == kSgBalanced ? 2 : 3) : 1) voi
 
     uint32_t status = (filtered && !fresh) ? SPX_NRT_ST_INVALID_TOPOLOGY : 0u;
     int score = non_g ? 100 : 0;
-    const bool want_filter = filtered && aligned;
-    const bool want_score = !non_g && aligned;
+    const bool want_filter = PH != kPhScore && filtered && aligned;
+    const bool want_score = PH != kPhFilter && !non_g && aligned;
 
     if ((want_filter || want_score) && pod_scope) {  // singleNUMAPodLevelHandler / podScopeScore
       const Item<RM> it = decode_item<RM>(pw);
-      if (want_filter) {
-        uint32_t pos;
-        if (!fits_fast(ns, it, &pos)) status = SPX_NRT_ST_POD;
+      if constexpr (PH != kPhScore) {
+        if (want_filter) {
+          uint32_t pos;
+          if (!fits_fast(ns, it, &pos)) status = SPX_NRT_ST_POD;
+        }
       }
-      if (want_score) score = score_each_fast<RM, SG>(ns, a, it, cpu_v);
+      if constexpr (PH != kPhFilter) {
+        if (want_score) score = score_each_fast<RM, SG>(ns, a, it, cpu_v);
+      }
     }
     if ((want_filter || want_score) && !pod_scope) {  // singleNUMAContainerLevelHandler / containerScopeScore
       // One pass in container order (init containers come first — checked at upload): an init container must fit
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(256, RM == 4 ? (SG == kSgBalanced ? 2 : 3) : 1) voi
       for (int c = 0; c < n_ctr; ++c) {
         const Words nw = uload(pi + 2 + (c + 1 < kC ? c + 1 : c));  // prefetch the next container's item
         const Item<RM> it = decode_item<RM>(cw);
-        if (want_filter) {
+        if constexpr (PH != kPhScore) if (want_filter) {
           uint32_t pos;
           const bool ok = fits_fast(ns, it, &pos);
           const bool live = status == 0;
@@ -328,12 +338,12 @@ __global__ __launch_bounds__(256, RM == 4 ? (SG == kSgBalanced ? 2 : 3) : 1) voi
             }
           }
         }
-        if constexpr (SG == kSgLeast) {
+        if constexpr (SG == kSgLeast && PH != kPhFilter) {
           if (want_score) sum += score_each_fast<RM, SG>(ns, a, it, cpu_v);
         }
         cw = nw;
       }
-      if (want_filter && last_app > 0) {  // undo: Filter works on a private copy in the reference
+      if constexpr (PH != kPhScore) if (want_filter && last_app > 0) {  // undo: Filter works on a private copy in the reference
         cw = uload(pi + 2);
         for (int c = 0; c < last_app; ++c) {
           const Words nw = uload(pi + 2 + c + 1);
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(256, RM == 4 ? (SG == kSgBalanced ? 2 : 3) : 1) voi
           cw = nw;
         }
       }
-      if constexpr (SG != kSgLeast) {
+      if constexpr (SG != kSgLeast && PH != kPhFilter) {
         if (want_score) {
           cw = uload(pi + 2);
           for (int c = 0; c < n_ctr; ++c) {
@@ -358,8 +368,8 @@ __global__ __launch_bounds__(256, RM == 4 ? (SG == kSgBalanced ? 2 : 3) : 1) voi
     if (in && a.out_raw != nullptr) {
       a.out_raw[n] = score;
     } else if (in) {
-      stage[0][pod - pod0][pos] = static_cast<uint8_t>(status);
-      stage[1][pod - pod0][pos] = static_cast<uint8_t>(score > 255 ? 255 : score);
+      if constexpr (PH != kPhScore) stage[0][pod - pod0][pos] = static_cast<uint8_t>(status);
+      if constexpr (PH != kPhFilter) stage[1][pod - pod0][pos] = static_cast<uint8_t>(score > 255 ? 255 : score);
     }
     hw = hnext;
   }
@@ -370,6 +380,7 @@ __global__ __launch_bounds__(256, RM == 4 ? (SG == kSgBalanced ? 2 : 3) : 1) voi
   if (col < a.row_stride) {
     for (int i = wave; i < 2 * rows; i += 4) {
       const int p = i >> 1, tbl = i & 1;
+      if ((PH == kPhFilter && tbl == 1) || (PH == kPhScore && tbl == 0)) continue;
       uint8_t* out = (tbl ? a.out_score : a.out_status) + (pod0 + p) * a.row_stride + col;
       *reinterpret_cast<uint32_t*>(out) = *reinterpret_cast<const uint32_t*>(&stage[tbl][p][lane * 4]);
     }
@@ -384,10 +395,16 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   const int64_t chunks = (a.row_end - a.row_begin + kPodsPerUnit - 1) / kPodsPerUnit;
   const unsigned blocks = static_cast<unsigned>(chunks * n_tiles);
   const int sg = a.strategy == SPX_NRT_BALANCED_ALLOCATION ? kSgBalanced : (a.strategy == SPX_NRT_LEAST_ALLOCATED ? kSgLeast : kSgMost);
-#define SPX_NRTF_CASE(RMV, SGV)                                                              \
-  if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                           \
-    hipLaunchKernelGGL((k_nrt_fast<RMV, SGV>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
-    return true;                                                                             \
+  const bool split = sg == kSgLeast && a.out_raw == nullptr && getenv("SPX_NRT_NOSPLIT") == nullptr;
+#define SPX_NRTF_CASE(RMV, SGV)                                                                           \
+  if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                                        \
+    if (SGV == kSgLeast && split) {                                                                       \
+      hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhFilter>), dim3(blocks), dim3(256), 0, s, a, n_tiles); \
+      hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
+    } else {                                                                                              \
+      hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhBoth>), dim3(blocks), dim3(256), 0, s, a, n_tiles);     \
+    }                                                                                                     \
+    return true;                                                                                          \
   }
   SPX_NRTF_CASE(4, kSgLeast)
   SPX_NRTF_CASE(4, kSgMost)
