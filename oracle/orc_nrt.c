@@ -610,3 +610,72 @@ int64_t orc_nrt_score(const spx_nrt_objects* nrt, const spx_resource_classes* rc
   if (n == 0) return 0; /* a pod without containers cannot exist; stat.Mean of nothing is NaN in the reference */
   return (int64_t)(sum / (double)n);
 }
+
+/* ---------------------------------------------------------------- hooks for the reference's helper-level tables
+ * (numaresources_test.go, pluginhelpers_test.go, nodeconfig/topologymanager_test.go, pkg/util/resource_test.go):
+ * thin exported views of the static restatements above, so that tests/ can pin them one by one. */
+
+int orc_nrt_is_host_level(const spx_resource_classes* rc, int32_t res) { return is_host_level(rc, res); }
+int orc_nrt_is_numa_affine(const spx_resource_classes* rc, int32_t res) { return is_numa_affine(rc, res); }
+
+/* util.GetPodEffectiveRequest: writes up to cap (resource id, quantity) pairs, returns their number */
+int orc_pod_effective_request(const spx_pod_objects* pods, int64_t pod, int32_t* res_out, int64_t* qty_out, int cap) {
+  rlist r;
+  effective_request(pods, pod, &r);
+  int n = r.n < cap ? r.n : cap;
+  for (int i = 0; i < n; ++i) {
+    res_out[i] = r.res[i];
+    qty_out[i] = r.qty[i];
+  }
+  return r.n;
+}
+
+/* TopologyManagerFromNodeResourceTopology: policy 0 none / 1 best-effort / 2 restricted / 3 single-numa-node,
+ * scope 0 container / 1 pod */
+void orc_nrt_conf(const spx_nrt_objects* nrt, int64_t node, int* policy, int* scope, int* max_numa) {
+  tm_conf c = conf_of(nrt, node);
+  *policy = c.policy;
+  *scope = c.scope;
+  *max_numa = c.max_numa;
+}
+
+/* onlyNonNUMAResources(node's NUMANodeList, requests of the pod's first container) */
+int orc_nrt_only_non_numa(const spx_nrt_objects* nrt, int64_t node, const spx_pod_objects* pods, int64_t pod) {
+  numa_list nl;
+  numa_list_of(nrt, node, &nl);
+  rlist r;
+  ctr_requests(pods, pods->ctr_ptr[pod], &r);
+  return only_non_numa(&nl, &r);
+}
+
+static void dump_zones(const numa_list* nl, const int32_t* q_res, int n_q, int64_t* out) {
+  for (int z = 0; z < nl->n; ++z)
+    for (int i = 0; i < n_q; ++i) {
+      int k = rl_find(&nl->z[z].resources, q_res[i]);
+      out[z * n_q + i] = k >= 0 ? nl->z[z].resources.qty[k] : -1;
+    }
+}
+
+/* subtractResourcesFromNUMANodeList(nodes, numa_id, qos, requests of the pod's first container); out[z*n_q+i] =
+ * zone z's quantity of q_res[i] afterwards (-1: not reported); returns 0, or -1 for the reference's error */
+int orc_nrt_test_subtract_numa(const spx_nrt_objects* nrt, const spx_resource_classes* rc, int64_t node, int numa_id, int qos,
+                               const spx_pod_objects* pods, int64_t pod, const int32_t* q_res, int n_q, int64_t* out) {
+  numa_list nl;
+  numa_list_of(nrt, node, &nl);
+  rlist r;
+  ctr_requests(pods, pods->ctr_ptr[pod], &r);
+  int rc_ = subtract_from_numa(rc, &nl, numa_id, qos, &r);
+  dump_zones(&nl, q_res, n_q, out);
+  return rc_;
+}
+
+/* subtractFromNUMAs(requests of the pod's first container, nodes, ids in `bits`...) */
+void orc_nrt_test_subtract_numas(const spx_nrt_objects* nrt, int64_t node, const spx_pod_objects* pods, int64_t pod, uint64_t bits,
+                                 const int32_t* q_res, int n_q, int64_t* out) {
+  numa_list nl;
+  numa_list_of(nrt, node, &nl);
+  rlist r;
+  ctr_requests(pods, pods->ctr_ptr[pod], &r);
+  subtract_from_numas(&r, &nl, bits);
+  dump_zones(&nl, q_res, n_q, out);
+}

@@ -61,6 +61,16 @@ int orc_nrt_filter(const spx_node_objects* nodes, const spx_nrt_objects* nrt, co
 int64_t orc_nrt_score(const spx_nrt_objects* nrt, const spx_resource_classes* rc, const spx_pod_objects* pods,
                       const spx_nrt_params* p, int64_t pod, int64_t node);
 int64_t orc_nrt_normalize_score(int numa_nodes_count, int is_min_avg_distance, int highest_numa_id);
+/* hooks for the reference's helper-level tables (see the end of orc_nrt.c) */
+int orc_nrt_is_host_level(const spx_resource_classes* rc, int32_t res);
+int orc_nrt_is_numa_affine(const spx_resource_classes* rc, int32_t res);
+int orc_pod_effective_request(const spx_pod_objects* pods, int64_t pod, int32_t* res_out, int64_t* qty_out, int cap);
+void orc_nrt_conf(const spx_nrt_objects* nrt, int64_t node, int* policy, int* scope, int* max_numa);
+int orc_nrt_only_non_numa(const spx_nrt_objects* nrt, int64_t node, const spx_pod_objects* pods, int64_t pod);
+int orc_nrt_test_subtract_numa(const spx_nrt_objects* nrt, const spx_resource_classes* rc, int64_t node, int numa_id, int qos,
+                               const spx_pod_objects* pods, int64_t pod, const int32_t* q_res, int n_q, int64_t* out);
+void orc_nrt_test_subtract_numas(const spx_nrt_objects* nrt, int64_t node, const spx_pod_objects* pods, int64_t pod, uint64_t bits,
+                                 const int32_t* q_res, int n_q, int64_t* out);
 int orc_nrt_numa_nodes_required(const spx_nrt_objects* nrt, const spx_resource_classes* rc, const spx_pod_objects* pods,
                                 int64_t pod, int64_t node, int qos, uint64_t* bitmask, int* is_min_distance);
 
