@@ -17,7 +17,8 @@
 //     total rounding error < 2^-45.6; MostAllocated: t = (v * (1 + 2^-49)) * b, relative error within
 //     2^-49 +- 3 * 2^-53; the final acc / sum(weights) uses the same biased reciprocal;
 //   * Quantity.Value() of a cpu capacity (ceil(milli / 1000)) is folded into b.
-// Snapshots that fail the check (and the LeastNUMANodes strategy) run the generic kernel.
+// Snapshots that fail the check run the generic kernel.  LeastNUMANodes shares the Filter and replaces the per-lane
+// subset enumeration by one wave-uniform search (numa_required_fast).
 //
 // Reference: pkg/noderesourcetopology/filter.go:42-245, score.go:62-191, least_allocated.go:25-55,
 // most_allocated.go:25-54, balanced_allocation.go:27-54, numaresources.go:105-182.
@@ -36,6 +37,7 @@ constexpr int kWindow = 256;  // nodes per block (4 wavefronts)
 constexpr int kSgLeast = 0;
 constexpr int kSgMost = 1;
 constexpr int kSgBalanced = 2;
+constexpr int kSgLeastNuma = 3;
 constexpr double kNoCap = kNrtNoCap;  // b[][] of a cell whose capacity is not positive
 
 template <int RM>
@@ -214,12 +216,125 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
   return static_cast<int>(m + 1u);
 }
 
+// ---------------------------------------------------------------- LeastNUMANodes (least_numa.go:35-233)
+__constant__ Combo8 kCombo8 = make_combo8();
+
+// numaNodesRequired + findSuitableCombination: the smallest subset size for which some subset of zones holds the
+// request, and among the fitting subsets of that size the one the reference returns: the first (lexicographic) whose
+// average distance equals the node's minimum for the size (is_min), else the first with the smallest distance.
+// The search runs as ONE wave-uniform loop over the (size, lexicographic) table of 8-position subsets — the generic
+// kernel's per-lane loops made the wave execute the union of all lanes' iterations, each of them divergent; here a
+// subset costs every lane the same ~30 VALU operations (membership as uniform 0/1 multipliers) and the loop ends as
+// soon as every lane has its answer.  Subsets with positions past a node's zone count fail the "every member reports
+// every requested resource" test by themselves.
+template <int RM>
+__device__ __forceinline__ uint32_t numa_required_fast(const FastNode<RM>& ns, const NrtArgs& a, const Item<RM>& it, int64_t n, bool active,
+                                                       bool* is_min) {
+  uint32_t result = 0;
+  bool done = !active;
+  bool hit_min = false;
+  const uint32_t used = it.used, need = it.fit | it.always;
+  // Bounds that let the wave skip whole subset sizes.  Every valid subset lies inside V = the zones reporting all
+  // requested resources, and sums grow with the subset: if even V cannot hold the request nothing can (answer 0 at
+  // once); at least ceil(request / largest zone) zones are needed per resource; at most |V| can be used.
+  uint32_t v_all = 0xffu;
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+    if ((used >> r) & 1u) v_all &= ns.repmask(r);
+  int k_lo = 1;
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    if (!((need >> r) & 1u)) continue;
+    double total = 0.0, largest = 0.0;
+#pragma unroll
+    for (int z = 0; z < kZ; ++z) {
+      const double v = ((v_all >> z) & 1u) ? ns.av[z][r] : 0.0;
+      total += v;
+      largest = __builtin_fmax(largest, v);
+    }
+    if (total < it.raw[r]) done = true;  // no subset fits
+    // zones needed if all were as large as the largest one (a float estimate rounded down is still a lower bound)
+    const float need_f = static_cast<float>(it.raw[r]) / static_cast<float>(largest > 0.0 ? largest : 1.0);
+    const int need_k = static_cast<int>(need_f * 0.999f);
+    k_lo = need_k + 1 > k_lo ? (need_k + 1 > kZ ? kZ : need_k + 1) : k_lo;
+  }
+  const int k_hi = __builtin_popcount(v_all);
+  for (int k = 1; k <= kZ; ++k) {
+    // skip sizes no unfinished lane can use (ballots, not shuffles: part of the wave may be masked off here, and a
+    // butterfly reduction through inactive lanes loses values)
+    while (k <= kZ && __ballot(!done && k_lo <= k && k <= k_hi) == 0) ++k;
+    if (k > kZ) break;
+    const float min_avg = a.min_avg[static_cast<int64_t>(k - 1) * a.n_nodes + n];
+    uint32_t best = 0;
+    float min_distance = 256.0f;
+    const int c1 = kCombo8.start[k];
+    for (int ci = kCombo8.start[k - 1]; ci < c1; ++ci) {
+      const uint32_t m = kCombo8.mask[ci];  // wave-uniform
+      bool ok = !done;
+      // isValidCombineResources: every member reports every requested name
+#pragma unroll
+      for (int r = 0; r < RM; ++r)
+        if ((used >> r) & 1u) ok &= (ns.repmask(r) & m) == m;
+      // combineResources + checkResourcesFit: the members' sum covers every non-zero request
+      double w[kZ];
+#pragma unroll
+      for (int z = 0; z < kZ; ++z) w[z] = ((m >> z) & 1u) ? 1.0 : 0.0;
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        if (!((need >> r) & 1u)) continue;
+        double sum = 0.0;
+#pragma unroll
+        for (int z = 0; z < kZ; ++z) sum = __builtin_fma(w[z], ns.av[z][r], sum);
+        ok &= sum >= it.raw[r];
+      }
+      if (__ballot(ok) != 0) {
+        const float d = a.dist[static_cast<int64_t>(ci) * a.n_nodes + n];
+        if (ok && d == min_avg) {
+          result = m;
+          hit_min = true;
+          done = true;
+        } else if (ok && d < min_distance) {
+          min_distance = d;
+          best = m;
+        }
+      }
+    }
+    if (!done && best != 0) {
+      result = best;
+      done = true;
+    }
+    if (__ballot(!done) == 0) break;
+  }
+  *is_min = hit_min;
+  return result;
+}
+
+// subtractFromNUMAs numaresources.go:184-215 with ids == positions: walk the chosen zones in order, taking from each
+// what it has until the request is covered
+template <int RM>
+__device__ __forceinline__ void subtract_from_numas_fast(FastNode<RM>& ns, const Item<RM>& it, uint32_t m) {
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    if (!((it.used >> r) & 1u)) continue;
+    double quantity = it.raw[r];
+    const uint32_t members = m & ns.repmask(r);
+#pragma unroll
+    for (int z = 0; z < kZ; ++z) {
+      const bool member = ((members >> z) & 1u) != 0;
+      const double available = ns.av[z][r];
+      const double take = member ? __builtin_fmin(quantity, available) : 0.0;
+      ns.av[z][r] = available - take;
+      quantity -= take;
+    }
+  }
+}
+
 // PH: 0 = Filter and Score in one launch; 1 = Filter only, 2 = Score only (LeastAllocated: its Score reads only b, the
 // Filter only the mutable table, so each half keeps 64 instead of 128 state registers and runs at higher occupancy)
 constexpr int kPhBoth = 0, kPhFilter = 1, kPhScore = 2;
 
 template <int RM, int SG, int PH>
-__global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? 5 : (PH == kPhFilter ? 4 : (SG == kSgBalanced ? 2 : 3))) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
+__global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? 5 : (PH == kPhFilter ? 4 : ((SG == kSgBalanced || SG == kSgLeastNuma) ? 2 : 3))) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
   typedef typename ItemWords<RM>::T Words;
   // A block owns a window of 256 consecutive nodes and a chunk of pod rows.  Inside the window the engine has
   // ordered the nodes by (aligned, scope) — perm[] — so that a wavefront's 64 nodes mostly share one code path
@@ -268,10 +383,11 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? 5 : (PH == kPhFilt
     for (int r = 0; r < RM; ++r) {
       const int64_t i = (static_cast<int64_t>(z) * R + r) * a.n_nodes + n;
       ns.av[z][r] = (in && r < R) ? a.f_av[i] : -1.0;
-      const double b = (SG != kSgBalanced && in && r < R) ? a.f_rc[i] : kNoCap;
+      const double b = (SG != kSgBalanced && SG != kSgLeastNuma && in && r < R) ? a.f_rc[i] : kNoCap;
       ns.b[z][r] = (SG == kSgLeast && b == kNoCap) ? __builtin_inf() : b;
     }
   }
+  const int nns = 100 / (in ? a.max_numa[n] : 8);  // normalizeScore's per-zone step, least_numa.go:90-100
   const bool fresh = flags & SPX_NRT_F_FRESH;
   const bool has_nrt = flags & SPX_NRT_F_HAS_NRT;
   const bool single = flags & SPX_NRT_F_SINGLE_NUMA;
@@ -297,7 +413,7 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? 5 : (PH == kPhFilt
     uint32_t status = (filtered && !fresh) ? SPX_NRT_ST_INVALID_TOPOLOGY : 0u;
     int score = non_g ? 100 : 0;
     const bool want_filter = PH != kPhScore && filtered && aligned;
-    const bool want_score = PH != kPhFilter && !non_g && aligned;
+    const bool want_score = SG != kSgLeastNuma && PH != kPhFilter && !non_g && aligned;
 
     if ((want_filter || want_score) && pod_scope) {  // singleNUMAPodLevelHandler / podScopeScore
       const Item<RM> it = decode_item<RM>(pw);
@@ -365,9 +481,63 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? 5 : (PH == kPhFilt
       if (want_score) score = static_cast<int>((static_cast<uint32_t>(sum) * inv_n) >> 16);  // int64(mean): sum / n_ctr, sum <= 800
     }
 
+    if constexpr (SG == kSgLeastNuma) {
+      // LeastNUMANodes scores every node that has a fresh NRT, whatever its topology-manager policy (score.go:167-191)
+      const bool want_ln = !non_g && fresh && has_nrt;
+      if (want_ln && pod_scope) {  // leastNUMAPodScopeScore
+        const Item<RM> it = decode_item<RM>(pw);
+        uint32_t any_rep = 0;
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+          if ((it.used >> r) & 1u) any_rep |= ns.repmask(r);
+        const bool non_numa = any_rep == 0;  // onlyNonNUMAResources
+        bool is_min;
+        const uint32_t m = numa_required_fast(ns, a, it, n, !non_numa, &is_min);
+        const int cnt = __builtin_popcount(m);
+        score = non_numa ? 100 : (m ? 100 - cnt * nns + (is_min ? nns / 2 : 0) : 0);
+      }
+      if (want_ln && !pod_scope) {  // leastNUMAContainerScopeScore
+        int max_count = 0;
+        bool all_min = true, failed = false, dirty = false;
+        cw = uload(pi + 2);
+        for (int c = 0; c < n_ctr; ++c) {
+          const Words nw = uload(pi + 2 + (c + 1 < kC ? c + 1 : c));
+          const Item<RM> it = decode_item<RM>(cw);
+          uint32_t any_rep = 0;
+#pragma unroll
+          for (int r = 0; r < RM; ++r)
+            if ((it.used >> r) & 1u) any_rep |= ns.repmask(r);
+          const bool go = !failed && any_rep != 0;
+          bool is_min;
+          const uint32_t m = numa_required_fast(ns, a, it, n, go, &is_min);
+          if (go) {
+            if (m == 0) {
+              failed = true;
+            } else {
+              all_min &= is_min;
+              const int cnt = __builtin_popcount(m);
+              max_count = cnt > max_count ? cnt : max_count;
+              subtract_from_numas_fast(ns, it, m);
+              dirty = true;
+            }
+          }
+          cw = nw;
+        }
+        score = failed ? 0 : (max_count == 0 ? 100 : 100 - max_count * nns + (all_min ? nns / 2 : 0));
+        if (__ballot(dirty) != 0) {  // the reference scored on a private NUMANodeList: restore this lane's table
+#pragma unroll
+          for (int z = 0; z < kZ; ++z)
+#pragma unroll
+            for (int r = 0; r < RM; ++r)
+              ns.av[z][r] = (in && r < R) ? a.f_av[(static_cast<int64_t>(z) * R + r) * a.n_nodes + n] : -1.0;
+        }
+      }
+    }
+
     if (in && a.out_raw != nullptr) {
       a.out_raw[n] = score;
     } else if (in) {
+      if constexpr (SG == kSgLeastNuma) score = score < 0 ? 0 : score;  // 100 - count*(100/maxNUMA) can go negative; the table saturates
       if constexpr (PH != kPhScore) stage[0][pod - pod0][pos] = static_cast<uint8_t>(status);
       if constexpr (PH != kPhFilter) stage[1][pod - pod0][pos] = static_cast<uint8_t>(score > 255 ? 255 : score);
     }
@@ -390,11 +560,12 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? 5 : (PH == kPhFilt
 }  // namespace
 
 bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
-  if (!a.fast || a.strategy == SPX_NRT_LEAST_NUMA_NODES) return false;
+  if (!a.fast) return false;
   const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);  // windows of 256 nodes
   const int64_t chunks = (a.row_end - a.row_begin + kPodsPerUnit - 1) / kPodsPerUnit;
   const unsigned blocks = static_cast<unsigned>(chunks * n_tiles);
-  const int sg = a.strategy == SPX_NRT_BALANCED_ALLOCATION ? kSgBalanced : (a.strategy == SPX_NRT_LEAST_ALLOCATED ? kSgLeast : kSgMost);
+  const int sg = a.strategy == SPX_NRT_LEAST_NUMA_NODES ? kSgLeastNuma
+               : a.strategy == SPX_NRT_BALANCED_ALLOCATION ? kSgBalanced : (a.strategy == SPX_NRT_LEAST_ALLOCATED ? kSgLeast : kSgMost);
   const bool split = sg == kSgLeast && a.out_raw == nullptr && getenv("SPX_NRT_NOSPLIT") == nullptr;
 #define SPX_NRTF_CASE(RMV, SGV)                                                                           \
   if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                                        \
@@ -409,9 +580,11 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   SPX_NRTF_CASE(4, kSgLeast)
   SPX_NRTF_CASE(4, kSgMost)
   SPX_NRTF_CASE(4, kSgBalanced)
+  SPX_NRTF_CASE(4, kSgLeastNuma)
   SPX_NRTF_CASE(8, kSgLeast)
   SPX_NRTF_CASE(8, kSgMost)
   SPX_NRTF_CASE(8, kSgBalanced)
+  SPX_NRTF_CASE(8, kSgLeastNuma)
 #undef SPX_NRTF_CASE
   return false;
 }

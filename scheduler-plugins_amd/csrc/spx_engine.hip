@@ -70,7 +70,7 @@ struct spx_engine {
   DevBuf d_nrt_flags, d_nrt_max_numa, d_nrt_nz, d_nrt_zid, d_nrt_zp, d_nrt_avail, d_nrt_cost, d_nrt_minavg, d_nrt_np;
   DevBuf d_nrt_qos, d_nrt_nn, d_nrt_nctr, d_nrt_ckind, d_nrt_cpres, d_nrt_creq, d_nrt_ppres, d_nrt_preq;
   // float64 formulation of the NRT sweep (kernels_nrt_fast.hip): derived tables + whether its preconditions hold
-  DevBuf d_nrt_fav, d_nrt_frc, d_nrt_fcpu, d_nrt_frep, d_nrt_items, d_nrt_perm;
+  DevBuf d_nrt_fav, d_nrt_frc, d_nrt_fcpu, d_nrt_frep, d_nrt_items, d_nrt_perm, d_nrt_dist;
   std::vector<double> nrt_wtab;  // [2^n_res][2]: sum of the weights of a slot subset, its biased reciprocal
   bool nrt_fast_slots = false, nrt_fast_nodes = false, nrt_fast_pods = false;
   int32_t nrt_cpu_slot = -1;
@@ -258,6 +258,7 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   na.f_rep = static_cast<const uint8_t*>(e->d_nrt_frep.p);
   na.pod_items = static_cast<const uint32_t*>(e->d_nrt_items.p);
   na.perm = static_cast<const int32_t*>(e->d_nrt_perm.p);
+  na.dist = static_cast<const float*>(e->d_nrt_dist.p);
 }
 
 // quantities the float64 NRT kernel may hold exactly, with room for x100 and the reciprocal trick
@@ -342,7 +343,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_raw_row,   &e->d_lv_exact, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
-                    &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm,
+                    &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_dist,
                     &e->d_net_region, &e->d_net_zone, &e->d_net_class, &e->d_net_class16, &e->d_net_cls_size, &e->d_net_cls_region, &e->d_net_cls_zone,
                     &e->d_net_rcost, &e->d_net_zcost, &e->d_net_pod_key, &e->d_net_key_flag, &e->d_net_pair_ptr,
                     &e->d_net_pair_node, &e->d_net_pair_max, &e->d_q_pod_ns, &e->d_q_pod_prio, &e->d_q_pod_req, &e->d_q_pod_reqp,
@@ -563,6 +564,27 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
         }
     }
     if ((rc = upload(e, e->d_nrt_perm, perm.data(), perm.size() * sizeof(int32_t)))) return rc;
+    // average distance of every subset of list positions (nodesAvgDistance least_numa.go:140-154, float32 like the
+    // reference), in the order the LeastNUMANodes search walks them
+    {
+      constexpr spx::Combo8 combo = spx::make_combo8();
+      std::vector<float> dist(static_cast<size_t>(255) * static_cast<size_t>(n));
+      spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
+        for (int64_t i = row0; i < row1; ++i)
+          for (int ci = 0; ci < 255; ++ci) {
+            const unsigned m = combo.mask[ci];
+            int accu = 0;
+            for (int za = 0; za < Zm; ++za)
+              if (m >> za & 1u)
+                for (int zb = 0; zb < Zm; ++zb)
+                  if (m >> zb & 1u) accu += t->zone_cost[(i * Zm + za) * Zm + zb];
+            const int k = __builtin_popcount(m);
+            dist[static_cast<size_t>(ci) * static_cast<size_t>(n) + static_cast<size_t>(i)] = static_cast<float>(accu) / static_cast<float>(k * k);
+          }
+      }, 512);
+      if ((rc = upload(e, e->d_nrt_dist, dist.data(), dist.size() * sizeof(float)))) return rc;
+      SPX_HIP(e, hipStreamSynchronize(e->stream));
+    }
     if ((rc = upload(e, e->d_nrt_fav, av.data(), av.size() * sizeof(double)))) return rc;
     if ((rc = upload(e, e->d_nrt_frc, rcp.data(), rcp.size() * sizeof(double)))) return rc;
     if ((rc = upload(e, e->d_nrt_fcpu, cpuv.data(), cpuv.size() * sizeof(double)))) return rc;
@@ -945,8 +967,7 @@ int spx_sync(spx_engine* e) {
 int spx_kernel_path(const spx_engine* e, int plugin) {
   if (!e) return SPX_ERR_ARG;
   if (plugin == SPX_PLUGIN_NRT)
-    return (e->nrt_fast_slots && e->nrt_fast_nodes && e->nrt_fast_pods && e->nrt_params.strategy != SPX_NRT_LEAST_NUMA_NODES &&
-            getenv("SPX_NRT_GENERIC") == nullptr)
+    return (e->nrt_fast_slots && e->nrt_fast_nodes && e->nrt_fast_pods && getenv("SPX_NRT_GENERIC") == nullptr)
                ? 1
                : 0;
   if (plugin == SPX_PLUGIN_NETOVERHEAD) return (e->net_nodes && e->net_class16 && e->net_n_classes > 0 && getenv("SPX_NET_GENERIC") == nullptr) ? 1 : 0;

@@ -109,10 +109,40 @@ struct NrtArgs {
   const double* f_rc;            // [Z][n_res][N] RN(100 / Value(capacity)), kNrtNoCap when the capacity is not positive
   const double* f_cpu;           // [Z][N] Value() of the cpu capacity
   const uint8_t* f_rep;          // [n_res][N] mask of the zones reporting the resource
+  const float* dist;             // [255][N] average distance of every zone subset (Combo8 order), float32 as least_numa.go:140-154
   const int32_t* perm;           // [ceil(N/256)*256] node index per slot, windows of 256 ordered by code path; -1 = empty
   const uint32_t* pod_items;     // [P][10][16 or 32] pod record stream (layout: spx_engine.hip nrt_pod_items)
 };
 constexpr double kNrtNoCap = 1e200;
+
+// combin.Combinations(8, k) for k = 1..8 as bitmasks over list positions, size-major then lexicographic — the order
+// least_numa.go:167-208 walks.  Subsets of a node with fewer zones are the entries without high positions, in the same
+// relative order.  Shared by the engine (per-node distance table) and the float64 LeastNUMANodes kernel.
+struct Combo8 {
+  uint8_t mask[256];
+  uint8_t start[10];  // start[k-1] .. start[k]: subsets of size k
+};
+constexpr Combo8 make_combo8() {
+  Combo8 t{};
+  int idx = 0;
+  for (int k = 1; k <= 8; ++k) {
+    t.start[k - 1] = static_cast<uint8_t>(idx);
+    int c[8] = {};
+    for (int i = 0; i < k; ++i) c[i] = i;
+    while (true) {
+      int m = 0;
+      for (int i = 0; i < k; ++i) m |= 1 << c[i];
+      t.mask[idx++] = static_cast<uint8_t>(m);
+      int i = k - 1;
+      while (i >= 0 && c[i] == 8 - k + i) --i;
+      if (i < 0) break;
+      ++c[i];
+      for (int j = i + 1; j < k; ++j) c[j] = c[j - 1] + 1;
+    }
+  }
+  t.start[8] = static_cast<uint8_t>(idx);  // 255
+  return t;
+}
 void launch_nrt(const NrtArgs& a, hipStream_t s);
 // returns false when the float64 kernel does not apply (preconditions, LeastNUMANodes)
 bool launch_nrt_fast(const NrtArgs& a, hipStream_t s);

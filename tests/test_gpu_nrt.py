@@ -102,8 +102,8 @@ def test_differential(gpu_required, hdr, oracle, strategy, n_nodes, n_pods, seed
     params = O.nrt_params(hdr, res, strategy, {"cpu": 2} if seed == 4 else None)
     with Engine(0) as e:
         e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
-        # synthetic snapshots satisfy the float64 kernel's preconditions; LeastNUMANodes always runs the generic kernel
-        assert e.kernel_path(NRT) == (0 if strategy == "LeastNUMANodes" else 1)
+        # synthetic snapshots satisfy the float64 kernel's preconditions
+        assert e.kernel_path(NRT) == 1
         e.eval(mask_of(NRT))
         e.sync()
         osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
@@ -120,7 +120,7 @@ def test_differential(gpu_required, hdr, oracle, strategy, n_nodes, n_pods, seed
             assert np.array_equal(e.raw(NRT, r), want_score[r])
 
 
-@pytest.mark.parametrize("strategy", ["LeastAllocated", "MostAllocated", "BalancedAllocation"])
+@pytest.mark.parametrize("strategy", ["LeastAllocated", "MostAllocated", "BalancedAllocation", "LeastNUMANodes"])
 @pytest.mark.parametrize("how", ["huge_zone_quantity", "huge_request", "permuted_numa_ids"])
 def test_differential_generic_kernel(gpu_required, hdr, oracle, strategy, how):
     """snapshots that break a precondition of the float64 formulation must select the generic int64 kernel and
