@@ -645,8 +645,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
   const int cpu_bits = __float_as_int(my_cpu), mem_bits = __float_as_int(my_mem);
 
   uint32_t alloc_w[NPL / 4];
-  float ca[NPL], cb[NPL], cc[NPL], ma[NPL], mb[NPL], mc[NPL];
-  uint32_t both_bits = 0;
+  // per node, (cpu, memory) pairs for v_pk_fma_f32: slope B, offset C = B*usedAvg, and s*A with s = -1 when both
+  // resources are valid (the reference takes the min of the two scores then) and +1 otherwise (max):
+  //   min(xc, xm) = -max(-xc, -xm), so with y_r = s*(A_r - clamp_r) the cell is x = s*max(y_c, y_m) and rint(x) = s*rint(y)
+  F32x2 kb[NPL], kc[NPL], ksa[NPL];
+  float ks[NPL];
   if constexpr (A) {
 #pragma unroll
     for (int j = 0; j < NPL / 4; ++j) alloc_w[j] = active ? reinterpret_cast<const uint32_t*>(a.alloc_norm + node0)[j] : 0u;
@@ -673,9 +676,14 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
       *fb = static_cast<float>(b);
       *fc = static_cast<float>(b * r.used_avg);
     };
-    consts(c, &ca[j], &cb[j], &cc[j]);
-    consts(m, &ma[j], &mb[j], &mc[j]);
-    both_bits |= (has && c.state != 0 && m.state != 0) ? (1u << j) : 0u;
+    float ca, cb, cc, ma, mb, mc;
+    consts(c, &ca, &cb, &cc);
+    consts(m, &ma, &mb, &mc);
+    const float sgn = (has && c.state != 0 && m.state != 0) ? -1.0f : 1.0f;
+    kb[j] = F32x2{cb, mb};
+    kc[j] = F32x2{cc, mc};
+    ksa[j] = F32x2{sgn * ca, sgn * ma};
+    ks[j] = sgn;
   }
   constexpr float kHalf = 0.5f - kTolLv;  // (no early exit: see k_tlp_fast2)
 
@@ -687,31 +695,42 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
     const float req_cpu = __int_as_float(__builtin_amdgcn_readlane(cpu_bits, r));
     const float req_mem = __int_as_float(__builtin_amdgcn_readlane(mem_bits, r));
     const bool row_bad = __builtin_amdgcn_readlane(my_bad, r) != 0;
-    bool amb[NPL];
     bool any = row_bad;
     uint32_t w[NPL / 4];
+    // one cell: y = s*x (see above), its rounding, and the distance to the rounding tie
+    auto cell = [&](int i, const F32x2& req, float* ry) -> float {
+      const F32x2 t = __builtin_elementwise_fma(kb[i], req, kc[i]);
+      const F32x2 cl{__builtin_amdgcn_fmed3f(t.x, 0.0f, 50.0f), __builtin_amdgcn_fmed3f(t.y, 0.0f, 50.0f)};
+      const F32x2 y2 = __builtin_elementwise_fma(F32x2{-ks[i], -ks[i]}, cl, ksa[i]);
+      const float y = __builtin_fmaxf(y2.x, y2.y);
+      *ry = __builtin_rintf(y);
+      return __builtin_fabsf(y - *ry);
+    };
+    const F32x2 req2{req_cpu, req_mem};
+    float worst = 0.0f;  // running max of the rounding margins (v_max3_f32), as in k_tlp_fast2
 #pragma unroll
     for (int j = 0; j < NPL / 4; ++j) {
       uint32_t acc = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = j * 4 + q;
-        const float xc = ca[i] - __builtin_amdgcn_fmed3f(__builtin_fmaf(cb[i], req_cpu, cc[i]), 0.0f, 50.0f);
-        const float xm = ma[i] - __builtin_amdgcn_fmed3f(__builtin_fmaf(mb[i], req_mem, mc[i]), 0.0f, 50.0f);
-        const float x = ((both_bits >> i) & 1u) ? __builtin_fminf(xm, xc) : __builtin_fmaxf(xm, xc);
-        const float rr = __builtin_rintf(x);
-        amb[i] = !(__builtin_fabsf(x - rr) < kHalf);
-        any |= amb[i];
-        acc = __builtin_amdgcn_cvt_pk_u8_f32(rr, q, acc);
+        float ry;
+        worst = __builtin_fmaxf(worst, cell(i, req2, &ry));
+        acc = __builtin_amdgcn_cvt_pk_u8_f32(ry * ks[i], q, acc);
       }
       w[j] = acc;
     }
+    any |= !(worst < kHalf);
     if (__builtin_expect(any, 0)) {
       const double req_cpu_d = fmax(static_cast<double>(a.lv_req_cpu_milli[pod0 + r]), 0.0);
       const double req_mem_d = fmax(static_cast<double>(a.lv_req_mem[pod0 + r]) * kMega, 0.0);
+      float rc = req_cpu, rm = req_mem;
+      asm volatile("" : "+v"(rc), "+v"(rm));  // opaque copies: recompute the flags here instead of carrying them across the branch
+      const F32x2 req2s{rc, rm};
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
-        if (amb[i] || row_bad) {  // exact re-evaluation of this cell from the original node columns
+        float ry;
+        if (!(cell(i, req2s, &ry) < kHalf) || row_bad) {  // exact re-evaluation of this cell from the original node columns
           const int64_t n = node0 + i;
           uint32_t b = 0;
           if (n < a.n_nodes) {
