@@ -442,6 +442,51 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast(TrimaranArgs
 constexpr float kTol32 = 4e-5f;
 constexpr float kTolU = 1e-6f;
 
+// node slot n of a sweep kernel with NPL nodes per lane -> index of its record in the tile-transposed constant tables
+// ([tile][j][lane]: for a fixed j the 64 lanes of a wavefront read consecutive records)
+template <int NPL>
+__device__ __forceinline__ int64_t tile_slot(int64_t n) {
+  const int64_t tile = n / (kWave * NPL);
+  const int lane = static_cast<int>((n / NPL) % kWave), j = static_cast<int>(n % NPL);
+  return (tile * NPL + j) * kWave + lane;
+}
+
+constexpr int kLvNpl = 8, kTlpNpl = 16;  // nodes per lane of k_lvrb_fast / k_tlp_fast2
+
+// (see k_lvrb_prepare_fast) TargetLoadPacking's per-node float32 constants: b2 = b2h + b2l and the two branch coefficients
+__global__ void k_tlp_prepare_fast(TrimaranArgs a, int64_t n_slots, double c1, double c2) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= n_slots) return;
+  const double t = a.tlp_target;
+  const bool in = n < a.n_nodes;
+  double b = 1e30;       // invalid / padding: u huge -> x' = T - u -> cvt_pk_u8 gives 0, never ambiguous
+  float f1 = -1.0f, f2 = 0.0f;
+  bool split = false;
+  if (in && a.tlp_valid[n] != 0) {
+    const double cap = static_cast<double>(a.cap_cpu_milli[n]);
+    const double um = (a.tlp_cpu_util[n] / 100.0) * cap;
+    const double miss = static_cast<double>(a.tlp_missing_milli[n]);
+    if (cap == 0.0) {
+      b = 1.0;  // predicted stays 0 (targetloadpacking.go:171): x = T for every pod
+      f1 = 0.0f;
+    } else if (!(um >= 0.0) || !(miss >= 0.0) || !(cap > 0.0) || !(um < 1e15) || !(miss < 1e15)) {
+      b = __builtin_nan("");
+    } else {
+      const double k = 100.0 / cap;
+      b = (um + miss) - t * cap / 100.0;
+      f1 = static_cast<float>(-c1 * k);
+      f2 = static_cast<float>(c2 * k);
+      split = __builtin_fabs(b) < 8388607.0;
+      if (!split) b = __builtin_nan("");  // beyond the exact float32 integer range: always the exact path
+    }
+  }
+  // u = (pod + b2h) + b2l: the first add is exact (two integers below 2^23), the second rounds once — the same
+  // single float32 rounding a float64 add followed by a conversion would make, without the two float64-rate ops
+  const double bh = split ? __builtin_rint(b) : b;
+  reinterpret_cast<float4*>(a.tlp_fast)[tile_slot<kTlpNpl>(n)] =
+      float4{static_cast<float>(bh), split ? static_cast<float>(b - bh) : 0.0f, f1, f2};
+}
+
 template <int NPL, bool A>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArgs a, int n_tiles, double c1, double c2) {
   static_assert(kPodsPerChunk == kWave, "one pod record per lane");
@@ -474,38 +519,17 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
 #pragma unroll
     for (int j = 0; j < NPL / 4; ++j) alloc_w[j] = active ? reinterpret_cast<const uint32_t*>(a.alloc_norm + node0)[j] : 0u;
   }
+  static_assert(NPL == kTlpNpl, "k_tlp_prepare_fast lays the constants out for this NPL");
+  {
+    const float4* tab = reinterpret_cast<const float4*>(a.tlp_fast) + static_cast<int64_t>(tile) * NPL * kWave + lane;
 #pragma unroll
-  for (int j = 0; j < NPL; ++j) {
-    const int64_t n = node0 + j;
-    const bool in = n < a.n_nodes;
-    double b = 1e30;       // invalid / padding: u huge -> x' = T - u -> cvt_pk_u8 gives 0, never ambiguous
-    float f1 = -1.0f, f2 = 0.0f;
-    bool split = false;
-    if (in && a.tlp_valid[n] != 0) {
-      const double cap = static_cast<double>(a.cap_cpu_milli[n]);
-      const double um = (a.tlp_cpu_util[n] / 100.0) * cap;
-      const double miss = static_cast<double>(a.tlp_missing_milli[n]);
-      if (cap == 0.0) {
-        b = 1.0;  // predicted stays 0 (targetloadpacking.go:171): x = T for every pod
-        f1 = 0.0f;
-      } else if (!(um >= 0.0) || !(miss >= 0.0) || !(cap > 0.0) || !(um < 1e15) || !(miss < 1e15)) {
-        b = __builtin_nan("");
-      } else {
-        const double k = 100.0 / cap;
-        b = (um + miss) - t * cap / 100.0;
-        f1 = static_cast<float>(-c1 * k);
-        f2 = static_cast<float>(c2 * k);
-        split = __builtin_fabs(b) < 8388607.0;
-        if (!split) b = __builtin_nan("");  // beyond the exact float32 integer range: always the exact path
-      }
+    for (int j = 0; j < NPL; ++j) {
+      const float4 v = tab[static_cast<int64_t>(j) * kWave];  // (b2h, b2l, coefficient for u > 0, coefficient for u <= 0)
+      lane_nan |= v.x != v.x;
+      b2h[j >> 1][j & 1] = v.x;
+      b2l[j >> 1][j & 1] = v.y;
+      kc[j] = F32x2{v.z, v.w};
     }
-    // u = (pod + b2h) + b2l: the first add is exact (two integers below 2^23), the second rounds once — the same
-    // single float32 rounding a float64 add followed by a conversion would make, without the two float64-rate ops
-    const double bh = split ? __builtin_rint(b) : b;
-    lane_nan |= bh != bh;
-    b2h[j >> 1][j & 1] = static_cast<float>(bh);
-    b2l[j >> 1][j & 1] = split ? static_cast<float>(b - bh) : 0.0f;
-    kc[j] = F32x2{f1, f2};
   }
   // no early exit for lanes past the row: every lane stays live so that the v_readlane broadcasts below always read
   // registers that were written under a full exec mask (stores are guarded by `active` instead)
@@ -617,6 +641,43 @@ __global__ void k_lvrb_prepare(TrimaranArgs a) {
   o[4] = m.cap; o[5] = m.used_avg; o[6] = m.sigma; o[7] = static_cast<double>(m.state + ((f & SPX_LV_HAS_METRICS) ? 8 : 0));
 }
 
+// The float32 per-node constants of the two fast sweeps, once per launch instead of once per (node tile, pod chunk) unit
+// — for LVRB that setup (lv_make: divisions, math.Pow) cost as much as the 64 rows it served.  One thread per padded
+// node slot; slots past n_nodes get constants that score 0 and never look ambiguous.
+__global__ void k_lvrb_prepare_fast(TrimaranArgs a, int64_t n_slots) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= n_slots) return;
+  float4 v0{0.0f, 0.0f, 0.0f, 0.0f}, v1{0.0f, 0.0f, 1.0f, 0.0f};
+  if (n < a.n_nodes) {
+    const uint8_t f = a.lv_flags[n];
+    const bool has = (f & SPX_LV_HAS_METRICS) != 0;
+    double mcap = static_cast<double>(a.lv_alloc_mem[n]);
+    mcap *= kMega;
+    const LvRes c = lv_make(has && (f & SPX_LV_CPU_VALID), static_cast<double>(a.lv_alloc_cpu_milli[n]), a.lv_cpu_avg[n], a.lv_cpu_std[n],
+                            a.lv_margin, a.lv_sensitivity);
+    const LvRes m = lv_make(has && (f & SPX_LV_MEM_VALID), mcap, a.lv_mem_avg[n], a.lv_mem_std[n], a.lv_margin, a.lv_sensitivity);
+    auto consts = [](const LvRes& r, float* fa, float* fb, float* fc) {
+      if (r.state != 2) {
+        *fa = *fb = *fc = 0.0f;
+        return;
+      }
+      const double b = 50.0 / r.cap;
+      *fa = static_cast<float>(100.0 - 50.0 * r.sigma);
+      *fb = static_cast<float>(b);
+      *fc = static_cast<float>(b * r.used_avg);
+    };
+    float ca, cb, cc, ma, mb, mc;
+    consts(c, &ca, &cb, &cc);
+    consts(m, &ma, &mb, &mc);
+    const float sgn = (has && c.state != 0 && m.state != 0) ? -1.0f : 1.0f;
+    v0 = float4{cb, mb, cc, mc};
+    v1 = float4{sgn * ca, sgn * ma, sgn, 0.0f};
+  }
+  float4* out = reinterpret_cast<float4*>(a.lv_fast) + tile_slot<kLvNpl>(n) * 2;
+  out[0] = v0;
+  out[1] = v1;
+}
+
 template <int NPL, bool A>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArgs a, int n_tiles) {
   static_assert(kPodsPerChunk == kWave, "one pod record per lane");
@@ -654,36 +715,17 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
 #pragma unroll
     for (int j = 0; j < NPL / 4; ++j) alloc_w[j] = active ? reinterpret_cast<const uint32_t*>(a.alloc_norm + node0)[j] : 0u;
   }
+  static_assert(NPL == kLvNpl, "k_lvrb_prepare_fast lays the constants out for this NPL");
+  {
+    const float4* tab = reinterpret_cast<const float4*>(a.lv_fast) + (static_cast<int64_t>(tile) * NPL * kWave + lane) * 2;
 #pragma unroll
-  for (int j = 0; j < NPL; ++j) {
-    const int64_t n = node0 + j;
-    const bool in = n < a.n_nodes;
-    const uint8_t f = in ? a.lv_flags[n] : 0;
-    const bool has = (f & SPX_LV_HAS_METRICS) != 0;
-    double mcap = in ? static_cast<double>(a.lv_alloc_mem[n]) : 0.0;
-    mcap *= kMega;
-    const LvRes c = lv_make(has && (f & SPX_LV_CPU_VALID), in ? static_cast<double>(a.lv_alloc_cpu_milli[n]) : 0.0,
-                            in ? a.lv_cpu_avg[n] : 0.0, in ? a.lv_cpu_std[n] : 0.0, a.lv_margin, a.lv_sensitivity);
-    const LvRes m = lv_make(has && (f & SPX_LV_MEM_VALID), mcap, in ? a.lv_mem_avg[n] : 0.0, in ? a.lv_mem_std[n] : 0.0,
-                            a.lv_margin, a.lv_sensitivity);
-    auto consts = [](const LvRes& r, float* fa, float* fb, float* fc) {
-      if (r.state != 2) {
-        *fa = *fb = *fc = 0.0f;
-        return;
-      }
-      const double b = 50.0 / r.cap;
-      *fa = static_cast<float>(100.0 - 50.0 * r.sigma);
-      *fb = static_cast<float>(b);
-      *fc = static_cast<float>(b * r.used_avg);
-    };
-    float ca, cb, cc, ma, mb, mc;
-    consts(c, &ca, &cb, &cc);
-    consts(m, &ma, &mb, &mc);
-    const float sgn = (has && c.state != 0 && m.state != 0) ? -1.0f : 1.0f;
-    kb[j] = F32x2{cb, mb};
-    kc[j] = F32x2{cc, mc};
-    ksa[j] = F32x2{sgn * ca, sgn * ma};
-    ks[j] = sgn;
+    for (int j = 0; j < NPL; ++j) {
+      const float4 v0 = tab[static_cast<int64_t>(j) * kWave * 2], v1 = tab[static_cast<int64_t>(j) * kWave * 2 + 1];
+      kb[j] = F32x2{v0.x, v0.y};
+      kc[j] = F32x2{v0.z, v0.w};
+      ksa[j] = F32x2{v1.x, v1.y};
+      ks[j] = v1.z;
+    }
   }
   constexpr float kHalf = 0.5f - kTolLv;  // (no early exit: see k_tlp_fast2)
 
@@ -825,6 +867,8 @@ void launch_tlp_fast(const TrimaranArgs& a, hipStream_t s) {
       hipLaunchKernelGGL((k_tlp_fast<NPL, false>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2);
     return;
   }
+  const int64_t n_slots = static_cast<int64_t>(n_tiles) * tile_nodes;
+  hipLaunchKernelGGL(k_tlp_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots, c1, c2);
   if (a.out_alloc)
     hipLaunchKernelGGL((k_tlp_fast2<NPL, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2);
   else
@@ -838,6 +882,8 @@ void launch_lvrb_fast(const TrimaranArgs& a, hipStream_t s) {
   const int64_t chunks = (a.row_end - a.row_begin + kPodsPerChunk - 1) / kPodsPerChunk;
   const unsigned blocks = static_cast<unsigned>((chunks * n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
   hipLaunchKernelGGL(k_lvrb_prepare, dim3(static_cast<unsigned>((a.n_nodes + 255) / 256)), dim3(256), 0, s, a);
+  const int64_t n_slots = static_cast<int64_t>(n_tiles) * tile_nodes;
+  hipLaunchKernelGGL(k_lvrb_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots);
   if (a.out_alloc)
     hipLaunchKernelGGL((k_lvrb_fast<NPL, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles);
   else
@@ -849,7 +895,7 @@ void launch_trimaran(const TrimaranArgs& a, hipStream_t s) {
   if (!a.out_alloc && !a.out_tlp && !a.out_lvrb) return;
   static const bool exact_only = getenv("SPX_EXACT_ONLY") != nullptr;
   const bool tlp_fast_ok = a.tlp_target >= 1.0 && a.tlp_target <= 99.0;
-  if (!exact_only && (a.out_tlp || a.out_lvrb) && (!a.out_tlp || tlp_fast_ok) && (!a.out_lvrb || a.lv_exact)) {
+  if (!exact_only && (a.out_tlp || a.out_lvrb) && (!a.out_tlp || (tlp_fast_ok && a.tlp_fast)) && (!a.out_lvrb || (a.lv_exact && a.lv_fast))) {
     // one bit-exact fast kernel per plugin; Allocatable's broadcast row rides with the first of them
     TrimaranArgs t = a;
     if (a.out_tlp) {

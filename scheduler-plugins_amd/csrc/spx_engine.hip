@@ -60,6 +60,7 @@ struct spx_engine {
   bool tri_pods = false;
   DevBuf d_raw_row;  // int64 [n_nodes] staging for spx_fetch_raw
   DevBuf d_lv_exact; // double [n_nodes][8] scratch of the LVRB fast kernel
+  DevBuf d_lv_fast, d_tlp_fast;  // float32 per-node constants of the fast sweeps (recomputed per launch)
 
   // NodeResourceTopologyMatch
   spx_nrt_params nrt_params{SPX_NRT_LEAST_ALLOCATED, 0, nullptr, nullptr};  // defaults.go:87-90
@@ -340,7 +341,7 @@ int spx_destroy(spx_engine* e) {
   DevBuf* bufs[] = {&e->d_alloc,   &e->d_alloc_w,  &e->d_alloc_raw, &e->d_alloc_norm, &e->d_alloc_rel, &e->d_cap_cpu, &e->d_tlp_util,
                     &e->d_tlp_missing, &e->d_tlp_valid, &e->d_lv_acpu, &e->d_lv_amem, &e->d_lv_cavg, &e->d_lv_cstd,
                     &e->d_lv_mavg, &e->d_lv_mstd,  &e->d_lv_flags,  &e->d_tlp_pod,    &e->d_lv_rcpu, &e->d_lv_rmem,
-                    &e->d_raw_row,   &e->d_lv_exact, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
+                    &e->d_raw_row,   &e->d_lv_exact, &e->d_lv_fast, &e->d_tlp_fast, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
                     &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_dist,
@@ -874,6 +875,12 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (L) {
     if ((rc = ensure(e, e->d_lv_exact, static_cast<size_t>(e->n_nodes) * 8 * sizeof(double)))) return rc;
     a.lv_exact = static_cast<double*>(e->d_lv_exact.p);
+    if ((rc = ensure(e, e->d_lv_fast, static_cast<size_t>(spx::round_up(e->row_stride, 512)) * 8 * sizeof(float)))) return rc;
+    a.lv_fast = static_cast<float*>(e->d_lv_fast.p);
+  }
+  if (T) {
+    if ((rc = ensure(e, e->d_tlp_fast, static_cast<size_t>(spx::round_up(e->row_stride, 1024)) * 4 * sizeof(float)))) return rc;
+    a.tlp_fast = static_cast<float*>(e->d_tlp_fast.p);
   }
   SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
   if (Q) {

@@ -58,6 +58,8 @@ struct TrimaranArgs {
   double lv_margin;
   double lv_sensitivity;
   double* lv_exact;  // scratch [n_nodes][8]: per-node exact LVRB state for the fast kernel's fallback
+  float* lv_fast;    // scratch [ceil(row_stride/512)*512][8]: LVRB fast constants, tile-transposed (k_lvrb_prepare_fast)
+  float* tlp_fast;   // scratch [ceil(row_stride/1024)*1024][4]: TLP fast constants, tile-transposed (k_tlp_prepare_fast)
   // outputs: uint8 [n_pods][row_stride] each (NULL = plugin not evaluated)
   uint8_t* out_alloc;
   uint8_t* out_tlp;
