@@ -38,6 +38,10 @@ WORKLOADS = {
                     desc="noderesourcetopology Filter+Score (LeastAllocated), 5k nodes x 8 NUMA zones x 50k pods"),
     "config3_leastnuma": dict(n_nodes=5_000, n_pods=50_000, plugins=("nrt",), node_row=324, pod_row=100, out=2, strategy="LeastNUMANodes",
                               desc="noderesourcetopology Filter+Score (LeastNUMANodes), 5k nodes x 8 NUMA zones x 50k pods"),
+    "config3_most": dict(n_nodes=5_000, n_pods=50_000, plugins=("nrt",), node_row=324, pod_row=100, out=2, strategy="MostAllocated",
+                         desc="noderesourcetopology Filter+Score (MostAllocated), 5k nodes x 8 NUMA zones x 50k pods"),
+    "config3_balanced": dict(n_nodes=5_000, n_pods=50_000, plugins=("nrt",), node_row=324, pod_row=100, out=2, strategy="BalancedAllocation",
+                             desc="noderesourcetopology Filter+Score (BalancedAllocation), 5k nodes x 8 NUMA zones x 50k pods"),
     "config4": dict(n_nodes=10_000, n_pods=200_000, plugins=("net",), node_row=4, pod_row=48, out=2,
                     desc="networkaware NetworkOverhead (+TopologicalSort keys), 10k nodes x 3-tier topology x 200k pods"),
     "config5": dict(n_nodes=20_000, n_pods=62_500, plugins=("cap", "alloc", "tlp", "lvrb", "nrt", "net"), node_row=405, pod_row=188, out=7,
@@ -267,7 +271,9 @@ def main() -> None:
                    "result_tables": "uint8 [pods][nodes] per plugin, resident in HBM"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": {"nrt": "spx::k_nrt", "net": "spx::k_net"}.get(w["plugins"][0], "spx::k_tlp_fast2 (Allocatable+TLP) / spx::k_trimaran (with LVRB)"),
+                     "kernel": {"nrt": "spx::k_nrt_fast (LeastAllocated: Filter launch + Score launch, both counted)", "net": "spx::k_net_cls",
+                                "cap": "full profile: k_quota, k_nrt_fast x2, k_net_cls, k_tlp_fast2, k_lvrb_fast, k_alloc_masked"}.get(
+                         w["plugins"][0], "spx::k_tlp_fast2 (Allocatable+TLP)" + (" + spx::k_lvrb_fast" if "lvrb" in w["plugins"] else "")),
                      "kernel_ms": kern_ms,
                      "algorithmic_bytes": algo_bytes, "frac_of_measured_copy_ceiling_6.29TBs": achieved / 6290.0},
         "kernel_evals_per_sec": n_nodes * n_pods / (kern_ms * 1e-3),
