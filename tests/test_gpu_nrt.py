@@ -184,6 +184,70 @@ def test_float64_kernel_boundaries(gpu_required, hdr, oracle):
             assert np.array_equal(e.all_scores(NRT).astype(np.int64), osnap.score_rows(NRT, want_norm=False)[0].clip(0, 255))
 
 
+def _wide_snapshot(hdr, n_nodes, n_pods, seed):
+    """7 resource slots (cpu, memory, ephemeral-storage, two hugepage sizes, two devices), built with the object
+    builders: exercises the 8-slot instantiations of both NRT kernels"""
+    rng = np.random.default_rng(seed)
+    res = O.Resources()
+    names = ["cpu", "memory", "ephemeral-storage", "hugepages-2Mi", "hugepages-1Gi", "vendor.io/gpu", "vendor.io/nic"]
+    policies = ["SingleNUMANodeContainerLevel", "SingleNUMANodePodLevel", "SingleNUMANodeContainerLevel", "RestrictedPodLevel"]
+    nrts, nodes = [], []
+    for _ in range(n_nodes):
+        nz = int(rng.choice([2, 4, 8, 8, 8]))
+        zones = []
+        for z in range(nz):
+            rl = {"cpu": f"{int(rng.integers(1, 17))}", "memory": f"{int(rng.integers(1, 65))}Gi"}
+            if rng.random() < 0.8:
+                rl["hugepages-2Mi"] = f"{int(rng.integers(0, 513)) * 2}Mi"
+            if rng.random() < 0.6:
+                rl["hugepages-1Gi"] = f"{int(rng.integers(0, 9))}Gi"
+            if rng.random() < 0.7:
+                rl["vendor.io/gpu"] = str(int(rng.integers(0, 5)))
+            if rng.random() < 0.5:
+                rl["vendor.io/nic"] = str(int(rng.integers(0, 9)))
+            costs = {f"node-{o}": (10 if o == z else int(rng.choice([12, 20, 32]))) for o in range(nz)}
+            zones.append({"name": f"node-{z}", "type": "Node", "resources": rl, "costs": costs})
+        nrts.append(O.nrt(zones, [policies[int(rng.integers(0, len(policies)))]]))
+        nodes.append(O.node_from_zones(zones, {"ephemeral-storage": "100Gi"}))
+    pods = []
+    for _ in range(n_pods):
+        guaranteed = rng.random() < 0.7
+        ctrs = []
+        for _c in range(int(rng.integers(1, 4))):
+            rl = {"cpu": f"{int(rng.integers(1, 9)) * 500}m", "memory": f"{int(rng.integers(1, 33)) * 256}Mi"}
+            for name, p, hi in (("ephemeral-storage", 0.3, 20), ("hugepages-2Mi", 0.3, 64), ("hugepages-1Gi", 0.2, 3),
+                                ("vendor.io/gpu", 0.3, 3), ("vendor.io/nic", 0.2, 3)):
+                if rng.random() < p:
+                    v = int(rng.integers(0, hi))
+                    rl[name] = {"ephemeral-storage": f"{v}Gi", "hugepages-2Mi": f"{2 * v}Mi", "hugepages-1Gi": f"{v}Gi"}.get(name, str(v))
+            ctrs.append(O.container(rl, rl if guaranteed else None))
+        init = [O.container({"cpu": "250m", "memory": "64Mi"}, {"cpu": "250m", "memory": "64Mi"} if guaranteed else None)] if rng.random() < 0.3 else []
+        pods.append(O.pod(ctrs, init))
+    for n in names:
+        res.id(n)
+    return res, O.build_node_objects(hdr, res, nodes), O.build_nrt_objects(hdr, res, nrts), O.build_pod_objects(hdr, res, pods)
+
+
+@pytest.mark.parametrize("kernel", ["float64", "generic"])
+@pytest.mark.parametrize("strategy", ["LeastAllocated", "MostAllocated", "BalancedAllocation", "LeastNUMANodes"])
+def test_differential_seven_resources(gpu_required, hdr, oracle, monkeypatch, strategy, kernel):
+    if kernel == "generic":
+        monkeypatch.setenv("SPX_NRT_GENERIC", "1")
+    res, nodes, nrts, pods = _wide_snapshot(hdr, 140, 60, seed=21)
+    params = O.nrt_params(hdr, res, strategy, {"cpu": 3, "vendor.io/gpu": 2})
+    with Engine(0) as e:
+        e.load_nrt_objects(nodes, nrts, res.table(hdr), pods, params)
+        assert e.nrt_soa["slots"].struct.n_res > 4
+        assert e.kernel_path(NRT) == (1 if kernel == "float64" else 0)
+        e.eval(mask_of(NRT))
+        e.sync()
+        osnap = oracle.Snapshot(nodes, pods, rc=res.table(hdr), nrt=nrts, nrt_params=params)
+        assert np.array_equal(e.all_status(NRT), osnap.filter_rows(NRT))
+        want = osnap.score_rows(NRT, want_norm=False)[0]
+        assert np.array_equal(e.all_scores(NRT).astype(np.int64), want.clip(0, 255))
+        assert (want > 0).any() and (want == 0).any()
+
+
 def test_partial_rows_and_mixed_plugins(gpu_required, hdr, oracle):
     """NRT evaluated in row slices; engine shape checks"""
     snap = synth.nrt_snapshot(hdr, 200, 90, seed=9)
