@@ -264,7 +264,9 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64",  # TLP/LVRB compute in float64 exactly as the reference; Allocatable in int64
+        # the arithmetic the sweep computes in (results are bit-exact against the reference's float64 / int64 either way):
+        # TLP/LVRB float32 with a per-cell exactness proof and a float64 fallback, NRT float64 (exact integers), NetworkOverhead int32
+        "dtype": {"nrt": "f64", "net": "i32", "cap": "f32+f64+i32"}.get(w["plugins"][0], "f32+f64"),
         "data": "synthetic",
         "config": {"workload": w["desc"], "n_nodes": n_nodes, "n_pods_per_gpu": n_pods, "plugins": list(w["plugins"]),
                    "sharding": "pod rows per rank, node tables replicated, no data-path collective",
