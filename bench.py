@@ -215,6 +215,14 @@ def main() -> None:
             full_cycle = {"ms": (c3 - c0) * 1e3, "flatten_upload_ms": (c1 - c0) * 1e3, "eval_argmax_ms": (c2 - c1) * 1e3,
                           "fetch_decisions_ms": (c3 - c2) * 1e3,
                           "what": "objects->SoA flatten + H2D, sweep, per-row weighted argmax, D2H of 32 B/pod decisions"}
+            # the same pods scheduled strictly one after the other, each seeing the commits before it (upstream's
+            # semantics; inherently sequential, one workgroup): spx_commit_sequential
+            c4 = time.perf_counter()
+            seq_node, _, _, _ = e.commit_sequential(mask)
+            c5 = time.perf_counter()
+            full_cycle["sequential_commit_ms"] = (c5 - c4) * 1e3
+            full_cycle["sequential_pods_per_s"] = n_pods / (c5 - c4)
+            full_cycle["sequential_distinct_nodes"] = int(len(set(seq_node.tolist())))
         except Exception as ex:
             full_cycle = {"error": repr(ex)[:200]}
 

@@ -513,6 +513,15 @@ int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_
  * n_ties / n_feasible may be NULL */
 int spx_fetch_best(spx_engine* e, int64_t row_begin, int64_t row_end, int32_t* node_idx, int64_t* weighted_score, int32_t* n_ties, int32_t* n_feasible);
 
+/* Sequential scheduling of pod rows [row_begin,row_end), in row (= queue) order, under the Filter-less profile
+ * plugin_mask, a subset of {ALLOCATABLE, TLP, LVRB}.  Unlike spx_eval's frozen snapshot, every pod sees the commits of the
+ * pods before it: a pod bound to a node adds its predicted CPU utilisation to that node's missing utilisation
+ * (pkg/trimaran/handler.go:131-139 feeding targetloadpacking.go:151-168).  Per pod: the node with the highest
+ * sum of plugin_weight x score (lowest index among ties; upstream's selectHost draws among them), that sum, and the size
+ * of the tie set (NULL = not wanted).  tlp_missing_out (NULL = not wanted) receives the per-node missing utilisation after
+ * the last commit.  The engine's uploaded tables and result tables are left untouched.  Synchronous. */
+int spx_commit_sequential(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end, int32_t* node_idx, int64_t* weighted_score, int32_t* n_ties, int64_t* tlp_missing_out);
+
 /* duration in ms of the last spx_eval's kernels measured with HIP events on the engine stream */
 int spx_last_eval_ms(spx_engine* e, float* ms);
 

@@ -791,6 +791,101 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sequential commit loop for the Filter-less profile (Allocatable + TargetLoadPacking + LoadVariationRiskBalancing),
+// SURVEY.md section 8f rank 1.  Upstream schedules one pod at a time: Score every node, pick the best, bind; the bound
+// pod enters trimaran's ScheduledPodsCache (handler.go:131-139) and from then on adds its predicted CPU utilisation to
+// that node's "missing utilisation" (targetloadpacking.go:151-168) until the metrics catch up.  So pod i+1's row
+// differs from what a frozen snapshot says in exactly one node — but which one depends on pod i's decision: the chain
+// is inherently sequential.  One workgroup keeps the chain on the device: per pod, 1024 threads evaluate the row with
+// the reference's float64 arithmetic against the current missing[] column, a block-wide argmax picks the node (lowest
+// index among ties; upstream draws one of them at random), and the winner's missing utilisation is bumped.
+// No table is read or written; the per-pod decisions are the output.
+constexpr int kCommitThreads = 1024;
+
+__global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c) {
+  __shared__ int64_t s_best[kCommitThreads / kWave];
+  __shared__ int s_node[kCommitThreads / kWave];
+  __shared__ int s_ties[kCommitThreads / kWave];
+  const TrimaranArgs& a = c.t;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1), wave = tid >> 6;
+  const bool A = c.use_mask & 1u, T = c.use_mask & 2u, L = c.use_mask & 4u;
+  for (int64_t pod = a.row_begin; pod < a.row_end; ++pod) {
+    const double pod_milli = T ? static_cast<double>(a.tlp_pod_milli[pod]) : 0.0;
+    const double req_cpu = L ? fmax(static_cast<double>(a.lv_req_cpu_milli[pod]), 0.0) : 0.0;
+    const double req_mem = L ? fmax(static_cast<double>(a.lv_req_mem[pod]) * kMega, 0.0) : 0.0;
+    int64_t best = INT64_MIN;
+    int best_n = INT32_MAX, ties = 0;
+    for (int64_t n = tid; n < a.n_nodes; n += kCommitThreads) {
+      int64_t total = 0;
+      if (A) total += c.w_alloc * static_cast<int64_t>(a.alloc_norm[n]);
+      if (T) {
+        TlpNode tn;
+        tn.cap = static_cast<double>(a.cap_cpu_milli[n]);
+        tn.util_millis = (a.tlp_cpu_util[n] / 100.0) * tn.cap;
+        tn.missing = static_cast<double>(c.missing[n]);
+        tn.valid = a.tlp_valid[n] != 0;
+        bool zero;
+        const double x = tlp_unrounded(tn, pod_milli, a.tlp_target, &zero);
+        total += c.w_tlp * static_cast<int64_t>(zero ? 0u : to_u8(x));
+      }
+      if (L) {
+        const double* o = a.lv_exact + n * 8;
+        const int ms = static_cast<int>(o[7]);
+        const LvRes cr{o[0], o[1], o[2], static_cast<int>(o[3])};
+        const LvRes mr{o[4], o[5], o[6], ms & 7};
+        total += c.w_lvrb * static_cast<int64_t>(to_u8(lv_total((ms & 8) != 0, cr, mr, req_cpu, req_mem)));
+      }
+      if (total > best) {  // a thread walks its nodes in increasing order: `>` keeps the lowest index among equals
+        best = total;
+        best_n = static_cast<int>(n);
+        ties = 1;
+      } else if (total == best) {
+        ++ties;
+      }
+    }
+    // wave-level then block-level argmax (every lane is live: no divergence around the shuffles)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const int64_t ob = shfl_xor_i64(best, m);
+      const int on = __shfl_xor(best_n, m, 64);
+      const int ot = __shfl_xor(ties, m, 64);
+      if (ob > best || (ob == best && on < best_n)) {
+        ties = ob > best ? ot : ties + ot;
+        best = ob;
+        best_n = on;
+      } else if (ob == best) {
+        ties += ot;
+      }
+    }
+    if (lane == 0) {
+      s_best[wave] = best;
+      s_node[wave] = best_n;
+      s_ties[wave] = ties;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < kCommitThreads / kWave; ++w) {
+        if (s_best[w] > best || (s_best[w] == best && s_node[w] < best_n)) {
+          ties = s_best[w] > best ? s_ties[w] : ties + s_ties[w];
+          best = s_best[w];
+          best_n = s_node[w];
+        } else if (s_best[w] == best) {
+          ties += s_ties[w];
+        }
+      }
+      const bool any = best_n != INT32_MAX;
+      c.out_node[pod - a.row_begin] = any ? best_n : -1;
+      c.out_score[pod - a.row_begin] = any ? best : 0;
+      if (c.out_ties) c.out_ties[pod - a.row_begin] = any ? ties : 0;
+      if (any && T) c.missing[best_n] += a.tlp_pod_milli[pod];  // the bound pod's predicted utilisation, from now on
+      __threadfence_block();
+    }
+    __syncthreads();
+  }
+}
+
 // raw int64 Score() of one row (parity harness / direct-call tests); one thread per node
 __global__ void k_trimaran_raw(TrimaranArgs a, int plugin, int64_t pod, int64_t* out) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -917,6 +1012,13 @@ void launch_trimaran(const TrimaranArgs& a, hipStream_t s) {
   if (L && T) launch_npl<4>(a, s);
   else if (L) launch_npl<8>(a, s);
   else launch_npl<16>(a, s);
+}
+
+void launch_commit_trimaran(const CommitArgs& c, hipStream_t s) {
+  if (c.t.row_end <= c.t.row_begin) return;
+  if (c.use_mask & 4u)  // the exact per-node LVRB state the loop reads
+    hipLaunchKernelGGL(k_lvrb_prepare, dim3(static_cast<unsigned>((c.t.n_nodes + 255) / 256)), dim3(256), 0, s, c.t);
+  hipLaunchKernelGGL(k_commit_trimaran, dim3(1), dim3(kCommitThreads), 0, s, c);
 }
 
 void launch_trimaran_raw(const TrimaranArgs& a, int plugin, int64_t pod_row, int64_t* out, hipStream_t s) {

@@ -61,6 +61,7 @@ struct spx_engine {
   DevBuf d_raw_row;  // int64 [n_nodes] staging for spx_fetch_raw
   DevBuf d_lv_exact; // double [n_nodes][8] scratch of the LVRB fast kernel
   DevBuf d_lv_fast, d_tlp_fast;  // float32 per-node constants of the fast sweeps (recomputed per launch)
+  DevBuf d_commit;               // scratch of spx_commit_sequential
 
   // NodeResourceTopologyMatch
   spx_nrt_params nrt_params{SPX_NRT_LEAST_ALLOCATED, 0, nullptr, nullptr};  // defaults.go:87-90
@@ -341,7 +342,7 @@ int spx_destroy(spx_engine* e) {
   DevBuf* bufs[] = {&e->d_alloc,   &e->d_alloc_w,  &e->d_alloc_raw, &e->d_alloc_norm, &e->d_alloc_rel, &e->d_cap_cpu, &e->d_tlp_util,
                     &e->d_tlp_missing, &e->d_tlp_valid, &e->d_lv_acpu, &e->d_lv_amem, &e->d_lv_cavg, &e->d_lv_cstd,
                     &e->d_lv_mavg, &e->d_lv_mstd,  &e->d_lv_flags,  &e->d_tlp_pod,    &e->d_lv_rcpu, &e->d_lv_rmem,
-                    &e->d_raw_row,   &e->d_lv_exact, &e->d_lv_fast, &e->d_tlp_fast, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
+                    &e->d_raw_row,   &e->d_lv_exact, &e->d_lv_fast, &e->d_tlp_fast, &e->d_commit, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
                     &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_dist,
@@ -967,6 +968,51 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
 
 int spx_sync(spx_engine* e) {
   if (!e) return SPX_ERR_ARG;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  return SPX_OK;
+}
+
+int spx_commit_sequential(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end, int32_t* node_idx,
+                          int64_t* weighted_score, int32_t* n_ties, int64_t* tlp_missing_out) {
+  if (!e || !node_idx || !weighted_score) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  const uint32_t allowed = (1u << SPX_PLUGIN_ALLOCATABLE) | (1u << SPX_PLUGIN_TLP) | (1u << SPX_PLUGIN_LVRB);
+  if (plugin_mask == 0 || (plugin_mask & ~allowed))
+    return fail(e, SPX_ERR_ARG, "spx_commit_sequential supports Allocatable / TargetLoadPacking / LoadVariationRiskBalancing only");
+  const bool A = plugin_mask & (1u << SPX_PLUGIN_ALLOCATABLE);
+  const bool T = plugin_mask & (1u << SPX_PLUGIN_TLP);
+  const bool L = plugin_mask & (1u << SPX_PLUGIN_LVRB);
+  if (!(e->tri_nodes && e->tri_pods)) return fail(e, SPX_ERR_STATE, "trimaran node/pod tables not uploaded");
+  if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
+  int rc;
+  if (A && (rc = prepare_alloc(e))) return rc;
+  const size_t rows = static_cast<size_t>(row_end - row_begin), N = static_cast<size_t>(e->n_nodes);
+  if (rows == 0) return SPX_OK;
+  // scratch: [missing int64 N | score int64 rows | node int32 rows | ties int32 rows]
+  if ((rc = ensure(e, e->d_commit, N * 8 + rows * 16))) return rc;
+  spx::CommitArgs c{};
+  fill_trimaran(e, c.t);
+  c.t.row_begin = row_begin;
+  c.t.row_end = row_end;
+  if (L) {
+    if ((rc = ensure(e, e->d_lv_exact, N * 8 * sizeof(double)))) return rc;
+    c.t.lv_exact = static_cast<double*>(e->d_lv_exact.p);
+  }
+  c.use_mask = (A ? 1u : 0u) | (T ? 2u : 0u) | (L ? 4u : 0u);
+  c.w_alloc = e->plugin_weight[SPX_PLUGIN_ALLOCATABLE];
+  c.w_tlp = e->plugin_weight[SPX_PLUGIN_TLP];
+  c.w_lvrb = e->plugin_weight[SPX_PLUGIN_LVRB];
+  c.missing = static_cast<int64_t*>(e->d_commit.p);
+  c.out_score = c.missing + N;
+  c.out_node = reinterpret_cast<int32_t*>(c.out_score + rows);
+  c.out_ties = c.out_node + rows;
+  SPX_HIP(e, hipMemcpyAsync(c.missing, e->d_tlp_missing.p, N * 8, hipMemcpyDeviceToDevice, e->stream));
+  spx::launch_commit_trimaran(c, e->stream);
+  SPX_HIP(e, hipGetLastError());
+  SPX_HIP(e, hipMemcpyAsync(weighted_score, c.out_score, rows * 8, hipMemcpyDeviceToHost, e->stream));
+  SPX_HIP(e, hipMemcpyAsync(node_idx, c.out_node, rows * 4, hipMemcpyDeviceToHost, e->stream));
+  if (n_ties) SPX_HIP(e, hipMemcpyAsync(n_ties, c.out_ties, rows * 4, hipMemcpyDeviceToHost, e->stream));
+  if (tlp_missing_out) SPX_HIP(e, hipMemcpyAsync(tlp_missing_out, c.missing, N * 8, hipMemcpyDeviceToHost, e->stream));
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   return SPX_OK;
 }

@@ -67,6 +67,17 @@ struct TrimaranArgs {
 };
 // evaluates the plugins whose out_* pointer is non-NULL
 void launch_trimaran(const TrimaranArgs& a, hipStream_t s);
+// sequential commit loop over pod rows [t.row_begin, t.row_end) for Allocatable (bit 0) / TLP (bit 1) / LVRB (bit 2)
+struct CommitArgs {
+  TrimaranArgs t;       // inputs; alloc_norm must be prepared, lv_exact allocated when LVRB takes part
+  uint32_t use_mask;
+  int64_t w_alloc, w_tlp, w_lvrb;
+  int64_t* missing;     // [n_nodes] mutable copy of tlp_missing_milli: advances with every commit
+  int32_t* out_node;    // [rows]
+  int64_t* out_score;
+  int32_t* out_ties;    // may be NULL
+};
+void launch_commit_trimaran(const CommitArgs& c, hipStream_t s);
 // raw int64 Score() of one pod row for `plugin` (SPX_PLUGIN_TLP / SPX_PLUGIN_LVRB)
 void launch_trimaran_raw(const TrimaranArgs& a, int plugin, int64_t pod_row, int64_t* out, hipStream_t s);
 
