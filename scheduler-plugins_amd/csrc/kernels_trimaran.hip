@@ -801,35 +801,93 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
 // the reference's float64 arithmetic against the current missing[] column, a block-wide argmax picks the node (lowest
 // index among ties; upstream draws one of them at random), and the winner's missing utilisation is bumped.
 // No table is read or written; the per-pod decisions are the output.
-constexpr int kCommitThreads = 1024;
+// float32 constants of one node for the TLP fast formula (same derivation as k_tlp_prepare_fast / k_tlp_fast2):
+// (b2h, b2l, coefficient for u > 0, coefficient for u <= 0); NaN b2h = always the exact path
+__device__ __forceinline__ float4 tlp_fast_consts(double cap, double util_pct, double missing, bool valid, double t, double c1, double c2) {
+  double b = 1e30;
+  float f1 = -1.0f, f2 = 0.0f;
+  bool split = false;
+  if (valid) {
+    const double um = (util_pct / 100.0) * cap;
+    if (cap == 0.0) {
+      b = 1.0;
+      f1 = 0.0f;
+    } else if (!(um >= 0.0) || !(missing >= 0.0) || !(cap > 0.0) || !(um < 1e15) || !(missing < 1e15)) {
+      b = __builtin_nan("");
+    } else {
+      const double k = 100.0 / cap;
+      b = (um + missing) - t * cap / 100.0;
+      f1 = static_cast<float>(-c1 * k);
+      f2 = static_cast<float>(c2 * k);
+      split = __builtin_fabs(b) < 8388607.0;
+      if (!split) b = __builtin_nan("");
+    }
+  }
+  const double bh = split ? __builtin_rint(b) : b;
+  return float4{static_cast<float>(bh), split ? static_cast<float>(b - bh) : 0.0f, f1, f2};
+}
 
+// K > 0: every thread keeps its K nodes' TLP fast constants in registers for the whole loop (n_nodes <= kCommitThreads * K;
+// 512 threads = 2 waves per SIMD): per cell the float32 formula of k_tlp_fast2 with the same ambiguity test, ambiguous
+// cells and out-of-range pods re-evaluated with the reference's float64 sequence against the missing[] column in memory,
+// which the winner's owner advances (and whose constants it rebuilds) after every commit.
+// K == 0: float64 throughout, state re-read from global memory per pod (any size, 1024 threads).
+template <int K, int kCommitThreads>
 __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c) {
   __shared__ int64_t s_best[kCommitThreads / kWave];
   __shared__ int s_node[kCommitThreads / kWave];
   __shared__ int s_ties[kCommitThreads / kWave];
+  __shared__ uint32_t s_key[2][kCommitThreads / kWave];
+  __shared__ int s_tie[2];
   const TrimaranArgs& a = c.t;
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1), wave = tid >> 6;
   const bool A = c.use_mask & 1u, T = c.use_mask & 2u, L = c.use_mask & 4u;
+  constexpr int KR = K > 0 ? K : 1;
+  if (tid < 2) s_tie[tid] = 0;
+  __syncthreads();
+  const double t = a.tlp_target;
+  const double c1 = t / (100.0 - t), c2 = (100.0 - t) / t;
+  const bool fast_ok = t >= 1.0 && t <= 99.0;
+  float4 r_k[KR];        // (b2h, b2l, kc1, kc2)
+  uint32_t r_flags[KR];  // bit 1: node exists, bits 8..: w_alloc * Allocatable's normalised score
+  if constexpr (K > 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int64_t n = static_cast<int64_t>(k) * kCommitThreads + tid;
+      const bool in = n < a.n_nodes;
+      r_k[k] = (in && T) ? tlp_fast_consts(static_cast<double>(a.cap_cpu_milli[n]), a.tlp_cpu_util[n], static_cast<double>(c.missing[n]),
+                                           a.tlp_valid[n] != 0, t, c1, c2)
+                         : float4{1e30f, 0.0f, -1.0f, 0.0f};
+      if (!fast_ok) r_k[k].x = __builtin_nanf("");
+      r_flags[k] = (in ? 2u : 0u) | ((in && A) ? (static_cast<uint32_t>(c.w_alloc) * a.alloc_norm[n]) << 8 : 0u);
+    }
+  }
+  constexpr float kHalf = 0.5f - kTol32;
+  const float tf = static_cast<float>(t);
   for (int64_t pod = a.row_begin; pod < a.row_end; ++pod) {
-    const double pod_milli = T ? static_cast<double>(a.tlp_pod_milli[pod]) : 0.0;
+    const int64_t pod_i = T ? a.tlp_pod_milli[pod] : 0;
+    const double pod_milli = static_cast<double>(pod_i);
+    const bool pod_bad = pod_i < 0 || pod_i >= (1 << 23);  // not exact as a float32 integer: exact path for the row
+    const float pod_f = static_cast<float>(pod_i);
     const double req_cpu = L ? fmax(static_cast<double>(a.lv_req_cpu_milli[pod]), 0.0) : 0.0;
     const double req_mem = L ? fmax(static_cast<double>(a.lv_req_mem[pod]) * kMega, 0.0) : 0.0;
     int64_t best = INT64_MIN;
     int best_n = INT32_MAX, ties = 0;
-    for (int64_t n = tid; n < a.n_nodes; n += kCommitThreads) {
+    auto exact_tlp = [&](int64_t n) -> uint32_t {
+      TlpNode tn;
+      tn.cap = static_cast<double>(a.cap_cpu_milli[n]);
+      tn.util_millis = (a.tlp_cpu_util[n] / 100.0) * tn.cap;
+      tn.missing = static_cast<double>(c.missing[n]);
+      tn.valid = a.tlp_valid[n] != 0;
+      bool zero;
+      const double x = tlp_unrounded(tn, pod_milli, t, &zero);
+      return zero ? 0u : to_u8(x);
+    };
+    auto consider = [&](int64_t n, uint32_t tlp_byte, uint32_t alloc_byte) {
       int64_t total = 0;
-      if (A) total += c.w_alloc * static_cast<int64_t>(a.alloc_norm[n]);
-      if (T) {
-        TlpNode tn;
-        tn.cap = static_cast<double>(a.cap_cpu_milli[n]);
-        tn.util_millis = (a.tlp_cpu_util[n] / 100.0) * tn.cap;
-        tn.missing = static_cast<double>(c.missing[n]);
-        tn.valid = a.tlp_valid[n] != 0;
-        bool zero;
-        const double x = tlp_unrounded(tn, pod_milli, a.tlp_target, &zero);
-        total += c.w_tlp * static_cast<int64_t>(zero ? 0u : to_u8(x));
-      }
+      if (A) total += c.w_alloc * static_cast<int64_t>(alloc_byte);
+      if (T) total += c.w_tlp * static_cast<int64_t>(tlp_byte);
       if (L) {
         const double* o = a.lv_exact + n * 8;
         const int ms = static_cast<int>(o[7]);
@@ -844,45 +902,128 @@ __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c
       } else if (total == best) {
         ++ties;
       }
-    }
-    // wave-level then block-level argmax (every lane is live: no divergence around the shuffles)
+    };
+    uint32_t kmax = 0, btot = 0;  // K > 0: best key (total << 14 | 16383 - node) and the total it carries
+    if constexpr (K > 0) {
+      // totals fit 18 bits here (launch condition): 32-bit arithmetic, Allocatable's share folded into a per-node base;
+      // ambiguous cells (and every cell of a pod that is not a float32 integer) take the reference's float64 sequence
+      const uint32_t wt = static_cast<uint32_t>(c.w_tlp), wl = static_cast<uint32_t>(c.w_lvrb);
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-      const int64_t ob = shfl_xor_i64(best, m);
-      const int on = __shfl_xor(best_n, m, 64);
-      const int ot = __shfl_xor(ties, m, 64);
-      if (ob > best || (ob == best && on < best_n)) {
-        ties = ob > best ? ot : ties + ot;
-        best = ob;
-        best_n = on;
-      } else if (ob == best) {
-        ties += ot;
-      }
-    }
-    if (lane == 0) {
-      s_best[wave] = best;
-      s_node[wave] = best_n;
-      s_ties[wave] = ties;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      for (int w = 1; w < kCommitThreads / kWave; ++w) {
-        if (s_best[w] > best || (s_best[w] == best && s_node[w] < best_n)) {
-          ties = s_best[w] > best ? s_ties[w] : ties + s_ties[w];
-          best = s_best[w];
-          best_n = s_node[w];
-        } else if (s_best[w] == best) {
-          ties += s_ties[w];
+      for (int k = 0; k < K; ++k) {
+        const int64_t n = static_cast<int64_t>(k) * kCommitThreads + tid;
+        if (!(r_flags[k] & 2u)) continue;
+        uint32_t tot = r_flags[k] >> 8;  // w_alloc * Allocatable's normalised score
+        if (T) {
+          const float u = (pod_f + r_k[k].x) + r_k[k].y;
+          const bool gt = __float_as_int(u) > 0;
+          const float x = __builtin_fmaf(gt ? r_k[k].z : r_k[k].w, u, gt ? tf : 100.0f);
+          const float rr = __builtin_rintf(x);
+          const bool amb = pod_bad || !(__builtin_fabsf(x - rr) < kHalf) || !(__builtin_fabsf(u) > kTolU);
+          const uint32_t tb = amb ? exact_tlp(n) : (__builtin_amdgcn_cvt_pk_u8_f32(rr, 0, 0u) & 0xffu);
+          tot += wt * tb;
+        }
+        if (L) {
+          const double* o = a.lv_exact + n * 8;
+          const int ms = static_cast<int>(o[7]);
+          const LvRes cr{o[0], o[1], o[2], static_cast<int>(o[3])};
+          const LvRes mr{o[4], o[5], o[6], ms & 7};
+          tot += wl * to_u8(lv_total((ms & 8) != 0, cr, mr, req_cpu, req_mem));
+        }
+        const uint32_t key = (tot << 14) | (16383u - static_cast<uint32_t>(n));
+        kmax = key > kmax ? key : kmax;
+        if (c.out_ties) {  // uniform
+          ties = tot > btot ? 1 : (tot == btot ? ties + 1 : ties);
+          btot = tot > btot ? tot : btot;
         }
       }
-      const bool any = best_n != INT32_MAX;
-      c.out_node[pod - a.row_begin] = any ? best_n : -1;
-      c.out_score[pod - a.row_begin] = any ? best : 0;
-      if (c.out_ties) c.out_ties[pod - a.row_begin] = any ? ties : 0;
-      if (any && T) c.missing[best_n] += a.tlp_pod_milli[pod];  // the bound pod's predicted utilisation, from now on
-      __threadfence_block();
+    } else {
+      for (int64_t n = tid; n < a.n_nodes; n += kCommitThreads) consider(n, T ? exact_tlp(n) : 0u, A ? a.alloc_norm[n] : 0u);
     }
+    if constexpr (K > 0) {
+      // One 32-bit key per thread orders (total descending, node ascending): key = total << 14 | (16383 - node); the launch
+      // picks this variant only when every total fits 18 bits and n_nodes <= 16384.  One butterfly, one barrier: every
+      // thread then reduces the per-wave keys itself (double-buffered by pod parity), so no second barrier is needed to
+      // broadcast the winner.
+      uint32_t key = kmax;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        const uint32_t o = static_cast<uint32_t>(__shfl_xor(static_cast<int>(key), m, 64));
+        key = o > key ? o : key;
+      }
+      const int par = static_cast<int>(pod & 1);
+      if (lane == 0) s_key[par][wave] = key;
+      __syncthreads();
+      uint32_t gkey = 0;
+#pragma unroll
+      for (int w = 0; w < kCommitThreads / kWave; ++w) gkey = s_key[par][w] > gkey ? s_key[par][w] : gkey;
+      const bool any = gkey != 0;
+      const int win = any ? static_cast<int>(16383u - (gkey & 16383u)) : -1;
+      const int64_t gbest = static_cast<int64_t>(gkey >> 14);
+      if (c.out_ties && any && kmax != 0 && static_cast<int64_t>(btot) == gbest) atomicAdd(&s_tie[par], ties);
+      if (tid == 0) {
+        c.out_node[pod - a.row_begin] = win;
+        c.out_score[pod - a.row_begin] = any ? gbest : 0;
+        // tie counters run one iteration late: the previous pod's adds all happened before this iteration's barrier
+        if (c.out_ties && pod > a.row_begin) c.out_ties[pod - 1 - a.row_begin] = s_tie[par ^ 1];
+        s_tie[par ^ 1] = 0;
+      }
+      // the winner's owner advances the column (only it ever reads that entry again) and shifts the node's constants: the
+      // real number b2h + b2l grows by exactly the pod's integer millicores, which tracks the float64 b within ~1e-10
+      if (T && win >= 0 && (win % kCommitThreads) == tid) {
+        c.missing[win] += pod_i;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if (win / kCommitThreads == k) {
+            const float nb = r_k[k].x + pod_f;
+            r_k[k].x = (pod_bad || !(__builtin_fabsf(nb) < 8388607.0f)) ? __builtin_nanf("") : nb;
+          }
+      }
+    } else {
+      // wave-level then block-level argmax (every lane is live: no divergence around the shuffles)
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        const int64_t ob = shfl_xor_i64(best, m);
+        const int on = __shfl_xor(best_n, m, 64);
+        const int ot = __shfl_xor(ties, m, 64);
+        if (ob > best || (ob == best && on < best_n)) {
+          ties = ob > best ? ot : ties + ot;
+          best = ob;
+          best_n = on;
+        } else if (ob == best) {
+          ties += ot;
+        }
+      }
+      if (lane == 0) {
+        s_best[wave] = best;
+        s_node[wave] = best_n;
+        s_ties[wave] = ties;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        for (int w = 1; w < kCommitThreads / kWave; ++w) {
+          if (s_best[w] > best || (s_best[w] == best && s_node[w] < best_n)) {
+            ties = s_best[w] > best ? s_ties[w] : ties + s_ties[w];
+            best = s_best[w];
+            best_n = s_node[w];
+          } else if (s_best[w] == best) {
+            ties += s_ties[w];
+          }
+        }
+        const bool any = best_n != INT32_MAX;
+        c.out_node[pod - a.row_begin] = any ? best_n : -1;
+        c.out_score[pod - a.row_begin] = any ? best : 0;
+        if (c.out_ties) c.out_ties[pod - a.row_begin] = any ? ties : 0;
+        if (any && T) {
+          c.missing[best_n] += pod_i;  // the bound pod's predicted utilisation, from now on
+          __threadfence_block();
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if constexpr (K > 0) {  // the last pod's tie count (counters are read one iteration late)
     __syncthreads();
+    if (tid == 0 && c.out_ties && a.row_end > a.row_begin) c.out_ties[a.row_end - 1 - a.row_begin] = s_tie[static_cast<int>((a.row_end - 1) & 1)];
   }
 }
 
@@ -1018,7 +1159,12 @@ void launch_commit_trimaran(const CommitArgs& c, hipStream_t s) {
   if (c.t.row_end <= c.t.row_begin) return;
   if (c.use_mask & 4u)  // the exact per-node LVRB state the loop reads
     hipLaunchKernelGGL(k_lvrb_prepare, dim3(static_cast<unsigned>((c.t.n_nodes + 255) / 256)), dim3(256), 0, s, c.t);
-  hipLaunchKernelGGL(k_commit_trimaran, dim3(1), dim3(kCommitThreads), 0, s, c);
+  const bool from_memory = getenv("SPX_COMMIT_FROM_MEMORY") != nullptr;  // differential tests (read per launch)
+  const bool key_fits = c.w_alloc >= 0 && c.w_tlp >= 0 && c.w_lvrb >= 0 && (c.w_alloc + c.w_tlp + c.w_lvrb) * 255 < (int64_t{1} << 18);
+  if (!from_memory && key_fits && c.t.n_nodes <= 20 * 512)
+    hipLaunchKernelGGL((k_commit_trimaran<20, 512>), dim3(1), dim3(512), 0, s, c);
+  else
+    hipLaunchKernelGGL((k_commit_trimaran<0, 1024>), dim3(1), dim3(1024), 0, s, c);
 }
 
 void launch_trimaran_raw(const TrimaranArgs& a, int plugin, int64_t pod_row, int64_t* out, hipStream_t s) {

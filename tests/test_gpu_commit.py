@@ -34,8 +34,12 @@ def _scenario(hdr, n_nodes, n_pods, seed):
 
 @pytest.mark.parametrize("plugins,weights", [((ALLOCATABLE, TLP), {ALLOCATABLE: 1, TLP: 1}), ((TLP,), {TLP: 1}),
                                              ((ALLOCATABLE, TLP, LVRB), {ALLOCATABLE: 1, TLP: 3, LVRB: 2})])
-@pytest.mark.parametrize("n_nodes,n_pods,seed", [(23, 90, 1), (70, 60, 2)])
-def test_commit_sequential_matches_one_pod_at_a_time(gpu_required, hdr, oracle, plugins, weights, n_nodes, n_pods, seed):
+@pytest.mark.parametrize("n_nodes,n_pods,seed", [(23, 90, 1), (70, 60, 2), (1100, 40, 3)])
+@pytest.mark.parametrize("state", ["registers", "memory"])
+def test_commit_sequential_matches_one_pod_at_a_time(gpu_required, hdr, oracle, monkeypatch, state, plugins, weights, n_nodes, n_pods, seed):
+    """both variants of the loop: node state resident in registers (up to 10240 nodes) and re-read from memory per pod"""
+    if state == "memory":
+        monkeypatch.setenv("SPX_COMMIT_FROM_MEMORY", "1")
     res, nodes, metrics, pods, earlier = _scenario(hdr, n_nodes, n_pods, seed)
     node_t = O.build_node_objects(hdr, res, nodes)
     pod_t = O.build_pod_objects(hdr, res, pods)
