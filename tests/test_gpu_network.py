@@ -94,3 +94,33 @@ def test_host_missing_from_snapshot_is_an_error(gpu_required, hdr):
         e.eval(mask_of(NETOVERHEAD))
         e.sync()
         assert (e.status(NETOVERHEAD, 0) == 255).all()
+
+
+# ------------------------------------------------------------------ full size (config #4): sampled rows + properties
+def test_config4_full_size_properties(gpu_required, hdr, oracle):
+    n_nodes, n_pods = 10_000, 200_000
+    snap = synth.network_snapshot(hdr, n_nodes, n_pods)
+    with Engine(0) as e:
+        e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+        assert e.kernel_path(NETOVERHEAD) == 1
+        e.eval(mask_of(NETOVERHEAD))
+        e.sync()
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], appgroups=snap["appgroups"], nettopo=snap["nettopo"])
+        rng = np.random.default_rng(11)
+        rows = sorted(set(rng.integers(0, n_pods, 12).tolist()) | {0, n_pods - 1})
+        for r in rows:
+            assert np.array_equal(e.status(NETOVERHEAD, r), osnap.filter_rows(NETOVERHEAD, r, r + 1)[0]), r
+            assert np.array_equal(e.scores(NETOVERHEAD, r).astype(np.int64), osnap.score_rows(NETOVERHEAD, r, r + 1)[1][0]), r
+        # a row depends on the pod only through its (AppGroup, selector): equal workloads -> equal rows
+        ag, sel = snap["pods"].array("appgroup"), snap["pods"].array("selector")
+        key = ag.astype(np.int64) * 64 + sel
+        order = np.argsort(key, kind="stable")
+        same = np.flatnonzero((key[order][1:] == key[order][:-1]))[:: 4001][:24]
+        assert same.size > 0
+        for i in same:
+            a, b = int(order[i]), int(order[i + 1])
+            assert np.array_equal(e.scores(NETOVERHEAD, a), e.scores(NETOVERHEAD, b)) and np.array_equal(e.status(NETOVERHEAD, a), e.status(NETOVERHEAD, b))
+        # NormalizeScore: every evaluated row spans exactly [.., 100] with 100 at its cheapest feasible node, or is all zero
+        for r in rows:
+            sc, st = e.scores(NETOVERHEAD, r), e.status(NETOVERHEAD, r)
+            assert sc.max() in (0, 100) and (sc[st != 0] == 0).all()

@@ -261,3 +261,35 @@ def test_partial_rows_and_mixed_plugins(gpu_required, hdr, oracle):
         osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
         assert np.array_equal(e.all_status(NRT), osnap.filter_rows(NRT))
         assert np.array_equal(e.all_scores(NRT).astype(np.int64), osnap.score_rows(NRT, want_norm=False)[0].clip(0, 255))
+
+
+# ------------------------------------------------------------------ full size (config #3): sampled rows + properties
+def test_config3_full_size_properties(gpu_required, hdr, oracle):
+    n_nodes, n_pods = 5_000, 50_000
+    snap = synth.nrt_snapshot(hdr, n_nodes, n_pods)
+    res = O.Resources()
+    params = O.nrt_params(hdr, res, "LeastAllocated")
+    with Engine(0) as e:
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+        assert e.kernel_path(NRT) == 1
+        e.eval(mask_of(NRT))
+        e.sync()
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
+        rng = np.random.default_rng(7)
+        rows = sorted(set(rng.integers(0, n_pods, 20).tolist()) | {0, 31, 32, n_pods - 1})
+        for r in rows:
+            assert np.array_equal(e.status(NRT, r), osnap.filter_rows(NRT, r, r + 1)[0]), r
+            assert np.array_equal(e.scores(NRT, r).astype(np.int64), osnap.score_rows(NRT, r, r + 1, want_norm=False)[0][0].clip(0, 255)), r
+        qos = e.nrt_soa["pods"]["qos"]
+        non_native = e.nrt_soa["pods"]["non_native"]
+        flags = e.nrt_soa["nodes"]["flags"]
+        fresh = (flags & hdr.consts["SPX_NRT_F_FRESH"]) != 0
+        # score.go:70-75: anything but Guaranteed scores MaxNodeScore on every node
+        for r in np.flatnonzero(qos != hdr.consts["SPX_QOS_GUARANTEED"])[:: 997][:24]:
+            assert (e.scores(NRT, int(r)) == 100).all()
+        # filter.go:186-190: BestEffort pods without non-native resources always pass; stale nodes reject everyone else
+        for r in np.flatnonzero((qos == hdr.consts["SPX_QOS_BESTEFFORT"]) & (non_native == 0))[:: 211][:16]:
+            assert (e.status(NRT, int(r)) == 0).all()
+        for r in np.flatnonzero(qos == hdr.consts["SPX_QOS_GUARANTEED"])[:: 1999][:12]:
+            st = e.status(NRT, int(r))
+            assert (st[~fresh] == hdr.consts["SPX_NRT_ST_INVALID_TOPOLOGY"]).all() and (st[fresh] != hdr.consts["SPX_NRT_ST_INVALID_TOPOLOGY"]).all()
