@@ -72,8 +72,6 @@ def test_score_least_numa(gpu_required, hdr, case):
 def test_numa_nodes_required_via_pod_scope_score(gpu_required, hdr, case):
     """TestNUMANodesRequired through the pod-scope LeastNUMANodes score: 100 - 12*count (+6 when the chosen
     combination has the minimal average distance); nil -> 0 (least_numa.go:73-100)."""
-    if any(n["id"] != i for i, n in enumerate(case["numa_nodes"])):
-        pytest.skip("unsorted/non-sequential NUMA ids: covered at oracle level; the SoA path keeps id == position")
     res = O.Resources()
     zones = [{"name": f"node-{n['id']}", "type": "Node", "resources": n["resources"],
               "costs": {f"node-{k}": v for k, v in n["costs"].items()}} for n in case["numa_nodes"]]
