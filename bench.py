@@ -218,7 +218,7 @@ def main() -> None:
             # the same pods scheduled strictly one after the other, each seeing the commits before it (upstream's
             # semantics; inherently sequential, one workgroup): spx_commit_sequential
             c4 = time.perf_counter()
-            seq_node, _, _, _ = e.commit_sequential(mask)
+            seq_node, _, _, _ = e.commit_sequential(mask, want_ties=False)
             c5 = time.perf_counter()
             full_cycle["sequential_commit_ms"] = (c5 - c4) * 1e3
             full_cycle["sequential_pods_per_s"] = n_pods / (c5 - c4)

@@ -832,7 +832,7 @@ __device__ __forceinline__ float4 tlp_fast_consts(double cap, double util_pct, d
 // cells and out-of-range pods re-evaluated with the reference's float64 sequence against the missing[] column in memory,
 // which the winner's owner advances (and whose constants it rebuilds) after every commit.
 // K == 0: float64 throughout, state re-read from global memory per pod (any size, 1024 threads).
-template <int K, int kCommitThreads>
+template <int K, int kCommitThreads, bool kHasL, bool kTies>
 __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c) {
   __shared__ int64_t s_best[kCommitThreads / kWave];
   __shared__ int s_node[kCommitThreads / kWave];
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c
   const TrimaranArgs& a = c.t;
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1), wave = tid >> 6;
-  const bool A = c.use_mask & 1u, T = c.use_mask & 2u, L = c.use_mask & 4u;
+  const bool A = c.use_mask & 1u, T = c.use_mask & 2u, L = kHasL && (c.use_mask & 4u);
   constexpr int KR = K > 0 ? K : 1;
   if (tid < 2) s_tie[tid] = 0;
   __syncthreads();
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c
           const uint32_t tb = amb ? exact_tlp(n) : (__builtin_amdgcn_cvt_pk_u8_f32(rr, 0, 0u) & 0xffu);
           tot += wt * tb;
         }
-        if (L) {
+        if constexpr (kHasL) {
           const double* o = a.lv_exact + n * 8;
           const int ms = static_cast<int>(o[7]);
           const LvRes cr{o[0], o[1], o[2], static_cast<int>(o[3])};
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c
         }
         const uint32_t key = (tot << 14) | (16383u - static_cast<uint32_t>(n));
         kmax = key > kmax ? key : kmax;
-        if (c.out_ties) {  // uniform
+        if constexpr (kTies) {
           ties = tot > btot ? 1 : (tot == btot ? ties + 1 : ties);
           btot = tot > btot ? tot : btot;
         }
@@ -959,7 +959,9 @@ __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c
       const bool any = gkey != 0;
       const int win = any ? static_cast<int>(16383u - (gkey & 16383u)) : -1;
       const int64_t gbest = static_cast<int64_t>(gkey >> 14);
-      if (c.out_ties && any && kmax != 0 && static_cast<int64_t>(btot) == gbest) atomicAdd(&s_tie[par], ties);
+      if constexpr (kTies) {
+        if (any && kmax != 0 && static_cast<int64_t>(btot) == gbest) atomicAdd(&s_tie[par], ties);
+      }
       if (tid == 0) {
         c.out_node[pod - a.row_begin] = win;
         c.out_score[pod - a.row_begin] = any ? gbest : 0;
@@ -1161,10 +1163,15 @@ void launch_commit_trimaran(const CommitArgs& c, hipStream_t s) {
     hipLaunchKernelGGL(k_lvrb_prepare, dim3(static_cast<unsigned>((c.t.n_nodes + 255) / 256)), dim3(256), 0, s, c.t);
   const bool from_memory = getenv("SPX_COMMIT_FROM_MEMORY") != nullptr;  // differential tests (read per launch)
   const bool key_fits = c.w_alloc >= 0 && c.w_tlp >= 0 && c.w_lvrb >= 0 && (c.w_alloc + c.w_tlp + c.w_lvrb) * 255 < (int64_t{1} << 18);
-  if (!from_memory && key_fits && c.t.n_nodes <= 20 * 512)
-    hipLaunchKernelGGL((k_commit_trimaran<20, 512>), dim3(1), dim3(512), 0, s, c);
-  else
-    hipLaunchKernelGGL((k_commit_trimaran<0, 1024>), dim3(1), dim3(1024), 0, s, c);
+  if (!from_memory && key_fits && c.t.n_nodes <= 20 * 512) {
+    const bool l = (c.use_mask & 4u) != 0, ties = c.out_ties != nullptr;
+    if (l && ties) hipLaunchKernelGGL((k_commit_trimaran<20, 512, true, true>), dim3(1), dim3(512), 0, s, c);
+    else if (l) hipLaunchKernelGGL((k_commit_trimaran<20, 512, true, false>), dim3(1), dim3(512), 0, s, c);
+    else if (ties) hipLaunchKernelGGL((k_commit_trimaran<20, 512, false, true>), dim3(1), dim3(512), 0, s, c);
+    else hipLaunchKernelGGL((k_commit_trimaran<20, 512, false, false>), dim3(1), dim3(512), 0, s, c);
+  } else {
+    hipLaunchKernelGGL((k_commit_trimaran<0, 1024, true, true>), dim3(1), dim3(1024), 0, s, c);
+  }
 }
 
 void launch_trimaran_raw(const TrimaranArgs& a, int plugin, int64_t pod_row, int64_t* out, hipStream_t s) {

@@ -1005,13 +1005,13 @@ int spx_commit_sequential(spx_engine* e, uint32_t plugin_mask, int64_t row_begin
   c.missing = static_cast<int64_t*>(e->d_commit.p);
   c.out_score = c.missing + N;
   c.out_node = reinterpret_cast<int32_t*>(c.out_score + rows);
-  c.out_ties = c.out_node + rows;
+  c.out_ties = n_ties ? c.out_node + rows : nullptr;
   SPX_HIP(e, hipMemcpyAsync(c.missing, e->d_tlp_missing.p, N * 8, hipMemcpyDeviceToDevice, e->stream));
   spx::launch_commit_trimaran(c, e->stream);
   SPX_HIP(e, hipGetLastError());
   SPX_HIP(e, hipMemcpyAsync(weighted_score, c.out_score, rows * 8, hipMemcpyDeviceToHost, e->stream));
   SPX_HIP(e, hipMemcpyAsync(node_idx, c.out_node, rows * 4, hipMemcpyDeviceToHost, e->stream));
-  if (n_ties) SPX_HIP(e, hipMemcpyAsync(n_ties, c.out_ties, rows * 4, hipMemcpyDeviceToHost, e->stream));
+  if (n_ties) SPX_HIP(e, hipMemcpyAsync(n_ties, c.out_node + rows, rows * 4, hipMemcpyDeviceToHost, e->stream));
   if (tlp_missing_out) SPX_HIP(e, hipMemcpyAsync(tlp_missing_out, c.missing, N * 8, hipMemcpyDeviceToHost, e->stream));
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   return SPX_OK;

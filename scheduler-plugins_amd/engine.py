@@ -323,16 +323,17 @@ class Engine:
                                           ties.ctypes.data_as(i32p), feas.ctypes.data_as(i32p)))
         return node, score, ties, feas
 
-    def commit_sequential(self, plugin_mask: int, row_begin: int = 0, row_end: Optional[int] = None):
+    def commit_sequential(self, plugin_mask: int, row_begin: int = 0, row_end: Optional[int] = None, want_ties: bool = True):
         """pods in row order, each seeing the commits before it (Allocatable/TLP/LVRB) -> (node, weighted score, ties, missing)"""
         row_end = self.n_pods if row_end is None else row_end
         n = row_end - row_begin
         node, score, ties = np.zeros(n, np.int32), np.zeros(n, np.int64), np.zeros(n, np.int32)
         missing = np.zeros(self.n_nodes, np.int64)
         self._ck(self._lib.spx_commit_sequential(self._h, plugin_mask, row_begin, row_end, node.ctypes.data_as(C.POINTER(C.c_int32)),
-                                                 score.ctypes.data_as(C.POINTER(C.c_int64)), ties.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                 score.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                 ties.ctypes.data_as(C.POINTER(C.c_int32)) if want_ties else None,
                                                  missing.ctypes.data_as(C.POINTER(C.c_int64))))
-        return node, score, ties, missing
+        return node, score, (ties if want_ties else None), missing
 
     def set_stream(self, stream: int) -> None:
         self._ck(self._lib.spx_set_stream(self._h, C.c_void_p(stream)))
