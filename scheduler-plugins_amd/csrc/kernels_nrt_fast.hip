@@ -150,7 +150,7 @@ __device__ __forceinline__ void adjust_fast(FastNode<RM>& ns, const Item<RM>& it
 // count hold no capacity and score 0 under Least/MostAllocated, so they drop out by themselves.
 template <int RM, int SG>
 __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const NrtArgs& a, const Item<RM>& it,
-                                               const double* __restrict__ cpu_v) {
+                                               const double* __restrict__ cpu_v, const double* __restrict__ braw) {
   const uint32_t used = it.used;
   uint32_t m = 0xffffffffu;  // min over zones of (score - 1) as unsigned: a zero score wraps to the maximum
   double value[RM];
@@ -204,8 +204,14 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
           // max(., 0) turns both into the reference's 0
           rs = __builtin_fmax(__builtin_floor(__builtin_fma(-value[r], ns.b[z][r], 100.0 + 0x1p-43)), 0.0);
         } else {
-          const double t = __builtin_floor((value[r] * (1.0 + 0x1p-49)) * ns.b[z][r]);
-          rs = it.raw[r] <= ns.av[z][r] ? t : 0.0;
+          // req_v * 100 / cap_v, zero when the request exceeds the capacity.  "request <= capacity" is read off the same
+          // kind of product instead of the mutable table (so MostAllocated, like LeastAllocated, scores from b alone):
+          // t = (q * (1 + 2^-49)) * RN(100 / c) <= 100 * (1 + 2^-48)  <=>  q <= c   for integers q, c < 2^42
+          // (q <= c gives t <= 100 * (1 + 1.2 * 2^-49); q >= c + 1 gives t >= 100 * (1 + 2^-42)).  The cpu slot compares the
+          // raw millicore quantities (braw), the score uses whole cores (b).
+          const double tp = (value[r] * (1.0 + 0x1p-49)) * ns.b[z][r];
+          const double chk = r == a.cpu_slot ? (it.raw[r] * (1.0 + 0x1p-49)) * braw[z] : tp;
+          rs = chk <= 100.0 * (1.0 + 0x1p-48) ? __builtin_floor(tp) : 0.0;
         }
         acc = __builtin_fma(rs, a.slot_weight_f[r], acc);
       }
@@ -334,7 +340,7 @@ __device__ __forceinline__ void subtract_from_numas_fast(FastNode<RM>& ns, const
 constexpr int kPhBoth = 0, kPhFilter = 1, kPhScore = 2;
 
 template <int RM, int SG, int PH>
-__global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? 5 : (PH == kPhFilter ? 4 : ((SG == kSgBalanced || SG == kSgLeastNuma) ? 2 : 3))) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
+__global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgMost ? 4 : 5) : (PH == kPhFilter ? 4 : (SG == kSgLeast ? 3 : 2))) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
   typedef typename ItemWords<RM>::T Words;
   // A block owns a window of 256 consecutive nodes and a chunk of pod rows.  Inside the window the engine has
   // ordered the nodes by (aligned, scope) — perm[] — so that a wavefront's 64 nodes mostly share one code path
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? 5 : (PH == kPhFilt
   }
 
   FastNode<RM> ns;
-  double cpu_v[kZ];
+  double cpu_v[kZ], braw[kZ];
   const uint32_t flags = in ? a.flags[n] : 0u;
   ns.nz = in ? a.n_zones[n] : 0;
   ns.node_present = in ? a.node_present[n] : 0u;
@@ -379,6 +385,7 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? 5 : (PH == kPhFilt
 #pragma unroll
   for (int z = 0; z < kZ; ++z) {
     cpu_v[z] = (SG == kSgBalanced && in && a.cpu_slot >= 0) ? a.f_cpu[static_cast<int64_t>(z) * a.n_nodes + n] : 0.0;
+    braw[z] = (SG == kSgMost && in && a.cpu_slot >= 0) ? a.f_braw[static_cast<int64_t>(z) * a.n_nodes + n] : kNoCap;
 #pragma unroll
     for (int r = 0; r < RM; ++r) {
       const int64_t i = (static_cast<int64_t>(z) * R + r) * a.n_nodes + n;
@@ -424,14 +431,14 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? 5 : (PH == kPhFilt
         }
       }
       if constexpr (PH != kPhFilter) {
-        if (want_score) score = score_each_fast<RM, SG>(ns, a, it, cpu_v);
+        if (want_score) score = score_each_fast<RM, SG>(ns, a, it, cpu_v, braw);
       }
     }
     if ((want_filter || want_score) && !pod_scope) {  // singleNUMAContainerLevelHandler / containerScopeScore
       // One pass in container order (init containers come first — checked at upload): an init container must fit
       // and is never subtracted; an app container is placed on the lowest fitting zone and subtracted from it.
-      // Least/MostAllocated's zone scores do not read the mutable table under Least (only b), so Least scores in
-      // the same pass; the other strategies score after the undo.
+      // Least/MostAllocated's zone scores read only b (never the mutable table), so they score in the same pass;
+      // BalancedAllocation scores after the undo.
       uint32_t chosen = 0;  // list position picked per app container (for the undo), 4 bits each
       uint32_t placed = 0;  // bit c: container c was subtracted on this lane
       int sum = 0;
@@ -454,8 +461,8 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? 5 : (PH == kPhFilt
             }
           }
         }
-        if constexpr (SG == kSgLeast && PH != kPhFilter) {
-          if (want_score) sum += score_each_fast<RM, SG>(ns, a, it, cpu_v);
+        if constexpr ((SG == kSgLeast || SG == kSgMost) && PH != kPhFilter) {
+          if (want_score) sum += score_each_fast<RM, SG>(ns, a, it, cpu_v, braw);
         }
         cw = nw;
       }
@@ -468,12 +475,12 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? 5 : (PH == kPhFilt
           cw = nw;
         }
       }
-      if constexpr (SG != kSgLeast && PH != kPhFilter) {
+      if constexpr (SG != kSgLeast && SG != kSgMost && PH != kPhFilter) {
         if (want_score) {
           cw = uload(pi + 2);
           for (int c = 0; c < n_ctr; ++c) {
             const Words nw = uload(pi + 2 + (c + 1 < kC ? c + 1 : c));
-            sum += score_each_fast<RM, SG>(ns, a, decode_item<RM>(cw), cpu_v);
+            sum += score_each_fast<RM, SG>(ns, a, decode_item<RM>(cw), cpu_v, braw);
             cw = nw;
           }
         }
@@ -566,12 +573,12 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   const unsigned blocks = static_cast<unsigned>(chunks * n_tiles);
   const int sg = a.strategy == SPX_NRT_LEAST_NUMA_NODES ? kSgLeastNuma
                : a.strategy == SPX_NRT_BALANCED_ALLOCATION ? kSgBalanced : (a.strategy == SPX_NRT_LEAST_ALLOCATED ? kSgLeast : kSgMost);
-  const bool split = sg == kSgLeast && a.out_raw == nullptr && getenv("SPX_NRT_NOSPLIT") == nullptr;
+  const bool split = (sg == kSgLeast || sg == kSgMost) && a.out_raw == nullptr && getenv("SPX_NRT_NOSPLIT") == nullptr;
 #define SPX_NRTF_CASE(RMV, SGV)                                                                           \
   if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                                        \
-    if (SGV == kSgLeast && split) {                                                                       \
+    if ((SGV == kSgLeast || SGV == kSgMost) && split) { /* the Filter half does not depend on the strategy */ \
       hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhFilter>), dim3(blocks), dim3(256), 0, s, a, n_tiles); \
-      hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
+      hipLaunchKernelGGL((k_nrt_fast<RMV, (SGV == kSgMost ? kSgMost : kSgLeast), kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
     } else {                                                                                              \
       hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhBoth>), dim3(blocks), dim3(256), 0, s, a, n_tiles);     \
     }                                                                                                     \

@@ -72,7 +72,7 @@ struct spx_engine {
   DevBuf d_nrt_flags, d_nrt_max_numa, d_nrt_nz, d_nrt_zid, d_nrt_zp, d_nrt_avail, d_nrt_cost, d_nrt_minavg, d_nrt_np;
   DevBuf d_nrt_qos, d_nrt_nn, d_nrt_nctr, d_nrt_ckind, d_nrt_cpres, d_nrt_creq, d_nrt_ppres, d_nrt_preq;
   // float64 formulation of the NRT sweep (kernels_nrt_fast.hip): derived tables + whether its preconditions hold
-  DevBuf d_nrt_fav, d_nrt_frc, d_nrt_fcpu, d_nrt_frep, d_nrt_items, d_nrt_perm, d_nrt_dist;
+  DevBuf d_nrt_fav, d_nrt_frc, d_nrt_fcpu, d_nrt_fbraw, d_nrt_frep, d_nrt_items, d_nrt_perm, d_nrt_dist;
   std::vector<double> nrt_wtab;  // [2^n_res][2]: sum of the weights of a slot subset, its biased reciprocal
   bool nrt_fast_slots = false, nrt_fast_nodes = false, nrt_fast_pods = false;
   int32_t nrt_cpu_slot = -1;
@@ -257,6 +257,7 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   na.f_av = static_cast<const double*>(e->d_nrt_fav.p);
   na.f_rc = static_cast<const double*>(e->d_nrt_frc.p);
   na.f_cpu = static_cast<const double*>(e->d_nrt_fcpu.p);
+  na.f_braw = static_cast<const double*>(e->d_nrt_fbraw.p);
   na.f_rep = static_cast<const uint8_t*>(e->d_nrt_frep.p);
   na.pod_items = static_cast<const uint32_t*>(e->d_nrt_items.p);
   na.perm = static_cast<const int32_t*>(e->d_nrt_perm.p);
@@ -345,7 +346,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_raw_row,   &e->d_lv_exact, &e->d_lv_fast, &e->d_tlp_fast, &e->d_commit, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
-                    &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_dist,
+                    &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_dist, &e->d_nrt_fbraw,
                     &e->d_net_region, &e->d_net_zone, &e->d_net_class, &e->d_net_class16, &e->d_net_cls_size, &e->d_net_cls_region, &e->d_net_cls_zone,
                     &e->d_net_rcost, &e->d_net_zcost, &e->d_net_pod_key, &e->d_net_key_flag, &e->d_net_pair_ptr,
                     &e->d_net_pair_node, &e->d_net_pair_max, &e->d_q_pod_ns, &e->d_q_pod_prio, &e->d_q_pod_req, &e->d_q_pod_reqp,
@@ -529,7 +530,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
   {  // float64 formulation: derived columns + precondition check
     const int64_t R = t->n_res;
     std::vector<double> av(static_cast<size_t>(Zm * R * n), -1.0), rcp(static_cast<size_t>(Zm * R * n), spx::kNrtNoCap),
-        cpuv(static_cast<size_t>(Zm * n), 0.0);
+        cpuv(static_cast<size_t>(Zm * n), 0.0), braw(static_cast<size_t>(Zm * n), spx::kNrtNoCap);
     std::vector<uint8_t> rep(static_cast<size_t>((R > 0 ? R : 1) * n), 0);
     bool ok = true;
     for (int64_t i = 0; i < n; ++i) {
@@ -545,6 +546,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
           av[static_cast<size_t>((z * R + r) * n + i)] = static_cast<double>(cap);
           rcp[static_cast<size_t>((z * R + r) * n + i)] = cap_v > 0.0 ? 100.0 / cap_v : spx::kNrtNoCap;
           if (is_cpu) cpuv[static_cast<size_t>(z * n + i)] = cap_v;
+          if (is_cpu && cap > 0) braw[static_cast<size_t>(z * n + i)] = 100.0 / static_cast<double>(cap);
           rep[static_cast<size_t>(r * n + i)] |= static_cast<uint8_t>(1u << z);
         }
       }
@@ -590,6 +592,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
     if ((rc = upload(e, e->d_nrt_fav, av.data(), av.size() * sizeof(double)))) return rc;
     if ((rc = upload(e, e->d_nrt_frc, rcp.data(), rcp.size() * sizeof(double)))) return rc;
     if ((rc = upload(e, e->d_nrt_fcpu, cpuv.data(), cpuv.size() * sizeof(double)))) return rc;
+    if ((rc = upload(e, e->d_nrt_fbraw, braw.data(), braw.size() * sizeof(double)))) return rc;
     if ((rc = upload(e, e->d_nrt_frep, rep.data(), rep.size()))) return rc;
     SPX_HIP(e, hipStreamSynchronize(e->stream));
   }

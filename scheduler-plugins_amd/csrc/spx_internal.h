@@ -121,6 +121,7 @@ struct NrtArgs {
   const double* f_av;            // [Z][n_res][N] reported ? available : -1
   const double* f_rc;            // [Z][n_res][N] RN(100 / Value(capacity)), kNrtNoCap when the capacity is not positive
   const double* f_cpu;           // [Z][N] Value() of the cpu capacity
+  const double* f_braw;          // [Z][N] RN(100 / cpu capacity in millicores), kNrtNoCap when it is not positive
   const uint8_t* f_rep;          // [n_res][N] mask of the zones reporting the resource
   const float* dist;             // [255][N] average distance of every zone subset (Combo8 order), float32 as least_numa.go:140-154
   const int32_t* perm;           // [ceil(N/256)*256] node index per slot, windows of 256 ordered by code path; -1 = empty
