@@ -230,9 +230,9 @@ __constant__ Combo8 kCombo8 = make_combo8();
 // average distance equals the node's minimum for the size (is_min), else the first with the smallest distance.
 // The search runs as ONE wave-uniform loop over the (size, lexicographic) table of 8-position subsets — the generic
 // kernel's per-lane loops made the wave execute the union of all lanes' iterations, each of them divergent; here a
-// subset costs every lane the same ~30 VALU operations (membership as uniform 0/1 multipliers) and the loop ends as
-// soon as every lane has its answer.  Subsets with positions past a node's zone count fail the "every member reports
-// every requested resource" test by themselves.
+// subset costs every lane the same few VALU operations and the loop ends as soon as every lane has its answer.
+// Subsets with positions past a node's zone count fail the "every member reports every requested resource" test by
+// themselves.
 template <int RM>
 __device__ __forceinline__ uint32_t numa_required_fast(const FastNode<RM>& ns, const NrtArgs& a, const Item<RM>& it, int64_t n, bool active,
                                                        bool* is_min) {
@@ -265,6 +265,7 @@ __device__ __forceinline__ uint32_t numa_required_fast(const FastNode<RM>& ns, c
     k_lo = need_k + 1 > k_lo ? (need_k + 1 > kZ ? kZ : need_k + 1) : k_lo;
   }
   const int k_hi = __builtin_popcount(v_all);
+  const uint32_t allrep = v_all;  // zones reporting every requested resource
   for (int k = 1; k <= kZ; ++k) {
     // skip sizes no unfinished lane can use (ballots, not shuffles: part of the wave may be masked off here, and a
     // butterfly reduction through inactive lanes loses values)
@@ -273,36 +274,48 @@ __device__ __forceinline__ uint32_t numa_required_fast(const FastNode<RM>& ns, c
     const float min_avg = a.min_avg[static_cast<int64_t>(k - 1) * a.n_nodes + n];
     uint32_t best = 0;
     float min_distance = 256.0f;
-    const int c1 = kCombo8.start[k];
-    for (int ci = kCombo8.start[k - 1]; ci < c1; ++ci) {
-      const uint32_t m = kCombo8.mask[ci];  // wave-uniform
-      bool ok = !done;
-      // isValidCombineResources: every member reports every requested name
-#pragma unroll
-      for (int r = 0; r < RM; ++r)
-        if ((used >> r) & 1u) ok &= (ns.repmask(r) & m) == m;
-      // combineResources + checkResourcesFit: the members' sum covers every non-zero request
+    // Subsets of size k in lexicographic order = for every (k-1)-prefix in lexicographic order, every last element
+    // above the prefix's highest one, ascending.  The prefix's sums cost R*8 multiply-adds (membership as uniform 0/1
+    // weights) once; each extension by zone j is then one add and one compare per resource with j a compile-time index.
+    int ci = kCombo8.start[k - 1];                                // table index of the next subset (for the distance)
+    const int p0 = k == 1 ? -1 : kCombo8.start[k - 2], p1 = k == 1 ? 0 : kCombo8.start[k - 1];
+    for (int pi = p0; pi < p1; ++pi) {
+      const uint32_t pm = pi < 0 ? 0u : kCombo8.mask[pi];         // wave-uniform prefix (empty for k == 1)
+      const int last = pm ? 31 - __builtin_clz(pm) : -1;
+      if (last >= kZ - 1) continue;                                // nothing above its highest element
+      bool pvalid = !done && (allrep & pm) == pm;                  // isValidCombineResources for the prefix
+      double psum[RM];
       double w[kZ];
 #pragma unroll
-      for (int z = 0; z < kZ; ++z) w[z] = ((m >> z) & 1u) ? 1.0 : 0.0;
+      for (int z = 0; z < kZ; ++z) w[z] = ((pm >> z) & 1u) ? 1.0 : 0.0;
 #pragma unroll
       for (int r = 0; r < RM; ++r) {
+        psum[r] = 0.0;
         if (!((need >> r) & 1u)) continue;
-        double sum = 0.0;
 #pragma unroll
-        for (int z = 0; z < kZ; ++z) sum = __builtin_fma(w[z], ns.av[z][r], sum);
-        ok &= sum >= it.raw[r];
+        for (int z = 0; z < kZ; ++z) psum[r] = __builtin_fma(w[z], ns.av[z][r], psum[r]);
       }
-      if (__ballot(ok) != 0) {
-        const float d = a.dist[static_cast<int64_t>(ci) * a.n_nodes + n];
-        if (ok && d == min_avg) {
-          result = m;
-          hit_min = true;
-          done = true;
-        } else if (ok && d < min_distance) {
-          min_distance = d;
-          best = m;
+#pragma unroll
+      for (int j = 0; j < kZ; ++j) {
+        if (j <= last) continue;                                   // uniform
+        bool ok = pvalid && ((allrep >> j) & 1u);
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+          if ((need >> r) & 1u) ok &= psum[r] + ns.av[j][r] >= it.raw[r];  // combineResources + checkResourcesFit
+        if (__ballot(ok) != 0) {
+          const uint32_t m = pm | (1u << j);
+          const float d = a.dist[static_cast<int64_t>(ci) * a.n_nodes + n];
+          if (ok && d == min_avg) {
+            result = m;
+            hit_min = true;
+            done = true;
+            pvalid = false;
+          } else if (ok && d < min_distance) {
+            min_distance = d;
+            best = m;
+          }
         }
+        ++ci;
       }
     }
     if (!done && best != 0) {
