@@ -8,6 +8,7 @@ pkg/noderesourcetopology/numaresources_test.go:375-462  TestSubstractNUMA
 pkg/noderesourcetopology/pluginhelpers_test.go:29-107   TestOnlyNonNUMAResources
 pkg/noderesourcetopology/nodeconfig/topologymanager_test.go:256-428, :430-498, :500-607
                                               TestConfigFromAttributes / TestConfigFromPolicies / TestConfigFromNRT
+pkg/noderesourcetopology/least_numa_test.go:758-920           TestMinDistance (minAvgDistanceInCombinations, float32)
 pkg/noderesourcetopology/cache/store_test.go:998-1108         TestResourceStoreUpdate
 pkg/noderesourcetopology/cache/overreserve_test.go:292-342    TestGetCachedNRTCopyReserve (topology: cache_test.go:282-309)
 """
@@ -121,4 +122,15 @@ OVER_RESERVE = [
          zones=[(0, {"cpu": "30", "memory": "60Gi", "vendor.com/nic": "16"}), (1, {"cpu": "30", "memory": "60Gi", "vendor.com/nic": "16"})],
          assumed_pods=[[{"cpu": "8", "memory": "16Gi"}]],
          expected=[(0, {"cpu": "22", "memory": "44Gi", "vendor.com/nic": "16"}), (1, {"cpu": "22", "memory": "44Gi", "vendor.com/nic": "16"})]),
+]
+
+# TestMinDistance (least_numa_test.go:758-920): zone cost maps and the minimal average distance per subset size
+# (float32; 255 per missing entry).  The "three numa node" case lists 3 of the 4 subsets; the fourth has the same average.
+MIN_DISTANCE_COSTS = {0: {0: 10, 1: 12, 2: 20, 3: 20}, 1: {0: 12, 1: 10, 2: 20, 3: 20}, 2: {0: 20, 1: 20, 2: 10, 3: 12},
+                      3: {0: 20, 1: 20, 2: 12, 3: 10}}
+MIN_DISTANCE = [  # (line, with costs?, subset size, expected)
+    (820, True, 1, 10.0),
+    (838, True, 2, 11.0),
+    (861, True, 3, 14.888889),
+    (878, False, 2, 255.0),
 ]

@@ -211,3 +211,26 @@ def test_over_reserve_assumed_pods(hdr, oracle, case):
     avail, present = outs[5].reshape(Z, R), outs[4]
     got = [[int(avail[z][r]) if (present[z] >> r) & 1 else -1 for r in range(R)] for z in range(len(case["zones"]))]
     assert got == want
+
+
+@pytest.mark.parametrize("case", G.MIN_DISTANCE, ids=lambda c: f"L{c[0]}")
+def test_min_avg_distance_in_combinations(hdr, case):
+    """the per-node, per-subset-size minimal average distance the LeastNUMANodes kernels compare against
+    (spx_flatten_nrt_nodes' min_avg_dist), float32 like the reference"""
+    import scheduler_plugins_amd as spx
+    from scheduler_plugins_amd._abi import Table
+    _, with_costs, k, want = case
+    res = O.Resources()
+    zones = [{"name": f"node-{i}", "type": "Node", "resources": {"cpu": "4"},
+              "costs": ({f"node-{j}": c for j, c in G.MIN_DISTANCE_COSTS[i].items()} if with_costs else {})} for i in range(4)]
+    nrts = O.build_nrt_objects(hdr, res, [O.nrt(zones, ["SingleNUMANodePodLevel"])])
+    nodes = O.build_node_objects(hdr, res, [O.node_from_zones(zones)])
+    slot_res = np.zeros(8, np.int32)
+    slot_res[0] = res.id("cpu")
+    slots = Table(hdr, "spx_nrt_slots", n_res=1, slot_res=slot_res, slot_flags=np.zeros(8, np.uint8), slot_weight=np.ones(8, np.int64))
+    Z = hdr.consts["SPX_NRT_MAX_ZONES"]
+    outs = [np.zeros(1, np.uint8), np.zeros(1, np.int32), np.zeros(1, np.uint8), np.zeros(Z, np.uint8), np.zeros(Z, np.uint8),
+            np.zeros(Z, np.int64), np.zeros(Z * Z, np.int32), np.zeros(Z, np.float32), np.zeros(1, np.uint8)]
+    fn = spx.lib().spx_flatten_nrt_nodes
+    assert fn(nodes.ref(), nrts.ref(), slots.ref(), *[o.ctypes.data_as(t) for o, t in zip(outs, fn.argtypes[3:])]) == 0
+    assert outs[7][k - 1] == np.float32(want)
