@@ -309,123 +309,13 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_trimaran(TrimaranArgs
 }
 
 // ------------------------------------------------------------------------------------------------
-// TargetLoadPacking fast path (bit-exact by construction).
+// TargetLoadPacking fast path (bit-exact by construction): float32 per cell, float64 only where it is needed.
 //
-// The exact expression costs two float64 divisions per (pod,node) and makes the sweep VALU-bound at
-// ~2 ms for 10^9 evals, 6x the HBM floor.  The result however is a small integer, round(g(pred)),
-// with g piecewise linear — so a cheaper evaluation x' of the same real number decides the SAME
-// integer whenever x' is not within its error bound of a rounding tie or of the pred == T branch
-// point.  Per node two doubles stay resident (base = util_millis + missing, k = 100/cap):
-//     pred' = (base + pod) * k                |pred' - pred| <= 4 ulp(pred)   (< 1e-12 for pred < 1e3)
-//     x'    = pred' > T ? c1*(100 - pred') : c2*pred' + T          c1 = T/(100-T), c2 = (100-T)/T
-//     score = max(int(rint(x')), 0)           (pred > 100 makes x' < 0 -> 0, as the reference's early return)
-// A lane whose x' lies within kTol of a half-integer, or whose pred' lies within kTol of T, is
-// "ambiguous": it re-reads the node's original columns and recomputes with the reference's exact
-// operation sequence (tlp_unrounded above).  kTol = 1e-9 is >1000x the worst-case error for
-// 1 <= T <= 99 (|x'-x| <= (1+99)*1e-12), so a non-ambiguous lane provably equals the exact result;
-// negative or non-finite inputs poison (base,k) with NaN and always take the exact path.
-// With real-valued utilisation the ambiguous fraction is ~1e-9; with "round" inputs (idle nodes,
-// pod == 0.4*cap) it is whatever it is — only speed changes, never the result.
-constexpr double kTol = 1e-9;
-
-template <int NPL, bool A>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast(TrimaranArgs a, int n_tiles, double c1, double c2) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
-  const int tile = static_cast<int>(unit % n_tiles);
-  const int64_t chunk = unit / n_tiles;
-  const int64_t pod0 = a.row_begin + chunk * kPodsPerChunk;
-  if (pod0 >= a.row_end) return;
-  const int64_t pod1 = (pod0 + kPodsPerChunk < a.row_end) ? pod0 + kPodsPerChunk : a.row_end;
-  const int64_t node0 = (static_cast<int64_t>(tile) * kWave + lane) * NPL;
-  if (node0 >= a.row_stride) return;
-
-  uint32_t alloc_w[NPL / 4];
-  double base[NPL], kk[NPL];
-  if constexpr (A) {
-#pragma unroll
-    for (int j = 0; j < NPL / 4; ++j) alloc_w[j] = reinterpret_cast<const uint32_t*>(a.alloc_norm + node0)[j];
-  }
-#pragma unroll
-  for (int j = 0; j < NPL; ++j) {
-    const int64_t n = node0 + j;
-    const bool in = n < a.n_nodes;
-    double b = 1e300, k = 1.0;  // invalid / padding: pred' huge -> x' << 0 -> score 0, never ambiguous
-    if (in && a.tlp_valid[n] != 0) {
-      const double cap = static_cast<double>(a.cap_cpu_milli[n]);
-      const double um = (a.tlp_cpu_util[n] / 100.0) * cap;
-      const double miss = static_cast<double>(a.tlp_missing_milli[n]);
-      if (cap == 0.0) {
-        b = 0.0;  // reference leaves predicted at 0 (targetloadpacking.go:171)
-        k = 0.0;
-      } else if (!(um >= 0.0) || !(miss >= 0.0) || !(cap > 0.0) || !(um < 1e15) || !(miss < 1e15)) {
-        b = __builtin_nan("");
-        k = __builtin_nan("");
-      } else {
-        b = um + miss;
-        k = 100.0 / cap;
-      }
-    }
-    base[j] = b;
-    kk[j] = k;
-  }
-  const double t = a.tlp_target;
-  const double off1 = 100.0 * c1;
-  constexpr double kHalf = 0.5 - kTol;
-
-  for (int64_t pod = pod0; pod < pod1; ++pod) {
-    const int64_t row = pod * a.row_stride + node0;
-    if constexpr (A) store_bytes<NPL>(a.out_alloc + row, alloc_w);
-    const double pod_milli = static_cast<double>(a.tlp_pod_milli[pod]);
-    bool any = !(pod_milli >= 0.0) || !(pod_milli < 1e15);
-    uint32_t w[NPL / 4];
-#pragma unroll
-    for (int j = 0; j < NPL / 4; ++j) {
-      uint32_t acc = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = j * 4 + q;
-        const double pred = (base[i] + pod_milli) * kk[i];
-        const bool gt = pred > t;
-        const double x = __builtin_fma(gt ? -c1 : c2, pred, gt ? off1 : t);
-        const double r = __builtin_rint(x);
-        const double d = x - r;
-        any |= !(__builtin_fabs(d) < kHalf) || !(__builtin_fabs(pred - t) > kTol);
-        int sc = static_cast<int>(r);
-        sc = sc < 0 ? 0 : sc;
-        acc |= static_cast<uint32_t>(sc) << (8 * q);
-      }
-      w[j] = acc;
-    }
-    if (__builtin_expect(any, 0)) {
-      // exact re-evaluation of this lane's NPL cells from the original node columns (rare)
-#pragma unroll 1
-      for (int i = 0; i < NPL; ++i) {
-        const int64_t n = node0 + i;
-        uint32_t b = 0;
-        if (n < a.n_nodes) {
-          TlpNode tn;
-          tn.cap = static_cast<double>(a.cap_cpu_milli[n]);
-          tn.util_millis = (a.tlp_cpu_util[n] / 100.0) * tn.cap;
-          tn.missing = static_cast<double>(a.tlp_missing_milli[n]);
-          tn.valid = a.tlp_valid[n] != 0;
-          bool zero;
-          const double x = tlp_unrounded(tn, pod_milli, t, &zero);
-          b = zero ? 0u : to_u8(x);
-        }
-        const int sh = (i & 3) * 8;
-        const uint32_t keep = ~(0xffu << sh);
-#pragma unroll
-        for (int j = 0; j < NPL / 4; ++j) w[j] = ((i >> 2) == j) ? ((w[j] & keep) | (b << sh)) : w[j];
-      }
-    }
-    store_bytes<NPL>(a.out_tlp + row, w);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// TargetLoadPacking fast path, second form: float64 only where the magnitude needs it.
+// The exact expression costs two float64 divisions per (pod,node) and makes the sweep VALU-bound at ~2 ms for 10^9
+// evals.  The result however is a small integer, round(g(pred)), with g piecewise linear — so a cheaper evaluation x' of
+// the same real number decides the SAME integer whenever x' is not within its error bound of a rounding tie or of the
+// pred == T branch point; cells that are ("ambiguous") re-read the node's original columns and recompute with the
+// reference's exact operation sequence (tlp_unrounded above).  Only speed depends on how many cells are ambiguous.
 //
 // With u = (util_millis + missing - T*cap/100) + pod   [millicores above the target line]
 //      pred - T = k*u,  k = 100/cap, and the reference's two branches become
@@ -1097,14 +987,6 @@ void launch_tlp_fast(const TrimaranArgs& a, hipStream_t s) {
   const unsigned blocks = static_cast<unsigned>((chunks * n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
   const double t = a.tlp_target;
   const double c1 = t / (100.0 - t), c2 = (100.0 - t) / t;
-  static const bool v1 = getenv("SPX_TLP_FAST1") != nullptr;
-  if (v1) {
-    if (a.out_alloc)
-      hipLaunchKernelGGL((k_tlp_fast<NPL, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2);
-    else
-      hipLaunchKernelGGL((k_tlp_fast<NPL, false>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2);
-    return;
-  }
   const int64_t n_slots = static_cast<int64_t>(n_tiles) * tile_nodes;
   hipLaunchKernelGGL(k_tlp_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots, c1, c2);
   if (a.out_alloc)
