@@ -519,7 +519,8 @@ int spx_fetch_best(spx_engine* e, int64_t row_begin, int64_t row_end, int32_t* n
  * (pkg/trimaran/handler.go:131-139 feeding targetloadpacking.go:151-168).  Per pod: the node with the highest
  * sum of plugin_weight x score (lowest index among ties; upstream's selectHost draws among them), that sum, and the size
  * of the tie set (NULL = not wanted).  tlp_missing_out (NULL = not wanted) receives the per-node missing utilisation after
- * the last commit.  The engine's uploaded tables and result tables are left untouched.  Synchronous. */
+ * the last commit.  The engine's uploaded tables are left untouched; with LVRB in the mask its score table is (re)evaluated
+ * for the row range first (LVRB carries no commit state, so the loop reads those rows).  Synchronous. */
 int spx_commit_sequential(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end, int32_t* node_idx, int64_t* weighted_score, int32_t* n_ties, int64_t* tlp_missing_out);
 
 /* duration in ms of the last spx_eval's kernels measured with HIP events on the engine stream */

@@ -734,6 +734,9 @@ __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c
   const int lane = tid & (kWave - 1), wave = tid >> 6;
   const bool A = c.use_mask & 1u, T = c.use_mask & 2u, L = kHasL && (c.use_mask & 4u);
   constexpr int KR = K > 0 ? K : 1;
+  static_assert(K % 4 == 0, "K > 0: cells come in groups of 4 consecutive nodes (one dword of a uint8 table row)");
+  // cell k of a thread = node ((k / 4) * kCommitThreads + tid) * 4 + k % 4
+  auto node_of = [&](int k) -> int64_t { return (static_cast<int64_t>(k >> 2) * kCommitThreads + tid) * 4 + (k & 3); };
   if (tid < 2) s_tie[tid] = 0;
   __syncthreads();
   const double t = a.tlp_target;
@@ -744,7 +747,7 @@ __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c
   if constexpr (K > 0) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const int64_t n = static_cast<int64_t>(k) * kCommitThreads + tid;
+      const int64_t n = node_of(k);
       const bool in = n < a.n_nodes;
       r_k[k] = (in && T) ? tlp_fast_consts(static_cast<double>(a.cap_cpu_milli[n]), a.tlp_cpu_util[n], static_cast<double>(c.missing[n]),
                                            a.tlp_valid[n] != 0, t, c1, c2)
@@ -755,13 +758,19 @@ __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c
   }
   constexpr float kHalf = 0.5f - kTol32;
   const float tf = static_cast<float>(t);
+  uint32_t lv_next[KR / 4 > 0 ? KR / 4 : 1] = {};
+  if constexpr (K > 0 && kHasL) {
+#pragma unroll
+    for (int g = 0; g < K / 4; ++g) {
+      const int64_t n0 = (static_cast<int64_t>(g) * kCommitThreads + tid) * 4;
+      lv_next[g] = (n0 < a.row_stride && a.row_begin < a.row_end) ? *reinterpret_cast<const uint32_t*>(c.lv_table + a.row_begin * a.row_stride + n0) : 0u;
+    }
+  }
   for (int64_t pod = a.row_begin; pod < a.row_end; ++pod) {
     const int64_t pod_i = T ? a.tlp_pod_milli[pod] : 0;
     const double pod_milli = static_cast<double>(pod_i);
     const bool pod_bad = pod_i < 0 || pod_i >= (1 << 23);  // not exact as a float32 integer: exact path for the row
     const float pod_f = static_cast<float>(pod_i);
-    const double req_cpu = L ? fmax(static_cast<double>(a.lv_req_cpu_milli[pod]), 0.0) : 0.0;
-    const double req_mem = L ? fmax(static_cast<double>(a.lv_req_mem[pod]) * kMega, 0.0) : 0.0;
     int64_t best = INT64_MIN;
     int best_n = INT32_MAX, ties = 0;
     auto exact_tlp = [&](int64_t n) -> uint32_t {
@@ -778,13 +787,7 @@ __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c
       int64_t total = 0;
       if (A) total += c.w_alloc * static_cast<int64_t>(alloc_byte);
       if (T) total += c.w_tlp * static_cast<int64_t>(tlp_byte);
-      if (L) {
-        const double* o = a.lv_exact + n * 8;
-        const int ms = static_cast<int>(o[7]);
-        const LvRes cr{o[0], o[1], o[2], static_cast<int>(o[3])};
-        const LvRes mr{o[4], o[5], o[6], ms & 7};
-        total += c.w_lvrb * static_cast<int64_t>(to_u8(lv_total((ms & 8) != 0, cr, mr, req_cpu, req_mem)));
-      }
+      if (L) total += c.w_lvrb * static_cast<int64_t>(c.lv_table[pod * a.row_stride + n]);
       if (total > best) {  // a thread walks its nodes in increasing order: `>` keeps the lowest index among equals
         best = total;
         best_n = static_cast<int>(n);
@@ -798,9 +801,22 @@ __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c
       // totals fit 18 bits here (launch condition): 32-bit arithmetic, Allocatable's share folded into a per-node base;
       // ambiguous cells (and every cell of a pod that is not a float32 integer) take the reference's float64 sequence
       const uint32_t wt = static_cast<uint32_t>(c.w_tlp), wl = static_cast<uint32_t>(c.w_lvrb);
+      // LVRB carries no commit state: its frozen-snapshot rows (evaluated by the sweep just before this loop) stay valid.
+      // One dword per group of 4 nodes; the next pod's dwords are requested now and used in the next iteration, so the
+      // HBM latency of a row that no cache holds yet is off the dependent chain.
+      uint32_t lv_now[KR / 4 > 0 ? KR / 4 : 1];
+      if constexpr (kHasL) {
+#pragma unroll
+        for (int g = 0; g < K / 4; ++g) {
+          lv_now[g] = lv_next[g];
+          const int64_t n0 = (static_cast<int64_t>(g) * kCommitThreads + tid) * 4;
+          const int64_t np = pod + 1 < a.row_end ? pod + 1 : pod;
+          lv_next[g] = n0 < a.row_stride ? *reinterpret_cast<const uint32_t*>(c.lv_table + np * a.row_stride + n0) : 0u;
+        }
+      }
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const int64_t n = static_cast<int64_t>(k) * kCommitThreads + tid;
+        const int64_t n = node_of(k);
         if (!(r_flags[k] & 2u)) continue;
         uint32_t tot = r_flags[k] >> 8;  // w_alloc * Allocatable's normalised score
         if (T) {
@@ -812,13 +828,7 @@ __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c
           const uint32_t tb = amb ? exact_tlp(n) : (__builtin_amdgcn_cvt_pk_u8_f32(rr, 0, 0u) & 0xffu);
           tot += wt * tb;
         }
-        if constexpr (kHasL) {
-          const double* o = a.lv_exact + n * 8;
-          const int ms = static_cast<int>(o[7]);
-          const LvRes cr{o[0], o[1], o[2], static_cast<int>(o[3])};
-          const LvRes mr{o[4], o[5], o[6], ms & 7};
-          tot += wl * to_u8(lv_total((ms & 8) != 0, cr, mr, req_cpu, req_mem));
-        }
+        if constexpr (kHasL) tot += wl * ((lv_now[k >> 2] >> (8 * (k & 3))) & 0xffu);
         const uint32_t key = (tot << 14) | (16383u - static_cast<uint32_t>(n));
         kmax = key > kmax ? key : kmax;
         if constexpr (kTies) {
@@ -861,11 +871,11 @@ __global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c
       }
       // the winner's owner advances the column (only it ever reads that entry again) and shifts the node's constants: the
       // real number b2h + b2l grows by exactly the pod's integer millicores, which tracks the float64 b within ~1e-10
-      if (T && win >= 0 && (win % kCommitThreads) == tid) {
+      if (T && win >= 0 && ((win >> 2) % kCommitThreads) == tid) {
         c.missing[win] += pod_i;
 #pragma unroll
         for (int k = 0; k < K; ++k)
-          if (win / kCommitThreads == k) {
+          if (((win >> 2) / kCommitThreads) * 4 + (win & 3) == k) {
             const float nb = r_k[k].x + pod_f;
             r_k[k].x = (pod_bad || !(__builtin_fabsf(nb) < 8388607.0f)) ? __builtin_nanf("") : nb;
           }
@@ -1041,8 +1051,6 @@ void launch_trimaran(const TrimaranArgs& a, hipStream_t s) {
 
 void launch_commit_trimaran(const CommitArgs& c, hipStream_t s) {
   if (c.t.row_end <= c.t.row_begin) return;
-  if (c.use_mask & 4u)  // the exact per-node LVRB state the loop reads
-    hipLaunchKernelGGL(k_lvrb_prepare, dim3(static_cast<unsigned>((c.t.n_nodes + 255) / 256)), dim3(256), 0, s, c.t);
   const bool from_memory = getenv("SPX_COMMIT_FROM_MEMORY") != nullptr;  // differential tests (read per launch)
   const bool key_fits = c.w_alloc >= 0 && c.w_tlp >= 0 && c.w_lvrb >= 0 && (c.w_alloc + c.w_tlp + c.w_lvrb) * 255 < (int64_t{1} << 18);
   if (!from_memory && key_fits && c.t.n_nodes <= 20 * 512) {

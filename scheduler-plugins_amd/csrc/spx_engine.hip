@@ -997,9 +997,10 @@ int spx_commit_sequential(spx_engine* e, uint32_t plugin_mask, int64_t row_begin
   fill_trimaran(e, c.t);
   c.t.row_begin = row_begin;
   c.t.row_end = row_end;
-  if (L) {
-    if ((rc = ensure(e, e->d_lv_exact, N * 8 * sizeof(double)))) return rc;
-    c.t.lv_exact = static_cast<double*>(e->d_lv_exact.p);
+  if (L) {  // LVRB has no commit state: sweep its rows once (the engine's LVRB table is (re)written for this row range)
+    if ((rc = spx_eval(e, 1u << SPX_PLUGIN_LVRB, row_begin, row_end))) return rc;
+    c.lv_table = static_cast<const uint8_t*>(e->score[SPX_PLUGIN_LVRB].p);
+    if (e->score_stride[SPX_PLUGIN_LVRB] != e->row_stride) return fail(e, SPX_ERR_STATE, "bound LVRB table must use the engine row stride");
   }
   c.use_mask = (A ? 1u : 0u) | (T ? 2u : 0u) | (L ? 4u : 0u);
   c.w_alloc = e->plugin_weight[SPX_PLUGIN_ALLOCATABLE];

@@ -69,9 +69,10 @@ struct TrimaranArgs {
 void launch_trimaran(const TrimaranArgs& a, hipStream_t s);
 // sequential commit loop over pod rows [t.row_begin, t.row_end) for Allocatable (bit 0) / TLP (bit 1) / LVRB (bit 2)
 struct CommitArgs {
-  TrimaranArgs t;       // inputs; alloc_norm must be prepared, lv_exact allocated when LVRB takes part
+  TrimaranArgs t;       // inputs; alloc_norm must be prepared
   uint32_t use_mask;
   int64_t w_alloc, w_tlp, w_lvrb;
+  const uint8_t* lv_table;  // LVRB's score table [pods][row_stride], evaluated for the rows beforehand (LVRB has no commit state)
   int64_t* missing;     // [n_nodes] mutable copy of tlp_missing_milli: advances with every commit
   int32_t* out_node;    // [rows]
   int64_t* out_score;
