@@ -447,6 +447,31 @@ typedef struct spx_quota_soa {
 
 /* ------------------------------------------------------------------ engine */
 
+/* What each entry point stands in for in the reference (sigs.k8s.io/scheduler-plugins; the Go method keeps its
+ * signature and becomes an index into a fetched row — INTEGRATION.md shows the cgo side):
+ *
+ *   spx_eval + spx_fetch_scores(ALLOCATABLE)   Allocatable.Score + NormalizeScore      pkg/noderesources/allocatable.go:63-71, :143-168
+ *   spx_fetch_raw(ALLOCATABLE)                 Allocatable.Score (raw int64)           pkg/noderesources/allocatable.go:117-140
+ *   spx_eval + spx_fetch_scores(TLP)           TargetLoadPacking.Score                 pkg/trimaran/targetloadpacking/targetloadpacking.go:107-187
+ *   spx_eval + spx_fetch_scores(LVRB)          LoadVariationRiskBalancing.Score        pkg/trimaran/loadvariationriskbalancing/loadvariationriskbalancing.go:84-122
+ *   spx_eval + spx_fetch_status(NRT)           TopologyMatch.Filter                    pkg/noderesourcetopology/filter.go:179-245
+ *   spx_eval + spx_fetch_scores(NRT)           TopologyMatch.Score                     pkg/noderesourcetopology/score.go:62-102
+ *   spx_eval + spx_fetch_status(NETOVERHEAD)   NetworkOverhead.PreFilter + Filter      pkg/networkaware/networkoverhead/networkoverhead.go:174-298, :326-359
+ *   spx_fetch_raw(NETOVERHEAD, cost/sat/vio)   NetworkOverhead.Score, PreFilterState   networkoverhead.go:362-386, :85-115
+ *   spx_eval + spx_fetch_scores(NETOVERHEAD)   NetworkOverhead.NormalizeScore          networkoverhead.go:389-418
+ *   spx_eval + spx_fetch_prefilter(CAPACITY)   CapacityScheduling.PreFilter            pkg/capacityscheduling/capacity_scheduling.go:208-283
+ *   spx_flatten_net_keys + spx_toposort_less   TopologicalSort.Less, FindPodOrder      pkg/networkaware/topologicalsort/topologicalsort.go:102-132, util/util.go:138-153
+ *   spx_flatten_trimaran_*                     GetNodeMetrics / ScheduledPodsCache / PredictUtilisation / GetResourceRequested
+ *                                              pkg/trimaran/collector.go:110-123, handler.go:47-58, targetloadpacking.go:198-205, resourcestats.go:45-146
+ *   spx_flatten_nrt_*                          createNUMANodeList / TopologyManagerFromNodeResourceTopology / GetPodEffectiveRequest / OverReserve
+ *                                              pkg/noderesourcetopology/pluginhelpers.go:105-173, nodeconfig/topologymanager.go:78-162, pkg/util/resource.go:51-85, cache/store.go:315-356
+ *   spx_flatten_net_topo                       populateCostMap                         networkoverhead.go:448-497
+ *   spx_flatten_quota                          ElasticQuotaInfos (used / min / max, nominated pods)   pkg/capacityscheduling/elasticquota.go:48-123
+ *   spx_eval_best + spx_fetch_best             upstream prioritizeNodes + selectHost input (sum of weight x score over feasible nodes)
+ *   spx_commit_sequential                      upstream scheduleOne repeated over the queue, with trimaran's bind-time bookkeeping
+ *                                              pkg/trimaran/handler.go:131-139, targetloadpacking.go:151-168
+ */
+
 typedef struct spx_engine spx_engine;
 
 /* create an engine on HIP device `device_id`; fails with SPX_ERR_NOGPU when no device exists
