@@ -177,6 +177,15 @@ def main() -> None:
     torch.cuda.set_stream(tstream)
     e.set_stream(tstream.cuda_stream)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # bring the device out of its idle clocks with unrelated work (not steps of the workload): a fresh box runs its first
+    # ~50 ms of kernels at low clocks, which would otherwise dominate short --steps runs
+    spin = torch.empty(64 << 20, dtype=torch.float32, device=f"cuda:{local_rank}")
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.15:
+        for _ in range(8):
+            spin.mul_(1.0001)
+        torch.cuda.synchronize()
+    del spin
     for _ in range(args.warmup):
         e.eval(mask)
     e.sync()
