@@ -1,0 +1,168 @@
+"""The exactness claims the fast kernels rest on, checked on the CPU with exact rational arithmetic
+and with numpy's IEEE float32/float64 — independent of any GPU run:
+
+  * k_nrt_fast / k_alloc_masked: floor(num / c) computed as floor of ONE float64 product with a biased multiplier,
+    for integers below 2^42 and quotients <= 100 (LeastAllocated, MostAllocated, the weighted mean, the masked normalisation);
+  * k_nrt_fast MostAllocated: "request <= capacity" read off the same kind of product;
+  * k_tlp_fast2 / k_commit_trimaran: the float32 TLP formula with its ambiguity test never disagrees with the float64
+    reference sequence on a cell it does not flag;
+  * k_lvrb_fast: the same for the float32 LVRB formula.
+"""
+import math
+from fractions import Fraction
+
+import numpy as np
+
+LIM = 1 << 42
+
+
+def rn(x: Fraction) -> float:
+    """round-to-nearest-even float64 of an exact rational (CPython's Fraction -> float conversion is correctly rounded)"""
+    return float(x)
+
+
+def fma(a: float, b: float, c: float) -> float:
+    return rn(Fraction(a) * Fraction(b) + Fraction(c))
+
+
+def _capacities(rng, n):
+    c = np.concatenate([rng.integers(1, 200, n // 4), rng.integers(1, 1 << 20, n // 4), (1 << rng.integers(1, 42, n // 4)) + rng.integers(-3, 4, n // 4),
+                        LIM - 1 - rng.integers(0, 1000, n - 3 * (n // 4))])
+    return [int(x) for x in np.clip(c, 1, LIM - 1)]
+
+
+def _requests_near_boundaries(c, rng):
+    """requests whose quotient (c - v) * 100 / c or v * 100 / c sits on or next to an integer, plus the ends and randoms"""
+    out = {0, 1, c - 1, c, c + 1, c + 2, 2 * c}
+    for q in list(range(0, 101, 7)) + [99, 100]:
+        base = (q * c) // 100
+        out.update({base - 1, base, base + 1, -(-q * c // 100)})
+    out.update(int(x) for x in rng.integers(0, c + 1, 6))
+    return sorted(v for v in out if 0 <= v < LIM)
+
+
+def test_least_allocated_single_product_floor():
+    rng = np.random.default_rng(1)
+    bias = 100.0 + 2.0 ** -43
+    for c in _capacities(rng, 1600):
+        b = rn(Fraction(100, c))
+        for v in _requests_near_boundaries(c, rng):
+            t = fma(-float(v), b, bias)
+            got = max(math.floor(t), 0)
+            want = ((c - v) * 100) // c if v <= c else 0  # least_allocated.go:46-54: request > capacity scores 0
+            assert got == want, (c, v, t)
+
+
+def test_most_allocated_single_product_floor_and_fit_test():
+    rng = np.random.default_rng(2)
+    thr = 100.0 * (1.0 + 2.0 ** -48)
+    one_eps = 1.0 + 2.0 ** -49
+    for c in _capacities(rng, 1600):
+        b = rn(Fraction(100, c))
+        for v in _requests_near_boundaries(c, rng):
+            tp = float(v) * one_eps  # one rounding
+            tp = tp * b              # second rounding
+            assert (tp <= thr) == (v <= c), (c, v, tp)
+            if v <= c:
+                assert math.floor(tp) == (v * 100) // c, (c, v, tp)
+
+
+def test_weighted_mean_and_masked_normalisation_single_product_floor():
+    rng = np.random.default_rng(3)
+    one_eps = 1.0 + 2.0 ** -49
+    for w in [1, 2, 3, 7, 10, 1000, (1 << 30) + 1, (LIM // 128) - 1] + [int(x) for x in rng.integers(1, LIM // 128, 200)]:
+        wrc = (1.0 / w) * one_eps  # nrt_biased_rcp: RN(RN(1/w) * (1 + 2^-49))
+        for acc in {0, w - 1, w, w + 1, 50 * w, 100 * w - 1, 100 * w} | {int(x) for x in rng.integers(0, 100 * w + 1, 8)}:
+            assert math.floor(float(acc) * wrc) == acc // w, (w, acc)
+    for rng_ in [1, 2, 99, 100, 101, (1 << 32) - 1, LIM - 1] + [int(x) for x in rng.integers(1, LIM, 400)]:
+        b = (100.0 / rng_) * one_eps  # k_alloc_masked: (100.0 / range) * (1 + 2^-49)
+        for d in {0, 1, rng_ - 1, rng_} | {(q * rng_) // 100 + k for q in range(0, 101, 9) for k in (-1, 0, 1)} | {int(x) for x in rng.integers(0, rng_ + 1, 6)}:
+            if 0 <= d <= rng_:
+                assert math.floor(float(d) * b) == (d * 100) // rng_, (rng_, d)
+
+
+def _f32(x):
+    return np.asarray(x, dtype=np.float32)
+
+
+def test_tlp_float32_formula_never_disagrees_unflagged():
+    """numpy model of k_tlp_fast2's per-cell arithmetic (float32 adds / fma / rint, the same constants) against the
+    reference's float64 sequence (targetloadpacking.go:170-184) on 4e6 cells, continuous and integer-valued inputs"""
+    rng = np.random.default_rng(4)
+    n = 4_000_000
+    t = 40.0
+    c1, c2 = t / (100.0 - t), (100.0 - t) / t
+    cap = rng.choice(np.array([2000, 8000, 16000, 64000, 128000], dtype=np.float64), n)
+    util = np.where(rng.random(n) < 0.3, rng.integers(0, 100, n).astype(np.float64), rng.uniform(0, 100, n))
+    missing = np.where(rng.random(n) < 0.5, 0.0, rng.integers(0, 4000, n).astype(np.float64))
+    pod = rng.integers(0, 12000, n).astype(np.float64)
+    # boundary stress: pods that land exactly on the target line of their node
+    on_line = rng.random(n) < 0.05
+    pod = np.where(on_line, np.floor(np.maximum(t * cap / 100.0 - (util / 100.0) * cap - missing, 0.0)), pod)
+    um = (util / 100.0) * cap
+    # ---- reference (float64, operation for operation)
+    pred = 100.0 * ((um + pod) + missing) / cap
+    x = np.where(pred > t, t * (100.0 - pred) / (100.0 - t), (100.0 - t) * pred / t + t)
+    want = np.where(pred > 100.0, 0, np.floor(np.abs(x) + 0.5) * np.sign(x)).astype(np.int64)  # math.Round: half away from zero
+    want = np.clip(want, 0, 255)
+    # ---- fast path (k_tlp_prepare_fast + k_tlp_fast2)
+    k = 100.0 / cap
+    b = (um + missing) - t * cap / 100.0
+    bh = np.rint(b)
+    b2h, b2l = _f32(bh), _f32(b - bh)
+    kc1, kc2 = _f32(-c1 * k), _f32(c2 * k)
+    pod_f = _f32(pod)
+    u = (pod_f + b2h) + b2l  # float32 adds
+    gt = u > 0
+    coef, off = np.where(gt, kc1, kc2), np.where(gt, _f32(t), _f32(100.0))
+    xf = _f32(coef.astype(np.float64) * u.astype(np.float64) + off.astype(np.float64))  # fma: exact product and sum in f64, one f32 rounding
+    rr = np.rint(xf)
+    amb = ~(np.abs(xf - rr) < np.float32(0.5) - np.float32(4e-5)) | ~(np.abs(u) > np.float32(1e-6))
+    got = np.clip(rr, 0, 255).astype(np.int64)  # v_cvt_pk_u8_f32 saturates
+    bad = (~amb) & (got != want)
+    assert not bad.any(), (int(bad.sum()), np.flatnonzero(bad)[:5])
+    assert amb.mean() < 0.08  # the stress inputs make ties common; on continuous inputs it is ~1e-4
+    cont = ~on_line & (util != np.floor(util))
+    assert amb[cont].mean() < 5e-4
+
+
+def test_lvrb_float32_formula_never_disagrees_unflagged():
+    """numpy model of k_lvrb_fast's per-cell arithmetic against lv_total's float64 sequence (analysis.go:34-60,
+    loadvariationriskbalancing.go:104-118) for regular resources (margin 1, sensitivity 1)"""
+    rng = np.random.default_rng(5)
+    n = 2_000_000
+    cap_c = rng.choice(np.array([2000, 8000, 64000, 128000], dtype=np.float64), n)
+    cap_m = rng.choice(np.array([16, 64, 256, 1024], dtype=np.float64), n) * 1024.0  # MiB
+    avg_c, sd_c = rng.uniform(0, 100, n), rng.uniform(0, 40, n)
+    avg_m, sd_m = np.where(rng.random(n) < 0.3, rng.integers(0, 100, n).astype(np.float64), rng.uniform(0, 100, n)), rng.uniform(0, 40, n)
+    req_c = rng.integers(0, 9000, n).astype(np.float64)
+    req_m = rng.integers(0, 40000, n).astype(np.float64)
+
+    def exact(cap, avg, sd, req):
+        used_avg = np.clip(avg * cap / 100.0, 0.0, cap)
+        sigma = np.clip(np.clip(sd * cap / 100.0, 0.0, cap) / cap, 0.0, 1.0)  # pow(sigma, 1/1) == sigma, margin 1
+        mu = np.clip((used_avg + req) / cap, 0.0, 1.0)
+        return (1.0 - (mu + sigma) / 2.0) * 100.0, used_avg, sigma
+
+    xc, ua_c, sg_c = exact(cap_c, avg_c, sd_c, req_c)
+    xm, ua_m, sg_m = exact(cap_m, avg_m, sd_m, req_m)
+    xr = np.minimum(xm, xc)  # both resources valid -> min
+    want = np.clip(np.floor(xr + 0.5), 0, 255).astype(np.int64)
+
+    def fast(cap, used_avg, sigma, req):
+        bq = 50.0 / cap
+        fa, fb, fc = _f32(100.0 - 50.0 * sigma), _f32(bq), _f32(bq * used_avg)
+        tt = _f32(fb.astype(np.float64) * _f32(req).astype(np.float64) + fc.astype(np.float64))
+        cl = np.clip(tt, np.float32(0), np.float32(50))
+        return _f32(cl.astype(np.float64) * -1.0 * -1.0 * -1.0 + fa.astype(np.float64))  # y = s*(A - clamp) with s = -1 folded below
+
+    # s = -1 (both valid): y_r = -(A_r - clamp_r); x = -max(y_c, y_m)
+    yc = -fast(cap_c, ua_c, sg_c, req_c)
+    ym = -fast(cap_m, ua_m, sg_m, req_m)
+    y = np.maximum(yc, ym)
+    ry = np.rint(y)
+    amb = ~(np.abs(y - ry) < np.float32(0.5) - np.float32(6e-5))
+    got = np.clip(-ry, 0, 255).astype(np.int64)
+    bad = (~amb) & (got != want)
+    assert not bad.any(), (int(bad.sum()), np.flatnonzero(bad)[:5])
+    assert amb.mean() < 0.02
