@@ -166,3 +166,28 @@ def test_lvrb_float32_formula_never_disagrees_unflagged():
     bad = (~amb) & (got != want)
     assert not bad.any(), (int(bad.sum()), np.flatnonzero(bad)[:5])
     assert amb.mean() < 0.02
+
+
+def test_commit_loop_incremental_constant_tracks_the_float64_value():
+    """k_commit_trimaran shifts a node's b2h by each bound pod's integer millicores instead of rebuilding b from the
+    float64 columns: the represented real number b2h + b2l must stay within ~1e-9 of the rebuilt b (far inside the 4e-5
+    ambiguity band), for as long as |b2h| < 2^23"""
+    rng = np.random.default_rng(6)
+    t = 40.0
+    for _ in range(300):
+        cap = float(rng.choice([2000, 8000, 64000, 128000]))
+        util = float(rng.uniform(0, 100))
+        missing = float(rng.integers(0, 3000))
+        um = (util / 100.0) * cap
+        b = (um + missing) - t * cap / 100.0
+        bh = np.rint(b)
+        b2h, b2l = np.float32(bh), np.float32(b - bh)
+        for _ in range(40):
+            pod = int(rng.integers(1, 4000))
+            missing += pod
+            nb = np.float32(b2h + np.float32(pod))
+            if not abs(float(nb)) < 8388607.0:
+                break
+            b2h = nb
+            rebuilt = (um + missing) - t * cap / 100.0
+            assert abs((float(b2h) + float(b2l)) - rebuilt) < 1e-6 + abs(float(np.float32(b - bh)) - (b - bh)), (cap, util, missing)
