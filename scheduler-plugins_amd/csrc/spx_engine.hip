@@ -136,7 +136,7 @@ int ensure(spx_engine* e, DevBuf& b, size_t bytes) {
 }
 
 int upload(spx_engine* e, DevBuf& b, const void* src, size_t bytes) {
-  if (!src) return fail(e, SPX_ERR_ARG, "NULL column in table");
+  if (!src && bytes) return fail(e, SPX_ERR_ARG, "NULL column in table");  // an empty column (e.g. no resource slots) may be NULL
   int rc = ensure(e, b, bytes);
   if (rc) return rc;
   if (bytes) SPX_HIP(e, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, e->stream));

@@ -8,6 +8,7 @@ such as resource.MustParse("2Gi"), identifiers — and returns plain Python valu
     T{a: 1, b: "x"}      -> {"a": 1, "b": "x"}          (keyed literal -> dict; keys that are
     []T{x, y}            -> [x, y]                        identifiers/selectors stay strings)
     f(a, b)              -> Call("f", [a, b])
+    x.M(a).N()           -> Call(".N", [Call(".M", [x, a])])   (method chains on call results)
     pkg.Name             -> Ident("pkg.Name")
     &x, *x               -> x
     20*1024*1024         -> 20971520
@@ -220,9 +221,23 @@ class Parser:
                     idx = self.parse_expr()
                     self.take("]")
                     val = Call("index", [val, idx])
-                elif self.peek() == "." and self.kind(1) == "id":  # selector on a call/index result
+                elif self.peek() == "." and self.kind(1) == "id":  # selector or method call on a call/index result
                     self.take()
-                    val = Call("select", [val, self.take()])
+                    member = self.take()
+                    if self.peek() == "(":  # builder chains: recv.Method(args) -> Call(".Method", [recv, args...])
+                        self.take()
+                        margs = []
+                        while self.peek() != ")":
+                            margs.append(self.parse_expr())
+                            if self.peek() == ",":
+                                self.take()
+                            elif self.peek() == ".":
+                                while self.peek() == ".":
+                                    self.take()
+                        self.take(")")
+                        val = Call("." + member, [val] + margs)
+                    else:
+                        val = Call("select", [val, member])
                 else:
                     return val
         raise SyntaxError(f"unexpected token {t!r} at {self.t[self.i][2]}: {self.src[self.t[self.i][2]:self.t[self.i][2]+60]!r}")

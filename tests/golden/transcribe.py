@@ -261,7 +261,91 @@ def capacity():
     return out
 
 
-FIXTURES = {"capacity.json": capacity, "nrt_filter.json": nrt_filter, "nrt_score.json": nrt_score, "nrt_least_numa.json": nrt_least_numa}
+def nrt_integration():
+    """test/integration/noderesourcetopology_test.go: the table of TestTopologyMatchPlugin (29 cases): one pod, two nodes
+    with NRTs built by the MakeNRT() wrapper (test/integration/nrtutils.go:159-207), the scheduler profile (= scoring
+    strategy) picked by SchedulerName, and the nodes the pod may land on.  Containers built with util.WithLimits carry
+    limits only; the API server the integration test talks to defaults requests to limits, so both are recorded."""
+    path = "test/integration/noderesourcetopology_test.go"
+    src = (REF / path).read_text()
+    consts = {"cpu": "cpu", "memory": "memory", "gpuResourceName": "vendor/gpu", "hugepages2Mi": "hugepages-2Mi",
+              "nicResourceName": "vendor/nic1", "v1.ResourceCPU": "cpu", "v1.ResourceMemory": "memory"}
+    strategy_of = {None: "MostAllocated", "mostAllocatedScheduler": "MostAllocated", "balancedAllocationScheduler": "BalancedAllocation",
+                   "leastAllocatedScheduler": "LeastAllocated", "leastNUMAScheduler": "LeastNUMANodes"}
+    attr_names = {"nodeconfig.AttributePolicy": "topologyManagerPolicy", "nodeconfig.AttributeScope": "topologyManagerScope"}
+
+    def rn(k):
+        return consts[k.name] if isinstance(k, Ident) else consts.get(k, k)
+
+    def rl(d):
+        return {rn(k): v for k, v in d.items()}
+
+    def pod_of(expr):
+        pod = {"containers": [], "init_containers": [], "scheduler": None}
+
+        def walk(e):
+            if isinstance(e, Call):
+                if e.fn == "st.MakePod":
+                    return
+                walk(e.args[0])
+                if e.fn == "util.WithLimits":
+                    init = isinstance(e.args[2], Ident) and e.args[2].name == "true"
+                    lim = rl(e.args[1])
+                    if lim:
+                        (pod["init_containers"] if init else pod["containers"]).append({"requests": dict(lim), "limits": dict(lim)})
+                elif e.fn == ".Req":
+                    pod["containers"].append({"requests": rl(e.args[1])})
+                elif e.fn == ".Container":
+                    pod["containers"].append({})
+                elif e.fn == ".SchedulerName":
+                    pod["scheduler"] = e.args[1].name
+                elif e.fn in (".Namespace", ".Name", ".Obj"):
+                    pass
+                else:
+                    raise ValueError(f"unknown pod builder {e.fn}")
+        walk(expr)
+        return pod
+
+    def nrt_of(expr):
+        out = {"name": None, "policies": [], "attributes": {}, "zones": []}
+
+        def walk(e):
+            if e.fn == "MakeNRT":
+                return
+            walk(e.args[0])
+            if e.fn == ".Name":
+                out["name"] = e.args[1]
+            elif e.fn == ".Policy":
+                out["policies"].append(e.args[1].name.split(".")[-1])
+            elif e.fn == ".Attributes":
+                for a in e.args[1]:
+                    out["attributes"][attr_names[a["Name"].name]] = a["Value"]
+            elif e.fn in (".Zone", ".ZoneWithCosts"):
+                z = {"name": f"node-{len(out['zones'])}", "type": "Node",
+                     "resources": [[rn(r.args[0]), r.args[1], r.args[2]] for r in e.args[1]]}
+                if e.fn == ".ZoneWithCosts":
+                    z["costs"] = {c["Name"]: c["Value"] for c in e.args[2]}
+                out["zones"].append(z)
+            elif e.fn != ".Obj":
+                raise ValueError(f"unknown NRT builder {e.fn}")
+        walk(expr)
+        return out
+
+    cases = []
+    cursor = 0
+    for t in parse_literal_after(src, "tests := "):
+        assert len(t["pods"]) == 1
+        pod = pod_of(t["pods"][0])
+        cursor = src.index('"' + t["name"] + '"', cursor) + 1  # names repeat: search onwards from the previous case
+        cases.append({"name": t["name"], "line": src.count("\n", 0, cursor) + 1, "strategy": strategy_of[pod.pop("scheduler")], "pod": pod,
+                      "nrts": [nrt_of(n) for n in t.get("nodeResourceTopologies", [])], "expected_nodes": list(t["expectedNodes"])})
+    return {"source": path, "node_names": ["fake-node-1", "fake-node-2"],
+            "node_capacity": {"cpu": "64", "memory": "128Gi", "pods": "32", "hugepages-2Mi": "896Mi", "vendor/nic1": "48", "ephemeral-storage": "32Gi"},
+            "cases": cases}
+
+
+FIXTURES = {"capacity.json": capacity, "nrt_filter.json": nrt_filter, "nrt_score.json": nrt_score, "nrt_least_numa.json": nrt_least_numa,
+            "nrt_integration.json": nrt_integration}
 
 if __name__ == "__main__":
     for fname, fn in FIXTURES.items():
