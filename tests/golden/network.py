@@ -61,3 +61,16 @@ LESS_CASES = [
     dict(line=207, p1=("onlineboutique", "p5"), p2=("onlineboutique", "p1"), want=False),
     dict(line=228, p1=("basic", "p1"), p2=("other", "p5"), want=False),  # equal priority and timestamp -> PrioritySort false
 ]
+
+# test/integration/topologicalsort_test.go:253-342: pods of ONE AppGroup created with equal priority are popped from
+# the queue in Status.TopologyOrder index order (the fixture's indexes, after the by-selector sort at :248-249).
+QUEUE_ORDER_CASES = [
+    dict(line=255, appgroup="basic", created=["p1", "p2"], popped=["p1", "p2"]),
+    dict(line=266, appgroup="basic", created=["p1", "p3"], popped=["p1", "p3"]),
+    dict(line=277, appgroup="basic", created=["p2", "p3"], popped=["p2", "p3"]),
+    dict(line=288, appgroup="basic", created=["p1", "p2", "p3"], popped=["p1", "p2", "p3"]),
+    dict(line=301, appgroup="onlineboutique", created=["p1", "p5"], popped=["p1", "p5"]),
+    dict(line=312, appgroup="onlineboutique", created=["p4", "p8"], popped=["p8", "p4"]),
+    dict(line=323, appgroup="onlineboutique", created=[f"p{i}" for i in range(1, 12)],
+         popped=["p1", "p10", "p9", "p8", "p7", "p6", "p5", "p4", "p3", "p2", "p11"]),
+]

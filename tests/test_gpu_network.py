@@ -48,6 +48,20 @@ def test_toposort_less_golden(gpu_required, hdr, case):
         assert bool(e.toposort_less(pods, [0], [1])[0]) == case["want"]
 
 
+@pytest.mark.parametrize("case", GN.QUEUE_ORDER_CASES, ids=lambda c: f"L{c['line']}")
+def test_toposort_queue_order_golden(gpu_required, hdr, case):
+    """test/integration/topologicalsort_test.go:253-342 through the product's comparator (all pairs in one call)."""
+    n = len(case["created"])
+    nodes, pods, ag, nt = build(hdr, [], [(case["appgroup"], s) for s in case["created"]])
+    with Engine(0) as e:
+        e.load_network_objects(nodes, pods, ag, nt)
+        a, b = np.divmod(np.arange(n * n), n)
+        less = e.toposort_less(pods, a, b).reshape(n, n)
+    assert not (less & less.T).any()
+    order = np.argsort(less.sum(axis=0), kind="stable")   # a strict total order here: rank = number of predecessors
+    assert [case["created"][i] for i in order] == case["popped"]
+
+
 @pytest.mark.parametrize("kernel", ["class_table", "generic"])
 @pytest.mark.parametrize("n_nodes,n_pods,seed,ppg", [(500, 300, 1, 30), (64, 40, 2, 5), (1, 3, 3, 1), (1030, 129, 4, 10), (257, 200, 5, 200)])
 def test_differential(gpu_required, hdr, oracle, monkeypatch, kernel, n_nodes, n_pods, seed, ppg):

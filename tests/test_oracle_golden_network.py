@@ -89,3 +89,14 @@ def test_normalize_edge_cases(oracle):
 def test_toposort_less(hdr, oracle, case):
     nodes, pods, ag, nt = build(hdr, [], [case["p1"], case["p2"]])
     assert bool(oracle.lib().orc_toposort_less(pods.ref(), ag.ref(), 0, 1)) == case["want"]
+
+
+@pytest.mark.parametrize("case", GN.QUEUE_ORDER_CASES, ids=lambda c: f"L{c['line']}")
+def test_toposort_queue_order(hdr, oracle, case):
+    """test/integration/topologicalsort_test.go:253-342: the activeQ is a heap over Less, so popping everything
+    yields the pods sorted by it."""
+    import functools
+    nodes, pods, ag, nt = build(hdr, [], [(case["appgroup"], s) for s in case["created"]])
+    less = lambda x, y: bool(oracle.lib().orc_toposort_less(pods.ref(), ag.ref(), x, y))
+    order = sorted(range(len(case["created"])), key=functools.cmp_to_key(lambda x, y: -1 if less(x, y) else (1 if less(y, x) else 0)))
+    assert [case["created"][i] for i in order] == case["popped"]
