@@ -59,7 +59,9 @@ extern "C" {
 #define SPX_PLUGIN_NETOVERHEAD 4
 #define SPX_PLUGIN_CAPACITY 5
 #define SPX_PLUGIN_TOPOSORT 6
-#define SPX_NUM_PLUGINS 7
+#define SPX_PLUGIN_LROC 7  /* trimaran LowRiskOverCommitment */
+#define SPX_PLUGIN_PEAKS 8 /* trimaran Peaks */
+#define SPX_NUM_PLUGINS 9
 
 /* fwk.Status codes (k8s.io/kube-scheduler/framework) */
 #define SPX_STATUS_SUCCESS 0
@@ -166,6 +168,14 @@ typedef struct spx_assigned_objects {
   const int32_t* e_pod;
   const spx_pod_objects* pods;
 } spx_assigned_objects;
+
+/* framework.NodeInfo.GetPods() image (what trimaran.GetNodeRequestsAndLimits walks, pkg/trimaran/resourcestats.go:163-206):
+ * the pods already on node n are p_pod[p_ptr[n]..p_ptr[n+1]), indexes into `pods` */
+typedef struct spx_node_pods_objects {
+  const int32_t* p_ptr;
+  const int32_t* p_pod;
+  const spx_pod_objects* pods;
+} spx_node_pods_objects;
 
 /* NodeResourceTopology CR image per node plus the NRT cache's verdict for it
  * (pkg/noderesourcetopology/cache: GetCachedNRTCopy -> (nrt, CachedNRTInfo{Fresh})).
@@ -279,6 +289,14 @@ typedef struct spx_lvrb_params {
   double safe_variance_sensitivity;
 } spx_lvrb_params;
 
+/* LowRiskOverCommitmentArgs after defaulting (apis/config/v1/defaults.go:172-188): SmoothingWindowSize > 0,
+ * RiskLimitWeights["cpu"/"memory"] (lowriskovercommitment.go:76-81) */
+typedef struct spx_lroc_params {
+  int64_t smoothing_window_size;
+  double risk_limit_weight_cpu;
+  double risk_limit_weight_mem;
+} spx_lroc_params;
+
 /* NodeResourceTopologyMatch scoring strategy (apis/config/types.go ScoringStrategyType) */
 #define SPX_NRT_MOST_ALLOCATED 0
 #define SPX_NRT_BALANCED_ALLOCATION 1
@@ -327,6 +345,26 @@ typedef struct spx_trimaran_pods_soa {
   const int64_t* lv_req_cpu_milli;
   const int64_t* lv_req_mem;
 } spx_trimaran_pods_soa;
+
+/* LowRiskOverCommitment.  Reads the LVRB columns of spx_trimaran_nodes_soa (allocatable, avg/std, flags:
+ * the same CreateResourceStats / GetResourceData inputs) plus, per node, the sums GetNodeRequestsAndLimits accumulates over the
+ * pods already on it (requests, and limits raised to the requests; resourcestats.go:184-206, before the capacity caps) */
+typedef struct spx_lroc_nodes_soa {
+  int64_t n_nodes;
+  const int64_t* req_cpu_milli;
+  const int64_t* req_mem;
+  const int64_t* lim_cpu_milli;
+  const int64_t* lim_mem;
+} spx_lroc_nodes_soa;
+
+/* PodResourcesStateData (lowriskovercommitment.go:259-275): requests, and limits raised to the requests */
+typedef struct spx_lroc_pods_soa {
+  int64_t n_pods;
+  const int64_t* req_cpu_milli;
+  const int64_t* req_mem;
+  const int64_t* lim_cpu_milli;
+  const int64_t* lim_mem;
+} spx_lroc_pods_soa;
 
 /* NodeResourceTopologyMatch.  Resources are renumbered into dense "slots" 0..n_res-1 (the union of
  * what pods request and zones report; slot_res gives the canonical id).  Limits of this build:
@@ -454,6 +492,7 @@ typedef struct spx_quota_soa {
  *   spx_fetch_raw(ALLOCATABLE)                 Allocatable.Score (raw int64)           pkg/noderesources/allocatable.go:117-140
  *   spx_eval + spx_fetch_scores(TLP)           TargetLoadPacking.Score                 pkg/trimaran/targetloadpacking/targetloadpacking.go:107-187
  *   spx_eval + spx_fetch_scores(LVRB)          LoadVariationRiskBalancing.Score        pkg/trimaran/loadvariationriskbalancing/loadvariationriskbalancing.go:84-122
+ *   spx_eval + spx_fetch_scores(LROC)          LowRiskOverCommitment.PreScore + Score  pkg/trimaran/lowriskovercommitment/lowriskovercommitment.go:96-141, :158-255, beta.go:85-191
  *   spx_eval + spx_fetch_status(NRT)           TopologyMatch.Filter                    pkg/noderesourcetopology/filter.go:179-245
  *   spx_eval + spx_fetch_scores(NRT)           TopologyMatch.Score                     pkg/noderesourcetopology/score.go:62-102
  *   spx_eval + spx_fetch_status(NETOVERHEAD)   NetworkOverhead.PreFilter + Filter      pkg/networkaware/networkoverhead/networkoverhead.go:174-298, :326-359
@@ -492,10 +531,14 @@ int spx_set_tlp_params(spx_engine* e, const spx_tlp_params* p);
 int spx_set_lvrb_params(spx_engine* e, const spx_lvrb_params* p);
 
 int spx_set_nrt_params(spx_engine* e, const spx_nrt_params* p);
+int spx_set_lroc_params(spx_engine* e, const spx_lroc_params* p);
 
 int spx_upload_alloc_nodes(spx_engine* e, const spx_alloc_nodes_soa* t);
 int spx_upload_trimaran_nodes(spx_engine* e, const spx_trimaran_nodes_soa* t);
 int spx_upload_trimaran_pods(spx_engine* e, const spx_trimaran_pods_soa* t);
+/* LowRiskOverCommitment tables; the node table needs spx_upload_trimaran_nodes first (same node count) */
+int spx_upload_lroc_nodes(spx_engine* e, const spx_lroc_nodes_soa* t);
+int spx_upload_lroc_pods(spx_engine* e, const spx_lroc_pods_soa* t);
 int spx_upload_nrt_slots(spx_engine* e, const spx_nrt_slots* t);
 int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t);
 int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t);
@@ -562,7 +605,9 @@ int spx_kernel_path(const spx_engine* e, int plugin);
 int spx_flatten_alloc_nodes(const spx_node_objects* nodes, const spx_resource_classes* rc, const spx_allocatable_params* p, int64_t* alloc_out);
 int spx_flatten_trimaran_nodes(const spx_node_objects* nodes, const spx_metrics_objects* metrics, const spx_assigned_objects* assigned, const spx_tlp_params* tlp, int64_t* cap_cpu_milli, double* tlp_cpu_util, int64_t* tlp_missing_milli, uint8_t* tlp_valid, int64_t* lv_alloc_cpu_milli, int64_t* lv_alloc_mem, double* lv_cpu_avg, double* lv_cpu_std, double* lv_mem_avg, double* lv_mem_std, uint8_t* lv_flags);
 int spx_flatten_trimaran_pods(const spx_pod_objects* pods, const spx_tlp_params* tlp, int64_t* tlp_pod_milli, int64_t* lv_req_cpu_milli, int64_t* lv_req_mem);
-
+/* LowRiskOverCommitment: every output array has one entry per node / per pod */
+int spx_flatten_lroc_nodes(const spx_node_objects* nodes, const spx_node_pods_objects* node_pods, int64_t* req_cpu_milli, int64_t* req_mem, int64_t* lim_cpu_milli, int64_t* lim_mem);
+int spx_flatten_lroc_pods(const spx_pod_objects* pods, int64_t* req_cpu_milli, int64_t* req_mem, int64_t* lim_cpu_milli, int64_t* lim_mem);
 
 /* NRT: builds the dense slot numbering from every resource id pods request or zones report
  * (slot_res/slot_flags/slot_weight sized SPX_NRT_MAX_RES; *n_res_out receives the count) */

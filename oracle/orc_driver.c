@@ -31,6 +31,8 @@ static int64_t score_one(const orc_snapshot* s, int plugin, int64_t pod, int64_t
     case SPX_PLUGIN_ALLOCATABLE: return orc_allocatable_score(s->nodes, s->rc, s->alloc_params, node);
     case SPX_PLUGIN_TLP: return orc_tlp_score(s->nodes, s->metrics, s->assigned, s->pods, s->tlp_params, pod, node);
     case SPX_PLUGIN_LVRB: return orc_lvrb_score(s->nodes, s->metrics, s->pods, s->lvrb_params, pod, node);
+    case SPX_PLUGIN_LROC: /* NormalizeScore is a no-op: lowriskovercommitment.go:153-155 */
+      return orc_lroc_score(s->nodes, s->node_pods, s->metrics, s->pods, s->lroc_params, pod, node);
     case SPX_PLUGIN_NRT: return orc_nrt_score(s->nrt, s->rc, s->pods, s->nrt_params, pod, node); /* no NormalizeScore: score.go:104-106 */
     default: return 0;
   }

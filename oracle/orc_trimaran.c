@@ -15,7 +15,7 @@
 
 /* Collector.GetNodeMetrics (collector.go:110-123): returns 0 when `metrics == nil` for the node
  * (nil map, node absent, or a nil Metrics slice), 1 otherwise with [*lo,*hi) the metric range. */
-static int node_metrics(const spx_metrics_objects* m, int64_t node, int32_t* lo, int32_t* hi) {
+int orc_node_metrics(const spx_metrics_objects* m, int64_t node, int32_t* lo, int32_t* hi) {
   if (m == 0 || m->map_is_nil) return 0;  /* :113-116 -> (nil, nil) */
   if (!m->node_present[node]) return 0;   /* :118-121 -> (nil, allMetrics) */
   if (m->node_metrics_nil && m->node_metrics_nil[node]) return 0;
@@ -24,7 +24,7 @@ static int node_metrics(const spx_metrics_objects* m, int64_t node, int32_t* lo,
   return 1;
 }
 
-static int find_qty(const int32_t* res, const int64_t* qty, int32_t lo, int32_t hi, int32_t want, int64_t* out) {
+int orc_find_qty(const int32_t* res, const int64_t* qty, int32_t lo, int32_t hi, int32_t want, int64_t* out) {
   for (int32_t i = lo; i < hi; ++i)
     if (res[i] == want) {
       *out = qty[i];
@@ -38,9 +38,9 @@ static int find_qty(const int32_t* res, const int64_t* qty, int32_t lo, int32_t 
 /* PredictUtilisation (targetloadpacking.go:198-205) */
 int64_t orc_tlp_predict_utilisation(const spx_pod_objects* pods, int32_t c, const spx_tlp_params* p) {
   int64_t q;
-  if (find_qty(pods->lim_res, pods->lim_qty, pods->lim_ptr[c], pods->lim_ptr[c + 1], SPX_RES_CPU, &q))
+  if (orc_find_qty(pods->lim_res, pods->lim_qty, pods->lim_ptr[c], pods->lim_ptr[c + 1], SPX_RES_CPU, &q))
     return q; /* Limits.Cpu().MilliValue() */
-  if (find_qty(pods->req_res, pods->req_qty, pods->req_ptr[c], pods->req_ptr[c + 1], SPX_RES_CPU, &q))
+  if (orc_find_qty(pods->req_res, pods->req_qty, pods->req_ptr[c], pods->req_ptr[c + 1], SPX_RES_CPU, &q))
     return (int64_t)round((double)q * p->requests_multiplier);
   return p->default_requests_milli;
 }
@@ -52,7 +52,7 @@ static int64_t tlp_pod_cpu(const spx_pod_objects* pods, int64_t pod, const spx_t
   for (int32_t c = pods->ctr_ptr[pod]; c < pods->ctr_ptr[pod + 1]; ++c)
     if (pods->ctr_kind[c] == SPX_CTR_APP) cur += orc_tlp_predict_utilisation(pods, c, p);
   int64_t ovh;
-  if (pods->ovh_ptr && find_qty(pods->ovh_res, pods->ovh_qty, pods->ovh_ptr[pod], pods->ovh_ptr[pod + 1], SPX_RES_CPU, &ovh))
+  if (pods->ovh_ptr && orc_find_qty(pods->ovh_res, pods->ovh_qty, pods->ovh_ptr[pod], pods->ovh_ptr[pod + 1], SPX_RES_CPU, &ovh))
     cur += ovh; /* pod.Spec.Overhead.Cpu().MilliValue(); nil map / missing key yield 0 */
   return cur;
 }
@@ -63,7 +63,7 @@ int64_t orc_tlp_score(const spx_node_objects* nodes, const spx_metrics_objects* 
                       const spx_tlp_params* p, int64_t pod, int64_t node) {
   const int64_t min_node_score = 0;
   int32_t lo, hi;
-  if (!node_metrics(metrics, node, &lo, &hi)) return min_node_score; /* :114-120 */
+  if (!orc_node_metrics(metrics, node, &lo, &hi)) return min_node_score; /* :114-120 */
 
   int64_t cur_pod_cpu = tlp_pod_cpu(pods, pod, p); /* :122-129 */
 
@@ -198,7 +198,7 @@ int orc_get_resource_data(const spx_metrics_objects* metrics, int64_t node, int 
   int32_t lo, hi;
   *avg = 0;
   *stdev = 0;
-  if (!node_metrics(metrics, node, &lo, &hi)) return 0;
+  if (!orc_node_metrics(metrics, node, &lo, &hi)) return 0;
   int avg_found = 0, is_valid = 0;
   for (int32_t i = lo; i < hi; ++i) {
     if (metrics->m_type[i] == type) {
@@ -223,24 +223,24 @@ void orc_get_resource_requested(const spx_pod_objects* pods, int64_t pod, int64_
   int64_t cpu = 0, mem = 0, q;
   for (int32_t c = pods->ctr_ptr[pod]; c < pods->ctr_ptr[pod + 1]; ++c) {
     if (pods->ctr_kind[c] != SPX_CTR_APP) continue;
-    if (find_qty(pods->req_res, pods->req_qty, pods->req_ptr[c], pods->req_ptr[c + 1], SPX_RES_CPU, &q)) cpu += q;
-    if (find_qty(pods->req_res, pods->req_qty, pods->req_ptr[c], pods->req_ptr[c + 1], SPX_RES_MEMORY, &q)) mem += q;
+    if (orc_find_qty(pods->req_res, pods->req_qty, pods->req_ptr[c], pods->req_ptr[c + 1], SPX_RES_CPU, &q)) cpu += q;
+    if (orc_find_qty(pods->req_res, pods->req_qty, pods->req_ptr[c], pods->req_ptr[c + 1], SPX_RES_MEMORY, &q)) mem += q;
   }
   for (int32_t c = pods->ctr_ptr[pod]; c < pods->ctr_ptr[pod + 1]; ++c) { /* :129-139 setMax per init container */
     if (pods->ctr_kind[c] == SPX_CTR_APP) continue;
-    if (find_qty(pods->req_res, pods->req_qty, pods->req_ptr[c], pods->req_ptr[c + 1], SPX_RES_CPU, &q) && q > cpu) cpu = q;
-    if (find_qty(pods->req_res, pods->req_qty, pods->req_ptr[c], pods->req_ptr[c + 1], SPX_RES_MEMORY, &q) && q > mem) mem = q;
+    if (orc_find_qty(pods->req_res, pods->req_qty, pods->req_ptr[c], pods->req_ptr[c + 1], SPX_RES_CPU, &q) && q > cpu) cpu = q;
+    if (orc_find_qty(pods->req_res, pods->req_qty, pods->req_ptr[c], pods->req_ptr[c + 1], SPX_RES_MEMORY, &q) && q > mem) mem = q;
   }
   if (pods->ovh_ptr) { /* :141-143 */
-    if (find_qty(pods->ovh_res, pods->ovh_qty, pods->ovh_ptr[pod], pods->ovh_ptr[pod + 1], SPX_RES_CPU, &q)) cpu += q;
-    if (find_qty(pods->ovh_res, pods->ovh_qty, pods->ovh_ptr[pod], pods->ovh_ptr[pod + 1], SPX_RES_MEMORY, &q)) mem += q;
+    if (orc_find_qty(pods->ovh_res, pods->ovh_qty, pods->ovh_ptr[pod], pods->ovh_ptr[pod + 1], SPX_RES_CPU, &q)) cpu += q;
+    if (orc_find_qty(pods->ovh_res, pods->ovh_qty, pods->ovh_ptr[pod], pods->ovh_ptr[pod + 1], SPX_RES_MEMORY, &q)) mem += q;
   }
   *milli_cpu = cpu;
   *memory = mem;
 }
 
 /* CreateResourceStats resourcestats.go:45-74 */
-static int create_resource_stats(const spx_node_objects* nodes, const spx_metrics_objects* metrics, int64_t node,
+int orc_create_resource_stats(const spx_node_objects* nodes, const spx_metrics_objects* metrics, int64_t node,
                                  int64_t req_cpu, int64_t req_mem, int type, orc_resource_stats* rs) {
   const double mega_factor = 1. / 1024. / 1024.; /* resourcestats.go:29 */
   double node_util, node_std;
@@ -262,14 +262,14 @@ static int create_resource_stats(const spx_node_objects* nodes, const spx_metric
 int64_t orc_lvrb_score(const spx_node_objects* nodes, const spx_metrics_objects* metrics,
                        const spx_pod_objects* pods, const spx_lvrb_params* p, int64_t pod, int64_t node) {
   int32_t lo, hi;
-  if (!node_metrics(metrics, node, &lo, &hi)) return 0; /* :90-94 */
+  if (!orc_node_metrics(metrics, node, &lo, &hi)) return 0; /* :90-94 */
   int64_t req_cpu, req_mem;
   orc_get_resource_requested(pods, pod, &req_cpu, &req_mem);
   double cpu_score = 0, memory_score = 0;
   orc_resource_stats cpu_stats, mem_stats;
-  int cpu_ok = create_resource_stats(nodes, metrics, node, req_cpu, req_mem, SPX_MT_CPU, &cpu_stats);
+  int cpu_ok = orc_create_resource_stats(nodes, metrics, node, req_cpu, req_mem, SPX_MT_CPU, &cpu_stats);
   if (cpu_ok) cpu_score = orc_lvrb_compute_score(&cpu_stats, p->safe_variance_margin, p->safe_variance_sensitivity);
-  int mem_ok = create_resource_stats(nodes, metrics, node, req_cpu, req_mem, SPX_MT_MEMORY, &mem_stats);
+  int mem_ok = orc_create_resource_stats(nodes, metrics, node, req_cpu, req_mem, SPX_MT_MEMORY, &mem_stats);
   if (mem_ok) memory_score = orc_lvrb_compute_score(&mem_stats, p->safe_variance_margin, p->safe_variance_sensitivity);
   double total;
   if (mem_ok && cpu_ok)

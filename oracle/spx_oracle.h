@@ -52,6 +52,39 @@ void orc_get_resource_requested(const spx_pod_objects* pods, int64_t pod, int64_
 int64_t orc_lvrb_score(const spx_node_objects* nodes, const spx_metrics_objects* metrics,
                        const spx_pod_objects* pods, const spx_lvrb_params* p, int64_t pod, int64_t node);
 
+/* helpers of orc_trimaran.c shared with orc_lroc.c / orc_peaks.c */
+int orc_node_metrics(const spx_metrics_objects* m, int64_t node, int32_t* lo, int32_t* hi);
+int orc_find_qty(const int32_t* res, const int64_t* qty, int32_t lo, int32_t hi, int32_t want, int64_t* out);
+int orc_create_resource_stats(const spx_node_objects* nodes, const spx_metrics_objects* metrics, int64_t node,
+                              int64_t req_cpu, int64_t req_mem, int type, orc_resource_stats* rs);
+
+/* ---- trimaran.LowRiskOverCommitment (pkg/trimaran/lowriskovercommitment/{lowriskovercommitment,beta}.go,
+ *      pkg/trimaran/resourcestats.go:109-232; gonum mathext.RegIncBeta restated from its published algorithm) */
+typedef struct orc_node_requests_limits { /* trimaran.NodeRequestsAndLimits resourcestats.go:149-160 */
+  int64_t req_cpu;
+  int64_t req_mem;
+  int64_t lim_cpu;
+  int64_t lim_mem;
+  int64_t req_minus_pod_cpu;
+  int64_t req_minus_pod_mem;
+  int64_t lim_minus_pod_cpu;
+  int64_t lim_minus_pod_mem;
+  int64_t cap_cpu;
+  int64_t cap_mem;
+} orc_node_requests_limits;
+double orc_reg_inc_beta(double a, double b, double x);
+double orc_beta_distribution_function(double alpha, double beta, double x);
+double orc_beta_max_variance(double m1);
+int orc_beta_match_moments(double m1, double m2, double* alpha, double* beta);
+double orc_lroc_compute_probability(double mu, double sigma, double threshold, int* has_dist, double* alpha, double* beta);
+void orc_get_resource_limits(const spx_pod_objects* pods, int64_t pod, int64_t* milli_cpu, int64_t* memory);
+void orc_node_requests_and_limits(const spx_node_objects* nodes, const spx_node_pods_objects* node_pods, int64_t node,
+                                  const int64_t* pod_rl, orc_node_requests_limits* out);
+double orc_lroc_compute_risk(const spx_node_objects* nodes, const spx_metrics_objects* metrics, int64_t node, int type,
+                             const orc_node_requests_limits* nrl, const spx_lroc_params* p);
+int64_t orc_lroc_score(const spx_node_objects* nodes, const spx_node_pods_objects* node_pods, const spx_metrics_objects* metrics,
+                       const spx_pod_objects* pods, const spx_lroc_params* p, int64_t pod, int64_t node);
+
 /* ---- NodeResourceTopologyMatch (pkg/noderesourcetopology/{filter,score,least_numa,...}.go) */
 int orc_pod_qos(const spx_pod_objects* pods, int64_t pod);
 int orc_include_non_native(const spx_pod_objects* pods, const spx_resource_classes* rc, int64_t pod);
@@ -103,6 +136,8 @@ typedef struct orc_snapshot {
   const spx_nrt_params* nrt_params;
   const spx_appgroup_objects* appgroups;
   const spx_nettopo_objects* nettopo;
+  const spx_node_pods_objects* node_pods; /* LowRiskOverCommitment */
+  const spx_lroc_params* lroc_params;
 } orc_snapshot;
 
 int orc_score_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t row_end,

@@ -234,6 +234,18 @@ def build_assigned_objects(hdr: Header, res: Resources, n_nodes: int, entries: D
                  e_pod=np.array([i for l in per_node for i in l], dtype=np.int32), pods=ptable)
 
 
+def build_node_pods_objects(hdr: Header, res: Resources, n_nodes: int, pods_on_node: Dict[int, list]) -> Table:
+    """pods_on_node: {node index: [pod dict, ...]} — framework.NodeInfo.GetPods() image."""
+    pods, per_node = [], [[] for _ in range(n_nodes)]
+    for ni in range(n_nodes):
+        for p in pods_on_node.get(ni, []):
+            per_node[ni].append(len(pods))
+            pods.append(p)
+    ptable = build_pod_objects(hdr, res, pods)
+    return Table(hdr, "spx_node_pods_objects", p_ptr=_csr(per_node),
+                 p_pod=np.array([i for l in per_node for i in l], dtype=np.int32), pods=ptable)
+
+
 # ------------------------------------------------------------------ NodeResourceTopology
 LEGACY_POLICIES = {  # topologyv1alpha2.TopologyManagerPolicy -> (policy << 1) | scope   nodeconfig/topologymanager.go:141-160
     "SingleNUMANodeContainerLevel": (3 << 1) | 0, "SingleNUMANodePodLevel": (3 << 1) | 1,

@@ -7,7 +7,7 @@ import scheduler_plugins_amd as spx
 from scheduler_plugins_amd import objects as O
 from scheduler_plugins_amd._abi import Table
 
-ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY, TOPOSORT = range(7)
+ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY, TOPOSORT, LROC, PEAKS = range(9)
 
 
 def alloc_params(hdr, res: O.Resources, resources: dict, mode: str) -> Table:
@@ -23,6 +23,10 @@ def tlp_params(hdr, target_utilization=40, default_requests_milli=1000, requests
 
 def lvrb_params(hdr, margin=1.0, sensitivity=1.0) -> Table:
     return Table(hdr, "spx_lvrb_params", safe_variance_margin=margin, safe_variance_sensitivity=sensitivity)
+
+
+def lroc_params(hdr, smoothing_window_size=5, w_cpu=0.5, w_mem=0.5) -> Table:
+    return Table(hdr, "spx_lroc_params", smoothing_window_size=smoothing_window_size, risk_limit_weight_cpu=w_cpu, risk_limit_weight_mem=w_mem)
 
 
 def make_node_info(milli_cpu: int, memory: int) -> dict:  # allocatable_test.go:315-331
