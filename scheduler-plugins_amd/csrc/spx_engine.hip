@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,7 +48,7 @@ struct spx_engine {
   std::vector<int64_t> alloc_weight{1, 1 << 20};  // defaultResourcesToWeightMap resource_allocation.go:36
   spx_tlp_params tlp{40, 1000, 1.5};             // apis/config/v1/defaults.go:51-55
   spx_lvrb_params lvrb{1.0, 1.0};                // defaults.go:65-67
-  int64_t plugin_weight[SPX_NUM_PLUGINS] = {1, 1, 1, 1, 1, 1, 1};
+  int64_t plugin_weight[SPX_NUM_PLUGINS] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
 
   // device tables
   DevBuf d_alloc, d_alloc_w, d_alloc_raw, d_alloc_norm, d_alloc_rel;
@@ -62,6 +63,12 @@ struct spx_engine {
   DevBuf d_lv_exact; // double [n_nodes][8] scratch of the LVRB fast kernel
   DevBuf d_lv_fast, d_tlp_fast;  // float32 per-node constants of the fast sweeps (recomputed per launch)
   DevBuf d_commit;               // scratch of spx_commit_sequential
+
+  // LowRiskOverCommitment (reads the LVRB node columns above as well)
+  spx_lroc_params lroc{5, 0.5, 0.5};  // apis/config/v1/defaults.go:72-80
+  DevBuf d_lroc_nreq_c, d_lroc_nreq_m, d_lroc_nlim_c, d_lroc_nlim_m, d_lroc_preq_c, d_lroc_preq_m, d_lroc_plim_c, d_lroc_plim_m, d_lroc_tab;
+  bool lroc_nodes = false, lroc_pods = false, lroc_tab_ready = false;
+  bool lroc_nodes_exact = false, lroc_pods_exact = false, lv_alloc_exact = false;  // all values in [0, 2^52)
 
   // NodeResourceTopologyMatch
   spx_nrt_params nrt_params{SPX_NRT_LEAST_ALLOCATED, 0, nullptr, nullptr};  // defaults.go:87-90
@@ -143,6 +150,13 @@ int upload(spx_engine* e, DevBuf& b, const void* src, size_t bytes) {
   return SPX_OK;
 }
 
+// every value in [0, 2^52): sums and differences of two such values are exact in float64
+bool all_below_2p52(const int64_t* v, size_t n) {
+  uint64_t acc = 0;
+  for (size_t i = 0; i < n; ++i) acc |= static_cast<uint64_t>(v[i]);
+  return (acc >> 52) == 0;
+}
+
 int set_nodes(spx_engine* e, int64_t n) {
   if (n <= 0) return fail(e, SPX_ERR_ARG, "n_nodes must be positive");
   if (e->n_nodes != -1 && e->n_nodes != n)
@@ -201,6 +215,35 @@ int prepare_alloc(spx_engine* e) {
   SPX_HIP(e, hipGetLastError());
   e->alloc_ready = true;
   return SPX_OK;
+}
+
+bool lroc_exact53(const spx_engine* e) {
+  return e->lroc_nodes_exact && e->lroc_pods_exact && e->lv_alloc_exact && getenv("SPX_LROC_GENERIC") == nullptr;
+}
+
+void fill_lroc(const spx_engine* e, spx::LrocArgs& a) {
+  a.n_nodes = e->n_nodes;
+  a.row_stride = e->row_stride;
+  a.alloc_cpu_milli = static_cast<const int64_t*>(e->d_lv_acpu.p);
+  a.alloc_mem = static_cast<const int64_t*>(e->d_lv_amem.p);
+  a.cpu_avg = static_cast<const double*>(e->d_lv_cavg.p);
+  a.cpu_std = static_cast<const double*>(e->d_lv_cstd.p);
+  a.mem_avg = static_cast<const double*>(e->d_lv_mavg.p);
+  a.mem_std = static_cast<const double*>(e->d_lv_mstd.p);
+  a.flags = static_cast<const uint8_t*>(e->d_lv_flags.p);
+  a.node_req_cpu = static_cast<const int64_t*>(e->d_lroc_nreq_c.p);
+  a.node_req_mem = static_cast<const int64_t*>(e->d_lroc_nreq_m.p);
+  a.node_lim_cpu = static_cast<const int64_t*>(e->d_lroc_nlim_c.p);
+  a.node_lim_mem = static_cast<const int64_t*>(e->d_lroc_nlim_m.p);
+  a.pod_req_cpu = static_cast<const int64_t*>(e->d_lroc_preq_c.p);
+  a.pod_req_mem = static_cast<const int64_t*>(e->d_lroc_preq_m.p);
+  a.pod_lim_cpu = static_cast<const int64_t*>(e->d_lroc_plim_c.p);
+  a.pod_lim_mem = static_cast<const int64_t*>(e->d_lroc_plim_m.p);
+  a.sqrt_window = std::sqrt(static_cast<double>(e->lroc.smoothing_window_size));  // math.Pow(x, 0.5) = Sqrt(x)
+  a.w_cpu = e->lroc.risk_limit_weight_cpu;
+  a.w_mem = e->lroc.risk_limit_weight_mem;
+  a.node_tab = static_cast<double*>(e->d_lroc_tab.p);
+  a.exact53 = lroc_exact53(e) ? 1 : 0;
 }
 
 void fill_trimaran(const spx_engine* e, spx::TrimaranArgs& a) {
@@ -448,7 +491,56 @@ int spx_upload_trimaran_nodes(spx_engine* e, const spx_trimaran_nodes_soa* t) {
   if ((rc = upload(e, e->d_lv_mavg, t->lv_mem_avg, n * 8))) return rc;
   if ((rc = upload(e, e->d_lv_mstd, t->lv_mem_std, n * 8))) return rc;
   if ((rc = upload(e, e->d_lv_flags, t->lv_flags, n))) return rc;
+  e->lv_alloc_exact = all_below_2p52(t->lv_alloc_cpu_milli, n) && all_below_2p52(t->lv_alloc_mem, n);
+  e->lroc_tab_ready = false;
   e->tri_nodes = true;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  return SPX_OK;
+}
+
+int spx_set_lroc_params(spx_engine* e, const spx_lroc_params* p) {
+  if (!e || !p) return SPX_ERR_ARG;
+  // defaults.go:176-186 substitutes defaults for bad values before the plugin sees them; the engine takes the result
+  if (p->smoothing_window_size <= 0) return fail(e, SPX_ERR_ARG, "LowRiskOverCommitment: SmoothingWindowSize must be positive");
+  if (!(p->risk_limit_weight_cpu >= 0 && p->risk_limit_weight_cpu <= 1) || !(p->risk_limit_weight_mem >= 0 && p->risk_limit_weight_mem <= 1))
+    return fail(e, SPX_ERR_ARG, "LowRiskOverCommitment: RiskLimitWeights must be in [0,1]");  // validation_pluginargs.go
+  e->lroc = *p;
+  e->lroc_tab_ready = false;
+  return SPX_OK;
+}
+
+int spx_upload_lroc_nodes(spx_engine* e, const spx_lroc_nodes_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  if (!e->tri_nodes) return fail(e, SPX_ERR_STATE, "LowRiskOverCommitment reads the trimaran node table: upload it first");
+  int rc = set_nodes(e, t->n_nodes);
+  if (rc) return rc;
+  const size_t n = static_cast<size_t>(t->n_nodes);
+  if ((rc = upload(e, e->d_lroc_nreq_c, t->req_cpu_milli, n * 8))) return rc;
+  if ((rc = upload(e, e->d_lroc_nreq_m, t->req_mem, n * 8))) return rc;
+  if ((rc = upload(e, e->d_lroc_nlim_c, t->lim_cpu_milli, n * 8))) return rc;
+  if ((rc = upload(e, e->d_lroc_nlim_m, t->lim_mem, n * 8))) return rc;
+  e->lroc_nodes_exact = all_below_2p52(t->req_cpu_milli, n) && all_below_2p52(t->req_mem, n) && all_below_2p52(t->lim_cpu_milli, n) &&
+                        all_below_2p52(t->lim_mem, n);
+  e->lroc_nodes = true;
+  e->lroc_tab_ready = false;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  return SPX_OK;
+}
+
+int spx_upload_lroc_pods(spx_engine* e, const spx_lroc_pods_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  int rc = set_pods(e, t->n_pods);
+  if (rc) return rc;
+  const size_t p = static_cast<size_t>(t->n_pods);
+  if ((rc = upload(e, e->d_lroc_preq_c, t->req_cpu_milli, p * 8))) return rc;
+  if ((rc = upload(e, e->d_lroc_preq_m, t->req_mem, p * 8))) return rc;
+  if ((rc = upload(e, e->d_lroc_plim_c, t->lim_cpu_milli, p * 8))) return rc;
+  if ((rc = upload(e, e->d_lroc_plim_m, t->lim_mem, p * 8))) return rc;
+  e->lroc_pods_exact = all_below_2p52(t->req_cpu_milli, p) && all_below_2p52(t->req_mem, p) && all_below_2p52(t->lim_cpu_milli, p) &&
+                       all_below_2p52(t->lim_mem, p);
+  e->lroc_pods = true;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   return SPX_OK;
 }
@@ -838,8 +930,10 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (!e) return SPX_ERR_ARG;
   SPX_HIP(e, hipSetDevice(e->device));
   const uint32_t known = (1u << SPX_PLUGIN_ALLOCATABLE) | (1u << SPX_PLUGIN_TLP) | (1u << SPX_PLUGIN_LVRB) | (1u << SPX_PLUGIN_NRT) |
-                         (1u << SPX_PLUGIN_NETOVERHEAD) | (1u << SPX_PLUGIN_CAPACITY);
+                         (1u << SPX_PLUGIN_NETOVERHEAD) | (1u << SPX_PLUGIN_CAPACITY) | (1u << SPX_PLUGIN_LROC);
   if (plugin_mask == 0 || (plugin_mask & ~known)) return fail(e, SPX_ERR_ARG, "plugin mask has unsupported bits");
+  const bool R = plugin_mask & (1u << SPX_PLUGIN_LROC);
+  if (R && !(e->tri_nodes && e->lroc_nodes && e->lroc_pods)) return fail(e, SPX_ERR_STATE, "LowRiskOverCommitment node/pod tables not uploaded");
   const bool Q = plugin_mask & (1u << SPX_PLUGIN_CAPACITY);
   if (Q && !e->quota) return fail(e, SPX_ERR_STATE, "CapacityScheduling quota tables not uploaded");
   if (e->n_nodes <= 0 && plugin_mask != (1u << SPX_PLUGIN_CAPACITY)) return fail(e, SPX_ERR_STATE, "no node table uploaded");
@@ -860,6 +954,10 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (W && !(e->net_nodes && e->net_topo && e->net_pods)) return fail(e, SPX_ERR_STATE, "NetworkOverhead node/topology/pod tables not uploaded");
   for (int p = 0; p < 5; ++p)
     if ((plugin_mask & (1u << p)) && (rc = ensure_score_table(e, p))) return rc;
+  if (R && (rc = ensure_score_table(e, SPX_PLUGIN_LROC))) return rc;
+  if (R && e->score_stride[SPX_PLUGIN_LROC] != e->row_stride)
+    return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
+  if (R && (rc = ensure(e, e->d_lroc_tab, static_cast<size_t>(e->row_stride) * 8 * sizeof(double)))) return rc;
   if (N && (rc = ensure(e, e->status[SPX_PLUGIN_NRT], static_cast<size_t>(e->n_pods) * static_cast<size_t>(e->row_stride)))) return rc;
   if (W && (rc = ensure(e, e->status[SPX_PLUGIN_NETOVERHEAD], static_cast<size_t>(e->n_pods) * static_cast<size_t>(e->row_stride)))) return rc;
 
@@ -945,6 +1043,20 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   }
   spx::launch_trimaran(a, e->stream);
   SPX_HIP(e, hipGetLastError());
+  if (R) {
+    spx::LrocArgs la{};
+    fill_lroc(e, la);
+    la.row_begin = row_begin;
+    la.row_end = row_end;
+    la.out_score = static_cast<uint8_t*>(e->score[SPX_PLUGIN_LROC].p);
+    if (!e->lroc_tab_ready) {  // per-node riskLoad: once per (node tables, params)
+      spx::launch_lroc_prepare(la, e->stream);
+      SPX_HIP(e, hipGetLastError());
+      e->lroc_tab_ready = true;
+    }
+    spx::launch_lroc(la, e->stream);
+    SPX_HIP(e, hipGetLastError());
+  }
   if (A && masked) {
     spx::ProfileArgs pa{};
     pa.n_nodes = e->n_nodes;
@@ -1028,6 +1140,7 @@ int spx_kernel_path(const spx_engine* e, int plugin) {
                ? 1
                : 0;
   if (plugin == SPX_PLUGIN_NETOVERHEAD) return (e->net_nodes && e->net_class16 && e->net_n_classes > 0 && getenv("SPX_NET_GENERIC") == nullptr) ? 1 : 0;
+  if (plugin == SPX_PLUGIN_LROC) return lroc_exact53(e) ? 1 : 0;
   if (plugin == SPX_PLUGIN_TLP) return (e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && getenv("SPX_EXACT_ONLY") == nullptr) ? 1 : 0;
   return 0;
 }
@@ -1167,7 +1280,7 @@ int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_
   pa.status[2] = e->ext_mask ? static_cast<const uint8_t*>(e->d_ext_status.p) : nullptr;
   pa.prefilter = (plugin_mask & (1u << SPX_PLUGIN_CAPACITY)) ? static_cast<const uint8_t*>(e->d_q_status.p) : nullptr;
   for (int k = 0; k < SPX_NUM_PLUGINS; ++k) {
-    const bool has_score = k <= SPX_PLUGIN_NETOVERHEAD;
+    const bool has_score = k <= SPX_PLUGIN_NETOVERHEAD || k == SPX_PLUGIN_LROC;
     if ((plugin_mask & (1u << k)) && has_score) {
       if (e->score_stride[k] != e->row_stride) return fail(e, SPX_ERR_STATE, "score table stride differs from the engine row stride");
       pa.score[k] = static_cast<const uint8_t*>(e->score[k].p);

@@ -82,6 +82,42 @@ void launch_commit_trimaran(const CommitArgs& c, hipStream_t s);
 // raw int64 Score() of one pod row for `plugin` (SPX_PLUGIN_TLP / SPX_PLUGIN_LVRB)
 void launch_trimaran_raw(const TrimaranArgs& a, int plugin, int64_t pod_row, int64_t* out, hipStream_t s);
 
+// ---------------------------------------------------------------- LowRiskOverCommitment (kernels_lroc.hip)
+struct LrocArgs {
+  int64_t n_nodes;
+  int64_t row_stride;
+  int64_t row_begin;
+  int64_t row_end;
+  // node columns: the LVRB columns of spx_trimaran_nodes_soa ...
+  const int64_t* alloc_cpu_milli;
+  const int64_t* alloc_mem;
+  const double* cpu_avg;
+  const double* cpu_std;
+  const double* mem_avg;
+  const double* mem_std;
+  const uint8_t* flags;
+  // ... and spx_lroc_nodes_soa
+  const int64_t* node_req_cpu;
+  const int64_t* node_req_mem;
+  const int64_t* node_lim_cpu;
+  const int64_t* node_lim_mem;
+  // pod columns (spx_lroc_pods_soa)
+  const int64_t* pod_req_cpu;
+  const int64_t* pod_req_mem;
+  const int64_t* pod_lim_cpu;
+  const int64_t* pod_lim_mem;
+  double sqrt_window;   // sqrt(SmoothingWindowSize)
+  double w_cpu, w_mem;  // RiskLimitWeights
+  // per-node table written by launch_lroc_prepare: [8][row_stride] doubles
+  //   0/1: (1 - w) * riskLoad for cpu / memory (slot 0 is NaN for a node without metrics);
+  //   2..7: float64 images of requested / limits / capacity for cpu, then memory
+  double* node_tab;
+  int32_t exact53;      // every integer the sweep touches is in [0, 2^52): float64 sums and differences are exact
+  uint8_t* out_score;   // [n_pods][row_stride]
+};
+void launch_lroc_prepare(const LrocArgs& a, hipStream_t s);
+void launch_lroc(const LrocArgs& a, hipStream_t s);
+
 // ---------------------------------------------------------------- NodeResourceTopologyMatch
 struct NrtArgs {
   int64_t n_nodes;

@@ -91,6 +91,11 @@ class Engine:
                                  safe_variance_sensitivity=sensitivity)
         self._ck(self._lib.spx_set_lvrb_params(self._h, self.lvrb_params.ref()))
 
+    def set_lroc(self, smoothing_window_size: int = 5, w_cpu: float = 0.5, w_mem: float = 0.5):
+        self.lroc_params = Table(self._hdr, "spx_lroc_params", smoothing_window_size=smoothing_window_size,
+                                 risk_limit_weight_cpu=w_cpu, risk_limit_weight_mem=w_mem)
+        self._ck(self._lib.spx_set_lroc_params(self._h, self.lroc_params.ref()))
+
     # ------------------------------------------------------------------ flatten (host C++) + upload
     def flatten_alloc_nodes(self, nodes: Table, rc: Optional[Table]) -> np.ndarray:
         n = nodes.struct.n_nodes
@@ -148,6 +153,36 @@ class Engine:
         self.upload_alloc_nodes(self.flatten_alloc_nodes(nodes, rc))
         self.upload_trimaran_nodes(self.flatten_trimaran_nodes(nodes, metrics, assigned))
         self.upload_trimaran_pods(self.flatten_trimaran_pods(pods))
+
+    # ------------------------------------------------------------------ LowRiskOverCommitment
+    _LROC_COLS = ("req_cpu_milli", "req_mem", "lim_cpu_milli", "lim_mem")
+
+    def flatten_lroc_nodes(self, nodes: Table, node_pods: Optional[Table]) -> Dict[str, np.ndarray]:
+        cols = {k: np.zeros(nodes.struct.n_nodes, np.int64) for k in self._LROC_COLS}
+        i64p = C.POINTER(C.c_int64)
+        self._ck(self._lib.spx_flatten_lroc_nodes(nodes.ref(), node_pods.ref() if node_pods else None,
+                                                   *[v.ctypes.data_as(i64p) for v in cols.values()]))
+        return cols
+
+    def flatten_lroc_pods(self, pods: Table) -> Dict[str, np.ndarray]:
+        cols = {k: np.zeros(pods.struct.n_pods, np.int64) for k in self._LROC_COLS}
+        i64p = C.POINTER(C.c_int64)
+        self._ck(self._lib.spx_flatten_lroc_pods(pods.ref(), *[v.ctypes.data_as(i64p) for v in cols.values()]))
+        return cols
+
+    def upload_lroc_nodes(self, cols: Dict[str, np.ndarray]) -> None:
+        t = Table(self._hdr, "spx_lroc_nodes_soa", n_nodes=len(cols["req_mem"]), **cols)
+        self._ck(self._lib.spx_upload_lroc_nodes(self._h, t.ref()))
+
+    def upload_lroc_pods(self, cols: Dict[str, np.ndarray]) -> None:
+        t = Table(self._hdr, "spx_lroc_pods_soa", n_pods=len(cols["req_mem"]), **cols)
+        self._ck(self._lib.spx_upload_lroc_pods(self._h, t.ref()))
+        self.n_pods = len(cols["req_mem"])
+
+    def load_lroc_objects(self, nodes: Table, node_pods: Optional[Table], pods: Table) -> None:
+        """LowRiskOverCommitment's own tables; the trimaran node table (metrics, allocatable) must be loaded already."""
+        self.upload_lroc_nodes(self.flatten_lroc_nodes(nodes, node_pods))
+        self.upload_lroc_pods(self.flatten_lroc_pods(pods))
 
     # ------------------------------------------------------------------ NodeResourceTopologyMatch
     def load_nrt_objects(self, nodes: Table, nrt: Table, rc: Optional[Table], pods: Table, params: Table) -> None:

@@ -152,6 +152,19 @@ def synth_assigned(hdr: Header, n_nodes: int, seed: int = SEED, window_end: int 
                  e_pod=np.arange(n_e, dtype=np.int32), pods=pods)
 
 
+def synth_node_pods(hdr: Header, n_nodes: int, seed: int = SEED, max_pods: int = 12) -> Table:
+    """framework.NodeInfo.GetPods(): 0..max_pods-1 pods already running per node, drawn like the pending pods (so a
+    share of Burstable pods carries cpu limits of twice the request: small nodes end up over-committed on limits, large
+    ones do not — both sides of lowriskovercommitment.go:206)."""
+    rng = np.random.default_rng(seed + 5)
+    cnt = rng.integers(0, max_pods, n_nodes)
+    p_ptr = np.zeros(n_nodes + 1, dtype=np.int32)
+    np.cumsum(cnt, out=p_ptr[1:])
+    n_p = int(p_ptr[-1])
+    return Table(hdr, "spx_node_pods_objects", p_ptr=p_ptr, p_pod=np.arange(n_p, dtype=np.int32),
+                 pods=synth_pods(hdr, max(n_p, 1), seed=seed + 55))
+
+
 def resource_classes(hdr: Header, flags: Optional[np.ndarray] = None) -> Table:
     if flags is None:
         flags = np.zeros(8, dtype=np.uint8)
@@ -159,15 +172,20 @@ def resource_classes(hdr: Header, flags: Optional[np.ndarray] = None) -> Table:
     return Table(hdr, "spx_resource_classes", n_res=len(flags), flags=flags)
 
 
-def trimaran_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, round_frac: float = 0.0) -> Dict[str, Table]:
-    """Object tables for BASELINE.json config #2 (Allocatable + TargetLoadPacking [+ LVRB])."""
-    return {
+def trimaran_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, round_frac: float = 0.0,
+                      with_node_pods: bool = False) -> Dict[str, Table]:
+    """Object tables for BASELINE.json config #2 (Allocatable + TargetLoadPacking [+ LVRB]); with_node_pods adds the pods
+    already running on every node, which LowRiskOverCommitment sums."""
+    snap = {
         "nodes": synth_nodes(hdr, n_nodes, seed),
         "pods": synth_pods(hdr, n_pods, seed),
         "metrics": synth_metrics(hdr, n_nodes, seed, round_frac=round_frac),
         "assigned": synth_assigned(hdr, n_nodes, seed),
         "rc": resource_classes(hdr),
     }
+    if with_node_pods:
+        snap["node_pods"] = synth_node_pods(hdr, n_nodes, seed)
+    return snap
 
 
 # ------------------------------------------------------------------ NodeResourceTopology (config #3)

@@ -88,3 +88,16 @@ NODE_REQUESTS_LIMITS = [
          want=dict(req_cpu=1500, req_mem=2048, lim_cpu=1500, lim_mem=3072, req_minus_pod_cpu=0, req_minus_pod_mem=0,
                    lim_minus_pod_cpu=0, lim_minus_pod_mem=0, cap_cpu=1600, cap_mem=6144)),
 ]
+
+
+def _pod(rc, rm, lc, lm):
+    return {"containers": [{"requests": {"cpu": f"{rc}m", "memory": rm}, "limits": {"cpu": f"{lc}m", "memory": lm}}]}
+
+
+# the same two fixtures rebuilt as pods, so that they can run through Score(): pods already on node_A whose sums are the
+# *MinusPod fields, and a pending pod that brings NodeRequest / NodeLimit to the fixture's totals.
+# rank = 1 - max(riskCPU, riskMemory) (lowriskovercommitment.go:165), score = round(100 * rank)
+COMPUTE_RISK_AS_PODS = [
+    dict(name="nrla_A1", on_node=[_pod(1000, 0, 2000, 0)], pod=_pod(1000, 2048, 1000, 6144), risk=(0.5, 0.25), score=50),
+    dict(name="nrla_A2", on_node=[_pod(3000, 512, 4000, 6144)], pod=_pod(1000, 512, 1000, 1024), risk=(1.0, 0.75), score=0),
+]

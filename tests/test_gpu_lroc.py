@@ -1,0 +1,134 @@
+"""GPU parity (through the C ABI) for trimaran LowRiskOverCommitment.
+
+Bar: scores within +-1 of the oracle (the special functions of the per-node riskLoad run on device libm; everything
+per cell is the reference's float64 arithmetic), and bit-equal almost everywhere."""
+import numpy as np
+import pytest
+
+from golden import lroc as GL
+from helpers import ALLOCATABLE, LROC, TLP, lroc_params
+from scheduler_plugins_amd import objects as O
+from scheduler_plugins_amd import synth
+from scheduler_plugins_amd.engine import Engine, mask_of
+
+pytestmark = pytest.mark.gpu
+
+
+def load(e, snap, **params):
+    e.set_lroc(**params)
+    e.upload_trimaran_nodes(e.flatten_trimaran_nodes(snap["nodes"], snap["metrics"], snap.get("assigned")))
+    e.load_lroc_objects(snap["nodes"], snap.get("node_pods"), snap["pods"])
+
+
+def oracle_scores(oracle, hdr, snap, rows=None, **params):
+    s = oracle.Snapshot(snap["nodes"], snap["pods"], metrics=snap["metrics"], node_pods=snap.get("node_pods"),
+                        lroc_params=lroc_params(hdr, **params))
+    if rows is None:
+        return s.score_rows(LROC, threads=8)[0]
+    return np.stack([s.score_rows(LROC, r, r + 1)[0][0] for r in rows])
+
+
+@pytest.mark.parametrize("case", GL.SCORE_CASES, ids=lambda c: f"L{c['line']}")
+def test_score_golden(gpu_required, hdr, case):
+    res = O.Resources()
+    snap = dict(nodes=O.build_node_objects(hdr, res, [O.node(case["node"])]), pods=O.build_pod_objects(hdr, res, [case["pod"]]),
+                metrics=O.build_metrics_objects(hdr, 1, case["metrics"]), node_pods=O.build_node_pods_objects(hdr, res, 1, {}))
+    with Engine(0) as e:
+        load(e, snap)
+        e.eval(mask_of(LROC))
+        e.sync()
+        assert e.scores(LROC, 0).tolist() == case["expected"]
+
+
+@pytest.mark.parametrize("case", GL.COMPUTE_RISK_AS_PODS, ids=lambda c: c["name"])
+def test_compute_risk_golden_through_the_sweep(gpu_required, hdr, case):
+    """lowriskovercommitment_test.go:341-395 rebuilt as pods (tests/golden/lroc.py): node_A, no load deviation"""
+    res = O.Resources()
+    snap = dict(nodes=O.build_node_objects(hdr, res, [O.node(GL.NODE_A)]), pods=O.build_pod_objects(hdr, res, [case["pod"]]),
+                metrics=O.build_metrics_objects(hdr, 1, {0: GL.METRICS_A}),
+                node_pods=O.build_node_pods_objects(hdr, res, 1, {0: case["on_node"]}))
+    with Engine(0) as e:
+        load(e, snap)
+        e.eval(mask_of(LROC))
+        e.sync()
+        assert e.scores(LROC, 0).tolist() == [case["score"]]
+
+
+@pytest.mark.parametrize("generic", [False, True], ids=["float64", "int64"])
+@pytest.mark.parametrize("seed,n_nodes,n_pods,params", [
+    (1, 700, 130, {}), (2, 257, 64, dict(smoothing_window_size=1, w_cpu=0.0, w_mem=1.0)), (3, 1500, 70, dict(smoothing_window_size=12, w_cpu=0.9, w_mem=0.2))])
+def test_parity_with_oracle(gpu_required, hdr, oracle, monkeypatch, generic, seed, n_nodes, n_pods, params):
+    if generic:
+        monkeypatch.setenv("SPX_LROC_GENERIC", "1")
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=seed, round_frac=0.1, with_node_pods=True)
+    want = oracle_scores(oracle, hdr, snap, **params)
+    with Engine(0) as e:
+        load(e, snap, **params)
+        assert e.kernel_path(LROC) == (0 if generic else 1)
+        e.eval(mask_of(LROC))
+        e.sync()
+        got = e.all_scores(LROC).astype(np.int64)
+    diff = np.abs(got - want)
+    assert diff.max() <= 1, int(diff.max())
+    assert (diff != 0).mean() < 1e-3, float((diff != 0).mean())
+    assert want.min() == 0 and want.max() > 50  # the snapshot exercises both ends
+
+
+def test_wide_values_take_the_int64_form(gpu_required, hdr, oracle):
+    """quantities at or above 2^52 cannot use the float64 images: the engine must select the int64 arithmetic"""
+    res = O.Resources()
+    big = 1 << 55
+    nodes = O.build_node_objects(hdr, res, [O.node({"cpu": "64000m", "memory": big}), O.node({"cpu": "8000m", "memory": big // 3})])
+    pods = O.build_pod_objects(hdr, res, [{"containers": [O.container({"cpu": "500m", "memory": big // 7}, {"cpu": "9000m", "memory": big // 2 + 12345})]},
+                                          {"containers": [O.container({"cpu": "100m", "memory": 1 << 20}, {})]}])
+    on = {0: [{"containers": [O.container({"cpu": "1000m", "memory": big // 5}, {"cpu": "2000m", "memory": big - 77})]}]}
+    snap = dict(nodes=nodes, pods=pods, metrics=O.build_metrics_objects(hdr, 2, {0: [("CPU", "AVG", 30), ("CPU", "STD", 4), ("Memory", "AVG", 55), ("Memory", "STD", 9)],
+                                                                                 1: [("CPU", "AVG", 70), ("Memory", "Latest", 20)]}),
+                node_pods=O.build_node_pods_objects(hdr, res, 2, on))
+    want = oracle_scores(oracle, hdr, snap)
+    with Engine(0) as e:
+        load(e, snap)
+        assert e.kernel_path(LROC) == 0
+        e.eval(mask_of(LROC))
+        e.sync()
+        got = e.all_scores(LROC).astype(np.int64)
+    assert np.abs(got - want).max() <= 1
+
+
+def test_profile_argmax_with_lroc(gpu_required, hdr, oracle):
+    """LROC's table takes part in the weighted argmax like any other score plugin"""
+    snap = synth.trimaran_snapshot(hdr, 400, 50, seed=9, with_node_pods=True)
+    with Engine(0) as e:
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        e.set_lroc()
+        e.load_lroc_objects(snap["nodes"], snap["node_pods"], snap["pods"])
+        e.set_plugin_weights({ALLOCATABLE: 1, TLP: 2, LROC: 3})
+        mask = mask_of(ALLOCATABLE, TLP, LROC)
+        e.eval(mask)
+        e.eval_best(mask)
+        node, score, ties, feas = e.best()
+        total = e.all_scores(ALLOCATABLE).astype(np.int64) + 2 * e.all_scores(TLP).astype(np.int64) + 3 * e.all_scores(LROC).astype(np.int64)
+    assert (score == total.max(axis=1)).all()
+    assert (node == total.argmax(axis=1)).all()
+
+
+def test_config2_sized_rows_match_oracle(gpu_required, hdr, oracle):
+    """BASELINE config #2 shape (10k pods x 100k nodes): sampled rows against the oracle, and the structural zeros"""
+    n_nodes, n_pods = 100_000, 10_000
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, with_node_pods=True)
+    rows = [0, 4999, 9999]
+    want = oracle_scores(oracle, hdr, snap, rows=rows)
+    with Engine(0) as e:
+        load(e, snap)
+        pcols = e.flatten_lroc_pods(snap["pods"])
+        e.eval(mask_of(LROC))
+        e.sync()
+        got = np.stack([e.scores(LROC, r) for r in rows]).astype(np.int64)
+        best_effort = np.flatnonzero((pcols["req_cpu_milli"] == 0) & (pcols["req_mem"] == 0) & (pcols["lim_cpu_milli"] == 0) & (pcols["lim_mem"] == 0))
+        assert len(best_effort) > 0
+        assert not e.scores(LROC, int(best_effort[0])).any()
+        flags = e.flatten_trimaran_nodes(snap["nodes"], snap["metrics"], snap["assigned"])["lv_flags"]
+        some = e.scores(LROC, 17)
+        assert not some[(flags & 1) == 0].any()
+    diff = np.abs(got - want)
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3

@@ -112,3 +112,20 @@ def test_node_requests_and_limits(hdr, oracle, case):
     out = oracle.header().structs["orc_node_requests_limits"]()
     oracle.lib().orc_node_requests_and_limits(nodes.ref(), node_pods.ref(), 0, rl, C.byref(out))
     assert {k: getattr(out, k) for k in case["want"]} == case["want"]
+
+
+@pytest.mark.parametrize("case", GL.COMPUTE_RISK_AS_PODS, ids=lambda c: c["name"])
+def test_compute_risk_fixtures_through_score(hdr, oracle, case):
+    res = O.Resources()
+    nodes = O.build_node_objects(hdr, res, [O.node(GL.NODE_A)])
+    pods = O.build_pod_objects(hdr, res, [case["pod"]])
+    node_pods = O.build_node_pods_objects(hdr, res, 1, {0: case["on_node"]})
+    snap = oracle.Snapshot(nodes, pods, metrics=O.build_metrics_objects(hdr, 1, {0: GL.METRICS_A}), node_pods=node_pods,
+                           lroc_params=lroc_params(hdr))
+    assert snap.score_rows(LROC)[0][0].tolist() == [case["score"]]
+    # and the intermediate sums are the fixture's
+    rl = (C.c_int64 * 4)(*pod_rl(oracle, pods))
+    out = oracle.header().structs["orc_node_requests_limits"]()
+    oracle.lib().orc_node_requests_and_limits(nodes.ref(), node_pods.ref(), 0, rl, C.byref(out))
+    want = GL.NRLA_A1 if case["name"] == "nrla_A1" else GL.NRLA_A2
+    assert {k: getattr(out, k) for k in want} == want
