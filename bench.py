@@ -34,6 +34,11 @@ WORKLOADS = {
                     desc="noderesources.Allocatable + trimaran.TargetLoadPacking, 10k nodes x 100k pods"),
     "config2_lvrb": dict(n_nodes=10_000, n_pods=100_000, plugins=("alloc", "tlp", "lvrb"), node_row=90, pod_row=24, out=3,
                          desc="Allocatable + TargetLoadPacking + LoadVariationRiskBalancing, 10k x 100k"),
+    # LowRiskOverCommitment alone: node_row = 4 int64 sums + the 7 LVRB columns (49 B), pod_row = 4 int64
+    "config2_lroc": dict(n_nodes=10_000, n_pods=100_000, plugins=("lroc",), node_row=81, pod_row=32, out=1,
+                         desc="trimaran.LowRiskOverCommitment, 10k nodes x 100k pods"),
+    "config2_peaks": dict(n_nodes=10_000, n_pods=100_000, plugins=("peaks",), node_row=33, pod_row=8, out=1,
+                          desc="trimaran.Peaks (Score + NormalizeScore), 10k nodes x 100k pods"),
     "config3": dict(n_nodes=5_000, n_pods=50_000, plugins=("nrt",), node_row=324, pod_row=100, out=2, strategy="LeastAllocated",
                     desc="noderesourcetopology Filter+Score (LeastAllocated), 5k nodes x 8 NUMA zones x 50k pods"),
     "config3_leastnuma": dict(n_nodes=5_000, n_pods=50_000, plugins=("nrt",), node_row=324, pod_row=100, out=2, strategy="LeastNUMANodes",
@@ -61,7 +66,8 @@ def cpu_baseline(spx, snap, e, plugins, budget_s: float):
     osnap = pyoracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], metrics=snap.get("metrics"), assigned=snap.get("assigned"),
                               alloc_params=e.alloc_params, tlp_params=e.tlp_params, lvrb_params=e.lvrb_params,
                               nrt=snap.get("nrt"), nrt_params=snap.get("nrt_params"), appgroups=snap.get("appgroups"),
-                              nettopo=snap.get("nettopo"))
+                              nettopo=snap.get("nettopo"), node_pods=snap.get("node_pods"), lroc_params=getattr(e, "lroc_params", None),
+                              power_models=snap.get("power_models"))
     cores = os.cpu_count() or 1
     n_nodes = osnap.n_nodes
 
@@ -136,7 +142,7 @@ def main() -> None:
     if args.plugins:
         w["plugins"] = tuple(args.plugins.split(","))
         w["out"] = len(w["plugins"])
-    pid = {"alloc": ALLOCATABLE, "tlp": TLP, "lvrb": LVRB, "nrt": NRT, "net": 4, "cap": 5}
+    pid = {"alloc": ALLOCATABLE, "tlp": TLP, "lvrb": LVRB, "nrt": NRT, "net": 4, "cap": 5, "lroc": 7, "peaks": 8}
     plugins = [pid[p] for p in w["plugins"]]
     mask = mask_of(*plugins)
     n_nodes, n_pods = w["n_nodes"], w["n_pods"]
@@ -162,10 +168,16 @@ def main() -> None:
         snap = synth.network_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED + 1000 * rank)
         e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
     else:
-        snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED, round_frac=args.round_frac)
+        snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED, round_frac=args.round_frac, with_node_pods="lroc" in w["plugins"])
         if rank:
             snap["pods"] = synth.synth_pods(hdr, n_pods, seed=synth.SEED + 1000 * rank)
         e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        if "peaks" in w["plugins"]:
+            snap["power_models"] = synth.synth_power_models(hdr, n_nodes, synth.SEED)
+            e.load_peaks_objects(snap["nodes"], snap["metrics"], snap["power_models"], snap["pods"])
+        if "lroc" in w["plugins"]:
+            e.set_lroc()
+            e.load_lroc_objects(snap["nodes"], snap["node_pods"], snap["pods"])
 
     def barrier():
         if dist is not None:
@@ -209,7 +221,7 @@ def main() -> None:
     # SURVEY §8d(ii) "full-cycle ms": snapshot delta (host flatten + H2D of the SoA columns) + sweep + device-side
     # per-row argmax + D2H of the per-pod decisions — measured once, outside the timed region, wall clock
     full_cycle = None
-    if args.workload.startswith("config2") and not args.plugins:
+    if args.workload in ("config2", "config2_lvrb") and not args.plugins:
         try:
             barrier()
             c0 = time.perf_counter()
@@ -283,14 +295,15 @@ def main() -> None:
         "vs_baseline": None,
         # the arithmetic the sweep computes in (results are bit-exact against the reference's float64 / int64 either way):
         # TLP/LVRB float32 with a per-cell exactness proof and a float64 fallback, NRT float64 (exact integers), NetworkOverhead int32
-        "dtype": {"nrt": "f64", "net": "i32", "cap": "f32+f64+i32"}.get(w["plugins"][0], "f32+f64"),
+        "dtype": {"nrt": "f64", "net": "i32", "cap": "f32+f64+i32", "lroc": "f64", "peaks": "f64"}.get(w["plugins"][0], "f32+f64"),
         "data": "synthetic",
         "config": {"workload": w["desc"], "n_nodes": n_nodes, "n_pods_per_gpu": n_pods, "plugins": list(w["plugins"]),
                    "sharding": "pod rows per rank, node tables replicated, no data-path collective",
                    "result_tables": "uint8 [pods][nodes] per plugin, resident in HBM"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": {"nrt": "spx::k_nrt_fast (LeastAllocated: Filter launch + Score launch, both counted)", "net": "spx::k_net_cls",
+                     "kernel": {"nrt": "spx::k_nrt_fast (LeastAllocated: Filter launch + Score launch, both counted)", "net": "spx::k_net_cls", "lroc": "spx::k_lroc<float64 form> (VALU-bound: two float64 divisions per cell)",
+                                "peaks": "spx::k_peaks<min/max pass> + spx::k_peaks<write pass> (VALU-bound: division + exp per cell and pass)",
                                 "cap": "full profile: k_quota, k_nrt_fast x2, k_net_cls, k_tlp_fast2, k_lvrb_fast, k_alloc_masked"}.get(
                          w["plugins"][0], "spx::k_tlp_fast2 (Allocatable+TLP)" + (" + spx::k_lvrb_fast" if "lvrb" in w["plugins"] else "")),
                      "kernel_ms": kern_ms,

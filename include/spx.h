@@ -177,6 +177,14 @@ typedef struct spx_node_pods_objects {
   const spx_pod_objects* pods;
 } spx_node_pods_objects;
 
+/* PeaksArgs.NodePowerModel image (apis/config/types.go:309-324): the power model of node n as getPowerModel resolves it by
+ * node name (peaks.go:190-196); all three are 0 for a node without an entry */
+typedef struct spx_power_model_objects {
+  const double* k0;
+  const double* k1;
+  const double* k2;
+} spx_power_model_objects;
+
 /* NodeResourceTopology CR image per node plus the NRT cache's verdict for it
  * (pkg/noderesourcetopology/cache: GetCachedNRTCopy -> (nrt, CachedNRTInfo{Fresh})).
  * legacy_policy encodes TopologyPolicies[0] (nodeconfig/topologymanager.go:131-162) as
@@ -366,6 +374,24 @@ typedef struct spx_lroc_pods_soa {
   const int64_t* lim_mem;
 } spx_lroc_pods_soa;
 
+/* Peaks.  cpu_util is the FIRST cpu metric whose operator is AVG or Latest (peaks.go:117-126; TLP takes
+ * the last one, LVRB prefers AVG — three different selections); valid = the node has metrics and such a
+ * metric exists; cap_cpu_milli is node.Status.Capacity (:131) */
+typedef struct spx_peaks_nodes_soa {
+  int64_t n_nodes;
+  const int64_t* cap_cpu_milli;
+  const double* cpu_util;
+  const uint8_t* valid;
+  const double* k1;
+  const double* k2;
+} spx_peaks_nodes_soa;
+
+/* resource.GetResourceRequestQuantity(pod, cpu).MilliValue() (peaks.go:114-115) */
+typedef struct spx_peaks_pods_soa {
+  int64_t n_pods;
+  const int64_t* cpu_milli;
+} spx_peaks_pods_soa;
+
 /* NodeResourceTopologyMatch.  Resources are renumbered into dense "slots" 0..n_res-1 (the union of
  * what pods request and zones report; slot_res gives the canonical id).  Limits of this build:
  * n_res <= 8, NUMA zones per node <= 8, containers per pod <= 8 (flatten fails beyond them). */
@@ -493,6 +519,8 @@ typedef struct spx_quota_soa {
  *   spx_eval + spx_fetch_scores(TLP)           TargetLoadPacking.Score                 pkg/trimaran/targetloadpacking/targetloadpacking.go:107-187
  *   spx_eval + spx_fetch_scores(LVRB)          LoadVariationRiskBalancing.Score        pkg/trimaran/loadvariationriskbalancing/loadvariationriskbalancing.go:84-122
  *   spx_eval + spx_fetch_scores(LROC)          LowRiskOverCommitment.PreScore + Score  pkg/trimaran/lowriskovercommitment/lowriskovercommitment.go:96-141, :158-255, beta.go:85-191
+ *   spx_eval + spx_fetch_scores(PEAKS)         Peaks.Score + NormalizeScore            pkg/trimaran/peaks/peaks.go:103-144, :150-166, :186-188
+ *   spx_fetch_raw(PEAKS)                       Peaks.Score (raw int64: power jump x 1e15)
  *   spx_eval + spx_fetch_status(NRT)           TopologyMatch.Filter                    pkg/noderesourcetopology/filter.go:179-245
  *   spx_eval + spx_fetch_scores(NRT)           TopologyMatch.Score                     pkg/noderesourcetopology/score.go:62-102
  *   spx_eval + spx_fetch_status(NETOVERHEAD)   NetworkOverhead.PreFilter + Filter      pkg/networkaware/networkoverhead/networkoverhead.go:174-298, :326-359
@@ -539,6 +567,8 @@ int spx_upload_trimaran_pods(spx_engine* e, const spx_trimaran_pods_soa* t);
 /* LowRiskOverCommitment tables; the node table needs spx_upload_trimaran_nodes first (same node count) */
 int spx_upload_lroc_nodes(spx_engine* e, const spx_lroc_nodes_soa* t);
 int spx_upload_lroc_pods(spx_engine* e, const spx_lroc_pods_soa* t);
+int spx_upload_peaks_nodes(spx_engine* e, const spx_peaks_nodes_soa* t);
+int spx_upload_peaks_pods(spx_engine* e, const spx_peaks_pods_soa* t);
 int spx_upload_nrt_slots(spx_engine* e, const spx_nrt_slots* t);
 int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t);
 int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t);
@@ -573,7 +603,8 @@ int spx_score_table(spx_engine* e, int plugin, void** dptr, int64_t* row_stride,
 int spx_bind_score_table(spx_engine* e, int plugin, void* dptr, int64_t row_stride, int64_t n_rows);
 
 /* per-pod weighted argmax over the evaluated plugins: best[k] node indices and their
- * sum_i weight[i]*score_i (upstream selectHost input); infeasible nodes are skipped */
+ * sum_i weight[i]*score_i (upstream selectHost input); infeasible nodes are skipped.
+ * `weights` holds SPX_NUM_PLUGINS entries indexed by plugin id */
 int spx_set_plugin_weights(spx_engine* e, const int64_t* weights);
 int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end);
 /* per pod in [row_begin,row_end): best node (lowest index among ties, -1 when no node is feasible or the pod
@@ -608,6 +639,9 @@ int spx_flatten_trimaran_pods(const spx_pod_objects* pods, const spx_tlp_params*
 /* LowRiskOverCommitment: every output array has one entry per node / per pod */
 int spx_flatten_lroc_nodes(const spx_node_objects* nodes, const spx_node_pods_objects* node_pods, int64_t* req_cpu_milli, int64_t* req_mem, int64_t* lim_cpu_milli, int64_t* lim_mem);
 int spx_flatten_lroc_pods(const spx_pod_objects* pods, int64_t* req_cpu_milli, int64_t* req_mem, int64_t* lim_cpu_milli, int64_t* lim_mem);
+/* Peaks: node arrays sized [N], pod array [P] */
+int spx_flatten_peaks_nodes(const spx_node_objects* nodes, const spx_metrics_objects* metrics, const spx_power_model_objects* models, int64_t* cap_cpu_milli, double* cpu_util, uint8_t* valid, double* k1, double* k2);
+int spx_flatten_peaks_pods(const spx_pod_objects* pods, int64_t* cpu_milli);
 
 /* NRT: builds the dense slot numbering from every resource id pods request or zones report
  * (slot_res/slot_flags/slot_weight sized SPX_NRT_MAX_RES; *n_res_out receives the count) */

@@ -33,6 +33,7 @@ static int64_t score_one(const orc_snapshot* s, int plugin, int64_t pod, int64_t
     case SPX_PLUGIN_LVRB: return orc_lvrb_score(s->nodes, s->metrics, s->pods, s->lvrb_params, pod, node);
     case SPX_PLUGIN_LROC: /* NormalizeScore is a no-op: lowriskovercommitment.go:153-155 */
       return orc_lroc_score(s->nodes, s->node_pods, s->metrics, s->pods, s->lroc_params, pod, node);
+    case SPX_PLUGIN_PEAKS: return orc_peaks_score(s->nodes, s->metrics, s->power_models, s->pods, pod, node);
     case SPX_PLUGIN_NRT: return orc_nrt_score(s->nrt, s->rc, s->pods, s->nrt_params, pod, node); /* no NormalizeScore: score.go:104-106 */
     default: return 0;
   }
@@ -85,6 +86,7 @@ static void* run(void* arg) {
      * (targetloadpacking.go:193-195, loadvariationriskbalancing.go:134-136) */
     if (j->plugin == SPX_PLUGIN_ALLOCATABLE) orc_allocatable_normalize(list, k);
     if (j->plugin == SPX_PLUGIN_NETOVERHEAD) orc_net_normalize(list, k);
+    if (j->plugin == SPX_PLUGIN_PEAKS) orc_peaks_normalize(list, k); /* peaks.go:150-166 */
     if (j->out_norm) {
       memset(j->out_norm + off, 0, sizeof(int64_t) * (size_t)n);
       for (int64_t i = 0; i < k; ++i) j->out_norm[off + (size_t)idx[i]] = list[i];

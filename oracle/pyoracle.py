@@ -59,11 +59,12 @@ class Snapshot:
                  tlp_params: Optional[Table] = None, lvrb_params: Optional[Table] = None,
                  nrt: Optional[Table] = None, nrt_params: Optional[Table] = None,
                  appgroups: Optional[Table] = None, nettopo: Optional[Table] = None,
-                 node_pods: Optional[Table] = None, lroc_params: Optional[Table] = None):
+                 node_pods: Optional[Table] = None, lroc_params: Optional[Table] = None,
+                 power_models: Optional[Table] = None):
         h = header()
         self.keep = dict(nodes=nodes, pods=pods, rc=rc, metrics=metrics, assigned=assigned, alloc_params=alloc_params,
                          tlp_params=tlp_params, lvrb_params=lvrb_params, nrt=nrt, nrt_params=nrt_params, appgroups=appgroups, nettopo=nettopo,
-                         node_pods=node_pods, lroc_params=lroc_params)
+                         node_pods=node_pods, lroc_params=lroc_params, power_models=power_models)
         self.struct = h.structs["orc_snapshot"]()
         for k, v in self.keep.items():
             if v is not None:

@@ -85,6 +85,12 @@ double orc_lroc_compute_risk(const spx_node_objects* nodes, const spx_metrics_ob
 int64_t orc_lroc_score(const spx_node_objects* nodes, const spx_node_pods_objects* node_pods, const spx_metrics_objects* metrics,
                        const spx_pod_objects* pods, const spx_lroc_params* p, int64_t pod, int64_t node);
 
+/* ---- trimaran.Peaks (pkg/trimaran/peaks/peaks.go; k8s.io/kubernetes v1.35.7 resource.GetResourceRequestQuantity restated) */
+int64_t orc_get_resource_request_quantity_cpu_milli(const spx_pod_objects* pods, int64_t pod);
+int64_t orc_peaks_score(const spx_node_objects* nodes, const spx_metrics_objects* metrics, const spx_power_model_objects* models,
+                        const spx_pod_objects* pods, int64_t pod, int64_t node);
+void orc_peaks_normalize(int64_t* scores, int64_t n);
+
 /* ---- NodeResourceTopologyMatch (pkg/noderesourcetopology/{filter,score,least_numa,...}.go) */
 int orc_pod_qos(const spx_pod_objects* pods, int64_t pod);
 int orc_include_non_native(const spx_pod_objects* pods, const spx_resource_classes* rc, int64_t pod);
@@ -138,6 +144,7 @@ typedef struct orc_snapshot {
   const spx_nettopo_objects* nettopo;
   const spx_node_pods_objects* node_pods; /* LowRiskOverCommitment */
   const spx_lroc_params* lroc_params;
+  const spx_power_model_objects* power_models; /* Peaks */
 } orc_snapshot;
 
 int orc_score_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t row_end,

@@ -1,0 +1,185 @@
+// kernels_peaks.hip — trimaran Peaks on gfx950.
+//
+// Reference: Peaks.Score pkg/trimaran/peaks/peaks.go:103-144 once per (pod, node) — the jump in node power
+// K1 * (e^(K2 * predicted) - e^(K2 * current)) scaled by 1e15 and truncated to int64 — then Peaks.NormalizeScore
+// (:150-166) once per pod over its node list: min-max rescale to 0..100, inverted (the smallest jump scores 100).
+//
+// The normalisation needs each pod row's min and max before any byte of the row can be written, while the sweeps of this
+// engine keep node state in registers and walk pods (a wave owns 256 nodes x 64 pods).  So the row statistic is gathered
+// across tiles: three launches on the engine stream,
+//   k_peaks_init     row_min / row_max <- +inf / -inf
+//   k_peaks<false>   raw scores of the wave's nodes for each of its pods, reduced over the wave (min, max of the
+//                    feasible nodes), one 64-bit atomic min and max per (tile, pod)
+//   k_peaks<true>    the same raw scores again (recomputing beats storing 8 B per cell), normalised against the row's
+//                    min/max, one byte per cell written.
+// Per cell and pass: one float64 division, one exp, a float64 -> int64 conversion: VALU-bound, like LowRiskOverCommitment.
+// The arithmetic is the reference's, operation for operation; exp is OCML's, so raw scores can differ from a Go
+// evaluation in the last digits (relative ~1e-16) and normalised scores by 1 at an exact truncation boundary.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "spx_internal.h"
+
+namespace spx {
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kPodsPerChunk = 64;
+constexpr int kNpl = 4;  // nodes per lane: one dword of scores (and of each status table) per pod row
+
+template <typename T>
+__device__ __forceinline__ T uload(const T* p) {  // wave-uniform read of immutable input -> scalar load
+  typedef const T __attribute__((address_space(4))) CT;
+  return *reinterpret_cast<CT*>(reinterpret_cast<uintptr_t>(p));
+}
+
+struct NodeP {
+  double cap;       // float64(node.Status.Capacity.Cpu().MilliValue())   peaks.go:132
+  double util_m;    // (util / 100) * cap                                  :133
+  double k1, k2;    // power model                                          :190-196
+  double e_now;     // exp(K2 * util)                                       :187
+  bool valid;       // metrics present and a CPU AVG/Latest metric found   :108-131
+};
+
+__device__ __forceinline__ NodeP load_node(const PeaksArgs& a, int64_t n) {
+  NodeP nd;
+  const bool in = n < a.n_nodes;
+  nd.valid = in && a.valid[n] != 0;
+  nd.cap = in ? static_cast<double>(a.cap_cpu_milli[n]) : 0.0;
+  const double util = in ? a.cpu_util[n] : 0.0;
+  nd.util_m = (util / 100) * nd.cap;
+  nd.k1 = in ? a.k1[n] : 0.0;
+  nd.k2 = in ? a.k2[n] : 0.0;
+  nd.e_now = exp(nd.k2 * util);
+  return nd;
+}
+
+// Peaks.Score for one node given float64(curPodCPUUsage)
+__device__ __forceinline__ int64_t raw_score(const NodeP& nd, double pod_cpu) {
+  double predicted = 0.0;
+  if (nd.cap != 0) predicted = 100 * (nd.util_m + pod_cpu) / nd.cap;  // :135-138
+  const double jump = nd.k1 * (exp(nd.k2 * predicted) - nd.e_now);     // :186-188
+  const int64_t v = static_cast<int64_t>(jump * 1e15);                 // :143
+  return (nd.valid && !(predicted > 100)) ? v : 0;                     // :108-112, :128-131, :139-140
+}
+
+__global__ void k_peaks_init(int64_t* row_min, int64_t* row_max, int64_t row_begin, int64_t row_end) {
+  const int64_t i = row_begin + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < row_end) {
+    row_min[i] = INT64_MAX;
+    row_max[i] = INT64_MIN;
+  }
+}
+
+__device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int m) {
+  const int lo = __shfl_xor(static_cast<int>(v & 0xffffffffll), m);
+  const int hi = __shfl_xor(static_cast<int>(v >> 32), m);
+  return (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+}
+
+// feasibility of the lane's 4 nodes for `pod`: every Filter status table says 0; columns past n_nodes never count
+__device__ __forceinline__ uint32_t infeasible_mask(const PeaksArgs& a, int64_t pod, int64_t node0, bool active) {
+  uint32_t bad = 0;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    if (a.other_status[t] != nullptr && active) bad |= *reinterpret_cast<const uint32_t*>(a.other_status[t] + pod * a.row_stride + node0);
+  }
+  uint32_t m = 0;
+#pragma unroll
+  for (int j = 0; j < kNpl; ++j) {
+    const bool out = !active || node0 + j >= a.n_nodes || ((bad >> (8 * j)) & 0xffu) != 0;
+    m |= (out ? 1u : 0u) << j;
+  }
+  return m;
+}
+
+template <bool kWrite>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks(PeaksArgs a, int n_tiles) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+  const int tile = static_cast<int>(unit % n_tiles);
+  const int64_t chunk = unit / n_tiles;
+  const int64_t pod0 = a.row_begin + chunk * kPodsPerChunk;
+  if (pod0 >= a.row_end) return;  // wave-uniform
+  const int64_t pod1 = (pod0 + kPodsPerChunk < a.row_end) ? pod0 + kPodsPerChunk : a.row_end;
+  const int64_t node0 = (static_cast<int64_t>(tile) * kWave + lane) * kNpl;
+  const bool active = node0 < a.row_stride;  // all 64 lanes stay in the loop: the reduction below shuffles across them
+
+  NodeP nd[kNpl];
+#pragma unroll
+  for (int j = 0; j < kNpl; ++j) nd[j] = load_node(a, active ? node0 + j : a.n_nodes);
+
+  for (int64_t pod = pod0; pod < pod1; ++pod) {
+    const double pod_cpu = static_cast<double>(uload(a.pod_cpu_milli + pod));
+    const uint32_t bad = infeasible_mask(a, pod, node0, active);
+    int64_t raw[kNpl];
+#pragma unroll
+    for (int j = 0; j < kNpl; ++j) raw[j] = raw_score(nd[j], pod_cpu);
+    if constexpr (!kWrite) {
+      int64_t mn = INT64_MAX, mx = INT64_MIN;
+#pragma unroll
+      for (int j = 0; j < kNpl; ++j) {
+        if (!((bad >> j) & 1u)) {
+          mn = raw[j] < mn ? raw[j] : mn;
+          mx = raw[j] > mx ? raw[j] : mx;
+        }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        const int64_t omn = shfl_xor_i64(mn, m), omx = shfl_xor_i64(mx, m);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+      }
+      if (lane == 0 && mn <= mx) {  // at least one feasible node in this tile
+        atomicMin(reinterpret_cast<long long*>(a.row_min + pod), static_cast<long long>(mn));
+        atomicMax(reinterpret_cast<long long*>(a.row_max + pod), static_cast<long long>(mx));
+      }
+    } else {
+      const int64_t mn = uload(a.row_min + pod), mx = uload(a.row_max + pod);
+      uint32_t word = 0;
+      if (!(mn == 0 && mx == 0)) {  // :152-154: all raw scores are 0 and stay 0
+        const double span = static_cast<double>(mx - mn);
+#pragma unroll
+        for (int j = 0; j < kNpl; ++j) {
+          double norm;
+          if (mx != mn) norm = 100.0 * static_cast<double>(raw[j] - mn) / span;  // :158
+          else norm = static_cast<double>(raw[j] - mn);                          // :161
+          const int64_t sc = 100 - static_cast<int64_t>(norm);                   // :159, :162
+          const uint32_t b = ((bad >> j) & 1u) ? 0u : static_cast<uint32_t>(sc < 0 ? 0 : (sc > 100 ? 100 : sc));
+          word |= b << (8 * j);
+        }
+      }
+      if (active) *reinterpret_cast<uint32_t*>(a.out_score + pod * a.row_stride + node0) = word;
+    }
+  }
+}
+
+__global__ void k_peaks_raw(PeaksArgs a) {  // Score() of one pod row as int64 (spx_fetch_raw)
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= a.n_nodes) return;
+  a.out_raw[n] = raw_score(load_node(a, n), static_cast<double>(a.pod_cpu_milli[a.row_begin]));
+}
+
+}  // namespace
+
+void launch_peaks(const PeaksArgs& a, hipStream_t s) {
+  if (a.out_raw != nullptr) {
+    hipLaunchKernelGGL(k_peaks_raw, dim3(static_cast<unsigned>((a.n_nodes + 255) / 256)), dim3(256), 0, s, a);
+    return;
+  }
+  const int64_t rows = a.row_end - a.row_begin;
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(k_peaks_init, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0, s, a.row_min, a.row_max, a.row_begin, a.row_end);
+  const int tile_nodes = kWave * kNpl;
+  const int n_tiles = static_cast<int>((a.row_stride + tile_nodes - 1) / tile_nodes);
+  const int64_t chunks = (rows + kPodsPerChunk - 1) / kPodsPerChunk;
+  const int64_t units = chunks * n_tiles;
+  const unsigned blocks = static_cast<unsigned>((units + kWavesPerBlock - 1) / kWavesPerBlock);
+  hipLaunchKernelGGL((k_peaks<false>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles);
+  hipLaunchKernelGGL((k_peaks<true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles);
+}
+
+}  // namespace spx

@@ -70,6 +70,10 @@ struct spx_engine {
   bool lroc_nodes = false, lroc_pods = false, lroc_tab_ready = false;
   bool lroc_nodes_exact = false, lroc_pods_exact = false, lv_alloc_exact = false;  // all values in [0, 2^52)
 
+  // Peaks
+  DevBuf d_pk_cap, d_pk_util, d_pk_valid, d_pk_k1, d_pk_k2, d_pk_pod, d_pk_min, d_pk_max;
+  bool peaks_nodes = false, peaks_pods = false;
+
   // NodeResourceTopologyMatch
   spx_nrt_params nrt_params{SPX_NRT_LEAST_ALLOCATED, 0, nullptr, nullptr};  // defaults.go:87-90
   int32_t nrt_n_res = 0;
@@ -244,6 +248,19 @@ void fill_lroc(const spx_engine* e, spx::LrocArgs& a) {
   a.w_mem = e->lroc.risk_limit_weight_mem;
   a.node_tab = static_cast<double*>(e->d_lroc_tab.p);
   a.exact53 = lroc_exact53(e) ? 1 : 0;
+}
+
+void fill_peaks(const spx_engine* e, spx::PeaksArgs& a) {
+  a.n_nodes = e->n_nodes;
+  a.row_stride = e->row_stride;
+  a.cap_cpu_milli = static_cast<const int64_t*>(e->d_pk_cap.p);
+  a.cpu_util = static_cast<const double*>(e->d_pk_util.p);
+  a.valid = static_cast<const uint8_t*>(e->d_pk_valid.p);
+  a.k1 = static_cast<const double*>(e->d_pk_k1.p);
+  a.k2 = static_cast<const double*>(e->d_pk_k2.p);
+  a.pod_cpu_milli = static_cast<const int64_t*>(e->d_pk_pod.p);
+  a.row_min = static_cast<int64_t*>(e->d_pk_min.p);
+  a.row_max = static_cast<int64_t*>(e->d_pk_max.p);
 }
 
 void fill_trimaran(const spx_engine* e, spx::TrimaranArgs& a) {
@@ -541,6 +558,33 @@ int spx_upload_lroc_pods(spx_engine* e, const spx_lroc_pods_soa* t) {
   e->lroc_pods_exact = all_below_2p52(t->req_cpu_milli, p) && all_below_2p52(t->req_mem, p) && all_below_2p52(t->lim_cpu_milli, p) &&
                        all_below_2p52(t->lim_mem, p);
   e->lroc_pods = true;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  return SPX_OK;
+}
+
+int spx_upload_peaks_nodes(spx_engine* e, const spx_peaks_nodes_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  int rc = set_nodes(e, t->n_nodes);
+  if (rc) return rc;
+  const size_t n = static_cast<size_t>(t->n_nodes);
+  if ((rc = upload(e, e->d_pk_cap, t->cap_cpu_milli, n * 8))) return rc;
+  if ((rc = upload(e, e->d_pk_util, t->cpu_util, n * 8))) return rc;
+  if ((rc = upload(e, e->d_pk_valid, t->valid, n))) return rc;
+  if ((rc = upload(e, e->d_pk_k1, t->k1, n * 8))) return rc;
+  if ((rc = upload(e, e->d_pk_k2, t->k2, n * 8))) return rc;
+  e->peaks_nodes = true;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  return SPX_OK;
+}
+
+int spx_upload_peaks_pods(spx_engine* e, const spx_peaks_pods_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  int rc = set_pods(e, t->n_pods);
+  if (rc) return rc;
+  if ((rc = upload(e, e->d_pk_pod, t->cpu_milli, static_cast<size_t>(t->n_pods) * 8))) return rc;
+  e->peaks_pods = true;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   return SPX_OK;
 }
@@ -930,10 +974,12 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (!e) return SPX_ERR_ARG;
   SPX_HIP(e, hipSetDevice(e->device));
   const uint32_t known = (1u << SPX_PLUGIN_ALLOCATABLE) | (1u << SPX_PLUGIN_TLP) | (1u << SPX_PLUGIN_LVRB) | (1u << SPX_PLUGIN_NRT) |
-                         (1u << SPX_PLUGIN_NETOVERHEAD) | (1u << SPX_PLUGIN_CAPACITY) | (1u << SPX_PLUGIN_LROC);
+                         (1u << SPX_PLUGIN_NETOVERHEAD) | (1u << SPX_PLUGIN_CAPACITY) | (1u << SPX_PLUGIN_LROC) | (1u << SPX_PLUGIN_PEAKS);
   if (plugin_mask == 0 || (plugin_mask & ~known)) return fail(e, SPX_ERR_ARG, "plugin mask has unsupported bits");
   const bool R = plugin_mask & (1u << SPX_PLUGIN_LROC);
   if (R && !(e->tri_nodes && e->lroc_nodes && e->lroc_pods)) return fail(e, SPX_ERR_STATE, "LowRiskOverCommitment node/pod tables not uploaded");
+  const bool K = plugin_mask & (1u << SPX_PLUGIN_PEAKS);
+  if (K && !(e->peaks_nodes && e->peaks_pods)) return fail(e, SPX_ERR_STATE, "Peaks node/pod tables not uploaded");
   const bool Q = plugin_mask & (1u << SPX_PLUGIN_CAPACITY);
   if (Q && !e->quota) return fail(e, SPX_ERR_STATE, "CapacityScheduling quota tables not uploaded");
   if (e->n_nodes <= 0 && plugin_mask != (1u << SPX_PLUGIN_CAPACITY)) return fail(e, SPX_ERR_STATE, "no node table uploaded");
@@ -958,6 +1004,10 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (R && e->score_stride[SPX_PLUGIN_LROC] != e->row_stride)
     return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
   if (R && (rc = ensure(e, e->d_lroc_tab, static_cast<size_t>(e->row_stride) * 8 * sizeof(double)))) return rc;
+  if (K && (rc = ensure_score_table(e, SPX_PLUGIN_PEAKS))) return rc;
+  if (K && e->score_stride[SPX_PLUGIN_PEAKS] != e->row_stride)
+    return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
+  if (K && ((rc = ensure(e, e->d_pk_min, static_cast<size_t>(e->n_pods) * 8)) || (rc = ensure(e, e->d_pk_max, static_cast<size_t>(e->n_pods) * 8)))) return rc;
   if (N && (rc = ensure(e, e->status[SPX_PLUGIN_NRT], static_cast<size_t>(e->n_pods) * static_cast<size_t>(e->row_stride)))) return rc;
   if (W && (rc = ensure(e, e->status[SPX_PLUGIN_NETOVERHEAD], static_cast<size_t>(e->n_pods) * static_cast<size_t>(e->row_stride)))) return rc;
 
@@ -1055,6 +1105,18 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
       e->lroc_tab_ready = true;
     }
     spx::launch_lroc(la, e->stream);
+    SPX_HIP(e, hipGetLastError());
+  }
+  if (K) {  // after the Filter plugins: NormalizeScore runs over each pod's feasible nodes
+    spx::PeaksArgs ka{};
+    fill_peaks(e, ka);
+    ka.row_begin = row_begin;
+    ka.row_end = row_end;
+    ka.other_status[0] = N ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NRT].p) : nullptr;
+    ka.other_status[1] = W ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NETOVERHEAD].p) : nullptr;
+    ka.other_status[2] = e->ext_mask ? static_cast<const uint8_t*>(e->d_ext_status.p) : nullptr;
+    ka.out_score = static_cast<uint8_t*>(e->score[SPX_PLUGIN_PEAKS].p);
+    spx::launch_peaks(ka, e->stream);
     SPX_HIP(e, hipGetLastError());
   }
   if (A && masked) {
@@ -1218,6 +1280,21 @@ int spx_fetch_raw(spx_engine* e, int plugin, int which, int64_t pod_row, int64_t
     SPX_HIP(e, hipStreamSynchronize(e->stream));
     return SPX_OK;
   }
+  if (plugin == SPX_PLUGIN_PEAKS) {  // Peaks.Score before NormalizeScore: the power jump x 1e15
+    if (!(e->peaks_nodes && e->peaks_pods)) return fail(e, SPX_ERR_STATE, "Peaks node/pod tables not uploaded");
+    if (pod_row < 0 || pod_row >= e->n_pods) return fail(e, SPX_ERR_ARG, "pod_row out of range");
+    if ((rc = ensure(e, e->d_raw_row, bytes))) return rc;
+    spx::PeaksArgs ka{};
+    fill_peaks(e, ka);
+    ka.row_begin = pod_row;
+    ka.row_end = pod_row + 1;
+    ka.out_raw = static_cast<int64_t*>(e->d_raw_row.p);
+    spx::launch_peaks(ka, e->stream);
+    SPX_HIP(e, hipGetLastError());
+    SPX_HIP(e, hipMemcpyAsync(out, e->d_raw_row.p, bytes, hipMemcpyDeviceToHost, e->stream));
+    SPX_HIP(e, hipStreamSynchronize(e->stream));
+    return SPX_OK;
+  }
   if (plugin != SPX_PLUGIN_TLP && plugin != SPX_PLUGIN_LVRB) return fail(e, SPX_ERR_ARG, "raw rows: unsupported plugin");
   if (!(e->tri_nodes && e->tri_pods)) return fail(e, SPX_ERR_STATE, "trimaran node/pod tables not uploaded");
   if (pod_row < 0 || pod_row >= e->n_pods) return fail(e, SPX_ERR_ARG, "pod_row out of range");
@@ -1280,7 +1357,7 @@ int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_
   pa.status[2] = e->ext_mask ? static_cast<const uint8_t*>(e->d_ext_status.p) : nullptr;
   pa.prefilter = (plugin_mask & (1u << SPX_PLUGIN_CAPACITY)) ? static_cast<const uint8_t*>(e->d_q_status.p) : nullptr;
   for (int k = 0; k < SPX_NUM_PLUGINS; ++k) {
-    const bool has_score = k <= SPX_PLUGIN_NETOVERHEAD || k == SPX_PLUGIN_LROC;
+    const bool has_score = k <= SPX_PLUGIN_NETOVERHEAD || k == SPX_PLUGIN_LROC || k == SPX_PLUGIN_PEAKS;
     if ((plugin_mask & (1u << k)) && has_score) {
       if (e->score_stride[k] != e->row_stride) return fail(e, SPX_ERR_STATE, "score table stride differs from the engine row stride");
       pa.score[k] = static_cast<const uint8_t*>(e->score[k].p);

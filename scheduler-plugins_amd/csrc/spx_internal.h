@@ -118,6 +118,26 @@ struct LrocArgs {
 void launch_lroc_prepare(const LrocArgs& a, hipStream_t s);
 void launch_lroc(const LrocArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- Peaks (kernels_peaks.hip)
+struct PeaksArgs {
+  int64_t n_nodes;
+  int64_t row_stride;
+  int64_t row_begin;
+  int64_t row_end;
+  const int64_t* cap_cpu_milli;  // [N] node.Status.Capacity
+  const double* cpu_util;        // [N] percent
+  const uint8_t* valid;          // [N]
+  const double* k1;              // [N] power model
+  const double* k2;
+  const int64_t* pod_cpu_milli;  // [P]
+  const uint8_t* other_status[3];  // Filter plugins' status tables [P][row_stride] (0 = passed), NULL = unused
+  int64_t* row_min;              // [P] scratch: min / max of the raw scores over each pod's feasible nodes
+  int64_t* row_max;
+  uint8_t* out_score;            // [P][row_stride]
+  int64_t* out_raw;              // when set: raw int64 scores of row_begin only, no table writes
+};
+void launch_peaks(const PeaksArgs& a, hipStream_t s);
+
 // ---------------------------------------------------------------- NodeResourceTopologyMatch
 struct NrtArgs {
   int64_t n_nodes;

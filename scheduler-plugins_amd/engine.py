@@ -18,7 +18,8 @@ PLUGINS = {
     "CapacityScheduling": 5,
     "TopologicalSort": 6,
 }
-ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY, TOPOSORT = range(7)
+ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY, TOPOSORT, LROC, PEAKS = range(9)
+NUM_PLUGINS = 9  # SPX_NUM_PLUGINS
 
 
 def mask_of(*plugins: int) -> int:
@@ -184,6 +185,21 @@ class Engine:
         self.upload_lroc_nodes(self.flatten_lroc_nodes(nodes, node_pods))
         self.upload_lroc_pods(self.flatten_lroc_pods(pods))
 
+    # ------------------------------------------------------------------ Peaks
+    def load_peaks_objects(self, nodes: Table, metrics: Table, power_models: Optional[Table], pods: Table) -> None:
+        n, p = nodes.struct.n_nodes, pods.struct.n_pods
+        cols = {"cap_cpu_milli": np.zeros(n, np.int64), "cpu_util": np.zeros(n, np.float64), "valid": np.zeros(n, np.uint8),
+                "k1": np.zeros(n, np.float64), "k2": np.zeros(n, np.float64)}
+        fn = self._lib.spx_flatten_peaks_nodes
+        self._ck(fn(nodes.ref(), metrics.ref(), power_models.ref() if power_models else None,
+                    *[v.ctypes.data_as(t) for v, t in zip(cols.values(), fn.argtypes[3:])]))
+        self._ck(self._lib.spx_upload_peaks_nodes(self._h, Table(self._hdr, "spx_peaks_nodes_soa", n_nodes=n, **cols).ref()))
+        cpu = np.zeros(p, np.int64)
+        self._ck(self._lib.spx_flatten_peaks_pods(pods.ref(), cpu.ctypes.data_as(C.POINTER(C.c_int64))))
+        self._ck(self._lib.spx_upload_peaks_pods(self._h, Table(self._hdr, "spx_peaks_pods_soa", n_pods=p, cpu_milli=cpu).ref()))
+        self.peaks_soa = dict(cols, cpu_milli=cpu)
+        self.n_nodes, self.n_pods = n, p
+
     # ------------------------------------------------------------------ NodeResourceTopologyMatch
     def load_nrt_objects(self, nodes: Table, nrt: Table, rc: Optional[Table], pods: Table, params: Table) -> None:
         """objects -> (host flatten: slots, node zone tables, pod request tables) -> HBM."""
@@ -339,7 +355,7 @@ class Engine:
         self._ck(self._lib.spx_upload_feasible_mask(self._h, mask.ctypes.data_as(C.POINTER(C.c_uint8)), mask.shape[0], mask.shape[1]))
 
     def set_plugin_weights(self, weights: Dict[int, int]) -> None:
-        w = np.ones(7, dtype=np.int64)
+        w = np.ones(NUM_PLUGINS, dtype=np.int64)
         for k, v in weights.items():
             w[k] = v
         self._ck(self._lib.spx_set_plugin_weights(self._h, w.ctypes.data_as(C.POINTER(C.c_int64))))

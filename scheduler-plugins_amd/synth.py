@@ -165,6 +165,17 @@ def synth_node_pods(hdr: Header, n_nodes: int, seed: int = SEED, max_pods: int =
                  pods=synth_pods(hdr, max(n_p, 1), seed=seed + 55))
 
 
+def synth_power_models(hdr: Header, n_nodes: int, seed: int = SEED) -> Table:
+    """PeaksArgs.NodePowerModel: Power = K0 + K1 * e^(K2 * utilisation) with K1, K2 < 0 around the reference's fixture
+    (peaks_test.go:80-86); 5% of the nodes have no entry (getPowerModel then yields the zero model, peaks.go:190-196)."""
+    rng = np.random.default_rng(seed + 6)
+    has = rng.random(n_nodes) >= 0.05
+    k0 = np.where(has, rng.uniform(300, 600, n_nodes), 0.0)
+    k1 = np.where(has, -rng.uniform(40, 160, n_nodes), 0.0)
+    k2 = np.where(has, -rng.uniform(0.02, 0.12, n_nodes), 0.0)
+    return Table(hdr, "spx_power_model_objects", k0=k0, k1=k1, k2=k2)
+
+
 def resource_classes(hdr: Header, flags: Optional[np.ndarray] = None) -> Table:
     if flags is None:
         flags = np.zeros(8, dtype=np.uint8)

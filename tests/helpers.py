@@ -29,5 +29,11 @@ def lroc_params(hdr, smoothing_window_size=5, w_cpu=0.5, w_mem=0.5) -> Table:
     return Table(hdr, "spx_lroc_params", smoothing_window_size=smoothing_window_size, risk_limit_weight_cpu=w_cpu, risk_limit_weight_mem=w_mem)
 
 
+def power_models(hdr, models) -> Table:
+    """models: one dict {"k0","k1","k2"} or None per node (getPowerModel returns the zero model for an unknown node)"""
+    g = lambda k: np.array([(m or {}).get(k, 0.0) for m in models], dtype=np.float64)
+    return Table(hdr, "spx_power_model_objects", k0=g("k0"), k1=g("k1"), k2=g("k2"))
+
+
 def make_node_info(milli_cpu: int, memory: int) -> dict:  # allocatable_test.go:315-331
     return O.node({"cpu": f"{milli_cpu}m", "memory": memory})

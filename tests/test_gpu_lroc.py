@@ -113,10 +113,10 @@ def test_profile_argmax_with_lroc(gpu_required, hdr, oracle):
 
 
 def test_config2_sized_rows_match_oracle(gpu_required, hdr, oracle):
-    """BASELINE config #2 shape (10k pods x 100k nodes): sampled rows against the oracle, and the structural zeros"""
-    n_nodes, n_pods = 100_000, 10_000
+    """BASELINE config #2 shape (10k nodes x 100k pods): sampled rows against the oracle, and the structural zeros"""
+    n_nodes, n_pods = 10_000, 100_000
     snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, with_node_pods=True)
-    rows = [0, 4999, 9999]
+    rows = [0, 49_999, 99_999]
     want = oracle_scores(oracle, hdr, snap, rows=rows)
     with Engine(0) as e:
         load(e, snap)
