@@ -66,7 +66,7 @@ struct spx_engine {
 
   // LowRiskOverCommitment (reads the LVRB node columns above as well)
   spx_lroc_params lroc{5, 0.5, 0.5};  // apis/config/v1/defaults.go:72-80
-  DevBuf d_lroc_nreq_c, d_lroc_nreq_m, d_lroc_nlim_c, d_lroc_nlim_m, d_lroc_preq_c, d_lroc_preq_m, d_lroc_plim_c, d_lroc_plim_m, d_lroc_tab;
+  DevBuf d_lroc_nreq_c, d_lroc_nreq_m, d_lroc_nlim_c, d_lroc_nlim_m, d_lroc_preq_c, d_lroc_preq_m, d_lroc_plim_c, d_lroc_plim_m, d_lroc_tab, d_lroc_podf;
   bool lroc_nodes = false, lroc_pods = false, lroc_tab_ready = false;
   bool lroc_nodes_exact = false, lroc_pods_exact = false, lv_alloc_exact = false;  // all values in [0, 2^52)
 
@@ -248,6 +248,8 @@ void fill_lroc(const spx_engine* e, spx::LrocArgs& a) {
   a.w_mem = e->lroc.risk_limit_weight_mem;
   a.node_tab = static_cast<double*>(e->d_lroc_tab.p);
   a.exact53 = lroc_exact53(e) ? 1 : 0;
+  a.pod_f64 = (a.exact53 && getenv("SPX_LROC_F64") == nullptr) ? static_cast<const double*>(e->d_lroc_podf.p) : nullptr;
+  a.n_pods_total = e->n_pods;
 }
 
 void fill_peaks(const spx_engine* e, spx::PeaksArgs& a) {
@@ -557,6 +559,18 @@ int spx_upload_lroc_pods(spx_engine* e, const spx_lroc_pods_soa* t) {
   if ((rc = upload(e, e->d_lroc_plim_m, t->lim_mem, p * 8))) return rc;
   e->lroc_pods_exact = all_below_2p52(t->req_cpu_milli, p) && all_below_2p52(t->req_mem, p) && all_below_2p52(t->lim_cpu_milli, p) &&
                        all_below_2p52(t->lim_mem, p);
+  if (e->lroc_pods_exact) {  // float64 pod records of the fast sweep: limit and limit - request per resource (exact below 2^52)
+    std::vector<double> f(4 * p);
+    for (size_t i = 0; i < p; ++i) {
+      const bool none = t->req_cpu_milli[i] == 0 && t->req_mem[i] == 0 && t->lim_cpu_milli[i] == 0 && t->lim_mem[i] == 0;
+      f[i] = none ? std::nan("") : static_cast<double>(t->lim_cpu_milli[i]);
+      f[p + i] = static_cast<double>(t->lim_cpu_milli[i] - t->req_cpu_milli[i]);
+      f[2 * p + i] = static_cast<double>(t->lim_mem[i]);
+      f[3 * p + i] = static_cast<double>(t->lim_mem[i] - t->req_mem[i]);
+    }
+    if ((rc = upload(e, e->d_lroc_podf, f.data(), f.size() * sizeof(double)))) return rc;
+    SPX_HIP(e, hipStreamSynchronize(e->stream));  // f goes out of scope
+  }
   e->lroc_pods = true;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   return SPX_OK;
@@ -1003,7 +1017,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (R && (rc = ensure_score_table(e, SPX_PLUGIN_LROC))) return rc;
   if (R && e->score_stride[SPX_PLUGIN_LROC] != e->row_stride)
     return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
-  if (R && (rc = ensure(e, e->d_lroc_tab, static_cast<size_t>(e->row_stride) * 8 * sizeof(double)))) return rc;
+  if (R && (rc = ensure(e, e->d_lroc_tab, static_cast<size_t>(e->row_stride) * spx::kLrocTabCols * sizeof(double)))) return rc;
   if (K && (rc = ensure_score_table(e, SPX_PLUGIN_PEAKS))) return rc;
   if (K && e->score_stride[SPX_PLUGIN_PEAKS] != e->row_stride)
     return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
@@ -1202,7 +1216,7 @@ int spx_kernel_path(const spx_engine* e, int plugin) {
                ? 1
                : 0;
   if (plugin == SPX_PLUGIN_NETOVERHEAD) return (e->net_nodes && e->net_class16 && e->net_n_classes > 0 && getenv("SPX_NET_GENERIC") == nullptr) ? 1 : 0;
-  if (plugin == SPX_PLUGIN_LROC) return lroc_exact53(e) ? 1 : 0;
+  if (plugin == SPX_PLUGIN_LROC) return (lroc_exact53(e) && getenv("SPX_LROC_F64") == nullptr) ? 1 : 0;
   if (plugin == SPX_PLUGIN_TLP) return (e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && getenv("SPX_EXACT_ONLY") == nullptr) ? 1 : 0;
   return 0;
 }

@@ -83,6 +83,7 @@ void launch_commit_trimaran(const CommitArgs& c, hipStream_t s);
 void launch_trimaran_raw(const TrimaranArgs& a, int plugin, int64_t pod_row, int64_t* out, hipStream_t s);
 
 // ---------------------------------------------------------------- LowRiskOverCommitment (kernels_lroc.hip)
+constexpr int kLrocTabCols = 14;
 struct LrocArgs {
   int64_t n_nodes;
   int64_t row_stride;
@@ -108,10 +109,15 @@ struct LrocArgs {
   const int64_t* pod_lim_mem;
   double sqrt_window;   // sqrt(SmoothingWindowSize)
   double w_cpu, w_mem;  // RiskLimitWeights
-  // per-node table written by launch_lroc_prepare: [8][row_stride] doubles
+  // per-node table written by launch_lroc_prepare: [kLrocTabCols][row_stride] doubles
   //   0/1: (1 - w) * riskLoad for cpu / memory (slot 0 is NaN for a node without metrics);
-  //   2..7: float64 images of requested / limits / capacity for cpu, then memory
+  //   2..7: float64 images of requested / limits / capacity for cpu, then memory;
+  //   8..13: the fast form's constants (limits - capacity, limits - requested per resource; the two riskLoad terms as float32)
   double* node_tab;
+  // fast form only: [4][n_pods_total] float64 = pod limit and (limit - request) for cpu, then memory, prepared by the engine at
+  // upload when the pod columns are exact; NaN in the first column marks a pod without requests and limits.  NULL = not available
+  const double* pod_f64;
+  int64_t n_pods_total;
   int32_t exact53;      // every integer the sweep touches is in [0, 2^52): float64 sums and differences are exact
   uint8_t* out_score;   // [n_pods][row_stride]
 };

@@ -191,3 +191,64 @@ def test_commit_loop_incremental_constant_tracks_the_float64_value():
             b2h = nb
             rebuilt = (um + missing) - t * cap / 100.0
             assert abs((float(b2h) + float(b2l)) - rebuilt) < 1e-6 + abs(float(np.float32(b - bh)) - (b - bh)), (cap, util, missing)
+
+
+def test_lroc_float32_quotient_is_exact_outside_the_ambiguity_band():
+    """k_lroc_fast (kernels_lroc.hip): over = A + podLimit and den = max(D + d, over) are formed exactly in float64; the
+    quotient, w*q + (1-w)*riskLoad and 100*(1 - max) run in float32 with a 1-ulp reciprocal.  Claim: the float32 value s is
+    within 6e-5 of the reference's float64 value, so a cell whose s is farther than 1.5e-4 from every k + 0.5 rounds to the
+    reference's score.  The reciprocal is emulated pessimistically: correctly rounded, then pushed one ulp either way."""
+    rng = np.random.default_rng(12)
+    n = 400_000
+    f32 = np.float32
+    cap_c = rng.choice(np.array([8, 16, 64, 128], dtype=np.int64), n) * 1000 - rng.integers(500, 2001, n)
+    cap_m = rng.choice(np.array([32, 128, 512, 1024], dtype=np.int64), n) * (1 << 30)
+    nreq_c = (rng.uniform(0, 1.5, n) * cap_c).astype(np.int64)
+    nlim_c = nreq_c + (rng.uniform(0, 1.5, n) * cap_c * (rng.random(n) < 0.7)).astype(np.int64)
+    nreq_m = (rng.uniform(0, 1.3, n) * cap_m).astype(np.int64)
+    nlim_m = nreq_m + (rng.uniform(0, 0.6, n) * cap_m * (rng.random(n) < 0.5)).astype(np.int64)
+    preq_c = rng.integers(0, 9000, n)
+    plim_c = preq_c + rng.integers(0, 9000, n) * (rng.random(n) < 0.5)
+    preq_m = rng.integers(0, 64 << 30, n)
+    plim_m = preq_m + rng.integers(0, 32 << 30, n) * (rng.random(n) < 0.5)
+    # adversarial slice: limits that exceed the capacity by a hair (tiny numerators) and denominators of 1
+    k = n // 20
+    nlim_c[:k] = cap_c[:k] - plim_c[:k] + rng.integers(-3, 4, k)
+    nreq_c[:k] = np.minimum(nreq_c[:k], nlim_c[:k].clip(0))
+    nlim_c[:k] = np.maximum(nlim_c[:k], nreq_c[:k])
+    load_c = rng.choice([0.0, 1.0, 0.5], n, p=[0.3, 0.2, 0.5]) * np.where(rng.random(n) < 0.5, 1.0, rng.random(n))
+    load_m = rng.choice([0.0, 1.0, 0.5], n, p=[0.3, 0.2, 0.5]) * np.where(rng.random(n) < 0.5, 1.0, rng.random(n))
+    for w_c, w_m in [(0.5, 0.5), (0.9, 0.2), (0.0, 1.0), (1.0, 0.0), (0.37, 0.63)]:
+        kl_c, kl_m = (1 - w_c) * load_c, (1 - w_m) * load_m
+
+        def ref(w, kl, nreq, nlim, cap, preq, plim):  # lowriskovercommitment.go:205-208, :250-253 in float64 / int64
+            limit = nlim + plim
+            request = np.minimum(nreq + preq, cap)
+            rl = np.where(limit > cap, (limit - cap).astype(np.float64) / np.maximum(limit - request, 1).astype(np.float64), 0.0)
+            return np.clip(w * rl + kl, 0.0, 1.0)
+
+        s64 = (1 - np.maximum(ref(w_c, kl_c, nreq_c, nlim_c, cap_c, preq_c, plim_c), ref(w_m, kl_m, nreq_m, nlim_m, cap_m, preq_m, plim_m))) * 100.0
+        want = np.floor(s64 + 0.5).astype(np.int64)  # math.Round on a non-negative value
+
+        for bump in (0, 1, -1):
+            def fast(w, kl, nreq, nlim, cap, preq, plim):
+                A, D, d = (nlim - cap).astype(np.float64), (nlim - nreq).astype(np.float64), (plim - preq).astype(np.float64)
+                over = A + plim.astype(np.float64)
+                den = np.maximum(D + d, over)
+                with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+                    rc = f32(1.0) / den.astype(f32)
+                    if bump:
+                        rc = np.nextafter(rc, f32(np.inf) * f32(bump))
+                    q = over.astype(f32) * rc
+                    t = (f32(w) * q.astype(np.float64) + f32(kl).astype(np.float64)).astype(f32)  # one fma: single rounding
+                return np.fmax(t, f32(kl))  # max(fma, kl) == fma(w, max(q, 0), kl); NaN-absorbing like v_max_f32
+
+            m = np.fmax(fast(w_c, kl_c, nreq_c, nlim_c, cap_c, preq_c, plim_c), fast(w_m, kl_m, nreq_m, nlim_m, cap_m, preq_m, plim_m))
+            s32 = (f32(-100.0) * m.astype(np.float64) + 100.0).astype(f32)
+            assert np.abs(s32.astype(np.float64) - s64).max() < 6e-5
+            rr = np.rint(s32)
+            amb = ~(np.abs(s32 - rr) < f32(0.5) - f32(1.5e-4))
+            bad = (~amb) & (rr.astype(np.int64) != want)
+            assert not bad.any(), (w_c, w_m, bump, int(bad.sum()))
+            generic = np.abs(s64 - np.floor(s64) - 0.5) > 1e-9   # cells that do not sit on a boundary by construction (e.g. 0.63 * 0.5)
+            assert amb[generic].mean() < 5e-3, (w_c, w_m, bump, float(amb[generic].mean()))
