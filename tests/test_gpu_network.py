@@ -57,8 +57,10 @@ def test_toposort_queue_order_golden(gpu_required, hdr, case):
         e.load_network_objects(nodes, pods, ag, nt)
         a, b = np.divmod(np.arange(n * n), n)
         less = e.toposort_less(pods, a, b).reshape(n, n)
-    assert not (less & less.T).any()
-    order = np.argsort(less.sum(axis=0), kind="stable")   # a strict total order here: rank = number of predecessors
+    assert less.diagonal().all()                           # Less is orderP1 <= orderP2 (topologicalsort.go:131)
+    off = less & ~np.eye(n, dtype=bool)
+    assert not (off & off.T).any()                         # distinct workloads: a strict total order off the diagonal
+    order = np.argsort(off.sum(axis=0), kind="stable")     # rank = number of predecessors
     assert [case["created"][i] for i in order] == case["popped"]
 
 
