@@ -302,7 +302,7 @@ def main() -> None:
                    "result_tables": "uint8 [pods][nodes] per plugin, resident in HBM"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": {"nrt": "spx::k_nrt_fast (LeastAllocated: Filter launch + Score launch, both counted)", "net": "spx::k_net_cls", "lroc": "spx::k_lroc<float64 form> (VALU-bound: two float64 divisions per cell)",
+                     "kernel": {"nrt": "spx::k_nrt_fast (LeastAllocated: Filter launch + Score launch, both counted)", "net": "spx::k_net_cls", "lroc": "spx::k_lroc_fast (float32 quotient on exact float64 numerator/denominator, float64 fallback; VALU-bound)",
                                 "peaks": "spx::k_peaks<min/max pass> + spx::k_peaks<write pass> (VALU-bound: division + exp per cell and pass)",
                                 "cap": "full profile: k_quota, k_nrt_fast x2, k_net_cls, k_tlp_fast2, k_lvrb_fast, k_alloc_masked"}.get(
                          w["plugins"][0], "spx::k_tlp_fast2 (Allocatable+TLP)" + (" + spx::k_lvrb_fast" if "lvrb" in w["plugins"] else "")),

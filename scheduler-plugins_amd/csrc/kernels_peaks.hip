@@ -12,7 +12,8 @@
 //                    feasible nodes), one 64-bit atomic min and max per (tile, pod)
 //   k_peaks<true>    the same raw scores again (recomputing beats storing 8 B per cell), normalised against the row's
 //                    min/max, one byte per cell written.
-// Per cell and pass: one float64 division, one exp, a float64 -> int64 conversion: VALU-bound, like LowRiskOverCommitment.
+// Per cell and pass: one float64 division, one exp, one trunc (the int64 conversion is never materialised, see raw_score);
+// the write pass adds the normalising division.  VALU-bound, like LowRiskOverCommitment.
 // The arithmetic is the reference's, operation for operation; exp is OCML's, so raw scores can differ from a Go
 // evaluation in the last digits (relative ~1e-16) and normalised scores by 1 at an exact truncation boundary.
 #include <hip/hip_runtime.h>
@@ -28,6 +29,7 @@ constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kPodsPerChunk = 64;
 constexpr int kNpl = 4;  // nodes per lane: one dword of scores (and of each status table) per pod row
+constexpr double kInf = __builtin_huge_val();
 
 template <typename T>
 __device__ __forceinline__ T uload(const T* p) {  // wave-uniform read of immutable input -> scalar load
@@ -35,8 +37,19 @@ __device__ __forceinline__ T uload(const T* p) {  // wave-uniform read of immuta
   return *reinterpret_cast<CT*>(reinterpret_cast<uintptr_t>(p));
 }
 
+// a / b correctly rounded from y = RN(1/b): q = RN(a*y) is within an ulp of the quotient, the residual a - b*q is exact in
+// one fma, and RN(q + r*y) is RN(a/b) (Markstein's theorem; the exception, a divisor whose significand is all ones, cannot
+// occur for the integer-valued divisors used here).  Three full-rate instructions instead of the ~14 of the IEEE division
+// sequence; tests/test_exactness_arguments.py replays it against true division in exact rational arithmetic.
+__device__ __forceinline__ double div_rn(double a, double b, double y) {
+  const double q = a * y;
+  const double r = fma(-b, q, a);
+  return fma(r, y, q);
+}
+
 struct NodeP {
   double cap;       // float64(node.Status.Capacity.Cpu().MilliValue())   peaks.go:132
+  double rcap;      // RN(1 / cap), for div_rn
   double util_m;    // (util / 100) * cap                                  :133
   double k1, k2;    // power model                                          :190-196
   double e_now;     // exp(K2 * util)                                       :187
@@ -49,6 +62,7 @@ __device__ __forceinline__ NodeP load_node(const PeaksArgs& a, int64_t n) {
   nd.valid = in && a.valid[n] != 0;
   nd.cap = in ? static_cast<double>(a.cap_cpu_milli[n]) : 0.0;
   const double util = in ? a.cpu_util[n] : 0.0;
+  nd.rcap = 1.0 / nd.cap;
   nd.util_m = (util / 100) * nd.cap;
   nd.k1 = in ? a.k1[n] : 0.0;
   nd.k2 = in ? a.k2[n] : 0.0;
@@ -56,13 +70,16 @@ __device__ __forceinline__ NodeP load_node(const PeaksArgs& a, int64_t n) {
   return nd;
 }
 
-// Peaks.Score for one node given float64(curPodCPUUsage)
-__device__ __forceinline__ int64_t raw_score(const NodeP& nd, double pod_cpu) {
+// Peaks.Score for one node given float64(curPodCPUUsage), as an integer-valued float64: int64(x) truncates toward zero and
+// |x| < 2^63 here, so trunc(x) is that int64 exactly (a float64 at or above 2^53 is an integer already).  Staying in float64
+// saves the two multi-instruction conversions per cell; differences of two such values taken in float64 are the correctly
+// rounded exact difference, i.e. the very float64(score - minCost) the reference forms (peaks.go:158).
+__device__ __forceinline__ double raw_score(const NodeP& nd, double pod_cpu) {
   double predicted = 0.0;
-  if (nd.cap != 0) predicted = 100 * (nd.util_m + pod_cpu) / nd.cap;  // :135-138
+  if (nd.cap != 0) predicted = div_rn(100 * (nd.util_m + pod_cpu), nd.cap, nd.rcap);  // :135-138
   const double jump = nd.k1 * (exp(nd.k2 * predicted) - nd.e_now);     // :186-188
-  const int64_t v = static_cast<int64_t>(jump * 1e15);                 // :143
-  return (nd.valid && !(predicted > 100)) ? v : 0;                     // :108-112, :128-131, :139-140
+  const double v = trunc(jump * 1e15);                                 // :143
+  return (nd.valid && !(predicted > 100)) ? v : 0.0;                   // :108-112, :128-131, :139-140
 }
 
 __global__ void k_peaks_init(int64_t* row_min, int64_t* row_max, int64_t row_begin, int64_t row_end) {
@@ -73,10 +90,10 @@ __global__ void k_peaks_init(int64_t* row_min, int64_t* row_max, int64_t row_beg
   }
 }
 
-__device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int m) {
-  const int lo = __shfl_xor(static_cast<int>(v & 0xffffffffll), m);
-  const int hi = __shfl_xor(static_cast<int>(v >> 32), m);
-  return (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  const int lo = __shfl_xor(__double2loint(v), m);
+  const int hi = __shfl_xor(__double2hiint(v), m);
+  return __hiloint2double(hi, lo);
 }
 
 // feasibility of the lane's 4 nodes for `pod`: every Filter status table says 0; columns past n_nodes never count
@@ -115,39 +132,40 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks(PeaksArgs a, in
   for (int64_t pod = pod0; pod < pod1; ++pod) {
     const double pod_cpu = static_cast<double>(uload(a.pod_cpu_milli + pod));
     const uint32_t bad = infeasible_mask(a, pod, node0, active);
-    int64_t raw[kNpl];
+    double raw[kNpl];
 #pragma unroll
     for (int j = 0; j < kNpl; ++j) raw[j] = raw_score(nd[j], pod_cpu);
     if constexpr (!kWrite) {
-      int64_t mn = INT64_MAX, mx = INT64_MIN;
+      double mn = kInf, mx = -kInf;
 #pragma unroll
       for (int j = 0; j < kNpl; ++j) {
         if (!((bad >> j) & 1u)) {
-          mn = raw[j] < mn ? raw[j] : mn;
-          mx = raw[j] > mx ? raw[j] : mx;
+          mn = fmin(mn, raw[j]);
+          mx = fmax(mx, raw[j]);
         }
       }
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) {
-        const int64_t omn = shfl_xor_i64(mn, m), omx = shfl_xor_i64(mx, m);
-        mn = omn < mn ? omn : mn;
-        mx = omx > mx ? omx : mx;
+        mn = fmin(mn, shfl_xor_f64(mn, m));
+        mx = fmax(mx, shfl_xor_f64(mx, m));
       }
-      if (lane == 0 && mn <= mx) {  // at least one feasible node in this tile
+      if (lane == 0 && mn <= mx) {  // at least one feasible node in this tile; the values are integers below 2^63
         atomicMin(reinterpret_cast<long long*>(a.row_min + pod), static_cast<long long>(mn));
         atomicMax(reinterpret_cast<long long*>(a.row_max + pod), static_cast<long long>(mx));
       }
     } else {
-      const int64_t mn = uload(a.row_min + pod), mx = uload(a.row_max + pod);
+      const int64_t mni = uload(a.row_min + pod), mxi = uload(a.row_max + pod);
       uint32_t word = 0;
-      if (!(mn == 0 && mx == 0)) {  // :152-154: all raw scores are 0 and stay 0
-        const double span = static_cast<double>(mx - mn);
+      if (!(mni == 0 && mxi == 0)) {  // :152-154: all raw scores are 0 and stay 0
+        const double mn = static_cast<double>(mni);          // exact: it was stored from an integer-valued float64
+        const double span = static_cast<double>(mxi - mni);  // float64(maxCost - minCost)
+        const bool flat = mxi == mni;
+        const double rspan = 1.0 / span;                      // once per pod and wave
 #pragma unroll
         for (int j = 0; j < kNpl; ++j) {
-          double norm;
-          if (mx != mn) norm = 100.0 * static_cast<double>(raw[j] - mn) / span;  // :158
-          else norm = static_cast<double>(raw[j] - mn);                          // :161
-          const int64_t sc = 100 - static_cast<int64_t>(norm);                   // :159, :162
+          const double diff = raw[j] - mn;                   // float64(score - minCost), see raw_score
+          const double norm = flat ? diff : div_rn(100.0 * diff, span, rspan);  // :158, :161
+          const int sc = 100 - static_cast<int>(norm);       // :159, :162 (|norm| <= 100 for a feasible node)
           const uint32_t b = ((bad >> j) & 1u) ? 0u : static_cast<uint32_t>(sc < 0 ? 0 : (sc > 100 ? 100 : sc));
           word |= b << (8 * j);
         }
@@ -160,7 +178,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks(PeaksArgs a, in
 __global__ void k_peaks_raw(PeaksArgs a) {  // Score() of one pod row as int64 (spx_fetch_raw)
   const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (n >= a.n_nodes) return;
-  a.out_raw[n] = raw_score(load_node(a, n), static_cast<double>(a.pod_cpu_milli[a.row_begin]));
+  a.out_raw[n] = static_cast<int64_t>(raw_score(load_node(a, n), static_cast<double>(a.pod_cpu_milli[a.row_begin])));
 }
 
 }  // namespace

@@ -252,3 +252,31 @@ def test_lroc_float32_quotient_is_exact_outside_the_ambiguity_band():
             assert not bad.any(), (w_c, w_m, bump, int(bad.sum()))
             generic = np.abs(s64 - np.floor(s64) - 0.5) > 1e-9   # cells that do not sit on a boundary by construction (e.g. 0.63 * 0.5)
             assert amb[generic].mean() < 5e-3, (w_c, w_m, bump, float(amb[generic].mean()))
+
+
+def test_reciprocal_division_is_correctly_rounded():
+    """k_peaks (kernels_peaks.hip: div_rn) divides by a per-node / per-pod constant through its correctly rounded reciprocal:
+    q = RN(a*y), r = a - b*q (one fma, exact), result RN(q + r*y).  Markstein's theorem says this is RN(a/b); replayed here
+    against true division with exact rationals on the two shapes the kernel uses (predicted utilisation, min-max rescale)."""
+    import random
+    from fractions import Fraction
+    rnd = random.Random(5)
+
+    def div_rn(a, b):
+        y = 1.0 / b
+        q = a * y
+        r = float(Fraction(a) - Fraction(b) * Fraction(q))   # fma(-b, q, a): float(Fraction) rounds correctly
+        return float(Fraction(q) + Fraction(r) * Fraction(y))
+
+    for _ in range(30000):
+        cap = float(rnd.choice([8, 16, 32, 64, 96, 128]) * 1000 - rnd.randint(0, 2000))
+        a = 100 * ((rnd.uniform(0, 100) / 100) * cap + float(rnd.randint(0, 9000)))
+        assert div_rn(a, cap) == a / cap
+    for _ in range(30000):
+        mx = float(rnd.randint(1, 10 ** 17))
+        span = mx - float(rnd.randint(0, int(mx)))
+        if span == 0:
+            continue
+        d = float(rnd.randint(0, int(span)))
+        assert div_rn(100.0 * d, span) == 100.0 * d / span
+        assert div_rn(100.0 * span, span) == 100.0 * span / span   # the row maximum: 100 or 99.99999999999999, as in the reference
