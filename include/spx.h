@@ -213,6 +213,7 @@ typedef struct spx_nrt_objects {
   const int32_t* arl_ptr;
   const int32_t* arl_res;
   const int64_t* arl_qty;
+  const int64_t* zres_allocatable; /* optional (may be NULL), same layout as zres_avail: ResourceInfo.Allocatable; only the eviction simulation reads it */
 } spx_nrt_objects;
 
 /* diktyo AppGroup CRs (appgroup.diktyo.x-k8s.io v1alpha1) as the network-aware plugins read them.
@@ -658,6 +659,24 @@ int spx_flatten_net_topo(const spx_nettopo_objects* nt, int32_t* region_cost, in
 int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int32_t* n_keys_out, int64_t* n_pairs_out, int32_t* pod_key, int32_t* topo_order, uint8_t* key_score_equally, int32_t* pair_ptr, int32_t* pair_node, int64_t* pair_max_cost);
 /* TopologicalSort.Less (topologicalsort.go:102-132) for n pairs of pod indices, from the flattened keys */
 int spx_toposort_less(const spx_pod_objects* pods, const int32_t* topo_order, int64_t n_pairs, const int64_t* a, const int64_t* b, uint8_t* less_out);
+
+/* NRT preemption flow: preemption.GetNRTPostPodsEviction (pkg/noderesourcetopology/preemption/preemption.go:39-157)
+ * for node `node`.  The Filter of a preemption dry-run (filter.go:205-220) is the ordinary Filter on the zone table this call
+ * produces, so a batch of candidate nodes is evaluated by uploading their post-eviction availabilities (spx_upload_nrt_nodes).
+ * `victims` are the victim pods; victim_qos[v] = v1qos.GetPodQOS; ctr_numa has one entry per container row of `victims`
+ * (CSR order): numaplacement.EncodedInfo.NUMAAffinity -> NUMA id >= 0, -1 = no affinity, SPX_EVICT_CTR_UNKNOWN = lookup error.
+ * placement_present = 0 stands for a nil EncodedInfo; placement_containers = EncodedInfo.Containers().
+ * zres_avail_out receives the node's zone-resource availabilities (its slice of nrt->zres_avail, same order) after the
+ * simulation, or unchanged when *code_out != SPX_EVICT_OK — the reference hands the original NRT back on every error. */
+#define SPX_EVICT_OK 0
+#define SPX_EVICT_NO_NRT 1                /* "NRT not found, cannot process eviction simulation"                    :41 */
+#define SPX_EVICT_NO_VICTIMS 2            /* "no victims found, cannot process eviction simulation"                  :45 */
+#define SPX_EVICT_NO_PLACEMENT 3          /* "numa placement info not found, cannot process eviction simulation"    :49 */
+#define SPX_EVICT_NO_CONTAINERS 4         /* "no containers found in numa placement info, cannot process ..."       :53 */
+#define SPX_EVICT_NOTHING_TO_ADD 5        /* "no resources to add, cannot process eviction simulation"               :62 */
+#define SPX_EVICT_EXCEEDS_ALLOCATABLE 6   /* "resource release request exceeds NUMA allocatable"                     :147 */
+#define SPX_EVICT_CTR_UNKNOWN (-2)
+int spx_nrt_post_eviction(const spx_nrt_objects* nrt, const spx_resource_classes* rc, int64_t node, const spx_pod_objects* victims, const uint8_t* victim_qos, const int32_t* ctr_numa, int32_t placement_present, int32_t placement_containers, int64_t* zres_avail_out, int32_t* code_out);
 
 /* CapacityScheduling: sizes are pod_req[P*8], pod_req_present[P]; the per-namespace arrays [NS*8] / [NS];
  * agg_*[8] / [1]; other_nominated[NS*8]: nominated requests of OTHER namespaces whose quota is not over min

@@ -679,3 +679,71 @@ void orc_nrt_test_subtract_numas(const spx_nrt_objects* nrt, int64_t node, const
   subtract_from_numas(&r, &nl, bits);
   dump_zones(&nl, q_res, n_q, out);
 }
+
+/* ---------------------------------------------------------------- preemption flow (preemption/preemption.go) */
+
+/* resourcerequests.IsExclusive exclusive.go:78-102; nrt_resources = cache.ResourceNamesFromNRT of the node */
+static int is_exclusive(const spx_resource_classes* rc, int qos, int32_t res, int64_t qty, const rlist* nrt_resources) {
+  if (!rc_flag(rc, res, SPX_RC_NATIVE)) return rl_find(nrt_resources, res) >= 0; /* :83-85 */
+  if (qos != SPX_QOS_GUARANTEED) return 0;                                        /* :86-89 */
+  if (res == SPX_RES_CPU && qty % 1000 == 0 && qty > 0) return 1;                 /* :90-95: Value()*1000 == MilliValue(), > 0 */
+  if ((res == SPX_RES_MEMORY || rc_flag(rc, res, SPX_RC_HUGEPAGE)) && qty > 0) return 1; /* :96-100 */
+  return 0;
+}
+
+int orc_nrt_post_eviction(const spx_nrt_objects* nrt, const spx_resource_classes* rc, int64_t node, const spx_pod_objects* victims,
+                          const uint8_t* victim_qos, const int32_t* ctr_numa, int32_t placement_present, int32_t placement_containers,
+                          int64_t* out) {
+  const int32_t z0 = nrt->zone_ptr[node], z1 = nrt->zone_ptr[node + 1];
+  const int32_t e0 = nrt->zres_ptr[z0], e1 = nrt->zres_ptr[z1];
+  for (int32_t e = e0; e < e1; ++e) out[e - e0] = nrt->zres_avail[e];
+  if (!nrt->has_nrt[node]) return SPX_EVICT_NO_NRT;                         /* :40-42 */
+  if (!victims || victims->n_pods == 0) return SPX_EVICT_NO_VICTIMS;        /* :44-46 */
+  if (!placement_present) return SPX_EVICT_NO_PLACEMENT;                    /* :48-50 */
+  if (placement_containers == 0) return SPX_EVICT_NO_CONTAINERS;            /* :52-54 */
+  rlist names; /* ResourceNamesFromNRT: every resource any zone reports */
+  names.n = 0;
+  for (int32_t e = e0; e < e1; ++e) rl_set(&names, nrt->zres_res[e], 0);
+  /* accumulateResourcesToAddPerNUMA :66-112 */
+  static __thread rlist to_add[64];
+  int used[64] = {0};
+  int any = 0;
+  for (int64_t v = 0; v < victims->n_pods; ++v) {
+    int qos = victim_qos[v];
+    if (qos != SPX_QOS_GUARANTEED && !orc_include_non_native(victims, rc, v)) continue; /* :70-73 */
+    for (int32_t c = victims->ctr_ptr[v]; c < victims->ctr_ptr[v + 1]; ++c) {
+      if (victims->ctr_kind[c] != SPX_CTR_APP) continue; /* victim.Spec.Containers */
+      int numa = ctr_numa[c];
+      if (numa == SPX_EVICT_CTR_UNKNOWN || numa == -1 || numa >= 64) continue; /* :81-85 */
+      for (int32_t i = victims->req_ptr[c]; i < victims->req_ptr[c + 1]; ++i) {
+        if (!is_exclusive(rc, qos, victims->req_res[i], victims->req_qty[i], &names)) continue; /* :88-90 */
+        if (!used[numa]) {
+          used[numa] = 1;
+          to_add[numa].n = 0;
+        }
+        int k = rl_find(&to_add[numa], victims->req_res[i]);
+        rl_set(&to_add[numa], victims->req_res[i], (k >= 0 ? to_add[numa].qty[k] : 0) + victims->req_qty[i]);
+        any = 1;
+      }
+    }
+  }
+  if (!any) return SPX_EVICT_NOTHING_TO_ADD; /* :60-62 */
+  /* addResourcesToNodeResourcesTopology :114-157 */
+  for (int32_t z = z0; z < z1; ++z) {
+    int id = nrt->zone_numa_id[z];
+    if (id < 0 || id >= 64 || !used[id]) continue; /* NameToID error / nothing to add for this zone */
+    for (int a = 0; a < to_add[id].n; ++a) {
+      for (int32_t e = nrt->zres_ptr[z]; e < nrt->zres_ptr[z + 1]; ++e) {
+        if (nrt->zres_res[e] != to_add[id].res[a]) continue;
+        int64_t tmp = nrt->zres_avail[e] + to_add[id].qty[a];
+        if (tmp > nrt->zres_allocatable[e]) { /* :136-148 one mistake voids the whole update */
+          for (int32_t r = e0; r < e1; ++r) out[r - e0] = nrt->zres_avail[r];
+          return SPX_EVICT_EXCEEDS_ALLOCATABLE;
+        }
+        out[e - e0] = tmp;
+        break;
+      }
+    }
+  }
+  return SPX_EVICT_OK;
+}

@@ -110,6 +110,10 @@ int orc_nrt_test_subtract_numa(const spx_nrt_objects* nrt, const spx_resource_cl
                                const spx_pod_objects* pods, int64_t pod, const int32_t* q_res, int n_q, int64_t* out);
 void orc_nrt_test_subtract_numas(const spx_nrt_objects* nrt, int64_t node, const spx_pod_objects* pods, int64_t pod, uint64_t bits,
                                  const int32_t* q_res, int n_q, int64_t* out);
+/* preemption.GetNRTPostPodsEviction preemption.go:39-157 (arguments as spx_nrt_post_eviction); returns the SPX_EVICT_* code */
+int orc_nrt_post_eviction(const spx_nrt_objects* nrt, const spx_resource_classes* rc, int64_t node, const spx_pod_objects* victims,
+                          const uint8_t* victim_qos, const int32_t* ctr_numa, int32_t placement_present, int32_t placement_containers,
+                          int64_t* zres_avail_out);
 int orc_nrt_numa_nodes_required(const spx_nrt_objects* nrt, const spx_resource_classes* rc, const spx_pod_objects* pods,
                                 int64_t pod, int64_t node, int qos, uint64_t* bitmask, int* is_min_distance);
 

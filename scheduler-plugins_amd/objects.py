@@ -266,8 +266,8 @@ def numa_name_to_id(name: str) -> int:  # numanode.NameToID: "node-<id>"
 
 
 def nrt(zones: Sequence[dict], policies: Sequence[str] = (), attributes: Optional[dict] = None) -> dict:
-    """zones: [{"name": "node-0", "type": "Node", "resources": {name: available} | [(name, capacity, available)],
-    "costs": {"node-1": 12, ...}}]"""
+    """zones: [{"name": "node-0", "type": "Node", "resources": {name: available} | [(name, capacity, available)] |
+    [(name, capacity, allocatable, available)], "costs": {"node-1": 12, ...}}]"""
     return {"zones": list(zones), "policies": list(policies), "attributes": dict(attributes or {})}
 
 
@@ -275,7 +275,7 @@ def build_nrt_objects(hdr: Header, res: Resources, nrts: Sequence[Optional[dict]
                       assumed: Optional[Dict[int, list]] = None) -> Table:
     n = len(nrts)
     legacy, a_scope, a_policy, a_max = [], [], [], []
-    zone_lists, zres, zcost, z_is_node, z_id = [], [], [], [], []
+    zone_lists, zres, zcost, z_is_node, z_id, zalloc = [], [], [], [], [], []
     for t in nrts:
         lp, sc, po, mx, zs = -1, -1, -1, -1, []
         if t is not None:
@@ -299,8 +299,10 @@ def build_nrt_objects(hdr: Header, res: Resources, nrts: Sequence[Optional[dict]
                 rl = z.get("resources") or {}
                 if isinstance(rl, dict):
                     zres.append([(res.id(k), res.canonical(k, v)) for k, v in rl.items()])
+                    zalloc.extend(res.canonical(k, v) for k, v in rl.items())
                 else:
-                    zres.append([(res.id(k), res.canonical(k, av)) for k, _cap, av in rl])
+                    zres.append([(res.id(t4[0]), res.canonical(t4[0], t4[-1])) for t4 in rl])
+                    zalloc.extend(res.canonical(t4[0], t4[2] if len(t4) == 4 else t4[1]) for t4 in rl)  # allocatable, else capacity
                 costs = z.get("costs") or {}
                 items = costs.items() if isinstance(costs, dict) else costs
                 zcost.append([(numa_name_to_id(k), int(v)) for k, v in items])
@@ -323,6 +325,7 @@ def build_nrt_objects(hdr: Header, res: Resources, nrts: Sequence[Optional[dict]
         zcost_ptr=_csr(zcost), zcost_numa_id=[x[0] for l in zcost for x in l], zcost_value=[x[1] for l in zcost for x in l],
         assumed_ptr=_csr(per_node), arl_ptr=_csr(a_lists), arl_res=[x[0] for l in a_lists for x in l],
         arl_qty=[x[1] for l in a_lists for x in l],
+        zres_allocatable=np.array(zalloc, dtype=np.int64),
     )
 
 
@@ -339,7 +342,7 @@ def node_from_zones(zones: Sequence[dict], extra: Optional[dict] = None) -> dict
     total: Dict[str, Fraction] = {}
     for z in zones:
         rl = z.get("resources") or {}
-        items = rl.items() if isinstance(rl, dict) else [(k, av) for k, _c, av in rl]
+        items = rl.items() if isinstance(rl, dict) else [(t[0], t[-1]) for t in rl]
         for k, v in items:
             total[k] = total.get(k, Fraction(0)) + parse_quantity(v)
     for k, v in (extra or {}).items():
