@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstdlib>
 
 #include "spx_internal.h"
 
@@ -28,7 +29,7 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kPodsPerChunk = 64;
-constexpr int kNpl = 4;  // nodes per lane: one dword of scores (and of each status table) per pod row
+// nodes per lane (template parameter of k_peaks): 4 = one dword of scores and of each status table per pod row, 8 = two
 constexpr double kInf = __builtin_huge_val();
 
 template <typename T>
@@ -96,23 +97,30 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
   return __hiloint2double(hi, lo);
 }
 
-// feasibility of the lane's 4 nodes for `pod`: every Filter status table says 0; columns past n_nodes never count
+// feasibility of the lane's NPL nodes for `pod` (bit j set = node j does not count): every Filter status table must say 0;
+// columns past n_nodes never count
+template <int NPL>
 __device__ __forceinline__ uint32_t infeasible_mask(const PeaksArgs& a, int64_t pod, int64_t node0, bool active) {
-  uint32_t bad = 0;
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    if (a.other_status[t] != nullptr && active) bad |= *reinterpret_cast<const uint32_t*>(a.other_status[t] + pod * a.row_stride + node0);
-  }
   uint32_t m = 0;
 #pragma unroll
-  for (int j = 0; j < kNpl; ++j) {
-    const bool out = !active || node0 + j >= a.n_nodes || ((bad >> (8 * j)) & 0xffu) != 0;
-    m |= (out ? 1u : 0u) << j;
+  for (int w = 0; w < NPL / 4; ++w) {
+    uint32_t bad = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (a.other_status[t] != nullptr && active)
+        bad |= *reinterpret_cast<const uint32_t*>(a.other_status[t] + pod * a.row_stride + node0 + 4 * w);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = 4 * w + q;
+      const bool out = !active || node0 + j >= a.n_nodes || ((bad >> (8 * q)) & 0xffu) != 0;
+      m |= (out ? 1u : 0u) << j;
+    }
   }
   return m;
 }
 
-template <bool kWrite>
+template <bool kWrite, int kNpl>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks(PeaksArgs a, int n_tiles) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks(PeaksArgs a, in
 
   for (int64_t pod = pod0; pod < pod1; ++pod) {
     const double pod_cpu = static_cast<double>(uload(a.pod_cpu_milli + pod));
-    const uint32_t bad = infeasible_mask(a, pod, node0, active);
+    const uint32_t bad = infeasible_mask<kNpl>(a, pod, node0, active);
     double raw[kNpl];
 #pragma unroll
     for (int j = 0; j < kNpl; ++j) raw[j] = raw_score(nd[j], pod_cpu);
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks(PeaksArgs a, in
       }
     } else {
       const int64_t mni = uload(a.row_min + pod), mxi = uload(a.row_max + pod);
-      uint32_t word = 0;
+      uint32_t word[kNpl / 4] = {};
       if (!(mni == 0 && mxi == 0)) {  // :152-154: all raw scores are 0 and stay 0
         const double mn = static_cast<double>(mni);          // exact: it was stored from an integer-valued float64
         const double span = static_cast<double>(mxi - mni);  // float64(maxCost - minCost)
@@ -167,10 +175,18 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks(PeaksArgs a, in
           const double norm = flat ? diff : div_rn(100.0 * diff, span, rspan);  // :158, :161
           const int sc = 100 - static_cast<int>(norm);       // :159, :162 (|norm| <= 100 for a feasible node)
           const uint32_t b = ((bad >> j) & 1u) ? 0u : static_cast<uint32_t>(sc < 0 ? 0 : (sc > 100 ? 100 : sc));
-          word |= b << (8 * j);
+          word[j >> 2] |= b << (8 * (j & 3));
         }
       }
-      if (active) *reinterpret_cast<uint32_t*>(a.out_score + pod * a.row_stride + node0) = word;
+      if (active) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(a.out_score + pod * a.row_stride + node0);
+        if constexpr (kNpl == 8) {
+          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+          *reinterpret_cast<u32x2*>(dst) = u32x2{word[0], word[1]};
+        } else {
+          dst[0] = word[0];
+        }
+      }
     }
   }
 }
@@ -191,13 +207,31 @@ void launch_peaks(const PeaksArgs& a, hipStream_t s) {
   const int64_t rows = a.row_end - a.row_begin;
   if (rows <= 0) return;
   hipLaunchKernelGGL(k_peaks_init, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0, s, a.row_min, a.row_max, a.row_begin, a.row_end);
-  const int tile_nodes = kWave * kNpl;
-  const int n_tiles = static_cast<int>((a.row_stride + tile_nodes - 1) / tile_nodes);
   const int64_t chunks = (rows + kPodsPerChunk - 1) / kPodsPerChunk;
-  const int64_t units = chunks * n_tiles;
-  const unsigned blocks = static_cast<unsigned>((units + kWavesPerBlock - 1) / kWavesPerBlock);
-  hipLaunchKernelGGL((k_peaks<false>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles);
-  hipLaunchKernelGGL((k_peaks<true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles);
+  auto grid = [&](int npl, int* n_tiles) {
+    const int tile_nodes = kWave * npl;
+    *n_tiles = static_cast<int>((a.row_stride + tile_nodes - 1) / tile_nodes);
+    return dim3(static_cast<unsigned>((chunks * *n_tiles + kWavesPerBlock - 1) / kWavesPerBlock));
+  };
+  // experiment knob: "44", "84", "48", "88" = nodes per lane of (min/max pass, write pass).  Measured on 10k x 100k: 3.49 /
+  // 3.50 / 3.55 / 3.57 ms — the wider tiles halve the cross-lane reductions per cell but cost occupancy (145 VGPRs): no gain
+  const char* env = getenv("SPX_PEAKS_NPL");
+  const int npl_a = (env && env[0] == '8') ? 8 : 4, npl_b = (env && env[0] && env[1] == '8') ? 8 : 4;
+  int nt;
+  if (npl_a == 8) {
+    const dim3 g = grid(8, &nt);
+    hipLaunchKernelGGL((k_peaks<false, 8>), g, dim3(kWave * kWavesPerBlock), 0, s, a, nt);
+  } else {
+    const dim3 g = grid(4, &nt);
+    hipLaunchKernelGGL((k_peaks<false, 4>), g, dim3(kWave * kWavesPerBlock), 0, s, a, nt);
+  }
+  if (npl_b == 8) {
+    const dim3 g = grid(8, &nt);
+    hipLaunchKernelGGL((k_peaks<true, 8>), g, dim3(kWave * kWavesPerBlock), 0, s, a, nt);
+  } else {
+    const dim3 g = grid(4, &nt);
+    hipLaunchKernelGGL((k_peaks<true, 4>), g, dim3(kWave * kWavesPerBlock), 0, s, a, nt);
+  }
 }
 
 }  // namespace spx
