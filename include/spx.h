@@ -684,6 +684,27 @@ int spx_nrt_post_eviction(const spx_nrt_objects* nrt, const spx_resource_classes
  * grouped by namespace (nom_ptr[NS+1]); n_nominated entries. */
 int spx_flatten_quota(const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_quota_objects* q, int32_t* pod_ns, int32_t* pod_priority, int64_t* pod_req, uint8_t* pod_req_present, int64_t* agg_used, uint8_t* agg_used_present, int64_t* agg_min, uint8_t* agg_min_present, int64_t* other_nominated, uint8_t* other_nominated_present, int32_t* nom_ptr, int32_t* nom_priority, int64_t* nom_pending_index, int64_t* nom_req, uint8_t* nom_req_present);
 
+/* ------------------------------------------------------------------ wire format -> object tables (first slice)
+ *
+ * NodeResourceTopology objects as the API server serves them (JSON of topology.node.k8s.io/v1alpha2; schema = the reference's
+ * manifests/crds/topology.node.k8s.io_noderesourcetopologies.yaml) decoded into the spx_nrt_objects columns, replacing the
+ * informer-cache walk of pluginhelpers.go:105-161 / nodeconfig/topologymanager.go:78-162 on the Go side.  The handle owns the
+ * tables; pointers returned by the accessors stay valid until the next spx_ingest_nrt_json / spx_ingest_destroy.  node_names fixes
+ * the node order of the snapshot (objects of other names are counted and skipped); resource_names pre-seeds the resource
+ * interner (ids >= SPX_RES_FIRST_DYNAMIC in that order) so that pod tables built elsewhere share the id space.  `fresh` is 1 for
+ * every node and the assumed-pod lists are empty: both are the NRT cache's verdict, which stays with the caller. */
+typedef struct spx_ingest spx_ingest;
+int spx_ingest_create(const char* const* node_names, int64_t n_nodes, const char* const* resource_names, int32_t n_resource_names, spx_ingest** out);
+int spx_ingest_destroy(spx_ingest* h);
+const char* spx_ingest_error(const spx_ingest* h);
+/* json: one object, a List ("items") or an array; may be called repeatedly — a later object replaces an earlier one of the same name */
+int spx_ingest_nrt_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_objects_out, int64_t* n_unknown_out);
+const spx_nrt_objects* spx_ingest_nrt_objects(const spx_ingest* h);
+const spx_resource_classes* spx_ingest_resource_classes(const spx_ingest* h);
+int32_t spx_ingest_resource_id(const spx_ingest* h, const char* name);
+/* resource.Quantity text -> canonical int64: MilliValue() when milli != 0 (cpu), Value() otherwise; both round up */
+int spx_ingest_quantity(const char* text, int32_t milli, int64_t* out);
+
 #ifdef __cplusplus
 }
 #endif
