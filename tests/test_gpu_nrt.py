@@ -324,3 +324,37 @@ def test_preemption_dry_run_filter(gpu_required, hdr, oracle):
     for t, want in ((before, st_before), (after, st_after)):   # and the oracle agrees on both
         snap = oracle.Snapshot(node, pods, rc=res.table(hdr), nrt=t, nrt_params=O.nrt_params(hdr, res, "LeastAllocated"))
         assert snap.filter_rows(NRT).tolist() == want.tolist()
+
+
+def test_wire_format_to_gpu_filter(gpu_required, hdr, oracle):
+    """the reference's example NodeResourceTopology manifests as API JSON -> host decoder -> flatten ->
+    GPU Filter/Score, against the oracle on the Python-built tables"""
+    import json
+
+    from scheduler_plugins_amd.ingest import NrtIngest
+    from test_ingest_nrt import GOLD, cr_to_dict
+
+    docs = json.loads((GOLD / "nrt_manifests.json").read_text())
+    names = [d["metadata"]["name"] for d in docs]
+    res = O.Resources()
+    for d in docs:
+        for z in d["zones"]:
+            for r in z["resources"]:
+                res.id(r["name"])
+    nodes = O.build_node_objects(hdr, res, [O.node({"cpu": "8", "memory": "16Gi", "example.com/deviceA": "3", "example.com/deviceB": "3"})] * 2)
+    pods = O.build_pod_objects(hdr, res, [{"containers": [O.container({"cpu": "1", "example.com/deviceA": "1"})]},
+                                          {"containers": [O.container({"cpu": "1", "example.com/deviceA": "3"})]},
+                                          {"containers": [O.container({"cpu": "1", "example.com/deviceB": "3"})]},
+                                          {"containers": [O.container({"cpu": "2", "memory": "1Gi"}, {"cpu": "2", "memory": "1Gi"})]}])
+    params = O.nrt_params(hdr, res, "LeastAllocated")
+    want = oracle.Snapshot(nodes, pods, rc=res.table(hdr), nrt=O.build_nrt_objects(hdr, res, [cr_to_dict(d) for d in docs]), nrt_params=params)
+    with NrtIngest(names) as ing:
+        ing.feed(json.dumps({"items": docs}).encode())
+        with Engine(0) as e:
+            e.load_nrt_objects(nodes, ing.nrt_objects(), ing.resource_classes(), pods, params)
+            e.eval(mask_of(NRT))
+            e.sync()
+            status, scores = e.all_status(NRT), e.all_scores(NRT)
+    assert status.tolist() == want.filter_rows(NRT).tolist() == [[0, 0], [4, 0], [4, 0], [4, 4]]
+    raw = want.score_rows(NRT)[0]
+    assert (scores.astype(np.int64)[status == 0] == raw[status == 0]).all()
