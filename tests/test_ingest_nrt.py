@@ -201,3 +201,35 @@ def test_throughput(hdr):
     rate = len(blob) / dt / 1e6
     print(f"NRT JSON ingest: {len(blob) / 1e6:.1f} MB in {dt * 1e3:.0f} ms = {rate:.0f} MB/s, {n / dt:.0f} objects/s")
     assert rate > 20
+
+
+def test_decoder_survives_mutated_input():
+    """robustness: truncations, byte flips and spliced fragments of valid documents must yield a clean error or a decode,
+    never a crash (the decoder reads caller-supplied bytes)"""
+    docs = json.loads((GOLD / "nrt_manifests.json").read_text())
+    base = json.dumps({"items": docs}).encode()
+    rng = np.random.default_rng(99)
+    outcomes = {"ok": 0, "err": 0}
+    with NrtIngest([d["metadata"]["name"] for d in docs]) as ing:
+        for it in range(4000):
+            b = bytearray(base)
+            kind = it % 4
+            if kind == 0:
+                b = b[: int(rng.integers(0, len(b)))]
+            elif kind == 1:
+                for _ in range(int(rng.integers(1, 6))):
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            elif kind == 2:
+                i, j = sorted(int(x) for x in rng.integers(0, len(b), 2))
+                b = b[:i] + b[j:]
+            else:
+                i, j = sorted(int(x) for x in rng.integers(0, len(b), 2))
+                b = b[:j] + b[i:j] + b[j:]
+            try:
+                ing.feed(bytes(b))
+                outcomes["ok"] += 1
+            except ValueError:
+                outcomes["err"] += 1
+        ing.feed(base)   # and the handle still works afterwards
+        assert column(ing.nrt_objects().struct, "has_nrt", 2) == [1, 1]
+    assert outcomes["err"] > 1000 and outcomes["ok"] > 0
