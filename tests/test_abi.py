@@ -57,3 +57,20 @@ def test_create_without_gpu_fails_loudly():
         assert err.code == -4 and "no CPU fallback" in err.msg
     else:  # on a GPU box this is simply a working engine
         e.close()
+
+
+def test_host_entry_points_reject_null_arguments():
+    """every host-side entry point (flatteners, comparator, eviction simulation, wire-format decoder) answers SPX_ERR_ARG to
+    an all-NULL call instead of dereferencing — the cgo shim's mistakes must come back as error codes"""
+    import ctypes as C
+
+    import scheduler_plugins_amd as spx
+
+    hdr, lib = spx.header(), spx.lib()
+    prefixes = ("spx_flatten", "spx_toposort", "spx_nrt_post", "spx_ingest_nrt_json", "spx_ingest_quantity", "spx_ingest_create")
+    names = [n for n in hdr.protos if n.startswith(prefixes)]
+    assert len(names) >= 18
+    for n in names:
+        fn = getattr(lib, n)
+        args = [0 if t in (C.c_int64, C.c_int32, C.c_int, C.c_uint32) else None for t in fn.argtypes]
+        assert fn(*args) == hdr.consts["SPX_ERR_ARG"], n
