@@ -236,6 +236,19 @@ def main() -> None:
             full_cycle = {"ms": (c3 - c0) * 1e3, "flatten_upload_ms": (c1 - c0) * 1e3, "eval_argmax_ms": (c2 - c1) * 1e3,
                           "fetch_decisions_ms": (c3 - c2) * 1e3,
                           "what": "objects->SoA flatten + H2D, sweep, per-row weighted argmax, D2H of 32 B/pod decisions"}
+            # decisions without tables (spx_decide: the argmax folded into the sweep), HIP-event time of the launch
+            try:
+                for _ in range(3):
+                    e.decide(mask)
+                e.sync()
+                d0 = time.perf_counter()
+                for _ in range(10):
+                    e.decide(mask)
+                e.sync()
+                full_cycle["decide_ms"] = (time.perf_counter() - d0) * 1e3 / 10
+                full_cycle["decide_what"] = "sweep + per-row argmax in one pass, no score table written; same decisions as eval_argmax"
+            except Exception as ex:
+                full_cycle["decide_error"] = repr(ex)[:200]
             # the same pods scheduled strictly one after the other, each seeing the commits before it (upstream's
             # semantics; inherently sequential, one workgroup): spx_commit_sequential
             c4 = time.perf_counter()

@@ -536,6 +536,7 @@ typedef struct spx_quota_soa {
  *   spx_flatten_net_topo                       populateCostMap                         networkoverhead.go:448-497
  *   spx_flatten_quota                          ElasticQuotaInfos (used / min / max, nominated pods)   pkg/capacityscheduling/elasticquota.go:48-123
  *   spx_eval_best + spx_fetch_best             upstream prioritizeNodes + selectHost input (sum of weight x score over feasible nodes)
+ *   spx_decide + spx_fetch_best                the same decision input without materialising the per-plugin tables
  *   spx_commit_sequential                      upstream scheduleOne repeated over the queue, with trimaran's bind-time bookkeeping
  *                                              pkg/trimaran/handler.go:131-139, targetloadpacking.go:151-168
  */
@@ -612,6 +613,13 @@ int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_
  * failed CapacityScheduling.PreFilter), its weighted score, how many nodes tie for it, how many were feasible;
  * n_ties / n_feasible may be NULL */
 int spx_fetch_best(spx_engine* e, int64_t row_begin, int64_t row_end, int32_t* node_idx, int64_t* weighted_score, int32_t* n_ties, int32_t* n_feasible);
+
+/* Decisions without tables: what spx_eval + spx_eval_best would leave for spx_fetch_best, computed in one sweep that never
+ * writes a score table (the per-row argmax is folded into the sweep: no 1 B/cell/plugin to HBM and back).  Fused for the
+ * Filter-less profile {TLP} or {ALLOCATABLE, TLP} with non-negative plugin weights and no caller feasibility mask; any other
+ * request is served by running spx_eval and spx_eval_best.  Score tables and their `evaluated` state are left untouched by the
+ * fused form.  Asynchronous on the engine stream like spx_eval. */
+int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end);
 
 /* Sequential scheduling of pod rows [row_begin,row_end), in row (= queue) order, under the Filter-less profile
  * plugin_mask, a subset of {ALLOCATABLE, TLP, LVRB}.  Unlike spx_eval's frozen snapshot, every pod sees the commits of the

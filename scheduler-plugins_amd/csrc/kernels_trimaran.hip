@@ -377,8 +377,25 @@ __global__ void k_tlp_prepare_fast(TrimaranArgs a, int64_t n_slots, double c1, d
       float4{static_cast<float>(bh), split ? static_cast<float>(b - bh) : 0.0f, f1, f2};
 }
 
-template <int NPL, bool A>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArgs a, int n_tiles, double c1, double c2) {
+// Decisions-only mode (template flag D): nothing is written to the score tables; each wave folds the weighted sum
+// w_alloc * alloc + w_tlp * tlp of its 64 x NPL nodes into (best total, lowest node with it, how many nodes tie) per pod and
+// leaves that triple in dec.key / dec.ties [tile][row]; k_decide_reduce merges the tiles.  The bytes are the very ones the
+// table mode stores (same code up to the store), so the decisions equal spx_eval + spx_eval_best by construction.
+struct DecideArgs {
+  int32_t w_alloc, w_tlp;
+  uint64_t* key;   // [n_tiles][rows]: (total + 1) << 32 | (0xffffffff - node); 0 = no node in the tile
+  int32_t* ties;   // [n_tiles][rows]
+  int64_t rows;
+};
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+  const uint32_t lo = static_cast<uint32_t>(__shfl_xor(static_cast<int>(static_cast<uint32_t>(v)), m));
+  const uint32_t hi = static_cast<uint32_t>(__shfl_xor(static_cast<int>(static_cast<uint32_t>(v >> 32)), m));
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+template <int NPL, bool A, bool D = false>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArgs a, int n_tiles, double c1, double c2, DecideArgs dec) {
   static_assert(kPodsPerChunk == kWave, "one pod record per lane");
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -428,7 +445,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
 
   for (int r = 0; r < n_rows; ++r) {
     const int64_t row = (pod0 + r) * a.row_stride + node0;
-    if constexpr (A) {
+    if constexpr (A && !D) {
       if (active) store_bytes<NPL>(a.out_alloc + row, alloc_w);
     }
     const float pod_f = __int_as_float(__builtin_amdgcn_readlane(pod_bits, r));
@@ -498,8 +515,64 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
         }
       }
     }
-    if (active) store_bytes<NPL>(a.out_tlp + row, w);
+    if constexpr (!D) {
+      if (active) store_bytes<NPL>(a.out_tlp + row, w);
+    } else {
+      // lane: best weighted total over its NPL nodes, the lowest node index reaching it, and the tie count
+      int best = -1, best_j = 0, ties = 0;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int tb = static_cast<int>((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        int ab = 0;
+        if constexpr (A) ab = static_cast<int>((alloc_w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        const bool in = active && node0 + i < a.n_nodes;
+        const int tot = in ? dec.w_tlp * tb + dec.w_alloc * ab : -1;
+        if (tot > best) best = tot, best_j = i, ties = 1;
+        else if (tot == best) ++ties;
+      }
+      // wave: every lane is live here (see the note above the loop), so plain butterflies are safe
+      uint64_t key = (static_cast<uint64_t>(static_cast<uint32_t>(best + 1)) << 32) |
+                     (0xffffffffu - static_cast<uint32_t>(node0 + best_j));
+      if (best < 0) key = 0;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        const uint64_t o = shfl_xor_u64(key, m);
+        key = o > key ? o : key;
+      }
+      const int wbest = static_cast<int>(key >> 32) - 1;
+      int t = (best == wbest && best >= 0) ? ties : 0;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
+      if (lane == 0) {
+        const int64_t slot = static_cast<int64_t>(tile) * dec.rows + (pod0 + r - a.row_begin);
+        dec.key[slot] = key;
+        dec.ties[slot] = t;
+      }
+    }
   }
+}
+
+// merges the per-tile triples of the decisions-only sweep into the layout spx_fetch_best reads
+__global__ void k_decide_reduce(DecideArgs dec, int n_tiles, int64_t row_begin, int64_t n_nodes, int64_t* best_score, int32_t* best_node,
+                                int32_t* best_ties, int32_t* best_feasible) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= dec.rows) return;
+  uint64_t key = 0;
+  for (int t = 0; t < n_tiles; ++t) {
+    const uint64_t k = dec.key[static_cast<int64_t>(t) * dec.rows + r];
+    key = k > key ? k : key;
+  }
+  int32_t ties = 0;
+  for (int t = 0; t < n_tiles; ++t) {
+    const int64_t slot = static_cast<int64_t>(t) * dec.rows + r;
+    if ((dec.key[slot] >> 32) == (key >> 32)) ties += dec.ties[slot];
+  }
+  const int64_t pod = row_begin + r;
+  const bool any = key != 0;
+  best_score[pod] = any ? static_cast<int64_t>(key >> 32) - 1 : 0;
+  best_node[pod] = any ? static_cast<int32_t>(0xffffffffu - static_cast<uint32_t>(key)) : -1;
+  best_ties[pod] = any ? ties : 0;
+  best_feasible[pod] = static_cast<int32_t>(n_nodes);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1000,9 +1073,9 @@ void launch_tlp_fast(const TrimaranArgs& a, hipStream_t s) {
   const int64_t n_slots = static_cast<int64_t>(n_tiles) * tile_nodes;
   hipLaunchKernelGGL(k_tlp_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots, c1, c2);
   if (a.out_alloc)
-    hipLaunchKernelGGL((k_tlp_fast2<NPL, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2);
+    hipLaunchKernelGGL((k_tlp_fast2<NPL, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, DecideArgs{});
   else
-    hipLaunchKernelGGL((k_tlp_fast2<NPL, false>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2);
+    hipLaunchKernelGGL((k_tlp_fast2<NPL, false>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, DecideArgs{});
 }
 
 template <int NPL>
@@ -1047,6 +1120,38 @@ void launch_trimaran(const TrimaranArgs& a, hipStream_t s) {
   if (L && T) launch_npl<4>(a, s);
   else if (L) launch_npl<8>(a, s);
   else launch_npl<16>(a, s);
+}
+
+size_t decide_scratch_bytes(int64_t row_stride, int64_t rows) {
+  const int n_tiles = static_cast<int>((row_stride + kWave * kTlpNpl - 1) / (kWave * kTlpNpl));
+  return static_cast<size_t>(n_tiles) * static_cast<size_t>(rows) * (sizeof(uint64_t) + sizeof(int32_t));
+}
+
+void launch_decide_trimaran(const DecideLaunch& d, hipStream_t s) {
+  const TrimaranArgs& a = d.t;
+  constexpr int NPL = kTlpNpl;
+  const int tile_nodes = kWave * NPL;
+  const int n_tiles = static_cast<int>((a.row_stride + tile_nodes - 1) / tile_nodes);
+  const int64_t rows = a.row_end - a.row_begin;
+  if (rows <= 0) return;
+  const int64_t chunks = (rows + kPodsPerChunk - 1) / kPodsPerChunk;
+  const unsigned blocks = static_cast<unsigned>((chunks * n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  const double t = a.tlp_target;
+  const double c1 = t / (100.0 - t), c2 = (100.0 - t) / t;
+  const int64_t n_slots = static_cast<int64_t>(n_tiles) * tile_nodes;
+  DecideArgs dec;
+  dec.w_alloc = d.w_alloc;
+  dec.w_tlp = d.w_tlp;
+  dec.key = static_cast<uint64_t*>(d.scratch);
+  dec.ties = reinterpret_cast<int32_t*>(dec.key + static_cast<int64_t>(n_tiles) * rows);
+  dec.rows = rows;
+  hipLaunchKernelGGL(k_tlp_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots, c1, c2);
+  if (d.use_alloc)
+    hipLaunchKernelGGL((k_tlp_fast2<NPL, true, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, dec);
+  else
+    hipLaunchKernelGGL((k_tlp_fast2<NPL, false, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, dec);
+  hipLaunchKernelGGL(k_decide_reduce, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0, s, dec, n_tiles, a.row_begin, a.n_nodes,
+                     d.best_score, d.best_node, d.best_ties, d.best_feasible);
 }
 
 void launch_commit_trimaran(const CommitArgs& c, hipStream_t s) {

@@ -63,6 +63,7 @@ struct spx_engine {
   DevBuf d_lv_exact; // double [n_nodes][8] scratch of the LVRB fast kernel
   DevBuf d_lv_fast, d_tlp_fast;  // float32 per-node constants of the fast sweeps (recomputed per launch)
   DevBuf d_commit;               // scratch of spx_commit_sequential
+  DevBuf d_decide;               // per-tile partial decisions of spx_decide
 
   // LowRiskOverCommitment (reads the LVRB node columns above as well)
   spx_lroc_params lroc{5, 0.5, 0.5};  // apis/config/v1/defaults.go:72-80
@@ -1384,6 +1385,49 @@ int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_
   pa.best_feasible = pa.best_ties + P;
   spx::launch_best(pa, e->stream);
   SPX_HIP(e, hipGetLastError());
+  e->best_valid = true;
+  return SPX_OK;
+}
+
+int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end) {
+  if (!e) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  const uint32_t A = 1u << SPX_PLUGIN_ALLOCATABLE, T = 1u << SPX_PLUGIN_TLP;
+  const int64_t wa = e->plugin_weight[SPX_PLUGIN_ALLOCATABLE], wt = e->plugin_weight[SPX_PLUGIN_TLP];
+  const bool fusable = (plugin_mask == T || plugin_mask == (A | T)) && !e->ext_mask && e->tri_nodes && e->tri_pods &&
+                       e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && getenv("SPX_EXACT_ONLY") == nullptr &&
+                       getenv("SPX_DECIDE_UNFUSED") == nullptr && wa >= 0 && wt >= 0 && wa + wt <= 10000000;
+  int rc;
+  if (!fusable) {
+    if ((rc = spx_eval(e, plugin_mask, row_begin, row_end))) return rc;
+    return spx_eval_best(e, plugin_mask, row_begin, row_end);
+  }
+  if (e->n_nodes <= 0 || e->n_pods <= 0) return fail(e, SPX_ERR_STATE, "shape unknown");
+  if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
+  const bool use_alloc = plugin_mask & A;
+  if (use_alloc && (rc = prepare_alloc(e))) return rc;
+  const size_t P = static_cast<size_t>(e->n_pods);
+  if ((rc = ensure(e, e->d_best, P * 20))) return rc;
+  if ((rc = ensure(e, e->d_tlp_fast, static_cast<size_t>(spx::round_up(e->row_stride, 1024)) * 4 * sizeof(float)))) return rc;
+  if ((rc = ensure(e, e->d_decide, spx::decide_scratch_bytes(e->row_stride, row_end - row_begin)))) return rc;
+  spx::DecideLaunch d{};
+  fill_trimaran(e, d.t);
+  d.t.row_begin = row_begin;
+  d.t.row_end = row_end;
+  d.t.tlp_fast = static_cast<float*>(e->d_tlp_fast.p);
+  d.use_alloc = use_alloc;
+  d.w_alloc = static_cast<int32_t>(use_alloc ? wa : 0);
+  d.w_tlp = static_cast<int32_t>(wt);
+  d.scratch = e->d_decide.p;
+  d.best_score = static_cast<int64_t*>(e->d_best.p);
+  d.best_node = reinterpret_cast<int32_t*>(d.best_score + P);
+  d.best_ties = d.best_node + P;
+  d.best_feasible = d.best_ties + P;
+  SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
+  spx::launch_decide_trimaran(d, e->stream);
+  SPX_HIP(e, hipGetLastError());
+  SPX_HIP(e, hipEventRecord(e->ev1, e->stream));
+  e->timed = true;
   e->best_valid = true;
   return SPX_OK;
 }

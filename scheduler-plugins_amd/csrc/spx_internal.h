@@ -79,6 +79,20 @@ struct CommitArgs {
   int32_t* out_ties;    // may be NULL
 };
 void launch_commit_trimaran(const CommitArgs& c, hipStream_t s);
+// decisions-only sweep of the Allocatable + TargetLoadPacking profile (no score tables written): per pod the best weighted
+// total, the lowest node reaching it, the tie count — in the layout spx_fetch_best reads
+struct DecideLaunch {
+  TrimaranArgs t;        // inputs; alloc_norm prepared when use_alloc; tlp_fast scratch set
+  bool use_alloc;
+  int32_t w_alloc, w_tlp;
+  void* scratch;         // decide_scratch_bytes(row_stride, rows)
+  int64_t* best_score;   // [n_pods] ...
+  int32_t* best_node;
+  int32_t* best_ties;
+  int32_t* best_feasible;
+};
+size_t decide_scratch_bytes(int64_t row_stride, int64_t rows);
+void launch_decide_trimaran(const DecideLaunch& d, hipStream_t s);
 // raw int64 Score() of one pod row for `plugin` (SPX_PLUGIN_TLP / SPX_PLUGIN_LVRB)
 void launch_trimaran_raw(const TrimaranArgs& a, int plugin, int64_t pod_row, int64_t* out, hipStream_t s);
 

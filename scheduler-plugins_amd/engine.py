@@ -363,6 +363,10 @@ class Engine:
     def eval_best(self, plugin_mask: int, row_begin: int = 0, row_end: Optional[int] = None) -> None:
         self._ck(self._lib.spx_eval_best(self._h, plugin_mask, row_begin, self.n_pods if row_end is None else row_end))
 
+    def decide(self, plugin_mask: int, row_begin: int = 0, row_end: Optional[int] = None) -> None:
+        """eval + per-row argmax without materialising score tables where the profile allows (spx_decide); read with best()"""
+        self._ck(self._lib.spx_decide(self._h, plugin_mask, row_begin, self.n_pods if row_end is None else row_end))
+
     def best(self, row_begin: int = 0, row_end: Optional[int] = None):
         """(best node, weighted score, ties, feasible count) per pod row."""
         row_end = self.n_pods if row_end is None else row_end

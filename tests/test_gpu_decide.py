@@ -1,0 +1,62 @@
+"""spx_decide: the per-pod decision (best node, weighted score, ties, feasible) computed without materialising score tables
+must equal spx_eval + spx_eval_best exactly — it is the same float32/float64 cell code with the argmax folded in."""
+import numpy as np
+import pytest
+
+from helpers import ALLOCATABLE, LVRB, TLP
+from scheduler_plugins_amd import synth
+from scheduler_plugins_amd.engine import Engine, mask_of
+
+pytestmark = pytest.mark.gpu
+
+
+def both(e, mask, rb=0, re=None):
+    e.eval(mask, rb, re)
+    e.eval_best(mask, rb, re)
+    want = [x.copy() for x in e.best(rb, re)]
+    e.decide(mask, rb, re)
+    got = e.best(rb, re)
+    return want, got
+
+
+@pytest.mark.parametrize("n_nodes,n_pods,seed,round_frac", [(1, 1, 1, 0.0), (17, 5, 2, 1.0), (1023, 70, 3, 0.3), (1025, 130, 4, 0.0),
+                                                              (3000, 257, 5, 1.0), (10_000, 300, 6, 0.1)])
+@pytest.mark.parametrize("plugins,weights", [((ALLOCATABLE, TLP), {ALLOCATABLE: 1, TLP: 1}), ((TLP,), {TLP: 3}),
+                                             ((ALLOCATABLE, TLP), {ALLOCATABLE: 5, TLP: 2}), ((ALLOCATABLE, TLP), {ALLOCATABLE: 0, TLP: 1})])
+def test_decide_equals_eval_plus_argmax(gpu_required, hdr, n_nodes, n_pods, seed, round_frac, plugins, weights):
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=seed, round_frac=round_frac)
+    with Engine(0) as e:
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        e.set_plugin_weights(weights)
+        want, got = both(e, mask_of(*plugins))
+    for name, w, g in zip(("node", "score", "ties", "feasible"), want, got):
+        assert (w == g).all(), (name, np.flatnonzero(w != g)[:5], w[w != g][:5], g[w != g][:5])
+    assert (want[2] > 1).any() or round_frac == 0.0 or n_nodes < 1000   # the larger rounded snapshots do produce ties
+
+
+def test_partial_rows_and_unfused_profiles(gpu_required, hdr):
+    snap = synth.trimaran_snapshot(hdr, 777, 200, seed=8, round_frac=0.5)
+    with Engine(0) as e:
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        want, got = both(e, mask_of(ALLOCATABLE, TLP), 37, 151)
+        for w, g in zip(want, got):
+            assert (w == g).all()
+        # a profile the fused form does not cover runs eval + eval_best inside: same answer by definition, tables evaluated
+        want, got = both(e, mask_of(ALLOCATABLE, TLP, LVRB))
+        for w, g in zip(want, got):
+            assert (w == g).all()
+        # a caller feasibility mask also takes the unfused route
+        rng = np.random.default_rng(1)
+        e.upload_feasible_mask((rng.random((200, 777)) < 0.7).astype(np.uint8))
+        want, got = both(e, mask_of(ALLOCATABLE, TLP))
+        for w, g in zip(want, got):
+            assert (w == g).all()
+
+
+def test_config2_size(gpu_required, hdr):
+    snap = synth.trimaran_snapshot(hdr, 10_000, 100_000)
+    with Engine(0) as e:
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        want, got = both(e, mask_of(ALLOCATABLE, TLP))
+    for w, g in zip(want, got):
+        assert (w == g).all()
