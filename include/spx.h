@@ -710,6 +710,21 @@ int spx_ingest_nrt_json(spx_ingest* h, const char* json, int64_t len, int64_t* n
 const spx_nrt_objects* spx_ingest_nrt_objects(const spx_ingest* h);
 const spx_resource_classes* spx_ingest_resource_classes(const spx_ingest* h);
 int32_t spx_ingest_resource_id(const spx_ingest* h, const char* name);
+/* v1.Node objects -> spx_node_objects in the handle's node order (by metadata.name): status.allocatable / capacity in canonical
+ * units, the scalar resources framework.Resource.Add keeps, topology.kubernetes.io/region and /zone label values interned
+ * (-1 when absent or empty).  v1.Pod objects -> spx_pod_objects, appended in document order until spx_ingest_pods_reset: init
+ * containers first (restartPolicy Always = SPX_CTR_SIDECAR) then app containers, requests / limits / overhead lists in document
+ * order, spec.priority, metadata.creationTimestamp as queue timestamp (microseconds), namespace and the two AppGroup labels
+ * (appgroup.diktyo.x-k8s.io, appgroup.diktyo.x-k8s.io.workload) interned, -1 when absent.  Name id spaces (kind: 0 region, 1 zone,
+ * 2 namespace, 3 AppGroup, 4 workload selector) grow in first-seen order; spx_ingest_seed_names fixes them beforehand — workload
+ * selectors MUST be seeded in lexicographic order (see spx_appgroup_objects). */
+int spx_ingest_nodes_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_objects_out, int64_t* n_unknown_out);
+int spx_ingest_pods_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_objects_out);
+int spx_ingest_pods_reset(spx_ingest* h);
+const spx_node_objects* spx_ingest_node_objects(const spx_ingest* h);
+const spx_pod_objects* spx_ingest_pod_objects(const spx_ingest* h);
+int spx_ingest_seed_names(spx_ingest* h, int32_t kind, const char* const* names, int32_t n);
+int32_t spx_ingest_name_id(const spx_ingest* h, int32_t kind, const char* name);
 /* resource.Quantity text -> canonical int64: MilliValue() when milli != 0 (cpu), Value() otherwise; both round up */
 int spx_ingest_quantity(const char* text, int32_t milli, int64_t* out);
 

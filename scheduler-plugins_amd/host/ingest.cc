@@ -1,4 +1,4 @@
-// ingest_nrt.cc — wire format -> object tables for NodeResourceTopology (first slice).
+// ingest.cc — wire format -> object tables: NodeResourceTopology, v1.Node, v1.Pod.
 // Host-side product code: what the API server sends (JSON of topology.node.k8s.io/v1alpha2 NodeResourceTopology objects — a
 // single object, a List with "items", or a bare array) decoded straight into the spx_nrt_objects columns the flattener
 // consumes, without an intermediate object graph.  The schema is the reference's own CRD
@@ -12,6 +12,12 @@
 //
 // Resource names are interned in first-seen order after the five fixed ids of spx.h; a caller that already interned names
 // for its pod tables passes them in so that both sides share one id space.
+//
+// v1.Node and v1.Pod (core/v1 JSON as the API server serves it) fill spx_node_objects / spx_pod_objects the way the Go shim of
+// INTEGRATION.md section 3 would: allocatable / capacity in canonical units, the scalar resources framework.Resource.Add keeps,
+// the two topology labels; per pod the init containers first (restartPolicy Always = sidecar) then the app containers with
+// their request / limit lists in document order, overhead, priority, namespace and the two AppGroup labels the network-aware
+// plugins read (pkg/networkaware/util/util.go:67-75; key strings as in manifests/appgroup/deploy-onlineBoutique-*.yaml).
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -345,6 +351,39 @@ struct spx_ingest {
   spx_nrt_objects table{};
   spx_resource_classes classes{};
   std::unordered_map<std::string, int64_t> node_index;
+
+  // ---- v1.Node / v1.Pod
+  struct Names {
+    std::unordered_map<std::string, int32_t> ids;
+    std::vector<std::string> names;
+    int32_t id(const std::string& n) {
+      auto it = ids.find(n);
+      if (it != ids.end()) return it->second;
+      const int32_t v = static_cast<int32_t>(names.size());
+      ids.emplace(n, v);
+      names.push_back(n);
+      return v;
+    }
+    int32_t find(const char* n) const {
+      auto it = ids.find(n);
+      return it == ids.end() ? -1 : it->second;
+    }
+  };
+  Names regions, zones, namespaces, appgroups, selectors;
+  struct NodeObj {
+    int64_t alloc_cpu = 0, alloc_mem = 0, alloc_eph = 0, alloc_pods = 0, cap_cpu = 0;
+    std::vector<std::pair<int32_t, int64_t>> scalars;
+    int32_t region = -1, zone = -1;
+  };
+  std::vector<NodeObj> node_objs;
+  std::vector<int64_t> n_alloc_cpu, n_alloc_mem, n_alloc_eph, n_alloc_pods, n_scalar_qty, n_cap_cpu;
+  std::vector<int32_t> n_scalar_ptr, n_scalar_res, n_region, n_zone;
+  spx_node_objects node_table{};
+  // pods are appended in document order
+  std::vector<int32_t> p_ctr_ptr{0}, p_req_ptr{0}, p_lim_ptr{0}, p_ovh_ptr{0}, p_req_res, p_lim_res, p_ovh_res, p_priority, p_appgroup, p_selector, p_ns;
+  std::vector<uint8_t> p_kind;
+  std::vector<int64_t> p_req_qty, p_lim_qty, p_ovh_qty, p_queue_ts;
+  spx_pod_objects pod_table{};
 };
 
 namespace {
@@ -533,11 +572,13 @@ void freeze(spx_ingest* h) {
 
 }  // namespace
 
+static void freeze_nodes_initial(spx_ingest* h);
 extern "C" int spx_ingest_create(const char* const* node_names, int64_t n_nodes, const char* const* resource_names, int32_t n_resource_names,
                                  spx_ingest** out) {
   if (!out || n_nodes <= 0 || !node_names) return SPX_ERR_ARG;
   auto* h = new spx_ingest();
   h->rows.resize(static_cast<size_t>(n_nodes));
+  h->node_objs.resize(static_cast<size_t>(n_nodes));
   for (int64_t i = 0; i < n_nodes; ++i) {
     if (!node_names[i]) {
       delete h;
@@ -548,6 +589,7 @@ extern "C" int spx_ingest_create(const char* const* node_names, int64_t n_nodes,
   for (int32_t i = 0; i < n_resource_names; ++i)
     if (resource_names && resource_names[i]) h->res.id(resource_names[i]);
   freeze(h);
+  freeze_nodes_initial(h);
   *out = h;
   return SPX_OK;
 }
@@ -612,4 +654,342 @@ extern "C" int32_t spx_ingest_resource_id(const spx_ingest* h, const char* name)
 extern "C" int spx_ingest_quantity(const char* text, int32_t milli, int64_t* out) {
   if (!text || !out) return SPX_ERR_ARG;
   return canonical_quantity(text, milli != 0, out) ? SPX_OK : SPX_ERR_ARG;
+}
+
+// ====================================================================== v1.Node / v1.Pod
+namespace {
+
+// top level: one object, a List ("items") or an array; calls one() with the reader positioned at each object
+template <typename Fn>
+bool for_each_object(Reader& r, Fn&& one) {
+  const char c = r.peek();
+  if (c == '[') return r.array([&] { return r.peek() == '{' ? one() : r.fail("list entry is not an object"); });
+  if (c != '{') return r.fail("expected an object, a List or an array");
+  Reader probe{r.p, r.end, {}, {}};
+  bool is_list = false;
+  probe.object([&](const std::string& k) {
+    if (k == "items") is_list = true;
+    return probe.skip();
+  });
+  if (!is_list) return one();
+  return r.object([&](const std::string& k) {
+    if (k != "items") return r.skip();
+    return r.array([&] { return r.peek() == '{' ? one() : r.fail("list entry is not an object"); });
+  });
+}
+
+// a v1.ResourceList object: fn(resource name, canonical quantity) per member, in document order
+template <typename Fn>
+bool resource_list(spx_ingest* h, Reader& r, std::string& buf, Fn&& fn) {
+  if (r.peek() == 'n') return r.skip();  // null
+  return r.object([&](const std::string& name) {
+    const std::string rn = name;  // the reader reuses its key buffer
+    if (!r.scalar(buf)) return false;
+    int64_t q = 0;
+    if (!canonical_quantity(buf, rn == "cpu", &q)) {
+      if (h->err.empty()) h->err = "bad quantity for " + rn + ": " + buf;
+      return false;
+    }
+    fn(rn, q);
+    return true;
+  });
+}
+
+bool scalar_resource_name(const std::string& n) { return (Interner::flags(n) & SPX_RC_SCALAR) != 0; }
+
+bool decode_node(spx_ingest* h, Reader& r) {
+  spx_ingest::NodeObj o;
+  std::string name, buf, region, zone;
+  bool have_name = false, has_region = false, has_zone = false;
+  const bool ok = r.object([&](const std::string& k) {
+    if (k == "metadata") {
+      return r.object([&](const std::string& mk) {
+        if (mk == "name" && r.peek() == '"') return have_name = true, r.str(name);
+        if (mk == "labels" && r.peek() == '{') {
+          return r.object([&](const std::string& lk) {
+            if (lk == "topology.kubernetes.io/region" && r.peek() == '"') return has_region = true, r.str(region);
+            if (lk == "topology.kubernetes.io/zone" && r.peek() == '"') return has_zone = true, r.str(zone);
+            return r.skip();
+          });
+        }
+        return r.skip();
+      });
+    }
+    if (k == "status" && r.peek() == '{') {
+      return r.object([&](const std::string& sk) {
+        if (sk == "allocatable") {
+          return resource_list(h, r, buf, [&](const std::string& rn, int64_t q) {
+            if (rn == "cpu") o.alloc_cpu = q;
+            else if (rn == "memory") o.alloc_mem = q;
+            else if (rn == "ephemeral-storage") o.alloc_eph = q;
+            else if (rn == "pods") o.alloc_pods = q;
+            else if (scalar_resource_name(rn)) o.scalars.emplace_back(h->res.id(rn), q);  // framework.Resource.Add keeps scalar names only
+          });
+        }
+        if (sk == "capacity") {
+          return resource_list(h, r, buf, [&](const std::string& rn, int64_t q) {
+            if (rn == "cpu") o.cap_cpu = q;
+          });
+        }
+        return r.skip();
+      });
+    }
+    return r.skip();
+  });
+  if (!ok) return false;
+  if (!have_name) return h->err = "Node without metadata.name", false;
+  auto it = h->node_index.find(name);
+  if (it == h->node_index.end()) {
+    ++h->unknown;
+    return true;
+  }
+  // an empty label value counts as unset, as the plugins' `region != ""` tests treat it (networkoverhead.go:459, :479)
+  o.region = (has_region && !region.empty()) ? h->regions.id(region) : -1;
+  o.zone = (has_zone && !zone.empty()) ? h->zones.id(zone) : -1;
+  h->node_objs[static_cast<size_t>(it->second)] = std::move(o);
+  return true;
+}
+
+void freeze_nodes(spx_ingest* h) {
+  const size_t n = h->node_objs.size();
+  h->n_alloc_cpu.resize(n), h->n_alloc_mem.resize(n), h->n_alloc_eph.resize(n), h->n_alloc_pods.resize(n), h->n_cap_cpu.resize(n);
+  h->n_region.resize(n), h->n_zone.resize(n);
+  h->n_scalar_ptr.assign(1, 0), h->n_scalar_res.clear(), h->n_scalar_qty.clear();
+  for (size_t i = 0; i < n; ++i) {
+    const auto& o = h->node_objs[i];
+    h->n_alloc_cpu[i] = o.alloc_cpu, h->n_alloc_mem[i] = o.alloc_mem, h->n_alloc_eph[i] = o.alloc_eph, h->n_alloc_pods[i] = o.alloc_pods;
+    h->n_cap_cpu[i] = o.cap_cpu, h->n_region[i] = o.region, h->n_zone[i] = o.zone;
+    for (const auto& s : o.scalars) h->n_scalar_res.push_back(s.first), h->n_scalar_qty.push_back(s.second);
+    h->n_scalar_ptr.push_back(static_cast<int32_t>(h->n_scalar_res.size()));
+  }
+  spx_node_objects& t = h->node_table;
+  t.n_nodes = static_cast<int64_t>(n);
+  t.alloc_cpu_milli = h->n_alloc_cpu.data(), t.alloc_mem = h->n_alloc_mem.data(), t.alloc_eph = h->n_alloc_eph.data();
+  t.alloc_pods = h->n_alloc_pods.data(), t.scalar_ptr = h->n_scalar_ptr.data(), t.scalar_res = h->n_scalar_res.data();
+  t.scalar_qty = h->n_scalar_qty.data(), t.cap_cpu_milli = h->n_cap_cpu.data(), t.region = h->n_region.data(), t.zone = h->n_zone.data();
+}
+
+// RFC 3339 timestamp -> microseconds since the epoch (0 when malformed): metav1.Time as the API server writes it
+int64_t rfc3339_micros(const std::string& t) {
+  auto num = [&](size_t pos, size_t len, int* out) {
+    if (pos + len > t.size()) return false;
+    int v = 0;
+    for (size_t i = pos; i < pos + len; ++i) {
+      if (t[i] < '0' || t[i] > '9') return false;
+      v = v * 10 + (t[i] - '0');
+    }
+    *out = v;
+    return true;
+  };
+  int y, mo, d, hh, mm, ss;
+  if (t.size() < 20 || !num(0, 4, &y) || t[4] != '-' || !num(5, 2, &mo) || t[7] != '-' || !num(8, 2, &d) || (t[10] != 'T' && t[10] != 't') ||
+      !num(11, 2, &hh) || t[13] != ':' || !num(14, 2, &mm) || t[16] != ':' || !num(17, 2, &ss))
+    return 0;
+  size_t i = 19;
+  int64_t frac = 0;
+  if (i < t.size() && t[i] == '.') {
+    int digits = 0;
+    for (++i; i < t.size() && t[i] >= '0' && t[i] <= '9'; ++i)
+      if (digits < 6) frac = frac * 10 + (t[i] - '0'), ++digits;
+    for (; digits < 6; ++digits) frac *= 10;
+  }
+  int64_t offset = 0;
+  if (i < t.size() && (t[i] == '+' || t[i] == '-')) {
+    int oh, om;
+    if (!num(i + 1, 2, &oh) || i + 3 >= t.size() || t[i + 3] != ':' || !num(i + 4, 2, &om)) return 0;
+    offset = (t[i] == '-' ? -1 : 1) * (oh * 3600 + om * 60);
+  } else if (i >= t.size() || (t[i] != 'Z' && t[i] != 'z')) {
+    return 0;
+  }
+  // days from civil (proleptic Gregorian)
+  const int yy = y - (mo <= 2);
+  const int era = (yy >= 0 ? yy : yy - 399) / 400;
+  const unsigned yoe = static_cast<unsigned>(yy - era * 400);
+  const unsigned doy = static_cast<unsigned>((153 * (mo + (mo > 2 ? -3 : 9)) + 2) / 5 + d - 1);
+  const unsigned doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+  const int64_t days = static_cast<int64_t>(era) * 146097 + static_cast<int64_t>(doe) - 719468;
+  return ((days * 86400 + hh * 3600 + mm * 60 + ss) - offset) * 1000000 + frac;
+}
+
+struct CtrRow {
+  uint8_t kind;
+  std::vector<std::pair<int32_t, int64_t>> req, lim;
+};
+
+bool decode_container(spx_ingest* h, Reader& r, std::string& buf, bool init, CtrRow* c) {
+  c->kind = init ? SPX_CTR_INIT : SPX_CTR_APP;
+  return r.object([&](const std::string& k) {
+    if (k == "resources" && r.peek() == '{') {
+      return r.object([&](const std::string& rk) {
+        if (rk == "requests") return resource_list(h, r, buf, [&](const std::string& rn, int64_t q) { c->req.emplace_back(h->res.id(rn), q); });
+        if (rk == "limits") return resource_list(h, r, buf, [&](const std::string& rn, int64_t q) { c->lim.emplace_back(h->res.id(rn), q); });
+        return r.skip();
+      });
+    }
+    if (k == "restartPolicy" && init && r.peek() == '"') {  // a restartable init container is a sidecar (pkg/util/sidecar.go)
+      if (!r.str(buf)) return false;
+      if (buf == "Always") c->kind = SPX_CTR_SIDECAR;
+      return true;
+    }
+    return r.skip();
+  });
+}
+
+bool decode_pod(spx_ingest* h, Reader& r) {
+  std::vector<CtrRow> init, app;
+  std::vector<std::pair<int32_t, int64_t>> overhead;
+  std::string buf, ns, group, selector, created;
+  bool has_group = false, has_selector = false;
+  int64_t priority = 0;
+  const bool ok = r.object([&](const std::string& k) {
+    if (k == "metadata" && r.peek() == '{') {
+      return r.object([&](const std::string& mk) {
+        if (mk == "namespace" && r.peek() == '"') return r.str(ns);
+        if (mk == "creationTimestamp" && r.peek() == '"') return r.str(created);
+        if (mk == "labels" && r.peek() == '{') {
+          return r.object([&](const std::string& lk) {
+            if (lk == "appgroup.diktyo.x-k8s.io" && r.peek() == '"') return has_group = true, r.str(group);
+            if (lk == "appgroup.diktyo.x-k8s.io.workload" && r.peek() == '"') return has_selector = true, r.str(selector);
+            return r.skip();
+          });
+        }
+        return r.skip();
+      });
+    }
+    if (k == "spec" && r.peek() == '{') {
+      return r.object([&](const std::string& sk) {
+        if (sk == "containers" && r.peek() == '[') {
+          return r.array([&] {
+            app.emplace_back();
+            return decode_container(h, r, buf, false, &app.back());
+          });
+        }
+        if (sk == "initContainers" && r.peek() == '[') {
+          return r.array([&] {
+            init.emplace_back();
+            return decode_container(h, r, buf, true, &init.back());
+          });
+        }
+        if (sk == "overhead") return resource_list(h, r, buf, [&](const std::string& rn, int64_t q) { overhead.emplace_back(h->res.id(rn), q); });
+        if (sk == "priority" && r.peek() != 'n') {
+          if (!r.scalar(buf) || !canonical_quantity(buf, false, &priority)) return r.fail("bad spec.priority");
+          return true;
+        }
+        return r.skip();
+      });
+    }
+    return r.skip();
+  });
+  if (!ok) return false;
+  auto emit = [&](const CtrRow& c) {  // init containers first, then app containers: the order the reference walks them in
+    h->p_kind.push_back(c.kind);
+    for (const auto& e : c.req) h->p_req_res.push_back(e.first), h->p_req_qty.push_back(e.second);
+    for (const auto& e : c.lim) h->p_lim_res.push_back(e.first), h->p_lim_qty.push_back(e.second);
+    h->p_req_ptr.push_back(static_cast<int32_t>(h->p_req_res.size()));
+    h->p_lim_ptr.push_back(static_cast<int32_t>(h->p_lim_res.size()));
+  };
+  for (const CtrRow& c : init) emit(c);
+  for (const CtrRow& c : app) emit(c);
+  h->p_ctr_ptr.push_back(static_cast<int32_t>(h->p_kind.size()));
+  for (const auto& e : overhead) h->p_ovh_res.push_back(e.first), h->p_ovh_qty.push_back(e.second);
+  h->p_ovh_ptr.push_back(static_cast<int32_t>(h->p_ovh_res.size()));
+  h->p_priority.push_back(static_cast<int32_t>(priority));
+  h->p_queue_ts.push_back(rfc3339_micros(created));
+  h->p_appgroup.push_back((has_group && !group.empty()) ? h->appgroups.id(group) : -1);
+  h->p_selector.push_back((has_selector && !selector.empty()) ? h->selectors.id(selector) : -1);
+  h->p_ns.push_back(h->namespaces.id(ns));
+  return true;
+}
+
+void freeze_pods(spx_ingest* h) {
+  spx_pod_objects& t = h->pod_table;
+  t.n_pods = static_cast<int64_t>(h->p_priority.size());
+  t.ctr_ptr = h->p_ctr_ptr.data(), t.ctr_kind = h->p_kind.data();
+  t.req_ptr = h->p_req_ptr.data(), t.req_res = h->p_req_res.data(), t.req_qty = h->p_req_qty.data();
+  t.lim_ptr = h->p_lim_ptr.data(), t.lim_res = h->p_lim_res.data(), t.lim_qty = h->p_lim_qty.data();
+  t.ovh_ptr = h->p_ovh_ptr.data(), t.ovh_res = h->p_ovh_res.data(), t.ovh_qty = h->p_ovh_qty.data();
+  t.priority = h->p_priority.data(), t.queue_ts = h->p_queue_ts.data(), t.appgroup = h->p_appgroup.data();
+  t.selector = h->p_selector.data(), t.ns = h->p_ns.data();
+}
+
+void refresh_classes(spx_ingest* h) {  // the resource interner may have grown
+  h->flags.assign(h->res.names.size(), 0);
+  for (size_t i = 0; i < h->res.names.size(); ++i)
+    if (!h->res.names[i].empty()) h->flags[i] = Interner::flags(h->res.names[i]);
+  h->classes.n_res = static_cast<int32_t>(h->flags.size());
+  h->classes.flags = h->flags.data();
+}
+
+template <typename Fn>
+int run_decoder(spx_ingest* h, const char* json, int64_t len, int64_t* n_out, Fn&& one) {
+  h->err.clear();
+  h->unknown = 0;
+  Reader r{json, json + len, {}, {}};
+  int64_t n = 0;
+  bool ok = for_each_object(r, [&] {
+    ++n;
+    return one(r);
+  });
+  if (ok && r.peek() != '\0') ok = r.fail("trailing characters");
+  if (!ok && h->err.empty()) h->err = "JSON: " + r.err;
+  if (n_out) *n_out = n;
+  return ok ? SPX_OK : SPX_ERR_ARG;
+}
+
+}  // namespace
+
+extern "C" int spx_ingest_nodes_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_objects_out, int64_t* n_unknown_out) {
+  if (!h || !json || len < 0) return SPX_ERR_ARG;
+  const int rc = run_decoder(h, json, len, n_objects_out, [&](Reader& r) { return decode_node(h, r); });
+  freeze_nodes(h);
+  refresh_classes(h);
+  if (n_unknown_out) *n_unknown_out = h->unknown;
+  return rc;
+}
+
+extern "C" int spx_ingest_pods_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_objects_out) {
+  if (!h || !json || len < 0) return SPX_ERR_ARG;
+  // a failed document must not leave half a pod behind: remember the sizes and roll back
+  const size_t n_pods = h->p_priority.size(), n_ctr = h->p_kind.size(), n_req = h->p_req_res.size(), n_lim = h->p_lim_res.size(), n_ovh = h->p_ovh_res.size();
+  const int rc = run_decoder(h, json, len, n_objects_out, [&](Reader& r) { return decode_pod(h, r); });
+  if (rc != SPX_OK) {
+    h->p_priority.resize(n_pods), h->p_queue_ts.resize(n_pods), h->p_appgroup.resize(n_pods), h->p_selector.resize(n_pods), h->p_ns.resize(n_pods);
+    h->p_ctr_ptr.resize(n_pods + 1), h->p_ovh_ptr.resize(n_pods + 1), h->p_kind.resize(n_ctr), h->p_req_ptr.resize(n_ctr + 1), h->p_lim_ptr.resize(n_ctr + 1);
+    h->p_req_res.resize(n_req), h->p_req_qty.resize(n_req), h->p_lim_res.resize(n_lim), h->p_lim_qty.resize(n_lim);
+    h->p_ovh_res.resize(n_ovh), h->p_ovh_qty.resize(n_ovh);
+  }
+  freeze_pods(h);
+  refresh_classes(h);
+  return rc;
+}
+
+extern "C" int spx_ingest_pods_reset(spx_ingest* h) {
+  if (!h) return SPX_ERR_ARG;
+  h->p_ctr_ptr.assign(1, 0), h->p_req_ptr.assign(1, 0), h->p_lim_ptr.assign(1, 0), h->p_ovh_ptr.assign(1, 0);
+  h->p_kind.clear(), h->p_req_res.clear(), h->p_req_qty.clear(), h->p_lim_res.clear(), h->p_lim_qty.clear(), h->p_ovh_res.clear(), h->p_ovh_qty.clear();
+  h->p_priority.clear(), h->p_queue_ts.clear(), h->p_appgroup.clear(), h->p_selector.clear(), h->p_ns.clear();
+  freeze_pods(h);
+  return SPX_OK;
+}
+
+extern "C" const spx_node_objects* spx_ingest_node_objects(const spx_ingest* h) { return h ? &h->node_table : nullptr; }
+extern "C" const spx_pod_objects* spx_ingest_pod_objects(const spx_ingest* h) { return h ? &h->pod_table : nullptr; }
+
+// kind: 0 region, 1 zone, 2 namespace, 3 AppGroup name, 4 workload selector
+extern "C" int spx_ingest_seed_names(spx_ingest* h, int32_t kind, const char* const* names, int32_t n) {
+  if (!h || kind < 0 || kind > 4 || (n > 0 && !names)) return SPX_ERR_ARG;
+  spx_ingest::Names* t[] = {&h->regions, &h->zones, &h->namespaces, &h->appgroups, &h->selectors};
+  for (int32_t i = 0; i < n; ++i)
+    if (names[i]) t[kind]->id(names[i]);
+  return SPX_OK;
+}
+extern "C" int32_t spx_ingest_name_id(const spx_ingest* h, int32_t kind, const char* name) {
+  if (!h || kind < 0 || kind > 4 || !name) return -1;
+  const spx_ingest::Names* t[] = {&h->regions, &h->zones, &h->namespaces, &h->appgroups, &h->selectors};
+  return t[kind]->find(name);
+}
+
+static void freeze_nodes_initial(spx_ingest* h) {
+  freeze_nodes(h);
+  freeze_pods(h);
 }

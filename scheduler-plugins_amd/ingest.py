@@ -1,4 +1,4 @@
-"""ctypes wrapper of the wire-format ingester (host/ingest_nrt.cc): NodeResourceTopology JSON -> spx_nrt_objects."""
+"""ctypes wrapper of the wire-format ingester (host/ingest.cc): NodeResourceTopology JSON -> spx_nrt_objects."""
 from __future__ import annotations
 
 import ctypes as C
@@ -62,6 +62,39 @@ class NrtIngest:
 
     def resource_id(self, name: str) -> int:
         return self._lib.spx_ingest_resource_id(self._h, name.encode())
+
+    # ------------------------------------------------------------------ v1.Node / v1.Pod
+    KINDS = {"region": 0, "zone": 1, "namespace": 2, "appgroup": 3, "selector": 4}
+
+    def seed(self, kind: str, names: Sequence[str]) -> None:
+        arr = (C.c_char_p * max(len(names), 1))(*[n.encode() for n in names])
+        rc = self._lib.spx_ingest_seed_names(self._h, self.KINDS[kind], C.cast(arr, C.POINTER(C.POINTER(C.c_char))), len(names))
+        if rc != 0:
+            raise RuntimeError(f"spx_ingest_seed_names failed: {rc}")
+
+    def name_id(self, kind: str, name: str) -> int:
+        return self._lib.spx_ingest_name_id(self._h, self.KINDS[kind], name.encode())
+
+    def feed_nodes(self, json_bytes: bytes):
+        n, unk = C.c_int64(), C.c_int64()
+        if self._lib.spx_ingest_nodes_json(self._h, json_bytes, len(json_bytes), C.byref(n), C.byref(unk)) != 0:
+            raise ValueError(self._lib.spx_ingest_error(self._h).decode())
+        return n.value, unk.value
+
+    def feed_pods(self, json_bytes: bytes) -> int:
+        n = C.c_int64()
+        if self._lib.spx_ingest_pods_json(self._h, json_bytes, len(json_bytes), C.byref(n)) != 0:
+            raise ValueError(self._lib.spx_ingest_error(self._h).decode())
+        return n.value
+
+    def reset_pods(self) -> None:
+        self._lib.spx_ingest_pods_reset(self._h)
+
+    def node_objects(self) -> _Borrowed:
+        return _Borrowed(self._lib.spx_ingest_node_objects(self._h), self)
+
+    def pod_objects(self) -> _Borrowed:
+        return _Borrowed(self._lib.spx_ingest_pod_objects(self._h), self)
 
 
 def quantity(text: str, milli: bool) -> Optional[int]:
