@@ -725,6 +725,16 @@ const spx_node_objects* spx_ingest_node_objects(const spx_ingest* h);
 const spx_pod_objects* spx_ingest_pod_objects(const spx_ingest* h);
 int spx_ingest_seed_names(spx_ingest* h, int32_t kind, const char* const* names, int32_t n);
 int32_t spx_ingest_name_id(const spx_ingest* h, int32_t kind, const char* name);
+/* AppGroup CRs (appgroup.diktyo.x-k8s.io/v1alpha1) -> spx_appgroup_objects, groups appended in document order (group id = name id of
+ * kind 3): spec.workloads[].workload.selector, their dependencies[].{workload.selector, maxNetworkCost}, status.topologyOrder[] as
+ * written.  Workload selectors are interned in lexicographic order when the selector table is still empty — feed AppGroups before
+ * pods — or must already be seeded in that order.  The scheduled-pods list is not part of the CR and stays empty.
+ * One NetworkTopology CR (networktopology.diktyo.x-k8s.io/v1alpha1) -> spx_nettopo_objects for the weights set weights_name
+ * (populateCostMap, networkoverhead.go:448-497); region / zone names share the id spaces of the node table (kinds 0 and 1). */
+int spx_ingest_appgroups_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_objects_out);
+const spx_appgroup_objects* spx_ingest_appgroup_objects(const spx_ingest* h);
+int spx_ingest_nettopo_json(spx_ingest* h, const char* json, int64_t len, const char* weights_name);
+const spx_nettopo_objects* spx_ingest_nettopo_objects(const spx_ingest* h);
 /* resource.Quantity text -> canonical int64: MilliValue() when milli != 0 (cpu), Value() otherwise; both round up */
 int spx_ingest_quantity(const char* text, int32_t milli, int64_t* out);
 

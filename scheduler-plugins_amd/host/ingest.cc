@@ -19,6 +19,7 @@
 // their request / limit lists in document order, overhead, priority, namespace and the two AppGroup labels the network-aware
 // plugins read (pkg/networkaware/util/util.go:67-75; key strings as in manifests/appgroup/deploy-onlineBoutique-*.yaml).
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -384,6 +385,14 @@ struct spx_ingest {
   std::vector<uint8_t> p_kind;
   std::vector<int64_t> p_req_qty, p_lim_qty, p_ovh_qty, p_queue_ts;
   spx_pod_objects pod_table{};
+  // ---- AppGroup / NetworkTopology CRs
+  std::vector<int32_t> g_wl_ptr{0}, g_wl_selector, g_dep_ptr{0}, g_dep_selector, g_topo_ptr{0}, g_topo_selector, g_topo_index, g_placed_ptr{0};
+  std::vector<int64_t> g_dep_max_cost;
+  spx_appgroup_objects group_table{};
+  std::vector<std::vector<std::pair<int32_t, int64_t>>> nt_region, nt_zone;  // per origin id: (destination id, cost) in document order
+  std::vector<int32_t> nt_rc_ptr{0}, nt_rc_dest, nt_zc_ptr{0}, nt_zc_dest;
+  std::vector<int64_t> nt_rc_cost, nt_zc_cost;
+  spx_nettopo_objects nettopo_table{};
 };
 
 namespace {
@@ -989,7 +998,248 @@ extern "C" int32_t spx_ingest_name_id(const spx_ingest* h, int32_t kind, const c
   return t[kind]->find(name);
 }
 
+
+// ====================================================================== AppGroup / NetworkTopology CRs (network-aware plugins)
+// Schemas: manifests/crds/appgroup.diktyo.x-k8s.io_appgroups.yaml, networktopology.diktyo.x-k8s.io_networktopologies.yaml.
+namespace {
+
+struct DepRow {
+  std::string selector;
+  int64_t max_cost = 0;
+};
+struct WorkloadRow {
+  std::string selector;
+  std::vector<DepRow> deps;
+};
+struct GroupRow {
+  std::string name;
+  std::vector<WorkloadRow> workloads;
+  std::vector<std::pair<std::string, int64_t>> topo;  // Status.TopologyOrder as written (the plugins binary-search it as is)
+};
+
+// {"workload": {"selector": "..."}} -> selector
+bool workload_selector(Reader& r, std::string& out, bool* found) {
+  return r.object([&](const std::string& k) {
+    if (k == "selector" && r.peek() == '"') return *found = true, r.str(out);
+    return r.skip();
+  });
+}
+
+bool decode_appgroup(spx_ingest* h, Reader& r, GroupRow* g) {
+  std::string buf;
+  return r.object([&](const std::string& k) {
+    if (k == "metadata" && r.peek() == '{') {
+      return r.object([&](const std::string& mk) { return (mk == "name" && r.peek() == '"') ? r.str(g->name) : r.skip(); });
+    }
+    if (k == "spec" && r.peek() == '{') {
+      return r.object([&](const std::string& sk) {
+        if (sk != "workloads" || r.peek() != '[') return r.skip();
+        return r.array([&] {
+          WorkloadRow w;
+          bool has_sel = false;
+          if (!r.object([&](const std::string& wk) {
+                if (wk == "workload" && r.peek() == '{') return workload_selector(r, w.selector, &has_sel);
+                if (wk == "dependencies" && r.peek() == '[') {
+                  return r.array([&] {
+                    DepRow d;
+                    bool dsel = false;
+                    if (!r.object([&](const std::string& dk) {
+                          if (dk == "workload" && r.peek() == '{') return workload_selector(r, d.selector, &dsel);
+                          if (dk == "maxNetworkCost" && r.peek() != 'n') return r.scalar(buf) && (canonical_quantity(buf, false, &d.max_cost) || r.fail("bad maxNetworkCost"));
+                          return r.skip();
+                        }))
+                      return false;
+                    if (!dsel) return h->err = "AppGroup dependency without workload.selector", false;
+                    w.deps.push_back(std::move(d));
+                    return true;
+                  });
+                }
+                return r.skip();
+              }))
+            return false;
+          if (!has_sel) return h->err = "AppGroup workload without workload.selector", false;
+          g->workloads.push_back(std::move(w));
+          return true;
+        });
+      });
+    }
+    if (k == "status" && r.peek() == '{') {
+      return r.object([&](const std::string& sk) {
+        if (sk != "topologyOrder" || r.peek() != '[') return r.skip();
+        return r.array([&] {
+          std::string sel;
+          int64_t index = 0;
+          bool has_sel = false;
+          if (!r.object([&](const std::string& tk) {
+                if (tk == "workload" && r.peek() == '{') return workload_selector(r, sel, &has_sel);
+                if (tk == "index" && r.peek() != 'n') return r.scalar(buf) && (canonical_quantity(buf, false, &index) || r.fail("bad topology index"));
+                return r.skip();
+              }))
+            return false;
+          if (!has_sel) return h->err = "topologyOrder entry without workload.selector", false;
+          g->topo.emplace_back(std::move(sel), index);
+          return true;
+        });
+      });
+    }
+    return r.skip();
+  });
+}
+
+
+void freeze_groups(spx_ingest* h) {
+  spx_appgroup_objects& t = h->group_table;
+  t.n_groups = static_cast<int32_t>(h->g_wl_ptr.size() - 1);
+  t.wl_ptr = h->g_wl_ptr.data(), t.wl_selector = h->g_wl_selector.data();
+  t.dep_ptr = h->g_dep_ptr.data(), t.dep_selector = h->g_dep_selector.data(), t.dep_max_cost = h->g_dep_max_cost.data();
+  t.topo_ptr = h->g_topo_ptr.data(), t.topo_selector = h->g_topo_selector.data(), t.topo_index = h->g_topo_index.data();
+  h->g_placed_ptr.assign(static_cast<size_t>(t.n_groups) + 1, 0);  // the scheduled list comes from the pod lister, not from the CR
+  t.placed_ptr = h->g_placed_ptr.data(), t.placed_selector = nullptr, t.placed_node = nullptr;
+}
+
+void freeze_nettopo(spx_ingest* h) {
+  auto flat = [](const std::vector<std::vector<std::pair<int32_t, int64_t>>>& per, size_t n, std::vector<int32_t>& ptr, std::vector<int32_t>& dest,
+                 std::vector<int64_t>& cost) {
+    ptr.assign(1, 0), dest.clear(), cost.clear();
+    for (size_t o = 0; o < n; ++o) {
+      if (o < per.size())
+        for (const auto& e : per[o]) dest.push_back(e.first), cost.push_back(e.second);
+      ptr.push_back(static_cast<int32_t>(dest.size()));
+    }
+  };
+  spx_nettopo_objects& t = h->nettopo_table;
+  t.n_regions = static_cast<int32_t>(h->regions.names.size());
+  t.n_zones = static_cast<int32_t>(h->zones.names.size());
+  flat(h->nt_region, h->regions.names.size(), h->nt_rc_ptr, h->nt_rc_dest, h->nt_rc_cost);
+  flat(h->nt_zone, h->zones.names.size(), h->nt_zc_ptr, h->nt_zc_dest, h->nt_zc_cost);
+  t.rc_ptr = h->nt_rc_ptr.data(), t.rc_dest = h->nt_rc_dest.data(), t.rc_cost = h->nt_rc_cost.data();
+  t.zc_ptr = h->nt_zc_ptr.data(), t.zc_dest = h->nt_zc_dest.data(), t.zc_cost = h->nt_zc_cost.data();
+}
+
+}  // namespace
+
+// AppGroup CRs -> spx_appgroup_objects (group id = position in the documents fed so far; also interned under kind 3).  The
+// selectors of all groups of one call are interned in lexicographic order when the selector table is still empty; otherwise
+// they must already be known (seeded by the caller in lexicographic order) — FindPodOrder compares selector strings.
+extern "C" int spx_ingest_appgroups_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_objects_out) {
+  if (!h || !json || len < 0) return SPX_ERR_ARG;
+  std::vector<GroupRow> groups;
+  const int rc = run_decoder(h, json, len, n_objects_out, [&](Reader& r) {
+    groups.emplace_back();
+    return decode_appgroup(h, r, &groups.back());
+  });
+  if (rc != SPX_OK) return rc;
+  std::vector<std::string> all;
+  for (const GroupRow& g : groups) {
+    for (const WorkloadRow& w : g.workloads) {
+      all.push_back(w.selector);
+      for (const DepRow& d : w.deps) all.push_back(d.selector);
+    }
+    for (const auto& t : g.topo) all.push_back(t.first);
+  }
+  std::sort(all.begin(), all.end());
+  all.erase(std::unique(all.begin(), all.end()), all.end());
+  if (h->selectors.names.empty()) {
+    for (const std::string& s : all) h->selectors.id(s);
+  } else {
+    for (const std::string& s : all)
+      if (h->selectors.find(s.c_str()) < 0) return h->err = "workload selector '" + s + "' is not in the seeded (lexicographically ordered) selector table", SPX_ERR_ARG;
+  }
+  for (const GroupRow& g : groups) {
+    h->appgroups.id(g.name);
+    for (const WorkloadRow& w : g.workloads) {
+      h->g_wl_selector.push_back(h->selectors.find(w.selector.c_str()));
+      for (const DepRow& d : w.deps) h->g_dep_selector.push_back(h->selectors.find(d.selector.c_str())), h->g_dep_max_cost.push_back(d.max_cost);
+      h->g_dep_ptr.push_back(static_cast<int32_t>(h->g_dep_selector.size()));
+    }
+    h->g_wl_ptr.push_back(static_cast<int32_t>(h->g_wl_selector.size()));
+    for (const auto& t : g.topo) h->g_topo_selector.push_back(h->selectors.find(t.first.c_str())), h->g_topo_index.push_back(static_cast<int32_t>(t.second));
+    h->g_topo_ptr.push_back(static_cast<int32_t>(h->g_topo_selector.size()));
+  }
+  freeze_groups(h);
+  return SPX_OK;
+}
+
+extern "C" const spx_appgroup_objects* spx_ingest_appgroup_objects(const spx_ingest* h) { return h ? &h->group_table : nullptr; }
+
+// one NetworkTopology CR -> spx_nettopo_objects for the weights set `weights_name` (NetworkOverheadArgs.WeightsName,
+// populateCostMap networkoverhead.go:448-497): spec.weights[name == weights_name].topologyList[topologyKey == region | zone label]
+// .originList[].{origin, costList[].{destination, networkCost}}.  Region / zone names share the id spaces of the node table.
+extern "C" int spx_ingest_nettopo_json(spx_ingest* h, const char* json, int64_t len, const char* weights_name) {
+  if (!h || !json || len < 0 || !weights_name) return SPX_ERR_ARG;
+  h->nt_region.clear(), h->nt_zone.clear();
+  std::string buf, wname, key, origin, dest;
+  const int rc = run_decoder(h, json, len, nullptr, [&](Reader& r) {
+    return r.object([&](const std::string& k) {
+      if (k != "spec" || r.peek() != '{') return r.skip();
+      return r.object([&](const std::string& sk) {
+        if (sk != "weights" || r.peek() != '[') return r.skip();
+        return r.array([&] {
+          // the weights entry may list its name after its topologyList: decode names into a scratch and intern them only on a match
+          using Origins = std::vector<std::pair<std::string, std::vector<std::pair<std::string, int64_t>>>>;
+          Origins reg, zon;
+          wname.clear();
+          if (!r.object([&](const std::string& wk) {
+                if (wk == "name" && r.peek() == '"') return r.str(wname);
+                if (wk != "topologyList" || r.peek() != '[') return r.skip();
+                return r.array([&] {
+                  key.clear();
+                  Origins origins;
+                  if (!r.object([&](const std::string& tk) {
+                        if (tk == "topologyKey" && r.peek() == '"') return r.str(key);
+                        if (tk != "originList" || r.peek() != '[') return r.skip();
+                        return r.array([&] {
+                          origins.emplace_back();
+                          auto& o = origins.back();
+                          return r.object([&](const std::string& ok) {
+                            if (ok == "origin" && r.peek() == '"') return r.str(o.first);
+                            if (ok != "costList" || r.peek() != '[') return r.skip();
+                            return r.array([&] {
+                              dest.clear();
+                              int64_t cost = 0;
+                              if (!r.object([&](const std::string& ck) {
+                                    if (ck == "destination" && r.peek() == '"') return r.str(dest);
+                                    if (ck == "networkCost" && r.peek() != 'n') return r.scalar(buf) && (canonical_quantity(buf, false, &cost) || r.fail("bad networkCost"));
+                                    return r.skip();
+                                  }))
+                                return false;
+                              o.second.emplace_back(dest, cost);
+                              return true;
+                            });
+                          });
+                        });
+                      }))
+                    return false;
+                  Origins* into = key == "topology.kubernetes.io/region" ? &reg : (key == "topology.kubernetes.io/zone" ? &zon : nullptr);
+                  if (into) into->insert(into->end(), origins.begin(), origins.end());
+                  return true;
+                });
+              }))
+            return false;
+          if (wname == weights_name) {  // several entries of that name: later lists are appended (map assignment order)
+            auto merge = [](spx_ingest::Names& names, std::vector<std::vector<std::pair<int32_t, int64_t>>>& out, const Origins& from) {
+              for (const auto& o : from) {
+                const size_t oid = static_cast<size_t>(names.id(o.first));
+                if (out.size() <= oid) out.resize(oid + 1);
+                for (const auto& c : o.second) out[oid].emplace_back(names.id(c.first), c.second);
+              }
+            };
+            merge(h->regions, h->nt_region, reg), merge(h->zones, h->nt_zone, zon);
+          }
+          return true;
+        });
+      });
+    });
+  });
+  freeze_nettopo(h);
+  return rc;
+}
+
+extern "C" const spx_nettopo_objects* spx_ingest_nettopo_objects(const spx_ingest* h) { return h ? &h->nettopo_table : nullptr; }
+
 static void freeze_nodes_initial(spx_ingest* h) {
   freeze_nodes(h);
   freeze_pods(h);
+  freeze_groups(h);
+  freeze_nettopo(h);
 }

@@ -90,6 +90,22 @@ class NrtIngest:
     def reset_pods(self) -> None:
         self._lib.spx_ingest_pods_reset(self._h)
 
+    def feed_appgroups(self, json_bytes: bytes) -> int:
+        n = C.c_int64()
+        if self._lib.spx_ingest_appgroups_json(self._h, json_bytes, len(json_bytes), C.byref(n)) != 0:
+            raise ValueError(self._lib.spx_ingest_error(self._h).decode())
+        return n.value
+
+    def feed_nettopo(self, json_bytes: bytes, weights_name: str) -> None:
+        if self._lib.spx_ingest_nettopo_json(self._h, json_bytes, len(json_bytes), weights_name.encode()) != 0:
+            raise ValueError(self._lib.spx_ingest_error(self._h).decode())
+
+    def appgroup_objects(self) -> _Borrowed:
+        return _Borrowed(self._lib.spx_ingest_appgroup_objects(self._h), self)
+
+    def nettopo_objects(self) -> _Borrowed:
+        return _Borrowed(self._lib.spx_ingest_nettopo_objects(self._h), self)
+
     def node_objects(self) -> _Borrowed:
         return _Borrowed(self._lib.spx_ingest_node_objects(self._h), self)
 

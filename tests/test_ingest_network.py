@@ -1,0 +1,154 @@
+"""Wire-format ingestion of the network-aware CRs: AppGroup and NetworkTopology JSON -> object tables,
+against the independent Python builders, on the reference's example AppGroups (tests/golden/appgroup_manifests.json) and on the
+fixtures of its network-aware unit tests (tests/golden/network.py) rendered in the CRD's shape; then the decoded tables drive
+the oracle's NetworkOverhead Filter/Score to the reference's known answers.  CPU only."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from golden import network as GN
+from scheduler_plugins_amd import objects as O
+from scheduler_plugins_amd.ingest import NrtIngest
+
+GOLD = Path(__file__).parent / "golden"
+REGION, ZONE = "topology.kubernetes.io/region", "topology.kubernetes.io/zone"
+
+
+def col(struct, name, n):
+    return np.ctypeslib.as_array(getattr(struct, name), (n,)).tolist() if n else []
+
+
+def appgroup_cr(name, g):
+    wl = lambda s: {"kind": "Deployment", "name": s, "selector": s, "apiVersion": "apps/v1", "namespace": "default"}
+    return {"apiVersion": "appgroup.diktyo.x-k8s.io/v1alpha1", "kind": "AppGroup", "metadata": {"name": name},
+            "spec": {"numMembers": len(g["workloads"]), "topologySortingAlgorithm": "KahnSort",
+                     "workloads": [{"workload": wl(w["selector"]), "dependencies": [{"workload": wl(s), "maxNetworkCost": c} for s, c in w["dependencies"]]}
+                                   for w in g["workloads"]]},
+            "status": {"runningWorkloads": 0, "topologyOrder": [{"workload": wl(s), "index": i} for s, i in g["topology_order"]]}}
+
+
+def nettopo_cr(region_costs, zone_costs, name="UserDefined"):
+    def tl(key, costs):
+        return {"topologyKey": key, "originList": [{"origin": o, "costList": [{"destination": d, "bandwidthCapacity": "1Gi", "networkCost": c} for d, c in l]}
+                                                   for o, l in costs.items()]}
+    return {"apiVersion": "networktopology.diktyo.x-k8s.io/v1alpha1", "kind": "NetworkTopology", "metadata": {"name": "nt", "namespace": "default"},
+            "spec": {"configmapName": "netperfMetrics",
+                     "weights": [{"name": "Other", "topologyList": [tl(REGION, {"x": [("y", 99)]})]},
+                                 {"name": name, "topologyList": [tl(REGION, region_costs), tl(ZONE, zone_costs)]}]}}
+
+
+def groups_equal(a, b):
+    n = a.n_groups
+    assert n == b.n_groups
+    nw = a.wl_ptr[n]
+    assert col(a, "wl_ptr", n + 1) == col(b, "wl_ptr", n + 1) and col(a, "wl_selector", nw) == col(b, "wl_selector", nw)
+    nd = a.dep_ptr[nw]
+    assert col(a, "dep_ptr", nw + 1) == col(b, "dep_ptr", nw + 1)
+    assert col(a, "dep_selector", nd) == col(b, "dep_selector", nd) and col(a, "dep_max_cost", nd) == col(b, "dep_max_cost", nd)
+    nt = a.topo_ptr[n]
+    assert col(a, "topo_ptr", n + 1) == col(b, "topo_ptr", n + 1)
+    assert col(a, "topo_selector", nt) == col(b, "topo_selector", nt) and col(a, "topo_index", nt) == col(b, "topo_index", nt)
+    assert col(a, "placed_ptr", n + 1) == [0] * (n + 1)
+
+
+def sorted_selectors(groups):
+    sel = O.Interner()
+    for g in groups:
+        for w in g["workloads"]:
+            sel.id(w["selector"])
+            for s, _ in w["dependencies"]:
+                sel.id(s)
+        for s, _ in g["topology_order"]:
+            sel.id(s)
+    sel.freeze_sorted()
+    return sel
+
+
+def test_reference_example_appgroups(hdr):
+    docs = json.loads((GOLD / "appgroup_manifests.json").read_text())
+    assert [d["metadata"]["name"] for d in docs] == ["a1", "redis-cluster"]
+    groups = []
+    for d in docs:
+        groups.append({"workloads": [{"selector": w["workload"]["selector"],
+                                      "dependencies": [(x["workload"]["selector"], x.get("maxNetworkCost", 0)) for x in w.get("dependencies", [])]}
+                                     for w in d["spec"]["workloads"]],
+                       "topology_order": [(t["workload"]["selector"], t["index"]) for t in (d.get("status") or {}).get("topologyOrder", [])]})
+    sel = sorted_selectors(groups)
+    want = O.build_appgroup_objects(hdr, sel, groups, {})
+    with NrtIngest(["n0"]) as ing:
+        assert ing.feed_appgroups(json.dumps({"items": docs}).encode()) == 2
+        groups_equal(ing.appgroup_objects().struct, want.struct)
+        assert ing.name_id("appgroup", "redis-cluster") == 1
+        for s, i in sel.ids.items():
+            assert ing.name_id("selector", s) == i     # lexicographic ids: "P1" < "P2" < "P3" < ...
+        t = ing.appgroup_objects().struct
+        assert col(t, "dep_max_cost", t.dep_ptr[t.wl_ptr[1]])[:2] == [30, 20]   # appGroup-example.yaml: P1 -> P2 (30), P2 -> P3 (20)
+
+
+def test_unit_test_fixtures_round_trip(hdr):
+    groups = [GN.APPGROUP_BASIC, GN.ONLINEBOUTIQUE]
+    sel = sorted_selectors(groups)
+    want = O.build_appgroup_objects(hdr, sel, groups, {})
+    regions, zones = O.Interner(), O.Interner()
+    want_nt = O.build_nettopo_objects(hdr, regions, zones, GN.REGION_COSTS, GN.ZONE_COSTS)
+    with NrtIngest(["n0"]) as ing:
+        ing.feed_appgroups(json.dumps([appgroup_cr("basic", groups[0]), appgroup_cr("onlineboutique", groups[1])]).encode())
+        groups_equal(ing.appgroup_objects().struct, want.struct)
+        ing.feed_nettopo(json.dumps(nettopo_cr(GN.REGION_COSTS, GN.ZONE_COSTS)).encode(), "UserDefined")
+        a, b = ing.nettopo_objects().struct, want_nt.struct
+        assert (a.n_regions, a.n_zones) == (b.n_regions, b.n_zones) == (2, 4)
+        for ptr, dest, cost, n in (("rc_ptr", "rc_dest", "rc_cost", 2), ("zc_ptr", "zc_dest", "zc_cost", 4)):
+            m = getattr(a, ptr)[n]
+            assert col(a, ptr, n + 1) == col(b, ptr, n + 1) and col(a, dest, m) == col(b, dest, m) and col(a, cost, m) == col(b, cost, m)
+        assert ing.name_id("region", "us-west-1") == regions.ids["us-west-1"] and ing.name_id("zone", "Z3") == zones.ids["Z3"]
+        # another weights set of the same CR
+        ing.feed_nettopo(json.dumps(nettopo_cr(GN.REGION_COSTS, GN.ZONE_COSTS)).encode(), "Other")
+        assert ing.nettopo_objects().struct.rc_ptr[ing.nettopo_objects().struct.n_regions] == 1
+
+
+def test_selectors_must_be_ordered(hdr):
+    with NrtIngest(["n0"]) as ing:
+        ing.seed("selector", ["p1", "p2"])             # a caller-fixed table that lacks p3
+        with pytest.raises(ValueError, match="selector 'p3'"):
+            ing.feed_appgroups(json.dumps(appgroup_cr("basic", GN.APPGROUP_BASIC)).encode())
+        with pytest.raises(ValueError, match="selector"):
+            ing.feed_appgroups(b'{"metadata": {"name": "g"}, "spec": {"workloads": [{"dependencies": []}]}}')
+
+
+@pytest.mark.parametrize("case", GN.SCORE_CASES, ids=lambda c: f"L{c['line']}")
+def test_decoded_crs_reproduce_the_reference_scores(hdr, oracle, case):
+    """networkoverhead_test.go:572-818 end to end from wire formats: Node, Pod, AppGroup and NetworkTopology JSON -> decoder ->
+    oracle NetworkOverhead.Score + NormalizeScore == the reference's expected lists (the scheduled-pods list, which no CR
+    carries, comes from the Python builder)"""
+    node_docs = [{"metadata": {"name": n, "labels": {REGION: r, ZONE: z}}, "status": {"allocatable": {"cpu": "8", "memory": "16Gi"}, "capacity": {"cpu": "8"}}}
+                 for n, r, z in GN.NODES]
+    pod = {"metadata": {"namespace": "default", "labels": {"appgroup.diktyo.x-k8s.io": "basic", "appgroup.diktyo.x-k8s.io.workload": case["selector"]}},
+           "spec": {"containers": [{"name": "c"}]}}
+    with NrtIngest([n for n, _, _ in GN.NODES]) as ing:
+        ing.feed_appgroups(json.dumps(appgroup_cr("basic", GN.APPGROUP_BASIC)).encode())
+        ing.feed_nodes(json.dumps(node_docs).encode())
+        ing.feed_nettopo(json.dumps(nettopo_cr(GN.REGION_COSTS, GN.ZONE_COSTS)).encode(), "UserDefined")
+        ing.feed_pods(json.dumps(pod).encode())
+        # placed pods: GetScheduledList reads them from the pod lister; rebuild the group table with them through the builder
+        sel = O.Interner()
+        for s in ("p1", "p2", "p3"):
+            sel.id(s)
+        sel.freeze_sorted()
+        assert all(ing.name_id("selector", s) == i for s, i in sel.ids.items())
+        g = dict(GN.APPGROUP_BASIC)
+        g["topology_order"] = sorted(g["topology_order"])
+        g["placed"] = GN.SCORE_PLACED
+        ag = O.build_appgroup_objects(hdr, sel, [g], {n: i for i, (n, _, _) in enumerate(GN.NODES)})
+        # as in tests/test_oracle_golden_network.py: the reference test scores every node and normalises the full list, so the
+        # plugin's own Filter is not applied (networkoverhead_test.go:790-814)
+        import ctypes as C
+        n = len(GN.NODES)
+        sat, vio, cost = (np.zeros(n, np.int64) for _ in range(3))
+        i64p = C.POINTER(C.c_int64)
+        oracle.lib().orc_net_prefilter(ing.node_objects().ref(), ing.pod_objects().ref(), ag.ref(), ing.nettopo_objects().ref(), 0,
+                                       sat.ctypes.data_as(i64p), vio.ctypes.data_as(i64p), cost.ctypes.data_as(i64p))
+        assert cost.tolist() == case["before"]
+        oracle.lib().orc_net_normalize(cost.ctypes.data_as(i64p), n)
+        assert cost.tolist() == case["after"]
