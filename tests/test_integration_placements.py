@@ -93,3 +93,37 @@ def test_allocatable_integration_placement_gpu(gpu_required, hdr, mode):
             row = np.where(feas[i] != 0, row, -1)
             got = {case["nodes"][int(n)]["name"] for n in np.flatnonzero(row == row.max())}
             assert got == case["expected"][mode][name], (name, got)
+
+
+def test_lroc_integration_placement_oracle(hdr, oracle):
+    """test/integration/lowriskovercommitment_test.go: pod-3 lands on node-1 (scores 100 vs 88)"""
+    from golden.integration import LROC as CASE
+    from helpers import LROC, lroc_params
+
+    res = O.Resources()
+    nodes = O.build_node_objects(hdr, res, [O.node(n["allocatable"], n["capacity"]) for n in CASE["nodes"]])
+    pods = O.build_pod_objects(hdr, res, [{"containers": [O.container(*CASE["pod"])]}])
+    node_pods = O.build_node_pods_objects(hdr, res, len(CASE["nodes"]), {i: [{"containers": [O.container(r, l)]} for r, l in ps] for i, ps in CASE["on_node"].items()})
+    snap = oracle.Snapshot(nodes, pods, metrics=O.build_metrics_objects(hdr, len(CASE["nodes"]), CASE["metrics"]), node_pods=node_pods,
+                           lroc_params=lroc_params(hdr, **CASE["params"]))
+    raw, _ = snap.score_rows(LROC)
+    assert raw[0].tolist() == CASE["scores"]
+    assert CASE["nodes"][int(raw[0].argmax())]["name"] == CASE["expected"]
+
+
+def test_peaks_integration_placement_oracle(hdr, oracle):
+    """test/integration/peaks_test.go: pod-1 -> node-1, pod-2 -> node-2 (node-1 is full for it)"""
+    import numpy as np
+
+    from golden.integration import PEAKS as CASE
+    from helpers import PEAKS, power_models
+
+    res = O.Resources()
+    nodes = O.build_node_objects(hdr, res, [O.node(n["allocatable"], n["capacity"]) for n in CASE["nodes"]])
+    pods = O.build_pod_objects(hdr, res, [{"containers": [O.container(p)]} for p in CASE["pods"]])
+    snap = oracle.Snapshot(nodes, pods, metrics=O.build_metrics_objects(hdr, 3, CASE["metrics"]), power_models=power_models(hdr, CASE["models"]))
+    mask = np.array(CASE["feasible"], dtype=np.uint8)
+    _, norm = snap.score_rows(PEAKS, mask=mask)
+    for i, want in enumerate(CASE["expected"]):
+        row = np.where(mask[i] != 0, norm[i], -1)
+        assert CASE["nodes"][int(row.argmax())]["name"] == want and (row == row.max()).sum() == 1
