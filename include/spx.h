@@ -735,6 +735,12 @@ int spx_ingest_appgroups_json(spx_ingest* h, const char* json, int64_t len, int6
 const spx_appgroup_objects* spx_ingest_appgroup_objects(const spx_ingest* h);
 int spx_ingest_nettopo_json(spx_ingest* h, const char* json, int64_t len, const char* weights_name);
 const spx_nettopo_objects* spx_ingest_nettopo_objects(const spx_ingest* h);
+/* ElasticQuota CRs (scheduling.x-k8s.io/v1alpha1) -> spx_quota_objects indexed by the given namespace list (which also seeds the
+ * namespace ids of the pod table): spec.min / spec.max with newElasticQuotaInfo's replacements for nil lists (elasticquota.go:70-76),
+ * `used` from status.used; quotas of other namespaces are counted and skipped; the nominated-pod list stays empty (queue state).
+ * NULL from the accessor until the first successful call. */
+int spx_ingest_quota_json(spx_ingest* h, const char* json, int64_t len, const char* const* namespaces, int32_t n_namespaces, int64_t* n_objects_out, int64_t* n_unknown_out);
+const spx_quota_objects* spx_ingest_quota_objects(const spx_ingest* h);
 /* resource.Quantity text -> canonical int64: MilliValue() when milli != 0 (cpu), Value() otherwise; both round up */
 int spx_ingest_quantity(const char* text, int32_t milli, int64_t* out);
 

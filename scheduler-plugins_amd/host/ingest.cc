@@ -339,7 +339,11 @@ struct NodeRow {
 
 }  // namespace
 
+struct spx_ingest_quota;
+static void free_quota(spx_ingest_quota* q);
+
 struct spx_ingest {
+  spx_ingest_quota* quota = nullptr;  // ElasticQuota tables (end of this file)
   Interner res;
   std::vector<NodeRow> rows;
   std::string err;
@@ -604,6 +608,7 @@ extern "C" int spx_ingest_create(const char* const* node_names, int64_t n_nodes,
 }
 
 extern "C" int spx_ingest_destroy(spx_ingest* h) {
+  if (h) free_quota(h->quota);
   delete h;
   return SPX_OK;
 }
@@ -1236,6 +1241,139 @@ extern "C" int spx_ingest_nettopo_json(spx_ingest* h, const char* json, int64_t 
 }
 
 extern "C" const spx_nettopo_objects* spx_ingest_nettopo_objects(const spx_ingest* h) { return h ? &h->nettopo_table : nullptr; }
+
+
+// ====================================================================== ElasticQuota CRs (CapacityScheduling)
+// Schema: manifests/crds/scheduling.x-k8s.io_elasticquotas.yaml (spec.min, spec.max, status.used: ResourceLists; one quota per
+// namespace).  Semantics as newElasticQuotaInfo / framework.NewResource read them (elasticquota.go:70-87): a nil Min becomes the
+// zero bound, a nil Max the upper bound (math.MaxInt64 for cpu / memory / ephemeral-storage); cpu in millicores, memory,
+// ephemeral-storage, pods, and scalar resources by slot.  `used` is taken from status.used — upstream keeps the same sum in
+// memory from pod events; the nominated-pod list is scheduling-queue state and stays with the caller (empty here).
+struct spx_ingest_quota {
+  std::vector<int32_t> scalar_res;  // canonical id per scalar slot
+  std::vector<uint8_t> has, min_p, max_p, used_p;
+  std::vector<int64_t> min, max, used;
+  spx_pod_objects no_pods{};
+  int32_t zero_ptr[2] = {0, 0};
+  spx_quota_objects table{};
+};
+
+namespace {
+
+struct QuotaRow {
+  bool seen = false;
+  bool has_min = false, has_max = false;
+  std::vector<std::pair<std::string, int64_t>> min, max, used;
+};
+
+bool quota_vector(spx_ingest* h, spx_ingest_quota* q, const std::vector<std::pair<std::string, int64_t>>& rl, int64_t* v, uint8_t* present) {
+  for (int i = 0; i < SPX_QUOTA_SLOTS; ++i) v[i] = 0;
+  *present = 0;
+  for (const auto& e : rl) {  // framework.Resource.Add
+    if (e.first == "cpu") v[0] += e.second;
+    else if (e.first == "memory") v[1] += e.second;
+    else if (e.first == "ephemeral-storage") v[2] += e.second;
+    else if (e.first == "pods") v[3] += e.second;
+    else if (scalar_resource_name(e.first)) {
+      const int32_t rid = h->res.id(e.first);
+      size_t s = 0;
+      while (s < q->scalar_res.size() && q->scalar_res[s] != rid) ++s;
+      if (s == q->scalar_res.size()) {
+        if (s >= SPX_QUOTA_SLOTS - 4) return h->err = "more scalar resources than quota slots", false;
+        q->scalar_res.push_back(rid);
+      }
+      v[4 + s] += e.second;
+      *present = static_cast<uint8_t>(*present | (1u << (4 + s)));
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+// namespaces fixes the namespace ids (= spx_pod_objects.ns; kind 2 of the name tables is seeded with them)
+extern "C" int spx_ingest_quota_json(spx_ingest* h, const char* json, int64_t len, const char* const* namespaces, int32_t n_namespaces,
+                                     int64_t* n_objects_out, int64_t* n_unknown_out) {
+  if (!h || !json || len < 0 || n_namespaces <= 0 || !namespaces) return SPX_ERR_ARG;
+  for (int32_t i = 0; i < n_namespaces; ++i) {
+    if (!namespaces[i]) return SPX_ERR_ARG;
+    h->namespaces.id(namespaces[i]);
+  }
+  std::vector<QuotaRow> rows(static_cast<size_t>(n_namespaces));
+  std::unordered_map<std::string, int32_t> index;
+  for (int32_t i = 0; i < n_namespaces; ++i) index.emplace(namespaces[i], i);
+  std::string buf, ns;
+  int64_t unknown = 0;
+  const int rc = run_decoder(h, json, len, n_objects_out, [&](Reader& r) {
+    QuotaRow row;
+    row.seen = true;
+    ns.clear();
+    auto list = [&](std::vector<std::pair<std::string, int64_t>>* out, bool* present) {
+      if (r.peek() == 'n') return r.skip();  // null: a nil list
+      if (present) *present = true;
+      return resource_list(h, r, buf, [&](const std::string& rn, int64_t q) { out->emplace_back(rn, q); });
+    };
+    if (!r.object([&](const std::string& k) {
+          if (k == "metadata" && r.peek() == '{')
+            return r.object([&](const std::string& mk) { return (mk == "namespace" && r.peek() == '"') ? r.str(ns) : r.skip(); });
+          if (k == "spec" && r.peek() == '{')
+            return r.object([&](const std::string& sk) {
+              if (sk == "min") return list(&row.min, &row.has_min);
+              if (sk == "max") return list(&row.max, &row.has_max);
+              return r.skip();
+            });
+          if (k == "status" && r.peek() == '{')
+            return r.object([&](const std::string& sk) { return sk == "used" ? list(&row.used, nullptr) : r.skip(); });
+          return r.skip();
+        }))
+      return false;
+    auto it = index.find(ns);
+    if (it == index.end()) {
+      ++unknown;
+      return true;
+    }
+    rows[static_cast<size_t>(it->second)] = std::move(row);  // "Each namespace can only have one ElasticQuota": the last one wins
+    return true;
+  });
+  if (n_unknown_out) *n_unknown_out = unknown;
+  if (rc != SPX_OK) return rc;
+  if (!h->quota) h->quota = new spx_ingest_quota();
+  spx_ingest_quota* q = h->quota;
+  q->scalar_res.clear();
+  const size_t n = rows.size();
+  q->has.assign(n, 0), q->min_p.assign(n, 0), q->max_p.assign(n, 0), q->used_p.assign(n, 0);
+  q->min.assign(n * SPX_QUOTA_SLOTS, 0), q->max.assign(n * SPX_QUOTA_SLOTS, 0), q->used.assign(n * SPX_QUOTA_SLOTS, 0);
+  for (size_t i = 0; i < n; ++i) {
+    const QuotaRow& row = rows[i];
+    q->has[i] = row.seen;
+    // a namespace without a quota keeps the bounds a nil list would get (the flattener only looks at has_quota there)
+    if (!quota_vector(h, q, row.has_min ? row.min : std::vector<std::pair<std::string, int64_t>>{}, &q->min[i * SPX_QUOTA_SLOTS], &q->min_p[i])) return SPX_ERR_ARG;
+    if (row.has_max) {
+      if (!quota_vector(h, q, row.max, &q->max[i * SPX_QUOTA_SLOTS], &q->max_p[i])) return SPX_ERR_ARG;
+    } else {
+      q->max[i * SPX_QUOTA_SLOTS + 0] = q->max[i * SPX_QUOTA_SLOTS + 1] = q->max[i * SPX_QUOTA_SLOTS + 2] = INT64_MAX;  // UpperBoundOfMax elasticquota.go:29
+    }
+    if (!quota_vector(h, q, row.used, &q->used[i * SPX_QUOTA_SLOTS], &q->used_p[i])) return SPX_ERR_ARG;
+  }
+  const int32_t slots = static_cast<int32_t>(q->scalar_res.size());
+  q->scalar_res.resize(SPX_QUOTA_SLOTS - 4, 0);
+  spx_quota_objects& t = q->table;
+  t.n_namespaces = n_namespaces;
+  t.n_scalar_slots = slots;
+  t.scalar_res = q->scalar_res.data(), t.has_quota = q->has.data();
+  t.min = q->min.data(), t.min_present = q->min_p.data(), t.max = q->max.data(), t.max_present = q->max_p.data();
+  t.used = q->used.data(), t.used_present = q->used_p.data();
+  t.n_nominated = 0, t.nom_ns = nullptr, t.nom_priority = nullptr, t.nom_pending_index = nullptr;
+  q->no_pods = spx_pod_objects{};
+  q->no_pods.ctr_ptr = q->no_pods.ovh_ptr = q->no_pods.req_ptr = q->no_pods.lim_ptr = q->zero_ptr;
+  t.nom_pods = &q->no_pods;
+  refresh_classes(h);
+  return SPX_OK;
+}
+
+extern "C" const spx_quota_objects* spx_ingest_quota_objects(const spx_ingest* h) { return (h && h->quota) ? &h->quota->table : nullptr; }
+
+static void free_quota(spx_ingest_quota* q) { delete q; }
 
 static void freeze_nodes_initial(spx_ingest* h) {
   freeze_nodes(h);

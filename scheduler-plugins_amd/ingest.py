@@ -100,6 +100,18 @@ class NrtIngest:
         if self._lib.spx_ingest_nettopo_json(self._h, json_bytes, len(json_bytes), weights_name.encode()) != 0:
             raise ValueError(self._lib.spx_ingest_error(self._h).decode())
 
+    def feed_quotas(self, json_bytes: bytes, namespaces: Sequence[str]):
+        arr = (C.c_char_p * len(namespaces))(*[n.encode() for n in namespaces])
+        n, unk = C.c_int64(), C.c_int64()
+        rc = self._lib.spx_ingest_quota_json(self._h, json_bytes, len(json_bytes), C.cast(arr, C.POINTER(C.POINTER(C.c_char))), len(namespaces),
+                                             C.byref(n), C.byref(unk))
+        if rc != 0:
+            raise ValueError(self._lib.spx_ingest_error(self._h).decode())
+        return n.value, unk.value
+
+    def quota_objects(self) -> _Borrowed:
+        return _Borrowed(self._lib.spx_ingest_quota_objects(self._h), self)
+
     def appgroup_objects(self) -> _Borrowed:
         return _Borrowed(self._lib.spx_ingest_appgroup_objects(self._h), self)
 
