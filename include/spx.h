@@ -594,6 +594,15 @@ int spx_sync(spx_engine* e);
 int spx_fetch_scores(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out);
 /* filter status row of one pod (n_nodes bytes; 0 = pass, else plugin-specific reason code) */
 int spx_fetch_status(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out);
+/* rows [row_begin,row_end) of a score / status table in one strided copy: row r lands at out + (r - row_begin) * out_stride
+ * (out_stride >= n_nodes bytes) — what a caller that drains a whole batch (or a parity harness) uses instead of row-by-row fetches */
+int spx_fetch_score_rows(spx_engine* e, int plugin, int64_t row_begin, int64_t row_end, uint8_t* out, int64_t out_stride);
+int spx_fetch_status_rows(spx_engine* e, int plugin, int64_t row_begin, int64_t row_end, uint8_t* out, int64_t out_stride);
+/* exactness bookkeeping of the fast formulations: how many cells the float32 sweeps of TLP, LVRB and
+ * LowRiskOverCommitment could not prove to round like the reference and re-evaluated with the reference's float64 sequence,
+ * accumulated per plugin id since the last reset (SPX_NUM_PLUGINS entries; plugins without a fallback report 0).  Synchronises
+ * the engine stream. */
+int spx_fetch_stats(spx_engine* e, int64_t* reevaluated_cells, int reset);
 /* raw int64 Score() row (before NormalizeScore) recomputed for one pod — the parity harness
  * and direct-call tests observe raw values (e.g. networkoverhead_test.go:803) */
 int spx_fetch_raw(spx_engine* e, int plugin, int which, int64_t pod_row, int64_t* out);
@@ -633,6 +642,27 @@ int spx_commit_sequential(spx_engine* e, uint32_t plugin_mask, int64_t row_begin
 
 /* duration in ms of the last spx_eval's kernels measured with HIP events on the engine stream */
 int spx_last_eval_ms(spx_engine* e, float* ms);
+
+/* Per-engine options (no process-wide state: two profiles in one scheduler process may differ).  Unknown option or value
+ * out of range -> SPX_ERR_ARG.  Options take effect at the next launch, except SPX_OPT_ROW_ALIGN (before the first upload).
+ *   SPX_OPT_ROW_ALIGN          row padding of the result tables in bytes (multiple of 16; default 128)
+ *   SPX_OPT_REFERENCE_KERNELS  bit mask of plugin ids whose sweep runs the reference-arithmetic ("generic") kernel instead of
+ *                              the fast formulation: TLP and LVRB (one switch for both), NRT, NETOVERHEAD, LROC (int64 form)
+ *   SPX_OPT_LROC_FLOAT64       1 = LowRiskOverCommitment in the float64 form (no float32 quotient)
+ *   SPX_OPT_DECIDE_UNFUSED     1 = spx_decide always runs spx_eval + spx_eval_best
+ *   SPX_OPT_NRT_SINGLE_LAUNCH  1 = NRT Filter and Score in one launch (default: two for Least/MostAllocated)
+ *   SPX_OPT_COMMIT_FROM_MEMORY 1 = spx_commit_sequential keeps node state in memory (any node count) instead of registers
+ *   SPX_OPT_PEAKS_TILE         nodes per lane of Peaks' (min/max pass, write pass): 44 (default), 84, 48, 88 */
+#define SPX_OPT_ROW_ALIGN 0
+#define SPX_OPT_REFERENCE_KERNELS 1
+#define SPX_OPT_LROC_FLOAT64 2
+#define SPX_OPT_DECIDE_UNFUSED 3
+#define SPX_OPT_NRT_SINGLE_LAUNCH 4
+#define SPX_OPT_COMMIT_FROM_MEMORY 5
+#define SPX_OPT_PEAKS_TILE 6
+#define SPX_NUM_OPTIONS 7
+int spx_set_option(spx_engine* e, int option, int64_t value);
+int spx_get_option(const spx_engine* e, int option, int64_t* value);
 
 /* which formulation of a plugin's sweep the uploaded tables select: 0 = generic (reference arithmetic, operation for
  * operation), 1 = fast formulation (same results; see DESIGN.md for each kernel's preconditions); <0 on error.

@@ -130,6 +130,7 @@ class Header:
             self.opaque.pop(name, None)
         # prototypes:  <ret> name(args);
         body = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
+        body = re.sub(r"^\s*#[^\n]*$", "", body, flags=re.M)  # preprocessor lines are not part of a prototype
         for m in re.finditer(r"([\w\s\*]+?)\b(\w+)\s*\(([^()]*)\)\s*;", body):
             ret, fname, args = m.group(1).strip(), m.group(2), m.group(3).strip()
             if not ret or ret.startswith("typedef") or ret.startswith("#"):

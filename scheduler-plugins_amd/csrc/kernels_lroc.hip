@@ -271,6 +271,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lroc_fast(LrocArgs a,
             w[j] = (w[j] & ~(0xffu << (8 * q))) | (b << (8 * q));
           }
         }
+        // spx_fetch_stats: the whole lane (NPL cells) is redone, not only the cells inside the band
+        if (a.stats) atomicAdd(a.stats + SPX_PLUGIN_LROC, static_cast<unsigned long long>(min<int64_t>(NPL, max<int64_t>(a.n_nodes - node0, 0))));
       }
     }
     uint32_t* dst = reinterpret_cast<uint32_t*>(a.out_score + pod * a.row_stride + node0);

@@ -390,7 +390,7 @@ void launch_net(const NetArgs& g, hipStream_t s) {
   if (g.row_end <= g.row_begin) return;
   const unsigned blocks = static_cast<unsigned>(g.row_end - g.row_begin);
   const size_t lds = g.n_classes > 0 ? net_lds_bytes(g.n_classes, g.n_nodes) : 16;
-  const bool generic_only = getenv("SPX_NET_GENERIC") != nullptr;  // experiments / differential tests (read per launch)
+  const bool generic_only = (g.opts & kOptNetGeneric) != 0;  // SPX_OPT_REFERENCE_KERNELS
   if (!generic_only && !g.out_raw && g.n_classes > 0 && g.n_classes <= 65535 && g.node_class16)
     hipLaunchKernelGGL(k_net_cls, dim3(blocks), dim3(64), lds, s, g);
   else

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void k_nrt(NrtArgs a, int n_tiles) {
 
 void launch_nrt(const NrtArgs& a, hipStream_t s) {
   if (a.row_end <= a.row_begin) return;
-  const bool generic_only = getenv("SPX_NRT_GENERIC") != nullptr;  // experiments / differential tests (read per launch)
+  const bool generic_only = (a.opts & kOptNrtGeneric) != 0;  // SPX_OPT_REFERENCE_KERNELS
   if (!generic_only && launch_nrt_fast(a, s)) return;
   const int n_tiles = static_cast<int>((a.n_nodes + 63) / 64);
   const int64_t chunks = (a.row_end - a.row_begin + kPodsPerUnit - 1) / kPodsPerUnit;

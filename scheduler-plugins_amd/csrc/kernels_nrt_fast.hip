@@ -586,7 +586,7 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   const unsigned blocks = static_cast<unsigned>(chunks * n_tiles);
   const int sg = a.strategy == SPX_NRT_LEAST_NUMA_NODES ? kSgLeastNuma
                : a.strategy == SPX_NRT_BALANCED_ALLOCATION ? kSgBalanced : (a.strategy == SPX_NRT_LEAST_ALLOCATED ? kSgLeast : kSgMost);
-  const bool split = (sg == kSgLeast || sg == kSgMost) && a.out_raw == nullptr && getenv("SPX_NRT_NOSPLIT") == nullptr;
+  const bool split = (sg == kSgLeast || sg == kSgMost) && a.out_raw == nullptr && !(a.opts & kOptNrtSingleLaunch);
 #define SPX_NRTF_CASE(RMV, SGV)                                                                           \
   if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                                        \
     if ((SGV == kSgLeast || SGV == kSgMost) && split) { /* the Filter half does not depend on the strategy */ \

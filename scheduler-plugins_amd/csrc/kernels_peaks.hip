@@ -213,10 +213,9 @@ void launch_peaks(const PeaksArgs& a, hipStream_t s) {
     *n_tiles = static_cast<int>((a.row_stride + tile_nodes - 1) / tile_nodes);
     return dim3(static_cast<unsigned>((chunks * *n_tiles + kWavesPerBlock - 1) / kWavesPerBlock));
   };
-  // experiment knob: "44", "84", "48", "88" = nodes per lane of (min/max pass, write pass).  Measured on 10k x 100k: 3.49 /
+  // experiment knob (SPX_OPT_PEAKS_TILE): 44, 84, 48, 88 = nodes per lane of (min/max pass, write pass).  Measured on 10k x 100k: 3.49 /
   // 3.50 / 3.55 / 3.57 ms — the wider tiles halve the cross-lane reductions per cell but cost occupancy (145 VGPRs): no gain
-  const char* env = getenv("SPX_PEAKS_NPL");
-  const int npl_a = (env && env[0] == '8') ? 8 : 4, npl_b = (env && env[0] && env[1] == '8') ? 8 : 4;
+  const int npl_a = (a.opts & kOptPeaksWideA) ? 8 : 4, npl_b = (a.opts & kOptPeaksWideB) ? 8 : 4;
   int nt;
   if (npl_a == 8) {
     const dim3 g = grid(8, &nt);

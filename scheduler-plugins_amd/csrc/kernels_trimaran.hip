@@ -494,6 +494,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
       float pf = pod_f;
       asm volatile("" : "+v"(pf));  // opaque copy: keeps the compiler from carrying the 16 flags across the branch instead
       const F32x2 pod2s{pf, pf};
+      unsigned reevaluated = 0;
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
         float rr;
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
           const int64_t n = node0 + i;
           uint32_t b = 0;
           if (n < a.n_nodes) {
+            ++reevaluated;
             TlpNode tn;
             tn.cap = static_cast<double>(a.cap_cpu_milli[n]);
             tn.util_millis = (a.tlp_cpu_util[n] / 100.0) * tn.cap;
@@ -514,6 +516,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
           w[i >> 2] = (w[i >> 2] & ~(0xffu << sh)) | (b << sh);
         }
       }
+      if (reevaluated && a.stats) atomicAdd(a.stats + SPX_PLUGIN_TLP, static_cast<unsigned long long>(reevaluated));  // spx_fetch_stats
     }
     if constexpr (!D) {
       if (active) store_bytes<NPL>(a.out_tlp + row, w);
@@ -732,6 +735,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
       float rc = req_cpu, rm = req_mem;
       asm volatile("" : "+v"(rc), "+v"(rm));  // opaque copies: recompute the flags here instead of carrying them across the branch
       const F32x2 req2s{rc, rm};
+      unsigned reevaluated = 0;
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
         float ry;
@@ -739,6 +743,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
           const int64_t n = node0 + i;
           uint32_t b = 0;
           if (n < a.n_nodes) {
+            ++reevaluated;
             const double* o = a.lv_exact + n * 8;
             const int ms = static_cast<int>(o[7]);
             const LvRes c{o[0], o[1], o[2], static_cast<int>(o[3])};
@@ -749,6 +754,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
           w[i >> 2] = (w[i >> 2] & ~(0xffu << sh)) | (b << sh);
         }
       }
+      if (reevaluated && a.stats) atomicAdd(a.stats + SPX_PLUGIN_LVRB, static_cast<unsigned long long>(reevaluated));  // spx_fetch_stats
     }
     if (active) store_bytes<NPL>(a.out_lvrb + row, w);
   }
@@ -1096,7 +1102,7 @@ void launch_lvrb_fast(const TrimaranArgs& a, hipStream_t s) {
 void launch_trimaran(const TrimaranArgs& a, hipStream_t s) {
   if (a.row_end <= a.row_begin) return;
   if (!a.out_alloc && !a.out_tlp && !a.out_lvrb) return;
-  static const bool exact_only = getenv("SPX_EXACT_ONLY") != nullptr;
+  const bool exact_only = (a.opts & kOptTrimaranExact) != 0;  // SPX_OPT_REFERENCE_KERNELS
   const bool tlp_fast_ok = a.tlp_target >= 1.0 && a.tlp_target <= 99.0;
   if (!exact_only && (a.out_tlp || a.out_lvrb) && (!a.out_tlp || (tlp_fast_ok && a.tlp_fast)) && (!a.out_lvrb || (a.lv_exact && a.lv_fast))) {
     // one bit-exact fast kernel per plugin; Allocatable's broadcast row rides with the first of them
@@ -1156,7 +1162,7 @@ void launch_decide_trimaran(const DecideLaunch& d, hipStream_t s) {
 
 void launch_commit_trimaran(const CommitArgs& c, hipStream_t s) {
   if (c.t.row_end <= c.t.row_begin) return;
-  const bool from_memory = getenv("SPX_COMMIT_FROM_MEMORY") != nullptr;  // differential tests (read per launch)
+  const bool from_memory = (c.t.opts & kOptCommitFromMemory) != 0;  // SPX_OPT_COMMIT_FROM_MEMORY
   const bool key_fits = c.w_alloc >= 0 && c.w_tlp >= 0 && c.w_lvrb >= 0 && (c.w_alloc + c.w_tlp + c.w_lvrb) * 255 < (int64_t{1} << 18);
   if (!from_memory && key_fits && c.t.n_nodes <= 20 * 512) {
     const bool l = (c.use_mask & 4u) != 0, ties = c.out_ties != nullptr;

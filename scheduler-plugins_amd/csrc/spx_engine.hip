@@ -42,6 +42,9 @@ struct spx_engine {
   int64_t n_pods = -1;
   int64_t row_stride = 0;
 
+  // spx_set_option state (per engine; nothing is read from the environment)
+  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44};
+
   // params
   int32_t alloc_mode = SPX_MODE_LEAST;
   std::vector<int32_t> alloc_res{SPX_RES_MEMORY, SPX_RES_CPU};
@@ -64,6 +67,7 @@ struct spx_engine {
   DevBuf d_lv_fast, d_tlp_fast;  // float32 per-node constants of the fast sweeps (recomputed per launch)
   DevBuf d_commit;               // scratch of spx_commit_sequential
   DevBuf d_decide;               // per-tile partial decisions of spx_decide
+  DevBuf d_stats;                // uint64 [SPX_NUM_PLUGINS]: cells re-evaluated by the fast sweeps' exact fallback
 
   // LowRiskOverCommitment (reads the LVRB node columns above as well)
   spx_lroc_params lroc{5, 0.5, 0.5};  // apis/config/v1/defaults.go:72-80
@@ -167,10 +171,7 @@ int set_nodes(spx_engine* e, int64_t n) {
   if (e->n_nodes != -1 && e->n_nodes != n)
     return fail(e, SPX_ERR_STATE, "n_nodes differs from tables already uploaded (one snapshot per engine; destroy and re-create to change shape)");
   e->n_nodes = n;
-  int64_t pad = spx::kRowPad;
-  if (const char* env = getenv("SPX_ROW_ALIGN")) pad = atoll(env);
-  if (pad < spx::kRowAlign || pad % spx::kRowAlign) pad = spx::kRowAlign;
-  e->row_stride = spx::round_up(n, pad);
+  e->row_stride = spx::round_up(n, e->option[SPX_OPT_ROW_ALIGN]);
   return SPX_OK;
 }
 
@@ -222,8 +223,23 @@ int prepare_alloc(spx_engine* e) {
   return SPX_OK;
 }
 
+bool forced_reference(const spx_engine* e, int plugin) { return (e->option[SPX_OPT_REFERENCE_KERNELS] >> plugin) & 1; }
+
+// the engine's options as the launch-level switches the kernel translation units read
+uint32_t launch_opts(const spx_engine* e) {
+  uint32_t o = 0;
+  if (forced_reference(e, SPX_PLUGIN_TLP) || forced_reference(e, SPX_PLUGIN_LVRB)) o |= spx::kOptTrimaranExact;
+  if (forced_reference(e, SPX_PLUGIN_NRT)) o |= spx::kOptNrtGeneric;
+  if (forced_reference(e, SPX_PLUGIN_NETOVERHEAD)) o |= spx::kOptNetGeneric;
+  if (e->option[SPX_OPT_NRT_SINGLE_LAUNCH]) o |= spx::kOptNrtSingleLaunch;
+  if (e->option[SPX_OPT_COMMIT_FROM_MEMORY]) o |= spx::kOptCommitFromMemory;
+  if (e->option[SPX_OPT_PEAKS_TILE] / 10 == 8) o |= spx::kOptPeaksWideA;
+  if (e->option[SPX_OPT_PEAKS_TILE] % 10 == 8) o |= spx::kOptPeaksWideB;
+  return o;
+}
+
 bool lroc_exact53(const spx_engine* e) {
-  return e->lroc_nodes_exact && e->lroc_pods_exact && e->lv_alloc_exact && getenv("SPX_LROC_GENERIC") == nullptr;
+  return e->lroc_nodes_exact && e->lroc_pods_exact && e->lv_alloc_exact && !forced_reference(e, SPX_PLUGIN_LROC);
 }
 
 void fill_lroc(const spx_engine* e, spx::LrocArgs& a) {
@@ -249,11 +265,13 @@ void fill_lroc(const spx_engine* e, spx::LrocArgs& a) {
   a.w_mem = e->lroc.risk_limit_weight_mem;
   a.node_tab = static_cast<double*>(e->d_lroc_tab.p);
   a.exact53 = lroc_exact53(e) ? 1 : 0;
-  a.pod_f64 = (a.exact53 && getenv("SPX_LROC_F64") == nullptr) ? static_cast<const double*>(e->d_lroc_podf.p) : nullptr;
+  a.pod_f64 = (a.exact53 && !e->option[SPX_OPT_LROC_FLOAT64]) ? static_cast<const double*>(e->d_lroc_podf.p) : nullptr;
   a.n_pods_total = e->n_pods;
+  a.stats = static_cast<unsigned long long*>(e->d_stats.p);
 }
 
 void fill_peaks(const spx_engine* e, spx::PeaksArgs& a) {
+  a.opts = launch_opts(e);
   a.n_nodes = e->n_nodes;
   a.row_stride = e->row_stride;
   a.cap_cpu_milli = static_cast<const int64_t*>(e->d_pk_cap.p);
@@ -267,6 +285,7 @@ void fill_peaks(const spx_engine* e, spx::PeaksArgs& a) {
 }
 
 void fill_trimaran(const spx_engine* e, spx::TrimaranArgs& a) {
+  a.opts = launch_opts(e);
   a.n_nodes = e->n_nodes;
   a.row_stride = e->row_stride;
   a.alloc_norm = static_cast<const uint8_t*>(e->d_alloc_norm.p);
@@ -287,9 +306,11 @@ void fill_trimaran(const spx_engine* e, spx::TrimaranArgs& a) {
   a.lv_req_mem = static_cast<const int64_t*>(e->d_lv_rmem.p);
   a.lv_margin = e->lvrb.safe_variance_margin;
   a.lv_sensitivity = e->lvrb.safe_variance_sensitivity;
+  a.stats = static_cast<unsigned long long*>(e->d_stats.p);
 }
 
 void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
+  na.opts = launch_opts(e);
   na.n_nodes = e->n_nodes;
   na.n_pods = e->n_pods;
   na.row_stride = e->row_stride;
@@ -335,6 +356,7 @@ inline double nrt_biased_rcp(double v) { return v > 0.0 ? (1.0 / v) * (1.0 + 0x1
 inline int64_t nrt_value_of(bool is_cpu, int64_t q) { return is_cpu ? (q + 999) / 1000 : q; }
 
 void fill_net(const spx_engine* e, spx::NetArgs& g) {
+  g.opts = launch_opts(e);
   g.n_nodes = e->n_nodes;
   g.row_stride = e->row_stride;
   g.n_regions = e->net_n_regions;
@@ -395,6 +417,13 @@ int spx_create(int device_id, spx_engine** out) {
     return fail(nullptr, SPX_ERR_HIP, msg);
   }
   e->stream = e->own_stream;
+  if ((st = hipMalloc(&e->d_stats.p, SPX_NUM_PLUGINS * sizeof(unsigned long long))) != hipSuccess ||
+      (st = hipMemset(e->d_stats.p, 0, SPX_NUM_PLUGINS * sizeof(unsigned long long))) != hipSuccess) {
+    std::string msg = std::string("engine init: ") + hipGetErrorString(st);
+    delete e;
+    return fail(nullptr, SPX_ERR_HIP, msg);
+  }
+  e->d_stats.bytes = SPX_NUM_PLUGINS * sizeof(unsigned long long);
   *out = e;
   return SPX_OK;
 }
@@ -415,7 +444,9 @@ int spx_destroy(spx_engine* e) {
                     &e->d_net_pair_node, &e->d_net_pair_max, &e->d_q_pod_ns, &e->d_q_pod_prio, &e->d_q_pod_req, &e->d_q_pod_reqp,
                     &e->d_q_has, &e->d_q_used, &e->d_q_max, &e->d_q_maxp, &e->d_q_other, &e->d_q_otherp, &e->d_q_nom_ptr,
                     &e->d_q_nom_prio, &e->d_q_nom_idx, &e->d_q_nom_req, &e->d_q_nom_reqp, &e->d_q_status, &e->d_ext_status,
-                    &e->d_best};
+                    &e->d_best, &e->d_stats, &e->d_decide, &e->d_lroc_nreq_c, &e->d_lroc_nreq_m, &e->d_lroc_nlim_c, &e->d_lroc_nlim_m,
+                    &e->d_lroc_preq_c, &e->d_lroc_preq_m, &e->d_lroc_plim_c, &e->d_lroc_plim_m, &e->d_lroc_tab, &e->d_lroc_podf,
+                    &e->d_pk_cap, &e->d_pk_util, &e->d_pk_valid, &e->d_pk_k1, &e->d_pk_k2, &e->d_pk_pod, &e->d_pk_min, &e->d_pk_max};
   for (DevBuf* b : bufs)
     if (b->p && !b->external) (void)hipFree(b->p);
   for (int i = 0; i < SPX_NUM_PLUGINS; ++i) {
@@ -440,6 +471,39 @@ int spx_set_stream(spx_engine* e, void* hip_stream) {
 int spx_get_stream(spx_engine* e, void** hip_stream) {
   if (!e || !hip_stream) return SPX_ERR_ARG;
   *hip_stream = static_cast<void*>(e->stream);
+  return SPX_OK;
+}
+
+int spx_set_option(spx_engine* e, int option, int64_t value) {
+  if (!e) return SPX_ERR_ARG;
+  switch (option) {
+    case SPX_OPT_ROW_ALIGN:
+      if (value < spx::kRowAlign || value % spx::kRowAlign || value > 4096) return fail(e, SPX_ERR_ARG, "SPX_OPT_ROW_ALIGN: a multiple of 16 in [16, 4096]");
+      if (e->n_nodes != -1) return fail(e, SPX_ERR_STATE, "SPX_OPT_ROW_ALIGN must be set before the first table upload");
+      break;
+    case SPX_OPT_REFERENCE_KERNELS:
+      if (value < 0 || value >= (int64_t{1} << SPX_NUM_PLUGINS)) return fail(e, SPX_ERR_ARG, "SPX_OPT_REFERENCE_KERNELS: a mask of plugin ids");
+      if (((value ^ e->option[option]) >> SPX_PLUGIN_LROC) & 1) e->lroc_tab_ready = false;
+      break;
+    case SPX_OPT_LROC_FLOAT64:
+    case SPX_OPT_DECIDE_UNFUSED:
+    case SPX_OPT_NRT_SINGLE_LAUNCH:
+    case SPX_OPT_COMMIT_FROM_MEMORY:
+      if (value != 0 && value != 1) return fail(e, SPX_ERR_ARG, "option takes 0 or 1");
+      break;
+    case SPX_OPT_PEAKS_TILE:
+      if (value != 44 && value != 84 && value != 48 && value != 88) return fail(e, SPX_ERR_ARG, "SPX_OPT_PEAKS_TILE: 44, 84, 48 or 88");
+      break;
+    default:
+      return fail(e, SPX_ERR_ARG, "unknown option");
+  }
+  e->option[option] = value;
+  return SPX_OK;
+}
+
+int spx_get_option(const spx_engine* e, int option, int64_t* value) {
+  if (!e || !value || option < 0 || option >= SPX_NUM_OPTIONS) return SPX_ERR_ARG;
+  *value = e->option[option];
   return SPX_OK;
 }
 
@@ -1213,12 +1277,10 @@ int spx_commit_sequential(spx_engine* e, uint32_t plugin_mask, int64_t row_begin
 int spx_kernel_path(const spx_engine* e, int plugin) {
   if (!e) return SPX_ERR_ARG;
   if (plugin == SPX_PLUGIN_NRT)
-    return (e->nrt_fast_slots && e->nrt_fast_nodes && e->nrt_fast_pods && getenv("SPX_NRT_GENERIC") == nullptr)
-               ? 1
-               : 0;
-  if (plugin == SPX_PLUGIN_NETOVERHEAD) return (e->net_nodes && e->net_class16 && e->net_n_classes > 0 && getenv("SPX_NET_GENERIC") == nullptr) ? 1 : 0;
-  if (plugin == SPX_PLUGIN_LROC) return (lroc_exact53(e) && getenv("SPX_LROC_F64") == nullptr) ? 1 : 0;
-  if (plugin == SPX_PLUGIN_TLP) return (e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && getenv("SPX_EXACT_ONLY") == nullptr) ? 1 : 0;
+    return (e->nrt_fast_slots && e->nrt_fast_nodes && e->nrt_fast_pods && !forced_reference(e, SPX_PLUGIN_NRT)) ? 1 : 0;
+  if (plugin == SPX_PLUGIN_NETOVERHEAD) return (e->net_nodes && e->net_class16 && e->net_n_classes > 0 && !forced_reference(e, SPX_PLUGIN_NETOVERHEAD)) ? 1 : 0;
+  if (plugin == SPX_PLUGIN_LROC) return (lroc_exact53(e) && !e->option[SPX_OPT_LROC_FLOAT64]) ? 1 : 0;
+  if (plugin == SPX_PLUGIN_TLP) return (e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && !(launch_opts(e) & spx::kOptTrimaranExact)) ? 1 : 0;
   return 0;
 }
 
@@ -1323,6 +1385,42 @@ int spx_fetch_raw(spx_engine* e, int plugin, int which, int64_t pod_row, int64_t
   return SPX_OK;
 }
 
+namespace {
+// rows [row_begin,row_end) of a uint8 table into a caller buffer with its own row stride: one strided D2H
+int fetch_rows(spx_engine* e, const uint8_t* table, int64_t stride, int64_t row_begin, int64_t row_end, uint8_t* out, int64_t out_stride) {
+  if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
+  if (out_stride < e->n_nodes) return fail(e, SPX_ERR_ARG, "out_stride is smaller than n_nodes");
+  if (row_begin == row_end) return SPX_OK;
+  SPX_HIP(e, hipMemcpy2D(out, static_cast<size_t>(out_stride), table + row_begin * stride, static_cast<size_t>(stride),
+                         static_cast<size_t>(e->n_nodes), static_cast<size_t>(row_end - row_begin), hipMemcpyDeviceToHost));
+  return SPX_OK;
+}
+}  // namespace
+
+int spx_fetch_score_rows(spx_engine* e, int plugin, int64_t row_begin, int64_t row_end, uint8_t* out, int64_t out_stride) {
+  if (!e || !out) return SPX_ERR_ARG;
+  if (plugin < 0 || plugin >= SPX_NUM_PLUGINS || !e->score[plugin].p || !(e->evaluated & (1u << plugin)))
+    return fail(e, SPX_ERR_STATE, "plugin has not been evaluated");
+  return fetch_rows(e, static_cast<const uint8_t*>(e->score[plugin].p), e->score_stride[plugin], row_begin, row_end, out, out_stride);
+}
+
+int spx_fetch_status_rows(spx_engine* e, int plugin, int64_t row_begin, int64_t row_end, uint8_t* out, int64_t out_stride) {
+  if (!e || !out) return SPX_ERR_ARG;
+  if (plugin < 0 || plugin >= SPX_NUM_PLUGINS || !e->status[plugin].p || !(e->evaluated & (1u << plugin)))
+    return fail(e, SPX_ERR_STATE, "plugin has no evaluated Filter table");
+  return fetch_rows(e, static_cast<const uint8_t*>(e->status[plugin].p), e->row_stride, row_begin, row_end, out, out_stride);
+}
+
+int spx_fetch_stats(spx_engine* e, int64_t* reevaluated_cells, int reset) {
+  if (!e || !reevaluated_cells) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  static_assert(sizeof(unsigned long long) == sizeof(int64_t), "counter width");
+  SPX_HIP(e, hipMemcpyAsync(reevaluated_cells, e->d_stats.p, SPX_NUM_PLUGINS * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
+  if (reset) SPX_HIP(e, hipMemsetAsync(e->d_stats.p, 0, SPX_NUM_PLUGINS * sizeof(int64_t), e->stream));
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  return SPX_OK;
+}
+
 int spx_score_table(spx_engine* e, int plugin, void** dptr, int64_t* row_stride, int64_t* n_rows) {
   if (!e || plugin < 0 || plugin >= SPX_NUM_PLUGINS) return SPX_ERR_ARG;
   if (e->n_nodes <= 0 || e->n_pods <= 0) return fail(e, SPX_ERR_STATE, "shape unknown: upload node and pod tables first");
@@ -1395,8 +1493,8 @@ int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t r
   const uint32_t A = 1u << SPX_PLUGIN_ALLOCATABLE, T = 1u << SPX_PLUGIN_TLP;
   const int64_t wa = e->plugin_weight[SPX_PLUGIN_ALLOCATABLE], wt = e->plugin_weight[SPX_PLUGIN_TLP];
   const bool fusable = (plugin_mask == T || plugin_mask == (A | T)) && !e->ext_mask && e->tri_nodes && e->tri_pods &&
-                       e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && getenv("SPX_EXACT_ONLY") == nullptr &&
-                       getenv("SPX_DECIDE_UNFUSED") == nullptr && wa >= 0 && wt >= 0 && wa + wt <= 10000000;
+                       e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && !(launch_opts(e) & spx::kOptTrimaranExact) &&
+                       !e->option[SPX_OPT_DECIDE_UNFUSED] && wa >= 0 && wt >= 0 && wa + wt <= 10000000;
   int rc;
   if (!fusable) {
     if ((rc = spx_eval(e, plugin_mask, row_begin, row_end))) return rc;

@@ -16,6 +16,17 @@ constexpr int64_t kRowPad = 128;
 
 inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// per-launch switches derived from the engine's options (spx_set_option); carried in every Args struct as `opts`
+enum : uint32_t {
+  kOptTrimaranExact = 1u << 0,     // TLP / LVRB: reference float64 sequence only
+  kOptNrtGeneric = 1u << 1,        // NRT: int64 kernel
+  kOptNetGeneric = 1u << 2,        // NetworkOverhead: per-node kernel
+  kOptNrtSingleLaunch = 1u << 3,   // NRT Least/MostAllocated: Filter and Score in one launch
+  kOptCommitFromMemory = 1u << 4,  // commit loop: node state in memory
+  kOptPeaksWideA = 1u << 5,        // Peaks: 8 nodes per lane in the min/max pass
+  kOptPeaksWideB = 1u << 6,        // Peaks: 8 nodes per lane in the write pass
+};
+
 // ---------------------------------------------------------------- Allocatable
 struct AllocPrepArgs {
   int64_t n_nodes;
@@ -32,6 +43,7 @@ void launch_alloc_prepare(const AllocPrepArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- fused Allocatable + TLP + LVRB sweep
 struct TrimaranArgs {
+  uint32_t opts;
   int64_t n_nodes;
   int64_t row_stride;
   int64_t row_begin;
@@ -60,6 +72,7 @@ struct TrimaranArgs {
   double* lv_exact;  // scratch [n_nodes][8]: per-node exact LVRB state for the fast kernel's fallback
   float* lv_fast;    // scratch [ceil(row_stride/512)*512][8]: LVRB fast constants, tile-transposed (k_lvrb_prepare_fast)
   float* tlp_fast;   // scratch [ceil(row_stride/1024)*1024][4]: TLP fast constants, tile-transposed (k_tlp_prepare_fast)
+  unsigned long long* stats;  // [SPX_NUM_PLUGINS] cells the fast sweeps re-evaluated with the reference sequence (spx_fetch_stats); may be NULL
   // outputs: uint8 [n_pods][row_stride] each (NULL = plugin not evaluated)
   uint8_t* out_alloc;
   uint8_t* out_tlp;
@@ -133,6 +146,7 @@ struct LrocArgs {
   const double* pod_f64;
   int64_t n_pods_total;
   int32_t exact53;      // every integer the sweep touches is in [0, 2^52): float64 sums and differences are exact
+  unsigned long long* stats;  // as TrimaranArgs::stats
   uint8_t* out_score;   // [n_pods][row_stride]
 };
 void launch_lroc_prepare(const LrocArgs& a, hipStream_t s);
@@ -140,6 +154,7 @@ void launch_lroc(const LrocArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- Peaks (kernels_peaks.hip)
 struct PeaksArgs {
+  uint32_t opts;
   int64_t n_nodes;
   int64_t row_stride;
   int64_t row_begin;
@@ -160,6 +175,7 @@ void launch_peaks(const PeaksArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- NodeResourceTopologyMatch
 struct NrtArgs {
+  uint32_t opts;
   int64_t n_nodes;
   int64_t n_pods;
   int64_t row_stride;
@@ -240,6 +256,7 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- NetworkOverhead
 struct NetArgs {
+  uint32_t opts;
   int64_t n_nodes;
   int64_t row_stride;
   int64_t row_begin;

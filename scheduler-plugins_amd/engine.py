@@ -72,6 +72,30 @@ class Engine:
     def __exit__(self, *a):
         self.close()
 
+    # ------------------------------------------------------------------ options (per engine, spx_set_option)
+    def set_option(self, option, value: int) -> None:
+        """option: an SPX_OPT_* id or its name without the prefix, e.g. "REFERENCE_KERNELS"."""
+        if isinstance(option, str):
+            option = self._hdr.consts["SPX_OPT_" + option]
+        self._ck(self._lib.spx_set_option(self._h, option, int(value)))
+
+    def get_option(self, option) -> int:
+        if isinstance(option, str):
+            option = self._hdr.consts["SPX_OPT_" + option]
+        v = C.c_int64()
+        self._ck(self._lib.spx_get_option(self._h, option, C.byref(v)))
+        return int(v.value)
+
+    def force_reference_kernels(self, *plugins: int) -> None:
+        """run the reference-arithmetic sweep for these plugins (differential tests); no argument = back to the fast forms"""
+        self.set_option("REFERENCE_KERNELS", mask_of(*plugins))
+
+    def stats(self, reset: bool = False) -> np.ndarray:
+        """cells re-evaluated by the exact float64 fallback of the fast sweeps, per plugin id (spx_fetch_stats)"""
+        out = np.zeros(NUM_PLUGINS, np.int64)
+        self._ck(self._lib.spx_fetch_stats(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), 1 if reset else 0))
+        return out
+
     # ------------------------------------------------------------------ params
     def set_allocatable(self, mode: str = "Least", resources: Optional[Dict[int, int]] = None) -> None:
         """resources: {resource id: weight}; default = {memory: 1, cpu: 1<<20} (resource_allocation.go:36)."""
@@ -306,8 +330,11 @@ class Engine:
         return out
 
     def all_status(self, plugin: int, row_begin: int = 0, row_end: Optional[int] = None) -> np.ndarray:
+        """[rows][n_nodes] uint8 in one strided copy (spx_fetch_status_rows)"""
         row_end = self.n_pods if row_end is None else row_end
-        return np.stack([self.status(plugin, r) for r in range(row_begin, row_end)])
+        out = np.empty((row_end - row_begin, self.n_nodes), dtype=np.uint8)
+        self._ck(self._lib.spx_fetch_status_rows(self._h, plugin, row_begin, row_end, out.ctypes.data_as(C.POINTER(C.c_uint8)), self.n_nodes))
+        return out
 
     # ------------------------------------------------------------------ eval / fetch
     def eval(self, plugin_mask: int, row_begin: int = 0, row_end: Optional[int] = None) -> None:
@@ -394,6 +421,8 @@ class Engine:
         self._ck(self._lib.spx_set_stream(self._h, C.c_void_p(stream)))
 
     def all_scores(self, plugin: int, row_begin: int = 0, row_end: Optional[int] = None) -> np.ndarray:
-        """[rows][n_nodes] uint8 — convenience for tests (row by row through the ABI)."""
+        """[rows][n_nodes] uint8 in one strided copy (spx_fetch_score_rows)"""
         row_end = self.n_pods if row_end is None else row_end
-        return np.stack([self.scores(plugin, r) for r in range(row_begin, row_end)])
+        out = np.empty((row_end - row_begin, self.n_nodes), dtype=np.uint8)
+        self._ck(self._lib.spx_fetch_score_rows(self._h, plugin, row_begin, row_end, out.ctypes.data_as(C.POINTER(C.c_uint8)), self.n_nodes))
+        return out

@@ -36,16 +36,15 @@ def _scenario(hdr, n_nodes, n_pods, seed):
                                              ((ALLOCATABLE, TLP, LVRB), {ALLOCATABLE: 1, TLP: 3, LVRB: 2})])
 @pytest.mark.parametrize("n_nodes,n_pods,seed", [(23, 90, 1), (70, 60, 2), (1100, 40, 3)])
 @pytest.mark.parametrize("state", ["registers", "memory"])
-def test_commit_sequential_matches_one_pod_at_a_time(gpu_required, hdr, oracle, monkeypatch, state, plugins, weights, n_nodes, n_pods, seed):
+def test_commit_sequential_matches_one_pod_at_a_time(gpu_required, hdr, oracle, state, plugins, weights, n_nodes, n_pods, seed):
     """both variants of the loop: node state resident in registers (up to 10240 nodes) and re-read from memory per pod"""
-    if state == "memory":
-        monkeypatch.setenv("SPX_COMMIT_FROM_MEMORY", "1")
     res, nodes, metrics, pods, earlier = _scenario(hdr, n_nodes, n_pods, seed)
     node_t = O.build_node_objects(hdr, res, nodes)
     pod_t = O.build_pod_objects(hdr, res, pods)
     met_t = O.build_metrics_objects(hdr, n_nodes, metrics, window_end=WINDOW_END)
     rc = res.table(hdr)
     with Engine(0) as e:
+        e.set_option("COMMIT_FROM_MEMORY", 1 if state == "memory" else 0)
         e.load_trimaran_objects(node_t, rc, pod_t, met_t, O.build_assigned_objects(hdr, res, n_nodes, earlier))
         e.set_plugin_weights(weights)
         got_node, got_score, got_ties, got_missing = e.commit_sequential(mask_of(*plugins))

@@ -1,0 +1,249 @@
+"""Exhaustive GPU-vs-oracle parity at the sizes BASELINE.json quotes: EVERY cell of every result table of configs #2
+(Allocatable + TLP + LVRB, 10k x 100k), #3 (NRT Filter + Score, all four strategies, 5k x 8 zones x 50k), #4
+(NetworkOverhead, 10k x 200k) and #5's one-GPU share (full profile with feasibility-masked normalisations, 20k x 62.5k),
+plus LowRiskOverCommitment and Peaks at config #2's size.  The oracle runs on all host cores, the tables come back in
+row blocks through spx_fetch_score_rows / spx_fetch_status_rows; nothing is sampled.
+
+The fast formulations re-evaluate the cells they cannot prove (spx_fetch_stats); the tests assert that such cells exist at
+these sizes — so the fallback is exercised — and since every row is compared, every one of them is.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ALLOCATABLE, CAPACITY, LROC, LVRB, NETOVERHEAD, NRT, PEAKS, TLP, lvrb_params, tlp_params
+from scheduler_plugins_amd import objects as O
+from scheduler_plugins_amd import synth
+from scheduler_plugins_amd.engine import Engine, mask_of
+
+pytestmark = pytest.mark.gpu
+
+THREADS = os.cpu_count() or 1
+
+
+def blocks(n_rows, n_nodes, cells=48_000_000):
+    step = max(THREADS, cells // n_nodes)
+    for r0 in range(0, n_rows, step):
+        yield r0, min(n_rows, r0 + step)
+
+
+def count_mismatches(got_u8, want_i64, tol=0):
+    """(cells differing by more than tol, cells differing at all); scores above 255 cannot occur (uint8 tables clip)"""
+    d = np.abs(got_u8.astype(np.int16) - np.clip(want_i64, 0, 255).astype(np.int16))
+    return int((d > tol).sum()), int((d != 0).sum())
+
+
+def test_config2_every_cell(gpu_required, hdr, oracle):
+    n_nodes, n_pods = 10_000, 100_000
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, round_frac=0.05)
+    with Engine(0) as e:
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        assert e.kernel_path(TLP) == 1
+        e.stats(reset=True)
+        e.eval(mask_of(ALLOCATABLE, TLP, LVRB))
+        e.sync()
+        st = e.stats()
+        # the float32 sweeps met cells they could not prove, and (below) every row that holds one is compared
+        assert 0 < st[TLP] < 2e-2 * n_nodes * n_pods and 0 < st[LVRB] < 2e-2 * n_nodes * n_pods, st  # 5 % of the nodes carry integer-valued metrics (exact ties)
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], metrics=snap["metrics"], assigned=snap["assigned"],
+                                alloc_params=e.alloc_params, tlp_params=tlp_params(hdr), lvrb_params=lvrb_params(hdr))
+        _, alloc_row = osnap.score_rows(ALLOCATABLE, 0, 1, want_raw=False)
+        bad = {ALLOCATABLE: 0, TLP: 0, LVRB: 0}
+        for r0, r1 in blocks(n_pods, n_nodes):
+            for p in (TLP, LVRB):  # no NormalizeScore: raw == final
+                want = osnap.score_rows(p, r0, r1, threads=THREADS, want_norm=False)[0]
+                bad[p] += count_mismatches(e.all_scores(p, r0, r1), want)[0]
+            # Allocatable ignores the pod (allocatable.go:118-126): the oracle's row 0 is every row
+            bad[ALLOCATABLE] += int((e.all_scores(ALLOCATABLE, r0, r1) != alloc_row[0].astype(np.uint8)[None, :]).sum())
+        assert bad == {ALLOCATABLE: 0, TLP: 0, LVRB: 0}
+        # the reference-arithmetic kernel on the same snapshot leaves the same tables (spot block) and counts nothing
+        e.force_reference_kernels(TLP, LVRB)
+        e.stats(reset=True)
+        keep = {p: e.all_scores(p, 4096, 4096 + 512) for p in (TLP, LVRB)}
+        e.eval(mask_of(TLP, LVRB), 4096, 4096 + 512)
+        e.sync()
+        assert e.kernel_path(TLP) == 0 and not e.stats().any()
+        for p in (TLP, LVRB):
+            assert np.array_equal(e.all_scores(p, 4096, 4096 + 512), keep[p])
+
+
+@pytest.mark.parametrize("strategy", ["LeastAllocated", "MostAllocated", "BalancedAllocation", "LeastNUMANodes"])
+def test_config3_every_cell(gpu_required, hdr, oracle, strategy):
+    n_nodes, n_pods = 5_000, 50_000
+    snap = synth.nrt_snapshot(hdr, n_nodes, n_pods)
+    params = O.nrt_params(hdr, O.Resources(), strategy)
+    with Engine(0) as e:
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+        assert e.kernel_path(NRT) == 1
+        e.eval(mask_of(NRT))
+        e.sync()
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
+        bad_status = bad_score = 0
+        rejected = 0
+        for r0, r1 in blocks(n_pods, n_nodes, cells=16_000_000):
+            want_st = osnap.filter_rows(NRT, r0, r1, threads=THREADS)
+            bad_status += int((e.all_status(NRT, r0, r1) != want_st).sum())
+            rejected += int((want_st != 0).sum())
+            want_sc = osnap.score_rows(NRT, r0, r1, threads=THREADS, want_norm=False)[0]  # TopologyMatch has no NormalizeScore
+            bad_score += count_mismatches(e.all_scores(NRT, r0, r1), want_sc)[0]
+        assert (bad_status, bad_score) == (0, 0)
+        assert 0.01 * n_nodes * n_pods < rejected < 0.9 * n_nodes * n_pods  # both Filter verdicts are well represented
+
+
+def test_config4_every_cell(gpu_required, hdr, oracle):
+    n_nodes, n_pods = 10_000, 200_000
+    snap = synth.network_snapshot(hdr, n_nodes, n_pods)
+    with Engine(0) as e:
+        e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+        assert e.kernel_path(NETOVERHEAD) == 1
+        e.eval(mask_of(NETOVERHEAD))
+        e.sync()
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], appgroups=snap["appgroups"], nettopo=snap["nettopo"])
+        bad_status = bad_score = rejected = 0
+        for r0, r1 in blocks(n_pods, n_nodes):
+            want_st = osnap.filter_rows(NETOVERHEAD, r0, r1, threads=THREADS)
+            bad_status += int((e.all_status(NETOVERHEAD, r0, r1) != want_st).sum())
+            rejected += int((want_st != 0).sum())
+            want_sc = osnap.score_rows(NETOVERHEAD, r0, r1, threads=THREADS, want_raw=False)[1]
+            bad_score += count_mismatches(e.all_scores(NETOVERHEAD, r0, r1), want_sc)[0]
+        assert (bad_status, bad_score) == (0, 0)
+        assert rejected > 0
+
+
+def test_config5_share_every_cell(gpu_required, hdr, oracle):
+    """the one-GPU share of config #5 (20k nodes x 62.5k of the 500k pods), full plugin set: Filter tables, the
+    non-normalising scores, NetworkOverhead normalised over the nodes that passed NRT, Allocatable normalised over the nodes
+    that passed both Filters, CapacityScheduling.PreFilter, and the per-pod weighted argmax with its tie set"""
+    n_nodes, n_pods = 20_000, 62_500
+    snap = synth.full_snapshot(hdr, n_nodes, n_pods)
+    params = O.nrt_params(hdr, O.Resources(), "LeastAllocated")
+    weights = {ALLOCATABLE: 1, TLP: 2, LVRB: 1, NRT: 3, NETOVERHEAD: 2}
+    allp = (ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY)
+    with Engine(0) as e:
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+        e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+        e.load_quota_objects(snap["pods"], snap["rc"], snap["quota"])
+        assert e.kernel_path(NRT) == 1 and e.kernel_path(NETOVERHEAD) == 1
+        e.set_plugin_weights(weights)
+        e.stats(reset=True)
+        e.eval(mask_of(*allp))
+        e.eval_best(mask_of(*allp))
+        e.sync()
+        st = e.stats()
+        assert st[TLP] > 0 and st[LVRB] > 0, st
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], metrics=snap["metrics"], assigned=snap["assigned"],
+                                alloc_params=e.alloc_params, tlp_params=tlp_params(hdr), lvrb_params=lvrb_params(hdr),
+                                nrt=snap["nrt"], nrt_params=params, appgroups=snap["appgroups"], nettopo=snap["nettopo"])
+        pre = np.array([oracle.lib().orc_capacity_prefilter(snap["pods"].ref(), snap["rc"].ref(), snap["quota"].ref(), i)
+                        for i in range(n_pods)], dtype=np.uint8)
+        assert np.array_equal(e.prefilter(CAPACITY), pre)
+        assert 0 < (pre != 0).sum() < n_pods
+        node, score, ties, feas = e.best()
+        bad = {k: 0 for k in ("nrt_status", "net_status", TLP, LVRB, NRT, NETOVERHEAD, ALLOCATABLE, "best")}
+        masked_rows_differ = 0
+        for r0, r1 in blocks(n_pods, n_nodes, cells=24_000_000):
+            nrt_st = osnap.filter_rows(NRT, r0, r1, threads=THREADS)
+            net_st = osnap.filter_rows(NETOVERHEAD, r0, r1, threads=THREADS)
+            bad["nrt_status"] += int((e.all_status(NRT, r0, r1) != nrt_st).sum())
+            bad["net_status"] += int((e.all_status(NETOVERHEAD, r0, r1) != net_st).sum())
+            want = {}
+            for p in (TLP, LVRB, NRT):
+                want[p] = osnap.score_rows(p, r0, r1, threads=THREADS, want_norm=False)[0].clip(0, 255)
+            # RunScorePlugins sees the nodes that passed every Filter: NetworkOverhead's min/max run over NRT-feasible nodes,
+            # Allocatable's over nodes that passed NRT and NetworkOverhead (masks are indexed from the block's first row)
+            want[NETOVERHEAD] = _masked(osnap, NETOVERHEAD, r0, r1, nrt_st == 0)
+            feasible = (nrt_st == 0) & (net_st == 0)
+            want[ALLOCATABLE] = _masked(osnap, ALLOCATABLE, r0, r1, feasible)
+            for p in weights:
+                got = e.all_scores(p, r0, r1)
+                bad[p] += count_mismatches(got, want[p])[0]
+                if p == ALLOCATABLE:
+                    masked_rows_differ += int((got != got[0][None, :]).any(axis=1).sum())
+            total = sum(weights[p] * want[p] for p in weights)
+            total[~feasible] = -1
+            best = total.max(axis=1)
+            n_best = (total == best[:, None]).sum(axis=1)
+            first = total.argmax(axis=1)
+            none = (pre[r0:r1] != 0) | (best < 0)
+            ok = np.where(none, (node[r0:r1] == -1) & (ties[r0:r1] == 0),
+                          (node[r0:r1] == first) & (score[r0:r1] == best) & (ties[r0:r1] == n_best) & (feas[r0:r1] == feasible.sum(axis=1)))
+            bad["best"] += int((~ok).sum())
+        assert not any(bad.values()), bad
+        assert masked_rows_differ > 0  # the feasibility sets really differ from row to row
+
+
+def _masked(osnap, plugin, r0, r1, feasible):
+    """oracle's normalised rows r0..r1 with NormalizeScore restricted to `feasible` ([r1-r0][N] bool, block-local); the oracle
+    indexes its mask by absolute row, so hand it a view that starts r0 rows earlier"""
+    n = feasible.shape[1]
+    full = np.zeros((r1, n), dtype=np.uint8)
+    full[r0:r1] = feasible
+    return osnap.score_rows(plugin, r0, r1, mask=full, threads=THREADS, want_raw=False)[1]
+
+
+def test_config2_lroc_every_cell(gpu_required, hdr, oracle):
+    """LowRiskOverCommitment at config #2's size, +-1 (lgamma / pow last digits); the oracle evaluates the
+    incomplete beta function per (pod, node) like the reference, so the full table costs it about a minute of CPU"""
+    n_nodes, n_pods = 10_000, 100_000
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, with_node_pods=True)
+    from helpers import lroc_params
+    with Engine(0) as e:
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        e.set_lroc()
+        e.load_lroc_objects(snap["nodes"], snap["node_pods"], snap["pods"])
+        assert e.kernel_path(LROC) == 1
+        e.stats(reset=True)
+        e.eval(mask_of(LROC))
+        e.sync()
+        assert e.stats()[LROC] > 0
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], metrics=snap["metrics"], node_pods=snap["node_pods"],
+                                lroc_params=lroc_params(hdr))
+        off = differ = 0
+        for r0, r1 in blocks(n_pods, n_nodes):
+            want = osnap.score_rows(LROC, r0, r1, threads=THREADS, want_norm=False)[0]
+            a, b = count_mismatches(e.all_scores(LROC, r0, r1), want, tol=1)
+            off += a
+            differ += b
+        assert off == 0 and differ < 1e-3 * n_nodes * n_pods, (off, differ)
+
+
+def test_config2_peaks_every_cell(gpu_required, hdr, oracle):
+    """Peaks at config #2's size.  Rows of pods that request cpu: normalised scores +-1 against the oracle (exp's last
+    digit).  Rows of pods that request none carry the reference's rounding-noise jumps (see test_gpu_peaks): their raw
+    scores are compared with the oracle's (within the noise), and their normalised row must be the reference's
+    NormalizeScore (peaks.go:150-166, integer arithmetic) of the raw row the GPU itself produced — so no row is exempt."""
+    n_nodes, n_pods = 10_000, 100_000
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, round_frac=0.1)
+    snap["power_models"] = synth.synth_power_models(hdr, n_nodes, synth.SEED)
+    with Engine(0) as e:
+        e.load_peaks_objects(snap["nodes"], snap["metrics"], snap["power_models"], snap["pods"])
+        e.eval(mask_of(PEAKS))
+        e.sync()
+        real = e.peaks_soa["cpu_milli"] > 0
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], metrics=snap["metrics"], power_models=snap["power_models"])
+        off = differ = n_real = 0
+        for r0, r1 in blocks(n_pods, n_nodes):
+            want = osnap.score_rows(PEAKS, r0, r1, threads=THREADS, want_raw=False)[1]
+            got = e.all_scores(PEAKS, r0, r1)
+            sel = real[r0:r1]
+            a, b = count_mismatches(got[sel], want[sel], tol=1)
+            off += a
+            differ += b
+            n_real += int(sel.sum()) * n_nodes
+        assert off == 0 and differ < 2e-3 * n_real, (off, differ)
+        noise_rows = np.flatnonzero(~real)
+        assert noise_rows.size > 0
+        for r in noise_rows[:: max(1, noise_rows.size // 200)]:
+            raw_g = e.raw(PEAKS, int(r))
+            raw_w = osnap.score_rows(PEAKS, int(r), int(r) + 1, want_norm=False)[0][0]
+            assert np.abs(raw_g - raw_w).max() <= 64, int(r)
+            lo, hi = int(raw_g.min()), int(raw_g.max())
+            if hi == 0 and lo == 0:
+                norm = np.zeros(n_nodes, np.int64)
+            elif hi == lo:
+                norm = np.full(n_nodes, 100, np.int64)
+            else:  # 100 - int64(float64(s - lo) * 100 / float64(hi - lo)): float64 as the reference, element-wise IEEE
+                norm = 100 - ((raw_g - lo).astype(np.float64) * 100.0 / float(hi - lo)).astype(np.int64)
+            assert np.array_equal(e.scores(PEAKS, int(r)).astype(np.int64), norm), int(r)

@@ -57,12 +57,14 @@ def test_compute_risk_golden_through_the_sweep(gpu_required, hdr, case):
 @pytest.mark.parametrize("generic", ["fast", "float64", "int64"])
 @pytest.mark.parametrize("seed,n_nodes,n_pods,params", [
     (1, 700, 130, {}), (2, 257, 64, dict(smoothing_window_size=1, w_cpu=0.0, w_mem=1.0)), (3, 1500, 70, dict(smoothing_window_size=12, w_cpu=0.9, w_mem=0.2))])
-def test_parity_with_oracle(gpu_required, hdr, oracle, monkeypatch, generic, seed, n_nodes, n_pods, params):
-    if generic != "fast":  # fast = float32 estimate + float64 fallback (default); the other two are the exact forms on their own
-        monkeypatch.setenv({"float64": "SPX_LROC_F64", "int64": "SPX_LROC_GENERIC"}[generic], "1")
+def test_parity_with_oracle(gpu_required, hdr, oracle, generic, seed, n_nodes, n_pods, params):
     snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=seed, round_frac=0.1, with_node_pods=True)
     want = oracle_scores(oracle, hdr, snap, **params)
     with Engine(0) as e:
+        if generic == "float64":  # fast = float32 estimate + float64 fallback (default); the other two are the exact forms on their own
+            e.set_option("LROC_FLOAT64", 1)
+        elif generic == "int64":
+            e.force_reference_kernels(LROC)
         load(e, snap, **params)
         assert e.kernel_path(LROC) == (1 if generic == "fast" else 0)
         e.eval(mask_of(LROC))

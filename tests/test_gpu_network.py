@@ -66,12 +66,12 @@ def test_toposort_queue_order_golden(gpu_required, hdr, case):
 
 @pytest.mark.parametrize("kernel", ["class_table", "generic"])
 @pytest.mark.parametrize("n_nodes,n_pods,seed,ppg", [(500, 300, 1, 30), (64, 40, 2, 5), (1, 3, 3, 1), (1030, 129, 4, 10), (257, 200, 5, 200)])
-def test_differential(gpu_required, hdr, oracle, monkeypatch, kernel, n_nodes, n_pods, seed, ppg):
+def test_differential(gpu_required, hdr, oracle, kernel, n_nodes, n_pods, seed, ppg):
     """both table sweeps (the class-table kernel and the per-node one it replaces) against the oracle"""
-    if kernel == "generic":
-        monkeypatch.setenv("SPX_NET_GENERIC", "1")  # read by the library at every launch
     snap = synth.network_snapshot(hdr, n_nodes, n_pods, seed=seed, pods_per_group=ppg)
     with Engine(0) as e:
+        if kernel == "generic":
+            e.force_reference_kernels(NETOVERHEAD)
         e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
         assert e.kernel_path(NETOVERHEAD) == (1 if kernel == "class_table" else 0)
         e.eval(mask_of(NETOVERHEAD))

@@ -228,12 +228,12 @@ def _wide_snapshot(hdr, n_nodes, n_pods, seed):
 
 @pytest.mark.parametrize("kernel", ["float64", "generic"])
 @pytest.mark.parametrize("strategy", ["LeastAllocated", "MostAllocated", "BalancedAllocation", "LeastNUMANodes"])
-def test_differential_seven_resources(gpu_required, hdr, oracle, monkeypatch, strategy, kernel):
-    if kernel == "generic":
-        monkeypatch.setenv("SPX_NRT_GENERIC", "1")
+def test_differential_seven_resources(gpu_required, hdr, oracle, strategy, kernel):
     res, nodes, nrts, pods = _wide_snapshot(hdr, 140, 60, seed=21)
     params = O.nrt_params(hdr, res, strategy, {"cpu": 3, "vendor.io/gpu": 2})
     with Engine(0) as e:
+        if kernel == "generic":
+            e.force_reference_kernels(NRT)
         e.load_nrt_objects(nodes, nrts, res.table(hdr), pods, params)
         assert e.nrt_soa["slots"].struct.n_res > 4
         assert e.kernel_path(NRT) == (1 if kernel == "float64" else 0)

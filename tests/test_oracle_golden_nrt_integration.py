@@ -49,12 +49,12 @@ def test_nrt_integration_oracle(hdr, oracle, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kernel", ["float64", "generic"])
 @pytest.mark.parametrize("case", G["cases"], ids=lambda c: f"L{c['line']}")
-def test_nrt_integration_gpu(gpu_required, hdr, monkeypatch, case, kernel):
+def test_nrt_integration_gpu(gpu_required, hdr, case, kernel):
     from scheduler_plugins_amd.engine import Engine, mask_of
-    if kernel == "generic":
-        monkeypatch.setenv("SPX_NRT_GENERIC", "1")
     res, nodes, nrts, pods, params = build(hdr, case)
     with Engine(0) as e:
+        if kernel == "generic":
+            e.force_reference_kernels(NRT)
         e.load_nrt_objects(nodes, nrts, res.table(hdr), pods, params)
         e.eval(mask_of(NRT))
         e.sync()
