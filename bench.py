@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the batched Filter/Score engine.
 
-Metric (BASELINE.json): pod x node Filter+Score evals/sec.  A "step" is one pass of the hot path
-(one spx_eval of the whole plugin set) over one batch of synthetic pods against the node snapshot,
-with every input table already resident in HBM.  N=1 workload = BASELINE.json configs[1]:
-noderesources.Allocatable + trimaran.TargetLoadPacking, 10k nodes x 100k pods.
+Metric (BASELINE.json): pod x node Filter+Score evals/sec.  A "step" is one pass of the hot path (one spx_eval of the whole
+plugin set) over one batch of synthetic pods against the node snapshot, with every input table already resident in HBM.
+N=1 workload = BASELINE.json configs[1]: noderesources.Allocatable + trimaran.TargetLoadPacking, 10k nodes x 100k pods.
 
-N>1 (launched by torch.distributed.run, one rank per GPU): pod rows are the sharded unit — every rank
-evaluates its own 100k-pod batch against the replicated node tables (weak scaling), no data-path
-collective; `value` = all ranks' evals / max-over-ranks time.
+`--gpus N` with N > 1 runs in one of two shapes, same numbers either way:
+  * launched bare (`python bench.py --gpus N`): ONE host process drives N devices through the C ABI's multi-device layer
+    (spx_multi_*: an engine and a host thread per device, RCCL all-gather for the exchange) — the shape north_star names
+    (a single Go scheduler, 8 GPUs);
+  * launched by torch.distributed.run (WORLD_SIZE set): one rank per GPU, torch.distributed (RCCL) for barrier / exchange.
+Pod rows are the sharded unit, node tables are replicated, the evaluation has no collective.  Weak-scaling workloads give
+every GPU its own batch (config2: 100k pods per GPU); the workloads BASELINE quotes on 8 GPUs are strong-scaling: config4
+shards 200k pods and config5 500k pods over the N GPUs.  The exchange (all-gather of the 20-byte per-pod decisions, and with
+`--gather table` of one uint8 table) is measured outside the timed region and reported next to the kernel-only step.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -29,7 +35,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 WORKLOADS = {
-    # name: (n_nodes, n_pods per GPU, plugins, algorithmic bytes: node_row, pod_row, out per eval) — SURVEY.md §8d
+    # n_pods: per GPU (weak) or for the whole job (strong); algorithmic bytes: node_row, pod_row, out per eval — SURVEY.md §8d
     "config2": dict(n_nodes=10_000, n_pods=100_000, plugins=("alloc", "tlp"), node_row=41, pod_row=8, out=2,
                     desc="noderesources.Allocatable + trimaran.TargetLoadPacking, 10k nodes x 100k pods"),
     "config2_lvrb": dict(n_nodes=10_000, n_pods=100_000, plugins=("alloc", "tlp", "lvrb"), node_row=90, pod_row=24, out=3,
@@ -47,20 +53,117 @@ WORKLOADS = {
                          desc="noderesourcetopology Filter+Score (MostAllocated), 5k nodes x 8 NUMA zones x 50k pods"),
     "config3_balanced": dict(n_nodes=5_000, n_pods=50_000, plugins=("nrt",), node_row=324, pod_row=100, out=2, strategy="BalancedAllocation",
                              desc="noderesourcetopology Filter+Score (BalancedAllocation), 5k nodes x 8 NUMA zones x 50k pods"),
-    "config4": dict(n_nodes=10_000, n_pods=200_000, plugins=("net",), node_row=4, pod_row=48, out=2,
-                    desc="networkaware NetworkOverhead (+TopologicalSort keys), 10k nodes x 3-tier topology x 200k pods"),
-    "config5": dict(n_nodes=20_000, n_pods=62_500, plugins=("cap", "alloc", "tlp", "lvrb", "nrt", "net"), node_row=405, pod_row=188, out=7,
-                    strategy="LeastAllocated",
-                    desc="full profile: CapacityScheduling PreFilter + Allocatable + TLP + LVRB + NRT + NetworkOverhead, 20k nodes x 62.5k pods per GPU (500k pods on 8)"),
+    "config4": dict(n_nodes=10_000, n_pods=200_000, plugins=("net",), node_row=4, pod_row=48, out=2, scaling="strong",
+                    desc="networkaware NetworkOverhead (+TopologicalSort keys), 10k nodes x 3-tier topology x 200k pods sharded over the GPUs"),
+    "config5": dict(n_nodes=20_000, n_pods=500_000, plugins=("cap", "alloc", "tlp", "lvrb", "nrt", "net"), node_row=405, pod_row=188, out=7,
+                    strategy="LeastAllocated", scaling="strong",
+                    desc="full profile: CapacityScheduling PreFilter + Allocatable + TLP + LVRB + NRT + NetworkOverhead, 20k nodes x 500k pods sharded over the GPUs"),
+    # config5's one-GPU share of the 8-GPU job (62.5k of the 500k pods), as a single-device workload
+    "config5_share": dict(n_nodes=20_000, n_pods=62_500, plugins=("cap", "alloc", "tlp", "lvrb", "nrt", "net"), node_row=405, pod_row=188, out=7,
+                          strategy="LeastAllocated",
+                          desc="full profile, 20k nodes x 62.5k pods (= one GPU's share of config5 on 8)"),
+    # the reference's own benchmark shapes: BenchmarkTargetLoadPackingPlugin (targetloadpacking_test.go:283-384:
+    # nodesNum / podsNum 100/1000, 1000/10000, 5000/30000; one pod per iteration, every node reporting CPU 0 Latest) and
+    # BenchmarkNetworkOverhead* (networkoverhead_test.go:349-570: onlineboutique, 10 pods placed, 10 ... 10000 nodes)
+    "ref_tlp_100": dict(n_nodes=100, n_pods=1_000, plugins=("tlp",), node_row=33, pod_row=8, out=1, ref_shape=True,
+                        desc="BenchmarkTargetLoadPackingPlugin/100nodes: TLP, 100 nodes x 1000 pods"),
+    "ref_tlp_1000": dict(n_nodes=1_000, n_pods=10_000, plugins=("tlp",), node_row=33, pod_row=8, out=1, ref_shape=True,
+                         desc="BenchmarkTargetLoadPackingPlugin/1000nodes: TLP, 1000 nodes x 10000 pods"),
+    "ref_tlp_5000": dict(n_nodes=5_000, n_pods=30_000, plugins=("tlp",), node_row=33, pod_row=8, out=1, ref_shape=True,
+                         desc="BenchmarkTargetLoadPackingPlugin/5000nodes: TLP, 5000 nodes x 30000 pods"),
+    "ref_net_1000": dict(n_nodes=1_000, n_pods=11_000, plugins=("net",), node_row=4, pod_row=48, out=2, pods_per_group=11,
+                         desc="BenchmarkNetworkOverhead*/1000 nodes: AppGroups of 11 workloads (onlineboutique), 1000 nodes x 11000 pods"),
+    "ref_net_10000": dict(n_nodes=10_000, n_pods=11_000, plugins=("net",), node_row=4, pod_row=48, out=2, pods_per_group=11,
+                          desc="BenchmarkNetworkOverhead*/10000 nodes: AppGroups of 11 workloads (onlineboutique), 10000 nodes x 11000 pods"),
     "small": dict(n_nodes=1_000, n_pods=4_000, plugins=("alloc", "tlp"), node_row=41, pod_row=8, out=2,
                   desc="plumbing-sized Allocatable + TLP"),
 }
+PID = {"alloc": 0, "tlp": 1, "lvrb": 2, "nrt": 3, "net": 4, "cap": 5, "lroc": 7, "peaks": 8}
+
+
+def kernel_source_hash() -> str:
+    """identifies the kernel sources a profile was taken with (the GPU box has no .git): profiles/ entries carry it, and
+    bench.py reports their counter figures only while it still matches"""
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "scheduler-plugins_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".h"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def build_snapshot(hdr, w, n_pods, seed):
+    from scheduler_plugins_amd import objects as O
+    from scheduler_plugins_amd import synth
+    n_nodes = w["n_nodes"]
+    if "cap" in w["plugins"]:
+        snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=seed)
+        snap["nrt_params"] = O.nrt_params(hdr, O.Resources(), w["strategy"])
+    elif "nrt" in w["plugins"]:
+        snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED)
+        if seed != synth.SEED:
+            snap["pods"] = synth.synth_pods(hdr, n_pods, seed=seed, device_res=synth.RES_DEVICE, hugepage_res=synth.RES_HUGEPAGES_2MI)
+        snap["nrt_params"] = O.nrt_params(hdr, O.Resources(), w["strategy"])
+    elif "net" in w["plugins"]:
+        snap = synth.network_snapshot(hdr, n_nodes, n_pods, seed=seed, **({"pods_per_group": w["pods_per_group"]} if "pods_per_group" in w else {}))
+    else:
+        snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED, round_frac=w.get("round_frac", 0.0),
+                                       with_node_pods="lroc" in w["plugins"])
+        if seed != synth.SEED:
+            snap["pods"] = synth.synth_pods(hdr, n_pods, seed=seed)
+        if w.get("ref_shape"):  # every node reports one metric: CPU, Latest, 0 (targetloadpacking_test.go:325-334)
+            snap["metrics"] = O.build_metrics_objects(hdr, n_nodes, {i: [("CPU", "Latest", 0.0)] for i in range(n_nodes)})
+            snap["assigned"] = None
+        if "peaks" in w["plugins"]:
+            snap["power_models"] = synth.synth_power_models(hdr, n_nodes, synth.SEED)
+    return snap
+
+
+def load_tables(target, w, snap, rows=None):
+    """target: Engine (rows = the slice of the batch this rank holds, None = all) or MultiEngine (shards itself)"""
+    from scheduler_plugins_amd.engine import Engine
+    pl = w["plugins"]
+    sliced = isinstance(target, Engine) and rows is not None
+    if any(p in pl for p in ("alloc", "tlp", "lvrb", "lroc", "peaks", "cap")):
+        if sliced:
+            target.upload_alloc_nodes(target.flatten_alloc_nodes(snap["nodes"], snap["rc"]))
+            target.upload_trimaran_nodes(target.flatten_trimaran_nodes(snap["nodes"], snap["metrics"], snap.get("assigned")))
+            target.upload_trimaran_pods(target.flatten_trimaran_pods(snap["pods"]), rows)
+        else:
+            target.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap.get("assigned"))
+    if "peaks" in pl:
+        target.load_peaks_objects(snap["nodes"], snap["metrics"], snap["power_models"], snap["pods"])
+    if "lroc" in pl:
+        if hasattr(target, "for_all"):
+            target.for_all(lambda e: e.set_lroc())
+        else:
+            target.set_lroc()
+        target.load_lroc_objects(snap["nodes"], snap["node_pods"], snap["pods"])
+    if "nrt" in pl:
+        if sliced:
+            target.upload_nrt(target.flatten_nrt(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], snap["nrt_params"]), rows)
+        else:
+            target.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], snap["nrt_params"])
+    if "net" in pl:
+        if sliced:
+            target.upload_network(target.flatten_network(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"]), rows)
+        else:
+            target.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+    if "cap" in pl:
+        if sliced:
+            target.upload_quota(target.flatten_quota(snap["pods"], snap["rc"], snap["quota"]), rows)
+        else:
+            target.load_quota_objects(snap["pods"], snap["rc"], snap["quota"])
 
 
 def cpu_baseline(spx, snap, e, plugins, budget_s: float):
-    """Times the CPU oracle (C restatement of the reference's per-(pod,node) path — NOT the Go binary)
-    on a bounded sample of the same workload's pod rows, all host cores, rows split across threads."""
+    """Times the CPU oracle (C restatement of the reference's per-(pod,node) path — NOT the Go binary) on bounded samples of
+    the same workload's pod rows, in three layouts: all host cores with pod rows split across threads (`value`: no per-pod
+    join, the most favourable layout for the CPU), one thread, and the reference benchmark's own structure — one pod at a
+    time, its node loop chunked over 16 workers that join per pod (targetloadpacking_test.go:369-405)."""
     sys.path.insert(0, str(ROOT / "oracle"))
+    import ctypes as C
+
     import pyoracle
 
     osnap = pyoracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], metrics=snap.get("metrics"), assigned=snap.get("assigned"),
@@ -71,37 +174,63 @@ def cpu_baseline(spx, snap, e, plugins, budget_s: float):
     cores = os.cpu_count() or 1
     n_nodes = osnap.n_nodes
 
-    def run(rows: int) -> float:
+    def run_rows(rows: int, threads: int) -> float:
         t0 = time.perf_counter()
         for p in plugins:
             if p == 5:  # CapacityScheduling.PreFilter is per pod, not per (pod,node): negligible, not part of the CPU sample
                 continue
-            osnap.score_rows(p, 0, rows, threads=cores, want_raw=False, want_norm=True)
+            osnap.score_rows(p, 0, rows, threads=threads, want_raw=False, want_norm=True)
             if p in (3, 4):  # NodeResourceTopologyMatch / NetworkOverhead also have a Filter extension point
-                osnap.filter_rows(p, 0, rows, threads=cores)
-        return time.perf_counter() - t0
+                osnap.filter_rows(p, 0, rows, threads=threads)
         return time.perf_counter() - t0
 
-    probe_rows = min(osnap.n_pods, 8 * cores)
-    t = run(probe_rows)
-    rate = probe_rows / max(t, 1e-9)
-    rows = int(max(probe_rows, min(osnap.n_pods, rate * budget_s)))
-    t = run(rows)
-    return {
+    def run_cycle(rows: int, workers: int) -> float:
+        t0 = time.perf_counter()
+        for p in plugins:
+            if p in (4, 5):  # NetworkOverhead's PreFilter state is per pod: its reference benchmarks are single-goroutine loops
+                continue
+            pyoracle.lib().orc_cycle_rows(C.byref(osnap.struct), p, 0, rows, workers, None)
+        return time.perf_counter() - t0
+
+    def sized(fn, arg, probe_rows, share):
+        probe_rows = max(1, min(osnap.n_pods, probe_rows))
+        t = fn(probe_rows, arg)
+        rows = int(max(probe_rows, min(osnap.n_pods, probe_rows / max(t, 1e-9) * budget_s * share)))
+        t = fn(rows, arg)
+        return rows, t
+
+    rows, t = sized(run_rows, cores, 8 * cores, 0.5)
+    out = {
         "value": rows * n_nodes / t, "unit": "evals/s", "cores": cores, "kind": "port",
-        "sample": f"{rows} pod rows x {n_nodes} nodes of the same snapshot, {len(plugins)} plugins, {t:.2f} s wall; "
-                  "C restatement of the reference CPU path (oracle/), not the Go binary",
+        "sample": f"{rows} pod rows x {n_nodes} nodes of the same snapshot, {len(plugins)} plugins, {t:.2f} s wall, pod rows split over "
+                  f"{cores} threads; C restatement of the reference CPU path (oracle/), not the Go binary",
     }
+    rows1, t1 = sized(run_rows, 1, 8, 0.25)
+    out["single_thread"] = {"value": rows1 * n_nodes / t1, "cores": 1, "sample": f"{rows1} pod rows, {t1:.2f} s"}
+    if any(p not in (4, 5) for p in plugins):
+        rows16, t16 = sized(run_cycle, 16, 16, 0.25)
+        out["reference_structure"] = {
+            "value": rows16 * n_nodes / t16, "cores": 16, "sample": f"{rows16} pods one after the other, {t16:.2f} s",
+            "what": "one pod at a time; its node loop in chunks of min(sqrt(N), N/16+1) claimed by 16 workers that join per pod, "
+                    "NormalizeScore serial (workqueue.ParallelizeUntil as copied into targetloadpacking_test.go:386-405)"}
+    return out
 
 
-def measured_traffic(workload: str):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN/<workload>_traffic.json;
-    collected by tools/prof1.sh in separate --pmc runs, FETCH_SIZE corrected x2 for gfx950)."""
+def profile_counters(workload: str):
+    """counter figures of the committed rocprofv3 PMC passes (profiles/rNN/<workload>_traffic.json: separate --pmc runs, FETCH_SIZE
+    corrected x2 for gfx950) — reported only when taken with the kernel sources this run was built from"""
     cands = sorted(ROOT.glob(f"profiles/r*/{workload}_traffic.json"))
     if not cands:
-        return None, None
+        return None
     d = json.loads(cands[-1].read_text())
-    return d.get("traffic_bytes_per_launch"), str(cands[-1].relative_to(ROOT))
+    src = str(cands[-1].relative_to(ROOT))
+    if d.get("kernel_source_hash") != kernel_source_hash():
+        return {"traffic": None, "stale_profile": src}
+    pmc = d.get("pmc_mean_per_dispatch", {})
+    valu = None
+    if pmc.get("SQ_BUSY_CYCLES") and pmc.get("SQ_ACTIVE_INST_VALU") is not None:
+        valu = pmc["SQ_ACTIVE_INST_VALU"] / (4.0 * pmc["SQ_BUSY_CYCLES"])
+    return {"traffic": d.get("traffic_bytes_per_launch"), "valu_busy_frac": valu, "source": src}
 
 
 def main() -> None:
@@ -114,6 +243,7 @@ def main() -> None:
     ap.add_argument("--round-frac", type=float, default=0.0, help="fraction of nodes with integer-valued metrics (tie stress)")
     ap.add_argument("--gather", default="best", choices=["none", "best", "table"],
                     help="N>1 only, measured OUTSIDE the timed region: all-gather of per-pod decisions and (table) of one score slab")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "copy"], help="single-process multi-device exchange (spx_multi)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -121,180 +251,238 @@ def main() -> None:
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env > 1 and world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.gpus > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible")
+    mode = "ranks" if world_env > 1 else ("multi" if args.gpus > 1 else "single")
+    world = args.gpus
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if mode == "ranks":
         import torch.distributed as dist  # RCCL over xGMI
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import scheduler_plugins_amd as spx
     from scheduler_plugins_amd import synth
-    from scheduler_plugins_amd import objects as O
-    from scheduler_plugins_amd.engine import ALLOCATABLE, LVRB, NRT, TLP, Engine, mask_of
+    from scheduler_plugins_amd.engine import Engine, mask_of
+    from scheduler_plugins_amd.multi import PEER_COPY, RCCL, MultiEngine
 
     w = dict(WORKLOADS[args.workload])
     if args.plugins:
         w["plugins"] = tuple(args.plugins.split(","))
         w["out"] = len(w["plugins"])
-    pid = {"alloc": ALLOCATABLE, "tlp": TLP, "lvrb": LVRB, "nrt": NRT, "net": 4, "cap": 5, "lroc": 7, "peaks": 8}
-    plugins = [pid[p] for p in w["plugins"]]
+    if args.round_frac:
+        w["round_frac"] = args.round_frac
+    plugins = [PID[p] for p in w["plugins"]]
     mask = mask_of(*plugins)
-    n_nodes, n_pods = w["n_nodes"], w["n_pods"]
-
+    n_nodes = w["n_nodes"]
+    strong = w.get("scaling") == "strong"
+    n_pods_total = w["n_pods"] if strong else w["n_pods"] * world  # pods evaluated per step by the whole job
     hdr = spx.header()
-    # every rank: same node snapshot, its own pod batch (seeded by rank)
-    e = Engine(local_rank)
-    if "cap" in w["plugins"]:
-        snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED + 1000 * rank)
-        snap["nrt_params"] = O.nrt_params(hdr, O.Resources(), w["strategy"])
-        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
-        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], snap["nrt_params"])
-        e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
-        e.load_quota_objects(snap["pods"], snap["rc"], snap["quota"])
-    elif "nrt" in w["plugins"]:
-        snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED)
-        if rank:
-            snap["pods"] = synth.synth_pods(hdr, n_pods, seed=synth.SEED + 1000 * rank, device_res=synth.RES_DEVICE,
-                                            hugepage_res=synth.RES_HUGEPAGES_2MI)
-        snap["nrt_params"] = O.nrt_params(hdr, O.Resources(), w["strategy"])
-        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], snap["nrt_params"])
-    elif "net" in w["plugins"]:
-        snap = synth.network_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED + 1000 * rank)
-        e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+
+    # ------------------------------------------------------------------ tables into HBM
+    if mode == "multi":
+        snap = build_snapshot(hdr, w, n_pods_total, synth.SEED)
+        target = MultiEngine(list(range(world)), RCCL if args.transport == "rccl" else PEER_COPY)
+        load_tables(target, w, snap)
+        e0 = target.engines[0]
+        local_pods = max(e.n_pods for e in target.engines)
     else:
-        snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED, round_frac=args.round_frac, with_node_pods="lroc" in w["plugins"])
-        if rank:
-            snap["pods"] = synth.synth_pods(hdr, n_pods, seed=synth.SEED + 1000 * rank)
-        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
-        if "peaks" in w["plugins"]:
-            snap["power_models"] = synth.synth_power_models(hdr, n_nodes, synth.SEED)
-            e.load_peaks_objects(snap["nodes"], snap["metrics"], snap["power_models"], snap["pods"])
-        if "lroc" in w["plugins"]:
-            e.set_lroc()
-            e.load_lroc_objects(snap["nodes"], snap["node_pods"], snap["pods"])
+        target = e0 = Engine(local_rank)
+        if strong and world > 1:  # every rank builds the same batch and keeps its shard
+            snap = build_snapshot(hdr, w, n_pods_total, synth.SEED)
+            per = -(-n_pods_total // world)
+            rows = (min(n_pods_total, rank * per), min(n_pods_total, (rank + 1) * per))
+            load_tables(target, w, snap, rows)
+        else:  # same node snapshot, an own pod batch per rank
+            snap = build_snapshot(hdr, w, w["n_pods"] if not strong else n_pods_total, synth.SEED + 1000 * rank)
+            load_tables(target, w, snap)
+        local_pods = target.n_pods
 
     def barrier():
         if dist is not None:
             dist.barrier()
+        if mode == "multi":
+            target.sync()
         torch.cuda.synchronize()
 
-    # the engine launches on torch's current stream so that torch.cuda.Event brackets exactly its kernels
-    tstream = torch.cuda.Stream(device=local_rank)
-    torch.cuda.set_stream(tstream)
-    e.set_stream(tstream.cuda_stream)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    # bring the device out of its idle clocks with unrelated work (not steps of the workload): a fresh box runs its first
+    # bring the device(s) out of idle clocks with unrelated work (not steps of the workload): a fresh box runs its first
     # ~50 ms of kernels at low clocks, which would otherwise dominate short --steps runs
-    spin = torch.empty(64 << 20, dtype=torch.float32, device=f"cuda:{local_rank}")
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.15:
-        for _ in range(8):
-            spin.mul_(1.0001)
-        torch.cuda.synchronize()
-    del spin
-    for _ in range(args.warmup):
-        e.eval(mask)
-    e.sync()
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record(tstream)
-    for _ in range(args.steps):
-        e.eval(mask)
-    ev1.record(tstream)
-    e.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # average launch duration of the sweep measured with HIP events over the timed region itself (back-to-back
-    # launches, sustained clocks); a plugin set evaluated by more than one kernel counts all of them as one launch
-    kern_ms = ev0.elapsed_time(ev1) / args.steps
+    for d in (range(world) if mode == "multi" else [local_rank]):
+        spin = torch.empty(64 << 20, dtype=torch.float32, device=f"cuda:{d}")
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.15:
+            for _ in range(8):
+                spin.mul_(1.0001)
+            torch.cuda.synchronize(d)
+        del spin
 
+    if mode == "multi":
+        for _ in range(args.warmup):
+            target.eval(mask)
+        barrier()
+        t0 = time.perf_counter()
+        target.mark(0)
+        for _ in range(args.steps):
+            target.eval(mask)
+        target.mark(1)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kern_ms = target.marked_ms()[0] / args.steps  # slowest rank's HIP-event time over the timed region, per step
+    else:
+        # the engine launches on torch's current stream so that torch.cuda.Event brackets exactly its kernels
+        tstream = torch.cuda.Stream(device=local_rank)
+        torch.cuda.set_stream(tstream)
+        target.set_stream(tstream.cuda_stream)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(args.warmup):
+            target.eval(mask)
+        target.sync()
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record(tstream)
+        for _ in range(args.steps):
+            target.eval(mask)
+        ev1.record(tstream)
+        target.sync()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        # average launch duration of the sweep measured with HIP events over the timed region itself (back-to-back
+        # launches, sustained clocks); a plugin set evaluated by more than one kernel counts all of them as one launch
+        kern_ms = ev0.elapsed_time(ev1) / args.steps
+
+    # ------------------------------------------------------------------ outside the timed region
     # SURVEY §8d(ii) "full-cycle ms": snapshot delta (host flatten + H2D of the SoA columns) + sweep + device-side
-    # per-row argmax + D2H of the per-pod decisions — measured once, outside the timed region, wall clock
+    # per-row argmax + D2H of the per-pod decisions — wall clock, once
     full_cycle = None
-    if args.workload in ("config2", "config2_lvrb") and not args.plugins:
+    score_mask = mask & ~(1 << 6)
+    if mode == "single" and not args.plugins and args.workload in ("config2", "config2_lvrb", "config5_share", "config4", "config3"):
         try:
             barrier()
             c0 = time.perf_counter()
-            e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+            load_tables(target, w, snap)
             c1 = time.perf_counter()
-            e.eval(mask)
-            e.eval_best(mask)
-            e.sync()
+            target.eval(mask)
+            target.eval_best(score_mask)
+            target.sync()
             c2 = time.perf_counter()
-            e.best()
+            target.best()
             c3 = time.perf_counter()
             full_cycle = {"ms": (c3 - c0) * 1e3, "flatten_upload_ms": (c1 - c0) * 1e3, "eval_argmax_ms": (c2 - c1) * 1e3,
                           "fetch_decisions_ms": (c3 - c2) * 1e3,
-                          "what": "objects->SoA flatten + H2D, sweep, per-row weighted argmax, D2H of 32 B/pod decisions"}
-            # decisions without tables (spx_decide: the argmax folded into the sweep), HIP-event time of the launch
+                          "what": "objects->SoA flatten + H2D, sweep, per-row weighted argmax, D2H of 20 B/pod decisions"}
+            # decisions without tables (spx_decide: the argmax folded into the sweep where the profile allows)
             try:
                 for _ in range(3):
-                    e.decide(mask)
-                e.sync()
+                    target.decide(score_mask)
+                target.sync()
                 d0 = time.perf_counter()
                 for _ in range(10):
-                    e.decide(mask)
-                e.sync()
+                    target.decide(score_mask)
+                target.sync()
                 full_cycle["decide_ms"] = (time.perf_counter() - d0) * 1e3 / 10
-                full_cycle["decide_what"] = "sweep + per-row argmax in one pass, no score table written; same decisions as eval_argmax"
+                full_cycle["decide_what"] = "sweep + per-row argmax, no score table written where the fused form applies; same decisions as eval_argmax"
             except Exception as ex:
                 full_cycle["decide_error"] = repr(ex)[:200]
-            # the same pods scheduled strictly one after the other, each seeing the commits before it (upstream's
-            # semantics; inherently sequential, one workgroup): spx_commit_sequential
-            c4 = time.perf_counter()
-            seq_node, _, _, _ = e.commit_sequential(mask, want_ties=False)
-            c5 = time.perf_counter()
-            full_cycle["sequential_commit_ms"] = (c5 - c4) * 1e3
-            full_cycle["sequential_pods_per_s"] = n_pods / (c5 - c4)
-            full_cycle["sequential_distinct_nodes"] = int(len(set(seq_node.tolist())))
+            if args.workload in ("config2", "config2_lvrb"):
+                # the same pods scheduled strictly one after the other, each seeing the commits before it (upstream's
+                # semantics; inherently sequential, one workgroup): spx_commit_sequential
+                c4 = time.perf_counter()
+                seq_node, _, _, _ = target.commit_sequential(mask, want_ties=False)
+                c5 = time.perf_counter()
+                full_cycle["sequential_commit_ms"] = (c5 - c4) * 1e3
+                full_cycle["sequential_pods_per_s"] = local_pods / (c5 - c4)
+                full_cycle["sequential_distinct_nodes"] = int(len(set(seq_node.tolist())))
         except Exception as ex:
             full_cycle = {"error": repr(ex)[:200]}
 
     # the exchange step of the sharded path, reported separately: per-pod decisions, optionally one table
     gather_info = None
-    if dist is not None and args.gather != "none":
+    if world > 1 and args.gather != "none":
         try:
-            from scheduler_plugins_amd import shard
-            score_mask = mask & ~(1 << 6)
-            e.eval_best(score_mask)
-            node, score, ties, feas = e.best()
-            barrier()
-            t1 = time.perf_counter()
-            shard.gather_best(dist, torch.device("cuda", local_rank), node, score, ties, feas, n_pods * world)
-            barrier()
-            gather_info = {"best_ms": (time.perf_counter() - t1) * 1e3, "bytes_per_rank": int(n_pods) * 32}
-            if args.gather == "table":
-                p0 = plugins[-1] if plugins[-1] <= 4 else plugins[0]
-                ptr, stride, rows = e.score_table(p0)
-                slab = torch.empty((rows, stride), dtype=torch.uint8, device=f"cuda:{local_rank}")
-                e.bind_score_table(p0, slab.data_ptr(), stride, rows)
-                e.eval(1 << p0)
-                e.sync()
+            if mode == "multi":
+                target.eval(mask)
+                target.eval_best(score_mask)
                 barrier()
                 t1 = time.perf_counter()
-                full = shard.gather_table(dist, slab)
+                target.gather_best()
+                best_wall = (time.perf_counter() - t1) * 1e3
+                gather_info = {"best_ms": best_wall, "best_device_ms": target.last_ms()[1], "bytes_per_rank": int(local_pods) * 20,
+                               "transport": args.transport, "host": "one process, spx_multi_gather_best (all-gather + one D2H)"}
                 barrier()
-                gather_info.update({"table_ms": (time.perf_counter() - t1) * 1e3, "table_bytes": int(full.numel())})
-                del full
+                t1 = time.perf_counter()
+                target.eval(mask)
+                target.eval_best(score_mask)
+                target.gather_best()
+                gather_info["step_plus_gather_ms"] = (time.perf_counter() - t1) * 1e3
+                gather_info["step_plus_gather_what"] = "sweep + per-row argmax + all-gather of decisions + D2H, wall clock (kernel-only step: ms_per_step)"
+                if args.gather == "table":
+                    p0 = plugins[-1] if plugins[-1] <= 4 else plugins[0]
+                    target.bind_global_table(p0)
+                    target.eval(1 << p0)
+                    barrier()
+                    t1 = time.perf_counter()
+                    target.allgather_table(p0)
+                    barrier()
+                    gather_info.update({"table_ms": (time.perf_counter() - t1) * 1e3, "table_device_ms": target.last_ms()[1],
+                                        "table_bytes": int(-(-n_pods_total // world) * world * e0.score_table(p0)[1])})
+            else:
+                from scheduler_plugins_amd import shard
+                target.eval_best(score_mask)
+                node, score, ties, feas = target.best()
+                barrier()
+                t1 = time.perf_counter()
+                if strong:  # equal shards of one batch
+                    shard.gather_best(dist, torch.device("cuda", local_rank), node, score, ties, feas, n_pods_total)
+                else:
+                    shard.gather_best(dist, torch.device("cuda", local_rank), node, score, ties, feas, local_pods * world)
+                barrier()
+                gather_info = {"best_ms": (time.perf_counter() - t1) * 1e3, "bytes_per_rank": int(local_pods) * 20,
+                               "host": "one process per GPU, torch.distributed all_gather_into_tensor"}
+                if args.gather == "table":
+                    p0 = plugins[-1] if plugins[-1] <= 4 else plugins[0]
+                    ptr, stride, rows_t = target.score_table(p0)
+                    slab = torch.empty((rows_t, stride), dtype=torch.uint8, device=f"cuda:{local_rank}")
+                    target.bind_score_table(p0, slab.data_ptr(), stride, rows_t)
+                    target.eval(1 << p0)
+                    target.sync()
+                    barrier()
+                    t1 = time.perf_counter()
+                    full = shard.gather_table(dist, slab)
+                    barrier()
+                    gather_info.update({"table_ms": (time.perf_counter() - t1) * 1e3, "table_bytes": int(full.numel())})
+                    del full
         except Exception as ex:  # never lose the bench line to the optional exchange measurement
-            gather_info = {"error": repr(ex)[:200]}
+            gather_info = {"error": repr(ex)[:300]}
 
-    evals_per_step = n_nodes * n_pods * world
+    evals_per_step = n_nodes * n_pods_total
     value = evals_per_step * args.steps / elapsed
-    algo_bytes = n_nodes * w["node_row"] + n_pods * w["pod_row"] + n_nodes * n_pods * w["out"]
+    # roofline of the slowest rank's launch: the algorithmic bytes of ITS rows over its kernel time
+    algo_bytes = n_nodes * w["node_row"] + local_pods * w["pod_row"] + n_nodes * local_pods * w["out"]
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
 
-    traffic, traffic_src = measured_traffic(args.workload) if not args.plugins else (None, None)
+    counters = profile_counters(args.workload) if not args.plugins else None
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": counters.get("traffic") if counters else None,
+                "kernel": {"nrt": "spx::k_nrt_fast (Filter launch + Score launch, both counted)", "net": "spx::k_net_cls",
+                           "lroc": "spx::k_lroc_fast (float32 quotient on exact float64 numerator/denominator, float64 fallback; VALU-bound)",
+                           "peaks": "spx::k_peaks<min/max pass> + spx::k_peaks<write pass> (VALU-bound: division + exp per cell and pass)",
+                           "cap": "full profile: k_quota, k_nrt_fast x2, k_net_cls, k_tlp_fast2, k_lvrb_fast, k_alloc_masked"}.get(
+                    w["plugins"][0], "spx::k_tlp_fast2 (Allocatable+TLP)" + (" + spx::k_lvrb_fast" if "lvrb" in w["plugins"] else "")),
+                "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes, "frac_of_measured_copy_ceiling_6.29TBs": achieved / 6290.0,
+                "kernel_source_hash": kernel_source_hash()}
+    if counters:
+        roofline.update({k: v for k, v in counters.items() if k != "traffic"})
+        roofline["valu_busy_what"] = "SQ_ACTIVE_INST_VALU / (4 * SQ_BUSY_CYCLES) of the dominant kernel, committed PMC pass: why an HBM fraction is low when it is (VALU-bound sweep)"
     out = {
         "metric": "pod_x_node_filter_score_evals_per_sec",
         "value": value,
@@ -304,32 +492,28 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         # the arithmetic the sweep computes in (results are bit-exact against the reference's float64 / int64 either way):
         # TLP/LVRB float32 with a per-cell exactness proof and a float64 fallback, NRT float64 (exact integers), NetworkOverhead int32
         "dtype": {"nrt": "f64", "net": "i32", "cap": "f32+f64+i32", "lroc": "f64", "peaks": "f64"}.get(w["plugins"][0], "f32+f64"),
         "data": "synthetic",
-        "config": {"workload": w["desc"], "n_nodes": n_nodes, "n_pods_per_gpu": n_pods, "plugins": list(w["plugins"]),
-                   "sharding": "pod rows per rank, node tables replicated, no data-path collective",
+        "config": {"workload": w["desc"], "n_nodes": n_nodes, "n_pods_per_step": n_pods_total, "n_pods_slowest_rank": int(local_pods),
+                   "plugins": list(w["plugins"]),
+                   "host": {"single": "one process, one device", "multi": f"one process driving {world} devices through spx_multi (C ABI)",
+                            "ranks": f"{world} processes, one per device (torch.distributed.run)"}[mode],
+                   "sharding": "pod rows per device, node tables replicated, no data-path collective",
                    "result_tables": "uint8 [pods][nodes] per plugin, resident in HBM"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": {"nrt": "spx::k_nrt_fast (LeastAllocated: Filter launch + Score launch, both counted)", "net": "spx::k_net_cls", "lroc": "spx::k_lroc_fast (float32 quotient on exact float64 numerator/denominator, float64 fallback; VALU-bound)",
-                                "peaks": "spx::k_peaks<min/max pass> + spx::k_peaks<write pass> (VALU-bound: division + exp per cell and pass)",
-                                "cap": "full profile: k_quota, k_nrt_fast x2, k_net_cls, k_tlp_fast2, k_lvrb_fast, k_alloc_masked"}.get(
-                         w["plugins"][0], "spx::k_tlp_fast2 (Allocatable+TLP)" + (" + spx::k_lvrb_fast" if "lvrb" in w["plugins"] else "")),
-                     "kernel_ms": kern_ms,
-                     "algorithmic_bytes": algo_bytes, "frac_of_measured_copy_ceiling_6.29TBs": achieved / 6290.0},
-        "kernel_evals_per_sec": n_nodes * n_pods / (kern_ms * 1e-3),
+        "roofline": roofline,
+        "kernel_evals_per_sec": n_nodes * local_pods / (kern_ms * 1e-3),
     }
     if full_cycle is not None:
         out["full_cycle"] = full_cycle
     if gather_info is not None:
         out["gather"] = gather_info
-    if rank == 0 and world == 1 and args.cpu_budget > 0:
-        out["cpu_baseline"] = cpu_baseline(spx, snap, e, plugins, args.cpu_budget)
-    e.close()
+    if rank == 0 and args.cpu_budget > 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(spx, snap, e0, plugins, args.cpu_budget)
+    target.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

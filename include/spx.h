@@ -669,6 +669,58 @@ int spx_get_option(const spx_engine* e, int option, int64_t* value);
  * Tests use it to make sure both formulations are exercised. */
 int spx_kernel_path(const spx_engine* e, int plugin);
 
+/* make the engine write a Filter plugin's status table (NRT, NETOVERHEAD) into caller-owned device memory; row_stride must be
+ * the engine's (spx_score_table reports it), n_rows >= n_pods; dptr NULL unbinds */
+int spx_bind_status_table(spx_engine* e, int plugin, void* dptr, int64_t row_stride, int64_t n_rows);
+
+/* ------------------------------------------------------------------ several devices, one host process
+ *
+ * north_star: "the pods x nodes matrix shards by pod rows across the 8 GPUs of one node with a single RCCL all-gather over
+ * xGMI to reassemble the global score/feasibility table", driven by ONE Go scheduler process.  spx_multi owns one engine per
+ * device and one host thread per device (launches of a step are issued concurrently).  Pod rows shard in equal contiguous
+ * ranges (spx_multi_shard); node tables are replicated: the caller uploads the node tables to every rank's engine and each
+ * rank's slice of the pod columns to that rank's engine (spx_multi_engine + the spx_upload_* calls — slicing SoA pod columns is
+ * pointer arithmetic).  The evaluation itself has no collective.  Afterwards:
+ *   spx_multi_gather_best        all-gathers the per-pod decisions (20 B per pod) so that every device holds the global vector and
+ *                                hands it to the host in batch order;
+ *   spx_multi_bind_global_table  gives every device a [n_pods_total][row_stride] uint8 table (which: 0 score, 1 Filter status)
+ *                                into whose own slice the rank's engine writes directly (no staging copy), and
+ *   spx_multi_allgather_table    reassembles it on every device in place.
+ * transport: SPX_MULTI_TRANSPORT_RCCL = ncclAllGather on each engine's stream (librccl.so.1 is dlopen'ed here, so a
+ * single-GPU scheduler never maps it; needs distinct devices); SPX_MULTI_TRANSPORT_PEER_COPY = the same bytes with
+ * hipMemcpyPeerAsync (also works with several ranks on one device: how the sharding logic is tested on a one-GPU box).
+ * Calls on one spx_multi must come from one thread at a time. */
+#define SPX_MULTI_TRANSPORT_RCCL 0
+#define SPX_MULTI_TRANSPORT_PEER_COPY 1
+typedef struct spx_multi spx_multi;
+int spx_multi_create(const int* device_ids, int n_devices, int transport, spx_multi** out);
+int spx_multi_destroy(spx_multi* m);
+/* of `m`, or of the failed spx_multi_create when m == NULL (thread-local) */
+const char* spx_multi_last_error(const spx_multi* m);
+int spx_multi_size(const spx_multi* m);
+int spx_multi_engine(spx_multi* m, int rank, spx_engine** out);
+/* rank's rows of a batch of n_pods_total pending pods: [rank * per, (rank + 1) * per) clipped to the batch, per = ceil(n / size) */
+int spx_multi_shard(const spx_multi* m, int64_t n_pods_total, int rank, int64_t* row_begin, int64_t* row_end);
+/* every rank: spx_eval / spx_eval_best / spx_decide over all of its local rows, issued concurrently, asynchronous */
+int spx_multi_eval(spx_multi* m, uint32_t plugin_mask);
+int spx_multi_eval_best(spx_multi* m, uint32_t plugin_mask);
+int spx_multi_decide(spx_multi* m, uint32_t plugin_mask);
+int spx_multi_sync(spx_multi* m);
+/* outputs are indexed by batch row, n_pods_total entries each; n_ties / n_feasible may be NULL.  Synchronous. */
+int spx_multi_gather_best(spx_multi* m, int64_t n_pods_total, int32_t* node_idx, int64_t* weighted_score, int32_t* n_ties, int32_t* n_feasible);
+int spx_multi_bind_global_table(spx_multi* m, int plugin, int which, int64_t n_pods_total);
+int spx_multi_allgather_table(spx_multi* m, int plugin, int which);
+/* rank's copy of the global table (device pointer on that rank's device) */
+int spx_multi_global_table(spx_multi* m, int plugin, int which, int rank, void** dptr, int64_t* row_stride, int64_t* n_rows);
+/* batch rows [row_begin,row_end) of rank's copy of a gathered global table (any rank holds all rows) */
+int spx_multi_fetch_global_rows(spx_multi* m, int plugin, int which, int rank, int64_t row_begin, int64_t row_end, uint8_t* out, int64_t out_stride);
+/* region timing with HIP events on every rank's stream: spx_multi_mark(m, 0) ... work ... spx_multi_mark(m, 1), then the
+ * elapsed time between the marks per rank (ms_per_rank: size entries, may be NULL) and its maximum */
+int spx_multi_mark(spx_multi* m, int which);
+int spx_multi_marked_ms(spx_multi* m, float* ms_max, float* ms_per_rank);
+/* HIP-event durations, max over ranks: of the last spx_multi_eval / _decide, and of the last gather (either may be NULL) */
+int spx_multi_last_ms(spx_multi* m, float* eval_ms, float* gather_ms);
+
 /* ------------------------------------------------------------------ host flatteners (object -> SoA) */
 
 /* output buffers are caller-allocated with the sizes noted */

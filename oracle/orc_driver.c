@@ -10,7 +10,10 @@
  * goroutines (Parallelizer, copied at targetloadpacking_test.go:386-405) and joins per pod; the row
  * split used here has no per-pod join and is therefore the more favourable layout for the CPU.
  */
+#define _POSIX_C_SOURCE 200809L
+#include <math.h>
 #include <pthread.h>
+#include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -186,5 +189,83 @@ int orc_filter_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_
     for (int t = 0; t < threads; ++t) pthread_join(th[t], 0);
   free(jobs);
   free(th);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * The reference's own parallel structure: ONE pod at a time; that pod's node loop is cut into chunks which `workers`
+ * goroutines claim from a shared counter (workqueue.ParallelizeUntil with chunkSizeFor, copied into the benchmark at
+ * pkg/trimaran/targetloadpacking/targetloadpacking_test.go:386-405: parallelism = 16, chunk = min(sqrt(n), n/16 + 1));
+ * the caller joins, then runs NormalizeScore serially (:369-381).  Restated with a persistent pthread pool and two
+ * barriers per pod standing in for the WaitGroup.  Used by bench.py's cpu_baseline ("reference structure") leg.
+ */
+typedef struct cyc {
+  const orc_snapshot* s;
+  int plugin;
+  int64_t n, chunk, pod;
+  int64_t* list;
+  atomic_llong next;
+  int stop;
+  pthread_barrier_t start, done;
+} cyc;
+
+static void cyc_work(cyc* c) {
+  for (;;) {
+    const int64_t k = (int64_t)atomic_fetch_add(&c->next, 1);
+    const int64_t b = k * c->chunk;
+    if (b >= c->n) return;
+    const int64_t e = b + c->chunk < c->n ? b + c->chunk : c->n;
+    for (int64_t node = b; node < e; ++node) c->list[node] = score_one(c->s, c->plugin, c->pod, node);
+  }
+}
+
+static void* cyc_thread(void* arg) {
+  cyc* c = (cyc*)arg;
+  for (;;) {
+    pthread_barrier_wait(&c->start);
+    if (c->stop) return 0;
+    cyc_work(c);
+    pthread_barrier_wait(&c->done);
+  }
+}
+
+int orc_cycle_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t row_end, int workers, int64_t* out_norm) {
+  if (!s || row_end < row_begin || plugin == SPX_PLUGIN_NETOVERHEAD) return -1;
+  if (workers < 1) workers = 1;
+  cyc c;
+  memset(&c, 0, sizeof c);
+  c.s = s;
+  c.plugin = plugin;
+  c.n = s->nodes->n_nodes;
+  int64_t sq = (int64_t)sqrt((double)c.n), r = c.n / workers + 1; /* chunkSizeFor, parallelism = workers */
+  c.chunk = sq > r ? r : (sq < 1 ? 1 : sq);
+  c.list = (int64_t*)malloc(sizeof(int64_t) * (size_t)(c.n > 0 ? c.n : 1));
+  if (!c.list) return -1;
+  pthread_t* th = 0;
+  if (workers > 1) { /* the calling thread is one of the workers, as in ParallelizeUntil's goroutines + wg.Wait */
+    th = (pthread_t*)calloc((size_t)(workers - 1), sizeof(pthread_t));
+    pthread_barrier_init(&c.start, 0, (unsigned)workers);
+    pthread_barrier_init(&c.done, 0, (unsigned)workers);
+    for (int t = 0; t < workers - 1; ++t) pthread_create(&th[t], 0, cyc_thread, &c);
+  }
+  for (int64_t pod = row_begin; pod < row_end; ++pod) {
+    c.pod = pod;
+    atomic_store(&c.next, 0);
+    if (workers > 1) pthread_barrier_wait(&c.start);
+    cyc_work(&c);
+    if (workers > 1) pthread_barrier_wait(&c.done);
+    if (plugin == SPX_PLUGIN_ALLOCATABLE) orc_allocatable_normalize(c.list, c.n);
+    if (plugin == SPX_PLUGIN_PEAKS) orc_peaks_normalize(c.list, c.n);
+    if (out_norm) memcpy(out_norm + (size_t)(pod - row_begin) * (size_t)c.n, c.list, sizeof(int64_t) * (size_t)c.n);
+  }
+  if (workers > 1) {
+    c.stop = 1;
+    pthread_barrier_wait(&c.start);
+    for (int t = 0; t < workers - 1; ++t) pthread_join(th[t], 0);
+    pthread_barrier_destroy(&c.start);
+    pthread_barrier_destroy(&c.done);
+    free(th);
+  }
+  free(c.list);
   return 0;
 }

@@ -157,6 +157,9 @@ int orc_score_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t
 /* Filter() of a filter plugin for pod rows [row_begin,row_end) x all nodes: out_status [rows][n_nodes],
  * 0 = pass, else the plugin's reason code (255 = fwk.Error) */
 int orc_filter_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t row_end, int threads, uint8_t* out_status);
+/* one pod at a time, that pod's node loop chunked over `workers` threads that join per pod, NormalizeScore serial: the
+ * reference benchmark's structure (targetloadpacking_test.go:369-405, parallelism 16).  out_norm ([rows][n_nodes]) may be NULL. */
+int orc_cycle_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t row_end, int workers, int64_t* out_norm);
 
 #ifdef __cplusplus
 }

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lroc_fast(LrocArgs a,
   const int64_t np = a.n_pods_total;
   constexpr float kHalf = 0.5f - kBand;
 
+  unsigned redone = 0;
   for (int64_t pod = pod0; pod < pod1; ++pod) {
     // per pod (host-prepared float64, scalar loads): podLimit and podLimit - podRequest for cpu, memory; NaN marks a
     // pod without requests or limits (MinNodeScore, lowriskovercommitment.go:124-128)
@@ -271,13 +272,17 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lroc_fast(LrocArgs a,
             w[j] = (w[j] & ~(0xffu << (8 * q))) | (b << (8 * q));
           }
         }
-        // spx_fetch_stats: the whole lane (NPL cells) is redone, not only the cells inside the band
-        if (a.stats) atomicAdd(a.stats + SPX_PLUGIN_LROC, static_cast<unsigned long long>(min<int64_t>(NPL, max<int64_t>(a.n_nodes - node0, 0))));
+        ++redone;  // spx_fetch_stats: the whole lane (NPL cells) is redone, not only the cells inside the band
       }
     }
     uint32_t* dst = reinterpret_cast<uint32_t*>(a.out_score + pod * a.row_stride + node0);
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     *reinterpret_cast<u32x2*>(dst) = u32x2{w[0], w[1]};
+  }
+  // one atomic per lane that met a band, each lane on its own counter line (lanes past the row have left: no wave reduction)
+  if (redone && a.stats) {
+    const int64_t cells = min<int64_t>(NPL, max<int64_t>(a.n_nodes - node0, 0));
+    atomicAdd(a.stats + (SPX_PLUGIN_LROC * kStatSlots + lane) * kStatStride, static_cast<unsigned long long>(redone) * static_cast<unsigned long long>(cells));
   }
 }
 

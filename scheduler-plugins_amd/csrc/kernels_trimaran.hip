@@ -388,6 +388,17 @@ struct DecideArgs {
   int64_t rows;
 };
 
+// Exactness bookkeeping (spx_fetch_stats): each lane counts the cells it re-evaluated; the wave adds them up once, at its
+// end, into one of kStatSlots counters per plugin.  One atomic per (rare) cell on a single address cost the config #2 sweep
+// 0.6 ms — the L2 serialises same-address atomics — hence per wave and spread over slots.  Every lane must be live here.
+__device__ __forceinline__ void flush_stats(unsigned long long* stats, int plugin, unsigned count, int64_t unit) {
+  if (!stats || __ballot(count != 0) == 0) return;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) count += static_cast<unsigned>(__shfl_xor(static_cast<int>(count), m));
+  if ((threadIdx.x & (kWave - 1)) == 0)
+    atomicAdd(stats + (plugin * kStatSlots + static_cast<int>(unit & (kStatSlots - 1))) * kStatStride, static_cast<unsigned long long>(count));
+}
+
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
   const uint32_t lo = static_cast<uint32_t>(__shfl_xor(static_cast<int>(static_cast<uint32_t>(v)), m));
   const uint32_t hi = static_cast<uint32_t>(__shfl_xor(static_cast<int>(static_cast<uint32_t>(v >> 32)), m));
@@ -442,6 +453,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
   // registers that were written under a full exec mask (stores are guarded by `active` instead)
   const float tf = static_cast<float>(t);
   constexpr float kHalf = 0.5f - kTol32;
+  unsigned reevaluated = 0;  // cells this lane sent through the exact path (spx_fetch_stats), flushed once per wave
 
   for (int r = 0; r < n_rows; ++r) {
     const int64_t row = (pod0 + r) * a.row_stride + node0;
@@ -494,7 +506,6 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
       float pf = pod_f;
       asm volatile("" : "+v"(pf));  // opaque copy: keeps the compiler from carrying the 16 flags across the branch instead
       const F32x2 pod2s{pf, pf};
-      unsigned reevaluated = 0;
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
         float rr;
@@ -516,7 +527,6 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
           w[i >> 2] = (w[i >> 2] & ~(0xffu << sh)) | (b << sh);
         }
       }
-      if (reevaluated && a.stats) atomicAdd(a.stats + SPX_PLUGIN_TLP, static_cast<unsigned long long>(reevaluated));  // spx_fetch_stats
     }
     if constexpr (!D) {
       if (active) store_bytes<NPL>(a.out_tlp + row, w);
@@ -553,6 +563,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
       }
     }
   }
+  flush_stats(a.stats, SPX_PLUGIN_TLP, reevaluated, unit);
 }
 
 // merges the per-tile triples of the decisions-only sweep into the layout spx_fetch_best reads
@@ -694,6 +705,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
     }
   }
   constexpr float kHalf = 0.5f - kTolLv;  // (no early exit: see k_tlp_fast2)
+  unsigned reevaluated = 0;  // as in k_tlp_fast2
 
   for (int r = 0; r < n_rows; ++r) {
     const int64_t row = (pod0 + r) * a.row_stride + node0;
@@ -735,7 +747,6 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
       float rc = req_cpu, rm = req_mem;
       asm volatile("" : "+v"(rc), "+v"(rm));  // opaque copies: recompute the flags here instead of carrying them across the branch
       const F32x2 req2s{rc, rm};
-      unsigned reevaluated = 0;
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
         float ry;
@@ -754,10 +765,10 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
           w[i >> 2] = (w[i >> 2] & ~(0xffu << sh)) | (b << sh);
         }
       }
-      if (reevaluated && a.stats) atomicAdd(a.stats + SPX_PLUGIN_LVRB, static_cast<unsigned long long>(reevaluated));  // spx_fetch_stats
     }
     if (active) store_bytes<NPL>(a.out_lvrb + row, w);
   }
+  flush_stats(a.stats, SPX_PLUGIN_LVRB, reevaluated, unit);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -197,6 +197,16 @@ int ensure_score_table(spx_engine* e, int plugin) {
   return SPX_OK;
 }
 
+int ensure_status_table(spx_engine* e, int plugin) {
+  DevBuf& b = e->status[plugin];
+  const size_t need = static_cast<size_t>(e->n_pods) * static_cast<size_t>(e->row_stride);
+  if (b.external) {
+    if (b.bytes < need) return fail(e, SPX_ERR_STATE, "bound status table is smaller than n_pods x row_stride");
+    return SPX_OK;
+  }
+  return ensure(e, b, need);
+}
+
 int prepare_alloc(spx_engine* e) {
   if (e->alloc_ready) return SPX_OK;
   if (!e->d_alloc.p) return fail(e, SPX_ERR_STATE, "Allocatable: spx_upload_alloc_nodes not called");
@@ -417,13 +427,12 @@ int spx_create(int device_id, spx_engine** out) {
     return fail(nullptr, SPX_ERR_HIP, msg);
   }
   e->stream = e->own_stream;
-  if ((st = hipMalloc(&e->d_stats.p, SPX_NUM_PLUGINS * sizeof(unsigned long long))) != hipSuccess ||
-      (st = hipMemset(e->d_stats.p, 0, SPX_NUM_PLUGINS * sizeof(unsigned long long))) != hipSuccess) {
+  if ((st = hipMalloc(&e->d_stats.p, spx::kStatBytes)) != hipSuccess || (st = hipMemset(e->d_stats.p, 0, spx::kStatBytes)) != hipSuccess) {
     std::string msg = std::string("engine init: ") + hipGetErrorString(st);
     delete e;
     return fail(nullptr, SPX_ERR_HIP, msg);
   }
-  e->d_stats.bytes = SPX_NUM_PLUGINS * sizeof(unsigned long long);
+  e->d_stats.bytes = spx::kStatBytes;
   *out = e;
   return SPX_OK;
 }
@@ -451,7 +460,7 @@ int spx_destroy(spx_engine* e) {
     if (b->p && !b->external) (void)hipFree(b->p);
   for (int i = 0; i < SPX_NUM_PLUGINS; ++i) {
     if (e->score[i].p && !e->score[i].external) (void)hipFree(e->score[i].p);
-    if (e->status[i].p) (void)hipFree(e->status[i].p);
+    if (e->status[i].p && !e->status[i].external) (void)hipFree(e->status[i].p);
   }
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -1087,8 +1096,8 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (K && e->score_stride[SPX_PLUGIN_PEAKS] != e->row_stride)
     return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
   if (K && ((rc = ensure(e, e->d_pk_min, static_cast<size_t>(e->n_pods) * 8)) || (rc = ensure(e, e->d_pk_max, static_cast<size_t>(e->n_pods) * 8)))) return rc;
-  if (N && (rc = ensure(e, e->status[SPX_PLUGIN_NRT], static_cast<size_t>(e->n_pods) * static_cast<size_t>(e->row_stride)))) return rc;
-  if (W && (rc = ensure(e, e->status[SPX_PLUGIN_NETOVERHEAD], static_cast<size_t>(e->n_pods) * static_cast<size_t>(e->row_stride)))) return rc;
+  if (N && (rc = ensure_status_table(e, SPX_PLUGIN_NRT))) return rc;
+  if (W && (rc = ensure_status_table(e, SPX_PLUGIN_NETOVERHEAD))) return rc;
 
   spx::TrimaranArgs a{};
   fill_trimaran(e, a);
@@ -1414,10 +1423,15 @@ int spx_fetch_status_rows(spx_engine* e, int plugin, int64_t row_begin, int64_t 
 int spx_fetch_stats(spx_engine* e, int64_t* reevaluated_cells, int reset) {
   if (!e || !reevaluated_cells) return SPX_ERR_ARG;
   SPX_HIP(e, hipSetDevice(e->device));
-  static_assert(sizeof(unsigned long long) == sizeof(int64_t), "counter width");
-  SPX_HIP(e, hipMemcpyAsync(reevaluated_cells, e->d_stats.p, SPX_NUM_PLUGINS * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
-  if (reset) SPX_HIP(e, hipMemsetAsync(e->d_stats.p, 0, SPX_NUM_PLUGINS * sizeof(int64_t), e->stream));
+  std::vector<unsigned long long> h(spx::kStatBytes / sizeof(unsigned long long));
+  SPX_HIP(e, hipMemcpyAsync(h.data(), e->d_stats.p, spx::kStatBytes, hipMemcpyDeviceToHost, e->stream));
+  if (reset) SPX_HIP(e, hipMemsetAsync(e->d_stats.p, 0, spx::kStatBytes, e->stream));
   SPX_HIP(e, hipStreamSynchronize(e->stream));
+  for (int p = 0; p < SPX_NUM_PLUGINS; ++p) {  // the kernels spread their counts over kStatSlots lines per plugin
+    unsigned long long sum = 0;
+    for (int k = 0; k < spx::kStatSlots; ++k) sum += h[static_cast<size_t>(p * spx::kStatSlots + k) * spx::kStatStride];
+    reevaluated_cells[p] = static_cast<int64_t>(sum);
+  }
   return SPX_OK;
 }
 
@@ -1450,6 +1464,44 @@ int spx_bind_score_table(spx_engine* e, int plugin, void* dptr, int64_t row_stri
   e->score_stride[plugin] = row_stride;
   return SPX_OK;
 }
+
+int spx_bind_status_table(spx_engine* e, int plugin, void* dptr, int64_t row_stride, int64_t n_rows) {
+  if (!e || (plugin != SPX_PLUGIN_NRT && plugin != SPX_PLUGIN_NETOVERHEAD)) return SPX_ERR_ARG;
+  DevBuf& b = e->status[plugin];
+  if (!dptr) {  // unbind
+    if (b.external) b = DevBuf{};
+    return SPX_OK;
+  }
+  if (e->row_stride <= 0) return fail(e, SPX_ERR_STATE, "shape unknown: upload the node table first");
+  if (row_stride != e->row_stride || (reinterpret_cast<uintptr_t>(dptr) % spx::kRowAlign) != 0)
+    return fail(e, SPX_ERR_ARG, "bound status table must be 16-byte aligned and use the engine row stride (spx_score_table reports it)");
+  if (b.p && !b.external) SPX_HIP(e, hipFree(b.p));
+  b.p = dptr;
+  b.bytes = static_cast<size_t>(row_stride) * static_cast<size_t>(n_rows);
+  b.external = true;
+  return SPX_OK;
+}
+
+}  // extern "C"
+
+namespace spx {
+EngineView engine_view(spx_engine* e) {
+  EngineView v{};
+  v.device = e->device;
+  v.stream = e->stream;
+  v.n_nodes = e->n_nodes;
+  v.n_pods = e->n_pods;
+  v.row_stride = e->row_stride;
+  v.best = e->d_best.p;
+  v.best_valid = e->best_valid;
+  v.ev0 = e->ev0;
+  v.ev1 = e->ev1;
+  v.timed = e->timed;
+  return v;
+}
+}  // namespace spx
+
+extern "C" {
 
 int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end) {
   if (!e) return SPX_ERR_ARG;

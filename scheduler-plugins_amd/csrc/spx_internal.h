@@ -16,6 +16,11 @@ constexpr int64_t kRowPad = 128;
 
 inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// spx_fetch_stats counters: kStatSlots per plugin, summed at fetch (same-address atomics serialise in the L2)
+constexpr int kStatSlots = 64;
+constexpr int kStatStride = 16;  // uint64 per slot: every slot on its own 128-byte line
+constexpr size_t kStatBytes = static_cast<size_t>(SPX_NUM_PLUGINS) * kStatSlots * kStatStride * sizeof(unsigned long long);
+
 // per-launch switches derived from the engine's options (spx_set_option); carried in every Args struct as `opts`
 enum : uint32_t {
   kOptTrimaranExact = 1u << 0,     // TLP / LVRB: reference float64 sequence only
@@ -26,6 +31,18 @@ enum : uint32_t {
   kOptPeaksWideA = 1u << 5,        // Peaks: 8 nodes per lane in the min/max pass
   kOptPeaksWideB = 1u << 6,        // Peaks: 8 nodes per lane in the write pass
 };
+
+// what the multi-device layer (spx_multi.hip) needs to see of an engine
+struct EngineView {
+  int device;
+  hipStream_t stream;
+  int64_t n_nodes, n_pods, row_stride;
+  void* best;        // decision block [score int64 P | node int32 P | ties int32 P | feasible int32 P], NULL before the first argmax
+  bool best_valid;
+  hipEvent_t ev0, ev1;  // recorded around the last spx_eval / spx_decide
+  bool timed;
+};
+EngineView engine_view(spx_engine* e);
 
 // ---------------------------------------------------------------- Allocatable
 struct AllocPrepArgs {
@@ -72,7 +89,7 @@ struct TrimaranArgs {
   double* lv_exact;  // scratch [n_nodes][8]: per-node exact LVRB state for the fast kernel's fallback
   float* lv_fast;    // scratch [ceil(row_stride/512)*512][8]: LVRB fast constants, tile-transposed (k_lvrb_prepare_fast)
   float* tlp_fast;   // scratch [ceil(row_stride/1024)*1024][4]: TLP fast constants, tile-transposed (k_tlp_prepare_fast)
-  unsigned long long* stats;  // [SPX_NUM_PLUGINS] cells the fast sweeps re-evaluated with the reference sequence (spx_fetch_stats); may be NULL
+  unsigned long long* stats;  // [SPX_NUM_PLUGINS][kStatSlots][kStatStride] cells the fast sweeps re-evaluated with the reference sequence (spx_fetch_stats); may be NULL
   // outputs: uint8 [n_pods][row_stride] each (NULL = plugin not evaluated)
   uint8_t* out_alloc;
   uint8_t* out_tlp;

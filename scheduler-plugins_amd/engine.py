@@ -29,18 +29,34 @@ def mask_of(*plugins: int) -> int:
     return m
 
 
+def _rows(cols: Dict[str, np.ndarray], n_total: int, rows) -> Dict[str, np.ndarray]:
+    """slice of per-pod SoA columns: every column holds a fixed number of entries per pod, pod-major"""
+    if rows is None:
+        return cols
+    b, e = rows
+    out = {}
+    for k, v in cols.items():
+        per = len(v) // max(n_total, 1)
+        out[k] = np.ascontiguousarray(v[b * per:e * per]) if e > b else np.zeros(max(per, 1), v.dtype)
+    return out
+
+
 class Engine:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _handle=None):
         from . import SpxError, header, lib
 
         self._lib = lib()
         self._hdr = header()
         self._err = SpxError
-        self._h = C.POINTER(self._hdr.opaque["spx_engine"])()
-        rc = self._lib.spx_create(device, C.byref(self._h))
-        if rc != 0:
-            msg = self._lib.spx_last_error(None)
-            raise SpxError(rc, msg.decode() if msg else "")
+        self._owned = _handle is None
+        if _handle is not None:  # an engine owned by a spx_multi (MultiEngine)
+            self._h = _handle
+        else:
+            self._h = C.POINTER(self._hdr.opaque["spx_engine"])()
+            rc = self._lib.spx_create(device, C.byref(self._h))
+            if rc != 0:
+                msg = self._lib.spx_last_error(None)
+                raise SpxError(rc, msg.decode() if msg else "")
         self.n_nodes = 0
         self.n_pods = 0
         self.alloc_params: Optional[Table] = None
@@ -57,7 +73,8 @@ class Engine:
 
     def close(self) -> None:
         if self._h:
-            self._lib.spx_destroy(self._h)
+            if self._owned:
+                self._lib.spx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -166,10 +183,12 @@ class Engine:
         self._ck(self._lib.spx_upload_trimaran_nodes(self._h, t.ref()))
         self.n_nodes = n
 
-    def upload_trimaran_pods(self, cols: Dict[str, np.ndarray]) -> None:
-        p = len(cols["tlp_pod_milli"])
-        t = Table(self._hdr, "spx_trimaran_pods_soa", n_pods=p, **cols)
-        self._ck(self._lib.spx_upload_trimaran_pods(self._h, t.ref()))
+    def upload_trimaran_pods(self, cols: Dict[str, np.ndarray], rows=None) -> None:
+        cols = _rows(cols, len(cols["tlp_pod_milli"]), rows)
+        p = len(cols["tlp_pod_milli"]) if rows is None else rows[1] - rows[0]
+        if p > 0:
+            t = Table(self._hdr, "spx_trimaran_pods_soa", n_pods=p, **cols)
+            self._ck(self._lib.spx_upload_trimaran_pods(self._h, t.ref()))
         self.n_pods = p
 
     def load_trimaran_objects(self, nodes: Table, rc: Optional[Table], pods: Table, metrics: Table,
@@ -199,10 +218,13 @@ class Engine:
         t = Table(self._hdr, "spx_lroc_nodes_soa", n_nodes=len(cols["req_mem"]), **cols)
         self._ck(self._lib.spx_upload_lroc_nodes(self._h, t.ref()))
 
-    def upload_lroc_pods(self, cols: Dict[str, np.ndarray]) -> None:
-        t = Table(self._hdr, "spx_lroc_pods_soa", n_pods=len(cols["req_mem"]), **cols)
-        self._ck(self._lib.spx_upload_lroc_pods(self._h, t.ref()))
-        self.n_pods = len(cols["req_mem"])
+    def upload_lroc_pods(self, cols: Dict[str, np.ndarray], rows=None) -> None:
+        cols = _rows(cols, len(cols["req_mem"]), rows)
+        p = len(cols["req_mem"]) if rows is None else rows[1] - rows[0]
+        if p > 0:
+            t = Table(self._hdr, "spx_lroc_pods_soa", n_pods=p, **cols)
+            self._ck(self._lib.spx_upload_lroc_pods(self._h, t.ref()))
+        self.n_pods = p
 
     def load_lroc_objects(self, nodes: Table, node_pods: Optional[Table], pods: Table) -> None:
         """LowRiskOverCommitment's own tables; the trimaran node table (metrics, allocatable) must be loaded already."""
@@ -210,26 +232,37 @@ class Engine:
         self.upload_lroc_pods(self.flatten_lroc_pods(pods))
 
     # ------------------------------------------------------------------ Peaks
-    def load_peaks_objects(self, nodes: Table, metrics: Table, power_models: Optional[Table], pods: Table) -> None:
+    def flatten_peaks(self, nodes: Table, metrics: Table, power_models: Optional[Table], pods: Table) -> dict:
         n, p = nodes.struct.n_nodes, pods.struct.n_pods
         cols = {"cap_cpu_milli": np.zeros(n, np.int64), "cpu_util": np.zeros(n, np.float64), "valid": np.zeros(n, np.uint8),
                 "k1": np.zeros(n, np.float64), "k2": np.zeros(n, np.float64)}
         fn = self._lib.spx_flatten_peaks_nodes
         self._ck(fn(nodes.ref(), metrics.ref(), power_models.ref() if power_models else None,
                     *[v.ctypes.data_as(t) for v, t in zip(cols.values(), fn.argtypes[3:])]))
-        self._ck(self._lib.spx_upload_peaks_nodes(self._h, Table(self._hdr, "spx_peaks_nodes_soa", n_nodes=n, **cols).ref()))
         cpu = np.zeros(p, np.int64)
         self._ck(self._lib.spx_flatten_peaks_pods(pods.ref(), cpu.ctypes.data_as(C.POINTER(C.c_int64))))
-        self._ck(self._lib.spx_upload_peaks_pods(self._h, Table(self._hdr, "spx_peaks_pods_soa", n_pods=p, cpu_milli=cpu).ref()))
-        self.peaks_soa = dict(cols, cpu_milli=cpu)
-        self.n_nodes, self.n_pods = n, p
+        return {"nodes": cols, "pods": {"cpu_milli": cpu}, "N": n, "P": p}
+
+    def upload_peaks(self, f: dict, rows=None) -> None:
+        pc = _rows(f["pods"], f["P"], rows)
+        p = f["P"] if rows is None else rows[1] - rows[0]
+        self._ck(self._lib.spx_upload_peaks_nodes(self._h, Table(self._hdr, "spx_peaks_nodes_soa", n_nodes=f["N"], **f["nodes"]).ref()))
+        if p > 0:
+            self._ck(self._lib.spx_upload_peaks_pods(self._h, Table(self._hdr, "spx_peaks_pods_soa", n_pods=p, **pc).ref()))
+        self.peaks_soa = dict(f["nodes"], cpu_milli=pc["cpu_milli"][:p])
+        self.n_nodes, self.n_pods = f["N"], p
+
+    def load_peaks_objects(self, nodes: Table, metrics: Table, power_models: Optional[Table], pods: Table) -> None:
+        self.upload_peaks(self.flatten_peaks(nodes, metrics, power_models, pods))
 
     # ------------------------------------------------------------------ NodeResourceTopologyMatch
     def load_nrt_objects(self, nodes: Table, nrt: Table, rc: Optional[Table], pods: Table, params: Table) -> None:
         """objects -> (host flatten: slots, node zone tables, pod request tables) -> HBM."""
+        self.upload_nrt(self.flatten_nrt(nodes, nrt, rc, pods, params))
+
+    def flatten_nrt(self, nodes: Table, nrt: Table, rc: Optional[Table], pods: Table, params: Table) -> dict:
         L, H = self._lib, self._hdr
         u8p, i32p, i64p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float)
-        self._ck(L.spx_set_nrt_params(self._h, params.ref()))
         n_res = C.c_int32()
         slot_res = np.zeros(8, np.int32)
         slot_flags = np.zeros(8, np.uint8)
@@ -239,7 +272,6 @@ class Engine:
                                          slot_weight.ctypes.data_as(i64p)))
         R = n_res.value
         slots = Table(H, "spx_nrt_slots", n_res=R, slot_res=slot_res, slot_flags=slot_flags, slot_weight=slot_weight)
-        self._ck(L.spx_upload_nrt_slots(self._h, slots.ref()))
         N, P = nodes.struct.n_nodes, pods.struct.n_pods
         nc = dict(flags=np.zeros(N, np.uint8), max_numa=np.zeros(N, np.int32), n_zones=np.zeros(N, np.uint8),
                   zone_id=np.zeros(N * 8, np.uint8), zone_present=np.zeros(N * 8, np.uint8),
@@ -247,30 +279,39 @@ class Engine:
                   min_avg_dist=np.zeros(N * 8, np.float32), node_present=np.zeros(N, np.uint8))
         fn = L.spx_flatten_nrt_nodes
         self._ck(fn(nodes.ref(), nrt.ref(), slots.ref(), *[v.ctypes.data_as(t) for v, t in zip(nc.values(), fn.argtypes[3:])]))
-        self._ck(L.spx_upload_nrt_nodes(self._h, Table(H, "spx_nrt_nodes_soa", n_nodes=N, n_res=R, **nc).ref()))
         pc = dict(qos=np.zeros(P, np.uint8), non_native=np.zeros(P, np.uint8), n_ctr=np.zeros(P, np.uint8),
                   ctr_kind=np.zeros(P * 8, np.uint8), ctr_present=np.zeros(P * 8, np.uint8),
                   ctr_req=np.zeros(P * 8 * max(R, 1), np.int64), pod_present=np.zeros(P, np.uint8),
                   pod_req=np.zeros(P * max(R, 1), np.int64))
         fn = L.spx_flatten_nrt_pods
         self._ck(fn(pods.ref(), rc.ref() if rc else None, slots.ref(), *[v.ctypes.data_as(t) for v, t in zip(pc.values(), fn.argtypes[3:])]))
-        self._ck(L.spx_upload_nrt_pods(self._h, Table(H, "spx_nrt_pods_soa", n_pods=P, n_res=R, **pc).ref()))
-        self.n_nodes, self.n_pods = N, P
-        self.nrt_soa = {"slots": slots, "nodes": nc, "pods": pc}
+        return {"params": params, "slots": slots, "nodes": nc, "pods": pc, "N": N, "P": P, "R": R}
+
+    def upload_nrt(self, f: dict, rows=None) -> None:
+        """rows = (begin, end): this engine holds only that slice of the pod batch (MultiEngine)"""
+        L, H = self._lib, self._hdr
+        self._ck(L.spx_set_nrt_params(self._h, f["params"].ref()))
+        self._ck(L.spx_upload_nrt_slots(self._h, f["slots"].ref()))
+        self._ck(L.spx_upload_nrt_nodes(self._h, Table(H, "spx_nrt_nodes_soa", n_nodes=f["N"], n_res=f["R"], **f["nodes"]).ref()))
+        pc = _rows(f["pods"], f["P"], rows)
+        P = f["P"] if rows is None else rows[1] - rows[0]
+        if P > 0:
+            self._ck(L.spx_upload_nrt_pods(self._h, Table(H, "spx_nrt_pods_soa", n_pods=P, n_res=f["R"], **pc).ref()))
+        self.n_nodes, self.n_pods = f["N"], P
+        self.nrt_soa = {"slots": f["slots"], "nodes": f["nodes"], "pods": pc}
 
     # ------------------------------------------------------------------ NetworkOverhead / TopologicalSort
     def load_network_objects(self, nodes: Table, pods: Table, appgroups: Table, nettopo: Table) -> None:
+        self.upload_network(self.flatten_network(nodes, pods, appgroups, nettopo))
+
+    def flatten_network(self, nodes: Table, pods: Table, appgroups: Table, nettopo: Table) -> dict:
         L, H = self._lib, self._hdr
         i32p, i64p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)
         N, P = nodes.struct.n_nodes, pods.struct.n_pods
-        self._ck(L.spx_upload_net_nodes(self._h, Table(H, "spx_net_nodes_soa", n_nodes=N, region=nodes.array("region"),
-                                                        zone=nodes.array("zone")).ref()))
         rg, zc = nettopo.struct.n_regions, nettopo.struct.n_zones
         rcost = np.full(max(rg * rg, 1), -1, np.int32)
         zcost = np.full(max(zc * zc, 1), -1, np.int32)
         self._ck(L.spx_flatten_net_topo(nettopo.ref(), rcost.ctypes.data_as(i32p), zcost.ctypes.data_as(i32p)))
-        self._ck(L.spx_upload_net_topo(self._h, Table(H, "spx_net_topo_soa", n_regions=rg, n_zones=zc, region_cost=rcost,
-                                                       zone_cost=zcost).ref()))
         nk, npairs = C.c_int32(), C.c_int64()
         self._ck(L.spx_flatten_net_keys(pods.ref(), appgroups.ref(), C.byref(nk), C.byref(npairs), None, None, None, None, None, None))
         cols = dict(pod_key=np.zeros(P, np.int32), topo_order=np.zeros(P, np.int32), key_score_equally=np.zeros(nk.value, np.uint8),
@@ -280,8 +321,20 @@ class Engine:
                                         cols["pod_key"].ctypes.data_as(i32p), cols["topo_order"].ctypes.data_as(i32p),
                                         cols["key_score_equally"].ctypes.data_as(u8p), cols["pair_ptr"].ctypes.data_as(i32p),
                                         cols["pair_node"].ctypes.data_as(i32p), cols["pair_max_cost"].ctypes.data_as(i64p)))
-        self._ck(L.spx_upload_net_pods(self._h, Table(H, "spx_net_pods_soa", n_pods=P, n_keys=nk.value, **cols).ref()))
-        self.n_nodes, self.n_pods = N, P
+        return {"region": nodes.array("region"), "zone": nodes.array("zone"), "rg": rg, "zc": zc, "rcost": rcost, "zcost": zcost,
+                "n_keys": nk.value, "cols": cols, "N": N, "P": P}
+
+    def upload_network(self, f: dict, rows=None) -> None:
+        L, H = self._lib, self._hdr
+        self._ck(L.spx_upload_net_nodes(self._h, Table(H, "spx_net_nodes_soa", n_nodes=f["N"], region=f["region"], zone=f["zone"]).ref()))
+        self._ck(L.spx_upload_net_topo(self._h, Table(H, "spx_net_topo_soa", n_regions=f["rg"], n_zones=f["zc"], region_cost=f["rcost"],
+                                                       zone_cost=f["zcost"]).ref()))
+        cols = dict(f["cols"])
+        P = f["P"] if rows is None else rows[1] - rows[0]
+        cols.update(_rows({k: cols[k] for k in ("pod_key", "topo_order")}, f["P"], rows))  # the key tables are per workload, not per pod
+        if P > 0:
+            self._ck(L.spx_upload_net_pods(self._h, Table(H, "spx_net_pods_soa", n_pods=P, n_keys=f["n_keys"], **cols).ref()))
+        self.n_nodes, self.n_pods = f["N"], P
         self.net_soa = cols
 
     def toposort_less(self, pods: Table, a: Sequence[int], b: Sequence[int]) -> np.ndarray:
@@ -301,6 +354,9 @@ class Engine:
 
     # ------------------------------------------------------------------ CapacityScheduling.PreFilter
     def load_quota_objects(self, pods: Table, rc: Optional[Table], quota: Table) -> None:
+        self.upload_quota(self.flatten_quota(pods, rc, quota))
+
+    def flatten_quota(self, pods: Table, rc: Optional[Table], quota: Table) -> dict:
         L, H = self._lib, self._hdr
         P, NS = pods.struct.n_pods, quota.struct.n_namespaces
         nn = max(int(quota.struct.n_nominated), 1)
@@ -313,9 +369,21 @@ class Engine:
         fn = L.spx_flatten_quota
         self._ck_static(fn(pods.ref(), rc.ref() if rc else None, quota.ref(),
                            *[v.ctypes.data_as(t) for v, t in zip(cols.values(), fn.argtypes[3:])]))
-        t = Table(H, "spx_quota_soa", n_pods=P, n_namespaces=NS, has_quota=quota.array("has_quota"), used=quota.array("used"),
-                  used_present=quota.array("used_present"), max=quota.array("max"), max_present=quota.array("max_present"), **cols)
-        self._ck(L.spx_upload_quota(self._h, t.ref()))
+        ns = dict(has_quota=quota.array("has_quota"), used=quota.array("used"), used_present=quota.array("used_present"),
+                  max=quota.array("max"), max_present=quota.array("max_present"))
+        return {"cols": cols, "ns": ns, "P": P, "NS": NS}
+
+    _QUOTA_POD_COLS = ("pod_ns", "pod_priority", "pod_req", "pod_req_present")
+
+    def upload_quota(self, f: dict, rows=None) -> None:
+        cols = dict(f["cols"])
+        P = f["P"] if rows is None else rows[1] - rows[0]
+        cols.update(_rows({k: cols[k] for k in self._QUOTA_POD_COLS}, f["P"], rows))
+        if rows is not None:  # a nominated pod is skipped when it is the pod under evaluation: indices are relative to this engine's rows
+            cols["nom_pending_index"] = cols["nom_pending_index"] - rows[0]
+        if P > 0:
+            t = Table(self._hdr, "spx_quota_soa", n_pods=P, n_namespaces=f["NS"], **f["ns"], **cols)
+            self._ck(self._lib.spx_upload_quota(self._h, t.ref()))
         self.n_pods = P
 
     def prefilter(self, plugin: int, row_begin: int = 0, row_end: Optional[int] = None) -> np.ndarray:

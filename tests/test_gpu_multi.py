@@ -1,0 +1,128 @@
+"""Multi-device layer of the C ABI (spx_multi_*): pod rows sharded across ranks inside ONE host process, node
+tables replicated, all-gather of decisions and of global score / status tables.
+
+On a one-GPU box two things can run and both do: (a) the RCCL transport with a single rank (librccl.so.1 is dlopen'ed,
+ncclCommInitAll / ncclAllGather really execute), and (b) several ranks on device 0 with the peer-copy transport, which
+exercises sharding, in-place binding of table slices and reassembly against the unsharded engine.  With two or more GPUs
+visible the same checks run over RCCL on distinct devices."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import ALLOCATABLE, CAPACITY, LVRB, NETOVERHEAD, NRT, TLP
+from scheduler_plugins_amd import objects as O
+from scheduler_plugins_amd import synth
+from scheduler_plugins_amd.engine import Engine, mask_of
+from scheduler_plugins_amd.multi import PEER_COPY, RCCL, MultiEngine
+
+pytestmark = pytest.mark.gpu
+
+ALL = (ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY)
+WEIGHTS = {ALLOCATABLE: 1, TLP: 2, LVRB: 1, NRT: 3, NETOVERHEAD: 2}
+
+
+def n_gpus():
+    import scheduler_plugins_amd as spx
+    n = C.c_int(0)
+    hip = C.CDLL("libamdhip64.so")
+    return n.value if hip.hipGetDeviceCount(C.byref(n)) == 0 else 0
+
+
+def load_full(e, hdr, snap):
+    params = O.nrt_params(hdr, O.Resources(), "LeastAllocated")
+    e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+    e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+    e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+    e.load_quota_objects(snap["pods"], snap["rc"], snap["quota"])
+
+
+def configs():
+    out = [("rccl-1", [0], RCCL), ("copy-2-on-dev0", [0, 0], PEER_COPY), ("copy-3-on-dev0", [0, 0, 0], PEER_COPY)]
+    g = n_gpus()
+    if g >= 2:
+        out.append((f"rccl-{min(g, 8)}", list(range(min(g, 8))), RCCL))
+        out.append(("copy-2", [0, 1], PEER_COPY))
+    return out
+
+
+@pytest.mark.parametrize("name,devices,transport", configs(), ids=lambda v: v if isinstance(v, str) else "")
+@pytest.mark.parametrize("n_nodes,n_pods", [(300, 1001), (130, 7)])
+def test_full_profile_sharded_equals_unsharded(gpu_required, hdr, name, devices, transport, n_nodes, n_pods):
+    snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=5, pods_per_group=20, n_namespaces=20)
+    with Engine(0) as ref:
+        load_full(ref, hdr, snap)
+        ref.set_plugin_weights(WEIGHTS)
+        ref.eval(mask_of(*ALL))
+        ref.eval_best(mask_of(*ALL))
+        ref.sync()
+        want_best = ref.best()
+        want_score = {p: ref.all_scores(p) for p in WEIGHTS}
+        want_status = {p: ref.all_status(p) for p in (NRT, NETOVERHEAD)}
+        want_pre = ref.prefilter(CAPACITY)
+    with MultiEngine(devices, transport) as m:
+        assert m.size == len(devices)
+        m.for_all(lambda e: e.set_plugin_weights(WEIGHTS))
+        load_full(m, hdr, snap)
+        # shards are equal contiguous ranges, the last ones possibly short or empty
+        per = -(-n_pods // m.size)
+        assert [m.shard(r) for r in range(m.size)] == [(min(n_pods, r * per), min(n_pods, (r + 1) * per)) for r in range(m.size)]
+        for p in WEIGHTS:
+            m.bind_global_table(p)
+        for p in (NRT, NETOVERHEAD):
+            m.bind_global_table(p, status=True)
+        m.eval(mask_of(*ALL))
+        m.eval_best(mask_of(*ALL))
+        got_best = m.gather_best()
+        for a, b in zip(got_best, want_best):
+            assert np.array_equal(a, b)
+        for p in WEIGHTS:
+            m.allgather_table(p)
+        for p in (NRT, NETOVERHEAD):
+            m.allgather_table(p, status=True)
+        m.sync()
+        for rank in range(m.size):  # every rank holds the whole table
+            for p in WEIGHTS:
+                assert np.array_equal(m.global_rows(p, rank), want_score[p]), (p, rank)
+            for p in (NRT, NETOVERHEAD):
+                assert np.array_equal(m.global_rows(p, rank, status=True), want_status[p]), (p, rank)
+        # CapacityScheduling.PreFilter: the nominated-pod self-exclusion is by batch row, so shards rebase it
+        pre = np.concatenate([e.prefilter(CAPACITY) for e in m.engines if e.n_pods > 0])
+        assert np.array_equal(pre, want_pre)
+        ev, ga = m.last_ms()
+        assert ev > 0 and ga > 0
+
+
+@pytest.mark.parametrize("name,devices,transport", configs(), ids=lambda v: v if isinstance(v, str) else "")
+def test_decide_sharded(gpu_required, hdr, name, devices, transport):
+    """the table-less decision sweep per rank + all-gather of 20 B per pod"""
+    snap = synth.trimaran_snapshot(hdr, 2100, 5003, seed=8, round_frac=0.2)
+    mask = mask_of(ALLOCATABLE, TLP)
+    with Engine(0) as ref:
+        ref.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        ref.decide(mask)
+        want = ref.best()
+    with MultiEngine(devices, transport) as m:
+        m.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        m.decide(mask)
+        for a, b in zip(m.gather_best(), want):
+            assert np.array_equal(a, b)
+
+
+def test_errors(gpu_required, hdr):
+    import scheduler_plugins_amd as spx
+    with pytest.raises(spx.SpxError, match="distinct devices"):
+        MultiEngine([0, 0], RCCL)
+    with pytest.raises(spx.SpxError):
+        MultiEngine([], RCCL)
+    with pytest.raises(spx.SpxError, match="device_id out of range"):
+        MultiEngine([0, 99], PEER_COPY)
+    snap = synth.trimaran_snapshot(hdr, 100, 50, seed=1)
+    with MultiEngine([0, 0], PEER_COPY) as m:
+        m.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        with pytest.raises(spx.SpxError, match="no decisions"):
+            m.gather_best()
+        with pytest.raises(spx.SpxError, match="no global table"):
+            m.allgather_table(TLP)
+        with pytest.raises(spx.SpxError, match="rank 0"):
+            m.eval(mask_of(NRT))  # NRT tables were never uploaded: the failing rank's message comes back

@@ -29,6 +29,7 @@ for d in sorted((ROOT / "gpurun_out").glob("prof_*")):
     if bench_line:
         b = json.loads(bench_line[-1])
         summ["bench_kernel_ms_under_rocprof"] = b["roofline"]["kernel_ms"]
+        summ["kernel_source_hash"] = b["roofline"].get("kernel_source_hash")  # bench.py reports these counters only while it matches
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for pm in sorted(d.glob("pmc*/p_counter_collection.csv")):
         for r in csv.DictReader(open(pm)):
