@@ -244,6 +244,8 @@ def main() -> None:
     ap.add_argument("--gather", default="best", choices=["none", "best", "table"],
                     help="N>1 only, measured OUTSIDE the timed region: all-gather of per-pod decisions and (table) of one score slab")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "copy"], help="single-process multi-device exchange (spx_multi)")
+    ap.add_argument("--devices", default="", help="single-process multi-device mode: explicit device list, e.g. 0,0 with --transport copy "
+                                                  "runs two ranks on one GPU (plumbing check of the sharded path on a one-GPU box)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -256,7 +258,10 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    if args.gpus > torch.cuda.device_count():
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if args.devices:
+        args.gpus = len(devices)
+    elif args.gpus > torch.cuda.device_count():
         raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible")
     mode = "ranks" if world_env > 1 else ("multi" if args.gpus > 1 else "single")
     world = args.gpus
@@ -288,7 +293,7 @@ def main() -> None:
     # ------------------------------------------------------------------ tables into HBM
     if mode == "multi":
         snap = build_snapshot(hdr, w, n_pods_total, synth.SEED)
-        target = MultiEngine(list(range(world)), RCCL if args.transport == "rccl" else PEER_COPY)
+        target = MultiEngine(devices, RCCL if args.transport == "rccl" else PEER_COPY)
         load_tables(target, w, snap)
         e0 = target.engines[0]
         local_pods = max(e.n_pods for e in target.engines)
@@ -313,7 +318,7 @@ def main() -> None:
 
     # bring the device(s) out of idle clocks with unrelated work (not steps of the workload): a fresh box runs its first
     # ~50 ms of kernels at low clocks, which would otherwise dominate short --steps runs
-    for d in (range(world) if mode == "multi" else [local_rank]):
+    for d in (sorted(set(devices)) if mode == "multi" else [local_rank]):
         spin = torch.empty(64 << 20, dtype=torch.float32, device=f"cuda:{d}")
         t_spin = time.perf_counter()
         while time.perf_counter() - t_spin < 0.15:
@@ -404,6 +409,26 @@ def main() -> None:
                 full_cycle["sequential_distinct_nodes"] = int(len(set(seq_node.tolist())))
         except Exception as ex:
             full_cycle = {"error": repr(ex)[:200]}
+
+    # config #4 names "NodeNetworkCost + TopologicalSort": the queue sort of the whole batch (one device; 16-byte keys), device time
+    sort_info = None
+    if "net" in w["plugins"] and rank == 0:
+        try:
+            q_pods = snap["pods"]
+            if mode == "multi":
+                target.sort_queue(q_pods)
+                ms = target.engines[0].last_eval_ms()
+            elif strong and world > 1:
+                f = target.flatten_network(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+                target.sort_queue(q_pods, topo_order=f["cols"]["topo_order"])
+                ms = target.last_eval_ms()
+            else:
+                target.sort_queue(q_pods)
+                ms = target.last_eval_ms()
+            sort_info = {"queue_sort_ms": ms, "n_keys": int(q_pods.struct.n_pods),
+                         "what": "spx_sort_keys: TopologicalSort order of the whole pending queue (two stable radix sorts of pod indices), HIP-event time"}
+        except Exception as ex:
+            sort_info = {"error": repr(ex)[:200]}
 
     # the exchange step of the sharded path, reported separately: per-pod decisions, optionally one table
     gather_info = None
@@ -511,6 +536,8 @@ def main() -> None:
         out["full_cycle"] = full_cycle
     if gather_info is not None:
         out["gather"] = gather_info
+    if sort_info is not None:
+        out["topological_sort"] = sort_info
     if rank == 0 and args.cpu_budget > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(spx, snap, e0, plugins, args.cpu_budget)
     target.close()

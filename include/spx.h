@@ -484,6 +484,18 @@ typedef struct spx_net_pods_soa {
   const int32_t* topo_order;
 } spx_net_pods_soa;
 
+/* TopologicalSort: the four per-pod values TopologicalSort.Less reads (topologicalsort.go:102-132): pod.Spec.Priority and
+ * QueuedPodInfo.Timestamp (upstream PrioritySort, :109-113), the AppGroup id (-1 = no label) and the pod's index in its
+ * group's Status.TopologyOrder as util.FindPodOrder returns it (-1 = selector not listed) — the `topo_order` column
+ * spx_flatten_net_keys produces. */
+typedef struct spx_sort_keys_soa {
+  int64_t n_pods;
+  const int32_t* priority;
+  const int64_t* queue_ts;
+  const int32_t* appgroup;
+  const int32_t* topo_order;
+} spx_sort_keys_soa;
+
 /* CapacityScheduling.PreFilter: per-pod request vectors and per-namespace nominated lists (CSR, any order) */
 typedef struct spx_quota_soa {
   int64_t n_pods;
@@ -529,6 +541,7 @@ typedef struct spx_quota_soa {
  *   spx_eval + spx_fetch_scores(NETOVERHEAD)   NetworkOverhead.NormalizeScore          networkoverhead.go:389-418
  *   spx_eval + spx_fetch_prefilter(CAPACITY)   CapacityScheduling.PreFilter            pkg/capacityscheduling/capacity_scheduling.go:208-283
  *   spx_flatten_net_keys + spx_toposort_less   TopologicalSort.Less, FindPodOrder      pkg/networkaware/topologicalsort/topologicalsort.go:102-132, util/util.go:138-153
+ *   spx_upload_sort_keys + spx_sort_keys       the activeQ ordering TopologicalSort.Less induces, as one device sort
  *   spx_flatten_trimaran_*                     GetNodeMetrics / ScheduledPodsCache / PredictUtilisation / GetResourceRequested
  *                                              pkg/trimaran/collector.go:110-123, handler.go:47-58, targetloadpacking.go:198-205, resourcestats.go:45-146
  *   spx_flatten_nrt_*                          createNUMANodeList / TopologyManagerFromNodeResourceTopology / GetPodEffectiveRequest / OverReserve
@@ -578,6 +591,15 @@ int spx_upload_net_nodes(spx_engine* e, const spx_net_nodes_soa* t);
 int spx_upload_net_topo(spx_engine* e, const spx_net_topo_soa* t);
 int spx_upload_net_pods(spx_engine* e, const spx_net_pods_soa* t);
 int spx_upload_quota(spx_engine* e, const spx_quota_soa* t);
+/* TopologicalSort as one batched sort of the pending queue (replaces the activeQ heap's pairwise Less calls).  Less is not a
+ * strict weak order (same AppGroup: `orderP1 <= orderP2`; otherwise PrioritySort), but it is complete, so an order exists in
+ * which EVERY ADJACENT PAIR (x, y) satisfies Less(x, y) — or ties under PrioritySort (equal priority and timestamp).
+ * spx_sort_keys returns such an order: perm_out[i] = pod row at queue position i.  Construction (kernels_sort.hip): stable
+ * radix sort by (priority descending, timestamp ascending), then every maximal run of consecutive pods of one AppGroup is
+ * reordered by topology index.  The table is independent of the other pod tables (its n_pods is the queue length).
+ * Synchronous; spx_last_eval_ms reports the device time. */
+int spx_upload_sort_keys(spx_engine* e, const spx_sort_keys_soa* t);
+int spx_sort_keys(spx_engine* e, int32_t* perm_out);
 /* CapacityScheduling.PreFilter status per pod (n_pods bytes: 0 Success, SPX_QUOTA_ST_*); valid after spx_eval with the CAPACITY bit */
 int spx_fetch_prefilter(spx_engine* e, int plugin, int64_t row_begin, int64_t row_end, uint8_t* out);
 

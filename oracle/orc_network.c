@@ -148,3 +148,30 @@ int orc_toposort_less(const spx_pod_objects* pods, const spx_appgroup_objects* a
   int32_t o2 = orc_find_pod_order(ag, g1, pods->selector[p2]);
   return o1 <= o2;
 }
+
+/* The parity statement for a batched TopologicalSort (hard part 6): Less is not a strict weak order, so
+ * "the sorted queue" is heap-implementation dependent; what can be checked is that every adjacent pair (x, y) of a proposed
+ * order satisfies Less(x, y) — or is a PrioritySort tie (different/no AppGroup, equal priority and timestamp), which the
+ * heap may pop either way.  Returns the number of adjacent pairs that do neither; -1 when perm is not a permutation. */
+int64_t orc_toposort_order_violations(const spx_pod_objects* pods, const spx_appgroup_objects* ag, const int32_t* perm, int64_t n) {
+  if (!pods || !ag || !perm || n != pods->n_pods) return -1;
+  unsigned char* seen = (unsigned char*)calloc((size_t)(n > 0 ? n : 1), 1);
+  if (!seen) return -1;
+  for (int64_t i = 0; i < n; ++i) {
+    if (perm[i] < 0 || perm[i] >= n || seen[perm[i]]) {
+      free(seen);
+      return -1;
+    }
+    seen[perm[i]] = 1;
+  }
+  free(seen);
+  int64_t bad = 0;
+  for (int64_t i = 0; i + 1 < n; ++i) {
+    const int64_t x = perm[i], y = perm[i + 1];
+    if (orc_toposort_less(pods, ag, x, y)) continue;
+    const int32_t gx = pods->appgroup[x], gy = pods->appgroup[y];
+    if ((gx != gy || gx < 0) && pods->priority[x] == pods->priority[y] && pods->queue_ts[x] == pods->queue_ts[y]) continue;
+    ++bad;
+  }
+  return bad;
+}

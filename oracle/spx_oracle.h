@@ -123,6 +123,8 @@ int orc_net_prefilter(const spx_node_objects* nodes, const spx_pod_objects* pods
 void orc_net_normalize(int64_t* scores, int64_t n);
 int32_t orc_find_pod_order(const spx_appgroup_objects* ag, int32_t g, int32_t selector);
 int orc_toposort_less(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int64_t p1, int64_t p2);
+/* adjacent pairs of the proposed queue order that satisfy neither Less nor a PrioritySort tie; -1: not a permutation */
+int64_t orc_toposort_order_violations(const spx_pod_objects* pods, const spx_appgroup_objects* ag, const int32_t* perm, int64_t n);
 
 /* ---- CapacityScheduling.PreFilter (pkg/capacityscheduling/{capacity_scheduling,elasticquota}.go) */
 int orc_quota_cmp2(const int64_t* x1, uint8_t x1_present, const int64_t* x2, const int64_t* y, uint8_t y_present, int64_t bound);

@@ -100,6 +100,10 @@ struct spx_engine {
   DevBuf d_net_region, d_net_zone, d_net_class, d_net_class16, d_net_cls_size, d_net_cls_region, d_net_cls_zone, d_net_rcost, d_net_zcost;
   bool net_class16 = false;
   DevBuf d_net_pod_key, d_net_key_flag, d_net_pair_ptr, d_net_pair_node, d_net_pair_max;
+  // TopologicalSort keys
+  DevBuf d_sort_prio, d_sort_ts, d_sort_group, d_sort_topo, d_sort_scratch;
+  int64_t sort_n = 0;
+  unsigned* h_sort_hist = nullptr;  // pinned
 
   // profile-level state
   DevBuf d_ext_status;  // caller's feasibility mask, stored as a status table (0 = feasible)
@@ -453,6 +457,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_net_pair_node, &e->d_net_pair_max, &e->d_q_pod_ns, &e->d_q_pod_prio, &e->d_q_pod_req, &e->d_q_pod_reqp,
                     &e->d_q_has, &e->d_q_used, &e->d_q_max, &e->d_q_maxp, &e->d_q_other, &e->d_q_otherp, &e->d_q_nom_ptr,
                     &e->d_q_nom_prio, &e->d_q_nom_idx, &e->d_q_nom_req, &e->d_q_nom_reqp, &e->d_q_status, &e->d_ext_status,
+                    &e->d_sort_prio, &e->d_sort_ts, &e->d_sort_group, &e->d_sort_topo, &e->d_sort_scratch,
                     &e->d_best, &e->d_stats, &e->d_decide, &e->d_lroc_nreq_c, &e->d_lroc_nreq_m, &e->d_lroc_nlim_c, &e->d_lroc_nlim_m,
                     &e->d_lroc_preq_c, &e->d_lroc_preq_m, &e->d_lroc_plim_c, &e->d_lroc_plim_m, &e->d_lroc_tab, &e->d_lroc_podf,
                     &e->d_pk_cap, &e->d_pk_util, &e->d_pk_valid, &e->d_pk_k1, &e->d_pk_k2, &e->d_pk_pod, &e->d_pk_min, &e->d_pk_max};
@@ -465,6 +470,7 @@ int spx_destroy(spx_engine* e) {
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->h_best) (void)hipHostFree(e->h_best);
+  if (e->h_sort_hist) (void)hipHostFree(e->h_sort_hist);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
   return SPX_OK;
@@ -989,6 +995,45 @@ int spx_upload_net_pods(spx_engine* e, const spx_net_pods_soa* t) {
   if ((rc = upload(e, e->d_net_pair_max, pairs ? static_cast<const void*>(t->pair_max_cost) : static_cast<const void*>(&rc), pairs * 8))) return rc;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   e->net_pods = true;
+  return SPX_OK;
+}
+
+int spx_upload_sort_keys(spx_engine* e, const spx_sort_keys_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  if (t->n_pods <= 0 || t->n_pods >= (int64_t{1} << 31)) return fail(e, SPX_ERR_ARG, "sort keys: n_pods must be in [1, 2^31)");
+  const size_t p = static_cast<size_t>(t->n_pods);
+  int rc;
+  if ((rc = upload(e, e->d_sort_prio, t->priority, p * 4))) return rc;
+  if ((rc = upload(e, e->d_sort_ts, t->queue_ts, p * 8))) return rc;
+  if ((rc = upload(e, e->d_sort_group, t->appgroup, p * 4))) return rc;
+  if ((rc = upload(e, e->d_sort_topo, t->topo_order, p * 4))) return rc;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  e->sort_n = t->n_pods;
+  return SPX_OK;
+}
+
+int spx_sort_keys(spx_engine* e, int32_t* perm_out) {
+  if (!e || !perm_out) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  if (e->sort_n <= 0) return fail(e, SPX_ERR_STATE, "TopologicalSort: spx_upload_sort_keys not called");
+  int rc;
+  if ((rc = ensure(e, e->d_sort_scratch, spx::sort_scratch_bytes(e->sort_n)))) return rc;
+  if (!e->h_sort_hist) SPX_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_sort_hist), 16 * 256 * sizeof(unsigned), hipHostMallocDefault));
+  spx::SortArgs a{};
+  a.n = e->sort_n;
+  a.priority = static_cast<const int32_t*>(e->d_sort_prio.p);
+  a.queue_ts = static_cast<const int64_t*>(e->d_sort_ts.p);
+  a.appgroup = static_cast<const int32_t*>(e->d_sort_group.p);
+  a.topo_order = static_cast<const int32_t*>(e->d_sort_topo.p);
+  SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
+  hipError_t st = hipSuccess;
+  const int32_t* perm = spx::launch_sort_keys(a, e->d_sort_scratch.p, e->h_sort_hist, e->stream, &st);
+  if (st != hipSuccess || !perm) return fail(e, SPX_ERR_HIP, std::string("spx_sort_keys: ") + hipGetErrorString(st));
+  SPX_HIP(e, hipEventRecord(e->ev1, e->stream));
+  e->timed = true;
+  SPX_HIP(e, hipMemcpyAsync(perm_out, perm, static_cast<size_t>(e->sort_n) * 4, hipMemcpyDeviceToHost, e->stream));
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
   return SPX_OK;
 }
 

@@ -304,6 +304,18 @@ struct NetArgs {
 void launch_net(const NetArgs& g, hipStream_t s);
 size_t net_lds_bytes(int n_classes, int64_t n_nodes);
 
+// ---------------------------------------------------------------- TopologicalSort (kernels_sort.hip)
+struct SortArgs {
+  int64_t n;
+  const int32_t* priority;    // [P] pod.Spec.Priority
+  const int64_t* queue_ts;    // [P] QueuedPodInfo.Timestamp
+  const int32_t* appgroup;    // [P] AppGroup id, -1 = none
+  const int32_t* topo_order;  // [P] FindPodOrder index (-1 = not found)
+  int32_t* run_of_pod;        // scratch, set by launch_sort_keys
+};
+size_t sort_scratch_bytes(int64_t n);
+const int32_t* launch_sort_keys(const SortArgs& a, void* scratch, unsigned* hist_host, hipStream_t s, hipError_t* err);
+
 // ---------------------------------------------------------------- CapacityScheduling.PreFilter
 struct QuotaArgs {
   int64_t row_begin;

@@ -337,6 +337,17 @@ class Engine:
         self.n_nodes, self.n_pods = f["N"], P
         self.net_soa = cols
 
+    def sort_queue(self, pods: Table, topo_order: Optional[np.ndarray] = None) -> np.ndarray:
+        """TopologicalSort as one device sort: queue order (pod rows) in which every adjacent pair satisfies Less (spx_sort_keys)"""
+        topo = np.ascontiguousarray(self.net_soa["topo_order"] if topo_order is None else topo_order, dtype=np.int32)
+        n = pods.struct.n_pods
+        t = Table(self._hdr, "spx_sort_keys_soa", n_pods=n, priority=pods.array("priority"), queue_ts=pods.array("queue_ts"),
+                  appgroup=pods.array("appgroup"), topo_order=topo)
+        self._ck(self._lib.spx_upload_sort_keys(self._h, t.ref()))
+        perm = np.zeros(n, np.int32)
+        self._ck(self._lib.spx_sort_keys(self._h, perm.ctypes.data_as(C.POINTER(C.c_int32))))
+        return perm
+
     def toposort_less(self, pods: Table, a: Sequence[int], b: Sequence[int]) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.int64)
         b = np.ascontiguousarray(b, dtype=np.int64)

@@ -114,6 +114,11 @@ class MultiEngine:
         for e, rows in self._each(f["P"]):
             e.upload_network(f, rows)
         self.n_nodes = f["N"]
+        self.net_topo_order = f["cols"]["topo_order"]  # of the whole batch (the queue sort is global)
+
+    def sort_queue(self, pods: Table) -> np.ndarray:
+        """TopologicalSort over the whole pending queue: a global sort of 16-byte keys, done on rank 0's device"""
+        return self.engines[0].sort_queue(pods, topo_order=self.net_topo_order)
 
     def load_quota_objects(self, pods: Table, rc, quota: Table) -> None:
         f = self.engines[0].flatten_quota(pods, rc, quota)

@@ -140,3 +140,72 @@ def test_config4_full_size_properties(gpu_required, hdr, oracle):
         for r in rows:
             sc, st = e.scores(NETOVERHEAD, r), e.status(NETOVERHEAD, r)
             assert sc.max() in (0, 100) and (sc[st != 0] == 0).all()
+
+
+# ------------------------------------------------------------------ TopologicalSort as a device sort (spx_sort_keys)
+def _violations(oracle, snap_pods, ag, perm):
+    import ctypes as C
+    perm = np.ascontiguousarray(perm, dtype=np.int32)
+    return int(oracle.lib().orc_toposort_order_violations(snap_pods.ref(), ag.ref(), perm.ctypes.data_as(C.POINTER(C.c_int32)), len(perm)))
+
+
+@pytest.mark.parametrize("case", GN.QUEUE_ORDER_CASES, ids=lambda c: f"L{c['line']}")
+def test_sort_queue_golden(gpu_required, hdr, oracle, case):
+    """test/integration/topologicalsort_test.go:253-342: pods of one AppGroup, equal priority — the queue pops them in
+    topology-index order, and distinct indexes make that order unique, so the device sort must reproduce it exactly"""
+    nodes, pods, ag, nt = build(hdr, [], [(case["appgroup"], s) for s in case["created"]])
+    with Engine(0) as e:
+        e.load_network_objects(nodes, pods, ag, nt)
+        perm = e.sort_queue(pods)
+    assert [case["created"][i] for i in perm] == case["popped"]
+    assert _violations(oracle, pods, ag, perm) == 0
+
+
+@pytest.mark.parametrize("n_pods,ppg,seed,mode", [(1, 1, 1, "mixed"), (63, 5, 2, "mixed"), (64, 64, 3, "mixed"), (1025, 30, 4, "mixed"), (5000, 7, 5, "equal_ts"),
+                                                  (4097, 300, 6, "one_priority"), (20000, 100, 7, "no_groups"), (3001, 11, 8, "negative")])
+def test_sort_queue_property(gpu_required, hdr, oracle, n_pods, ppg, seed, mode):
+    """every adjacent pair of the returned order satisfies the reference's Less (or is a PrioritySort tie), on queues that
+    stress each key: interleaved AppGroups, timestamp ties, a single priority, no AppGroup at all, negative priorities and
+    timestamps, pods whose selector is not in the topology order (index -1)"""
+    snap = synth.network_snapshot(hdr, 40, n_pods, seed=seed, pods_per_group=ppg)
+    pods = snap["pods"]
+    rng = np.random.default_rng(seed)
+    if mode == "equal_ts":
+        pods.array("queue_ts")[:] = 1_700_000_000_000_000 + rng.integers(0, 3, n_pods)
+    elif mode == "one_priority":
+        pods.array("priority")[:] = 7
+        pods.array("queue_ts")[:] = rng.permutation(n_pods).astype(np.int64) * 977
+    elif mode == "no_groups":
+        pods.array("appgroup")[:] = -1
+    elif mode == "negative":
+        pods.array("priority")[:] = rng.integers(-2**31, 2**31 - 1, n_pods, dtype=np.int64).astype(np.int32)
+        pods.array("queue_ts")[:] = rng.integers(-2**62, 2**62, n_pods)
+        pods.array("selector")[rng.random(n_pods) < 0.1] = 10_000  # not listed in Status.TopologyOrder -> FindPodOrder = -1
+    else:
+        pods.array("queue_ts")[:] = rng.permutation(n_pods).astype(np.int64) * 1000 + 1_700_000_000_000_000
+    with Engine(0) as e:
+        e.load_network_objects(snap["nodes"], pods, snap["appgroups"], snap["nettopo"])
+        perm = e.sort_queue(pods)
+        # the per-pod keys the sort used are the ones the pairwise comparator agrees with the oracle on
+        a, b = rng.integers(0, n_pods, 300), rng.integers(0, n_pods, 300)
+        want = [bool(oracle.lib().orc_toposort_less(pods.ref(), snap["appgroups"].ref(), int(x), int(y))) for x, y in zip(a, b)]
+        assert e.toposort_less(pods, a, b).tolist() == want
+    assert sorted(perm.tolist()) == list(range(n_pods))
+    assert _violations(oracle, pods, snap["appgroups"], perm) == 0
+    if mode == "no_groups":  # plain PrioritySort: the order is the lexicographic one
+        key = np.lexsort((pods.array("queue_ts"), -pods.array("priority").astype(np.int64)))
+        assert np.array_equal(perm, key.astype(np.int32))
+
+
+def test_sort_queue_config4(gpu_required, hdr, oracle):
+    """BASELINE config #4's queue: 200k pending pods"""
+    n_pods = 200_000
+    snap = synth.network_snapshot(hdr, 10_000, n_pods)
+    rng = np.random.default_rng(3)
+    snap["pods"].array("queue_ts")[:] = rng.permutation(n_pods).astype(np.int64) * 1000 + 1_700_000_000_000_000  # arrival order != row order
+    with Engine(0) as e:
+        e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+        perm = e.sort_queue(snap["pods"])
+        ms = e.last_eval_ms()
+    assert _violations(oracle, snap["pods"], snap["appgroups"], perm) == 0
+    assert ms < 20.0, ms
