@@ -820,8 +820,8 @@ int32_t spx_ingest_resource_id(const spx_ingest* h, const char* name);
  * containers first (restartPolicy Always = SPX_CTR_SIDECAR) then app containers, requests / limits / overhead lists in document
  * order, spec.priority, metadata.creationTimestamp as queue timestamp (microseconds), namespace and the two AppGroup labels
  * (appgroup.diktyo.x-k8s.io, appgroup.diktyo.x-k8s.io.workload) interned, -1 when absent.  Name id spaces (kind: 0 region, 1 zone,
- * 2 namespace, 3 AppGroup, 4 workload selector) grow in first-seen order; spx_ingest_seed_names fixes them beforehand — workload
- * selectors MUST be seeded in lexicographic order (see spx_appgroup_objects). */
+ * 2 namespace, 3 AppGroup, 4 workload selector) grow in first-seen order; spx_ingest_seed_names fixes them beforehand (workload
+ * selectors are the exception: see spx_ingest_appgroups_json). */
 int spx_ingest_nodes_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_objects_out, int64_t* n_unknown_out);
 int spx_ingest_pods_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_objects_out);
 int spx_ingest_pods_reset(spx_ingest* h);
@@ -829,10 +829,11 @@ const spx_node_objects* spx_ingest_node_objects(const spx_ingest* h);
 const spx_pod_objects* spx_ingest_pod_objects(const spx_ingest* h);
 int spx_ingest_seed_names(spx_ingest* h, int32_t kind, const char* const* names, int32_t n);
 int32_t spx_ingest_name_id(const spx_ingest* h, int32_t kind, const char* name);
-/* AppGroup CRs (appgroup.diktyo.x-k8s.io/v1alpha1) -> spx_appgroup_objects, groups appended in document order (group id = name id of
- * kind 3): spec.workloads[].workload.selector, their dependencies[].{workload.selector, maxNetworkCost}, status.topologyOrder[] as
- * written.  Workload selectors are interned in lexicographic order when the selector table is still empty — feed AppGroups before
- * pods — or must already be seeded in that order.  The scheduled-pods list is not part of the CR and stays empty.
+/* AppGroup CRs (appgroup.diktyo.x-k8s.io/v1alpha1) -> spx_appgroup_objects, row g = the group whose name id (kind 3) is g — the id
+ * the pod table's appgroup column carries, whatever order CRs and pods arrive in; a later CR of the same name replaces the earlier one: spec.workloads[].workload.selector, their dependencies[].{workload.selector, maxNetworkCost}, status.topologyOrder[] as
+ * written.  Workload selector ids always preserve the lexicographic order of the selector strings: whenever a call (AppGroups or pods)
+ * leaves the table out of order it is re-sorted and the pod table's selector column renumbered — query ids (spx_ingest_name_id)
+ * after the last ingestion call, not before.  The scheduled-pods list is not part of the CR and stays empty.
  * One NetworkTopology CR (networktopology.diktyo.x-k8s.io/v1alpha1) -> spx_nettopo_objects for the weights set weights_name
  * (populateCostMap, networkoverhead.go:448-497); region / zone names share the id spaces of the node table (kinds 0 and 1). */
 int spx_ingest_appgroups_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_objects_out);
@@ -841,10 +842,22 @@ int spx_ingest_nettopo_json(spx_ingest* h, const char* json, int64_t len, const 
 const spx_nettopo_objects* spx_ingest_nettopo_objects(const spx_ingest* h);
 /* ElasticQuota CRs (scheduling.x-k8s.io/v1alpha1) -> spx_quota_objects indexed by the given namespace list (which also seeds the
  * namespace ids of the pod table): spec.min / spec.max with newElasticQuotaInfo's replacements for nil lists (elasticquota.go:70-76),
- * `used` from status.used; quotas of other namespaces are counted and skipped; the nominated-pod list stays empty (queue state).
+ * `used` from status.used; quotas of other namespaces are counted and skipped.  The nominated-pod list (capacity_scheduling.go:231-253 walks
+ * PodNominator.NominatedPodsForNode over the snapshot's nodes) is rebuilt from the handle's pod table on every pod / quota call: the
+ * pods whose status.nominatedNodeName names a node of the snapshot, nom_pending_index = the pod's own row (the reference skips the pod
+ * under evaluation by UID).
  * NULL from the accessor until the first successful call. */
 int spx_ingest_quota_json(spx_ingest* h, const char* json, int64_t len, const char* const* namespaces, int32_t n_namespaces, int64_t* n_objects_out, int64_t* n_unknown_out);
 const spx_quota_objects* spx_ingest_quota_objects(const spx_ingest* h);
+/* The load-watcher response trimaran's Collector polls (collector.go:139-150) -> spx_metrics_objects in the handle's node order.
+ * The struct it decodes into (watcher.WatcherMetrics, github.com/paypal/load-watcher v0.2.4) is not vendored in the reference and
+ * the reference holds no golden document: field names are the struct's published json tags, decoding rules are encoding/json's
+ * (case-insensitive member names, unknown members ignored) — PARITY UNPINNED.  A successful call replaces the whole
+ * metrics snapshot; a failed one keeps the previous one, like the Collector.  n_nodes_out counts the entries of
+ * data.NodeMetricsMap, n_unknown_out those whose name is not in the handle's node list.  NULL from the accessor until the first
+ * successful call. */
+int spx_ingest_metrics_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_nodes_out, int64_t* n_unknown_out);
+const spx_metrics_objects* spx_ingest_metrics_objects(const spx_ingest* h);
 /* resource.Quantity text -> canonical int64: MilliValue() when milli != 0 (cpu), Value() otherwise; both round up */
 int spx_ingest_quantity(const char* text, int32_t milli, int64_t* out);
 

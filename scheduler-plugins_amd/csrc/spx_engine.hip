@@ -97,6 +97,7 @@ struct spx_engine {
   // NetworkOverhead / TopologicalSort
   bool net_nodes = false, net_topo = false, net_pods = false;
   int32_t net_n_regions = 0, net_n_zones = 0, net_n_classes = 0;
+  int64_t net_max_cost = SPX_NET_MAX_COST, net_max_pairs = 0;  // bound of a row's accumulated cost (the sweep adds in int32)
   DevBuf d_net_region, d_net_zone, d_net_class, d_net_class16, d_net_cls_size, d_net_cls_region, d_net_cls_zone, d_net_rcost, d_net_zcost;
   bool net_class16 = false;
   DevBuf d_net_pod_key, d_net_key_flag, d_net_pair_ptr, d_net_pair_node, d_net_pair_max;
@@ -125,7 +126,15 @@ struct spx_engine {
   int64_t score_rows[SPX_NUM_PLUGINS] = {0};
   int64_t score_stride[SPX_NUM_PLUGINS] = {0};
   uint32_t evaluated = 0;  // plugins with valid rows
-  int64_t eval_begin = 0, eval_end = 0;
+  // what each plugin's table currently holds: the row range evaluated, and under which feasibility context — the Filter
+  // plugins of that spx_eval call and the caller's mask generation — NormalizeScore-type plugins ran (upstream normalises over
+  // the nodes that passed every Filter of the cycle, so a table is only meaningful together with that set)
+  struct EvalInfo {
+    int64_t begin = 0, end = 0;
+    uint32_t filters = 0;
+    uint64_t ext_gen = 0;
+  } eval_info[SPX_NUM_PLUGINS];
+  uint64_t ext_gen = 0;
 };
 
 namespace {
@@ -198,6 +207,19 @@ int ensure_score_table(spx_engine* e, int plugin) {
   if (rc) return rc;
   e->score_rows[plugin] = e->n_pods;
   e->score_stride[plugin] = e->row_stride;
+  return SPX_OK;
+}
+
+constexpr uint32_t kFilterPlugins = (1u << SPX_PLUGIN_NRT) | (1u << SPX_PLUGIN_NETOVERHEAD);
+// plugins whose NormalizeScore depends on the feasible set of the cycle
+constexpr uint32_t kNormalizingPlugins = (1u << SPX_PLUGIN_ALLOCATABLE) | (1u << SPX_PLUGIN_NETOVERHEAD) | (1u << SPX_PLUGIN_PEAKS);
+
+// rows [b, e) of `plugin` hold results of an spx_eval
+int rows_evaluated(const spx_engine* e, int plugin, int64_t b, int64_t en) {
+  const spx_engine::EvalInfo& i = e->eval_info[plugin];
+  if (!(e->evaluated & (1u << plugin)) || b < i.begin || en > i.end)
+    return fail(e, SPX_ERR_STATE, "rows requested have not been evaluated for this plugin (spx_eval covers [" + std::to_string(i.begin) + ", " +
+                                      std::to_string(i.end) + "))");
   return SPX_OK;
 }
 
@@ -976,6 +998,9 @@ int spx_upload_net_topo(spx_engine* e, const spx_net_topo_soa* t) {
     return rc;
   e->net_n_regions = t->n_regions;
   e->net_n_zones = t->n_zones;
+  e->net_max_cost = SPX_NET_MAX_COST;
+  for (int64_t i = 0; t->region_cost && i < static_cast<int64_t>(t->n_regions) * t->n_regions; ++i) e->net_max_cost = std::max<int64_t>(e->net_max_cost, t->region_cost[i]);
+  for (int64_t i = 0; t->zone_cost && i < static_cast<int64_t>(t->n_zones) * t->n_zones; ++i) e->net_max_cost = std::max<int64_t>(e->net_max_cost, t->zone_cost[i]);
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   e->net_topo = true;
   return SPX_OK;
@@ -988,6 +1013,8 @@ int spx_upload_net_pods(spx_engine* e, const spx_net_pods_soa* t) {
   if (rc) return rc;
   if (t->n_keys <= 0 || !t->pair_ptr) return fail(e, SPX_ERR_ARG, "net pods: key table missing");
   const size_t pairs = static_cast<size_t>(t->pair_ptr[t->n_keys]);
+  e->net_max_pairs = 0;
+  for (int32_t k = 0; k < t->n_keys; ++k) e->net_max_pairs = std::max<int64_t>(e->net_max_pairs, t->pair_ptr[k + 1] - t->pair_ptr[k]);
   if ((rc = upload(e, e->d_net_pod_key, t->pod_key, static_cast<size_t>(t->n_pods) * 4))) return rc;
   if ((rc = upload(e, e->d_net_key_flag, t->key_score_equally, static_cast<size_t>(t->n_keys)))) return rc;
   if ((rc = upload(e, e->d_net_pair_ptr, t->pair_ptr, static_cast<size_t>(t->n_keys + 1) * 4))) return rc;
@@ -1045,8 +1072,17 @@ int spx_upload_quota(spx_engine* e, const spx_quota_soa* t) {
   if (t->n_namespaces < 0 || !t->nom_ptr) return fail(e, SPX_ERR_ARG, "quota: namespace tables missing");
   const size_t P = static_cast<size_t>(t->n_pods), NS = static_cast<size_t>(t->n_namespaces), S = SPX_QUOTA_SLOTS;
   const size_t nn = static_cast<size_t>(t->nom_ptr[t->n_namespaces]);
+  // a column may be NULL only when it has no entries (no namespaces / no nominated pods); upload() rejects the rest.  Every exit
+  // after the first asynchronous copy waits for the stream: the host columns are only borrowed for the call.
   const int64_t dummy[SPX_QUOTA_SLOTS] = {0};
   auto col = [&](const void* p) { return p ? p : static_cast<const void*>(dummy); };
+  struct Drain {
+    spx_engine* e;
+    ~Drain() { (void)hipStreamSynchronize(e->stream); }
+  } drain{e};
+  if ((NS > 0 && (!t->has_quota || !t->used || !t->max || !t->max_present || !t->other_nominated || !t->other_nominated_present)) ||
+      (nn > 0 && (!t->nom_priority || !t->nom_pending_index || !t->nom_req || !t->nom_req_present)))
+    return fail(e, SPX_ERR_ARG, "quota: NULL column in a non-empty table");
   if ((rc = upload(e, e->d_q_pod_ns, t->pod_ns, P * 4))) return rc;
   if ((rc = upload(e, e->d_q_pod_prio, t->pod_priority, P * 4))) return rc;
   if ((rc = upload(e, e->d_q_pod_req, t->pod_req, P * S * 8))) return rc;
@@ -1078,6 +1114,7 @@ int spx_fetch_prefilter(spx_engine* e, int plugin, int64_t row_begin, int64_t ro
   if (plugin != SPX_PLUGIN_CAPACITY || !(e->evaluated & (1u << SPX_PLUGIN_CAPACITY)))
     return fail(e, SPX_ERR_STATE, "CapacityScheduling.PreFilter has not been evaluated");
   if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
+  if (int rc = rows_evaluated(e, SPX_PLUGIN_CAPACITY, row_begin, row_end)) return rc;
   SPX_HIP(e, hipMemcpy(out, static_cast<const uint8_t*>(e->d_q_status.p) + row_begin, static_cast<size_t>(row_end - row_begin),
                        hipMemcpyDeviceToHost));
   return SPX_OK;
@@ -1086,6 +1123,7 @@ int spx_fetch_prefilter(spx_engine* e, int plugin, int64_t row_begin, int64_t ro
 int spx_upload_feasible_mask(spx_engine* e, const uint8_t* mask, int64_t n_pods, int64_t n_nodes) {
   if (!e) return SPX_ERR_ARG;
   SPX_HIP(e, hipSetDevice(e->device));
+  ++e->ext_gen;
   if (!mask) {  // clear
     e->ext_mask = false;
     return SPX_OK;
@@ -1131,6 +1169,10 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (A && (rc = prepare_alloc(e))) return rc;
   const bool W = plugin_mask & (1u << SPX_PLUGIN_NETOVERHEAD);
   if (W && !(e->net_nodes && e->net_topo && e->net_pods)) return fail(e, SPX_ERR_STATE, "NetworkOverhead node/topology/pod tables not uploaded");
+  // the reference accumulates a node's cost in int64 (networkoverhead.go:605-633); the sweeps add in int32 and keep the Filter
+  // verdict in the sign bit, which is exact as long as (largest cost entry) x (most pairs of any workload) stays below 2^31
+  if (W && e->net_max_cost * std::max<int64_t>(e->net_max_pairs, 1) >= (int64_t{1} << 31))
+    return fail(e, SPX_ERR_ARG, "NetworkOverhead: accumulated cost of a node may exceed 2^31 (cost entries x dependency pairs); this build sweeps in int32");
   for (int p = 0; p < 5; ++p)
     if ((plugin_mask & (1u << p)) && (rc = ensure_score_table(e, p))) return rc;
   if (R && (rc = ensure_score_table(e, SPX_PLUGIN_LROC))) return rc;
@@ -1271,8 +1313,20 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   e->timed = true;
   e->best_valid = false;
   e->evaluated |= plugin_mask;
-  e->eval_begin = row_begin;
-  e->eval_end = row_end;
+  if (row_end > row_begin) {
+    const uint32_t filters = plugin_mask & kFilterPlugins;
+    for (int p = 0; p < SPX_NUM_PLUGINS; ++p) {
+      if (!((plugin_mask >> p) & 1u)) continue;
+      spx_engine::EvalInfo& i = e->eval_info[p];
+      const bool same_ctx = i.filters == filters && i.ext_gen == e->ext_gen && i.end > i.begin;
+      if (same_ctx && row_begin <= i.end && row_end >= i.begin) {  // overlapping or adjacent: the evaluated rows grow
+        i.begin = std::min(i.begin, row_begin);
+        i.end = std::max(i.end, row_end);
+      } else {
+        i.begin = row_begin, i.end = row_end, i.filters = filters, i.ext_gen = e->ext_gen;
+      }
+    }
+  }
   return SPX_OK;
 }
 
@@ -1351,6 +1405,7 @@ int spx_fetch_scores(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out) {
   if (plugin < 0 || plugin >= SPX_NUM_PLUGINS || !(e->evaluated & (1u << plugin)))
     return fail(e, SPX_ERR_STATE, "plugin has not been evaluated");
   if (pod_row < 0 || pod_row >= e->n_pods) return fail(e, SPX_ERR_ARG, "pod_row out of range");
+  if (int rc = rows_evaluated(e, plugin, pod_row, pod_row + 1)) return rc;
   // plain synchronous D2H copy of one row: safe from concurrent reader threads after spx_sync()
   const uint8_t* src = static_cast<const uint8_t*>(e->score[plugin].p) + pod_row * e->score_stride[plugin];
   SPX_HIP(e, hipMemcpy(out, src, static_cast<size_t>(e->n_nodes), hipMemcpyDeviceToHost));
@@ -1362,6 +1417,7 @@ int spx_fetch_status(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out) {
   if (plugin < 0 || plugin >= SPX_NUM_PLUGINS || !e->status[plugin].p || !(e->evaluated & (1u << plugin)))
     return fail(e, SPX_ERR_STATE, "plugin has no evaluated Filter table");
   if (pod_row < 0 || pod_row >= e->n_pods) return fail(e, SPX_ERR_ARG, "pod_row out of range");
+  if (int rc = rows_evaluated(e, plugin, pod_row, pod_row + 1)) return rc;
   const uint8_t* src = static_cast<const uint8_t*>(e->status[plugin].p) + pod_row * e->row_stride;
   SPX_HIP(e, hipMemcpy(out, src, static_cast<size_t>(e->n_nodes), hipMemcpyDeviceToHost));
   return SPX_OK;
@@ -1455,6 +1511,8 @@ int spx_fetch_score_rows(spx_engine* e, int plugin, int64_t row_begin, int64_t r
   if (!e || !out) return SPX_ERR_ARG;
   if (plugin < 0 || plugin >= SPX_NUM_PLUGINS || !e->score[plugin].p || !(e->evaluated & (1u << plugin)))
     return fail(e, SPX_ERR_STATE, "plugin has not been evaluated");
+  if (row_end > row_begin)
+    if (int rc = rows_evaluated(e, plugin, row_begin, row_end)) return rc;
   return fetch_rows(e, static_cast<const uint8_t*>(e->score[plugin].p), e->score_stride[plugin], row_begin, row_end, out, out_stride);
 }
 
@@ -1462,6 +1520,8 @@ int spx_fetch_status_rows(spx_engine* e, int plugin, int64_t row_begin, int64_t 
   if (!e || !out) return SPX_ERR_ARG;
   if (plugin < 0 || plugin >= SPX_NUM_PLUGINS || !e->status[plugin].p || !(e->evaluated & (1u << plugin)))
     return fail(e, SPX_ERR_STATE, "plugin has no evaluated Filter table");
+  if (row_end > row_begin)
+    if (int rc = rows_evaluated(e, plugin, row_begin, row_end)) return rc;
   return fetch_rows(e, static_cast<const uint8_t*>(e->status[plugin].p), e->row_stride, row_begin, row_end, out, out_stride);
 }
 
@@ -1555,6 +1615,19 @@ int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_
   if (e->n_nodes <= 0 || e->n_pods <= 0) return fail(e, SPX_ERR_STATE, "shape unknown");
   if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
   int rc;
+  // every table in the sum must cover the rows, and the normalising plugins must have been evaluated under exactly the Filter
+  // set this argmax uses (their NormalizeScore ran over the nodes that passed those Filters, as upstream's RunScorePlugins does)
+  for (int p = 0; p < SPX_NUM_PLUGINS && row_end > row_begin; ++p) {
+    if (!((plugin_mask >> p) & 1u)) continue;
+    if ((rc = rows_evaluated(e, p, row_begin, row_end))) return rc;
+    const spx_engine::EvalInfo& i = e->eval_info[p];
+    const bool ctx_matters = ((kNormalizingPlugins >> p) & 1u) != 0;
+    uint32_t want = plugin_mask & kFilterPlugins;
+    if (p == SPX_PLUGIN_NETOVERHEAD) want &= ~(1u << SPX_PLUGIN_NETOVERHEAD), want |= i.filters & (1u << SPX_PLUGIN_NETOVERHEAD);  // its own Filter is implied
+    if (ctx_matters && (i.filters != want || i.ext_gen != e->ext_gen))
+      return fail(e, SPX_ERR_STATE, "spx_eval_best: a normalising plugin (Allocatable / NetworkOverhead / Peaks) was evaluated under a different Filter set "
+                                    "or feasibility mask than this argmax uses; evaluate the whole profile in one spx_eval");
+  }
   const size_t P = static_cast<size_t>(e->n_pods);
   if ((rc = ensure(e, e->d_best, P * 20))) return rc;
   spx::ProfileArgs pa{};

@@ -20,6 +20,7 @@
 // plugins read (pkg/networkaware/util/util.go:67-75; key strings as in manifests/appgroup/deploy-onlineBoutique-*.yaml).
 #include <cstdint>
 #include <algorithm>
+#include <cctype>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -212,13 +213,19 @@ bool canonical_quantity(const std::string& t, bool milli, int64_t* out) {
   if (i < n && (t[i] == '+' || t[i] == '-')) neg = t[i++] == '-';
   unsigned __int128 mant = 0;
   int dec = 0;  // value = mant * 10^dec
-  bool any = false, frac = false;
+  bool any = false, frac = false, sticky = false;
   for (; i < n; ++i) {
     const char c = t[i];
     if (c >= '0' && c <= '9') {
-      if (mant > UINT64_MAX / 10) return false;  // more than ~19 significant digits: not a quantity this engine can hold
-      mant = mant * 10 + static_cast<unsigned>(c - '0');
-      if (frac) --dec;
+      if (mant > UINT64_MAX / 10) {
+        // more than ~19 significant digits (apimachinery holds them in an inf.Dec): keep the leading ones exactly and remember
+        // that something non-zero was dropped — enough for the round-up that Value() / MilliValue() apply
+        if (c != '0') sticky = true;
+        if (!frac) ++dec;
+      } else {
+        mant = mant * 10 + static_cast<unsigned>(c - '0');
+        if (frac) --dec;
+      }
       any = true;
     } else if (c == '.' && !frac) {
       frac = true;
@@ -261,7 +268,7 @@ bool canonical_quantity(const std::string& t, bool milli, int64_t* out) {
   if (milli) dec += 3;
   const unsigned __int128 kMax = static_cast<unsigned __int128>(INT64_MAX);
   mant <<= bin;  // mant < 2^68 here, bin <= 60: fits 128 bits; the range check below decides
-  bool inexact = false;
+  bool inexact = sticky;
   while (dec > 0 && mant != 0) {
     if (mant > kMax) return false;
     mant *= 10;
@@ -273,9 +280,10 @@ bool canonical_quantity(const std::string& t, bool milli, int64_t* out) {
     ++dec;
   }
   if (mant > kMax) return false;
-  int64_t v = static_cast<int64_t>(mant);
-  if (neg) v = -v;                 // ceil of a negative value truncates toward zero
-  else if (inexact) v += 1;        // ceil
+  // inexact values round AWAY from zero for either sign (negativeScaleInt64 in apimachinery's amount.go: value++ / value--)
+  if (inexact && mant == kMax) return false;
+  int64_t v = static_cast<int64_t>(mant) + (inexact ? 1 : 0);
+  if (neg) v = -v;
   *out = v;
   return true;
 }
@@ -342,6 +350,21 @@ struct NodeRow {
 struct spx_ingest_quota;
 static void free_quota(spx_ingest_quota* q);
 
+// AppGroup CR as decoded (selectors still strings: their ids are assigned, and re-assigned, in lexicographic order)
+struct DepRow {
+  std::string selector;
+  int64_t max_cost = 0;
+};
+struct WorkloadRow {
+  std::string selector;
+  std::vector<DepRow> deps;
+};
+struct GroupRow {
+  std::string name;
+  std::vector<WorkloadRow> workloads;
+  std::vector<std::pair<std::string, int64_t>> topo;  // Status.TopologyOrder as written (the plugins binary-search it as is)
+};
+
 struct spx_ingest {
   spx_ingest_quota* quota = nullptr;  // ElasticQuota tables (end of this file)
   Interner res;
@@ -388,10 +411,18 @@ struct spx_ingest {
   std::vector<int32_t> p_ctr_ptr{0}, p_req_ptr{0}, p_lim_ptr{0}, p_ovh_ptr{0}, p_req_res, p_lim_res, p_ovh_res, p_priority, p_appgroup, p_selector, p_ns;
   std::vector<uint8_t> p_kind;
   std::vector<int64_t> p_req_qty, p_lim_qty, p_ovh_qty, p_queue_ts;
+  std::vector<int32_t> p_nominated;  // status.nominatedNodeName as a node index of the snapshot, -1 = none / unknown node
   spx_pod_objects pod_table{};
   // ---- AppGroup / NetworkTopology CRs
   std::vector<int32_t> g_wl_ptr{0}, g_wl_selector, g_dep_ptr{0}, g_dep_selector, g_topo_ptr{0}, g_topo_selector, g_topo_index, g_placed_ptr{0};
   std::vector<int64_t> g_dep_max_cost;
+  // ---- load-watcher metrics (watcher.WatcherMetrics)
+  std::vector<uint8_t> m_present, m_nil, m_type, m_op;
+  std::vector<int32_t> m_ptr;
+  std::vector<double> m_value;
+  spx_metrics_objects metrics_table{};
+  bool metrics_valid = false;
+  std::vector<GroupRow> group_rows;  // indexed by AppGroup name id (kind 3) — the id pods carry; empty row = no CR seen
   spx_appgroup_objects group_table{};
   std::vector<std::vector<std::pair<int32_t, int64_t>>> nt_region, nt_zone;  // per origin id: (destination id, cost) in document order
   std::vector<int32_t> nt_rc_ptr{0}, nt_rc_dest, nt_zc_ptr{0}, nt_zc_dest;
@@ -852,7 +883,7 @@ bool decode_container(spx_ingest* h, Reader& r, std::string& buf, bool init, Ctr
 bool decode_pod(spx_ingest* h, Reader& r) {
   std::vector<CtrRow> init, app;
   std::vector<std::pair<int32_t, int64_t>> overhead;
-  std::string buf, ns, group, selector, created;
+  std::string buf, ns, group, selector, created, nominated;
   bool has_group = false, has_selector = false;
   int64_t priority = 0;
   const bool ok = r.object([&](const std::string& k) {
@@ -892,6 +923,8 @@ bool decode_pod(spx_ingest* h, Reader& r) {
         return r.skip();
       });
     }
+    if (k == "status" && r.peek() == '{')
+      return r.object([&](const std::string& sk) { return (sk == "nominatedNodeName" && r.peek() == '"') ? r.str(nominated) : r.skip(); });
     return r.skip();
   });
   if (!ok) return false;
@@ -912,6 +945,10 @@ bool decode_pod(spx_ingest* h, Reader& r) {
   h->p_appgroup.push_back((has_group && !group.empty()) ? h->appgroups.id(group) : -1);
   h->p_selector.push_back((has_selector && !selector.empty()) ? h->selectors.id(selector) : -1);
   h->p_ns.push_back(h->namespaces.id(ns));
+  {
+    const auto it = nominated.empty() ? h->node_index.end() : h->node_index.find(nominated);
+    h->p_nominated.push_back(it == h->node_index.end() ? -1 : static_cast<int32_t>(it->second));
+  }
   return true;
 }
 
@@ -961,6 +998,12 @@ extern "C" int spx_ingest_nodes_json(spx_ingest* h, const char* json, int64_t le
   return rc;
 }
 
+namespace {
+void normalize_selectors(spx_ingest* h);
+void freeze_groups(spx_ingest* h);
+void rebuild_nominated(spx_ingest* h);
+}  // namespace
+
 extern "C" int spx_ingest_pods_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_objects_out) {
   if (!h || !json || len < 0) return SPX_ERR_ARG;
   // a failed document must not leave half a pod behind: remember the sizes and roll back
@@ -968,11 +1011,15 @@ extern "C" int spx_ingest_pods_json(spx_ingest* h, const char* json, int64_t len
   const int rc = run_decoder(h, json, len, n_objects_out, [&](Reader& r) { return decode_pod(h, r); });
   if (rc != SPX_OK) {
     h->p_priority.resize(n_pods), h->p_queue_ts.resize(n_pods), h->p_appgroup.resize(n_pods), h->p_selector.resize(n_pods), h->p_ns.resize(n_pods);
+    h->p_nominated.resize(n_pods);
     h->p_ctr_ptr.resize(n_pods + 1), h->p_ovh_ptr.resize(n_pods + 1), h->p_kind.resize(n_ctr), h->p_req_ptr.resize(n_ctr + 1), h->p_lim_ptr.resize(n_ctr + 1);
     h->p_req_res.resize(n_req), h->p_req_qty.resize(n_req), h->p_lim_res.resize(n_lim), h->p_lim_qty.resize(n_lim);
     h->p_ovh_res.resize(n_ovh), h->p_ovh_qty.resize(n_ovh);
   }
+  normalize_selectors(h);  // pod labels may have introduced selectors (first-seen ids) and AppGroup names
+  freeze_groups(h);
   freeze_pods(h);
+  rebuild_nominated(h);
   refresh_classes(h);
   return rc;
 }
@@ -982,7 +1029,9 @@ extern "C" int spx_ingest_pods_reset(spx_ingest* h) {
   h->p_ctr_ptr.assign(1, 0), h->p_req_ptr.assign(1, 0), h->p_lim_ptr.assign(1, 0), h->p_ovh_ptr.assign(1, 0);
   h->p_kind.clear(), h->p_req_res.clear(), h->p_req_qty.clear(), h->p_lim_res.clear(), h->p_lim_qty.clear(), h->p_ovh_res.clear(), h->p_ovh_qty.clear();
   h->p_priority.clear(), h->p_queue_ts.clear(), h->p_appgroup.clear(), h->p_selector.clear(), h->p_ns.clear();
+  h->p_nominated.clear();
   freeze_pods(h);
+  rebuild_nominated(h);
   return SPX_OK;
 }
 
@@ -1007,20 +1056,6 @@ extern "C" int32_t spx_ingest_name_id(const spx_ingest* h, int32_t kind, const c
 // ====================================================================== AppGroup / NetworkTopology CRs (network-aware plugins)
 // Schemas: manifests/crds/appgroup.diktyo.x-k8s.io_appgroups.yaml, networktopology.diktyo.x-k8s.io_networktopologies.yaml.
 namespace {
-
-struct DepRow {
-  std::string selector;
-  int64_t max_cost = 0;
-};
-struct WorkloadRow {
-  std::string selector;
-  std::vector<DepRow> deps;
-};
-struct GroupRow {
-  std::string name;
-  std::vector<WorkloadRow> workloads;
-  std::vector<std::pair<std::string, int64_t>> topo;  // Status.TopologyOrder as written (the plugins binary-search it as is)
-};
 
 // {"workload": {"selector": "..."}} -> selector
 bool workload_selector(Reader& r, std::string& out, bool* found) {
@@ -1092,7 +1127,43 @@ bool decode_appgroup(spx_ingest* h, Reader& r, GroupRow* g) {
 }
 
 
+// Selector ids must preserve the lexicographic order of the selector strings (FindPodOrder binary-searches TopologyOrder with
+// string comparisons, util.go:138-153).  Pods intern selectors first-seen and AppGroups may arrive in any order, so the table
+// is re-sorted whenever it is out of order and the ids already handed out — the pod table's selector column — are remapped.
+void normalize_selectors(spx_ingest* h) {
+  std::vector<std::string>& names = h->selectors.names;
+  if (std::is_sorted(names.begin(), names.end())) return;
+  std::vector<int32_t> order(names.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = static_cast<int32_t>(i);
+  std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return names[static_cast<size_t>(a)] < names[static_cast<size_t>(b)]; });
+  std::vector<int32_t> remap(names.size());
+  std::vector<std::string> sorted(names.size());
+  for (size_t i = 0; i < order.size(); ++i) {
+    remap[static_cast<size_t>(order[i])] = static_cast<int32_t>(i);
+    sorted[i] = names[static_cast<size_t>(order[i])];
+  }
+  names = std::move(sorted);
+  h->selectors.ids.clear();
+  for (size_t i = 0; i < names.size(); ++i) h->selectors.ids.emplace(names[i], static_cast<int32_t>(i));
+  for (int32_t& v : h->p_selector)
+    if (v >= 0) v = remap[static_cast<size_t>(v)];
+}
+
+// group rows (indexed by AppGroup name id) -> the CSR columns of spx_appgroup_objects
 void freeze_groups(spx_ingest* h) {
+  h->group_rows.resize(h->appgroups.names.size());  // groups only named by pod labels so far: no workloads
+  h->g_wl_ptr.assign(1, 0), h->g_dep_ptr.assign(1, 0), h->g_topo_ptr.assign(1, 0);
+  h->g_wl_selector.clear(), h->g_dep_selector.clear(), h->g_dep_max_cost.clear(), h->g_topo_selector.clear(), h->g_topo_index.clear();
+  for (const GroupRow& g : h->group_rows) {
+    for (const WorkloadRow& w : g.workloads) {
+      h->g_wl_selector.push_back(h->selectors.find(w.selector.c_str()));
+      for (const DepRow& d : w.deps) h->g_dep_selector.push_back(h->selectors.find(d.selector.c_str())), h->g_dep_max_cost.push_back(d.max_cost);
+      h->g_dep_ptr.push_back(static_cast<int32_t>(h->g_dep_selector.size()));
+    }
+    h->g_wl_ptr.push_back(static_cast<int32_t>(h->g_wl_selector.size()));
+    for (const auto& t : g.topo) h->g_topo_selector.push_back(h->selectors.find(t.first.c_str())), h->g_topo_index.push_back(static_cast<int32_t>(t.second));
+    h->g_topo_ptr.push_back(static_cast<int32_t>(h->g_topo_selector.size()));
+  }
   spx_appgroup_objects& t = h->group_table;
   t.n_groups = static_cast<int32_t>(h->g_wl_ptr.size() - 1);
   t.wl_ptr = h->g_wl_ptr.data(), t.wl_selector = h->g_wl_selector.data();
@@ -1134,34 +1205,19 @@ extern "C" int spx_ingest_appgroups_json(spx_ingest* h, const char* json, int64_
     return decode_appgroup(h, r, &groups.back());
   });
   if (rc != SPX_OK) return rc;
-  std::vector<std::string> all;
-  for (const GroupRow& g : groups) {
+  for (GroupRow& g : groups) {  // a group's row sits at its name id, whatever order CRs and pods arrive in; a later CR replaces an earlier one
+    const int32_t id = h->appgroups.id(g.name);
+    if (h->group_rows.size() <= static_cast<size_t>(id)) h->group_rows.resize(static_cast<size_t>(id) + 1);
     for (const WorkloadRow& w : g.workloads) {
-      all.push_back(w.selector);
-      for (const DepRow& d : w.deps) all.push_back(d.selector);
+      h->selectors.id(w.selector);
+      for (const DepRow& d : w.deps) h->selectors.id(d.selector);
     }
-    for (const auto& t : g.topo) all.push_back(t.first);
+    for (const auto& t : g.topo) h->selectors.id(t.first);
+    h->group_rows[static_cast<size_t>(id)] = std::move(g);
   }
-  std::sort(all.begin(), all.end());
-  all.erase(std::unique(all.begin(), all.end()), all.end());
-  if (h->selectors.names.empty()) {
-    for (const std::string& s : all) h->selectors.id(s);
-  } else {
-    for (const std::string& s : all)
-      if (h->selectors.find(s.c_str()) < 0) return h->err = "workload selector '" + s + "' is not in the seeded (lexicographically ordered) selector table", SPX_ERR_ARG;
-  }
-  for (const GroupRow& g : groups) {
-    h->appgroups.id(g.name);
-    for (const WorkloadRow& w : g.workloads) {
-      h->g_wl_selector.push_back(h->selectors.find(w.selector.c_str()));
-      for (const DepRow& d : w.deps) h->g_dep_selector.push_back(h->selectors.find(d.selector.c_str())), h->g_dep_max_cost.push_back(d.max_cost);
-      h->g_dep_ptr.push_back(static_cast<int32_t>(h->g_dep_selector.size()));
-    }
-    h->g_wl_ptr.push_back(static_cast<int32_t>(h->g_wl_selector.size()));
-    for (const auto& t : g.topo) h->g_topo_selector.push_back(h->selectors.find(t.first.c_str())), h->g_topo_index.push_back(static_cast<int32_t>(t.second));
-    h->g_topo_ptr.push_back(static_cast<int32_t>(h->g_topo_selector.size()));
-  }
+  normalize_selectors(h);
   freeze_groups(h);
+  freeze_pods(h);  // the selector column may have been renumbered
   return SPX_OK;
 }
 
@@ -1243,6 +1299,122 @@ extern "C" int spx_ingest_nettopo_json(spx_ingest* h, const char* json, int64_t 
 extern "C" const spx_nettopo_objects* spx_ingest_nettopo_objects(const spx_ingest* h) { return h ? &h->nettopo_table : nullptr; }
 
 
+// ====================================================================== load-watcher response (trimaran Collector)
+// What Collector.updateMetrics stores (collector.go:139-150): the JSON the load-watcher service returns, decoded into
+// watcher.WatcherMetrics.  That struct lives in github.com/paypal/load-watcher v0.2.4 (pkg/watcher/api.go), which is NOT vendored
+// under the reference; the reference's tests only round-trip the Go struct through encoding/json.  The field names below are the
+// struct's json tags as published (timestamp, window{duration,start,end}, source, data{NodeMetricsMap{<node>{metrics[{name,type,
+// operator,rollup,value}],tags,metadata}}}) — PARITY UNPINNED: no golden document exists in the reference.  Decoding follows
+// encoding/json: member names match case-insensitively, unknown members are ignored, null leaves the zero value.  So a document
+// without data.NodeMetricsMap (e.g. the draft payload in kep/61-Trimaran-real-load-aware-scheduling/README.md:301-352, which
+// lists nodes directly under "data") yields a nil map: "Metrics not available from watcher" (collector.go:113-116).
+// Metric.Type / Operator are compared by identity with the load-watcher constants (targetloadpacking.go:134-135,
+// resourcestats.go:94-103): "CPU", "Memory"; "AVG", "STD", "Latest", "" — anything else is SPX_MT_OTHER / SPX_MO_OTHER.
+namespace {
+
+bool ieq(const std::string& a, const char* b) {
+  size_t i = 0;
+  for (; i < a.size() && b[i]; ++i)
+    if (std::tolower(static_cast<unsigned char>(a[i])) != std::tolower(static_cast<unsigned char>(b[i]))) return false;
+  return i == a.size() && !b[i];
+}
+
+struct MetricRow {
+  uint8_t type = SPX_MT_OTHER, op = SPX_MO_EMPTY;
+  double value = 0.0;
+};
+
+bool decode_metric(Reader& r, MetricRow* m, std::string& buf) {
+  return r.object([&](const std::string& k) {
+    if (ieq(k, "type") && r.peek() == '"') {
+      if (!r.str(buf)) return false;
+      m->type = buf == "CPU" ? SPX_MT_CPU : (buf == "Memory" ? SPX_MT_MEMORY : SPX_MT_OTHER);
+      return true;
+    }
+    if (ieq(k, "operator") && r.peek() == '"') {
+      if (!r.str(buf)) return false;
+      m->op = buf == "AVG" ? SPX_MO_AVG : (buf == "STD" ? SPX_MO_STD : (buf == "Latest" ? SPX_MO_LATEST : (buf.empty() ? SPX_MO_EMPTY : SPX_MO_OTHER)));
+      return true;
+    }
+    if (ieq(k, "value") && r.peek() != 'n' && r.peek() != '"') {
+      if (!r.scalar(buf)) return false;
+      char* endp = nullptr;
+      m->value = std::strtod(buf.c_str(), &endp);
+      return (endp && *endp == '\0') || r.fail("bad metric value");
+    }
+    return r.skip();
+  });
+}
+
+}  // namespace
+
+extern "C" int spx_ingest_metrics_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_nodes_out, int64_t* n_unknown_out) {
+  if (!h || !json || len < 0) return SPX_ERR_ARG;
+  h->err.clear();
+  const size_t N = h->rows.size();
+  std::vector<uint8_t> present(N, 0), isnil(N, 0);
+  std::vector<std::vector<MetricRow>> lists(N);
+  bool map_nil = true;
+  int64_t window_end = 0, n_nodes = 0, unknown = 0;
+  std::string buf;
+  Reader r{json, json + len, {}, {}};
+  bool ok = r.object([&](const std::string& k) {
+    if (ieq(k, "window") && r.peek() == '{')
+      return r.object([&](const std::string& wk) {
+        if (ieq(wk, "end") && r.peek() != 'n' && r.peek() != '"') return r.scalar(buf) && (canonical_quantity(buf, false, &window_end) || r.fail("bad window.end"));
+        return r.skip();
+      });
+    if (ieq(k, "data") && r.peek() == '{')
+      return r.object([&](const std::string& dk) {
+        if (!ieq(dk, "NodeMetricsMap") || r.peek() != '{') return r.skip();  // null / absent: the map stays nil
+        map_nil = false;
+        return r.object([&](const std::string& node) {
+          ++n_nodes;
+          const auto it = h->node_index.find(node);
+          if (it == h->node_index.end()) {
+            ++unknown;
+            return r.skip();
+          }
+          const size_t ni = static_cast<size_t>(it->second);
+          present[ni] = 1, isnil[ni] = 1, lists[ni].clear();  // a repeated key replaces the earlier entry (Go map assignment)
+          if (r.peek() != '{') return r.skip();
+          return r.object([&](const std::string& nk) {
+            if (!ieq(nk, "metrics") || r.peek() != '[') return r.skip();  // null: Metrics stays a nil slice
+            isnil[ni] = 0;
+            return r.array([&] {
+              MetricRow m;
+              if (r.peek() != '{') return r.fail("metric is not an object");
+              if (!decode_metric(r, &m, buf)) return false;
+              lists[ni].push_back(m);
+              return true;
+            });
+          });
+        });
+      });
+    return r.skip();
+  });
+  if (ok && r.peek() != '\0') ok = r.fail("trailing characters");
+  if (n_nodes_out) *n_nodes_out = n_nodes;
+  if (n_unknown_out) *n_unknown_out = unknown;
+  if (!ok) return h->err = "JSON: " + r.err, SPX_ERR_ARG;
+  // a successful fetch replaces the whole snapshot (collector.metrics = *metrics); a failed one keeps the last (:140-150)
+  h->m_present = std::move(present), h->m_nil = std::move(isnil);
+  h->m_ptr.assign(1, 0), h->m_type.clear(), h->m_op.clear(), h->m_value.clear();
+  for (size_t i = 0; i < N; ++i) {
+    for (const MetricRow& m : lists[i]) h->m_type.push_back(m.type), h->m_op.push_back(m.op), h->m_value.push_back(m.value);
+    h->m_ptr.push_back(static_cast<int32_t>(h->m_type.size()));
+  }
+  spx_metrics_objects& t = h->metrics_table;
+  t.map_is_nil = map_nil ? 1 : 0;
+  t.window_end = window_end;
+  t.node_present = h->m_present.data(), t.node_metrics_nil = h->m_nil.data();
+  t.m_ptr = h->m_ptr.data(), t.m_type = h->m_type.data(), t.m_op = h->m_op.data(), t.m_value = h->m_value.data();
+  h->metrics_valid = true;
+  return SPX_OK;
+}
+
+extern "C" const spx_metrics_objects* spx_ingest_metrics_objects(const spx_ingest* h) { return (h && h->metrics_valid) ? &h->metrics_table : nullptr; }
+
 // ====================================================================== ElasticQuota CRs (CapacityScheduling)
 // Schema: manifests/crds/scheduling.x-k8s.io_elasticquotas.yaml (spec.min, spec.max, status.used: ResourceLists; one quota per
 // namespace).  Semantics as newElasticQuotaInfo / framework.NewResource read them (elasticquota.go:70-87): a nil Min becomes the
@@ -1256,6 +1428,12 @@ struct spx_ingest_quota {
   spx_pod_objects no_pods{};
   int32_t zero_ptr[2] = {0, 0};
   spx_quota_objects table{};
+  // nominated pods = the pending pods that carry status.nominatedNodeName for a node of the snapshot (what
+  // PodNominator.NominatedPodsForNode yields over the node list, capacity_scheduling.go:231-253), as a compact pod table
+  std::vector<int32_t> nom_ns, nom_priority, n_ctr_ptr, n_req_ptr, n_lim_ptr, n_ovh_ptr, n_req_res, n_lim_res, n_ovh_res;
+  std::vector<int64_t> nom_pending, n_req_qty, n_lim_qty, n_ovh_qty;
+  std::vector<uint8_t> n_kind;
+  spx_pod_objects nom_pods{};
 };
 
 namespace {
@@ -1367,11 +1545,54 @@ extern "C" int spx_ingest_quota_json(spx_ingest* h, const char* json, int64_t le
   q->no_pods = spx_pod_objects{};
   q->no_pods.ctr_ptr = q->no_pods.ovh_ptr = q->no_pods.req_ptr = q->no_pods.lim_ptr = q->zero_ptr;
   t.nom_pods = &q->no_pods;
+  rebuild_nominated(h);
   refresh_classes(h);
   return SPX_OK;
 }
 
 extern "C" const spx_quota_objects* spx_ingest_quota_objects(const spx_ingest* h) { return (h && h->quota) ? &h->quota->table : nullptr; }
+
+namespace {
+void rebuild_nominated(spx_ingest* h) {
+  spx_ingest_quota* q = h->quota;
+  if (!q) return;  // no quota table yet: spx_ingest_quota_json calls this again
+  q->nom_ns.clear(), q->nom_priority.clear(), q->nom_pending.clear();
+  q->n_ctr_ptr.assign(1, 0), q->n_req_ptr.assign(1, 0), q->n_lim_ptr.assign(1, 0), q->n_ovh_ptr.assign(1, 0);
+  q->n_kind.clear(), q->n_req_res.clear(), q->n_req_qty.clear(), q->n_lim_res.clear(), q->n_lim_qty.clear(), q->n_ovh_res.clear(), q->n_ovh_qty.clear();
+  const size_t P = h->p_nominated.size();
+  for (size_t i = 0; i < P; ++i) {
+    if (h->p_nominated[i] < 0) continue;
+    q->nom_ns.push_back(h->p_ns[i]);
+    q->nom_priority.push_back(h->p_priority[i]);
+    q->nom_pending.push_back(static_cast<int64_t>(i));  // the same pod object as pending row i: skipped for itself (p.UID == pod.UID, :236)
+    for (int32_t c = h->p_ctr_ptr[i]; c < h->p_ctr_ptr[i + 1]; ++c) {
+      q->n_kind.push_back(h->p_kind[static_cast<size_t>(c)]);
+      for (int32_t k = h->p_req_ptr[static_cast<size_t>(c)]; k < h->p_req_ptr[static_cast<size_t>(c) + 1]; ++k)
+        q->n_req_res.push_back(h->p_req_res[static_cast<size_t>(k)]), q->n_req_qty.push_back(h->p_req_qty[static_cast<size_t>(k)]);
+      for (int32_t k = h->p_lim_ptr[static_cast<size_t>(c)]; k < h->p_lim_ptr[static_cast<size_t>(c) + 1]; ++k)
+        q->n_lim_res.push_back(h->p_lim_res[static_cast<size_t>(k)]), q->n_lim_qty.push_back(h->p_lim_qty[static_cast<size_t>(k)]);
+      q->n_req_ptr.push_back(static_cast<int32_t>(q->n_req_res.size()));
+      q->n_lim_ptr.push_back(static_cast<int32_t>(q->n_lim_res.size()));
+    }
+    q->n_ctr_ptr.push_back(static_cast<int32_t>(q->n_kind.size()));
+    for (int32_t k = h->p_ovh_ptr[i]; k < h->p_ovh_ptr[i + 1]; ++k)
+      q->n_ovh_res.push_back(h->p_ovh_res[static_cast<size_t>(k)]), q->n_ovh_qty.push_back(h->p_ovh_qty[static_cast<size_t>(k)]);
+    q->n_ovh_ptr.push_back(static_cast<int32_t>(q->n_ovh_res.size()));
+  }
+  spx_pod_objects& t = q->nom_pods;
+  t = spx_pod_objects{};
+  t.n_pods = static_cast<int64_t>(q->nom_ns.size());
+  t.ctr_ptr = q->n_ctr_ptr.data(), t.ctr_kind = q->n_kind.data();
+  t.req_ptr = q->n_req_ptr.data(), t.req_res = q->n_req_res.data(), t.req_qty = q->n_req_qty.data();
+  t.lim_ptr = q->n_lim_ptr.data(), t.lim_res = q->n_lim_res.data(), t.lim_qty = q->n_lim_qty.data();
+  t.ovh_ptr = q->n_ovh_ptr.data(), t.ovh_res = q->n_ovh_res.data(), t.ovh_qty = q->n_ovh_qty.data();
+  t.priority = q->nom_priority.data(), t.ns = q->nom_ns.data();
+  spx_quota_objects& qt = q->table;
+  qt.n_nominated = t.n_pods;
+  qt.nom_ns = q->nom_ns.data(), qt.nom_priority = q->nom_priority.data(), qt.nom_pending_index = q->nom_pending.data();
+  qt.nom_pods = t.n_pods ? &q->nom_pods : &q->no_pods;
+}
+}  // namespace
 
 static void free_quota(spx_ingest_quota* q) { delete q; }
 

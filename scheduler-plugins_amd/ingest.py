@@ -109,6 +109,17 @@ class NrtIngest:
             raise ValueError(self._lib.spx_ingest_error(self._h).decode())
         return n.value, unk.value
 
+    def feed_metrics(self, json_bytes: bytes):
+        """load-watcher response -> (entries of data.NodeMetricsMap, entries naming a node outside the snapshot)"""
+        n, unk = C.c_int64(), C.c_int64()
+        if self._lib.spx_ingest_metrics_json(self._h, json_bytes, len(json_bytes), C.byref(n), C.byref(unk)) != 0:
+            raise ValueError(self._lib.spx_ingest_error(self._h).decode())
+        return n.value, unk.value
+
+    def metrics_objects(self) -> Optional[_Borrowed]:
+        p = self._lib.spx_ingest_metrics_objects(self._h)
+        return _Borrowed(p, self) if p else None
+
     def quota_objects(self) -> _Borrowed:
         return _Borrowed(self._lib.spx_ingest_quota_objects(self._h), self)
 

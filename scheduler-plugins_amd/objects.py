@@ -43,6 +43,10 @@ def parse_quantity(q) -> Fraction:
 
 
 def _ceil(fr: Fraction) -> int:
+    """Quantity.Value() / MilliValue() rounding: inexact values go AWAY from zero for either sign (apimachinery
+    resource/math.go negativeScaleInt64: value++ for positive, value-- for negative amounts) — a ceiling only for v >= 0"""
+    if fr < 0:
+        return -_ceil(-fr)
     return -((-fr.numerator) // fr.denominator)
 
 
@@ -80,7 +84,7 @@ class Resources:
         return self.ids[name]
 
     def canonical(self, name: str, q) -> int:
-        """cpu -> MilliValue() (ceil of milli), everything else -> Value() (ceil)."""
+        """cpu -> MilliValue(), everything else -> Value(); both round inexact values away from zero."""
         fr = parse_quantity(q)
         return _ceil(fr * 1000) if name == "cpu" else _ceil(fr)
 

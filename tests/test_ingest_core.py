@@ -190,3 +190,16 @@ def test_ingested_tables_flatten_like_built_ones(hdr):
     with NrtIngest(["n0"]) as ing:
         ing.feed_pods(json.dumps(doc).encode())
         assert flat(ing.pod_objects()) == flat(built)
+
+
+def test_quantity_rounds_away_from_zero_and_keeps_long_mantissas():
+    """resource.Quantity.Value() / MilliValue() round inexact values away from zero for either sign (negativeScaleInt64 in
+    apimachinery's amount.go: value++ / value--), and apimachinery accepts more significant digits than an int64 holds"""
+    from scheduler_plugins_amd.ingest import quantity
+    assert quantity("-1.5", False) == -2 and quantity("-1.5", True) == -1500
+    assert quantity("-100m", False) == -1 and quantity("-1", False) == -1 and quantity("-0.0001", True) == -1
+    assert quantity("1.5", False) == 2 and quantity("100m", False) == 1
+    assert quantity("1.00000000000000000000001", False) == 2          # 24 significant digits: sticky remainder
+    assert quantity("1.00000000000000000000000", False) == 1
+    assert quantity("123456789012345678901234n", False) == 123456789012346   # 1.2345...e14 rounded up
+    assert quantity("12345678901234567890123", False) is None          # really out of range

@@ -108,13 +108,50 @@ def test_unit_test_fixtures_round_trip(hdr):
         assert ing.nettopo_objects().struct.rc_ptr[ing.nettopo_objects().struct.n_regions] == 1
 
 
-def test_selectors_must_be_ordered(hdr):
+def test_selector_ids_stay_lexicographic_whatever_the_feed_order(hdr):
+    """FindPodOrder compares selector strings (util.go:138-153), so selector ids must follow the strings' order — also when a
+    caller-seeded table lacks a selector, and when pods (which intern selectors first-seen) arrive before the AppGroup CRs"""
     with NrtIngest(["n0"]) as ing:
-        ing.seed("selector", ["p1", "p2"])             # a caller-fixed table that lacks p3
-        with pytest.raises(ValueError, match="selector 'p3'"):
-            ing.feed_appgroups(json.dumps(appgroup_cr("basic", GN.APPGROUP_BASIC)).encode())
+        ing.seed("selector", ["p2", "p1"])             # out of order, and lacks p3
+        ing.feed_appgroups(json.dumps(appgroup_cr("basic", GN.APPGROUP_BASIC)).encode())
+        assert [ing.name_id("selector", s) for s in ("p1", "p2", "p3")] == [0, 1, 2]
         with pytest.raises(ValueError, match="selector"):
             ing.feed_appgroups(b'{"metadata": {"name": "g"}, "spec": {"workloads": [{"dependencies": []}]}}')
+
+
+def test_pods_before_appgroups_and_reingest(hdr):
+    """group rows are indexed by the AppGroup name id the pods carry; a re-ingested CR replaces its row; a group known only from
+    pod labels has an empty row"""
+    def pod(group, sel):
+        return {"metadata": {"namespace": "default", "labels": {"appgroup.diktyo.x-k8s.io": group, "appgroup.diktyo.x-k8s.io.workload": sel}},
+                "spec": {"containers": [{"name": "c"}]}}
+    ga = {"workloads": [{"selector": "aa", "dependencies": [("zz", 7)]}, {"selector": "zz", "dependencies": []}], "topology_order": [("aa", 2), ("zz", 1)]}
+    gb = {"workloads": [{"selector": "mm", "dependencies": [("aa", 3)]}], "topology_order": [("mm", 1)]}
+    with NrtIngest(["n0"]) as ing:
+        ing.feed_pods(json.dumps([pod("b", "zz"), pod("a", "aa"), pod("ghost", "qq")]).encode())
+        assert [ing.name_id("appgroup", g) for g in ("b", "a", "ghost")] == [0, 1, 2]     # first seen
+        ing.feed_appgroups(json.dumps([appgroup_cr("a", ga), appgroup_cr("b", gb)]).encode())  # CRs in the other order
+        sel = {s: ing.name_id("selector", s) for s in ("aa", "mm", "qq", "zz")}
+        assert sel == {"aa": 0, "mm": 1, "qq": 2, "zz": 3}
+        pods = ing.pod_objects().struct
+        assert col(pods, "appgroup", 3) == [0, 1, 2] and col(pods, "selector", 3) == [sel["zz"], sel["aa"], sel["qq"]]   # renumbered
+        t = ing.appgroup_objects().struct
+        assert t.n_groups == 3
+        # row 0 = group "b" (the id pods[0] carries), row 1 = group "a", row 2 = "ghost" without a CR
+        assert col(t, "wl_ptr", 4) == [0, 1, 3, 3]
+        assert col(t, "wl_selector", 3) == [sel["mm"], sel["aa"], sel["zz"]]
+        assert col(t, "dep_selector", t.dep_ptr[3]) == [sel["aa"], sel["zz"]] and col(t, "dep_max_cost", t.dep_ptr[3]) == [3, 7]
+        assert col(t, "topo_ptr", 4) == [0, 1, 3, 3]
+        # the same CR again with a change: same row, no duplicate
+        gb2 = {"workloads": [{"selector": "mm", "dependencies": [("aa", 9)]}], "topology_order": [("mm", 1)]}
+        ing.feed_appgroups(json.dumps(appgroup_cr("b", gb2)).encode())
+        t = ing.appgroup_objects().struct
+        assert t.n_groups == 3 and col(t, "dep_max_cost", t.dep_ptr[3]) == [9, 7]
+        # a later pod with a new, lexicographically earlier selector renumbers again; the tables follow
+        ing.feed_pods(json.dumps(pod("a", "00")).encode())
+        assert ing.name_id("selector", "00") == 0 and ing.name_id("selector", "aa") == 1
+        t, pods = ing.appgroup_objects().struct, ing.pod_objects().struct
+        assert col(t, "wl_selector", 3) == [2, 1, 4] and col(pods, "selector", 4) == [4, 1, 3, 0]
 
 
 @pytest.mark.parametrize("case", GN.SCORE_CASES, ids=lambda c: f"L{c['line']}")

@@ -109,7 +109,7 @@ QUANTITIES = ["0", "1", "3", "100m", "1500m", "0.5", "1.5", "2.0001", "250u", "1
 
 @pytest.mark.parametrize("text", QUANTITIES)
 def test_quantity_semantics(text):
-    """MilliValue() = ceil(v * 1000), Value() = ceil(v), against exact rationals"""
+    """MilliValue() / Value() round inexact values away from zero (a ceiling for v >= 0), against exact rationals"""
     try:
         fr = O.parse_quantity(text)
     except (ValueError, ZeroDivisionError):

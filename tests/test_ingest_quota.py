@@ -89,3 +89,40 @@ def test_prefilter_on_decoded_quota(hdr, oracle):
         want_t = O.build_quota_objects(hdr, res, [{"min": d["spec"]["min"], "max": d["spec"]["max"], "used": d["status"]["used"]} for d in docs])
         assert got == [f(pods.ref(), res.table(hdr).ref(), want_t.ref(), i) for i in range(3)]
         assert got == [1, 0, 2]   # SPX_QUOTA_ST_OVER_MAX, pass, SPX_QUOTA_ST_OVER_MIN (the aggregate check, capacity_scheduling.go:279)
+
+
+def test_nominated_pods_come_from_the_pod_table(hdr, oracle):
+    """capacity_scheduling.go:231-253: PreFilter adds the requests of nominated pods (PodNominator.NominatedPodsForNode over the
+    snapshot's nodes).  On the wire a nominated pod is a pending pod with status.nominatedNodeName; the decoder derives the list
+    from the pod table, and the oracle's PreFilter answers exactly as with the Python builder's list."""
+    namespaces = ["team-a", "team-b"]
+    docs = [cr("team-a", {"min": {"cpu": "2", "memory": "4Gi"}, "max": {"cpu": "4", "memory": "8Gi"}, "used": {"cpu": "1", "memory": "1Gi"}}),
+            cr("team-b", {"min": {"cpu": "6", "memory": "4Gi"}, "max": {"cpu": "8", "memory": "16Gi"}, "used": {"cpu": "2", "memory": "1Gi"}})]
+
+    def pod_doc(ns, cpu, prio, nominated=None):
+        d = {"metadata": {"namespace": ns}, "spec": {"priority": prio, "containers": [{"name": "c", "resources": {"requests": {"cpu": cpu, "memory": "1Gi"}}}]}}
+        if nominated is not None:
+            d["status"] = {"nominatedNodeName": nominated}
+        return d
+    pend = [pod_doc("team-a", "1500m", 10),                        # 1 + 1.5 + nominated 2 (row 1, same quota, higher priority) > max 4
+            pod_doc("team-a", "2", 100, nominated="n1"),           # nominated itself: its own request is not added twice
+            pod_doc("team-b", "1", 5, nominated="gone"),           # nominated to a node outside the snapshot: not in the list
+            pod_doc("team-a", "1500m", 1000)]                      # more important than the nominated pod: does not count it
+    res = O.Resources()
+    mk = lambda ns, cpu, prio: O.pod([O.container({"cpu": cpu, "memory": "1Gi"})], ns=ns, priority=prio)
+    pods_t = O.build_pod_objects(hdr, res, [mk(0, "1500m", 10), mk(0, "2", 100), mk(1, "1", 5), mk(0, "1500m", 1000)])
+    want_q = O.build_quota_objects(hdr, res, [{"min": d["spec"]["min"], "max": d["spec"]["max"], "used": d["status"]["used"]} for d in docs],
+                                   nominated=[(0, 100, 1, mk(0, "2", 100))])
+    with NrtIngest(["n0", "n1"]) as ing:
+        ing.feed_quotas(json.dumps(docs).encode(), namespaces)
+        assert ing.quota_objects().struct.n_nominated == 0
+        ing.feed_pods(json.dumps(pend).encode())
+        q = ing.quota_objects().struct
+        assert q.n_nominated == 1 and q.nom_ns[0] == 0 and q.nom_priority[0] == 100 and q.nom_pending_index[0] == 1
+        f = oracle.lib().orc_capacity_prefilter
+        rc = ing.resource_classes()
+        got = [f(ing.pod_objects().ref(), rc.ref(), ing.quota_objects().ref(), i) for i in range(4)]
+        want = [f(pods_t.ref(), res.table(hdr).ref(), want_q.ref(), i) for i in range(4)]
+        assert got == want == [1, 0, 0, 0]
+        ing.reset_pods()
+        assert ing.quota_objects().struct.n_nominated == 0

@@ -5,7 +5,7 @@ four sizes under AddressSanitizer + UBSan.  The host sources are compiled on the
         scheduler-plugins_amd/host/*.cc -o /tmp/asan/libhost_asan.so
     LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python tools/asan_host.py
 
-Last run: clean (round 1).  The wire-format decoder is fuzzed the same way by tests/test_ingest_nrt.py::test_decoder_survives_mutated_input."""
+Last run: clean (round 2, including the decoder fuzz at the end).  The wire-format decoder is fuzzed the same way by tests/test_ingest_nrt.py::test_decoder_survives_mutated_input."""
 import ctypes as C, sys, numpy as np
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
 import scheduler_plugins_amd as spx
@@ -81,4 +81,67 @@ for seed, (N, P) in enumerate([(1, 1), (7, 3), (300, 129), (5000, 800)]):
     o = outs(fn, 3, [P, P, P * 8, P, 8, 1, 8, 1, NS * 8, NS, NS + 1, max(q.n_nominated, 1), max(q.n_nominated, 1), max(q.n_nominated, 1) * 8, max(q.n_nominated, 1)])
     assert fn(snap["pods"].ref(), snap["rc"].ref(), snap["quota"].ref(), *[x.ctypes.data_as(t) for x, t in zip(o, fn.argtypes[3:])]) == 0
     print("ok", N, P)
+
+# wire-format decoders added in round 2 (load-watcher metrics; AppGroups / pods in any order with selector renumbering; nominated
+# pods): valid documents, then truncated / byte-flipped / spliced mutations — the decoder must answer with an error code or a
+# valid table, never touch memory it does not own
+import json, random
+random.seed(7)
+names = [f"n{i}" for i in range(6)]
+pp_ = C.POINTER(C.POINTER(C.c_char))
+def mk():
+    h = C.POINTER(hdr.opaque["spx_ingest"])()
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    assert L.spx_ingest_create(C.cast(arr, pp_), len(names), None, 0, C.byref(h)) == 0
+    return h
+metrics = json.dumps({"timestamp": 1, "window": {"duration": "15m", "start": 1, "end": 2}, "source": "t", "data": {"NodeMetricsMap": {
+    n: {"metrics": [{"name": "x", "type": t, "operator": o, "value": v} for t, o, v in (("CPU", "AVG", 10.5), ("Memory", "STD", 3), ("CPU", "", 1e-3))], "tags": {}, "metadata": {}}
+    for n in names + ["other"]}}}).encode()
+wl = lambda s_: {"selector": s_}
+groups = json.dumps([{"metadata": {"name": g}, "spec": {"workloads": [{"workload": wl(a), "dependencies": [{"workload": wl(b), "maxNetworkCost": 5}]} for a, b in (("zz", "aa"), ("mm", "zz"))]},
+                      "status": {"topologyOrder": [{"workload": wl("aa"), "index": 1}, {"workload": wl("zz"), "index": 2}]}} for g in ("g1", "g2")]).encode()
+pods = json.dumps([{"metadata": {"namespace": "ns", "labels": {"appgroup.diktyo.x-k8s.io": g, "appgroup.diktyo.x-k8s.io.workload": s_}},
+                    "spec": {"priority": 3, "containers": [{"name": "c", "resources": {"requests": {"cpu": "100m"}}}]}, "status": {"nominatedNodeName": nn}}
+                   for g, s_, nn in (("g2", "zz", "n1"), ("g9", "00", "nowhere"), ("g1", "mm", "n0"))]).encode()
+quota = json.dumps([{"metadata": {"namespace": "ns"}, "spec": {"min": {"cpu": "1"}, "max": {"cpu": "2"}}, "status": {"used": {"cpu": "500m"}}}]).encode()
+def mutate(b):
+    b = bytearray(b)
+    k = random.random()
+    if k < 0.4: return bytes(b[: random.randrange(len(b))])
+    if k < 0.8:
+        for _ in range(random.randrange(1, 4)): b[random.randrange(len(b))] = random.randrange(256)
+        return bytes(b)
+    i, j = sorted(random.randrange(len(b)) for _ in range(2))
+    return bytes(b[:i] + b[j:] + b[i:j])
+n64, u64 = C.c_int64(), C.c_int64()
+for it in range(400):
+    h = mk()
+    docs = [("m", metrics), ("g", groups), ("p", pods), ("q", quota)]
+    random.shuffle(docs)
+    for kind, d in docs + docs[:2]:
+        d = d if it == 0 or random.random() < 0.3 else mutate(d)
+        if kind == "m": L.spx_ingest_metrics_json(h, d, len(d), C.byref(n64), C.byref(u64))
+        elif kind == "g": L.spx_ingest_appgroups_json(h, d, len(d), C.byref(n64))
+        elif kind == "p": L.spx_ingest_pods_json(h, d, len(d), C.byref(n64))
+        else:
+            ns = (C.c_char_p * 1)(b"ns")
+            L.spx_ingest_quota_json(h, d, len(d), C.cast(ns, pp_), 1, C.byref(n64), C.byref(u64))
+        # walk the tables the way a consumer would
+        t = L.spx_ingest_appgroup_objects(h).contents
+        for g in range(t.n_groups):
+            for w in range(t.wl_ptr[g], t.wl_ptr[g + 1]):
+                assert t.wl_selector[w] >= 0
+                for k in range(t.dep_ptr[w], t.dep_ptr[w + 1]): assert t.dep_selector[k] >= 0
+        pt = L.spx_ingest_pod_objects(h).contents
+        for i in range(pt.n_pods): assert pt.selector[i] >= -1 and pt.appgroup[i] < max(t.n_groups, 1) + 100
+        mp = L.spx_ingest_metrics_objects(h)
+        if mp:
+            m = mp.contents
+            assert m.m_ptr[len(names)] >= 0 and sum(m.node_present[i] for i in range(len(names))) <= len(names)
+        qp = L.spx_ingest_quota_objects(h)
+        if qp:
+            q_ = qp.contents
+            for j in range(q_.n_nominated): assert 0 <= q_.nom_pending_index[j] < pt.n_pods
+    L.spx_ingest_destroy(h)
+print("decoder fuzz ok")
 print("host asan ok")
