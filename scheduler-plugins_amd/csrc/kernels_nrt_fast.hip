@@ -34,6 +34,7 @@ constexpr int kZ = SPX_NRT_MAX_ZONES;
 constexpr int kC = SPX_NRT_MAX_CTRS;
 constexpr int kPodsPerUnit = 32;
 constexpr int kWindow = 256;  // nodes per block (4 wavefronts)
+constexpr int kXcdMapWindows = 32;  // from this many node windows on (8k nodes), blocks are mapped XCD-aware (see k_nrt_fast)
 constexpr int kSgLeast = 0;
 constexpr int kSgMost = 1;
 constexpr int kSgBalanced = 2;
@@ -62,21 +63,52 @@ __device__ __forceinline__ T uload(const T* p) {
   return *reinterpret_cast<CT*>(reinterpret_cast<uintptr_t>(p));
 }
 
-// The pod record stream (built by the engine at upload, spx_engine.hip: nrt_pod_items): per pod 10 items of IW
-// dwords — item 0 the header, item 1 the pod-level request, items 2..9 the containers in order (init containers
-// first).  One item is one scalar load; the next one is requested before the current one is processed, so the
-// SMEM latency (the kernel's main stall once the arithmetic is cheap) overlaps with the VALU work.
-template <int RM>
-struct ItemWords;
-template <>
-struct ItemWords<4> {
-  typedef uint32_t T __attribute__((ext_vector_type(16)));
-};
-template <>
-struct ItemWords<8> {
-  typedef uint32_t T __attribute__((ext_vector_type(32)));
-};
+// The pod record stream (built by the engine at upload, spx_engine.hip: nrt_pod_items): per pod 10 items of IW dwords
+// (16 for <= 4 resource slots, else 32) — item 0 the header (2 dwords used), item 1 the pod-level request, items 2..9 the
+// containers in order (init containers first).  A request item: doubles raw[RM] (dwords 0..2RM-1), the slot-set dword
+// (2RM), a pad, then the three doubles only the Score reads: Value() of the cpu request, the sum of the weights of the
+// requested slots and its biased reciprocal.  Items are fetched with scalar loads, the next one before the current one is
+// processed so that the SMEM latency overlaps with the VALU work.  How much of an item a kernel keeps in scalar registers
+// matters: the Filter needs 2RM + 1 dwords of it, and with three items in flight (pod level, current and next container)
+// loading all 16 costs scalar registers and SMEM bandwidth for nothing (measured: config #3 3.2 -> 3.0 ms).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 constexpr int kItemsPerPod = 2 + kC;
+template <int RM>
+constexpr int item_words() { return RM == 4 ? 16 : 32; }
+
+template <int RM, bool FULL>
+struct ItemRegs;
+template <>
+struct ItemRegs<4, false> {  // the request quantities and the slot sets
+  u32x8 raw;
+  u32x2 tail;
+};
+template <>
+struct ItemRegs<4, true> {
+  u32x16 w;
+};
+template <bool FULL>
+struct ItemRegs<8, FULL> {
+  u32x16 lo, hi;
+};
+
+template <int RM, bool FULL>
+__device__ __forceinline__ ItemRegs<RM, FULL> load_item(const uint32_t* items, int64_t index) {
+  const uint32_t* p = items + index * item_words<RM>();
+  ItemRegs<RM, FULL> r;
+  if constexpr (RM == 4 && !FULL) {
+    r.raw = uload(reinterpret_cast<const u32x8*>(p));
+    r.tail = uload(reinterpret_cast<const u32x2*>(p + 8));
+  } else if constexpr (RM == 4) {
+    r.w = uload(reinterpret_cast<const u32x16*>(p));
+  } else {
+    r.lo = uload(reinterpret_cast<const u32x16*>(p));
+    r.hi = uload(reinterpret_cast<const u32x16*>(p + 16));
+  }
+  return r;
+}
 
 template <int RM>
 struct Item {
@@ -90,19 +122,29 @@ struct Item {
   uint32_t kind;   // SPX_CTR_*
 };
 
-template <int RM>
-__device__ __forceinline__ Item<RM> decode_item(const typename ItemWords<RM>::T& w) {
+template <int RM, bool FULL>
+__device__ __forceinline__ Item<RM> decode_item(const ItemRegs<RM, FULL>& g) {
   Item<RM> it;
+  auto word = [&](int i) -> uint32_t {
+    if constexpr (RM == 4 && !FULL) return i < 8 ? g.raw[i] : g.tail[i - 8];
+    else if constexpr (RM == 4) return g.w[i];
+    else return i < 16 ? g.lo[i] : g.hi[i - 16];
+  };
+  auto f64 = [&](int i) { return __hiloint2double(static_cast<int>(word(i + 1)), static_cast<int>(word(i))); };
 #pragma unroll
-  for (int r = 0; r < RM; ++r) it.raw[r] = __hiloint2double(static_cast<int>(w[2 * r + 1]), static_cast<int>(w[2 * r]));
-  it.cpu_v = __hiloint2double(static_cast<int>(w[2 * RM + 1]), static_cast<int>(w[2 * RM]));
-  it.wsum = __hiloint2double(static_cast<int>(w[2 * RM + 3]), static_cast<int>(w[2 * RM + 2]));
-  it.wrc = __hiloint2double(static_cast<int>(w[2 * RM + 5]), static_cast<int>(w[2 * RM + 4]));
-  const uint32_t s = w[2 * RM + 6];
+  for (int r = 0; r < RM; ++r) it.raw[r] = f64(2 * r);
+  const uint32_t s = word(2 * RM);
   it.used = s & 0xffu;
   it.fit = (s >> 8) & 0xffu;
   it.always = (s >> 16) & 0xffu;
   it.kind = s >> 24;
+  if constexpr (FULL) {
+    it.cpu_v = f64(2 * RM + 2);
+    it.wsum = f64(2 * RM + 4);
+    it.wrc = f64(2 * RM + 6);
+  } else {
+    it.cpu_v = it.wsum = it.wrc = 0.0;  // Score-only fields
+  }
   return it;
 }
 
@@ -157,7 +199,20 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
 #pragma unroll
   for (int r = 0; r < RM; ++r) value[r] = r == a.cpu_slot ? it.cpu_v : it.raw[r];
   if constexpr (SG == kSgBalanced) {
-    const double n = static_cast<double>(__builtin_popcount(used));
+    // The reference's float64 divisions, correctly rounded, without the hardware's ~10-instruction division sequence: with
+    // y = RN(1 / b) (per zone and resource from the engine's table — Balanced scores on the pristine zone table, so the
+    // divisors are node constants; per container for the two uniform divisors), q0 = RN(a * y), r = a - b * q0 (exact in one
+    // fma) and RN(q0 + r * y) is RN(a / b) (Markstein; the only exception, a divisor whose 53-bit significand is all ones,
+    // cannot occur for integers below 2^42).  Replayed against exact rationals in tests/test_exactness_arguments.py.
+    // A single requested resource (n == 1) divides by n - 1 == 0: that row keeps the real divisions and their NaN.
+    const int n_used = __builtin_popcount(used);
+    const double n = static_cast<double>(n_used);
+    const bool multi = n_used >= 2;  // uniform
+    const double yn = 1.0 / n, ym = 1.0 / (n - 1.0);
+    auto div_rn = [](double x, double b, double y) {
+      const double q0 = x * y;
+      return __builtin_fma(__builtin_fma(-b, q0, x), y, q0);
+    };
 #pragma unroll
     for (int z = 0; z < kZ; ++z) {
       double fr[RM];
@@ -168,7 +223,7 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
         if (!((used >> r) & 1u)) continue;
         const double cap = ns.av[z][r];
         const double cap_v = r == a.cpu_slot ? cpu_v[z] : cap;
-        const double f = cap > 0.0 ? value[r] / cap_v : 1.0;  // fractionOfCapacity balanced_allocation.go:49-54
+        const double f = cap > 0.0 ? div_rn(value[r], cap_v, ns.b[z][r]) : 1.0;  // fractionOfCapacity balanced_allocation.go:49-54
         over |= f > 1.0;
         fr[r] = f;
       }
@@ -176,7 +231,7 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
       double sum = 0.0;
 #pragma unroll
       for (int r = 0; r < RM; ++r) sum += fr[r];
-      const double mean = sum / n;
+      const double mean = multi ? div_rn(sum, n, yn) : sum / n;
       double ss = 0.0, comp = 0.0;
 #pragma unroll
       for (int r = 0; r < RM; ++r) {
@@ -184,7 +239,7 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
         ss += d * d;
         comp += d;
       }
-      const double variance = (ss - comp * comp / n) / (n - 1.0);
+      const double variance = multi ? div_rn(ss - div_rn(comp * comp, n, yn), n - 1.0, ym) : (ss - comp * comp / n) / (n - 1.0);
       const int s = (over || z >= ns.nz) ? 0 : static_cast<int>((1.0 - variance) * 100.0);
       const uint32_t s1 = static_cast<uint32_t>(s) - 1u;
       m = s1 < m ? s1 : m;
@@ -353,8 +408,9 @@ __device__ __forceinline__ void subtract_from_numas_fast(FastNode<RM>& ns, const
 constexpr int kPhBoth = 0, kPhFilter = 1, kPhScore = 2;
 
 template <int RM, int SG, int PH>
-__global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgMost ? 4 : 5) : (PH == kPhFilter ? 4 : (SG == kSgLeast ? 3 : 2))) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
-  typedef typename ItemWords<RM>::T Words;
+__global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgBalanced ? 2 : (SG == kSgMost ? 4 : 5)) : (PH == kPhFilter ? 5 : (SG == kSgLeast ? 3 : 2))) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
+  constexpr bool FULL = PH != kPhFilter;  // only the Score reads the second half of a request item
+  typedef ItemRegs<RM, FULL> Regs;
   // A block owns a window of 256 consecutive nodes and a chunk of pod rows.  Inside the window the engine has
   // ordered the nodes by (aligned, scope) — perm[] — so that a wavefront's 64 nodes mostly share one code path
   // (measured before: 49 % of the VALU lanes active, pod-scope and container-scope nodes being interleaved).
@@ -362,9 +418,24 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgMost ? 4
   __shared__ __align__(16) uint8_t stage[2][kPodsPerUnit][kWindow];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Blocks are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD has its own L2.  Each XCD
+  // therefore gets its own set of node windows — {x, x + 8, ...} — and walks the pod chunks over them: its share of the
+  // node tables (about 130 KB per window) stays in its L2 instead of all windows cycling through all eight (at 20k nodes
+  // the Filter launch used to fetch 10.7 GB to write 1.25 GB).  Measured: 20k nodes 17.9 -> 17.6 ms for the full profile; at 5k
+  // nodes (20 windows, 4 of 24 slots idle) the same map costs 17 %, hence the threshold.
   const int n_windows = n_tiles;  // (the launch passes the window count)
-  const int window = static_cast<int>(blockIdx.x % n_windows);
-  const int64_t chunk = blockIdx.x / n_windows;
+  int window;
+  int64_t chunk;
+  if (n_windows >= kXcdMapWindows) {
+    const int wpx = (n_windows + 7) >> 3;
+    const int64_t seq = blockIdx.x >> 3;
+    window = static_cast<int>(blockIdx.x & 7u) + 8 * static_cast<int>(seq % wpx);
+    chunk = seq / wpx;
+    if (window >= n_windows) return;  // block-uniform: the XCDs' window sets differ by at most one
+  } else {  // the tables fit every XCD's L2 anyway (5k nodes: 2.6 MB); the plain order keeps all slots busy
+    window = static_cast<int>(blockIdx.x % n_windows);
+    chunk = blockIdx.x / n_windows;
+  }
   const int64_t pod0 = a.row_begin + chunk * kPodsPerUnit;
   if (pod0 >= a.row_end) return;  // block-uniform
   const int64_t pod1 = pod0 + kPodsPerUnit < a.row_end ? pod0 + kPodsPerUnit : a.row_end;
@@ -405,6 +476,7 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgMost ? 4
       ns.av[z][r] = (in && r < R) ? a.f_av[i] : -1.0;
       const double b = (SG != kSgBalanced && SG != kSgLeastNuma && in && r < R) ? a.f_rc[i] : kNoCap;
       ns.b[z][r] = (SG == kSgLeast && b == kNoCap) ? __builtin_inf() : b;
+      if constexpr (SG == kSgBalanced) ns.b[z][r] = (in && r < R) ? a.f_rcv[i] : 1.0;  // RN(1 / Value(capacity)) for div_rn
     }
   }
   const int nns = 100 / (in ? a.max_numa[n] : 8);  // normalizeScore's per-zone step, least_numa.go:90-100
@@ -414,14 +486,15 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgMost ? 4
   const bool pod_scope = flags & SPX_NRT_F_POD_SCOPE;
   const bool aligned = fresh && has_nrt && single;  // the node's NUMA table decides Filter and Score
 
-  const Words* items = reinterpret_cast<const Words*>(a.pod_items);
-  Words hw = uload(items + pod0 * kItemsPerPod);
+  const uint32_t* items = a.pod_items;
+  auto header = [&](int64_t pod) { return uload(reinterpret_cast<const u32x2*>(items + pod * kItemsPerPod * item_words<RM>())); };
+  u32x2 hw = header(pod0);
   for (int64_t pod = pod0; pod < pod1; ++pod) {
     // ---- wave-uniform pod record: this pod's request items now, the next pod's header for the next iteration
-    const Words* pi = items + pod * kItemsPerPod;
-    const Words pw = uload(pi + 1);
-    Words cw = uload(pi + 2);
-    const Words hnext = uload(items + (pod + 1 < pod1 ? pod + 1 : pod) * kItemsPerPod);
+    const int64_t pi = pod * kItemsPerPod;  // index of the pod's first item
+    const Regs pw = load_item<RM, FULL>(items, pi + 1);
+    Regs cw = load_item<RM, FULL>(items, pi + 2);
+    const u32x2 hnext = header(pod + 1 < pod1 ? pod + 1 : pod);
     const int qos = hw[0] & 0xffu;
     const bool non_native = ((hw[0] >> 8) & 0xffu) != 0;
     const int n_ctr = (hw[0] >> 16) & 0xffu;
@@ -436,7 +509,7 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgMost ? 4
     const bool want_score = SG != kSgLeastNuma && PH != kPhFilter && !non_g && aligned;
 
     if ((want_filter || want_score) && pod_scope) {  // singleNUMAPodLevelHandler / podScopeScore
-      const Item<RM> it = decode_item<RM>(pw);
+      const Item<RM> it = decode_item<RM, FULL>(pw);
       if constexpr (PH != kPhScore) {
         if (want_filter) {
           uint32_t pos;
@@ -452,12 +525,11 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgMost ? 4
       // and is never subtracted; an app container is placed on the lowest fitting zone and subtracted from it.
       // Least/MostAllocated's zone scores read only b (never the mutable table), so they score in the same pass;
       // BalancedAllocation scores after the undo.
-      uint32_t chosen = 0;  // list position picked per app container (for the undo), 4 bits each
-      uint32_t placed = 0;  // bit c: container c was subtracted on this lane
+      uint32_t chosen = 0;  // per app container: the zone it was subtracted from + 1 (0 = not placed), 4 bits each, for the undo
       int sum = 0;
       for (int c = 0; c < n_ctr; ++c) {
-        const Words nw = uload(pi + 2 + (c + 1 < kC ? c + 1 : c));  // prefetch the next container's item
-        const Item<RM> it = decode_item<RM>(cw);
+        const Regs nw = load_item<RM, FULL>(items, pi + 2 + (c + 1 < kC ? c + 1 : c));  // prefetch the next container's item
+        const Item<RM> it = decode_item<RM, FULL>(cw);
         if constexpr (PH != kPhScore) if (want_filter) {
           uint32_t pos;
           const bool ok = fits_fast(ns, it, &pos);
@@ -469,8 +541,7 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgMost ? 4
             if (c != last_app) {  // nothing reads the table after the last app container
               const bool apply = live && ok;
               adjust_fast(ns, it, pos, apply, -1.0);
-              chosen |= (apply ? pos : 0u) << (4 * c);
-              placed |= (apply ? 1u : 0u) << c;
+              chosen |= (apply ? pos + 1u : 0u) << (4 * c);
             }
           }
         }
@@ -480,20 +551,20 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgMost ? 4
         cw = nw;
       }
       if constexpr (PH != kPhScore) if (want_filter && last_app > 0) {  // undo: Filter works on a private copy in the reference
-        cw = uload(pi + 2);
+        cw = load_item<RM, FULL>(items, pi + 2);
         for (int c = 0; c < last_app; ++c) {
-          const Words nw = uload(pi + 2 + c + 1);
-          const Item<RM> it = decode_item<RM>(cw);
-          if (it.kind == SPX_CTR_APP) adjust_fast(ns, it, (chosen >> (4 * c)) & 0xfu, (placed >> c) & 1u, 1.0);
+          const Regs nw = load_item<RM, FULL>(items, pi + 2 + c + 1);
+          const Item<RM> it = decode_item<RM, FULL>(cw);
+          if (it.kind == SPX_CTR_APP) adjust_fast(ns, it, ((chosen >> (4 * c)) & 0xfu) - 1u, ((chosen >> (4 * c)) & 0xfu) != 0, 1.0);
           cw = nw;
         }
       }
       if constexpr (SG != kSgLeast && SG != kSgMost && PH != kPhFilter) {
         if (want_score) {
-          cw = uload(pi + 2);
+          cw = load_item<RM, FULL>(items, pi + 2);
           for (int c = 0; c < n_ctr; ++c) {
-            const Words nw = uload(pi + 2 + (c + 1 < kC ? c + 1 : c));
-            sum += score_each_fast<RM, SG>(ns, a, decode_item<RM>(cw), cpu_v, braw);
+            const Regs nw = load_item<RM, FULL>(items, pi + 2 + (c + 1 < kC ? c + 1 : c));
+            sum += score_each_fast<RM, SG>(ns, a, decode_item<RM, FULL>(cw), cpu_v, braw);
             cw = nw;
           }
         }
@@ -505,7 +576,7 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgMost ? 4
       // LeastNUMANodes scores every node that has a fresh NRT, whatever its topology-manager policy (score.go:167-191)
       const bool want_ln = !non_g && fresh && has_nrt;
       if (want_ln && pod_scope) {  // leastNUMAPodScopeScore
-        const Item<RM> it = decode_item<RM>(pw);
+        const Item<RM> it = decode_item<RM, FULL>(pw);
         uint32_t any_rep = 0;
 #pragma unroll
         for (int r = 0; r < RM; ++r)
@@ -519,10 +590,10 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgMost ? 4
       if (want_ln && !pod_scope) {  // leastNUMAContainerScopeScore
         int max_count = 0;
         bool all_min = true, failed = false, dirty = false;
-        cw = uload(pi + 2);
+        cw = load_item<RM, FULL>(items, pi + 2);
         for (int c = 0; c < n_ctr; ++c) {
-          const Words nw = uload(pi + 2 + (c + 1 < kC ? c + 1 : c));
-          const Item<RM> it = decode_item<RM>(cw);
+          const Regs nw = load_item<RM, FULL>(items, pi + 2 + (c + 1 < kC ? c + 1 : c));
+          const Item<RM> it = decode_item<RM, FULL>(cw);
           uint32_t any_rep = 0;
 #pragma unroll
           for (int r = 0; r < RM; ++r)
@@ -583,15 +654,15 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   if (!a.fast) return false;
   const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);  // windows of 256 nodes
   const int64_t chunks = (a.row_end - a.row_begin + kPodsPerUnit - 1) / kPodsPerUnit;
-  const unsigned blocks = static_cast<unsigned>(chunks * n_tiles);
+  const unsigned blocks = static_cast<unsigned>(chunks * (n_tiles >= kXcdMapWindows ? ((n_tiles + 7) / 8) * 8 : n_tiles));  // see the kernel's block map
   const int sg = a.strategy == SPX_NRT_LEAST_NUMA_NODES ? kSgLeastNuma
                : a.strategy == SPX_NRT_BALANCED_ALLOCATION ? kSgBalanced : (a.strategy == SPX_NRT_LEAST_ALLOCATED ? kSgLeast : kSgMost);
-  const bool split = (sg == kSgLeast || sg == kSgMost) && a.out_raw == nullptr && !(a.opts & kOptNrtSingleLaunch);
+  const bool split = sg != kSgLeastNuma && a.out_raw == nullptr && !(a.opts & kOptNrtSingleLaunch);
 #define SPX_NRTF_CASE(RMV, SGV)                                                                           \
   if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                                        \
-    if ((SGV == kSgLeast || SGV == kSgMost) && split) { /* the Filter half does not depend on the strategy */ \
+    if (SGV != kSgLeastNuma && split) { /* the Filter half does not depend on the strategy */ \
       hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhFilter>), dim3(blocks), dim3(256), 0, s, a, n_tiles); \
-      hipLaunchKernelGGL((k_nrt_fast<RMV, (SGV == kSgMost ? kSgMost : kSgLeast), kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
+      hipLaunchKernelGGL((k_nrt_fast<RMV, (SGV == kSgLeastNuma ? kSgLeast : SGV), kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
     } else {                                                                                              \
       hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhBoth>), dim3(blocks), dim3(256), 0, s, a, n_tiles);     \
     }                                                                                                     \

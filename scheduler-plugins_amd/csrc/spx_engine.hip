@@ -88,7 +88,7 @@ struct spx_engine {
   DevBuf d_nrt_flags, d_nrt_max_numa, d_nrt_nz, d_nrt_zid, d_nrt_zp, d_nrt_avail, d_nrt_cost, d_nrt_minavg, d_nrt_np;
   DevBuf d_nrt_qos, d_nrt_nn, d_nrt_nctr, d_nrt_ckind, d_nrt_cpres, d_nrt_creq, d_nrt_ppres, d_nrt_preq;
   // float64 formulation of the NRT sweep (kernels_nrt_fast.hip): derived tables + whether its preconditions hold
-  DevBuf d_nrt_fav, d_nrt_frc, d_nrt_fcpu, d_nrt_fbraw, d_nrt_frep, d_nrt_items, d_nrt_perm, d_nrt_dist;
+  DevBuf d_nrt_fav, d_nrt_frc, d_nrt_frcv, d_nrt_fcpu, d_nrt_fbraw, d_nrt_frep, d_nrt_items, d_nrt_perm, d_nrt_dist;
   std::vector<double> nrt_wtab;  // [2^n_res][2]: sum of the weights of a slot subset, its biased reciprocal
   bool nrt_fast_slots = false, nrt_fast_nodes = false, nrt_fast_pods = false;
   int32_t nrt_cpu_slot = -1;
@@ -376,6 +376,7 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   for (int i = 0; i < SPX_NRT_MAX_RES; ++i) na.slot_weight_f[i] = static_cast<double>(e->nrt_slot_weight[i]);
   na.f_av = static_cast<const double*>(e->d_nrt_fav.p);
   na.f_rc = static_cast<const double*>(e->d_nrt_frc.p);
+  na.f_rcv = static_cast<const double*>(e->d_nrt_frcv.p);
   na.f_cpu = static_cast<const double*>(e->d_nrt_fcpu.p);
   na.f_braw = static_cast<const double*>(e->d_nrt_fbraw.p);
   na.f_rep = static_cast<const uint8_t*>(e->d_nrt_frep.p);
@@ -473,7 +474,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_raw_row,   &e->d_lv_exact, &e->d_lv_fast, &e->d_tlp_fast, &e->d_commit, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
-                    &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_dist, &e->d_nrt_fbraw,
+                    &e->d_nrt_frcv, &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_dist, &e->d_nrt_fbraw,
                     &e->d_net_region, &e->d_net_zone, &e->d_net_class, &e->d_net_class16, &e->d_net_cls_size, &e->d_net_cls_region, &e->d_net_cls_zone,
                     &e->d_net_rcost, &e->d_net_zcost, &e->d_net_pod_key, &e->d_net_key_flag, &e->d_net_pair_ptr,
                     &e->d_net_pair_node, &e->d_net_pair_max, &e->d_q_pod_ns, &e->d_q_pod_prio, &e->d_q_pod_req, &e->d_q_pod_reqp,
@@ -781,7 +782,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
   if ((rc = upload_transposed(e, e->d_nrt_minavg, t->min_avg_dist, n, Zm))) return rc;
   {  // float64 formulation: derived columns + precondition check
     const int64_t R = t->n_res;
-    std::vector<double> av(static_cast<size_t>(Zm * R * n), -1.0), rcp(static_cast<size_t>(Zm * R * n), spx::kNrtNoCap),
+    std::vector<double> av(static_cast<size_t>(Zm * R * n), -1.0), rcp(static_cast<size_t>(Zm * R * n), spx::kNrtNoCap), rcv(static_cast<size_t>(Zm * R * n), 1.0),
         cpuv(static_cast<size_t>(Zm * n), 0.0), braw(static_cast<size_t>(Zm * n), spx::kNrtNoCap);
     std::vector<uint8_t> rep(static_cast<size_t>((R > 0 ? R : 1) * n), 0);
     bool ok = true;
@@ -797,6 +798,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
           const double cap_v = static_cast<double>(nrt_value_of(is_cpu, cap));
           av[static_cast<size_t>((z * R + r) * n + i)] = static_cast<double>(cap);
           rcp[static_cast<size_t>((z * R + r) * n + i)] = cap_v > 0.0 ? 100.0 / cap_v : spx::kNrtNoCap;
+          rcv[static_cast<size_t>((z * R + r) * n + i)] = cap_v > 0.0 ? 1.0 / cap_v : 1.0;
           if (is_cpu) cpuv[static_cast<size_t>(z * n + i)] = cap_v;
           if (is_cpu && cap > 0) braw[static_cast<size_t>(z * n + i)] = 100.0 / static_cast<double>(cap);
           rep[static_cast<size_t>(r * n + i)] |= static_cast<uint8_t>(1u << z);
@@ -843,6 +845,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
     }
     if ((rc = upload(e, e->d_nrt_fav, av.data(), av.size() * sizeof(double)))) return rc;
     if ((rc = upload(e, e->d_nrt_frc, rcp.data(), rcp.size() * sizeof(double)))) return rc;
+    if ((rc = upload(e, e->d_nrt_frcv, rcv.data(), rcv.size() * sizeof(double)))) return rc;
     if ((rc = upload(e, e->d_nrt_fcpu, cpuv.data(), cpuv.size() * sizeof(double)))) return rc;
     if ((rc = upload(e, e->d_nrt_fbraw, braw.data(), braw.size() * sizeof(double)))) return rc;
     if ((rc = upload(e, e->d_nrt_frep, rep.data(), rep.size()))) return rc;
@@ -874,9 +877,9 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
     //   item 0   header: w0 = qos | non_native << 8 | n_ctr << 16 | last app container << 24 (0xff: none),
     //                    w1 = ceil(2^16 / n_ctr)
     //   item 1   the pod-level effective request;  items 2..9  the containers, in order
-    //   request item: doubles raw[RM] (dwords 0..2RM-1), Value() of the cpu request (2RM), sum of the weights of the
-    //                 requested slots (2RM+2) and its biased reciprocal (2RM+4); dword 2RM+6 =
-    //                 requested slots | compared slots << 8 | "any reporting zone suits" slots << 16 | kind << 24
+    //   request item: doubles raw[RM] (dwords 0..2RM-1); dword 2RM = requested slots | compared slots << 8 |
+    //                 "any reporting zone suits" slots << 16 | kind << 24; a pad; then what only the Score reads: Value() of the
+    //                 cpu request (2RM+2), sum of the weights of the requested slots (2RM+4), its biased reciprocal (2RM+6)
     const int RMs = R <= 4 ? 4 : 8;
     const size_t IW = R <= 4 ? 16 : 32;
     std::vector<uint32_t> items(p * 10 * IW, 0u);
@@ -894,12 +897,12 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
         else fit |= 1u << r;
       }
       const int64_t cpu_q = e->nrt_cpu_slot >= 0 ? req[e->nrt_cpu_slot] : 0;
-      put_f64(w + 2 * RMs, static_cast<double>(nrt_value_of(true, cpu_q)));
+      w[2 * RMs] = used | (fit << 8) | (always << 16) | (kind << 24);
+      put_f64(w + 2 * RMs + 2, static_cast<double>(nrt_value_of(true, cpu_q)));
       if (ok.load(std::memory_order_relaxed)) {
-        put_f64(w + 2 * RMs + 2, e->nrt_wtab[2 * used]);
-        put_f64(w + 2 * RMs + 4, e->nrt_wtab[2 * used + 1]);
+        put_f64(w + 2 * RMs + 4, e->nrt_wtab[2 * used]);
+        put_f64(w + 2 * RMs + 6, e->nrt_wtab[2 * used + 1]);
       }
-      w[2 * RMs + 6] = used | (fit << 8) | (always << 16) | (kind << 24);
     };
     spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
     for (size_t i = static_cast<size_t>(row0); i < static_cast<size_t>(row1); ++i) {

@@ -230,6 +230,7 @@ struct NrtArgs {
   double slot_weight_f[SPX_NRT_MAX_RES];
   const double* f_av;            // [Z][n_res][N] reported ? available : -1
   const double* f_rc;            // [Z][n_res][N] RN(100 / Value(capacity)), kNrtNoCap when the capacity is not positive
+  const double* f_rcv;           // [Z][n_res][N] RN(1 / Value(capacity)) (BalancedAllocation's divisions), 1 when the capacity is not positive
   const double* f_cpu;           // [Z][N] Value() of the cpu capacity
   const double* f_braw;          // [Z][N] RN(100 / cpu capacity in millicores), kNrtNoCap when it is not positive
   const uint8_t* f_rep;          // [n_res][N] mask of the zones reporting the resource

@@ -280,3 +280,45 @@ def test_reciprocal_division_is_correctly_rounded():
         d = float(rnd.randint(0, int(span)))
         assert div_rn(100.0 * d, span) == 100.0 * d / span
         assert div_rn(100.0 * span, span) == 100.0 * span / span   # the row maximum: 100 or 99.99999999999999, as in the reference
+
+
+def test_balanced_allocation_divisions_are_correctly_rounded():
+    """k_nrt_fast<., BalancedAllocation> (kernels_nrt_fast.hip: div_rn) computes fractionOfCapacity = request / capacity, the mean
+    sum / n and stat.Variance's two divisions through correctly rounded reciprocals (Markstein).  Replayed with exact rationals on
+    the operand shapes that occur: integer request / integer capacity below 2^42 (quotients above 1 included), sums and sums of
+    squares of such fractions divided by n and n - 1 for n = 2..8."""
+    import random
+    from fractions import Fraction
+    rnd = random.Random(11)
+
+    def div_rn(a, b):
+        y = 1.0 / b
+        q = a * y
+        r = float(Fraction(a) - Fraction(b) * Fraction(q))
+        return float(Fraction(q) + Fraction(r) * Fraction(y))
+
+    def rn_div(a, b):  # the correctly rounded quotient, independent of the platform's division
+        return float(Fraction(a) / Fraction(b))
+
+    caps = [float(c) for c in (1, 2, 3, 7, 96, 1000, 1023, 4095, 2 ** 20 - 1, 2 ** 30 + 1, 2 ** 41 + 12345, 2 ** 42 - 1)]
+    for _ in range(40000):
+        cap = rnd.choice(caps) if rnd.random() < 0.3 else float(rnd.randint(1, 2 ** rnd.randint(1, 42) - 1))
+        req = float(rnd.randint(0, int(cap) * 2)) if rnd.random() < 0.7 else float(rnd.randint(0, 2 ** 42 - 1))
+        assert div_rn(req, cap) == rn_div(req, cap) == req / cap
+    for _ in range(40000):
+        n = rnd.randint(2, 8)
+        fr = [rnd.randint(0, 2 ** 30) / rnd.randint(1, 2 ** 30) for _ in range(n)]
+        s = 0.0
+        for f in fr:
+            s += f
+        assert div_rn(s, float(n)) == rn_div(s, float(n))
+        mean = s / n
+        ss = comp = 0.0
+        for f in fr:
+            d = f - mean
+            ss += d * d
+            comp += d
+        c2 = comp * comp
+        assert div_rn(c2, float(n)) == rn_div(c2, float(n))
+        num = ss - c2 / n
+        assert div_rn(num, float(n - 1)) == rn_div(num, float(n - 1))
