@@ -398,7 +398,7 @@ def main() -> None:
                 full_cycle["decide_what"] = "sweep + per-row argmax, no score table written where the fused form applies; same decisions as eval_argmax"
             except Exception as ex:
                 full_cycle["decide_error"] = repr(ex)[:200]
-            if args.workload in ("config2", "config2_lvrb"):
+            if args.workload in ("config2", "config2_lvrb", "config5_share"):
                 # the same pods scheduled strictly one after the other, each seeing the commits before it (upstream's
                 # semantics; inherently sequential, one workgroup): spx_commit_sequential
                 c4 = time.perf_counter()
@@ -407,6 +407,10 @@ def main() -> None:
                 full_cycle["sequential_commit_ms"] = (c5 - c4) * 1e3
                 full_cycle["sequential_pods_per_s"] = local_pods / (c5 - c4)
                 full_cycle["sequential_distinct_nodes"] = int(len(set(seq_node.tolist())))
+                full_cycle["sequential_unschedulable"] = int((seq_node < 0).sum())
+                full_cycle["sequential_what"] = ("one workgroup carrying trimaran's bind-time state" if args.workload != "config5_share" else
+                                                 "per pod: single-row sweep of the whole profile on the current tables + argmax + Reserve bookkeeping "
+                                                 "(NRT assumed resources, AppGroup scheduled list, ElasticQuota used, trimaran cache), all on the device")
         except Exception as ex:
             full_cycle = {"error": repr(ex)[:200]}
 

@@ -520,7 +520,19 @@ typedef struct spx_quota_soa {
   const int64_t* nom_pending_index;
   const int64_t* nom_req;
   const uint8_t* nom_req_present;
+  const int64_t* min;          /* optional (may be NULL), [NS][8] + min_present [NS]: ElasticQuotaInfo.Min per namespace.  Only the */
+  const uint8_t* min_present;  /* sequential commit loop reads them (a bound pod can push its quota over min, elasticquota.go:166-191) */
 } spx_quota_soa;
+
+/* NetworkOverhead bookkeeping of the sequential commit loop: what binding pending pod p adds to the AppGroup scheduled lists the
+ * later pods see.  Entries of pod p: eff_key / eff_max_cost [eff_ptr[p], eff_ptr[p+1]); eff_max_cost >= 0: workload key eff_key gains
+ * the pair (p's node, that MaxNetworkCost); -1: the key merely stops scoring equally.  Built by spx_flatten_net_commit. */
+typedef struct spx_net_commit_soa {
+  int64_t n_pods;
+  const int32_t* eff_ptr;
+  const int32_t* eff_key;
+  const int64_t* eff_max_cost;
+} spx_net_commit_soa;
 
 /* ------------------------------------------------------------------ engine */
 
@@ -591,6 +603,8 @@ int spx_upload_net_nodes(spx_engine* e, const spx_net_nodes_soa* t);
 int spx_upload_net_topo(spx_engine* e, const spx_net_topo_soa* t);
 int spx_upload_net_pods(spx_engine* e, const spx_net_pods_soa* t);
 int spx_upload_quota(spx_engine* e, const spx_quota_soa* t);
+/* after spx_upload_net_pods; only spx_commit_sequential with NETOVERHEAD in its mask needs it */
+int spx_upload_net_commit(spx_engine* e, const spx_net_commit_soa* t);
 /* TopologicalSort as one batched sort of the pending queue (replaces the activeQ heap's pairwise Less calls).  Less is not a
  * strict weak order (same AppGroup: `orderP1 <= orderP2`; otherwise PrioritySort), but it is complete, so an order exists in
  * which EVERY ADJACENT PAIR (x, y) satisfies Less(x, y) — or ties under PrioritySort (equal priority and timestamp).
@@ -652,10 +666,19 @@ int spx_fetch_best(spx_engine* e, int64_t row_begin, int64_t row_end, int32_t* n
  * fused form.  Asynchronous on the engine stream like spx_eval. */
 int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end);
 
-/* Sequential scheduling of pod rows [row_begin,row_end), in row (= queue) order, under the Filter-less profile
- * plugin_mask, a subset of {ALLOCATABLE, TLP, LVRB}.  Unlike spx_eval's frozen snapshot, every pod sees the commits of the
- * pods before it: a pod bound to a node adds its predicted CPU utilisation to that node's missing utilisation
- * (pkg/trimaran/handler.go:131-139 feeding targetloadpacking.go:151-168).  Per pod: the node with the highest
+/* Sequential scheduling of pod rows [row_begin,row_end), in row (= queue) order.  Unlike spx_eval's frozen
+ * snapshot, every pod sees the commits of the pods before it:
+ *   trimaran           a bound pod adds its predicted CPU utilisation to its node's missing utilisation
+ *                      (pkg/trimaran/handler.go:131-139 feeding targetloadpacking.go:151-168);
+ *   NRT                TopologyMatch.Reserve: the pod's effective request is subtracted from every zone of its node that reports the
+ *                      resource (reserve.go:28-46, cache/overreserve.go:170-186, cache/store.go:315-356);
+ *   CAPACITY           Reserve: the namespace's Used grows by the pod's request, a nominated pod that gets bound stops counting as
+ *                      nominated (capacity_scheduling.go:350-364, elasticquota.go:89-98) — needs spx_quota_soa.min;
+ *   NETOVERHEAD        the pod joins its AppGroup's scheduled list (networkoverhead.go:205-224) — needs spx_upload_net_commit.
+ * plugin_mask is a subset of {ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY}.  Without a Filter plugin the whole chain runs in one
+ * workgroup (about 3 us per pod); with one, every pod is one single-row spx_eval + spx_eval_best + a bookkeeping launch on the engine
+ * stream (tens of us per pod), score / status tables end up holding each row as its pod saw it.  A pod that fails PreFilter or has no
+ * feasible node gets node -1 and reserves nothing.  Per pod: the node with the highest
  * sum of plugin_weight x score (lowest index among ties; upstream's selectHost draws among them), that sum, and the size
  * of the tie set (NULL = not wanted).  tlp_missing_out (NULL = not wanted) receives the per-node missing utilisation after
  * the last commit.  The engine's uploaded tables are left untouched; with LVRB in the mask its score table is (re)evaluated
@@ -771,6 +794,8 @@ int spx_flatten_net_topo(const spx_nettopo_objects* nt, int32_t* region_cost, in
 int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int32_t* n_keys_out, int64_t* n_pairs_out, int32_t* pod_key, int32_t* topo_order, uint8_t* key_score_equally, int32_t* pair_ptr, int32_t* pair_node, int64_t* pair_max_cost);
 /* TopologicalSort.Less (topologicalsort.go:102-132) for n pairs of pod indices, from the flattened keys */
 int spx_toposort_less(const spx_pod_objects* pods, const int32_t* topo_order, int64_t n_pairs, const int64_t* a, const int64_t* b, uint8_t* less_out);
+/* spx_net_commit_soa columns: *n_entries_out first (NULL arrays), then eff_ptr[P+1], eff_key / eff_max_cost[n_entries] */
+int spx_flatten_net_commit(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int64_t* n_entries_out, int32_t* eff_ptr, int32_t* eff_key, int64_t* eff_max_cost);
 
 /* NRT preemption flow: preemption.GetNRTPostPodsEviction (pkg/noderesourcetopology/preemption/preemption.go:39-157)
  * for node `node`.  The Filter of a preemption dry-run (filter.go:205-220) is the ordinary Filter on the zone table this call

@@ -31,6 +31,7 @@ __device__ bool cmp2(const int64_t* x1, uint32_t x1p, const int64_t* x2, const i
 }
 
 __global__ void k_quota(QuotaArgs a) {
+  SPX_RESOLVE_ROWS(a);
   const int64_t pod = a.row_begin + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (pod >= a.row_end) return;
   const int ns = a.pod_ns[pod];
@@ -52,8 +53,9 @@ __global__ void k_quota(QuotaArgs a) {
     } else {
       int64_t agg[S];
 #pragma unroll
-      for (int s = 0; s < S; ++s) agg[s] = wadd(wadd(a.agg_used[s], in_eq[s]), a.other_nominated[static_cast<int64_t>(ns) * S + s]);
-      const uint32_t agg_p = a.agg_used_present | in_p | a.other_nominated_present[ns];
+      for (int s = 0; s < S; ++s)
+        agg[s] = wadd(wadd(a.agg_used_dyn ? a.agg_used_dyn[s] : a.agg_used[s], in_eq[s]), a.other_nominated[static_cast<int64_t>(ns) * S + s]);
+      const uint32_t agg_p = (a.agg_used_dyn ? static_cast<uint32_t>(a.agg_used_dyn[S]) : a.agg_used_present) | in_p | a.other_nominated_present[ns];
       if (cmp2(agg, agg_p, nullptr, a.agg_min, a.agg_min_present, 0)) status = SPX_QUOTA_ST_OVER_MIN;
     }
   }

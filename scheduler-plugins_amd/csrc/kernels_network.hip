@@ -97,6 +97,7 @@ __device__ __forceinline__ int wave_max(int v) {
 }
 
 __global__ __launch_bounds__(64) void k_net(NetArgs g) {
+  SPX_RESOLVE_ROWS(g);
   extern __shared__ __align__(16) int lds[];
   int* cls_sat = lds;
   int* cls_vio = lds + g.n_classes;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(64) void k_net(NetArgs g) {
   if (pod >= g.row_end) return;
   const int key = g.pod_key[pod];
   const int flag = g.key_flag[key];
-  const int lo = g.pair_ptr[key], hi = g.pair_ptr[key + 1];
+  const int lo = g.pair_ptr[key], hi = g.pair_end ? g.pair_end[key] : g.pair_ptr[key + 1];  // pair_end: lists that grow (commit loop)
   const int64_t n_words = (g.n_nodes + 31) / 32;
   const bool use_cls = g.n_classes > 0;
   const uint8_t* other0 = g.other_status[0] ? g.other_status[0] + pod * g.row_stride : nullptr;
@@ -235,19 +236,23 @@ __device__ __forceinline__ int norm_cost(int cost, int mn, int mx) {
   return range != 0 ? 100 - (100 * (cost - mn)) / range : 100 - (cost - mn);
 }
 
-__global__ __launch_bounds__(64) void k_net_cls(NetArgs g) {
+// One wavefront per pod row in a batch launch; a single-row launch (the sequential commit loop) puts kRowThreads threads on
+// its row — every loop below strides by the block size, the one reduction combines the waves through LDS.
+constexpr int kRowThreads = 1024;
+__global__ __launch_bounds__(kRowThreads) void k_net_cls(NetArgs g) {
+  SPX_RESOLVE_ROWS(g);
   extern __shared__ __align__(16) int lds[];
   const int C = g.n_classes;
   int* cls_word = lds;                                            // cost | (Filter fails) << 31
   int* cls_hosts = lds + C;                                       // distinct host nodes of the class
   uint32_t* cls_fin = reinterpret_cast<uint32_t*>(lds + 2 * C);   // status << 8 | normalised score
   unsigned* host_bits = reinterpret_cast<unsigned*>(lds + 3 * C);
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, nthr = blockDim.x;
   const int64_t pod = g.row_begin + blockIdx.x;
   if (pod >= g.row_end) return;
   const int key = g.pod_key[pod];
   const int flag = g.key_flag[key];
-  const int lo = g.pair_ptr[key], hi = g.pair_ptr[key + 1];
+  const int lo = g.pair_ptr[key], hi = g.pair_end ? g.pair_end[key] : g.pair_ptr[key + 1];  // pair_end: lists that grow (commit loop)
   const int64_t n_words = (g.n_nodes + 31) / 32;
   const uint8_t* other0 = g.other_status[0] ? g.other_status[0] + pod * g.row_stride : nullptr;
   const uint8_t* other1 = g.other_status[1] ? g.other_status[1] + pod * g.row_stride : nullptr;
@@ -257,8 +262,8 @@ __global__ __launch_bounds__(64) void k_net_cls(NetArgs g) {
 
   if (flag != 0) {  // scoreEqually / PreFilter error, as in k_net
     const uint32_t st = flag == 2 ? 0xffffffffu : 0u;
-    for (int64_t t = 0; t < tiles; ++t) {
-      const int64_t n0 = (t * 64 + lane) * kNpl;
+    for (int64_t q = lane; q < tiles * 64; q += nthr) {
+      const int64_t n0 = q * kNpl;
       if (n0 >= g.row_stride) continue;
       *reinterpret_cast<uint32_t*>(out_st + n0) = st;
       *reinterpret_cast<uint32_t*>(out_sc + n0) = 0u;
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(64) void k_net_cls(NetArgs g) {
   }
 
   // ---- phase 1 + 2
-  for (int c = lane; c < C; c += 64) {
+  for (int c = lane; c < C; c += nthr) {
     Acc a{0, 0, 0};
     const int region = g.cls_region[c], zone = g.cls_zone[c];
     for (int i = lo; i < hi; ++i) {
@@ -277,9 +282,9 @@ __global__ __launch_bounds__(64) void k_net_cls(NetArgs g) {
     cls_word[c] = a.cost | (a.vio > a.sat ? static_cast<int>(0x80000000u) : 0);
     cls_hosts[c] = 0;
   }
-  for (int64_t w = lane; w < n_words; w += 64) host_bits[w] = 0u;
+  for (int64_t w = lane; w < n_words; w += nthr) host_bits[w] = 0u;
   __syncthreads();
-  for (int i = lo + lane; i < hi; i += 64) {
+  for (int i = lo + lane; i < hi; i += nthr) {
     const int host = g.pair_node[i];
     const unsigned bit = 1u << (host & 31);
     if (!(atomicOr(&host_bits[host >> 5], bit) & bit)) atomicAdd(&cls_hosts[g.node_class16[host]], 1);
@@ -300,14 +305,14 @@ __global__ __launch_bounds__(64) void k_net_cls(NetArgs g) {
   // ---- phase 3
   int mn = INT32_MAX, mx = INT32_MIN;
   if (!other0 && !other1) {
-    for (int c = lane; c < C; c += 64) {
+    for (int c = lane; c < C; c += nthr) {
       const int w = cls_word[c];
       if (w >= 0 && g.cls_size[c] - cls_hosts[c] > 0) {
         mn = w < mn ? w : mn;
         mx = w > mx ? w : mx;
       }
     }
-    for (int i = lo + lane; i < hi; i += 64) {
+    for (int i = lo + lane; i < hi; i += nthr) {
       const Acc a = direct_eval(g, g.pair_node[i], lo, hi);
       if (!(a.vio > a.sat)) {
         mn = a.cost < mn ? a.cost : mn;
@@ -315,8 +320,8 @@ __global__ __launch_bounds__(64) void k_net_cls(NetArgs g) {
       }
     }
   } else {
-    for (int64_t t = 0; t < tiles; ++t) {
-      const int64_t n0 = (t * 64 + lane) * kNpl;
+    for (int64_t q = lane; q < tiles * 64; q += nthr) {
+      const int64_t n0 = q * kNpl;
       if (n0 >= g.n_nodes) continue;
       const uint32_t oth = other4(n0);
       const uint64_t cw = classes4(n0);
@@ -340,9 +345,19 @@ __global__ __launch_bounds__(64) void k_net_cls(NetArgs g) {
   }
   mn = wave_min(mn);
   mx = wave_max(mx);
+  if (nthr > 64) {
+    __shared__ int s_mn[kRowThreads / 64], s_mx[kRowThreads / 64];
+    if ((lane & 63) == 0) s_mn[lane >> 6] = mn, s_mx[lane >> 6] = mx;
+    __syncthreads();
+    mn = INT32_MAX, mx = INT32_MIN;
+    for (int w = 0; w < (nthr >> 6); ++w) {
+      mn = s_mn[w] < mn ? s_mn[w] : mn;
+      mx = s_mx[w] > mx ? s_mx[w] : mx;
+    }
+  }
 
   // ---- phase 3b
-  for (int c = lane; c < C; c += 64) {
+  for (int c = lane; c < C; c += nthr) {
     const int w = cls_word[c];
     int score = w >= 0 ? norm_cost(w, mn, mx) : 0;
     score = score < 0 ? 0 : (score > 255 ? 255 : score);
@@ -351,8 +366,8 @@ __global__ __launch_bounds__(64) void k_net_cls(NetArgs g) {
   __syncthreads();
 
   // ---- phase 4
-  for (int64_t t = 0; t < tiles; ++t) {
-    const int64_t n0 = (t * 64 + lane) * kNpl;
+  for (int64_t q = lane; q < tiles * 64; q += nthr) {
+    const int64_t n0 = q * kNpl;
     if (n0 >= g.row_stride) continue;
     uint32_t st_w = 0, sc_w = 0;
     if (n0 < g.n_nodes) {
@@ -392,7 +407,7 @@ void launch_net(const NetArgs& g, hipStream_t s) {
   const size_t lds = g.n_classes > 0 ? net_lds_bytes(g.n_classes, g.n_nodes) : 16;
   const bool generic_only = (g.opts & kOptNetGeneric) != 0;  // SPX_OPT_REFERENCE_KERNELS
   if (!generic_only && !g.out_raw && g.n_classes > 0 && g.n_classes <= 65535 && g.node_class16)
-    hipLaunchKernelGGL(k_net_cls, dim3(blocks), dim3(64), lds, s, g);
+    hipLaunchKernelGGL(k_net_cls, dim3(blocks), dim3(blocks == 1 ? kRowThreads : 64), lds, s, g);
   else
     hipLaunchKernelGGL(k_net, dim3(blocks), dim3(64), lds, s, g);
 }

@@ -326,6 +326,7 @@ __device__ __forceinline__ uint64_t ids_of(const NodeState<RM>& ns, uint32_t pos
 
 template <int RM, int SG>
 __global__ __launch_bounds__(256, 2) void k_nrt(NrtArgs a, int n_tiles) {
+  SPX_RESOLVE_ROWS(a);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t unit = static_cast<int64_t>(blockIdx.x) * 4 + wave;

@@ -409,6 +409,7 @@ constexpr int kPhBoth = 0, kPhFilter = 1, kPhScore = 2;
 
 template <int RM, int SG, int PH>
 __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgBalanced ? 2 : (SG == kSgMost ? 4 : 5)) : (PH == kPhFilter ? 5 : (SG == kSgLeast ? 3 : 2))) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
+  SPX_RESOLVE_ROWS(a);
   constexpr bool FULL = PH != kPhFilter;  // only the Score reads the second half of a request item
   typedef ItemRegs<RM, FULL> Regs;
   // A block owns a window of 256 consecutive nodes and a chunk of pod rows.  Inside the window the engine has

@@ -12,6 +12,7 @@ namespace spx {
 
 namespace {
 
+constexpr int kMaxRowWaves = 16;  // waves a single-row launch puts on its row
 constexpr int kNpl = 4;
 
 __device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int m) {
@@ -53,11 +54,11 @@ __device__ __forceinline__ uint32_t infeasible4(const ProfileArgs& a, int64_t po
 // read from L2 per row and pass, 32-bit min/max, and the quotient as one float64 multiply (range < 2^32 < 2^42).
 // The first pass leaves each lane's 4 feasibility bits per tile in LDS (one byte), so the status tables — whose rows
 // do not survive in L2 between the passes at full occupancy — are read from HBM once.
-__device__ __forceinline__ void alloc_masked_compact(const ProfileArgs& a, int64_t pod, int lane, int64_t tiles, uint8_t* feas) {
+__device__ __forceinline__ void alloc_masked_compact(const ProfileArgs& a, int64_t pod, int lane, int wave, int n_waves, int64_t tiles, uint8_t* feas) {
   uint32_t lo = 0xffffffffu, hi = 0u;
   bool any = false;
 #pragma unroll 4
-  for (int64_t t = 0; t < tiles; ++t) {
+  for (int64_t t = wave; t < tiles; t += n_waves) {
     const int64_t n0 = (t * 64 + lane) * kNpl;
     uint32_t ok = 0;
     if (n0 < a.n_nodes) {
@@ -81,11 +82,22 @@ __device__ __forceinline__ void alloc_masked_compact(const ProfileArgs& a, int64
     lo = olo < lo ? olo : lo;
     hi = ohi > hi ? ohi : hi;
   }
-  const bool some = __ballot(any) != 0;
+  bool some = __ballot(any) != 0;
+  if (n_waves > 1) {  // a whole workgroup on one row (single-row launches of the sequential commit loop): combine the waves
+    __shared__ uint32_t s_lo[kMaxRowWaves], s_hi[kMaxRowWaves], s_any[kMaxRowWaves];
+    if (lane == 0) s_lo[wave] = lo, s_hi[wave] = hi, s_any[wave] = some ? 1u : 0u;
+    __syncthreads();
+    lo = 0xffffffffu, hi = 0u, some = false;
+    for (int w = 0; w < n_waves; ++w) {
+      lo = s_lo[w] < lo ? s_lo[w] : lo;
+      hi = s_hi[w] > hi ? s_hi[w] : hi;
+      some |= s_any[w] != 0;
+    }
+  }
   const uint32_t range = some ? hi - lo : 0u;
   const double b = range ? (100.0 / static_cast<double>(range)) * (1.0 + 0x1p-49) : 0.0;
 #pragma unroll 4
-  for (int64_t t = 0; t < tiles; ++t) {
+  for (int64_t t = wave; t < tiles; t += n_waves) {
     const int64_t n0 = (t * 64 + lane) * kNpl;
     if (n0 >= a.row_stride) continue;
     uint32_t w = 0;
@@ -101,18 +113,19 @@ __device__ __forceinline__ void alloc_masked_compact(const ProfileArgs& a, int64
   }
 }
 
-__global__ __launch_bounds__(64) void k_alloc_masked(ProfileArgs a) {
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * kMaxRowWaves) void k_alloc_masked(ProfileArgs a) {
+  SPX_RESOLVE_ROWS(a);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;  // one wave per row, or a workgroup on a single row
   const int64_t pod = a.row_begin + blockIdx.x;
   if (pod >= a.row_end) return;
   const int64_t tiles = (a.row_stride + 64 * kNpl - 1) / (64 * kNpl);
   extern __shared__ uint8_t feas[];  // [tiles][64]
   if (a.alloc_rel != nullptr && a.alloc_rel[a.row_stride] != 0u) {  // wave-uniform
-    alloc_masked_compact(a, pod, lane, tiles, feas);
+    alloc_masked_compact(a, pod, lane, wave, n_waves, tiles, feas);
     return;
   }
   int64_t lo = INT64_MAX, hi = -INT64_MAX;
-  for (int64_t t = 0; t < tiles; ++t) {
+  for (int64_t t = wave; t < tiles; t += n_waves) {
     const int64_t n0 = (t * 64 + lane) * kNpl;
     if (n0 >= a.n_nodes) continue;
     const uint32_t bad = infeasible4(a, pod, n0);
@@ -131,13 +144,23 @@ __global__ __launch_bounds__(64) void k_alloc_masked(ProfileArgs a) {
     lo = olo < lo ? olo : lo;
     hi = ohi > hi ? ohi : hi;
   }
+  if (n_waves > 1) {
+    __shared__ int64_t s_lo[kMaxRowWaves], s_hi[kMaxRowWaves];
+    if (lane == 0) s_lo[wave] = lo, s_hi[wave] = hi;
+    __syncthreads();
+    lo = INT64_MAX, hi = -INT64_MAX;
+    for (int w = 0; w < n_waves; ++w) {
+      lo = s_lo[w] < lo ? s_lo[w] : lo;
+      hi = s_hi[w] > hi ? s_hi[w] : hi;
+    }
+  }
   const uint64_t range = static_cast<uint64_t>(hi) - static_cast<uint64_t>(lo);
   // (s - lo) * 100 / range with a wave-uniform range: below 2^42 the quotient is floor(d * b) for
   // b = RN(100 / range) * (1 + 2^-49) — the float64 product lies in [x, x + 2^-42) and frac(x) <= 1 - 1/range, so the
   // floor is exact (same argument as kernels_nrt_fast.hip); wider ranges keep the int64 division
   const bool small = hi >= lo && range < (1ull << 42);
   const double b = small && range ? (100.0 / static_cast<double>(range)) * (1.0 + 0x1p-49) : 0.0;
-  for (int64_t t = 0; t < tiles; ++t) {
+  for (int64_t t = wave; t < tiles; t += n_waves) {
     const int64_t n0 = (t * 64 + lane) * kNpl;
     if (n0 >= a.row_stride) continue;
     uint32_t w = 0;
@@ -165,15 +188,16 @@ __global__ __launch_bounds__(64) void k_alloc_masked(ProfileArgs a) {
 
 // per pod: argmax over feasible nodes of Σ_plugin weight x score; ties resolved to the lowest node index, the
 // tie count is returned so that callers can compare tie SETS (upstream selectHost picks randomly among them)
-__global__ __launch_bounds__(64) void k_best(ProfileArgs a) {
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * kMaxRowWaves) void k_best(ProfileArgs a) {
+  SPX_RESOLVE_ROWS(a);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   const int64_t pod = a.row_begin + blockIdx.x;
   if (pod >= a.row_end) return;
   int64_t best = INT64_MIN;
   int best_n = -1, ties = 0, feas = 0;
   const bool pod_ok = !a.prefilter || a.prefilter[pod] == 0;
   const int64_t tiles = pod_ok ? (a.n_nodes + 64 * kNpl - 1) / (64 * kNpl) : 0;
-  for (int64_t t = 0; t < tiles; ++t) {  // 4 consecutive nodes per lane: one dword per table
+  for (int64_t t = wave; t < tiles; t += n_waves) {  // 4 consecutive nodes per lane: one dword per table
     const int64_t n0 = (t * 64 + lane) * kNpl;
     if (n0 >= a.n_nodes) continue;
     const uint32_t bad = infeasible4(a, pod, n0);
@@ -213,6 +237,22 @@ __global__ __launch_bounds__(64) void k_best(ProfileArgs a) {
       ties += ot;
     }
   }
+  if (n_waves > 1) {  // merge the waves' (best, lowest node, ties, feasible) with the rule of the butterfly above
+    __shared__ int64_t s_best[kMaxRowWaves];
+    __shared__ int s_n[kMaxRowWaves], s_t[kMaxRowWaves], s_f[kMaxRowWaves];
+    if (lane == 0) s_best[wave] = best, s_n[wave] = best_n, s_t[wave] = ties, s_f[wave] = feas;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    best = INT64_MIN, best_n = -1, ties = 0, feas = 0;
+    for (int w = 0; w < n_waves; ++w) {
+      const int64_t ob = s_best[w];
+      const int on = s_n[w], ot = s_t[w];
+      feas += s_f[w];
+      if (on < 0) continue;
+      if (best_n < 0 || ob > best) best = ob, best_n = on, ties = ot;
+      else if (ob == best) ties += ot, best_n = on < best_n ? on : best_n;
+    }
+  }
   if (lane == 0) {
     a.best_node[pod] = best_n;
     a.best_score[pod] = best_n >= 0 ? best : 0;
@@ -226,12 +266,14 @@ __global__ __launch_bounds__(64) void k_best(ProfileArgs a) {
 void launch_alloc_masked(const ProfileArgs& a, hipStream_t s) {
   if (a.row_end <= a.row_begin) return;
   const size_t tiles = static_cast<size_t>((a.row_stride + 64 * kNpl - 1) / (64 * kNpl));
-  hipLaunchKernelGGL(k_alloc_masked, dim3(static_cast<unsigned>(a.row_end - a.row_begin)), dim3(64), tiles * 64, s, a);
+  const unsigned rows = static_cast<unsigned>(a.row_end - a.row_begin);
+  hipLaunchKernelGGL(k_alloc_masked, dim3(rows), dim3(rows == 1 ? 64 * kMaxRowWaves : 64), tiles * 64, s, a);
 }
 
 void launch_best(const ProfileArgs& a, hipStream_t s) {
   if (a.row_end <= a.row_begin) return;
-  hipLaunchKernelGGL(k_best, dim3(static_cast<unsigned>(a.row_end - a.row_begin)), dim3(64), 0, s, a);
+  const unsigned rows = static_cast<unsigned>(a.row_end - a.row_begin);
+  hipLaunchKernelGGL(k_best, dim3(rows), dim3(rows == 1 ? 64 * kMaxRowWaves : 64), 0, s, a);
 }
 
 }  // namespace spx

@@ -223,6 +223,7 @@ __device__ __forceinline__ void store_bytes(uint8_t* dst, const uint32_t (&w)[NP
 
 template <int NPL, bool A, bool T, bool L>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_trimaran(TrimaranArgs a, int n_tiles) {
+  SPX_RESOLVE_ROWS(a);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
@@ -407,6 +408,7 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
 
 template <int NPL, bool A, bool D = false>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArgs a, int n_tiles, double c1, double c2, DecideArgs dec) {
+  SPX_RESOLVE_ROWS(a);
   static_assert(kPodsPerChunk == kWave, "one pod record per lane");
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -657,6 +659,7 @@ __global__ void k_lvrb_prepare_fast(TrimaranArgs a, int64_t n_slots) {
 
 template <int NPL, bool A>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArgs a, int n_tiles) {
+  SPX_RESOLVE_ROWS(a);
   static_assert(kPodsPerChunk == kWave, "one pod record per lane");
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -16,6 +16,17 @@ constexpr int64_t kRowPad = 128;
 
 inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// Row range of a sweep: [row_begin, row_end) from the launch, or — row_ptr set — the single row whose index sits in device memory.
+// The sequential commit loop replays ONE captured graph per pod; the graph's kernels read the row from the counter k_commit_apply
+// advances.  Call first thing in a kernel, on its by-value argument struct.
+#define SPX_RESOLVE_ROWS(a)              \
+  do {                                   \
+    if ((a).row_ptr) {                   \
+      (a).row_begin = *(a).row_ptr;      \
+      (a).row_end = (a).row_begin + 1;   \
+    }                                    \
+  } while (0)
+
 // spx_fetch_stats counters: kStatSlots per plugin, summed at fetch (same-address atomics serialise in the L2)
 constexpr int kStatSlots = 64;
 constexpr int kStatStride = 16;  // uint64 per slot: every slot on its own 128-byte line
@@ -65,6 +76,7 @@ struct TrimaranArgs {
   int64_t row_stride;
   int64_t row_begin;
   int64_t row_end;
+  const int64_t* row_ptr;  // when set: evaluate the single row *row_ptr (sequential commit: the row counter lives on the device)
   // Allocatable: pod-independent normalized row (no per-row feasibility mask)
   const uint8_t* alloc_norm;
   // TargetLoadPacking
@@ -198,6 +210,7 @@ struct NrtArgs {
   int64_t row_stride;
   int64_t row_begin;
   int64_t row_end;
+  const int64_t* row_ptr;  // when set: evaluate the single row *row_ptr (sequential commit: the row counter lives on the device)
   int32_t n_res;
   int32_t strategy;
   uint8_t slot_flags[SPX_NRT_MAX_RES];
@@ -279,6 +292,7 @@ struct NetArgs {
   int64_t row_stride;
   int64_t row_begin;
   int64_t row_end;
+  const int64_t* row_ptr;  // when set: evaluate the single row *row_ptr (sequential commit: the row counter lives on the device)
   int32_t n_regions;
   int32_t n_zones;
   int32_t n_classes;            // 0 = no class table: every node takes the exact per-pair path
@@ -294,6 +308,7 @@ struct NetArgs {
   const int32_t* pod_key;       // [P]
   const uint8_t* key_flag;      // [K] 0 evaluate, 1 scoreEqually, 2 PreFilter error
   const int32_t* pair_ptr;      // [K+1]
+  const int32_t* pair_end;      // [K] end of key k's list when the lists have slack and grow (sequential commit); NULL = pair_ptr[k+1]
   const int32_t* pair_node;
   const int64_t* pair_max;
   const uint8_t* other_status[2];  // other Filter plugins' status tables [P][row_stride] (0 = passed), NULL = unused
@@ -321,6 +336,7 @@ const int32_t* launch_sort_keys(const SortArgs& a, void* scratch, unsigned* hist
 struct QuotaArgs {
   int64_t row_begin;
   int64_t row_end;
+  const int64_t* row_ptr;  // when set: evaluate the single row *row_ptr (sequential commit: the row counter lives on the device)
   int32_t n_namespaces;
   const int32_t* pod_ns;
   const int32_t* pod_priority;
@@ -334,6 +350,7 @@ struct QuotaArgs {
   uint32_t agg_used_present;
   int64_t agg_min[SPX_QUOTA_SLOTS];
   uint32_t agg_min_present;
+  const int64_t* agg_used_dyn;     // when set: [8] aggregate used + [1] its presence bits, in device memory (advances with commits)
   const int64_t* other_nominated;  // [NS][8]
   const uint8_t* other_nominated_present;
   const int32_t* nom_ptr;          // [NS+1]
@@ -345,12 +362,64 @@ struct QuotaArgs {
 };
 void launch_quota(const QuotaArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- sequential commit with Filter plugins (kernels_commit.hip)
+// Bookkeeping of ONE bound pod (row `pod`, node = best_node[pod]) on the engine's device tables: what the reference's Reserve /
+// assume-time hooks do between two scheduling cycles.  NULL table groups are skipped.
+struct CommitApplyArgs {
+  int64_t pod;                    // row just decided
+  int64_t* row_counter;           // when set: the row is *row_counter, and the kernel advances it (graph replay)
+  int64_t n_nodes, n_pods;
+  const int32_t* best_node;       // [P] (spx_eval_best layout)
+  // trimaran: handler.go:131-139 feeding targetloadpacking.go:151-168
+  int64_t* tlp_missing;           // [N]
+  const int64_t* tlp_pod_milli;   // [P]
+  // NRT: OverReserve.ReserveNodeResources -> resourceStore.UpdateNRT (cache/overreserve.go:170-186, store.go:315-356)
+  int32_t nrt_n_res, nrt_cpu_slot;
+  const uint8_t* nrt_flags;       // [N]
+  const uint8_t* nrt_zone_present;// [Z][N] bit r: zone reports slot r
+  int64_t* nrt_avail;             // [Z][R][N]
+  double* f_av;                   // derived float64 tables of the fast sweep, same cell order
+  double* f_rc;
+  double* f_rcv;
+  double* f_cpu;                  // [Z][N]
+  double* f_braw;                 // [Z][N]
+  const uint8_t* nrt_pod_present; // [P] bit r: the pod's effective request lists slot r
+  const int64_t* nrt_pod_req;     // [P][R]
+  // CapacityScheduling: Reserve -> addPodIfNotPresent -> reserveResource (capacity_scheduling.go:350-364, elasticquota.go:89-98)
+  int32_t q_n_namespaces;
+  const int32_t* q_pod_ns;
+  const int64_t* q_pod_req;       // [P][8]
+  const uint8_t* q_pod_reqp;
+  const uint8_t* q_has;           // [NS]
+  int64_t* q_used;                // [NS][8]
+  uint8_t* q_used_present;        // [NS]
+  const int64_t* q_min;           // [NS][8]
+  const uint8_t* q_min_present;
+  int64_t* q_agg_used;            // [8] + [1] presence
+  const int32_t* q_nom_ptr;       // [NS+1]
+  const int64_t* q_nom_pending;   // per nominated entry: pending row, -1 none
+  int64_t* q_nom_req;             // [n][8]  (zeroed when the nominated pod itself is bound: it left the nominator)
+  uint8_t* q_nom_reqp;
+  int64_t* q_other;               // [NS][8] nominated requests of OTHER namespaces whose quota is not over min: recomputed
+  uint8_t* q_otherp;
+  // NetworkOverhead: the bound pod joins its AppGroup's scheduled list (util.GetScheduledList over the pod lister)
+  const int32_t* net_eff_ptr;     // [P+1]
+  const int32_t* net_eff_key;     // workload key that sees the new pod
+  const int64_t* net_eff_cost;    // dependency MaxNetworkCost, -1 = the key only stops scoring equally
+  uint8_t* net_key_flag;          // [K]
+  int32_t* net_pair_end;          // [K]
+  int32_t* net_pair_node;
+  int64_t* net_pair_max;
+};
+void launch_commit_apply(const CommitApplyArgs& a, hipStream_t s);
+
 // ---------------------------------------------------------------- profile-level passes
 struct ProfileArgs {
   int64_t n_nodes;
   int64_t row_stride;
   int64_t row_begin;
   int64_t row_end;
+  const int64_t* row_ptr;  // when set: evaluate the single row *row_ptr (sequential commit: the row counter lives on the device)
   const uint8_t* status[3];                // filter status tables in play (0 = passed); NULL = unused
   const uint8_t* prefilter;                // [P] CapacityScheduling.PreFilter status, NULL = unused
   const int64_t* alloc_raw;                // [N] Allocatable raw scores

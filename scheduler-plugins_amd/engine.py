@@ -321,8 +321,14 @@ class Engine:
                                         cols["pod_key"].ctypes.data_as(i32p), cols["topo_order"].ctypes.data_as(i32p),
                                         cols["key_score_equally"].ctypes.data_as(u8p), cols["pair_ptr"].ctypes.data_as(i32p),
                                         cols["pair_node"].ctypes.data_as(i32p), cols["pair_max_cost"].ctypes.data_as(i64p)))
+        # what binding each pod adds to the AppGroup scheduled lists (sequential commit loop)
+        n_eff = C.c_int64()
+        self._ck(L.spx_flatten_net_commit(pods.ref(), appgroups.ref(), C.byref(n_eff), None, None, None))
+        eff = dict(eff_ptr=np.zeros(P + 1, np.int32), eff_key=np.zeros(max(n_eff.value, 1), np.int32), eff_max_cost=np.zeros(max(n_eff.value, 1), np.int64))
+        self._ck(L.spx_flatten_net_commit(pods.ref(), appgroups.ref(), C.byref(n_eff), eff["eff_ptr"].ctypes.data_as(i32p),
+                                          eff["eff_key"].ctypes.data_as(i32p), eff["eff_max_cost"].ctypes.data_as(i64p)))
         return {"region": nodes.array("region"), "zone": nodes.array("zone"), "rg": rg, "zc": zc, "rcost": rcost, "zcost": zcost,
-                "n_keys": nk.value, "cols": cols, "N": N, "P": P}
+                "n_keys": nk.value, "cols": cols, "N": N, "P": P, "commit": eff}
 
     def upload_network(self, f: dict, rows=None) -> None:
         L, H = self._lib, self._hdr
@@ -334,6 +340,8 @@ class Engine:
         cols.update(_rows({k: cols[k] for k in ("pod_key", "topo_order")}, f["P"], rows))  # the key tables are per workload, not per pod
         if P > 0:
             self._ck(L.spx_upload_net_pods(self._h, Table(H, "spx_net_pods_soa", n_pods=P, n_keys=f["n_keys"], **cols).ref()))
+            if rows is None:  # the commit effects index the whole batch
+                self._ck(L.spx_upload_net_commit(self._h, Table(H, "spx_net_commit_soa", n_pods=P, **f["commit"]).ref()))
         self.n_nodes, self.n_pods = f["N"], P
         self.net_soa = cols
 
@@ -381,7 +389,7 @@ class Engine:
         self._ck_static(fn(pods.ref(), rc.ref() if rc else None, quota.ref(),
                            *[v.ctypes.data_as(t) for v, t in zip(cols.values(), fn.argtypes[3:])]))
         ns = dict(has_quota=quota.array("has_quota"), used=quota.array("used"), used_present=quota.array("used_present"),
-                  max=quota.array("max"), max_present=quota.array("max_present"))
+                  max=quota.array("max"), max_present=quota.array("max_present"), min=quota.array("min"), min_present=quota.array("min_present"))
         return {"cols": cols, "ns": ns, "P": P, "NS": NS}
 
     _QUOTA_POD_COLS = ("pod_ns", "pod_priority", "pod_req", "pod_req_present")
@@ -485,7 +493,8 @@ class Engine:
         return node, score, ties, feas
 
     def commit_sequential(self, plugin_mask: int, row_begin: int = 0, row_end: Optional[int] = None, want_ties: bool = True):
-        """pods in row order, each seeing the commits before it (Allocatable/TLP/LVRB) -> (node, weighted score, ties, missing)"""
+        """pods in row order, each seeing the commits before it -> (node, weighted score, ties, missing); plugin_mask may hold
+        Allocatable / TLP / LVRB / NRT / NetworkOverhead / CapacityScheduling (spx_commit_sequential)"""
         row_end = self.n_pods if row_end is None else row_end
         n = row_end - row_begin
         node, score, ties = np.zeros(n, np.int32), np.zeros(n, np.int64), np.zeros(n, np.int32)

@@ -8,6 +8,7 @@
 // A pod's PreFilter state depends only on its (AppGroup, workload selector): the join is done once per such
 // "workload key" and pods carry the key.  TopologicalSort's per-comparison CR Get + two binary searches
 // (topologicalsort.go:118-127) become one FindPodOrder per pod.
+#include <climits>
 #include <cstdint>
 #include <cstddef>
 #include <map>
@@ -117,6 +118,56 @@ extern "C" int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgr
   }
   *n_keys_out = static_cast<int32_t>(order.size());
   *n_pairs_out = n_pairs;
+  return SPX_OK;
+}
+
+// What binding pending pod p changes for NetworkOverhead's view of the pods scheduled after it (sequential commit, SURVEY 8f
+// rank 1): p joins its AppGroup's scheduled list (util.GetScheduledList over the pod lister), so
+//   * every workload key of the group that has dependencies stops "scoring equally" (the list is no longer empty:
+//     networkoverhead.go:215-224) -> an entry (key, -1);
+//   * every dependency of such a workload on p's workload selector gains a (host, MaxNetworkCost) pair -> (key, cost).
+// Keys are numbered exactly as spx_flatten_net_keys numbers them.  Sizes first (NULL arrays), then the CSR.
+extern "C" int spx_flatten_net_commit(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int64_t* n_entries_out, int32_t* eff_ptr,
+                                      int32_t* eff_key, int64_t* eff_cost) {
+  if (!pods || !ag || !n_entries_out) return SPX_ERR_ARG;
+  const bool fill = eff_ptr && eff_key && eff_cost;
+  std::map<std::pair<int32_t, int32_t>, int32_t> keys;
+  keys[{-1, -1}] = 0;
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> by_group(static_cast<size_t>(ag->n_groups > 0 ? ag->n_groups : 0));  // (selector, key)
+  int32_t next = 1;
+  for (int64_t p = 0; p < pods->n_pods; ++p) {
+    const int32_t g = pods->appgroup[p];
+    if (g < 0 || g >= ag->n_groups) continue;
+    const std::pair<int32_t, int32_t> k{g, pods->selector[p]};
+    if (keys.emplace(k, next).second) by_group[static_cast<size_t>(g)].emplace_back(k.second, next++);
+  }
+  int64_t n = 0;
+  if (fill) eff_ptr[0] = 0;
+  for (int64_t p = 0; p < pods->n_pods; ++p) {
+    const int32_t g = pods->appgroup[p], sel = pods->selector[p];
+    if (g >= 0 && g < ag->n_groups)
+      for (const auto& kk : by_group[static_cast<size_t>(g)]) {
+        bool any_dep = false;
+        for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w)
+          if (ag->wl_selector[w] == kk.first && ag->dep_ptr[w + 1] > ag->dep_ptr[w]) any_dep = true;
+        if (!any_dep) continue;
+        if (fill) eff_key[n] = kk.second, eff_cost[n] = -1;
+        ++n;
+        for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w) {
+          if (ag->wl_selector[w] != kk.first) continue;
+          for (int32_t d = ag->dep_ptr[w]; d < ag->dep_ptr[w + 1]; ++d) {
+            if (ag->dep_selector[d] != sel) continue;
+            if (fill) eff_key[n] = kk.second, eff_cost[n] = ag->dep_max_cost[d];
+            ++n;
+          }
+        }
+      }
+    if (fill) {
+      if (n > INT32_MAX) return SPX_ERR_ARG;
+      eff_ptr[p + 1] = static_cast<int32_t>(n);
+    }
+  }
+  *n_entries_out = n;
   return SPX_OK;
 }
 
