@@ -358,3 +358,59 @@ def test_wire_format_to_gpu_filter(gpu_required, hdr, oracle):
     assert status.tolist() == want.filter_rows(NRT).tolist() == [[0, 0], [4, 0], [4, 0], [4, 4]]
     raw = want.score_rows(NRT)[0]
     assert (scores.astype(np.int64)[status == 0] == raw[status == 0]).all()
+
+
+# ------------------------------------------------------------------ DiscardReserved cache (cache/discardreserved.go:62-115)
+def test_discard_reserved_cache_semantics(gpu_required, hdr, oracle):
+    """The DiscardReserved NRT cache answers (nil, CachedNRTInfo{Fresh: false}) for a node while any pod holds a reservation on
+    it (GetCachedNRTCopy :62-76; Reserve adds the pod's UID :86-95, Unreserve / PostBind remove it :97-115), otherwise the NRT as
+    the API server has it with Fresh = true.  The reservation map is control-plane state and stays on the Go side; what reaches
+    the engine is its verdict per node: the `fresh` column (and no NRT).  Filter must then answer "invalid node topology data"
+    for every pod it filters (filter.go:197-199, checked before the nil-NRT pass-through) and Score 0 for Guaranteed pods
+    (score.go:78-81) — on exactly the reserved nodes, and the verdict must flip back when the reservation goes away."""
+    res, nodes, nrt_t, pods = _wide_snapshot(hdr, 96, 40, seed=33)
+    params = O.nrt_params(hdr, res, "LeastAllocated")
+    n = 96
+    reservations = {}                                      # node index -> {pod uid}: the cache's reservationMap
+
+    def cache_view():
+        """GetCachedNRTCopy for every node: (NRT or None, Fresh)"""
+        reserved = np.array([len(reservations.get(i, ())) > 0 for i in range(n)])
+        nrt_t.array("fresh")[:] = ~reserved          # CachedNRTInfo.Fresh per node (the table is the shim's per-cycle marshalling)
+        return reserved, nrt_t
+
+    def evaluate(nrt_t):
+        with Engine(0) as e:
+            e.load_nrt_objects(nodes, nrt_t, res.table(hdr), pods, params)
+            e.eval(mask_of(NRT))
+            e.sync()
+            st, sc = e.all_status(NRT), e.all_scores(NRT)
+            qos = e.nrt_soa["pods"]["qos"].copy()
+            nn = e.nrt_soa["pods"]["non_native"].copy()
+        osnap = oracle.Snapshot(nodes, pods, rc=res.table(hdr), nrt=nrt_t, nrt_params=params)
+        assert np.array_equal(st, osnap.filter_rows(NRT)) and np.array_equal(sc.astype(np.int64), osnap.score_rows(NRT, want_norm=False)[0].clip(0, 255))
+        return st, sc, qos, nn
+
+    INVALID = hdr.consts["SPX_NRT_ST_INVALID_TOPOLOGY"]
+    reserved, t0 = cache_view()
+    st0, sc0, qos, nn = evaluate(t0)
+    assert not reserved.any() and not (st0 == INVALID).any()
+    # Reserve: two pods on node 5, one on node 40
+    for node, uid in ((5, "a"), (5, "b"), (40, "c")):
+        reservations.setdefault(node, set()).add(uid)
+    reserved, t1 = cache_view()
+    st1, sc1, _, _ = evaluate(t1)
+    filtered = ~((qos == hdr.consts["SPX_QOS_BESTEFFORT"]) & (nn == 0))       # filter.go:186-190
+    guaranteed = qos == hdr.consts["SPX_QOS_GUARANTEED"]
+    assert filtered.any() and guaranteed.any() and (~guaranteed).any()
+    assert (st1[filtered][:, reserved] == INVALID).all() and (st1[~filtered] == 0).all()
+    assert (sc1[guaranteed][:, reserved] == 0).all() and (sc1[~guaranteed] == 100).all()
+    assert np.array_equal(st1[:, ~reserved], st0[:, ~reserved]) and np.array_equal(sc1[:, ~reserved], sc0[:, ~reserved])
+    # PostBind of one of node 5's pods: still reserved; Unreserve of the other and PostBind on node 40: back to the API server's view
+    reservations[5].discard("a")
+    assert cache_view()[0][5]
+    reservations[5].discard("b")
+    reservations[40].discard("c")
+    reserved, t2 = cache_view()
+    st2, sc2, _, _ = evaluate(t2)
+    assert not reserved.any() and np.array_equal(st2, st0) and np.array_equal(sc2, sc0)
