@@ -442,8 +442,10 @@ template <typename T>
 int upload_transposed(spx_engine* e, DevBuf& b, const T* src, int64_t n, int64_t inner) {
   if (!src) return fail(e, SPX_ERR_ARG, "NULL column in table");
   std::vector<T> tmp(static_cast<size_t>(n) * static_cast<size_t>(inner));
-  for (int64_t i = 0; i < n; ++i)
-    for (int64_t k = 0; k < inner; ++k) tmp[static_cast<size_t>(k) * n + i] = src[static_cast<size_t>(i) * inner + k];
+  spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
+    for (int64_t i = row0; i < row1; ++i)
+      for (int64_t k = 0; k < inner; ++k) tmp[static_cast<size_t>(k) * n + i] = src[static_cast<size_t>(i) * inner + k];
+  }, 2048);
   int rc = upload(e, b, tmp.data(), tmp.size() * sizeof(T));
   if (rc) return rc;
   SPX_HIP(e, hipStreamSynchronize(e->stream));  // tmp dies at scope exit
@@ -809,8 +811,9 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
     std::vector<double> av(static_cast<size_t>(Zm * R * n), -1.0), rcp(static_cast<size_t>(Zm * R * n), spx::kNrtNoCap), rcv(static_cast<size_t>(Zm * R * n), 1.0),
         cpuv(static_cast<size_t>(Zm * n), 0.0), braw(static_cast<size_t>(Zm * n), spx::kNrtNoCap);
     std::vector<uint8_t> rep(static_cast<size_t>((R > 0 ? R : 1) * n), 0);
-    bool ok = true;
-    for (int64_t i = 0; i < n; ++i) {
+    std::atomic<bool> ok{true};
+    spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
+    for (int64_t i = row0; i < row1; ++i) {
       const int nz = t->n_zones[i];
       for (int z = 0; z < nz && z < Zm; ++z) {
         if (t->zone_id[i * Zm + z] != z) ok = false;  // "lowest NUMA id" must be "lowest list position"
@@ -829,7 +832,8 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
         }
       }
     }
-    e->nrt_fast_nodes = ok;
+    }, 1024);
+    e->nrt_fast_nodes = ok.load();
     // window-local node order: inside each run of 256 nodes, group the nodes by the code path their flags select
     // (not aligned / pod scope / container scope) so that wavefronts are mostly homogeneous
     const int64_t n_slots = spx::round_up(n, 256);

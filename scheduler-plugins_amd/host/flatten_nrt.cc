@@ -128,7 +128,10 @@ extern "C" int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nr
   std::memset(zone_id, 0, static_cast<size_t>(n) * Z);
   std::memset(zone_present, 0, static_cast<size_t>(n) * Z);
   std::memset(zone_avail, 0, static_cast<size_t>(n) * Z * R * sizeof(int64_t));
-  for (int64_t i = 0; i < n; ++i) {
+  std::atomic<int> err{SPX_OK};
+  // nodes are independent: split across host threads (20k nodes x 255 zone subsets for the distance minima alone)
+  spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
+  for (int64_t i = row0; i < row1; ++i) {
     // ---- TopologyManager config
     int scope = 0, policy = 0, mx = 8;
     const int lp = nrt->legacy_policy ? nrt->legacy_policy[i] : -1;
@@ -159,13 +162,19 @@ extern "C" int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nr
         if (!nrt->zone_is_node[z]) continue;
         const int id = nrt->zone_numa_id[z];
         if (id < 0 || id > 64) continue;
-        if (nz >= Z || id > 63) return SPX_ERR_ARG;  // beyond this build's limits (8 zones, ids 0..63)
+        if (nz >= Z || id > 63) {
+          err = SPX_ERR_ARG;
+          return;
+        }  // beyond this build's limits (8 zones, ids 0..63)
         zsrc[nz] = z;
         zone_id[i * Z + nz] = static_cast<uint8_t>(id);
         uint8_t present = 0;
         for (int32_t k = nrt->zres_ptr[z]; k < nrt->zres_ptr[z + 1]; ++k) {
           const int s = slot_of(slots, nrt->zres_res[k]);
-          if (s < 0) return SPX_ERR_ARG;
+          if (s < 0) {
+            err = SPX_ERR_ARG;
+            return;
+          }
           int64_t avail = nrt->zres_avail[k];
           if (nrt->assumed_ptr)
             for (int32_t a = nrt->assumed_ptr[i]; a < nrt->assumed_ptr[i + 1]; ++a)
@@ -191,24 +200,22 @@ extern "C" int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nr
         zone_cost[(i * Z + a) * Z + b] = cost;
       }
     // ---- minAvgDistanceInCombinations for every subset size (float32 exactly as the reference)
-    for (int k = 1; k <= Z; ++k) {
-      float best = 255.0f;
-      if (k <= nz) {
-        for (unsigned m = 1; m < (1u << nz); ++m) {
-          if (__builtin_popcount(m) != k) continue;
-          int accu = 0;
-          for (int a = 0; a < nz; ++a)
-            if (m >> a & 1)
-              for (int b = 0; b < nz; ++b)
-                if (m >> b & 1) accu += zone_cost[(i * Z + a) * Z + b];
-          const float d = static_cast<float>(accu) / static_cast<float>(k * k);
-          if (d < best) best = d;
-        }
-      }
-      min_avg_dist[i * Z + (k - 1)] = best;
+    float best[Z];
+    for (int k = 0; k < Z; ++k) best[k] = 255.0f;
+    for (unsigned m = 1; m < (1u << nz); ++m) {  // every subset once, filed under its size
+      const int k = __builtin_popcount(m);
+      int accu = 0;
+      for (int a = 0; a < nz; ++a)
+        if (m >> a & 1)
+          for (int b = 0; b < nz; ++b)
+            if (m >> b & 1) accu += zone_cost[(i * Z + a) * Z + b];
+      const float d = static_cast<float>(accu) / static_cast<float>(k * k);
+      if (d < best[k - 1]) best[k - 1] = d;
     }
+    for (int k = 0; k < Z; ++k) min_avg_dist[i * Z + k] = best[k];
   }
-  return SPX_OK;
+  }, 256);
+  return err.load();
 }
 
 extern "C" int spx_flatten_nrt_pods(const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_nrt_slots* slots,
