@@ -661,9 +661,11 @@ int spx_fetch_best(spx_engine* e, int64_t row_begin, int64_t row_end, int32_t* n
 
 /* Decisions without tables: what spx_eval + spx_eval_best would leave for spx_fetch_best, computed in one sweep that never
  * writes a score table (the per-row argmax is folded into the sweep: no 1 B/cell/plugin to HBM and back).  Fused for the
- * Filter-less profile {TLP} or {ALLOCATABLE, TLP} with non-negative plugin weights and no caller feasibility mask; any other
- * request is served by running spx_eval and spx_eval_best.  Score tables and their `evaluated` state are left untouched by the
- * fused form.  Asynchronous on the engine stream like spx_eval. */
+ * Filter-less profiles made of TLP, optionally ALLOCATABLE, and any of the Score-only plugins LVRB / LROC / PEAKS, with
+ * non-negative plugin weights and no caller feasibility mask.  ALLOCATABLE's and TLP's tables are never written; the
+ * Score-only plugins' tables ARE evaluated (spx_eval on those plugins, so they can be fetched afterwards) and read once by
+ * the fused sweep in place of spx_eval_best's pass over every table.  Any other request is served by running spx_eval and
+ * spx_eval_best.  Asynchronous on the engine stream like spx_eval. */
 int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end);
 
 /* Sequential scheduling of pod rows [row_begin,row_end), in row (= queue) order.  Unlike spx_eval's frozen

@@ -382,8 +382,15 @@ __global__ void k_tlp_prepare_fast(TrimaranArgs a, int64_t n_slots, double c1, d
 // w_alloc * alloc + w_tlp * tlp of its 64 x NPL nodes into (best total, lowest node with it, how many nodes tie) per pod and
 // leaves that triple in dec.key / dec.ties [tile][row]; k_decide_reduce merges the tiles.  The bytes are the very ones the
 // table mode stores (same code up to the store), so the decisions equal spx_eval + spx_eval_best by construction.
+constexpr int kDecideExtras = 3;
 struct DecideArgs {
   int32_t w_alloc, w_tlp;
+  // score tables of further Score-only plugins of the profile, already evaluated for these rows (LVRB, LowRiskOverCommitment,
+  // Peaks): their bytes are read once and folded into the total, so neither this sweep's tables nor a second pass over
+  // all tables (k_best) is needed
+  int32_t n_extra;
+  int32_t w_extra[kDecideExtras];
+  const uint8_t* extra[kDecideExtras];  // [pods][row_stride]
   uint64_t* key;   // [n_tiles][rows]: (total + 1) << 32 | (0xffffffff - node); 0 = no node in the tile
   int32_t* ties;   // [n_tiles][rows]
   int64_t rows;
@@ -535,13 +542,24 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
     } else {
       // lane: best weighted total over its NPL nodes, the lowest node index reaching it, and the tie count
       int best = -1, best_j = 0, ties = 0;
+      int ext[NPL];
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) ext[i] = 0;
+      for (int x = 0; x < dec.n_extra; ++x) {
+        uint32_t xw[NPL / 4];
+#pragma unroll
+        for (int j = 0; j < NPL / 4; ++j) xw[j] = active ? reinterpret_cast<const uint32_t*>(dec.extra[x] + row)[j] : 0u;
+        const int wx = dec.w_extra[x];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) ext[i] += wx * static_cast<int>((xw[i >> 2] >> (8 * (i & 3))) & 0xffu);
+      }
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
         const int tb = static_cast<int>((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
         int ab = 0;
         if constexpr (A) ab = static_cast<int>((alloc_w[i >> 2] >> (8 * (i & 3))) & 0xffu);
         const bool in = active && node0 + i < a.n_nodes;
-        const int tot = in ? dec.w_tlp * tb + dec.w_alloc * ab : -1;
+        const int tot = in ? dec.w_tlp * tb + dec.w_alloc * ab + ext[i] : -1;
         if (tot > best) best = tot, best_j = i, ties = 1;
         else if (tot == best) ++ties;
       }
@@ -1162,6 +1180,8 @@ void launch_decide_trimaran(const DecideLaunch& d, hipStream_t s) {
   DecideArgs dec;
   dec.w_alloc = d.w_alloc;
   dec.w_tlp = d.w_tlp;
+  dec.n_extra = d.n_extra;
+  for (int x = 0; x < kDecideExtras; ++x) dec.w_extra[x] = d.w_extra[x], dec.extra[x] = d.extra[x];
   dec.key = static_cast<uint64_t*>(d.scratch);
   dec.ties = reinterpret_cast<int32_t*>(dec.key + static_cast<int64_t>(n_tiles) * rows);
   dec.rows = rows;

@@ -35,6 +35,7 @@ struct spx_engine {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool hold_ev0 = false;  // spx_decide times its preparatory spx_eval together with its own sweep
   bool timed = false;
   mutable std::string err;
 
@@ -1258,7 +1259,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     if ((rc = ensure(e, e->d_tlp_fast, static_cast<size_t>(spx::round_up(e->row_stride, 1024)) * 4 * sizeof(float)))) return rc;
     a.tlp_fast = static_cast<float*>(e->d_tlp_fast.p);
   }
-  SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
+  if (!e->hold_ev0) SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
   if (Q) {
     if ((rc = ensure(e, e->d_q_status, static_cast<size_t>(e->n_pods)))) return rc;
     spx::QuotaArgs qa{};
@@ -1942,10 +1943,19 @@ int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t r
   if (!e) return SPX_ERR_ARG;
   SPX_HIP(e, hipSetDevice(e->device));
   const uint32_t A = 1u << SPX_PLUGIN_ALLOCATABLE, T = 1u << SPX_PLUGIN_TLP;
+  // Score-only plugins whose tables the fused sweep can fold in: no Filter, and their bytes are final once evaluated
+  // (Peaks normalises inside its own sweep)
+  const int kExtra[3] = {SPX_PLUGIN_LVRB, SPX_PLUGIN_LROC, SPX_PLUGIN_PEAKS};
+  uint32_t extra_mask = 0;
+  int64_t w_sum = 0;
+  bool w_ok = true;
+  for (int p = 0; p < SPX_NUM_PLUGINS; ++p)
+    if (plugin_mask & (1u << p)) w_sum += e->plugin_weight[p], w_ok &= e->plugin_weight[p] >= 0;
+  for (int x = 0; x < 3; ++x) extra_mask |= plugin_mask & (1u << kExtra[x]);
   const int64_t wa = e->plugin_weight[SPX_PLUGIN_ALLOCATABLE], wt = e->plugin_weight[SPX_PLUGIN_TLP];
-  const bool fusable = (plugin_mask == T || plugin_mask == (A | T)) && !e->ext_mask && e->tri_nodes && e->tri_pods &&
+  const bool fusable = (plugin_mask & T) && !(plugin_mask & ~(A | T | extra_mask)) && !e->ext_mask && e->tri_nodes && e->tri_pods &&
                        e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && !(launch_opts(e) & spx::kOptTrimaranExact) &&
-                       !e->option[SPX_OPT_DECIDE_UNFUSED] && wa >= 0 && wt >= 0 && wa + wt <= 10000000;
+                       !e->option[SPX_OPT_DECIDE_UNFUSED] && w_ok && w_sum <= 10000000;
   int rc;
   if (!fusable) {
     if ((rc = spx_eval(e, plugin_mask, row_begin, row_end))) return rc;
@@ -1973,6 +1983,17 @@ int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t r
   d.best_ties = d.best_node + P;
   d.best_feasible = d.best_ties + P;
   SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
+  if (extra_mask) {
+    e->hold_ev0 = true;
+    rc = spx_eval(e, extra_mask, row_begin, row_end);
+    e->hold_ev0 = false;
+    if (rc) return rc;
+    for (int x = 0; x < 3; ++x)
+      if (extra_mask & (1u << kExtra[x])) {
+        d.w_extra[d.n_extra] = static_cast<int32_t>(e->plugin_weight[kExtra[x]]);
+        d.extra[d.n_extra++] = static_cast<const uint8_t*>(e->score[kExtra[x]].p);
+      }
+  }
   spx::launch_decide_trimaran(d, e->stream);
   SPX_HIP(e, hipGetLastError());
   SPX_HIP(e, hipEventRecord(e->ev1, e->stream));

@@ -127,6 +127,9 @@ struct DecideLaunch {
   TrimaranArgs t;        // inputs; alloc_norm prepared when use_alloc; tlp_fast scratch set
   bool use_alloc;
   int32_t w_alloc, w_tlp;
+  int32_t n_extra;       // score tables of other Score-only plugins, evaluated for the rows beforehand, folded into the total
+  int32_t w_extra[3];
+  const uint8_t* extra[3];
   void* scratch;         // decide_scratch_bytes(row_stride, rows)
   int64_t* best_score;   // [n_pods] ...
   int32_t* best_node;

@@ -3,8 +3,9 @@ must equal spx_eval + spx_eval_best exactly — it is the same float32/float64 c
 import numpy as np
 import pytest
 
-from helpers import ALLOCATABLE, LVRB, TLP
+from helpers import ALLOCATABLE, LROC, LVRB, PEAKS, TLP
 from scheduler_plugins_amd import synth
+from scheduler_plugins_amd import SpxError
 from scheduler_plugins_amd.engine import Engine, mask_of
 
 pytestmark = pytest.mark.gpu
@@ -41,10 +42,16 @@ def test_partial_rows_and_unfused_profiles(gpu_required, hdr):
         want, got = both(e, mask_of(ALLOCATABLE, TLP), 37, 151)
         for w, g in zip(want, got):
             assert (w == g).all()
-        # a profile the fused form does not cover runs eval + eval_best inside: same answer by definition, tables evaluated
+        # LVRB joins the fused form as a table that is read once (see test_decide_folds_score_only_tables)
+        want, got = both(e, mask_of(ALLOCATABLE, TLP, LVRB), 11, 190)
+        for w, g in zip(want, got):
+            assert (w == g).all()
+        # SPX_OPT_DECIDE_UNFUSED runs eval + eval_best inside: same answer by definition, tables evaluated
+        e.set_option("DECIDE_UNFUSED", 1)
         want, got = both(e, mask_of(ALLOCATABLE, TLP, LVRB))
         for w, g in zip(want, got):
             assert (w == g).all()
+        e.set_option("DECIDE_UNFUSED", 0)
         # a caller feasibility mask also takes the unfused route
         rng = np.random.default_rng(1)
         e.upload_feasible_mask((rng.random((200, 777)) < 0.7).astype(np.uint8))
@@ -53,10 +60,50 @@ def test_partial_rows_and_unfused_profiles(gpu_required, hdr):
             assert (w == g).all()
 
 
+@pytest.mark.parametrize("n_nodes,n_pods,seed,round_frac", [(17, 5, 2, 1.0), (1025, 130, 4, 0.0), (3000, 257, 5, 1.0), (10_000, 300, 6, 0.1)])
+@pytest.mark.parametrize("plugins,weights", [((ALLOCATABLE, TLP, LVRB), {ALLOCATABLE: 1, TLP: 1, LVRB: 1}),
+                                             ((TLP, LVRB), {TLP: 2, LVRB: 7}),
+                                             ((ALLOCATABLE, TLP, LVRB, LROC, PEAKS), {ALLOCATABLE: 1, TLP: 1, LVRB: 1, LROC: 1, PEAKS: 1}),
+                                             ((ALLOCATABLE, TLP, LROC, PEAKS), {ALLOCATABLE: 3, TLP: 1, LROC: 4, PEAKS: 2})])
+def test_decide_folds_score_only_tables(gpu_required, hdr, n_nodes, n_pods, seed, round_frac, plugins, weights):
+    """Profiles that add LoadVariationRiskBalancing / LowRiskOverCommitment / Peaks to {Allocatable, TargetLoadPacking}: those
+    plugins' tables are evaluated and read ONCE by the fused sweep; Allocatable's and TargetLoadPacking's are never
+    written and no second pass (spx_eval_best) runs.  Decisions identical to spx_eval + spx_eval_best."""
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=seed, round_frac=round_frac, with_node_pods=True)
+    snap["power_models"] = synth.synth_power_models(hdr, n_nodes, seed)
+
+    def load(e):
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        if LROC in plugins:
+            e.set_lroc()
+            e.load_lroc_objects(snap["nodes"], snap["node_pods"], snap["pods"])
+        if PEAKS in plugins:
+            e.load_peaks_objects(snap["nodes"], snap["metrics"], snap["power_models"], snap["pods"])
+        e.set_plugin_weights(weights)
+
+    with Engine(0) as e:
+        load(e)
+        want, got = both(e, mask_of(*plugins))
+    for name, w, g in zip(("node", "score", "ties", "feasible"), want, got):
+        assert (w == g).all(), (name, np.flatnonzero(w != g)[:5], w[w != g][:5], g[w != g][:5])
+    with Engine(0) as e:   # the fused form ran: TargetLoadPacking's table was never evaluated, the folded plugins' were
+        load(e)
+        e.decide(mask_of(*plugins))
+        assert (e.best()[0] == want[0]).all()
+        with pytest.raises(SpxError):
+            e.all_scores(TLP, 0, n_pods)
+        for p in plugins:
+            if p not in (ALLOCATABLE, TLP):
+                assert e.all_scores(p, 0, n_pods).shape == (n_pods, n_nodes)
+
+
 def test_config2_size(gpu_required, hdr):
     snap = synth.trimaran_snapshot(hdr, 10_000, 100_000)
     with Engine(0) as e:
         e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
         want, got = both(e, mask_of(ALLOCATABLE, TLP))
+        for w, g in zip(want, got):
+            assert (w == g).all()
+        want, got = both(e, mask_of(ALLOCATABLE, TLP, LVRB))
     for w, g in zip(want, got):
         assert (w == g).all()
