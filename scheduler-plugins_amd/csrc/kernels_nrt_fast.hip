@@ -23,6 +23,7 @@
 // Reference: pkg/noderesourcetopology/filter.go:42-245, score.go:62-191, least_allocated.go:25-55,
 // most_allocated.go:25-54, balanced_allocation.go:27-54, numaresources.go:105-182.
 #include <cstdlib>
+#include <utility>
 
 #include "spx_internal.h"
 
@@ -61,6 +62,19 @@ template <typename T>
 __device__ __forceinline__ T uload(const T* p) {
   typedef const T __attribute__((address_space(4))) CT;
   return *reinterpret_cast<CT*>(reinterpret_cast<uintptr_t>(p));
+}
+
+// A load at (wave-uniform base) + (per-lane 32-bit byte offset): the form the backend turns into saddr + voffset.  With
+// 64-bit per-lane pointers the loop-invariant address arithmetic of the loads inside the pod loop was hoisted out of it and
+// held 70 VGPRs of addresses for the whole kernel (the LeastNUMANodes table restore: 32 columns); callers there also make the node index opaque
+// (opaque_lane) so that not even the 32-bit offsets are precomputed and parked in scratch.
+__device__ __forceinline__ uint32_t opaque_lane(uint32_t x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+template <typename T>
+__device__ __forceinline__ T ld_off(const T* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
 // The pod record stream (built by the engine at upload, spx_engine.hip: nrt_pod_items): per pod 10 items of IW dwords
@@ -278,109 +292,167 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
 }
 
 // ---------------------------------------------------------------- LeastNUMANodes (least_numa.go:35-233)
-__constant__ Combo8 kCombo8 = make_combo8();
-
-// numaNodesRequired + findSuitableCombination: the smallest subset size for which some subset of zones holds the
-// request, and among the fitting subsets of that size the one the reference returns: the first (lexicographic) whose
+//
+// numaNodesRequired + findSuitableCombination: the smallest subset size for which some subset of zones holds the request,
+// and among the fitting subsets of that size the one the reference returns — the first in lexicographic order whose
 // average distance equals the node's minimum for the size (is_min), else the first with the smallest distance.
-// The search runs as ONE wave-uniform loop over the (size, lexicographic) table of 8-position subsets — the generic
-// kernel's per-lane loops made the wave execute the union of all lanes' iterations, each of them divergent; here a
-// subset costs every lane the same few VALU operations and the loop ends as soon as every lane has its answer.
-// Subsets with positions past a node's zone count fail the "every member reports every requested resource" test by
-// themselves.
+//
+// Every lane (node) evaluates ALL 255 subsets, branch-free, into a bit set (layout: LnLayout, spx_internal.h): the sums
+// of a subset split into the part over zones 0..3 and the part over zones 4..7, so per requested resource 16 + 16 partial
+// sums are built once and a subset costs one v_cmp_ge_f64 (lo[S & 15] >= request - hi[S >> 4], exact: all quantities are
+// integers below 2^53) and one v_addc that shifts the verdict into the set.  The earlier form walked the subsets in a
+// wave-uniform loop that stopped when all 64 lanes had their answer: some lane nearly always needs size 4 or 5, every
+// iteration carried ballots, scalar table reads and a dependent distance load, and config #3 took 141 ms
+// (3.3e10 scalar + 1.9e10 vector instructions per launch, 54 % of wave cycles waiting).  Here the selection needs no
+// distance at all in the common case (the node's minimum-distance subsets are a register-resident bit set), and a
+// 7-step bit-sliced minimum over per-node rank planes otherwise.
+constexpr LnLayout kLn = make_ln_layout();
+__constant__ LnLayout kLnDev = make_ln_layout();  // the copy indexed at run time (position -> zone mask)
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int D, int Q>
+__device__ __forceinline__ void ln_step(uint32_t& f, const double (&lo)[16], const double (&thr)[16]) {
+  constexpr int S = kLn.subset[D][Q];
+  asm("v_cmp_ge_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(f) : "v"(lo[S & 15]), "v"(thr[S >> 4]) : "vcc");
+}
+// four subsets per asm statement (the compiler pads every statement with an s_nop)
+template <int D, int Q>
+__device__ __forceinline__ void ln_step4(uint32_t& f, const double (&lo)[16], const double (&thr)[16]) {
+  constexpr int S0 = kLn.subset[D][Q], S1 = kLn.subset[D][Q - 1], S2 = kLn.subset[D][Q - 2], S3 = kLn.subset[D][Q - 3];
+  asm("v_cmp_ge_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+      "v_cmp_ge_f64 vcc, %3, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+      "v_cmp_ge_f64 vcc, %5, %6\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+      "v_cmp_ge_f64 vcc, %7, %8\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+      : "+v"(f)
+      : "v"(lo[S0 & 15]), "v"(thr[S0 >> 4]), "v"(lo[S1 & 15]), "v"(thr[S1 >> 4]), "v"(lo[S2 & 15]), "v"(thr[S2 >> 4]), "v"(lo[S3 & 15]),
+        "v"(thr[S3 >> 4])
+      : "vcc");
+}
+template <int D>
+__device__ __forceinline__ uint32_t ln_dword(const double (&lo)[16], const double (&thr)[16]) {
+  uint32_t f = 0;
+  constexpr int cnt = kLn.cnt[D];
+  // highest used bit first: each step shifts the set left by one
+  static_for<cnt / 4>([&](auto g) { ln_step4<D, cnt - 1 - 4 * decltype(g)::value>(f, lo, thr); });
+  static_for<cnt % 4>([&](auto g) { ln_step<D, cnt % 4 - 1 - decltype(g)::value>(f, lo, thr); });
+  return f;
+}
+
+// fall &= { S : sum over S of v[z] >= want }
+__device__ __forceinline__ void ln_resource(uint32_t (&fall)[kLnDwords], const double (&v)[kZ], double want) {
+  double lo[16], thr[16];
+  lo[0] = 0.0;
+  thr[0] = 0.0;
+#pragma unroll
+  for (int m = 1; m < 16; ++m) {
+    lo[m] = lo[m & (m - 1)] + v[__builtin_ctz(m)];
+    thr[m] = thr[m & (m - 1)] + v[4 + __builtin_ctz(m)];
+  }
+#pragma unroll
+  for (int m = 0; m < 16; ++m) thr[m] = want - thr[m];
+  static_for<kLnDwords>([&](auto d) { fall[decltype(d)::value] &= ln_dword<decltype(d)::value>(lo, thr); });
+}
+
+// `choice`: the caller needs the reference's subset itself (a later container is charged against it); otherwise only
+// its size and is_min are read and the distance ranks are not consulted.
 template <int RM>
 __device__ __forceinline__ uint32_t numa_required_fast(const FastNode<RM>& ns, const NrtArgs& a, const Item<RM>& it, int64_t n, bool active,
-                                                       bool* is_min) {
-  uint32_t result = 0;
-  bool done = !active;
-  bool hit_min = false;
+                                                       bool choice, const uint32_t (&mmin)[kLnDwords], const uint8_t* subset_lds, bool* is_min) {
+  *is_min = false;
+  if (__ballot(active) == 0) return 0;
   const uint32_t used = it.used, need = it.fit | it.always;
-  // Bounds that let the wave skip whole subset sizes.  Every valid subset lies inside V = the zones reporting all
-  // requested resources, and sums grow with the subset: if even V cannot hold the request nothing can (answer 0 at
-  // once); at least ceil(request / largest zone) zones are needed per resource; at most |V| can be used.
-  uint32_t v_all = 0xffu;
+  // a valid subset lies inside V = the zones reporting every requested resource (isValidCombineResources); a zone outside
+  // V enters the sums as -1e300, so that no subset containing it reaches any request
+  uint32_t v_all = active ? 0xffu : 0u;
 #pragma unroll
   for (int r = 0; r < RM; ++r)
     if ((used >> r) & 1u) v_all &= ns.repmask(r);
-  int k_lo = 1;
+  uint32_t fall[kLnDwords];
 #pragma unroll
-  for (int r = 0; r < RM; ++r) {
-    if (!((need >> r) & 1u)) continue;
-    double total = 0.0, largest = 0.0;
+  for (int d = 0; d < kLnDwords; ++d) fall[d] = 0xffffffffu;
+  // one pass per compared resource; a request of zero quantities compares nothing, and every subset of V "fits": that
+  // is the pass over the pseudo resource RM (no quantity anywhere, nothing wanted).  The resource index is wave-uniform,
+  // so picking its column is a handful of scalar-conditioned moves and the 255-subset sequence exists once in the code.
+  uint32_t todo = need ? need : (1u << RM);
+  while (todo) {
+    const int r = __builtin_ctz(todo);
+    todo &= todo - 1;
+    double v[kZ], want = 0.0;
+#pragma unroll
+    for (int q = 0; q < RM; ++q) want = r == q ? it.raw[q] : want;
 #pragma unroll
     for (int z = 0; z < kZ; ++z) {
-      const double v = ((v_all >> z) & 1u) ? ns.av[z][r] : 0.0;
-      total += v;
-      largest = __builtin_fmax(largest, v);
+      double x = 0.0;
+#pragma unroll
+      for (int q = 0; q < RM; ++q) x = r == q ? ns.av[z][q] : x;
+      v[z] = ((v_all >> z) & 1u) ? x : -1e300;
     }
-    if (total < it.raw[r]) done = true;  // no subset fits
-    // zones needed if all were as large as the largest one (a float estimate rounded down is still a lower bound)
-    const float need_f = static_cast<float>(it.raw[r]) / static_cast<float>(largest > 0.0 ? largest : 1.0);
-    const int need_k = static_cast<int>(need_f * 0.999f);
-    k_lo = need_k + 1 > k_lo ? (need_k + 1 > kZ ? kZ : need_k + 1) : k_lo;
+    ln_resource(fall, v, want);
   }
-  const int k_hi = __builtin_popcount(v_all);
-  const uint32_t allrep = v_all;  // zones reporting every requested resource
-  for (int k = 1; k <= kZ; ++k) {
-    // skip sizes no unfinished lane can use (ballots, not shuffles: part of the wave may be masked off here, and a
-    // butterfly reduction through inactive lanes loses values)
-    while (k <= kZ && __ballot(!done && k_lo <= k && k <= k_hi) == 0) ++k;
-    if (k > kZ) break;
-    const float min_avg = a.min_avg[static_cast<int64_t>(k - 1) * a.n_nodes + n];
-    uint32_t best = 0;
-    float min_distance = 256.0f;
-    // Subsets of size k in lexicographic order = for every (k-1)-prefix in lexicographic order, every last element
-    // above the prefix's highest one, ascending.  The prefix's sums cost R*8 multiply-adds (membership as uniform 0/1
-    // weights) once; each extension by zone j is then one add and one compare per resource with j a compile-time index.
-    int ci = kCombo8.start[k - 1];                                // table index of the next subset (for the distance)
-    const int p0 = k == 1 ? -1 : kCombo8.start[k - 2], p1 = k == 1 ? 0 : kCombo8.start[k - 1];
-    for (int pi = p0; pi < p1; ++pi) {
-      const uint32_t pm = pi < 0 ? 0u : kCombo8.mask[pi];         // wave-uniform prefix (empty for k == 1)
-      const int last = pm ? 31 - __builtin_clz(pm) : -1;
-      if (last >= kZ - 1) continue;                                // nothing above its highest element
-      bool pvalid = !done && (allrep & pm) == pm;                  // isValidCombineResources for the prefix
-      double psum[RM];
-      double w[kZ];
+  // the smallest size with a fitting subset: its candidates c, those of them at the node's minimum distance h
+  uint32_t c[3] = {0, 0, 0}, h[3] = {0, 0, 0};
+  int ksel = 0, fsel = 0;
+  static_for<8>([&](auto ki) {
+    constexpr int k = 8 - decltype(ki)::value, f = kLn.first[k], nd = kLn.nd[k];
+    uint32_t t = fall[f];
+    if constexpr (nd > 1) t |= fall[f + 1];
+    if constexpr (nd > 2) t |= fall[f + 2];
+    const bool sel = t != 0;
+    static_for<3>([&](auto ji) {
+      constexpr int j = decltype(ji)::value;
+      uint32_t cj = 0u, hj = 0u;
+      if constexpr (j < nd) cj = fall[f + j], hj = fall[f + j] & mmin[f + j];
+      c[j] = sel ? cj : c[j];
+      h[j] = sel ? hj : h[j];
+    });
+    ksel = sel ? k : ksel;
+    fsel = sel ? f : fsel;
+  });
+  const bool found = ksel != 0;
+  const bool hit = (h[0] | h[1] | h[2]) != 0;
+  if (hit) {
 #pragma unroll
-      for (int z = 0; z < kZ; ++z) w[z] = ((pm >> z) & 1u) ? 1.0 : 0.0;
+    for (int j = 0; j < 3; ++j) c[j] = h[j];
+  } else if (choice && __ballot(found) != 0) {
+    // no fitting subset at the minimum distance: the fitting subset with the smallest distance = the smallest rank;
+    // bit-sliced minimum from the top plane down (a plane keeps the candidates whose rank has that bit clear, if any)
+    if (found) {
+      int bits = 0, nd = 1, prow = 0;
+      static_for<8>([&](auto ki) {
+        constexpr int k = 1 + decltype(ki)::value, bk = kLn.bits[k], ndk = kLn.nd[k], pk = kLnDwords + kLn.pbase[k];
+        const bool is = ksel == k;
+        bits = is ? bk : bits;
+        nd = is ? ndk : nd;
+        prow = is ? pk : prow;
+      });
+      const uint32_t nn = static_cast<uint32_t>(a.n_nodes), n32 = opaque_lane(static_cast<uint32_t>(n));
+      uint32_t pl[7][3];
 #pragma unroll
-      for (int r = 0; r < RM; ++r) {
-        psum[r] = 0.0;
-        if (!((need >> r) & 1u)) continue;
+      for (int b = 0; b < 7; ++b)
 #pragma unroll
-        for (int z = 0; z < kZ; ++z) psum[r] = __builtin_fma(w[z], ns.av[z][r], psum[r]);
-      }
+        for (int j = 0; j < 3; ++j)
+          pl[b][j] = (b < bits && j < nd) ? ld_off(a.ln_tab, (static_cast<uint32_t>(prow + b * nd + j) * nn + n32) * 4u) : 0u;
 #pragma unroll
-      for (int j = 0; j < kZ; ++j) {
-        if (j <= last) continue;                                   // uniform
-        bool ok = pvalid && ((allrep >> j) & 1u);
-#pragma unroll
-        for (int r = 0; r < RM; ++r)
-          if ((need >> r) & 1u) ok &= psum[r] + ns.av[j][r] >= it.raw[r];  // combineResources + checkResourcesFit
-        if (__ballot(ok) != 0) {
-          const uint32_t m = pm | (1u << j);
-          const float d = a.dist[static_cast<int64_t>(ci) * a.n_nodes + n];
-          if (ok && d == min_avg) {
-            result = m;
-            hit_min = true;
-            done = true;
-            pvalid = false;
-          } else if (ok && d < min_distance) {
-            min_distance = d;
-            best = m;
-          }
-        }
-        ++ci;
+      for (int b = 6; b >= 0; --b) {
+        const uint32_t t0 = c[0] & ~pl[b][0], t1 = c[1] & ~pl[b][1], t2 = c[2] & ~pl[b][2];
+        const bool any = (t0 | t1 | t2) != 0;
+        c[0] = any ? t0 : c[0];
+        c[1] = any ? t1 : c[1];
+        c[2] = any ? t2 : c[2];
       }
     }
-    if (!done && best != 0) {
-      result = best;
-      done = true;
-    }
-    if (__ballot(!done) == 0) break;
   }
-  *is_min = hit_min;
-  return result;
+  const int p = c[0] ? __builtin_ctz(c[0]) : (c[1] ? 32 + __builtin_ctz(c[1]) : 64 + __builtin_ctz(c[2] | 0x80000000u));
+  *is_min = found && hit;
+  return found ? subset_lds[fsel * 32 + p] : 0u;
 }
 
 // subtractFromNUMAs numaresources.go:184-215 with ids == positions: walk the chosen zones in order, taking from each
@@ -408,7 +480,7 @@ __device__ __forceinline__ void subtract_from_numas_fast(FastNode<RM>& ns, const
 constexpr int kPhBoth = 0, kPhFilter = 1, kPhScore = 2;
 
 template <int RM, int SG, int PH>
-__global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgBalanced ? 2 : (SG == kSgMost ? 4 : 5)) : (PH == kPhFilter ? 5 : (SG == kSgLeast ? 3 : 2))) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
+__global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? ((SG == kSgBalanced || SG == kSgLeastNuma) ? 2 : (SG == kSgMost ? 4 : 5)) : (PH == kPhFilter ? 5 : (SG == kSgLeast ? 3 : 2))) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
   SPX_RESOLVE_ROWS(a);
   constexpr bool FULL = PH != kPhFilter;  // only the Score reads the second half of a request item
   typedef ItemRegs<RM, FULL> Regs;
@@ -417,6 +489,7 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgBalanced
   // (measured before: 49 % of the VALU lanes active, pod-scope and container-scope nodes being interleaved).
   // Results are staged in LDS at the nodes' original positions and leave as whole 256-byte row segments.
   __shared__ __align__(16) uint8_t stage[2][kPodsPerUnit][kWindow];
+  __shared__ uint8_t ln_subset[SG == kSgLeastNuma ? kLnDwords * 32 : 1];  // LeastNUMANodes: bit position -> zone mask
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // Blocks are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD has its own L2.  Each XCD
@@ -481,6 +554,13 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgBalanced
     }
   }
   const int nns = 100 / (in ? a.max_numa[n] : 8);  // normalizeScore's per-zone step, least_numa.go:90-100
+  uint32_t mmin[kLnDwords];  // LeastNUMANodes: the node's minimum-distance subsets per size (LnLayout)
+#pragma unroll
+  for (int d = 0; d < kLnDwords; ++d) mmin[d] = (SG == kSgLeastNuma && in) ? a.ln_tab[static_cast<int64_t>(d) * a.n_nodes + n] : 0u;
+  if constexpr (SG == kSgLeastNuma) {
+    for (int i = threadIdx.x; i < kLnDwords * 32; i += blockDim.x) ln_subset[i] = kLnDev.subset[i >> 5][i & 31];
+    __syncthreads();
+  }
   const bool fresh = flags & SPX_NRT_F_FRESH;
   const bool has_nrt = flags & SPX_NRT_F_HAS_NRT;
   const bool single = flags & SPX_NRT_F_SINGLE_NUMA;
@@ -574,55 +654,52 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgBalanced
     }
 
     if constexpr (SG == kSgLeastNuma) {
-      // LeastNUMANodes scores every node that has a fresh NRT, whatever its topology-manager policy (score.go:167-191)
+      // LeastNUMANodes scores every node that has a fresh NRT, whatever its topology-manager policy (score.go:167-191).
+      // One loop serves both scopes — step -1 is the pod-level request for the pod-scope nodes (leastNUMAPodScopeScore),
+      // steps 0.. the containers for the others (leastNUMAContainerScopeScore) — so that the subset search exists once
+      // in the code; a step none of the wave's nodes takes part in is skipped.
       const bool want_ln = !non_g && fresh && has_nrt;
-      if (want_ln && pod_scope) {  // leastNUMAPodScopeScore
-        const Item<RM> it = decode_item<RM, FULL>(pw);
+      int max_count = 0;
+      bool all_min = true, failed = false, dirty = false;
+      cw = load_item<RM, FULL>(items, pi + 2);
+      for (int c = -1; c < n_ctr; ++c) {
+        const bool mine = want_ln && (c < 0 ? pod_scope : !pod_scope);
+        if (__ballot(mine) == 0) {
+          if (c >= 0) cw = load_item<RM, FULL>(items, pi + 2 + (c + 1 < kC ? c + 1 : c));
+          continue;
+        }
+        const Regs nw = c < 0 ? cw : load_item<RM, FULL>(items, pi + 2 + (c + 1 < kC ? c + 1 : c));
+        const Item<RM> it = decode_item<RM, FULL>(c < 0 ? pw : cw);
         uint32_t any_rep = 0;
 #pragma unroll
         for (int r = 0; r < RM; ++r)
           if ((it.used >> r) & 1u) any_rep |= ns.repmask(r);
-        const bool non_numa = any_rep == 0;  // onlyNonNUMAResources
+        const bool go = mine && !failed && any_rep != 0;  // any_rep == 0: onlyNonNUMAResources, the item is passed over
         bool is_min;
-        const uint32_t m = numa_required_fast(ns, a, it, n, !non_numa, &is_min);
-        const int cnt = __builtin_popcount(m);
-        score = non_numa ? 100 : (m ? 100 - cnt * nns + (is_min ? nns / 2 : 0) : 0);
+        const uint32_t m = numa_required_fast(ns, a, it, n, go, c >= 0 && c + 1 < n_ctr, mmin, ln_subset, &is_min);
+        if (go) {
+          if (m == 0) {
+            failed = true;
+          } else {
+            all_min &= is_min;
+            const int cnt = __builtin_popcount(m);
+            max_count = cnt > max_count ? cnt : max_count;
+          }
+        }
+        if (c >= 0 && c + 1 < n_ctr && __ballot(go && m != 0) != 0) {  // the next container sees what this one took
+          subtract_from_numas_fast(ns, it, go ? m : 0u);
+          dirty |= go && m != 0;
+        }
+        cw = nw;
       }
-      if (want_ln && !pod_scope) {  // leastNUMAContainerScopeScore
-        int max_count = 0;
-        bool all_min = true, failed = false, dirty = false;
-        cw = load_item<RM, FULL>(items, pi + 2);
-        for (int c = 0; c < n_ctr; ++c) {
-          const Regs nw = load_item<RM, FULL>(items, pi + 2 + (c + 1 < kC ? c + 1 : c));
-          const Item<RM> it = decode_item<RM, FULL>(cw);
-          uint32_t any_rep = 0;
+      if (want_ln) score = failed ? 0 : (max_count == 0 ? 100 : 100 - max_count * nns + (all_min ? nns / 2 : 0));
+      if (__ballot(dirty) != 0) {  // the reference scored on a private NUMANodeList: restore this lane's table
+        const uint32_t n32 = opaque_lane(static_cast<uint32_t>(n));
+#pragma unroll
+        for (int z = 0; z < kZ; ++z)
 #pragma unroll
           for (int r = 0; r < RM; ++r)
-            if ((it.used >> r) & 1u) any_rep |= ns.repmask(r);
-          const bool go = !failed && any_rep != 0;
-          bool is_min;
-          const uint32_t m = numa_required_fast(ns, a, it, n, go, &is_min);
-          if (go) {
-            if (m == 0) {
-              failed = true;
-            } else {
-              all_min &= is_min;
-              const int cnt = __builtin_popcount(m);
-              max_count = cnt > max_count ? cnt : max_count;
-              subtract_from_numas_fast(ns, it, m);
-              dirty = true;
-            }
-          }
-          cw = nw;
-        }
-        score = failed ? 0 : (max_count == 0 ? 100 : 100 - max_count * nns + (all_min ? nns / 2 : 0));
-        if (__ballot(dirty) != 0) {  // the reference scored on a private NUMANodeList: restore this lane's table
-#pragma unroll
-          for (int z = 0; z < kZ; ++z)
-#pragma unroll
-            for (int r = 0; r < RM; ++r)
-              ns.av[z][r] = (in && r < R) ? a.f_av[(static_cast<int64_t>(z) * R + r) * a.n_nodes + n] : -1.0;
-        }
+            ns.av[z][r] = (in && r < R) ? ld_off(a.f_av, (static_cast<uint32_t>(z * R + r) * static_cast<uint32_t>(a.n_nodes) + n32) * 8u) : -1.0;
       }
     }
 
@@ -653,17 +730,18 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgBalanced
 
 bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   if (!a.fast) return false;
+  if (a.strategy == SPX_NRT_LEAST_NUMA_NODES && !a.ln_tab) return false;
   const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);  // windows of 256 nodes
   const int64_t chunks = (a.row_end - a.row_begin + kPodsPerUnit - 1) / kPodsPerUnit;
   const unsigned blocks = static_cast<unsigned>(chunks * (n_tiles >= kXcdMapWindows ? ((n_tiles + 7) / 8) * 8 : n_tiles));  // see the kernel's block map
   const int sg = a.strategy == SPX_NRT_LEAST_NUMA_NODES ? kSgLeastNuma
                : a.strategy == SPX_NRT_BALANCED_ALLOCATION ? kSgBalanced : (a.strategy == SPX_NRT_LEAST_ALLOCATED ? kSgLeast : kSgMost);
-  const bool split = sg != kSgLeastNuma && a.out_raw == nullptr && !(a.opts & kOptNrtSingleLaunch);
+  const bool split = a.out_raw == nullptr && !(a.opts & kOptNrtSingleLaunch);
 #define SPX_NRTF_CASE(RMV, SGV)                                                                           \
   if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                                        \
-    if (SGV != kSgLeastNuma && split) { /* the Filter half does not depend on the strategy */ \
+    if (split) { /* the Filter half does not depend on the strategy */ \
       hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhFilter>), dim3(blocks), dim3(256), 0, s, a, n_tiles); \
-      hipLaunchKernelGGL((k_nrt_fast<RMV, (SGV == kSgLeastNuma ? kSgLeast : SGV), kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
+      hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
     } else {                                                                                              \
       hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhBoth>), dim3(blocks), dim3(256), 0, s, a, n_tiles);     \
     }                                                                                                     \

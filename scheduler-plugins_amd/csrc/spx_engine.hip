@@ -89,9 +89,10 @@ struct spx_engine {
   DevBuf d_nrt_flags, d_nrt_max_numa, d_nrt_nz, d_nrt_zid, d_nrt_zp, d_nrt_avail, d_nrt_cost, d_nrt_minavg, d_nrt_np;
   DevBuf d_nrt_qos, d_nrt_nn, d_nrt_nctr, d_nrt_ckind, d_nrt_cpres, d_nrt_creq, d_nrt_ppres, d_nrt_preq;
   // float64 formulation of the NRT sweep (kernels_nrt_fast.hip): derived tables + whether its preconditions hold
-  DevBuf d_nrt_fav, d_nrt_frc, d_nrt_frcv, d_nrt_fcpu, d_nrt_fbraw, d_nrt_frep, d_nrt_items, d_nrt_perm, d_nrt_dist;
+  DevBuf d_nrt_fav, d_nrt_frc, d_nrt_frcv, d_nrt_fcpu, d_nrt_fbraw, d_nrt_frep, d_nrt_items, d_nrt_perm, d_nrt_ln;
   std::vector<double> nrt_wtab;  // [2^n_res][2]: sum of the weights of a slot subset, its biased reciprocal
   bool nrt_fast_slots = false, nrt_fast_nodes = false, nrt_fast_pods = false;
+  bool nrt_ln_ok = false;  // LeastNUMANodes tables valid: every zone cost within [0, 255]
   int32_t nrt_cpu_slot = -1;
   DevBuf status[SPX_NUM_PLUGINS];
 
@@ -398,7 +399,7 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   na.f_rep = static_cast<const uint8_t*>(e->d_nrt_frep.p);
   na.pod_items = static_cast<const uint32_t*>(e->d_nrt_items.p);
   na.perm = static_cast<const int32_t*>(e->d_nrt_perm.p);
-  na.dist = static_cast<const float*>(e->d_nrt_dist.p);
+  na.ln_tab = e->nrt_ln_ok ? static_cast<const uint32_t*>(e->d_nrt_ln.p) : nullptr;
 }
 
 // quantities the float64 NRT kernel may hold exactly, with room for x100 and the reciprocal trick
@@ -499,7 +500,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_raw_row,   &e->d_lv_exact, &e->d_lv_fast, &e->d_tlp_fast, &e->d_commit, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
-                    &e->d_nrt_frcv, &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_dist, &e->d_nrt_fbraw,
+                    &e->d_nrt_frcv, &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_ln, &e->d_nrt_fbraw,
                     &e->d_net_region, &e->d_net_zone, &e->d_net_class, &e->d_net_class16, &e->d_net_cls_size, &e->d_net_cls_region, &e->d_net_cls_zone,
                     &e->d_net_rcost, &e->d_net_zcost, &e->d_net_pod_key, &e->d_net_key_flag, &e->d_net_pair_ptr,
                     &e->d_net_pair_node, &e->d_net_pair_max, &e->d_q_pod_ns, &e->d_q_pod_prio, &e->d_q_pod_req, &e->d_q_pod_reqp,
@@ -851,25 +852,61 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
         }
     }
     if ((rc = upload(e, e->d_nrt_perm, perm.data(), perm.size() * sizeof(int32_t)))) return rc;
-    // average distance of every subset of list positions (nodesAvgDistance least_numa.go:140-154, float32 like the
-    // reference), in the order the LeastNUMANodes search walks them
+    // LeastNUMANodes: per node the subsets of list positions at the node's minimum average distance for their size, and
+    // bit-planes of every subset's distance rank within its size (layout: LnLayout, spx_internal.h).  The average distance
+    // is nodesAvgDistance least_numa.go:115-138 — the sum over all ordered pairs, float32(sum) / float32(k*k); for one size
+    // the divisor is shared and sums below 2^14 stay distinct after the division, so ranking the integer sums ranks the
+    // reference's float32 values.  Only subsets of the node's own zones take part in the minimum (:102-113).
     {
-      constexpr spx::Combo8 combo = spx::make_combo8();
-      std::vector<float> dist(static_cast<size_t>(255) * static_cast<size_t>(n));
+      constexpr spx::LnLayout L = spx::make_ln_layout();
+      std::vector<uint32_t> tab(static_cast<size_t>(L.rows) * static_cast<size_t>(n), 0u);
+      std::atomic<bool> ln_ok{true};
       spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
-        for (int64_t i = row0; i < row1; ++i)
-          for (int ci = 0; ci < 255; ++ci) {
-            const unsigned m = combo.mask[ci];
-            int accu = 0;
-            for (int za = 0; za < Zm; ++za)
-              if (m >> za & 1u)
-                for (int zb = 0; zb < Zm; ++zb)
-                  if (m >> zb & 1u) accu += t->zone_cost[(i * Zm + za) * Zm + zb];
-            const int k = __builtin_popcount(m);
-            dist[static_cast<size_t>(ci) * static_cast<size_t>(n) + static_cast<size_t>(i)] = static_cast<float>(accu) / static_cast<float>(k * k);
+        for (int64_t i = row0; i < row1; ++i) {
+          const int nz = std::min<int>(t->n_zones[i], static_cast<int>(Zm));
+          for (int za = 0; za < nz; ++za)
+            for (int zb = 0; zb < nz; ++zb) {
+              const int64_t c = t->zone_cost[(i * Zm + za) * Zm + zb];
+              if (c < 0 || c > 255) ln_ok = false;  // findSuitableCombination's 256 sentinel would come into play
+            }
+          for (int k = 1; k <= 8; ++k) {
+            int sums[70], order[70], cnt = 0;
+            bool exists[70];
+            for (int d = 0; d < L.nd[k]; ++d)
+              for (int q = 0; q < L.cnt[L.first[k] + d]; ++q) {
+                const unsigned m = L.subset[L.first[k] + d][q];
+                int accu = 0;
+                for (int za = 0; za < Zm; ++za)
+                  if (m >> za & 1u)
+                    for (int zb = 0; zb < Zm; ++zb)
+                      if (m >> zb & 1u) accu += t->zone_cost[(i * Zm + za) * Zm + zb];
+                exists[cnt] = (m >> nz) == 0;
+                sums[cnt] = accu;
+                order[cnt] = cnt;
+                ++cnt;
+              }
+            std::sort(order, order + cnt, [&](int x, int y) { return sums[x] < sums[y]; });
+            int rank_of[70], level = -1, last = 0;
+            for (int j = 0; j < cnt; ++j) rank_of[j] = (1 << L.bits[k]) - 1;  // subsets past the node's zones: never candidates
+            for (int j = 0; j < cnt; ++j) {
+              const int sidx = order[j];
+              if (!exists[sidx]) continue;
+              if (level < 0 || sums[sidx] != last) ++level, last = sums[sidx];
+              rank_of[sidx] = level;
+            }
+            for (int pos = 0; pos < cnt; ++pos) {
+              const size_t d = static_cast<size_t>(L.first[k] + pos / 32);
+              const uint32_t bit = 1u << (pos % 32);
+              if (exists[pos] && rank_of[pos] == 0) tab[d * static_cast<size_t>(n) + static_cast<size_t>(i)] |= bit;
+              for (int b = 0; b < L.bits[k]; ++b)
+                if ((rank_of[pos] >> b) & 1)
+                  tab[static_cast<size_t>(spx::kLnDwords + L.pbase[k] + b * L.nd[k] + pos / 32) * static_cast<size_t>(n) + static_cast<size_t>(i)] |= bit;
+            }
           }
+        }
       }, 512);
-      if ((rc = upload(e, e->d_nrt_dist, dist.data(), dist.size() * sizeof(float)))) return rc;
+      e->nrt_ln_ok = ln_ok.load();
+      if ((rc = upload(e, e->d_nrt_ln, tab.data(), tab.size() * sizeof(uint32_t)))) return rc;
       SPX_HIP(e, hipStreamSynchronize(e->stream));
     }
     if ((rc = upload(e, e->d_nrt_fav, av.data(), av.size() * sizeof(double)))) return rc;
@@ -1666,7 +1703,8 @@ int spx_commit_sequential(spx_engine* e, uint32_t plugin_mask, int64_t row_begin
 int spx_kernel_path(const spx_engine* e, int plugin) {
   if (!e) return SPX_ERR_ARG;
   if (plugin == SPX_PLUGIN_NRT)
-    return (e->nrt_fast_slots && e->nrt_fast_nodes && e->nrt_fast_pods && !forced_reference(e, SPX_PLUGIN_NRT)) ? 1 : 0;
+    return (e->nrt_fast_slots && e->nrt_fast_nodes && e->nrt_fast_pods && !forced_reference(e, SPX_PLUGIN_NRT) &&
+            (e->nrt_params.strategy != SPX_NRT_LEAST_NUMA_NODES || e->nrt_ln_ok)) ? 1 : 0;
   if (plugin == SPX_PLUGIN_NETOVERHEAD) return (e->net_nodes && e->net_class16 && e->net_n_classes > 0 && !forced_reference(e, SPX_PLUGIN_NETOVERHEAD)) ? 1 : 0;
   if (plugin == SPX_PLUGIN_LROC) return (lroc_exact53(e) && !e->option[SPX_OPT_LROC_FLOAT64]) ? 1 : 0;
   if (plugin == SPX_PLUGIN_TLP) return (e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && !(launch_opts(e) & spx::kOptTrimaranExact)) ? 1 : 0;

@@ -250,7 +250,8 @@ struct NrtArgs {
   const double* f_cpu;           // [Z][N] Value() of the cpu capacity
   const double* f_braw;          // [Z][N] RN(100 / cpu capacity in millicores), kNrtNoCap when it is not positive
   const uint8_t* f_rep;          // [n_res][N] mask of the zones reporting the resource
-  const float* dist;             // [255][N] average distance of every zone subset (Combo8 order), float32 as least_numa.go:140-154
+  const uint32_t* ln_tab;        // [LnLayout.rows][N] LeastNUMANodes: minimum-distance subsets + distance-rank planes; NULL when a
+                                 // cost lies outside [0, 255] (the reference-arithmetic kernel then serves that strategy)
   const int32_t* perm;           // [ceil(N/256)*256] node index per slot, windows of 256 ordered by code path; -1 = empty
   const uint32_t* pod_items;     // [P][10][16 or 32] pod record stream (layout: spx_engine.hip nrt_pod_items)
 };
@@ -283,6 +284,41 @@ constexpr Combo8 make_combo8() {
   }
   t.start[8] = static_cast<uint8_t>(idx);  // 255
   return t;
+}
+// Bit layout of "which zone subsets hold the request" in the float64 LeastNUMANodes search (kernels_nrt_fast.hip): subsets of
+// size k occupy their own dwords — first[k] .. first[k] + nd[k] — in lexicographic order from bit 0 up, so "the smallest
+// size with a fitting subset" is the first non-zero class and "the first in the reference's walk" the lowest set bit.
+// Per node the engine stores, in the same layout, the subsets whose average distance is the node's minimum for their size
+// (rows 0..11 of NrtArgs.ln_tab) and, per class, bit-planes of the RANK of each subset's distance among the node's distinct
+// distances for that size (bits[k] planes of nd[k] dwords each, from row 12 + pbase[k]; plane b = bit b of the rank).
+constexpr int kLnDwords = 12;
+struct LnLayout {
+  uint8_t subset[kLnDwords][32];  // zone mask of bit q of dword d; 0 = unused
+  uint8_t cnt[kLnDwords];         // used bits of the dword
+  uint8_t first[9], nd[9], bits[9], pbase[9];  // by subset size 1..8
+  int rows;                       // 12 + plane rows
+};
+constexpr LnLayout make_ln_layout() {
+  LnLayout l{};
+  const Combo8 c = make_combo8();
+  int d = 0, prow = 0;
+  for (int k = 1; k <= 8; ++k) {
+    const int n = c.start[k] - c.start[k - 1];
+    l.first[k] = static_cast<uint8_t>(d);
+    l.nd[k] = static_cast<uint8_t>((n + 31) / 32);
+    int b = 0;
+    while ((1 << b) < n) ++b;
+    l.bits[k] = static_cast<uint8_t>(b);
+    l.pbase[k] = static_cast<uint8_t>(prow);
+    prow += b * l.nd[k];
+    for (int p = 0; p < n; ++p) {
+      l.subset[d + p / 32][p % 32] = c.mask[c.start[k - 1] + p];
+      l.cnt[d + p / 32] = static_cast<uint8_t>(p % 32 + 1);
+    }
+    d += l.nd[k];
+  }
+  l.rows = kLnDwords + prow;
+  return l;
 }
 void launch_nrt(const NrtArgs& a, hipStream_t s);
 // returns false when the float64 kernel does not apply (preconditions, LeastNUMANodes)
