@@ -108,9 +108,12 @@ struct ItemRegs<8, FULL> {
   u32x16 lo, hi;
 };
 
+// `pod_items`: the pod's first item; `slot`: 0 header, 1 pod-level request, 2.. containers.  A small 32-bit slot on a per-pod
+// base keeps the address arithmetic at one scalar shift-add per load (a 64-bit item index cost ~9 scalar instructions each,
+// and the Filter launch was issuing as many scalar as vector instructions).
 template <int RM, bool FULL>
-__device__ __forceinline__ ItemRegs<RM, FULL> load_item(const uint32_t* items, int64_t index) {
-  const uint32_t* p = items + index * item_words<RM>();
+__device__ __forceinline__ ItemRegs<RM, FULL> load_item(const uint32_t* pod_items, int slot) {
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(pod_items) + static_cast<uint32_t>(slot) * (item_words<RM>() * 4u));
   ItemRegs<RM, FULL> r;
   if constexpr (RM == 4 && !FULL) {
     r.raw = uload(reinterpret_cast<const u32x8*>(p));
@@ -175,9 +178,20 @@ __device__ __forceinline__ bool fits_fast(const FastNode<RM>& ns, const Item<RM>
     if ((it.always >> r) & 1u) {
       rb = ns.repmask(r);
     } else {
-      rb = 0;
-#pragma unroll
-      for (int z = 0; z < kZ; ++z) rb |= ns.av[z][r] >= it.raw[r] ? (1u << z) : 0u;
+      rb = 0;  // zone 7 first: each compare's verdict is shifted in from the right (v_cmp + v_addc, no select/or)
+      static_assert(kZ == 8, "one asm statement for the eight zones");
+      asm("v_cmp_le_f64 vcc, %1, %9\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+          "v_cmp_le_f64 vcc, %1, %8\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+          "v_cmp_le_f64 vcc, %1, %7\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+          "v_cmp_le_f64 vcc, %1, %6\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+          "v_cmp_le_f64 vcc, %1, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+          "v_cmp_le_f64 vcc, %1, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+          "v_cmp_le_f64 vcc, %1, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+          "v_cmp_le_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+          : "+v"(rb)
+          : "s"(it.raw[r]), "v"(ns.av[0][r]), "v"(ns.av[1][r]), "v"(ns.av[2][r]), "v"(ns.av[3][r]), "v"(ns.av[4][r]), "v"(ns.av[5][r]),
+            "v"(ns.av[6][r]), "v"(ns.av[7][r])
+          : "vcc");
     }
     mask &= rb | ns.fillmask(r);
   }
@@ -572,9 +586,9 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? ((SG == kSgBalance
   u32x2 hw = header(pod0);
   for (int64_t pod = pod0; pod < pod1; ++pod) {
     // ---- wave-uniform pod record: this pod's request items now, the next pod's header for the next iteration
-    const int64_t pi = pod * kItemsPerPod;  // index of the pod's first item
-    const Regs pw = load_item<RM, FULL>(items, pi + 1);
-    Regs cw = load_item<RM, FULL>(items, pi + 2);
+    const uint32_t* pit = items + pod * (kItemsPerPod * item_words<RM>());  // the pod's first item
+    const Regs pw = load_item<RM, FULL>(pit, 1);
+    Regs cw = load_item<RM, FULL>(pit, 2);
     const u32x2 hnext = header(pod + 1 < pod1 ? pod + 1 : pod);
     const int qos = hw[0] & 0xffu;
     const bool non_native = ((hw[0] >> 8) & 0xffu) != 0;
@@ -609,7 +623,7 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? ((SG == kSgBalance
       uint32_t chosen = 0;  // per app container: the zone it was subtracted from + 1 (0 = not placed), 4 bits each, for the undo
       int sum = 0;
       for (int c = 0; c < n_ctr; ++c) {
-        const Regs nw = load_item<RM, FULL>(items, pi + 2 + (c + 1 < kC ? c + 1 : c));  // prefetch the next container's item
+        const Regs nw = load_item<RM, FULL>(pit, 2 + (c + 1 < kC ? c + 1 : c));  // prefetch the next container's item
         const Item<RM> it = decode_item<RM, FULL>(cw);
         if constexpr (PH != kPhScore) if (want_filter) {
           uint32_t pos;
@@ -632,9 +646,9 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? ((SG == kSgBalance
         cw = nw;
       }
       if constexpr (PH != kPhScore) if (want_filter && last_app > 0) {  // undo: Filter works on a private copy in the reference
-        cw = load_item<RM, FULL>(items, pi + 2);
+        cw = load_item<RM, FULL>(pit, 2);
         for (int c = 0; c < last_app; ++c) {
-          const Regs nw = load_item<RM, FULL>(items, pi + 2 + c + 1);
+          const Regs nw = load_item<RM, FULL>(pit, 2 + c + 1);
           const Item<RM> it = decode_item<RM, FULL>(cw);
           if (it.kind == SPX_CTR_APP) adjust_fast(ns, it, ((chosen >> (4 * c)) & 0xfu) - 1u, ((chosen >> (4 * c)) & 0xfu) != 0, 1.0);
           cw = nw;
@@ -642,9 +656,9 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? ((SG == kSgBalance
       }
       if constexpr (SG != kSgLeast && SG != kSgMost && PH != kPhFilter) {
         if (want_score) {
-          cw = load_item<RM, FULL>(items, pi + 2);
+          cw = load_item<RM, FULL>(pit, 2);
           for (int c = 0; c < n_ctr; ++c) {
-            const Regs nw = load_item<RM, FULL>(items, pi + 2 + (c + 1 < kC ? c + 1 : c));
+            const Regs nw = load_item<RM, FULL>(pit, 2 + (c + 1 < kC ? c + 1 : c));
             sum += score_each_fast<RM, SG>(ns, a, decode_item<RM, FULL>(cw), cpu_v, braw);
             cw = nw;
           }
@@ -661,14 +675,14 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? ((SG == kSgBalance
       const bool want_ln = !non_g && fresh && has_nrt;
       int max_count = 0;
       bool all_min = true, failed = false, dirty = false;
-      cw = load_item<RM, FULL>(items, pi + 2);
+      cw = load_item<RM, FULL>(pit, 2);
       for (int c = -1; c < n_ctr; ++c) {
         const bool mine = want_ln && (c < 0 ? pod_scope : !pod_scope);
         if (__ballot(mine) == 0) {
-          if (c >= 0) cw = load_item<RM, FULL>(items, pi + 2 + (c + 1 < kC ? c + 1 : c));
+          if (c >= 0) cw = load_item<RM, FULL>(pit, 2 + (c + 1 < kC ? c + 1 : c));
           continue;
         }
-        const Regs nw = c < 0 ? cw : load_item<RM, FULL>(items, pi + 2 + (c + 1 < kC ? c + 1 : c));
+        const Regs nw = c < 0 ? cw : load_item<RM, FULL>(pit, 2 + (c + 1 < kC ? c + 1 : c));
         const Item<RM> it = decode_item<RM, FULL>(c < 0 ? pw : cw);
         uint32_t any_rep = 0;
 #pragma unroll
