@@ -81,14 +81,29 @@ WORKLOADS = {
 PID = {"alloc": 0, "tlp": 1, "lvrb": 2, "nrt": 3, "net": 4, "cap": 5, "lroc": 7, "peaks": 8}
 
 
-def kernel_source_hash() -> str:
+# kernel sources per plugin key of WORKLOADS (csrc/); spx_internal.h (argument structs, launch constants) counts for all
+KERNEL_FILES = {
+    "alloc": ("kernels_trimaran.hip", "kernels_profile.hip"), "tlp": ("kernels_trimaran.hip",), "lvrb": ("kernels_trimaran.hip",),
+    "lroc": ("kernels_lroc.hip", "lroc_math.h"), "peaks": ("kernels_peaks.hip",),
+    "nrt": ("kernels_nrt_fast.hip", "kernels_nrt.hip"), "net": ("kernels_network.hip", "kernels_sort.hip"),
+    "cap": ("kernels_capacity.hip", "kernels_profile.hip"),
+}
+
+
+def kernel_source_hash(plugins=None) -> str:
     """identifies the kernel sources a profile was taken with (the GPU box has no .git): profiles/ entries carry it, and
-    bench.py reports their counter figures only while it still matches"""
+    bench.py reports their counter figures only while it still matches.  Covers the files the workload's kernels are
+    compiled from (KERNEL_FILES + spx_internal.h) — not the host-side engine — so that work on one plugin's kernel does not
+    orphan the other workloads' profiles; plugins=None hashes every kernel source."""
+    csrc = ROOT / "scheduler-plugins_amd" / "csrc"
+    if plugins is None:
+        names = sorted(f.name for f in csrc.glob("*") if f.suffix in (".hip", ".h") and f.name != "spx_engine.hip" and f.name != "spx_multi.hip")
+    else:
+        names = sorted({"spx_internal.h"} | {f for p in plugins for f in KERNEL_FILES[p]})
     h = hashlib.sha256()
-    for f in sorted((ROOT / "scheduler-plugins_amd" / "csrc").glob("*")):
-        if f.suffix in (".hip", ".h"):
-            h.update(f.name.encode())
-            h.update(f.read_bytes())
+    for name in names:
+        h.update(name.encode())
+        h.update((csrc / name).read_bytes())
     return h.hexdigest()[:16]
 
 
@@ -216,7 +231,7 @@ def cpu_baseline(spx, snap, e, plugins, budget_s: float):
     return out
 
 
-def profile_counters(workload: str):
+def profile_counters(workload: str, plugins):
     """counter figures of the committed rocprofv3 PMC passes (profiles/rNN/<workload>_traffic.json: separate --pmc runs, FETCH_SIZE
     corrected x2 for gfx950) — reported only when taken with the kernel sources this run was built from"""
     cands = sorted(ROOT.glob(f"profiles/r*/{workload}_traffic.json"))
@@ -224,7 +239,7 @@ def profile_counters(workload: str):
         return None
     d = json.loads(cands[-1].read_text())
     src = str(cands[-1].relative_to(ROOT))
-    if d.get("kernel_source_hash") != kernel_source_hash():
+    if d.get("kernel_source_hash") != kernel_source_hash(plugins):
         return {"traffic": None, "stale_profile": src}
     pmc = d.get("pmc_mean_per_dispatch", {})
     valu = None
@@ -499,7 +514,7 @@ def main() -> None:
     algo_bytes = n_nodes * w["node_row"] + local_pods * w["pod_row"] + n_nodes * local_pods * w["out"]
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
 
-    counters = profile_counters(args.workload) if not args.plugins else None
+    counters = profile_counters(args.workload, w["plugins"]) if not args.plugins else None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": counters.get("traffic") if counters else None,
                 "kernel": {"nrt": "spx::k_nrt_fast (Filter launch + Score launch, both counted)", "net": "spx::k_net_cls",
@@ -508,7 +523,7 @@ def main() -> None:
                            "cap": "full profile: k_quota, k_nrt_fast x2, k_net_cls, k_tlp_fast2, k_lvrb_fast, k_alloc_masked"}.get(
                     w["plugins"][0], "spx::k_tlp_fast2 (Allocatable+TLP)" + (" + spx::k_lvrb_fast" if "lvrb" in w["plugins"] else "")),
                 "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes, "frac_of_measured_copy_ceiling_6.29TBs": achieved / 6290.0,
-                "kernel_source_hash": kernel_source_hash()}
+                "kernel_source_hash": kernel_source_hash(w["plugins"])}
     if counters:
         roofline.update({k: v for k, v in counters.items() if k != "traffic"})
         roofline["valu_busy_what"] = "SQ_ACTIVE_INST_VALU / (4 * SQ_BUSY_CYCLES) of the dominant kernel, committed PMC pass: why an HBM fraction is low when it is (VALU-bound sweep)"
