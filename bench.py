@@ -244,7 +244,10 @@ def profile_counters(workload: str, plugins):
     pmc = d.get("pmc_mean_per_dispatch", {})
     valu = None
     if pmc.get("SQ_BUSY_CYCLES") and pmc.get("SQ_ACTIVE_INST_VALU") is not None:
-        valu = pmc["SQ_ACTIVE_INST_VALU"] / (4.0 * pmc["SQ_BUSY_CYCLES"])
+        # SQ_BUSY_CYCLES sums the chip's 32 SQ instances (4 per XCD: kernel cycles x 32, checked against GRBM_GUI_ACTIVE / 8 and the
+        # kernel duration); the 1024 SIMDs issue one VALU instruction per 4 cycles each, and SQ_ACTIVE_INST_VALU counts in those
+        # 4-cycle slots (it equals SQ_INSTS_VALU on these kernels): slots available = SQ_BUSY_CYCLES / 32 * 1024 / 4
+        valu = pmc["SQ_ACTIVE_INST_VALU"] / (8.0 * pmc["SQ_BUSY_CYCLES"])
     return {"traffic": d.get("traffic_bytes_per_launch"), "valu_busy_frac": valu, "source": src}
 
 
@@ -261,6 +264,7 @@ def main() -> None:
     ap.add_argument("--transport", default="rccl", choices=["rccl", "copy"], help="single-process multi-device exchange (spx_multi)")
     ap.add_argument("--devices", default="", help="single-process multi-device mode: explicit device list, e.g. 0,0 with --transport copy "
                                                   "runs two ranks on one GPU (plumbing check of the sharded path on a one-GPU box)")
+    ap.add_argument("--sweep-only", action="store_true", help="skip the full_cycle section (profiling runs: rocprofv3 counter passes crash in hipGraph capture)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -385,7 +389,7 @@ def main() -> None:
     # per-row argmax + D2H of the per-pod decisions — wall clock, once
     full_cycle = None
     score_mask = mask & ~(1 << 6)
-    if mode == "single" and not args.plugins and args.workload in ("config2", "config2_lvrb", "config5_share", "config4", "config3"):
+    if mode == "single" and not args.plugins and not args.sweep_only and args.workload in ("config2", "config2_lvrb", "config5_share", "config4", "config3"):
         try:
             barrier()
             c0 = time.perf_counter()
@@ -526,7 +530,7 @@ def main() -> None:
                 "kernel_source_hash": kernel_source_hash(w["plugins"])}
     if counters:
         roofline.update({k: v for k, v in counters.items() if k != "traffic"})
-        roofline["valu_busy_what"] = "SQ_ACTIVE_INST_VALU / (4 * SQ_BUSY_CYCLES) of the dominant kernel, committed PMC pass: why an HBM fraction is low when it is (VALU-bound sweep)"
+        roofline["valu_busy_what"] = "VALU issue slots used, summed over the workload's sweep kernels: SQ_ACTIVE_INST_VALU / (8 * SQ_BUSY_CYCLES) (32 SQ instances, 1024 SIMDs, one VALU instruction per SIMD per 4 cycles); committed PMC pass — why an HBM fraction is low when it is (issue-bound sweep)"
     out = {
         "metric": "pod_x_node_filter_score_evals_per_sec",
         "value": value,

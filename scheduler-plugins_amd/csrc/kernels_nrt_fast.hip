@@ -305,6 +305,78 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
   return static_cast<int>(m + 1u);
 }
 
+// ---------------------------------------------------------------- BalancedAllocation in float32 (Score launch)
+//
+// The float64 form above costs ~44 float64 instructions per zone and container and holds 144 VGPRs of node tables; float32
+// instructions issue twice as fast on this part (tools/micro/valu_rate.hip).  The zone score is (1 - variance) * 100 truncated,
+// and scoreForEachNUMANode takes the minimum of the zones' truncated scores — truncation is monotone, so that minimum is
+// trunc(min over zones of the untruncated value): ONE truncation per container, and a float32 evaluation decides it
+// whenever the float32 minimum is farther from an integer than its error bound.  Otherwise — and whenever float32 cannot
+// tell "request > capacity" — the cell is marked kBalRedo in the score table; k_nrt_bal_scan collects the marked
+// cells and k_nrt_bal_redo recomputes them with the float64 form (whole cell, all containers).
+//   fraction   f = RN32(RN32(request) * RN32(RN64(1 / capacity)) + one)      |f - request/capacity| <= 1.9e-7 * f
+//   variance   (sum f^2 - (sum f)^2 / n) / (n - 1)  — algebraically the reference's corrected two-pass value — with
+//              f in [0, 1], n in 2..8:   |s32 - s| < 2.3e-4  (replayed in tests/test_exactness_arguments.py)
+// A cell with capacity <= 0 contributes the reference's f = 1.0 through `one` (rcp = 0), and does not count for "over".
+// Valid zone scores are >= 50 (unbiased variance of n values in [0,1] is at most 1/2), so 0 only ever means "no valid zone".
+constexpr float kBalBand = 3e-4f;
+constexpr float kBalTol = 2.4e-7f;  // 2^-22: two float32 roundings of nearly equal quantities
+constexpr float kBalNoCap = 1e38f;
+constexpr int kBalRedo = 255;  // score byte of a cell the fix-up launch recomputes (scores are <= 100)
+
+// "request > capacity" (fractionOfCapacity > 1: the zone scores 0) is decided on the quantities themselves, not on the
+// rounded quotient — a request that equals the capacity (one device wanted, one device free) is the common case, and its
+// float32 quotient is 1.0 either way.  For integers, RN64(request / capacity) > 1.0 exactly when request > capacity; slots whose
+// requests and capacities are all below 2^24 cluster-wide (NrtArgs.exact32_slots: whole cores, devices) compare exactly in
+// float32, the others (bytes) are undecided when the two lie within 2^-22 of each other.
+template <int RM>
+struct BalNode {
+  float rcp[kZ][RM];   // RN32(1 / Value(capacity)), 0 where the capacity is not positive
+  float one[kZ][RM];   // 1 where the capacity is not positive, else 0
+  float capf[kZ][RM];  // RN32(Value(capacity)), kBalNoCap where the capacity is not positive
+};
+
+template <int RM>
+__device__ __forceinline__ int score_balanced_f32(const BalNode<RM>& bn, int nz, int cpu_slot, uint32_t exact32, const Item<RM>& it, bool* redo) {
+  const uint32_t used = it.used;
+  const int n_used = __builtin_popcount(used);
+  if (n_used < 2) {
+    // uniform.  One requested resource: the deviation from the mean is exactly 0, the variance 0 / (n - 1) = 0 / 0 is NaN, and the
+    // float64 form's int(NaN) is 0 for every zone (v_cvt_i32_f64) — "no zone scores", 0, whatever the quantities are
+    *redo = false;
+    return 0;
+  }
+  const float rn = 1.0f / static_cast<float>(n_used), rm = 1.0f / static_cast<float>(n_used - 1);
+  float value[RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r) value[r] = static_cast<float>(r == cpu_slot ? it.cpu_v : it.raw[r]);
+  float best = __builtin_inff();
+  bool undecided = false;
+#pragma unroll
+  for (int z = 0; z < kZ; ++z) {
+    float sum = 0.0f, sq = 0.0f, mxd = -kBalNoCap, nr = -1.0f;
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      if (!((used >> r) & 1u)) continue;  // uniform
+      const float f = __builtin_fmaf(value[r], bn.rcp[z][r], bn.one[z][r]);
+      const float d = value[r] - bn.capf[z][r];
+      mxd = __builtin_fmaxf(mxd, d);
+      if (!((exact32 >> r) & 1u)) nr = __builtin_fmaxf(nr, __builtin_fmaf(bn.capf[z][r], kBalTol, -__builtin_fabsf(d)));  // uniform
+      sum += f;
+      sq = __builtin_fmaf(f, f, sq);
+    }
+    const float var = __builtin_fmaf(-(sum * sum), rn, sq) * rm;
+    const float sc = __builtin_fmaf(-var, 100.0f, 100.0f);
+    const bool exists = z < nz;
+    undecided |= exists && nr >= 0.0f;
+    best = (exists && !(mxd > 0.0f)) ? __builtin_fminf(best, sc) : best;
+  }
+  const bool has = best < __builtin_inff();
+  const float fl = __builtin_floorf(best), frac = best - fl;
+  *redo = undecided || (has && (frac < kBalBand || frac > 1.0f - kBalBand));
+  return has ? static_cast<int>(fl) : 0;
+}
+
 // ---------------------------------------------------------------- LeastNUMANodes (least_numa.go:35-233)
 //
 // numaNodesRequired + findSuitableCombination: the smallest subset size for which some subset of zones holds the request,
@@ -489,12 +561,42 @@ __device__ __forceinline__ void subtract_from_numas_fast(FastNode<RM>& ns, const
   }
 }
 
+// the node's zone tables into registers (prologue of the sweep; the BalancedAllocation fix-up loads single nodes with it)
+template <int RM, int SG>
+__device__ __forceinline__ void load_fast_node(const NrtArgs& a, int64_t n, bool in, FastNode<RM>& ns, double (&cpu_v)[kZ], double (&braw)[kZ]) {
+  const int R = a.n_res;
+  ns.nz = in ? a.n_zones[n] : 0;
+  ns.node_present = in ? a.node_present[n] : 0u;
+#pragma unroll
+  for (int i = 0; i < RM / 4; ++i) ns.rep[i] = ns.fill[i] = 0;
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    if (r >= R) continue;
+    const uint32_t rep = in ? a.f_rep[static_cast<int64_t>(r) * a.n_nodes + n] : 0u;
+    ns.rep[r >> 2] |= rep << (8 * (r & 3));
+    if ((a.slot_flags[r] & SPX_NRT_SLOT_HOST_LEVEL) && rep == 0) ns.fill[r >> 2] |= 0xffu << (8 * (r & 3));
+  }
+#pragma unroll
+  for (int z = 0; z < kZ; ++z) {
+    cpu_v[z] = (SG == kSgBalanced && in && a.cpu_slot >= 0) ? a.f_cpu[static_cast<int64_t>(z) * a.n_nodes + n] : 0.0;
+    braw[z] = (SG == kSgMost && in && a.cpu_slot >= 0) ? a.f_braw[static_cast<int64_t>(z) * a.n_nodes + n] : kNoCap;
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const int64_t i = (static_cast<int64_t>(z) * R + r) * a.n_nodes + n;
+      ns.av[z][r] = (in && r < R) ? a.f_av[i] : -1.0;
+      const double b = (SG != kSgBalanced && SG != kSgLeastNuma && in && r < R) ? a.f_rc[i] : kNoCap;
+      ns.b[z][r] = (SG == kSgLeast && b == kNoCap) ? __builtin_inf() : b;
+      if constexpr (SG == kSgBalanced) ns.b[z][r] = (in && r < R) ? a.f_rcv[i] : 1.0;  // RN(1 / Value(capacity)) for div_rn
+    }
+  }
+}
+
 // PH: 0 = Filter and Score in one launch; 1 = Filter only, 2 = Score only (LeastAllocated: its Score reads only b, the
 // Filter only the mutable table, so each half keeps 64 instead of 128 state registers and runs at higher occupancy)
 constexpr int kPhBoth = 0, kPhFilter = 1, kPhScore = 2;
 
 template <int RM, int SG, int PH>
-__global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? ((SG == kSgBalanced || SG == kSgLeastNuma) ? 2 : (SG == kSgMost ? 4 : 5)) : (PH == kPhFilter ? 5 : (SG == kSgLeast ? 3 : 2))) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
+__global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgLeastNuma ? 2 : ((SG == kSgMost || SG == kSgBalanced) ? 4 : 5)) : (PH == kPhFilter ? 5 : (SG == kSgLeast ? 3 : 2))) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
   SPX_RESOLVE_ROWS(a);
   constexpr bool FULL = PH != kPhFilter;  // only the Score reads the second half of a request item
   typedef ItemRegs<RM, FULL> Regs;
@@ -543,29 +645,20 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? ((SG == kSgBalance
   FastNode<RM> ns;
   double cpu_v[kZ], braw[kZ];
   const uint32_t flags = in ? a.flags[n] : 0u;
-  ns.nz = in ? a.n_zones[n] : 0;
-  ns.node_present = in ? a.node_present[n] : 0u;
+  load_fast_node<RM, SG>(a, n, in, ns, cpu_v, braw);
+  // BalancedAllocation's Score launch works from float32 images of the reciprocals; the float64 tables die here
+  constexpr bool kBalF32 = SG == kSgBalanced && PH == kPhScore;
+  BalNode<RM> bn;
+  if constexpr (kBalF32) {
 #pragma unroll
-  for (int i = 0; i < RM / 4; ++i) ns.rep[i] = ns.fill[i] = 0;
+    for (int z = 0; z < kZ; ++z)
 #pragma unroll
-  for (int r = 0; r < RM; ++r) {
-    if (r >= R) continue;
-    const uint32_t rep = in ? a.f_rep[static_cast<int64_t>(r) * a.n_nodes + n] : 0u;
-    ns.rep[r >> 2] |= rep << (8 * (r & 3));
-    if ((a.slot_flags[r] & SPX_NRT_SLOT_HOST_LEVEL) && rep == 0) ns.fill[r >> 2] |= 0xffu << (8 * (r & 3));
-  }
-#pragma unroll
-  for (int z = 0; z < kZ; ++z) {
-    cpu_v[z] = (SG == kSgBalanced && in && a.cpu_slot >= 0) ? a.f_cpu[static_cast<int64_t>(z) * a.n_nodes + n] : 0.0;
-    braw[z] = (SG == kSgMost && in && a.cpu_slot >= 0) ? a.f_braw[static_cast<int64_t>(z) * a.n_nodes + n] : kNoCap;
-#pragma unroll
-    for (int r = 0; r < RM; ++r) {
-      const int64_t i = (static_cast<int64_t>(z) * R + r) * a.n_nodes + n;
-      ns.av[z][r] = (in && r < R) ? a.f_av[i] : -1.0;
-      const double b = (SG != kSgBalanced && SG != kSgLeastNuma && in && r < R) ? a.f_rc[i] : kNoCap;
-      ns.b[z][r] = (SG == kSgLeast && b == kNoCap) ? __builtin_inf() : b;
-      if constexpr (SG == kSgBalanced) ns.b[z][r] = (in && r < R) ? a.f_rcv[i] : 1.0;  // RN(1 / Value(capacity)) for div_rn
-    }
+      for (int r = 0; r < RM; ++r) {
+        const bool cap = ns.av[z][r] > 0.0;
+        bn.rcp[z][r] = cap ? static_cast<float>(ns.b[z][r]) : 0.0f;
+        bn.one[z][r] = cap ? 0.0f : 1.0f;
+        bn.capf[z][r] = cap ? static_cast<float>(r == a.cpu_slot ? cpu_v[z] : ns.av[z][r]) : kBalNoCap;
+      }
   }
   const int nns = 100 / (in ? a.max_numa[n] : 8);  // normalizeScore's per-zone step, least_numa.go:90-100
   uint32_t mmin[kLnDwords];  // LeastNUMANodes: the node's minimum-distance subsets per size (LnLayout)
@@ -602,6 +695,7 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? ((SG == kSgBalance
     int score = non_g ? 100 : 0;
     const bool want_filter = PH != kPhScore && filtered && aligned;
     const bool want_score = SG != kSgLeastNuma && PH != kPhFilter && !non_g && aligned;
+    bool redo = false;  // BalancedAllocation, float32 form: some container's score could not be decided
 
     if ((want_filter || want_score) && pod_scope) {  // singleNUMAPodLevelHandler / podScopeScore
       const Item<RM> it = decode_item<RM, FULL>(pw);
@@ -612,7 +706,15 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? ((SG == kSgBalance
         }
       }
       if constexpr (PH != kPhFilter) {
-        if (want_score) score = score_each_fast<RM, SG>(ns, a, it, cpu_v, braw);
+        if (want_score) {
+          if constexpr (kBalF32) {
+            bool rd;
+            score = score_balanced_f32(bn, ns.nz, a.cpu_slot, a.exact32_slots, it, &rd);
+            redo |= rd;
+          } else {
+            score = score_each_fast<RM, SG>(ns, a, it, cpu_v, braw);
+          }
+        }
       }
     }
     if ((want_filter || want_score) && !pod_scope) {  // singleNUMAContainerLevelHandler / containerScopeScore
@@ -659,13 +761,20 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? ((SG == kSgBalance
           cw = load_item<RM, FULL>(pit, 2);
           for (int c = 0; c < n_ctr; ++c) {
             const Regs nw = load_item<RM, FULL>(pit, 2 + (c + 1 < kC ? c + 1 : c));
-            sum += score_each_fast<RM, SG>(ns, a, decode_item<RM, FULL>(cw), cpu_v, braw);
+            if constexpr (kBalF32) {
+              bool rd;
+              sum += score_balanced_f32(bn, ns.nz, a.cpu_slot, a.exact32_slots, decode_item<RM, FULL>(cw), &rd);
+              redo |= rd;
+            } else {
+              sum += score_each_fast<RM, SG>(ns, a, decode_item<RM, FULL>(cw), cpu_v, braw);
+            }
             cw = nw;
           }
         }
       }
       if (want_score) score = static_cast<int>((static_cast<uint32_t>(sum) * inv_n) >> 16);  // int64(mean): sum / n_ctr, sum <= 800
     }
+    if constexpr (kBalF32) score = (want_score && redo) ? kBalRedo : score;  // k_nrt_bal_scan / k_nrt_bal_redo recompute the cell in float64
 
     if constexpr (SG == kSgLeastNuma) {
       // LeastNUMANodes scores every node that has a fresh NRT, whatever its topology-manager policy (score.go:167-191).
@@ -740,6 +849,127 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? ((SG == kSgBalance
   }
 }
 
+// BalancedAllocation fix-up: the cells the float32 Score launch marked kBalRedo, recomputed with the float64 form — the node's
+// tables loaded for that one cell, the pod's items read with ordinary (per-lane) loads.  One thread per 16 bytes of a score
+// row; nearly all threads find nothing.
+template <int RM>
+__device__ __forceinline__ ItemRegs<RM, true> load_item_lane(const uint32_t* pod_items, int slot) {
+  const uint32_t* p = pod_items + slot * item_words<RM>();
+  ItemRegs<RM, true> r;
+  if constexpr (RM == 4) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.w[i] = p[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.lo[i] = p[i], r.hi[i] = p[16 + i];
+  }
+  return r;
+}
+
+// the float64 form for one (pod, node) cell
+template <int RM>
+__device__ __forceinline__ int balanced_cell_exact(const NrtArgs& a, int64_t pod, int64_t n) {
+  const uint32_t* pit = a.pod_items + pod * (kItemsPerPod * item_words<RM>());
+  const uint32_t h0 = pit[0], inv_n = pit[1];
+  const int n_ctr = (h0 >> 16) & 0xffu;
+  FastNode<RM> ns;
+  double cpu_v[kZ], braw[kZ];
+  load_fast_node<RM, kSgBalanced>(a, n, true, ns, cpu_v, braw);
+  int score;
+  if (a.flags[n] & SPX_NRT_F_POD_SCOPE) {
+    score = score_each_fast<RM, kSgBalanced>(ns, a, decode_item<RM, true>(load_item_lane<RM>(pit, 1)), cpu_v, braw);
+  } else {
+    int sum = 0;
+#pragma unroll 1
+    for (int c = 0; c < n_ctr; ++c) sum += score_each_fast<RM, kSgBalanced>(ns, a, decode_item<RM, true>(load_item_lane<RM>(pit, 2 + c)), cpu_v, braw);
+    score = static_cast<int>((static_cast<uint32_t>(sum) * inv_n) >> 16);
+  }
+  return score > 254 ? 254 : score;
+}
+
+// Scan: one thread per 16 bytes of a score row.  The marked cells are rare and scattered (config #3: 0.7 % — exactly integer
+// scores of small-integer quantities, mostly), and recomputing them where they are found leaves 1-7 lanes of a wave working
+// through ~30 us of dependent loads each (10 ms for 1.8e6 cells).  So the scan only compacts them into a list — one atomic
+// per block of 1024 threads — and k_nrt_bal_redo works through the list with full waves.  Cells that do not fit the list are
+// recomputed in place.
+constexpr int kScanThreads = 1024;
+template <int RM>
+__global__ __launch_bounds__(kScanThreads) void k_nrt_bal_scan(NrtArgs a) {
+  SPX_RESOLVE_ROWS(a);
+  __shared__ uint32_t wave_total[kScanThreads / 64];
+  __shared__ uint32_t block_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t per_row = a.row_stride / 16;
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool live = idx < (a.row_end - a.row_begin) * per_row;
+  const int64_t pod = a.row_begin + (live ? idx / per_row : 0);
+  const int64_t col = live ? (idx % per_row) * 16 : 0;
+  uint8_t* cells = a.out_score + pod * a.row_stride + col;
+  uint4 w = uint4{0, 0, 0, 0};
+  if (live) w = *reinterpret_cast<const uint4*>(cells);
+  // bit j of `marks`: byte j is kBalRedo (0xff)
+  uint32_t marks = 0;
+  {
+    const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) marks |= (((words[q] >> (8 * b)) & 0xffu) == static_cast<uint32_t>(kBalRedo) ? 1u : 0u) << (4 * q + b);
+  }
+  const uint32_t mine = static_cast<uint32_t>(__builtin_popcount(marks));
+  if (__syncthreads_or(mine != 0) == 0) return;  // nothing marked in this block's 16 KB of table
+  // exclusive prefix over the block: in the wave by shuffles, across waves through LDS
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), d));
+    incl += lane >= d ? up : 0u;
+  }
+  if (lane == 63) wave_total[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int i = 0; i < kScanThreads / 64; ++i) {
+      const uint32_t c = wave_total[i];
+      wave_total[i] = t;
+      t += c;
+    }
+    block_base = atomicAdd(a.redo_list, t);
+  }
+  __syncthreads();
+  uint32_t at = block_base + wave_total[wave] + incl - mine;
+  unsigned in_place = 0;
+  while (marks) {
+    const int j = __builtin_ctz(marks);
+    marks &= marks - 1;
+    if (at < a.redo_cap) {
+      a.redo_list[2 + 2 * static_cast<size_t>(at)] = static_cast<uint32_t>(pod - a.row_begin);
+      a.redo_list[3 + 2 * static_cast<size_t>(at)] = static_cast<uint32_t>(col + j);
+    } else {
+      cells[j] = static_cast<uint8_t>(balanced_cell_exact<RM>(a, pod, col + j));
+      ++in_place;
+    }
+    ++at;
+  }
+  if (a.stats && in_place)
+    atomicAdd(a.stats + (SPX_PLUGIN_NRT * kStatSlots + static_cast<int>(idx & (kStatSlots - 1))) * kStatStride, static_cast<unsigned long long>(in_place));
+}
+
+template <int RM>
+__global__ __launch_bounds__(256) void k_nrt_bal_redo(NrtArgs a) {
+  SPX_RESOLVE_ROWS(a);
+  const uint32_t count = a.redo_list[0] < a.redo_cap ? a.redo_list[0] : a.redo_cap;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int64_t pod = a.row_begin + a.redo_list[2 + 2 * static_cast<size_t>(i)];
+  const int64_t n = a.redo_list[3 + 2 * static_cast<size_t>(i)];
+  a.out_score[pod * a.row_stride + n] = static_cast<uint8_t>(balanced_cell_exact<RM>(a, pod, n));
+  if (a.stats && (threadIdx.x & 63) == 0) {  // one update per wave: the live lanes of the wave
+    const unsigned live = min(64u, count - i);
+    atomicAdd(a.stats + (SPX_PLUGIN_NRT * kStatSlots + static_cast<int>((i >> 6) & (kStatSlots - 1))) * kStatStride, static_cast<unsigned long long>(live));
+  }
+}
+
 }  // namespace
 
 bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
@@ -756,6 +986,12 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
     if (split) { /* the Filter half does not depend on the strategy */ \
       hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhFilter>), dim3(blocks), dim3(256), 0, s, a, n_tiles); \
       hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
+      if (SGV == kSgBalanced) { /* float32 Score launch: the cells it could not decide, compacted and recomputed in float64 */ \
+        const int64_t units = (a.row_end - a.row_begin) * (a.row_stride / 16); \
+        (void)hipMemsetAsync(a.redo_list, 0, 8, s); \
+        hipLaunchKernelGGL((k_nrt_bal_scan<RMV>), dim3(static_cast<unsigned>((units + kScanThreads - 1) / kScanThreads)), dim3(kScanThreads), 0, s, a); \
+        hipLaunchKernelGGL((k_nrt_bal_redo<RMV>), dim3((a.redo_cap + 255) / 256), dim3(256), 0, s, a); \
+      } \
     } else {                                                                                              \
       hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhBoth>), dim3(blocks), dim3(256), 0, s, a, n_tiles);     \
     }                                                                                                     \

@@ -92,6 +92,9 @@ struct spx_engine {
   DevBuf d_nrt_fav, d_nrt_frc, d_nrt_frcv, d_nrt_fcpu, d_nrt_fbraw, d_nrt_frep, d_nrt_items, d_nrt_perm, d_nrt_ln;
   std::vector<double> nrt_wtab;  // [2^n_res][2]: sum of the weights of a slot subset, its biased reciprocal
   bool nrt_fast_slots = false, nrt_fast_nodes = false, nrt_fast_pods = false;
+  DevBuf d_nrt_redo;       // BalancedAllocation: list of the cells the float32 Score launch leaves to the float64 form
+  uint32_t nrt_redo_cap = 0;
+  uint32_t nrt_big_nodes = ~0u, nrt_big_pods = ~0u;  // slots with a capacity / a request (Value() form) of 2^24 or more
   bool nrt_ln_ok = false;  // LeastNUMANodes tables valid: every zone cost within [0, 255]
   int32_t nrt_cpu_slot = -1;
   DevBuf status[SPX_NUM_PLUGINS];
@@ -399,6 +402,10 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   na.f_rep = static_cast<const uint8_t*>(e->d_nrt_frep.p);
   na.pod_items = static_cast<const uint32_t*>(e->d_nrt_items.p);
   na.perm = static_cast<const int32_t*>(e->d_nrt_perm.p);
+  na.stats = static_cast<unsigned long long*>(e->d_stats.p);
+  na.exact32_slots = ~(e->nrt_big_nodes | e->nrt_big_pods);
+  na.redo_list = static_cast<uint32_t*>(e->d_nrt_redo.p);
+  na.redo_cap = e->nrt_redo_cap;
   na.ln_tab = e->nrt_ln_ok ? static_cast<const uint32_t*>(e->d_nrt_ln.p) : nullptr;
 }
 
@@ -500,7 +507,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_raw_row,   &e->d_lv_exact, &e->d_lv_fast, &e->d_tlp_fast, &e->d_commit, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
-                    &e->d_nrt_frcv, &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_ln, &e->d_nrt_fbraw,
+                    &e->d_nrt_frcv, &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_ln, &e->d_nrt_fbraw, &e->d_nrt_redo,
                     &e->d_net_region, &e->d_net_zone, &e->d_net_class, &e->d_net_class16, &e->d_net_cls_size, &e->d_net_cls_region, &e->d_net_cls_zone,
                     &e->d_net_rcost, &e->d_net_zcost, &e->d_net_pod_key, &e->d_net_key_flag, &e->d_net_pair_ptr,
                     &e->d_net_pair_node, &e->d_net_pair_max, &e->d_q_pod_ns, &e->d_q_pod_prio, &e->d_q_pod_req, &e->d_q_pod_reqp,
@@ -814,6 +821,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
         cpuv(static_cast<size_t>(Zm * n), 0.0), braw(static_cast<size_t>(Zm * n), spx::kNrtNoCap);
     std::vector<uint8_t> rep(static_cast<size_t>((R > 0 ? R : 1) * n), 0);
     std::atomic<bool> ok{true};
+    std::atomic<uint32_t> big_nodes{0};
     spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
     for (int64_t i = row0; i < row1; ++i) {
       const int nz = t->n_zones[i];
@@ -825,6 +833,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
           if (!nrt_fast_qty(cap)) ok = false;
           const bool is_cpu = r == e->nrt_cpu_slot;
           const double cap_v = static_cast<double>(nrt_value_of(is_cpu, cap));
+          if (cap_v >= 16777216.0) big_nodes.fetch_or(1u << r, std::memory_order_relaxed);
           av[static_cast<size_t>((z * R + r) * n + i)] = static_cast<double>(cap);
           rcp[static_cast<size_t>((z * R + r) * n + i)] = cap_v > 0.0 ? 100.0 / cap_v : spx::kNrtNoCap;
           rcv[static_cast<size_t>((z * R + r) * n + i)] = cap_v > 0.0 ? 1.0 / cap_v : 1.0;
@@ -836,6 +845,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
     }
     }, 1024);
     e->nrt_fast_nodes = ok.load();
+    e->nrt_big_nodes = big_nodes.load();
     // window-local node order: inside each run of 256 nodes, group the nodes by the code path their flags select
     // (not aligned / pod scope / container scope) so that wavefronts are mostly homogeneous
     const int64_t n_slots = spx::round_up(n, 256);
@@ -951,12 +961,14 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
     std::vector<uint32_t> items(p * 10 * IW, 0u);
     const uint32_t slot_mask = (1u << R) - 1u;
     std::atomic<bool> ok{e->nrt_wtab.size() == (static_cast<size_t>(2) << R)};
+    std::atomic<uint32_t> big_pods{0};
     auto put_f64 = [](uint32_t* w, double v) { std::memcpy(w, &v, sizeof v); };
     auto fill = [&](uint32_t* w, uint32_t present, const int64_t* req, bool non_g, uint32_t kind) {
       const uint32_t used = present & slot_mask;
       uint32_t fit = 0, always = 0;
       for (size_t r = 0; r < R; ++r) {
         if (!nrt_fast_qty(req[r])) ok = false;
+        if (nrt_value_of(static_cast<int>(r) == e->nrt_cpu_slot, req[r]) >= 16777216) big_pods.fetch_or(1u << r, std::memory_order_relaxed);
         put_f64(w + 2 * r, static_cast<double>(req[r]));
         if (!((used >> r) & 1u) || req[r] == 0) continue;  // "ignoring zero-qty resource request" filter.go:103-106
         if (non_g && (e->nrt_slot_flags[r] & SPX_NRT_SLOT_AFFINE)) always |= 1u << r;
@@ -996,6 +1008,7 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
     }, 4096);
     if ((rc = upload(e, e->d_nrt_items, items.data(), items.size() * sizeof(uint32_t)))) return rc;
     e->nrt_fast_pods = ok.load();
+    e->nrt_big_pods = big_pods.load();
     SPX_HIP(e, hipStreamSynchronize(e->stream));
   }
   e->nrt_pods = true;
@@ -1331,6 +1344,16 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (N) {
     if (e->score_stride[SPX_PLUGIN_NRT] != e->row_stride)
       return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
+    if (e->nrt_params.strategy == SPX_NRT_BALANCED_ALLOCATION) {
+      // room for 1/32 of the cells (config #3 marks 0.7 %); what does not fit is recomputed where it is found.  Inside the
+      // sequential commit loop (row_indirect: one row per launch, graph capture) the list allocated for the first pod is kept.
+      const uint64_t want = std::max<uint64_t>(4096, static_cast<uint64_t>(row_end - row_begin) * static_cast<uint64_t>(e->row_stride) / 32);
+      const uint32_t cap = static_cast<uint32_t>(std::min<uint64_t>(want, 1u << 28));
+      if (cap > e->nrt_redo_cap) {
+        if ((rc = ensure(e, e->d_nrt_redo, (2 + 2 * static_cast<size_t>(cap)) * sizeof(uint32_t)))) return rc;
+        e->nrt_redo_cap = cap;
+      }
+    }
     spx::NrtArgs na{};
     fill_nrt(e, na);
     na.row_begin = row_begin;

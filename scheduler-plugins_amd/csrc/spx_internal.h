@@ -254,6 +254,10 @@ struct NrtArgs {
                                  // cost lies outside [0, 255] (the reference-arithmetic kernel then serves that strategy)
   const int32_t* perm;           // [ceil(N/256)*256] node index per slot, windows of 256 ordered by code path; -1 = empty
   const uint32_t* pod_items;     // [P][10][16 or 32] pod record stream (layout: spx_engine.hip nrt_pod_items)
+  unsigned long long* stats;     // as TrimaranArgs::stats: BalancedAllocation cells recomputed in float64 (SPX_PLUGIN_NRT)
+  uint32_t* redo_list;           // BalancedAllocation: [count, pad, (row - row_begin, node) x redo_cap] cells the float32 Score launch left to float64
+  uint32_t redo_cap;
+  uint32_t exact32_slots;        // resource slots whose requests and capacities (Value() form) are all below 2^24: exact in float32
 };
 constexpr double kNrtNoCap = 1e200;
 

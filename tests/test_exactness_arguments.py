@@ -322,3 +322,76 @@ def test_balanced_allocation_divisions_are_correctly_rounded():
         assert div_rn(c2, float(n)) == rn_div(c2, float(n))
         num = ss - c2 / n
         assert div_rn(num, float(n - 1)) == rn_div(num, float(n - 1))
+
+
+def test_balanced_allocation_float32_score_is_exact_outside_the_band():
+    """numpy model of score_balanced_f32 (kernels_nrt_fast.hip): fractions as float32 products with the float32 image of
+    RN64(1/capacity), variance as (sum f^2 - (sum f)^2 / n) / (n - 1), score fma(-var, 100, 100) — against the reference's float64
+    sequence (balanced_allocation.go:32-54 + gonum stat.Variance) on integer requests / capacities up to 2^40, n = 2..8 resources.
+    Outside the band (kBalBand around integers; request within 2^-22 of the capacity) the truncated float32 score equals the reference's,
+    and the float32 value itself stays within 2.3e-4 of the float64 one (the bound DESIGN.md 3.4 derives)."""
+    rng = np.random.default_rng(21)
+    cells = 400_000
+    band = np.float32(3e-4)
+    worst = 0.0
+    undecided = plain_cells = 0
+    for n in range(2, 9):
+        mag = rng.integers(1, 41, (cells, n))
+        cap = np.floor(rng.random((cells, n)) * (2.0 ** mag)) + 1.0                      # capacities 1 .. 2^40
+        kind = rng.random((cells, n))
+        req = np.where(kind < 0.95, np.floor(rng.random((cells, n)) * cap),               # 0 <= request < capacity
+                       np.where(kind < 0.97, cap,                                         # exactly full
+                                np.where(kind < 0.98, cap + 1.0, np.floor(cap * 0.5))))    # just over; exactly half
+        plain = (kind < 0.95).all(axis=1)
+        nocap = rng.random((cells, n)) < 0.05                                              # capacity <= 0: the reference's f = 1
+        # ---- reference, float64, operation for operation
+        f = np.where(nocap, 1.0, req / cap)
+        over = (f > 1.0).any(axis=1)
+        s = np.zeros(cells)
+        for i in range(n):
+            s = s + f[:, i]
+        mean = s / n
+        ss = np.zeros(cells)
+        comp = np.zeros(cells)
+        for i in range(n):
+            d = f[:, i] - mean
+            ss = ss + d * d
+            comp = comp + d
+        var = (ss - comp * comp / n) / (n - 1)
+        score64 = (1.0 - var) * 100.0
+        want = np.where(over, 0, np.trunc(score64)).astype(np.int64)
+        # ---- float32 form
+        rcp = np.where(nocap, np.float32(0), _f32(1.0 / cap))
+        one = np.where(nocap, np.float32(1), np.float32(0)).astype(np.float32)
+        ff = _f32(_f32(req).astype(np.float64) * rcp.astype(np.float64) + one.astype(np.float64))   # fma
+        capf = np.where(nocap, np.float32(1e38), _f32(cap)).astype(np.float32)
+        dd = (_f32(req) - capf).astype(np.float32)
+        mxd = dd.max(axis=1)
+        # slots not known to stay below 2^24: undecided when request and capacity lie within 2^-22 of each other
+        nr = (_f32(capf.astype(np.float64) * 2.4e-7 - np.abs(dd).astype(np.float64))).max(axis=1)
+        sm = np.zeros(cells, np.float32)
+        sq = np.zeros(cells, np.float32)
+        for i in range(n):
+            sm = (sm + ff[:, i]).astype(np.float32)
+            sq = _f32(ff[:, i].astype(np.float64) * ff[:, i].astype(np.float64) + sq.astype(np.float64))       # fma
+        rn_, rm_ = np.float32(1.0) / np.float32(n), np.float32(1.0) / np.float32(n - 1)
+        ssq = (sm * sm).astype(np.float32)
+        v32 = (_f32(-(ssq.astype(np.float64)) * np.float64(rn_) + sq.astype(np.float64)) * rm_).astype(np.float32)
+        sc = _f32(-(v32.astype(np.float64)) * 100.0 + 100.0)
+        near_one = nr >= 0
+        valid = ~(mxd > 0)
+        # where the float32 comparison is taken as decided it is the exact one (the reference's f > 1.0 <=> request > capacity)
+        assert (valid[~near_one] == ~over[~near_one]).all()
+        fl = np.floor(sc)
+        frac = sc - fl
+        redo = near_one | (valid & ((frac < band) | (frac > np.float32(1) - band)))
+        got = np.where(valid, fl, 0).astype(np.int64)
+        ok = ~redo
+        assert (got[ok] == want[ok]).all(), (n, np.flatnonzero(ok & (got != want))[:5])
+        both = valid & ~over
+        worst = max(worst, float(np.abs(sc[both].astype(np.float64) - score64[both]).max()))
+        undecided += int((redo & plain).sum())
+        plain_cells += int(plain.sum())
+    assert worst < 2.3e-4, worst
+    # 2 * kBalBand of the cells, the rare fraction next to 1, and the exactly integer scores small capacities produce (all fractions 0 or equal)
+    assert undecided < 5e-3 * plain_cells, (undecided, plain_cells)
