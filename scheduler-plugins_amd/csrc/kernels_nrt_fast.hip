@@ -42,6 +42,13 @@ constexpr int kSgBalanced = 2;
 constexpr int kSgLeastNuma = 3;
 constexpr double kNoCap = kNrtNoCap;  // b[][] of a cell whose capacity is not positive
 
+// Placed at the top of a block guarded by a wave-uniform condition (a requested-resource bit of the pod record): an empty
+// volatile asm cannot be speculated, so the backend keeps the scalar branch and the wave skips the block.  Without it the
+// optimiser may if-convert the short per-resource blocks — compute all RM resources and select — depending on code that has
+// nothing to do with them: LeastAllocated's Score launch went from 1.5 to 2.1 ms that way when the BalancedAllocation
+// fix-up kernel was added to this file.
+#define SPX_KEEP_BRANCH() asm volatile("")
+
 template <int RM>
 struct FastNode {
   double av[kZ][RM];     // zone reports the resource ? available : -1
@@ -210,6 +217,7 @@ __device__ __forceinline__ void adjust_fast(FastNode<RM>& ns, const Item<RM>& it
 #pragma unroll
   for (int r = 0; r < RM; ++r) {
     if (!((it.fit >> r) & 1u)) continue;
+    SPX_KEEP_BRANCH();
 #pragma unroll
     for (int z = 0; z < kZ; ++z) ns.av[z][r] = __builtin_fma(sel[z], it.raw[r], ns.av[z][r]);
   }
@@ -249,6 +257,7 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
       for (int r = 0; r < RM; ++r) {
         fr[r] = 0.0;
         if (!((used >> r) & 1u)) continue;
+        SPX_KEEP_BRANCH();
         const double cap = ns.av[z][r];
         const double cap_v = r == a.cpu_slot ? cpu_v[z] : cap;
         const double f = cap > 0.0 ? div_rn(value[r], cap_v, ns.b[z][r]) : 1.0;  // fractionOfCapacity balanced_allocation.go:49-54
@@ -280,6 +289,7 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
 #pragma unroll
       for (int r = 0; r < RM; ++r) {
         if (!((used >> r) & 1u)) continue;
+        SPX_KEEP_BRANCH();
         double rs;
         if constexpr (SG == kSgLeast) {
           // (cap_v - req_v) * 100 / cap_v == 100 - req_v * (100 / cap_v); see the header for why the floor is exact.
@@ -358,6 +368,7 @@ __device__ __forceinline__ int score_balanced_f32(const BalNode<RM>& bn, int nz,
 #pragma unroll
     for (int r = 0; r < RM; ++r) {
       if (!((used >> r) & 1u)) continue;  // uniform
+      SPX_KEEP_BRANCH();
       const float f = __builtin_fmaf(value[r], bn.rcp[z][r], bn.one[z][r]);
       const float d = value[r] - bn.capf[z][r];
       mxd = __builtin_fmaxf(mxd, d);

@@ -54,27 +54,41 @@ __device__ __forceinline__ uint32_t infeasible4(const ProfileArgs& a, int64_t po
 // read from L2 per row and pass, 32-bit min/max, and the quotient as one float64 multiply (range < 2^32 < 2^42).
 // The first pass leaves each lane's 4 feasibility bits per tile in LDS (one byte), so the status tables — whose rows
 // do not survive in L2 between the passes at full occupancy — are read from HBM once.
-__device__ __forceinline__ void alloc_masked_compact(const ProfileArgs& a, int64_t pod, int lane, int wave, int n_waves, int64_t tiles, uint8_t* feas) {
+constexpr int kNplCompact = 16;  // nodes per lane and tile of the compact path: one dwordx4 per status table, four of offsets
+__device__ __forceinline__ void alloc_masked_compact(const ProfileArgs& a, int64_t pod, int lane, int wave, int n_waves, uint8_t* feas_bytes) {
+  uint16_t* feas = reinterpret_cast<uint16_t*>(feas_bytes);  // [tiles][64]: the lane's 16 feasibility bits
+  const int64_t tiles = (a.row_stride + 64 * kNplCompact - 1) / (64 * kNplCompact);
+  const int64_t row = pod * a.row_stride;
   uint32_t lo = 0xffffffffu, hi = 0u;
   bool any = false;
-#pragma unroll 4
+#pragma unroll 2
   for (int64_t t = wave; t < tiles; t += n_waves) {
-    const int64_t n0 = (t * 64 + lane) * kNpl;
+    const int64_t n0 = (t * 64 + lane) * kNplCompact;
     uint32_t ok = 0;
-    if (n0 < a.n_nodes) {
-      const uint32_t bad = infeasible4(a, pod, n0);
-      const uint4 r4 = *reinterpret_cast<const uint4*>(a.alloc_rel + n0);
-      const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
+    if (n0 < a.n_nodes) {  // rows are padded to a multiple of 16 bytes
+      uint4 bad = uint4{0, 0, 0, 0};
 #pragma unroll
-      for (int j = 0; j < kNpl; ++j) {
-        if (n0 + j >= a.n_nodes || ((bad >> (8 * j)) & 0xffu)) continue;
-        lo = r[j] < lo ? r[j] : lo;
-        hi = r[j] > hi ? r[j] : hi;
-        ok |= 1u << j;
+      for (int k = 0; k < 3; ++k)
+        if (a.status[k]) {
+          const uint4 v = *reinterpret_cast<const uint4*>(a.status[k] + row + n0);
+          bad.x |= v.x, bad.y |= v.y, bad.z |= v.z, bad.w |= v.w;
+        }
+      const uint32_t badw[4] = {bad.x, bad.y, bad.z, bad.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint4 r4 = *reinterpret_cast<const uint4*>(a.alloc_rel + n0 + 4 * q);
+        const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (n0 + 4 * q + j >= a.n_nodes || ((badw[q] >> (8 * j)) & 0xffu)) continue;
+          lo = r[j] < lo ? r[j] : lo;
+          hi = r[j] > hi ? r[j] : hi;
+          ok |= 1u << (4 * q + j);
+        }
       }
     }
     any |= ok != 0;
-    feas[t * 64 + lane] = static_cast<uint8_t>(ok);
+    feas[t * 64 + lane] = static_cast<uint16_t>(ok);
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
@@ -96,20 +110,23 @@ __device__ __forceinline__ void alloc_masked_compact(const ProfileArgs& a, int64
   }
   const uint32_t range = some ? hi - lo : 0u;
   const double b = range ? (100.0 / static_cast<double>(range)) * (1.0 + 0x1p-49) : 0.0;
-#pragma unroll 4
+#pragma unroll 2
   for (int64_t t = wave; t < tiles; t += n_waves) {
-    const int64_t n0 = (t * 64 + lane) * kNpl;
+    const int64_t n0 = (t * 64 + lane) * kNplCompact;
     if (n0 >= a.row_stride) continue;
-    uint32_t w = 0;
+    uint32_t w[4] = {0, 0, 0, 0};
     const uint32_t ok = feas[t * 64 + lane];  // written by this lane
     if (ok != 0 && range != 0) {
-      const uint4 r4 = *reinterpret_cast<const uint4*>(a.alloc_rel + n0);
-      const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
-      for (int j = 0; j < kNpl; ++j)
-        if ((ok >> j) & 1u) w |= static_cast<uint32_t>(static_cast<double>(r[j] - lo) * b) << (8 * j);  // infeasible cells hold 0
+      for (int q = 0; q < 4; ++q) {
+        const uint4 r4 = *reinterpret_cast<const uint4*>(a.alloc_rel + n0 + 4 * q);
+        const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((ok >> (4 * q + j)) & 1u) w[q] |= static_cast<uint32_t>(static_cast<double>(r[j] - lo) * b) << (8 * j);  // infeasible cells hold 0
+      }
     }
-    *reinterpret_cast<uint32_t*>(a.out_alloc + pod * a.row_stride + n0) = w;
+    *reinterpret_cast<uint4*>(a.out_alloc + row + n0) = uint4{w[0], w[1], w[2], w[3]};
   }
 }
 
@@ -120,8 +137,8 @@ __global__ __launch_bounds__(64 * kMaxRowWaves) void k_alloc_masked(ProfileArgs 
   if (pod >= a.row_end) return;
   const int64_t tiles = (a.row_stride + 64 * kNpl - 1) / (64 * kNpl);
   extern __shared__ uint8_t feas[];  // [tiles][64]
-  if (a.alloc_rel != nullptr && a.alloc_rel[a.row_stride] != 0u) {  // wave-uniform
-    alloc_masked_compact(a, pod, lane, wave, n_waves, tiles, feas);
+  if (a.alloc_rel != nullptr && a.alloc_rel[a.row_stride] != 0u && a.row_stride % kNplCompact == 0) {  // wave-uniform
+    alloc_masked_compact(a, pod, lane, wave, n_waves, feas);
     return;
   }
   int64_t lo = INT64_MAX, hi = -INT64_MAX;
@@ -183,6 +200,94 @@ __global__ __launch_bounds__(64 * kMaxRowWaves) void k_alloc_masked(ProfileArgs 
       }
     }
     *reinterpret_cast<uint32_t*>(a.out_alloc + pod * a.row_stride + n0) = w;
+  }
+}
+
+// The common case of the argmax below — non-negative weights whose weighted sum fits 31 bits — in 32-bit arithmetic, the
+// tables in play compacted by the launcher (no per-plugin NULL tests), 16 nodes per lane and table (one dwordx4 each).  The
+// general kernel multiplied int64 weights per cell and plugin and read one dword per lane: config #2's two tables took 1.12 ms
+// (1.8 TB/s), more than the sweep that wrote them.
+struct BestFastArgs {
+  int32_t n_tab;
+  const uint8_t* tab[SPX_NUM_PLUGINS];
+  int32_t w[SPX_NUM_PLUGINS];
+};
+constexpr int kNplBest = 16;
+
+__global__ __launch_bounds__(64 * kMaxRowWaves) void k_best_fast(ProfileArgs a, BestFastArgs f) {
+  SPX_RESOLVE_ROWS(a);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const int64_t pod = a.row_begin + blockIdx.x;
+  if (pod >= a.row_end) return;
+  int best = -1, best_n = -1, ties = 0, feas = 0;
+  const bool pod_ok = !a.prefilter || a.prefilter[pod] == 0;
+  const int64_t tiles = pod_ok ? (a.n_nodes + 64 * kNplBest - 1) / (64 * kNplBest) : 0;
+  const int64_t row = pod * a.row_stride;
+#pragma unroll 2
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t n0 = (t * 64 + lane) * kNplBest;
+    if (n0 >= a.n_nodes) continue;  // rows are padded to a multiple of 16 bytes: a lane's 16 bytes are inside the row
+    uint4 bad = uint4{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (a.status[k]) {
+        const uint4 v = *reinterpret_cast<const uint4*>(a.status[k] + row + n0);
+        bad.x |= v.x, bad.y |= v.y, bad.z |= v.z, bad.w |= v.w;
+      }
+    int tot[kNplBest];
+#pragma unroll
+    for (int j = 0; j < kNplBest; ++j) tot[j] = 0;
+    for (int k = 0; k < f.n_tab; ++k) {
+      const uint4 v = *reinterpret_cast<const uint4*>(f.tab[k] + row + n0);
+      const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+      const int w = f.w[k];
+#pragma unroll
+      for (int j = 0; j < kNplBest; ++j) tot[j] += w * static_cast<int>((words[j >> 2] >> (8 * (j & 3))) & 0xffu);
+    }
+    const uint32_t badw[4] = {bad.x, bad.y, bad.z, bad.w};
+#pragma unroll
+    for (int j = 0; j < kNplBest; ++j) {
+      const bool ok = n0 + j < a.n_nodes && ((badw[j >> 2] >> (8 * (j & 3))) & 0xffu) == 0;
+      const int total = ok ? tot[j] : -1;
+      feas += ok ? 1 : 0;
+      // a lane walks its nodes in increasing order: `>` keeps the lowest index among equals
+      ties = total > best ? 1 : ties + ((total == best && ok) ? 1 : 0);
+      best_n = total > best ? static_cast<int>(n0) + j : best_n;
+      best = total > best ? total : best;
+    }
+  }
+  // (best, lowest node, ties, feasible) over the wave; best_n < 0 marks "none"
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const int ob = __shfl_xor(best, m, 64), on = __shfl_xor(best_n, m, 64), ot = __shfl_xor(ties, m, 64);
+    feas += __shfl_xor(feas, m, 64);
+    if (on >= 0 && (best_n < 0 || ob > best || (ob == best && on < best_n))) {
+      ties = (best_n >= 0 && ob == best) ? ties + ot : ot;
+      best = ob;
+      best_n = on;
+    } else if (on >= 0 && ob == best) {
+      ties += ot;
+    }
+  }
+  if (n_waves > 1) {
+    __shared__ int s_best[kMaxRowWaves], s_n[kMaxRowWaves], s_t[kMaxRowWaves], s_f[kMaxRowWaves];
+    if (lane == 0) s_best[wave] = best, s_n[wave] = best_n, s_t[wave] = ties, s_f[wave] = feas;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    best = -1, best_n = -1, ties = 0, feas = 0;
+    for (int w = 0; w < n_waves; ++w) {
+      const int ob = s_best[w], on = s_n[w], ot = s_t[w];
+      feas += s_f[w];
+      if (on < 0) continue;
+      if (best_n < 0 || ob > best) best = ob, best_n = on, ties = ot;
+      else if (ob == best) ties += ot, best_n = on < best_n ? on : best_n;
+    }
+  }
+  if (lane == 0) {
+    a.best_node[pod] = best_n;
+    a.best_score[pod] = best_n >= 0 ? best : 0;
+    a.best_ties[pod] = best_n >= 0 ? ties : 0;
+    a.best_feasible[pod] = feas;
   }
 }
 
@@ -273,6 +378,20 @@ void launch_alloc_masked(const ProfileArgs& a, hipStream_t s) {
 void launch_best(const ProfileArgs& a, hipStream_t s) {
   if (a.row_end <= a.row_begin) return;
   const unsigned rows = static_cast<unsigned>(a.row_end - a.row_begin);
+  BestFastArgs f{};
+  int64_t bound = 0;
+  bool fast = a.row_stride % 16 == 0;
+  for (int k = 0; k < SPX_NUM_PLUGINS; ++k)
+    if (a.score[k]) {
+      fast &= a.weight[k] >= 0 && a.weight[k] < (int64_t{1} << 23);
+      bound += a.weight[k] * 255;
+      f.tab[f.n_tab] = a.score[k];
+      f.w[f.n_tab++] = static_cast<int32_t>(a.weight[k]);
+    }
+  if (fast && bound < (int64_t{1} << 31)) {
+    hipLaunchKernelGGL(k_best_fast, dim3(rows), dim3(rows == 1 ? 64 * kMaxRowWaves : 64), 0, s, a, f);
+    return;
+  }
   hipLaunchKernelGGL(k_best, dim3(rows), dim3(rows == 1 ? 64 * kMaxRowWaves : 64), 0, s, a);
 }
 
