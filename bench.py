@@ -83,7 +83,7 @@ PID = {"alloc": 0, "tlp": 1, "lvrb": 2, "nrt": 3, "net": 4, "cap": 5, "lroc": 7,
 
 # kernel sources per plugin key of WORKLOADS (csrc/); spx_internal.h (argument structs, launch constants) counts for all
 KERNEL_FILES = {
-    "alloc": ("kernels_trimaran.hip", "kernels_profile.hip"), "tlp": ("kernels_trimaran.hip",), "lvrb": ("kernels_trimaran.hip",),
+    "alloc": ("kernels_trimaran.hip",), "tlp": ("kernels_trimaran.hip",), "lvrb": ("kernels_trimaran.hip",),
     "lroc": ("kernels_lroc.hip", "lroc_math.h"), "peaks": ("kernels_peaks.hip",),
     "nrt": ("kernels_nrt_fast.hip", "kernels_nrt.hip"), "net": ("kernels_network.hip", "kernels_sort.hip"),
     "cap": ("kernels_capacity.hip", "kernels_profile.hip"),
