@@ -81,30 +81,35 @@ WORKLOADS = {
 PID = {"alloc": 0, "tlp": 1, "lvrb": 2, "nrt": 3, "net": 4, "cap": 5, "lroc": 7, "peaks": 8}
 
 
-# kernel sources per plugin key of WORKLOADS (csrc/); spx_internal.h (argument structs, launch constants) counts for all
+# kernel translation units per plugin key of WORKLOADS (csrc/)
 KERNEL_FILES = {
     "alloc": ("kernels_trimaran.hip",), "tlp": ("kernels_trimaran.hip",), "lvrb": ("kernels_trimaran.hip",),
-    "lroc": ("kernels_lroc.hip", "lroc_math.h"), "peaks": ("kernels_peaks.hip",),
-    "nrt": ("kernels_nrt_fast.hip", "kernels_nrt.hip"), "net": ("kernels_network.hip", "kernels_sort.hip"),
+    "lroc": ("kernels_lroc.hip",), "peaks": ("kernels_peaks.hip",),
+    "nrt": ("kernels_nrt_fast.hip", "kernels_nrt.hip"), "net": ("kernels_network.hip",),
     "cap": ("kernels_capacity.hip", "kernels_profile.hip"),
 }
 
 
 def kernel_source_hash(plugins=None) -> str:
-    """identifies the kernel sources a profile was taken with (the GPU box has no .git): profiles/ entries carry it, and
-    bench.py reports their counter figures only while it still matches.  Covers the files the workload's kernels are
-    compiled from (KERNEL_FILES + spx_internal.h) — not the host-side engine — so that work on one plugin's kernel does not
-    orphan the other workloads' profiles; plugins=None hashes every kernel source."""
+    """identifies the kernels a profile was taken with (the GPU box has no .git): profiles/ entries carry it, and bench.py
+    reports their counter figures only while it still matches.  It is a hash of the gfx950 machine code of the translation
+    units the workload's sweep kernels are compiled from (build.device_code_hash over the in-tree objects), so it follows what
+    the kernels ARE: an edit to a shared header or to another plugin's kernel leaves it alone, any change of the generated code
+    moves it.  Falls back to hashing the sources ("src:" prefix, never equal to a stamped code hash) when the objects are absent."""
+    from scheduler_plugins_amd import build as spx_build
     csrc = ROOT / "scheduler-plugins_amd" / "csrc"
     if plugins is None:
-        names = sorted(f.name for f in csrc.glob("*") if f.suffix in (".hip", ".h") and f.name != "spx_engine.hip" and f.name != "spx_multi.hip")
+        names = sorted(f.name for f in csrc.glob("kernels_*.hip"))
     else:
-        names = sorted({"spx_internal.h"} | {f for p in plugins for f in KERNEL_FILES[p]})
-    h = hashlib.sha256()
-    for name in names:
-        h.update(name.encode())
-        h.update((csrc / name).read_bytes())
-    return h.hexdigest()[:16]
+        names = sorted({f for p in plugins for f in KERNEL_FILES[p]})
+    try:
+        return spx_build.device_code_hash(names)
+    except (OSError, ValueError):
+        h = hashlib.sha256()
+        for name in names + ["spx_internal.h"]:
+            h.update(name.encode())
+            h.update((csrc / name).read_bytes())
+        return "src:" + h.hexdigest()[:12]
 
 
 def build_snapshot(hdr, w, n_pods, seed):

@@ -70,5 +70,43 @@ def build(verbose: bool = False, force: bool = False) -> Path:
     return LIB
 
 
+def device_code_hash(sources, obj_dir: Path = OBJ) -> str:
+    """sha256 over the gfx950 machine code (.text + .rodata of the code object embedded in <source>.o) of the given kernel
+    translation units — what identifies "the kernels a profile was taken with": unlike a hash of the sources it does not move
+    when a shared header gains a field some other translation unit uses.  Raises FileNotFoundError when an object is missing."""
+    import hashlib
+    import struct
+    h = hashlib.sha256()
+    for name in sorted(set(sources)):
+        b = (Path(obj_dir) / (name + ".o")).read_bytes()
+        i = b.find(b"__CLANG_OFFLOAD_BUNDLE__")
+        if i < 0:
+            raise ValueError(f"{name}.o holds no offload bundle")
+        n, = struct.unpack_from("<Q", b, i + 24)
+        p = i + 32
+        found = False
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", b, p)
+            p += 24
+            triple = b[p:p + tl].decode()
+            p += tl
+            if "amdgcn" not in triple:
+                continue
+            co = b[i + off:i + off + size]
+            shoff, = struct.unpack_from("<Q", co, 0x28)
+            shentsize, shnum, shstrndx = struct.unpack_from("<HHH", co, 0x3A)
+            secs = [struct.unpack_from("<IIQQQQIIQQ", co, shoff + j * shentsize) for j in range(shnum)]
+            stroff = secs[shstrndx][4]
+            for sec in secs:
+                sname = co[stroff + sec[0]:co.index(b"\0", stroff + sec[0])].decode()
+                if sname in (".text", ".rodata"):
+                    h.update(name.encode() + sname.encode())
+                    h.update(co[sec[4]:sec[4] + sec[5]])
+            found = True
+        if not found:
+            raise ValueError(f"{name}.o holds no amdgcn code object")
+    return h.hexdigest()[:16]
+
+
 if __name__ == "__main__":
     print(build(verbose=True, force="--force" in sys.argv))
