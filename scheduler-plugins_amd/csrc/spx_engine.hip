@@ -95,7 +95,10 @@ struct spx_engine {
   DevBuf d_nrt_redo;       // BalancedAllocation: list of the cells the float32 Score launch leaves to the float64 form
   uint32_t nrt_redo_cap = 0;
   uint32_t nrt_big_nodes = ~0u, nrt_big_pods = ~0u;  // slots with a capacity / a request (Value() form) of 2^24 or more
-  bool nrt_ln_ok = false;  // LeastNUMANodes tables valid: every zone cost within [0, 255]
+  bool nrt_ln_ok = false;  // LeastNUMANodes tables can be built: every zone cost within [0, 255]
+  bool nrt_ln_built = false;
+  std::vector<int32_t> h_nrt_cost;  // [N][Z][Z] host copy of the zone costs, what build_ln_tab works from
+  std::vector<uint8_t> h_nrt_nz;
   int32_t nrt_cpu_slot = -1;
   DevBuf status[SPX_NUM_PLUGINS];
 
@@ -406,7 +409,7 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   na.exact32_slots = ~(e->nrt_big_nodes | e->nrt_big_pods);
   na.redo_list = static_cast<uint32_t*>(e->d_nrt_redo.p);
   na.redo_cap = e->nrt_redo_cap;
-  na.ln_tab = e->nrt_ln_ok ? static_cast<const uint32_t*>(e->d_nrt_ln.p) : nullptr;
+  na.ln_tab = (e->nrt_ln_ok && e->nrt_ln_built) ? static_cast<const uint32_t*>(e->d_nrt_ln.p) : nullptr;
 }
 
 // quantities the float64 NRT kernel may hold exactly, with room for x100 and the reciprocal trick
@@ -862,14 +865,12 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
         }
     }
     if ((rc = upload(e, e->d_nrt_perm, perm.data(), perm.size() * sizeof(int32_t)))) return rc;
-    // LeastNUMANodes: per node the subsets of list positions at the node's minimum average distance for their size, and
-    // bit-planes of every subset's distance rank within its size (layout: LnLayout, spx_internal.h).  The average distance
-    // is nodesAvgDistance least_numa.go:115-138 — the sum over all ordered pairs, float32(sum) / float32(k*k); for one size
-    // the divisor is shared and sums below 2^14 stay distinct after the division, so ranking the integer sums ranks the
-    // reference's float32 values.  Only subsets of the node's own zones take part in the minimum (:102-113).
+    // LeastNUMANodes' per-node tables are built when that strategy is first evaluated (build_ln_tab): they cost more host time
+    // than everything else in this call and the default strategy never reads them.  Here: the host copy they are built from,
+    // and whether they can be (every zone cost within [0, 255] — findSuitableCombination's 256 sentinel would interfere).
     {
-      constexpr spx::LnLayout L = spx::make_ln_layout();
-      std::vector<uint32_t> tab(static_cast<size_t>(L.rows) * static_cast<size_t>(n), 0u);
+      e->h_nrt_cost.assign(t->zone_cost, t->zone_cost + static_cast<size_t>(n) * Zm * Zm);
+      e->h_nrt_nz.assign(t->n_zones, t->n_zones + static_cast<size_t>(n));
       std::atomic<bool> ln_ok{true};
       spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
         for (int64_t i = row0; i < row1; ++i) {
@@ -877,47 +878,12 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
           for (int za = 0; za < nz; ++za)
             for (int zb = 0; zb < nz; ++zb) {
               const int64_t c = t->zone_cost[(i * Zm + za) * Zm + zb];
-              if (c < 0 || c > 255) ln_ok = false;  // findSuitableCombination's 256 sentinel would come into play
+              if (c < 0 || c > 255) ln_ok = false;
             }
-          for (int k = 1; k <= 8; ++k) {
-            int sums[70], order[70], cnt = 0;
-            bool exists[70];
-            for (int d = 0; d < L.nd[k]; ++d)
-              for (int q = 0; q < L.cnt[L.first[k] + d]; ++q) {
-                const unsigned m = L.subset[L.first[k] + d][q];
-                int accu = 0;
-                for (int za = 0; za < Zm; ++za)
-                  if (m >> za & 1u)
-                    for (int zb = 0; zb < Zm; ++zb)
-                      if (m >> zb & 1u) accu += t->zone_cost[(i * Zm + za) * Zm + zb];
-                exists[cnt] = (m >> nz) == 0;
-                sums[cnt] = accu;
-                order[cnt] = cnt;
-                ++cnt;
-              }
-            std::sort(order, order + cnt, [&](int x, int y) { return sums[x] < sums[y]; });
-            int rank_of[70], level = -1, last = 0;
-            for (int j = 0; j < cnt; ++j) rank_of[j] = (1 << L.bits[k]) - 1;  // subsets past the node's zones: never candidates
-            for (int j = 0; j < cnt; ++j) {
-              const int sidx = order[j];
-              if (!exists[sidx]) continue;
-              if (level < 0 || sums[sidx] != last) ++level, last = sums[sidx];
-              rank_of[sidx] = level;
-            }
-            for (int pos = 0; pos < cnt; ++pos) {
-              const size_t d = static_cast<size_t>(L.first[k] + pos / 32);
-              const uint32_t bit = 1u << (pos % 32);
-              if (exists[pos] && rank_of[pos] == 0) tab[d * static_cast<size_t>(n) + static_cast<size_t>(i)] |= bit;
-              for (int b = 0; b < L.bits[k]; ++b)
-                if ((rank_of[pos] >> b) & 1)
-                  tab[static_cast<size_t>(spx::kLnDwords + L.pbase[k] + b * L.nd[k] + pos / 32) * static_cast<size_t>(n) + static_cast<size_t>(i)] |= bit;
-            }
-          }
         }
-      }, 512);
+      }, 4096);
       e->nrt_ln_ok = ln_ok.load();
-      if ((rc = upload(e, e->d_nrt_ln, tab.data(), tab.size() * sizeof(uint32_t)))) return rc;
-      SPX_HIP(e, hipStreamSynchronize(e->stream));
+      e->nrt_ln_built = false;
     }
     if ((rc = upload(e, e->d_nrt_fav, av.data(), av.size() * sizeof(double)))) return rc;
     if ((rc = upload(e, e->d_nrt_frc, rcp.data(), rcp.size() * sizeof(double)))) return rc;
@@ -928,6 +894,64 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
     SPX_HIP(e, hipStreamSynchronize(e->stream));
   }
   e->nrt_nodes = true;
+  return SPX_OK;
+}
+
+static int build_ln_tab(spx_engine* e) {
+  if (e->nrt_ln_built || !e->nrt_ln_ok) return SPX_OK;
+  constexpr int64_t Zm = SPX_NRT_MAX_ZONES;
+  const int64_t n = e->n_nodes;
+  const int32_t* cost = e->h_nrt_cost.data();
+  int rc;
+  // LeastNUMANodes: per node the subsets of list positions at the node's minimum average distance for their size, and
+  // bit-planes of every subset's distance rank within its size (layout: LnLayout, spx_internal.h).  The average distance
+  // is nodesAvgDistance least_numa.go:115-138 — the sum over all ordered pairs, float32(sum) / float32(k*k); for one size
+  // the divisor is shared and sums below 2^14 stay distinct after the division, so ranking the integer sums ranks the
+  // reference's float32 values.  Only subsets of the node's own zones take part in the minimum (:102-113).
+  constexpr spx::LnLayout L = spx::make_ln_layout();
+  std::vector<uint32_t> tab(static_cast<size_t>(L.rows) * static_cast<size_t>(n), 0u);
+  spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
+    for (int64_t i = row0; i < row1; ++i) {
+      const int nz = std::min<int>(e->h_nrt_nz[static_cast<size_t>(i)], static_cast<int>(Zm));
+      for (int k = 1; k <= 8; ++k) {
+        int sums[70], order[70], cnt = 0;
+        bool exists[70];
+        for (int d = 0; d < L.nd[k]; ++d)
+          for (int q = 0; q < L.cnt[L.first[k] + d]; ++q) {
+            const unsigned m = L.subset[L.first[k] + d][q];
+            int accu = 0;
+            for (int za = 0; za < Zm; ++za)
+              if (m >> za & 1u)
+                for (int zb = 0; zb < Zm; ++zb)
+                  if (m >> zb & 1u) accu += cost[(i * Zm + za) * Zm + zb];
+            exists[cnt] = (m >> nz) == 0;
+            sums[cnt] = accu;
+            order[cnt] = cnt;
+            ++cnt;
+          }
+        std::sort(order, order + cnt, [&](int x, int y) { return sums[x] < sums[y]; });
+        int rank_of[70], level = -1, last = 0;
+        for (int j = 0; j < cnt; ++j) rank_of[j] = (1 << L.bits[k]) - 1;  // subsets past the node's zones: never candidates
+        for (int j = 0; j < cnt; ++j) {
+          const int sidx = order[j];
+          if (!exists[sidx]) continue;
+          if (level < 0 || sums[sidx] != last) ++level, last = sums[sidx];
+          rank_of[sidx] = level;
+        }
+        for (int pos = 0; pos < cnt; ++pos) {
+          const size_t d = static_cast<size_t>(L.first[k] + pos / 32);
+          const uint32_t bit = 1u << (pos % 32);
+          if (exists[pos] && rank_of[pos] == 0) tab[d * static_cast<size_t>(n) + static_cast<size_t>(i)] |= bit;
+          for (int b = 0; b < L.bits[k]; ++b)
+            if ((rank_of[pos] >> b) & 1)
+              tab[static_cast<size_t>(spx::kLnDwords + L.pbase[k] + b * L.nd[k] + pos / 32) * static_cast<size_t>(n) + static_cast<size_t>(i)] |= bit;
+        }
+      }
+    }
+  }, 512);
+  if ((rc = upload(e, e->d_nrt_ln, tab.data(), tab.size() * sizeof(uint32_t)))) return rc;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  e->nrt_ln_built = true;
   return SPX_OK;
 }
 
@@ -1344,6 +1368,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (N) {
     if (e->score_stride[SPX_PLUGIN_NRT] != e->row_stride)
       return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
+    if (e->nrt_params.strategy == SPX_NRT_LEAST_NUMA_NODES && (rc = build_ln_tab(e))) return rc;
     if (e->nrt_params.strategy == SPX_NRT_BALANCED_ALLOCATION) {
       // room for 1/32 of the cells (config #3 marks 0.7 %); what does not fit is recomputed where it is found.  Inside the
       // sequential commit loop (row_indirect: one row per launch, graph capture) the list allocated for the first pod is kept.
@@ -1781,6 +1806,7 @@ int spx_fetch_raw(spx_engine* e, int plugin, int which, int64_t pod_row, int64_t
     if (!(e->nrt_slots && e->nrt_nodes && e->nrt_pods)) return fail(e, SPX_ERR_STATE, "NRT slot/node/pod tables not uploaded");
     if (pod_row < 0 || pod_row >= e->n_pods) return fail(e, SPX_ERR_ARG, "pod_row out of range");
     if ((rc = ensure(e, e->d_raw_row, bytes))) return rc;
+    if (e->nrt_params.strategy == SPX_NRT_LEAST_NUMA_NODES && (rc = build_ln_tab(e))) return rc;
     spx::NrtArgs na{};
     fill_nrt(e, na);
     na.row_begin = pod_row;
