@@ -11,7 +11,7 @@
 #include <climits>
 #include <cstdint>
 #include <cstddef>
-#include <map>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -57,23 +57,32 @@ extern "C" int spx_flatten_net_topo(const spx_nettopo_objects* nt, int32_t* regi
   return SPX_OK;
 }
 
+namespace {
+inline uint64_t pack_key(int32_t group, int32_t selector) {
+  return (static_cast<uint64_t>(static_cast<uint32_t>(group)) << 32) | static_cast<uint32_t>(selector);
+}
+}  // namespace
+
 extern "C" int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int32_t* n_keys_out,
                                     int64_t* n_pairs_out, int32_t* pod_key, int32_t* topo_order, uint8_t* key_score_equally,
                                     int32_t* pair_ptr, int32_t* pair_node, int64_t* pair_max_cost) {
   if (!pods || !ag || !n_keys_out || !n_pairs_out) return SPX_ERR_ARG;
   const bool fill = pod_key && topo_order && key_score_equally && pair_ptr && pair_node && pair_max_cost;
-  std::map<std::pair<int32_t, int32_t>, int32_t> keys;
+  // (AppGroup, workload selector) -> key id, in order of first appearance; hashed on the packed pair (an ordered map cost a
+  // cache-missing tree walk per pod: 40 ms per call at 62.5k pods)
+  std::unordered_map<uint64_t, int32_t> keys;
+  keys.reserve(static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 1) / 4 + 16);
   std::vector<std::pair<int32_t, int32_t>> order;
   // key 0: "Pod does not belong to an AppGroup" -> scoreEqually (networkoverhead.go:187-190)
-  keys[{-1, -1}] = 0;
+  keys[pack_key(-1, -1)] = 0;
   order.push_back({-1, -1});
   for (int64_t p = 0; p < pods->n_pods; ++p) {
     int32_t g = pods->appgroup[p];
     std::pair<int32_t, int32_t> k{-1, -1};
     if (g >= 0 && g < ag->n_groups) k = {g, pods->selector[p]};
-    auto it = keys.find(k);
+    auto it = keys.find(pack_key(k.first, k.second));
     if (it == keys.end()) {
-      it = keys.emplace(k, static_cast<int32_t>(order.size())).first;
+      it = keys.emplace(pack_key(k.first, k.second), static_cast<int32_t>(order.size())).first;
       order.push_back(k);
     }
     if (fill) {
@@ -131,37 +140,47 @@ extern "C" int spx_flatten_net_commit(const spx_pod_objects* pods, const spx_app
                                       int32_t* eff_key, int64_t* eff_cost) {
   if (!pods || !ag || !n_entries_out) return SPX_ERR_ARG;
   const bool fill = eff_ptr && eff_key && eff_cost;
-  std::map<std::pair<int32_t, int32_t>, int32_t> keys;
-  keys[{-1, -1}] = 0;
+  std::unordered_map<uint64_t, int32_t> keys;
+  keys.reserve(static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 1) / 4 + 16);
+  keys[pack_key(-1, -1)] = 0;
   std::vector<std::vector<std::pair<int32_t, int32_t>>> by_group(static_cast<size_t>(ag->n_groups > 0 ? ag->n_groups : 0));  // (selector, key)
   int32_t next = 1;
   for (int64_t p = 0; p < pods->n_pods; ++p) {
     const int32_t g = pods->appgroup[p];
     if (g < 0 || g >= ag->n_groups) continue;
     const std::pair<int32_t, int32_t> k{g, pods->selector[p]};
-    if (keys.emplace(k, next).second) by_group[static_cast<size_t>(g)].emplace_back(k.second, next++);
+    if (keys.emplace(pack_key(k.first, k.second), next).second) by_group[static_cast<size_t>(g)].emplace_back(k.second, next++);
   }
+  // The effects of binding a pod depend only on its (AppGroup, selector), i.e. on its key: computed once per key, copied per
+  // pod (at 62.5k pods of 6.9k keys the per-pod evaluation was 21 ms per call, and the function runs twice: sizes, then fill).
+  std::vector<std::vector<std::pair<int32_t, int64_t>>> tmpl(static_cast<size_t>(next));  // per key: (affected key, cost or -1)
+  std::vector<uint8_t> have(static_cast<size_t>(next), 0);
   int64_t n = 0;
   if (fill) eff_ptr[0] = 0;
   for (int64_t p = 0; p < pods->n_pods; ++p) {
     const int32_t g = pods->appgroup[p], sel = pods->selector[p];
-    if (g >= 0 && g < ag->n_groups)
-      for (const auto& kk : by_group[static_cast<size_t>(g)]) {
-        bool any_dep = false;
-        for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w)
-          if (ag->wl_selector[w] == kk.first && ag->dep_ptr[w + 1] > ag->dep_ptr[w]) any_dep = true;
-        if (!any_dep) continue;
-        if (fill) eff_key[n] = kk.second, eff_cost[n] = -1;
-        ++n;
-        for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w) {
-          if (ag->wl_selector[w] != kk.first) continue;
-          for (int32_t d = ag->dep_ptr[w]; d < ag->dep_ptr[w + 1]; ++d) {
-            if (ag->dep_selector[d] != sel) continue;
-            if (fill) eff_key[n] = kk.second, eff_cost[n] = ag->dep_max_cost[d];
-            ++n;
+    if (g >= 0 && g < ag->n_groups) {
+      const size_t key = static_cast<size_t>(keys.find(pack_key(g, sel))->second);
+      auto& t = tmpl[key];
+      if (!have[key]) {
+        have[key] = 1;
+        for (const auto& kk : by_group[static_cast<size_t>(g)]) {
+          bool any_dep = false;
+          for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w)
+            if (ag->wl_selector[w] == kk.first && ag->dep_ptr[w + 1] > ag->dep_ptr[w]) any_dep = true;
+          if (!any_dep) continue;
+          t.emplace_back(kk.second, int64_t{-1});
+          for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w) {
+            if (ag->wl_selector[w] != kk.first) continue;
+            for (int32_t d = ag->dep_ptr[w]; d < ag->dep_ptr[w + 1]; ++d)
+              if (ag->dep_selector[d] == sel) t.emplace_back(kk.second, ag->dep_max_cost[d]);
           }
         }
       }
+      if (fill)
+        for (size_t j = 0; j < t.size(); ++j) eff_key[n + static_cast<int64_t>(j)] = t[j].first, eff_cost[n + static_cast<int64_t>(j)] = t[j].second;
+      n += static_cast<int64_t>(t.size());
+    }
     if (fill) {
       if (n > INT32_MAX) return SPX_ERR_ARG;
       eff_ptr[p + 1] = static_cast<int32_t>(n);
