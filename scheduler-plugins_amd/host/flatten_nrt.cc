@@ -9,6 +9,7 @@
 //   pod QoS class, IncludeNonNative, GetPodEffectiveRequest          filter.go:183-186, pkg/util/resource.go:51-85
 #include <algorithm>
 #include <cstdint>
+#include <climits>
 #include <cstring>
 #include <vector>
 
@@ -202,14 +203,27 @@ extern "C" int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nr
     // ---- minAvgDistanceInCombinations for every subset size (float32 exactly as the reference)
     float best[Z];
     for (int k = 0; k < Z; ++k) best[k] = 255.0f;
-    for (unsigned m = 1; m < (1u << nz); ++m) {  // every subset once, filed under its size
+    // every subset once, filed under its size; the sum over all ordered pairs of a subset grows from the subset without its
+    // lowest member z: + cost[z][z] + sum over the others j of (cost[z][j] + cost[j][z])  (same integer as the double loop)
+    int pair_sum[1 << Z], least[Z];
+    pair_sum[0] = 0;
+    for (int k = 0; k < Z; ++k) least[k] = INT32_MAX;
+    const int32_t* c = zone_cost + i * Z * Z;
+    for (unsigned m = 1; m < (1u << nz); ++m) {
+      const int z = __builtin_ctz(m);
+      const unsigned rest = m & (m - 1);
+      int accu = pair_sum[rest] + c[z * Z + z];
+      for (unsigned r = rest; r; r &= r - 1) {
+        const int j = __builtin_ctz(r);
+        accu += c[z * Z + j] + c[j * Z + z];
+      }
+      pair_sum[m] = accu;
       const int k = __builtin_popcount(m);
-      int accu = 0;
-      for (int a = 0; a < nz; ++a)
-        if (m >> a & 1)
-          for (int b = 0; b < nz; ++b)
-            if (m >> b & 1) accu += zone_cost[(i * Z + a) * Z + b];
-      const float d = static_cast<float>(accu) / static_cast<float>(k * k);
+      if (accu < least[k - 1]) least[k - 1] = accu;
+    }
+    // float32(sum) / float32(k*k) is monotone in the sum: the minimum distance of a size is the distance of its smallest sum
+    for (int k = 1; k <= nz; ++k) {
+      const float d = static_cast<float>(least[k - 1]) / static_cast<float>(k * k);
       if (d < best[k - 1]) best[k - 1] = d;
     }
     for (int k = 0; k < Z; ++k) min_avg_dist[i * Z + k] = best[k];
