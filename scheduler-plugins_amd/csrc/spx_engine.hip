@@ -897,22 +897,21 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
   return SPX_OK;
 }
 
-static int build_ln_tab(spx_engine* e) {
-  if (e->nrt_ln_built || !e->nrt_ln_ok) return SPX_OK;
+// LeastNUMANodes: per node the subsets of list positions at the node's minimum average distance for their size, and
+// bit-planes of every subset's distance rank within its size (layout: LnLayout, spx_internal.h).  The average distance
+// is nodesAvgDistance least_numa.go:115-138 — the sum over all ordered pairs, float32(sum) / float32(k*k); for one size
+// the divisor is shared and sums below 2^14 stay distinct after the division, so ranking the integer sums ranks the
+// reference's float32 values.  Only subsets of the node's own zones take part in the minimum (:102-113).
+// Host-only; exported (not part of spx.h) so that tests/test_ln_tables.py can replay the kernel's selection against the
+// reference's walk without a GPU.  zone_cost [n][Z][Z], n_zones [n], out [LnLayout.rows][n] zero-initialised by the callee.
+int spx_internal_ln_tables(const int32_t* cost, const uint8_t* n_zones, int64_t n, uint32_t* tab) {
+  if (!cost || !n_zones || !tab || n < 0) return SPX_ERR_ARG;
   constexpr int64_t Zm = SPX_NRT_MAX_ZONES;
-  const int64_t n = e->n_nodes;
-  const int32_t* cost = e->h_nrt_cost.data();
-  int rc;
-  // LeastNUMANodes: per node the subsets of list positions at the node's minimum average distance for their size, and
-  // bit-planes of every subset's distance rank within its size (layout: LnLayout, spx_internal.h).  The average distance
-  // is nodesAvgDistance least_numa.go:115-138 — the sum over all ordered pairs, float32(sum) / float32(k*k); for one size
-  // the divisor is shared and sums below 2^14 stay distinct after the division, so ranking the integer sums ranks the
-  // reference's float32 values.  Only subsets of the node's own zones take part in the minimum (:102-113).
   constexpr spx::LnLayout L = spx::make_ln_layout();
-  std::vector<uint32_t> tab(static_cast<size_t>(L.rows) * static_cast<size_t>(n), 0u);
+  std::fill(tab, tab + static_cast<size_t>(L.rows) * static_cast<size_t>(n), 0u);
   spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
     for (int64_t i = row0; i < row1; ++i) {
-      const int nz = std::min<int>(e->h_nrt_nz[static_cast<size_t>(i)], static_cast<int>(Zm));
+      const int nz = std::min<int>(n_zones[i], static_cast<int>(Zm));
       for (int k = 1; k <= 8; ++k) {
         int sums[70], order[70], cnt = 0;
         bool exists[70];
@@ -949,6 +948,29 @@ static int build_ln_tab(spx_engine* e) {
       }
     }
   }, 512);
+  return SPX_OK;
+}
+
+// the bit layout itself, for the same tests: subset[12][32] zone masks, then cnt[12], first[9], nd[9], bits[9], pbase[9], rows
+int spx_internal_ln_layout(uint8_t* subset, uint8_t* cnt, uint8_t* first, uint8_t* nd, uint8_t* bits, uint8_t* pbase, int32_t* rows) {
+  if (!subset || !cnt || !first || !nd || !bits || !pbase || !rows) return SPX_ERR_ARG;
+  constexpr spx::LnLayout L = spx::make_ln_layout();
+  std::memcpy(subset, L.subset, sizeof L.subset);
+  std::memcpy(cnt, L.cnt, sizeof L.cnt);
+  std::memcpy(first, L.first, sizeof L.first);
+  std::memcpy(nd, L.nd, sizeof L.nd);
+  std::memcpy(bits, L.bits, sizeof L.bits);
+  std::memcpy(pbase, L.pbase, sizeof L.pbase);
+  *rows = L.rows;
+  return SPX_OK;
+}
+
+static int build_ln_tab(spx_engine* e) {
+  if (e->nrt_ln_built || !e->nrt_ln_ok) return SPX_OK;
+  constexpr spx::LnLayout L = spx::make_ln_layout();
+  std::vector<uint32_t> tab(static_cast<size_t>(L.rows) * static_cast<size_t>(e->n_nodes));
+  int rc = spx_internal_ln_tables(e->h_nrt_cost.data(), e->h_nrt_nz.data(), e->n_nodes, tab.data());
+  if (rc) return fail(e, rc, "LeastNUMANodes tables");
   if ((rc = upload(e, e->d_nrt_ln, tab.data(), tab.size() * sizeof(uint32_t)))) return rc;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   e->nrt_ln_built = true;
