@@ -134,3 +134,23 @@ MIN_DISTANCE = [  # (line, with costs?, subset size, expected)
     (861, True, 3, 14.888889),
     (878, False, 2, 255.0),
 ]
+
+
+# TestIncludeNonNative  pkg/noderesourcetopology/resourcerequests/exclusive_test.go:36-46 over coreTestCases (:174-437):
+# (line, name, app containers, init containers, sidecar init containers, expectedNonNative); a container = its requests
+# (limits equal the requests in every case).  expectedExclusive (AreExclusiveForPod) belongs to the cache's foreign-pod
+# tracking, which is outside the scored path.
+_GU = {"cpu": "4", "memory": "2Gi"}
+_FPGA = {"veryfast.io/fpga": "1"}
+INCLUDE_NON_NATIVE = [
+    (178, "no containers", [], [], [], False),
+    (189, "single-container-gu-no-devs", [_GU], [], [], False),
+    (217, "single-initcontainer-gu-no-devs", [], [_GU], [], False),
+    (245, "single-sidecar-initcontainer-gu-no-devs", [], [], [_GU], False),
+    (274, "single-container-devs-only", [_FPGA], [], [], True),
+    (300, "single-initcontainer-devs-only", [], [_FPGA], [], True),
+    (326, "single-sidecar-initcontainer-devs-only", [], [], [_FPGA], True),
+    (353, "single-container-gu-core-and-devs", [{"cpu": "8", "memory": "16Gi", "veryfast.io/fpga": "1"}], [], [], True),
+    (383, "single-container-nongu-cpus-and-devs", [{"cpu": "8", "veryfast.io/fpga": "1"}], [], [], True),
+    (411, "single-container-nongu-cpus-only", [{"cpu": "8"}], [], [], False),
+]

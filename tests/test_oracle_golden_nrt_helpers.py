@@ -66,6 +66,38 @@ def test_get_pod_effective_request(hdr, oracle, case):
     assert prod == got
 
 
+@pytest.mark.parametrize("case", G.INCLUDE_NON_NATIVE, ids=lambda c: f"L{c[0]}")
+def test_include_non_native(hdr, oracle, case):
+    """resourcerequests.IncludeNonNative (exclusive.go:28-44): a BestEffort pod is only filtered by TopologyMatch when some
+    container — init and sidecar ones included — requests a non-native resource (filter.go:183-186)"""
+    _, _, app, init, sidecar, want = case
+    res = O.Resources()
+    ctr = lambda r, sc=False: O.container(dict(r), dict(r), sidecar=sc)
+    pod = O.pod([ctr(r) for r in app], [ctr(r) for r in init] + [ctr(r, True) for r in sidecar])
+    pods = O.build_pod_objects(hdr, res, [pod])
+    assert bool(oracle.lib().orc_include_non_native(pods.ref(), res.table(hdr).ref(), 0)) == want
+    # product: the per-pod flag column the NRT sweep reads
+    import scheduler_plugins_amd as spx
+    from scheduler_plugins_amd._abi import Table
+    lib = spx.lib()
+    rc = res.table(hdr)
+    M, CM = hdr.consts["SPX_NRT_MAX_RES"], hdr.consts["SPX_NRT_MAX_CTRS"]
+    slot_res, slot_flags, slot_w = np.zeros(M, np.int32), np.zeros(M, np.uint8), np.zeros(M, np.int64)
+    n_res = C.c_int32()
+    U8P = C.POINTER(C.c_uint8)
+    assert lib.spx_flatten_nrt_slots(pods.ref(), O.build_nrt_objects(hdr, res, [None]).ref(), rc.ref(), O.nrt_params(hdr, res).ref(), C.byref(n_res),
+                                     slot_res.ctypes.data_as(I32P), slot_flags.ctypes.data_as(U8P), slot_w.ctypes.data_as(I64P)) == 0
+    R = n_res.value
+    slots = Table(hdr, "spx_nrt_slots", n_res=R, slot_res=slot_res, slot_flags=slot_flags, slot_weight=slot_w)
+    u8 = lambda n: np.zeros(n, np.uint8)
+    qos, nn, nctr, kind, cpres, ppres = u8(1), u8(1), u8(1), u8(CM), u8(CM), u8(1)
+    creq, preq = np.zeros(CM * max(R, 1), np.int64), np.zeros(max(R, 1), np.int64)
+    assert lib.spx_flatten_nrt_pods(pods.ref(), rc.ref(), slots.ref(), qos.ctypes.data_as(U8P), nn.ctypes.data_as(U8P), nctr.ctypes.data_as(U8P),
+                                    kind.ctypes.data_as(U8P), cpres.ctypes.data_as(U8P), creq.ctypes.data_as(I64P), ppres.ctypes.data_as(U8P),
+                                    preq.ctypes.data_as(I64P)) == 0
+    assert bool(nn[0]) == want
+
+
 @pytest.mark.parametrize("name", sorted(G.RESOURCE_CLASSES))
 def test_resource_classes(hdr, oracle, name):
     host_level, affine = G.RESOURCE_CLASSES[name]
