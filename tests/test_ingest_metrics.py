@@ -83,3 +83,21 @@ def test_decoded_metrics_reproduce_the_reference_tlp_scores(hdr, oracle, case):
         snap = oracle.Snapshot(nodes, pods, rc=res.table(hdr), metrics=ing.metrics_objects(), tlp_params=tlp_params(hdr, **GT.TLP_PARAMS))
         raw, _ = snap.score_rows(TLP)
         assert raw[0].tolist() == case["expected"]
+
+
+def test_collector_fixtures_round_trip(hdr):
+    """pkg/trimaran/collector_test.go: TestGetNodeMetrics (:149-170, fixture watcherResponse :38-68) — what the server marshalled is
+    what GetNodeMetrics returns for the node — and TestGetNodeMetricsNilForNode (:172-194, noWatcherResponseForNode :70-75): an
+    empty NodeMetricsMap is a non-nil response with no metrics for the node."""
+    response = {"node-1": [("CPU", "AVG", 80), ("CPU", "STD", 16), ("Memory", "AVG", 25), ("Memory", "STD", 6.25)]}
+    K = hdr.consts
+    with NrtIngest(["node-1", "node-2"]) as ing:
+        assert ing.feed_metrics(marshal(response)) == (1, 0)   # one map entry, none outside the snapshot
+        got = cols(ing.metrics_objects().struct, 2)
+        assert got["nil"] == 0 and got["present"] == [1, 0] and got["ptr"] == [0, 4, 4]
+        assert got["type"] == [K["SPX_MT_CPU"], K["SPX_MT_CPU"], K["SPX_MT_MEMORY"], K["SPX_MT_MEMORY"]]
+        assert got["op"] == [K["SPX_MO_AVG"], K["SPX_MO_STD"], K["SPX_MO_AVG"], K["SPX_MO_STD"]]
+        assert got["value"] == [80.0, 16.0, 25.0, 6.25]
+        assert ing.feed_metrics(marshal({})) == (0, 0)
+        got = cols(ing.metrics_objects().struct, 2)
+        assert got["nil"] == 0 and got["present"] == [0, 0] and got["value"] == []
