@@ -71,6 +71,11 @@ for seed, (N, P) in enumerate([(1, 1), (7, 3), (300, 129), (5000, 800)]):
     kse, pp = np.zeros(max(nk.value, 1), np.uint8), np.zeros(nk.value + 1, np.int32)
     pn, pmx = np.zeros(max(npairs.value, 1), np.int32), np.zeros(max(npairs.value, 1), np.int64)
     assert L.spx_flatten_net_keys(snap["pods"].ref(), snap["appgroups"].ref(), C.byref(nk), C.byref(npairs), pk.ctypes.data_as(i32p), to.ctypes.data_as(i32p), kse.ctypes.data_as(u8p), pp.ctypes.data_as(i32p), pn.ctypes.data_as(i32p), pmx.ctypes.data_as(i64p)) == 0
+    ne = C.c_int64()
+    assert L.spx_flatten_net_commit(snap["pods"].ref(), snap["appgroups"].ref(), C.byref(ne), None, None, None) == 0
+    ep, ek, ec = np.zeros(P + 1, np.int32), np.zeros(max(ne.value, 1), np.int32), np.zeros(max(ne.value, 1), np.int64)
+    assert L.spx_flatten_net_commit(snap["pods"].ref(), snap["appgroups"].ref(), C.byref(ne), ep.ctypes.data_as(i32p), ek.ctypes.data_as(i32p), ec.ctypes.data_as(i64p)) == 0
+    assert ep[-1] == ne.value
     a_, b_ = np.arange(P, dtype=np.int64), np.arange(P, dtype=np.int64)[::-1].copy()
     out = np.zeros(P, np.uint8)
     assert L.spx_toposort_less(snap["pods"].ref(), to.ctypes.data_as(i32p), P, a_.ctypes.data_as(i64p), b_.ctypes.data_as(i64p), out.ctypes.data_as(u8p)) == 0
