@@ -15,7 +15,7 @@ sys.path.insert(0, str(ROOT))
 @pytest.fixture(scope="module")
 def bench_mod():
     import scheduler_plugins_amd as spx
-    spx.lib()  # builds the in-tree objects if they are missing
+    spx.lib()  # the library and its objects come from `python __graft_entry__.py build`; nothing here builds them
     import bench
     return bench
 
