@@ -76,8 +76,13 @@ def test_config3_every_cell(gpu_required, hdr, oracle, strategy):
     with Engine(0) as e:
         e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
         assert e.kernel_path(NRT) == 1
+        e.stats(reset=True)
         e.eval(mask_of(NRT))
         e.sync()
+        # BalancedAllocation scores in float32 and recomputes the cells it cannot decide in float64: those cells exist at this
+        # size (0.7 % of them, measured) and are compared below like every other cell; the other strategies count nothing
+        redone = int(e.stats()[NRT])
+        assert (redone > 0) == (strategy == "BalancedAllocation") and redone < 0.03 * n_nodes * n_pods, redone
         osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
         bad_status = bad_score = 0
         rejected = 0
