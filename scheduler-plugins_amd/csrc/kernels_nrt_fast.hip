@@ -88,49 +88,42 @@ __device__ __forceinline__ T ld_off(const T* base, uint32_t byte_off) {
 // (16 for <= 4 resource slots, else 32) — item 0 the header (2 dwords used), item 1 the pod-level request, items 2..9 the
 // containers in order (init containers first).  A request item: doubles raw[RM] (dwords 0..2RM-1), the slot-set dword
 // (2RM), a pad, then the three doubles only the Score reads: Value() of the cpu request, the sum of the weights of the
-// requested slots and its biased reciprocal.  Items are fetched with scalar loads, the next one before the current one is
-// processed so that the SMEM latency overlaps with the VALU work.  How much of an item a kernel keeps in scalar registers
-// matters: the Filter needs 2RM + 1 dwords of it, and with three items in flight (pod level, current and next container)
-// loading all 16 costs scalar registers and SMEM bandwidth for nothing (measured: config #3 3.2 -> 3.0 ms).
+// requested slots and its biased reciprocal.
+//
+// Round 3: a block copies the records of its 32 pods into LDS once (coalesced 16-byte loads: ONE memory round trip per
+// chunk) and every wave reads them from there with broadcast ds_reads.  Rounds 1-2 fetched them with scalar loads, one
+// pod ahead: 32 MB of records (50k pods) do not stay in the 16 KB scalar cache nor in an XCD's L2, so every pod iteration
+// of every wave waited ~650 ns for its s_loads — a batch of BestEffort pods, which the sweep has nothing to compute for,
+// took 1.0 of the mixed batch's 2.8 ms (tools/r3/exp_qos.py).  The quantities now sit in VGPRs (the same value in every
+// lane, read as VGPR operands); the slot-set dword and the header are made scalar (v_readfirstlane) because they steer
+// wave-uniform branches.
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kItemsPerPod = 2 + kC;
 template <int RM>
 constexpr int item_words() { return RM == 4 ? 16 : 32; }
+template <int RM>
+constexpr int pod_words() { return kItemsPerPod * item_words<RM>(); }
 
+// an item's dwords as fetched: w[0 .. 2RM] always, the Score's tail (2RM+2 .. 2RM+7) when FULL
 template <int RM, bool FULL>
-struct ItemRegs;
-template <>
-struct ItemRegs<4, false> {  // the request quantities and the slot sets
-  u32x8 raw;
-  u32x2 tail;
-};
-template <>
-struct ItemRegs<4, true> {
-  u32x16 w;
-};
-template <bool FULL>
-struct ItemRegs<8, FULL> {
-  u32x16 lo, hi;
+struct ItemRegs {
+  uint32_t w[FULL ? 2 * RM + 8 : 2 * RM + 1];
 };
 
-// `pod_items`: the pod's first item; `slot`: 0 header, 1 pod-level request, 2.. containers.  A small 32-bit slot on a per-pod
-// base keeps the address arithmetic at one scalar shift-add per load (a 64-bit item index cost ~9 scalar instructions each,
-// and the Filter launch was issuing as many scalar as vector instructions).
+// `pod_rec`: the pod's record (in LDS for the sweep, in global memory for the per-cell fix-up); `slot`: 0 header, 1 pod-level
+// request, 2.. containers
 template <int RM, bool FULL>
-__device__ __forceinline__ ItemRegs<RM, FULL> load_item(const uint32_t* pod_items, int slot) {
-  const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(pod_items) + static_cast<uint32_t>(slot) * (item_words<RM>() * 4u));
+__device__ __forceinline__ ItemRegs<RM, FULL> load_item(const uint32_t* pod_rec, int slot) {
+  const u32x4* p = reinterpret_cast<const u32x4*>(pod_rec + slot * item_words<RM>());
   ItemRegs<RM, FULL> r;
-  if constexpr (RM == 4 && !FULL) {
-    r.raw = uload(reinterpret_cast<const u32x8*>(p));
-    r.tail = uload(reinterpret_cast<const u32x2*>(p + 8));
-  } else if constexpr (RM == 4) {
-    r.w = uload(reinterpret_cast<const u32x16*>(p));
-  } else {
-    r.lo = uload(reinterpret_cast<const u32x16*>(p));
-    r.hi = uload(reinterpret_cast<const u32x16*>(p + 16));
+  constexpr int kQuads = (FULL ? 2 * RM + 8 : 2 * RM) / 4;
+#pragma unroll
+  for (int q = 0; q < kQuads; ++q) {
+    const u32x4 v = p[q];
+    r.w[4 * q] = v.x, r.w[4 * q + 1] = v.y, r.w[4 * q + 2] = v.z, r.w[4 * q + 3] = v.w;
   }
+  if constexpr (!FULL) r.w[2 * RM] = pod_rec[slot * item_words<RM>() + 2 * RM];
   return r;
 }
 
@@ -140,24 +133,22 @@ struct Item {
   double cpu_v;    // Quantity.Value() of the cpu request (whole cores, rounded up)
   double wsum;     // sum of the weights of the requested slots
   double wrc;      // its biased reciprocal
+  uint32_t wsum_i; // the same sum as an integer (Least/MostAllocated accumulate integer zone totals)
   uint32_t used;   // requested slots (Score iterates these)
   uint32_t fit;    // non-zero requests compared per zone: available >= quantity
   uint32_t always; // non-zero requests of a non-Guaranteed pod for a NUMA-affine resource: any reporting zone suits
   uint32_t kind;   // SPX_CTR_*
 };
 
-template <int RM, bool FULL>
+// UNIFORM: every lane holds the same item (the sweep): the slot sets are made scalar so that the per-resource tests stay
+// scalar branches.  The per-cell fix-up decodes a different item per lane.
+template <int RM, bool FULL, bool UNIFORM = true>
 __device__ __forceinline__ Item<RM> decode_item(const ItemRegs<RM, FULL>& g) {
   Item<RM> it;
-  auto word = [&](int i) -> uint32_t {
-    if constexpr (RM == 4 && !FULL) return i < 8 ? g.raw[i] : g.tail[i - 8];
-    else if constexpr (RM == 4) return g.w[i];
-    else return i < 16 ? g.lo[i] : g.hi[i - 16];
-  };
-  auto f64 = [&](int i) { return __hiloint2double(static_cast<int>(word(i + 1)), static_cast<int>(word(i))); };
+  auto f64 = [&](int i) { return __hiloint2double(static_cast<int>(g.w[i + 1]), static_cast<int>(g.w[i])); };
 #pragma unroll
   for (int r = 0; r < RM; ++r) it.raw[r] = f64(2 * r);
-  const uint32_t s = word(2 * RM);
+  const uint32_t s = UNIFORM ? static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g.w[2 * RM]))) : g.w[2 * RM];
   it.used = s & 0xffu;
   it.fit = (s >> 8) & 0xffu;
   it.always = (s >> 16) & 0xffu;
@@ -166,8 +157,10 @@ __device__ __forceinline__ Item<RM> decode_item(const ItemRegs<RM, FULL>& g) {
     it.cpu_v = f64(2 * RM + 2);
     it.wsum = f64(2 * RM + 4);
     it.wrc = f64(2 * RM + 6);
+    it.wsum_i = UNIFORM ? static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g.w[2 * RM + 1]))) : g.w[2 * RM + 1];
   } else {
     it.cpu_v = it.wsum = it.wrc = 0.0;  // Score-only fields
+    it.wsum_i = 0;
   }
   return it;
 }
@@ -196,7 +189,7 @@ __device__ __forceinline__ bool fits_fast(const FastNode<RM>& ns, const Item<RM>
           "v_cmp_le_f64 vcc, %1, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
           "v_cmp_le_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
           : "+v"(rb)
-          : "s"(it.raw[r]), "v"(ns.av[0][r]), "v"(ns.av[1][r]), "v"(ns.av[2][r]), "v"(ns.av[3][r]), "v"(ns.av[4][r]), "v"(ns.av[5][r]),
+          : "v"(it.raw[r]), "v"(ns.av[0][r]), "v"(ns.av[1][r]), "v"(ns.av[2][r]), "v"(ns.av[3][r]), "v"(ns.av[4][r]), "v"(ns.av[5][r]),
             "v"(ns.av[6][r]), "v"(ns.av[7][r])
           : "vcc");
     }
@@ -282,35 +275,61 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
       m = s1 < m ? s1 : m;
     }
   } else {
-    if (__double_as_longlong(it.wsum) == 0) return 0;
+    // Zone totals as integers (round 3): a resource score t >= 0 is truncated AND clamped by ONE v_cvt_u32_f64 (it saturates
+    // negatives, -inf and NaN to 0: the reference's "request exceeds capacity" / "no capacity" zeros), the weighted sum is a
+    // v_mad_u32_u24 per resource (scores <= 100, weights below 2^20 — checked at upload), and the total starts at -sum(weights):
+    // a zone whose score floor(total / sum(weights)) is 0 ends negative, i.e. huge as unsigned, and drops out of the unsigned
+    // minimum — scoreForEachNUMANode's "minimum of the non-zero zone scores" is floor(min valid total / sum(weights)), one
+    // division per item instead of one per zone.  3 instructions per (zone, resource) + 1 per zone; the float64 form took 4 + 4.
+    const uint32_t wsum = it.wsum_i;
+    if (wsum == 0) return 0;  // no weighted slot requested: wave-uniform
+    double vq[RM];  // MostAllocated: the request pre-multiplied for the "request <= capacity" product test
 #pragma unroll
-    for (int z = 0; z < kZ; ++z) {
-      double acc = 0.0;
+    for (int r = 0; r < RM; ++r) vq[r] = SG == kSgMost ? value[r] * (1.0 + 0x1p-49) : 0.0;
+    double rawq = 0.0;  // the cpu slot's request in millicores (a dynamic index would move the array to scratch)
+    if constexpr (SG == kSgMost) {
 #pragma unroll
-      for (int r = 0; r < RM; ++r) {
-        if (!((used >> r) & 1u)) continue;
-        SPX_KEEP_BRANCH();
-        double rs;
+      for (int r = 0; r < RM; ++r) rawq = r == a.cpu_slot ? it.raw[r] * (1.0 + 0x1p-49) : rawq;
+    }
+    auto cvt_u32 = [](double t) {
+      uint32_t q;
+      asm("v_cvt_u32_f64 %0, %1" : "=v"(q) : "v"(t));
+      return q;
+    };
+    // resource outside, zone inside: the requested-slot test is a scalar branch, and the CU's ONE scalar unit serves all four
+    // SIMDs (a scalar instruction costs a SIMD the same issue slot as a vector one) — zone outside paid it 8 x RM times per item
+    uint32_t acc[kZ];
+#pragma unroll
+    for (int z = 0; z < kZ; ++z) acc[z] = 0u - wsum;
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      if (!((used >> r) & 1u)) continue;
+      SPX_KEEP_BRANCH();
+      const uint32_t w = static_cast<uint32_t>(a.slot_weight[r]);
+#pragma unroll
+      for (int z = 0; z < kZ; ++z) {
+        uint32_t rs;
         if constexpr (SG == kSgLeast) {
           // (cap_v - req_v) * 100 / cap_v == 100 - req_v * (100 / cap_v); see the header for why the floor is exact.
-          // Cells without capacity hold b = +inf: -v * inf is -inf (v > 0) or NaN (explicit zero request), and
-          // max(., 0) turns both into the reference's 0
-          rs = __builtin_fmax(__builtin_floor(__builtin_fma(-value[r], ns.b[z][r], 100.0 + 0x1p-43)), 0.0);
+          // Cells without capacity hold b = +inf: -v * inf is -inf (v > 0) or NaN (explicit zero request) -> 0
+          rs = cvt_u32(__builtin_fma(-value[r], ns.b[z][r], 100.0 + 0x1p-43));
         } else {
           // req_v * 100 / cap_v, zero when the request exceeds the capacity.  "request <= capacity" is read off the same
           // kind of product instead of the mutable table (so MostAllocated, like LeastAllocated, scores from b alone):
           // t = (q * (1 + 2^-49)) * RN(100 / c) <= 100 * (1 + 2^-48)  <=>  q <= c   for integers q, c < 2^42
           // (q <= c gives t <= 100 * (1 + 1.2 * 2^-49); q >= c + 1 gives t >= 100 * (1 + 2^-42)).  The cpu slot compares the
           // raw millicore quantities (braw), the score uses whole cores (b).
-          const double tp = (value[r] * (1.0 + 0x1p-49)) * ns.b[z][r];
-          const double chk = r == a.cpu_slot ? (it.raw[r] * (1.0 + 0x1p-49)) * braw[z] : tp;
-          rs = chk <= 100.0 * (1.0 + 0x1p-48) ? __builtin_floor(tp) : 0.0;
+          const double tp = vq[r] * ns.b[z][r];
+          const double chk = r == a.cpu_slot ? rawq * braw[z] : tp;
+          rs = chk <= 100.0 * (1.0 + 0x1p-48) ? cvt_u32(tp) : 0u;
         }
-        acc = __builtin_fma(rs, a.slot_weight_f[r], acc);
+        acc[z] = __umul24(rs, w) + acc[z];
       }
-      const uint32_t s1 = static_cast<uint32_t>(static_cast<int>(acc * it.wrc)) - 1u;  // floor(acc / wsum) in 0..100
-      m = s1 < m ? s1 : m;
     }
+#pragma unroll
+    for (int z = 0; z < kZ; ++z) m = acc[z] < m ? acc[z] : m;
+    if (m >= 0x80000000u) return 0;  // no zone scores
+    return static_cast<int>(static_cast<double>(m + wsum) * it.wrc);  // floor(total / sum(weights)) in 1..100
   }
   return static_cast<int>(m + 1u);
 }
@@ -606,16 +625,48 @@ __device__ __forceinline__ void load_fast_node(const NrtArgs& a, int64_t n, bool
 // Filter only the mutable table, so each half keeps 64 instead of 128 state registers and runs at higher occupancy)
 constexpr int kPhBoth = 0, kPhFilter = 1, kPhScore = 2;
 
+// waves per SIMD the register allocation is bounded for (<= 4 resource slots).  A spilled VGPR is not cheap here: whatever the
+// allocator parks in scratch is reloaded inside the pod loop behind an s_waitcnt vmcnt(0) (round 2's Filter launch, bounded to 5
+// waves = 96 VGPRs, reloaded the lane's staging offset from scratch for EVERY pod: ~1300 cycles per pod and wave)
+#ifndef SPX_NRT_ABLATE
+#define SPX_NRT_ABLATE 0  // experiments (tools/r3): 1 skip the pod loop, 2 skip the record fill, 4 skip the flush, 8 skip the node tables
+#endif
+#ifndef SPX_NRT_LB_FILTER
+#define SPX_NRT_LB_FILTER 4
+#endif
+#ifndef SPX_NRT_LB_LEAST
+#define SPX_NRT_LB_LEAST 4
+#endif
+#ifndef SPX_NRT_LB_MOST
+#define SPX_NRT_LB_MOST 4
+#endif
+#ifndef SPX_NRT_LB_BAL
+#define SPX_NRT_LB_BAL 4
+#endif
+#ifndef SPX_NRT_LB_LN
+#define SPX_NRT_LB_LN 2
+#endif
 template <int RM, int SG, int PH>
-__global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgLeastNuma ? 2 : ((SG == kSgMost || SG == kSgBalanced) ? 4 : 5)) : (PH == kPhFilter ? 5 : (SG == kSgLeast ? 3 : 2))) : 1) void k_nrt_fast(NrtArgs a, int n_tiles) {
+constexpr int nrt_waves() {
+  if (RM != 4) return 1;
+  if (PH == kPhFilter) return SPX_NRT_LB_FILTER;
+  if (PH == kPhScore) return SG == kSgLeastNuma ? SPX_NRT_LB_LN : (SG == kSgMost ? SPX_NRT_LB_MOST : (SG == kSgBalanced ? SPX_NRT_LB_BAL : SPX_NRT_LB_LEAST));
+  return SG == kSgLeast ? 3 : 2;
+}
+
+template <int RM, int SG, int PH>
+__global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(NrtArgs a, int n_tiles) {
   SPX_RESOLVE_ROWS(a);
   constexpr bool FULL = PH != kPhFilter;  // only the Score reads the second half of a request item
-  typedef ItemRegs<RM, FULL> Regs;
   // A block owns a window of 256 consecutive nodes and a chunk of pod rows.  Inside the window the engine has
   // ordered the nodes by (aligned, scope) — perm[] — so that a wavefront's 64 nodes mostly share one code path
   // (measured before: 49 % of the VALU lanes active, pod-scope and container-scope nodes being interleaved).
   // Results are staged in LDS at the nodes' original positions and leave as whole 256-byte row segments.
-  __shared__ __align__(16) uint8_t stage[2][kPodsPerUnit][kWindow];
+  // (round 3) staged as one dword per node and group of four pod rows — a lane keeps its last four results in a register and
+  // stores once per group: one LDS round trip per four pods instead of per pod — and regrouped into row segments on the way out
+  constexpr int kScoreTab = PH == kPhBoth ? 1 : 0;  // a split launch stages one table
+  __shared__ __align__(16) uint32_t stage[kScoreTab + 1][kPodsPerUnit / 4][kWindow];
+  __shared__ __align__(16) uint32_t pod_lds[kPodsPerUnit * pod_words<RM>()];  // the chunk's pod records (20 KB for <= 4 slots)
   __shared__ uint8_t ln_subset[SG == kSgLeastNuma ? kLnDwords * 32 : 1];  // LeastNUMANodes: bit position -> zone mask
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -639,24 +690,18 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgLeastNum
   }
   const int64_t pod0 = a.row_begin + chunk * kPodsPerUnit;
   if (pod0 >= a.row_end) return;  // block-uniform
-  const int64_t pod1 = pod0 + kPodsPerUnit < a.row_end ? pod0 + kPodsPerUnit : a.row_end;
+  const int rows = static_cast<int>(a.row_end - pod0 < kPodsPerUnit ? a.row_end - pod0 : kPodsPerUnit);
   const int64_t base = static_cast<int64_t>(window) * kWindow;
   const int32_t pn = a.perm[base + threadIdx.x];
   const bool in = pn >= 0;
   const int64_t n = in ? pn : 0;
   const int pos = in ? static_cast<int>(n - base) : 0;
   const int R = a.n_res;
-  if (a.out_raw == nullptr) {
-    uint4* z = reinterpret_cast<uint4*>(&stage[0][0][0]) + threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < static_cast<int>(sizeof(stage) / 16 / 256); ++i) z[i * 256] = uint4{0, 0, 0, 0};
-    __syncthreads();
-  }
 
   FastNode<RM> ns;
   double cpu_v[kZ], braw[kZ];
   const uint32_t flags = in ? a.flags[n] : 0u;
-  load_fast_node<RM, SG>(a, n, in, ns, cpu_v, braw);
+  load_fast_node<RM, SG>(a, n, in && !(SPX_NRT_ABLATE & 8), ns, cpu_v, braw);
   // BalancedAllocation's Score launch works from float32 images of the reciprocals; the float64 tables die here
   constexpr bool kBalF32 = SG == kSgBalanced && PH == kPhScore;
   BalNode<RM> bn;
@@ -685,15 +730,32 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgLeastNum
   const bool pod_scope = flags & SPX_NRT_F_POD_SCOPE;
   const bool aligned = fresh && has_nrt && single;  // the node's NUMA table decides Filter and Score
 
-  const uint32_t* items = a.pod_items;
-  auto header = [&](int64_t pod) { return uload(reinterpret_cast<const u32x2*>(items + pod * kItemsPerPod * item_words<RM>())); };
-  u32x2 hw = header(pod0);
-  for (int64_t pod = pod0; pod < pod1; ++pod) {
-    // ---- wave-uniform pod record: this pod's request items now, the next pod's header for the next iteration
-    const uint32_t* pit = items + pod * (kItemsPerPod * item_words<RM>());  // the pod's first item
-    const Regs pw = load_item<RM, FULL>(pit, 1);
-    Regs cw = load_item<RM, FULL>(pit, 2);
-    const u32x2 hnext = header(pod + 1 < pod1 ? pod + 1 : pod);
+  {  // the chunk's pod records -> LDS: contiguous in memory, 16-byte pieces, one round trip
+    const int n_quads = rows * (pod_words<RM>() / 4);
+    const uint4* src = reinterpret_cast<const uint4*>(a.pod_items + pod0 * pod_words<RM>());
+    uint4* dst = reinterpret_cast<uint4*>(pod_lds);
+    if (!(SPX_NRT_ABLATE & 2)) for (int i = threadIdx.x; i < n_quads; i += 256) dst[i] = src[i];
+    uint4* z = reinterpret_cast<uint4*>(&stage[0][0][0]) + threadIdx.x;  // empty slots of the window stay 0 (row padding)
+#pragma unroll
+    for (int i = 0; i < static_cast<int>(sizeof(stage) / 16 / 256); ++i) z[i * 256] = uint4{0, 0, 0, 0};
+  }
+  __syncthreads();
+
+  // What the wave's 64 nodes have in common (wave-uniform): a pod the launch has nothing to compute for — not filtered,
+  // not Guaranteed — skips the exec-masked regions with one scalar branch.  Round 2's loop ran every pod through them
+  // (48 scalar instructions for a BestEffort pod; scalar and vector instructions issue at the same rate per SIMD).
+  const bool w_pod = __ballot(aligned && pod_scope) != 0, w_ctr = __ballot(aligned && !pod_scope) != 0;
+  const uint32_t st_stale = fresh ? 0u : static_cast<uint32_t>(SPX_NRT_ST_INVALID_TOPOLOGY);
+  uint32_t acc_status = 0, acc_score = 0;  // this node's results of the current group of four pods
+  int raw_score = 0;
+  auto header = [&](int p) { return *reinterpret_cast<const u32x2*>(pod_lds + p * pod_words<RM>()); };
+  u32x2 hv = header(0);
+  for (int p = 0; p < ((SPX_NRT_ABLATE & 1) ? 0 : rows); ++p) {
+    // ---- wave-uniform pod record, from LDS; the next pod's header is requested before this pod's work
+    const uint32_t* pit = pod_lds + p * pod_words<RM>();  // the pod's first item
+    const uint32_t hw[2] = {static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(hv.x))),
+                            static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(hv.y)))};
+    hv = header(p + 1 < rows ? p + 1 : p);
     const int qos = hw[0] & 0xffu;
     const bool non_native = ((hw[0] >> 8) & 0xffu) != 0;
     const int n_ctr = (hw[0] >> 16) & 0xffu;
@@ -701,15 +763,18 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgLeastNum
     const uint32_t inv_n = hw[1];  // ceil(2^16 / n_ctr)
     const bool non_g = qos != SPX_QOS_GUARANTEED;
     const bool filtered = !(qos == SPX_QOS_BESTEFFORT && !non_native);  // filter.go:186-190
+    const bool u_filter = PH != kPhScore && filtered;                            // wave-uniform: the pod has a Filter verdict to compute
+    const bool u_score = SG != kSgLeastNuma && PH != kPhFilter && !non_g;        // ... a Score
 
-    uint32_t status = (filtered && !fresh) ? SPX_NRT_ST_INVALID_TOPOLOGY : 0u;
+    uint32_t status = filtered ? st_stale : 0u;
     int score = non_g ? 100 : 0;
-    const bool want_filter = PH != kPhScore && filtered && aligned;
-    const bool want_score = SG != kSgLeastNuma && PH != kPhFilter && !non_g && aligned;
     bool redo = false;  // BalancedAllocation, float32 form: some container's score could not be decided
+    if (u_filter || u_score) {
+    const bool want_filter = u_filter && aligned;
+    const bool want_score = u_score && aligned;
 
-    if ((want_filter || want_score) && pod_scope) {  // singleNUMAPodLevelHandler / podScopeScore
-      const Item<RM> it = decode_item<RM, FULL>(pw);
+    if (w_pod && pod_scope && aligned) {  // singleNUMAPodLevelHandler / podScopeScore
+      const Item<RM> it = decode_item<RM, FULL>(load_item<RM, FULL>(pit, 1));
       if constexpr (PH != kPhScore) {
         if (want_filter) {
           uint32_t pos;
@@ -728,16 +793,17 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgLeastNum
         }
       }
     }
-    if ((want_filter || want_score) && !pod_scope) {  // singleNUMAContainerLevelHandler / containerScopeScore
+    if (w_ctr && !pod_scope && aligned) {  // singleNUMAContainerLevelHandler / containerScopeScore
       // One pass in container order (init containers come first — checked at upload): an init container must fit
       // and is never subtracted; an app container is placed on the lowest fitting zone and subtracted from it.
       // Least/MostAllocated's zone scores read only b (never the mutable table), so they score in the same pass;
-      // BalancedAllocation scores after the undo.
+      // BalancedAllocation scores after the undo.  The next container's item is requested from LDS before this one is worked on.
       uint32_t chosen = 0;  // per app container: the zone it was subtracted from + 1 (0 = not placed), 4 bits each, for the undo
       int sum = 0;
+      ItemRegs<RM, FULL> cur = load_item<RM, FULL>(pit, 2);
       for (int c = 0; c < n_ctr; ++c) {
-        const Regs nw = load_item<RM, FULL>(pit, 2 + (c + 1 < kC ? c + 1 : c));  // prefetch the next container's item
-        const Item<RM> it = decode_item<RM, FULL>(cw);
+        const ItemRegs<RM, FULL> nxt = load_item<RM, FULL>(pit, 2 + (c + 1 < kC ? c + 1 : c));
+        const Item<RM> it = decode_item<RM, FULL>(cur);
         if constexpr (PH != kPhScore) if (want_filter) {
           uint32_t pos;
           const bool ok = fits_fast(ns, it, &pos);
@@ -756,36 +822,35 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgLeastNum
         if constexpr ((SG == kSgLeast || SG == kSgMost) && PH != kPhFilter) {
           if (want_score) sum += score_each_fast<RM, SG>(ns, a, it, cpu_v, braw);
         }
-        cw = nw;
+        cur = nxt;
       }
       if constexpr (PH != kPhScore) if (want_filter && last_app > 0) {  // undo: Filter works on a private copy in the reference
-        cw = load_item<RM, FULL>(pit, 2);
+        cur = load_item<RM, FULL>(pit, 2);
         for (int c = 0; c < last_app; ++c) {
-          const Regs nw = load_item<RM, FULL>(pit, 2 + c + 1);
-          const Item<RM> it = decode_item<RM, FULL>(cw);
+          const ItemRegs<RM, FULL> nxt = load_item<RM, FULL>(pit, 2 + c + 1);
+          const Item<RM> it = decode_item<RM, FULL>(cur);
           if (it.kind == SPX_CTR_APP) adjust_fast(ns, it, ((chosen >> (4 * c)) & 0xfu) - 1u, ((chosen >> (4 * c)) & 0xfu) != 0, 1.0);
-          cw = nw;
+          cur = nxt;
         }
       }
       if constexpr (SG != kSgLeast && SG != kSgMost && PH != kPhFilter) {
         if (want_score) {
-          cw = load_item<RM, FULL>(pit, 2);
           for (int c = 0; c < n_ctr; ++c) {
-            const Regs nw = load_item<RM, FULL>(pit, 2 + (c + 1 < kC ? c + 1 : c));
+            const Item<RM> it = decode_item<RM, FULL>(load_item<RM, FULL>(pit, 2 + c));
             if constexpr (kBalF32) {
               bool rd;
-              sum += score_balanced_f32(bn, ns.nz, a.cpu_slot, a.exact32_slots, decode_item<RM, FULL>(cw), &rd);
+              sum += score_balanced_f32(bn, ns.nz, a.cpu_slot, a.exact32_slots, it, &rd);
               redo |= rd;
             } else {
-              sum += score_each_fast<RM, SG>(ns, a, decode_item<RM, FULL>(cw), cpu_v, braw);
+              sum += score_each_fast<RM, SG>(ns, a, it, cpu_v, braw);
             }
-            cw = nw;
           }
         }
       }
       if (want_score) score = static_cast<int>((static_cast<uint32_t>(sum) * inv_n) >> 16);  // int64(mean): sum / n_ctr, sum <= 800
     }
     if constexpr (kBalF32) score = (want_score && redo) ? kBalRedo : score;  // k_nrt_bal_scan / k_nrt_bal_redo recompute the cell in float64
+    }  // the pod has something to compute
 
     if constexpr (SG == kSgLeastNuma) {
       // LeastNUMANodes scores every node that has a fresh NRT, whatever its topology-manager policy (score.go:167-191).
@@ -795,15 +860,11 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgLeastNum
       const bool want_ln = !non_g && fresh && has_nrt;
       int max_count = 0;
       bool all_min = true, failed = false, dirty = false;
-      cw = load_item<RM, FULL>(pit, 2);
+      if (!non_g)
       for (int c = -1; c < n_ctr; ++c) {
         const bool mine = want_ln && (c < 0 ? pod_scope : !pod_scope);
-        if (__ballot(mine) == 0) {
-          if (c >= 0) cw = load_item<RM, FULL>(pit, 2 + (c + 1 < kC ? c + 1 : c));
-          continue;
-        }
-        const Regs nw = c < 0 ? cw : load_item<RM, FULL>(pit, 2 + (c + 1 < kC ? c + 1 : c));
-        const Item<RM> it = decode_item<RM, FULL>(c < 0 ? pw : cw);
+        if (__ballot(mine) == 0) continue;
+        const Item<RM> it = decode_item<RM, FULL>(load_item<RM, FULL>(pit, c < 0 ? 1 : 2 + c));
         uint32_t any_rep = 0;
 #pragma unroll
         for (int r = 0; r < RM; ++r)
@@ -824,7 +885,6 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgLeastNum
           subtract_from_numas_fast(ns, it, go ? m : 0u);
           dirty |= go && m != 0;
         }
-        cw = nw;
       }
       if (want_ln) score = failed ? 0 : (max_count == 0 ? 100 : 100 - max_count * nns + (all_min ? nns / 2 : 0));
       if (__ballot(dirty) != 0) {  // the reference scored on a private NUMANodeList: restore this lane's table
@@ -837,25 +897,38 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgLeastNum
       }
     }
 
-    if (in && a.out_raw != nullptr) {
-      a.out_raw[n] = score;
-    } else if (in) {
-      if constexpr (SG == kSgLeastNuma) score = score < 0 ? 0 : score;  // 100 - count*(100/maxNUMA) can go negative; the table saturates
-      if constexpr (PH != kPhScore) stage[0][pod - pod0][pos] = static_cast<uint8_t>(status);
-      if constexpr (PH != kPhFilter) stage[1][pod - pod0][pos] = static_cast<uint8_t>(score > 255 ? 255 : score);
+    raw_score = score;  // (raw rows: the single row of the launch)
+    if constexpr (SG == kSgLeastNuma) score = score < 0 ? 0 : score;  // 100 - count*(100/maxNUMA) can go negative; the table saturates
+    const int sh = 8 * (p & 3);
+    if constexpr (PH != kPhScore) acc_status |= status << sh;
+    if constexpr (PH != kPhFilter) acc_score |= static_cast<uint32_t>(score > 255 ? 255 : score) << sh;
+    if ((p & 3) == 3 || p + 1 == rows) {  // wave-uniform
+      if (in) {
+        if constexpr (PH != kPhScore) stage[0][p >> 2][pos] = acc_status;
+        if constexpr (PH != kPhFilter) stage[kScoreTab][p >> 2][pos] = acc_score;
+      }
+      acc_status = acc_score = 0;
     }
-    hw = hnext;
   }
-  if (a.out_raw != nullptr) return;
+  if (a.out_raw != nullptr) {  // raw int64 scores of the launch's single row, no table writes
+    if (in) a.out_raw[n] = raw_score;
+    return;
+  }
   __syncthreads();
-  const int rows = static_cast<int>(pod1 - pod0);
+  // rows leave as whole 256-byte segments: lane l gathers byte (row & 3) of the four dwords of nodes 4l .. 4l+3
   const int64_t col = base + lane * 4;
-  if (col < a.row_stride) {
-    for (int i = wave; i < 2 * rows; i += 4) {
-      const int p = i >> 1, tbl = i & 1;
-      if ((PH == kPhFilter && tbl == 1) || (PH == kPhScore && tbl == 0)) continue;
-      uint8_t* out = (tbl ? a.out_score : a.out_status) + (pod0 + p) * a.row_stride + col;
-      *reinterpret_cast<uint32_t*>(out) = *reinterpret_cast<const uint32_t*>(&stage[tbl][p][lane * 4]);
+  if (col < a.row_stride && !(SPX_NRT_ABLATE & 4)) {
+    for (int i = wave; i < rows; i += 4) {
+      const uint32_t b = static_cast<uint32_t>(i & 3);
+      const uint32_t pick = 0x0c0c0000u | ((4u + b) << 8) | b;  // v_perm_b32: byte b of the low operand, byte b of the high one, 0, 0
+#pragma unroll
+      for (int tbl = 0; tbl < 2; ++tbl) {
+        if ((PH == kPhFilter && tbl == 1) || (PH == kPhScore && tbl == 0)) continue;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(&stage[tbl ? kScoreTab : 0][i >> 2][lane * 4]);
+        const uint32_t lo = __builtin_amdgcn_perm(w.y, w.x, pick), hi = __builtin_amdgcn_perm(w.w, w.z, pick);
+        uint8_t* out = (tbl ? a.out_score : a.out_status) + (pod0 + i) * a.row_stride + col;
+        *reinterpret_cast<uint32_t*>(out) = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+      }
     }
   }
 }
@@ -863,20 +936,6 @@ __global__ __launch_bounds__(256, RM == 4 ? (PH == kPhScore ? (SG == kSgLeastNum
 // BalancedAllocation fix-up: the cells the float32 Score launch marked kBalRedo, recomputed with the float64 form — the node's
 // tables loaded for that one cell, the pod's items read with ordinary (per-lane) loads.  One thread per 16 bytes of a score
 // row; nearly all threads find nothing.
-template <int RM>
-__device__ __forceinline__ ItemRegs<RM, true> load_item_lane(const uint32_t* pod_items, int slot) {
-  const uint32_t* p = pod_items + slot * item_words<RM>();
-  ItemRegs<RM, true> r;
-  if constexpr (RM == 4) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r.w[i] = p[i];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r.lo[i] = p[i], r.hi[i] = p[16 + i];
-  }
-  return r;
-}
-
 // the float64 form for one (pod, node) cell
 template <int RM>
 __device__ __forceinline__ int balanced_cell_exact(const NrtArgs& a, int64_t pod, int64_t n) {
@@ -888,11 +947,11 @@ __device__ __forceinline__ int balanced_cell_exact(const NrtArgs& a, int64_t pod
   load_fast_node<RM, kSgBalanced>(a, n, true, ns, cpu_v, braw);
   int score;
   if (a.flags[n] & SPX_NRT_F_POD_SCOPE) {
-    score = score_each_fast<RM, kSgBalanced>(ns, a, decode_item<RM, true>(load_item_lane<RM>(pit, 1)), cpu_v, braw);
+    score = score_each_fast<RM, kSgBalanced>(ns, a, decode_item<RM, true, false>(load_item<RM, true>(pit, 1)), cpu_v, braw);
   } else {
     int sum = 0;
 #pragma unroll 1
-    for (int c = 0; c < n_ctr; ++c) sum += score_each_fast<RM, kSgBalanced>(ns, a, decode_item<RM, true>(load_item_lane<RM>(pit, 2 + c)), cpu_v, braw);
+    for (int c = 0; c < n_ctr; ++c) sum += score_each_fast<RM, kSgBalanced>(ns, a, decode_item<RM, true, false>(load_item<RM, true>(pit, 2 + c)), cpu_v, braw);
     score = static_cast<int>((static_cast<uint32_t>(sum) * inv_n) >> 16);
   }
   return score > 254 ? 254 : score;
@@ -926,6 +985,10 @@ __global__ __launch_bounds__(kScanThreads) void k_nrt_bal_scan(NrtArgs a) {
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int b = 0; b < 4; ++b) marks |= (((words[q] >> (8 * b)) & 0xffu) == static_cast<uint32_t>(kBalRedo) ? 1u : 0u) << (4 * q + b);
+    // row padding past the last node window is never written by the sweep (and not zeroed at allocation): a stray 0xff there is
+    // not a cell
+    const int64_t left = a.n_nodes - col;
+    marks = left >= 16 ? marks : (left <= 0 ? 0u : marks & ((1u << left) - 1u));
   }
   const uint32_t mine = static_cast<uint32_t>(__builtin_popcount(marks));
   if (__syncthreads_or(mine != 0) == 0) return;  // nothing marked in this block's 16 KB of table
@@ -988,7 +1051,8 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   if (a.strategy == SPX_NRT_LEAST_NUMA_NODES && !a.ln_tab) return false;
   const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);  // windows of 256 nodes
   const int64_t chunks = (a.row_end - a.row_begin + kPodsPerUnit - 1) / kPodsPerUnit;
-  const unsigned blocks = static_cast<unsigned>(chunks * (n_tiles >= kXcdMapWindows ? ((n_tiles + 7) / 8) * 8 : n_tiles));  // see the kernel's block map
+  const int64_t per_round = n_tiles >= kXcdMapWindows ? ((n_tiles + 7) / 8) * 8 : n_tiles;
+  const unsigned blocks = static_cast<unsigned>(chunks * per_round);  // see the kernel's block map
   const int sg = a.strategy == SPX_NRT_LEAST_NUMA_NODES ? kSgLeastNuma
                : a.strategy == SPX_NRT_BALANCED_ALLOCATION ? kSgBalanced : (a.strategy == SPX_NRT_LEAST_ALLOCATED ? kSgLeast : kSgMost);
   const bool split = a.out_raw == nullptr && !(a.opts & kOptNrtSingleLaunch);

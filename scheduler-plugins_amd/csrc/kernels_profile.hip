@@ -370,9 +370,13 @@ __global__ __launch_bounds__(64 * kMaxRowWaves) void k_best(ProfileArgs a) {
 
 void launch_alloc_masked(const ProfileArgs& a, hipStream_t s) {
   if (a.row_end <= a.row_begin) return;
-  const size_t tiles = static_cast<size_t>((a.row_stride + 64 * kNpl - 1) / (64 * kNpl));
+  // dynamic LDS = the larger of the two layouts the kernel may pick: uint8[tiles of 4 nodes per lane][64] (general path) and
+  // uint16[tiles of 16 nodes per lane][64] (alloc_masked_compact) — for rows of <= 256 bytes the second is the larger one
+  const size_t tiles4 = static_cast<size_t>((a.row_stride + 64 * kNpl - 1) / (64 * kNpl));
+  const size_t tiles16 = static_cast<size_t>((a.row_stride + 64 * kNplCompact - 1) / (64 * kNplCompact));
+  const size_t lds = tiles4 * 64 > tiles16 * 128 ? tiles4 * 64 : tiles16 * 128;
   const unsigned rows = static_cast<unsigned>(a.row_end - a.row_begin);
-  hipLaunchKernelGGL(k_alloc_masked, dim3(rows), dim3(rows == 1 ? 64 * kMaxRowWaves : 64), tiles * 64, s, a);
+  hipLaunchKernelGGL(k_alloc_masked, dim3(rows), dim3(rows == 1 ? 64 * kMaxRowWaves : 64), lds, s, a);
 }
 
 void launch_best(const ProfileArgs& a, hipStream_t s) {

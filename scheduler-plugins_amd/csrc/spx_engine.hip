@@ -414,6 +414,7 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
 
 // quantities the float64 NRT kernel may hold exactly, with room for x100 and the reciprocal trick
 constexpr int64_t kNrtFastLimit = int64_t{1} << 42;
+constexpr int64_t kNrtWeightLimit = int64_t{1} << 20;  // sum of the NRT scoring weights the float64 formulation accepts
 inline bool nrt_fast_qty(int64_t v) { return v >= 0 && v < kNrtFastLimit; }
 // RN(1/v) * (1 + 2^-49): floor(num * rc) == num / v for 0 <= num <= 101 * v, 0 < v < 2^42 (kernels_nrt_fast.hip)
 inline double nrt_biased_rcp(double v) { return v > 0.0 ? (1.0 / v) * (1.0 + 0x1p-49) : 0.0; }
@@ -783,10 +784,12 @@ int spx_upload_nrt_slots(spx_engine* e, const spx_nrt_slots* t) {
   int64_t wtotal = 0;
   for (int i = 0; i < t->n_res; ++i) {
     if (t->slot_flags[i] & SPX_NRT_SLOT_CPU) e->nrt_cpu_slot = i;
-    if (t->slot_weight[i] < 0 || t->slot_weight[i] >= kNrtFastLimit / 128) e->nrt_fast_slots = false;
+    // the Least/MostAllocated Score accumulates integer zone totals (v_mad_u32_u24: weights below 2^24) whose high bit marks a
+    // zero zone score: 100 * sum(weights) must stay below 2^31 — with room, sum(weights) < 2^20 (upstream weights are 1..100)
+    if (t->slot_weight[i] < 0 || t->slot_weight[i] >= kNrtWeightLimit) e->nrt_fast_slots = false;
     else wtotal += t->slot_weight[i];
   }
-  if (wtotal >= kNrtFastLimit / 128) e->nrt_fast_slots = false;
+  if (wtotal >= kNrtWeightLimit) e->nrt_fast_slots = false;
   std::vector<double> wtab(static_cast<size_t>(2) << t->n_res, 0.0);
   if (e->nrt_fast_slots)
     for (unsigned m = 0; m < (1u << t->n_res); ++m) {
@@ -1000,7 +1003,8 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
     //                    w1 = ceil(2^16 / n_ctr)
     //   item 1   the pod-level effective request;  items 2..9  the containers, in order
     //   request item: doubles raw[RM] (dwords 0..2RM-1); dword 2RM = requested slots | compared slots << 8 |
-    //                 "any reporting zone suits" slots << 16 | kind << 24; a pad; then what only the Score reads: Value() of the
+    //                 "any reporting zone suits" slots << 16 | kind << 24; dword 2RM+1 = sum of the weights of the requested
+    //                 slots as an integer; then what only the Score reads: Value() of the
     //                 cpu request (2RM+2), sum of the weights of the requested slots (2RM+4), its biased reciprocal (2RM+6)
     const int RMs = R <= 4 ? 4 : 8;
     const size_t IW = R <= 4 ? 16 : 32;
@@ -1024,6 +1028,7 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
       w[2 * RMs] = used | (fit << 8) | (always << 16) | (kind << 24);
       put_f64(w + 2 * RMs + 2, static_cast<double>(nrt_value_of(true, cpu_q)));
       if (ok.load(std::memory_order_relaxed)) {
+        w[2 * RMs + 1] = static_cast<uint32_t>(e->nrt_wtab[2 * used]);  // the weight sum as an integer (< 2^20)
         put_f64(w + 2 * RMs + 4, e->nrt_wtab[2 * used]);
         put_f64(w + 2 * RMs + 6, e->nrt_wtab[2 * used + 1]);
       }

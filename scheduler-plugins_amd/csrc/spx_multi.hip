@@ -132,6 +132,7 @@ class Workers {
 struct GlobalTable {
   std::vector<void*> dptr;  // per rank: uint8 [size * rows_per][row_stride]
   int64_t rows_per = 0, row_stride = 0, n_pods_total = 0;
+  size_t bytes = 0;         // of each rank's allocation
   bool gathered = false;
 };
 
@@ -231,6 +232,16 @@ int all_gather_in_place(spx_multi* m, const std::vector<void*>& buf, size_t byte
   for (int r = 0; r < m->n; ++r) {
     SPXM_HIP(m, hipSetDevice(v[static_cast<size_t>(r)].device));
     SPXM_HIP(m, hipEventRecord(m->g1[static_cast<size_t>(r)], v[static_cast<size_t>(r)].stream));
+  }
+  if (m->transport != SPX_MULTI_TRANSPORT_RCCL) {
+    // the pulls read the producers' own slots from the consumers' streams: a producer's next write into its slot (the next
+    // gather's copy, or an eval into a bound global table) must come after every consumer's pulls — each stream waits on the
+    // other ranks' end-of-gather events
+    for (int r = 0; r < m->n; ++r) {
+      SPXM_HIP(m, hipSetDevice(v[static_cast<size_t>(r)].device));
+      for (int s = 0; s < m->n; ++s)
+        if (s != r) SPXM_HIP(m, hipStreamWaitEvent(v[static_cast<size_t>(r)].stream, m->g1[static_cast<size_t>(s)], 0));
+    }
   }
   return SPX_OK;
 }
@@ -463,19 +474,52 @@ int spx_multi_bind_global_table(spx_multi* m, int plugin, int which, int64_t n_p
     stride = v.row_stride;
     if (v.n_pods > per) return mfail(m, SPX_ERR_STATE, "rank " + std::to_string(r) + " holds more pod rows than a shard of this batch");
   }
-  t.dptr.assign(static_cast<size_t>(m->n), nullptr);
+  const size_t slab = static_cast<size_t>(per) * static_cast<size_t>(stride);
+  const size_t bytes = slab * static_cast<size_t>(m->n);
+  const bool reuse = !t.dptr.empty() && t.bytes == bytes;  // same slab size (the usual per-batch re-bind): keep the allocations
+  auto bind = [&](int r, void* p) {
+    spx_engine* e = m->engine[static_cast<size_t>(r)];
+    return which == 0 ? spx_bind_score_table(e, plugin, p, p ? stride : 0, p ? per : 0) : spx_bind_status_table(e, plugin, p, p ? stride : 0, p ? per : 0);
+  };
+  // every rank: wait for work that may still write the old slab, unbind it, free it unless it is reused
+  auto release = [&](GlobalTable& g, bool keep) {
+    for (int r = 0; r < m->n && !g.dptr.empty(); ++r) {
+      if (!g.dptr[static_cast<size_t>(r)]) continue;
+      const spx::EngineView v = spx::engine_view(m->engine[static_cast<size_t>(r)]);
+      (void)hipSetDevice(v.device);
+      (void)hipStreamSynchronize(v.stream);
+      (void)bind(r, nullptr);
+      if (!keep) {
+        (void)hipFree(g.dptr[static_cast<size_t>(r)]);
+        g.dptr[static_cast<size_t>(r)] = nullptr;
+      }
+    }
+    if (!keep) g = GlobalTable{};
+  };
+  release(t, reuse);
+  if (!reuse) t.dptr.assign(static_cast<size_t>(m->n), nullptr);
+  t.bytes = bytes;
   t.rows_per = per;
   t.row_stride = stride;
   t.n_pods_total = n_pods_total;
   t.gathered = false;
-  const size_t slab = static_cast<size_t>(per) * static_cast<size_t>(stride);
   for (int r = 0; r < m->n; ++r) {
-    spx_engine* e = m->engine[static_cast<size_t>(r)];
-    SPXM_HIP(m, hipSetDevice(m->device[static_cast<size_t>(r)]));
-    SPXM_HIP(m, hipMalloc(&t.dptr[static_cast<size_t>(r)], slab * static_cast<size_t>(m->n)));
-    char* mine = static_cast<char*>(t.dptr[static_cast<size_t>(r)]) + static_cast<size_t>(r) * slab;
-    const int rc = which == 0 ? spx_bind_score_table(e, plugin, mine, stride, per) : spx_bind_status_table(e, plugin, mine, stride, per);
-    if (rc) return engine_failed(m, r, rc);
+    int rc = SPX_OK;
+    hipError_t he = hipSetDevice(m->device[static_cast<size_t>(r)]);
+    if (he == hipSuccess && !t.dptr[static_cast<size_t>(r)]) he = hipMalloc(&t.dptr[static_cast<size_t>(r)], bytes);
+    if (he == hipSuccess) {
+      char* mine = static_cast<char*>(t.dptr[static_cast<size_t>(r)]) + static_cast<size_t>(r) * slab;
+      rc = bind(r, mine);
+    }
+    if (he != hipSuccess || rc) {  // roll back: no rank stays bound to a table that is not recorded as complete
+      std::string why = he != hipSuccess ? std::string(hipGetErrorString(he)) : std::string();
+      if (rc) (void)engine_failed(m, r, rc);
+      const std::string kept = m->err;
+      release(t, false);
+      if (he != hipSuccess) return mfail(m, SPX_ERR_HIP, "bind_global_table, rank " + std::to_string(r) + ": " + why);
+      m->err = kept;
+      return rc;
+    }
   }
   return SPX_OK;
 }

@@ -411,7 +411,10 @@ struct spx_ingest {
   std::vector<int32_t> p_ctr_ptr{0}, p_req_ptr{0}, p_lim_ptr{0}, p_ovh_ptr{0}, p_req_res, p_lim_res, p_ovh_res, p_priority, p_appgroup, p_selector, p_ns;
   std::vector<uint8_t> p_kind;
   std::vector<int64_t> p_req_qty, p_lim_qty, p_ovh_qty, p_queue_ts;
-  std::vector<int32_t> p_nominated;  // status.nominatedNodeName as a node index of the snapshot, -1 = none / unknown node
+  std::vector<int32_t> p_nominated;  // status.nominatedNodeName as a node index of the CURRENT node snapshot, -1 = none / unknown node:
+                                     // derived from p_nominated_name by rebuild_nominated, so pods may be ingested before nodes and
+                                     // the node snapshot may be replaced afterwards
+  std::vector<std::string> p_nominated_name;  // status.nominatedNodeName as written ("" = none)
   spx_pod_objects pod_table{};
   // ---- AppGroup / NetworkTopology CRs
   std::vector<int32_t> g_wl_ptr{0}, g_wl_selector, g_dep_ptr{0}, g_dep_selector, g_topo_ptr{0}, g_topo_selector, g_topo_index, g_placed_ptr{0};
@@ -945,10 +948,8 @@ bool decode_pod(spx_ingest* h, Reader& r) {
   h->p_appgroup.push_back((has_group && !group.empty()) ? h->appgroups.id(group) : -1);
   h->p_selector.push_back((has_selector && !selector.empty()) ? h->selectors.id(selector) : -1);
   h->p_ns.push_back(h->namespaces.id(ns));
-  {
-    const auto it = nominated.empty() ? h->node_index.end() : h->node_index.find(nominated);
-    h->p_nominated.push_back(it == h->node_index.end() ? -1 : static_cast<int32_t>(it->second));
-  }
+  h->p_nominated.push_back(-1);  // resolved against the node snapshot in rebuild_nominated
+  h->p_nominated_name.push_back(nominated);
   return true;
 }
 
@@ -987,12 +988,15 @@ int run_decoder(spx_ingest* h, const char* json, int64_t len, int64_t* n_out, Fn
   return ok ? SPX_OK : SPX_ERR_ARG;
 }
 
+void rebuild_nominated(spx_ingest* h);
+
 }  // namespace
 
 extern "C" int spx_ingest_nodes_json(spx_ingest* h, const char* json, int64_t len, int64_t* n_objects_out, int64_t* n_unknown_out) {
   if (!h || !json || len < 0) return SPX_ERR_ARG;
   const int rc = run_decoder(h, json, len, n_objects_out, [&](Reader& r) { return decode_node(h, r); });
   freeze_nodes(h);
+  rebuild_nominated(h);  // nominatedNodeName is resolved against the node snapshot: pods may have arrived first
   refresh_classes(h);
   if (n_unknown_out) *n_unknown_out = h->unknown;
   return rc;
@@ -1011,7 +1015,7 @@ extern "C" int spx_ingest_pods_json(spx_ingest* h, const char* json, int64_t len
   const int rc = run_decoder(h, json, len, n_objects_out, [&](Reader& r) { return decode_pod(h, r); });
   if (rc != SPX_OK) {
     h->p_priority.resize(n_pods), h->p_queue_ts.resize(n_pods), h->p_appgroup.resize(n_pods), h->p_selector.resize(n_pods), h->p_ns.resize(n_pods);
-    h->p_nominated.resize(n_pods);
+    h->p_nominated.resize(n_pods), h->p_nominated_name.resize(n_pods);
     h->p_ctr_ptr.resize(n_pods + 1), h->p_ovh_ptr.resize(n_pods + 1), h->p_kind.resize(n_ctr), h->p_req_ptr.resize(n_ctr + 1), h->p_lim_ptr.resize(n_ctr + 1);
     h->p_req_res.resize(n_req), h->p_req_qty.resize(n_req), h->p_lim_res.resize(n_lim), h->p_lim_qty.resize(n_lim);
     h->p_ovh_res.resize(n_ovh), h->p_ovh_qty.resize(n_ovh);
@@ -1029,7 +1033,7 @@ extern "C" int spx_ingest_pods_reset(spx_ingest* h) {
   h->p_ctr_ptr.assign(1, 0), h->p_req_ptr.assign(1, 0), h->p_lim_ptr.assign(1, 0), h->p_ovh_ptr.assign(1, 0);
   h->p_kind.clear(), h->p_req_res.clear(), h->p_req_qty.clear(), h->p_lim_res.clear(), h->p_lim_qty.clear(), h->p_ovh_res.clear(), h->p_ovh_qty.clear();
   h->p_priority.clear(), h->p_queue_ts.clear(), h->p_appgroup.clear(), h->p_selector.clear(), h->p_ns.clear();
-  h->p_nominated.clear();
+  h->p_nominated.clear(), h->p_nominated_name.clear();
   freeze_pods(h);
   rebuild_nominated(h);
   return SPX_OK;
@@ -1554,6 +1558,13 @@ extern "C" const spx_quota_objects* spx_ingest_quota_objects(const spx_ingest* h
 
 namespace {
 void rebuild_nominated(spx_ingest* h) {
+  // only pods nominated to a node of the snapshot count (capacity_scheduling.go:231-253 walks the snapshot's nodes and asks
+  // NominatedPodsForNode for each): resolve the names against the node table as it is NOW
+  for (size_t i = 0; i < h->p_nominated_name.size(); ++i) {
+    const std::string& nm = h->p_nominated_name[i];
+    const auto it = nm.empty() ? h->node_index.end() : h->node_index.find(nm);
+    h->p_nominated[i] = it == h->node_index.end() ? -1 : static_cast<int32_t>(it->second);
+  }
   spx_ingest_quota* q = h->quota;
   if (!q) return;  // no quota table yet: spx_ingest_quota_json calls this again
   q->nom_ns.clear(), q->nom_priority.clear(), q->nom_pending.clear();

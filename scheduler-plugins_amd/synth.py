@@ -27,7 +27,8 @@ def _csr_from_mask(mask: np.ndarray):
 
 
 def synth_pods(hdr: Header, n_pods: int, seed: int = SEED, device_res: int = -1, n_appgroups: int = 0,
-               n_namespaces: int = 100, hugepage_res: int = -1) -> Table:
+               n_namespaces: int = 100, hugepage_res: int = -1, qos_p=(0.5, 0.4, 0.1)) -> Table:
+    """`qos_p`: shares of Guaranteed / Burstable / BestEffort pods (50 / 40 / 10 %; experiments vary it)."""
     rng = np.random.default_rng(seed + 1)
     n_app = rng.integers(1, 4, n_pods)
     has_init = rng.random(n_pods) < 0.2
@@ -41,7 +42,7 @@ def synth_pods(hdr: Header, n_pods: int, seed: int = SEED, device_res: int = -1,
     # 10% of init containers are sidecars
     kind = np.where((kind == 1) & (rng.random(total) < 0.1), 2, kind).astype(np.uint8)
 
-    qos = rng.choice(3, n_pods, p=[0.5, 0.4, 0.1])  # 0 Guaranteed, 1 Burstable, 2 BestEffort
+    qos = rng.choice(3, n_pods, p=list(qos_p))  # 0 Guaranteed, 1 Burstable, 2 BestEffort
     q = qos[pod_of]
     cpu = np.exp(rng.uniform(np.log(100), np.log(8000), total)).astype(np.int64)
     whole = rng.random(total) < 0.3
