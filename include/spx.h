@@ -699,7 +699,9 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *   SPX_OPT_DECIDE_UNFUSED     1 = spx_decide always runs spx_eval + spx_eval_best
  *   SPX_OPT_NRT_SINGLE_LAUNCH  1 = NRT Filter and Score in one launch (default: two for Least/MostAllocated)
  *   SPX_OPT_COMMIT_FROM_MEMORY 1 = spx_commit_sequential keeps node state in memory (any node count) instead of registers
- *   SPX_OPT_PEAKS_TILE         nodes per lane of Peaks' (min/max pass, write pass): 44 (default), 84, 48, 88 */
+ *   SPX_OPT_PEAKS_TILE         nodes per lane of Peaks' (min/max pass, write pass): 44 (default), 84, 48, 88
+ *   SPX_OPT_NRT_POD_CLASSES    1 (default) = a whole-batch NRT sweep evaluates one representative row per class of pods whose
+ *                              records agree in everything the sweep reads and copies it to the rest of the class; 0 = every row */
 #define SPX_OPT_ROW_ALIGN 0
 #define SPX_OPT_REFERENCE_KERNELS 1
 #define SPX_OPT_LROC_FLOAT64 2
@@ -707,9 +709,16 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
 #define SPX_OPT_NRT_SINGLE_LAUNCH 4
 #define SPX_OPT_COMMIT_FROM_MEMORY 5
 #define SPX_OPT_PEAKS_TILE 6
-#define SPX_NUM_OPTIONS 7
+#define SPX_OPT_NRT_POD_CLASSES 7
+#define SPX_NUM_OPTIONS 8
 int spx_set_option(spx_engine* e, int option, int64_t value);
 int spx_get_option(const spx_engine* e, int option, int64_t* value);
+
+/* Pod equivalence classes of the uploaded NRT pod batch (spx_upload_nrt_pods): n_unique = rows that represent a class (or only
+ * themselves), n_copies = rows that repeat an earlier row's NRT record in everything the sweep reads — Deployment replicas, and
+ * pods whose verdict does not depend on quantities (not filtered: filter.go:186-190; non-Guaranteed: score.go:72-76,
+ * numaresources.go:137-142).  n_unique + n_copies = n_pods.  A whole-batch spx_eval of NRT evaluates the unique rows and copies. */
+int spx_nrt_pod_classes(const spx_engine* e, int64_t* n_unique, int64_t* n_copies);
 
 /* which formulation of a plugin's sweep the uploaded tables select: 0 = generic (reference arithmetic, operation for
  * operation), 1 = fast formulation (same results; see DESIGN.md for each kernel's preconditions); <0 on error.

@@ -291,11 +291,8 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
 #pragma unroll
       for (int r = 0; r < RM; ++r) rawq = r == a.cpu_slot ? it.raw[r] * (1.0 + 0x1p-49) : rawq;
     }
-    auto cvt_u32 = [](double t) {
-      uint32_t q;
-      asm("v_cvt_u32_f64 %0, %1" : "=v"(q) : "v"(t));
-      return q;
-    };
+    // v_cvt_u32_f64 (what the conversion compiles to; an asm statement would cost an s_nop each) saturates: < 0, -inf, NaN -> 0
+    auto cvt_u32 = [](double t) { return static_cast<uint32_t>(t); };
     // resource outside, zone inside: the requested-slot test is a scalar branch, and the CU's ONE scalar unit serves all four
     // SIMDs (a scalar instruction costs a SIMD the same issue slot as a vector one) — zone outside paid it 8 x RM times per item
     uint32_t acc[kZ];
@@ -599,24 +596,28 @@ __device__ __forceinline__ void load_fast_node(const NrtArgs& a, int64_t n, bool
   ns.node_present = in ? a.node_present[n] : 0u;
 #pragma unroll
   for (int i = 0; i < RM / 4; ++i) ns.rep[i] = ns.fill[i] = 0;
+  // element offsets fit 32 bits (Z * R * N < 2^28 for the node counts a device holds): one scalar multiply per column instead of a
+  // 64-bit multiply-add chain — the prologue runs once per block of 32 pods, and scalar instructions are not free (one scalar unit per CU)
+  const uint32_t nn = static_cast<uint32_t>(a.n_nodes), n32 = static_cast<uint32_t>(n);
 #pragma unroll
   for (int r = 0; r < RM; ++r) {
     if (r >= R) continue;
-    const uint32_t rep = in ? a.f_rep[static_cast<int64_t>(r) * a.n_nodes + n] : 0u;
+    const uint32_t rep = in ? ld_off(a.f_rep, static_cast<uint32_t>(r) * nn + n32) : 0u;
     ns.rep[r >> 2] |= rep << (8 * (r & 3));
     if ((a.slot_flags[r] & SPX_NRT_SLOT_HOST_LEVEL) && rep == 0) ns.fill[r >> 2] |= 0xffu << (8 * (r & 3));
   }
 #pragma unroll
   for (int z = 0; z < kZ; ++z) {
-    cpu_v[z] = (SG == kSgBalanced && in && a.cpu_slot >= 0) ? a.f_cpu[static_cast<int64_t>(z) * a.n_nodes + n] : 0.0;
-    braw[z] = (SG == kSgMost && in && a.cpu_slot >= 0) ? a.f_braw[static_cast<int64_t>(z) * a.n_nodes + n] : kNoCap;
+    const uint32_t zo = (static_cast<uint32_t>(z) * nn + n32) * 8u;
+    cpu_v[z] = (SG == kSgBalanced && in && a.cpu_slot >= 0) ? ld_off(a.f_cpu, zo) : 0.0;
+    braw[z] = (SG == kSgMost && in && a.cpu_slot >= 0) ? ld_off(a.f_braw, zo) : kNoCap;
 #pragma unroll
     for (int r = 0; r < RM; ++r) {
-      const int64_t i = (static_cast<int64_t>(z) * R + r) * a.n_nodes + n;
-      ns.av[z][r] = (in && r < R) ? a.f_av[i] : -1.0;
-      const double b = (SG != kSgBalanced && SG != kSgLeastNuma && in && r < R) ? a.f_rc[i] : kNoCap;
+      const uint32_t i = (static_cast<uint32_t>(z * R + r) * nn + n32) * 8u;
+      ns.av[z][r] = (in && r < R) ? ld_off(a.f_av, i) : -1.0;
+      const double b = (SG != kSgBalanced && SG != kSgLeastNuma && in && r < R) ? ld_off(a.f_rc, i) : kNoCap;
       ns.b[z][r] = (SG == kSgLeast && b == kNoCap) ? __builtin_inf() : b;
-      if constexpr (SG == kSgBalanced) ns.b[z][r] = (in && r < R) ? a.f_rcv[i] : 1.0;  // RN(1 / Value(capacity)) for div_rn
+      if constexpr (SG == kSgBalanced) ns.b[z][r] = (in && r < R) ? ld_off(a.f_rcv, i) : 1.0;  // RN(1 / Value(capacity)) for div_rn
     }
   }
 }
@@ -643,6 +644,9 @@ constexpr int kPhBoth = 0, kPhFilter = 1, kPhScore = 2;
 #ifndef SPX_NRT_LB_BAL
 #define SPX_NRT_LB_BAL 4
 #endif
+#ifndef SPX_NRT_LB_BOTH
+#define SPX_NRT_LB_BOTH 3
+#endif
 #ifndef SPX_NRT_LB_LN
 #define SPX_NRT_LB_LN 2
 #endif
@@ -651,7 +655,7 @@ constexpr int nrt_waves() {
   if (RM != 4) return 1;
   if (PH == kPhFilter) return SPX_NRT_LB_FILTER;
   if (PH == kPhScore) return SG == kSgLeastNuma ? SPX_NRT_LB_LN : (SG == kSgMost ? SPX_NRT_LB_MOST : (SG == kSgBalanced ? SPX_NRT_LB_BAL : SPX_NRT_LB_LEAST));
-  return SG == kSgLeast ? 3 : 2;
+  return SG == kSgLeast ? SPX_NRT_LB_BOTH : 2;
 }
 
 template <int RM, int SG, int PH>
@@ -688,9 +692,12 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
     window = static_cast<int>(blockIdx.x % n_windows);
     chunk = blockIdx.x / n_windows;
   }
-  const int64_t pod0 = a.row_begin + chunk * kPodsPerUnit;
-  if (pod0 >= a.row_end) return;  // block-uniform
-  const int rows = static_cast<int>(a.row_end - pod0 < kPodsPerUnit ? a.row_end - pod0 : kPodsPerUnit);
+  // the chunk's rows: 32 consecutive rows of the range, or 32 consecutive entries of the row list (pod equivalence classes)
+  const bool listed = a.row_list != nullptr;
+  const int64_t first = listed ? chunk * kPodsPerUnit : a.row_begin + chunk * kPodsPerUnit, last = listed ? a.n_list : a.row_end;
+  if (first >= last) return;  // block-uniform
+  const int rows = static_cast<int>(last - first < kPodsPerUnit ? last - first : kPodsPerUnit);
+  auto row_of = [&](int p) -> int64_t { return listed ? static_cast<int64_t>(uload(a.row_list + first + p)) : first + p; };
   const int64_t base = static_cast<int64_t>(window) * kWindow;
   const int32_t pn = a.perm[base + threadIdx.x];
   const bool in = pn >= 0;
@@ -731,10 +738,18 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
   const bool aligned = fresh && has_nrt && single;  // the node's NUMA table decides Filter and Score
 
   {  // the chunk's pod records -> LDS: contiguous in memory, 16-byte pieces, one round trip
-    const int n_quads = rows * (pod_words<RM>() / 4);
-    const uint4* src = reinterpret_cast<const uint4*>(a.pod_items + pod0 * pod_words<RM>());
+    constexpr int kPodQuads = pod_words<RM>() / 4;
+    const int n_quads = rows * kPodQuads;
     uint4* dst = reinterpret_cast<uint4*>(pod_lds);
-    if (!(SPX_NRT_ABLATE & 2)) for (int i = threadIdx.x; i < n_quads; i += 256) dst[i] = src[i];
+    if (!listed) {
+      const uint4* src = reinterpret_cast<const uint4*>(a.pod_items + first * pod_words<RM>());
+      if (!(SPX_NRT_ABLATE & 2)) for (int i = threadIdx.x; i < n_quads; i += 256) dst[i] = src[i];
+    } else {  // a record per listed row
+      for (int i = threadIdx.x; i < n_quads; i += 256) {
+        const int p = i / kPodQuads, q = i - p * kPodQuads;
+        dst[i] = reinterpret_cast<const uint4*>(a.pod_items + static_cast<int64_t>(a.row_list[first + p]) * pod_words<RM>())[q];
+      }
+    }
     uint4* z = reinterpret_cast<uint4*>(&stage[0][0][0]) + threadIdx.x;  // empty slots of the window stay 0 (row padding)
 #pragma unroll
     for (int i = 0; i < static_cast<int>(sizeof(stage) / 16 / 256); ++i) z[i * 256] = uint4{0, 0, 0, 0};
@@ -756,6 +771,9 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
     const uint32_t hw[2] = {static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(hv.x))),
                             static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(hv.y)))};
     hv = header(p + 1 < rows ? p + 1 : p);
+    // the first container's item is requested now, ahead of the header decode (container-scope nodes nearly always need it)
+    ItemRegs<RM, FULL> cur;
+    if (w_ctr) cur = load_item<RM, FULL>(pit, 2);
     const int qos = hw[0] & 0xffu;
     const bool non_native = ((hw[0] >> 8) & 0xffu) != 0;
     const int n_ctr = (hw[0] >> 16) & 0xffu;
@@ -800,7 +818,6 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
       // BalancedAllocation scores after the undo.  The next container's item is requested from LDS before this one is worked on.
       uint32_t chosen = 0;  // per app container: the zone it was subtracted from + 1 (0 = not placed), 4 bits each, for the undo
       int sum = 0;
-      ItemRegs<RM, FULL> cur = load_item<RM, FULL>(pit, 2);
       for (int c = 0; c < n_ctr; ++c) {
         const ItemRegs<RM, FULL> nxt = load_item<RM, FULL>(pit, 2 + (c + 1 < kC ? c + 1 : c));
         const Item<RM> it = decode_item<RM, FULL>(cur);
@@ -919,6 +936,7 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
   const int64_t col = base + lane * 4;
   if (col < a.row_stride && !(SPX_NRT_ABLATE & 4)) {
     for (int i = wave; i < rows; i += 4) {
+      const int64_t row = row_of(i);
       const uint32_t b = static_cast<uint32_t>(i & 3);
       const uint32_t pick = 0x0c0c0000u | ((4u + b) << 8) | b;  // v_perm_b32: byte b of the low operand, byte b of the high one, 0, 0
 #pragma unroll
@@ -926,7 +944,7 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
         if ((PH == kPhFilter && tbl == 1) || (PH == kPhScore && tbl == 0)) continue;
         const u32x4 w = *reinterpret_cast<const u32x4*>(&stage[tbl ? kScoreTab : 0][i >> 2][lane * 4]);
         const uint32_t lo = __builtin_amdgcn_perm(w.y, w.x, pick), hi = __builtin_amdgcn_perm(w.w, w.z, pick);
-        uint8_t* out = (tbl ? a.out_score : a.out_status) + (pod0 + i) * a.row_stride + col;
+        uint8_t* out = (tbl ? a.out_score : a.out_status) + row * a.row_stride + col;
         *reinterpret_cast<uint32_t*>(out) = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
       }
     }
@@ -1050,7 +1068,7 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   if (!a.fast) return false;
   if (a.strategy == SPX_NRT_LEAST_NUMA_NODES && !a.ln_tab) return false;
   const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);  // windows of 256 nodes
-  const int64_t chunks = (a.row_end - a.row_begin + kPodsPerUnit - 1) / kPodsPerUnit;
+  const int64_t chunks = ((a.row_list ? a.n_list : a.row_end - a.row_begin) + kPodsPerUnit - 1) / kPodsPerUnit;
   const int64_t per_round = n_tiles >= kXcdMapWindows ? ((n_tiles + 7) / 8) * 8 : n_tiles;
   const unsigned blocks = static_cast<unsigned>(chunks * per_round);  // see the kernel's block map
   const int sg = a.strategy == SPX_NRT_LEAST_NUMA_NODES ? kSgLeastNuma

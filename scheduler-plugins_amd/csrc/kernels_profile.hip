@@ -366,7 +366,23 @@ __global__ __launch_bounds__(64 * kMaxRowWaves) void k_best(ProfileArgs a) {
   }
 }
 
+// Pod equivalence classes: the sweep evaluated one representative row per class; every other member's row is a copy.  One
+// workgroup per copied row and table, 16 bytes per lane; the representatives' rows are few and stay in L2.
+__global__ __launch_bounds__(256) void k_rows_expand(const int32_t* __restrict__ pairs, uint8_t* t0, uint8_t* t1, int64_t row_stride) {
+  const int64_t dst = pairs[2 * static_cast<int64_t>(blockIdx.x)], src = pairs[2 * static_cast<int64_t>(blockIdx.x) + 1];
+  uint8_t* t = blockIdx.y ? t1 : t0;
+  const uint4* from = reinterpret_cast<const uint4*>(t + src * row_stride);
+  uint4* to = reinterpret_cast<uint4*>(t + dst * row_stride);
+  for (int64_t i = threadIdx.x; i < row_stride / 16; i += 256) to[i] = from[i];
+}
+
 }  // namespace
+
+void launch_rows_expand(const int32_t* pairs, int64_t n_pairs, uint8_t* t0, uint8_t* t1, int64_t row_stride, hipStream_t s) {
+  if (n_pairs <= 0 || (!t0 && !t1)) return;
+  if (!t0) t0 = t1, t1 = nullptr;
+  hipLaunchKernelGGL(k_rows_expand, dim3(static_cast<unsigned>(n_pairs), t1 ? 2 : 1), dim3(256), 0, s, pairs, t0, t1, row_stride);
+}
 
 void launch_alloc_masked(const ProfileArgs& a, hipStream_t s) {
   if (a.row_end <= a.row_begin) return;

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include <atomic>
@@ -44,7 +45,7 @@ struct spx_engine {
   int64_t row_stride = 0;
 
   // spx_set_option state (per engine; nothing is read from the environment)
-  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44};
+  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1};
 
   // params
   int32_t alloc_mode = SPX_MODE_LEAST;
@@ -95,6 +96,9 @@ struct spx_engine {
   DevBuf d_nrt_redo;       // BalancedAllocation: list of the cells the float32 Score launch leaves to the float64 form
   uint32_t nrt_redo_cap = 0;
   uint32_t nrt_big_nodes = ~0u, nrt_big_pods = ~0u;  // slots with a capacity / a request (Value() form) of 2^24 or more
+  // pod equivalence classes (spx_upload_nrt_pods): rows whose NRT records agree in everything the sweep reads
+  DevBuf d_nrt_uniq, d_nrt_dups;  // int32 [n_uniq] representative rows, ascending; int32 [n_dups][2] (row, its representative)
+  int64_t nrt_n_uniq = 0, nrt_n_dups = 0;
   bool nrt_ln_ok = false;  // LeastNUMANodes tables can be built: every zone cost within [0, 255]
   bool nrt_ln_built = false;
   std::vector<int32_t> h_nrt_cost;  // [N][Z][Z] host copy of the zone costs, what build_ln_tab works from
@@ -566,6 +570,7 @@ int spx_set_option(spx_engine* e, int option, int64_t value) {
     case SPX_OPT_DECIDE_UNFUSED:
     case SPX_OPT_NRT_SINGLE_LAUNCH:
     case SPX_OPT_COMMIT_FROM_MEMORY:
+    case SPX_OPT_NRT_POD_CLASSES:
       if (value != 0 && value != 1) return fail(e, SPX_ERR_ARG, "option takes 0 or 1");
       break;
     case SPX_OPT_PEAKS_TILE:
@@ -575,6 +580,13 @@ int spx_set_option(spx_engine* e, int option, int64_t value) {
       return fail(e, SPX_ERR_ARG, "unknown option");
   }
   e->option[option] = value;
+  return SPX_OK;
+}
+
+int spx_nrt_pod_classes(const spx_engine* e, int64_t* n_unique, int64_t* n_copies) {
+  if (!e || !n_unique || !n_copies) return SPX_ERR_ARG;
+  *n_copies = e->nrt_pods ? e->nrt_n_dups : 0;
+  *n_unique = e->nrt_pods ? e->n_pods - *n_copies : 0;
   return SPX_OK;
 }
 
@@ -1061,6 +1073,80 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
     e->nrt_fast_pods = ok.load();
     e->nrt_big_pods = big_pods.load();
     SPX_HIP(e, hipStreamSynchronize(e->stream));
+    // Pod equivalence classes.  Two pods get the same NRT rows on every node when their records agree in everything the
+    // sweep reads, and a queue is full of such pods: replicas of one Deployment, and every pod whose verdict does not depend
+    // on quantities — a pod that is not filtered (BestEffort without non-native resources, filter.go:186-190) passes and
+    // scores 100 whatever it asks for; a non-Guaranteed pod scores 100 (score.go:72-76) and its NUMA-affine requests suit any
+    // reporting zone (numaresources.go:137-142), so only their presence counts.  The record is canonicalised accordingly,
+    // hashed, and equal records (verified word for word) share the first such row as their representative.
+    e->nrt_n_uniq = e->nrt_n_dups = 0;
+    if (e->nrt_fast_pods && p > 0) {
+      const size_t PW = 10 * IW;
+      auto canon = [&](size_t i, uint32_t* c) {
+        const uint32_t* w = &items[i * PW];
+        std::memcpy(c, w, PW * sizeof(uint32_t));
+        const uint32_t qos = w[0] & 0xffu, n_ctr = (w[0] >> 16) & 0xffu;
+        const bool non_native = ((w[0] >> 8) & 0xffu) != 0;
+        if (qos == SPX_QOS_BESTEFFORT && !non_native) {  // nothing but the class is read
+          std::memset(c, 0, PW * sizeof(uint32_t));
+          c[0] = qos;
+          return;
+        }
+        for (size_t slot = 2 + n_ctr; slot < 10; ++slot) std::memset(c + slot * IW, 0, IW * sizeof(uint32_t));  // past the last container
+        if (qos != SPX_QOS_GUARANTEED) {
+          c[1] = 0;  // the mean over containers belongs to the Score
+          for (size_t slot = 1; slot < 2 + n_ctr; ++slot) {
+            uint32_t* it = c + slot * IW;
+            const uint32_t sets = it[2 * RMs], fit = (sets >> 8) & 0xffu;
+            for (size_t r = 0; r < static_cast<size_t>(RMs); ++r)
+              if (!((fit >> r) & 1u)) it[2 * r] = it[2 * r + 1] = 0;  // only compared quantities matter
+            it[2 * RMs] = sets & 0xffffff00u;                        // "requested" steers the Score only
+            for (size_t k = 2 * RMs + 1; k < IW; ++k) it[k] = 0;      // weight sums, Value() of the cpu request
+          }
+        }
+      };
+      std::vector<uint64_t> hash(p);
+      spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
+        std::vector<uint32_t> c(PW);
+        for (int64_t i = row0; i < row1; ++i) {
+          canon(static_cast<size_t>(i), c.data());
+          uint64_t h = 0x9e3779b97f4a7c15ull;
+          for (size_t k = 0; k < PW; k += 2) {
+            h ^= (static_cast<uint64_t>(c[k + 1]) << 32) | c[k];
+            h *= 0xff51afd7ed558ccdull;
+            h ^= h >> 29;
+          }
+          hash[static_cast<size_t>(i)] = h;
+        }
+      }, 4096);
+      std::unordered_map<uint64_t, int32_t> rep_of_hash;
+      rep_of_hash.reserve(p);
+      std::vector<int32_t> uniq, dups;
+      std::vector<uint32_t> ca(PW), cb(PW);
+      for (size_t i = 0; i < p; ++i) {
+        auto it = rep_of_hash.find(hash[i]);
+        if (it == rep_of_hash.end()) {
+          rep_of_hash.emplace(hash[i], static_cast<int32_t>(i));
+          uniq.push_back(static_cast<int32_t>(i));
+          continue;
+        }
+        canon(i, ca.data());
+        canon(static_cast<size_t>(it->second), cb.data());
+        if (std::memcmp(ca.data(), cb.data(), PW * sizeof(uint32_t)) == 0) {
+          dups.push_back(static_cast<int32_t>(i));
+          dups.push_back(it->second);
+        } else {
+          uniq.push_back(static_cast<int32_t>(i));  // a hash collision: the row stands for itself
+        }
+      }
+      if (!dups.empty()) {
+        if ((rc = upload(e, e->d_nrt_uniq, uniq.data(), uniq.size() * sizeof(int32_t)))) return rc;
+        if ((rc = upload(e, e->d_nrt_dups, dups.data(), dups.size() * sizeof(int32_t)))) return rc;
+        SPX_HIP(e, hipStreamSynchronize(e->stream));
+        e->nrt_n_uniq = static_cast<int64_t>(uniq.size());
+        e->nrt_n_dups = static_cast<int64_t>(dups.size() / 2);
+      }
+    }
   }
   e->nrt_pods = true;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
@@ -1412,7 +1498,18 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     na.row_end = row_end;
     na.out_status = static_cast<uint8_t*>(e->status[SPX_PLUGIN_NRT].p);
     na.out_score = static_cast<uint8_t*>(e->score[SPX_PLUGIN_NRT].p);
+    // one representative per pod equivalence class when the whole batch is evaluated with the float64 formulation and enough
+    // rows are copies (a partial range may cut a class off from its representative)
+    const bool classes = e->option[SPX_OPT_NRT_POD_CLASSES] && na.fast && !(na.opts & spx::kOptNrtGeneric) && !e->row_indirect &&
+                         row_begin == 0 && row_end == e->n_pods && e->nrt_n_dups > 0 && e->nrt_n_dups * 32 >= e->n_pods &&
+                         !(na.strategy == SPX_NRT_LEAST_NUMA_NODES && !na.ln_tab);
+    if (classes) {
+      na.row_list = static_cast<const int32_t*>(e->d_nrt_uniq.p);
+      na.n_list = e->nrt_n_uniq;
+    }
     spx::launch_nrt(na, e->stream);
+    if (classes)
+      spx::launch_rows_expand(static_cast<const int32_t*>(e->d_nrt_dups.p), e->nrt_n_dups, na.out_status, na.out_score, e->row_stride, e->stream);
     SPX_HIP(e, hipGetLastError());
   }
   if (W) {

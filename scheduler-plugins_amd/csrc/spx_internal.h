@@ -214,6 +214,11 @@ struct NrtArgs {
   int64_t row_begin;
   int64_t row_end;
   const int64_t* row_ptr;  // when set: evaluate the single row *row_ptr (sequential commit: the row counter lives on the device)
+  // pod equivalence classes (float64 formulation only): when set, the sweep evaluates the rows listed here — one representative
+  // per class of pods whose NRT records agree, ascending — instead of [row_begin, row_end); launch_rows_expand copies each
+  // representative's rows to the rest of its class afterwards
+  const int32_t* row_list;
+  int64_t n_list;
   int32_t n_res;
   int32_t strategy;
   uint8_t slot_flags[SPX_NRT_MAX_RES];
@@ -476,6 +481,8 @@ struct ProfileArgs {
   int32_t* best_feasible;
 };
 void launch_alloc_masked(const ProfileArgs& a, hipStream_t s);
+// copies row pairs[2i+1] to row pairs[2i] in up to two uint8 tables of row_stride bytes per row (NULL = skip)
+void launch_rows_expand(const int32_t* pairs, int64_t n_pairs, uint8_t* t0, uint8_t* t1, int64_t row_stride, hipStream_t s);
 void launch_best(const ProfileArgs& a, hipStream_t s);
 
 }  // namespace spx

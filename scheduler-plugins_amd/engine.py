@@ -103,6 +103,12 @@ class Engine:
         self._ck(self._lib.spx_get_option(self._h, option, C.byref(v)))
         return int(v.value)
 
+    def nrt_pod_classes(self):
+        """(representative rows, copied rows) of the uploaded NRT pod batch (spx_nrt_pod_classes); (n_pods, 0) when no two pods agree"""
+        u, d = C.c_int64(), C.c_int64()
+        self._ck(self._lib.spx_nrt_pod_classes(self._h, C.byref(u), C.byref(d)))
+        return int(u.value), int(d.value)
+
     def force_reference_kernels(self, *plugins: int) -> None:
         """run the reference-arithmetic sweep for these plugins (differential tests); no argument = back to the fast forms"""
         self.set_option("REFERENCE_KERNELS", mask_of(*plugins))

@@ -90,6 +90,34 @@ def synth_pods(hdr: Header, n_pods: int, seed: int = SEED, device_res: int = -1,
     )
 
 
+
+def _gather_csr(ptr: np.ndarray, idx: np.ndarray):
+    """rows `idx` of a CSR structure: (new ptr, positions of the gathered entries in the old value arrays)"""
+    cnt = (ptr[1:] - ptr[:-1])[idx]
+    nptr = np.zeros(len(idx) + 1, dtype=np.int32)
+    np.cumsum(cnt, out=nptr[1:])
+    pos = np.repeat(ptr[:-1][idx] - nptr[:-1], cnt) + np.arange(int(nptr[-1]))
+    return nptr, pos
+
+
+def take_pods(hdr: Header, pods: Table, idx) -> Table:
+    """The pod table made of rows `idx` of `pods`, in that order, repeats allowed: a queue of Deployment replicas is
+    take_pods(templates, rng.integers(0, n_templates, n_pods)).  Queue timestamps are renumbered (they are per queue entry)."""
+    idx = np.asarray(idx, dtype=np.int64)
+    ctr_ptr, cpos = _gather_csr(pods.array("ctr_ptr"), idx)
+    req_ptr, rpos = _gather_csr(pods.array("req_ptr"), cpos)
+    lim_ptr, lpos = _gather_csr(pods.array("lim_ptr"), cpos)
+    ovh_ptr, opos = _gather_csr(pods.array("ovh_ptr"), idx)
+    return Table(
+        hdr, "spx_pod_objects", n_pods=len(idx), ctr_ptr=ctr_ptr, ctr_kind=pods.array("ctr_kind")[cpos],
+        req_ptr=req_ptr, req_res=pods.array("req_res")[rpos], req_qty=pods.array("req_qty")[rpos],
+        lim_ptr=lim_ptr, lim_res=pods.array("lim_res")[lpos], lim_qty=pods.array("lim_qty")[lpos],
+        ovh_ptr=ovh_ptr, ovh_res=pods.array("ovh_res")[opos], ovh_qty=pods.array("ovh_qty")[opos],
+        priority=pods.array("priority")[idx], queue_ts=np.arange(len(idx), dtype=np.int64) * 1000 + 1_700_000_000_000_000,
+        appgroup=pods.array("appgroup")[idx], selector=pods.array("selector")[idx], ns=pods.array("ns")[idx],
+    )
+
+
 def synth_nodes(hdr: Header, n_nodes: int, seed: int = SEED, device_res: int = -1, n_regions: int = 8,
                 zones_per_region: int = 8) -> Table:
     rng = np.random.default_rng(seed + 2)

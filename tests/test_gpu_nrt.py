@@ -261,6 +261,51 @@ def test_partial_rows_and_mixed_plugins(gpu_required, hdr, oracle):
         assert np.array_equal(e.all_scores(NRT).astype(np.int64), osnap.score_rows(NRT, want_norm=False)[0].clip(0, 255))
 
 
+
+# ------------------------------------------------------------------ pod equivalence classes (SPX_OPT_NRT_POD_CLASSES)
+@pytest.mark.parametrize("strategy", ["LeastAllocated", "MostAllocated", "BalancedAllocation", "LeastNUMANodes"])
+def test_pod_classes_replicated_queue(gpu_required, hdr, oracle, strategy):
+    """A queue of Deployment replicas (700 pods drawn from 60 templates, shuffled): the whole-batch sweep evaluates one row per
+    class of pods with equal NRT records and copies it; every row must equal the oracle's and the table computed row by row
+    with the option off.  Rows evaluated in slices never use the classes (a slice may not hold the representative)."""
+    n_nodes, n_pods = 300, 700
+    snap = synth.nrt_snapshot(hdr, n_nodes, 60, seed=21)
+    rng = np.random.default_rng(5)
+    pods = synth.take_pods(hdr, snap["pods"], rng.integers(0, 60, n_pods))
+    params = O.nrt_params(hdr, O.Resources(), strategy)
+    osnap = oracle.Snapshot(snap["nodes"], pods, rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
+    want_status = osnap.filter_rows(NRT)
+    want_score = osnap.score_rows(NRT, want_norm=False)[0].clip(0, 255)
+    with Engine(0) as e:
+        assert e.get_option("NRT_POD_CLASSES") == 1
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], pods, params)
+        uniq, dups = e.nrt_pod_classes()
+        assert uniq + dups == n_pods and uniq <= 60 and dups >= n_pods - 60
+        e.eval(mask_of(NRT))
+        e.sync()
+        got_status, got_score = e.all_status(NRT), e.all_scores(NRT).astype(np.int64)
+        assert np.array_equal(got_status, want_status)
+        assert np.array_equal(got_score, want_score)
+        e.set_option("NRT_POD_CLASSES", 0)
+        e.eval(mask_of(NRT))
+        e.sync()
+        assert np.array_equal(e.all_status(NRT), got_status) and np.array_equal(e.all_scores(NRT).astype(np.int64), got_score)
+        e.set_option("NRT_POD_CLASSES", 1)
+        for b, en in [(0, 333), (333, 700)]:  # slices: plain rows
+            e.eval(mask_of(NRT), b, en)
+        e.sync()
+        assert np.array_equal(e.all_status(NRT), want_status) and np.array_equal(e.all_scores(NRT).astype(np.int64), want_score)
+
+
+def test_pod_classes_of_the_synthetic_queue(gpu_required, hdr):
+    """the synthetic batch has no replicas, yet nearly half of it collapses: BestEffort pods are not filtered and score 100,
+    non-Guaranteed pods score 100 and only the presence of their NUMA-affine requests counts (canonical records)"""
+    snap = synth.nrt_snapshot(hdr, 64, 4000, seed=2)
+    with Engine(0) as e:
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], O.nrt_params(hdr, O.Resources(), "LeastAllocated"))
+        uniq, dups = e.nrt_pod_classes()
+        assert uniq + dups == 4000 and dups > 1200
+
 # ------------------------------------------------------------------ full size (config #3): sampled rows + properties
 def test_config3_full_size_properties(gpu_required, hdr, oracle):
     n_nodes, n_pods = 5_000, 50_000
