@@ -55,11 +55,13 @@ WORKLOADS = {
                              desc="noderesourcetopology Filter+Score (BalancedAllocation), 5k nodes x 8 NUMA zones x 50k pods"),
     "config4": dict(n_nodes=10_000, n_pods=200_000, plugins=("net",), node_row=4, pod_row=48, out=2, scaling="strong",
                     desc="networkaware NetworkOverhead (+TopologicalSort keys), 10k nodes x 3-tier topology x 200k pods sharded over the GPUs"),
-    "config5": dict(n_nodes=20_000, n_pods=500_000, plugins=("cap", "alloc", "tlp", "lvrb", "nrt", "net"), node_row=405, pod_row=188, out=7,
+    # out: SURVEY.md 8d counts 4 score tables + LVRB's + ONE status byte per eval = 6 (the engine keeps two status tables, NRT's
+    # and NetworkOverhead's: the seventh byte it writes is not algorithmic)
+    "config5": dict(n_nodes=20_000, n_pods=500_000, plugins=("cap", "alloc", "tlp", "lvrb", "nrt", "net"), node_row=405, pod_row=188, out=6,
                     strategy="LeastAllocated", scaling="strong",
                     desc="full profile: CapacityScheduling PreFilter + Allocatable + TLP + LVRB + NRT + NetworkOverhead, 20k nodes x 500k pods sharded over the GPUs"),
     # config5's one-GPU share of the 8-GPU job (62.5k of the 500k pods), as a single-device workload
-    "config5_share": dict(n_nodes=20_000, n_pods=62_500, plugins=("cap", "alloc", "tlp", "lvrb", "nrt", "net"), node_row=405, pod_row=188, out=7,
+    "config5_share": dict(n_nodes=20_000, n_pods=62_500, plugins=("cap", "alloc", "tlp", "lvrb", "nrt", "net"), node_row=405, pod_row=188, out=6,
                           strategy="LeastAllocated",
                           desc="full profile, 20k nodes x 62.5k pods (= one GPU's share of config5 on 8)"),
     # the reference's own benchmark shapes: BenchmarkTargetLoadPackingPlugin (targetloadpacking_test.go:283-384:
@@ -77,6 +79,16 @@ WORKLOADS = {
                           desc="BenchmarkNetworkOverhead*/10000 nodes: AppGroups of 11 workloads (onlineboutique), 10000 nodes x 11000 pods"),
     "small": dict(n_nodes=1_000, n_pods=4_000, plugins=("alloc", "tlp"), node_row=41, pod_row=8, out=2,
                   desc="plumbing-sized Allocatable + TLP"),
+    # plumbing-sized strong-scaling shapes: what tests/test_gpu_bench.py runs through `--devices 0,0` on a one-GPU box
+    "small_net": dict(n_nodes=2_000, n_pods=8_000, plugins=("net",), node_row=4, pod_row=48, out=2, scaling="strong",
+                      desc="plumbing-sized NetworkOverhead (+TopologicalSort keys), 2k nodes x 8k pods sharded over the GPUs"),
+    "small_full": dict(n_nodes=2_000, n_pods=8_000, plugins=("cap", "alloc", "tlp", "lvrb", "nrt", "net"), node_row=405, pod_row=188, out=6,
+                       strategy="LeastAllocated", scaling="strong",
+                       desc="plumbing-sized full profile, 2k nodes x 8k pods sharded over the GPUs"),
+    # BASELINE.json configs[0]: noderesources.Allocatable (LeastAllocated) on 100 nodes x 1k pods — the reference's own CPU-runnable
+    # case (test/integration/allocatable_test.go through hack/integration-test.sh); here the same shape through the C ABI
+    "config1": dict(n_nodes=100, n_pods=1_000, plugins=("alloc",), node_row=16, pod_row=0, out=1,
+                    desc="noderesources.Allocatable (LeastAllocated), 100 nodes x 1k pods (plumbing)"),
 }
 PID = {"alloc": 0, "tlp": 1, "lvrb": 2, "nrt": 3, "net": 4, "cap": 5, "lroc": 7, "peaks": 8}
 
@@ -553,7 +565,7 @@ def main() -> None:
         "data": "synthetic",
         "config": {"workload": w["desc"], "n_nodes": n_nodes, "n_pods_per_step": n_pods_total, "n_pods_slowest_rank": int(local_pods),
                    "plugins": list(w["plugins"]),
-                   "host": {"single": "one process, one device", "multi": f"one process driving {world} devices through spx_multi (C ABI)",
+                   "host": {"single": "one process, one device (`--gpus 1` IS this path: the N=1 point of a scaling curve is this line's value)", "multi": f"one process driving {world} devices through spx_multi (C ABI)",
                             "ranks": f"{world} processes, one per device (torch.distributed.run)"}[mode],
                    "sharding": "pod rows per device, node tables replicated, no data-path collective",
                    "result_tables": "uint8 [pods][nodes] per plugin, resident in HBM"},

@@ -376,27 +376,34 @@ __device__ __forceinline__ int score_balanced_f32(const BalNode<RM>& bn, int nz,
   float value[RM];
 #pragma unroll
   for (int r = 0; r < RM; ++r) value[r] = static_cast<float>(r == cpu_slot ? it.cpu_v : it.raw[r]);
+  // resource outside, zone inside (the requested-slot test is a scalar branch; see score_each_fast): per-zone accumulators
+  float sum[kZ], sq[kZ], mxd[kZ], nr[kZ];
+#pragma unroll
+  for (int z = 0; z < kZ; ++z) sum[z] = 0.0f, sq[z] = 0.0f, mxd[z] = -kBalNoCap, nr[z] = -1.0f;
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    if (!((used >> r) & 1u)) continue;  // uniform
+    SPX_KEEP_BRANCH();
+    const bool inexact = !((exact32 >> r) & 1u);  // uniform
+#pragma unroll
+    for (int z = 0; z < kZ; ++z) {
+      const float f = __builtin_fmaf(value[r], bn.rcp[z][r], bn.one[z][r]);
+      const float d = value[r] - bn.capf[z][r];
+      mxd[z] = __builtin_fmaxf(mxd[z], d);
+      if (inexact) nr[z] = __builtin_fmaxf(nr[z], __builtin_fmaf(bn.capf[z][r], kBalTol, -__builtin_fabsf(d)));
+      sum[z] += f;
+      sq[z] = __builtin_fmaf(f, f, sq[z]);
+    }
+  }
   float best = __builtin_inff();
   bool undecided = false;
 #pragma unroll
   for (int z = 0; z < kZ; ++z) {
-    float sum = 0.0f, sq = 0.0f, mxd = -kBalNoCap, nr = -1.0f;
-#pragma unroll
-    for (int r = 0; r < RM; ++r) {
-      if (!((used >> r) & 1u)) continue;  // uniform
-      SPX_KEEP_BRANCH();
-      const float f = __builtin_fmaf(value[r], bn.rcp[z][r], bn.one[z][r]);
-      const float d = value[r] - bn.capf[z][r];
-      mxd = __builtin_fmaxf(mxd, d);
-      if (!((exact32 >> r) & 1u)) nr = __builtin_fmaxf(nr, __builtin_fmaf(bn.capf[z][r], kBalTol, -__builtin_fabsf(d)));  // uniform
-      sum += f;
-      sq = __builtin_fmaf(f, f, sq);
-    }
-    const float var = __builtin_fmaf(-(sum * sum), rn, sq) * rm;
+    const float var = __builtin_fmaf(-(sum[z] * sum[z]), rn, sq[z]) * rm;
     const float sc = __builtin_fmaf(-var, 100.0f, 100.0f);
     const bool exists = z < nz;
-    undecided |= exists && nr >= 0.0f;
-    best = (exists && !(mxd > 0.0f)) ? __builtin_fminf(best, sc) : best;
+    undecided |= exists && nr[z] >= 0.0f;
+    best = (exists && !(mxd[z] > 0.0f)) ? __builtin_fminf(best, sc) : best;
   }
   const bool has = best < __builtin_inff();
   const float fl = __builtin_floorf(best), frac = best - fl;
@@ -459,7 +466,11 @@ __device__ __forceinline__ uint32_t ln_dword(const double (&lo)[16], const doubl
   return f;
 }
 
-// fall &= { S : sum over S of v[z] >= want }
+// fall &= { S : sum over S of v[z] >= want }, for the dwords [D0, D1) of the layout.  The partial-sum tables are indexed by
+// compile-time constants: a call that only covers sizes 1 and 2 (dwords 0 and 1) builds just the entries those subsets touch.
+constexpr int kLnSmall = 2;  // dwords holding the subsets of sizes 1 and 2 (8 + 28)
+static_assert(make_ln_layout().first[3] == kLnSmall, "sizes 1 and 2 occupy the first two dwords");
+template <int D0, int D1>
 __device__ __forceinline__ void ln_resource(uint32_t (&fall)[kLnDwords], const double (&v)[kZ], double want) {
   double lo[16], thr[16];
   lo[0] = 0.0;
@@ -471,44 +482,79 @@ __device__ __forceinline__ void ln_resource(uint32_t (&fall)[kLnDwords], const d
   }
 #pragma unroll
   for (int m = 0; m < 16; ++m) thr[m] = want - thr[m];
-  static_for<kLnDwords>([&](auto d) { fall[decltype(d)::value] &= ln_dword<decltype(d)::value>(lo, thr); });
+  static_for<D1 - D0>([&](auto d) { fall[D0 + decltype(d)::value] &= ln_dword<D0 + decltype(d)::value>(lo, thr); });
 }
 
 // `choice`: the caller needs the reference's subset itself (a later container is charged against it); otherwise only
 // its size and is_min are read and the distance ranks are not consulted.
 template <int RM>
 __device__ __forceinline__ uint32_t numa_required_fast(const FastNode<RM>& ns, const NrtArgs& a, const Item<RM>& it, int64_t n, bool active,
-                                                       bool choice, const uint32_t (&mmin)[kLnDwords], const uint8_t* subset_lds, bool* is_min) {
+                                                       bool choice, const uint32_t (&mmin)[kLnDwords], const uint8_t* subset_lds,
+                                                       const uint32_t* allow_lds, const double (&tot_all)[RM], bool* is_min) {
   *is_min = false;
   if (__ballot(active) == 0) return 0;
   const uint32_t used = it.used, need = it.fit | it.always;
-  // a valid subset lies inside V = the zones reporting every requested resource (isValidCombineResources); a zone outside
-  // V enters the sums as -1e300, so that no subset containing it reaches any request
+  // a valid subset lies inside V = the zones reporting every requested resource (isValidCombineResources): the bit set starts
+  // as { S : S inside V } — a per-block LDS table indexed by V — and the sums use the table as it is (an unreported cell holds -1;
+  // the subsets it would spoil are not in the set)
   uint32_t v_all = active ? 0xffu : 0u;
 #pragma unroll
   for (int r = 0; r < RM; ++r)
     if ((used >> r) & 1u) v_all &= ns.repmask(r);
+  const uint32_t* allow = allow_lds + v_all * kLnDwords;
   uint32_t fall[kLnDwords];
 #pragma unroll
-  for (int d = 0; d < kLnDwords; ++d) fall[d] = 0xffffffffu;
-  // one pass per compared resource; a request of zero quantities compares nothing, and every subset of V "fits": that
-  // is the pass over the pseudo resource RM (no quantity anywhere, nothing wanted).  The resource index is wave-uniform,
-  // so picking its column is a handful of scalar-conditioned moves and the 255-subset sequence exists once in the code.
-  uint32_t todo = need ? need : (1u << RM);
-  while (todo) {
+  for (int d = 0; d < kLnSmall; ++d) fall[d] = allow[d];
+  // One pass per compared resource; a request of zero quantities compares nothing, and every subset of V "fits": that is the
+  // pass over the pseudo resource RM (no quantity anywhere, nothing wanted).  The resource index is wave-uniform: its column is
+  // picked by a scalar branch (as selects the eight doubles cost 64 v_cndmask per resource, more than the first pass's compares).
+  //
+  // Round 3: two passes.  71 % of config #3's (container, node) pairs fit one zone, 11 % two, 9 % no subset at all (the zones'
+  // total is short) — so the first pass evaluates the 36 subsets of sizes 1 and 2, and only when some lane of the wave is
+  // still open (the node's total suffices but no single zone or pair does) does the wave run the other 219 subsets.  The engine
+  // orders the nodes of a window by how tight their largest zones are, so that such lanes share waves.
+  auto column = [&](int r, double (&v)[kZ], double* want, double* total) {
+    double w = 0.0, tot = 0.0;
+#pragma unroll
+    for (int z = 0; z < kZ; ++z) v[z] = 0.0;
+#pragma unroll
+    for (int q = 0; q < RM; ++q)
+      if (r == q) {  // uniform
+        SPX_KEEP_BRANCH();
+        w = it.raw[q];
+        tot = tot_all[q];
+#pragma unroll
+        for (int z = 0; z < kZ; ++z) v[z] = ns.av[z][q];
+      }
+    *want = w;
+    *total = tot;
+  };
+  const uint32_t todo0 = need ? need : (1u << RM);
+  // tot_all: what the node's zones held at the start of the pod (an upper bound once earlier containers were charged): a lane
+  // it closes can hold no subset; a lane it fails to close merely takes the second pass
+  bool feasible = active;
+  for (uint32_t todo = todo0; todo;) {
     const int r = __builtin_ctz(todo);
     todo &= todo - 1;
-    double v[kZ], want = 0.0;
+    double v[kZ], want, total;
+    column(r, v, &want, &total);
+    feasible &= total >= want;
+    ln_resource<0, kLnSmall>(fall, v, want);
+  }
+  const bool open = feasible && (fall[0] | fall[1]) == 0;
+  if (__ballot(open) != 0) {
 #pragma unroll
-    for (int q = 0; q < RM; ++q) want = r == q ? it.raw[q] : want;
-#pragma unroll
-    for (int z = 0; z < kZ; ++z) {
-      double x = 0.0;
-#pragma unroll
-      for (int q = 0; q < RM; ++q) x = r == q ? ns.av[z][q] : x;
-      v[z] = ((v_all >> z) & 1u) ? x : -1e300;
+    for (int d = kLnSmall; d < kLnDwords; ++d) fall[d] = allow[d];
+    for (uint32_t todo = todo0; todo;) {
+      const int r = __builtin_ctz(todo);
+      todo &= todo - 1;
+      double v[kZ], want, total;
+      column(r, v, &want, &total);
+      ln_resource<kLnSmall, kLnDwords>(fall, v, want);
     }
-    ln_resource(fall, v, want);
+  } else {
+#pragma unroll
+    for (int d = kLnSmall; d < kLnDwords; ++d) fall[d] = 0u;  // nobody needs a larger subset: closed lanes hold sizes 1-2, the others nothing
   }
   // the smallest size with a fitting subset: its candidates c, those of them at the node's minimum distance h
   uint32_t c[3] = {0, 0, 0}, h[3] = {0, 0, 0};
@@ -642,7 +688,7 @@ constexpr int kPhBoth = 0, kPhFilter = 1, kPhScore = 2;
 #define SPX_NRT_LB_MOST 4
 #endif
 #ifndef SPX_NRT_LB_BAL
-#define SPX_NRT_LB_BAL 4
+#define SPX_NRT_LB_BAL 3
 #endif
 #ifndef SPX_NRT_LB_BOTH
 #define SPX_NRT_LB_BOTH 3
@@ -672,6 +718,12 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
   __shared__ __align__(16) uint32_t stage[kScoreTab + 1][kPodsPerUnit / 4][kWindow];
   __shared__ __align__(16) uint32_t pod_lds[kPodsPerUnit * pod_words<RM>()];  // the chunk's pod records (20 KB for <= 4 slots)
   __shared__ uint8_t ln_subset[SG == kSgLeastNuma ? kLnDwords * 32 : 1];  // LeastNUMANodes: bit position -> zone mask
+  __shared__ uint32_t ln_allow[SG == kSgLeastNuma ? 256 * kLnDwords : 1];  // ... zone set V -> the subsets inside V, in the bit layout
+  // BalancedAllocation, float32 Score launch: the cells it leaves to the float64 form, collected per block and appended to the
+  // global list with ONE atomic (round 2 found them again by scanning the 0.25 GB score table: 0.5 ms)
+  constexpr int kRedoBuf = (SG == kSgBalanced && PH == kPhScore) ? 1024 : 1;
+  __shared__ uint32_t redo_buf[kRedoBuf][2];
+  __shared__ uint32_t redo_n, redo_base;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // Blocks are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD has its own L2.  Each XCD
@@ -729,7 +781,25 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
   for (int d = 0; d < kLnDwords; ++d) mmin[d] = (SG == kSgLeastNuma && in) ? a.ln_tab[static_cast<int64_t>(d) * a.n_nodes + n] : 0u;
   if constexpr (SG == kSgLeastNuma) {
     for (int i = threadIdx.x; i < kLnDwords * 32; i += blockDim.x) ln_subset[i] = kLnDev.subset[i >> 5][i & 31];
+    for (int i = threadIdx.x; i < 256 * kLnDwords; i += blockDim.x) {
+      const uint32_t vset = static_cast<uint32_t>(i / kLnDwords), d = static_cast<uint32_t>(i % kLnDwords);
+      uint32_t bits = 0;
+      for (int q = 0; q < 32; ++q) {
+        const uint32_t sub = kLnDev.subset[d][q];
+        if (sub != 0 && (sub & ~vset) == 0) bits |= 1u << q;
+      }
+      ln_allow[i] = bits;
+    }
     __syncthreads();
+  }
+  double ln_tot[RM];  // LeastNUMANodes: what the node's zones hold per resource (first-pass bound of numa_required_fast)
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    ln_tot[r] = 0.0;
+    if constexpr (SG == kSgLeastNuma) {
+#pragma unroll
+      for (int z = 0; z < kZ; ++z) ln_tot[r] += __builtin_fmax(ns.av[z][r], 0.0);
+    }
   }
   const bool fresh = flags & SPX_NRT_F_FRESH;
   const bool has_nrt = flags & SPX_NRT_F_HAS_NRT;
@@ -750,6 +820,7 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
         dst[i] = reinterpret_cast<const uint4*>(a.pod_items + static_cast<int64_t>(a.row_list[first + p]) * pod_words<RM>())[q];
       }
     }
+    if (threadIdx.x == 0) redo_n = 0;
     uint4* z = reinterpret_cast<uint4*>(&stage[0][0][0]) + threadIdx.x;  // empty slots of the window stay 0 (row padding)
 #pragma unroll
     for (int i = 0; i < static_cast<int>(sizeof(stage) / 16 / 256); ++i) z[i * 256] = uint4{0, 0, 0, 0};
@@ -866,7 +937,27 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
       }
       if (want_score) score = static_cast<int>((static_cast<uint32_t>(sum) * inv_n) >> 16);  // int64(mean): sum / n_ctr, sum <= 800
     }
-    if constexpr (kBalF32) score = (want_score && redo) ? kBalRedo : score;  // k_nrt_bal_scan / k_nrt_bal_redo recompute the cell in float64
+    if constexpr (kBalF32) {
+      const bool mark = want_score && redo;
+      score = mark ? kBalRedo : score;  // k_nrt_bal_redo recomputes the cell in float64
+      const uint64_t mm = __ballot(mark);
+      if (mm != 0) {  // wave-uniform: one LDS atomic per wave and pod
+        const int leader = __builtin_ctzll(mm);
+        uint32_t at = 0;
+        if (lane == leader) at = atomicAdd(&redo_n, static_cast<uint32_t>(__builtin_popcountll(mm)));
+        at = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(at), leader)) +
+             static_cast<uint32_t>(__builtin_popcountll(mm & ((1ull << lane) - 1ull)));
+        if (mark) {
+          const uint32_t row = static_cast<uint32_t>(row_of(p));
+          if (at < static_cast<uint32_t>(kRedoBuf)) {
+            redo_buf[at][0] = row, redo_buf[at][1] = static_cast<uint32_t>(n);
+          } else {  // the block's buffer is full (a window of exactly-integer scores): straight to the global list
+            const uint32_t g = atomicAdd(a.redo_list, 1u);
+            if (g < a.redo_cap) a.redo_list[2 + 2 * static_cast<size_t>(g)] = row, a.redo_list[3 + 2 * static_cast<size_t>(g)] = static_cast<uint32_t>(n);
+          }
+        }
+      }
+    }
     }  // the pod has something to compute
 
     if constexpr (SG == kSgLeastNuma) {
@@ -888,7 +979,7 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
           if ((it.used >> r) & 1u) any_rep |= ns.repmask(r);
         const bool go = mine && !failed && any_rep != 0;  // any_rep == 0: onlyNonNUMAResources, the item is passed over
         bool is_min;
-        const uint32_t m = numa_required_fast(ns, a, it, n, go, c >= 0 && c + 1 < n_ctr, mmin, ln_subset, &is_min);
+        const uint32_t m = numa_required_fast(ns, a, it, n, go, c >= 0 && c + 1 < n_ctr, mmin, ln_subset, ln_allow, ln_tot, &is_min);
         if (go) {
           if (m == 0) {
             failed = true;
@@ -932,6 +1023,17 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
     return;
   }
   __syncthreads();
+  if constexpr (kBalF32) {
+    const uint32_t cnt = redo_n < static_cast<uint32_t>(kRedoBuf) ? redo_n : static_cast<uint32_t>(kRedoBuf);
+    if (cnt != 0) {  // block-uniform
+      if (threadIdx.x == 0) redo_base = atomicAdd(a.redo_list, cnt);
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+        const uint32_t g = redo_base + i;  // past the capacity: the count says so and k_nrt_bal_scan takes over
+        if (g < a.redo_cap) a.redo_list[2 + 2 * static_cast<size_t>(g)] = redo_buf[i][0], a.redo_list[3 + 2 * static_cast<size_t>(g)] = redo_buf[i][1];
+      }
+    }
+  }
   // rows leave as whole 256-byte segments: lane l gathers byte (row & 3) of the four dwords of nodes 4l .. 4l+3
   const int64_t col = base + lane * 4;
   if (col < a.row_stride && !(SPX_NRT_ABLATE & 4)) {
@@ -984,6 +1086,9 @@ constexpr int kScanThreads = 1024;
 template <int RM>
 __global__ __launch_bounds__(kScanThreads) void k_nrt_bal_scan(NrtArgs a) {
   SPX_RESOLVE_ROWS(a);
+  // the Score launch lists its undecided cells itself; this pass only runs when they did not all fit the list — it then finds
+  // every cell still marked and recomputes it where it is (the list is full: `at` below is past the capacity)
+  if (a.redo_list[0] <= a.redo_cap) return;
   __shared__ uint32_t wave_total[kScanThreads / 64];
   __shared__ uint32_t block_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1035,7 +1140,7 @@ __global__ __launch_bounds__(kScanThreads) void k_nrt_bal_scan(NrtArgs a) {
     const int j = __builtin_ctz(marks);
     marks &= marks - 1;
     if (at < a.redo_cap) {
-      a.redo_list[2 + 2 * static_cast<size_t>(at)] = static_cast<uint32_t>(pod - a.row_begin);
+      a.redo_list[2 + 2 * static_cast<size_t>(at)] = static_cast<uint32_t>(pod);
       a.redo_list[3 + 2 * static_cast<size_t>(at)] = static_cast<uint32_t>(col + j);
     } else {
       cells[j] = static_cast<uint8_t>(balanced_cell_exact<RM>(a, pod, col + j));
@@ -1053,7 +1158,7 @@ __global__ __launch_bounds__(256) void k_nrt_bal_redo(NrtArgs a) {
   const uint32_t count = a.redo_list[0] < a.redo_cap ? a.redo_list[0] : a.redo_cap;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  const int64_t pod = a.row_begin + a.redo_list[2 + 2 * static_cast<size_t>(i)];
+  const int64_t pod = a.redo_list[2 + 2 * static_cast<size_t>(i)];  // absolute row
   const int64_t n = a.redo_list[3 + 2 * static_cast<size_t>(i)];
   a.out_score[pod * a.row_stride + n] = static_cast<uint8_t>(balanced_cell_exact<RM>(a, pod, n));
   if (a.stats && (threadIdx.x & 63) == 0) {  // one update per wave: the live lanes of the wave
@@ -1078,10 +1183,10 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                                        \
     if (split) { /* the Filter half does not depend on the strategy */ \
       hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhFilter>), dim3(blocks), dim3(256), 0, s, a, n_tiles); \
+      if (SGV == kSgBalanced) (void)hipMemsetAsync(a.redo_list, 0, 8, s); /* the float32 Score launch lists the cells it could not decide */ \
       hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
-      if (SGV == kSgBalanced) { /* float32 Score launch: the cells it could not decide, compacted and recomputed in float64 */ \
+      if (SGV == kSgBalanced) { /* ... recomputed in float64 from the list; the scan pass only acts when the list overflowed */ \
         const int64_t units = (a.row_end - a.row_begin) * (a.row_stride / 16); \
-        (void)hipMemsetAsync(a.redo_list, 0, 8, s); \
         hipLaunchKernelGGL((k_nrt_bal_scan<RMV>), dim3(static_cast<unsigned>((units + kScanThreads - 1) / kScanThreads)), dim3(kScanThreads), 0, s, a); \
         hipLaunchKernelGGL((k_nrt_bal_redo<RMV>), dim3((a.redo_cap + 255) / 256), dim3(256), 0, s, a); \
       } \

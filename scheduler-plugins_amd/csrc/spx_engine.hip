@@ -15,6 +15,7 @@
 #include <vector>
 
 #include <atomic>
+#include <mutex>
 
 #include "spx_internal.h"
 #include "../host/parallel.hpp"
@@ -38,7 +39,11 @@ struct spx_engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool hold_ev0 = false;  // spx_decide times its preparatory spx_eval together with its own sweep
   bool timed = false;
+  // last error: the engine's own copy (whoever failed last) under a lock; every thread also keeps the text of ITS last failure
+  // (spx_last_error returns thread-local storage: concurrent readers may fail concurrently)
   mutable std::string err;
+  mutable std::mutex err_mu;
+  std::mutex raw_mu;  // spx_fetch_raw launches on the engine stream into one scratch row: concurrent callers take turns
 
   int64_t n_nodes = -1;
   int64_t n_pods = -1;
@@ -164,9 +169,20 @@ struct spx_engine {
 
 namespace {
 
+thread_local std::string tl_err;              // this thread's last failure ...
+thread_local const spx_engine* tl_err_engine = nullptr;  // ... and on which engine
+
 int fail(const spx_engine* e, int code, const std::string& msg) {
-  if (e) e->err = msg;
-  else g_create_error = msg;
+  if (e) {
+    {
+      std::lock_guard<std::mutex> g(e->err_mu);
+      e->err = msg;
+    }
+    tl_err = msg;
+    tl_err_engine = e;
+  } else {
+    g_create_error = msg;
+  }
   return code;
 }
 
@@ -475,7 +491,15 @@ extern "C" {
 
 int spx_abi_version(void) { return 1; }
 
-const char* spx_last_error(const spx_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+const char* spx_last_error(const spx_engine* e) {
+  if (!e) return g_create_error.c_str();
+  if (tl_err_engine != e) {  // this thread has not failed on this engine: hand out a private copy of the engine's last message
+    std::lock_guard<std::mutex> g(e->err_mu);
+    tl_err = e->err;
+    tl_err_engine = e;
+  }
+  return tl_err.c_str();
+}
 
 int spx_create(int device_id, spx_engine** out) {
   if (!out) return fail(nullptr, SPX_ERR_ARG, "out is NULL");
@@ -865,20 +889,48 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
     e->nrt_fast_nodes = ok.load();
     e->nrt_big_nodes = big_nodes.load();
     // window-local node order: inside each run of 256 nodes, group the nodes by the code path their flags select
-    // (not aligned / pod scope / container scope) so that wavefronts are mostly homogeneous
+    // (not aligned / pod scope / container scope) so that wavefronts are mostly homogeneous; inside a group, by how tight the
+    // node's two largest zones are (the smaller of its ranks, within the window, by the sum of the two largest zone quantities of
+    // slot 0 and of slot 1 — cpu and memory): LeastNUMANodes' second pass runs for a wave when one of its lanes needs more than two
+    // zones, and those lanes are the tight nodes — sorted, they share waves (config #3: 69 % -> 37 % of the waves)
     const int64_t n_slots = spx::round_up(n, 256);
     std::vector<int32_t> perm(static_cast<size_t>(n_slots), -1);
-    for (int64_t w0 = 0; w0 < n; w0 += 256) {
+    spx_host::parallel_rows((n + 255) / 256, [&](int64_t win0, int64_t win1) {
+    for (int64_t w0 = win0 * 256; w0 < std::min<int64_t>(win1 * 256, n); w0 += 256) {
       const int64_t w1 = std::min<int64_t>(w0 + 256, n);
-      int64_t k = w0;
-      for (int cls = 0; cls < 3; ++cls)
-        for (int64_t i = w0; i < w1; ++i) {
-          const uint8_t f = t->flags[i];
-          const bool aligned = (f & SPX_NRT_F_FRESH) && (f & SPX_NRT_F_HAS_NRT) && (f & SPX_NRT_F_SINGLE_NUMA);
-          const int c = !aligned ? 0 : ((f & SPX_NRT_F_POD_SCOPE) ? 1 : 2);
-          if (c == cls) perm[static_cast<size_t>(k++)] = static_cast<int32_t>(i);
+      const int cnt = static_cast<int>(w1 - w0);
+      int rank[2][256];
+      for (int slot = 0; slot < 2; ++slot) {
+        int64_t top2[256];
+        int order[256];
+        for (int k = 0; k < cnt; ++k) {
+          const int64_t i = w0 + k;
+          int64_t a = 0, b = 0;  // the two largest
+          if (slot < R)
+            for (int z = 0; z < t->n_zones[i] && z < Zm; ++z) {
+              if (!((t->zone_present[i * Zm + z] >> slot) & 1u)) continue;
+              const int64_t q = t->zone_avail[(i * Zm + z) * R + slot];
+              if (q > a) b = a, a = q;
+              else if (q > b) b = q;
+            }
+          top2[k] = a + b;
+          order[k] = k;
         }
+        std::stable_sort(order, order + cnt, [&](int x, int y) { return top2[x] < top2[y]; });
+        for (int k = 0; k < cnt; ++k) rank[slot][order[k]] = k;
+      }
+      int order[256], cls_of[256], key[256];
+      for (int k = 0; k < cnt; ++k) {
+        const uint8_t f = t->flags[w0 + k];
+        const bool aligned = (f & SPX_NRT_F_FRESH) && (f & SPX_NRT_F_HAS_NRT) && (f & SPX_NRT_F_SINGLE_NUMA);
+        cls_of[k] = !aligned ? 0 : ((f & SPX_NRT_F_POD_SCOPE) ? 1 : 2);
+        key[k] = std::min(rank[0][k], rank[1][k]);
+        order[k] = k;
+      }
+      std::stable_sort(order, order + cnt, [&](int x, int y) { return cls_of[x] != cls_of[y] ? cls_of[x] < cls_of[y] : key[x] < key[y]; });
+      for (int k = 0; k < cnt; ++k) perm[static_cast<size_t>(w0 + k)] = static_cast<int32_t>(w0 + order[k]);
     }
+    }, 16);
     if ((rc = upload(e, e->d_nrt_perm, perm.data(), perm.size() * sizeof(int32_t)))) return rc;
     // LeastNUMANodes' per-node tables are built when that strategy is first evaluated (build_ln_tab): they cost more host time
     // than everything else in this call and the default strategy never reads them.  Here: the host copy they are built from,
@@ -1352,6 +1404,7 @@ int spx_fetch_prefilter(spx_engine* e, int plugin, int64_t row_begin, int64_t ro
     return fail(e, SPX_ERR_STATE, "CapacityScheduling.PreFilter has not been evaluated");
   if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
   if (int rc = rows_evaluated(e, SPX_PLUGIN_CAPACITY, row_begin, row_end)) return rc;
+  SPX_HIP(e, hipSetDevice(e->device));
   SPX_HIP(e, hipMemcpy(out, static_cast<const uint8_t*>(e->d_q_status.p) + row_begin, static_cast<size_t>(row_end - row_begin),
                        hipMemcpyDeviceToHost));
   return SPX_OK;
@@ -1891,16 +1944,59 @@ int spx_last_eval_ms(spx_engine* e, float* ms) {
   return SPX_OK;
 }
 
+namespace {
+// A reader thread's own pinned staging buffer and stream (thread-local, per device): a row lands in pinned memory with an async
+// copy on the reader's stream and is copied out from there — no pageable-memory path through the runtime's shared staging
+// buffers, no engine stream, no engine state.  The calling thread's current device is set first (it is arbitrary on a reader
+// thread; with spx_multi the engines live on different devices).
+struct ReaderSlot {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  void* pinned = nullptr;
+  size_t bytes = 0;
+  ~ReaderSlot() {
+    if (device < 0) return;
+    if (hipSetDevice(device) != hipSuccess) return;
+    if (pinned) (void)hipHostFree(pinned);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+thread_local ReaderSlot tl_reader[8];  // by device id modulo 8
+
+int reader_copy(spx_engine* e, void* out, const void* src, size_t bytes) {
+  SPX_HIP(e, hipSetDevice(e->device));
+  ReaderSlot& r = tl_reader[static_cast<unsigned>(e->device) & 7u];
+  if (r.device != e->device) {
+    if (r.device >= 0) {  // slot taken by another device id (more than 8 devices): the plain copy
+      SPX_HIP(e, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+      return SPX_OK;
+    }
+    SPX_HIP(e, hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+    r.device = e->device;
+  }
+  if (r.bytes < bytes) {
+    if (r.pinned) SPX_HIP(e, hipHostFree(r.pinned));
+    r.pinned = nullptr, r.bytes = 0;
+    const size_t want = (bytes + 65535) & ~static_cast<size_t>(65535);
+    SPX_HIP(e, hipHostMalloc(&r.pinned, want, hipHostMallocDefault));
+    r.bytes = want;
+  }
+  SPX_HIP(e, hipMemcpyAsync(r.pinned, src, bytes, hipMemcpyDeviceToHost, r.stream));
+  SPX_HIP(e, hipStreamSynchronize(r.stream));
+  std::memcpy(out, r.pinned, bytes);
+  return SPX_OK;
+}
+}  // namespace
+
 int spx_fetch_scores(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out) {
   if (!e || !out) return SPX_ERR_ARG;
   if (plugin < 0 || plugin >= SPX_NUM_PLUGINS || !(e->evaluated & (1u << plugin)))
     return fail(e, SPX_ERR_STATE, "plugin has not been evaluated");
   if (pod_row < 0 || pod_row >= e->n_pods) return fail(e, SPX_ERR_ARG, "pod_row out of range");
   if (int rc = rows_evaluated(e, plugin, pod_row, pod_row + 1)) return rc;
-  // plain synchronous D2H copy of one row: safe from concurrent reader threads after spx_sync()
+  // one row, D2H, from any number of reader threads after spx_sync() (no engine state is touched: reader_copy)
   const uint8_t* src = static_cast<const uint8_t*>(e->score[plugin].p) + pod_row * e->score_stride[plugin];
-  SPX_HIP(e, hipMemcpy(out, src, static_cast<size_t>(e->n_nodes), hipMemcpyDeviceToHost));
-  return SPX_OK;
+  return reader_copy(e, out, src, static_cast<size_t>(e->n_nodes));
 }
 
 int spx_fetch_status(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out) {
@@ -1910,12 +2006,14 @@ int spx_fetch_status(spx_engine* e, int plugin, int64_t pod_row, uint8_t* out) {
   if (pod_row < 0 || pod_row >= e->n_pods) return fail(e, SPX_ERR_ARG, "pod_row out of range");
   if (int rc = rows_evaluated(e, plugin, pod_row, pod_row + 1)) return rc;
   const uint8_t* src = static_cast<const uint8_t*>(e->status[plugin].p) + pod_row * e->row_stride;
-  SPX_HIP(e, hipMemcpy(out, src, static_cast<size_t>(e->n_nodes), hipMemcpyDeviceToHost));
-  return SPX_OK;
+  return reader_copy(e, out, src, static_cast<size_t>(e->n_nodes));
 }
 
 int spx_fetch_raw(spx_engine* e, int plugin, int which, int64_t pod_row, int64_t* out) {
   if (!e || !out) return SPX_ERR_ARG;
+  // a raw row is computed on demand (a single-row launch on the engine stream into one scratch row): concurrent readers are
+  // serialised here — correct from any thread, but not a fan-out path; the uint8 tables are
+  std::lock_guard<std::mutex> raw_guard(e->raw_mu);
   SPX_HIP(e, hipSetDevice(e->device));
   if (e->n_nodes <= 0) return fail(e, SPX_ERR_STATE, "no node table uploaded");
   int rc;
@@ -1993,6 +2091,7 @@ int fetch_rows(spx_engine* e, const uint8_t* table, int64_t stride, int64_t row_
   if (row_begin < 0 || row_end > e->n_pods || row_begin > row_end) return fail(e, SPX_ERR_ARG, "row range out of bounds");
   if (out_stride < e->n_nodes) return fail(e, SPX_ERR_ARG, "out_stride is smaller than n_nodes");
   if (row_begin == row_end) return SPX_OK;
+  SPX_HIP(e, hipSetDevice(e->device));  // reader threads: the current device is per thread
   SPX_HIP(e, hipMemcpy2D(out, static_cast<size_t>(out_stride), table + row_begin * stride, static_cast<size_t>(stride),
                          static_cast<size_t>(e->n_nodes), static_cast<size_t>(row_end - row_begin), hipMemcpyDeviceToHost));
   return SPX_OK;

@@ -1240,9 +1240,9 @@ extern "C" int spx_ingest_nettopo_json(spx_ingest* h, const char* json, int64_t 
       return r.object([&](const std::string& sk) {
         if (sk != "weights" || r.peek() != '[') return r.skip();
         return r.array([&] {
-          // the weights entry may list its name after its topologyList: decode names into a scratch and intern them only on a match
+          // the weights entry may list its name after its topologyList: decode into a scratch and intern names only on a match
           using Origins = std::vector<std::pair<std::string, std::vector<std::pair<std::string, int64_t>>>>;
-          Origins reg, zon;
+          std::vector<std::pair<std::string, Origins>> topo;  // the entry's topologyList, in document order
           wname.clear();
           if (!r.object([&](const std::string& wk) {
                 if (wk == "name" && r.peek() == '"') return r.str(wname);
@@ -1275,22 +1275,62 @@ extern "C" int spx_ingest_nettopo_json(spx_ingest* h, const char* json, int64_t 
                         });
                       }))
                     return false;
-                  Origins* into = key == "topology.kubernetes.io/region" ? &reg : (key == "topology.kubernetes.io/zone" ? &zon : nullptr);
-                  if (into) into->insert(into->end(), origins.begin(), origins.end());
+                  topo.emplace_back(key, std::move(origins));
                   return true;
                 });
               }))
             return false;
-          if (wname == weights_name) {  // several entries of that name: later lists are appended (map assignment order)
-            auto merge = [](spx_ingest::Names& names, std::vector<std::vector<std::pair<int32_t, int64_t>>>& out, const Origins& from) {
-              for (const auto& o : from) {
-                const size_t oid = static_cast<size_t>(names.id(o.first));
-                if (out.size() <= oid) out.resize(oid + 1);
-                for (const auto& c : o.second) out[oid].emplace_back(names.id(c.first), c.second);
-              }
-            };
-            merge(h->regions, h->nt_region, reg), merge(h->zones, h->nt_zone, zon);
+          if (wname != weights_name) return true;
+          // The reference does not look names up in a map: it binary-searches the lists (util.FindTopologyKey / FindOriginCosts,
+          // util.go:156-191), after sorting them only when the weights are not the controller's ("NetperfCosts":
+          // sortNetworkTopologyCosts networkoverhead.go:438-445, ByOrigin :462-465).  So a duplicated key or origin is found through
+          // whichever entry the search lands on (the reference's own fixture lists "topology.kubernetes.io/region" twice,
+          // networkoverhead_test.go:93,127: the search finds the first and never sees zones), and an unsorted NetperfCosts list
+          // misses entries.  Reproduced here: the same search over the same order.  Go's sort.Sort is an insertion sort — stable —
+          // up to 12 elements; beyond that its order among equal keys is unspecified, and such input is refused.
+          const bool manual = std::strcmp(weights_name, "NetperfCosts") != 0;
+          bool ambiguous = false;
+          auto go_sort = [&](auto& list) {  // sort.Sort by .first
+            if (!manual) return;
+            std::stable_sort(list.begin(), list.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+            if (list.size() > 12)
+              for (size_t i = 1; i < list.size(); ++i) ambiguous |= list[i].first == list[i - 1].first;
+          };
+          auto go_find = [](const auto& list, const std::string& want) -> int {  // the loop of FindTopologyKey / FindOriginCosts
+            int low = 0, high = static_cast<int>(list.size()) - 1;
+            while (low <= high) {
+              const int mid = (low + high) / 2;
+              if (list[static_cast<size_t>(mid)].first == want) return mid;
+              if (list[static_cast<size_t>(mid)].first < want) low = mid + 1;
+              else high = mid - 1;
+            }
+            return -1;
+          };
+          for (const auto& t : topo) {  // name ids follow the document (first-seen order, as the object-table builders intern them)
+            spx_ingest::Names* names = t.first == "topology.kubernetes.io/region" ? &h->regions : (t.first == "topology.kubernetes.io/zone" ? &h->zones : nullptr);
+            if (!names) continue;
+            for (const auto& o : t.second) {
+              names->id(o.first);
+              for (const auto& c : o.second) names->id(c.first);
+            }
           }
+          go_sort(topo);
+          auto take = [&](const char* label, spx_ingest::Names& names, std::vector<std::vector<std::pair<int32_t, int64_t>>>& out) {
+            const int at = go_find(topo, label);
+            if (at < 0) return;
+            Origins origins = topo[static_cast<size_t>(at)].second;
+            go_sort(origins);
+            for (const auto& o : origins) {  // every origin name a node may carry: what the search returns for it
+              const int oi = go_find(origins, o.first);
+              if (oi < 0 || &origins[static_cast<size_t>(oi)] != &o) continue;  // not reachable (or reached through its twin: once)
+              const size_t oid = static_cast<size_t>(names.id(o.first));
+              if (out.size() <= oid) out.resize(oid + 1);
+              for (const auto& c : o.second) out[oid].emplace_back(names.id(c.first), c.second);  // costMap assignment: the last one wins
+            }
+          };
+          take("topology.kubernetes.io/region", h->regions, h->nt_region);
+          take("topology.kubernetes.io/zone", h->zones, h->nt_zone);
+          if (ambiguous) return r.fail("NetworkTopology: a list of more than 12 entries repeats a key; the reference's pick depends on sort.Sort's unspecified order");
           return true;
         });
       });

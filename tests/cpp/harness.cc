@@ -9,6 +9,8 @@
 #include <atomic>
 #include <cstdio>
 #include <string>
+#include <chrono>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -202,6 +204,59 @@ static int filter_profile() {
   return 0;
 }
 
+// Boundary throughput (SURVEY 8b "threading"): what a per-pod Score() is bounded by once the sweep is done — rows per second
+// through spx_fetch_scores / spx_fetch_score_rows under the reference's fan-out of 16 concurrent callers
+// (targetloadpacking_test.go:386-405), on config #2's node count.
+int boundary_throughput() {
+  const int64_t N = 10000, P = 4096;
+  Engine e(0);
+  e.n_nodes = N;
+  std::vector<int64_t> alloc(2 * N), cap(N), missing(N, 0), acpu(N), amem(N), pod_milli(P), rcpu(P), rmem(P);
+  std::vector<double> util(N), z(N, 0.0);
+  std::vector<uint8_t> valid(N, 1), flags(N, 7);
+  for (int64_t i = 0; i < N; ++i) cap[i] = 8000 + 1000 * (i % 57), acpu[i] = cap[i], amem[i] = (32ll + i % 100) << 30, alloc[i] = amem[i], alloc[N + i] = acpu[i], util[i] = (i * 37 % 1000) / 10.0;
+  for (int64_t p = 0; p < P; ++p) pod_milli[p] = 100 + (371 * p) % 7000, rcpu[p] = pod_milli[p], rmem[p] = (1ll + p % 64) << 28;
+  spx_alloc_nodes_soa an{N, 2, alloc.data()};
+  e.check(spx_upload_alloc_nodes(e.raw(), &an));
+  spx_trimaran_nodes_soa tn{N, cap.data(), util.data(), missing.data(), valid.data(), acpu.data(), amem.data(), z.data(), z.data(), z.data(), z.data(), flags.data()};
+  e.check(spx_upload_trimaran_nodes(e.raw(), &tn));
+  spx_trimaran_pods_soa tp{P, pod_milli.data(), rcpu.data(), rmem.data()};
+  e.check(spx_upload_trimaran_pods(e.raw(), &tp));
+  e.Eval((1u << SPX_PLUGIN_ALLOCATABLE) | (1u << SPX_PLUGIN_TLP), 0, P);
+  std::vector<uint8_t> want(static_cast<size_t>(N));
+  e.check(spx_fetch_scores(e.raw(), SPX_PLUGIN_TLP, 17, want.data()));
+  auto run = [&](int readers, int rows_per_call, double seconds) {
+    std::atomic<int64_t> rows{0};
+    std::atomic<int> bad{0};
+    std::vector<std::thread> th;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int w = 0; w < readers; ++w)
+      th.emplace_back([&, w] {
+        std::vector<uint8_t> buf(static_cast<size_t>(N) * rows_per_call);
+        int64_t pod = (w * 257) % P, mine = 0;
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+          const int64_t b = std::min<int64_t>(pod, P - rows_per_call);
+          const int rc = rows_per_call == 1 ? spx_fetch_scores(e.raw(), SPX_PLUGIN_TLP, b, buf.data())
+                                            : spx_fetch_score_rows(e.raw(), SPX_PLUGIN_TLP, b, b + rows_per_call, buf.data(), N);
+          if (rc != SPX_OK) { bad++; return; }
+          if (b <= 17 && 17 < b + rows_per_call && std::memcmp(buf.data() + (17 - b) * N, want.data(), static_cast<size_t>(N)) != 0) bad++;
+          mine += rows_per_call;
+          pod = (pod + 16 * rows_per_call + 1) % P;
+        }
+        rows += mine;
+      });
+    for (auto& t : th) t.join();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (bad.load()) return -1.0;
+    return static_cast<double>(rows.load()) / dt;
+  };
+  const double r1 = run(1, 1, 0.3), r16 = run(16, 1, 0.4), b1 = run(1, 64, 0.3), b16 = run(16, 64, 0.4);
+  if (r1 < 0 || r16 < 0 || b1 < 0 || b16 < 0) return 60;
+  std::printf("boundary throughput, %lld-node rows (uint8): 1 reader %.0f rows/s, 16 readers %.0f rows/s; 64-row bulk fetch: 1 reader %.0f rows/s, "
+              "16 readers %.0f rows/s (%.2f GB/s)\n", static_cast<long long>(N), r1, r16, b1, b16, b16 * N / 1e9);
+  return 0;
+}
+
 int main() {
   const int64_t N = 777, P = 40;
   Engine e(0);
@@ -302,6 +357,11 @@ int main() {
   if (rc2 != 0) {
     std::fprintf(stderr, "filter profile failed at check %d\n", rc2);
     return rc2;
+  }
+  const int rc3 = boundary_throughput();
+  if (rc3 != 0) {
+    std::fprintf(stderr, "boundary throughput failed at check %d\n", rc3);
+    return rc3;
   }
   std::printf("harness ok: %lld pods x %lld nodes, %d concurrent readers\n", static_cast<long long>(P), static_cast<long long>(N), parallelism);
   return 0;

@@ -108,6 +108,67 @@ def test_unit_test_fixtures_round_trip(hdr):
         assert ing.nettopo_objects().struct.rc_ptr[ing.nettopo_objects().struct.n_regions] == 1
 
 
+
+def _costs_of(t, which, names):
+    """{origin: {destination: cost}} of the decoded region ('r') / zone ('z') table, names looked up by id"""
+    ptr, dest, cost = (t.rc_ptr, t.rc_dest, t.rc_cost) if which == "r" else (t.zc_ptr, t.zc_dest, t.zc_cost)
+    n = t.n_regions if which == "r" else t.n_zones
+    out = {}
+    for o in range(n):
+        row = {names[dest[k]]: cost[k] for k in range(ptr[o], ptr[o + 1])}
+        if row:
+            out[names[o]] = row
+    return out
+
+
+def test_nettopo_lookups_follow_the_reference_binary_searches(hdr):
+    """populateCostMap finds the topology key and the origin by BINARY SEARCH (util.FindTopologyKey / FindOriginCosts,
+    util.go:156-191) over lists it sorts only for manually defined weights (networkoverhead.go:438-445, :462-465).  The decoder
+    reproduces that, bug for bug: (a) the reference's own fixture lists the region key twice (networkoverhead_test.go:93,127) —
+    the search lands on the first entry and zones are never found; (b) an unsorted NetperfCosts list (the controller writes it
+    sorted; nothing re-sorts it) misses origins; (c) the same unsorted list under manual weights is sorted first and complete."""
+    def tl(key, costs):
+        return {"topologyKey": key, "originList": [{"origin": o, "costList": [{"destination": d, "networkCost": c} for d, c in l]} for o, l in costs]}
+
+    def cr(name, topo):
+        return json.dumps({"kind": "NetworkTopology", "spec": {"weights": [{"name": name, "topologyList": topo}]}}).encode()
+
+    def names_of(ing, kind, candidates):
+        out = {}
+        for c in candidates:
+            i = ing.name_id(kind, c)
+            if i >= 0:
+                out[i] = c
+        return out
+
+    r_costs = [("R1", [("R2", 50)]), ("R2", [("R1", 50)])]
+    z_costs = [("Z1", [("Z2", 10)]), ("Z2", [("Z1", 10)])]
+    with NrtIngest(["n0"]) as ing:
+        # (a) both entries keyed "region": zones unreachable, regions = the FIRST entry
+        ing.feed_nettopo(cr("UserDefined", [tl(REGION, r_costs), tl(REGION, z_costs)]), "UserDefined")
+        t = ing.nettopo_objects().struct
+        assert _costs_of(t, "r", names_of(ing, "region", ["R1", "R2", "Z1", "Z2"])) == {"R1": {"R2": 50}, "R2": {"R1": 50}}
+        assert t.zc_ptr[t.n_zones] == 0
+        # (b) NetperfCosts, origins out of order [C, A, B]: the search (mid = 1 -> "A") finds A and B, never C
+        unsorted = [("C", [("A", 3)]), ("A", [("B", 1)]), ("B", [("A", 2)])]
+        ing.feed_nettopo(cr("NetperfCosts", [tl(REGION, unsorted)]), "NetperfCosts")
+        t = ing.nettopo_objects().struct
+        assert _costs_of(t, "r", names_of(ing, "region", ["A", "B", "C"])) == {"A": {"B": 1}, "B": {"A": 2}}
+        # keys out of order under NetperfCosts: [zone, region] — "region" < "zone": mid = 0 is "zone" > "region", high = -1: missed
+        ing.feed_nettopo(cr("NetperfCosts", [tl(ZONE, z_costs), tl(REGION, r_costs)]), "NetperfCosts")
+        t = ing.nettopo_objects().struct
+        assert t.rc_ptr[t.n_regions] == 0 and _costs_of(t, "z", names_of(ing, "zone", ["Z1", "Z2"])) == {"Z1": {"Z2": 10}, "Z2": {"Z1": 10}}
+        # (c) manual weights: sorted before the searches, nothing is missed
+        ing.feed_nettopo(cr("UserDefined", [tl(ZONE, z_costs), tl(REGION, unsorted)]), "UserDefined")
+        t = ing.nettopo_objects().struct
+        assert _costs_of(t, "r", names_of(ing, "region", ["A", "B", "C"])) == {"A": {"B": 1}, "B": {"A": 2}, "C": {"A": 3}}
+        assert _costs_of(t, "z", names_of(ing, "zone", ["Z1", "Z2"])) == {"Z1": {"Z2": 10}, "Z2": {"Z1": 10}}
+        # a duplicated origin among more than 12 manual entries: Go's sort.Sort is unstable there — refused
+        many = [(f"o{i:02d}", [("x", i)]) for i in range(12)] + [("o03", [("x", 99)])]
+        with pytest.raises(Exception):
+            ing.feed_nettopo(cr("UserDefined", [tl(REGION, many)]), "UserDefined")
+
+
 def test_selector_ids_stay_lexicographic_whatever_the_feed_order(hdr):
     """FindPodOrder compares selector strings (util.go:138-153), so selector ids must follow the strings' order — also when a
     caller-seeded table lacks a selector, and when pods (which intern selectors first-seen) arrive before the AppGroup CRs"""

@@ -18,10 +18,12 @@ strategies = sys.argv[1:] or ["LeastAllocated"]
 snap = synth.nrt_snapshot(hdr, N, P, seed=synth.SEED)
 out = {}
 with Engine(0) as e:
+    if os.environ.get('SPX_NOSIDE'):
+        e.set_option('NRT_SIDE_STREAM', 0)
     if os.environ.get('SPX_SINGLE'):
         e.set_option('NRT_SINGLE_LAUNCH', 1)
     for strat in strategies:
-        for name, qp in (("mix", (0.5, 0.4, 0.1)), ("guaranteed", (1, 0, 0)), ("burstable", (0, 1, 0)), ("besteffort", (0, 0, 1))):
+        for name, qp in ((("mix", (0.5, 0.4, 0.1)),) if os.environ.get("SPX_QOS_ONLY") else (("mix", (0.5, 0.4, 0.1)), ("guaranteed", (1, 0, 0)), ("burstable", (0, 1, 0)), ("besteffort", (0, 0, 1)))):
             pods = synth.synth_pods(hdr, P, seed=synth.SEED, device_res=synth.RES_DEVICE, hugepage_res=synth.RES_HUGEPAGES_2MI, qos_p=qp)
             e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], pods, O.nrt_params(hdr, O.Resources(), strat))
             for _ in range(3):

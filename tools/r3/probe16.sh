@@ -1,0 +1,3 @@
+#!/bin/bash
+timeout 400 python -m pytest tests/test_gpu_nrt.py -m gpu -x -q 2>&1 | tail -2
+timeout 200 python tools/r3/exp_qos.py LeastNUMANodes 2>&1 | tail -1
