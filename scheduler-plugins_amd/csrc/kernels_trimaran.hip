@@ -413,13 +413,41 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
   return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
+// one cell through the reference's float64 sequence, from the original node columns (the fast sweep's rare path)
+#ifdef SPX_TLP_OUTLINE
+__device__ __noinline__
+#else
+__device__ __forceinline__
+#endif
+uint32_t tlp_cell_exact(const TrimaranArgs& a, int64_t n, double pod_milli) {
+  TlpNode tn;
+  tn.cap = static_cast<double>(a.cap_cpu_milli[n]);
+  tn.util_millis = (a.tlp_cpu_util[n] / 100.0) * tn.cap;
+  tn.missing = static_cast<double>(a.tlp_missing_milli[n]);
+  tn.valid = a.tlp_valid[n] != 0;
+  bool zero;
+  const double x = tlp_unrounded(tn, pod_milli, a.tlp_target, &zero);
+  return zero ? 0u : to_u8(x);
+}
+
+#ifndef SPX_TLP_LB
+#define SPX_TLP_LB 0
+#endif
 template <int NPL, bool A, bool D = false>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArgs a, int n_tiles, double c1, double c2, DecideArgs dec) {
+__global__
+#if SPX_TLP_LB
+__launch_bounds__(kWave* kWavesPerBlock, D ? 2 : SPX_TLP_LB)
+#elif defined(SPX_TLP_ROWBLOCK)
+__launch_bounds__(704)  // experiment (tools/r3): a block = the waves of ONE chunk's full row width (n_tiles <= 11)
+#else
+__launch_bounds__(kWave* kWavesPerBlock)
+#endif
+void k_tlp_fast2(TrimaranArgs a, int n_tiles, double c1, double c2, DecideArgs dec) {
   SPX_RESOLVE_ROWS(a);
   static_assert(kPodsPerChunk == kWave, "one pod record per lane");
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * static_cast<int>(blockDim.x >> 6) + wave;
   const int tile = static_cast<int>(unit % n_tiles);
   const int64_t chunk = unit / n_tiles;
   const int64_t pod0 = a.row_begin + chunk * kPodsPerChunk;
@@ -522,15 +550,10 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
           const int64_t n = node0 + i;
           uint32_t b = 0;
           if (n < a.n_nodes) {
+#ifndef SPX_TLP_NOSTATS
             ++reevaluated;
-            TlpNode tn;
-            tn.cap = static_cast<double>(a.cap_cpu_milli[n]);
-            tn.util_millis = (a.tlp_cpu_util[n] / 100.0) * tn.cap;
-            tn.missing = static_cast<double>(a.tlp_missing_milli[n]);
-            tn.valid = a.tlp_valid[n] != 0;
-            bool zero;
-            const double x = tlp_unrounded(tn, pod_milli, t, &zero);
-            b = zero ? 0u : to_u8(x);
+#endif
+            b = tlp_cell_exact(a, n, pod_milli);
           }
           const int sh = (i & 3) * 8;
           w[i >> 2] = (w[i >> 2] & ~(0xffu << sh)) | (b << sh);
@@ -583,7 +606,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
       }
     }
   }
+#ifndef SPX_TLP_NOSTATS
   flush_stats(a.stats, SPX_PLUGIN_TLP, reevaluated, unit);
+#endif
 }
 
 // merges the per-tile triples of the decisions-only sweep into the layout spx_fetch_best reads
@@ -1110,6 +1135,13 @@ void launch_tlp_fast(const TrimaranArgs& a, hipStream_t s) {
   const double c1 = t / (100.0 - t), c2 = (100.0 - t) / t;
   const int64_t n_slots = static_cast<int64_t>(n_tiles) * tile_nodes;
   hipLaunchKernelGGL(k_tlp_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots, c1, c2);
+#ifdef SPX_TLP_ROWBLOCK
+  if (n_tiles <= 11) {  // experiment: one block per chunk, its waves side by side across the row
+    if (a.out_alloc) hipLaunchKernelGGL((k_tlp_fast2<NPL, true>), dim3(static_cast<unsigned>(chunks)), dim3(kWave * n_tiles), 0, s, a, n_tiles, c1, c2, DecideArgs{});
+    else hipLaunchKernelGGL((k_tlp_fast2<NPL, false>), dim3(static_cast<unsigned>(chunks)), dim3(kWave * n_tiles), 0, s, a, n_tiles, c1, c2, DecideArgs{});
+    return;
+  }
+#endif
   if (a.out_alloc)
     hipLaunchKernelGGL((k_tlp_fast2<NPL, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, DecideArgs{});
   else

