@@ -596,6 +596,14 @@ int spx_upload_lroc_nodes(spx_engine* e, const spx_lroc_nodes_soa* t);
 int spx_upload_lroc_pods(spx_engine* e, const spx_lroc_pods_soa* t);
 int spx_upload_peaks_nodes(spx_engine* e, const spx_peaks_nodes_soa* t);
 int spx_upload_peaks_pods(spx_engine* e, const spx_peaks_pods_soa* t);
+/* Snapshot deltas (SURVEY 8d "upload deltas"): `t` holds t->n_nodes ROWS in the layout of the full upload; row i replaces node
+ * idx[i] of the table already on the device (spx_upload_* must have run once: it fixes the shape).  The changed rows travel as one
+ * staged blob and are scattered into the device columns; for NRT the float64 formulation's derived columns are recomputed on the
+ * device for those nodes (bit-identical to a full re-upload).  Every table evaluated from the old rows becomes stale.
+ *   trimaran: collector refresh of a node's metrics (collector.go:139-150), the bind-time cache (handler.go:131-139)
+ *   NRT: a republished NodeResourceTopology (pluginhelpers.go:105-161), an assumed pod charged to a node (overreserve.go:170-203) */
+int spx_update_trimaran_nodes(spx_engine* e, const int64_t* idx, const spx_trimaran_nodes_soa* t);
+int spx_update_nrt_nodes(spx_engine* e, const int64_t* idx, const spx_nrt_nodes_soa* t);
 int spx_upload_nrt_slots(spx_engine* e, const spx_nrt_slots* t);
 int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t);
 int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t);

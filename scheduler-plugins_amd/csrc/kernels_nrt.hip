@@ -471,6 +471,26 @@ __global__ __launch_bounds__(256, 2) void k_nrt(NrtArgs a, int n_tiles) {
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void k_nrt_creq_from_items(const uint32_t* __restrict__ items, int n_res, int64_t n_pods, int64_t* __restrict__ out) {
+  const int iw = n_res <= 4 ? 16 : 32;  // dwords per item; items 2.. of a pod's 10 are its containers (spx_engine.hip: nrt_pod_items)
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;  // (pod, container, resource)
+  if (i >= n_pods * SPX_NRT_MAX_CTRS * n_res) return;
+  const int r = static_cast<int>(i % n_res);
+  const int64_t pc = i / n_res;
+  const int c = static_cast<int>(pc % SPX_NRT_MAX_CTRS);
+  const int64_t pod = pc / SPX_NRT_MAX_CTRS;
+  const uint32_t* w = items + (pod * 10 + 2 + c) * iw + 2 * r;
+  out[i] = static_cast<int64_t>(__hiloint2double(static_cast<int>(w[1]), static_cast<int>(w[0])));
+}
+}  // namespace
+
+void launch_nrt_creq_from_items(const uint32_t* pod_items, int n_res, int64_t n_pods, int64_t* ctr_req, hipStream_t s) {
+  const int64_t n = n_pods * SPX_NRT_MAX_CTRS * n_res;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_nrt_creq_from_items, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, pod_items, n_res, n_pods, ctr_req);
+}
+
 void launch_nrt(const NrtArgs& a, hipStream_t s) {
   if (a.row_end <= a.row_begin) return;
   const bool generic_only = (a.opts & kOptNrtGeneric) != 0;  // SPX_OPT_REFERENCE_KERNELS

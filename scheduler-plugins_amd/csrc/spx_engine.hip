@@ -102,6 +102,10 @@ struct spx_engine {
   uint32_t nrt_redo_cap = 0;
   uint32_t nrt_big_nodes = ~0u, nrt_big_pods = ~0u;  // slots with a capacity / a request (Value() form) of 2^24 or more
   // pod equivalence classes (spx_upload_nrt_pods): rows whose NRT records agree in everything the sweep reads
+  bool nrt_creq_valid = false;   // d_nrt_creq (read by the reference-arithmetic kernel only) holds this batch's column
+  void* h_stage = nullptr;       // pinned staging for the large derived tables (pod record stream): built in place, one DMA
+  size_t h_stage_bytes = 0;
+  DevBuf d_delta;                // staged rows of a node-table delta (spx_update_*_nodes)
   DevBuf d_nrt_uniq, d_nrt_dups;  // int32 [n_uniq] representative rows, ascending; int32 [n_dups][2] (row, its representative)
   int64_t nrt_n_uniq = 0, nrt_n_dups = 0;
   bool nrt_ln_ok = false;  // LeastNUMANodes tables can be built: every zone cost within [0, 255]
@@ -432,6 +436,20 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   na.ln_tab = (e->nrt_ln_ok && e->nrt_ln_built) ? static_cast<const uint32_t*>(e->d_nrt_ln.p) : nullptr;
 }
 
+// the reference-arithmetic NRT kernel's request column, when the coming launch may take that kernel and the batch did not ship it
+int ensure_nrt_creq(spx_engine* e) {
+  const bool fast = e->nrt_fast_slots && e->nrt_fast_nodes && e->nrt_fast_pods && !forced_reference(e, SPX_PLUGIN_NRT) &&
+                    !(e->nrt_params.strategy == SPX_NRT_LEAST_NUMA_NODES && !(e->nrt_ln_ok && e->nrt_ln_built));
+  if (fast || e->nrt_creq_valid) return SPX_OK;
+  const size_t bytes = static_cast<size_t>(e->n_pods) * SPX_NRT_MAX_CTRS * static_cast<size_t>(e->nrt_n_res) * sizeof(int64_t);
+  int rc = ensure(e, e->d_nrt_creq, bytes);
+  if (rc) return rc;
+  spx::launch_nrt_creq_from_items(static_cast<const uint32_t*>(e->d_nrt_items.p), e->nrt_n_res, e->n_pods, static_cast<int64_t*>(e->d_nrt_creq.p), e->stream);
+  SPX_HIP(e, hipGetLastError());
+  e->nrt_creq_valid = true;
+  return SPX_OK;
+}
+
 // quantities the float64 NRT kernel may hold exactly, with room for x100 and the reciprocal trick
 constexpr int64_t kNrtFastLimit = int64_t{1} << 42;
 constexpr int64_t kNrtWeightLimit = int64_t{1} << 20;  // sum of the NRT scoring weights the float64 formulation accepts
@@ -560,6 +578,7 @@ int spx_destroy(spx_engine* e) {
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->h_best) (void)hipHostFree(e->h_best);
+  if (e->h_stage) (void)hipHostFree(e->h_stage);
   if (e->h_sort_hist) (void)hipHostFree(e->h_sort_hist);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
@@ -691,6 +710,161 @@ int spx_upload_trimaran_nodes(spx_engine* e, const spx_trimaran_nodes_soa* t) {
   e->lv_alloc_exact = all_below_2p52(t->lv_alloc_cpu_milli, n) && all_below_2p52(t->lv_alloc_mem, n);
   e->lroc_tab_ready = false;
   e->tri_nodes = true;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  return SPX_OK;
+}
+
+
+namespace {
+// one pinned blob for a delta's columns: [idx int32 n] then each column, 16-byte aligned; uploaded with one DMA
+struct DeltaBlob {
+  spx_engine* e;
+  size_t bytes = 0;
+  std::vector<std::pair<const void*, size_t>> parts;  // (source, bytes)
+  std::vector<size_t> offset;
+  size_t add(const void* src, size_t n) {
+    const size_t at = bytes;
+    parts.emplace_back(src, n);
+    offset.push_back(at);
+    bytes = (bytes + n + 15) & ~static_cast<size_t>(15);
+    return at;
+  }
+  int ship() {
+    if (e->h_stage_bytes < bytes) {
+      if (e->h_stage) SPX_HIP(e, hipHostFree(e->h_stage));
+      e->h_stage = nullptr, e->h_stage_bytes = 0;
+      SPX_HIP(e, hipHostMalloc(&e->h_stage, bytes + 65536, hipHostMallocDefault));
+      e->h_stage_bytes = bytes + 65536;
+    }
+    for (size_t k = 0; k < parts.size(); ++k)
+      if (parts[k].second) std::memcpy(static_cast<char*>(e->h_stage) + offset[k], parts[k].first, parts[k].second);
+    return upload(e, e->d_delta, e->h_stage, bytes);
+  }
+  const char* dev(size_t at) const { return static_cast<const char*>(e->d_delta.p) + at; }
+};
+
+int delta_indices(spx_engine* e, const int64_t* idx, int64_t n_rows, std::vector<int32_t>& out) {
+  if (n_rows < 0 || (n_rows && !idx)) return fail(e, SPX_ERR_ARG, "delta: NULL index column");
+  out.resize(static_cast<size_t>(n_rows));
+  for (int64_t i = 0; i < n_rows; ++i) {
+    if (idx[i] < 0 || idx[i] >= e->n_nodes) return fail(e, SPX_ERR_ARG, "delta: node index out of range");
+    out[static_cast<size_t>(i)] = static_cast<int32_t>(idx[i]);
+  }
+  return SPX_OK;
+}
+}  // namespace
+
+int spx_update_trimaran_nodes(spx_engine* e, const int64_t* idx, const spx_trimaran_nodes_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  if (!e->tri_nodes) return fail(e, SPX_ERR_STATE, "trimaran node delta: upload the full table first");
+  const int64_t n = t->n_nodes;
+  if (n == 0) return SPX_OK;
+  if (!t->cap_cpu_milli || !t->tlp_cpu_util || !t->tlp_missing_milli || !t->tlp_valid || !t->lv_alloc_cpu_milli || !t->lv_alloc_mem ||
+      !t->lv_cpu_avg || !t->lv_cpu_std || !t->lv_mem_avg || !t->lv_mem_std || !t->lv_flags)
+    return fail(e, SPX_ERR_ARG, "NULL column in table");
+  std::vector<int32_t> ix;
+  int rc = delta_indices(e, idx, n, ix);
+  if (rc) return rc;
+  const size_t m = static_cast<size_t>(n);
+  DeltaBlob b{e};
+  const size_t o_idx = b.add(ix.data(), m * 4);
+  struct Col { DevBuf* dst; const void* src; int bytes; } cols[] = {
+      {&e->d_cap_cpu, t->cap_cpu_milli, 8}, {&e->d_tlp_util, t->tlp_cpu_util, 8}, {&e->d_tlp_missing, t->tlp_missing_milli, 8}, {&e->d_tlp_valid, t->tlp_valid, 1},
+      {&e->d_lv_acpu, t->lv_alloc_cpu_milli, 8}, {&e->d_lv_amem, t->lv_alloc_mem, 8}, {&e->d_lv_cavg, t->lv_cpu_avg, 8}, {&e->d_lv_cstd, t->lv_cpu_std, 8},
+      {&e->d_lv_mavg, t->lv_mem_avg, 8}, {&e->d_lv_mstd, t->lv_mem_std, 8}, {&e->d_lv_flags, t->lv_flags, 1}};
+  size_t at[11];
+  for (int k = 0; k < 11; ++k) at[k] = b.add(cols[k].src, m * static_cast<size_t>(cols[k].bytes));
+  if ((rc = b.ship())) return rc;
+  for (int k = 0; k < 11; ++k)
+    spx::launch_scatter_rows(cols[k].dst->p, e->n_nodes, 1, reinterpret_cast<const int32_t*>(b.dev(o_idx)), b.dev(at[k]), n, cols[k].bytes, e->stream);
+  SPX_HIP(e, hipGetLastError());
+  // the aggregate property stays conservative: rows may only take it away (a full upload re-establishes it)
+  e->lv_alloc_exact = e->lv_alloc_exact && all_below_2p52(t->lv_alloc_cpu_milli, m) && all_below_2p52(t->lv_alloc_mem, m);
+  e->lroc_tab_ready = false;
+  e->evaluated = 0;  // every table computed from the old rows is stale
+  e->best_valid = false;
+  SPX_HIP(e, hipStreamSynchronize(e->stream));  // host columns are only borrowed for the call
+  return SPX_OK;
+}
+
+int spx_update_nrt_nodes(spx_engine* e, const int64_t* idx, const spx_nrt_nodes_soa* t) {
+  if (!e || !t) return SPX_ERR_ARG;
+  SPX_HIP(e, hipSetDevice(e->device));
+  if (!e->nrt_nodes || !e->nrt_slots) return fail(e, SPX_ERR_STATE, "NRT node delta: upload the slot and node tables first");
+  if (t->n_res != e->nrt_n_res) return fail(e, SPX_ERR_ARG, "NRT node delta: n_res differs from the slot table");
+  const int64_t n = t->n_nodes;
+  if (n == 0) return SPX_OK;
+  if (!t->flags || !t->max_numa || !t->n_zones || !t->zone_id || !t->zone_present || !t->zone_cost || !t->min_avg_dist || !t->node_present ||
+      (!t->zone_avail && t->n_res))
+    return fail(e, SPX_ERR_ARG, "NULL column in table");
+  std::vector<int32_t> ix;
+  int rc = delta_indices(e, idx, n, ix);
+  if (rc) return rc;
+  constexpr int64_t Zm = SPX_NRT_MAX_ZONES;
+  const int64_t R = t->n_res, N = e->n_nodes;
+  const size_t m = static_cast<size_t>(n);
+  // the float64 formulation's preconditions for the new rows (the same tests as spx_upload_nrt_nodes); a row that breaks them
+  // sends the whole table to the reference-arithmetic kernel until the next full upload
+  bool ok = true, cost_changed = false, ln_ok = true;
+  uint32_t big = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int nz = t->n_zones[i];
+    for (int z = 0; z < nz && z < Zm; ++z) {
+      if (t->zone_id[i * Zm + z] != z) ok = false;
+      for (int64_t r = 0; r < R; ++r) {
+        if (!((t->zone_present[i * Zm + z] >> r) & 1u)) continue;
+        const int64_t cap = t->zone_avail[(i * Zm + z) * R + r];
+        if (!nrt_fast_qty(cap)) ok = false;
+        if (static_cast<double>(nrt_value_of(r == e->nrt_cpu_slot, cap)) >= 16777216.0) big |= 1u << r;
+      }
+    }
+    int32_t* hc = &e->h_nrt_cost[static_cast<size_t>(ix[static_cast<size_t>(i)]) * Zm * Zm];
+    if (std::memcmp(hc, t->zone_cost + i * Zm * Zm, sizeof(int32_t) * Zm * Zm) != 0 || e->h_nrt_nz[static_cast<size_t>(ix[static_cast<size_t>(i)])] != t->n_zones[i]) {
+      cost_changed = true;
+      std::memcpy(hc, t->zone_cost + i * Zm * Zm, sizeof(int32_t) * Zm * Zm);
+      e->h_nrt_nz[static_cast<size_t>(ix[static_cast<size_t>(i)])] = t->n_zones[i];
+      for (int za = 0; za < nz && za < Zm; ++za)
+        for (int zb = 0; zb < nz && zb < Zm; ++zb) {
+          const int64_t c = t->zone_cost[(i * Zm + za) * Zm + zb];
+          if (c < 0 || c > 255) ln_ok = false;
+        }
+    }
+  }
+  DeltaBlob b{e};
+  const size_t o_idx = b.add(ix.data(), m * 4);
+  const size_t o_flags = b.add(t->flags, m), o_max = b.add(t->max_numa, m * 4), o_nz = b.add(t->n_zones, m), o_np = b.add(t->node_present, m);
+  const size_t o_zid = b.add(t->zone_id, m * Zm), o_zp = b.add(t->zone_present, m * Zm);
+  const size_t o_av = b.add(t->zone_avail, m * Zm * static_cast<size_t>(R) * 8), o_cost = b.add(t->zone_cost, m * Zm * Zm * 4);
+  const size_t o_min = b.add(t->min_avg_dist, m * Zm * 4);
+  if ((rc = b.ship())) return rc;
+  const int32_t* d_idx = reinterpret_cast<const int32_t*>(b.dev(o_idx));
+  hipStream_t s = e->stream;
+  spx::launch_scatter_rows(e->d_nrt_flags.p, N, 1, d_idx, b.dev(o_flags), n, 1, s);
+  spx::launch_scatter_rows(e->d_nrt_max_numa.p, N, 1, d_idx, b.dev(o_max), n, 4, s);
+  spx::launch_scatter_rows(e->d_nrt_nz.p, N, 1, d_idx, b.dev(o_nz), n, 1, s);
+  spx::launch_scatter_rows(e->d_nrt_np.p, N, 1, d_idx, b.dev(o_np), n, 1, s);
+  spx::launch_scatter_rows(e->d_nrt_zid.p, N, static_cast<int>(Zm), d_idx, b.dev(o_zid), n, 1, s);
+  spx::launch_scatter_rows(e->d_nrt_zp.p, N, static_cast<int>(Zm), d_idx, b.dev(o_zp), n, 1, s);
+  if (R) spx::launch_scatter_rows(e->d_nrt_avail.p, N, static_cast<int>(Zm * R), d_idx, b.dev(o_av), n, 8, s);
+  spx::launch_scatter_rows(e->d_nrt_cost.p, N, static_cast<int>(Zm * Zm), d_idx, b.dev(o_cost), n, 4, s);
+  spx::launch_scatter_rows(e->d_nrt_minavg.p, N, static_cast<int>(Zm), d_idx, b.dev(o_min), n, 4, s);
+  spx::NrtDeltaArgs da{};
+  da.n_rows = n, da.n_nodes = N, da.n_res = static_cast<int32_t>(R), da.cpu_slot = e->nrt_cpu_slot;
+  da.idx = d_idx, da.n_zones = reinterpret_cast<const uint8_t*>(b.dev(o_nz)), da.zone_present = reinterpret_cast<const uint8_t*>(b.dev(o_zp)), da.zone_avail = reinterpret_cast<const int64_t*>(b.dev(o_av));
+  da.f_av = static_cast<double*>(e->d_nrt_fav.p), da.f_rc = static_cast<double*>(e->d_nrt_frc.p), da.f_rcv = static_cast<double*>(e->d_nrt_frcv.p);
+  da.f_cpu = static_cast<double*>(e->d_nrt_fcpu.p), da.f_braw = static_cast<double*>(e->d_nrt_fbraw.p), da.f_rep = static_cast<uint8_t*>(e->d_nrt_frep.p);
+  spx::launch_nrt_derive_rows(da, s);
+  SPX_HIP(e, hipGetLastError());
+  e->nrt_fast_nodes = e->nrt_fast_nodes && ok;
+  e->nrt_big_nodes |= big;
+  if (cost_changed) {  // LeastNUMANodes' per-node tables are rebuilt when that strategy is next evaluated
+    e->nrt_ln_built = false;
+    e->nrt_ln_ok = e->nrt_ln_ok && ln_ok;
+  }
+  // (the window-local node order — perm — is a grouping hint for the sweep, not a correctness input: left as it is)
+  e->evaluated &= ~(1u << SPX_PLUGIN_NRT);
+  e->best_valid = false;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   return SPX_OK;
 }
@@ -1058,7 +1232,7 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
   if ((rc = upload(e, e->d_nrt_nctr, t->n_ctr, p))) return rc;
   if ((rc = upload(e, e->d_nrt_ckind, t->ctr_kind, p * Cm))) return rc;
   if ((rc = upload(e, e->d_nrt_cpres, t->ctr_present, p * Cm))) return rc;
-  if ((rc = upload(e, e->d_nrt_creq, t->ctr_req, p * Cm * R * 8))) return rc;
+  if (!t->ctr_req && p * R) return fail(e, SPX_ERR_ARG, "NULL column in table");
   if ((rc = upload(e, e->d_nrt_ppres, t->pod_present, p))) return rc;
   if ((rc = upload(e, e->d_nrt_preq, t->pod_req, p * R * 8))) return rc;
   {  // float64 formulation: the pod record stream + precondition check
@@ -1072,7 +1246,14 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
     //                 cpu request (2RM+2), sum of the weights of the requested slots (2RM+4), its biased reciprocal (2RM+6)
     const int RMs = R <= 4 ? 4 : 8;
     const size_t IW = R <= 4 ? 16 : 32;
-    std::vector<uint32_t> items(p * 10 * IW, 0u);
+    const size_t items_bytes = p * 10 * IW * sizeof(uint32_t);
+    if (e->h_stage_bytes < items_bytes) {
+      if (e->h_stage) SPX_HIP(e, hipHostFree(e->h_stage));
+      e->h_stage = nullptr, e->h_stage_bytes = 0;
+      SPX_HIP(e, hipHostMalloc(&e->h_stage, items_bytes + (items_bytes >> 3), hipHostMallocDefault));
+      e->h_stage_bytes = items_bytes + (items_bytes >> 3);
+    }
+    uint32_t* const items = static_cast<uint32_t*>(e->h_stage);  // pinned: built in place (rows zeroed by the thread that fills them)
     const uint32_t slot_mask = (1u << R) - 1u;
     std::atomic<bool> ok{e->nrt_wtab.size() == (static_cast<size_t>(2) << R)};
     std::atomic<uint32_t> big_pods{0};
@@ -1098,6 +1279,7 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
       }
     };
     spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
+    std::memset(items + static_cast<size_t>(row0) * 10 * IW, 0, static_cast<size_t>(row1 - row0) * 10 * IW * sizeof(uint32_t));
     for (size_t i = static_cast<size_t>(row0); i < static_cast<size_t>(row1); ++i) {
       uint32_t* w = &items[i * 10 * IW];
       const bool non_g = t->qos[i] != SPX_QOS_GUARANTEED;
@@ -1121,10 +1303,15 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
       w[1] = n_ctr ? (65536u + n_ctr - 1u) / n_ctr : 0u;
     }
     }, 4096);
-    if ((rc = upload(e, e->d_nrt_items, items.data(), items.size() * sizeof(uint32_t)))) return rc;
+    if ((rc = upload(e, e->d_nrt_items, items, items_bytes))) return rc;  // from pinned memory: one DMA at link speed, asynchronous
     e->nrt_fast_pods = ok.load();
     e->nrt_big_pods = big_pods.load();
-    SPX_HIP(e, hipStreamSynchronize(e->stream));
+    // the reference-arithmetic kernel's request column: shipped only when the record stream cannot stand in for it
+    e->nrt_creq_valid = false;
+    if (!e->nrt_fast_pods) {
+      if ((rc = upload(e, e->d_nrt_creq, t->ctr_req, p * Cm * R * 8))) return rc;
+      e->nrt_creq_valid = true;
+    }
     // Pod equivalence classes.  Two pods get the same NRT rows on every node when their records agree in everything the
     // sweep reads, and a queue is full of such pods: replicas of one Deployment, and every pod whose verdict does not depend
     // on quantities — a pod that is not filtered (BestEffort without non-native resources, filter.go:186-190) passes and
@@ -1135,7 +1322,7 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
     if (e->nrt_fast_pods && p > 0) {
       const size_t PW = 10 * IW;
       auto canon = [&](size_t i, uint32_t* c) {
-        const uint32_t* w = &items[i * PW];
+        const uint32_t* w = items + i * PW;
         std::memcpy(c, w, PW * sizeof(uint32_t));
         const uint32_t qos = w[0] & 0xffu, n_ctr = (w[0] >> 16) & 0xffu;
         const bool non_native = ((w[0] >> 8) & 0xffu) != 0;
@@ -1171,25 +1358,26 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
           hash[static_cast<size_t>(i)] = h;
         }
       }, 4096);
+      // serial: first row of each hash value; parallel: every other row verified word for word against that row
       std::unordered_map<uint64_t, int32_t> rep_of_hash;
       rep_of_hash.reserve(p);
+      std::vector<int32_t> rep(p);
+      for (size_t i = 0; i < p; ++i) rep[i] = rep_of_hash.emplace(hash[i], static_cast<int32_t>(i)).first->second;
+      spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
+        std::vector<uint32_t> ca(PW), cb(PW);
+        for (int64_t i = row0; i < row1; ++i) {
+          const int32_t r0 = rep[static_cast<size_t>(i)];
+          if (r0 == i) continue;
+          canon(static_cast<size_t>(i), ca.data());
+          canon(static_cast<size_t>(r0), cb.data());
+          if (std::memcmp(ca.data(), cb.data(), PW * sizeof(uint32_t)) != 0) rep[static_cast<size_t>(i)] = static_cast<int32_t>(i);  // a hash collision: the row stands for itself
+        }
+      }, 2048);
       std::vector<int32_t> uniq, dups;
-      std::vector<uint32_t> ca(PW), cb(PW);
+      uniq.reserve(p), dups.reserve(2 * p);
       for (size_t i = 0; i < p; ++i) {
-        auto it = rep_of_hash.find(hash[i]);
-        if (it == rep_of_hash.end()) {
-          rep_of_hash.emplace(hash[i], static_cast<int32_t>(i));
-          uniq.push_back(static_cast<int32_t>(i));
-          continue;
-        }
-        canon(i, ca.data());
-        canon(static_cast<size_t>(it->second), cb.data());
-        if (std::memcmp(ca.data(), cb.data(), PW * sizeof(uint32_t)) == 0) {
-          dups.push_back(static_cast<int32_t>(i));
-          dups.push_back(it->second);
-        } else {
-          uniq.push_back(static_cast<int32_t>(i));  // a hash collision: the row stands for itself
-        }
+        if (rep[i] == static_cast<int32_t>(i)) uniq.push_back(static_cast<int32_t>(i));
+        else dups.push_back(static_cast<int32_t>(i)), dups.push_back(rep[i]);
       }
       if (!dups.empty()) {
         if ((rc = upload(e, e->d_nrt_uniq, uniq.data(), uniq.size() * sizeof(int32_t)))) return rc;
@@ -1545,6 +1733,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
         e->nrt_redo_cap = cap;
       }
     }
+    if ((rc = ensure_nrt_creq(e))) return rc;
     spx::NrtArgs na{};
     fill_nrt(e, na);
     na.row_begin = row_begin;
@@ -2029,6 +2218,7 @@ int spx_fetch_raw(spx_engine* e, int plugin, int which, int64_t pod_row, int64_t
     if (pod_row < 0 || pod_row >= e->n_pods) return fail(e, SPX_ERR_ARG, "pod_row out of range");
     if ((rc = ensure(e, e->d_raw_row, bytes))) return rc;
     if (e->nrt_params.strategy == SPX_NRT_LEAST_NUMA_NODES && (rc = build_ln_tab(e))) return rc;
+    if ((rc = ensure_nrt_creq(e))) return rc;
     spx::NrtArgs na{};
     fill_nrt(e, na);
     na.row_begin = pod_row;

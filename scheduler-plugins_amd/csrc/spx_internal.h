@@ -330,8 +330,31 @@ constexpr LnLayout make_ln_layout() {
   return l;
 }
 void launch_nrt(const NrtArgs& a, hipStream_t s);
+// the reference-arithmetic kernel's per-container request column [P][8][n_res] int64, rebuilt from the pod record stream (whose
+// quantities are exact doubles whenever the stream is valid): the engine does not ship that column — 256 bytes per pod — with every
+// pod batch, only when a launch is going to read it
+void launch_nrt_creq_from_items(const uint32_t* pod_items, int n_res, int64_t n_pods, int64_t* ctr_req, hipStream_t s);
 // returns false when the float64 kernel does not apply (preconditions, LeastNUMANodes)
 bool launch_nrt_fast(const NrtArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- snapshot deltas (kernels_delta.hip)
+// dst column-major [inner][n_nodes] <- src row-major [n_rows][inner] at nodes idx[row]; elem_bytes 1, 4 or 8
+void launch_scatter_rows(void* dst, int64_t n_nodes, int inner, const int32_t* idx, const void* src, int64_t n_rows, int elem_bytes, hipStream_t s);
+struct NrtDeltaArgs {
+  int64_t n_rows, n_nodes;
+  int32_t n_res, cpu_slot;
+  const int32_t* idx;           // [n_rows] node of each row
+  const uint8_t* n_zones;       // staged rows, as spx_nrt_nodes_soa holds them
+  const uint8_t* zone_present;  // [n_rows][Z]
+  const int64_t* zone_avail;    // [n_rows][Z][n_res]
+  double* f_av;                 // the float64 formulation's derived columns (NrtArgs)
+  double* f_rc;
+  double* f_rcv;
+  double* f_cpu;
+  double* f_braw;
+  uint8_t* f_rep;
+};
+void launch_nrt_derive_rows(const NrtDeltaArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- NetworkOverhead
 struct NetArgs {

@@ -189,6 +189,25 @@ class Engine:
         self._ck(self._lib.spx_upload_trimaran_nodes(self._h, t.ref()))
         self.n_nodes = n
 
+    def update_trimaran_nodes(self, idx, cols: Dict[str, np.ndarray]) -> None:
+        """rows `idx` of the trimaran node table replaced in place: cols = flatten_trimaran_nodes()'s columns for ALL nodes, of
+        which only rows idx travel (spx_update_trimaran_nodes)"""
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        sub = {k: np.ascontiguousarray(v[idx]) for k, v in cols.items()}
+        self._ck(self._lib.spx_update_trimaran_nodes(self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                     Table(self._hdr, "spx_trimaran_nodes_soa", n_nodes=len(idx), **sub).ref()))
+
+    def update_nrt_nodes(self, idx, f: dict) -> None:
+        """rows `idx` of the NRT node tables replaced in place: f = flatten_nrt()'s result for the NEW snapshot
+        (spx_update_nrt_nodes; the derived float64 columns are recomputed on the device for those nodes)"""
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        N, R = f["N"], f["R"]
+        per = {"flags": 1, "max_numa": 1, "n_zones": 1, "zone_id": 8, "zone_present": 8, "zone_avail": 8 * max(R, 1), "zone_cost": 64,
+               "min_avg_dist": 8, "node_present": 1}
+        sub = {k: np.ascontiguousarray(f["nodes"][k].reshape(N, per[k])[idx].reshape(-1)) for k in per}
+        self._ck(self._lib.spx_update_nrt_nodes(self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                Table(self._hdr, "spx_nrt_nodes_soa", n_nodes=len(idx), n_res=R, **sub).ref()))
+
     def upload_trimaran_pods(self, cols: Dict[str, np.ndarray], rows=None) -> None:
         cols = _rows(cols, len(cols["tlp_pod_milli"]), rows)
         p = len(cols["tlp_pod_milli"]) if rows is None else rows[1] - rows[0]
