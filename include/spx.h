@@ -803,6 +803,8 @@ int spx_flatten_peaks_pods(const spx_pod_objects* pods, int64_t* cpu_milli);
 int spx_flatten_nrt_slots(const spx_pod_objects* pods, const spx_nrt_objects* nrt, const spx_resource_classes* rc, const spx_nrt_params* p, int32_t* n_res_out, int32_t* slot_res, uint8_t* slot_flags, int64_t* slot_weight);
 /* node arrays sized: flags[N], max_numa[N], n_zones[N], zone_id[N*8], zone_present[N*8], zone_avail[N*8*n_res], zone_cost[N*8*8], min_avg_dist[N*8], node_present[N] */
 int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_nrt_slots* slots, uint8_t* flags, int32_t* max_numa, uint8_t* n_zones, uint8_t* zone_id, uint8_t* zone_present, int64_t* zone_avail, int32_t* zone_cost, float* min_avg_dist, uint8_t* node_present);
+/* the same columns for the listed nodes only (n_rows rows; row j = node idx[j]): the input of spx_update_nrt_nodes */
+int spx_flatten_nrt_node_rows(const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_nrt_slots* slots, const int64_t* idx, int64_t n_rows, uint8_t* flags, int32_t* max_numa, uint8_t* n_zones, uint8_t* zone_id, uint8_t* zone_present, int64_t* zone_avail, int32_t* zone_cost, float* min_avg_dist, uint8_t* node_present);
 /* pod arrays sized: qos[P], non_native[P], n_ctr[P], ctr_kind[P*8], ctr_present[P*8], ctr_req[P*8*n_res], pod_present[P], pod_req[P*n_res] */
 int spx_flatten_nrt_pods(const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_nrt_slots* slots, uint8_t* qos, uint8_t* non_native, uint8_t* n_ctr, uint8_t* ctr_kind, uint8_t* ctr_present, int64_t* ctr_req, uint8_t* pod_present, int64_t* pod_req);
 

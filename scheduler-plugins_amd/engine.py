@@ -312,6 +312,64 @@ class Engine:
         self._ck(fn(pods.ref(), rc.ref() if rc else None, slots.ref(), *[v.ctypes.data_as(t) for v, t in zip(pc.values(), fn.argtypes[3:])]))
         return {"params": params, "slots": slots, "nodes": nc, "pods": pc, "N": N, "P": P, "R": R}
 
+    def flatten_nrt_node_rows(self, nodes: Table, nrt: Table, slots: Table, idx) -> Dict[str, np.ndarray]:
+        """the SoA rows of the listed nodes only (spx_flatten_nrt_node_rows): what a delta encoder produces for the changed nodes"""
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        n, R = len(idx), int(slots.struct.n_res)
+        nc = dict(flags=np.zeros(n, np.uint8), max_numa=np.zeros(n, np.int32), n_zones=np.zeros(n, np.uint8),
+                  zone_id=np.zeros(n * 8, np.uint8), zone_present=np.zeros(n * 8, np.uint8),
+                  zone_avail=np.zeros(n * 8 * max(R, 1), np.int64), zone_cost=np.zeros(n * 64, np.int32),
+                  min_avg_dist=np.zeros(n * 8, np.float32), node_present=np.zeros(n, np.uint8))
+        fn = self._lib.spx_flatten_nrt_node_rows
+        self._ck(fn(nodes.ref(), nrt.ref(), slots.ref(), idx.ctypes.data_as(C.POINTER(C.c_int64)), n,
+                    *[v.ctypes.data_as(t) for v, t in zip(nc.values(), fn.argtypes[5:])]))
+        return nc
+
+    def update_nrt_node_rows(self, idx, rows: Dict[str, np.ndarray], n_res: int) -> None:
+        """spx_update_nrt_nodes with rows as flatten_nrt_node_rows returns them"""
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        self._ck(self._lib.spx_update_nrt_nodes(self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                Table(self._hdr, "spx_nrt_nodes_soa", n_nodes=len(idx), n_res=n_res, **rows).ref()))
+
+    def flatten_nrt_pods(self, pods: Table, rc: Optional[Table], slots: Table) -> Dict[str, np.ndarray]:
+        """the pod half of flatten_nrt for a NEW pending batch against slots already uploaded (a cycle's pod delta)"""
+        u8p, i64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64)
+        P, R = pods.struct.n_pods, int(slots.struct.n_res)
+        pc = dict(qos=np.zeros(P, np.uint8), non_native=np.zeros(P, np.uint8), n_ctr=np.zeros(P, np.uint8),
+                  ctr_kind=np.zeros(P * 8, np.uint8), ctr_present=np.zeros(P * 8, np.uint8),
+                  ctr_req=np.zeros(P * 8 * max(R, 1), np.int64), pod_present=np.zeros(P, np.uint8),
+                  pod_req=np.zeros(P * max(R, 1), np.int64))
+        fn = self._lib.spx_flatten_nrt_pods
+        self._ck(fn(pods.ref(), rc.ref() if rc else None, slots.ref(), *[v.ctypes.data_as(t) for v, t in zip(pc.values(), fn.argtypes[3:])]))
+        return pc
+
+    def upload_nrt_pods(self, pc: Dict[str, np.ndarray], n_res: int) -> None:
+        P = len(pc["qos"])
+        self._ck(self._lib.spx_upload_nrt_pods(self._h, Table(self._hdr, "spx_nrt_pods_soa", n_pods=P, n_res=n_res, **pc).ref()))
+        self.n_pods = P
+        self.nrt_soa["pods"] = pc
+
+    def flatten_network_pods(self, pods: Table, appgroups: Table) -> dict:
+        """the per-batch half of flatten_network (workload keys of the pending pods), without the commit effects"""
+        L = self._lib
+        i32p, i64p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)
+        P = pods.struct.n_pods
+        nk, npairs = C.c_int32(), C.c_int64()
+        self._ck(L.spx_flatten_net_keys(pods.ref(), appgroups.ref(), C.byref(nk), C.byref(npairs), None, None, None, None, None, None))
+        cols = dict(pod_key=np.zeros(P, np.int32), topo_order=np.zeros(P, np.int32), key_score_equally=np.zeros(nk.value, np.uint8),
+                    pair_ptr=np.zeros(nk.value + 1, np.int32), pair_node=np.zeros(max(npairs.value, 1), np.int32),
+                    pair_max_cost=np.zeros(max(npairs.value, 1), np.int64))
+        self._ck(L.spx_flatten_net_keys(pods.ref(), appgroups.ref(), C.byref(nk), C.byref(npairs),
+                                        cols["pod_key"].ctypes.data_as(i32p), cols["topo_order"].ctypes.data_as(i32p),
+                                        cols["key_score_equally"].ctypes.data_as(u8p), cols["pair_ptr"].ctypes.data_as(i32p),
+                                        cols["pair_node"].ctypes.data_as(i32p), cols["pair_max_cost"].ctypes.data_as(i64p)))
+        return {"cols": cols, "n_keys": nk.value, "P": P}
+
+    def upload_network_pods(self, f: dict) -> None:
+        self._ck(self._lib.spx_upload_net_pods(self._h, Table(self._hdr, "spx_net_pods_soa", n_pods=f["P"], n_keys=f["n_keys"], **f["cols"]).ref()))
+        self.n_pods = f["P"]
+        self.net_soa = f["cols"]
+
     def upload_nrt(self, f: dict, rows=None) -> None:
         """rows = (begin, end): this engine holds only that slice of the pod batch (MultiEngine)"""
         L, H = self._lib, self._hdr

@@ -116,23 +116,12 @@ extern "C" int spx_flatten_nrt_slots(const spx_pod_objects* pods, const spx_nrt_
   return SPX_OK;
 }
 
-extern "C" int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_nrt_slots* slots,
-                                     uint8_t* flags, int32_t* max_numa, uint8_t* n_zones, uint8_t* zone_id,
-                                     uint8_t* zone_present, int64_t* zone_avail, int32_t* zone_cost, float* min_avg_dist,
-                                     uint8_t* node_present) {
-  if (!nodes || !nrt || !slots || !flags || !max_numa || !n_zones || !zone_id || !zone_present || !zone_avail || !zone_cost ||
-      !min_avg_dist || !node_present)
-    return SPX_ERR_ARG;
-  const int64_t n = nodes->n_nodes;
-  if (nrt->n_nodes != n) return SPX_ERR_ARG;
+namespace {
+// node i of the object tables -> row j of the SoA columns
+int flatten_nrt_node(const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_nrt_slots* slots, int64_t i, int64_t j,
+                     uint8_t* flags, int32_t* max_numa, uint8_t* n_zones, uint8_t* zone_id, uint8_t* zone_present, int64_t* zone_avail,
+                     int32_t* zone_cost, float* min_avg_dist, uint8_t* node_present) {
   const int R = slots->n_res;
-  std::memset(zone_id, 0, static_cast<size_t>(n) * Z);
-  std::memset(zone_present, 0, static_cast<size_t>(n) * Z);
-  std::memset(zone_avail, 0, static_cast<size_t>(n) * Z * R * sizeof(int64_t));
-  std::atomic<int> err{SPX_OK};
-  // nodes are independent: split across host threads (20k nodes x 255 zone subsets for the distance minima alone)
-  spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
-  for (int64_t i = row0; i < row1; ++i) {
     // ---- TopologyManager config
     int scope = 0, policy = 0, mx = 8;
     const int lp = nrt->legacy_policy ? nrt->legacy_policy[i] : -1;
@@ -143,9 +132,9 @@ extern "C" int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nr
     if (nrt->attr_scope && nrt->attr_scope[i] >= 0) scope = nrt->attr_scope[i];
     if (nrt->attr_policy && nrt->attr_policy[i] >= 0) policy = nrt->attr_policy[i];
     if (nrt->attr_max_numa && nrt->attr_max_numa[i] > 1) mx = nrt->attr_max_numa[i] > 1024 ? 1024 : nrt->attr_max_numa[i];
-    flags[i] = static_cast<uint8_t>((nrt->has_nrt[i] ? SPX_NRT_F_HAS_NRT : 0) | (nrt->fresh[i] ? SPX_NRT_F_FRESH : 0) |
+    flags[j] = static_cast<uint8_t>((nrt->has_nrt[i] ? SPX_NRT_F_HAS_NRT : 0) | (nrt->fresh[i] ? SPX_NRT_F_FRESH : 0) |
                                     (policy == 3 ? SPX_NRT_F_SINGLE_NUMA : 0) | (scope == 1 ? SPX_NRT_F_POD_SCOPE : 0));
-    max_numa[i] = mx;
+    max_numa[j] = mx;
     // ---- node-level key set of util.ResourceList(allocatable)
     uint8_t np = 0;
     for (int s = 0; s < R; ++s) {
@@ -154,7 +143,7 @@ extern "C" int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nr
       for (int32_t k = nodes->scalar_ptr[i]; !has && k < nodes->scalar_ptr[i + 1]; ++k) has = nodes->scalar_res[k] == r;
       if (has) np |= static_cast<uint8_t>(1u << s);
     }
-    node_present[i] = np;
+    node_present[j] = np;
     // ---- NUMA node list (list order = zone order), with assumed pods subtracted from every zone
     int nz = 0;
     int32_t zsrc[Z];
@@ -164,17 +153,15 @@ extern "C" int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nr
         const int id = nrt->zone_numa_id[z];
         if (id < 0 || id > 64) continue;
         if (nz >= Z || id > 63) {
-          err = SPX_ERR_ARG;
-          return;
+          return SPX_ERR_ARG;
         }  // beyond this build's limits (8 zones, ids 0..63)
         zsrc[nz] = z;
-        zone_id[i * Z + nz] = static_cast<uint8_t>(id);
+        zone_id[j * Z + nz] = static_cast<uint8_t>(id);
         uint8_t present = 0;
         for (int32_t k = nrt->zres_ptr[z]; k < nrt->zres_ptr[z + 1]; ++k) {
           const int s = slot_of(slots, nrt->zres_res[k]);
           if (s < 0) {
-            err = SPX_ERR_ARG;
-            return;
+            return SPX_ERR_ARG;
           }
           int64_t avail = nrt->zres_avail[k];
           if (nrt->assumed_ptr)
@@ -182,23 +169,23 @@ extern "C" int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nr
               for (int32_t q = nrt->arl_ptr[a]; q < nrt->arl_ptr[a + 1]; ++q)
                 if (nrt->arl_res[q] == nrt->zres_res[k]) avail = avail < nrt->arl_qty[q] ? 0 : avail - nrt->arl_qty[q];
           present |= static_cast<uint8_t>(1u << s);
-          zone_avail[(i * Z + nz) * R + s] = avail;
+          zone_avail[(j * Z + nz) * R + s] = avail;
         }
-        zone_present[i * Z + nz] = present;
+        zone_present[j * Z + nz] = present;
         ++nz;
       }
     }
-    n_zones[i] = static_cast<uint8_t>(nz);
+    n_zones[j] = static_cast<uint8_t>(nz);
     // ---- distance matrix by list position; 255 where Costs has no entry (least_numa.go:127-132)
     for (int a = 0; a < Z; ++a)
       for (int b = 0; b < Z; ++b) {
         int32_t cost = 255;
         if (a < nz && b < nz && nrt->zcost_ptr) {
-          const int want = zone_id[i * Z + b];
+          const int want = zone_id[j * Z + b];
           for (int32_t k = nrt->zcost_ptr[zsrc[a]]; k < nrt->zcost_ptr[zsrc[a] + 1]; ++k)
             if (nrt->zcost_numa_id[k] == want) cost = static_cast<int32_t>(nrt->zcost_value[k]);
         }
-        zone_cost[(i * Z + a) * Z + b] = cost;
+        zone_cost[(j * Z + a) * Z + b] = cost;
       }
     // ---- minAvgDistanceInCombinations for every subset size (float32 exactly as the reference)
     float best[Z];
@@ -208,7 +195,7 @@ extern "C" int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nr
     int pair_sum[1 << Z], least[Z];
     pair_sum[0] = 0;
     for (int k = 0; k < Z; ++k) least[k] = INT32_MAX;
-    const int32_t* c = zone_cost + i * Z * Z;
+    const int32_t* c = zone_cost + j * Z * Z;
     for (unsigned m = 1; m < (1u << nz); ++m) {
       const int z = __builtin_ctz(m);
       const unsigned rest = m & (m - 1);
@@ -226,10 +213,57 @@ extern "C" int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nr
       const float d = static_cast<float>(least[k - 1]) / static_cast<float>(k * k);
       if (d < best[k - 1]) best[k - 1] = d;
     }
-    for (int k = 0; k < Z; ++k) min_avg_dist[i * Z + k] = best[k];
-  }
+    for (int k = 0; k < Z; ++k) min_avg_dist[j * Z + k] = best[k];
+  return SPX_OK;
+}
+}  // namespace
+
+extern "C" int spx_flatten_nrt_nodes(const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_nrt_slots* slots,
+                                     uint8_t* flags, int32_t* max_numa, uint8_t* n_zones, uint8_t* zone_id,
+                                     uint8_t* zone_present, int64_t* zone_avail, int32_t* zone_cost, float* min_avg_dist,
+                                     uint8_t* node_present) {
+  if (!nodes || !nrt || !slots || !flags || !max_numa || !n_zones || !zone_id || !zone_present || !zone_avail || !zone_cost ||
+      !min_avg_dist || !node_present)
+    return SPX_ERR_ARG;
+  const int64_t n = nodes->n_nodes;
+  if (nrt->n_nodes != n) return SPX_ERR_ARG;
+  const int R = slots->n_res;
+  std::memset(zone_id, 0, static_cast<size_t>(n) * Z);
+  std::memset(zone_present, 0, static_cast<size_t>(n) * Z);
+  std::memset(zone_avail, 0, static_cast<size_t>(n) * Z * R * sizeof(int64_t));
+  std::atomic<int> err{SPX_OK};
+  // nodes are independent: split across host threads (20k nodes x 255 zone subsets for the distance minima alone)
+  spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
+    for (int64_t i = row0; i < row1; ++i) {
+      const int rc = flatten_nrt_node(nodes, nrt, slots, i, i, flags, max_numa, n_zones, zone_id, zone_present, zone_avail, zone_cost, min_avg_dist, node_present);
+      if (rc != SPX_OK) {
+        err = rc;
+        return;
+      }
+    }
   }, 256);
   return err.load();
+}
+
+// the same columns for the listed nodes only (a snapshot delta: spx_update_nrt_nodes takes these rows): row j describes node idx[j]
+extern "C" int spx_flatten_nrt_node_rows(const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_nrt_slots* slots,
+                                         const int64_t* idx, int64_t n_rows, uint8_t* flags, int32_t* max_numa, uint8_t* n_zones,
+                                         uint8_t* zone_id, uint8_t* zone_present, int64_t* zone_avail, int32_t* zone_cost, float* min_avg_dist,
+                                         uint8_t* node_present) {
+  if (!nodes || !nrt || !slots || !idx || !flags || !max_numa || !n_zones || !zone_id || !zone_present || !zone_avail || !zone_cost ||
+      !min_avg_dist || !node_present || n_rows < 0)
+    return SPX_ERR_ARG;
+  if (nrt->n_nodes != nodes->n_nodes) return SPX_ERR_ARG;
+  const int R = slots->n_res;
+  std::memset(zone_id, 0, static_cast<size_t>(n_rows) * Z);
+  std::memset(zone_present, 0, static_cast<size_t>(n_rows) * Z);
+  std::memset(zone_avail, 0, static_cast<size_t>(n_rows) * Z * R * sizeof(int64_t));
+  for (int64_t j = 0; j < n_rows; ++j) {
+    if (idx[j] < 0 || idx[j] >= nodes->n_nodes) return SPX_ERR_ARG;
+    const int rc = flatten_nrt_node(nodes, nrt, slots, idx[j], j, flags, max_numa, n_zones, zone_id, zone_present, zone_avail, zone_cost, min_avg_dist, node_present);
+    if (rc != SPX_OK) return rc;
+  }
+  return SPX_OK;
 }
 
 extern "C" int spx_flatten_nrt_pods(const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_nrt_slots* slots,
