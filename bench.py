@@ -129,7 +129,9 @@ def build_snapshot(hdr, w, n_pods, seed):
     from scheduler_plugins_amd import synth
     n_nodes = w["n_nodes"]
     if "cap" in w["plugins"]:
-        snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=seed)
+        # quotas in proportion to the batch's requests (round 3): with the fixed-size quotas 89 % of a 62.5k-pod batch scheduled one
+        # after the other ended over Max and the sequential commit mostly timed rejected pods
+        snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=seed, quota_sized_for_batch=True)
         snap["nrt_params"] = O.nrt_params(hdr, O.Resources(), w["strategy"])
     elif "nrt" in w["plugins"]:
         snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED)
@@ -199,7 +201,7 @@ def delta_cycle(target, w, snap, hdr, mask, score_mask):
     idx = np.sort(rng.choice(n_nodes, max(1, n_nodes // 100), replace=False))
     # the next cycle's pending batch (another seed: other requests, other AppGroup members)
     if "cap" in pl:
-        pods = synth.full_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED + 17)["pods"]
+        pods = synth.full_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED + 17, quota_sized_for_batch=True)["pods"]
     elif "nrt" in pl:
         pods = synth.synth_pods(hdr, n_pods, seed=synth.SEED + 17, device_res=synth.RES_DEVICE, hugepage_res=synth.RES_HUGEPAGES_2MI)
     elif "net" in pl:

@@ -401,7 +401,7 @@ def network_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, p
 
 # ------------------------------------------------------------------ CapacityScheduling (config #5's PreFilter gate)
 def synth_quota(hdr: Header, pods: Table, seed: int = SEED, n_namespaces: int = 100, n_nominated: int = 300, device_res: int = -1,
-                hugepage_res: int = -1) -> Table:
+                hugepage_res: int = -1, sized_for_batch: bool = False) -> Table:
     """ElasticQuotas for Q namespaces (Q=100): 85% of namespaces carry a quota; Used is drawn
     around Min so that both PreFilter gates fire for a visible share of pods; nominated pods with priorities in
     {0,100,1000}, a few of them being pending pods themselves (the uid exclusion, capacity_scheduling.go:239)."""
@@ -418,6 +418,23 @@ def synth_quota(hdr: Header, pods: Table, seed: int = SEED, n_namespaces: int = 
     no_max = rng.random(NS) < 0.1
     mx[no_max, :3] = (1 << 63) - 1
     us[:, :3] = (mn[:, :3] * rng.uniform(0.2, 1.3, (NS, 3))).astype(np.int64)
+    if sized_for_batch:
+        # Quotas in proportion to what the batch's namespaces ask for (the fixed sizes above suit the frozen sweep's PreFilter
+        # hit rate; scheduled one after the other against them, 89 % of a 62.5k-pod batch ends over Max).  Min = 0.7 - 1.4 x the
+        # namespace's total request, Max = 1 - 2 x Min, Used = 0 - 0.25 x Min.
+        P = pods.struct.n_pods
+        cp, qp = pods.array("ctr_ptr"), pods.array("req_ptr")
+        ctr_of = np.repeat(np.arange(len(qp) - 1), np.diff(qp))
+        pod_of_ctr = np.repeat(np.arange(P), np.diff(cp))
+        pod_of_req = pod_of_ctr[ctr_of]
+        ns_of_req = pods.array("ns")[pod_of_req]
+        rr, qq = pods.array("req_res"), pods.array("req_qty")
+        for slot, res in ((0, 0), (1, 1)):
+            demand = np.bincount(ns_of_req[rr == res], weights=qq[rr == res].astype(np.float64), minlength=NS)
+            mn[:, slot] = (np.maximum(demand, 1.0) * rng.uniform(0.7, 1.4, NS)).astype(np.int64)
+        mx[:, :2] = (mn[:, :2] * rng.uniform(1.0, 2.0, (NS, 2))).astype(np.int64)
+        mx[no_max, :2] = (1 << 63) - 1
+        us[:, :2] = (mn[:, :2] * rng.uniform(0.0, 0.25, (NS, 2))).astype(np.int64)
     present = np.zeros(NS, dtype=np.uint8)
     n_scalar = 0
     scalar_res = np.zeros(4, dtype=np.int32)
@@ -427,11 +444,28 @@ def synth_quota(hdr: Header, pods: Table, seed: int = SEED, n_namespaces: int = 
         mn[:, 4] = rng.integers(0, 64, NS)
         mx[:, 4] = mn[:, 4] + rng.integers(0, 64, NS)
         us[:, 4] = rng.integers(0, 80, NS)
+        if sized_for_batch:  # ~10 % of the pods ask for 1-2 devices
+            per_ns = max(1, pods.struct.n_pods // NS)
+            mn[:, 4] = rng.integers(per_ns // 8, per_ns // 3 + 2, NS)
+            mx[:, 4] = mn[:, 4] + rng.integers(0, per_ns // 4 + 2, NS)
+            us[:, 4] = rng.integers(0, per_ns // 40 + 2, NS)
         present[:] = 1 << 4
+    hp_slot = -1
     if hugepage_res >= 0:  # pods may request hugepages: a scalar resource the quotas do not bound (no key in Min/Max)
         scalar_res[n_scalar] = hugepage_res
+        hp_slot = 4 + n_scalar
         n_scalar += 1
     min_present = np.where(rng.random(NS) < 0.9, present, 0).astype(np.uint8)  # some quotas do not list the device in Min
+    if sized_for_batch:
+        # every quota lists every scalar the batch asks for: a scalar missing from Min counts as Min = 0 in the AGGREGATE gate
+        # (cmp2's LowerBoundOfMin, elasticquota.go:193-221 via aggregatedUsedOverMinWith :48-59), so one nominated pod with
+        # hugepages anywhere in the cluster turns every quota'd pod away — faithful, and a degenerate queue to time a commit loop on
+        min_present = present.copy()
+        if hp_slot >= 0:
+            mn[:, hp_slot] = 1 << 44
+            mx[:, hp_slot] = 1 << 45
+            present = (present | (1 << hp_slot)).astype(np.uint8)
+            min_present = present.copy()
     P = pods.struct.n_pods
     nom_ns = rng.integers(0, NS, n_nominated).astype(np.int32)
     nom_prio = rng.choice(np.array([0, 100, 1000], dtype=np.int32), n_nominated)
@@ -450,7 +484,7 @@ def synth_quota(hdr: Header, pods: Table, seed: int = SEED, n_namespaces: int = 
 
 # ------------------------------------------------------------------ full profile (config #5)
 def full_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, pods_per_group: int = 100,
-                  n_namespaces: int = 100) -> Dict[str, Table]:
+                  n_namespaces: int = 100, quota_sized_for_batch: bool = False) -> Dict[str, Table]:
     """One snapshot carrying every table of the full profile: CapacityScheduling PreFilter + Allocatable + NRT +
     trimaran + network-aware (BASELINE.json config #5)."""
     snap = nrt_snapshot(hdr, n_nodes, n_pods, seed)  # nodes (with hugepages/devices), NRT, rc
@@ -461,5 +495,5 @@ def full_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, pods
     snap["assigned"] = synth_assigned(hdr, n_nodes, seed)
     snap["appgroups"], snap["nettopo"] = synth_network(hdr, snap["nodes"], n_groups, seed)
     snap["quota"] = synth_quota(hdr, snap["pods"], seed, n_namespaces=n_namespaces, device_res=RES_DEVICE,
-                                hugepage_res=RES_HUGEPAGES_2MI)
+                                hugepage_res=RES_HUGEPAGES_2MI, sized_for_batch=quota_sized_for_batch)
     return snap
