@@ -79,6 +79,28 @@ __device__ Acc direct_eval(const NetArgs& g, int64_t node, int lo, int hi) {
   return a;
 }
 
+// the same over a pair list staged in LDS (host, its region and zone, MaxNetworkCost): the single-row launch of the sequential
+// commit loop has one workgroup and nothing to hide the two dependent global loads per pair behind (25 us per pod at 20k nodes)
+struct StagedPairs {
+  const int* host;
+  const int* region;
+  const int* zone;
+  const long long* max_cost;
+  int n;
+};
+__device__ Acc direct_eval_staged(const NetArgs& g, int64_t node, const StagedPairs& sp) {
+  Acc a{0, 0, 0};
+  const int region = g.region[node], zone = g.zone[node];
+  for (int i = 0; i < sp.n; ++i) {
+    if (sp.host[i] == node) {
+      a.sat += 1;
+      continue;
+    }
+    add_pair(a, g, region, zone, sp.region[i], sp.zone[i], sp.max_cost[i]);
+  }
+  return a;
+}
+
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
@@ -239,6 +261,7 @@ __device__ __forceinline__ int norm_cost(int cost, int mn, int mx) {
 // One wavefront per pod row in a batch launch; a single-row launch (the sequential commit loop) puts kRowThreads threads on
 // its row — every loop below strides by the block size, the one reduction combines the waves through LDS.
 constexpr int kRowThreads = 1024;
+constexpr int kNetStagePairs = 512;  // pairs of a key staged in LDS by a single-row launch
 __global__ __launch_bounds__(kRowThreads) void k_net_cls(NetArgs g) {
   SPX_RESOLVE_ROWS(g);
   extern __shared__ __align__(16) int lds[];
@@ -271,13 +294,35 @@ __global__ __launch_bounds__(kRowThreads) void k_net_cls(NetArgs g) {
     return;
   }
 
+  // ---- the pair list into LDS when it is short enough (it nearly always is: the placed pods of one AppGroup's dependencies)
+  // (dynamic LDS behind the host bitmap, present only in a single-row launch: a batch launch runs one wave per row and keeps its
+  // LDS footprint — its occupancy — as it was)
+  constexpr int kStage = kNetStagePairs;
+  long long* sp_max = reinterpret_cast<long long*>(lds + ((3 * C + static_cast<int>(n_words) + 1) & ~1));
+  int* sp_host = reinterpret_cast<int*>(sp_max + kStage);
+  int* sp_region = sp_host + kStage;
+  int* sp_zone = sp_region + kStage;
+  const bool staged = nthr == kRowThreads && hi - lo <= kStage;
+  const StagedPairs sp{sp_host, sp_region, sp_zone, sp_max, hi - lo};
+  if (staged) {
+    for (int i = lane; i < hi - lo; i += nthr) {
+      const int host = g.pair_node[lo + i];
+      sp_host[i] = host, sp_region[i] = g.region[host], sp_zone[i] = g.zone[host], sp_max[i] = g.pair_max[lo + i];
+    }
+    __syncthreads();
+  }
+  auto direct = [&](int64_t node) { return staged ? direct_eval_staged(g, node, sp) : direct_eval(g, node, lo, hi); };
   // ---- phase 1 + 2
   for (int c = lane; c < C; c += nthr) {
     Acc a{0, 0, 0};
     const int region = g.cls_region[c], zone = g.cls_zone[c];
-    for (int i = lo; i < hi; ++i) {
-      const int host = g.pair_node[i];  // wave-uniform
-      add_pair(a, g, region, zone, g.region[host], g.zone[host], g.pair_max[i]);
+    if (staged) {
+      for (int i = 0; i < sp.n; ++i) add_pair(a, g, region, zone, sp_region[i], sp_zone[i], sp_max[i]);
+    } else {
+      for (int i = lo; i < hi; ++i) {
+        const int host = g.pair_node[i];  // wave-uniform
+        add_pair(a, g, region, zone, g.region[host], g.zone[host], g.pair_max[i]);
+      }
     }
     cls_word[c] = a.cost | (a.vio > a.sat ? static_cast<int>(0x80000000u) : 0);
     cls_hosts[c] = 0;
@@ -313,7 +358,7 @@ __global__ __launch_bounds__(kRowThreads) void k_net_cls(NetArgs g) {
       }
     }
     for (int i = lo + lane; i < hi; i += nthr) {
-      const Acc a = direct_eval(g, g.pair_node[i], lo, hi);
+      const Acc a = direct(g.pair_node[i]);
       if (!(a.vio > a.sat)) {
         mn = a.cost < mn ? a.cost : mn;
         mx = a.cost > mx ? a.cost : mx;
@@ -331,7 +376,7 @@ __global__ __launch_bounds__(kRowThreads) void k_net_cls(NetArgs g) {
         if (n0 + j >= g.n_nodes || ((oth >> (8 * j)) & 0xffu)) continue;
         int w;
         if ((hb >> j) & 1u) {
-          const Acc a = direct_eval(g, n0 + j, lo, hi);
+          const Acc a = direct(n0 + j);
           w = a.cost | (a.vio > a.sat ? static_cast<int>(0x80000000u) : 0);
         } else {
           w = cls_word[(cw >> (16 * j)) & 0xffffu];
@@ -378,7 +423,7 @@ __global__ __launch_bounds__(kRowThreads) void k_net_cls(NetArgs g) {
       for (int j = 0; j < kNpl; ++j) {
         uint32_t fin = cls_fin[(cw >> (16 * j)) & 0xffffu];
         if ((hb >> j) & 1u) {  // a host of one of the pod's pairs: exact
-          const Acc a = direct_eval(g, n0 + j, lo, hi);
+          const Acc a = direct(n0 + j);
           const bool pass = !(a.vio > a.sat);
           int score = pass ? norm_cost(a.cost, mn, mx) : 0;
           score = score < 0 ? 0 : (score > 255 ? 255 : score);
@@ -404,7 +449,8 @@ size_t net_lds_bytes(int n_classes, int64_t n_nodes) {
 void launch_net(const NetArgs& g, hipStream_t s) {
   if (g.row_end <= g.row_begin) return;
   const unsigned blocks = static_cast<unsigned>(g.row_end - g.row_begin);
-  const size_t lds = g.n_classes > 0 ? net_lds_bytes(g.n_classes, g.n_nodes) : 16;
+  size_t lds = g.n_classes > 0 ? net_lds_bytes(g.n_classes, g.n_nodes) : 16;
+  if (blocks == 1) lds = ((lds + 7) & ~static_cast<size_t>(7)) + kNetStagePairs * (sizeof(long long) + 3 * sizeof(int));  // the staged pair list
   const bool generic_only = (g.opts & kOptNetGeneric) != 0;  // SPX_OPT_REFERENCE_KERNELS
   if (!generic_only && !g.out_raw && g.n_classes > 0 && g.n_classes <= 65535 && g.node_class16)
     hipLaunchKernelGGL(k_net_cls, dim3(blocks), dim3(blocks == 1 ? kRowThreads : 64), lds, s, g);

@@ -1178,7 +1178,9 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   const unsigned blocks = static_cast<unsigned>(chunks * per_round);  // see the kernel's block map
   const int sg = a.strategy == SPX_NRT_LEAST_NUMA_NODES ? kSgLeastNuma
                : a.strategy == SPX_NRT_BALANCED_ALLOCATION ? kSgBalanced : (a.strategy == SPX_NRT_LEAST_ALLOCATED ? kSgLeast : kSgMost);
-  const bool split = a.out_raw == nullptr && !(a.opts & kOptNrtSingleLaunch);
+  // two launches (Filter, Score) for a batch; one for a single row — the sequential commit loop replays its per-pod launches from
+  // a graph and is bound by their number, not by occupancy
+  const bool split = a.out_raw == nullptr && !(a.opts & kOptNrtSingleLaunch) && a.row_ptr == nullptr;
 #define SPX_NRTF_CASE(RMV, SGV)                                                                           \
   if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                                        \
     if (split) { /* the Filter half does not depend on the strategy */ \

@@ -1420,7 +1420,7 @@ int spx_upload_net_nodes(spx_engine* e, const spx_net_nodes_soa* t) {
     }
   }
   int32_t n_classes = static_cast<int32_t>(cr.size());
-  if (spx::net_lds_bytes(n_classes, n) > 60 * 1024) n_classes = 0;  // too many label pairs for LDS: exact path only
+  if (spx::net_lds_bytes(n_classes, n) > 52 * 1024) n_classes = 0;  // too many label pairs for LDS (64 KB with a single-row launch's staged pairs): exact path only
   e->net_n_classes = n_classes;
   if ((rc = upload(e, e->d_net_region, t->region, static_cast<size_t>(n) * 4))) return rc;
   if ((rc = upload(e, e->d_net_zone, t->zone, static_cast<size_t>(n) * 4))) return rc;

@@ -9,7 +9,7 @@ from scheduler_plugins_amd.engine import Engine, mask_of
 
 n_pods = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 hdr = spx.header()
-snap = synth.full_snapshot(hdr, 20_000, n_pods)
+snap = synth.full_snapshot(hdr, 20_000, n_pods, quota_sized_for_batch=True)
 params = O.nrt_params(hdr, O.Resources(), "LeastAllocated")
 with Engine(0) as e:
     if len(sys.argv) > 2 and sys.argv[2] == "direct":  # plain launches instead of the replayed graph (rocprofv3 7.2 crashes on the capture)
