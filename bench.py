@@ -97,7 +97,7 @@ PID = {"alloc": 0, "tlp": 1, "lvrb": 2, "nrt": 3, "net": 4, "cap": 5, "lroc": 7,
 KERNEL_FILES = {
     "alloc": ("kernels_trimaran.hip",), "tlp": ("kernels_trimaran.hip",), "lvrb": ("kernels_trimaran.hip",),
     "lroc": ("kernels_lroc.hip",), "peaks": ("kernels_peaks.hip",),
-    "nrt": ("kernels_nrt_fast.hip", "kernels_nrt.hip"), "net": ("kernels_network.hip",),
+    "nrt": ("kernels_nrt_fast.hip", "kernels_nrt.hip", "kernels_profile.hip"), "net": ("kernels_network.hip",),
     "cap": ("kernels_capacity.hip", "kernels_profile.hip"),
 }
 
