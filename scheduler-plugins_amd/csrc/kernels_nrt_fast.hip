@@ -685,7 +685,7 @@ constexpr int kPhBoth = 0, kPhFilter = 1, kPhScore = 2;
 #define SPX_NRT_LB_LEAST 4
 #endif
 #ifndef SPX_NRT_LB_MOST
-#define SPX_NRT_LB_MOST 4
+#define SPX_NRT_LB_MOST 3
 #endif
 #ifndef SPX_NRT_LB_BAL
 #define SPX_NRT_LB_BAL 3
