@@ -1218,6 +1218,174 @@ static int build_ln_tab(spx_engine* e) {
   return SPX_OK;
 }
 
+namespace {
+// The pod record stream of the float64 NRT formulation, built on the host (no device involved: spx_internal_nrt_pod_classes lets
+// the CPU tests see it).
+// nrt_pod_items: per pod 10 items of IW dwords (IW = 16 for <= 4 resource slots, else 32), RM = 4 or 8 slots:
+//   item 0   header: w0 = qos | non_native << 8 | n_ctr << 16 | last app container << 24 (0xff: none),
+//                    w1 = ceil(2^16 / n_ctr)
+//   item 1   the pod-level effective request;  items 2..9  the containers, in order
+//   request item: doubles raw[RM] (dwords 0..2RM-1); dword 2RM = requested slots | compared slots << 8 |
+//                 "any reporting zone suits" slots << 16 | kind << 24; dword 2RM+1 = sum of the weights of the requested
+//                 slots as an integer; then what only the Score reads: Value() of the
+//                 cpu request (2RM+2), sum of the weights of the requested slots (2RM+4), its biased reciprocal (2RM+6)
+void nrt_build_items(const spx_nrt_pods_soa* t, const uint8_t* slot_flags, int cpu_slot, const std::vector<double>& wtab, uint32_t* items,
+                     bool* ok_out, uint32_t* big_out) {
+  const size_t p = static_cast<size_t>(t->n_pods), R = static_cast<size_t>(t->n_res);
+  constexpr size_t Cm = SPX_NRT_MAX_CTRS;
+  const int RMs = R <= 4 ? 4 : 8;
+  const size_t IW = R <= 4 ? 16 : 32;
+  const uint32_t slot_mask = (1u << R) - 1u;
+  std::atomic<bool> ok{wtab.size() == (static_cast<size_t>(2) << R)};
+  std::atomic<uint32_t> big_pods{0};
+  auto put_f64 = [](uint32_t* w, double v) { std::memcpy(w, &v, sizeof v); };
+  auto fill = [&](uint32_t* w, uint32_t present, const int64_t* req, bool non_g, uint32_t kind) {
+    const uint32_t used = present & slot_mask;
+    uint32_t fit = 0, always = 0;
+    for (size_t r = 0; r < R; ++r) {
+      if (!nrt_fast_qty(req[r])) ok = false;
+      if (nrt_value_of(static_cast<int>(r) == cpu_slot, req[r]) >= 16777216) big_pods.fetch_or(1u << r, std::memory_order_relaxed);
+      put_f64(w + 2 * r, static_cast<double>(req[r]));
+      if (!((used >> r) & 1u) || req[r] == 0) continue;  // "ignoring zero-qty resource request" filter.go:103-106
+      if (non_g && (slot_flags[r] & SPX_NRT_SLOT_AFFINE)) always |= 1u << r;
+      else fit |= 1u << r;
+    }
+    const int64_t cpu_q = cpu_slot >= 0 ? req[cpu_slot] : 0;
+    w[2 * RMs] = used | (fit << 8) | (always << 16) | (kind << 24);
+    put_f64(w + 2 * RMs + 2, static_cast<double>(nrt_value_of(true, cpu_q)));
+    if (ok.load(std::memory_order_relaxed)) {
+      w[2 * RMs + 1] = static_cast<uint32_t>(wtab[2 * used]);  // the weight sum as an integer (< 2^20)
+      put_f64(w + 2 * RMs + 4, wtab[2 * used]);
+      put_f64(w + 2 * RMs + 6, wtab[2 * used + 1]);
+    }
+  };
+  spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
+  std::memset(items + static_cast<size_t>(row0) * 10 * IW, 0, static_cast<size_t>(row1 - row0) * 10 * IW * sizeof(uint32_t));
+  for (size_t i = static_cast<size_t>(row0); i < static_cast<size_t>(row1); ++i) {
+    uint32_t* w = &items[i * 10 * IW];
+    const bool non_g = t->qos[i] != SPX_QOS_GUARANTEED;
+    const uint32_t n_ctr = t->n_ctr[i];
+    uint32_t last_app = 0xffu;
+    bool seen_app = false;
+    for (size_t c = 0; c < Cm; ++c) {
+      const uint32_t kind = t->ctr_kind[i * Cm + c];
+      if (c < n_ctr) {
+        if (kind == SPX_CTR_APP) {
+          last_app = static_cast<uint32_t>(c);
+          seen_app = true;
+        } else if (seen_app) {
+          ok = false;  // the single-pass Filter needs init containers listed before app containers
+        }
+      }
+      fill(w + (2 + c) * IW, t->ctr_present[i * Cm + c], t->ctr_req + (i * Cm + c) * R, non_g, kind);
+    }
+    fill(w + IW, t->pod_present[i], t->pod_req + i * R, non_g, 0);
+    w[0] = t->qos[i] | (static_cast<uint32_t>(t->non_native[i] != 0) << 8) | (n_ctr << 16) | (last_app << 24);
+    w[1] = n_ctr ? (65536u + n_ctr - 1u) / n_ctr : 0u;
+  }
+  }, 4096);
+  *ok_out = ok.load();
+  *big_out = big_pods.load();
+}
+
+// Pod equivalence classes: rep[i] = the first row whose canonical record equals row i's (rep[i] == i: a representative).  Two pods
+// get the same NRT rows on every node when their records agree in everything the sweep reads, and a queue is full of such pods:
+// replicas of one Deployment, and every pod whose verdict does not depend on quantities — a pod that is not filtered (BestEffort
+// without non-native resources, filter.go:186-190) passes and scores 100 whatever it asks for; a non-Guaranteed pod scores 100
+// (score.go:72-76) and its NUMA-affine requests suit any reporting zone (numaresources.go:137-142), so only their presence counts.
+// The record is canonicalised accordingly, hashed, and equal records (verified word for word) share their first row.
+void nrt_build_classes(const uint32_t* items, size_t p, size_t R, int32_t* rep) {
+  const int RMs = R <= 4 ? 4 : 8;
+  const size_t IW = R <= 4 ? 16 : 32;
+  const size_t PW = 10 * IW;
+  auto canon = [&](size_t i, uint32_t* c) {
+    const uint32_t* w = items + i * PW;
+    std::memcpy(c, w, PW * sizeof(uint32_t));
+    const uint32_t qos = w[0] & 0xffu, n_ctr = (w[0] >> 16) & 0xffu;
+    const bool non_native = ((w[0] >> 8) & 0xffu) != 0;
+    if (qos == SPX_QOS_BESTEFFORT && !non_native) {  // nothing but the class is read
+      std::memset(c, 0, PW * sizeof(uint32_t));
+      c[0] = qos;
+      return;
+    }
+    for (size_t slot = 2 + n_ctr; slot < 10; ++slot) std::memset(c + slot * IW, 0, IW * sizeof(uint32_t));  // past the last container
+    if (qos != SPX_QOS_GUARANTEED) {
+      c[1] = 0;  // the mean over containers belongs to the Score
+      for (size_t slot = 1; slot < 2 + n_ctr; ++slot) {
+        uint32_t* it = c + slot * IW;
+        const uint32_t sets = it[2 * RMs], fit = (sets >> 8) & 0xffu;
+        for (size_t r = 0; r < static_cast<size_t>(RMs); ++r)
+          if (!((fit >> r) & 1u)) it[2 * r] = it[2 * r + 1] = 0;  // only compared quantities matter
+        it[2 * RMs] = sets & 0xffffff00u;                        // "requested" steers the Score only
+        for (size_t k = 2 * RMs + 1; k < IW; ++k) it[k] = 0;      // weight sums, Value() of the cpu request
+      }
+    }
+  };
+  std::vector<uint64_t> hash(p);
+  spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
+    std::vector<uint32_t> c(PW);
+    for (int64_t i = row0; i < row1; ++i) {
+      canon(static_cast<size_t>(i), c.data());
+      uint64_t h = 0x9e3779b97f4a7c15ull;
+      for (size_t k = 0; k < PW; k += 2) {
+        h ^= (static_cast<uint64_t>(c[k + 1]) << 32) | c[k];
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 29;
+      }
+      hash[static_cast<size_t>(i)] = h;
+    }
+  }, 4096);
+  // serial: first row of each hash value; parallel: every other row verified word for word against that row
+  std::unordered_map<uint64_t, int32_t> rep_of_hash;
+  rep_of_hash.reserve(p);
+  for (size_t i = 0; i < p; ++i) rep[i] = rep_of_hash.emplace(hash[i], static_cast<int32_t>(i)).first->second;
+  spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
+    std::vector<uint32_t> ca(PW), cb(PW);
+    for (int64_t i = row0; i < row1; ++i) {
+      const int32_t r0 = rep[static_cast<size_t>(i)];
+      if (r0 == i) continue;
+      canon(static_cast<size_t>(i), ca.data());
+      canon(static_cast<size_t>(r0), cb.data());
+      if (std::memcmp(ca.data(), cb.data(), PW * sizeof(uint32_t)) != 0) rep[static_cast<size_t>(i)] = static_cast<int32_t>(i);  // a hash collision: the row stands for itself
+    }
+  }, 2048);
+}
+}  // namespace
+
+// test hook (host only, no device): the representative row of every pod of a batch, as spx_upload_nrt_pods computes it
+// (rep_out[i] == i for a representative); *fast_ok_out = whether the batch satisfies the float64 formulation's preconditions
+// (the classes are only built, and only used, when it does)
+int spx_internal_nrt_pod_classes(const spx_nrt_slots* slots, const spx_nrt_pods_soa* t, int32_t* rep_out, int32_t* fast_ok_out) {
+  if (!slots || !t || !rep_out || !fast_ok_out || t->n_res != slots->n_res || t->n_pods <= 0) return SPX_ERR_ARG;
+  const int R = t->n_res;
+  int cpu_slot = -1;
+  int64_t wtotal = 0;
+  bool slots_ok = true;
+  for (int i = 0; i < R; ++i) {
+    if (slots->slot_flags[i] & SPX_NRT_SLOT_CPU) cpu_slot = i;
+    if (slots->slot_weight[i] < 0 || slots->slot_weight[i] >= kNrtWeightLimit) slots_ok = false;
+    else wtotal += slots->slot_weight[i];
+  }
+  if (wtotal >= kNrtWeightLimit) slots_ok = false;
+  std::vector<double> wtab(static_cast<size_t>(2) << R, 0.0);
+  for (unsigned m = 0; m < (1u << R); ++m) {
+    int64_t w = 0;
+    for (int i = 0; i < R; ++i)
+      if ((m >> i) & 1u) w += slots->slot_weight[i];
+    wtab[2 * m] = static_cast<double>(w);
+    wtab[2 * m + 1] = nrt_biased_rcp(static_cast<double>(w));
+  }
+  const size_t p = static_cast<size_t>(t->n_pods), IW = R <= 4 ? 16 : 32;
+  std::vector<uint32_t> items(p * 10 * IW);
+  bool ok = false;
+  uint32_t big = 0;
+  nrt_build_items(t, slots->slot_flags, cpu_slot, wtab, items.data(), &ok, &big);
+  *fast_ok_out = (ok && slots_ok) ? 1 : 0;
+  for (size_t i = 0; i < p; ++i) rep_out[i] = static_cast<int32_t>(i);
+  if (ok && slots_ok) nrt_build_classes(items.data(), p, static_cast<size_t>(R), rep_out);
+  return SPX_OK;
+}
+
 int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
   if (!e || !t) return SPX_ERR_ARG;
   SPX_HIP(e, hipSetDevice(e->device));
@@ -1235,16 +1403,7 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
   if (!t->ctr_req && p * R) return fail(e, SPX_ERR_ARG, "NULL column in table");
   if ((rc = upload(e, e->d_nrt_ppres, t->pod_present, p))) return rc;
   if ((rc = upload(e, e->d_nrt_preq, t->pod_req, p * R * 8))) return rc;
-  {  // float64 formulation: the pod record stream + precondition check
-    // nrt_pod_items: per pod 10 items of IW dwords (IW = 16 for <= 4 resource slots, else 32), RM = 4 or 8 slots:
-    //   item 0   header: w0 = qos | non_native << 8 | n_ctr << 16 | last app container << 24 (0xff: none),
-    //                    w1 = ceil(2^16 / n_ctr)
-    //   item 1   the pod-level effective request;  items 2..9  the containers, in order
-    //   request item: doubles raw[RM] (dwords 0..2RM-1); dword 2RM = requested slots | compared slots << 8 |
-    //                 "any reporting zone suits" slots << 16 | kind << 24; dword 2RM+1 = sum of the weights of the requested
-    //                 slots as an integer; then what only the Score reads: Value() of the
-    //                 cpu request (2RM+2), sum of the weights of the requested slots (2RM+4), its biased reciprocal (2RM+6)
-    const int RMs = R <= 4 ? 4 : 8;
+  {  // float64 formulation: the pod record stream (nrt_build_items) + its preconditions, then the pod equivalence classes
     const size_t IW = R <= 4 ? 16 : 32;
     const size_t items_bytes = p * 10 * IW * sizeof(uint32_t);
     if (e->h_stage_bytes < items_bytes) {
@@ -1254,125 +1413,22 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
       e->h_stage_bytes = items_bytes + (items_bytes >> 3);
     }
     uint32_t* const items = static_cast<uint32_t*>(e->h_stage);  // pinned: built in place (rows zeroed by the thread that fills them)
-    const uint32_t slot_mask = (1u << R) - 1u;
-    std::atomic<bool> ok{e->nrt_wtab.size() == (static_cast<size_t>(2) << R)};
-    std::atomic<uint32_t> big_pods{0};
-    auto put_f64 = [](uint32_t* w, double v) { std::memcpy(w, &v, sizeof v); };
-    auto fill = [&](uint32_t* w, uint32_t present, const int64_t* req, bool non_g, uint32_t kind) {
-      const uint32_t used = present & slot_mask;
-      uint32_t fit = 0, always = 0;
-      for (size_t r = 0; r < R; ++r) {
-        if (!nrt_fast_qty(req[r])) ok = false;
-        if (nrt_value_of(static_cast<int>(r) == e->nrt_cpu_slot, req[r]) >= 16777216) big_pods.fetch_or(1u << r, std::memory_order_relaxed);
-        put_f64(w + 2 * r, static_cast<double>(req[r]));
-        if (!((used >> r) & 1u) || req[r] == 0) continue;  // "ignoring zero-qty resource request" filter.go:103-106
-        if (non_g && (e->nrt_slot_flags[r] & SPX_NRT_SLOT_AFFINE)) always |= 1u << r;
-        else fit |= 1u << r;
-      }
-      const int64_t cpu_q = e->nrt_cpu_slot >= 0 ? req[e->nrt_cpu_slot] : 0;
-      w[2 * RMs] = used | (fit << 8) | (always << 16) | (kind << 24);
-      put_f64(w + 2 * RMs + 2, static_cast<double>(nrt_value_of(true, cpu_q)));
-      if (ok.load(std::memory_order_relaxed)) {
-        w[2 * RMs + 1] = static_cast<uint32_t>(e->nrt_wtab[2 * used]);  // the weight sum as an integer (< 2^20)
-        put_f64(w + 2 * RMs + 4, e->nrt_wtab[2 * used]);
-        put_f64(w + 2 * RMs + 6, e->nrt_wtab[2 * used + 1]);
-      }
-    };
-    spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
-    std::memset(items + static_cast<size_t>(row0) * 10 * IW, 0, static_cast<size_t>(row1 - row0) * 10 * IW * sizeof(uint32_t));
-    for (size_t i = static_cast<size_t>(row0); i < static_cast<size_t>(row1); ++i) {
-      uint32_t* w = &items[i * 10 * IW];
-      const bool non_g = t->qos[i] != SPX_QOS_GUARANTEED;
-      const uint32_t n_ctr = t->n_ctr[i];
-      uint32_t last_app = 0xffu;
-      bool seen_app = false;
-      for (size_t c = 0; c < Cm; ++c) {
-        const uint32_t kind = t->ctr_kind[i * Cm + c];
-        if (c < n_ctr) {
-          if (kind == SPX_CTR_APP) {
-            last_app = static_cast<uint32_t>(c);
-            seen_app = true;
-          } else if (seen_app) {
-            ok = false;  // the single-pass Filter needs init containers listed before app containers
-          }
-        }
-        fill(w + (2 + c) * IW, t->ctr_present[i * Cm + c], t->ctr_req + (i * Cm + c) * R, non_g, kind);
-      }
-      fill(w + IW, t->pod_present[i], t->pod_req + i * R, non_g, 0);
-      w[0] = t->qos[i] | (static_cast<uint32_t>(t->non_native[i] != 0) << 8) | (n_ctr << 16) | (last_app << 24);
-      w[1] = n_ctr ? (65536u + n_ctr - 1u) / n_ctr : 0u;
-    }
-    }, 4096);
+    bool ok = false;
+    uint32_t big = 0;
+    nrt_build_items(t, e->nrt_slot_flags, e->nrt_cpu_slot, e->nrt_wtab, items, &ok, &big);
     if ((rc = upload(e, e->d_nrt_items, items, items_bytes))) return rc;  // from pinned memory: one DMA at link speed, asynchronous
-    e->nrt_fast_pods = ok.load();
-    e->nrt_big_pods = big_pods.load();
+    e->nrt_fast_pods = ok;
+    e->nrt_big_pods = big;
     // the reference-arithmetic kernel's request column: shipped only when the record stream cannot stand in for it
     e->nrt_creq_valid = false;
     if (!e->nrt_fast_pods) {
       if ((rc = upload(e, e->d_nrt_creq, t->ctr_req, p * Cm * R * 8))) return rc;
       e->nrt_creq_valid = true;
     }
-    // Pod equivalence classes.  Two pods get the same NRT rows on every node when their records agree in everything the
-    // sweep reads, and a queue is full of such pods: replicas of one Deployment, and every pod whose verdict does not depend
-    // on quantities — a pod that is not filtered (BestEffort without non-native resources, filter.go:186-190) passes and
-    // scores 100 whatever it asks for; a non-Guaranteed pod scores 100 (score.go:72-76) and its NUMA-affine requests suit any
-    // reporting zone (numaresources.go:137-142), so only their presence counts.  The record is canonicalised accordingly,
-    // hashed, and equal records (verified word for word) share the first such row as their representative.
     e->nrt_n_uniq = e->nrt_n_dups = 0;
     if (e->nrt_fast_pods && p > 0) {
-      const size_t PW = 10 * IW;
-      auto canon = [&](size_t i, uint32_t* c) {
-        const uint32_t* w = items + i * PW;
-        std::memcpy(c, w, PW * sizeof(uint32_t));
-        const uint32_t qos = w[0] & 0xffu, n_ctr = (w[0] >> 16) & 0xffu;
-        const bool non_native = ((w[0] >> 8) & 0xffu) != 0;
-        if (qos == SPX_QOS_BESTEFFORT && !non_native) {  // nothing but the class is read
-          std::memset(c, 0, PW * sizeof(uint32_t));
-          c[0] = qos;
-          return;
-        }
-        for (size_t slot = 2 + n_ctr; slot < 10; ++slot) std::memset(c + slot * IW, 0, IW * sizeof(uint32_t));  // past the last container
-        if (qos != SPX_QOS_GUARANTEED) {
-          c[1] = 0;  // the mean over containers belongs to the Score
-          for (size_t slot = 1; slot < 2 + n_ctr; ++slot) {
-            uint32_t* it = c + slot * IW;
-            const uint32_t sets = it[2 * RMs], fit = (sets >> 8) & 0xffu;
-            for (size_t r = 0; r < static_cast<size_t>(RMs); ++r)
-              if (!((fit >> r) & 1u)) it[2 * r] = it[2 * r + 1] = 0;  // only compared quantities matter
-            it[2 * RMs] = sets & 0xffffff00u;                        // "requested" steers the Score only
-            for (size_t k = 2 * RMs + 1; k < IW; ++k) it[k] = 0;      // weight sums, Value() of the cpu request
-          }
-        }
-      };
-      std::vector<uint64_t> hash(p);
-      spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
-        std::vector<uint32_t> c(PW);
-        for (int64_t i = row0; i < row1; ++i) {
-          canon(static_cast<size_t>(i), c.data());
-          uint64_t h = 0x9e3779b97f4a7c15ull;
-          for (size_t k = 0; k < PW; k += 2) {
-            h ^= (static_cast<uint64_t>(c[k + 1]) << 32) | c[k];
-            h *= 0xff51afd7ed558ccdull;
-            h ^= h >> 29;
-          }
-          hash[static_cast<size_t>(i)] = h;
-        }
-      }, 4096);
-      // serial: first row of each hash value; parallel: every other row verified word for word against that row
-      std::unordered_map<uint64_t, int32_t> rep_of_hash;
-      rep_of_hash.reserve(p);
       std::vector<int32_t> rep(p);
-      for (size_t i = 0; i < p; ++i) rep[i] = rep_of_hash.emplace(hash[i], static_cast<int32_t>(i)).first->second;
-      spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
-        std::vector<uint32_t> ca(PW), cb(PW);
-        for (int64_t i = row0; i < row1; ++i) {
-          const int32_t r0 = rep[static_cast<size_t>(i)];
-          if (r0 == i) continue;
-          canon(static_cast<size_t>(i), ca.data());
-          canon(static_cast<size_t>(r0), cb.data());
-          if (std::memcmp(ca.data(), cb.data(), PW * sizeof(uint32_t)) != 0) rep[static_cast<size_t>(i)] = static_cast<int32_t>(i);  // a hash collision: the row stands for itself
-        }
-      }, 2048);
+      nrt_build_classes(items, p, R, rep.data());
       std::vector<int32_t> uniq, dups;
       uniq.reserve(p), dups.reserve(2 * p);
       for (size_t i = 0; i < p; ++i) {
