@@ -16,6 +16,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <thread>
 
 #include "spx_internal.h"
 #include "../host/parallel.hpp"
@@ -1219,6 +1220,64 @@ static int build_ln_tab(spx_engine* e) {
 }
 
 namespace {
+// The canonical view of a pod record, on which the pod equivalence classes are built (nrt_build_classes).  Two pods get the same
+// NRT rows on every node when their records agree in everything the sweep reads, and a queue is full of such pods: replicas of
+// one Deployment, and every pod whose verdict does not depend on quantities — a pod that is not filtered (BestEffort without
+// non-native resources, filter.go:186-190) passes and scores 100 whatever it asks for; a non-Guaranteed pod scores 100
+// (score.go:72-76) and its NUMA-affine requests suit any reporting zone (numaresources.go:137-142), so only their presence
+// counts.  The view is never materialised: a header pair and, per live item (pod level + the n_ctr containers), IW dwords
+// produced on the stack; everything past the last container is out of it (equal headers = equal n_ctr).
+struct NrtCanon {
+  size_t RMs, IW;
+  struct Head {
+    uint32_t w0, w1;
+    size_t n_items;  // 0: a pod nothing but whose class is read
+    bool guaranteed;
+  };
+  Head head_of(const uint32_t* w) const {
+    const uint32_t qos = w[0] & 0xffu, n_ctr = (w[0] >> 16) & 0xffu;
+    const bool non_native = ((w[0] >> 8) & 0xffu) != 0;
+    if (qos == SPX_QOS_BESTEFFORT && !non_native) return Head{qos, 0u, 0, false};
+    const bool g = qos == SPX_QOS_GUARANTEED;
+    return Head{w[0], g ? w[1] : 0u, 1 + static_cast<size_t>(n_ctr), g};  // the mean over containers (w1) belongs to the Score
+  }
+  void item(const uint32_t* it, bool guaranteed, uint32_t* c) const {
+    std::memcpy(c, it, IW * sizeof(uint32_t));
+    if (guaranteed) return;
+    const uint32_t sets = it[2 * RMs], fit = (sets >> 8) & 0xffu;
+    for (size_t r = 0; r < RMs; ++r)
+      if (!((fit >> r) & 1u)) c[2 * r] = c[2 * r + 1] = 0;  // only compared quantities matter
+    c[2 * RMs] = sets & 0xffffff00u;                        // "requested" steers the Score only
+    for (size_t k = 2 * RMs + 1; k < IW; ++k) c[k] = 0;      // weight sums, Value() of the cpu request
+  }
+  static uint64_t mix(uint64_t h, uint64_t v) {
+    h ^= v;
+    h *= 0xff51afd7ed558ccdull;
+    return h ^ (h >> 29);
+  }
+  uint64_t hash(const uint32_t* w) const {
+    uint32_t c[32];
+    const Head hd = head_of(w);
+    uint64_t h = mix(0x9e3779b97f4a7c15ull, (static_cast<uint64_t>(hd.w1) << 32) | hd.w0);
+    for (size_t s = 1; s <= hd.n_items; ++s) {
+      item(w + s * IW, hd.guaranteed, c);
+      for (size_t k = 0; k < IW; k += 2) h = mix(h, (static_cast<uint64_t>(c[k + 1]) << 32) | c[k]);
+    }
+    return h;
+  }
+  bool equal(const uint32_t* wa, const uint32_t* wb) const {
+    uint32_t ca[32], cb[32];
+    const Head ha = head_of(wa), hb = head_of(wb);
+    bool same = ha.w0 == hb.w0 && ha.w1 == hb.w1 && ha.n_items == hb.n_items;
+    for (size_t s = 1; same && s <= ha.n_items; ++s) {
+      item(wa + s * IW, ha.guaranteed, ca);
+      item(wb + s * IW, hb.guaranteed, cb);
+      same = std::memcmp(ca, cb, IW * sizeof(uint32_t)) == 0;
+    }
+    return same;
+  }
+};
+
 // The pod record stream of the float64 NRT formulation, built on the host (no device involved: spx_internal_nrt_pod_classes lets
 // the CPU tests see it).
 // nrt_pod_items: per pod 10 items of IW dwords (IW = 16 for <= 4 resource slots, else 32), RM = 4 or 8 slots:
@@ -1229,8 +1288,9 @@ namespace {
 //                 "any reporting zone suits" slots << 16 | kind << 24; dword 2RM+1 = sum of the weights of the requested
 //                 slots as an integer; then what only the Score reads: Value() of the
 //                 cpu request (2RM+2), sum of the weights of the requested slots (2RM+4), its biased reciprocal (2RM+6)
+// hash_out (optional): the hash of each record's canonical view, taken while the record is still in cache
 void nrt_build_items(const spx_nrt_pods_soa* t, const uint8_t* slot_flags, int cpu_slot, const std::vector<double>& wtab, uint32_t* items,
-                     bool* ok_out, uint32_t* big_out) {
+                     bool* ok_out, uint32_t* big_out, uint64_t* hash_out) {
   const size_t p = static_cast<size_t>(t->n_pods), R = static_cast<size_t>(t->n_res);
   constexpr size_t Cm = SPX_NRT_MAX_CTRS;
   const int RMs = R <= 4 ? 4 : 8;
@@ -1239,12 +1299,15 @@ void nrt_build_items(const spx_nrt_pods_soa* t, const uint8_t* slot_flags, int c
   std::atomic<bool> ok{wtab.size() == (static_cast<size_t>(2) << R)};
   std::atomic<uint32_t> big_pods{0};
   auto put_f64 = [](uint32_t* w, double v) { std::memcpy(w, &v, sizeof v); };
-  auto fill = [&](uint32_t* w, uint32_t present, const int64_t* req, bool non_g, uint32_t kind) {
+  const bool tab_ok = ok.load();
+  const NrtCanon canon{static_cast<size_t>(RMs), IW};
+  // bad / big: per calling thread, merged once per chunk (the shared flags would bounce between the cores otherwise)
+  auto fill = [&](uint32_t* w, uint32_t present, const int64_t* req, bool non_g, uint32_t kind, bool& bad, uint32_t& big) {
     const uint32_t used = present & slot_mask;
     uint32_t fit = 0, always = 0;
     for (size_t r = 0; r < R; ++r) {
-      if (!nrt_fast_qty(req[r])) ok = false;
-      if (nrt_value_of(static_cast<int>(r) == cpu_slot, req[r]) >= 16777216) big_pods.fetch_or(1u << r, std::memory_order_relaxed);
+      if (!nrt_fast_qty(req[r])) bad = true;
+      if (nrt_value_of(static_cast<int>(r) == cpu_slot, req[r]) >= 16777216) big |= 1u << r;
       put_f64(w + 2 * r, static_cast<double>(req[r]));
       if (!((used >> r) & 1u) || req[r] == 0) continue;  // "ignoring zero-qty resource request" filter.go:103-106
       if (non_g && (slot_flags[r] & SPX_NRT_SLOT_AFFINE)) always |= 1u << r;
@@ -1253,100 +1316,70 @@ void nrt_build_items(const spx_nrt_pods_soa* t, const uint8_t* slot_flags, int c
     const int64_t cpu_q = cpu_slot >= 0 ? req[cpu_slot] : 0;
     w[2 * RMs] = used | (fit << 8) | (always << 16) | (kind << 24);
     put_f64(w + 2 * RMs + 2, static_cast<double>(nrt_value_of(true, cpu_q)));
-    if (ok.load(std::memory_order_relaxed)) {
+    if (tab_ok) {
       w[2 * RMs + 1] = static_cast<uint32_t>(wtab[2 * used]);  // the weight sum as an integer (< 2^20)
       put_f64(w + 2 * RMs + 4, wtab[2 * used]);
       put_f64(w + 2 * RMs + 6, wtab[2 * used + 1]);
     }
   };
   spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
-  std::memset(items + static_cast<size_t>(row0) * 10 * IW, 0, static_cast<size_t>(row1 - row0) * 10 * IW * sizeof(uint32_t));
-  for (size_t i = static_cast<size_t>(row0); i < static_cast<size_t>(row1); ++i) {
-    uint32_t* w = &items[i * 10 * IW];
-    const bool non_g = t->qos[i] != SPX_QOS_GUARANTEED;
-    const uint32_t n_ctr = t->n_ctr[i];
-    uint32_t last_app = 0xffu;
-    bool seen_app = false;
-    for (size_t c = 0; c < Cm; ++c) {
-      const uint32_t kind = t->ctr_kind[i * Cm + c];
-      if (c < n_ctr) {
+    bool bad = false;
+    uint32_t big = 0;
+    for (size_t i = static_cast<size_t>(row0); i < static_cast<size_t>(row1); ++i) {
+      uint32_t* w = &items[i * 10 * IW];
+      std::memset(w, 0, 10 * IW * sizeof(uint32_t));  // the record ends with the last container: zeros after it
+      const bool non_g = t->qos[i] != SPX_QOS_GUARANTEED;
+      const uint32_t n_ctr = t->n_ctr[i];
+      uint32_t last_app = 0xffu;
+      bool seen_app = false;
+      for (size_t c = 0; c < Cm && c < n_ctr; ++c) {
+        const uint32_t kind = t->ctr_kind[i * Cm + c];
         if (kind == SPX_CTR_APP) {
           last_app = static_cast<uint32_t>(c);
           seen_app = true;
         } else if (seen_app) {
-          ok = false;  // the single-pass Filter needs init containers listed before app containers
+          bad = true;  // the single-pass Filter needs init containers listed before app containers
         }
+        fill(w + (2 + c) * IW, t->ctr_present[i * Cm + c], t->ctr_req + (i * Cm + c) * R, non_g, kind, bad, big);
       }
-      fill(w + (2 + c) * IW, t->ctr_present[i * Cm + c], t->ctr_req + (i * Cm + c) * R, non_g, kind);
+      fill(w + IW, t->pod_present[i], t->pod_req + i * R, non_g, 0, bad, big);
+      w[0] = t->qos[i] | (static_cast<uint32_t>(t->non_native[i] != 0) << 8) | (n_ctr << 16) | (last_app << 24);
+      w[1] = n_ctr ? (65536u + n_ctr - 1u) / n_ctr : 0u;
+      if (hash_out) hash_out[i] = canon.hash(w);
     }
-    fill(w + IW, t->pod_present[i], t->pod_req + i * R, non_g, 0);
-    w[0] = t->qos[i] | (static_cast<uint32_t>(t->non_native[i] != 0) << 8) | (n_ctr << 16) | (last_app << 24);
-    w[1] = n_ctr ? (65536u + n_ctr - 1u) / n_ctr : 0u;
-  }
+    if (bad) ok = false;
+    if (big) big_pods.fetch_or(big, std::memory_order_relaxed);
   }, 4096);
   *ok_out = ok.load();
   *big_out = big_pods.load();
 }
 
-// Pod equivalence classes: rep[i] = the first row whose canonical record equals row i's (rep[i] == i: a representative).  Two pods
-// get the same NRT rows on every node when their records agree in everything the sweep reads, and a queue is full of such pods:
-// replicas of one Deployment, and every pod whose verdict does not depend on quantities — a pod that is not filtered (BestEffort
-// without non-native resources, filter.go:186-190) passes and scores 100 whatever it asks for; a non-Guaranteed pod scores 100
-// (score.go:72-76) and its NUMA-affine requests suit any reporting zone (numaresources.go:137-142), so only their presence counts.
-// The record is canonicalised accordingly, hashed, and equal records (verified word for word) share their first row.
-void nrt_build_classes(const uint32_t* items, size_t p, size_t R, int32_t* rep) {
-  const int RMs = R <= 4 ? 4 : 8;
-  const size_t IW = R <= 4 ? 16 : 32;
-  const size_t PW = 10 * IW;
-  auto canon = [&](size_t i, uint32_t* c) {
-    const uint32_t* w = items + i * PW;
-    std::memcpy(c, w, PW * sizeof(uint32_t));
-    const uint32_t qos = w[0] & 0xffu, n_ctr = (w[0] >> 16) & 0xffu;
-    const bool non_native = ((w[0] >> 8) & 0xffu) != 0;
-    if (qos == SPX_QOS_BESTEFFORT && !non_native) {  // nothing but the class is read
-      std::memset(c, 0, PW * sizeof(uint32_t));
-      c[0] = qos;
-      return;
+// Pod equivalence classes: rep[i] = the first row whose canonical record (NrtCanon) equals row i's (rep[i] == i: a
+// representative).  hash[i] = NrtCanon::hash of row i (nrt_build_items); rows with equal hashes are verified word for word.
+void nrt_build_classes(const uint32_t* items, const uint64_t* hash, size_t p, size_t R, int32_t* rep) {
+  const NrtCanon canon{R <= 4 ? size_t{4} : size_t{8}, R <= 4 ? size_t{16} : size_t{32}};
+  const size_t PW = 10 * canon.IW;
+  // first row of each hash value: a flat open-addressing table, rows visited in order (serial: ~15 ns per row)
+  {
+    size_t cap = 64;
+    while (cap < 2 * p) cap <<= 1;
+    struct Slot {
+      uint64_t h;
+      int32_t row;
+    };
+    std::vector<Slot> tab(cap, Slot{0, -1});
+    for (size_t i = 0; i < p; ++i) {
+      size_t k = static_cast<size_t>(hash[i] >> 20) & (cap - 1);
+      while (tab[k].row >= 0 && tab[k].h != hash[i]) k = (k + 1) & (cap - 1);
+      if (tab[k].row < 0) tab[k] = Slot{hash[i], static_cast<int32_t>(i)};
+      rep[i] = tab[k].row;
     }
-    for (size_t slot = 2 + n_ctr; slot < 10; ++slot) std::memset(c + slot * IW, 0, IW * sizeof(uint32_t));  // past the last container
-    if (qos != SPX_QOS_GUARANTEED) {
-      c[1] = 0;  // the mean over containers belongs to the Score
-      for (size_t slot = 1; slot < 2 + n_ctr; ++slot) {
-        uint32_t* it = c + slot * IW;
-        const uint32_t sets = it[2 * RMs], fit = (sets >> 8) & 0xffu;
-        for (size_t r = 0; r < static_cast<size_t>(RMs); ++r)
-          if (!((fit >> r) & 1u)) it[2 * r] = it[2 * r + 1] = 0;  // only compared quantities matter
-        it[2 * RMs] = sets & 0xffffff00u;                        // "requested" steers the Score only
-        for (size_t k = 2 * RMs + 1; k < IW; ++k) it[k] = 0;      // weight sums, Value() of the cpu request
-      }
-    }
-  };
-  std::vector<uint64_t> hash(p);
+  }
   spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
-    std::vector<uint32_t> c(PW);
-    for (int64_t i = row0; i < row1; ++i) {
-      canon(static_cast<size_t>(i), c.data());
-      uint64_t h = 0x9e3779b97f4a7c15ull;
-      for (size_t k = 0; k < PW; k += 2) {
-        h ^= (static_cast<uint64_t>(c[k + 1]) << 32) | c[k];
-        h *= 0xff51afd7ed558ccdull;
-        h ^= h >> 29;
-      }
-      hash[static_cast<size_t>(i)] = h;
-    }
-  }, 4096);
-  // serial: first row of each hash value; parallel: every other row verified word for word against that row
-  std::unordered_map<uint64_t, int32_t> rep_of_hash;
-  rep_of_hash.reserve(p);
-  for (size_t i = 0; i < p; ++i) rep[i] = rep_of_hash.emplace(hash[i], static_cast<int32_t>(i)).first->second;
-  spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
-    std::vector<uint32_t> ca(PW), cb(PW);
     for (int64_t i = row0; i < row1; ++i) {
       const int32_t r0 = rep[static_cast<size_t>(i)];
-      if (r0 == i) continue;
-      canon(static_cast<size_t>(i), ca.data());
-      canon(static_cast<size_t>(r0), cb.data());
-      if (std::memcmp(ca.data(), cb.data(), PW * sizeof(uint32_t)) != 0) rep[static_cast<size_t>(i)] = static_cast<int32_t>(i);  // a hash collision: the row stands for itself
+      if (r0 != i && !canon.equal(items + static_cast<size_t>(i) * PW, items + static_cast<size_t>(r0) * PW))
+        rep[static_cast<size_t>(i)] = static_cast<int32_t>(i);  // a hash collision: the row stands for itself
     }
   }, 2048);
 }
@@ -1377,12 +1410,13 @@ int spx_internal_nrt_pod_classes(const spx_nrt_slots* slots, const spx_nrt_pods_
   }
   const size_t p = static_cast<size_t>(t->n_pods), IW = R <= 4 ? 16 : 32;
   std::vector<uint32_t> items(p * 10 * IW);
+  std::vector<uint64_t> hash(p);
   bool ok = false;
   uint32_t big = 0;
-  nrt_build_items(t, slots->slot_flags, cpu_slot, wtab, items.data(), &ok, &big);
+  nrt_build_items(t, slots->slot_flags, cpu_slot, wtab, items.data(), &ok, &big, hash.data());
   *fast_ok_out = (ok && slots_ok) ? 1 : 0;
   for (size_t i = 0; i < p; ++i) rep_out[i] = static_cast<int32_t>(i);
-  if (ok && slots_ok) nrt_build_classes(items.data(), p, static_cast<size_t>(R), rep_out);
+  if (ok && slots_ok) nrt_build_classes(items.data(), hash.data(), p, static_cast<size_t>(R), rep_out);
   return SPX_OK;
 }
 
@@ -1415,7 +1449,8 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
     uint32_t* const items = static_cast<uint32_t*>(e->h_stage);  // pinned: built in place (rows zeroed by the thread that fills them)
     bool ok = false;
     uint32_t big = 0;
-    nrt_build_items(t, e->nrt_slot_flags, e->nrt_cpu_slot, e->nrt_wtab, items, &ok, &big);
+    std::vector<uint64_t> hash(p);
+    nrt_build_items(t, e->nrt_slot_flags, e->nrt_cpu_slot, e->nrt_wtab, items, &ok, &big, hash.data());
     if ((rc = upload(e, e->d_nrt_items, items, items_bytes))) return rc;  // from pinned memory: one DMA at link speed, asynchronous
     e->nrt_fast_pods = ok;
     e->nrt_big_pods = big;
@@ -1428,7 +1463,7 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
     e->nrt_n_uniq = e->nrt_n_dups = 0;
     if (e->nrt_fast_pods && p > 0) {
       std::vector<int32_t> rep(p);
-      nrt_build_classes(items, p, R, rep.data());
+      nrt_build_classes(items, hash.data(), p, R, rep.data());
       std::vector<int32_t> uniq, dups;
       uniq.reserve(p), dups.reserve(2 * p);
       for (size_t i = 0; i < p; ++i) {

@@ -8,6 +8,7 @@
 // A pod's PreFilter state depends only on its (AppGroup, workload selector): the join is done once per such
 // "workload key" and pods carry the key.  TopologicalSort's per-comparison CR Get + two binary searches
 // (topologicalsort.go:118-127) become one FindPodOrder per pod.
+#include <algorithm>
 #include <climits>
 #include <cstdint>
 #include <cstddef>
@@ -63,39 +64,56 @@ inline uint64_t pack_key(int32_t group, int32_t selector) {
 }
 }  // namespace
 
-extern "C" int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int32_t* n_keys_out,
-                                    int64_t* n_pairs_out, int32_t* pod_key, int32_t* topo_order, uint8_t* key_score_equally,
-                                    int32_t* pair_ptr, int32_t* pair_node, int64_t* pair_max_cost) {
-  if (!pods || !ag || !n_keys_out || !n_pairs_out) return SPX_ERR_ARG;
-  const bool fill = pod_key && topo_order && key_score_equally && pair_ptr && pair_node && pair_max_cost;
-  // (AppGroup, workload selector) -> key id, in order of first appearance; hashed on the packed pair (an ordered map cost a
-  // cache-missing tree walk per pod: 40 ms per call at 62.5k pods)
-  std::unordered_map<uint64_t, int32_t> keys;
-  keys.reserve(static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 1) / 4 + 16);
+namespace {
+// Everything spx_flatten_net_keys returns, computed in one pass.  The C entry point is called twice per batch (sizes, then the
+// arrays): the sizing call leaves its result here, per calling thread, and the fill call that follows it with the same tables
+// copies it out instead of repeating the pass.
+struct NetKeys {
+  const void *pods = nullptr, *ag = nullptr;
+  int64_t n_pods = -1;
+  std::vector<int32_t> pod_key, topo_order, pair_ptr, pair_node;
+  std::vector<int64_t> pair_max_cost;
+  std::vector<uint8_t> key_score_equally;
+};
+thread_local NetKeys tl_net_keys;
+
+void build_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag, NetKeys& k) {
+  const size_t P = static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 0);
+  k.pods = pods, k.ag = ag, k.n_pods = pods->n_pods;
+  k.pod_key.assign(P, 0), k.topo_order.assign(P, -1);
+  k.pair_ptr.assign(1, 0), k.pair_node.clear(), k.pair_max_cost.clear(), k.key_score_equally.clear();
+  // (AppGroup, workload selector) -> key id, in order of first appearance.  A group has a handful of workloads: its keys sit in
+  // a short list searched linearly (a hash map of packed pairs cost 50 ns per pod, an ordered map a tree walk)
+  struct GroupKey {
+    int32_t selector, key, topo;
+  };
+  std::vector<std::vector<GroupKey>> by_group(static_cast<size_t>(ag->n_groups > 0 ? ag->n_groups : 0));
   std::vector<std::pair<int32_t, int32_t>> order;
-  // key 0: "Pod does not belong to an AppGroup" -> scoreEqually (networkoverhead.go:187-190)
-  keys[pack_key(-1, -1)] = 0;
-  order.push_back({-1, -1});
-  for (int64_t p = 0; p < pods->n_pods; ++p) {
-    int32_t g = pods->appgroup[p];
-    std::pair<int32_t, int32_t> k{-1, -1};
-    if (g >= 0 && g < ag->n_groups) k = {g, pods->selector[p]};
-    auto it = keys.find(pack_key(k.first, k.second));
-    if (it == keys.end()) {
-      it = keys.emplace(pack_key(k.first, k.second), static_cast<int32_t>(order.size())).first;
-      order.push_back(k);
+  order.push_back({-1, -1});  // key 0: "Pod does not belong to an AppGroup" -> scoreEqually (networkoverhead.go:187-190)
+  for (size_t p = 0; p < P; ++p) {
+    const int32_t g = pods->appgroup[p];
+    if (g < 0 || g >= ag->n_groups) continue;
+    const int32_t sel = pods->selector[p];
+    auto& list = by_group[static_cast<size_t>(g)];
+    const GroupKey* hit = nullptr;
+    for (const GroupKey& e : list)
+      if (e.selector == sel) {
+        hit = &e;
+        break;
+      }
+    if (!hit) {
+      list.push_back(GroupKey{sel, static_cast<int32_t>(order.size()), find_pod_order(ag, g, sel)});
+      order.push_back({g, sel});
+      hit = &list.back();
     }
-    if (fill) {
-      pod_key[p] = it->second;
-      topo_order[p] = k.first >= 0 ? find_pod_order(ag, k.first, k.second) : -1;
-    }
+    k.pod_key[p] = hit->key;
+    k.topo_order[p] = hit->topo;
   }
-  int64_t n_pairs = 0;
-  if (fill) pair_ptr[0] = 0;
+  k.key_score_equally.resize(order.size());
+  k.pair_ptr.reserve(order.size() + 1);
   for (std::size_t ki = 0; ki < order.size(); ++ki) {
     const int32_t g = order[ki].first, sel = order[ki].second;
     uint8_t flag = 1;  // scoreEqually
-    const int64_t first = n_pairs;
     if (g >= 0) {
       // dependencyList: Dependencies of every workload whose selector matches (util.go:203-209)
       bool any_dep = false;
@@ -110,23 +128,38 @@ extern "C" int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgr
             for (int32_t d = ag->dep_ptr[w]; d < ag->dep_ptr[w + 1]; ++d) {
               if (ag->placed_selector[s] != ag->dep_selector[d]) continue;
               if (ag->placed_node[s] < 0) flag = 2;  // host not in the snapshot: PreFilter returns Error (:258, :274)
-              if (fill) {
-                pair_node[n_pairs] = ag->placed_node[s];
-                pair_max_cost[n_pairs] = ag->dep_max_cost[d];
-              }
-              ++n_pairs;
+              k.pair_node.push_back(ag->placed_node[s]);
+              k.pair_max_cost.push_back(ag->dep_max_cost[d]);
             }
           }
       }
     }
-    (void)first;
-    if (fill) {
-      key_score_equally[ki] = flag;
-      pair_ptr[ki + 1] = static_cast<int32_t>(n_pairs);
-    }
+    k.key_score_equally[ki] = flag;
+    k.pair_ptr.push_back(static_cast<int32_t>(k.pair_node.size()));
   }
-  *n_keys_out = static_cast<int32_t>(order.size());
-  *n_pairs_out = n_pairs;
+}
+}  // namespace
+
+extern "C" int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int32_t* n_keys_out,
+                                    int64_t* n_pairs_out, int32_t* pod_key, int32_t* topo_order, uint8_t* key_score_equally,
+                                    int32_t* pair_ptr, int32_t* pair_node, int64_t* pair_max_cost) {
+  if (!pods || !ag || !n_keys_out || !n_pairs_out) return SPX_ERR_ARG;
+  const bool fill = pod_key && topo_order && key_score_equally && pair_ptr && pair_node && pair_max_cost;
+  NetKeys& k = tl_net_keys;
+  // a fill call right after the sizing call for the same tables (the documented sequence) reuses that pass
+  if (!(fill && k.pods == pods && k.ag == ag && k.n_pods == pods->n_pods)) build_net_keys(pods, ag, k);
+  *n_keys_out = static_cast<int32_t>(k.key_score_equally.size());
+  *n_pairs_out = static_cast<int64_t>(k.pair_node.size());
+  if (k.pair_node.size() > static_cast<size_t>(INT32_MAX)) return SPX_ERR_ARG;
+  if (fill) {
+    std::copy(k.pod_key.begin(), k.pod_key.end(), pod_key);
+    std::copy(k.topo_order.begin(), k.topo_order.end(), topo_order);
+    std::copy(k.key_score_equally.begin(), k.key_score_equally.end(), key_score_equally);
+    std::copy(k.pair_ptr.begin(), k.pair_ptr.end(), pair_ptr);
+    std::copy(k.pair_node.begin(), k.pair_node.end(), pair_node);
+    std::copy(k.pair_max_cost.begin(), k.pair_max_cost.end(), pair_max_cost);
+    k = NetKeys{};  // one use: the tables may change before the next call
+  }
   return SPX_OK;
 }
 
