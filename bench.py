@@ -96,7 +96,7 @@ PID = {"alloc": 0, "tlp": 1, "lvrb": 2, "nrt": 3, "net": 4, "cap": 5, "lroc": 7,
 # kernel translation units per plugin key of WORKLOADS (csrc/)
 KERNEL_FILES = {
     "alloc": ("kernels_trimaran.hip",), "tlp": ("kernels_trimaran.hip",), "lvrb": ("kernels_trimaran.hip",),
-    "lroc": ("kernels_lroc.hip",), "peaks": ("kernels_peaks.hip",),
+    "lroc": ("kernels_lroc.hip",), "peaks": ("kernels_peaks.hip", "kernels_profile.hip"),
     "nrt": ("kernels_nrt_fast.hip", "kernels_nrt.hip", "kernels_profile.hip"), "net": ("kernels_network.hip",),
     "cap": ("kernels_capacity.hip", "kernels_profile.hip"),
 }
@@ -227,17 +227,16 @@ def delta_cycle(target, w, snap, hdr, mask, score_mask):
     if "cap" in pl:
         target.upload_quota(target.flatten_quota(pods, snap["rc"], snap["quota"]))
     t2 = time.perf_counter()
-    target.eval(mask)
-    target.eval_best(score_mask)
+    target.decide(score_mask)
     target.sync()
     t3 = time.perf_counter()
     target.best()
     t4 = time.perf_counter()
     out = {"ms": (t4 - t0) * 1e3, "node_delta_ms": (t1 - t0) * 1e3, "node_delta_trimaran_ms": (t0b - t0) * 1e3, "node_rows": int(len(idx)), "new_pods_ms": (t2 - t1) * 1e3,
-           "eval_argmax_ms": (t3 - t2) * 1e3, "fetch_decisions_ms": (t4 - t3) * 1e3,
+           "decide_ms": (t3 - t2) * 1e3, "fetch_decisions_ms": (t4 - t3) * 1e3,
            "what": "1 % of the nodes' trimaran + NRT rows replaced in place (spx_update_*_nodes; NRT rows flattened for those nodes only, the "
-                   "trimaran flattener still walks every node), a new pending batch flattened and uploaded for every plugin, sweep, per-row "
-                   "weighted argmax, D2H of the decisions"}
+                   "trimaran flattener still walks every node), a new pending batch flattened and uploaded for every plugin, spx_decide (sweep + "
+                   "per-row weighted argmax), D2H of the decisions"}
     return out
 
 
@@ -335,6 +334,8 @@ def main() -> None:
     ap.add_argument("--devices", default="", help="single-process multi-device mode: explicit device list, e.g. 0,0 with --transport copy "
                                                   "runs two ranks on one GPU (plumbing check of the sharded path on a one-GPU box)")
     ap.add_argument("--sweep-only", action="store_true", help="skip the full_cycle section (profiling runs: rocprofv3 counter passes crash in hipGraph capture)")
+    ap.add_argument("--no-pod-classes", action="store_true", help="evaluate every pod row (SPX_OPT_NRT_POD_CLASSES / SPX_OPT_PEAKS_POD_CLASSES off): "
+                    "by default a whole-batch NRT or Peaks sweep evaluates one row per class of pods with equal records and copies it")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -397,6 +398,17 @@ def main() -> None:
             snap = build_snapshot(hdr, w, w["n_pods"] if not strong else n_pods_total, synth.SEED + 1000 * rank)
             load_tables(target, w, snap)
         local_pods = target.n_pods
+
+    engines = target.engines if mode == "multi" else [e0]
+    if args.no_pod_classes:
+        for e in engines:
+            e.set_option("NRT_POD_CLASSES", 0)
+            e.set_option("PEAKS_POD_CLASSES", 0)
+    pod_classes = {}
+    for name, fn in (("nrt", e0.nrt_pod_classes), ("peaks", e0.peaks_pod_classes)):
+        if name in w["plugins"]:
+            uniq, copies = fn()
+            pod_classes[name] = {"rows_evaluated": uniq, "rows_copied": copies, "enabled": not args.no_pod_classes}
 
     def barrier():
         if dist is not None:
@@ -484,7 +496,9 @@ def main() -> None:
                     target.decide(score_mask)
                 target.sync()
                 full_cycle["decide_ms"] = (time.perf_counter() - d0) * 1e3 / 10
-                full_cycle["decide_what"] = "sweep + per-row argmax, no score table written where the fused form applies; same decisions as eval_argmax"
+                full_cycle["decide_what"] = ("sweep + per-row argmax, same decisions as eval_argmax.  Filter-less trimaran profiles: no score table written (argmax folded into "
+                                             "the sweep); profiles with Filter plugins: their sweeps write their tables, Allocatable's feasibility-aware "
+                                             "NormalizeScore is folded into the argmax kernel (k_decide_masked: no Allocatable table, status rows read once)")
             except Exception as ex:
                 full_cycle["decide_error"] = repr(ex)[:200]
             if args.workload in ("config2", "config2_lvrb", "config5_share", "config3"):
@@ -601,7 +615,8 @@ def main() -> None:
                 "traffic": counters.get("traffic") if counters else None,
                 "kernel": {"nrt": "spx::k_nrt_fast (Filter launch + Score launch, both counted)", "net": "spx::k_net_cls",
                            "lroc": "spx::k_lroc_fast (float32 quotient on exact float64 numerator/denominator, float64 fallback; VALU-bound)",
-                           "peaks": "spx::k_peaks<min/max pass> + spx::k_peaks<write pass> (VALU-bound: division + exp per cell and pass)",
+                           "peaks": "spx::k_peaks<min/max pass> + spx::k_peaks<write pass> (VALU-bound: division + exp per cell and pass) over one row per "
+                                    "distinct pod cpu request + spx::k_rows_expand (config.pod_classes)",
                            "cap": "full profile: k_quota, k_nrt_fast x2, k_net_cls, k_tlp_fast2, k_lvrb_fast, k_alloc_masked"}.get(
                     w["plugins"][0], "spx::k_tlp_fast2 (Allocatable+TLP)" + (" + spx::k_lvrb_fast" if "lvrb" in w["plugins"] else "")),
                 "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes, "frac_of_measured_copy_ceiling_6.29TBs": achieved / 6290.0,
@@ -629,7 +644,9 @@ def main() -> None:
                    "host": {"single": "one process, one device (`--gpus 1` IS this path: the N=1 point of a scaling curve is this line's value)", "multi": f"one process driving {world} devices through spx_multi (C ABI)",
                             "ranks": f"{world} processes, one per device (torch.distributed.run)"}[mode],
                    "sharding": "pod rows per device, node tables replicated, no data-path collective",
-                   "result_tables": "uint8 [pods][nodes] per plugin, resident in HBM"},
+                   "result_tables": "uint8 [pods][nodes] per plugin, resident in HBM",
+                   **({"pod_classes": dict(pod_classes, what="rows of pods whose records agree in everything the plugin reads are evaluated once and "
+                                                              "copied (device 0's share; --no-pod-classes evaluates every row)")} if pod_classes else {})},
         "roofline": roofline,
         "kernel_evals_per_sec": n_nodes * local_pods / (kern_ms * 1e-3),
     }

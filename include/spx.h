@@ -709,7 +709,9 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *   SPX_OPT_COMMIT_FROM_MEMORY 1 = spx_commit_sequential keeps node state in memory (any node count) instead of registers
  *   SPX_OPT_PEAKS_TILE         nodes per lane of Peaks' (min/max pass, write pass): 44 (default), 84, 48, 88
  *   SPX_OPT_NRT_POD_CLASSES    1 (default) = a whole-batch NRT sweep evaluates one representative row per class of pods whose
- *                              records agree in everything the sweep reads and copies it to the rest of the class; 0 = every row */
+ *                              records agree in everything the sweep reads and copies it to the rest of the class; 0 = every row
+ *   SPX_OPT_PEAKS_POD_CLASSES  1 (default) = a whole-batch Peaks sweep with no Filter table in play evaluates one row per distinct
+ *                              pod cpu request (all Peaks.Score reads of the pod, peaks.go:134-138) and copies it; 0 = every row */
 #define SPX_OPT_ROW_ALIGN 0
 #define SPX_OPT_REFERENCE_KERNELS 1
 #define SPX_OPT_LROC_FLOAT64 2
@@ -718,7 +720,8 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
 #define SPX_OPT_COMMIT_FROM_MEMORY 5
 #define SPX_OPT_PEAKS_TILE 6
 #define SPX_OPT_NRT_POD_CLASSES 7
-#define SPX_NUM_OPTIONS 8
+#define SPX_OPT_PEAKS_POD_CLASSES 8
+#define SPX_NUM_OPTIONS 9
 int spx_set_option(spx_engine* e, int option, int64_t value);
 int spx_get_option(const spx_engine* e, int option, int64_t* value);
 
@@ -727,6 +730,10 @@ int spx_get_option(const spx_engine* e, int option, int64_t* value);
  * pods whose verdict does not depend on quantities (not filtered: filter.go:186-190; non-Guaranteed: score.go:72-76,
  * numaresources.go:137-142).  n_unique + n_copies = n_pods.  A whole-batch spx_eval of NRT evaluates the unique rows and copies. */
 int spx_nrt_pod_classes(const spx_engine* e, int64_t* n_unique, int64_t* n_copies);
+/* The same for the uploaded Peaks pod batch (spx_upload_peaks_pods): Peaks.Score reads one number of the pod — the cpu request of
+ * peaks.go:134 (GetResourceRequestQuantity) — so pods that request the same amount get the same raw row, and, when no Filter plugin
+ * or feasibility mask narrows a pod's node list, the same NormalizeScore (peaks.go:150-166). */
+int spx_peaks_pod_classes(const spx_engine* e, int64_t* n_unique, int64_t* n_copies);
 
 /* which formulation of a plugin's sweep the uploaded tables select: 0 = generic (reference arithmetic, operation for
  * operation), 1 = fast formulation (same results; see DESIGN.md for each kernel's preconditions); <0 on error.

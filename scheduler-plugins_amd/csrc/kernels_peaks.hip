@@ -127,9 +127,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks(PeaksArgs a, in
   const int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
   const int tile = static_cast<int>(unit % n_tiles);
   const int64_t chunk = unit / n_tiles;
-  const int64_t pod0 = a.row_begin + chunk * kPodsPerChunk;
-  if (pod0 >= a.row_end) return;  // wave-uniform
-  const int64_t pod1 = (pod0 + kPodsPerChunk < a.row_end) ? pod0 + kPodsPerChunk : a.row_end;
+  // rows of this chunk: positions [i0, i1) of the row list when there is one, else of [row_begin, row_end)
+  const int64_t n_rows = a.row_list ? a.n_list : a.row_end - a.row_begin;
+  const int64_t i0 = chunk * kPodsPerChunk;
+  if (i0 >= n_rows) return;  // wave-uniform
+  const int64_t i1 = (i0 + kPodsPerChunk < n_rows) ? i0 + kPodsPerChunk : n_rows;
   const int64_t node0 = (static_cast<int64_t>(tile) * kWave + lane) * kNpl;
   const bool active = node0 < a.row_stride;  // all 64 lanes stay in the loop: the reduction below shuffles across them
 
@@ -137,7 +139,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks(PeaksArgs a, in
 #pragma unroll
   for (int j = 0; j < kNpl; ++j) nd[j] = load_node(a, active ? node0 + j : a.n_nodes);
 
-  for (int64_t pod = pod0; pod < pod1; ++pod) {
+  for (int64_t i = i0; i < i1; ++i) {
+    const int64_t pod = a.row_list ? static_cast<int64_t>(uload(a.row_list + i)) : a.row_begin + i;
     const double pod_cpu = static_cast<double>(uload(a.pod_cpu_milli + pod));
     const uint32_t bad = infeasible_mask<kNpl>(a, pod, node0, active);
     double raw[kNpl];
@@ -207,7 +210,8 @@ void launch_peaks(const PeaksArgs& a, hipStream_t s) {
   const int64_t rows = a.row_end - a.row_begin;
   if (rows <= 0) return;
   hipLaunchKernelGGL(k_peaks_init, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0, s, a.row_min, a.row_max, a.row_begin, a.row_end);
-  const int64_t chunks = (rows + kPodsPerChunk - 1) / kPodsPerChunk;
+  const int64_t swept = a.row_list ? a.n_list : rows;
+  const int64_t chunks = (swept + kPodsPerChunk - 1) / kPodsPerChunk;
   auto grid = [&](int npl, int* n_tiles) {
     const int tile_nodes = kWave * npl;
     *n_tiles = static_cast<int>((a.row_stride + tile_nodes - 1) / tile_nodes);

@@ -291,6 +291,141 @@ __global__ __launch_bounds__(64 * kMaxRowWaves) void k_best_fast(ProfileArgs a, 
   }
 }
 
+// spx_decide for a profile with Filter plugins (round 3): alloc_masked_compact's normalisation and k_best_fast's argmax in one
+// pass pair over the row, so that Allocatable's table is neither written nor read back and the Filter status rows are read from
+// HBM once instead of three times.  First pass: as alloc_masked_compact (min/max of the feasible nodes' Allocatable offsets, the
+// lanes' feasibility bits parked in LDS).  Second pass: the Allocatable byte of each feasible node in registers, the other
+// plugins' bytes from their tables (f: every scoring table of the mask except Allocatable's), the weighted total and the running
+// (best, lowest node, ties) — k_best_fast's rule, a lane walking its nodes in increasing order.  Same bytes, same totals,
+// same decision as spx_eval + spx_eval_best (tests/test_gpu_decide.py compares every row).
+__global__ __launch_bounds__(64 * kMaxRowWaves) void k_decide_masked(ProfileArgs a, BestFastArgs f, int w_alloc) {
+  SPX_RESOLVE_ROWS(a);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const int64_t pod = a.row_begin + blockIdx.x;
+  if (pod >= a.row_end) return;
+  extern __shared__ uint8_t feas_bytes[];
+  uint16_t* feas_bits = reinterpret_cast<uint16_t*>(feas_bytes);  // [tiles][64]: the lane's 16 feasibility bits
+  const bool pod_ok = !a.prefilter || a.prefilter[pod] == 0;    // wave-uniform
+  const int64_t tiles = pod_ok ? (a.n_nodes + 64 * kNplCompact - 1) / (64 * kNplCompact) : 0;
+  const int64_t row = pod * a.row_stride;
+  uint32_t lo = 0xffffffffu, hi = 0u;
+  bool any = false;
+#pragma unroll 2
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t n0 = (t * 64 + lane) * kNplCompact;
+    uint32_t ok = 0;
+    if (n0 < a.n_nodes) {
+      uint4 bad = uint4{0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (a.status[k]) {
+          const uint4 v = *reinterpret_cast<const uint4*>(a.status[k] + row + n0);
+          bad.x |= v.x, bad.y |= v.y, bad.z |= v.z, bad.w |= v.w;
+        }
+      const uint32_t badw[4] = {bad.x, bad.y, bad.z, bad.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint4 r4 = *reinterpret_cast<const uint4*>(a.alloc_rel + n0 + 4 * q);
+        const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (n0 + 4 * q + j >= a.n_nodes || ((badw[q] >> (8 * j)) & 0xffu)) continue;
+          lo = r[j] < lo ? r[j] : lo;
+          hi = r[j] > hi ? r[j] : hi;
+          ok |= 1u << (4 * q + j);
+        }
+      }
+    }
+    any |= ok != 0;
+    feas_bits[t * 64 + lane] = static_cast<uint16_t>(ok);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const uint32_t olo = __shfl_xor(lo, m, 64), ohi = __shfl_xor(hi, m, 64);
+    lo = olo < lo ? olo : lo;
+    hi = ohi > hi ? ohi : hi;
+  }
+  bool some = __ballot(any) != 0;
+  __shared__ uint32_t s_lo[kMaxRowWaves], s_hi[kMaxRowWaves], s_any[kMaxRowWaves];
+  __shared__ int s_best[kMaxRowWaves], s_n[kMaxRowWaves], s_t[kMaxRowWaves], s_f[kMaxRowWaves];
+  if (n_waves > 1) {
+    if (lane == 0) s_lo[wave] = lo, s_hi[wave] = hi, s_any[wave] = some ? 1u : 0u;
+    __syncthreads();
+    lo = 0xffffffffu, hi = 0u, some = false;
+    for (int w = 0; w < n_waves; ++w) {
+      lo = s_lo[w] < lo ? s_lo[w] : lo;
+      hi = s_hi[w] > hi ? s_hi[w] : hi;
+      some |= s_any[w] != 0;
+    }
+  }
+  const uint32_t range = some ? hi - lo : 0u;
+  const double b = range ? (100.0 / static_cast<double>(range)) * (1.0 + 0x1p-49) : 0.0;
+  int best = -1, best_n = -1, ties = 0, feas = 0;
+#pragma unroll 2
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t n0 = (t * 64 + lane) * kNplCompact;
+    if (n0 >= a.n_nodes) continue;
+    const uint32_t ok = feas_bits[t * 64 + lane];  // written by this lane
+    if (ok == 0) continue;                          // none of the lane's 16 nodes is feasible: nothing to count
+    int tot[kNplCompact];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 r4 = *reinterpret_cast<const uint4*>(a.alloc_rel + n0 + 4 * q);
+      const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)  // the byte alloc_masked_compact writes (infeasible cells are never read below)
+        tot[4 * q + j] = range != 0 ? w_alloc * static_cast<int>(static_cast<uint32_t>(static_cast<double>(r[j] - lo) * b)) : 0;
+    }
+    for (int k = 0; k < f.n_tab; ++k) {
+      const uint4 v = *reinterpret_cast<const uint4*>(f.tab[k] + row + n0);
+      const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+      const int w = f.w[k];
+#pragma unroll
+      for (int j = 0; j < kNplCompact; ++j) tot[j] += w * static_cast<int>((words[j >> 2] >> (8 * (j & 3))) & 0xffu);
+    }
+#pragma unroll
+    for (int j = 0; j < kNplCompact; ++j) {
+      const bool okj = (ok >> j) & 1u;
+      const int total = okj ? tot[j] : -1;
+      feas += okj ? 1 : 0;
+      ties = total > best ? 1 : ties + ((total == best && okj) ? 1 : 0);
+      best_n = total > best ? static_cast<int>(n0) + j : best_n;
+      best = total > best ? total : best;
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const int ob = __shfl_xor(best, m, 64), on = __shfl_xor(best_n, m, 64), ot = __shfl_xor(ties, m, 64);
+    feas += __shfl_xor(feas, m, 64);
+    if (on >= 0 && (best_n < 0 || ob > best || (ob == best && on < best_n))) {
+      ties = (best_n >= 0 && ob == best) ? ties + ot : ot;
+      best = ob;
+      best_n = on;
+    } else if (on >= 0 && ob == best) {
+      ties += ot;
+    }
+  }
+  if (n_waves > 1) {
+    if (lane == 0) s_best[wave] = best, s_n[wave] = best_n, s_t[wave] = ties, s_f[wave] = feas;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    best = -1, best_n = -1, ties = 0, feas = 0;
+    for (int w = 0; w < n_waves; ++w) {
+      const int ob = s_best[w], on = s_n[w], ot = s_t[w];
+      feas += s_f[w];
+      if (on < 0) continue;
+      if (best_n < 0 || ob > best) best = ob, best_n = on, ties = ot;
+      else if (ob == best) ties += ot, best_n = on < best_n ? on : best_n;
+    }
+  }
+  if (lane == 0) {
+    a.best_node[pod] = best_n;
+    a.best_score[pod] = best_n >= 0 ? best : 0;
+    a.best_ties[pod] = best_n >= 0 ? ties : 0;
+    a.best_feasible[pod] = feas;
+  }
+}
+
 // per pod: argmax over feasible nodes of Σ_plugin weight x score; ties resolved to the lowest node index, the
 // tie count is returned so that callers can compare tie SETS (upstream selectHost picks randomly among them)
 __global__ __launch_bounds__(64 * kMaxRowWaves) void k_best(ProfileArgs a) {
@@ -393,6 +528,31 @@ void launch_alloc_masked(const ProfileArgs& a, hipStream_t s) {
   const size_t lds = tiles4 * 64 > tiles16 * 128 ? tiles4 * 64 : tiles16 * 128;
   const unsigned rows = static_cast<unsigned>(a.row_end - a.row_begin);
   hipLaunchKernelGGL(k_alloc_masked, dim3(rows), dim3(rows == 1 ? 64 * kMaxRowWaves : 64), lds, s, a);
+}
+
+bool decide_masked_ok(const ProfileArgs& a) {
+  int64_t bound = 0;
+  bool ok = a.row_stride % kNplCompact == 0 && a.alloc_rel != nullptr;
+  for (int k = 0; k < SPX_NUM_PLUGINS; ++k)
+    if (a.score[k] || k == SPX_PLUGIN_ALLOCATABLE) {
+      ok &= a.weight[k] >= 0 && a.weight[k] < (int64_t{1} << 23);
+      bound += a.weight[k] * 255;
+    }
+  return ok && bound < (int64_t{1} << 31);
+}
+
+void launch_decide_masked(const ProfileArgs& a, hipStream_t s) {
+  if (a.row_end <= a.row_begin) return;
+  BestFastArgs f{};
+  for (int k = 0; k < SPX_NUM_PLUGINS; ++k)
+    if (a.score[k] && k != SPX_PLUGIN_ALLOCATABLE) {
+      f.tab[f.n_tab] = a.score[k];
+      f.w[f.n_tab++] = static_cast<int32_t>(a.weight[k]);
+    }
+  const size_t tiles16 = static_cast<size_t>((a.row_stride + 64 * kNplCompact - 1) / (64 * kNplCompact));
+  const unsigned rows = static_cast<unsigned>(a.row_end - a.row_begin);
+  hipLaunchKernelGGL(k_decide_masked, dim3(rows), dim3(rows == 1 ? 64 * kMaxRowWaves : 64), tiles16 * 128, s, a, f,
+                     static_cast<int>(a.weight[SPX_PLUGIN_ALLOCATABLE]));
 }
 
 void launch_best(const ProfileArgs& a, hipStream_t s) {

@@ -39,6 +39,8 @@ struct spx_engine {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool hold_ev0 = false;  // spx_decide times its preparatory spx_eval together with its own sweep
+  bool skip_alloc_masked = false;  // spx_decide folds Allocatable's masked normalisation into its argmax kernel
+  bool alloc_compact = false;      // k_alloc_prepare found the raw scores spanning less than 2^32 (AllocPrepArgs.rel is valid)
   bool timed = false;
   // last error: the engine's own copy (whoever failed last) under a lock; every thread also keeps the text of ITS last failure
   // (spx_last_error returns thread-local storage: concurrent readers may fail concurrently)
@@ -51,7 +53,7 @@ struct spx_engine {
   int64_t row_stride = 0;
 
   // spx_set_option state (per engine; nothing is read from the environment)
-  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1};
+  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1};
 
   // params
   int32_t alloc_mode = SPX_MODE_LEAST;
@@ -109,6 +111,8 @@ struct spx_engine {
   DevBuf d_delta;                // staged rows of a node-table delta (spx_update_*_nodes)
   DevBuf d_nrt_uniq, d_nrt_dups;  // int32 [n_uniq] representative rows, ascending; int32 [n_dups][2] (row, its representative)
   int64_t nrt_n_uniq = 0, nrt_n_dups = 0;
+  DevBuf d_pk_uniq, d_pk_dups;    // the same for Peaks: classes of pods with equal cpu requests
+  int64_t pk_n_uniq = 0, pk_n_dups = 0;
   bool nrt_ln_ok = false;  // LeastNUMANodes tables can be built: every zone cost within [0, 255]
   bool nrt_ln_built = false;
   std::vector<int32_t> h_nrt_cost;  // [N][Z][Z] host copy of the zone costs, what build_ln_tab works from
@@ -301,6 +305,10 @@ int prepare_alloc(spx_engine* e) {
   a.norm = static_cast<uint8_t*>(e->d_alloc_norm.p);
   spx::launch_alloc_prepare(a, e->stream);
   SPX_HIP(e, hipGetLastError());
+  uint32_t compact = 0;  // once per node table: the flag the kernel leaves behind the offsets
+  SPX_HIP(e, hipMemcpyAsync(&compact, static_cast<const uint32_t*>(e->d_alloc_rel.p) + e->row_stride, sizeof compact, hipMemcpyDeviceToHost, e->stream));
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  e->alloc_compact = compact != 0;
   e->alloc_ready = true;
   return SPX_OK;
 }
@@ -569,7 +577,8 @@ int spx_destroy(spx_engine* e) {
                     &e->d_sort_prio, &e->d_sort_ts, &e->d_sort_group, &e->d_sort_topo, &e->d_sort_scratch,
                     &e->d_best, &e->d_stats, &e->d_decide, &e->d_lroc_nreq_c, &e->d_lroc_nreq_m, &e->d_lroc_nlim_c, &e->d_lroc_nlim_m,
                     &e->d_lroc_preq_c, &e->d_lroc_preq_m, &e->d_lroc_plim_c, &e->d_lroc_plim_m, &e->d_lroc_tab, &e->d_lroc_podf,
-                    &e->d_pk_cap, &e->d_pk_util, &e->d_pk_valid, &e->d_pk_k1, &e->d_pk_k2, &e->d_pk_pod, &e->d_pk_min, &e->d_pk_max};
+                    &e->d_pk_cap, &e->d_pk_util, &e->d_pk_valid, &e->d_pk_k1, &e->d_pk_k2, &e->d_pk_pod, &e->d_pk_min, &e->d_pk_max,
+                    &e->d_nrt_uniq, &e->d_nrt_dups, &e->d_pk_uniq, &e->d_pk_dups, &e->d_delta};
   for (DevBuf* b : bufs)
     if (b->p && !b->external) (void)hipFree(b->p);
   for (int i = 0; i < SPX_NUM_PLUGINS; ++i) {
@@ -615,6 +624,7 @@ int spx_set_option(spx_engine* e, int option, int64_t value) {
     case SPX_OPT_NRT_SINGLE_LAUNCH:
     case SPX_OPT_COMMIT_FROM_MEMORY:
     case SPX_OPT_NRT_POD_CLASSES:
+    case SPX_OPT_PEAKS_POD_CLASSES:
       if (value != 0 && value != 1) return fail(e, SPX_ERR_ARG, "option takes 0 or 1");
       break;
     case SPX_OPT_PEAKS_TILE:
@@ -631,6 +641,13 @@ int spx_nrt_pod_classes(const spx_engine* e, int64_t* n_unique, int64_t* n_copie
   if (!e || !n_unique || !n_copies) return SPX_ERR_ARG;
   *n_copies = e->nrt_pods ? e->nrt_n_dups : 0;
   *n_unique = e->nrt_pods ? e->n_pods - *n_copies : 0;
+  return SPX_OK;
+}
+
+int spx_peaks_pod_classes(const spx_engine* e, int64_t* n_unique, int64_t* n_copies) {
+  if (!e || !n_unique || !n_copies) return SPX_ERR_ARG;
+  *n_copies = e->peaks_pods ? e->pk_n_dups : 0;
+  *n_unique = e->peaks_pods ? e->n_pods - *n_copies : 0;
   return SPX_OK;
 }
 
@@ -951,6 +968,31 @@ int spx_upload_peaks_pods(spx_engine* e, const spx_peaks_pods_soa* t) {
   int rc = set_pods(e, t->n_pods);
   if (rc) return rc;
   if ((rc = upload(e, e->d_pk_pod, t->cpu_milli, static_cast<size_t>(t->n_pods) * 8))) return rc;
+  // Pod classes: the pod's cpu request is all Peaks.Score reads of it (peaks.go:134-138), so rows of equal requests are equal —
+  // raw scores always, normalised scores when every pod's node list is the whole snapshot.  First row of each distinct value
+  // (flat open-addressing table, rows in order), the others as (row, representative) pairs.
+  e->pk_n_uniq = e->pk_n_dups = 0;
+  if (t->n_pods > 1) {
+    const size_t p = static_cast<size_t>(t->n_pods);
+    size_t cap = 64;
+    while (cap < 2 * p) cap <<= 1;
+    std::vector<int32_t> tab(cap, -1), uniq, dups;
+    uniq.reserve(p), dups.reserve(2 * p);
+    for (size_t i = 0; i < p; ++i) {
+      const int64_t v = t->cpu_milli[i];
+      size_t k = static_cast<size_t>((static_cast<uint64_t>(v) * 0x9e3779b97f4a7c15ull) >> 24) & (cap - 1);
+      while (tab[k] >= 0 && t->cpu_milli[tab[k]] != v) k = (k + 1) & (cap - 1);
+      if (tab[k] < 0) tab[k] = static_cast<int32_t>(i), uniq.push_back(static_cast<int32_t>(i));
+      else dups.push_back(static_cast<int32_t>(i)), dups.push_back(tab[k]);
+    }
+    if (!dups.empty()) {
+      if ((rc = upload(e, e->d_pk_uniq, uniq.data(), uniq.size() * sizeof(int32_t)))) return rc;
+      if ((rc = upload(e, e->d_pk_dups, dups.data(), dups.size() * sizeof(int32_t)))) return rc;
+      SPX_HIP(e, hipStreamSynchronize(e->stream));  // the vectors go out of scope
+      e->pk_n_uniq = static_cast<int64_t>(uniq.size());
+      e->pk_n_dups = static_cast<int64_t>(dups.size() / 2);
+    }
+  }
   e->peaks_pods = true;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   return SPX_OK;
@@ -1885,10 +1927,20 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     ka.other_status[1] = W ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NETOVERHEAD].p) : nullptr;
     ka.other_status[2] = e->ext_mask ? static_cast<const uint8_t*>(e->d_ext_status.p) : nullptr;
     ka.out_score = static_cast<uint8_t*>(e->score[SPX_PLUGIN_PEAKS].p);
+    // one row per distinct cpu request when the whole batch is swept and nothing narrows a pod's node list (NormalizeScore runs
+    // over the same nodes for every pod then), provided enough rows are copies
+    const bool classes = e->option[SPX_OPT_PEAKS_POD_CLASSES] && !ka.other_status[0] && !ka.other_status[1] && !ka.other_status[2] &&
+                         row_begin == 0 && row_end == e->n_pods && e->pk_n_dups > 0 && e->pk_n_dups * 8 >= e->n_pods;
+    if (classes) {
+      ka.row_list = static_cast<const int32_t*>(e->d_pk_uniq.p);
+      ka.n_list = e->pk_n_uniq;
+    }
     spx::launch_peaks(ka, e->stream);
+    if (classes)
+      spx::launch_rows_expand(static_cast<const int32_t*>(e->d_pk_dups.p), e->pk_n_dups, ka.out_score, nullptr, e->row_stride, e->stream);
     SPX_HIP(e, hipGetLastError());
   }
-  if (A && masked) {
+  if (A && masked && !e->skip_alloc_masked) {
     spx::ProfileArgs pa{};
     pa.n_nodes = e->n_nodes;
     pa.row_stride = e->row_stride;
@@ -1908,10 +1960,15 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   e->timed = true;
   e->best_valid = false;
   e->evaluated |= plugin_mask;
+  const bool alloc_skipped = A && masked && e->skip_alloc_masked;  // spx_decide: the table is not written — nothing to fetch
+  if (alloc_skipped) {
+    e->evaluated &= ~(1u << SPX_PLUGIN_ALLOCATABLE);
+    e->eval_info[SPX_PLUGIN_ALLOCATABLE] = spx_engine::EvalInfo{};
+  }
   if (row_end > row_begin) {
     const uint32_t filters = plugin_mask & kFilterPlugins;
     for (int p = 0; p < SPX_NUM_PLUGINS; ++p) {
-      if (!((plugin_mask >> p) & 1u)) continue;
+      if (!((plugin_mask >> p) & 1u) || (alloc_skipped && p == SPX_PLUGIN_ALLOCATABLE)) continue;
       spx_engine::EvalInfo& i = e->eval_info[p];
       const bool same_ctx = i.filters == filters && i.ext_gen == e->ext_gen && i.end > i.begin;
       if (same_ctx && row_begin <= i.end && row_end >= i.begin) {  // overlapping or adjacent: the evaluated rows grow
@@ -2548,6 +2605,57 @@ int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t r
                        e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && !(launch_opts(e) & spx::kOptTrimaranExact) &&
                        !e->option[SPX_OPT_DECIDE_UNFUSED] && w_ok && w_sum <= 10000000;
   int rc;
+  // A profile with Filter plugins (NRT / NetworkOverhead / a caller mask): their sweeps write status and score tables as in
+  // spx_eval; Allocatable's feasibility-aware normalisation is folded into the argmax kernel (k_decide_masked) — its table is
+  // not written, and ALLOCATABLE is left "not evaluated" for the fetch functions.
+  const bool masked = (plugin_mask & ((1u << SPX_PLUGIN_NRT) | (1u << SPX_PLUGIN_NETOVERHEAD))) || e->ext_mask;
+  if (!fusable && (plugin_mask & A) && masked && !e->option[SPX_OPT_DECIDE_UNFUSED] && e->n_nodes > 0 && e->n_pods > 0 && row_begin >= 0 &&
+      row_end <= e->n_pods && row_begin < row_end) {
+    if ((rc = prepare_alloc(e))) return rc;
+    const size_t P = static_cast<size_t>(e->n_pods);
+    spx::ProfileArgs pa{};
+    pa.n_nodes = e->n_nodes;
+    pa.row_stride = e->row_stride;
+    pa.row_begin = row_begin;
+    pa.row_end = row_end;
+    pa.row_ptr = e->row_indirect;
+    pa.alloc_rel = static_cast<const uint32_t*>(e->d_alloc_rel.p);
+    bool tables_ok = true;
+    for (int k = 0; k < SPX_NUM_PLUGINS; ++k) {
+      const bool has_score = k <= SPX_PLUGIN_NETOVERHEAD || k == SPX_PLUGIN_LROC || k == SPX_PLUGIN_PEAKS;
+      // the tables the sweep below will have written by the time the kernel runs (engine-owned or bound: same row stride)
+      if ((plugin_mask & (1u << k)) && has_score && k != SPX_PLUGIN_ALLOCATABLE) pa.score[k] = reinterpret_cast<const uint8_t*>(uintptr_t{1});
+      pa.weight[k] = e->plugin_weight[k];
+    }
+    if (e->alloc_compact && spx::decide_masked_ok(pa)) {
+      if ((rc = ensure(e, e->d_best, P * 20))) return rc;
+      SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
+      e->hold_ev0 = e->skip_alloc_masked = true;
+      rc = spx_eval(e, plugin_mask, row_begin, row_end);
+      e->hold_ev0 = e->skip_alloc_masked = false;
+      if (rc) return rc;
+      for (int k = 0; k < SPX_NUM_PLUGINS; ++k)
+        if (pa.score[k]) {
+          tables_ok &= e->score_stride[k] == e->row_stride;
+          pa.score[k] = static_cast<const uint8_t*>(e->score[k].p);
+        }
+      if (!tables_ok) return fail(e, SPX_ERR_STATE, "score table stride differs from the engine row stride");
+      pa.status[0] = (plugin_mask & (1u << SPX_PLUGIN_NRT)) ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NRT].p) : nullptr;
+      pa.status[1] = (plugin_mask & (1u << SPX_PLUGIN_NETOVERHEAD)) ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NETOVERHEAD].p) : nullptr;
+      pa.status[2] = e->ext_mask ? static_cast<const uint8_t*>(e->d_ext_status.p) : nullptr;
+      pa.prefilter = (plugin_mask & (1u << SPX_PLUGIN_CAPACITY)) ? static_cast<const uint8_t*>(e->d_q_status.p) : nullptr;
+      pa.best_score = static_cast<int64_t*>(e->d_best.p);
+      pa.best_node = reinterpret_cast<int32_t*>(pa.best_score + P);
+      pa.best_ties = pa.best_node + P;
+      pa.best_feasible = pa.best_ties + P;
+      spx::launch_decide_masked(pa, e->stream);
+      SPX_HIP(e, hipGetLastError());
+      SPX_HIP(e, hipEventRecord(e->ev1, e->stream));
+      e->timed = true;
+      e->best_valid = true;
+      return SPX_OK;
+    }
+  }
   if (!fusable) {
     if ((rc = spx_eval(e, plugin_mask, row_begin, row_end))) return rc;
     return spx_eval_best(e, plugin_mask, row_begin, row_end);

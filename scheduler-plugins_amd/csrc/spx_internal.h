@@ -202,6 +202,10 @@ struct PeaksArgs {
   int64_t* row_max;
   uint8_t* out_score;            // [P][row_stride]
   int64_t* out_raw;              // when set: raw int64 scores of row_begin only, no table writes
+  // when set: the sweep walks these n_list rows — the first row of each distinct pod cpu request, ascending — instead of
+  // [row_begin, row_end); launch_rows_expand copies each to the rows that repeat it
+  const int32_t* row_list;
+  int64_t n_list;
 };
 void launch_peaks(const PeaksArgs& a, hipStream_t s);
 
@@ -507,5 +511,10 @@ void launch_alloc_masked(const ProfileArgs& a, hipStream_t s);
 // copies row pairs[2i+1] to row pairs[2i] in up to two uint8 tables of row_stride bytes per row (NULL = skip)
 void launch_rows_expand(const int32_t* pairs, int64_t n_pairs, uint8_t* t0, uint8_t* t1, int64_t row_stride, hipStream_t s);
 void launch_best(const ProfileArgs& a, hipStream_t s);
+// spx_decide with Filter plugins in the mask: Allocatable's feasibility-aware normalisation and the weighted argmax in one kernel
+// (no Allocatable table).  decide_masked_ok: weights fit the 32-bit totals and the rows the 16-byte tiles; the caller also needs
+// the compact Allocatable form (AllocPrepArgs.rel valid: raw scores span less than 2^32)
+bool decide_masked_ok(const ProfileArgs& a);
+void launch_decide_masked(const ProfileArgs& a, hipStream_t s);
 
 }  // namespace spx

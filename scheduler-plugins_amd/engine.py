@@ -109,6 +109,12 @@ class Engine:
         self._ck(self._lib.spx_nrt_pod_classes(self._h, C.byref(u), C.byref(d)))
         return int(u.value), int(d.value)
 
+    def peaks_pod_classes(self):
+        """(rows that are the first with their cpu request, rows that repeat one) of the uploaded Peaks pod batch (spx_peaks_pod_classes)"""
+        u, d = C.c_int64(), C.c_int64()
+        self._ck(self._lib.spx_peaks_pod_classes(self._h, C.byref(u), C.byref(d)))
+        return int(u.value), int(d.value)
+
     def force_reference_kernels(self, *plugins: int) -> None:
         """run the reference-arithmetic sweep for these plugins (differential tests); no argument = back to the fast forms"""
         self.set_option("REFERENCE_KERNELS", mask_of(*plugins))

@@ -3,7 +3,7 @@ must equal spx_eval + spx_eval_best exactly — it is the same float32/float64 c
 import numpy as np
 import pytest
 
-from helpers import ALLOCATABLE, LROC, LVRB, PEAKS, TLP
+from helpers import ALLOCATABLE, CAPACITY, LROC, LVRB, NETOVERHEAD, NRT, PEAKS, TLP
 from scheduler_plugins_amd import synth
 from scheduler_plugins_amd import SpxError
 from scheduler_plugins_amd.engine import Engine, mask_of
@@ -107,3 +107,72 @@ def test_config2_size(gpu_required, hdr):
         want, got = both(e, mask_of(ALLOCATABLE, TLP, LVRB))
     for w, g in zip(want, got):
         assert (w == g).all()
+
+
+# ------------------------------------------------------------------ profiles with Filter plugins (k_decide_masked)
+def _full(e, hdr, n_nodes, n_pods, seed, weights):
+    from test_gpu_profile import load_all
+    snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=seed, pods_per_group=20, n_namespaces=20)
+    load_all(e, hdr, snap)
+    e.set_plugin_weights(weights)
+    return snap
+
+
+@pytest.mark.parametrize("n_nodes,n_pods,seed", [(300, 200, 1), (65, 33, 2), (17, 9, 3), (2100, 150, 4)])
+@pytest.mark.parametrize("weights", [{ALLOCATABLE: 1, TLP: 2, LVRB: 1, NRT: 3, NETOVERHEAD: 2}, {ALLOCATABLE: 7, TLP: 0, LVRB: 1, NRT: 1, NETOVERHEAD: 1}])
+def test_decide_with_filter_plugins(gpu_required, hdr, n_nodes, n_pods, seed, weights):
+    """the whole profile (CapacityScheduling PreFilter, NRT and NetworkOverhead Filters, five scoring plugins): Allocatable's
+    feasibility-aware NormalizeScore happens inside the argmax kernel and its table is not written — same decisions"""
+    from test_gpu_profile import ALL
+    with Engine(0) as e:
+        _full(e, hdr, n_nodes, n_pods, seed, weights)
+        want, got = both(e, mask_of(*ALL))
+        for name, w, g in zip(("node", "score", "ties", "feasible"), want, got):
+            assert (w == g).all(), (name, np.flatnonzero(w != g)[:5], w[w != g][:5], g[w != g][:5])
+        assert (want[0] < 0).any() or n_pods < 30      # pods without a feasible node / rejected by PreFilter are in the batch
+        with pytest.raises(SpxError):                   # nothing was written to Allocatable's table by the fused form
+            e.all_scores(ALLOCATABLE)
+        assert e.all_scores(NRT).shape == (n_pods, n_nodes)   # the Filter plugins' tables are there as after spx_eval
+        # subsets of the profile, partial rows, a single row (a whole workgroup on the row)
+        for mask in (mask_of(ALLOCATABLE, NRT), mask_of(ALLOCATABLE, TLP, NETOVERHEAD), mask_of(ALLOCATABLE, NRT, NETOVERHEAD, CAPACITY)):
+            want, got = both(e, mask)
+            for w, g in zip(want, got):
+                assert (w == g).all()
+        if n_pods > 40:
+            for rb, re in ((7, 8), (11, 40), (0, n_pods)):
+                want, got = both(e, mask_of(*ALL), rb, re)
+                for w, g in zip(want, got):
+                    assert (w == g).all()
+
+
+def test_decide_with_a_caller_mask_and_the_unfused_switch(gpu_required, hdr):
+    from test_gpu_profile import ALL
+    weights = {ALLOCATABLE: 2, TLP: 1, LVRB: 1, NRT: 1, NETOVERHEAD: 1}
+    with Engine(0) as e:
+        _full(e, hdr, 500, 120, 6, weights)
+        e.upload_feasible_mask((np.random.default_rng(3).random((120, 500)) < 0.6).astype(np.uint8))
+        want, got = both(e, mask_of(*ALL))
+        for w, g in zip(want, got):
+            assert (w == g).all()
+        want, got = both(e, mask_of(ALLOCATABLE, TLP))       # the caller's mask alone makes Allocatable feasibility-aware
+        for w, g in zip(want, got):
+            assert (w == g).all()
+        e.set_option("DECIDE_UNFUSED", 1)
+        want, got = both(e, mask_of(*ALL))
+        for w, g in zip(want, got):
+            assert (w == g).all()
+        assert e.all_scores(ALLOCATABLE).shape == (120, 500)   # the unfused route is spx_eval + spx_eval_best: table written
+
+
+def test_decide_with_filter_plugins_falls_back_on_a_wide_allocatable_range(gpu_required, hdr):
+    """raw Allocatable scores spanning more than 2^32 have no compact form: spx_decide runs spx_eval + spx_eval_best"""
+    from test_gpu_profile import ALL, load_all
+    snap = synth.full_snapshot(hdr, 200, 60, seed=9, pods_per_group=20, n_namespaces=20)
+    snap["nodes"].array("alloc_mem")[:] *= 64
+    with Engine(0) as e:
+        e.set_allocatable("Least", {1: 1})
+        load_all(e, hdr, snap)
+        want, got = both(e, mask_of(*ALL))
+        for w, g in zip(want, got):
+            assert (w == g).all()
+        assert e.all_scores(ALLOCATABLE).shape == (60, 200)

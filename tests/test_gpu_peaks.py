@@ -98,6 +98,56 @@ def test_normalizes_over_feasible_nodes_only(gpu_required, hdr, oracle):
     assert not got[3].any()
 
 
+def test_pod_classes_equal_cpu_requests(gpu_required, hdr, oracle):
+    """SPX_OPT_PEAKS_POD_CLASSES: a whole-batch sweep evaluates the first row of each distinct cpu request and copies it.  The
+    table must be byte-identical with the option off, agree with the oracle like any other, and the classes must stand down when
+    a feasibility mask narrows the node lists (NormalizeScore then differs between pods of equal requests) and for row slices."""
+    n_nodes, n_pods = 600, 900
+    snap = snapshot(hdr, n_nodes, 120, 4)
+    pods = synth.take_pods(hdr, snap["pods"], np.random.default_rng(2).integers(0, 120, n_pods))   # replicas: equal requests
+    snap = dict(snap, pods=pods)
+    _, norm_w = oracle_rows(oracle, snap)
+    with Engine(0) as e:
+        assert e.get_option("PEAKS_POD_CLASSES") == 1
+        e.load_peaks_objects(snap["nodes"], snap["metrics"], snap["power_models"], pods)
+        uniq, dups = e.peaks_pod_classes()
+        assert uniq + dups == n_pods and uniq == len(np.unique(e.peaks_soa["cpu_milli"])) and uniq <= 120
+        e.eval(mask_of(PEAKS))
+        e.sync()
+        got = e.all_scores(PEAKS).copy()
+        real = e.peaks_soa["cpu_milli"] > 0
+        diff = np.abs(got.astype(np.int64) - norm_w)[real]
+        assert diff.max() <= 1 and (diff != 0).mean() < 2e-3
+        e.set_option("PEAKS_POD_CLASSES", 0)
+        e.eval(mask_of(PEAKS))
+        e.sync()
+        assert np.array_equal(e.all_scores(PEAKS), got)
+        e.set_option("PEAKS_POD_CLASSES", 1)
+        for b, en in [(0, 311), (311, n_pods)]:      # slices: plain rows
+            e.eval(mask_of(PEAKS), b, en)
+        e.sync()
+        assert np.array_equal(e.all_scores(PEAKS), got)
+        # a feasibility mask: rows of equal requests normalise over different node lists
+        mask = (np.random.default_rng(8).random((n_pods, n_nodes)) < 0.5).astype(np.uint8)
+        _, norm_m = oracle_rows(oracle, snap, mask=mask)
+        e.upload_feasible_mask(mask)
+        e.eval(mask_of(PEAKS))
+        e.sync()
+        gm = e.all_scores(PEAKS).astype(np.int64)
+        assert not gm[mask == 0].any()
+        diff = np.abs(gm - norm_m)[real]
+        assert diff.max() <= 1 and (diff != 0).mean() < 2e-3
+
+
+def test_pod_classes_of_the_synthetic_queue(gpu_required, hdr):
+    """config #2's batch has no replicas; its 100k cpu requests still take about 12k distinct values"""
+    snap = snapshot(hdr, 64, 100_000, synth.SEED)
+    with Engine(0) as e:
+        e.load_peaks_objects(snap["nodes"], snap["metrics"], snap["power_models"], snap["pods"])
+        uniq, dups = e.peaks_pod_classes()
+        assert uniq + dups == 100_000 and uniq < 25_000
+
+
 def test_profile_argmax_with_peaks(gpu_required, hdr):
     snap = snapshot(hdr, 400, 50, 9)
     with Engine(0) as e:
