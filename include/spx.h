@@ -710,6 +710,9 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *   SPX_OPT_PEAKS_TILE         nodes per lane of Peaks' (min/max pass, write pass): 44 (default), 84, 48, 88
  *   SPX_OPT_NRT_POD_CLASSES    1 (default) = a whole-batch NRT sweep evaluates one representative row per class of pods whose
  *                              records agree in everything the sweep reads and copies it to the rest of the class; 0 = every row
+ *   SPX_OPT_NRT_LN_LIST_PERMILLE  LeastNUMANodes, batch Score launch: room, in thousandths of the node count, of each per-(row, scope)
+ *                              list of cells left to the complete subset search (default 375; 4 bytes per entry).  A list that
+ *                              overflows sends the launch back to the complete sweep: same table, slower
  *   SPX_OPT_PEAKS_POD_CLASSES  1 (default) = a whole-batch Peaks sweep with no Filter table in play evaluates one row per distinct
  *                              pod cpu request (all Peaks.Score reads of the pod, peaks.go:134-138) and copies it; 0 = every row */
 #define SPX_OPT_ROW_ALIGN 0
@@ -721,7 +724,8 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
 #define SPX_OPT_PEAKS_TILE 6
 #define SPX_OPT_NRT_POD_CLASSES 7
 #define SPX_OPT_PEAKS_POD_CLASSES 8
-#define SPX_NUM_OPTIONS 9
+#define SPX_OPT_NRT_LN_LIST_PERMILLE 9
+#define SPX_NUM_OPTIONS 10
 int spx_set_option(spx_engine* e, int option, int64_t value);
 int spx_get_option(const spx_engine* e, int option, int64_t* value);
 

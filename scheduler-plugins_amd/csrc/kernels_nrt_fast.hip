@@ -427,7 +427,6 @@ __device__ __forceinline__ int score_balanced_f32(const BalNode<RM>& bn, int nz,
 // distance at all in the common case (the node's minimum-distance subsets are a register-resident bit set), and a
 // 7-step bit-sliced minimum over per-node rank planes otherwise.
 constexpr LnLayout kLn = make_ln_layout();
-__constant__ LnLayout kLnDev = make_ln_layout();  // the copy indexed at run time (position -> zone mask)
 
 template <typename F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -487,11 +486,20 @@ __device__ __forceinline__ void ln_resource(uint32_t (&fall)[kLnDwords], const d
 
 // `choice`: the caller needs the reference's subset itself (a later container is charged against it); otherwise only
 // its size and is_min are read and the distance ranks are not consulted.
-template <int RM>
+//
+// UNIFORM (the sweep): every lane holds the same item — the requested-resource sets are scalar, a resource's column is picked by a
+// scalar branch.  !UNIFORM (k_nrt_ln_redo: a lane = one (pod, node) cell): sets and quantities are per lane; all RM resources
+// are walked, a resource the lane does not compare gets the request -inf (every subset holds it), and both passes always run.
+// DEFER (the sweep's batch Score launch): lanes the first pass leaves open are reported in *deferred instead of being worked
+// through — 7 % of the (container, node) pairs, but spread so evenly that 87 % of the wave-level searches used to run the 219
+// larger subsets for them; the launch lists those cells and k_nrt_ln_redo searches them with every lane of a wave at work.
+template <int RM, bool UNIFORM = true, bool DEFER = false>
 __device__ __forceinline__ uint32_t numa_required_fast(const FastNode<RM>& ns, const NrtArgs& a, const Item<RM>& it, int64_t n, bool active,
                                                        bool choice, const uint32_t (&mmin)[kLnDwords], const uint8_t* subset_lds,
-                                                       const uint32_t* allow_lds, const double (&tot_all)[RM], bool* is_min) {
+                                                       const uint32_t* allow_lds, const double (&tot_all)[RM], bool* is_min,
+                                                       bool* deferred = nullptr) {
   *is_min = false;
+  if constexpr (DEFER) *deferred = false;
   if (__ballot(active) == 0) return 0;
   const uint32_t used = it.used, need = it.fit | it.always;
   // a valid subset lies inside V = the zones reporting every requested resource (isValidCombineResources): the bit set starts
@@ -529,6 +537,7 @@ __device__ __forceinline__ uint32_t numa_required_fast(const FastNode<RM>& ns, c
     *want = w;
     *total = tot;
   };
+  if constexpr (UNIFORM) {
   const uint32_t todo0 = need ? need : (1u << RM);
   // tot_all: what the node's zones held at the start of the pod (an upper bound once earlier containers were charged): a lane
   // it closes can hold no subset; a lane it fails to close merely takes the second pass
@@ -542,7 +551,11 @@ __device__ __forceinline__ uint32_t numa_required_fast(const FastNode<RM>& ns, c
     ln_resource<0, kLnSmall>(fall, v, want);
   }
   const bool open = feasible && (fall[0] | fall[1]) == 0;
-  if (__ballot(open) != 0) {
+  if constexpr (DEFER) {
+    *deferred = open;
+#pragma unroll
+    for (int d = kLnSmall; d < kLnDwords; ++d) fall[d] = 0u;  // open lanes: their cells are searched by k_nrt_ln_redo
+  } else if (__ballot(open) != 0) {
 #pragma unroll
     for (int d = kLnSmall; d < kLnDwords; ++d) fall[d] = allow[d];
     for (uint32_t todo = todo0; todo;) {
@@ -555,6 +568,20 @@ __device__ __forceinline__ uint32_t numa_required_fast(const FastNode<RM>& ns, c
   } else {
 #pragma unroll
     for (int d = kLnSmall; d < kLnDwords; ++d) fall[d] = 0u;  // nobody needs a larger subset: closed lanes hold sizes 1-2, the others nothing
+  }
+  } else {
+    (void)column;
+#pragma unroll
+    for (int d = kLnSmall; d < kLnDwords; ++d) fall[d] = allow[d];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      if (__ballot(active && ((need >> r) & 1u)) == 0) continue;  // no lane of the wave compares this resource
+      double v[kZ];
+#pragma unroll
+      for (int z = 0; z < kZ; ++z) v[z] = ns.av[z][r];
+      const double want = ((need >> r) & 1u) ? it.raw[r] : -__builtin_inf();
+      ln_resource<0, kLnDwords>(fall, v, want);
+    }
   }
   // the smallest size with a fitting subset: its candidates c, those of them at the node's minimum distance h
   uint32_t c[3] = {0, 0, 0}, h[3] = {0, 0, 0};
@@ -668,6 +695,59 @@ __device__ __forceinline__ void load_fast_node(const NrtArgs& a, int64_t n, bool
   }
 }
 
+// The LeastNUMANodes score of one pod on the wave's nodes (score.go:167-191): every node that has a fresh NRT is scored,
+// whatever its topology-manager policy.  One loop serves both scopes — step -1 is the pod-level request for the pod-scope
+// nodes (leastNUMAPodScopeScore), steps 0.. the containers for the others (leastNUMAContainerScopeScore) — so that the subset
+// search exists once in the code; a step none of the wave's nodes takes part in is skipped.  `pit`: the pod's record (LDS),
+// the same for every lane.  DEFER: a lane whose search needs more than sizes 1-2 stops and reports *listed (see
+// numa_required_fast); its score is then meaningless.
+template <int RM, bool DEFER, bool RESTORE = true>
+__device__ __forceinline__ int ln_score_wave(FastNode<RM>& ns, const NrtArgs& a, const uint32_t* pit, int n_ctr, int64_t n, bool in, bool want_ln,
+                                             bool pod_scope, int nns, const uint32_t (&mmin)[kLnDwords], const uint8_t* ln_subset,
+                                             const uint32_t* ln_allow, const double (&ln_tot)[RM], int score, bool* listed) {
+  const int R = a.n_res;
+  int max_count = 0;
+  bool all_min = true, failed = false, dirty = false, listed_cell = false;
+  for (int c = -1; c < n_ctr; ++c) {
+    const bool mine = want_ln && (c < 0 ? pod_scope : !pod_scope);
+    if (__ballot(mine) == 0) continue;
+    const Item<RM> it = decode_item<RM, true>(load_item<RM, true>(pit, c < 0 ? 1 : 2 + c));
+    uint32_t any_rep = 0;
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+      if ((it.used >> r) & 1u) any_rep |= ns.repmask(r);
+    // any_rep == 0: onlyNonNUMAResources, the item is passed over.  A cell already listed for k_nrt_ln_redo stops here.
+    const bool go = mine && !failed && !listed_cell && any_rep != 0;
+    bool is_min, deferred = false;
+    const uint32_t m = numa_required_fast<RM, true, DEFER>(ns, a, it, n, go, c >= 0 && c + 1 < n_ctr, mmin, ln_subset, ln_allow, ln_tot, &is_min, &deferred);
+    listed_cell |= go && deferred;
+    if (go && !deferred) {
+      if (m == 0) {
+        failed = true;
+      } else {
+        all_min &= is_min;
+        const int cnt = __builtin_popcount(m);
+        max_count = cnt > max_count ? cnt : max_count;
+      }
+    }
+    if (c >= 0 && c + 1 < n_ctr && __ballot(go && m != 0) != 0) {  // the next container sees what this one took
+      subtract_from_numas_fast(ns, it, go ? m : 0u);
+      dirty |= go && m != 0;
+    }
+  }
+  if (want_ln) score = failed ? 0 : (max_count == 0 ? 100 : 100 - max_count * nns + (all_min ? nns / 2 : 0));
+  if (RESTORE && __ballot(dirty) != 0) {  // the reference scored on a private NUMANodeList: restore this lane's table
+    const uint32_t n32 = opaque_lane(static_cast<uint32_t>(n));
+#pragma unroll
+    for (int z = 0; z < kZ; ++z)
+#pragma unroll
+      for (int r = 0; r < RM; ++r)
+        ns.av[z][r] = (in && r < R) ? ld_off(a.f_av, (static_cast<uint32_t>(z * R + r) * static_cast<uint32_t>(a.n_nodes) + n32) * 8u) : -1.0;
+  }
+  *listed = listed_cell;
+  return score;
+}
+
 // PH: 0 = Filter and Score in one launch; 1 = Filter only, 2 = Score only (LeastAllocated: its Score reads only b, the
 // Filter only the mutable table, so each half keeps 64 instead of 128 state registers and runs at higher occupancy)
 constexpr int kPhBoth = 0, kPhFilter = 1, kPhScore = 2;
@@ -704,9 +784,18 @@ constexpr int nrt_waves() {
   return SG == kSgLeast ? SPX_NRT_LB_BOTH : 2;
 }
 
-template <int RM, int SG, int PH>
+// LNM (LeastNUMANodes, batch Score launch): kLnDefer = cells whose subset search needs more than sizes 1-2 are listed — per pod
+// row, NrtArgs::redo_list — for k_nrt_ln_redo instead of searched here; kLnIfOverflow = the complete search, but the launch only
+// acts when some row's list overflowed (every block leaves at once otherwise) — it then simply rewrites the whole table
+constexpr int kLnFull = 0, kLnDefer = 1, kLnIfOverflow = 2;
+constexpr int kLnRedo = 255;  // score byte of a listed cell (scores are <= 100)
+
+template <int RM, int SG, int PH, int LNM = kLnFull>
 __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(NrtArgs a, int n_tiles) {
   SPX_RESOLVE_ROWS(a);
+  if constexpr (LNM == kLnIfOverflow) {
+    if (a.redo_list[0] == 0u) return;  // block-uniform: no row's list overflowed
+  }
   constexpr bool FULL = PH != kPhFilter;  // only the Score reads the second half of a request item
   // A block owns a window of 256 consecutive nodes and a chunk of pod rows.  Inside the window the engine has
   // ordered the nodes by (aligned, scope) — perm[] — so that a wavefront's 64 nodes mostly share one code path
@@ -717,10 +806,11 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
   constexpr int kScoreTab = PH == kPhBoth ? 1 : 0;  // a split launch stages one table
   __shared__ __align__(16) uint32_t stage[kScoreTab + 1][kPodsPerUnit / 4][kWindow];
   __shared__ __align__(16) uint32_t pod_lds[kPodsPerUnit * pod_words<RM>()];  // the chunk's pod records (20 KB for <= 4 slots)
-  __shared__ uint8_t ln_subset[SG == kSgLeastNuma ? kLnDwords * 32 : 1];  // LeastNUMANodes: bit position -> zone mask
+  __shared__ __align__(4) uint8_t ln_subset[SG == kSgLeastNuma ? kLnDwords * 32 : 4];  // LeastNUMANodes: bit position -> zone mask
   __shared__ uint32_t ln_allow[SG == kSgLeastNuma ? 256 * kLnDwords : 1];  // ... zone set V -> the subsets inside V, in the bit layout
   // BalancedAllocation, float32 Score launch: the cells it leaves to the float64 form, collected per block and appended to the
   // global list with ONE atomic (round 2 found them again by scanning the 0.25 GB score table: 0.5 ms)
+  constexpr bool kLnDeferred = SG == kSgLeastNuma && LNM == kLnDefer;
   constexpr int kRedoBuf = (SG == kSgBalanced && PH == kPhScore) ? 1024 : 1;
   __shared__ uint32_t redo_buf[kRedoBuf][2];
   __shared__ uint32_t redo_n, redo_base;
@@ -779,17 +869,9 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
   uint32_t mmin[kLnDwords];  // LeastNUMANodes: the node's minimum-distance subsets per size (LnLayout)
 #pragma unroll
   for (int d = 0; d < kLnDwords; ++d) mmin[d] = (SG == kSgLeastNuma && in) ? a.ln_tab[static_cast<int64_t>(d) * a.n_nodes + n] : 0u;
-  if constexpr (SG == kSgLeastNuma) {
-    for (int i = threadIdx.x; i < kLnDwords * 32; i += blockDim.x) ln_subset[i] = kLnDev.subset[i >> 5][i & 31];
-    for (int i = threadIdx.x; i < 256 * kLnDwords; i += blockDim.x) {
-      const uint32_t vset = static_cast<uint32_t>(i / kLnDwords), d = static_cast<uint32_t>(i % kLnDwords);
-      uint32_t bits = 0;
-      for (int q = 0; q < 32; ++q) {
-        const uint32_t sub = kLnDev.subset[d][q];
-        if (sub != 0 && (sub & ~vset) == 0) bits |= 1u << q;
-      }
-      ln_allow[i] = bits;
-    }
+  if constexpr (SG == kSgLeastNuma) {  // the block-constant tables, prepared by the engine: coalesced copies
+    for (int i = threadIdx.x; i < 256 * kLnDwords; i += blockDim.x) ln_allow[i] = a.ln_const[i];
+    for (int i = threadIdx.x; i < kLnDwords * 32 / 4; i += blockDim.x) reinterpret_cast<uint32_t*>(ln_subset)[i] = a.ln_const[256 * kLnDwords + i];
     __syncthreads();
   }
   double ln_tot[RM];  // LeastNUMANodes: what the node's zones hold per resource (first-pass bound of numa_required_fast)
@@ -961,47 +1043,34 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
     }  // the pod has something to compute
 
     if constexpr (SG == kSgLeastNuma) {
-      // LeastNUMANodes scores every node that has a fresh NRT, whatever its topology-manager policy (score.go:167-191).
-      // One loop serves both scopes — step -1 is the pod-level request for the pod-scope nodes (leastNUMAPodScopeScore),
-      // steps 0.. the containers for the others (leastNUMAContainerScopeScore) — so that the subset search exists once
-      // in the code; a step none of the wave's nodes takes part in is skipped.
-      const bool want_ln = !non_g && fresh && has_nrt;
-      int max_count = 0;
-      bool all_min = true, failed = false, dirty = false;
-      if (!non_g)
-      for (int c = -1; c < n_ctr; ++c) {
-        const bool mine = want_ln && (c < 0 ? pod_scope : !pod_scope);
-        if (__ballot(mine) == 0) continue;
-        const Item<RM> it = decode_item<RM, FULL>(load_item<RM, FULL>(pit, c < 0 ? 1 : 2 + c));
-        uint32_t any_rep = 0;
+      if (!non_g) {
+        bool listed_cell = false;
+        score = ln_score_wave<RM, kLnDeferred>(ns, a, pit, n_ctr, n, in, fresh && has_nrt, pod_scope, nns, mmin, ln_subset, ln_allow, ln_tot, score,
+                                               &listed_cell);
+        if constexpr (kLnDeferred) {
+          // the listed cells of this pod row: appended to the row's node lists — one for the pod-scope nodes (they take the
+          // pod-level item), one for the container-scope nodes, so that a wave of k_nrt_ln_redo walks one kind of item — with one
+          // atomic per wave, pod and scope (the engine groups a window's nodes by scope: a wave nearly always holds one)
+          if (__ballot(listed_cell) != 0) {
+            const int64_t slot = listed ? first + p : first + p - a.row_begin;
 #pragma unroll
-        for (int r = 0; r < RM; ++r)
-          if ((it.used >> r) & 1u) any_rep |= ns.repmask(r);
-        const bool go = mine && !failed && any_rep != 0;  // any_rep == 0: onlyNonNUMAResources, the item is passed over
-        bool is_min;
-        const uint32_t m = numa_required_fast(ns, a, it, n, go, c >= 0 && c + 1 < n_ctr, mmin, ln_subset, ln_allow, ln_tot, &is_min);
-        if (go) {
-          if (m == 0) {
-            failed = true;
-          } else {
-            all_min &= is_min;
-            const int cnt = __builtin_popcount(m);
-            max_count = cnt > max_count ? cnt : max_count;
+            for (int sc = 0; sc < 2; ++sc) {
+              const bool mine = listed_cell && (pod_scope ? 1 : 0) == sc;
+              const uint64_t mm = __ballot(mine);
+              if (mm == 0) continue;
+              const int leader = __builtin_ctzll(mm);
+              uint32_t at = 0;
+              if (lane == leader) at = atomicAdd(a.redo_list + 2 + 2 * slot + sc, static_cast<uint32_t>(__builtin_popcountll(mm)));
+              at = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(at), leader)) +
+                   static_cast<uint32_t>(__builtin_popcountll(mm & ((1ull << lane) - 1ull)));
+              if (mine) {
+                if (at < a.ln_per_row) a.redo_list[2 + 2 * a.ln_rows + (2 * slot + sc) * a.ln_per_row + at] = static_cast<uint32_t>(n);
+                else a.redo_list[0] = 1u;  // the list is full: the launch falls back to the complete sweep
+              }
+            }
           }
+          score = listed_cell ? kLnRedo : score;
         }
-        if (c >= 0 && c + 1 < n_ctr && __ballot(go && m != 0) != 0) {  // the next container sees what this one took
-          subtract_from_numas_fast(ns, it, go ? m : 0u);
-          dirty |= go && m != 0;
-        }
-      }
-      if (want_ln) score = failed ? 0 : (max_count == 0 ? 100 : 100 - max_count * nns + (all_min ? nns / 2 : 0));
-      if (__ballot(dirty) != 0) {  // the reference scored on a private NUMANodeList: restore this lane's table
-        const uint32_t n32 = opaque_lane(static_cast<uint32_t>(n));
-#pragma unroll
-        for (int z = 0; z < kZ; ++z)
-#pragma unroll
-          for (int r = 0; r < RM; ++r)
-            ns.av[z][r] = (in && r < R) ? ld_off(a.f_av, (static_cast<uint32_t>(z * R + r) * static_cast<uint32_t>(a.n_nodes) + n32) * 8u) : -1.0;
       }
     }
 
@@ -1021,6 +1090,10 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
   if (a.out_raw != nullptr) {  // raw int64 scores of the launch's single row, no table writes
     if (in) a.out_raw[n] = raw_score;
     return;
+  }
+  if constexpr (LNM == kLnIfOverflow) {  // the fallback ran: its cells count as re-evaluated (spx_fetch_stats)
+    if (a.stats && threadIdx.x == 0)
+      atomicAdd(a.stats + (SPX_PLUGIN_NRT * kStatSlots + static_cast<int>(blockIdx.x & (kStatSlots - 1))) * kStatStride, static_cast<unsigned long long>(rows) * kWindow);
   }
   __syncthreads();
   if constexpr (kBalF32) {
@@ -1167,6 +1240,152 @@ __global__ __launch_bounds__(256) void k_nrt_bal_redo(NrtArgs a) {
   }
 }
 
+// What k_nrt_ln_redo reads of a node, as ONE record: its lanes hold arbitrary nodes, and the column layout the sweep streams
+// through (a cache line = 16 consecutive nodes of one column) cost every lane ~50 separate lines — 57 GB of L2 traffic for
+// config #3's 1.8e7 listed cells, the kernel's bound.  Record: av[kZ][RM] doubles, then kLnDwords dwords of minimum-distance
+// sets, then {rep masks (RM bytes, padded to 8), node_present, flags | n_zones << 8 | max_numa << 16}; 16-byte aligned.
+template <int RM>
+constexpr int ln_rec_words() { return kZ * RM * 2 + kLnDwords + 4; }
+static_assert(ln_rec_words<4>() % 4 == 0 && ln_rec_words<8>() % 4 == 0, "records are read as uint4");
+
+template <int RM>
+__global__ __launch_bounds__(256) void k_nrt_ln_pack(NrtArgs a) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= a.n_nodes) return;
+  FastNode<RM> ns;
+  double cpu_v[kZ], braw[kZ];
+  load_fast_node<RM, kSgLeastNuma>(a, n, true, ns, cpu_v, braw);
+  uint32_t* rec = a.ln_rec + n * ln_rec_words<RM>();
+#pragma unroll
+  for (int z = 0; z < kZ; ++z)
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      rec[2 * (z * RM + r)] = static_cast<uint32_t>(__double2loint(ns.av[z][r]));
+      rec[2 * (z * RM + r) + 1] = static_cast<uint32_t>(__double2hiint(ns.av[z][r]));
+    }
+  uint32_t* t = rec + kZ * RM * 2;
+#pragma unroll
+  for (int d = 0; d < kLnDwords; ++d) t[d] = a.ln_tab[static_cast<int64_t>(d) * a.n_nodes + n];
+  t[kLnDwords] = ns.rep[0];
+  t[kLnDwords + 1] = RM > 4 ? ns.rep[RM > 4 ? 1 : 0] : 0u;
+  t[kLnDwords + 2] = ns.node_present;
+  t[kLnDwords + 3] = static_cast<uint32_t>(a.flags[n]) | (static_cast<uint32_t>(ns.nz) << 8) | (static_cast<uint32_t>(a.max_numa[n]) << 16);
+}
+
+// LeastNUMANodes fix-up: the cells the batch Score launch listed (kLnRedo) because some container's subset search needs more
+// than sizes 1 and 2 — 13 % of config #3's cells, spread so evenly that nearly every wave of the sweep used to run the 219 larger
+// subsets for a handful of its lanes.  The lists are per pod row: a wave here takes 64 listed nodes of ONE pod, so the pod's
+// items are wave-uniform exactly as in the sweep (scalar resource sets, the same ln_score_wave), every lane has work, and the
+// node tables are loaded per lane.  A workgroup = four consecutive 64-node segments of a row's list.
+// redo_list[1] = the longest list: bounds k_nrt_ln_redo's walk (one workgroup; an atomicMax per wave and pod in the sweep, all on
+// one address, cost 16 ms)
+__global__ __launch_bounds__(1024) void k_nrt_ln_longest(NrtArgs a) {
+  __shared__ uint32_t part[16];
+  uint32_t m = 0;
+  for (int64_t i = threadIdx.x; i < 2 * a.ln_rows; i += 1024) {
+    const uint32_t c = a.redo_list[2 + i];
+    m = c > m ? c : m;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = static_cast<uint32_t>(__shfl_xor(static_cast<int>(m), d, 64));
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) m = part[w] > m ? part[w] : m;
+    a.redo_list[1] = m;
+  }
+}
+
+template <int RM>
+__global__ __launch_bounds__(256, 2) void k_nrt_ln_redo(NrtArgs a) {
+  SPX_RESOLVE_ROWS(a);
+  __shared__ __align__(4) uint8_t ln_subset[kLnDwords * 32];
+  __shared__ uint32_t ln_allow[256 * kLnDwords];
+  __shared__ __align__(16) uint32_t pod_recs[4][pod_words<RM>()];
+  // Persistent waves: the 12 KB of block-constant tables are copied once per workgroup, then every wave walks its share of the
+  // (list, 64-entry segment) units on its own — a workgroup per 256 entries spent as long on that copy as on the search.
+  // Segment-major order: consecutive units are the same segment of consecutive lists, so that the lists' first (often only)
+  // segments spread over all waves; redo_list[1] = the longest list bounds the walk.
+  for (int i = threadIdx.x; i < 256 * kLnDwords; i += blockDim.x) ln_allow[i] = a.ln_const[i];
+  for (int i = threadIdx.x; i < kLnDwords * 32 / 4; i += blockDim.x) reinterpret_cast<uint32_t*>(ln_subset)[i] = a.ln_const[256 * kLnDwords + i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t* pod_rec = pod_recs[wave];
+  const int64_t n_lists = 2 * a.ln_rows;
+  const uint32_t longest = a.redo_list[1] < a.ln_per_row ? a.redo_list[1] : a.ln_per_row;
+  const int64_t units = n_lists * ((longest + 63u) / 64u);
+  for (int64_t u = static_cast<int64_t>(blockIdx.x) * 4 + wave; u < units; u += static_cast<int64_t>(gridDim.x) * 4) {
+  const int64_t list = u % n_lists;  // 2 * row slot + scope
+  const int64_t slot = list >> 1;
+  const uint32_t seg0 = static_cast<uint32_t>(u / n_lists) * 64u;
+  const uint32_t listed = uload(a.redo_list + 2 + list);
+  const uint32_t count = listed < a.ln_per_row ? listed : a.ln_per_row;
+  if (seg0 >= count) continue;  // wave-uniform
+  const int64_t pod = a.row_list ? static_cast<int64_t>(uload(a.row_list + slot)) : a.row_begin + slot;
+  __builtin_amdgcn_wave_barrier();  // the previous unit's reads of pod_rec are done (LDS is in order within a wave)
+  for (int i = lane; i < pod_words<RM>(); i += 64) pod_rec[i] = a.pod_items[pod * pod_words<RM>() + i];
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t at = seg0 + lane;
+  const bool live = at < count;
+  const int64_t n = a.redo_list[2 + 2 * a.ln_rows + list * a.ln_per_row + (live ? at : seg0)];
+  const int n_ctr = static_cast<int>((static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(pod_rec[0]))) >> 16) & 0xffu);
+  FastNode<RM> ns;
+  uint32_t mmin[kLnDwords];
+  uint32_t flags;
+  int nns;
+  {  // the node's record (k_nrt_ln_pack): a few adjacent cache lines per lane
+    constexpr int kW = ln_rec_words<RM>();
+    const u32x4* rec = reinterpret_cast<const u32x4*>(a.ln_rec + n * kW);
+    uint32_t w[kW];
+#pragma unroll
+    for (int q = 0; q < kW / 4; ++q) {
+      const u32x4 v = rec[q];
+      w[4 * q] = v.x, w[4 * q + 1] = v.y, w[4 * q + 2] = v.z, w[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int z = 0; z < kZ; ++z)
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        ns.av[z][r] = __hiloint2double(static_cast<int>(w[2 * (z * RM + r) + 1]), static_cast<int>(w[2 * (z * RM + r)]));
+        ns.b[z][r] = kNoCap;
+      }
+    const uint32_t* t = w + kZ * RM * 2;
+#pragma unroll
+    for (int d = 0; d < kLnDwords; ++d) mmin[d] = t[d];
+    ns.rep[0] = t[kLnDwords];
+    if constexpr (RM > 4) ns.rep[1] = t[kLnDwords + 1];
+    ns.node_present = t[kLnDwords + 2];
+    flags = t[kLnDwords + 3] & 0xffu;
+    ns.nz = static_cast<int>((t[kLnDwords + 3] >> 8) & 0xffu);
+    nns = 100 / static_cast<int>(t[kLnDwords + 3] >> 16);
+#pragma unroll
+    for (int i = 0; i < RM / 4; ++i) ns.fill[i] = 0;
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+      if (r < a.n_res && (a.slot_flags[r] & SPX_NRT_SLOT_HOST_LEVEL) && ns.repmask(r) == 0) ns.fill[r >> 2] |= 0xffu << (8 * (r & 3));
+  }
+  double ln_tot[RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    ln_tot[r] = 0.0;
+#pragma unroll
+    for (int z = 0; z < kZ; ++z) ln_tot[r] += __builtin_fmax(ns.av[z][r], 0.0);
+  }
+  bool unused;
+  // a listed cell belongs to a Guaranteed pod and a node with a fresh NRT
+  int score = ln_score_wave<RM, false, false>(ns, a, pod_rec, n_ctr, n, true, live, (flags & SPX_NRT_F_POD_SCOPE) != 0, nns, mmin, ln_subset, ln_allow, ln_tot, 0, &unused);
+  if (live) {
+    score = score < 0 ? 0 : (score > 254 ? 254 : score);
+    a.out_score[pod * a.row_stride + n] = static_cast<uint8_t>(score);
+  }
+  if (a.stats && lane == 0)  // one update per wave: the live lanes of the wave
+    atomicAdd(a.stats + (SPX_PLUGIN_NRT * kStatSlots + static_cast<int>(u & (kStatSlots - 1))) * kStatStride, static_cast<unsigned long long>(min(64u, count - at)));
+  }  // units
+}
+
 }  // namespace
 
 bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
@@ -1185,8 +1404,18 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                                        \
     if (split) { /* the Filter half does not depend on the strategy */ \
       hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhFilter>), dim3(blocks), dim3(256), 0, s, a, n_tiles); \
+      const bool ln_lists = SGV == kSgLeastNuma && a.redo_list && a.ln_rec && a.ln_rows > 0; \
       if (SGV == kSgBalanced) (void)hipMemsetAsync(a.redo_list, 0, 8, s); /* the float32 Score launch lists the cells it could not decide */ \
-      hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
+      if (ln_lists) { /* sizes 1-2 here, the listed cells in k_nrt_ln_redo; the complete sweep if a row's list overflowed */ \
+        (void)hipMemsetAsync(a.redo_list, 0, (2 + 2 * static_cast<size_t>(a.ln_rows)) * sizeof(uint32_t), s); \
+        hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore, SGV == kSgLeastNuma ? kLnDefer : kLnFull>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
+        hipLaunchKernelGGL(k_nrt_ln_longest, dim3(1), dim3(1024), 0, s, a); \
+        hipLaunchKernelGGL((k_nrt_ln_pack<RMV>), dim3(static_cast<unsigned>((a.n_nodes + 255) / 256)), dim3(256), 0, s, a); \
+        hipLaunchKernelGGL((k_nrt_ln_redo<RMV>), dim3(2048), dim3(256), 0, s, a); /* persistent waves */ \
+        hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore, SGV == kSgLeastNuma ? kLnIfOverflow : kLnFull>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
+      } else { \
+        hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
+      } \
       if (SGV == kSgBalanced) { /* ... recomputed in float64 from the list; the scan pass only acts when the list overflowed */ \
         const int64_t units = (a.row_end - a.row_begin) * (a.row_stride / 16); \
         hipLaunchKernelGGL((k_nrt_bal_scan<RMV>), dim3(static_cast<unsigned>((units + kScanThreads - 1) / kScanThreads)), dim3(kScanThreads), 0, s, a); \

@@ -53,7 +53,7 @@ struct spx_engine {
   int64_t row_stride = 0;
 
   // spx_set_option state (per engine; nothing is read from the environment)
-  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1};
+  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375};
 
   // params
   int32_t alloc_mode = SPX_MODE_LEAST;
@@ -101,6 +101,7 @@ struct spx_engine {
   DevBuf d_nrt_fav, d_nrt_frc, d_nrt_frcv, d_nrt_fcpu, d_nrt_fbraw, d_nrt_frep, d_nrt_items, d_nrt_perm, d_nrt_ln;
   std::vector<double> nrt_wtab;  // [2^n_res][2]: sum of the weights of a slot subset, its biased reciprocal
   bool nrt_fast_slots = false, nrt_fast_nodes = false, nrt_fast_pods = false;
+  DevBuf d_nrt_lnrec;      // LeastNUMANodes: the nodes' tables as one record each (scratch of a batch launch)
   DevBuf d_nrt_redo;       // BalancedAllocation: list of the cells the float32 Score launch leaves to the float64 form
   uint32_t nrt_redo_cap = 0;
   uint32_t nrt_big_nodes = ~0u, nrt_big_pods = ~0u;  // slots with a capacity / a request (Value() form) of 2^24 or more
@@ -443,6 +444,7 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   na.redo_list = static_cast<uint32_t*>(e->d_nrt_redo.p);
   na.redo_cap = e->nrt_redo_cap;
   na.ln_tab = (e->nrt_ln_ok && e->nrt_ln_built) ? static_cast<const uint32_t*>(e->d_nrt_ln.p) : nullptr;
+  na.ln_const = na.ln_tab ? na.ln_tab + static_cast<size_t>(spx::make_ln_layout().rows) * static_cast<size_t>(e->n_nodes) : nullptr;
 }
 
 // the reference-arithmetic NRT kernel's request column, when the coming launch may take that kernel and the batch did not ship it
@@ -578,7 +580,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_best, &e->d_stats, &e->d_decide, &e->d_lroc_nreq_c, &e->d_lroc_nreq_m, &e->d_lroc_nlim_c, &e->d_lroc_nlim_m,
                     &e->d_lroc_preq_c, &e->d_lroc_preq_m, &e->d_lroc_plim_c, &e->d_lroc_plim_m, &e->d_lroc_tab, &e->d_lroc_podf,
                     &e->d_pk_cap, &e->d_pk_util, &e->d_pk_valid, &e->d_pk_k1, &e->d_pk_k2, &e->d_pk_pod, &e->d_pk_min, &e->d_pk_max,
-                    &e->d_nrt_uniq, &e->d_nrt_dups, &e->d_pk_uniq, &e->d_pk_dups, &e->d_delta};
+                    &e->d_nrt_uniq, &e->d_nrt_dups, &e->d_pk_uniq, &e->d_pk_dups, &e->d_delta, &e->d_nrt_lnrec};
   for (DevBuf* b : bufs)
     if (b->p && !b->external) (void)hipFree(b->p);
   for (int i = 0; i < SPX_NUM_PLUGINS; ++i) {
@@ -626,6 +628,9 @@ int spx_set_option(spx_engine* e, int option, int64_t value) {
     case SPX_OPT_NRT_POD_CLASSES:
     case SPX_OPT_PEAKS_POD_CLASSES:
       if (value != 0 && value != 1) return fail(e, SPX_ERR_ARG, "option takes 0 or 1");
+      break;
+    case SPX_OPT_NRT_LN_LIST_PERMILLE:
+      if (value < 1 || value > 1000) return fail(e, SPX_ERR_ARG, "SPX_OPT_NRT_LN_LIST_PERMILLE: 1..1000");
       break;
     case SPX_OPT_PEAKS_TILE:
       if (value != 44 && value != 84 && value != 48 && value != 88) return fail(e, SPX_ERR_ARG, "SPX_OPT_PEAKS_TILE: 44, 84, 48 or 88");
@@ -1252,9 +1257,25 @@ int spx_internal_ln_layout(uint8_t* subset, uint8_t* cnt, uint8_t* first, uint8_
 static int build_ln_tab(spx_engine* e) {
   if (e->nrt_ln_built || !e->nrt_ln_ok) return SPX_OK;
   constexpr spx::LnLayout L = spx::make_ln_layout();
-  std::vector<uint32_t> tab(static_cast<size_t>(L.rows) * static_cast<size_t>(e->n_nodes));
+  // [L.rows][N] per-node tables, then what every workgroup keeps in LDS (spx::LnConst: it used to be rebuilt by every block from
+  // the constant-memory layout — 384 dependent byte loads per thread, ~30 us per block)
+  const size_t per_node = static_cast<size_t>(L.rows) * static_cast<size_t>(e->n_nodes);
+  std::vector<uint32_t> tab(per_node + spx::kLnConstWords);
   int rc = spx_internal_ln_tables(e->h_nrt_cost.data(), e->h_nrt_nz.data(), e->n_nodes, tab.data());
   if (rc) return fail(e, rc, "LeastNUMANodes tables");
+  {
+    uint32_t* allow = tab.data() + per_node;  // [256 zone sets V][kLnDwords]: the subsets inside V, in the bit layout
+    for (uint32_t vset = 0; vset < 256; ++vset)
+      for (int d = 0; d < spx::kLnDwords; ++d) {
+        uint32_t bits = 0;
+        for (int q = 0; q < 32; ++q) {
+          const uint32_t sub = L.subset[d][q];
+          if (sub != 0 && (sub & ~vset) == 0) bits |= 1u << q;
+        }
+        allow[vset * spx::kLnDwords + d] = bits;
+      }
+    std::memcpy(allow + 256 * spx::kLnDwords, L.subset, sizeof L.subset);  // [kLnDwords][32] bytes: bit position -> zone mask
+  }
   if ((rc = upload(e, e->d_nrt_ln, tab.data(), tab.size() * sizeof(uint32_t)))) return rc;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   e->nrt_ln_built = true;
@@ -1881,6 +1902,22 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     if (classes) {
       na.row_list = static_cast<const int32_t*>(e->d_nrt_uniq.p);
       na.n_list = e->nrt_n_uniq;
+    }
+    if (na.strategy == SPX_NRT_LEAST_NUMA_NODES && na.fast && !(na.opts & spx::kOptNrtGeneric) && !e->row_indirect) {
+      // LeastNUMANodes, batch launch: per evaluated row and node scope a list of the nodes whose cell needs the complete subset
+      // search (k_nrt_ln_redo) — room for 3/8 of the nodes per list by default (config #3 lists 13 % of the cells, no row more than 40 %); a
+      // list that overflows sends the launch back to the complete sweep
+      const int64_t rows = classes ? e->nrt_n_uniq : row_end - row_begin;
+      const uint32_t per_row = static_cast<uint32_t>(spx::round_up(std::max<int64_t>(64, e->n_nodes * e->option[SPX_OPT_NRT_LN_LIST_PERMILLE] / 1000), 64));
+      const size_t words = 2 + 2 * static_cast<size_t>(rows) * (1 + static_cast<size_t>(per_row));
+      if (rows > 0 && words < (size_t{1} << 31)) {
+        if ((rc = ensure(e, e->d_nrt_redo, words * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(e, e->d_nrt_lnrec, static_cast<size_t>(e->n_nodes) * (SPX_NRT_MAX_ZONES * (e->nrt_n_res <= 4 ? 4 : 8) * 2 + 16) * sizeof(uint32_t)))) return rc;
+        na.redo_list = static_cast<uint32_t*>(e->d_nrt_redo.p);
+        na.ln_rec = static_cast<uint32_t*>(e->d_nrt_lnrec.p);
+        na.ln_rows = rows;
+        na.ln_per_row = per_row;
+      }
     }
     spx::launch_nrt(na, e->stream);
     if (classes)

@@ -259,6 +259,7 @@ struct NrtArgs {
   const double* f_cpu;           // [Z][N] Value() of the cpu capacity
   const double* f_braw;          // [Z][N] RN(100 / cpu capacity in millicores), kNrtNoCap when it is not positive
   const uint8_t* f_rep;          // [n_res][N] mask of the zones reporting the resource
+  const uint32_t* ln_const;      // LeastNUMANodes: the block-constant tables (kLnConstWords dwords), behind ln_tab's rows
   const uint32_t* ln_tab;        // [LnLayout.rows][N] LeastNUMANodes: minimum-distance subsets + distance-rank planes; NULL when a
                                  // cost lies outside [0, 255] (the reference-arithmetic kernel then serves that strategy)
   const int32_t* perm;           // [ceil(N/256)*256] node index per slot, windows of 256 ordered by code path; -1 = empty
@@ -266,6 +267,12 @@ struct NrtArgs {
   unsigned long long* stats;     // as TrimaranArgs::stats: BalancedAllocation cells recomputed in float64 (SPX_PLUGIN_NRT)
   uint32_t* redo_list;           // BalancedAllocation: [count, pad, (row - row_begin, node) x redo_cap] cells the float32 Score launch left to float64
   uint32_t redo_cap;
+  // LeastNUMANodes (batch Score launch) uses the same buffer as node lists per (row, scope): [overflow flag, pad, count x 2 ln_rows,
+  // node x 2 ln_rows x ln_per_row] — the cells whose subset search needs more than sizes 1-2 (k_nrt_ln_redo); ln_rows = 0: not in
+  // use.  List 2 j + s: row slot j = position in row_list, or row - row_begin; s = 1 for the pod-scope nodes
+  int64_t ln_rows;
+  uint32_t ln_per_row;
+  uint32_t* ln_rec;              // [N][kZ * RM * 2 + 16] scratch: the nodes' tables as one record each (k_nrt_ln_pack -> k_nrt_ln_redo)
   uint32_t exact32_slots;        // resource slots whose requests and capacities (Value() form) are all below 2^24: exact in float32
 };
 constexpr double kNrtNoCap = 1e200;
@@ -305,6 +312,9 @@ constexpr Combo8 make_combo8() {
 // (rows 0..11 of NrtArgs.ln_tab) and, per class, bit-planes of the RANK of each subset's distance among the node's distinct
 // distances for that size (bits[k] planes of nd[k] dwords each, from row 12 + pbase[k]; plane b = bit b of the rank).
 constexpr int kLnDwords = 12;
+// what a LeastNUMANodes workgroup copies into LDS (NrtArgs::ln_const): [256][kLnDwords] dwords "zone set V -> the subsets inside V",
+// then [kLnDwords][32] bytes "bit position -> zone mask"
+constexpr int kLnConstWords = 256 * kLnDwords + kLnDwords * 32 / 4;
 struct LnLayout {
   uint8_t subset[kLnDwords][32];  // zone mask of bit q of dword d; 0 = unused
   uint8_t cnt[kLnDwords];         // used bits of the dword

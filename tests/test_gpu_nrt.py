@@ -459,3 +459,37 @@ def test_discard_reserved_cache_semantics(gpu_required, hdr, oracle):
     reserved, t2 = cache_view()
     st2, sc2, _, _ = evaluate(t2)
     assert not reserved.any() and np.array_equal(st2, st0) and np.array_equal(sc2, sc0)
+
+
+# ------------------------------------------------------------------ LeastNUMANodes: listed cells (k_nrt_ln_redo) and the overflow fallback
+@pytest.mark.parametrize("permille,expect_overflow", [(375, False), (1, True)])
+def test_least_numa_listed_cells_and_overflow(gpu_required, hdr, oracle, permille, expect_overflow):
+    """The batch Score launch searches subset sizes 1-2 and lists the cells that need more for k_nrt_ln_redo (spx_fetch_stats counts
+    them).  With room for 64 nodes per (row, scope) list (SPX_OPT_NRT_LN_LIST_PERMILLE 1) the lists of a 2000-node snapshot overflow
+    and the launch falls back to the complete sweep.  Every cell against the oracle either way."""
+    n_nodes, n_pods = 2000, 64
+    snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=12)
+    params = O.nrt_params(hdr, O.Resources(), "LeastNUMANodes")
+    osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
+    want = osnap.score_rows(NRT, want_norm=False)[0].clip(0, 255)
+    with Engine(0) as e:
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+        assert e.kernel_path(NRT) == 1
+        e.set_option("NRT_POD_CLASSES", 0)
+        e.set_option("NRT_LN_LIST_PERMILLE", permille)
+        e.stats(reset=True)
+        e.eval(mask_of(NRT))
+        e.sync()
+        listed = int(e.stats(reset=True)[NRT])
+        got = e.all_scores(NRT).astype(np.int64)
+        assert np.array_equal(got, want)
+        if expect_overflow:   # the fallback counts every cell of its windows
+            assert listed >= n_pods * n_nodes
+        else:
+            assert 0 < listed < n_pods * n_nodes // 3
+        # the single-launch form (no lists) gives the same table
+        e.set_option("NRT_SINGLE_LAUNCH", 1)
+        e.eval(mask_of(NRT))
+        e.sync()
+        assert np.array_equal(e.all_scores(NRT).astype(np.int64), want)
+        assert int(e.stats(reset=True)[NRT]) == 0
