@@ -80,9 +80,12 @@ def test_config3_every_cell(gpu_required, hdr, oracle, strategy):
         e.eval(mask_of(NRT))
         e.sync()
         # BalancedAllocation scores in float32 and recomputes the cells it cannot decide in float64: those cells exist at this
-        # size (0.7 % of them, measured) and are compared below like every other cell; the other strategies count nothing
+        # size (0.7 % of them, measured); LeastNUMANodes' sweep searches subset sizes 1-2 and lists the cells that need more for
+        # k_nrt_ln_redo (13 % of the evaluated cells = 7 % of the table: half of the rows are class copies).  Both kinds are
+        # compared below like every other cell; the other strategies count nothing
         redone = int(e.stats()[NRT])
-        assert (redone > 0) == (strategy == "BalancedAllocation") and redone < 0.03 * n_nodes * n_pods, redone
+        bound = {"BalancedAllocation": 0.03, "LeastNUMANodes": 0.15}.get(strategy, 0.0)
+        assert (redone > 0) == (bound > 0) and redone <= bound * n_nodes * n_pods, redone
         osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
         bad_status = bad_score = 0
         rejected = 0
