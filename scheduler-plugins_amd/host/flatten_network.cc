@@ -12,7 +12,6 @@
 #include <climits>
 #include <cstdint>
 #include <cstddef>
-#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -58,11 +57,6 @@ extern "C" int spx_flatten_net_topo(const spx_nettopo_objects* nt, int32_t* regi
   return SPX_OK;
 }
 
-namespace {
-inline uint64_t pack_key(int32_t group, int32_t selector) {
-  return (static_cast<uint64_t>(static_cast<uint32_t>(group)) << 32) | static_cast<uint32_t>(selector);
-}
-}  // namespace
 
 namespace {
 // Everything spx_flatten_net_keys returns, computed in one pass.  The C entry point is called twice per batch (sizes, then the
@@ -169,57 +163,87 @@ extern "C" int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgr
 //     networkoverhead.go:215-224) -> an entry (key, -1);
 //   * every dependency of such a workload on p's workload selector gains a (host, MaxNetworkCost) pair -> (key, cost).
 // Keys are numbered exactly as spx_flatten_net_keys numbers them.  Sizes first (NULL arrays), then the CSR.
+namespace {
+// computed in one pass; the sizing call leaves it for the fill call that follows (as spx_flatten_net_keys does)
+struct NetCommit {
+  const void *pods = nullptr, *ag = nullptr;
+  int64_t n_pods = -1;
+  std::vector<int32_t> eff_ptr, eff_key;
+  std::vector<int64_t> eff_cost;
+};
+thread_local NetCommit tl_net_commit;
+
+void build_net_commit(const spx_pod_objects* pods, const spx_appgroup_objects* ag, NetCommit& out) {
+  const size_t P = static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 0);
+  out.pods = pods, out.ag = ag, out.n_pods = pods->n_pods;
+  out.eff_ptr.assign(1, 0), out.eff_ptr.reserve(P + 1);
+  out.eff_key.clear(), out.eff_cost.clear();
+  // key ids in order of first appearance, per group a short list (selector, key) — the numbering of spx_flatten_net_keys
+  struct GroupKey {
+    int32_t selector, key;
+  };
+  std::vector<std::vector<GroupKey>> by_group(static_cast<size_t>(ag->n_groups > 0 ? ag->n_groups : 0));
+  std::vector<int32_t> key_of(P, 0);
+  int32_t next = 1;
+  for (size_t p = 0; p < P; ++p) {
+    const int32_t g = pods->appgroup[p];
+    if (g < 0 || g >= ag->n_groups) continue;
+    const int32_t sel = pods->selector[p];
+    auto& list = by_group[static_cast<size_t>(g)];
+    int32_t key = -1;
+    for (const GroupKey& e : list)
+      if (e.selector == sel) {
+        key = e.key;
+        break;
+      }
+    if (key < 0) list.push_back(GroupKey{sel, key = next++});
+    key_of[p] = key;
+  }
+  // The effects of binding a pod depend only on its (AppGroup, selector), i.e. on its key: computed once per key, copied per
+  // pod (at 62.5k pods of 6.9k keys the per-pod evaluation was 21 ms per call, and the function used to run twice)
+  std::vector<std::vector<std::pair<int32_t, int64_t>>> tmpl(static_cast<size_t>(next));  // per key: (affected key, cost or -1)
+  std::vector<uint8_t> have(static_cast<size_t>(next), 0);
+  for (size_t p = 0; p < P; ++p) {
+    const int32_t g = pods->appgroup[p], sel = pods->selector[p];
+    if (g >= 0 && g < ag->n_groups) {
+      const size_t key = static_cast<size_t>(key_of[p]);
+      auto& t = tmpl[key];
+      if (!have[key]) {
+        have[key] = 1;
+        for (const GroupKey& kk : by_group[static_cast<size_t>(g)]) {
+          bool any_dep = false;
+          for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w)
+            if (ag->wl_selector[w] == kk.selector && ag->dep_ptr[w + 1] > ag->dep_ptr[w]) any_dep = true;
+          if (!any_dep) continue;
+          t.emplace_back(kk.key, int64_t{-1});
+          for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w) {
+            if (ag->wl_selector[w] != kk.selector) continue;
+            for (int32_t d = ag->dep_ptr[w]; d < ag->dep_ptr[w + 1]; ++d)
+              if (ag->dep_selector[d] == sel) t.emplace_back(kk.key, ag->dep_max_cost[d]);
+          }
+        }
+      }
+      for (const auto& e : t) out.eff_key.push_back(e.first), out.eff_cost.push_back(e.second);
+    }
+    out.eff_ptr.push_back(static_cast<int32_t>(out.eff_key.size()));
+  }
+}
+}  // namespace
+
 extern "C" int spx_flatten_net_commit(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int64_t* n_entries_out, int32_t* eff_ptr,
                                       int32_t* eff_key, int64_t* eff_cost) {
   if (!pods || !ag || !n_entries_out) return SPX_ERR_ARG;
   const bool fill = eff_ptr && eff_key && eff_cost;
-  std::unordered_map<uint64_t, int32_t> keys;
-  keys.reserve(static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 1) / 4 + 16);
-  keys[pack_key(-1, -1)] = 0;
-  std::vector<std::vector<std::pair<int32_t, int32_t>>> by_group(static_cast<size_t>(ag->n_groups > 0 ? ag->n_groups : 0));  // (selector, key)
-  int32_t next = 1;
-  for (int64_t p = 0; p < pods->n_pods; ++p) {
-    const int32_t g = pods->appgroup[p];
-    if (g < 0 || g >= ag->n_groups) continue;
-    const std::pair<int32_t, int32_t> k{g, pods->selector[p]};
-    if (keys.emplace(pack_key(k.first, k.second), next).second) by_group[static_cast<size_t>(g)].emplace_back(k.second, next++);
+  NetCommit& k = tl_net_commit;
+  if (!(fill && k.pods == pods && k.ag == ag && k.n_pods == pods->n_pods)) build_net_commit(pods, ag, k);
+  if (k.eff_key.size() > static_cast<size_t>(INT32_MAX)) return SPX_ERR_ARG;
+  *n_entries_out = static_cast<int64_t>(k.eff_key.size());
+  if (fill) {
+    std::copy(k.eff_ptr.begin(), k.eff_ptr.end(), eff_ptr);
+    std::copy(k.eff_key.begin(), k.eff_key.end(), eff_key);
+    std::copy(k.eff_cost.begin(), k.eff_cost.end(), eff_cost);
+    k = NetCommit{};  // one use: the tables may change before the next call
   }
-  // The effects of binding a pod depend only on its (AppGroup, selector), i.e. on its key: computed once per key, copied per
-  // pod (at 62.5k pods of 6.9k keys the per-pod evaluation was 21 ms per call, and the function runs twice: sizes, then fill).
-  std::vector<std::vector<std::pair<int32_t, int64_t>>> tmpl(static_cast<size_t>(next));  // per key: (affected key, cost or -1)
-  std::vector<uint8_t> have(static_cast<size_t>(next), 0);
-  int64_t n = 0;
-  if (fill) eff_ptr[0] = 0;
-  for (int64_t p = 0; p < pods->n_pods; ++p) {
-    const int32_t g = pods->appgroup[p], sel = pods->selector[p];
-    if (g >= 0 && g < ag->n_groups) {
-      const size_t key = static_cast<size_t>(keys.find(pack_key(g, sel))->second);
-      auto& t = tmpl[key];
-      if (!have[key]) {
-        have[key] = 1;
-        for (const auto& kk : by_group[static_cast<size_t>(g)]) {
-          bool any_dep = false;
-          for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w)
-            if (ag->wl_selector[w] == kk.first && ag->dep_ptr[w + 1] > ag->dep_ptr[w]) any_dep = true;
-          if (!any_dep) continue;
-          t.emplace_back(kk.second, int64_t{-1});
-          for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w) {
-            if (ag->wl_selector[w] != kk.first) continue;
-            for (int32_t d = ag->dep_ptr[w]; d < ag->dep_ptr[w + 1]; ++d)
-              if (ag->dep_selector[d] == sel) t.emplace_back(kk.second, ag->dep_max_cost[d]);
-          }
-        }
-      }
-      if (fill)
-        for (size_t j = 0; j < t.size(); ++j) eff_key[n + static_cast<int64_t>(j)] = t[j].first, eff_cost[n + static_cast<int64_t>(j)] = t[j].second;
-      n += static_cast<int64_t>(t.size());
-    }
-    if (fill) {
-      if (n > INT32_MAX) return SPX_ERR_ARG;
-      eff_ptr[p + 1] = static_cast<int32_t>(n);
-    }
-  }
-  *n_entries_out = n;
   return SPX_OK;
 }
 
