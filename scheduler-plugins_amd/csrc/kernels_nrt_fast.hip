@@ -583,16 +583,19 @@ __device__ __forceinline__ uint32_t numa_required_fast(const FastNode<RM>& ns, c
       ln_resource<0, kLnDwords>(fall, v, want);
     }
   }
-  // the smallest size with a fitting subset: its candidates c, those of them at the node's minimum distance h
+  // the smallest size with a fitting subset: its candidates c, those of them at the node's minimum distance h.  DEFER: only
+  // sizes 1 and 2 can have been found (one dword each, rank planes of at most 5 bits)
+  constexpr int KMAX = DEFER ? 2 : 8, JMAX = DEFER ? 1 : 3, BMAX = DEFER ? 5 : 7;
+  static_assert(!DEFER || (kLn.nd[1] == 1 && kLn.nd[2] == 1 && kLn.bits[1] <= 5 && kLn.bits[2] <= 5), "sizes 1-2: one dword, <= 5 rank bits");
   uint32_t c[3] = {0, 0, 0}, h[3] = {0, 0, 0};
   int ksel = 0, fsel = 0;
-  static_for<8>([&](auto ki) {
-    constexpr int k = 8 - decltype(ki)::value, f = kLn.first[k], nd = kLn.nd[k];
+  static_for<KMAX>([&](auto ki) {
+    constexpr int k = KMAX - decltype(ki)::value, f = kLn.first[k], nd = kLn.nd[k];
     uint32_t t = fall[f];
     if constexpr (nd > 1) t |= fall[f + 1];
     if constexpr (nd > 2) t |= fall[f + 2];
     const bool sel = t != 0;
-    static_for<3>([&](auto ji) {
+    static_for<JMAX>([&](auto ji) {
       constexpr int j = decltype(ji)::value;
       uint32_t cj = 0u, hj = 0u;
       if constexpr (j < nd) cj = fall[f + j], hj = fall[f + j] & mmin[f + j];
@@ -606,13 +609,13 @@ __device__ __forceinline__ uint32_t numa_required_fast(const FastNode<RM>& ns, c
   const bool hit = (h[0] | h[1] | h[2]) != 0;
   if (hit) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) c[j] = h[j];
+    for (int j = 0; j < JMAX; ++j) c[j] = h[j];
   } else if (choice && __ballot(found) != 0) {
     // no fitting subset at the minimum distance: the fitting subset with the smallest distance = the smallest rank;
     // bit-sliced minimum from the top plane down (a plane keeps the candidates whose rank has that bit clear, if any)
     if (found) {
       int bits = 0, nd = 1, prow = 0;
-      static_for<8>([&](auto ki) {
+      static_for<KMAX>([&](auto ki) {
         constexpr int k = 1 + decltype(ki)::value, bk = kLn.bits[k], ndk = kLn.nd[k], pk = kLnDwords + kLn.pbase[k];
         const bool is = ksel == k;
         bits = is ? bk : bits;
@@ -620,14 +623,14 @@ __device__ __forceinline__ uint32_t numa_required_fast(const FastNode<RM>& ns, c
         prow = is ? pk : prow;
       });
       const uint32_t nn = static_cast<uint32_t>(a.n_nodes), n32 = opaque_lane(static_cast<uint32_t>(n));
-      uint32_t pl[7][3];
+      uint32_t pl[BMAX][3];
 #pragma unroll
-      for (int b = 0; b < 7; ++b)
+      for (int b = 0; b < BMAX; ++b)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-          pl[b][j] = (b < bits && j < nd) ? ld_off(a.ln_tab, (static_cast<uint32_t>(prow + b * nd + j) * nn + n32) * 4u) : 0u;
+          pl[b][j] = (j < JMAX && b < bits && j < nd) ? ld_off(a.ln_tab, (static_cast<uint32_t>(prow + b * nd + j) * nn + n32) * 4u) : 0u;
 #pragma unroll
-      for (int b = 6; b >= 0; --b) {
+      for (int b = BMAX - 1; b >= 0; --b) {
         const uint32_t t0 = c[0] & ~pl[b][0], t1 = c[1] & ~pl[b][1], t2 = c[2] & ~pl[b][2];
         const bool any = (t0 | t1 | t2) != 0;
         c[0] = any ? t0 : c[0];
