@@ -687,7 +687,8 @@ int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t r
  *   NETOVERHEAD        the pod joins its AppGroup's scheduled list (networkoverhead.go:205-224) — needs spx_upload_net_commit.
  * plugin_mask is a subset of {ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY}.  Without a Filter plugin the whole chain runs in one
  * workgroup (about 3 us per pod); with one, every pod is one single-row spx_eval + spx_eval_best + a bookkeeping launch on the engine
- * stream (tens of us per pod), score / status tables end up holding each row as its pod saw it.  A pod that fails PreFilter or has no
+ * stream (tens of us per pod), score / status tables end up holding each row as its pod saw it (except Allocatable's when Filter
+ * plugins are in the mask: its feasibility-aware normalisation then happens inside the argmax kernel, as in spx_decide).  A pod that fails PreFilter or has no
  * feasible node gets node -1 and reserves nothing.  Per pod: the node with the highest
  * sum of plugin_weight x score (lowest index among ties; upstream's selectHost draws among them), that sum, and the size
  * of the tie set (NULL = not wanted).  tlp_missing_out (NULL = not wanted) receives the per-node missing utilisation after

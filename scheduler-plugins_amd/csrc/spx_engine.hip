@@ -178,6 +178,10 @@ struct spx_engine {
 };
 
 namespace {
+int decide_masked(spx_engine* e, uint32_t eval_mask, uint32_t score_mask, int64_t row_begin, int64_t row_end, bool* done);  // defined with spx_decide
+}
+
+namespace {
 
 thread_local std::string tl_err;              // this thread's last failure ...
 thread_local const spx_engine* tl_err_engine = nullptr;  // ... and on which engine
@@ -2175,8 +2179,12 @@ int commit_with_filters(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, 
   rc = (plugin_mask & lvrb_bit) ? spx_eval(e, lvrb_bit, row_begin, row_end) : SPX_OK;
   auto step = [&](int64_t pod) -> int {  // one pod: sweep its row on the current tables, argmax, Reserve bookkeeping
     int r;
-    if ((r = spx_eval(e, step_mask, pod, pod + 1))) return r;
-    if ((r = spx_eval_best(e, plugin_mask, pod, pod + 1))) return r;
+    bool decided = false;  // Allocatable's masked normalisation and the argmax in one kernel where that form applies
+    if ((r = decide_masked(e, step_mask, plugin_mask, pod, pod + 1, &decided))) return r;
+    if (!decided) {
+      if ((r = spx_eval(e, step_mask, pod, pod + 1))) return r;
+      if ((r = spx_eval_best(e, plugin_mask, pod, pod + 1))) return r;
+    }
     ca.pod = pod;
     spx::launch_commit_apply(ca, e->stream);
     return hipGetLastError() == hipSuccess ? SPX_OK : fail(e, SPX_ERR_HIP, "k_commit_apply launch failed");
@@ -2572,6 +2580,66 @@ EngineView engine_view(spx_engine* e) {
 }
 }  // namespace spx
 
+namespace {
+// spx_decide for a profile with Filter plugins (NRT / NetworkOverhead / a caller mask): the sweeps of `eval_mask` write their
+// status and score tables as in spx_eval; Allocatable's feasibility-aware normalisation is folded into the argmax kernel
+// (k_decide_masked) over the scoring plugins of `score_mask` — its table is not written, and ALLOCATABLE is left "not evaluated"
+// for the fetch functions.  eval_mask differs from score_mask in the sequential commit loop (LVRB's rows are swept once, up
+// front).  *done = false: the form does not apply (no Filter in play, wide Allocatable range, weights) — nothing was launched.
+int decide_masked(spx_engine* e, uint32_t eval_mask, uint32_t score_mask, int64_t row_begin, int64_t row_end, bool* done) {
+  *done = false;
+  const uint32_t A = 1u << SPX_PLUGIN_ALLOCATABLE;
+  const bool masked = (score_mask & ((1u << SPX_PLUGIN_NRT) | (1u << SPX_PLUGIN_NETOVERHEAD))) || e->ext_mask;
+  if (!(score_mask & A) || !(eval_mask & A) || !masked || e->option[SPX_OPT_DECIDE_UNFUSED] || e->n_nodes <= 0 || e->n_pods <= 0 || row_begin < 0 ||
+      row_end > e->n_pods || row_begin >= row_end)
+    return SPX_OK;
+  int rc;
+  if ((rc = prepare_alloc(e))) return rc;
+  const size_t P = static_cast<size_t>(e->n_pods);
+  spx::ProfileArgs pa{};
+  pa.n_nodes = e->n_nodes;
+  pa.row_stride = e->row_stride;
+  pa.row_begin = row_begin;
+  pa.row_end = row_end;
+  pa.row_ptr = e->row_indirect;
+  pa.alloc_rel = static_cast<const uint32_t*>(e->d_alloc_rel.p);
+  for (int k = 0; k < SPX_NUM_PLUGINS; ++k) {
+    const bool has_score = k <= SPX_PLUGIN_NETOVERHEAD || k == SPX_PLUGIN_LROC || k == SPX_PLUGIN_PEAKS;
+    // the tables the sweep below will have written by the time the kernel runs (engine-owned or bound: same row stride)
+    if ((score_mask & (1u << k)) && has_score && k != SPX_PLUGIN_ALLOCATABLE) pa.score[k] = reinterpret_cast<const uint8_t*>(uintptr_t{1});
+    pa.weight[k] = e->plugin_weight[k];
+  }
+  if (!e->alloc_compact || !spx::decide_masked_ok(pa)) return SPX_OK;
+  if ((rc = ensure(e, e->d_best, P * 20))) return rc;
+  SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
+  e->hold_ev0 = e->skip_alloc_masked = true;
+  rc = spx_eval(e, eval_mask, row_begin, row_end);
+  e->hold_ev0 = e->skip_alloc_masked = false;
+  if (rc) return rc;
+  for (int k = 0; k < SPX_NUM_PLUGINS; ++k)
+    if (pa.score[k]) {
+      if (!(e->evaluated & (1u << k)) || e->score_stride[k] != e->row_stride)
+        return fail(e, SPX_ERR_STATE, "spx_decide: a scoring plugin of the mask has no evaluated table with the engine row stride");
+      pa.score[k] = static_cast<const uint8_t*>(e->score[k].p);
+    }
+  pa.status[0] = (score_mask & (1u << SPX_PLUGIN_NRT)) ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NRT].p) : nullptr;
+  pa.status[1] = (score_mask & (1u << SPX_PLUGIN_NETOVERHEAD)) ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NETOVERHEAD].p) : nullptr;
+  pa.status[2] = e->ext_mask ? static_cast<const uint8_t*>(e->d_ext_status.p) : nullptr;
+  pa.prefilter = (score_mask & (1u << SPX_PLUGIN_CAPACITY)) ? static_cast<const uint8_t*>(e->d_q_status.p) : nullptr;
+  pa.best_score = static_cast<int64_t*>(e->d_best.p);
+  pa.best_node = reinterpret_cast<int32_t*>(pa.best_score + P);
+  pa.best_ties = pa.best_node + P;
+  pa.best_feasible = pa.best_ties + P;
+  spx::launch_decide_masked(pa, e->stream);
+  SPX_HIP(e, hipGetLastError());
+  SPX_HIP(e, hipEventRecord(e->ev1, e->stream));
+  e->timed = true;
+  e->best_valid = true;
+  *done = true;
+  return SPX_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int spx_eval_best(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end) {
@@ -2642,56 +2710,9 @@ int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t r
                        e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && !(launch_opts(e) & spx::kOptTrimaranExact) &&
                        !e->option[SPX_OPT_DECIDE_UNFUSED] && w_ok && w_sum <= 10000000;
   int rc;
-  // A profile with Filter plugins (NRT / NetworkOverhead / a caller mask): their sweeps write status and score tables as in
-  // spx_eval; Allocatable's feasibility-aware normalisation is folded into the argmax kernel (k_decide_masked) — its table is
-  // not written, and ALLOCATABLE is left "not evaluated" for the fetch functions.
-  const bool masked = (plugin_mask & ((1u << SPX_PLUGIN_NRT) | (1u << SPX_PLUGIN_NETOVERHEAD))) || e->ext_mask;
-  if (!fusable && (plugin_mask & A) && masked && !e->option[SPX_OPT_DECIDE_UNFUSED] && e->n_nodes > 0 && e->n_pods > 0 && row_begin >= 0 &&
-      row_end <= e->n_pods && row_begin < row_end) {
-    if ((rc = prepare_alloc(e))) return rc;
-    const size_t P = static_cast<size_t>(e->n_pods);
-    spx::ProfileArgs pa{};
-    pa.n_nodes = e->n_nodes;
-    pa.row_stride = e->row_stride;
-    pa.row_begin = row_begin;
-    pa.row_end = row_end;
-    pa.row_ptr = e->row_indirect;
-    pa.alloc_rel = static_cast<const uint32_t*>(e->d_alloc_rel.p);
-    bool tables_ok = true;
-    for (int k = 0; k < SPX_NUM_PLUGINS; ++k) {
-      const bool has_score = k <= SPX_PLUGIN_NETOVERHEAD || k == SPX_PLUGIN_LROC || k == SPX_PLUGIN_PEAKS;
-      // the tables the sweep below will have written by the time the kernel runs (engine-owned or bound: same row stride)
-      if ((plugin_mask & (1u << k)) && has_score && k != SPX_PLUGIN_ALLOCATABLE) pa.score[k] = reinterpret_cast<const uint8_t*>(uintptr_t{1});
-      pa.weight[k] = e->plugin_weight[k];
-    }
-    if (e->alloc_compact && spx::decide_masked_ok(pa)) {
-      if ((rc = ensure(e, e->d_best, P * 20))) return rc;
-      SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
-      e->hold_ev0 = e->skip_alloc_masked = true;
-      rc = spx_eval(e, plugin_mask, row_begin, row_end);
-      e->hold_ev0 = e->skip_alloc_masked = false;
-      if (rc) return rc;
-      for (int k = 0; k < SPX_NUM_PLUGINS; ++k)
-        if (pa.score[k]) {
-          tables_ok &= e->score_stride[k] == e->row_stride;
-          pa.score[k] = static_cast<const uint8_t*>(e->score[k].p);
-        }
-      if (!tables_ok) return fail(e, SPX_ERR_STATE, "score table stride differs from the engine row stride");
-      pa.status[0] = (plugin_mask & (1u << SPX_PLUGIN_NRT)) ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NRT].p) : nullptr;
-      pa.status[1] = (plugin_mask & (1u << SPX_PLUGIN_NETOVERHEAD)) ? static_cast<const uint8_t*>(e->status[SPX_PLUGIN_NETOVERHEAD].p) : nullptr;
-      pa.status[2] = e->ext_mask ? static_cast<const uint8_t*>(e->d_ext_status.p) : nullptr;
-      pa.prefilter = (plugin_mask & (1u << SPX_PLUGIN_CAPACITY)) ? static_cast<const uint8_t*>(e->d_q_status.p) : nullptr;
-      pa.best_score = static_cast<int64_t*>(e->d_best.p);
-      pa.best_node = reinterpret_cast<int32_t*>(pa.best_score + P);
-      pa.best_ties = pa.best_node + P;
-      pa.best_feasible = pa.best_ties + P;
-      spx::launch_decide_masked(pa, e->stream);
-      SPX_HIP(e, hipGetLastError());
-      SPX_HIP(e, hipEventRecord(e->ev1, e->stream));
-      e->timed = true;
-      e->best_valid = true;
-      return SPX_OK;
-    }
+  if (!fusable) {  // a profile with Filter plugins: see decide_masked
+    bool done = false;
+    if ((rc = decide_masked(e, plugin_mask, plugin_mask, row_begin, row_end, &done)) || done) return rc;
   }
   if (!fusable) {
     if ((rc = spx_eval(e, plugin_mask, row_begin, row_end))) return rc;
