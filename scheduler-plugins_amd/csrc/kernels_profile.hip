@@ -130,13 +130,37 @@ __device__ __forceinline__ void alloc_masked_compact(const ProfileArgs& a, int64
   }
 }
 
-__global__ __launch_bounds__(64 * kMaxRowWaves) void k_alloc_masked(ProfileArgs a) {
+// Row mapping of the per-row kernels of this file: a batch launch gives every wave of a workgroup its own row (kRowsPerBlock
+// rows per workgroup: 62.5k single-wave workgroups were bound by the workgroup launch rate), a single-row launch (the sequential
+// commit loop) puts the whole workgroup on the row.  `lds_per_row`: bytes of dynamic LDS a row's wave owns.
+constexpr int kRowsPerBlock = 4;
+struct RowMap {
+  int64_t pod;
+  int wave, n_waves;
+  uint8_t* lds;
+};
+__device__ __forceinline__ RowMap row_map(const ProfileArgs& a, uint8_t* lds, size_t lds_per_row) {
+  const bool single = a.row_end - a.row_begin == 1;  // uniform
+  const int w = threadIdx.x >> 6;
+  RowMap m;
+  m.pod = single ? a.row_begin : a.row_begin + static_cast<int64_t>(blockIdx.x) * kRowsPerBlock + w;
+  m.wave = single ? w : 0;
+  m.n_waves = single ? static_cast<int>(blockDim.x >> 6) : 1;
+  m.lds = single ? lds : lds + static_cast<size_t>(w) * lds_per_row;
+  return m;
+}
+inline unsigned row_blocks(unsigned rows) { return rows == 1 ? 1u : (rows + kRowsPerBlock - 1) / kRowsPerBlock; }
+inline unsigned row_threads(unsigned rows) { return rows == 1 ? 64u * kMaxRowWaves : 64u * kRowsPerBlock; }
+
+__global__ __launch_bounds__(64 * kMaxRowWaves) void k_alloc_masked(ProfileArgs a, unsigned lds_per_row) {
   SPX_RESOLVE_ROWS(a);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;  // one wave per row, or a workgroup on a single row
-  const int64_t pod = a.row_begin + blockIdx.x;
-  if (pod >= a.row_end) return;
+  extern __shared__ uint8_t feas_all[];  // per row: [tiles][64]
+  const RowMap rm = row_map(a, feas_all, lds_per_row);
+  const int lane = threadIdx.x & 63, wave = rm.wave, n_waves = rm.n_waves;
+  const int64_t pod = rm.pod;
+  if (pod >= a.row_end) return;  // wave-uniform; a batch launch has no workgroup barrier
   const int64_t tiles = (a.row_stride + 64 * kNpl - 1) / (64 * kNpl);
-  extern __shared__ uint8_t feas[];  // [tiles][64]
+  uint8_t* feas = rm.lds;
   if (a.alloc_rel != nullptr && a.alloc_rel[a.row_stride] != 0u && a.row_stride % kNplCompact == 0) {  // wave-uniform
     alloc_masked_compact(a, pod, lane, wave, n_waves, feas);
     return;
@@ -216,9 +240,10 @@ constexpr int kNplBest = 16;
 
 __global__ __launch_bounds__(64 * kMaxRowWaves) void k_best_fast(ProfileArgs a, BestFastArgs f) {
   SPX_RESOLVE_ROWS(a);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-  const int64_t pod = a.row_begin + blockIdx.x;
-  if (pod >= a.row_end) return;
+  const RowMap rm = row_map(a, nullptr, 0);
+  const int lane = threadIdx.x & 63, wave = rm.wave, n_waves = rm.n_waves;
+  const int64_t pod = rm.pod;
+  if (pod >= a.row_end) return;  // wave-uniform
   int best = -1, best_n = -1, ties = 0, feas = 0;
   const bool pod_ok = !a.prefilter || a.prefilter[pod] == 0;
   const int64_t tiles = pod_ok ? (a.n_nodes + 64 * kNplBest - 1) / (64 * kNplBest) : 0;
@@ -298,13 +323,14 @@ __global__ __launch_bounds__(64 * kMaxRowWaves) void k_best_fast(ProfileArgs a, 
 // plugins' bytes from their tables (f: every scoring table of the mask except Allocatable's), the weighted total and the running
 // (best, lowest node, ties) — k_best_fast's rule, a lane walking its nodes in increasing order.  Same bytes, same totals,
 // same decision as spx_eval + spx_eval_best (tests/test_gpu_decide.py compares every row).
-__global__ __launch_bounds__(64 * kMaxRowWaves) void k_decide_masked(ProfileArgs a, BestFastArgs f, int w_alloc) {
+__global__ __launch_bounds__(64 * kMaxRowWaves) void k_decide_masked(ProfileArgs a, BestFastArgs f, int w_alloc, unsigned lds_per_row) {
   SPX_RESOLVE_ROWS(a);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-  const int64_t pod = a.row_begin + blockIdx.x;
-  if (pod >= a.row_end) return;
   extern __shared__ uint8_t feas_bytes[];
-  uint16_t* feas_bits = reinterpret_cast<uint16_t*>(feas_bytes);  // [tiles][64]: the lane's 16 feasibility bits
+  const RowMap rm = row_map(a, feas_bytes, lds_per_row);
+  const int lane = threadIdx.x & 63, wave = rm.wave, n_waves = rm.n_waves;
+  const int64_t pod = rm.pod;
+  if (pod >= a.row_end) return;  // wave-uniform
+  uint16_t* feas_bits = reinterpret_cast<uint16_t*>(rm.lds);  // [tiles][64]: the lane's 16 feasibility bits
   const bool pod_ok = !a.prefilter || a.prefilter[pod] == 0;    // wave-uniform
   const int64_t tiles = pod_ok ? (a.n_nodes + 64 * kNplCompact - 1) / (64 * kNplCompact) : 0;
   const int64_t row = pod * a.row_stride;
@@ -527,7 +553,7 @@ void launch_alloc_masked(const ProfileArgs& a, hipStream_t s) {
   const size_t tiles16 = static_cast<size_t>((a.row_stride + 64 * kNplCompact - 1) / (64 * kNplCompact));
   const size_t lds = tiles4 * 64 > tiles16 * 128 ? tiles4 * 64 : tiles16 * 128;
   const unsigned rows = static_cast<unsigned>(a.row_end - a.row_begin);
-  hipLaunchKernelGGL(k_alloc_masked, dim3(rows), dim3(rows == 1 ? 64 * kMaxRowWaves : 64), lds, s, a);
+  hipLaunchKernelGGL(k_alloc_masked, dim3(row_blocks(rows)), dim3(row_threads(rows)), rows == 1 ? lds : lds * kRowsPerBlock, s, a, static_cast<unsigned>(lds));
 }
 
 bool decide_masked_ok(const ProfileArgs& a) {
@@ -551,8 +577,8 @@ void launch_decide_masked(const ProfileArgs& a, hipStream_t s) {
     }
   const size_t tiles16 = static_cast<size_t>((a.row_stride + 64 * kNplCompact - 1) / (64 * kNplCompact));
   const unsigned rows = static_cast<unsigned>(a.row_end - a.row_begin);
-  hipLaunchKernelGGL(k_decide_masked, dim3(rows), dim3(rows == 1 ? 64 * kMaxRowWaves : 64), tiles16 * 128, s, a, f,
-                     static_cast<int>(a.weight[SPX_PLUGIN_ALLOCATABLE]));
+  hipLaunchKernelGGL(k_decide_masked, dim3(row_blocks(rows)), dim3(row_threads(rows)), tiles16 * 128 * (rows == 1 ? 1 : kRowsPerBlock), s, a, f,
+                     static_cast<int>(a.weight[SPX_PLUGIN_ALLOCATABLE]), static_cast<unsigned>(tiles16 * 128));
 }
 
 void launch_best(const ProfileArgs& a, hipStream_t s) {
@@ -569,7 +595,7 @@ void launch_best(const ProfileArgs& a, hipStream_t s) {
       f.w[f.n_tab++] = static_cast<int32_t>(a.weight[k]);
     }
   if (fast && bound < (int64_t{1} << 31)) {
-    hipLaunchKernelGGL(k_best_fast, dim3(rows), dim3(rows == 1 ? 64 * kMaxRowWaves : 64), 0, s, a, f);
+    hipLaunchKernelGGL(k_best_fast, dim3(row_blocks(rows)), dim3(row_threads(rows)), 0, s, a, f);
     return;
   }
   hipLaunchKernelGGL(k_best, dim3(rows), dim3(rows == 1 ? 64 * kMaxRowWaves : 64), 0, s, a);
