@@ -71,3 +71,38 @@ def test_commit_effects_match_the_per_pod_definition():
         assert np.array_equal(ptr, np.array(want_ptr, np.int32))
         assert np.array_equal(key[:n], np.array([k for k, _ in want], np.int32))
         assert np.array_equal(cost[:n], np.array([c for _, c in want], np.int64))
+
+
+def test_sizing_result_is_reused_once_and_only_for_the_same_tables():
+    """Both flatteners run ONE pass: the sizing call (NULL arrays) leaves its result for the fill call that follows it with the
+    same tables, per calling thread; a fill call for other tables (or a second fill) computes afresh.  Whatever the sequence, the
+    arrays are those of a fresh computation."""
+    hdr, lib = spx.header(), spx.lib()
+    a = synth.network_snapshot(hdr, 40, 300, seed=5)
+    b = synth.network_snapshot(hdr, 40, 300, seed=6)      # same sizes, other contents
+    want_a, want_b = _commit(lib, a["pods"], a["appgroups"]), _commit(lib, b["pods"], b["appgroups"])
+    assert want_a[0] != want_b[0] or not np.array_equal(want_a[2], want_b[2])
+    i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+    def fill(snap, n_alloc):
+        P = snap["pods"].struct.n_pods
+        n = C.c_int64()
+        ptr, key, cost = np.zeros(P + 1, np.int32), np.zeros(max(n_alloc, 1), np.int32), np.zeros(max(n_alloc, 1), np.int64)
+        assert lib.spx_flatten_net_commit(snap["pods"].ref(), snap["appgroups"].ref(), C.byref(n), ptr.ctypes.data_as(i32p),
+                                          key.ctypes.data_as(i32p), cost.ctypes.data_as(i64p)) == 0
+        return n.value, ptr, key, cost
+
+    # size A, then fill B (other tables): B's arrays, not A's leftovers
+    n = C.c_int64()
+    assert lib.spx_flatten_net_commit(a["pods"].ref(), a["appgroups"].ref(), C.byref(n), None, None, None) == 0
+    got = fill(b, max(want_a[0], want_b[0]))
+    assert got[0] == want_b[0] and np.array_equal(got[1], want_b[1]) and np.array_equal(got[2][:got[0]], want_b[2][:got[0]])
+    # two fills in a row without a sizing call in between
+    for _ in range(2):
+        got = fill(a, want_a[0])
+        assert got[0] == want_a[0] and np.array_equal(got[1], want_a[1]) and np.array_equal(got[3][:got[0]], want_a[3][:got[0]])
+    # the keys flattener: the same protocol
+    ka, kb = _keys(lib, a["pods"], a["appgroups"]), _keys(lib, b["pods"], b["appgroups"])
+    nk, npairs = C.c_int32(), C.c_int64()
+    assert lib.spx_flatten_net_keys(a["pods"].ref(), a["appgroups"].ref(), C.byref(nk), C.byref(npairs), None, None, None, None, None, None) == 0
+    assert np.array_equal(_keys(lib, b["pods"], b["appgroups"]), kb) and np.array_equal(_keys(lib, a["pods"], a["appgroups"]), ka)
