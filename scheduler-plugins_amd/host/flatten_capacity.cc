@@ -6,11 +6,13 @@
 //   Σ Used, Σ Min over all quotas                                    elasticquota.go:52-55
 //   per namespace: nominated requests of OTHER namespaces whose quota is not over min   :248-250
 // What stays per pod (the kernel): the same-namespace nominated pods with priority >= the pod's, and cmp2.
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <vector>
 
 #include "../../include/spx.h"
+#include "parallel.hpp"
 
 namespace {
 
@@ -88,14 +90,21 @@ extern "C" int spx_flatten_quota(const spx_pod_objects* pods, const spx_resource
   if (q->n_scalar_slots < 0 || q->n_scalar_slots > S - 4) return SPX_ERR_ARG;
   const int32_t NS = q->n_namespaces;
   static const int64_t zero[S] = {0};
-  for (int64_t p = 0; p < pods->n_pods; ++p) {
-    Vec r;
-    if (!pod_request(pods, q, rc, p, r)) return SPX_ERR_ARG;
-    pod_ns[p] = pods->ns[p];
-    pod_priority[p] = pods->priority[p];
-    std::memcpy(pod_req + p * S, r.v, sizeof r.v);
-    pod_req_present[p] = r.present;
-  }
+  std::atomic<bool> bad{false};
+  spx_host::parallel_rows(pods->n_pods, [&](int64_t row0, int64_t row1) {  // pods are independent (2-3 ms serial for 62.5k)
+    for (int64_t p = row0; p < row1; ++p) {
+      Vec r;
+      if (!pod_request(pods, q, rc, p, r)) {
+        bad = true;
+        return;
+      }
+      pod_ns[p] = pods->ns[p];
+      pod_priority[p] = pods->priority[p];
+      std::memcpy(pod_req + p * S, r.v, sizeof r.v);
+      pod_req_present[p] = r.present;
+    }
+  }, 4096);
+  if (bad) return SPX_ERR_ARG;
   Vec used, mn;
   for (int32_t k = 0; k < NS; ++k) {
     if (!q->has_quota[k]) continue;

@@ -273,14 +273,16 @@ extern "C" int spx_flatten_nrt_pods(const spx_pod_objects* pods, const spx_resou
     return SPX_ERR_ARG;
   const int R = slots->n_res;
   const int64_t P = pods->n_pods;
-  std::memset(ctr_kind, 0, static_cast<size_t>(P) * CM);
-  std::memset(ctr_present, 0, static_cast<size_t>(P) * CM);
-  std::memset(ctr_req, 0, static_cast<size_t>(P) * CM * R * sizeof(int64_t));
-  std::memset(pod_req, 0, static_cast<size_t>(P) * R * sizeof(int64_t));
   std::atomic<int> err{SPX_OK};
   spx_host::parallel_rows(P, [&](int64_t row0, int64_t row1) {
   std::vector<KV> init_res, res;
   for (int64_t i = row0; i < row1; ++i) {
+    // the row's cells are cleared by the thread that fills them, row by row (one serial memset of the 16 MB request column cost
+    // more than the whole parallel fill)
+    std::memset(ctr_kind + i * CM, 0, CM);
+    std::memset(ctr_present + i * CM, 0, CM);
+    std::memset(ctr_req + i * CM * R, 0, static_cast<size_t>(CM) * R * sizeof(int64_t));
+    std::memset(pod_req + i * R, 0, static_cast<size_t>(R) * sizeof(int64_t));
     const int32_t c0 = pods->ctr_ptr[i], c1 = pods->ctr_ptr[i + 1];
     if (c1 - c0 > CM) {
       err = SPX_ERR_ARG;

@@ -175,6 +175,6 @@ extern "C" int spx_flatten_trimaran_pods(const spx_pod_objects* pods, const spx_
     if (lv_req_cpu_milli) lv_req_cpu_milli[i] = cpu;
     if (lv_req_mem) lv_req_mem[i] = mem;
   }
-  });
+  }, 4096);
   return SPX_OK;
 }
