@@ -203,3 +203,16 @@ def test_quantity_rounds_away_from_zero_and_keeps_long_mantissas():
     assert quantity("1.00000000000000000000000", False) == 1
     assert quantity("123456789012345678901234n", False) == 123456789012346   # 1.2345...e14 rounded up
     assert quantity("12345678901234567890123", False) is None          # really out of range
+
+
+def test_is_sidecar_init_container_table(hdr):
+    """pkg/util/sidecar_test.go:27-61 (TestIsSidecarInitContainer) through the pod decoder: an init container is a sidecar exactly
+    when its restartPolicy is "Always" — the zero value and an explicit nil are not (the NRT Filter words its rejection after the
+    kind: filter.go:77-91).  The fourth row is what the API can also carry and the reference treats as not-a-sidecar: a regular
+    container never is one, whatever its restartPolicy says (only initContainers are asked)."""
+    cases = [({}, 1), ({"restartPolicy": None}, 1), ({"name": "init-1", "restartPolicy": "Always"}, 2)]
+    with NrtIngest(["n0"]) as ing:
+        pod = {"spec": {"initContainers": [c for c, _ in cases], "containers": [{"name": "app", "restartPolicy": "Always"}]}}
+        assert ing.feed_pods(json.dumps(pod).encode()) == 1
+        t = ing.pod_objects().struct
+        assert col(t, "ctr_kind", 4) == [k for _, k in cases] + [0]
