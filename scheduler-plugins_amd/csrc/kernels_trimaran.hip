@@ -19,10 +19,13 @@
 #include <cstdlib>
 
 #include "spx_internal.h"
+#include "trimaran_math.h"
 
 namespace spx {
 
 namespace {
+
+using namespace trimath;
 
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
@@ -93,40 +96,6 @@ __global__ __launch_bounds__(1024) void k_alloc_prepare(AllocPrepArgs a) {
   if (a.rel && tid == 0) a.rel[a.row_stride] = static_cast<uint64_t>(range) < (1ull << 32) ? 1u : 0u;
 }
 
-// ------------------------------------------------------------------------------------------------
-// per-node state held in registers
-
-struct TlpNode {
-  double util_millis;  // (util% / 100) * cap   targetloadpacking.go:147
-  double missing;      // float64(missingCPUUtilMillis)
-  double cap;          // float64(Capacity.Cpu().MilliValue())
-  bool valid;          // metrics != nil && cpuMetricFound
-};
-
-__device__ __forceinline__ double tlp_predicted(const TlpNode& n, double pod_milli) {
-  double predicted = 0.0;
-  if (n.cap != 0.0) predicted = 100.0 * ((n.util_millis + pod_milli) + n.missing) / n.cap;  // :170-173
-  return predicted;
-}
-
-// float64 value the reference rounds; *zero is set when the reference returns MinNodeScore outright
-__device__ __forceinline__ double tlp_unrounded(const TlpNode& n, double pod_milli, double t, bool* zero) {
-  *zero = false;
-  if (!n.valid) {
-    *zero = true;
-    return 0.0;
-  }
-  const double predicted = tlp_predicted(n, pod_milli);
-  if (predicted > t) {  // :174-181
-    if (predicted > 100.0) {
-      *zero = true;
-      return 0.0;
-    }
-    return t * (100.0 - predicted) / (100.0 - t);
-  }
-  return (100.0 - t) * predicted / t + t;  // :183-184
-}
-
 // LVRB per resource: state 0 = metric type absent (CreateResourceStats !ok), 1 = capacity <= 0
 // (computeScore returns 0), 2 = regular
 struct LvRes {
@@ -193,13 +162,6 @@ __device__ __forceinline__ double lv_total(bool has_metrics, const LvRes& c, con
 }
 
 constexpr double kMega = 1.0 / 1024.0 / 1024.0;  // resourcestats.go:29
-
-__device__ __forceinline__ uint32_t to_u8(double unrounded) {
-  // int64(math.Round(x)) then saturate into the uint8 table cell
-  int v = static_cast<int>(round(unrounded));
-  v = v < 0 ? 0 : (v > 255 ? 255 : v);
-  return static_cast<uint32_t>(v);
-}
 
 typedef float F32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -330,8 +292,6 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_trimaran(TrimaranArgs
 // provably the exact result; the others ("ambiguous", ~8e-5 of cells on continuous inputs) are
 // recomputed per cell with the reference's exact float64 sequence from the node's original columns.
 // The 64 pod records of a chunk are fetched with one coalesced load and broadcast with v_readlane.
-constexpr float kTol32 = 4e-5f;
-constexpr float kTolU = 1e-6f;
 
 // node slot n of a sweep kernel with NPL nodes per lane -> index of its record in the tile-transposed constant tables
 // ([tile][j][lane]: for a fixed j the 64 lanes of a wavefront read consecutive records)
@@ -414,12 +374,7 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
 }
 
 // one cell through the reference's float64 sequence, from the original node columns (the fast sweep's rare path)
-#ifdef SPX_TLP_OUTLINE
-__device__ __noinline__
-#else
-__device__ __forceinline__
-#endif
-uint32_t tlp_cell_exact(const TrimaranArgs& a, int64_t n, double pod_milli) {
+__device__ __forceinline__ uint32_t tlp_cell_exact(const TrimaranArgs& a, int64_t n, double pod_milli) {
   TlpNode tn;
   tn.cap = static_cast<double>(a.cap_cpu_milli[n]);
   tn.util_millis = (a.tlp_cpu_util[n] / 100.0) * tn.cap;
@@ -430,19 +385,8 @@ uint32_t tlp_cell_exact(const TrimaranArgs& a, int64_t n, double pod_milli) {
   return zero ? 0u : to_u8(x);
 }
 
-#ifndef SPX_TLP_LB
-#define SPX_TLP_LB 0
-#endif
 template <int NPL, bool A, bool D = false>
-__global__
-#if SPX_TLP_LB
-__launch_bounds__(kWave* kWavesPerBlock, D ? 2 : SPX_TLP_LB)
-#elif defined(SPX_TLP_ROWBLOCK)
-__launch_bounds__(704)  // experiment (tools/r3): a block = the waves of ONE chunk's full row width (n_tiles <= 11)
-#else
-__launch_bounds__(kWave* kWavesPerBlock)
-#endif
-void k_tlp_fast2(TrimaranArgs a, int n_tiles, double c1, double c2, DecideArgs dec) {
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArgs a, int n_tiles, double c1, double c2, DecideArgs dec) {
   SPX_RESOLVE_ROWS(a);
   static_assert(kPodsPerChunk == kWave, "one pod record per lane");
   const int lane = threadIdx.x & (kWave - 1);
@@ -550,9 +494,7 @@ void k_tlp_fast2(TrimaranArgs a, int n_tiles, double c1, double c2, DecideArgs d
           const int64_t n = node0 + i;
           uint32_t b = 0;
           if (n < a.n_nodes) {
-#ifndef SPX_TLP_NOSTATS
             ++reevaluated;
-#endif
             b = tlp_cell_exact(a, n, pod_milli);
           }
           const int sh = (i & 3) * 8;
@@ -606,9 +548,7 @@ void k_tlp_fast2(TrimaranArgs a, int n_tiles, double c1, double c2, DecideArgs d
       }
     }
   }
-#ifndef SPX_TLP_NOSTATS
   flush_stats(a.stats, SPX_PLUGIN_TLP, reevaluated, unit);
-#endif
 }
 
 // merges the per-tile triples of the decisions-only sweep into the layout spx_fetch_best reads
@@ -817,254 +757,6 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
   flush_stats(a.stats, SPX_PLUGIN_LVRB, reevaluated, unit);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Sequential commit loop for the Filter-less profile (Allocatable + TargetLoadPacking + LoadVariationRiskBalancing),
-// SURVEY.md section 8f rank 1.  Upstream schedules one pod at a time: Score every node, pick the best, bind; the bound
-// pod enters trimaran's ScheduledPodsCache (handler.go:131-139) and from then on adds its predicted CPU utilisation to
-// that node's "missing utilisation" (targetloadpacking.go:151-168) until the metrics catch up.  So pod i+1's row
-// differs from what a frozen snapshot says in exactly one node — but which one depends on pod i's decision: the chain
-// is inherently sequential.  One workgroup keeps the chain on the device: per pod, 1024 threads evaluate the row with
-// the reference's float64 arithmetic against the current missing[] column, a block-wide argmax picks the node (lowest
-// index among ties; upstream draws one of them at random), and the winner's missing utilisation is bumped.
-// No table is read or written; the per-pod decisions are the output.
-// float32 constants of one node for the TLP fast formula (same derivation as k_tlp_prepare_fast / k_tlp_fast2):
-// (b2h, b2l, coefficient for u > 0, coefficient for u <= 0); NaN b2h = always the exact path
-__device__ __forceinline__ float4 tlp_fast_consts(double cap, double util_pct, double missing, bool valid, double t, double c1, double c2) {
-  double b = 1e30;
-  float f1 = -1.0f, f2 = 0.0f;
-  bool split = false;
-  if (valid) {
-    const double um = (util_pct / 100.0) * cap;
-    if (cap == 0.0) {
-      b = 1.0;
-      f1 = 0.0f;
-    } else if (!(um >= 0.0) || !(missing >= 0.0) || !(cap > 0.0) || !(um < 1e15) || !(missing < 1e15)) {
-      b = __builtin_nan("");
-    } else {
-      const double k = 100.0 / cap;
-      b = (um + missing) - t * cap / 100.0;
-      f1 = static_cast<float>(-c1 * k);
-      f2 = static_cast<float>(c2 * k);
-      split = __builtin_fabs(b) < 8388607.0;
-      if (!split) b = __builtin_nan("");
-    }
-  }
-  const double bh = split ? __builtin_rint(b) : b;
-  return float4{static_cast<float>(bh), split ? static_cast<float>(b - bh) : 0.0f, f1, f2};
-}
-
-// K > 0: every thread keeps its K nodes' TLP fast constants in registers for the whole loop (n_nodes <= kCommitThreads * K;
-// 512 threads = 2 waves per SIMD): per cell the float32 formula of k_tlp_fast2 with the same ambiguity test, ambiguous
-// cells and out-of-range pods re-evaluated with the reference's float64 sequence against the missing[] column in memory,
-// which the winner's owner advances (and whose constants it rebuilds) after every commit.
-// K == 0: float64 throughout, state re-read from global memory per pod (any size, 1024 threads).
-template <int K, int kCommitThreads, bool kHasL, bool kTies>
-__global__ __launch_bounds__(kCommitThreads) void k_commit_trimaran(CommitArgs c) {
-  __shared__ int64_t s_best[kCommitThreads / kWave];
-  __shared__ int s_node[kCommitThreads / kWave];
-  __shared__ int s_ties[kCommitThreads / kWave];
-  __shared__ uint32_t s_key[2][kCommitThreads / kWave];
-  __shared__ int s_tie[2];
-  const TrimaranArgs& a = c.t;
-  const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1), wave = tid >> 6;
-  const bool A = c.use_mask & 1u, T = c.use_mask & 2u, L = kHasL && (c.use_mask & 4u);
-  constexpr int KR = K > 0 ? K : 1;
-  static_assert(K % 4 == 0, "K > 0: cells come in groups of 4 consecutive nodes (one dword of a uint8 table row)");
-  // cell k of a thread = node ((k / 4) * kCommitThreads + tid) * 4 + k % 4
-  auto node_of = [&](int k) -> int64_t { return (static_cast<int64_t>(k >> 2) * kCommitThreads + tid) * 4 + (k & 3); };
-  if (tid < 2) s_tie[tid] = 0;
-  __syncthreads();
-  const double t = a.tlp_target;
-  const double c1 = t / (100.0 - t), c2 = (100.0 - t) / t;
-  const bool fast_ok = t >= 1.0 && t <= 99.0;
-  float4 r_k[KR];        // (b2h, b2l, kc1, kc2)
-  uint32_t r_flags[KR];  // bit 1: node exists, bits 8..: w_alloc * Allocatable's normalised score
-  if constexpr (K > 0) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int64_t n = node_of(k);
-      const bool in = n < a.n_nodes;
-      r_k[k] = (in && T) ? tlp_fast_consts(static_cast<double>(a.cap_cpu_milli[n]), a.tlp_cpu_util[n], static_cast<double>(c.missing[n]),
-                                           a.tlp_valid[n] != 0, t, c1, c2)
-                         : float4{1e30f, 0.0f, -1.0f, 0.0f};
-      if (!fast_ok) r_k[k].x = __builtin_nanf("");
-      r_flags[k] = (in ? 2u : 0u) | ((in && A) ? (static_cast<uint32_t>(c.w_alloc) * a.alloc_norm[n]) << 8 : 0u);
-    }
-  }
-  constexpr float kHalf = 0.5f - kTol32;
-  const float tf = static_cast<float>(t);
-  uint32_t lv_next[KR / 4 > 0 ? KR / 4 : 1] = {};
-  if constexpr (K > 0 && kHasL) {
-#pragma unroll
-    for (int g = 0; g < K / 4; ++g) {
-      const int64_t n0 = (static_cast<int64_t>(g) * kCommitThreads + tid) * 4;
-      lv_next[g] = (n0 < a.row_stride && a.row_begin < a.row_end) ? *reinterpret_cast<const uint32_t*>(c.lv_table + a.row_begin * a.row_stride + n0) : 0u;
-    }
-  }
-  for (int64_t pod = a.row_begin; pod < a.row_end; ++pod) {
-    const int64_t pod_i = T ? a.tlp_pod_milli[pod] : 0;
-    const double pod_milli = static_cast<double>(pod_i);
-    const bool pod_bad = pod_i < 0 || pod_i >= (1 << 23);  // not exact as a float32 integer: exact path for the row
-    const float pod_f = static_cast<float>(pod_i);
-    int64_t best = INT64_MIN;
-    int best_n = INT32_MAX, ties = 0;
-    auto exact_tlp = [&](int64_t n) -> uint32_t {
-      TlpNode tn;
-      tn.cap = static_cast<double>(a.cap_cpu_milli[n]);
-      tn.util_millis = (a.tlp_cpu_util[n] / 100.0) * tn.cap;
-      tn.missing = static_cast<double>(c.missing[n]);
-      tn.valid = a.tlp_valid[n] != 0;
-      bool zero;
-      const double x = tlp_unrounded(tn, pod_milli, t, &zero);
-      return zero ? 0u : to_u8(x);
-    };
-    auto consider = [&](int64_t n, uint32_t tlp_byte, uint32_t alloc_byte) {
-      int64_t total = 0;
-      if (A) total += c.w_alloc * static_cast<int64_t>(alloc_byte);
-      if (T) total += c.w_tlp * static_cast<int64_t>(tlp_byte);
-      if (L) total += c.w_lvrb * static_cast<int64_t>(c.lv_table[pod * a.row_stride + n]);
-      if (total > best) {  // a thread walks its nodes in increasing order: `>` keeps the lowest index among equals
-        best = total;
-        best_n = static_cast<int>(n);
-        ties = 1;
-      } else if (total == best) {
-        ++ties;
-      }
-    };
-    uint32_t kmax = 0, btot = 0;  // K > 0: best key (total << 14 | 16383 - node) and the total it carries
-    if constexpr (K > 0) {
-      // totals fit 18 bits here (launch condition): 32-bit arithmetic, Allocatable's share folded into a per-node base;
-      // ambiguous cells (and every cell of a pod that is not a float32 integer) take the reference's float64 sequence
-      const uint32_t wt = static_cast<uint32_t>(c.w_tlp), wl = static_cast<uint32_t>(c.w_lvrb);
-      // LVRB carries no commit state: its frozen-snapshot rows (evaluated by the sweep just before this loop) stay valid.
-      // One dword per group of 4 nodes; the next pod's dwords are requested now and used in the next iteration, so the
-      // HBM latency of a row that no cache holds yet is off the dependent chain.
-      uint32_t lv_now[KR / 4 > 0 ? KR / 4 : 1];
-      if constexpr (kHasL) {
-#pragma unroll
-        for (int g = 0; g < K / 4; ++g) {
-          lv_now[g] = lv_next[g];
-          const int64_t n0 = (static_cast<int64_t>(g) * kCommitThreads + tid) * 4;
-          const int64_t np = pod + 1 < a.row_end ? pod + 1 : pod;
-          lv_next[g] = n0 < a.row_stride ? *reinterpret_cast<const uint32_t*>(c.lv_table + np * a.row_stride + n0) : 0u;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const int64_t n = node_of(k);
-        if (!(r_flags[k] & 2u)) continue;
-        uint32_t tot = r_flags[k] >> 8;  // w_alloc * Allocatable's normalised score
-        if (T) {
-          const float u = (pod_f + r_k[k].x) + r_k[k].y;
-          const bool gt = __float_as_int(u) > 0;
-          const float x = __builtin_fmaf(gt ? r_k[k].z : r_k[k].w, u, gt ? tf : 100.0f);
-          const float rr = __builtin_rintf(x);
-          const bool amb = pod_bad || !(__builtin_fabsf(x - rr) < kHalf) || !(__builtin_fabsf(u) > kTolU);
-          const uint32_t tb = amb ? exact_tlp(n) : (__builtin_amdgcn_cvt_pk_u8_f32(rr, 0, 0u) & 0xffu);
-          tot += wt * tb;
-        }
-        if constexpr (kHasL) tot += wl * ((lv_now[k >> 2] >> (8 * (k & 3))) & 0xffu);
-        const uint32_t key = (tot << 14) | (16383u - static_cast<uint32_t>(n));
-        kmax = key > kmax ? key : kmax;
-        if constexpr (kTies) {
-          ties = tot > btot ? 1 : (tot == btot ? ties + 1 : ties);
-          btot = tot > btot ? tot : btot;
-        }
-      }
-    } else {
-      for (int64_t n = tid; n < a.n_nodes; n += kCommitThreads) consider(n, T ? exact_tlp(n) : 0u, A ? a.alloc_norm[n] : 0u);
-    }
-    if constexpr (K > 0) {
-      // One 32-bit key per thread orders (total descending, node ascending): key = total << 14 | (16383 - node); the launch
-      // picks this variant only when every total fits 18 bits and n_nodes <= 16384.  One butterfly, one barrier: every
-      // thread then reduces the per-wave keys itself (double-buffered by pod parity), so no second barrier is needed to
-      // broadcast the winner.
-      uint32_t key = kmax;
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) {
-        const uint32_t o = static_cast<uint32_t>(__shfl_xor(static_cast<int>(key), m, 64));
-        key = o > key ? o : key;
-      }
-      const int par = static_cast<int>(pod & 1);
-      if (lane == 0) s_key[par][wave] = key;
-      __syncthreads();
-      uint32_t gkey = 0;
-#pragma unroll
-      for (int w = 0; w < kCommitThreads / kWave; ++w) gkey = s_key[par][w] > gkey ? s_key[par][w] : gkey;
-      const bool any = gkey != 0;
-      const int win = any ? static_cast<int>(16383u - (gkey & 16383u)) : -1;
-      const int64_t gbest = static_cast<int64_t>(gkey >> 14);
-      if constexpr (kTies) {
-        if (any && kmax != 0 && static_cast<int64_t>(btot) == gbest) atomicAdd(&s_tie[par], ties);
-      }
-      if (tid == 0) {
-        c.out_node[pod - a.row_begin] = win;
-        c.out_score[pod - a.row_begin] = any ? gbest : 0;
-        // tie counters run one iteration late: the previous pod's adds all happened before this iteration's barrier
-        if (c.out_ties && pod > a.row_begin) c.out_ties[pod - 1 - a.row_begin] = s_tie[par ^ 1];
-        s_tie[par ^ 1] = 0;
-      }
-      // the winner's owner advances the column (only it ever reads that entry again) and shifts the node's constants: the
-      // real number b2h + b2l grows by exactly the pod's integer millicores, which tracks the float64 b within ~1e-10
-      if (T && win >= 0 && ((win >> 2) % kCommitThreads) == tid) {
-        c.missing[win] += pod_i;
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-          if (((win >> 2) / kCommitThreads) * 4 + (win & 3) == k) {
-            const float nb = r_k[k].x + pod_f;
-            r_k[k].x = (pod_bad || !(__builtin_fabsf(nb) < 8388607.0f)) ? __builtin_nanf("") : nb;
-          }
-      }
-    } else {
-      // wave-level then block-level argmax (every lane is live: no divergence around the shuffles)
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) {
-        const int64_t ob = shfl_xor_i64(best, m);
-        const int on = __shfl_xor(best_n, m, 64);
-        const int ot = __shfl_xor(ties, m, 64);
-        if (ob > best || (ob == best && on < best_n)) {
-          ties = ob > best ? ot : ties + ot;
-          best = ob;
-          best_n = on;
-        } else if (ob == best) {
-          ties += ot;
-        }
-      }
-      if (lane == 0) {
-        s_best[wave] = best;
-        s_node[wave] = best_n;
-        s_ties[wave] = ties;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        for (int w = 1; w < kCommitThreads / kWave; ++w) {
-          if (s_best[w] > best || (s_best[w] == best && s_node[w] < best_n)) {
-            ties = s_best[w] > best ? s_ties[w] : ties + s_ties[w];
-            best = s_best[w];
-            best_n = s_node[w];
-          } else if (s_best[w] == best) {
-            ties += s_ties[w];
-          }
-        }
-        const bool any = best_n != INT32_MAX;
-        c.out_node[pod - a.row_begin] = any ? best_n : -1;
-        c.out_score[pod - a.row_begin] = any ? best : 0;
-        if (c.out_ties) c.out_ties[pod - a.row_begin] = any ? ties : 0;
-        if (any && T) {
-          c.missing[best_n] += pod_i;  // the bound pod's predicted utilisation, from now on
-          __threadfence_block();
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if constexpr (K > 0) {  // the last pod's tie count (counters are read one iteration late)
-    __syncthreads();
-    if (tid == 0 && c.out_ties && a.row_end > a.row_begin) c.out_ties[a.row_end - 1 - a.row_begin] = s_tie[static_cast<int>((a.row_end - 1) & 1)];
-  }
-}
-
 // raw int64 Score() of one row (parity harness / direct-call tests); one thread per node
 __global__ void k_trimaran_raw(TrimaranArgs a, int plugin, int64_t pod, int64_t* out) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1135,13 +827,6 @@ void launch_tlp_fast(const TrimaranArgs& a, hipStream_t s) {
   const double c1 = t / (100.0 - t), c2 = (100.0 - t) / t;
   const int64_t n_slots = static_cast<int64_t>(n_tiles) * tile_nodes;
   hipLaunchKernelGGL(k_tlp_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots, c1, c2);
-#ifdef SPX_TLP_ROWBLOCK
-  if (n_tiles <= 11) {  // experiment: one block per chunk, its waves side by side across the row
-    if (a.out_alloc) hipLaunchKernelGGL((k_tlp_fast2<NPL, true>), dim3(static_cast<unsigned>(chunks)), dim3(kWave * n_tiles), 0, s, a, n_tiles, c1, c2, DecideArgs{});
-    else hipLaunchKernelGGL((k_tlp_fast2<NPL, false>), dim3(static_cast<unsigned>(chunks)), dim3(kWave * n_tiles), 0, s, a, n_tiles, c1, c2, DecideArgs{});
-    return;
-  }
-#endif
   if (a.out_alloc)
     hipLaunchKernelGGL((k_tlp_fast2<NPL, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, DecideArgs{});
   else
@@ -1224,21 +909,6 @@ void launch_decide_trimaran(const DecideLaunch& d, hipStream_t s) {
     hipLaunchKernelGGL((k_tlp_fast2<NPL, false, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, dec);
   hipLaunchKernelGGL(k_decide_reduce, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0, s, dec, n_tiles, a.row_begin, a.n_nodes,
                      d.best_score, d.best_node, d.best_ties, d.best_feasible);
-}
-
-void launch_commit_trimaran(const CommitArgs& c, hipStream_t s) {
-  if (c.t.row_end <= c.t.row_begin) return;
-  const bool from_memory = (c.t.opts & kOptCommitFromMemory) != 0;  // SPX_OPT_COMMIT_FROM_MEMORY
-  const bool key_fits = c.w_alloc >= 0 && c.w_tlp >= 0 && c.w_lvrb >= 0 && (c.w_alloc + c.w_tlp + c.w_lvrb) * 255 < (int64_t{1} << 18);
-  if (!from_memory && key_fits && c.t.n_nodes <= 20 * 512) {
-    const bool l = (c.use_mask & 4u) != 0, ties = c.out_ties != nullptr;
-    if (l && ties) hipLaunchKernelGGL((k_commit_trimaran<20, 512, true, true>), dim3(1), dim3(512), 0, s, c);
-    else if (l) hipLaunchKernelGGL((k_commit_trimaran<20, 512, true, false>), dim3(1), dim3(512), 0, s, c);
-    else if (ties) hipLaunchKernelGGL((k_commit_trimaran<20, 512, false, true>), dim3(1), dim3(512), 0, s, c);
-    else hipLaunchKernelGGL((k_commit_trimaran<20, 512, false, false>), dim3(1), dim3(512), 0, s, c);
-  } else {
-    hipLaunchKernelGGL((k_commit_trimaran<0, 1024, true, true>), dim3(1), dim3(1024), 0, s, c);
-  }
 }
 
 void launch_trimaran_raw(const TrimaranArgs& a, int plugin, int64_t pod_row, int64_t* out, hipStream_t s) {

@@ -168,6 +168,54 @@ def test_lvrb_float32_formula_never_disagrees_unflagged():
     assert amb.mean() < 0.02
 
 
+def test_commit_loop_cell_arrangement_never_disagrees_unflagged():
+    """numpy model of tlp_cell32 (kernels_commit_trimaran.hip) — the same real number as k_tlp_fast2's cell, arranged for the issue
+    rates: branch picked on u's sign bit, coefficients and offsets scaled by 1/256 so that the fma's clamp modifier bounds the score
+    to [0, 256], rounding by adding 1.5 * 2^23 — against the reference's float64 sequence (targetloadpacking.go:170-184)"""
+    rng = np.random.default_rng(14)
+    n = 4_000_000
+    t = 40.0
+    c1, c2 = t / (100.0 - t), (100.0 - t) / t
+    cap = rng.choice(np.array([2000, 8000, 16000, 64000, 128000], dtype=np.float64), n)
+    util = np.where(rng.random(n) < 0.3, rng.integers(0, 100, n).astype(np.float64), rng.uniform(0, 100, n))
+    missing = np.where(rng.random(n) < 0.5, 0.0, rng.integers(0, 4000, n).astype(np.float64))
+    pod = rng.integers(0, 12000, n).astype(np.float64)
+    on_line = rng.random(n) < 0.05
+    pod = np.where(on_line, np.floor(np.maximum(t * cap / 100.0 - (util / 100.0) * cap - missing, 0.0)), pod)
+    overload = rng.random(n) < 0.1   # far beyond capacity: the unclamped value is very negative
+    pod = np.where(overload, pod + 3 * cap, pod)
+    um = (util / 100.0) * cap
+    pred = 100.0 * ((um + pod) + missing) / cap
+    x = np.where(pred > t, t * (100.0 - pred) / (100.0 - t), (100.0 - t) * pred / t + t)
+    want = np.where(pred > 100.0, 0, np.floor(np.abs(x) + 0.5) * np.sign(x)).astype(np.int64)
+    want = np.clip(want, 0, 255)
+    k = 100.0 / cap
+    b = (um + missing) - t * cap / 100.0
+    bh = np.rint(b)
+    b2h, b2l = _f32(bh), _f32(b - bh)
+    s256 = np.float32(1.0 / 256.0)
+    kc1, kc2 = _f32(-c1 * k) * s256, _f32(c2 * k) * s256   # the prologue scales the float32 constants (exact: a power of two)
+    assert np.array_equal(kc1.astype(np.float64) * 256.0, _f32(-c1 * k).astype(np.float64))
+    tfs, hs = np.float32(t) * s256, np.float32(100.0) / np.float32(256.0)
+    u = (_f32(pod) + b2h) + b2l
+    neg = np.signbit(u)
+    coef, off = np.where(neg, kc2, kc1), np.where(neg, hs, tfs)
+    xs = _f32(coef.astype(np.float64) * u.astype(np.float64) + off.astype(np.float64))
+    xs = np.clip(xs, np.float32(0), np.float32(1))
+    magic = np.float32(12582912.0)
+    y = _f32(xs.astype(np.float64) * 256.0 + np.float64(magic))
+    rr = y - magic
+    d = np.abs(_f32(xs.astype(np.float64) * 256.0 - rr.astype(np.float64)))
+    tb = y.view(np.uint32) & np.uint32(0x1ff)
+    assert np.array_equal(tb.astype(np.float32), rr)
+    amb = ~(d < np.float32(0.5) - np.float32(4e-5)) | ~(np.abs(u) > np.float32(1e-6))
+    got = tb.astype(np.int64)
+    bad = (~amb) & (got != want)
+    assert not bad.any(), (int(bad.sum()), np.flatnonzero(bad)[:5])
+    cont = ~on_line & (util != np.floor(util))
+    assert amb[cont].mean() < 5e-4
+
+
 def test_commit_loop_incremental_constant_tracks_the_float64_value():
     """k_commit_trimaran shifts a node's b2h by each bound pod's integer millicores instead of rebuilding b from the
     float64 columns: the represented real number b2h + b2l must stay within ~1e-9 of the rebuilt b (far inside the 4e-5
