@@ -715,7 +715,11 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *                              list of cells left to the complete subset search (default 375; 4 bytes per entry).  A list that
  *                              overflows sends the launch back to the complete sweep: same table, slower
  *   SPX_OPT_PEAKS_POD_CLASSES  1 (default) = a whole-batch Peaks sweep with no Filter table in play evaluates one row per distinct
- *                              pod cpu request (all Peaks.Score reads of the pod, peaks.go:134-138) and copies it; 0 = every row */
+ *                              pod cpu request (all Peaks.Score reads of the pod, peaks.go:134-138) and copies it; 0 = every row
+ *   SPX_OPT_COMMIT_COOP        1 (default) = spx_commit_sequential with Filter plugins in the mask runs as ONE cooperative persistent launch
+ *                              (node state in registers, two granule exchanges per pod) when the profile fits it; 0 = always the per-pod
+ *                              single-row launches replayed from a graph
+ */
 #define SPX_OPT_ROW_ALIGN 0
 #define SPX_OPT_REFERENCE_KERNELS 1
 #define SPX_OPT_LROC_FLOAT64 2
@@ -726,7 +730,8 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
 #define SPX_OPT_NRT_POD_CLASSES 7
 #define SPX_OPT_PEAKS_POD_CLASSES 8
 #define SPX_OPT_NRT_LN_LIST_PERMILLE 9
-#define SPX_NUM_OPTIONS 10
+#define SPX_OPT_COMMIT_COOP 10
+#define SPX_NUM_OPTIONS 11
 int spx_set_option(spx_engine* e, int option, int64_t value);
 int spx_get_option(const spx_engine* e, int option, int64_t* value);
 
@@ -739,6 +744,10 @@ int spx_nrt_pod_classes(const spx_engine* e, int64_t* n_unique, int64_t* n_copie
  * peaks.go:134 (GetResourceRequestQuantity) — so pods that request the same amount get the same raw row, and, when no Filter plugin
  * or feasibility mask narrows a pod's node list, the same NormalizeScore (peaks.go:150-166). */
 int spx_peaks_pod_classes(const spx_engine* e, int64_t* n_unique, int64_t* n_copies);
+
+/* Which form the last spx_commit_sequential ran: 1 = the one-workgroup chain of the Filter-less profile, 2 = per-pod single-row
+ * launches (replayed from a graph), 3 = the cooperative persistent kernel; 0 = none yet */
+int spx_commit_path(const spx_engine* e);
 
 /* which formulation of a plugin's sweep the uploaded tables select: 0 = generic (reference arithmetic, operation for
  * operation), 1 = fast formulation (same results; see DESIGN.md for each kernel's preconditions); <0 on error.

@@ -53,7 +53,7 @@ struct spx_engine {
   int64_t row_stride = 0;
 
   // spx_set_option state (per engine; nothing is read from the environment)
-  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375};
+  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1};
 
   // params
   int32_t alloc_mode = SPX_MODE_LEAST;
@@ -159,6 +159,8 @@ struct spx_engine {
   bool net_commit = false, net_dyn_active = false;
   int32_t net_n_keys = 0;
   DevBuf d_commit_save;  // backup of every table the commit loop mutates
+  DevBuf d_coop_sync, d_coop_node, d_coop_max;  // cooperative commit kernel: granules + error flag, the workgroups' private pair lists
+  int last_commit_path = 0;  // what the last spx_commit_sequential ran: 1 one-workgroup trimaran chain, 2 per-pod launches, 3 cooperative kernel
   DevBuf d_row_counter;  // int64: the row the replayed per-pod graph works on
   const int64_t* row_indirect = nullptr;  // non-NULL while that graph is captured: sweeps read their row from the device
 
@@ -579,7 +581,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_q_has, &e->d_q_used, &e->d_q_max, &e->d_q_maxp, &e->d_q_other, &e->d_q_otherp, &e->d_q_nom_ptr,
                     &e->d_q_nom_prio, &e->d_q_nom_idx, &e->d_q_nom_req, &e->d_q_nom_reqp, &e->d_q_status, &e->d_ext_status,
                     &e->d_q_usedp, &e->d_q_min, &e->d_q_minp, &e->d_q_agg, &e->d_net_eff_ptr, &e->d_net_eff_key, &e->d_net_eff_cost, &e->d_net_dyn_ptr,
-                    &e->d_net_dyn_end, &e->d_net_dyn_node, &e->d_net_dyn_max, &e->d_commit_save, &e->d_row_counter,
+                    &e->d_net_dyn_end, &e->d_net_dyn_node, &e->d_net_dyn_max, &e->d_commit_save, &e->d_row_counter, &e->d_coop_sync, &e->d_coop_node, &e->d_coop_max,
                     &e->d_sort_prio, &e->d_sort_ts, &e->d_sort_group, &e->d_sort_topo, &e->d_sort_scratch,
                     &e->d_best, &e->d_stats, &e->d_decide, &e->d_lroc_nreq_c, &e->d_lroc_nreq_m, &e->d_lroc_nlim_c, &e->d_lroc_nlim_m,
                     &e->d_lroc_preq_c, &e->d_lroc_preq_m, &e->d_lroc_plim_c, &e->d_lroc_plim_m, &e->d_lroc_tab, &e->d_lroc_podf,
@@ -631,6 +633,7 @@ int spx_set_option(spx_engine* e, int option, int64_t value) {
     case SPX_OPT_COMMIT_FROM_MEMORY:
     case SPX_OPT_NRT_POD_CLASSES:
     case SPX_OPT_PEAKS_POD_CLASSES:
+    case SPX_OPT_COMMIT_COOP:
       if (value != 0 && value != 1) return fail(e, SPX_ERR_ARG, "option takes 0 or 1");
       break;
     case SPX_OPT_NRT_LN_LIST_PERMILLE:
@@ -2053,6 +2056,138 @@ int spx_upload_net_commit(spx_engine* e, const spx_net_commit_soa* t) {
 
 namespace {
 
+// The sequential commit of a profile with Filter plugins as one cooperative persistent launch (kernels_commit_coop.hip).  *ran stays
+// false when the profile does not fit the kernel (strategy, sizes, weights, forced reference kernels, SPX_OPT_COMMIT_COOP 0): the
+// caller then runs the per-pod loop.  `dyn_ptr`: the workload pair lists' starts in the layout with slack (built by the caller).
+int commit_coop(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row_end, const std::vector<int32_t>& dyn_ptr, int32_t* node_idx,
+                int64_t* weighted_score, int32_t* n_ties, int64_t* tlp_missing_out, bool* ran) {
+  *ran = false;
+  const bool A = plugin_mask & (1u << SPX_PLUGIN_ALLOCATABLE), T = plugin_mask & (1u << SPX_PLUGIN_TLP), Lv = plugin_mask & (1u << SPX_PLUGIN_LVRB);
+  const bool N = plugin_mask & (1u << SPX_PLUGIN_NRT), W = plugin_mask & (1u << SPX_PLUGIN_NETOVERHEAD), Q = plugin_mask & (1u << SPX_PLUGIN_CAPACITY);
+  if (!e->option[SPX_OPT_COMMIT_COOP] || e->option[SPX_OPT_COMMIT_FROM_MEMORY]) return SPX_OK;
+  for (int p : {SPX_PLUGIN_TLP, SPX_PLUGIN_LVRB, SPX_PLUGIN_NRT, SPX_PLUGIN_NETOVERHEAD})
+    if (((plugin_mask >> p) & 1u) && forced_reference(e, p)) return SPX_OK;
+  const int64_t n_wg = (e->n_nodes + spx::kCoopWindow - 1) / spx::kCoopWindow;
+  if (n_wg > spx::kCoopMaxWg) return SPX_OK;
+  int64_t bound = 0;
+  for (int k = 0; k <= SPX_PLUGIN_NETOVERHEAD; ++k)
+    if ((plugin_mask >> k) & 1u) {
+      if (e->plugin_weight[k] < 0 || e->plugin_weight[k] >= (int64_t{1} << 23)) return SPX_OK;
+      bound += e->plugin_weight[k] * 255;
+    }
+  if (bound >= (int64_t{1} << 31)) return SPX_OK;
+  int rc;
+  if (A) {
+    if ((rc = prepare_alloc(e))) return rc;
+    if (!e->alloc_compact) return SPX_OK;
+  }
+  if (N) {
+    const bool fast = e->nrt_fast_slots && e->nrt_fast_nodes && e->nrt_fast_pods;
+    if (!fast || e->nrt_n_res > 4 || (e->nrt_params.strategy != SPX_NRT_LEAST_ALLOCATED && e->nrt_params.strategy != SPX_NRT_MOST_ALLOCATED)) return SPX_OK;
+  }
+  if (W) {
+    if (e->net_n_classes <= 0 || e->net_n_classes > spx::kCoopMaxClasses || e->net_n_keys <= 0) return SPX_OK;
+    for (size_t k = 0; k + 1 < dyn_ptr.size(); ++k)
+      if (dyn_ptr[k + 1] - dyn_ptr[k] > spx::kCoopMaxPairs) return SPX_OK;
+    for (int64_t i = row_begin; i < row_end; ++i)
+      if (e->h_eff_ptr[static_cast<size_t>(i) + 1] - e->h_eff_ptr[static_cast<size_t>(i)] > spx::kCoopMaxEffects) return SPX_OK;
+  }
+  const size_t P = static_cast<size_t>(e->n_pods), Nn = static_cast<size_t>(e->n_nodes);
+  spx::CoopArgs c{};
+  c.use = plugin_mask;
+  for (int k = 0; k < SPX_NUM_PLUGINS; ++k) c.w[k] = static_cast<int32_t>(e->plugin_weight[k]);
+  c.n_nodes = e->n_nodes, c.n_pods = e->n_pods, c.row_stride = e->row_stride, c.row_begin = row_begin, c.row_end = row_end;
+  c.n_wg = static_cast<int32_t>(n_wg);
+  c.nrt_sg = e->nrt_params.strategy == SPX_NRT_MOST_ALLOCATED ? 1 : 0;
+  c.alloc_rel = static_cast<const uint32_t*>(e->d_alloc_rel.p);
+  fill_trimaran(e, c.t);
+  if (N) fill_nrt(e, c.nrt);
+  if (W) {
+    fill_net(e, c.net);
+    c.net.pair_ptr = static_cast<const int32_t*>(e->d_net_dyn_ptr.p);
+    c.net_init_end = static_cast<const int32_t*>(e->d_net_dyn_end.p);
+    c.net_init_flag = static_cast<const uint8_t*>(e->d_net_key_flag.p);
+    c.net_init_node = static_cast<const int32_t*>(e->d_net_dyn_node.p);
+    c.net_init_max = static_cast<const int64_t*>(e->d_net_dyn_max.p);
+    c.net_cap = dyn_ptr.empty() ? 0 : dyn_ptr.back();
+    c.net_n_keys = e->net_n_keys;
+    c.eff_ptr = static_cast<const int32_t*>(e->d_net_eff_ptr.p);
+    c.eff_key = static_cast<const int32_t*>(e->d_net_eff_key.p);
+    c.eff_cost = static_cast<const int64_t*>(e->d_net_eff_cost.p);
+  }
+  if (Q) {
+    c.q_ns = e->q_n_namespaces;
+    c.q_n_nom = static_cast<int32_t>(e->q_n_nominated);
+    c.q_pod_ns = static_cast<const int32_t*>(e->d_q_pod_ns.p);
+    c.q_pod_prio = static_cast<const int32_t*>(e->d_q_pod_prio.p);
+    c.q_pod_req = static_cast<const int64_t*>(e->d_q_pod_req.p);
+    c.q_pod_reqp = static_cast<const uint8_t*>(e->d_q_pod_reqp.p);
+    c.q_has = static_cast<const uint8_t*>(e->d_q_has.p);
+    c.q_used = static_cast<const int64_t*>(e->d_q_used.p);
+    c.q_usedp = static_cast<const uint8_t*>(e->d_q_usedp.p);
+    c.q_max = static_cast<const int64_t*>(e->d_q_max.p);
+    c.q_maxp = static_cast<const uint8_t*>(e->d_q_maxp.p);
+    c.q_min = static_cast<const int64_t*>(e->d_q_min.p);
+    c.q_minp = static_cast<const uint8_t*>(e->d_q_minp.p);
+    c.q_agg = static_cast<const int64_t*>(e->d_q_agg.p);
+    std::memcpy(c.q_agg_min, e->q_agg_min, sizeof c.q_agg_min);
+    c.q_agg_min_present = e->q_agg_min_present;
+    c.q_other = static_cast<const int64_t*>(e->d_q_other.p);
+    c.q_otherp = static_cast<const uint8_t*>(e->d_q_otherp.p);
+    c.q_nom_ptr = static_cast<const int32_t*>(e->d_q_nom_ptr.p);
+    c.q_nom_prio = static_cast<const int32_t*>(e->d_q_nom_prio.p);
+    c.q_nom_pending = static_cast<const int64_t*>(e->d_q_nom_idx.p);
+    c.q_nom_req = static_cast<const int64_t*>(e->d_q_nom_req.p);
+    c.q_nom_reqp = static_cast<const uint8_t*>(e->d_q_nom_reqp.p);
+  }
+  int lds_max = 0;
+  SPX_HIP(e, hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, e->device));
+  const size_t lds = spx::commit_coop_lds_bytes(c);
+  if (lds + 4096 > static_cast<size_t>(lds_max)) return SPX_OK;  // (4 KB: the kernel's static LDS)
+  // ---- from here on the kernel runs
+  if (Lv) {  // LVRB carries no commit state: its rows are swept once
+    if ((rc = spx_eval(e, 1u << SPX_PLUGIN_LVRB, row_begin, row_end))) return rc;
+    if (e->score_stride[SPX_PLUGIN_LVRB] != e->row_stride) return fail(e, SPX_ERR_STATE, "bound LVRB table must use the engine row stride");
+    c.lv_table = static_cast<const uint8_t*>(e->score[SPX_PLUGIN_LVRB].p);
+  }
+  const size_t sync_bytes = 2 * static_cast<size_t>(spx::kCoopKinds) * spx::kCoopMaxWg * 8;
+  if ((rc = ensure(e, e->d_coop_sync, sync_bytes + 64))) return rc;
+  SPX_HIP(e, hipMemsetAsync(e->d_coop_sync.p, 0, sync_bytes + 64, e->stream));
+  c.sync = static_cast<unsigned long long*>(e->d_coop_sync.p);
+  c.err = reinterpret_cast<int32_t*>(static_cast<char*>(e->d_coop_sync.p) + sync_bytes);
+  if (W) {
+    const size_t cap = static_cast<size_t>(c.net_cap ? c.net_cap : 1);
+    if ((rc = ensure(e, e->d_coop_node, static_cast<size_t>(n_wg) * cap * 4)) || (rc = ensure(e, e->d_coop_max, static_cast<size_t>(n_wg) * cap * 8))) return rc;
+    c.net_priv_node = static_cast<int32_t*>(e->d_coop_node.p);
+    c.net_priv_max = static_cast<int64_t*>(e->d_coop_max.p);
+  }
+  if ((rc = ensure(e, e->d_best, P * 20))) return rc;
+  c.best_score = static_cast<int64_t*>(e->d_best.p);
+  c.best_node = reinterpret_cast<int32_t*>(c.best_score + P);
+  c.best_ties = c.best_node + P;
+  c.best_feasible = c.best_ties + P;
+  if (tlp_missing_out && T) {
+    if ((rc = ensure(e, e->d_commit, Nn * 8))) return rc;
+    c.missing_out = static_cast<int64_t*>(e->d_commit.p);
+  }
+  spx::launch_commit_coop(c, e->stream);
+  SPX_HIP(e, hipGetLastError());
+  const size_t rows = static_cast<size_t>(row_end - row_begin);
+  int32_t err = 0;
+  SPX_HIP(e, hipMemcpyAsync(&err, c.err, 4, hipMemcpyDeviceToHost, e->stream));
+  SPX_HIP(e, hipMemcpyAsync(weighted_score, c.best_score + row_begin, rows * 8, hipMemcpyDeviceToHost, e->stream));
+  SPX_HIP(e, hipMemcpyAsync(node_idx, c.best_node + row_begin, rows * 4, hipMemcpyDeviceToHost, e->stream));
+  if (n_ties) SPX_HIP(e, hipMemcpyAsync(n_ties, c.best_ties + row_begin, rows * 4, hipMemcpyDeviceToHost, e->stream));
+  if (tlp_missing_out && T) SPX_HIP(e, hipMemcpyAsync(tlp_missing_out, c.missing_out, Nn * 8, hipMemcpyDeviceToHost, e->stream));
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  if (err != 0) return fail(e, SPX_ERR_HIP, "cooperative commit kernel: a workgroup gave up waiting for another one (device shared with other work?)");
+  if (tlp_missing_out && !T) std::memset(tlp_missing_out, 0, Nn * 8);
+  e->best_valid = false;
+  e->last_commit_path = 3;
+  *ran = true;
+  return SPX_OK;
+}
+
 // Sequential commit with Filter plugins in the profile: per pod one single-row evaluation of the whole plugin set on the
 // CURRENT device tables, the weighted argmax, and k_commit_apply.  Everything is enqueued on the engine stream without a host
 // sync; the tables the loop mutates are saved before and restored after.
@@ -2086,15 +2221,20 @@ int commit_with_filters(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, 
     if ((rc = upload(e, e->d_net_dyn_end, dyn_end.data(), K * 4))) return rc;
     if ((rc = ensure(e, e->d_net_dyn_node, cap * 4)) || (rc = ensure(e, e->d_net_dyn_max, cap * 8))) return rc;
     SPX_HIP(e, hipStreamSynchronize(e->stream));  // the vectors above are locals
-    for (size_t k = 0; k < K; ++k) {  // the initial pairs, list by list
-      const size_t len = static_cast<size_t>(e->h_pair_ptr[k + 1] - e->h_pair_ptr[k]);
-      if (!len) continue;
-      SPX_HIP(e, hipMemcpyAsync(static_cast<int32_t*>(e->d_net_dyn_node.p) + dyn_ptr[k], static_cast<const int32_t*>(e->d_net_pair_node.p) + e->h_pair_ptr[k], len * 4,
-                                hipMemcpyDeviceToDevice, e->stream));
-      SPX_HIP(e, hipMemcpyAsync(static_cast<int64_t*>(e->d_net_dyn_max.p) + dyn_ptr[k], static_cast<const int64_t*>(e->d_net_pair_max.p) + e->h_pair_ptr[k], len * 8,
-                                hipMemcpyDeviceToDevice, e->stream));
-    }
+    // the initial pairs into the layout with slack: one launch (round 3 issued two copies per key: 14k tiny copies for config #5's share)
+    spx::launch_spread_pairs(static_cast<int32_t>(K), static_cast<const int32_t*>(e->d_net_pair_ptr.p), static_cast<const int32_t*>(e->d_net_dyn_ptr.p),
+                             static_cast<const int32_t*>(e->d_net_pair_node.p), static_cast<const int64_t*>(e->d_net_pair_max.p),
+                             static_cast<int32_t*>(e->d_net_dyn_node.p), static_cast<int64_t*>(e->d_net_dyn_max.p), e->stream);
+    SPX_HIP(e, hipGetLastError());
   }
+  // ---- the cooperative persistent kernel (kernels_commit_coop.hip) when the profile fits it: nothing is mutated in the engine's
+  // tables (the state lives in the kernel's registers / LDS), so nothing is saved or restored
+  {
+    bool ran = false;
+    if ((rc = commit_coop(e, plugin_mask, row_begin, row_end, dyn_ptr, node_idx, weighted_score, n_ties, tlp_missing_out, &ran))) return rc;
+    if (ran) return SPX_OK;
+  }
+  e->last_commit_path = 2;
   // ---- save what the loop mutates
   struct Saved {
     DevBuf* buf;
@@ -2298,6 +2438,7 @@ int spx_commit_sequential(spx_engine* e, uint32_t plugin_mask, int64_t row_begin
   c.out_ties = n_ties ? c.out_node + rows : nullptr;
   SPX_HIP(e, hipMemcpyAsync(c.missing, e->d_tlp_missing.p, N * 8, hipMemcpyDeviceToDevice, e->stream));
   spx::launch_commit_trimaran(c, e->stream);
+  e->last_commit_path = 1;
   SPX_HIP(e, hipGetLastError());
   SPX_HIP(e, hipMemcpyAsync(weighted_score, c.out_score, rows * 8, hipMemcpyDeviceToHost, e->stream));
   SPX_HIP(e, hipMemcpyAsync(node_idx, c.out_node, rows * 4, hipMemcpyDeviceToHost, e->stream));
@@ -2306,6 +2447,8 @@ int spx_commit_sequential(spx_engine* e, uint32_t plugin_mask, int64_t row_begin
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   return SPX_OK;
 }
+
+int spx_commit_path(const spx_engine* e) { return e ? e->last_commit_path : SPX_ERR_ARG; }
 
 int spx_kernel_path(const spx_engine* e, int plugin) {
   if (!e) return SPX_ERR_ARG;

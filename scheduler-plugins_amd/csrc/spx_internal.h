@@ -498,6 +498,77 @@ struct CommitApplyArgs {
 };
 void launch_commit_apply(const CommitApplyArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- sequential commit, cooperative persistent kernel (kernels_commit_coop.hip)
+// One launch schedules a whole row range one pod at a time for profiles with Filter plugins.  A workgroup owns a window of 256 nodes
+// and keeps their state in registers; per pod the workgroups exchange two sets of self-tagged 8-byte granules (feasible-set
+// minima / maxima, then the weighted argmax) — the only memory they share.  What Reserve changes (NRT zones, trimaran's missing
+// utilisation, quota usage, AppGroup placement) is applied by the owner lane or replayed identically in every workgroup.
+constexpr int kCoopWindow = 256;    // nodes per workgroup (= the NRT node order's window)
+constexpr int kCoopMaxWg = 256;     // one thread polls one workgroup's granules
+constexpr int kCoopMaxPairs = 512;  // (host, MaxNetworkCost) pairs of one workload key staged in LDS
+constexpr int kCoopMaxEffects = 32; // workload keys one bound pod changes
+constexpr int kCoopMaxClasses = 512;
+constexpr int kCoopKinds = 8;       // granules per workgroup and parity: 4 for the feasible set, 4 for the argmax
+struct CoopArgs {
+  uint32_t use;                     // profile: bit SPX_PLUGIN_*
+  int32_t w[SPX_NUM_PLUGINS];       // plugin weights (the launcher checks the 32-bit totals)
+  int64_t n_nodes, n_pods, row_stride, row_begin, row_end;
+  int32_t n_wg;
+  int32_t nrt_sg;                   // 0 LeastAllocated, 1 MostAllocated (nrtdev::kSg*)
+  const uint32_t* alloc_rel;        // Allocatable: raw scores as offsets from the global minimum (AllocPrepArgs.rel)
+  TrimaranArgs t;                   // node / pod columns of TargetLoadPacking
+  const uint8_t* lv_table;          // LVRB's rows, swept beforehand (no commit state)
+  NrtArgs nrt;                      // float64 formulation's tables
+  NetArgs net;                      // labels, cost matrices, classes, pod_key; pair_ptr = start of each key's list WITH slack
+  const int32_t* net_init_end;      // [K] end of the initial pairs in that layout
+  const uint8_t* net_init_flag;     // [K]
+  const int32_t* net_init_node;     // [cap] the initial pairs in the slack layout: every workgroup copies them into its private lists
+  const int64_t* net_init_max;
+  int64_t net_cap;
+  int32_t net_n_keys;
+  int32_t* net_priv_node;           // [n_wg][cap]
+  int64_t* net_priv_max;            // [n_wg][cap]
+  const int32_t* eff_ptr;           // commit effects per pod (spx_upload_net_commit)
+  const int32_t* eff_key;
+  const int64_t* eff_cost;
+  // CapacityScheduling: inputs; the mutable part (used, aggregate, nominated requests, other-namespace sums) is copied into LDS
+  int32_t q_ns, q_n_nom;
+  const int32_t* q_pod_ns;
+  const int32_t* q_pod_prio;
+  const int64_t* q_pod_req;
+  const uint8_t* q_pod_reqp;
+  const uint8_t* q_has;
+  const int64_t* q_used;
+  const uint8_t* q_usedp;
+  const int64_t* q_max;
+  const uint8_t* q_maxp;
+  const int64_t* q_min;
+  const uint8_t* q_minp;
+  const int64_t* q_agg;             // [8] aggregate used + [1] presence bits
+  int64_t q_agg_min[SPX_QUOTA_SLOTS];
+  uint32_t q_agg_min_present;
+  const int64_t* q_other;
+  const uint8_t* q_otherp;
+  const int32_t* q_nom_ptr;
+  const int32_t* q_nom_prio;
+  const int64_t* q_nom_pending;
+  const int64_t* q_nom_req;
+  const uint8_t* q_nom_reqp;
+  unsigned long long* sync;         // [2 parities][kCoopKinds][kCoopMaxWg] granules: value | tag << 32, zeroed before the launch
+  int64_t* best_score;              // [n_pods] decisions, spx_eval_best's layout
+  int32_t* best_node;
+  int32_t* best_ties;
+  int32_t* best_feasible;
+  int64_t* missing_out;             // [N] trimaran's missing utilisation after the last commit (NULL: not wanted)
+  int32_t* err;                     // set when a workgroup gave up waiting for another one (the launch is then void)
+};
+// dynamic LDS of one workgroup, 0 when the profile does not fit the kernel's staging areas (the caller then runs the per-pod loop)
+size_t commit_coop_lds_bytes(const CoopArgs& c);
+void launch_commit_coop(const CoopArgs& c, hipStream_t s);
+// key k's pairs src[src_ptr[k] .. src_ptr[k+1]) -> dst[dst_ptr[k] ..): the workload pair lists re-laid with room to grow
+void launch_spread_pairs(int32_t n_keys, const int32_t* src_ptr, const int32_t* dst_ptr, const int32_t* src_node, const int64_t* src_max, int32_t* dst_node,
+                         int64_t* dst_max, hipStream_t s);
+
 // ---------------------------------------------------------------- profile-level passes
 struct ProfileArgs {
   int64_t n_nodes;

@@ -523,6 +523,10 @@ class Engine:
         """0 = generic sweep kernel, 1 = fast formulation (same results)."""
         return int(self._lib.spx_kernel_path(self._h, plugin))
 
+    def commit_path(self) -> int:
+        """which form the last commit_sequential ran: 1 one-workgroup trimaran chain, 2 per-pod launches, 3 cooperative kernel"""
+        return int(self._lib.spx_commit_path(self._h))
+
     def last_eval_ms(self) -> float:
         ms = C.c_float()
         self._ck(self._lib.spx_last_eval_ms(self._h, C.byref(ms)))

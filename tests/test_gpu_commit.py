@@ -135,14 +135,16 @@ def _full_scenario(hdr, n_nodes, n_pods, seed):
     return nrts, nodes, node_labels, pods, meta, metrics, quotas, nominated
 
 
-@pytest.mark.parametrize("kernels", ["fast", "reference", "fast-direct"])
-@pytest.mark.parametrize("n_nodes,n_pods,seed", [(40, 70, 1), (150, 60, 2)])
+@pytest.mark.parametrize("kernels", ["coop", "coop-most", "graph", "reference", "fast-direct"])
+@pytest.mark.parametrize("n_nodes,n_pods,seed", [(40, 70, 1), (150, 60, 2), (700, 50, 3)])
 def test_commit_sequential_full_profile(gpu_required, hdr, oracle, kernels, n_nodes, n_pods, seed):
     """NRT + NetworkOverhead + CapacityScheduling + Allocatable + TLP + LVRB scheduled one pod at a time.  After every decision the
     test applies what the reference's Reserve hooks do to its own Python-side state (NRT assumed resources on the node, the
     AppGroup's scheduled list, the namespace's Used, the nominated-pod list, trimaran's ScheduledPodsCache), rebuilds the object
     tables from it and lets the CPU oracle evaluate the next pod's row from scratch; node, weighted score, tie-set size and the
-    unschedulable verdicts must equal the device loop's."""
+    unschedulable verdicts must equal the device loop's.  Forms of the loop: the cooperative persistent kernel (one workgroup per 256
+    nodes: 700 nodes = three workgroups exchanging granules), the per-pod launches replayed from a graph, the same with the
+    reference-arithmetic kernels, and plain per-pod launches."""
     from helpers import CAPACITY, NETOVERHEAD, NRT
     nrts, nodes, node_labels, pods, meta, metrics, quotas, nominated = _full_scenario(hdr, n_nodes, n_pods, seed)
     res = O.Resources()
@@ -159,7 +161,9 @@ def test_commit_sequential_full_profile(gpu_required, hdr, oracle, kernels, n_no
     pod_t = O.build_pod_objects(hdr, res, pod_dicts)
     met_t = O.build_metrics_objects(hdr, n_nodes, metrics, window_end=WINDOW_END)
     rc = res.table(hdr)
-    params = O.nrt_params(hdr, res, "LeastAllocated")
+    if n_nodes > 200 and kernels in ("reference", "fast-direct"):
+        pytest.skip("the large scenario exists for the cooperative kernel's granule exchange")
+    params = O.nrt_params(hdr, res, "MostAllocated" if kernels == "coop-most" else "LeastAllocated")
     names = {f"n{i}": i for i in range(n_nodes)}
 
     def tables(assumed, placed, used, nom):
@@ -178,6 +182,8 @@ def test_commit_sequential_full_profile(gpu_required, hdr, oracle, kernels, n_no
             e.force_reference_kernels(TLP, LVRB, NRT, NETOVERHEAD)
         if kernels == "fast-direct":   # plain launches per pod instead of the replayed graph (rows from the host, not the device counter)
             e.set_option("COMMIT_FROM_MEMORY", 1)
+        if kernels == "graph":
+            e.set_option("COMMIT_COOP", 0)
         e.load_trimaran_objects(node_t, rc, pod_t, met_t, O.build_assigned_objects(hdr, res, n_nodes, {}))
         e.load_nrt_objects(node_t, nrt_t, rc, pod_t, params)
         e.load_network_objects(node_t, pod_t, ag_t, nt_t)
@@ -185,6 +191,7 @@ def test_commit_sequential_full_profile(gpu_required, hdr, oracle, kernels, n_no
         e.set_plugin_weights(weights)
         assert e.kernel_path(NRT) == (0 if kernels == "reference" else 1)
         got_node, got_score, got_ties, _ = e.commit_sequential(mask_of(*plugins))
+        assert e.commit_path() == (3 if kernels.startswith("coop") else 2)
         # the snapshot is intact afterwards: a frozen-snapshot evaluation gives what a fresh engine gives
         e.eval(mask_of(*plugins))
         e.sync()
