@@ -91,6 +91,7 @@ WORKLOADS = {
                     desc="noderesources.Allocatable (LeastAllocated), 100 nodes x 1k pods (plumbing)"),
 }
 PID = {"alloc": 0, "tlp": 1, "lvrb": 2, "nrt": 3, "net": 4, "cap": 5, "lroc": 7, "peaks": 8}
+SEQ_PATH = {1: "one-workgroup chain (Filter-less profile)", 2: "per-pod single-row launches replayed from a graph", 3: "cooperative persistent kernel"}
 
 
 # kernel translation units per plugin key of WORKLOADS (csrc/)
@@ -188,6 +189,56 @@ def load_tables(target, w, snap, rows=None):
             target.upload_quota(target.flatten_quota(snap["pods"], snap["rc"], snap["quota"]), rows)
         else:
             target.load_quota_objects(snap["pods"], snap["rc"], snap["quota"])
+
+
+def config5_leg(hdr, device, n_pods=8192):
+    """A bounded leg of BASELINE config #5 inside the default (config #2) line, so that the full profile's numbers are driver-timed
+    too: config #5's node count and plugin set, a batch of `n_pods` pods — sweep, decisions, and the one-pod-at-a-time cycle."""
+    from scheduler_plugins_amd.engine import Engine
+    w = dict(WORKLOADS["config5_share"], n_pods=n_pods)
+    out = {"workload": f"full profile, {w['n_nodes']} nodes x {n_pods} pods (config #5's node count and plugins, a bounded batch)"}
+    t0 = time.perf_counter()
+    snap = build_snapshot(hdr, w, n_pods, synth_seed())
+    out["synth_s"] = time.perf_counter() - t0
+    mask = 0
+    for p in w["plugins"]:
+        mask |= 1 << PID[p]
+    with Engine(device) as e:
+        t0 = time.perf_counter()
+        load_tables(e, w, snap)
+        e.sync()
+        out["flatten_upload_ms"] = (time.perf_counter() - t0) * 1e3
+        for _ in range(2):
+            e.eval(mask)
+        e.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            e.eval(mask)
+        e.sync()
+        out["sweep_ms"] = (time.perf_counter() - t0) * 1e3 / 5
+        out["evals_per_sec"] = w["n_nodes"] * n_pods / (out["sweep_ms"] * 1e-3)
+        e.decide(mask)
+        e.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            e.decide(mask)
+        e.sync()
+        out["decide_ms"] = (time.perf_counter() - t0) * 1e3 / 5
+        e.commit_sequential(mask, 0, min(n_pods, 256), want_ties=False)  # first call allocates
+        t0 = time.perf_counter()
+        node, _, _, _ = e.commit_sequential(mask, want_ties=False)
+        dt = time.perf_counter() - t0
+        out["sequential_commit_ms"] = dt * 1e3
+        out["sequential_us_per_pod"] = dt * 1e6 / n_pods
+        out["sequential_path"] = SEQ_PATH.get(e.commit_path(), "?")
+        out["sequential_unschedulable"] = int((node < 0).sum())
+        out["sequential_distinct_nodes"] = int(len(set(node.tolist())))
+    return out
+
+
+def synth_seed():
+    from scheduler_plugins_amd import synth
+    return synth.SEED
 
 
 def delta_cycle(target, w, snap, hdr, mask, score_mask):
@@ -336,6 +387,7 @@ def main() -> None:
     ap.add_argument("--sweep-only", action="store_true", help="skip the full_cycle section (profiling runs: rocprofv3 counter passes crash in hipGraph capture)")
     ap.add_argument("--no-pod-classes", action="store_true", help="evaluate every pod row (SPX_OPT_NRT_POD_CLASSES / SPX_OPT_PEAKS_POD_CLASSES off): "
                     "by default a whole-batch NRT or Peaks sweep evaluates one row per class of pods with equal records and copies it")
+    ap.add_argument("--no-config5-leg", action="store_true", help="default (config2) line only: skip the bounded full-profile leg (config5_leg)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -519,9 +571,13 @@ def main() -> None:
                 full_cycle["sequential_pods_per_s"] = local_pods / (c5 - c4)
                 full_cycle["sequential_distinct_nodes"] = int(len(set(seq_node.tolist())))
                 full_cycle["sequential_unschedulable"] = int((seq_node < 0).sum())
-                full_cycle["sequential_what"] = ("one workgroup carrying trimaran's bind-time state" if args.workload != "config5_share" else
-                                                 "per pod: single-row sweep of the whole profile on the current tables + argmax + Reserve bookkeeping "
-                                                 "(NRT assumed resources, AppGroup scheduled list, ElasticQuota used, trimaran cache), all on the device")
+                full_cycle["sequential_us_per_pod"] = (c5 - c4) * 1e6 / local_pods
+                full_cycle["sequential_path"] = SEQ_PATH.get(target.commit_path(), "?")
+                full_cycle["sequential_what"] = ("one workgroup carrying trimaran's bind-time state in registers (k_commit_trimaran_reg)" if args.workload != "config5_share" else
+                                                 "one cooperative persistent launch: a workgroup per 256 nodes keeps NRT zones / TLP columns in registers, two granule "
+                                                 "exchanges per pod (feasible-set extremes, weighted argmax), Reserve bookkeeping (NRT assumed resources, AppGroup "
+                                                 "scheduled list, ElasticQuota used, trimaran cache) applied in place — k_commit_coop; falls back to per-pod launches "
+                                                 "when the profile does not fit (sequential_path)")
         except Exception as ex:
             full_cycle = {"error": repr(ex)[:200]}
 
@@ -656,6 +712,11 @@ def main() -> None:
         out["gather"] = gather_info
     if sort_info is not None:
         out["topological_sort"] = sort_info
+    if rank == 0 and world == 1 and mode == "single" and args.workload == "config2" and not args.plugins and not args.sweep_only and not args.no_config5_leg:
+        try:
+            out["config5_leg"] = config5_leg(hdr, local_rank)
+        except Exception as ex:
+            out["config5_leg"] = {"error": repr(ex)[:300]}
     if rank == 0 and args.cpu_budget > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(spx, snap, e0, plugins, args.cpu_budget)
     target.close()

@@ -99,43 +99,39 @@ __host__ __device__ inline Layout make_layout(const CoopArgs& c) {
   return l;
 }
 
-// ---- cross-lane helpers (every lane live)
+// ---- cross-lane helpers (every lane live).  Reductions run on DPP row permutations (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
+// row_mirror: every lane of a 16-lane row ends with the row's result) and combine the four rows on the scalar unit — a fraction of the
+// latency of six ds_bpermute round trips per value, and an exchange reduces eight values twice.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_perm(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), CTRL, 0xf, 0xf, false));
+}
+template <typename F>
+__device__ __forceinline__ uint32_t wave_reduce(uint32_t v, F f) {
+  v = f(v, dpp_perm<0xB1>(v));
+  v = f(v, dpp_perm<0x4E>(v));
+  v = f(v, dpp_perm<0x141>(v));
+  v = f(v, dpp_perm<0x140>(v));
+  const uint32_t r0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 0));
+  const uint32_t r1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 16));
+  const uint32_t r2 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 32));
+  const uint32_t r3 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 48));
+  return f(f(r0, r1), f(r2, r3));
+}
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const uint32_t o = static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), m, 64));
-    v = o < v ? o : v;
-  }
-  return v;
+  return wave_reduce(v, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const uint32_t o = static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), m, 64));
-    v = o > v ? o : v;
-  }
-  return v;
+  return wave_reduce(v, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const int o = __shfl_xor(v, m, 64);
-    v = o < v ? o : v;
-  }
-  return v;
+  return static_cast<int>(wave_reduce(static_cast<uint32_t>(v), [](uint32_t a, uint32_t b) { return static_cast<int>(a) < static_cast<int>(b) ? a : b; }));
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const int o = __shfl_xor(v, m, 64);
-    v = o > v ? o : v;
-  }
-  return v;
+  return static_cast<int>(wave_reduce(static_cast<uint32_t>(v), [](uint32_t a, uint32_t b) { return static_cast<int>(a) > static_cast<int>(b) ? a : b; }));
 }
 __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  return static_cast<int>(wave_reduce(static_cast<uint32_t>(v), [](uint32_t a, uint32_t b) { return a + b; }));
 }
 
 // (best total, lowest node reaching it, how many nodes tie) merged the way k_best_fast merges lanes; node < 0 = none
@@ -151,16 +147,17 @@ __device__ __forceinline__ void merge_best(Best& a, const Best& b) {
     a.node = b.node < a.node ? b.node : a.node;
   }
 }
+// the same over a wavefront, as three dependent reductions: the best total, then the lowest node and the tie count among its holders
 __device__ __forceinline__ Best wave_best(Best v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    Best o;
-    o.total = __shfl_xor(v.total, m, 64);
-    o.node = __shfl_xor(v.node, m, 64);
-    o.ties = __shfl_xor(v.ties, m, 64);
-    merge_best(v, o);
-  }
-  return v;
+  const int has = v.node >= 0;
+  const int best = wave_max_i32(has ? v.total : INT32_MIN);
+  const bool mine = has && v.total == best;
+  Best r;
+  r.total = best;
+  r.node = wave_min_i32(mine ? v.node : INT32_MAX);
+  r.ties = wave_sum_i32(mine ? v.ties : 0);
+  if (r.node == INT32_MAX) r = Best{0, -1, 0};
+  return r;
 }
 
 // ---- the granule exchange: every workgroup publishes four 32-bit values, every workgroup reads everybody's.
@@ -170,25 +167,24 @@ __device__ __forceinline__ void publish(unsigned long long* sync, int par, int k
   unsigned long long* slot = sync + (static_cast<size_t>(par) * kCoopKinds + static_cast<size_t>(kind0 + k)) * kCoopMaxWg + wg;
   __hip_atomic_store(slot, static_cast<unsigned long long>(value) | (static_cast<unsigned long long>(tag) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the four values workgroup `wg` published for this tag; false when it never came (bounded spin)
+// the four values workgroup `wg` published for this tag; false when it never came (bounded spin).  The four loads are in flight
+// together (one round trip when everybody has published; polled one after the other they cost four)
 __device__ __forceinline__ bool collect(const unsigned long long* sync, int par, int kind0, int wg, uint32_t tag, uint32_t (&v)[4]) {
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const unsigned long long* slot = sync + (static_cast<size_t>(par) * kCoopKinds + static_cast<size_t>(kind0 + k)) * kCoopMaxWg + wg;
-    unsigned long long g = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t spins = 0;
-    while (static_cast<uint32_t>(g >> 32) != tag) {
-      if (++spins > kSpinLimit) {
-        ok = false;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-      g = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long* slot = sync + (static_cast<size_t>(par) * kCoopKinds + static_cast<size_t>(kind0)) * kCoopMaxWg + wg;
+  uint32_t spins = 0;
+  while (true) {
+    const unsigned long long g0 = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long g1 = __hip_atomic_load(slot + kCoopMaxWg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long g2 = __hip_atomic_load(slot + 2 * kCoopMaxWg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long g3 = __hip_atomic_load(slot + 3 * kCoopMaxWg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (static_cast<uint32_t>(g0 >> 32) == tag && static_cast<uint32_t>(g1 >> 32) == tag && static_cast<uint32_t>(g2 >> 32) == tag &&
+        static_cast<uint32_t>(g3 >> 32) == tag) {
+      v[0] = static_cast<uint32_t>(g0), v[1] = static_cast<uint32_t>(g1), v[2] = static_cast<uint32_t>(g2), v[3] = static_cast<uint32_t>(g3);
+      return true;
     }
-    v[k] = static_cast<uint32_t>(g);
+    if (++spins > kSpinLimit) return false;
+    __builtin_amdgcn_s_sleep(1);
   }
-  return ok;
 }
 
 // contribution of one (scheduled pod on a host with labels hr / hz, dependency with max_cost) pair to a node with labels (region, zone)
@@ -237,7 +233,9 @@ __device__ __forceinline__ int64_t wadd(int64_t a, int64_t b) { return static_ca
 template <int SG>
 __global__ __launch_bounds__(kT) void k_commit_coop(CoopArgs c) {
   extern __shared__ __align__(16) unsigned char lds[];
-  __shared__ uint32_t s_red[8][kT / 64];
+  __shared__ uint32_t s_red[4][kT / 64];                    // a workgroup's own partials on their way to its granules
+  __shared__ uint32_t s_x1[4][kT / 64], s_x2[4][kT / 64];  // the waves' shares of the two exchanges' results (separate arrays: no barrier between
+                                                           // a slow reader of one exchange and the writers of the next)
   __shared__ uint32_t s_all[8];
   __shared__ int s_flag_misc[8];  // [0] pod_ok, [1] q_other needs a rebuild, [2] this pod's network flag, [3] staged pair count, [4] give up
   const Layout L = make_layout(c);
@@ -405,26 +403,52 @@ __global__ __launch_bounds__(kT) void k_commit_coop(CoopArgs c) {
     }
   };
   // NetworkOverhead: the pod's pair list -> LDS (host, its labels, MaxNetworkCost), the class table over it, and how many pairs sit
-  // on each node of this window (a node that hosts a pair counts that pair differently: networkoverhead.go:536-544)
-  auto stage_pairs = [&](const PodBlk& b) {
-    const int key = b.net_key, lo = b.net_lo;
-    const int np = dyn_end[key] - lo;  // (<= kCoopMaxPairs: checked by the launcher over the batch's final lists)
+  // on each node of this window (a node that hosts a pair counts that pair differently: networkoverhead.go:536-544).  In three
+  // steps so that the two dependent rounds of global loads (the list, then the hosts' labels) fly while the quota verdict and the
+  // NRT evaluation run: stage_issue -> stage_labels -> stage_land.
+  constexpr int kSlots = kCoopMaxPairs / kT;  // staged pairs per thread
+  int st_host[kSlots], st_region[kSlots], st_zone[kSlots], st_np = 0;
+  long long st_max[kSlots];
+  auto stage_issue = [&](const PodBlk& b) {
+    const int lo = b.net_lo;
+    st_np = dyn_end[b.net_key] - lo;  // (<= kCoopMaxPairs: checked by the launcher over the batch's final lists)
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) {
+      const int i = tid + q * kT;
+      st_host[q] = 0, st_max[q] = 0;
+      if (i < st_np) st_host[q] = priv_node[lo + i], st_max[q] = priv_max[lo + i];
+    }
     hostcnt[tid] = 0;
-    __syncthreads();
-    for (int i = tid; i < np; i += kT) {
-      const int host = priv_node[lo + i];
-      p_host[i] = host;
-      p_region[i] = c.net.region[host];
-      p_zone[i] = c.net.zone[host];
-      p_max[i] = priv_max[lo + i];
-      if (host >= base && host < base + kT && pos_of[host - base] >= 0) atomicAdd(&hostcnt[pos_of[host - base]], 1);
+    for (int i = tid; i < 3 * C; i += kT) cls_sat[i] = 0;  // (sat | vio | cost are one array)
+  };
+  auto stage_labels = [&]() {
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) {
+      st_region[q] = -1, st_zone[q] = -1;
+      if (tid + q * kT < st_np) st_region[q] = c.net.region[st_host[q]], st_zone[q] = c.net.zone[st_host[q]];
+    }
+  };
+  // classes x pairs spread over the workgroup: slice q of the threads takes every n_slices-th pair of its class
+  const int n_slices = C > 0 ? (kT / C > 0 ? kT / C : 1) : 1;
+  auto stage_land = [&]() {
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) {
+      const int i = tid + q * kT;
+      if (i < st_np) {
+        const int host = st_host[q];
+        p_host[i] = host, p_region[i] = st_region[q], p_zone[i] = st_zone[q], p_max[i] = st_max[q];
+        if (host >= base && host < base + kT && pos_of[host - base] >= 0) atomicAdd(&hostcnt[pos_of[host - base]], 1);
+      }
     }
     __syncthreads();
-    for (int cl = tid; cl < C; cl += kT) {
+    for (int u = tid; u < C * n_slices; u += kT) {
+      const int cl = u % C, q = u / C;
       Acc acc{0, 0, 0};
       const int region = cls_region[cl], zone = cls_zone[cl];
-      for (int i = 0; i < np; ++i) add_pair(acc, region, zone, p_region[i], p_zone[i], p_max[i], zcost, c.net.n_zones, rcost, c.net.n_regions);
-      cls_sat[cl] = acc.sat, cls_vio[cl] = acc.vio, cls_cost[cl] = acc.cost;
+      for (int i = q; i < st_np; i += n_slices) add_pair(acc, region, zone, p_region[i], p_zone[i], p_max[i], zcost, c.net.n_zones, rcost, c.net.n_regions);
+      if (acc.sat) atomicAdd(&cls_sat[cl], acc.sat);
+      if (acc.vio) atomicAdd(&cls_vio[cl], acc.vio);
+      if (acc.cost) atomicAdd(&cls_cost[cl], acc.cost);
     }
     __syncthreads();
   };
@@ -436,6 +460,12 @@ __global__ __launch_bounds__(kT) void k_commit_coop(CoopArgs c) {
   land_block(c.row_begin + 1, pre);
   __syncthreads();
 
+#ifdef SPX_COOP_PROF
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = wall_clock64();
+#define SPX_MARK(i) do { const unsigned long long t_now = wall_clock64(); prof[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define SPX_MARK(i) do { } while (0)
+#endif
   uint8_t lv_next = (Lv && in) ? c.lv_table[c.row_begin * c.row_stride + n] : 0;
   const double t_tlp = c.t.tlp_target;
   bool dead = false;
@@ -449,46 +479,40 @@ __global__ __launch_bounds__(kT) void k_commit_coop(CoopArgs c) {
     const uint32_t lv_byte = lv_next;
     if (Lv && in && pod + 1 < c.row_end) lv_next = c.lv_table[(pod + 1) * c.row_stride + n];
 
-    // ---- CapacityScheduling.PreFilter on the replicated quota state (capacity_scheduling.go:208-283; as k_quota)
-    if (Q && tid == 0) {
+    if (W) stage_issue(b);
+    // ---- CapacityScheduling.PreFilter on the replicated quota state (capacity_scheduling.go:208-283; as k_quota), one lane per
+    // resource slot (a single thread walking ~100 dependent LDS reads cost 1.9 us per pod)
+    if (Q && wave == 3 && lane < S) {
+      const int s = lane;
       const int nsid = b.q_ns;
       int status = 0;
       if (nsid >= 0 && nsid < NS && q_has[nsid]) {
-        int64_t in_eq[S];
+        int64_t in_eq = b.q_req[s];
         uint32_t in_p = b.q_reqp;
-        for (int s = 0; s < S; ++s) in_eq[s] = b.q_req[s];
         for (int j = q_nom_ptr[nsid]; j < q_nom_ptr[nsid + 1]; ++j) {
           if (q_nom_pending[j] == static_cast<int32_t>(pod) || q_nom_prio[j] < b.q_prio) continue;
-          for (int s = 0; s < S; ++s) in_eq[s] = wadd(in_eq[s], q_nomreq[j * S + s]);
+          in_eq = wadd(in_eq, q_nomreq[j * S + s]);
           in_p |= q_nomreqp[j];
         }
-        bool over = false;
-        for (int s = 0; s < 4; ++s) over |= wadd(in_eq[s], q_used[nsid * S + s]) > q_max[nsid * S + s];
-        for (int s = 4; s < S; ++s) {
-          const int64_t yq = ((q_maxp[nsid] >> s) & 1u) ? q_max[nsid * S + s] : INT64_MAX;
-          over |= ((in_p >> s) & 1u) && wadd(in_eq[s], q_used[nsid * S + s]) > yq;
-        }
-        if (over) {
+        const int64_t with_used = wadd(in_eq, q_used[nsid * S + s]);
+        const int64_t ymax = (s < 4 || ((q_maxp[nsid] >> s) & 1u)) ? q_max[nsid * S + s] : INT64_MAX;
+        const bool over = (s < 4 || ((in_p >> s) & 1u)) && with_used > ymax;
+        if (__ballot(over) != 0) {
           status = SPX_QUOTA_ST_OVER_MAX;
         } else {
           const uint32_t agg_p = static_cast<uint32_t>(q_agg[S]) | in_p | q_otherp[nsid];
-          bool over_min = false;
-          for (int s = 0; s < S; ++s) {
-            const int64_t agg = wadd(wadd(q_agg[s], in_eq[s]), q_other[nsid * S + s]);
-            if (s < 4) {
-              over_min |= agg > c.q_agg_min[s];
-            } else {
-              const int64_t yq = ((c.q_agg_min_present >> s) & 1u) ? c.q_agg_min[s] : 0;
-              over_min |= ((agg_p >> s) & 1u) && agg > yq;
-            }
-          }
-          if (over_min) status = SPX_QUOTA_ST_OVER_MIN;
+          const int64_t agg = wadd(wadd(q_agg[s], in_eq), q_other[nsid * S + s]);
+          const int64_t ymin = (s < 4 || ((c.q_agg_min_present >> s) & 1u)) ? c.q_agg_min[s] : 0;
+          const bool over_min = (s < 4 || ((agg_p >> s) & 1u)) && agg > ymin;
+          if (__ballot(over_min) != 0) status = SPX_QUOTA_ST_OVER_MIN;
         }
       }
-      s_flag_misc[0] = status;
+      if (s == 0) s_flag_misc[0] = status;
     }
-    if (W) stage_pairs(b);  // (its barriers also publish the verdict above)
-    else __syncthreads();
+    if (W) stage_labels();
+    SPX_MARK(0);
+    __syncthreads();  // the verdict above; the staging areas zeroed by stage_issue
+    SPX_MARK(1);
     const bool pod_ok = !Q || s_flag_misc[0] == 0;
     const int net_flag = W ? key_flag[b.net_key] : 0;
 
@@ -553,6 +577,7 @@ __global__ __launch_bounds__(kT) void k_commit_coop(CoopArgs c) {
         }
       }
       // ---- NetworkOverhead: accumulated cost / satisfied / violated of this node from the class table
+      if (W) stage_land();
       Acc na{0, 0, 0};
       bool net_pass = true;
       if (W) {
@@ -571,11 +596,16 @@ __global__ __launch_bounds__(kT) void k_commit_coop(CoopArgs c) {
         }
       }
       const bool feasible = in && nrt_status == 0 && net_pass;
+      SPX_MARK(2);
       // ---- first exchange: what NormalizeScore runs over (allocatable.go:143-168, networkoverhead.go:389-418)
       {
         uint32_t lo = feasible ? rel : 0xffffffffu, hi = feasible ? rel : 0u;
         int mn = (feasible && net_flag == 0) ? na.cost : INT32_MAX, mx = (feasible && net_flag == 0) ? na.cost : INT32_MIN;
         lo = wave_min_u32(lo), hi = wave_max_u32(hi), mn = wave_min_i32(mn), mx = wave_max_i32(mx);
+        if (c.n_wg == 1) {  // one window: the waves' partials ARE the result (a granule hop costs 1.6 us even to oneself)
+          if (lane == 0) s_x1[0][wave] = lo, s_x1[1][wave] = hi, s_x1[2][wave] = static_cast<uint32_t>(mn), s_x1[3][wave] = static_cast<uint32_t>(mx);
+          __syncthreads();
+        } else {
         if (lane == 0) s_red[0][wave] = lo, s_red[1][wave] = hi, s_red[2][wave] = static_cast<uint32_t>(mn), s_red[3][wave] = static_cast<uint32_t>(mx);
         __syncthreads();
         if (tid < 4) {
@@ -594,23 +624,24 @@ __global__ __launch_bounds__(kT) void k_commit_coop(CoopArgs c) {
         if (tid < c.n_wg) ok = collect(c.sync, par, 0, tid, tag, v4);
         lo = wave_min_u32(v4[0]), hi = wave_max_u32(v4[1]), mn = wave_min_i32(static_cast<int>(v4[2])), mx = wave_max_i32(static_cast<int>(v4[3]));
         const bool wok = __ballot(!ok) == 0;
-        __syncthreads();  // (everybody has read s_red's first use)
-        if (lane == 0) s_red[4][wave] = lo, s_red[5][wave] = hi, s_red[6][wave] = static_cast<uint32_t>(mn), s_red[7][wave] = static_cast<uint32_t>(mx);
+        if (lane == 0) s_x1[0][wave] = lo, s_x1[1][wave] = hi, s_x1[2][wave] = static_cast<uint32_t>(mn), s_x1[3][wave] = static_cast<uint32_t>(mx);
         if (lane == 0 && !wok) s_flag_misc[4] = 1;
         __syncthreads();
+        }
       }
       if (s_flag_misc[4]) {
         dead = true;
         break;
       }
-      uint32_t g_lo = s_red[4][0], g_hi = s_red[5][0];
-      int g_mn = static_cast<int>(s_red[6][0]), g_mx = static_cast<int>(s_red[7][0]);
+      SPX_MARK(3);
+      uint32_t g_lo = s_x1[0][0], g_hi = s_x1[1][0];
+      int g_mn = static_cast<int>(s_x1[2][0]), g_mx = static_cast<int>(s_x1[3][0]);
 #pragma unroll
       for (int wv = 1; wv < kT / 64; ++wv) {
-        g_lo = s_red[4][wv] < g_lo ? s_red[4][wv] : g_lo;
-        g_hi = s_red[5][wv] > g_hi ? s_red[5][wv] : g_hi;
-        g_mn = static_cast<int>(s_red[6][wv]) < g_mn ? static_cast<int>(s_red[6][wv]) : g_mn;
-        g_mx = static_cast<int>(s_red[7][wv]) > g_mx ? static_cast<int>(s_red[7][wv]) : g_mx;
+        g_lo = s_x1[0][wv] < g_lo ? s_x1[0][wv] : g_lo;
+        g_hi = s_x1[1][wv] > g_hi ? s_x1[1][wv] : g_hi;
+        g_mn = static_cast<int>(s_x1[2][wv]) < g_mn ? static_cast<int>(s_x1[2][wv]) : g_mn;
+        g_mx = static_cast<int>(s_x1[3][wv]) > g_mx ? static_cast<int>(s_x1[3][wv]) : g_mx;
       }
       // ---- this node's weighted total
       int total = 0;
@@ -638,6 +669,11 @@ __global__ __launch_bounds__(kT) void k_commit_coop(CoopArgs c) {
         Best mine{total, feasible ? static_cast<int>(n) : -1, feasible ? 1 : 0};
         mine = wave_best(mine);
         const int feas = wave_sum_i32(feasible ? 1 : 0);
+        if (c.n_wg == 1) {
+          if (lane == 0) s_x2[0][wave] = static_cast<uint32_t>(mine.total), s_x2[1][wave] = static_cast<uint32_t>(mine.node), s_x2[2][wave] = static_cast<uint32_t>(mine.ties),
+                         s_x2[3][wave] = static_cast<uint32_t>(feas);
+          __syncthreads();
+        } else {
         if (lane == 0) s_red[0][wave] = static_cast<uint32_t>(mine.total), s_red[1][wave] = static_cast<uint32_t>(mine.node), s_red[2][wave] = static_cast<uint32_t>(mine.ties),
                        s_red[3][wave] = static_cast<uint32_t>(feas);
         __syncthreads();
@@ -660,22 +696,23 @@ __global__ __launch_bounds__(kT) void k_commit_coop(CoopArgs c) {
         theirs = wave_best(theirs);
         const int feas_all = wave_sum_i32(static_cast<int>(v4[3]));
         const bool wok = __ballot(!ok) == 0;
-        __syncthreads();
-        if (lane == 0) s_red[4][wave] = static_cast<uint32_t>(theirs.total), s_red[5][wave] = static_cast<uint32_t>(theirs.node), s_red[6][wave] = static_cast<uint32_t>(theirs.ties),
-                       s_red[7][wave] = static_cast<uint32_t>(feas_all);
+        if (lane == 0) s_x2[0][wave] = static_cast<uint32_t>(theirs.total), s_x2[1][wave] = static_cast<uint32_t>(theirs.node), s_x2[2][wave] = static_cast<uint32_t>(theirs.ties),
+                       s_x2[3][wave] = static_cast<uint32_t>(feas_all);
         if (lane == 0 && !wok) s_flag_misc[4] = 1;
         __syncthreads();
+        }
       }
       if (s_flag_misc[4]) {
         dead = true;
         break;
       }
-      gbest = Best{static_cast<int>(s_red[4][0]), static_cast<int>(s_red[5][0]), static_cast<int>(s_red[6][0])};
-      gfeas = static_cast<int>(s_red[7][0]);
+      SPX_MARK(4);
+      gbest = Best{static_cast<int>(s_x2[0][0]), static_cast<int>(s_x2[1][0]), static_cast<int>(s_x2[2][0])};
+      gfeas = static_cast<int>(s_x2[3][0]);
 #pragma unroll
       for (int wv = 1; wv < kT / 64; ++wv) {
-        merge_best(gbest, Best{static_cast<int>(s_red[4][wv]), static_cast<int>(s_red[5][wv]), static_cast<int>(s_red[6][wv])});
-        gfeas += static_cast<int>(s_red[7][wv]);
+        merge_best(gbest, Best{static_cast<int>(s_x2[0][wv]), static_cast<int>(s_x2[1][wv]), static_cast<int>(s_x2[2][wv])});
+        gfeas += static_cast<int>(s_x2[3][wv]);
       }
     }
     const int win = gbest.node;
@@ -698,6 +735,7 @@ __global__ __launch_bounds__(kT) void k_commit_coop(CoopArgs c) {
           for (int r = 0; r < RM; ++r) {
             if (!((b.nrt_present >> r) & 1u) || r >= a.n_res) continue;
             const int64_t qty = b.nrt_req[r];
+            if (qty == 0) continue;  // nothing to subtract: the derived cells stay as they are
             const bool is_cpu = r == a.cpu_slot;
 #pragma unroll
             for (int z = 0; z < kZ; ++z) {
@@ -716,36 +754,34 @@ __global__ __launch_bounds__(kT) void k_commit_coop(CoopArgs c) {
       if (Q) {  // reserveResource elasticquota.go:89-98; a bound pod that was nominated leaves the nominator
         const int nsid = b.q_ns;
         const bool counted = nsid >= 0 && nsid < NS && q_has[nsid];
-        if (tid == 0) {
-          s_flag_misc[1] = 0;
+        if (wave == 3 && lane < S) {  // one lane per resource slot
+          const int s = lane;
+          int rebuild = 0;
           if (counted) {
-            auto over_min = [&](int m) {
-              bool over = false;
-              for (int s = 0; s < 4; ++s) over |= q_used[m * S + s] > q_min[m * S + s];
-              for (int s = 4; s < S; ++s) {
-                const int64_t yq = ((q_minp[m] >> s) & 1u) ? q_min[m * S + s] : 0;
-                over |= ((q_usedp[m] >> s) & 1u) && q_used[m * S + s] > yq;
-              }
-              return over;
+            auto slot_over_min = [&]() {
+              const int64_t ymin = (s < 4 || ((q_minp[nsid] >> s) & 1u)) ? q_min[nsid * S + s] : 0;
+              return (s < 4 || ((q_usedp[nsid] >> s) & 1u)) && q_used[nsid * S + s] > ymin;
             };
-            const bool before = over_min(nsid);
-            for (int s = 0; s < S; ++s) {
-              q_used[nsid * S + s] = wadd(q_used[nsid * S + s], b.q_req[s]);
-              q_agg[s] = wadd(q_agg[s], b.q_req[s]);
+            const bool before = __ballot(slot_over_min()) != 0;
+            q_used[nsid * S + s] = wadd(q_used[nsid * S + s], b.q_req[s]);
+            q_agg[s] = wadd(q_agg[s], b.q_req[s]);
+            if (s == 0) {
+              q_usedp[nsid] = static_cast<uint8_t>(q_usedp[nsid] | b.q_reqp);
+              q_agg[S] |= static_cast<int64_t>(b.q_reqp);
             }
-            q_usedp[nsid] = static_cast<uint8_t>(q_usedp[nsid] | b.q_reqp);
-            q_agg[S] |= static_cast<int64_t>(b.q_reqp);
             bool was_nominated = false;
             for (int j = q_nom_ptr[nsid]; j < q_nom_ptr[nsid + 1]; ++j)
               if (q_nom_pending[j] == static_cast<int32_t>(pod)) {
-                for (int s = 0; s < S; ++s) q_nomreq[j * S + s] = 0;
-                q_nomreqp[j] = 0;
+                q_nomreq[j * S + s] = 0;
+                if (s == 0) q_nomreqp[j] = 0;
                 was_nominated = true;
               }
             // "nominated requests of the other namespaces whose quota is not over min" changes only when this namespace's own
             // contribution does: its over-min status flipped, or one of its nominated pods just left
-            s_flag_misc[1] = (was_nominated || before != over_min(nsid)) ? 1 : 0;
+            const bool after = __ballot(slot_over_min()) != 0;  // (reads what the eight lanes just wrote: one wave, LDS in order)
+            rebuild = (was_nominated || before != after) ? 1 : 0;
           }
+          if (s == 0) s_flag_misc[1] = rebuild;
         }
         __syncthreads();
         if (s_flag_misc[1]) {  // as k_commit_apply: own[m] per namespace, their total, then total - own[k]
@@ -798,9 +834,17 @@ __global__ __launch_bounds__(kT) void k_commit_coop(CoopArgs c) {
         }
       }
     }
+    SPX_MARK(5);
     land_block(pod + 2, pre);
     __syncthreads();  // the pod block two ahead, the quota state and the grown lists are in place
+    SPX_MARK(6);
   }
+#ifdef SPX_COOP_PROF
+  if (tid == 0 && (wg == 0 || wg == c.n_wg - 1))
+    printf("wg %d: per pod, 10 ns units: quota %llu | stage %llu | eval %llu | exchange1 %llu | total+exchange2 %llu | reserve %llu | land %llu\n", wg,
+           prof[0] / (c.row_end - c.row_begin), prof[1] / (c.row_end - c.row_begin), prof[2] / (c.row_end - c.row_begin), prof[3] / (c.row_end - c.row_begin),
+           prof[4] / (c.row_end - c.row_begin), prof[5] / (c.row_end - c.row_begin), prof[6] / (c.row_end - c.row_begin));
+#endif
 
   if (dead) {
     if (tid == 0) atomicExch(c.err, 1);
