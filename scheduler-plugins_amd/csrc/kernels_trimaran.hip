@@ -339,10 +339,17 @@ __global__ void k_tlp_prepare_fast(TrimaranArgs a, int64_t n_slots, double c1, d
 }
 
 // Decisions-only mode (template flag D): nothing is written to the score tables; each wave folds the weighted sum
-// w_alloc * alloc + w_tlp * tlp of its 64 x NPL nodes into (best total, lowest node with it, how many nodes tie) per pod and
-// leaves that triple in dec.key / dec.ties [tile][row]; k_decide_reduce merges the tiles.  The bytes are the very ones the
-// table mode stores (same code up to the store), so the decisions equal spx_eval + spx_eval_best by construction.
+// w_alloc * alloc + w_tlp * tlp (+ the bytes of further Score-only tables) of its 64 x NPL nodes into ONE 32-bit key per pod,
+//     key = total << 11 | (1024 - node's index in the tile),        0 = no node of the tile is a node
+// so that "highest total, lowest node" is a plain unsigned maximum: per cell one v_mad_u32_u24 on the byte the table mode would
+// have stored (the cell code up to that byte is shared, so the decisions equal spx_eval + spx_eval_best by construction), the
+// lane's maximum by v_max3, the wave's by four DPP row steps and a scalar combine, and the tie count as scalar population counts
+// of "key > best total << 11" — no cross-lane traffic.  dec.key / dec.ties [tile][row]; k_decide_reduce merges the tiles.
+// Round 3's form (per-cell int accumulators, 64-bit keys, three 6-step ds_bpermute butterflies per row; 175 VGPRs, 2 waves per
+// SIMD) took 0.84 ms for 10k x 100k against the table mode's 0.41.  The launcher takes this form when every weighted total fits
+// 21 bits (sum of the weights <= 8000), otherwise the tables are written and k_best reads them.
 constexpr int kDecideExtras = 3;
+constexpr int kKeyShift = 11;
 struct DecideArgs {
   int32_t w_alloc, w_tlp;
   // score tables of further Score-only plugins of the profile, already evaluated for these rows (LVRB, LowRiskOverCommitment,
@@ -351,10 +358,30 @@ struct DecideArgs {
   int32_t n_extra;
   int32_t w_extra[kDecideExtras];
   const uint8_t* extra[kDecideExtras];  // [pods][row_stride]
-  uint64_t* key;   // [n_tiles][rows]: (total + 1) << 32 | (0xffffffff - node); 0 = no node in the tile
-  int32_t* ties;   // [n_tiles][rows]
+  uint32_t* key;   // [n_tiles][rows]
+  int32_t* ties;   // [n_tiles][rows]: cells of the tile reaching the tile's best total
   int64_t rows;
 };
+
+// every lane of a 16-lane row ends with the row's maximum (DPP quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror); the four
+// rows are combined on the scalar unit.  Every lane must be live.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dmax_dpp(uint32_t v) {
+  const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xf, 0xf, true));
+  return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+  v = dmax_dpp<0xB1>(v);
+  v = dmax_dpp<0x4E>(v);
+  v = dmax_dpp<0x141>(v);
+  v = dmax_dpp<0x140>(v);
+  const uint32_t r0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 0));
+  const uint32_t r1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 16));
+  const uint32_t r2 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 32));
+  const uint32_t r3 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 48));
+  const uint32_t a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+  return a > b ? a : b;
+}
 
 // Exactness bookkeeping (spx_fetch_stats): each lane counts the cells it re-evaluated; the wave adds them up once, at its
 // end, into one of kStatSlots counters per plugin.  One atomic per (rare) cell on a single address cost the config #2 sweep
@@ -386,7 +413,7 @@ __device__ __forceinline__ uint32_t tlp_cell_exact(const TrimaranArgs& a, int64_
 }
 
 template <int NPL, bool A, bool D = false>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArgs a, int n_tiles, double c1, double c2, DecideArgs dec) {
+__global__ __launch_bounds__(kWave* kWavesPerBlock, D ? 3 : 1) void k_tlp_fast2(TrimaranArgs a, int n_tiles, double c1, double c2, DecideArgs dec) {
   SPX_RESOLVE_ROWS(a);
   static_assert(kPodsPerChunk == kWave, "one pod record per lane");
   const int lane = threadIdx.x & (kWave - 1);
@@ -418,6 +445,23 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
 #pragma unroll
     for (int j = 0; j < NPL / 4; ++j) alloc_w[j] = active ? reinterpret_cast<const uint32_t*>(a.alloc_norm + node0)[j] : 0u;
   }
+  // decisions-only mode: per node (w_alloc * Allocatable's byte) << 11 | 1024 - (index in the tile), 0 for a slot past the node
+  // list (its TLP constants score 0, so its key stays 0); which bytes of a row's 16 are nodes (masks the other tables' padding)
+  uint32_t cbase[D ? NPL : 1], inmask[D ? NPL / 4 : 1];
+  if constexpr (D) {
+    static_assert(kWave * NPL <= 1024, "the in-tile index takes the key's low 11 bits");
+#pragma unroll
+    for (int j = 0; j < NPL / 4; ++j) inmask[j] = 0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const bool in = active && node0 + i < a.n_nodes;
+      uint32_t ab = 0;
+      if constexpr (A) ab = (alloc_w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+      cbase[i] = in ? ((static_cast<uint32_t>(dec.w_alloc) * ab) << kKeyShift) | (1024u - static_cast<uint32_t>(lane * NPL + i)) : 0u;
+      inmask[i >> 2] |= in ? 0xffu << (8 * (i & 3)) : 0u;
+    }
+  }
+  const uint32_t wt_sh = D ? static_cast<uint32_t>(dec.w_tlp) << kKeyShift : 0u;
   static_assert(NPL == kTlpNpl, "k_tlp_prepare_fast lays the constants out for this NPL");
   {
     const float4* tab = reinterpret_cast<const float4*>(a.tlp_fast) + static_cast<int64_t>(tile) * NPL * kWave + lane;
@@ -461,6 +505,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
     // cell) instead of 32 compares and a chain of lane-mask ORs; NaN cells (nodes outside the float32 range) are
     // invisible to max/min and are flagged per lane by lane_nan
     float worst = 0.0f, minu = 1e30f;
+    uint32_t tb[D ? NPL : 1];  // decisions-only mode: the byte of each cell on its own (the table mode packs four per dword)
 #pragma unroll
     for (int j = 0; j < NPL / 4; ++j) {
       uint32_t acc = 0;
@@ -475,7 +520,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
         const float rr = __builtin_rintf(x);
         worst = __builtin_fmaxf(worst, __builtin_fabsf(x - rr));
         minu = __builtin_fminf(minu, __builtin_fabsf(u));
-        acc = __builtin_amdgcn_cvt_pk_u8_f32(rr, q, acc);
+        if constexpr (D) tb[i] = __builtin_amdgcn_cvt_pk_u8_f32(rr, 0, 0u);
+        else acc = __builtin_amdgcn_cvt_pk_u8_f32(rr, q, acc);
       }
       w[j] = acc;
     }
@@ -497,53 +543,44 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
             ++reevaluated;
             b = tlp_cell_exact(a, n, pod_milli);
           }
-          const int sh = (i & 3) * 8;
-          w[i >> 2] = (w[i >> 2] & ~(0xffu << sh)) | (b << sh);
+          if constexpr (D) {
+            tb[i] = b;
+          } else {
+            const int sh = (i & 3) * 8;
+            w[i >> 2] = (w[i >> 2] & ~(0xffu << sh)) | (b << sh);
+          }
         }
       }
     }
     if constexpr (!D) {
       if (active) store_bytes<NPL>(a.out_tlp + row, w);
     } else {
-      // lane: best weighted total over its NPL nodes, the lowest node index reaching it, and the tie count
-      int best = -1, best_j = 0, ties = 0;
-      int ext[NPL];
+      // one key per cell: total << 11 | 1024 - index in the tile (the cells' registers are reused)
 #pragma unroll
-      for (int i = 0; i < NPL; ++i) ext[i] = 0;
+      for (int i = 0; i < NPL; ++i) tb[i] = __umul24(tb[i], wt_sh) + cbase[i];
       for (int x = 0; x < dec.n_extra; ++x) {
+        const uint32_t wx = static_cast<uint32_t>(dec.w_extra[x]) << kKeyShift;
         uint32_t xw[NPL / 4];
 #pragma unroll
-        for (int j = 0; j < NPL / 4; ++j) xw[j] = active ? reinterpret_cast<const uint32_t*>(dec.extra[x] + row)[j] : 0u;
-        const int wx = dec.w_extra[x];
+        for (int j = 0; j < NPL / 4; ++j) xw[j] = active ? reinterpret_cast<const uint32_t*>(dec.extra[x] + row)[j] & inmask[j] : 0u;
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) ext[i] += wx * static_cast<int>((xw[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        for (int i = 0; i < NPL; ++i) tb[i] += __umul24((xw[i >> 2] >> (8 * (i & 3))) & 0xffu, wx);
       }
+      uint32_t kmax = 0;
 #pragma unroll
-      for (int i = 0; i < NPL; ++i) {
-        const int tb = static_cast<int>((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
-        int ab = 0;
-        if constexpr (A) ab = static_cast<int>((alloc_w[i >> 2] >> (8 * (i & 3))) & 0xffu);
-        const bool in = active && node0 + i < a.n_nodes;
-        const int tot = in ? dec.w_tlp * tb + dec.w_alloc * ab + ext[i] : -1;
-        if (tot > best) best = tot, best_j = i, ties = 1;
-        else if (tot == best) ++ties;
+      for (int i = 0; i < NPL; ++i) kmax = tb[i] > kmax ? tb[i] : kmax;
+      // wave: every lane is live here (see the note above the loop)
+      const uint32_t wkey = wave_umax(kmax);
+      // cells of the tile reaching its best total: scalar population counts of the per-cell compare masks
+      int t = 0;
+      if (wkey != 0u) {
+        const uint32_t thr = wkey & ~((1u << kKeyShift) - 1u);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) t += __builtin_popcountll(__ballot(tb[i] > thr));  // (a node's low bits are >= 1: a slot past the list, key 0, never counts)
       }
-      // wave: every lane is live here (see the note above the loop), so plain butterflies are safe
-      uint64_t key = (static_cast<uint64_t>(static_cast<uint32_t>(best + 1)) << 32) |
-                     (0xffffffffu - static_cast<uint32_t>(node0 + best_j));
-      if (best < 0) key = 0;
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) {
-        const uint64_t o = shfl_xor_u64(key, m);
-        key = o > key ? o : key;
-      }
-      const int wbest = static_cast<int>(key >> 32) - 1;
-      int t = (best == wbest && best >= 0) ? ties : 0;
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
       if (lane == 0) {
         const int64_t slot = static_cast<int64_t>(tile) * dec.rows + (pod0 + r - a.row_begin);
-        dec.key[slot] = key;
+        dec.key[slot] = wkey;
         dec.ties[slot] = t;
       }
     }
@@ -551,25 +588,28 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_tlp_fast2(TrimaranArg
   flush_stats(a.stats, SPX_PLUGIN_TLP, reevaluated, unit);
 }
 
-// merges the per-tile triples of the decisions-only sweep into the layout spx_fetch_best reads
+// merges the per-tile (key, tie count) pairs of the decisions-only sweep into the layout spx_fetch_best reads: the best total, the
+// lowest tile holding it (= the lowest node), the tie counts of every tile holding it
 __global__ void k_decide_reduce(DecideArgs dec, int n_tiles, int64_t row_begin, int64_t n_nodes, int64_t* best_score, int32_t* best_node,
                                 int32_t* best_ties, int32_t* best_feasible) {
   const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= dec.rows) return;
-  uint64_t key = 0;
+  uint32_t best = 0;
+  int best_tile = -1;
   for (int t = 0; t < n_tiles; ++t) {
-    const uint64_t k = dec.key[static_cast<int64_t>(t) * dec.rows + r];
-    key = k > key ? k : key;
+    const uint32_t k = dec.key[static_cast<int64_t>(t) * dec.rows + r];
+    if (k != 0u && (best_tile < 0 || (k >> kKeyShift) > (best >> kKeyShift))) best = k, best_tile = t;
   }
   int32_t ties = 0;
   for (int t = 0; t < n_tiles; ++t) {
     const int64_t slot = static_cast<int64_t>(t) * dec.rows + r;
-    if ((dec.key[slot] >> 32) == (key >> 32)) ties += dec.ties[slot];
+    const uint32_t k = dec.key[slot];
+    if (best_tile >= 0 && k != 0u && (k >> kKeyShift) == (best >> kKeyShift)) ties += dec.ties[slot];
   }
   const int64_t pod = row_begin + r;
-  const bool any = key != 0;
-  best_score[pod] = any ? static_cast<int64_t>(key >> 32) - 1 : 0;
-  best_node[pod] = any ? static_cast<int32_t>(0xffffffffu - static_cast<uint32_t>(key)) : -1;
+  const bool any = best_tile >= 0;
+  best_score[pod] = any ? static_cast<int64_t>(best >> kKeyShift) : 0;
+  best_node[pod] = any ? best_tile * (kWave * kTlpNpl) + static_cast<int32_t>(1024u - (best & ((1u << kKeyShift) - 1u))) : -1;
   best_ties[pod] = any ? ties : 0;
   best_feasible[pod] = static_cast<int32_t>(n_nodes);
 }
@@ -879,7 +919,7 @@ void launch_trimaran(const TrimaranArgs& a, hipStream_t s) {
 
 size_t decide_scratch_bytes(int64_t row_stride, int64_t rows) {
   const int n_tiles = static_cast<int>((row_stride + kWave * kTlpNpl - 1) / (kWave * kTlpNpl));
-  return static_cast<size_t>(n_tiles) * static_cast<size_t>(rows) * (sizeof(uint64_t) + sizeof(int32_t));
+  return static_cast<size_t>(n_tiles) * static_cast<size_t>(rows) * (sizeof(uint32_t) + sizeof(int32_t));
 }
 
 void launch_decide_trimaran(const DecideLaunch& d, hipStream_t s) {
@@ -899,7 +939,7 @@ void launch_decide_trimaran(const DecideLaunch& d, hipStream_t s) {
   dec.w_tlp = d.w_tlp;
   dec.n_extra = d.n_extra;
   for (int x = 0; x < kDecideExtras; ++x) dec.w_extra[x] = d.w_extra[x], dec.extra[x] = d.extra[x];
-  dec.key = static_cast<uint64_t*>(d.scratch);
+  dec.key = static_cast<uint32_t*>(d.scratch);
   dec.ties = reinterpret_cast<int32_t*>(dec.key + static_cast<int64_t>(n_tiles) * rows);
   dec.rows = rows;
   hipLaunchKernelGGL(k_tlp_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots, c1, c2);

@@ -2851,7 +2851,7 @@ int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t r
   const int64_t wa = e->plugin_weight[SPX_PLUGIN_ALLOCATABLE], wt = e->plugin_weight[SPX_PLUGIN_TLP];
   const bool fusable = (plugin_mask & T) && !(plugin_mask & ~(A | T | extra_mask)) && !e->ext_mask && e->tri_nodes && e->tri_pods &&
                        e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && !(launch_opts(e) & spx::kOptTrimaranExact) &&
-                       !e->option[SPX_OPT_DECIDE_UNFUSED] && w_ok && w_sum <= 10000000;
+                       !e->option[SPX_OPT_DECIDE_UNFUSED] && w_ok && w_sum <= 8000;  // (every weighted total in 21 bits: the sweep's 32-bit key)
   int rc;
   if (!fusable) {  // a profile with Filter plugins: see decide_masked
     bool done = false;
