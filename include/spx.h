@@ -745,6 +745,16 @@ int spx_nrt_pod_classes(const spx_engine* e, int64_t* n_unique, int64_t* n_copie
  * or feasibility mask narrows a pod's node list, the same NormalizeScore (peaks.go:150-166). */
 int spx_peaks_pod_classes(const spx_engine* e, int64_t* n_unique, int64_t* n_copies);
 
+/* Object tables -> SoA columns -> device in one call per plugin family: the host flatteners (spx_flatten_*, below) run with the
+ * engine's current plugin parameters and their result is uploaded.  For callers that hold object tables — marshalled by the shim or
+ * decoded by spx_ingest_* — and would rather not size and own the intermediate arrays (the cgo shim: shim/go/pkg/spx/snapshot.go).
+ * spx_load_trimaran serves Allocatable + TargetLoadPacking + LoadVariationRiskBalancing (rc / assigned may be NULL);
+ * spx_load_network also uploads the commit effects spx_commit_sequential needs. */
+int spx_load_trimaran(spx_engine* e, const spx_node_objects* nodes, const spx_resource_classes* rc, const spx_pod_objects* pods, const spx_metrics_objects* metrics, const spx_assigned_objects* assigned);
+int spx_load_nrt(spx_engine* e, const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_resource_classes* rc, const spx_pod_objects* pods, const spx_nrt_params* params);
+int spx_load_network(spx_engine* e, const spx_node_objects* nodes, const spx_pod_objects* pods, const spx_appgroup_objects* appgroups, const spx_nettopo_objects* nettopo);
+int spx_load_quota(spx_engine* e, const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_quota_objects* quota);
+
 /* Which form the last spx_commit_sequential ran: 1 = the one-workgroup chain of the Filter-less profile, 2 = per-pod single-row
  * launches (replayed from a graph), 3 = the cooperative persistent kernel; 0 = none yet */
 int spx_commit_path(const spx_engine* e);

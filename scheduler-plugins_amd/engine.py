@@ -523,6 +523,22 @@ class Engine:
         """0 = generic sweep kernel, 1 = fast formulation (same results)."""
         return int(self._lib.spx_kernel_path(self._h, plugin))
 
+    # ------------------------------------------------------------------ one-call loaders (spx_load_*: flatten + upload inside the library)
+    def load_c(self, snap: dict, nrt_params: Optional[Table] = None) -> None:
+        """the object tables of `snap` (keys as synth.full_snapshot's) through spx_load_trimaran / _nrt / _network / _quota — the calls
+        the cgo shim makes — instead of this module's own flatten_* + upload_* sequences"""
+        L = self._lib
+        ref = lambda t: t.ref() if t is not None else None
+        if "metrics" in snap:
+            self._ck(L.spx_load_trimaran(self._h, snap["nodes"].ref(), ref(snap.get("rc")), snap["pods"].ref(), snap["metrics"].ref(), ref(snap.get("assigned"))))
+        if "nrt" in snap:
+            self._ck(L.spx_load_nrt(self._h, snap["nodes"].ref(), snap["nrt"].ref(), ref(snap.get("rc")), snap["pods"].ref(), nrt_params.ref()))
+        if "appgroups" in snap:
+            self._ck(L.spx_load_network(self._h, snap["nodes"].ref(), snap["pods"].ref(), snap["appgroups"].ref(), snap["nettopo"].ref()))
+        if "quota" in snap:
+            self._ck(L.spx_load_quota(self._h, snap["pods"].ref(), ref(snap.get("rc")), snap["quota"].ref()))
+        self.n_nodes, self.n_pods = snap["nodes"].struct.n_nodes, snap["pods"].struct.n_pods
+
     def commit_path(self) -> int:
         """which form the last commit_sequential ran: 1 one-workgroup trimaran chain, 2 per-pod launches, 3 cooperative kernel"""
         return int(self._lib.spx_commit_path(self._h))

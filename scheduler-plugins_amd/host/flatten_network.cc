@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstddef>
 #include <utility>
+#include <cstring>
 #include <vector>
 
 #include "../../include/spx.h"
@@ -58,13 +59,51 @@ extern "C" int spx_flatten_net_topo(const spx_nettopo_objects* nt, int32_t* regi
 }
 
 
+// The sizing call leaves its result for the fill call that follows it on the same OS thread.  What identifies "the same tables" is
+// their CONTENT, not their addresses: an ingest handle hands out the same table addresses cycle after cycle and batch sizes repeat,
+// and under cgo the two calls of one cycle may land on different OS threads — so a result left behind by an abandoned sizing call
+// could otherwise be served to a later cycle's fill call (round 3's advisor finding: wrong keys, and a heap overflow when the
+// old cycle had more pairs).  A 64-bit fingerprint over every array the builders read costs one pass (~0.1 ms at 62.5k pods)
+// against the 3-6 ms of the rebuild it saves.
+uint64_t fnv(uint64_t h, const void* p, size_t bytes) {
+  const uint64_t* w = static_cast<const uint64_t*>(p);
+  size_t i = 0;
+  for (; i + 8 <= bytes; i += 8) {  // the object tables' arrays are 8-byte aligned (malloc / numpy / std::vector)
+    uint64_t v;
+    std::memcpy(&v, reinterpret_cast<const char*>(p) + i, 8);
+    h = (h ^ v) * 0x100000001b3ull;
+    h ^= h >> 29;
+  }
+  (void)w;
+  for (; i < bytes; ++i) h = (h ^ reinterpret_cast<const unsigned char*>(p)[i]) * 0x100000001b3ull;
+  return h;
+}
+uint64_t net_fingerprint(const spx_pod_objects* pods, const spx_appgroup_objects* ag) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  const size_t P = static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 0), G = static_cast<size_t>(ag->n_groups > 0 ? ag->n_groups : 0);
+  h = fnv(h, &pods->n_pods, sizeof pods->n_pods);
+  h = fnv(h, &ag->n_groups, sizeof ag->n_groups);
+  if (P) h = fnv(h, pods->appgroup, P * 4), h = fnv(h, pods->selector, P * 4);
+  if (G) {
+    h = fnv(h, ag->wl_ptr, (G + 1) * 4), h = fnv(h, ag->topo_ptr, (G + 1) * 4), h = fnv(h, ag->placed_ptr, (G + 1) * 4);
+    const size_t W = static_cast<size_t>(ag->wl_ptr[G]), T = static_cast<size_t>(ag->topo_ptr[G]), S = static_cast<size_t>(ag->placed_ptr[G]);
+    if (W) {
+      h = fnv(h, ag->wl_selector, W * 4), h = fnv(h, ag->dep_ptr, (W + 1) * 4);
+      const size_t D = static_cast<size_t>(ag->dep_ptr[W]);
+      if (D) h = fnv(h, ag->dep_selector, D * 4), h = fnv(h, ag->dep_max_cost, D * 8);
+    }
+    if (T) h = fnv(h, ag->topo_selector, T * 4), h = fnv(h, ag->topo_index, T * 4);
+    if (S) h = fnv(h, ag->placed_selector, S * 4), h = fnv(h, ag->placed_node, S * 4);
+  }
+  return h ? h : 1;  // 0 = "nothing cached"
+}
+
 namespace {
 // Everything spx_flatten_net_keys returns, computed in one pass.  The C entry point is called twice per batch (sizes, then the
 // arrays): the sizing call leaves its result here, per calling thread, and the fill call that follows it with the same tables
 // copies it out instead of repeating the pass.
 struct NetKeys {
-  const void *pods = nullptr, *ag = nullptr;
-  int64_t n_pods = -1;
+  uint64_t fp = 0;  // net_fingerprint of the tables the vectors were built from; 0 = nothing cached
   std::vector<int32_t> pod_key, topo_order, pair_ptr, pair_node;
   std::vector<int64_t> pair_max_cost;
   std::vector<uint8_t> key_score_equally;
@@ -73,7 +112,7 @@ thread_local NetKeys tl_net_keys;
 
 void build_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag, NetKeys& k) {
   const size_t P = static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 0);
-  k.pods = pods, k.ag = ag, k.n_pods = pods->n_pods;
+  k.fp = 0;  // set by the caller once the build is complete
   k.pod_key.assign(P, 0), k.topo_order.assign(P, -1);
   k.pair_ptr.assign(1, 0), k.pair_node.clear(), k.pair_max_cost.clear(), k.key_score_equally.clear();
   // (AppGroup, workload selector) -> key id, in order of first appearance.  A group has a handful of workloads: its keys sit in
@@ -140,8 +179,13 @@ extern "C" int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgr
   if (!pods || !ag || !n_keys_out || !n_pairs_out) return SPX_ERR_ARG;
   const bool fill = pod_key && topo_order && key_score_equally && pair_ptr && pair_node && pair_max_cost;
   NetKeys& k = tl_net_keys;
-  // a fill call right after the sizing call for the same tables (the documented sequence) reuses that pass
-  if (!(fill && k.pods == pods && k.ag == ag && k.n_pods == pods->n_pods)) build_net_keys(pods, ag, k);
+  // a fill call after the sizing call for tables of the same CONTENT (the documented sequence) reuses that pass; a sizing call
+  // always rebuilds
+  const uint64_t fp = net_fingerprint(pods, ag);
+  if (!(fill && k.fp == fp)) {
+    build_net_keys(pods, ag, k);
+    k.fp = fp;
+  }
   *n_keys_out = static_cast<int32_t>(k.key_score_equally.size());
   *n_pairs_out = static_cast<int64_t>(k.pair_node.size());
   if (k.pair_node.size() > static_cast<size_t>(INT32_MAX)) return SPX_ERR_ARG;
@@ -166,8 +210,7 @@ extern "C" int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgr
 namespace {
 // computed in one pass; the sizing call leaves it for the fill call that follows (as spx_flatten_net_keys does)
 struct NetCommit {
-  const void *pods = nullptr, *ag = nullptr;
-  int64_t n_pods = -1;
+  uint64_t fp = 0;
   std::vector<int32_t> eff_ptr, eff_key;
   std::vector<int64_t> eff_cost;
 };
@@ -175,7 +218,7 @@ thread_local NetCommit tl_net_commit;
 
 void build_net_commit(const spx_pod_objects* pods, const spx_appgroup_objects* ag, NetCommit& out) {
   const size_t P = static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 0);
-  out.pods = pods, out.ag = ag, out.n_pods = pods->n_pods;
+  out.fp = 0;
   out.eff_ptr.assign(1, 0), out.eff_ptr.reserve(P + 1);
   out.eff_key.clear(), out.eff_cost.clear();
   // key ids in order of first appearance, per group a short list (selector, key) — the numbering of spx_flatten_net_keys
@@ -235,7 +278,11 @@ extern "C" int spx_flatten_net_commit(const spx_pod_objects* pods, const spx_app
   if (!pods || !ag || !n_entries_out) return SPX_ERR_ARG;
   const bool fill = eff_ptr && eff_key && eff_cost;
   NetCommit& k = tl_net_commit;
-  if (!(fill && k.pods == pods && k.ag == ag && k.n_pods == pods->n_pods)) build_net_commit(pods, ag, k);
+  const uint64_t fp = net_fingerprint(pods, ag);
+  if (!(fill && k.fp == fp)) {
+    build_net_commit(pods, ag, k);
+    k.fp = fp;
+  }
   if (k.eff_key.size() > static_cast<size_t>(INT32_MAX)) return SPX_ERR_ARG;
   *n_entries_out = static_cast<int64_t>(k.eff_key.size());
   if (fill) {

@@ -4,16 +4,18 @@
 
 usage: apply_shim.py <checkout of kubernetes-sigs/scheduler-plugins> <output dir>
 Writes the edited copies of the six files under <output dir> (same relative paths) and prints a summary.  Besides the bodies a
-maintainer adds: the field `spx *spx.Engine` to Allocatable / TargetLoadPacking / TopologyMatch / NetworkOverhead (set in their
-New functions from the profile's engine), `order map[string]int32` to TopologicalSort, the import of pkg/spx (shim/go/pkg/spx),
+maintainer adds: the field `spx *spx.Engine` to Allocatable / TargetLoadPacking / LoadVariationRiskBalancing / TopologyMatch /
+NetworkOverhead / CapacityScheduling (set in their New functions from the profile's engine), `order map[string]int32` to TopologicalSort, the import of pkg/spx (shim/go/pkg/spx),
 and renames the reference's TopologyMatch.Filter body to filterWithVictims for the preemption dry run.  UNCOMPILED: no Go
 toolchain in this image; tests/test_go_shim_apply.py checks that every edit still finds its method in /root/reference.
 
-Reference methods replaced (file:line in the surveyed checkout):
+Reference methods replaced (file:line in the surveyed checkout; twelve bodies in eight files):
   pkg/noderesources/allocatable.go:63 Score, :143 NormalizeScore
   pkg/trimaran/targetloadpacking/targetloadpacking.go:107 Score
+  pkg/trimaran/loadvariationriskbalancing/loadvariationriskbalancing.go:84 Score
+  pkg/capacityscheduling/capacity_scheduling.go:208 PreFilter
   pkg/noderesourcetopology/filter.go:179 Filter, score.go:62 Score
-  pkg/networkaware/networkoverhead/networkoverhead.go:326 Filter, :362 Score, :389 NormalizeScore
+  pkg/networkaware/networkoverhead/networkoverhead.go:174 PreFilter, :326 Filter, :362 Score, :389 NormalizeScore
   pkg/networkaware/topologicalsort/topologicalsort.go:102 Less
 """
 import re
@@ -50,6 +52,34 @@ EDITS = {
 	}
 	return int64(row[pl.spx.Column(nodeInfo.Node().Name)]), nil"""),
     ],
+    "pkg/trimaran/loadvariationriskbalancing/loadvariationriskbalancing.go": [
+        (r"^func \(pl \*LoadVariationRiskBalancing\) Score\([^\n]*\{", """\
+	row, err := pl.spx.ScoreRow(pod, spx.PluginLVRB)
+	if err != nil {
+		return fwk.MinNodeScore, fwk.AsStatus(err)
+	}
+	return int64(row[pl.spx.Column(nodeInfo.Node().Name)]), nil"""),
+    ],
+    "pkg/capacityscheduling/capacity_scheduling.go": [
+        (r"^func \(c \*CapacityScheduling\) PreFilter\([^\n]*\{", """\
+	// the snapshot and the preFilterState stay (PostFilter's preemption reads them); the two cmp2 gates and the nominated-pod
+	// walk (:231-283) were evaluated for the whole pending batch by spx_eval (k_quota)
+	snapshotElasticQuota := c.snapshotElasticQuota()
+	state.Write(ElasticQuotaSnapshotKey, snapshotElasticQuota)
+	podReq := computePodResourceRequest(pod)
+	state.Write(preFilterStateKey, &PreFilterState{podReq: *podReq})
+	verdict, err := c.spx.PreFilter(pod)
+	if err != nil {
+		return nil, fwk.AsStatus(err)
+	}
+	switch verdict {
+	case spx.QuotaOverMax:
+		return nil, fwk.NewStatus(fwk.Unschedulable, fmt.Sprintf("Pod %v/%v is rejected in PreFilter because ElasticQuota %v is more than Max", pod.Namespace, pod.Name, pod.Namespace))
+	case spx.QuotaOverMin:
+		return nil, fwk.NewStatus(fwk.Unschedulable, fmt.Sprintf("Pod %v/%v is rejected in PreFilter because total ElasticQuota used is more than min", pod.Namespace, pod.Name))
+	}
+	return nil, fwk.NewStatus(fwk.Success, "")"""),
+    ],
     "pkg/noderesourcetopology/filter.go": [
         (r"^func \(tm \*TopologyMatch\) Filter\([^\n]*\{", """\
 	if nodeInfo.Node() == nil {
@@ -81,6 +111,17 @@ EDITS = {
 	return int64(row[tm.spx.Column(nodeInfo.Node().Name)]), nil"""),
     ],
     "pkg/networkaware/networkoverhead/networkoverhead.go": [
+        (r"^func \(no \*NetworkOverhead\) PreFilter\([^\n]*\{", """\
+	// the per-pod work of PreFilter — AppGroup / NetworkTopology lookups, the dependency and scheduled lists, the cost map of every
+	// node (:174-298) — happened once for the whole batch when it was flattened (spx_flatten_net_keys) and swept (spx_eval).  What the
+	// reference decides here per pod is whether Filter and Score have anything to do: a pod without AppGroup, a workload without
+	// dependencies or an AppGroup with nothing scheduled yet "scores equally" — the engine's rows carry that (status 0, score 0)
+	preFilterState := &PreFilterState{scoreEqually: true}
+	state.Write(preFilterStateKey, preFilterState)
+	if _, err := no.spx.StatusRow(pod, spx.PluginNetOverhead); err != nil {
+		return nil, fwk.AsStatus(err)
+	}
+	return nil, fwk.NewStatus(fwk.Success, "")"""),
         (r"^func \(no \*NetworkOverhead\) Filter\(ctx context\.Context,\n[^{]*\{", """\
 	if nodeInfo.Node() == nil {
 		return fwk.NewStatus(fwk.Error, "node not found")
@@ -99,11 +140,11 @@ EDITS = {
 	return fwk.NewStatus(fwk.Unschedulable,
 		fmt.Sprintf("Node %v does not meet several network requirements from Workload dependencies: Satisfied: %v Violated: %v", nodeInfo.Node().Name, sat[col], vio[col]))"""),
         (r"^func \(no \*NetworkOverhead\) Score\(ctx context\.Context,\n[^{]*\{", """\
-	row, err := no.spx.RawRow(pod, spx.PluginNetOverhead, 0) // the accumulated cost (getAccumulatedCost :576-638)
+	row, err := no.spx.RawRow(pod, spx.PluginNetOverhead, 0) // the accumulated cost (getAccumulatedCost :576-638); cached per pod
 	if err != nil {
 		return 0, fwk.AsStatus(err)
 	}
-	return row[no.spx.Column(nodeName)], nil"""),
+	return row[no.spx.Column(nodeInfo.Node().Name)], nil"""),
         (r"^func \(no \*NetworkOverhead\) NormalizeScore\(ctx context\.Context,\n[^{]*\{", """\
 	row, err := no.spx.ScoreRow(pod, spx.PluginNetOverhead)
 	if err != nil {

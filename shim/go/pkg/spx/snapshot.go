@@ -7,7 +7,10 @@ package spx
 */
 import "C"
 
-import "unsafe"
+import (
+	"fmt"
+	"unsafe"
+)
 
 // cArray copies a Go slice into C memory (no Go pointer may be retained by, or nested in, what crosses the boundary) and returns
 // the C pointer plus its release function.
@@ -91,15 +94,151 @@ func (e *Engine) UploadTrimaranPods(tlpMilli, reqCPUMilli, reqMem []int64) error
 	return nil
 }
 
-// IngestNRT hands the JSON of a NodeResourceTopology list (or of the objects of a watch batch) to the library instead of
-// marshalling Go structs field by field (pluginhelpers.go:105-161, nodeconfig/topologymanager.go:78-162); the object table it
-// returns feeds spx_flatten_nrt_nodes / spx_flatten_nrt_node_rows + spx_upload_nrt_nodes / spx_update_nrt_nodes.
-func IngestNRT(h *C.spx_ingest, doc []byte) (objects, unknown int64, err error) {
+// Ingest decodes the API server's JSON (NodeResourceTopology, v1.Node, v1.Pod, AppGroup, NetworkTopology, ElasticQuota, the
+// load-watcher response) into the library's object tables — the alternative to marshalling Go structs field by field
+// (pluginhelpers.go:105-161, nodeconfig/topologymanager.go:78-162, networkoverhead.go:448-497, elasticquota.go:48-123).  The
+// tables live inside the handle; Load* hands them to an engine.
+type Ingest struct {
+	h *C.spx_ingest
+}
+
+func cStrings(s []string) (**C.char, func()) {
+	if len(s) == 0 {
+		return nil, func() {}
+	}
+	arr := (**C.char)(C.malloc(C.size_t(len(s)) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	view := unsafe.Slice(arr, len(s))
+	for i, v := range s {
+		view[i] = C.CString(v)
+	}
+	return arr, func() {
+		for _, p := range view {
+			C.free(unsafe.Pointer(p))
+		}
+		C.free(unsafe.Pointer(arr))
+	}
+}
+
+// NewIngest fixes the node order (= snapshot columns) and the resource names the tables will use.
+func NewIngest(nodeNames, resourceNames []string) (*Ingest, error) {
+	nn, freeN := cStrings(nodeNames)
+	defer freeN()
+	rn, freeR := cStrings(resourceNames)
+	defer freeR()
+	var h *C.spx_ingest
+	if rc := C.spx_ingest_create(nn, C.int64_t(len(nodeNames)), rn, C.int32_t(len(resourceNames)), &h); rc != 0 {
+		return nil, fmt.Errorf("spx_ingest_create failed (%d)", int(rc))
+	}
+	return &Ingest{h: h}, nil
+}
+
+func (in *Ingest) Close() { C.spx_ingest_destroy(in.h) }
+
+type ingestFn func(p *C.char, n C.int64_t) C.int
+
+func (in *Ingest) feed(doc []byte, fn ingestFn) error {
 	p := C.CBytes(doc)
 	defer C.free(p)
-	var n, u C.int64_t
-	if rc := C.spx_ingest_nrt_json(h, (*C.char)(p), C.int64_t(len(doc)), &n, &u); rc != 0 {
-		return 0, 0, fmtIngestError(h)
+	if rc := fn((*C.char)(p), C.int64_t(len(doc))); rc != 0 {
+		return fmtIngestError(in.h)
 	}
-	return int64(n), int64(u), nil
+	return nil
+}
+
+// NRT / Nodes / Pods / AppGroups / NetworkTopology / Quotas / Metrics feed one JSON document (a List, or the objects of a watch batch).
+func (in *Ingest) NRT(doc []byte) error {
+	var n, u C.int64_t
+	return in.feed(doc, func(p *C.char, l C.int64_t) C.int { return C.spx_ingest_nrt_json(in.h, p, l, &n, &u) })
+}
+func (in *Ingest) Nodes(doc []byte) error {
+	var n, u C.int64_t
+	return in.feed(doc, func(p *C.char, l C.int64_t) C.int { return C.spx_ingest_nodes_json(in.h, p, l, &n, &u) })
+}
+func (in *Ingest) Pods(doc []byte) error {
+	var n C.int64_t
+	return in.feed(doc, func(p *C.char, l C.int64_t) C.int { return C.spx_ingest_pods_json(in.h, p, l, &n) })
+}
+func (in *Ingest) ResetPods() { C.spx_ingest_pods_reset(in.h) }
+func (in *Ingest) AppGroups(doc []byte) error {
+	var n C.int64_t
+	return in.feed(doc, func(p *C.char, l C.int64_t) C.int { return C.spx_ingest_appgroups_json(in.h, p, l, &n) })
+}
+func (in *Ingest) NetworkTopology(doc []byte, weightsName string) error {
+	w := C.CString(weightsName)
+	defer C.free(unsafe.Pointer(w))
+	return in.feed(doc, func(p *C.char, l C.int64_t) C.int { return C.spx_ingest_nettopo_json(in.h, p, l, w) })
+}
+func (in *Ingest) Quotas(doc []byte, namespaces []string) error {
+	ns, freeNS := cStrings(namespaces)
+	defer freeNS()
+	var n, u C.int64_t
+	return in.feed(doc, func(p *C.char, l C.int64_t) C.int {
+		return C.spx_ingest_quota_json(in.h, p, l, ns, C.int32_t(len(namespaces)), &n, &u)
+	})
+}
+func (in *Ingest) Metrics(doc []byte) error {
+	var n, u C.int64_t
+	return in.feed(doc, func(p *C.char, l C.int64_t) C.int { return C.spx_ingest_metrics_json(in.h, p, l, &n, &u) })
+}
+
+// LoadTrimaran / LoadNRT / LoadNetwork / LoadQuota: object tables -> SoA columns -> device in one library call each (spx_load_*):
+// the flatteners run with the engine's plugin parameters, nothing is sized or owned on the Go side.
+func (e *Engine) LoadTrimaran(in *Ingest) error {
+	if rc := C.spx_load_trimaran(e.h, C.spx_ingest_node_objects(in.h), C.spx_ingest_resource_classes(in.h), C.spx_ingest_pod_objects(in.h),
+		C.spx_ingest_metrics_objects(in.h), nil); rc != 0 {
+		return e.err("spx_load_trimaran")
+	}
+	return nil
+}
+
+// NRTParams is NodeResourceTopologyMatchArgs.ScoringStrategy (apis/config/types.go): Type and the per-resource weights.
+type NRTParams struct {
+	Strategy  int // SPX_NRT_*
+	Resources []string
+	Weights   []int64
+}
+
+func (e *Engine) LoadNRT(in *Ingest, p NRTParams) error {
+	ids := make([]int32, len(p.Resources))
+	for i, r := range p.Resources {
+		cs := C.CString(r)
+		ids[i] = int32(C.spx_ingest_resource_id(in.h, cs))
+		C.free(unsafe.Pointer(cs))
+	}
+	idp, freeID := cArray(ids)
+	defer freeID()
+	wp, freeW := cArray(p.Weights)
+	defer freeW()
+	params := C.spx_nrt_params{strategy: C.int32_t(p.Strategy), n_weights: C.int32_t(len(ids)), weight_res: (*C.int32_t)(idp), weight: (*C.int64_t)(wp)}
+	if rc := C.spx_load_nrt(e.h, C.spx_ingest_node_objects(in.h), C.spx_ingest_nrt_objects(in.h), C.spx_ingest_resource_classes(in.h),
+		C.spx_ingest_pod_objects(in.h), &params); rc != 0 {
+		return e.err("spx_load_nrt")
+	}
+	return nil
+}
+
+func (e *Engine) LoadNetwork(in *Ingest) error {
+	if rc := C.spx_load_network(e.h, C.spx_ingest_node_objects(in.h), C.spx_ingest_pod_objects(in.h), C.spx_ingest_appgroup_objects(in.h),
+		C.spx_ingest_nettopo_objects(in.h)); rc != 0 {
+		return e.err("spx_load_network")
+	}
+	return nil
+}
+
+func (e *Engine) LoadQuota(in *Ingest) error {
+	if rc := C.spx_load_quota(e.h, C.spx_ingest_pod_objects(in.h), C.spx_ingest_resource_classes(in.h), C.spx_ingest_quota_objects(in.h)); rc != 0 {
+		return e.err("spx_load_quota")
+	}
+	return nil
+}
+
+// UploadFeasibleMask tells the engine which (pod, node) cells passed the Filter plugins that run OUTSIDE it (upstream's in-tree
+// filters): NormalizeScore-type plugins then normalise over those cells only, as RunScorePlugins does.  mask[p*nNodes+n] != 0 = feasible.
+func (e *Engine) UploadFeasibleMask(mask []uint8, nPods, nNodes int64) error {
+	p, free := cArray(mask)
+	defer free()
+	if rc := C.spx_upload_feasible_mask(e.h, (*C.uint8_t)(p), C.int64_t(nPods), C.int64_t(nNodes)); rc != 0 {
+		return e.err("spx_upload_feasible_mask")
+	}
+	return nil
 }

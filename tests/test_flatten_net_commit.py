@@ -106,3 +106,39 @@ def test_sizing_result_is_reused_once_and_only_for_the_same_tables():
     nk, npairs = C.c_int32(), C.c_int64()
     assert lib.spx_flatten_net_keys(a["pods"].ref(), a["appgroups"].ref(), C.byref(nk), C.byref(npairs), None, None, None, None, None, None) == 0
     assert np.array_equal(_keys(lib, b["pods"], b["appgroups"]), kb) and np.array_equal(_keys(lib, a["pods"], a["appgroups"]), ka)
+
+
+def test_sizing_result_is_not_served_to_tables_that_changed_in_place():
+    """The advisor's scenario (round 3): an ingest handle hands out the SAME table addresses every cycle and the batch size repeats.
+    A sizing call of cycle 1 that is never followed by its fill call (or whose fill lands on another OS thread under cgo) must not be
+    served to cycle 2's fill call: the cache is keyed on the tables' content, so contents changed in place count as other tables."""
+    hdr, lib = spx.header(), spx.lib()
+    a = synth.network_snapshot(hdr, 40, 300, seed=5)
+    i32p, i64p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)
+    P = a["pods"].struct.n_pods
+    n = C.c_int64()
+    nk, npairs = C.c_int32(), C.c_int64()
+    # cycle 1: sizing calls, never filled
+    assert lib.spx_flatten_net_commit(a["pods"].ref(), a["appgroups"].ref(), C.byref(n), None, None, None) == 0
+    assert lib.spx_flatten_net_keys(a["pods"].ref(), a["appgroups"].ref(), C.byref(nk), C.byref(npairs), None, None, None, None, None, None) == 0
+    old_key = _keys(lib, a["pods"], a["appgroups"]).copy()
+    assert lib.spx_flatten_net_keys(a["pods"].ref(), a["appgroups"].ref(), C.byref(nk), C.byref(npairs), None, None, None, None, None, None) == 0
+    # cycle 2: the same table objects (same addresses, same n_pods) hold another batch
+    for name in ("appgroup", "selector"):
+        col = a["pods"].array(name)
+        col[:] = np.roll(col, 7)
+    # fill-only calls, as a caller whose sizing call ran on another OS thread would issue them (room for any result)
+    room = 8 * max(n.value, 1) + 64
+    ptr, key, cost = np.zeros(P + 1, np.int32), np.zeros(room, np.int32), np.zeros(room, np.int64)
+    got_n = C.c_int64()
+    assert lib.spx_flatten_net_commit(a["pods"].ref(), a["appgroups"].ref(), C.byref(got_n), ptr.ctypes.data_as(i32p), key.ctypes.data_as(i32p),
+                                      cost.ctypes.data_as(i64p)) == 0
+    pod_key, topo = np.zeros(P, np.int32), np.zeros(P, np.int32)
+    se, pp = np.zeros(P + 1, np.uint8), np.zeros(P + 2, np.int32)
+    pn, pc = np.zeros(8 * max(npairs.value, 1) + 64, np.int32), np.zeros(8 * max(npairs.value, 1) + 64, np.int64)
+    assert lib.spx_flatten_net_keys(a["pods"].ref(), a["appgroups"].ref(), C.byref(nk), C.byref(npairs), pod_key.ctypes.data_as(i32p), topo.ctypes.data_as(i32p),
+                                    se.ctypes.data_as(u8p), pp.ctypes.data_as(i32p), pn.ctypes.data_as(i32p), pc.ctypes.data_as(i64p)) == 0
+    want = _commit(lib, a["pods"], a["appgroups"])          # sizing + fill: a fresh computation on the current contents
+    want_key = _keys(lib, a["pods"], a["appgroups"])
+    assert got_n.value == want[0] and np.array_equal(ptr, want[1]) and np.array_equal(key[:got_n.value], want[2][:got_n.value])
+    assert np.array_equal(pod_key, want_key) and not np.array_equal(pod_key, old_key)

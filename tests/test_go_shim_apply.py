@@ -16,7 +16,7 @@ def test_every_edit_applies(tmp_path):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     done = mod.apply(REF, tmp_path)
-    assert sum(n for _, n in done) == 9 and len(done) == 6
+    assert sum(n for _, n in done) == 12 and len(done) == 8
     for rel, _ in done:
         new = (tmp_path / rel).read_text()
         assert new.count("{") == new.count("}")
@@ -34,3 +34,141 @@ def test_shim_sources_name_only_exported_entry_points():
             assert re.search(rf"\b{name}\(", hdr), (f.name, name)
         for const in set(re.findall(r"C\.(SPX_[A-Z_0-9]+)", f.read_text())):
             assert re.search(rf"#define {const}\b", hdr), (f.name, const)
+
+
+# ---- what a compiler would have caught (round 3: an undefined identifier in a replacement body): every identifier a body uses
+# freely — not as a selector's field, not declared in the body — must be a parameter or the receiver of the matched signature, a
+# package-level name of the package the file belongs to, an imported package, or a Go predeclared name.
+GO_KEYWORDS = set("break case chan const continue default defer else fallthrough for func go goto if import interface map package range return "
+                  "select struct switch type var".split())
+GO_PREDECLARED = set("bool byte complex64 complex128 error float32 float64 int int8 int16 int32 int64 rune string uint uint8 uint16 uint32 uint64 uintptr any "
+                     "true false iota nil append cap clear close complex copy delete imag len make max min new panic print println real recover".split())
+
+
+def _go_tokens(src):
+    import sys
+    sys.path.insert(0, str(ROOT / "tests" / "golden"))
+    import goparse
+    return goparse.tokenize(src)
+
+
+def _strip(src):
+    import re
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r'"(?:\\.|[^"\\])*"', '""', src)
+    return re.sub(r"`[^`]*`", '""', src)
+
+
+def _free_identifiers(body):
+    """identifiers used in `body` that are neither selectors' right-hand sides, struct-literal keys, nor declared inside it"""
+    import re
+    b = _strip(body)
+    declared = set()
+    for m in re.finditer(r"([A-Za-z_][\w, ]*?)\s*:=", b):          # a, b := ...  (also `for i, x := range`)
+        declared.update(x.strip().split()[-1] for x in m.group(1).split(",") if x.strip())  # (`for i, x := range`: the last word of each part)
+    for m in re.finditer(r"\bvar\s+((?:[A-Za-z_]\w*\s*,\s*)*[A-Za-z_]\w*)", b):   # var a, b T
+        declared.update(x.strip() for x in m.group(1).split(","))
+    for m in re.finditer(r"\bfunc\s*\(([^)]*)\)", b):              # parameters of function literals
+        for part in m.group(1).split(","):
+            names = part.strip().split()
+            if names:
+                declared.add(names[0].lstrip("*"))
+    used = set()
+    for m in re.finditer(r"(?<![\w.])([A-Za-z_]\w*)", b):
+        name = m.group(1)
+        after = b[m.end():m.end() + 2].lstrip()
+        if after.startswith(":") and not after.startswith(":="):    # struct literal key / label
+            continue
+        used.add(name)
+    return {u for u in used if u not in declared and u not in GO_KEYWORDS and u not in GO_PREDECLARED}
+
+
+def _package_names(pkg_dir):
+    import re
+    names = set()
+    for f in pkg_dir.glob("*.go"):
+        if f.name.endswith("_test.go"):
+            continue
+        t = _strip(f.read_text())
+        names.update(re.findall(r"^func\s+([A-Za-z_]\w*)", t, re.M))
+        names.update(re.findall(r"^type\s+([A-Za-z_]\w*)", t, re.M))
+        names.update(re.findall(r"^(?:var|const)\s+([A-Za-z_]\w*)", t, re.M))
+        for blk in re.findall(r"^(?:var|const)\s*\((.*?)^\)", t, re.M | re.S):
+            names.update(re.findall(r"^\s*([A-Za-z_]\w*)", blk, re.M))
+        for blk in re.findall(r"^type\s*\((.*?)^\)", t, re.M | re.S):
+            names.update(re.findall(r"^\s*([A-Za-z_]\w*)", blk, re.M))
+    return names
+
+
+def _imports(text):
+    import re
+    out = set()
+    for blk in re.findall(r"^import\s*\((.*?)^\)", text, re.M | re.S) + re.findall(r'^import\s+([^\n(]+)$', text, re.M):
+        for line in blk.splitlines():
+            m = re.match(r'\s*(?:([A-Za-z_]\w*)\s+)?"([^"]+)"', line)
+            if m:
+                out.add(m.group(1) or m.group(2).rsplit("/", 1)[-1])
+    return out
+
+
+def _signature_names(sig_text):
+    """receiver and parameter names of `func (r *T) M(a, b T1, c T2) ...`"""
+    import re
+    names = set()
+    for group in re.findall(r"\(([^()]*)\)", sig_text)[:2]:
+        for part in group.split(","):
+            toks = part.strip().split()
+            if toks:
+                names.add(toks[0].lstrip("*"))
+    return names
+
+
+@pytest.mark.skipif(not REF.exists(), reason="the reference checkout only exists in the build container")
+def test_replacement_bodies_use_only_declared_identifiers():
+    import re
+    spec = importlib.util.spec_from_file_location("apply_shim", ROOT / "shim" / "go" / "apply_shim.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    checked = 0
+    for rel, edits in mod.EDITS.items():
+        text = (REF / rel).read_text()
+        known = _package_names((REF / rel).parent) | _imports(text) | {"spx", "fmt", "fwk"}
+        for sig, body in edits:
+            m = re.search(sig, text, re.M | re.S)
+            assert m, (rel, sig)
+            free = _free_identifiers(body) - known - _signature_names(m.group(0))
+            assert not free, (rel, m.group(0)[:60], sorted(free))
+            checked += 1
+    assert checked == 12
+    # the defect round 3 shipped is caught: `nodeName` is a local of the body that was replaced
+    no = mod.EDITS["pkg/networkaware/networkoverhead/networkoverhead.go"]
+    sig = [s for s, _ in no if "Score" in s][0]
+    text = (REF / "pkg/networkaware/networkoverhead/networkoverhead.go").read_text()
+    m = re.search(sig, text, re.M | re.S)
+    bad = "\treturn row[no.spx.Column(nodeName)], nil"
+    known = _package_names((REF / "pkg/networkaware/networkoverhead")) | _imports(text) | {"spx", "fmt", "fwk"}
+    assert "nodeName" in _free_identifiers(bad) - known - _signature_names(m.group(0))
+
+
+def test_shim_package_uses_only_declared_identifiers():
+    """the cgo package itself: every free identifier of a function body is a parameter, a package-level name, an import or `C`"""
+    import re
+    pkg = ROOT / "shim" / "go" / "pkg" / "spx"
+    known = _package_names(pkg) | {"C"}
+    for f in pkg.glob("*.go"):
+        known |= _imports(f.read_text())
+    for f in pkg.glob("*.go"):
+        t = _strip(f.read_text())
+        for m in re.finditer(r"^func\s*(\([^)]*\))?\s*[A-Za-z_]\w*(?:\[[^\]]*\])?\s*\([^)]*\)[^{\n]*\{", t, re.M):
+            start = m.end() - 1
+            depth, i = 0, start
+            while True:
+                depth += t[i] == "{"
+                depth -= t[i] == "}"
+                if depth == 0:
+                    break
+                i += 1
+            generic = set(re.findall(r"\[([A-Za-z_]\w*)\s", m.group(0)))  # type parameters: func cArray[T any]
+            free = _free_identifiers(t[start:i + 1]) - known - _signature_names(m.group(0)) - generic
+            assert not free, (f.name, m.group(0)[:70], sorted(free))

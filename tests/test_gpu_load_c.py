@@ -1,0 +1,43 @@
+"""spx_load_* (object tables -> SoA -> device inside the library, the calls the cgo shim makes) leave the engine in the state the
+ctypes binding's own flatten + upload sequences leave it in: every table of the full profile, the decisions and the one-pod-at-a-time
+commit loop agree."""
+import numpy as np
+import pytest
+
+from helpers import ALLOCATABLE, CAPACITY, LVRB, NETOVERHEAD, NRT, TLP
+from scheduler_plugins_amd import objects as O
+from scheduler_plugins_amd import synth
+from scheduler_plugins_amd.engine import Engine, mask_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("strategy", ["LeastAllocated", "BalancedAllocation"])
+def test_load_c_equals_python_loaders(gpu_required, hdr, strategy):
+    snap = synth.full_snapshot(hdr, 700, 400, seed=5, quota_sized_for_batch=True)
+    params = O.nrt_params(hdr, O.Resources(), strategy)
+    mask = mask_of(ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY)
+    out = []
+    for via_c in (False, True):
+        with Engine(0) as e:
+            if via_c:
+                e.load_c(snap, params)
+            else:
+                e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+                e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+                e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+                e.load_quota_objects(snap["pods"], snap["rc"], snap["quota"])
+            e.eval(mask)
+            e.sync()
+            tables = {("score", p): e.all_scores(p) for p in (ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD)}
+            tables.update({("status", p): e.all_status(p) for p in (NRT, NETOVERHEAD)})
+            tables["prefilter"] = e.prefilter(CAPACITY)
+            e.eval_best(mask)
+            tables["best"] = np.stack([np.asarray(x, dtype=np.int64) for x in e.best()])
+            node, score, ties, missing = e.commit_sequential(mask, 0, 120)
+            tables["commit"] = np.stack([node.astype(np.int64), score, ties.astype(np.int64)])
+            tables["missing"] = missing
+            out.append(tables)
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), k
+    assert (out[0]["prefilter"] != 0).any() and (out[0][("status", NRT)] != 0).any()
