@@ -53,6 +53,12 @@ WORKLOADS = {
                          desc="noderesourcetopology Filter+Score (MostAllocated), 5k nodes x 8 NUMA zones x 50k pods"),
     "config3_balanced": dict(n_nodes=5_000, n_pods=50_000, plugins=("nrt",), node_row=324, pod_row=100, out=2, strategy="BalancedAllocation",
                              desc="noderesourcetopology Filter+Score (BalancedAllocation), 5k nodes x 8 NUMA zones x 50k pods"),
+    # the kernels' 8-slot instantiations: six NUMA-affine resources (cpu, memory, hugepages-2Mi, hugepages-1Gi, two extended resources);
+    # node_row = 8 zones x 6 slots x 8 B + flags, pod_row = 8 containers x 6 x 8 B + header
+    "config3_r8": dict(n_nodes=5_000, n_pods=50_000, plugins=("nrt",), node_row=452, pod_row=148, out=2, strategy="LeastAllocated", wide=True,
+                       desc="noderesourcetopology Filter+Score (LeastAllocated), six resource slots, 5k nodes x 8 NUMA zones x 50k pods"),
+    "config3_r8_balanced": dict(n_nodes=5_000, n_pods=50_000, plugins=("nrt",), node_row=452, pod_row=148, out=2, strategy="BalancedAllocation", wide=True,
+                                desc="noderesourcetopology Filter+Score (BalancedAllocation), six resource slots, 5k x 8 x 50k"),
     "config4": dict(n_nodes=10_000, n_pods=200_000, plugins=("net",), node_row=4, pod_row=48, out=2, scaling="strong",
                     desc="networkaware NetworkOverhead (+TopologicalSort keys), 10k nodes x 3-tier topology x 200k pods sharded over the GPUs"),
     # out: SURVEY.md 8d counts 4 score tables + LVRB's + ONE status byte per eval = 6 (the engine keeps two status tables, NRT's
@@ -135,9 +141,11 @@ def build_snapshot(hdr, w, n_pods, seed):
         snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=seed, quota_sized_for_batch=True)
         snap["nrt_params"] = O.nrt_params(hdr, O.Resources(), w["strategy"])
     elif "nrt" in w["plugins"]:
-        snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED)
+        wide = bool(w.get("wide"))
+        snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED, wide=wide)
         if seed != synth.SEED:
-            snap["pods"] = synth.synth_pods(hdr, n_pods, seed=seed, device_res=synth.RES_DEVICE, hugepage_res=synth.RES_HUGEPAGES_2MI)
+            snap["pods"] = synth.synth_pods(hdr, n_pods, seed=seed, device_res=synth.RES_DEVICE, hugepage_res=synth.RES_HUGEPAGES_2MI,
+                                            device2_res=synth.RES_DEVICE2 if wide else -1, hugepage2_res=synth.RES_HUGEPAGES_1GI if wide else -1)
         snap["nrt_params"] = O.nrt_params(hdr, O.Resources(), w["strategy"])
     elif "net" in w["plugins"]:
         snap = synth.network_snapshot(hdr, n_nodes, n_pods, seed=seed, **({"pods_per_group": w["pods_per_group"]} if "pods_per_group" in w else {}))
@@ -387,6 +395,10 @@ def main() -> None:
     ap.add_argument("--sweep-only", action="store_true", help="skip the full_cycle section (profiling runs: rocprofv3 counter passes crash in hipGraph capture)")
     ap.add_argument("--no-pod-classes", action="store_true", help="evaluate every pod row (SPX_OPT_NRT_POD_CLASSES / SPX_OPT_PEAKS_POD_CLASSES off): "
                     "by default a whole-batch NRT or Peaks sweep evaluates one row per class of pods with equal records and copies it")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="ranks mode (torch.distributed.run): nccl = RCCL over xGMI (the driver's "
+                    "scaling run); gloo = the same code path with the collectives on host tensors, for boxes with fewer GPUs than ranks (tests)")
+    ap.add_argument("--rank-devices", default="", help="ranks mode: device of each local rank, e.g. 0,0 puts two ranks on device 0 (needs --dist-backend gloo: RCCL "
+                    "refuses two ranks on one device)")
     ap.add_argument("--no-config5-leg", action="store_true", help="default (config2) line only: skip the bounded full-profile leg (config5_leg)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     args = ap.parse_args()
@@ -395,6 +407,8 @@ def main() -> None:
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rank_devices:  # (tests) several ranks per device
+        local_rank = int(args.rank_devices.split(",")[local_rank])
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env > 1 and world_env != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
@@ -403,7 +417,7 @@ def main() -> None:
     devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
     if args.devices:
         args.gpus = len(devices)
-    elif args.gpus > torch.cuda.device_count():
+    elif args.gpus > torch.cuda.device_count() and not args.rank_devices:
         raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible")
     mode = "ranks" if world_env > 1 else ("multi" if args.gpus > 1 else "single")
     world = args.gpus
@@ -412,7 +426,11 @@ def main() -> None:
     if mode == "ranks":
         import torch.distributed as dist  # RCCL over xGMI
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
 
     import scheduler_plugins_amd as spx
     from scheduler_plugins_amd import synth
@@ -511,7 +529,7 @@ def main() -> None:
         barrier()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+            t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         # average launch duration of the sweep measured with HIP events over the timed region itself (back-to-back
@@ -638,9 +656,9 @@ def main() -> None:
                 barrier()
                 t1 = time.perf_counter()
                 if strong:  # equal shards of one batch
-                    shard.gather_best(dist, torch.device("cuda", local_rank), node, score, ties, feas, n_pods_total)
+                    shard.gather_best(dist, coll_dev, node, score, ties, feas, n_pods_total)
                 else:
-                    shard.gather_best(dist, torch.device("cuda", local_rank), node, score, ties, feas, local_pods * world)
+                    shard.gather_best(dist, coll_dev, node, score, ties, feas, local_pods * world)
                 barrier()
                 gather_info = {"best_ms": (time.perf_counter() - t1) * 1e3, "bytes_per_rank": int(local_pods) * 20,
                                "host": "one process per GPU, torch.distributed all_gather_into_tensor"}
@@ -653,7 +671,7 @@ def main() -> None:
                     target.sync()
                     barrier()
                     t1 = time.perf_counter()
-                    full = shard.gather_table(dist, slab)
+                    full = shard.gather_table(dist, slab if args.dist_backend == "nccl" else slab.cpu())
                     barrier()
                     gather_info.update({"table_ms": (time.perf_counter() - t1) * 1e3, "table_bytes": int(full.numel())})
                     del full

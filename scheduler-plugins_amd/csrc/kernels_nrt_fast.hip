@@ -830,9 +830,12 @@ __device__ __forceinline__ int balanced_cell_exact(const NrtArgs& a, int64_t pod
 // through ~30 us of dependent loads each (10 ms for 1.8e6 cells).  So the scan only compacts them into a list — one atomic
 // per block of 1024 threads — and k_nrt_bal_redo works through the list with full waves.  Cells that do not fit the list are
 // recomputed in place.
-constexpr int kScanThreads = 1024;
+// (5-8 resource slots: the in-place recomputation holds a node's 2 x 8 x 8 doubles — 256 threads, so that it has the registers)
 template <int RM>
-__global__ __launch_bounds__(kScanThreads) void k_nrt_bal_scan(NrtArgs a) {
+constexpr int scan_threads() { return RM == 4 ? 1024 : 256; }
+template <int RM>
+__global__ __launch_bounds__(scan_threads<RM>()) void k_nrt_bal_scan(NrtArgs a) {
+  constexpr int kScanThreads = scan_threads<RM>();
   SPX_RESOLVE_ROWS(a);
   // the Score launch lists its undecided cells itself; this pass only runs when they did not all fit the list — it then finds
   // every cell still marked and recomputes it where it is (the list is full: `at` below is past the capacity)
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(1024) void k_nrt_ln_longest(NrtArgs a) {
 }
 
 template <int RM>
-__global__ __launch_bounds__(256, 2) void k_nrt_ln_redo(NrtArgs a) {
+__global__ __launch_bounds__(256, RM == 4 ? 2 : 1) void k_nrt_ln_redo(NrtArgs a) {
   SPX_RESOLVE_ROWS(a);
   __shared__ __align__(4) uint8_t ln_subset[kLnDwords * 32];
   __shared__ uint32_t ln_allow[256 * kLnDwords];
@@ -1093,7 +1096,7 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
       } \
       if (SGV == kSgBalanced) { /* ... recomputed in float64 from the list; the scan pass only acts when the list overflowed */ \
         const int64_t units = (a.row_end - a.row_begin) * (a.row_stride / 16); \
-        hipLaunchKernelGGL((k_nrt_bal_scan<RMV>), dim3(static_cast<unsigned>((units + kScanThreads - 1) / kScanThreads)), dim3(kScanThreads), 0, s, a); \
+        hipLaunchKernelGGL((k_nrt_bal_scan<RMV>), dim3(static_cast<unsigned>((units + scan_threads<RMV>() - 1) / scan_threads<RMV>())), dim3(scan_threads<RMV>()), 0, s, a); \
         hipLaunchKernelGGL((k_nrt_bal_redo<RMV>), dim3((a.redo_cap + 255) / 256), dim3(256), 0, s, a); \
       } \
     } else {                                                                                              \

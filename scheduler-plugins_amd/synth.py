@@ -27,8 +27,10 @@ def _csr_from_mask(mask: np.ndarray):
 
 
 def synth_pods(hdr: Header, n_pods: int, seed: int = SEED, device_res: int = -1, n_appgroups: int = 0,
-               n_namespaces: int = 100, hugepage_res: int = -1, qos_p=(0.5, 0.4, 0.1)) -> Table:
-    """`qos_p`: shares of Guaranteed / Burstable / BestEffort pods (50 / 40 / 10 %; experiments vary it)."""
+               n_namespaces: int = 100, hugepage_res: int = -1, qos_p=(0.5, 0.4, 0.1), device2_res: int = -1, hugepage2_res: int = -1) -> Table:
+    """`qos_p`: shares of Guaranteed / Burstable / BestEffort pods (50 / 40 / 10 %; experiments vary it).
+    `device2_res` / `hugepage2_res`: a second extended resource and a second hugepage size (the six-slot NRT workload); their
+    random streams are separate, so every other column is the same with or without them."""
     rng = np.random.default_rng(seed + 1)
     n_app = rng.integers(1, 4, n_pods)
     has_init = rng.random(n_pods) < 0.2
@@ -57,14 +59,19 @@ def synth_pods(hdr: Header, n_pods: int, seed: int = SEED, device_res: int = -1,
     hp_q = rng_hp.integers(0, 65, total).astype(np.int64) * (2 << 20)  # includes explicit zero-quantity requests
     bur_cpu = rng.random(total) < 0.8  # burstable containers may omit one of the two
     bur_mem = rng.random(total) < 0.8
-    req_mask = np.stack([(q == 0) | ((q == 1) & bur_cpu), (q == 0) | ((q == 1) & bur_mem), dev, hp], axis=1)
-    req_res = np.tile(np.array([0, 1, max(device_res, 0), max(hugepage_res, 0)], dtype=np.int32), (total, 1))
-    req_qty = np.stack([cpu, mem, dev_n, hp_q], axis=1)
+    rng_w = np.random.default_rng(seed + 202)
+    dev2 = (rng_w.random(n_pods) < 0.08)[pod_of] & (device2_res >= 0) & (kind == 0) & (pos == has_init[pod_of])
+    dev2_n = rng_w.integers(1, 3, total)
+    hp2 = (rng_w.random(total) < 0.08) & (hugepage2_res >= 0) & (q != 2)
+    hp2_q = rng_w.integers(1, 5, total).astype(np.int64) * GiB
+    req_mask = np.stack([(q == 0) | ((q == 1) & bur_cpu), (q == 0) | ((q == 1) & bur_mem), dev, hp, dev2, hp2], axis=1)
+    req_res = np.tile(np.array([0, 1, max(device_res, 0), max(hugepage_res, 0), max(device2_res, 0), max(hugepage2_res, 0)], dtype=np.int32), (total, 1))
+    req_qty = np.stack([cpu, mem, dev_n, hp_q, dev2_n, hp2_q], axis=1)
     req_ptr, sel = _csr_from_mask(req_mask)
     # limits: Guaranteed == requests; Burstable sometimes a larger cpu limit; devices/hugepages always limit == request
     bur_lim = (q == 1) & bur_cpu & (rng.random(total) < 0.5)
-    lim_mask = np.stack([(q == 0) | bur_lim, (q == 0), dev, hp], axis=1)
-    lim_qty = np.stack([np.where(q == 0, cpu, cpu * 2), mem, dev_n, hp_q], axis=1)
+    lim_mask = np.stack([(q == 0) | bur_lim, (q == 0), dev, hp, dev2, hp2], axis=1)
+    lim_qty = np.stack([np.where(q == 0, cpu, cpu * 2), mem, dev_n, hp_q, dev2_n, hp2_q], axis=1)
     lim_ptr, lsel = _csr_from_mask(lim_mask)
 
     ovh = rng.random(n_pods) < 0.05
@@ -231,17 +238,22 @@ def trimaran_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, 
 # ------------------------------------------------------------------ NodeResourceTopology (config #3)
 RES_HUGEPAGES_2MI = 8   # "hugepages-2Mi"
 RES_DEVICE = 9          # "example.com/gpu" style extended resource
+RES_HUGEPAGES_1GI = 10  # "hugepages-1Gi"      (the six-slot workload: a cluster with two hugepage sizes and two device types)
+RES_DEVICE2 = 11        # a second extended resource
 
 
-def nrt_resource_classes(hdr: Header) -> Table:
-    flags = np.zeros(10, dtype=np.uint8)
+def nrt_resource_classes(hdr: Header, wide: bool = False) -> Table:
+    flags = np.zeros(12 if wide else 10, dtype=np.uint8)
     flags[[0, 1, 2, 3, 4]] = 2              # native
     flags[RES_HUGEPAGES_2MI] = 1 | 2 | 4    # hugepage, native, scalar
     flags[RES_DEVICE] = 4                   # extended: not native, scalar
+    if wide:
+        flags[RES_HUGEPAGES_1GI] = 1 | 2 | 4
+        flags[RES_DEVICE2] = 4
     return Table(hdr, "spx_resource_classes", n_res=len(flags), flags=flags)
 
 
-def synth_nrt(hdr: Header, nodes: Table, seed: int = SEED, n_zones: int = 8, vary: bool = True):
+def synth_nrt(hdr: Header, nodes: Table, seed: int = SEED, n_zones: int = 8, vary: bool = True, wide: bool = False):
     """NRT objects for the given nodes: Z NUMA zones per node with ids == list positions,
     per-zone available = alloc/Z x U[0.1,1] for {cpu, memory, hugepages-2Mi, device}; distances 10 on the
     diagonal and {12,20,32} off it; single-numa-node policy, container scope 70% / pod scope 30%,
@@ -275,6 +287,15 @@ def synth_nrt(hdr: Header, nodes: Table, seed: int = SEED, n_zones: int = 8, var
     mask = np.stack([np.ones(nzt, bool), np.ones(nzt, bool), rep_hp, rep_dev], axis=1)
     res = np.tile(np.array([0, 1, RES_HUGEPAGES_2MI, RES_DEVICE], dtype=np.int32), (nzt, 1))
     qty = np.stack([z_cpu, z_mem, z_hp, z_dev], axis=1)
+    if wide:  # two more zone resources, from their own stream (the four above stay as they are)
+        rng_w = np.random.default_rng(seed + 205)
+        z_hp1g = (rng_w.integers(0, 9, nzt) * GiB).astype(np.int64)
+        z_dev2 = rng_w.integers(0, 3, nzt).astype(np.int64)
+        rep_hp1g = (rng_w.random(N) < 0.7)[node_of]
+        rep_dev2 = (rng_w.random(N) < 0.5)[node_of] & (rng_w.random(nzt) < 0.9)
+        mask = np.concatenate([mask, np.stack([rep_hp1g, rep_dev2], axis=1)], axis=1)
+        res = np.tile(np.array([0, 1, RES_HUGEPAGES_2MI, RES_DEVICE, RES_HUGEPAGES_1GI, RES_DEVICE2], dtype=np.int32), (nzt, 1))
+        qty = np.concatenate([qty, np.stack([z_hp1g, z_dev2], axis=1)], axis=1)
     zres_ptr, sel = _csr_from_mask(mask)
     # costs: full matrix per node, 5% of entries dropped when vary
     cnt = nz[node_of]
@@ -319,8 +340,9 @@ def synth_nrt(hdr: Header, nodes: Table, seed: int = SEED, n_zones: int = 8, var
     )
 
 
-def nrt_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, vary: bool = True) -> Dict[str, Table]:
-    """Object tables for BASELINE.json config #3 (NRT Filter+Score, 8 NUMA zones)."""
+def nrt_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, vary: bool = True, wide: bool = False) -> Dict[str, Table]:
+    """Object tables for BASELINE.json config #3 (NRT Filter+Score, 8 NUMA zones).  `wide`: six resource slots (cpu, memory,
+    hugepages-2Mi, hugepages-1Gi, two extended resources) instead of four — the kernels' 8-slot instantiations."""
     nodes = synth_nodes(hdr, n_nodes, seed, device_res=RES_DEVICE)
     # node-level allocatable must list hugepages too (util.ResourceList key check, filter.go:110-116)
     rng = np.random.default_rng(seed + 6)
@@ -328,18 +350,24 @@ def nrt_snapshot(hdr: Header, n_nodes: int, n_pods: int, seed: int = SEED, vary:
     has_hp = rng.random(N) < 0.9
     has_dev = rng.random(N) < 0.7
     mask = np.stack([has_hp, has_dev], axis=1)
-    ptr, sel = _csr_from_mask(mask)
     res = np.tile(np.array([RES_HUGEPAGES_2MI, RES_DEVICE], dtype=np.int32), (N, 1))
     qty = np.stack([np.full(N, 1 << 30, dtype=np.int64), rng.integers(1, 17, N)], axis=1)
+    if wide:
+        rng_w = np.random.default_rng(seed + 206)
+        mask = np.concatenate([mask, np.stack([rng_w.random(N) < 0.85, rng_w.random(N) < 0.6], axis=1)], axis=1)
+        res = np.tile(np.array([RES_HUGEPAGES_2MI, RES_DEVICE, RES_HUGEPAGES_1GI, RES_DEVICE2], dtype=np.int32), (N, 1))
+        qty = np.concatenate([qty, np.stack([np.full(N, 64 * GiB, dtype=np.int64), rng_w.integers(1, 9, N)], axis=1)], axis=1)
+    ptr, sel = _csr_from_mask(mask)
     nodes = Table(hdr, "spx_node_objects", n_nodes=N, alloc_cpu_milli=nodes.array("alloc_cpu_milli"),
                   alloc_mem=nodes.array("alloc_mem"), alloc_eph=nodes.array("alloc_eph"), alloc_pods=nodes.array("alloc_pods"),
                   scalar_ptr=ptr, scalar_res=res.reshape(-1)[sel], scalar_qty=qty.reshape(-1)[sel],
                   cap_cpu_milli=nodes.array("cap_cpu_milli"), region=nodes.array("region"), zone=nodes.array("zone"))
     return {
         "nodes": nodes,
-        "pods": synth_pods(hdr, n_pods, seed, device_res=RES_DEVICE, hugepage_res=RES_HUGEPAGES_2MI),
-        "nrt": synth_nrt(hdr, nodes, seed, vary=vary),
-        "rc": nrt_resource_classes(hdr),
+        "pods": synth_pods(hdr, n_pods, seed, device_res=RES_DEVICE, hugepage_res=RES_HUGEPAGES_2MI,
+                           device2_res=RES_DEVICE2 if wide else -1, hugepage2_res=RES_HUGEPAGES_1GI if wide else -1),
+        "nrt": synth_nrt(hdr, nodes, seed, vary=vary, wide=wide),
+        "rc": nrt_resource_classes(hdr, wide),
     }
 
 

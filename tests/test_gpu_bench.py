@@ -108,3 +108,28 @@ def test_multi_mark_brackets_the_steps(gpu_required, hdr):
         m.mark(1)
         m.sync()
         assert m.marked_ms()[0] < mx  # marks move: an empty region is shorter than five steps
+
+
+@pytest.mark.parametrize("workload,scaling,gather", [("small", "weak", "best"), ("small_net", "strong", "table"), ("small_full", "strong", "best")])
+def test_ranks_mode_two_processes(gpu_required, workload, scaling, gather):
+    """bench.py as the driver launches it for N > 1: `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`, one process
+    per rank — sharding by rank, the barrier / max-over-ranks timing, the all-gather of the decisions (and of one table).  On a one-GPU
+    box both ranks sit on device 0 and the collectives run over gloo (RCCL refuses two ranks on one device); with two GPUs visible
+    the same test runs over RCCL.  No N > 1 hardware figure comes out of this: it is the code path, not the number."""
+    two = n_gpus() >= 2
+    extra = [] if two else ["--rank-devices", "0,0", "--dist-backend", "gloo"]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29613",
+           str(ROOT / "bench.py"), "--gpus", "2", "--workload", workload, "--steps", "3", "--warmup", "1", "--cpu-budget", "0", "--gather", gather, *extra]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]   # rank 0 prints, nobody else
+    d = json.loads(lines[0])
+    check_line(d, 2, scaling)
+    assert d["config"]["host"].startswith("2 processes")
+    assert d["gather"]["best_ms"] > 0 and d["gather"]["backend"] == ("nccl" if two else "gloo")
+    if gather == "table":
+        assert d["gather"]["table_bytes"] > 0

@@ -99,6 +99,31 @@ def test_config3_every_cell(gpu_required, hdr, oracle, strategy):
         assert 0.01 * n_nodes * n_pods < rejected < 0.9 * n_nodes * n_pods  # both Filter verdicts are well represented
 
 
+@pytest.mark.parametrize("strategy", ["LeastAllocated", "MostAllocated", "BalancedAllocation", "LeastNUMANodes"])
+def test_config3_six_slots_every_cell(gpu_required, hdr, oracle, strategy):
+    """The kernels' 8-slot instantiations (5-8 NUMA-affine resources: cpu, memory, two hugepage sizes, two extended resources):
+    every cell of a 2k-node x 12k-pod batch of the six-slot synthetic cluster (bench.py --workload config3_r8) against the oracle.
+    (LeastNUMANodes: the CPU oracle walks every NUMA subset per cell — a quarter of the rows.)"""
+    n_nodes, n_pods = 2_000, 12_000 if strategy != "LeastNUMANodes" else 3_000
+    snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, wide=True)
+    params = O.nrt_params(hdr, O.Resources(), strategy)
+    with Engine(0) as e:
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+        assert e.kernel_path(NRT) == 1 and int(e.nrt_soa["slots"].struct.n_res) == 6
+        e.eval(mask_of(NRT))
+        e.sync()
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
+        bad_status = bad_score = rejected = 0
+        for r0, r1 in blocks(n_pods, n_nodes, cells=8_000_000):
+            want_st = osnap.filter_rows(NRT, r0, r1, threads=THREADS)
+            bad_status += int((e.all_status(NRT, r0, r1) != want_st).sum())
+            rejected += int((want_st != 0).sum())
+            want_sc = osnap.score_rows(NRT, r0, r1, threads=THREADS, want_norm=False)[0]
+            bad_score += count_mismatches(e.all_scores(NRT, r0, r1), want_sc)[0]
+        assert (bad_status, bad_score) == (0, 0)
+        assert 0.01 * n_nodes * n_pods < rejected < 0.9 * n_nodes * n_pods
+
+
 def test_config4_every_cell(gpu_required, hdr, oracle):
     n_nodes, n_pods = 10_000, 200_000
     snap = synth.network_snapshot(hdr, n_nodes, n_pods)
