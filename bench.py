@@ -661,7 +661,8 @@ def main() -> None:
                     shard.gather_best(dist, coll_dev, node, score, ties, feas, local_pods * world)
                 barrier()
                 gather_info = {"best_ms": (time.perf_counter() - t1) * 1e3, "bytes_per_rank": int(local_pods) * 20,
-                               "host": "one process per GPU, torch.distributed all_gather_into_tensor"}
+                               "host": "one process per GPU, torch.distributed all_gather_into_tensor", "backend": args.dist_backend,
+                               "note": "no N > 1 hardware figure has been measured by the builder: one-GPU boxes only (two ranks on one device run over gloo)"}
                 if args.gather == "table":
                     p0 = plugins[-1] if plugins[-1] <= 4 else plugins[0]
                     ptr, stride, rows_t = target.score_table(p0)

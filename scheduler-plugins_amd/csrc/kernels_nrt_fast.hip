@@ -59,8 +59,8 @@ constexpr int kBalRedo = 255;  // score byte of a cell the fix-up launch recompu
 // "request > capacity" (fractionOfCapacity > 1: the zone scores 0) is decided on the quantities themselves, not on the
 // rounded quotient — a request that equals the capacity (one device wanted, one device free) is the common case, and its
 // float32 quotient is 1.0 either way.  For integers, RN64(request / capacity) > 1.0 exactly when request > capacity; slots whose
-// requests and capacities are all below 2^24 cluster-wide (NrtArgs.exact32_slots: whole cores, devices) compare exactly in
-// float32, the others (bytes) are undecided when the two lie within 2^-22 of each other.
+// requests and capacities are all float32 values cluster-wide (NrtArgs.exact32_slots: whole cores, devices, GiB hugepages) compare
+// exactly in float32, the others (bytes) are undecided when the two lie within 2^-22 of each other.
 template <int RM>
 struct BalNode {
   float rcp[kZ][RM];   // RN32(1 / Value(capacity)), 0 where the capacity is not positive

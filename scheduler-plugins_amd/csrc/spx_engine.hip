@@ -104,7 +104,7 @@ struct spx_engine {
   DevBuf d_nrt_lnrec;      // LeastNUMANodes: the nodes' tables as one record each (scratch of a batch launch)
   DevBuf d_nrt_redo;       // BalancedAllocation: list of the cells the float32 Score launch leaves to the float64 form
   uint32_t nrt_redo_cap = 0;
-  uint32_t nrt_big_nodes = ~0u, nrt_big_pods = ~0u;  // slots with a capacity / a request (Value() form) of 2^24 or more
+  uint32_t nrt_big_nodes = ~0u, nrt_big_pods = ~0u;  // slots with a capacity / a request (Value() form) that float32 does not hold exactly
   // pod equivalence classes (spx_upload_nrt_pods): rows whose NRT records agree in everything the sweep reads
   bool nrt_creq_valid = false;   // d_nrt_creq (read by the reference-arithmetic kernel only) holds this batch's column
   void* h_stage = nullptr;       // pinned staging for the large derived tables (pod record stream): built in place, one DMA
@@ -474,6 +474,10 @@ inline bool nrt_fast_qty(int64_t v) { return v >= 0 && v < kNrtFastLimit; }
 // RN(1/v) * (1 + 2^-49): floor(num * rc) == num / v for 0 <= num <= 101 * v, 0 < v < 2^42 (kernels_nrt_fast.hip)
 inline double nrt_biased_rcp(double v) { return v > 0.0 ? (1.0 / v) * (1.0 + 0x1p-49) : 0.0; }
 inline int64_t nrt_value_of(bool is_cpu, int64_t q) { return is_cpu ? (q + 999) / 1000 : q; }
+// a quantity the float32 BalancedAllocation Score holds exactly: below 2^24, or any integer whose float32 image is itself (hugepage
+// and device-memory quantities are small multiples of a power of two: 3 x 2^30 is as exact in float32 as 3).  Slots whose requests
+// and capacities are all of that kind compare "request > capacity" exactly; the others (memory in bytes) are undecided near equality
+inline bool nrt_exact_f32(double v) { return v >= 0.0 && v < 9.2e18 && static_cast<double>(static_cast<float>(v)) == v; }
 
 void fill_net(const spx_engine* e, spx::NetArgs& g) {
   g.opts = launch_opts(e);
@@ -846,7 +850,7 @@ int spx_update_nrt_nodes(spx_engine* e, const int64_t* idx, const spx_nrt_nodes_
         if (!((t->zone_present[i * Zm + z] >> r) & 1u)) continue;
         const int64_t cap = t->zone_avail[(i * Zm + z) * R + r];
         if (!nrt_fast_qty(cap)) ok = false;
-        if (static_cast<double>(nrt_value_of(r == e->nrt_cpu_slot, cap)) >= 16777216.0) big |= 1u << r;
+        if (!nrt_exact_f32(static_cast<double>(nrt_value_of(r == e->nrt_cpu_slot, cap)))) big |= 1u << r;
       }
     }
     int32_t* hc = &e->h_nrt_cost[static_cast<size_t>(ix[static_cast<size_t>(i)]) * Zm * Zm];
@@ -1104,7 +1108,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
           if (!nrt_fast_qty(cap)) ok = false;
           const bool is_cpu = r == e->nrt_cpu_slot;
           const double cap_v = static_cast<double>(nrt_value_of(is_cpu, cap));
-          if (cap_v >= 16777216.0) big_nodes.fetch_or(1u << r, std::memory_order_relaxed);
+          if (!nrt_exact_f32(cap_v)) big_nodes.fetch_or(1u << r, std::memory_order_relaxed);
           av[static_cast<size_t>((z * R + r) * n + i)] = static_cast<double>(cap);
           rcp[static_cast<size_t>((z * R + r) * n + i)] = cap_v > 0.0 ? 100.0 / cap_v : spx::kNrtNoCap;
           rcv[static_cast<size_t>((z * R + r) * n + i)] = cap_v > 0.0 ? 1.0 / cap_v : 1.0;
@@ -1377,7 +1381,7 @@ void nrt_build_items(const spx_nrt_pods_soa* t, const uint8_t* slot_flags, int c
     uint32_t fit = 0, always = 0;
     for (size_t r = 0; r < R; ++r) {
       if (!nrt_fast_qty(req[r])) bad = true;
-      if (nrt_value_of(static_cast<int>(r) == cpu_slot, req[r]) >= 16777216) big |= 1u << r;
+      if (!nrt_exact_f32(static_cast<double>(nrt_value_of(static_cast<int>(r) == cpu_slot, req[r])))) big |= 1u << r;
       put_f64(w + 2 * r, static_cast<double>(req[r]));
       if (!((used >> r) & 1u) || req[r] == 0) continue;  // "ignoring zero-qty resource request" filter.go:103-106
       if (non_g && (slot_flags[r] & SPX_NRT_SLOT_AFFINE)) always |= 1u << r;

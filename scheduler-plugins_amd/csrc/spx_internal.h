@@ -273,7 +273,7 @@ struct NrtArgs {
   int64_t ln_rows;
   uint32_t ln_per_row;
   uint32_t* ln_rec;              // [N][kZ * RM * 2 + 16] scratch: the nodes' tables as one record each (k_nrt_ln_pack -> k_nrt_ln_redo)
-  uint32_t exact32_slots;        // resource slots whose requests and capacities (Value() form) are all below 2^24: exact in float32
+  uint32_t exact32_slots;        // resource slots whose requests and capacities (Value() form) are all float32 values (below 2^24, or a multiple of a large power of two): compared exactly
 };
 constexpr double kNrtNoCap = 1e200;
 
