@@ -271,7 +271,7 @@ def delta_cycle(target, w, snap, hdr, mask, score_mask):
     target.sync()
     t0 = time.perf_counter()
     if any(p in pl for p in ("tlp", "lvrb", "cap")):
-        target.update_trimaran_nodes(idx, target.flatten_trimaran_nodes(snap["nodes"], snap["metrics"], snap.get("assigned")))
+        target.update_trimaran_node_rows(idx, target.flatten_trimaran_node_rows(snap["nodes"], snap["metrics"], snap.get("assigned"), idx))
     t0b = time.perf_counter()
     if "nrt" in pl:
         slots = target.nrt_soa["slots"]
@@ -293,8 +293,7 @@ def delta_cycle(target, w, snap, hdr, mask, score_mask):
     t4 = time.perf_counter()
     out = {"ms": (t4 - t0) * 1e3, "node_delta_ms": (t1 - t0) * 1e3, "node_delta_trimaran_ms": (t0b - t0) * 1e3, "node_rows": int(len(idx)), "new_pods_ms": (t2 - t1) * 1e3,
            "decide_ms": (t3 - t2) * 1e3, "fetch_decisions_ms": (t4 - t3) * 1e3,
-           "what": "1 % of the nodes' trimaran + NRT rows replaced in place (spx_update_*_nodes; NRT rows flattened for those nodes only, the "
-                   "trimaran flattener still walks every node), a new pending batch flattened and uploaded for every plugin, spx_decide (sweep + "
+           "what": "1 % of the nodes' trimaran + NRT rows replaced in place (spx_update_*_nodes; both flattened for those nodes only), a new pending batch flattened and uploaded for every plugin, spx_decide (sweep + "
                    "per-row weighted argmax), D2H of the decisions"}
     return out
 

@@ -822,6 +822,8 @@ int spx_multi_last_ms(spx_multi* m, float* eval_ms, float* gather_ms);
 int spx_flatten_alloc_nodes(const spx_node_objects* nodes, const spx_resource_classes* rc, const spx_allocatable_params* p, int64_t* alloc_out);
 int spx_flatten_trimaran_nodes(const spx_node_objects* nodes, const spx_metrics_objects* metrics, const spx_assigned_objects* assigned, const spx_tlp_params* tlp, int64_t* cap_cpu_milli, double* tlp_cpu_util, int64_t* tlp_missing_milli, uint8_t* tlp_valid, int64_t* lv_alloc_cpu_milli, int64_t* lv_alloc_mem, double* lv_cpu_avg, double* lv_cpu_std, double* lv_mem_avg, double* lv_mem_std, uint8_t* lv_flags);
 int spx_flatten_trimaran_pods(const spx_pod_objects* pods, const spx_tlp_params* tlp, int64_t* tlp_pod_milli, int64_t* lv_req_cpu_milli, int64_t* lv_req_mem);
+/* the same columns for the listed nodes only (n_rows rows; row j = node idx[j]): the input of spx_update_trimaran_nodes */
+int spx_flatten_trimaran_node_rows(const spx_node_objects* nodes, const spx_metrics_objects* metrics, const spx_assigned_objects* assigned, const spx_tlp_params* tlp, const int64_t* idx, int64_t n_rows, int64_t* cap_cpu_milli, double* tlp_cpu_util, int64_t* tlp_missing_milli, uint8_t* tlp_valid, int64_t* lv_alloc_cpu_milli, int64_t* lv_alloc_mem, double* lv_cpu_avg, double* lv_cpu_std, double* lv_mem_avg, double* lv_mem_std, uint8_t* lv_flags);
 /* LowRiskOverCommitment: every output array has one entry per node / per pod */
 int spx_flatten_lroc_nodes(const spx_node_objects* nodes, const spx_node_pods_objects* node_pods, int64_t* req_cpu_milli, int64_t* req_mem, int64_t* lim_cpu_milli, int64_t* lim_mem);
 int spx_flatten_lroc_pods(const spx_pod_objects* pods, int64_t* req_cpu_milli, int64_t* req_mem, int64_t* lim_cpu_milli, int64_t* lim_mem);

@@ -430,33 +430,14 @@ constexpr int kPhBoth = 0, kPhFilter = 1, kPhScore = 2;
 // waves per SIMD the register allocation is bounded for (<= 4 resource slots).  A spilled VGPR is not cheap here: whatever the
 // allocator parks in scratch is reloaded inside the pod loop behind an s_waitcnt vmcnt(0) (round 2's Filter launch, bounded to 5
 // waves = 96 VGPRs, reloaded the lane's staging offset from scratch for EVERY pod: ~1300 cycles per pod and wave)
-#ifndef SPX_NRT_ABLATE
-#define SPX_NRT_ABLATE 0  // experiments (tools/r3): 1 skip the pod loop, 2 skip the record fill, 4 skip the flush, 8 skip the node tables
-#endif
-#ifndef SPX_NRT_LB_FILTER
-#define SPX_NRT_LB_FILTER 4
-#endif
-#ifndef SPX_NRT_LB_LEAST
-#define SPX_NRT_LB_LEAST 4
-#endif
-#ifndef SPX_NRT_LB_MOST
-#define SPX_NRT_LB_MOST 3
-#endif
-#ifndef SPX_NRT_LB_BAL
-#define SPX_NRT_LB_BAL 3
-#endif
-#ifndef SPX_NRT_LB_BOTH
-#define SPX_NRT_LB_BOTH 3
-#endif
-#ifndef SPX_NRT_LB_LN
-#define SPX_NRT_LB_LN 2
-#endif
+// (measured, tools/r3 + tools/variant.py builds: Filter 4, LeastAllocated Score 4, MostAllocated / BalancedAllocation Score 3 — more spills —
+// LeastNUMANodes 2, one-launch form 3)
 template <int RM, int SG, int PH>
 constexpr int nrt_waves() {
   if (RM != 4) return 1;
-  if (PH == kPhFilter) return SPX_NRT_LB_FILTER;
-  if (PH == kPhScore) return SG == kSgLeastNuma ? SPX_NRT_LB_LN : (SG == kSgMost ? SPX_NRT_LB_MOST : (SG == kSgBalanced ? SPX_NRT_LB_BAL : SPX_NRT_LB_LEAST));
-  return SG == kSgLeast ? SPX_NRT_LB_BOTH : 2;
+  if (PH == kPhFilter) return 4;
+  if (PH == kPhScore) return SG == kSgLeastNuma ? 2 : (SG == kSgMost || SG == kSgBalanced ? 3 : 4);
+  return SG == kSgLeast ? 3 : 2;
 }
 
 // LNM (LeastNUMANodes, batch Score launch): kLnDefer = cells whose subset search needs more than sizes 1-2 are listed — per pod
@@ -525,7 +506,7 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
   FastNode<RM> ns;
   double cpu_v[kZ], braw[kZ];
   const uint32_t flags = in ? a.flags[n] : 0u;
-  load_fast_node<RM, SG>(a, n, in && !(SPX_NRT_ABLATE & 8), ns, cpu_v, braw);
+  load_fast_node<RM, SG>(a, n, in, ns, cpu_v, braw);
   // BalancedAllocation's Score launch works from float32 images of the reciprocals; the float64 tables die here
   constexpr bool kBalF32 = SG == kSgBalanced && PH == kPhScore;
   BalNode<RM> bn;
@@ -570,7 +551,7 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
     uint4* dst = reinterpret_cast<uint4*>(pod_lds);
     if (!listed) {
       const uint4* src = reinterpret_cast<const uint4*>(a.pod_items + first * pod_words<RM>());
-      if (!(SPX_NRT_ABLATE & 2)) for (int i = threadIdx.x; i < n_quads; i += 256) dst[i] = src[i];
+      for (int i = threadIdx.x; i < n_quads; i += 256) dst[i] = src[i];
     } else {  // a record per listed row
       for (int i = threadIdx.x; i < n_quads; i += 256) {
         const int p = i / kPodQuads, q = i - p * kPodQuads;
@@ -593,7 +574,7 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
   int raw_score = 0;
   auto header = [&](int p) { return *reinterpret_cast<const u32x2*>(pod_lds + p * pod_words<RM>()); };
   u32x2 hv = header(0);
-  for (int p = 0; p < ((SPX_NRT_ABLATE & 1) ? 0 : rows); ++p) {
+  for (int p = 0; p < rows; ++p) {
     // ---- wave-uniform pod record, from LDS; the next pod's header is requested before this pod's work
     const uint32_t* pit = pod_lds + p * pod_words<RM>();  // the pod's first item
     const uint32_t hw[2] = {static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(hv.x))),
@@ -784,7 +765,7 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
   }
   // rows leave as whole 256-byte segments: lane l gathers byte (row & 3) of the four dwords of nodes 4l .. 4l+3
   const int64_t col = base + lane * 4;
-  if (col < a.row_stride && !(SPX_NRT_ABLATE & 4)) {
+  if (col < a.row_stride) {
     for (int i = wave; i < rows; i += 4) {
       const int64_t row = row_of(i);
       const uint32_t b = static_cast<uint32_t>(i & 3);

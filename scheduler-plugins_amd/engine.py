@@ -174,6 +174,24 @@ class Engine:
         self._ck(fn(nodes.ref(), metrics.ref(), assigned.ref() if assigned else None, self.tlp_params.ref(), *ptrs))
         return cols
 
+    def flatten_trimaran_node_rows(self, nodes: Table, metrics: Table, assigned: Optional[Table], idx) -> Dict[str, np.ndarray]:
+        """flatten_trimaran_nodes() for the listed nodes only (row j = node idx[j]): the input of update_trimaran_node_rows"""
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        n = len(idx)
+        cols = {
+            "cap_cpu_milli": np.zeros(n, np.int64), "tlp_cpu_util": np.zeros(n, np.float64),
+            "tlp_missing_milli": np.zeros(n, np.int64), "tlp_valid": np.zeros(n, np.uint8),
+            "lv_alloc_cpu_milli": np.zeros(n, np.int64), "lv_alloc_mem": np.zeros(n, np.int64),
+            "lv_cpu_avg": np.zeros(n, np.float64), "lv_cpu_std": np.zeros(n, np.float64),
+            "lv_mem_avg": np.zeros(n, np.float64), "lv_mem_std": np.zeros(n, np.float64),
+            "lv_flags": np.zeros(n, np.uint8),
+        }
+        fn = self._lib.spx_flatten_trimaran_node_rows
+        ptrs = [v.ctypes.data_as(t) for v, t in zip(cols.values(), fn.argtypes[6:])]
+        self._ck(fn(nodes.ref(), metrics.ref(), assigned.ref() if assigned else None, self.tlp_params.ref(),
+                    idx.ctypes.data_as(C.POINTER(C.c_int64)), n, *ptrs))
+        return cols
+
     def flatten_trimaran_pods(self, pods: Table) -> Dict[str, np.ndarray]:
         p = pods.struct.n_pods
         cols = {"tlp_pod_milli": np.zeros(p, np.int64), "lv_req_cpu_milli": np.zeros(p, np.int64),
@@ -202,6 +220,12 @@ class Engine:
         sub = {k: np.ascontiguousarray(v[idx]) for k, v in cols.items()}
         self._ck(self._lib.spx_update_trimaran_nodes(self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)),
                                                      Table(self._hdr, "spx_trimaran_nodes_soa", n_nodes=len(idx), **sub).ref()))
+
+    def update_trimaran_node_rows(self, idx, rows: Dict[str, np.ndarray]) -> None:
+        """rows `idx` of the trimaran node table replaced in place: rows = flatten_trimaran_node_rows()'s columns (len(idx) rows)"""
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        self._ck(self._lib.spx_update_trimaran_nodes(self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                     Table(self._hdr, "spx_trimaran_nodes_soa", n_nodes=len(idx), **rows).ref()))
 
     def update_nrt_nodes(self, idx, f: dict) -> None:
         """rows `idx` of the NRT node tables replaced in place: f = flatten_nrt()'s result for the NEW snapshot

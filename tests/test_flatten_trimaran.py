@@ -103,3 +103,23 @@ def test_flatten_nodes_metric_selection(hdr, oracle):
         for t in (0, 1):
             ok = oracle.lib().orc_get_resource_data(metrics.ref(), n, t, C.byref(avg), C.byref(sd))
             assert bool(ok) == bool(cols["lv_flags"][n] & (2 << t))
+
+
+def test_node_rows_equal_the_rows_of_the_whole_table(hdr):
+    """spx_flatten_trimaran_node_rows (the delta's flattener) = the listed rows of spx_flatten_trimaran_nodes, every column"""
+    tlp = tlp_params(hdr, 40, 1000, 1.5)
+    snap = synth.trimaran_snapshot(hdr, 700, 10, seed=11)
+    nodes, metrics, assigned = snap["nodes"], snap["metrics"], snap.get("assigned")
+    f = _Flat(hdr, tlp)
+    whole = f.nodes(nodes, metrics, assigned)
+    idx = np.array([699, 0, 5, 5, 123, 698], dtype=np.int64)  # unsorted, with a repeat
+    rows = {k: np.zeros(len(idx), v.dtype) for k, v in whole.items()}
+    fn = f.lib.spx_flatten_trimaran_node_rows
+    rc = fn(nodes.ref(), metrics.ref(), assigned.ref() if assigned else None, tlp.ref(), idx.ctypes.data_as(C.POINTER(C.c_int64)), len(idx),
+            *[v.ctypes.data_as(t) for v, t in zip(rows.values(), fn.argtypes[6:])])
+    assert rc == 0
+    for k in whole:
+        assert np.array_equal(rows[k], whole[k][idx]), k
+    bad = np.array([700], dtype=np.int64)
+    assert fn(nodes.ref(), metrics.ref(), None, tlp.ref(), bad.ctypes.data_as(C.POINTER(C.c_int64)), 1,
+              *[v.ctypes.data_as(t) for v, t in zip(rows.values(), fn.argtypes[6:])]) != 0
