@@ -278,7 +278,7 @@ def delta_cycle(target, w, snap, hdr, mask, score_mask):
         target.update_nrt_node_rows(idx, target.flatten_nrt_node_rows(snap["nodes"], snap["nrt"], slots, idx), int(slots.struct.n_res))
     t1 = time.perf_counter()
     if any(p in pl for p in ("alloc", "tlp", "lvrb", "cap")):
-        target.upload_trimaran_pods(target.flatten_trimaran_pods(pods))
+        target.load_trimaran_pods(pods)
     if "nrt" in pl:
         target.upload_nrt_pods(target.flatten_nrt_pods(pods, snap["rc"], slots), int(slots.struct.n_res))
     if "net" in pl:

@@ -604,6 +604,13 @@ int spx_upload_peaks_pods(spx_engine* e, const spx_peaks_pods_soa* t);
  *   NRT: a republished NodeResourceTopology (pluginhelpers.go:105-161), an assumed pod charged to a node (overreserve.go:170-203) */
 int spx_update_trimaran_nodes(spx_engine* e, const int64_t* idx, const spx_trimaran_nodes_soa* t);
 int spx_update_nrt_nodes(spx_engine* e, const int64_t* idx, const spx_nrt_nodes_soa* t);
+/* NetworkOverhead: pairs appended to the workload keys' lists (AppGroup scheduled lists grow between cycles, networkoverhead.go:654-694).
+ * Entry i: key[i] gains (node[i], max_cost[i]); max_cost[i] == -1: the key merely stops scoring equally.  Built by spx_flatten_net_placed.
+ * Equal to re-uploading spx_flatten_net_keys' tables of the grown AppGroups (tests/test_gpu_delta.py). */
+int spx_update_net_placed(spx_engine* e, int64_t n, const int32_t* key, const int32_t* node, const int64_t* max_cost);
+/* CapacityScheduling: rows of ElasticQuotaInfo.Used replaced (AddPod / DeletePod events, capacity_scheduling.go:679-803): namespace ns[i]
+ * takes used[i][SPX_QUOTA_SLOTS] / used_present[i]; agg_used[SPX_QUOTA_SLOTS] / *agg_used_present: the new aggregate over all quotas. */
+int spx_update_quota_used(spx_engine* e, int64_t n_rows, const int32_t* ns, const int64_t* used, const uint8_t* used_present, const int64_t* agg_used, const uint8_t* agg_used_present);
 int spx_upload_nrt_slots(spx_engine* e, const spx_nrt_slots* t);
 int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t);
 int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t);
@@ -751,6 +758,8 @@ int spx_peaks_pod_classes(const spx_engine* e, int64_t* n_unique, int64_t* n_cop
  * spx_load_trimaran serves Allocatable + TargetLoadPacking + LoadVariationRiskBalancing (rc / assigned may be NULL);
  * spx_load_network also uploads the commit effects spx_commit_sequential needs. */
 int spx_load_trimaran(spx_engine* e, const spx_node_objects* nodes, const spx_resource_classes* rc, const spx_pod_objects* pods, const spx_metrics_objects* metrics, const spx_assigned_objects* assigned);
+/* a new pending batch only (node tables stay): the trimaran / Allocatable pod columns flattened straight into pinned staging, one pass */
+int spx_load_trimaran_pods(spx_engine* e, const spx_pod_objects* pods);
 int spx_load_nrt(spx_engine* e, const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_resource_classes* rc, const spx_pod_objects* pods, const spx_nrt_params* params);
 int spx_load_network(spx_engine* e, const spx_node_objects* nodes, const spx_pod_objects* pods, const spx_appgroup_objects* appgroups, const spx_nettopo_objects* nettopo);
 int spx_load_quota(spx_engine* e, const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_quota_objects* quota);
@@ -850,6 +859,8 @@ int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects
 int spx_toposort_less(const spx_pod_objects* pods, const int32_t* topo_order, int64_t n_pairs, const int64_t* a, const int64_t* b, uint8_t* less_out);
 /* spx_net_commit_soa columns: *n_entries_out first (NULL arrays), then eff_ptr[P+1], eff_key / eff_max_cost[n_entries] */
 int spx_flatten_net_commit(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int64_t* n_entries_out, int32_t* eff_ptr, int32_t* eff_key, int64_t* eff_max_cost);
+/* pods that joined AppGroup scheduled lists since the flatten: the entries spx_update_net_placed appends (sizes first: NULL arrays) */
+int spx_flatten_net_placed(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int64_t n_placed, const int32_t* group, const int32_t* selector, const int32_t* node, int64_t* n_entries_out, int32_t* key_out, int32_t* node_out, int64_t* cost_out);
 
 /* NRT preemption flow: preemption.GetNRTPostPodsEviction (pkg/noderesourcetopology/preemption/preemption.go:39-157)
  * for node `node`.  The Filter of a preemption dry-run (filter.go:205-220) is the ordinary Filter on the zone table this call

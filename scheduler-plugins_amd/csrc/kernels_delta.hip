@@ -23,6 +23,24 @@ __global__ __launch_bounds__(256) void k_scatter_rows(T* __restrict__ dst, int64
   dst[static_cast<int64_t>(k) * n_nodes + idx[row]] = src[i];
 }
 
+// dst row-major [n][inner]  <-  src row-major [n_rows][inner] at rows idx[row] (the ElasticQuota tables: one 64-byte row per namespace)
+template <typename T>
+__global__ __launch_bounds__(256) void k_scatter_rows_rm(T* __restrict__ dst, int inner, const int32_t* __restrict__ idx, const T* __restrict__ src, int64_t n_rows) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_rows * inner) return;
+  const int64_t row = i / inner;
+  dst[static_cast<int64_t>(idx[row]) * inner + (i - row * inner)] = src[i];
+}
+
+// NetworkOverhead: pairs appended to the workload keys' lists — the host has laid the new CSR out and numbered the positions
+__global__ __launch_bounds__(256) void k_net_append(int64_t n, const int32_t* __restrict__ pos, const int32_t* __restrict__ node, const int64_t* __restrict__ cost,
+                                                    int32_t* __restrict__ dst_node, int64_t* __restrict__ dst_max) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  dst_node[pos[i]] = node[i];
+  dst_max[pos[i]] = cost[i];
+}
+
 __global__ __launch_bounds__(256) void k_nrt_derive_rows(NrtDeltaArgs a) {
   constexpr int Z = SPX_NRT_MAX_ZONES;
   const int R = a.n_res;
@@ -69,6 +87,19 @@ void launch_scatter_rows(void* dst, int64_t n_nodes, int inner, const int32_t* i
   if (elem_bytes == 1) hipLaunchKernelGGL(k_scatter_rows<uint8_t>, grid, block, 0, s, static_cast<uint8_t*>(dst), n_nodes, inner, idx, static_cast<const uint8_t*>(src), n_rows);
   else if (elem_bytes == 4) hipLaunchKernelGGL(k_scatter_rows<uint32_t>, grid, block, 0, s, static_cast<uint32_t*>(dst), n_nodes, inner, idx, static_cast<const uint32_t*>(src), n_rows);
   else hipLaunchKernelGGL(k_scatter_rows<uint64_t>, grid, block, 0, s, static_cast<uint64_t*>(dst), n_nodes, inner, idx, static_cast<const uint64_t*>(src), n_rows);
+}
+
+void launch_scatter_rows_rowmajor(void* dst, int inner, const int32_t* idx, const void* src, int64_t n_rows, int elem_bytes, hipStream_t s) {
+  const int64_t n = n_rows * inner;
+  if (n <= 0) return;
+  const dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
+  if (elem_bytes == 1) hipLaunchKernelGGL(k_scatter_rows_rm<uint8_t>, grid, block, 0, s, static_cast<uint8_t*>(dst), inner, idx, static_cast<const uint8_t*>(src), n_rows);
+  else hipLaunchKernelGGL(k_scatter_rows_rm<uint64_t>, grid, block, 0, s, static_cast<uint64_t*>(dst), inner, idx, static_cast<const uint64_t*>(src), n_rows);
+}
+
+void launch_net_append(int64_t n, const int32_t* pos, const int32_t* node, const int64_t* cost, int32_t* dst_node, int64_t* dst_max, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_net_append, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, n, pos, node, cost, dst_node, dst_max);
 }
 
 void launch_nrt_derive_rows(const NrtDeltaArgs& a, hipStream_t s) {

@@ -354,6 +354,8 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s);
 // ---------------------------------------------------------------- snapshot deltas (kernels_delta.hip)
 // dst column-major [inner][n_nodes] <- src row-major [n_rows][inner] at nodes idx[row]; elem_bytes 1, 4 or 8
 void launch_scatter_rows(void* dst, int64_t n_nodes, int inner, const int32_t* idx, const void* src, int64_t n_rows, int elem_bytes, hipStream_t s);
+void launch_scatter_rows_rowmajor(void* dst, int inner, const int32_t* idx, const void* src, int64_t n_rows, int elem_bytes, hipStream_t s);
+void launch_net_append(int64_t n, const int32_t* pos, const int32_t* node, const int64_t* cost, int32_t* dst_node, int64_t* dst_max, hipStream_t s);
 struct NrtDeltaArgs {
   int64_t n_rows, n_nodes;
   int32_t n_res, cpu_slot;

@@ -400,6 +400,34 @@ class Engine:
         self.n_pods = f["P"]
         self.net_soa = f["cols"]
 
+    def flatten_net_placed(self, pods: Table, appgroups: Table, group, selector, node) -> dict:
+        """pods that joined AppGroup scheduled lists since flatten_network_pods(pods, appgroups): the entries update_net_placed appends"""
+        L = self._lib
+        i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        g, sel, nd = (np.ascontiguousarray(x, dtype=np.int32) for x in (group, selector, node))
+        n = C.c_int64()
+        args = (pods.ref(), appgroups.ref(), len(g), g.ctypes.data_as(i32p), sel.ctypes.data_as(i32p), nd.ctypes.data_as(i32p), C.byref(n))
+        self._ck_static(L.spx_flatten_net_placed(*args, None, None, None))
+        out = dict(key=np.zeros(max(n.value, 1), np.int32), node=np.zeros(max(n.value, 1), np.int32), max_cost=np.zeros(max(n.value, 1), np.int64))
+        self._ck_static(L.spx_flatten_net_placed(*args, out["key"].ctypes.data_as(i32p), out["node"].ctypes.data_as(i32p), out["max_cost"].ctypes.data_as(i64p)))
+        return {k: v[:n.value] for k, v in out.items()}
+
+    def update_net_placed(self, ent: dict) -> None:
+        """the workload keys' pair lists grown in place on the device (spx_update_net_placed)"""
+        i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        k, nd, c = np.ascontiguousarray(ent["key"], np.int32), np.ascontiguousarray(ent["node"], np.int32), np.ascontiguousarray(ent["max_cost"], np.int64)
+        self._ck(self._lib.spx_update_net_placed(self._h, len(k), k.ctypes.data_as(i32p), nd.ctypes.data_as(i32p), c.ctypes.data_as(i64p)))
+
+    def update_quota_used(self, ns, used, used_present, agg_used, agg_used_present) -> None:
+        """rows `ns` of ElasticQuotaInfo.Used replaced in place, with the new aggregate (spx_update_quota_used)"""
+        i32p, i64p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)
+        ns = np.ascontiguousarray(ns, np.int32)
+        used = np.ascontiguousarray(used, np.int64).reshape(-1)
+        up, au, aup = np.ascontiguousarray(used_present, np.uint8), np.ascontiguousarray(agg_used, np.int64), np.ascontiguousarray(agg_used_present, np.uint8).reshape(-1)
+        assert used.size == len(ns) * 8 and au.size == 8
+        self._ck(self._lib.spx_update_quota_used(self._h, len(ns), ns.ctypes.data_as(i32p), used.ctypes.data_as(i64p), up.ctypes.data_as(u8p),
+                                                 au.ctypes.data_as(i64p), aup.ctypes.data_as(u8p)))
+
     def upload_nrt(self, f: dict, rows=None) -> None:
         """rows = (begin, end): this engine holds only that slice of the pod batch (MultiEngine)"""
         L, H = self._lib, self._hdr
@@ -562,6 +590,11 @@ class Engine:
         if "quota" in snap:
             self._ck(L.spx_load_quota(self._h, snap["pods"].ref(), ref(snap.get("rc")), snap["quota"].ref()))
         self.n_nodes, self.n_pods = snap["nodes"].struct.n_nodes, snap["pods"].struct.n_pods
+
+    def load_trimaran_pods(self, pods: Table) -> None:
+        """a new pending batch for Allocatable / TLP / LVRB: flattened straight into the engine's pinned staging (spx_load_trimaran_pods)"""
+        self._ck(self._lib.spx_load_trimaran_pods(self._h, pods.ref()))
+        self.n_pods = pods.struct.n_pods
 
     def commit_path(self) -> int:
         """which form the last commit_sequential ran: 1 one-workgroup trimaran chain, 2 per-pod launches, 3 cooperative kernel"""

@@ -294,6 +294,56 @@ extern "C" int spx_flatten_net_commit(const spx_pod_objects* pods, const spx_app
   return SPX_OK;
 }
 
+// Pods that joined AppGroup scheduled lists since the tables were flattened (bound by an earlier cycle, by another scheduler):
+// what each adds to the workload keys' pair lists, in the key numbering spx_flatten_net_keys gives the pending batch `pods` — the
+// input of spx_update_net_placed.  Placed pod j = (group[j], selector[j], node[j]); per affected key of its group an entry
+// (key, node, -1) "the scheduled list is no longer empty" and, per dependency of the key's workloads on the pod's selector, an
+// entry (key, node, MaxNetworkCost) — exactly what a re-flatten with the pod appended to the group's placed list would add.
+// Sizes first (NULL arrays), then the entries.
+extern "C" int spx_flatten_net_placed(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int64_t n_placed, const int32_t* group,
+                                      const int32_t* selector, const int32_t* node, int64_t* n_entries_out, int32_t* key_out, int32_t* node_out,
+                                      int64_t* cost_out) {
+  if (!pods || !ag || !n_entries_out || n_placed < 0 || (n_placed && (!group || !selector || !node))) return SPX_ERR_ARG;
+  const bool fill = key_out && node_out && cost_out;
+  const size_t P = static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 0);
+  struct GroupKey {
+    int32_t selector, key;
+  };
+  std::vector<std::vector<GroupKey>> by_group(static_cast<size_t>(ag->n_groups > 0 ? ag->n_groups : 0));
+  int32_t next = 1;
+  for (size_t p = 0; p < P; ++p) {  // the numbering of spx_flatten_net_keys: first appearance in the pending batch
+    const int32_t g = pods->appgroup[p];
+    if (g < 0 || g >= ag->n_groups) continue;
+    auto& list = by_group[static_cast<size_t>(g)];
+    bool seen = false;
+    for (const GroupKey& e : list) seen |= e.selector == pods->selector[p];
+    if (!seen) list.push_back(GroupKey{pods->selector[p], next++});
+  }
+  int64_t n_out = 0;
+  for (int64_t j = 0; j < n_placed; ++j) {
+    const int32_t g = group[j];
+    if (g < 0 || g >= ag->n_groups) continue;  // not an AppGroup member: no list changes
+    for (const GroupKey& kk : by_group[static_cast<size_t>(g)]) {
+      bool any_dep = false;
+      for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w)
+        if (ag->wl_selector[w] == kk.selector && ag->dep_ptr[w + 1] > ag->dep_ptr[w]) any_dep = true;
+      if (!any_dep) continue;
+      if (fill) key_out[n_out] = kk.key, node_out[n_out] = node[j], cost_out[n_out] = -1;
+      ++n_out;
+      for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w) {
+        if (ag->wl_selector[w] != kk.selector) continue;
+        for (int32_t d = ag->dep_ptr[w]; d < ag->dep_ptr[w + 1]; ++d) {
+          if (ag->dep_selector[d] != selector[j]) continue;
+          if (fill) key_out[n_out] = kk.key, node_out[n_out] = node[j], cost_out[n_out] = ag->dep_max_cost[d];
+          ++n_out;
+        }
+      }
+    }
+  }
+  *n_entries_out = n_out;
+  return SPX_OK;
+}
+
 extern "C" int spx_toposort_less(const spx_pod_objects* pods, const int32_t* topo_order, int64_t n_pairs, const int64_t* a,
                                  const int64_t* b, uint8_t* less_out) {
   if (!pods || !topo_order || !a || !b || !less_out) return SPX_ERR_ARG;

@@ -1,32 +1,112 @@
-// parallel.hpp — chunked parallel-for over independent rows for the host flatteners (plain std::thread; the
-// flatteners are called from cgo / ctypes threads and own no thread pool).  Small inputs run inline.
+// parallel.hpp — chunked parallel-for over independent rows for the host flatteners.
+//
+// Round 4: a lazily created, process-wide pool of parked worker threads.  Rounds 1-3 spawned std::threads per call ("the
+// flatteners own no thread pool"): 16 thread creations cost ~0.4 ms — at 100 000 pods the whole trimaran pod flatten is 0.1 ms of
+// work, and the spawn was most of the 0.58 ms the call took (tools/r4/time_host_cycle.py).  The pool holds one job at a time: a
+// second caller (another cgo / ctypes thread, or a nested call) finds it busy and runs its rows inline, which is always correct.
+// Rows are handed out in chunks from an atomic counter, the calling thread works too.  After a fork() the child starts a pool of
+// its own (the parent's threads do not exist there).  Never destroyed: the workers sleep on a condition variable until exit.
 #pragma once
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 namespace spx_host {
 
+class RowPool {
+ public:
+  static RowPool& get() {
+    static std::mutex guard;
+    static RowPool* pool = nullptr;
+    static pid_t owner = 0;
+    std::lock_guard<std::mutex> lk(guard);
+    if (!pool || owner != getpid()) pool = new RowPool, owner = getpid();  // (a forked child leaks the parent's object: its threads are gone)
+    return *pool;
+  }
+
+  // fn(ctx, begin, end) over [0, n) in chunks of `chunk` rows on up to `threads` threads (the caller is one of them);
+  // false = the pool is busy, nothing was run
+  bool run(void (*fn)(void*, int64_t, int64_t), void* ctx, int64_t n, int64_t chunk, unsigned threads) {
+    if (!busy_.try_lock()) return false;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      while (workers_.size() + 1 < threads) {
+        const unsigned id = static_cast<unsigned>(workers_.size());
+        workers_.emplace_back([this, id] { work(id); });
+        workers_.back().detach();
+      }
+      fn_ = fn, ctx_ = ctx, n_ = n, chunk_ = chunk;
+      next_.store(0, std::memory_order_relaxed);
+      helpers_ = threads - 1;
+      pending_ = static_cast<int>(threads - 1);
+      ++gen_;
+    }
+    cv_.notify_all();
+    drain();
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      done_.wait(lk, [this] { return pending_ == 0; });
+    }
+    busy_.unlock();
+    return true;
+  }
+
+ private:
+  void drain() {
+    for (;;) {
+      const int64_t b = next_.fetch_add(chunk_, std::memory_order_relaxed);
+      if (b >= n_) return;
+      fn_(ctx_, b, std::min(n_, b + chunk_));
+    }
+  }
+  void work(unsigned id) {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (id >= helpers_) continue;  // this job wants fewer threads
+      }
+      drain();
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+
+  std::mutex busy_, mu_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> workers_;
+  void (*fn_)(void*, int64_t, int64_t) = nullptr;
+  void* ctx_ = nullptr;
+  int64_t n_ = 0, chunk_ = 1;
+  std::atomic<int64_t> next_{0};
+  unsigned helpers_ = 0;
+  int pending_ = 0;
+  uint64_t gen_ = 0;
+};
+
+// fn(begin, end) is called for disjoint ranges covering [0, n), possibly several times per thread (per-call state belongs inside fn)
 template <typename Fn>
 inline void parallel_rows(int64_t n, Fn&& fn, int64_t min_rows_per_thread = 8192, unsigned max_threads = 16) {
-  unsigned hw = std::thread::hardware_concurrency();
-  if (hw == 0) hw = 1;
+  static const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const unsigned want = static_cast<unsigned>(std::min<int64_t>(std::min(hw, max_threads), n / min_rows_per_thread));
   if (want <= 1) {
     fn(static_cast<int64_t>(0), n);
     return;
   }
-  std::vector<std::thread> th;
-  th.reserve(want);
-  const int64_t chunk = (n + want - 1) / want;
-  for (unsigned t = 0; t < want; ++t) {
-    const int64_t b = static_cast<int64_t>(t) * chunk, e = std::min(n, b + chunk);
-    if (b >= e) break;
-    th.emplace_back([&fn, b, e] { fn(b, e); });
-  }
-  for (auto& x : th) x.join();
+  // a few chunks per thread: the rows are not equally expensive (pods differ in container counts) and the workers wake at different times
+  const int64_t chunk = std::max<int64_t>(64, (n + 4 * want - 1) / (4 * want));
+  auto thunk = [](void* c, int64_t b, int64_t e) { (*static_cast<std::remove_reference_t<Fn>*>(c))(b, e); };
+  if (!RowPool::get().run(thunk, const_cast<void*>(static_cast<const void*>(&fn)), n, chunk, want)) fn(static_cast<int64_t>(0), n);
 }
 
 }  // namespace spx_host

@@ -76,3 +76,100 @@ def test_nrt_node_delta_equals_full_upload(gpu_required, hdr, strategy, kernel):
         assert np.array_equal(e.all_scores(NRT), ref.all_scores(NRT))
         for r in (0, n_pods - 1):
             assert np.array_equal(e.raw(NRT, r), ref.raw(NRT, r))
+
+
+def _grown_appgroups(hdr, ag, group, selector, node):
+    """the AppGroup table with the pods (group[j], selector[j], node[j]) appended to their groups' placed lists"""
+    from scheduler_plugins_amd._abi import Table
+    G = ag.struct.n_groups
+    ptr = ag.array("placed_ptr")[:G + 1].astype(np.int64)
+    sel, nd = ag.array("placed_selector"), ag.array("placed_node")
+    new_sel, new_nd, new_ptr = [], [], [0]
+    for g in range(G):
+        extra = [j for j in range(len(group)) if group[j] == g]
+        new_sel += list(sel[ptr[g]:ptr[g + 1]]) + [selector[j] for j in extra]
+        new_nd += list(nd[ptr[g]:ptr[g + 1]]) + [node[j] for j in extra]
+        new_ptr.append(len(new_sel))
+    keep = {f: ag.array(f) for f in ("wl_ptr", "wl_selector", "dep_ptr", "dep_selector", "dep_max_cost", "topo_ptr", "topo_selector", "topo_index")}
+    return Table(hdr, "spx_appgroup_objects", n_groups=G, placed_ptr=np.array(new_ptr, np.int32), placed_selector=np.array(new_sel, np.int32),
+                 placed_node=np.array(new_nd, np.int32), **keep)
+
+
+def test_net_placed_delta_equals_full_upload(gpu_required, hdr):
+    """AppGroup scheduled lists that grew between two cycles: spx_flatten_net_placed + spx_update_net_placed leave the tables a
+    re-flatten + re-upload of the grown AppGroups leaves (scores, statuses, and the decisions)"""
+    from helpers import NETOVERHEAD
+    n_nodes, n_pods = 900, 600
+    snap = synth.network_snapshot(hdr, n_nodes, n_pods, seed=21, pods_per_group=40)
+    ag = snap["appgroups"]
+    rng = np.random.default_rng(5)
+    G = ag.struct.n_groups
+    m = 57
+    group = rng.integers(0, G, m).astype(np.int32)
+    group[:3] = -1                                  # not AppGroup members: no entries
+    wl_ptr, wl_sel = ag.array("wl_ptr"), ag.array("wl_selector")
+    selector = np.array([wl_sel[rng.integers(wl_ptr[g], wl_ptr[g + 1])] if g >= 0 else 0 for g in group], np.int32)
+    node = rng.integers(0, n_nodes, m).astype(np.int32)
+    node[5] = -1                                    # a host outside the snapshot: the key's PreFilter turns to Error
+    grown = _grown_appgroups(hdr, ag, group, selector, node)
+    mask = mask_of(NETOVERHEAD)
+    with Engine(0) as ref, Engine(0) as e:
+        ref.load_network_objects(snap["nodes"], snap["pods"], grown, snap["nettopo"])
+        e.load_network_objects(snap["nodes"], snap["pods"], ag, snap["nettopo"])
+        e.eval(mask)
+        e.sync()
+        before = e.all_scores(NETOVERHEAD)
+        ent = e.flatten_net_placed(snap["pods"], ag, group, selector, node)
+        assert len(ent["key"]) > m // 2 and (ent["max_cost"] >= 0).any() and (ent["max_cost"] == -1).any()
+        e.update_net_placed(ent)
+        with pytest.raises(Exception):
+            e.all_scores(NETOVERHEAD)  # computed from the old lists: stale
+        e.eval(mask), ref.eval(mask)
+        e.sync(), ref.sync()
+        assert np.array_equal(e.all_scores(NETOVERHEAD), ref.all_scores(NETOVERHEAD))
+        assert np.array_equal(e.all_status(NETOVERHEAD), ref.all_status(NETOVERHEAD))
+        assert not np.array_equal(before, e.all_scores(NETOVERHEAD))
+        for which in (0, 1, 2):
+            assert np.array_equal(e.raw(NETOVERHEAD, 17, which), ref.raw(NETOVERHEAD, 17, which))
+        e.update_net_placed(e.flatten_net_placed(snap["pods"], grown, group[10:20], selector[10:20], node[10:20]))  # a second delta on top
+        ref2 = _grown_appgroups(hdr, grown, group[10:20], selector[10:20], node[10:20])
+        with Engine(0) as r2:
+            r2.load_network_objects(snap["nodes"], snap["pods"], ref2, snap["nettopo"])
+            r2.eval(mask), e.eval(mask)
+            r2.sync(), e.sync()
+            assert np.array_equal(e.all_scores(NETOVERHEAD), r2.all_scores(NETOVERHEAD))
+            assert np.array_equal(e.all_status(NETOVERHEAD), r2.all_status(NETOVERHEAD))
+
+
+def test_quota_used_delta_equals_full_upload(gpu_required, hdr):
+    """ElasticQuota Used rows replaced in place (AddPod / DeletePod between cycles) = a full upload of the new quota table"""
+    from helpers import CAPACITY
+    from scheduler_plugins_amd._abi import Table
+    snap = synth.full_snapshot(hdr, 300, 900, seed=9, quota_sized_for_batch=True)
+    quota = snap["quota"]
+    NS = quota.struct.n_namespaces
+    used, usedp = quota.array("used").reshape(-1, 8).copy(), quota.array("used_present").copy()
+    rng = np.random.default_rng(2)
+    ns = np.sort(rng.choice(NS, 9, replace=False)).astype(np.int32)
+    mx = quota.array("max").reshape(-1, 8)
+    used[ns] = np.where(rng.random((9, 8)) < 0.5, mx[ns], used[ns] // 2)  # some namespaces now sit at Max, others freed
+    usedp[ns[:2]] = 1
+    fields = {f: quota.array(f) for f in quota._keep if f not in ("used", "used_present")}
+    scalars = {f: getattr(quota.struct, f) for f, _ in quota.struct._fields_ if f not in hdr.field_np["spx_quota_objects"]}
+    new_quota = Table(hdr, "spx_quota_objects", used=used.reshape(-1), used_present=usedp, **fields, **scalars)
+    mask = mask_of(CAPACITY)
+    with Engine(0) as ref, Engine(0) as e:
+        f_new = ref.flatten_quota(snap["pods"], snap["rc"], new_quota)
+        ref.upload_quota(f_new)
+        e.upload_quota(e.flatten_quota(snap["pods"], snap["rc"], quota))
+        e.eval(mask)
+        e.sync()
+        before = e.prefilter(CAPACITY)
+        e.update_quota_used(ns, used[ns], usedp[ns], f_new["cols"]["agg_used"], f_new["cols"]["agg_used_present"])
+        with pytest.raises(Exception):
+            e.prefilter(CAPACITY)
+        e.eval(mask), ref.eval(mask)
+        e.sync(), ref.sync()
+        after = e.prefilter(CAPACITY)
+        assert np.array_equal(after, ref.prefilter(CAPACITY))
+        assert not np.array_equal(before, after)

@@ -41,3 +41,24 @@ def test_load_c_equals_python_loaders(gpu_required, hdr, strategy):
     for k in out[0]:
         assert np.array_equal(out[0][k], out[1][k]), k
     assert (out[0]["prefilter"] != 0).any() and (out[0][("status", NRT)] != 0).any()
+
+
+def test_load_trimaran_pods_equals_flatten_and_upload(gpu_required, hdr):
+    """a new batch through spx_load_trimaran_pods (pinned staging, one pass) = flatten_trimaran_pods + upload_trimaran_pods"""
+    snap = synth.trimaran_snapshot(hdr, 900, 500, seed=3)
+    batch2 = synth.synth_pods(hdr, 500, seed=77)
+    mask = mask_of(ALLOCATABLE, TLP, LVRB)
+    out = []
+    for fused in (False, True):
+        with Engine(0) as e:
+            e.load_trimaran_objects(snap["nodes"], snap.get("rc"), snap["pods"], snap["metrics"], snap.get("assigned"))
+            e.eval(mask)
+            if fused:
+                e.load_trimaran_pods(batch2)
+            else:
+                e.upload_trimaran_pods(e.flatten_trimaran_pods(batch2))
+            e.eval(mask)
+            e.sync()
+            out.append([e.all_scores(p) for p in (ALLOCATABLE, TLP, LVRB)])
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
