@@ -344,8 +344,81 @@ def nrt_integration():
             "cases": cases}
 
 
+def trimaran_handler():
+    """pkg/trimaran/handler_test.go:12-77 TestHandlerCacheCleanup: the PodAssignEventHandler cache after OnUpdate + cleanupCache.
+    Timestamps become offsets in seconds from time.Now() (null: the zero time.Time of an entry built without one)."""
+    import re
+    path = "pkg/trimaran/handler_test.go"
+    src = (REF / path).read_text()
+    pod_names = dict(re.findall(r"(pod\d) := st\.MakePod\(\)\.Name\(\"([^\"]+)\"\)", src))
+    unit = {"time.Minute": 60, "time.Second": 1}
+
+    def offset(ts):
+        if ts is None:
+            return None
+        if isinstance(ts, Call) and ts.fn == "time.Now":
+            return 0
+        assert isinstance(ts, Call) and ts.fn == ".Add" and ts.args[0].fn == "time.Now" and ts.args[1].fn == "op*", ts
+        n, u = ts.args[1].args
+        return n * unit[u.name]
+
+    def name_of(v):
+        return pod_names[v.name.split(".")[0]] if isinstance(v, Ident) else v
+
+    cases = []
+    for t in parse_literal_after(src, "tests := "):
+        cases.append({"name": t["name"], "line": line_of(src, '"' + t["name"] + '"', 0),
+                      "cache": [{"pod": name_of(e["Pod"]), "age_offset_s": offset(e.get("Timestamp"))} for e in t["podInfoList"]],
+                      "pod_to_update": t.get("podToUpdate", ""), "expected_pods": [name_of(v) for v in t["expectedCachePods"]],
+                      "expected_size": t["expectedCacheSize"]})
+    return {"source": path, "node": re.search(r'testNode := "([^"]+)"', src).group(1), "reporting_interval_s": 60, "cases": cases}
+
+
+def nrt_discard_reserved():
+    """pkg/noderesourcetopology/cache/discardreserved_test.go:34-140: the four tests of the DiscardReserved cache as operation lists.
+    The tests are straight-line code, not tables: the operations and assertions below are read off the statements (cited per step)."""
+    import re
+    path = "pkg/noderesourcetopology/cache/discardreserved_test.go"
+    src = (REF / path).read_text()
+
+    def ln(needle, start=0):
+        return line_of(src, needle, start)
+
+    out = {"source": path, "tests": []}
+    # TestDiscardReservedNodesGetCachedNRTCopy (:34-58): one table case through checkGetCachedNRTCopy
+    p = src.index("func TestDiscardReservedNodesGetCachedNRTCopy")
+    node = re.search(r'testNodeName := "([^"]+)"', src[p:]).group(1)
+    (case,) = parse_literal_after(src[p:], "testCases := ")
+    out["tests"].append({"name": "TestDiscardReservedNodesGetCachedNRTCopy", "line": ln("func TestDiscardReservedNodesGetCachedNRTCopy"),
+                         "steps": [{"op": "store_nrt", "node": node},
+                                   {"op": "get", "node": node, "has_foreign_pods": case["hasForeignPods"].name == "true",
+                                    "expect_ok": case["expectedOK"].name == "true", "expect_nrt": True, "case": case["name"]}]})
+    # TestDiscardReservedNodesGetNRTCopyFails (:60-77): a reservation on node1 -> (nil, Fresh false)
+    p = src.index("func TestDiscardReservedNodesGetNRTCopyFails")
+    m = re.search(r'"(node\d)": \{\s*types\.UID\("([^"]+)"\): true', src[p:])
+    out["tests"].append({"name": "TestDiscardReservedNodesGetNRTCopyFails", "line": ln("func TestDiscardReservedNodesGetNRTCopyFails"),
+                         "steps": [{"op": "preset", "node": m.group(1), "uid": m.group(2)},
+                                   {"op": "get", "node": re.search(r'GetCachedNRTCopy\(context\.Background\(\), "([^"]+)"', src[p:]).group(1),
+                                    "expect_ok": False, "expect_nrt": False}]})
+    # TestDiscardReservedNodesReserveNodeResources (:79-104)
+    p = src.index("func TestDiscardReservedNodesReserveNodeResources")
+    m = re.search(r'ReserveNodeResources\("([^"]+)", &corev1\.Pod\{\s*ObjectMeta: metav1\.ObjectMeta\{\s*Name:\s*"([^"]+)",\s*Namespace:\s*"([^"]+)",\s*UID:\s*"([^"]+)"', src[p:])
+    out["tests"].append({"name": "TestDiscardReservedNodesReserveNodeResources", "line": ln("func TestDiscardReservedNodesReserveNodeResources"),
+                         "steps": [{"op": "reserve", "node": m.group(1), "uid": m.group(4)},
+                                   {"op": "expect_map", "node": m.group(1), "uids": {m.group(4): True}}]})
+    # TestDiscardReservedNodesRemoveReservationForNode (:106-150)
+    p = src.index("func TestDiscardReservedNodesRemoveReservationForNode")
+    uid = re.search(r'UID:\s*"([^"]+)"', src[p:]).group(1)
+    n1 = re.search(r'ReserveNodeResources\("([^"]+)", pod\)', src[p:]).group(1)
+    n2 = re.search(r'removeReservationForNode\("([^"]+)", pod\)', src[p:]).group(1)
+    out["tests"].append({"name": "TestDiscardReservedNodesRemoveReservationForNode", "line": ln("func TestDiscardReservedNodesRemoveReservationForNode"),
+                         "steps": [{"op": "reserve", "node": n1, "uid": uid}, {"op": "expect_map", "node": n1, "uids": {uid: True}},
+                                   {"op": "remove", "node": n2, "uid": uid}, {"op": "expect_map", "node": n2, "uids": {}}]})
+    return out
+
+
 FIXTURES = {"capacity.json": capacity, "nrt_filter.json": nrt_filter, "nrt_score.json": nrt_score, "nrt_least_numa.json": nrt_least_numa,
-            "nrt_integration.json": nrt_integration}
+            "nrt_integration.json": nrt_integration, "trimaran_handler.json": trimaran_handler, "nrt_discard_reserved.json": nrt_discard_reserved}
 
 if __name__ == "__main__":
     for fname, fn in FIXTURES.items():

@@ -416,11 +416,15 @@ def test_discard_reserved_cache_semantics(gpu_required, hdr, oracle):
     res, nodes, nrt_t, pods = _wide_snapshot(hdr, 96, 40, seed=33)
     params = O.nrt_params(hdr, res, "LeastAllocated")
     n = 96
-    reservations = {}                                      # node index -> {pod uid}: the cache's reservationMap
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "oracle"))
+    from cache_models import DiscardReservedModel   # the restatement tests/golden/nrt_discard_reserved.json pins (test_oracle_golden_caches.py)
+    cache = DiscardReservedModel({str(i): True for i in range(n)})
 
     def cache_view():
         """GetCachedNRTCopy for every node: (NRT or None, Fresh)"""
-        reserved = np.array([len(reservations.get(i, ())) > 0 for i in range(n)])
+        reserved = np.array([not cache.get_cached_nrt_copy(str(i))[1] for i in range(n)])
         nrt_t.array("fresh")[:] = ~reserved          # CachedNRTInfo.Fresh per node (the table is the shim's per-cycle marshalling)
         return reserved, nrt_t
 
@@ -442,7 +446,7 @@ def test_discard_reserved_cache_semantics(gpu_required, hdr, oracle):
     assert not reserved.any() and not (st0 == INVALID).any()
     # Reserve: two pods on node 5, one on node 40
     for node, uid in ((5, "a"), (5, "b"), (40, "c")):
-        reservations.setdefault(node, set()).add(uid)
+        cache.reserve(str(node), uid)
     reserved, t1 = cache_view()
     st1, sc1, _, _ = evaluate(t1)
     filtered = ~((qos == hdr.consts["SPX_QOS_BESTEFFORT"]) & (nn == 0))       # filter.go:186-190
@@ -452,10 +456,10 @@ def test_discard_reserved_cache_semantics(gpu_required, hdr, oracle):
     assert (sc1[guaranteed][:, reserved] == 0).all() and (sc1[~guaranteed] == 100).all()
     assert np.array_equal(st1[:, ~reserved], st0[:, ~reserved]) and np.array_equal(sc1[:, ~reserved], sc0[:, ~reserved])
     # PostBind of one of node 5's pods: still reserved; Unreserve of the other and PostBind on node 40: back to the API server's view
-    reservations[5].discard("a")
+    cache.remove_reservation("5", "a")
     assert cache_view()[0][5]
-    reservations[5].discard("b")
-    reservations[40].discard("c")
+    cache.remove_reservation("5", "b")
+    cache.remove_reservation("40", "c")
     reserved, t2 = cache_view()
     st2, sc2, _, _ = evaluate(t2)
     assert not reserved.any() and np.array_equal(st2, st0) and np.array_equal(sc2, sc0)
