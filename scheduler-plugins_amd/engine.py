@@ -589,7 +589,9 @@ class Engine:
             self._ck(L.spx_load_network(self._h, snap["nodes"].ref(), snap["pods"].ref(), snap["appgroups"].ref(), snap["nettopo"].ref()))
         if "quota" in snap:
             self._ck(L.spx_load_quota(self._h, snap["pods"].ref(), ref(snap.get("rc")), snap["quota"].ref()))
-        self.n_nodes, self.n_pods = snap["nodes"].struct.n_nodes, snap["pods"].struct.n_pods
+        self.n_pods = snap["pods"].struct.n_pods
+        if "nodes" in snap:
+            self.n_nodes = snap["nodes"].struct.n_nodes
 
     def load_trimaran_pods(self, pods: Table) -> None:
         """a new pending batch for Allocatable / TLP / LVRB: flattened straight into the engine's pinned staging (spx_load_trimaran_pods)"""
