@@ -726,6 +726,9 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *   SPX_OPT_COMMIT_COOP        1 (default) = spx_commit_sequential with Filter plugins in the mask runs as ONE cooperative persistent launch
  *                              (node state in registers, two granule exchanges per pod) when the profile fits it; 0 = always the per-pod
  *                              single-row launches replayed from a graph
+ *   SPX_OPT_NRT_RANK_FILTER    1 (default) = a whole-batch NRT sweep over pod classes runs its Filter launch in rank space (requests and
+ *                              zone quantities as positions in the chunk's sorted request list: integer subtracts instead of float64
+ *                              compares, no zone-table mutation); 0 = the float64 Filter launch.  Same status table either way
  */
 #define SPX_OPT_ROW_ALIGN 0
 #define SPX_OPT_REFERENCE_KERNELS 1
@@ -738,7 +741,8 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
 #define SPX_OPT_PEAKS_POD_CLASSES 8
 #define SPX_OPT_NRT_LN_LIST_PERMILLE 9
 #define SPX_OPT_COMMIT_COOP 10
-#define SPX_NUM_OPTIONS 11
+#define SPX_OPT_NRT_RANK_FILTER 11
+#define SPX_NUM_OPTIONS 12
 int spx_set_option(spx_engine* e, int option, int64_t value);
 int spx_get_option(const spx_engine* e, int option, int64_t* value);
 
@@ -767,6 +771,9 @@ int spx_load_quota(spx_engine* e, const spx_pod_objects* pods, const spx_resourc
 /* Which form the last spx_commit_sequential ran: 1 = the one-workgroup chain of the Filter-less profile, 2 = per-pod single-row
  * launches (replayed from a graph), 3 = the cooperative persistent kernel; 0 = none yet */
 int spx_commit_path(const spx_engine* e);
+/* Which Filter launch the last NodeResourceTopologyMatch sweep ran: 1 = float64 compares (k_nrt_fast / the reference-arithmetic
+ * kernel), 2 = rank space (SPX_OPT_NRT_RANK_FILTER: whole-batch sweeps over pod classes); 0 = none yet */
+int spx_nrt_filter_path(const spx_engine* e);
 
 /* which formulation of a plugin's sweep the uploaded tables select: 0 = generic (reference arithmetic, operation for
  * operation), 1 = fast formulation (same results; see DESIGN.md for each kernel's preconditions); <0 on error.

@@ -34,9 +34,6 @@ namespace {
 
 using namespace nrtdev;
 
-constexpr int kPodsPerUnit = 32;
-constexpr int kWindow = 256;  // nodes per block (4 wavefronts)
-constexpr int kXcdMapWindows = 32;  // from this many node windows on (8k nodes), blocks are mapped XCD-aware (see k_nrt_fast)
 // ---------------------------------------------------------------- BalancedAllocation in float32 (Score launch)
 //
 // The float64 form above costs ~44 float64 instructions per zone and container and holds 144 VGPRs of node tables; float32
@@ -1062,7 +1059,8 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
 #define SPX_NRTF_CASE(RMV, SGV)                                                                           \
   if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                                        \
     if (split) { /* the Filter half does not depend on the strategy */ \
-      hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhFilter>), dim3(blocks), dim3(256), 0, s, a, n_tiles); \
+      if (!launch_nrt_filter_rank(a, n_tiles, blocks, s)) /* rank space when the engine built the chunk stream (kernels_nrt_rank.hip) */ \
+        hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhFilter>), dim3(blocks), dim3(256), 0, s, a, n_tiles); \
       const bool ln_lists = SGV == kSgLeastNuma && a.redo_list && a.ln_rec && a.ln_rows > 0; \
       if (SGV == kSgBalanced) (void)hipMemsetAsync(a.redo_list, 0, 8, s); /* the float32 Score launch lists the cells it could not decide */ \
       if (ln_lists) { /* sizes 1-2 here, the listed cells in k_nrt_ln_redo; the complete sweep if a row's list overflowed */ \

@@ -19,6 +19,9 @@ constexpr int kSgMost = 1;
 constexpr int kSgBalanced = 2;
 constexpr int kSgLeastNuma = 3;
 constexpr double kNoCap = kNrtNoCap;  // b[][] of a cell whose capacity is not positive
+constexpr int kPodsPerUnit = 32;    // pod rows per block
+constexpr int kWindow = 256;        // nodes per block (4 wavefronts)
+constexpr int kXcdMapWindows = 32;  // from this many node windows on (8k nodes), blocks are mapped XCD-aware (see k_nrt_fast)
 
 // Placed at the top of a block guarded by a wave-uniform condition (a requested-resource bit of the pod record): an empty
 // volatile asm cannot be speculated, so the backend keeps the scalar branch and the wave skips the block.  Without it the

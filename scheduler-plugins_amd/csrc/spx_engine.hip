@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -53,7 +54,7 @@ struct spx_engine {
   int64_t row_stride = 0;
 
   // spx_set_option state (per engine; nothing is read from the environment)
-  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1};
+  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1};
 
   // params
   int32_t alloc_mode = SPX_MODE_LEAST;
@@ -112,6 +113,9 @@ struct spx_engine {
   DevBuf d_delta;                // staged rows of a node-table delta (spx_update_*_nodes)
   DevBuf d_nrt_uniq, d_nrt_dups;  // int32 [n_uniq] representative rows, ascending; int32 [n_dups][2] (row, its representative)
   int64_t nrt_n_uniq = 0, nrt_n_dups = 0;
+  DevBuf d_nrt_rk, d_nrt_rk_off;  // rank-space Filter: the chunk stream of the listed rows (nrt_build_rank_stream) and its chunk offsets
+  uint32_t nrt_rk_max_dwords = 0;  // largest chunk block; 0 = no stream (the float64 Filter runs)
+  int last_nrt_filter = 0;         // spx_nrt_filter_path
   DevBuf d_pk_uniq, d_pk_dups;    // the same for Peaks: classes of pods with equal cpu requests
   int64_t pk_n_uniq = 0, pk_n_dups = 0;
   bool nrt_ln_ok = false;  // LeastNUMANodes tables can be built: every zone cost within [0, 255]
@@ -592,7 +596,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_best, &e->d_stats, &e->d_decide, &e->d_lroc_nreq_c, &e->d_lroc_nreq_m, &e->d_lroc_nlim_c, &e->d_lroc_nlim_m,
                     &e->d_lroc_preq_c, &e->d_lroc_preq_m, &e->d_lroc_plim_c, &e->d_lroc_plim_m, &e->d_lroc_tab, &e->d_lroc_podf,
                     &e->d_pk_cap, &e->d_pk_util, &e->d_pk_valid, &e->d_pk_k1, &e->d_pk_k2, &e->d_pk_pod, &e->d_pk_min, &e->d_pk_max,
-                    &e->d_nrt_uniq, &e->d_nrt_dups, &e->d_pk_uniq, &e->d_pk_dups, &e->d_delta, &e->d_nrt_lnrec, &e->d_net_pair_node2, &e->d_net_pair_max2};
+                    &e->d_nrt_uniq, &e->d_nrt_dups, &e->d_pk_uniq, &e->d_pk_dups, &e->d_delta, &e->d_nrt_lnrec, &e->d_net_pair_node2, &e->d_net_pair_max2, &e->d_nrt_rk, &e->d_nrt_rk_off};
   for (DevBuf* b : bufs)
     if (b->p && !b->external) (void)hipFree(b->p);
   for (int i = 0; i < SPX_NUM_PLUGINS; ++i) {
@@ -640,6 +644,7 @@ int spx_set_option(spx_engine* e, int option, int64_t value) {
     case SPX_OPT_NRT_POD_CLASSES:
     case SPX_OPT_PEAKS_POD_CLASSES:
     case SPX_OPT_COMMIT_COOP:
+    case SPX_OPT_NRT_RANK_FILTER:
       if (value != 0 && value != 1) return fail(e, SPX_ERR_ARG, "option takes 0 or 1");
       break;
     case SPX_OPT_NRT_LN_LIST_PERMILLE:
@@ -1552,6 +1557,115 @@ void nrt_build_classes(const uint32_t* items, const uint64_t* hash, size_t p, si
     }
   }, 2048);
 }
+
+// The rank-space Filter's input (kernels_nrt_rank.hip), built per chunk of 32 listed rows: what the chunk's pods ask for, as RANKS.
+// For every resource slot the chunk's distinct compared quantities, sorted, behind a leading 0 ("any reporting zone"): a node's
+// zone then needs one number per resource — how many of them its available quantity reaches — and "available >= request" becomes
+// "that count >= the request's position + 1", an 11-bit integer comparison the kernel does with a subtract (two zones per dword).
+// The container-scope handler charges an app container to the zone it chose before the next one is tested
+// (filter.go:131-163 -> numaresources.go:145-182); instead of mutating the zone table, the later container is compared with the
+// SUM of the requests a zone would have been charged — available - charged >= request  <=>  available >= charged + request, exact
+// in integers — so the chunk's lists also hold those sums: per pod 13 comparison vectors (layout: spx::kRk*, spx_internal.h):
+// the pod-level request, the eight containers, and for the second / third app container the sums with the earlier app
+// containers a zone may carry.  Pods with more than three app containers have no such finite list: *ok_out = false and the
+// batch keeps the float64 Filter.  Chunk block: 16 header dwords (per slot: search steps | list offset << 8; [8] rows),
+// the lists (2^steps - 1 doubles each, padded with +inf), then per pod kRkPodHead + 13 x RM dwords.
+void nrt_build_rank_stream(const uint32_t* items, const int32_t* list, size_t n_list, size_t R, std::vector<uint32_t>& words, std::vector<uint32_t>& off,
+                           uint32_t* max_dwords_out, bool* ok_out) {
+  const size_t RM = R <= 4 ? 4 : 8, IW = R <= 4 ? 16 : 32, PW = 10 * IW, PWR = spx::kRkPodHead + spx::kRkVectors * RM;
+  const size_t n_chunks = (n_list + spx::kRkChunkRows - 1) / spx::kRkChunkRows;
+  std::vector<std::vector<uint32_t>> blocks(n_chunks);
+  std::atomic<bool> ok{true};
+  auto f64 = [](const uint32_t* w) { double v; std::memcpy(&v, w, sizeof v); return v; };
+  spx_host::parallel_rows(static_cast<int64_t>(n_chunks), [&](int64_t c0, int64_t c1) {
+    std::vector<double> vals[SPX_NRT_MAX_RES];
+    for (int64_t c = c0; c < c1; ++c) {
+      const size_t first = static_cast<size_t>(c) * spx::kRkChunkRows, rows = std::min<size_t>(spx::kRkChunkRows, n_list - first);
+      // pass 1: every pod's 13 vectors (value per slot, NaN = not compared)
+      std::vector<double> vec(rows * spx::kRkVectors * RM, std::numeric_limits<double>::quiet_NaN());
+      std::vector<uint32_t> head(rows * spx::kRkPodHead, 0u);
+      for (size_t r = 0; r < R; ++r) vals[r].clear();
+      for (size_t i = 0; i < rows; ++i) {
+        const uint32_t* w = items + static_cast<size_t>(list[first + i]) * PW;
+        uint32_t* h = &head[i * spx::kRkPodHead];
+        h[0] = w[0], h[1] = w[1];
+        const uint32_t n_ctr = (w[0] >> 16) & 0xffu;
+        uint32_t app[3] = {0xffu, 0xffu, 0xffu}, n_app = 0;
+        for (size_t k = 1; k <= 9; ++k) h[1 + k] = w[k * IW + 2 * RM];  // the items' slot sets (absent items are zero)
+        for (uint32_t ctr = 0; ctr < n_ctr && ctr < SPX_NRT_MAX_CTRS; ++ctr)
+          if ((h[3 + ctr] >> 24) == SPX_CTR_APP) {
+            if (n_app < 3) app[n_app] = ctr;
+            ++n_app;
+          }
+        if (n_app > 3) ok = false;
+        h[11] = app[0] | (app[1] << 8) | (app[2] << 16) | (std::min<uint32_t>(n_app, 255u) << 24);
+        auto fit_of = [&](size_t item) { return (w[item * IW + 2 * RM] >> 8) & 0xffu; };
+        auto raw_of = [&](size_t item, size_t r) { return f64(w + item * IW + 2 * r); };
+        double* v = &vec[i * spx::kRkVectors * RM];
+        auto put = [&](size_t vi, size_t item, std::initializer_list<uint32_t> charged) {
+          const uint32_t fit = fit_of(item);
+          for (size_t r = 0; r < R; ++r) {
+            if (!((fit >> r) & 1u)) continue;
+            double q = raw_of(item, r);
+            for (uint32_t j : charged)
+              if ((fit_of(2 + j) >> r) & 1u) q += raw_of(2 + j, r);
+            v[vi * RM + r] = q;
+            vals[r].push_back(q);
+          }
+        };
+        put(0, 1, {});
+        for (uint32_t ctr = 0; ctr < n_ctr && ctr < SPX_NRT_MAX_CTRS; ++ctr) put(1 + ctr, 2 + ctr, {});
+        if (n_app >= 2 && n_app <= 3) put(9, 2 + app[1], {app[0]});
+        if (n_app == 3) put(10, 2 + app[2], {app[0]}), put(11, 2 + app[2], {app[1]}), put(12, 2 + app[2], {app[0], app[1]});
+      }
+      // pass 2: the lists, then the thresholds
+      uint32_t steps[SPX_NRT_MAX_RES] = {0}, loff[SPX_NRT_MAX_RES] = {0};
+      size_t list_doubles = 0;
+      for (size_t r = 0; r < R; ++r) {
+        auto& a = vals[r];
+        a.push_back(0.0);
+        std::sort(a.begin(), a.end());
+        a.erase(std::unique(a.begin(), a.end()), a.end());
+        uint32_t k = 1;
+        while ((size_t{1} << k) - 1 < a.size()) ++k;
+        steps[r] = k, loff[r] = static_cast<uint32_t>(list_doubles);
+        list_doubles += (size_t{1} << k);  // 2^k - 1 entries and one pad: every list starts 16-byte aligned
+      }
+      std::vector<uint32_t>& b = blocks[static_cast<size_t>(c)];
+      b.assign(16 + 2 * list_doubles + rows * PWR, 0u);
+      for (size_t r = 0; r < R; ++r) b[r] = steps[r] | (loff[r] << 8);
+      b[8] = static_cast<uint32_t>(rows);
+      for (size_t r = 0; r < R; ++r) {
+        double* dst = reinterpret_cast<double*>(&b[16]) + loff[r];
+        const size_t n = size_t{1} << steps[r];
+        for (size_t j = 0; j < n; ++j) dst[j] = j < vals[r].size() ? vals[r][j] : std::numeric_limits<double>::infinity();
+      }
+      for (size_t i = 0; i < rows; ++i) {
+        uint32_t* dst = &b[16 + 2 * list_doubles + i * PWR];
+        std::memcpy(dst, &head[i * spx::kRkPodHead], spx::kRkPodHead * sizeof(uint32_t));
+        for (size_t vi = 0; vi < spx::kRkVectors; ++vi)
+          for (size_t r = 0; r < R; ++r) {
+            const double q = vec[(i * spx::kRkVectors + vi) * RM + r];
+            if (q != q) continue;
+            const uint32_t t = static_cast<uint32_t>(std::lower_bound(vals[r].begin(), vals[r].end(), q) - vals[r].begin()) + 1u;
+            dst[spx::kRkPodHead + vi * RM + r] = t | (t << 16);
+          }
+      }
+    }
+  }, 8);
+  off.assign(n_chunks + 1, 0u);
+  uint32_t max_dwords = 0;
+  for (size_t c = 0; c < n_chunks; ++c) {
+    off[c + 1] = off[c] + static_cast<uint32_t>((blocks[c].size() + 3) & ~size_t{3});
+    max_dwords = std::max<uint32_t>(max_dwords, off[c + 1] - off[c]);
+  }
+  words.assign(off[n_chunks], 0u);
+  spx_host::parallel_rows(static_cast<int64_t>(n_chunks), [&](int64_t c0, int64_t c1) {
+    for (int64_t c = c0; c < c1; ++c) std::memcpy(&words[off[static_cast<size_t>(c)]], blocks[static_cast<size_t>(c)].data(), blocks[static_cast<size_t>(c)].size() * sizeof(uint32_t));
+  }, 64);
+  *max_dwords_out = max_dwords;
+  *ok_out = ok.load();
+}
 }  // namespace
 
 // test hook (host only, no device): the representative row of every pod of a batch, as spx_upload_nrt_pods computes it
@@ -1630,6 +1744,7 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
       e->nrt_creq_valid = true;
     }
     e->nrt_n_uniq = e->nrt_n_dups = 0;
+    e->nrt_rk_max_dwords = 0;
     if (e->nrt_fast_pods && p > 0) {
       std::vector<int32_t> rep(p);
       nrt_build_classes(items, hash.data(), p, R, rep.data());
@@ -1645,6 +1760,18 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
         SPX_HIP(e, hipStreamSynchronize(e->stream));
         e->nrt_n_uniq = static_cast<int64_t>(uniq.size());
         e->nrt_n_dups = static_cast<int64_t>(dups.size() / 2);
+        // the representatives' requests as ranks, per chunk of 32 (kernels_nrt_rank.hip)
+        std::vector<uint32_t> rk, rk_off;
+        uint32_t rk_max = 0;
+        bool rk_ok = false;
+        nrt_build_rank_stream(items, uniq.data(), uniq.size(), R, rk, rk_off, &rk_max, &rk_ok);
+        e->nrt_rk_max_dwords = 0;
+        if (rk_ok && rk_max * sizeof(uint32_t) <= spx::kRkMaxChunkBytes) {
+          if ((rc = upload(e, e->d_nrt_rk, rk.data(), rk.size() * sizeof(uint32_t)))) return rc;
+          if ((rc = upload(e, e->d_nrt_rk_off, rk_off.data(), rk_off.size() * sizeof(uint32_t)))) return rc;
+          SPX_HIP(e, hipStreamSynchronize(e->stream));
+          e->nrt_rk_max_dwords = rk_max;
+        }
       }
     }
   }
@@ -2009,6 +2136,11 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     if (classes) {
       na.row_list = static_cast<const int32_t*>(e->d_nrt_uniq.p);
       na.n_list = e->nrt_n_uniq;
+      if (e->nrt_rk_max_dwords && e->option[SPX_OPT_NRT_RANK_FILTER]) {  // the Filter launch in rank space
+        na.rk_stream = static_cast<const uint32_t*>(e->d_nrt_rk.p);
+        na.rk_off = static_cast<const uint32_t*>(e->d_nrt_rk_off.p);
+        na.rk_max_dwords = e->nrt_rk_max_dwords;
+      }
     }
     if (na.strategy == SPX_NRT_LEAST_NUMA_NODES && na.fast && !(na.opts & spx::kOptNrtGeneric) && !e->row_indirect) {
       // LeastNUMANodes, batch launch: per evaluated row and node scope a list of the nodes whose cell needs the complete subset
@@ -2027,6 +2159,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
       }
     }
     spx::launch_nrt(na, e->stream);
+    e->last_nrt_filter = na.rk_stream ? 2 : 1;
     if (classes)
       spx::launch_rows_expand(static_cast<const int32_t*>(e->d_nrt_dups.p), e->nrt_n_dups, na.out_status, na.out_score, e->row_stride, e->stream);
     SPX_HIP(e, hipGetLastError());
@@ -2686,6 +2819,8 @@ int spx_load_quota(spx_engine* e, const spx_pod_objects* pods, const spx_resourc
   q.min = quota->min, q.min_present = quota->min_present;
   return spx_upload_quota(e, &q);
 }
+
+int spx_nrt_filter_path(const spx_engine* e) { return e ? e->last_nrt_filter : 0; }
 
 int spx_commit_path(const spx_engine* e) { return e ? e->last_commit_path : SPX_ERR_ARG; }
 

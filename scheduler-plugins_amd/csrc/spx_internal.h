@@ -273,9 +273,18 @@ struct NrtArgs {
   int64_t ln_rows;
   uint32_t ln_per_row;
   uint32_t* ln_rec;              // [N][kZ * RM * 2 + 16] scratch: the nodes' tables as one record each (k_nrt_ln_pack -> k_nrt_ln_redo)
+  // rank-space Filter (kernels_nrt_rank.hip): the chunk stream of the listed rows; NULL = the float64 Filter launch
+  const uint32_t* rk_stream;
+  const uint32_t* rk_off;        // [chunks + 1] dword offsets of the chunk blocks
+  uint32_t rk_max_dwords;        // largest chunk block (dynamic LDS)
   uint32_t exact32_slots;        // resource slots whose requests and capacities (Value() form) are all float32 values (below 2^24, or a multiple of a large power of two): compared exactly
 };
 constexpr double kNrtNoCap = 1e200;
+// rank-space Filter: chunk rows, comparison vectors per pod (pod-level, 8 containers, 4 sums), head dwords of a pod record
+// (w0, w1, the slot sets of items 1..9, app containers a0 | a1 << 8 | a2 << 16 | count << 24, pad), largest chunk block
+constexpr int kRkChunkRows = 32, kRkVectors = 13, kRkPodHead = 16;
+constexpr size_t kRkMaxChunkBytes = 56 * 1024;
+bool launch_nrt_filter_rank(const NrtArgs& a, int n_tiles, unsigned blocks, hipStream_t s);
 
 // combin.Combinations(8, k) for k = 1..8 as bitmasks over list positions, size-major then lexicographic — the order
 // least_numa.go:167-208 walks.  Subsets of a node with fewer zones are the entries without high positions, in the same

@@ -598,6 +598,10 @@ class Engine:
         self._ck(self._lib.spx_load_trimaran_pods(self._h, pods.ref()))
         self.n_pods = pods.struct.n_pods
 
+    def nrt_filter_path(self) -> int:
+        """which Filter launch the last NRT sweep ran: 1 float64 compares, 2 rank space"""
+        return int(self._lib.spx_nrt_filter_path(self._h))
+
     def commit_path(self) -> int:
         """which form the last commit_sequential ran: 1 one-workgroup trimaran chain, 2 per-pod launches, 3 cooperative kernel"""
         return int(self._lib.spx_commit_path(self._h))

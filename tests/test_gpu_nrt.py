@@ -306,6 +306,34 @@ def test_pod_classes_of_the_synthetic_queue(gpu_required, hdr):
         uniq, dups = e.nrt_pod_classes()
         assert uniq + dups == 4000 and dups > 1200
 
+# ------------------------------------------------------------------ the Filter launch in rank space (SPX_OPT_NRT_RANK_FILTER)
+@pytest.mark.parametrize("wide", [False, True], ids=["4slots", "6slots"])
+def test_rank_filter_equals_float64_filter(gpu_required, hdr, oracle, wide):
+    """A whole-batch sweep over pod classes runs its Filter launch in rank space (kernels_nrt_rank.hip: requests and zone quantities
+    as positions in the chunk's sorted request list, charged zones through request sums instead of table mutation); with the
+    option off the float64 launch runs.  Same status table, cell for cell, and the oracle's on sampled rows.  The batch holds pods
+    with one to three app containers (the second and third are tested against zones their predecessors were charged to), init
+    containers and sidecars, both node scopes, stale and NRT-less nodes, unreported and host-level resources."""
+    n_nodes, n_pods = 1500, 2500
+    snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=31, wide=wide)
+    params = O.nrt_params(hdr, O.Resources(), "MostAllocated")
+    with Engine(0) as e:
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+        e.eval(mask_of(NRT))
+        e.sync()
+        assert e.nrt_filter_path() == 2
+        ranked, score = e.all_status(NRT), e.all_scores(NRT)
+        e.set_option("NRT_RANK_FILTER", 0)
+        e.eval(mask_of(NRT))
+        e.sync()
+        assert e.nrt_filter_path() == 1
+        assert np.array_equal(e.all_status(NRT), ranked) and np.array_equal(e.all_scores(NRT), score)
+        assert len(set(np.unique(ranked).tolist())) >= 4  # several of the Filter's verdicts occur
+    osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
+    for r in list(range(0, n_pods, 97)) + [n_pods - 1]:
+        assert np.array_equal(ranked[r], osnap.filter_rows(NRT, r, r + 1)[0]), r
+
+
 # ------------------------------------------------------------------ full size (config #3): sampled rows + properties
 def test_config3_full_size_properties(gpu_required, hdr, oracle):
     n_nodes, n_pods = 5_000, 50_000

@@ -8,7 +8,7 @@ for rep in 1 2; do
     for w in $WL; do
       out=gpurun_out/ab_nrt/$v.$w.$rep
       rm -rf $out && mkdir -p $out
-      timeout 300 rocprofv3 --kernel-trace --stats -d $out -o p -- python tools/variant.py run $v bench.py --workload $w --steps 20 --warmup 3 --cpu-budget 0 --sweep-only > $out/line.json 2> $out/err.log
+      timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python tools/variant.py run $v bench.py --workload $w --steps 20 --warmup 3 --cpu-budget 0 --sweep-only > $out/line.json 2> $out/err.log
       f=$(find $out -name '*kernel_stats.csv' | head -1)
       echo "== $v $w rep$rep ms_per_step=$(python -c "import json,sys; print(round(json.loads(open('$out/line.json').read().strip().splitlines()[-1])['ms_per_step'],4))" 2>/dev/null)"
       python - "$f" <<'PY'
