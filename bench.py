@@ -225,6 +225,17 @@ def config5_leg(hdr, device, n_pods=8192):
         e.sync()
         out["sweep_ms"] = (time.perf_counter() - t0) * 1e3 / 5
         out["evals_per_sec"] = w["n_nodes"] * n_pods / (out["sweep_ms"] * 1e-3)
+        uniq, copies = e.nrt_pod_classes()
+        out["nrt_rows_evaluated"], out["nrt_rows_copied"] = uniq, copies
+        e.set_option("NRT_POD_CLASSES", 0)  # the same sweep with every pod row evaluated (no representative rows + copies)
+        e.eval(mask)
+        e.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            e.eval(mask)
+        e.sync()
+        out["sweep_every_row_ms"] = (time.perf_counter() - t0) * 1e3 / 5
+        e.set_option("NRT_POD_CLASSES", 1)
         e.decide(mask)
         e.sync()
         t0 = time.perf_counter()
@@ -392,6 +403,8 @@ def main() -> None:
     ap.add_argument("--devices", default="", help="single-process multi-device mode: explicit device list, e.g. 0,0 with --transport copy "
                                                   "runs two ranks on one GPU (plumbing check of the sharded path on a one-GPU box)")
     ap.add_argument("--sweep-only", action="store_true", help="skip the full_cycle section (profiling runs: rocprofv3 counter passes crash in hipGraph capture)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="spx_set_option before the timed region, e.g. --opt NET_FOLD_ALLOC=0 (A/B experiments; repeatable)")
     ap.add_argument("--no-pod-classes", action="store_true", help="evaluate every pod row (SPX_OPT_NRT_POD_CLASSES / SPX_OPT_PEAKS_POD_CLASSES off): "
                     "by default a whole-batch NRT or Peaks sweep evaluates one row per class of pods with equal records and copies it")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="ranks mode (torch.distributed.run): nccl = RCCL over xGMI (the driver's "
@@ -473,6 +486,10 @@ def main() -> None:
         for e in engines:
             e.set_option("NRT_POD_CLASSES", 0)
             e.set_option("PEAKS_POD_CLASSES", 0)
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        for e in engines:
+            e.set_option(name, int(val))
     pod_classes = {}
     for name, fn in (("nrt", e0.nrt_pod_classes), ("peaks", e0.peaks_pod_classes)):
         if name in w["plugins"]:
@@ -534,6 +551,32 @@ def main() -> None:
         # average launch duration of the sweep measured with HIP events over the timed region itself (back-to-back
         # launches, sustained clocks); a plugin set evaluated by more than one kernel counts all of them as one launch
         kern_ms = ev0.elapsed_time(ev1) / args.steps
+
+    # the same sweep with every pod row evaluated (no representative rows + copies), outside the timed region: how much of `value`
+    # is the synthetic queue's repetitiveness — printed next to it in every line that uses pod classes
+    every_row = None
+    if mode == "single" and not args.no_pod_classes and any(v["rows_copied"] > 0 for v in pod_classes.values()):
+        try:
+            for name in pod_classes:
+                target.set_option("NRT_POD_CLASSES" if name == "nrt" else "PEAKS_POD_CLASSES", 0)
+            n_er = max(3, min(args.steps, 10))
+            target.eval(mask)
+            target.sync()
+            er0, er1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            er0.record(tstream)
+            for _ in range(n_er):
+                target.eval(mask)
+            er1.record(tstream)
+            target.sync()
+            every_row = {"kernel_ms": er0.elapsed_time(er1) / n_er, "steps": n_er,
+                         "what": "the same sweep with SPX_OPT_*_POD_CLASSES off: every pod row evaluated, none copied (HIP events, outside the timed region)"}
+        except Exception as ex:
+            every_row = {"error": repr(ex)[:200]}
+        finally:
+            for name in pod_classes:
+                target.set_option("NRT_POD_CLASSES" if name == "nrt" else "PEAKS_POD_CLASSES", 1)
+            target.eval(mask)
+            target.sync()
 
     # ------------------------------------------------------------------ outside the timed region
     # SURVEY §8d(ii) "full-cycle ms": snapshot delta (host flatten + H2D of the SoA columns) + sweep + device-side
@@ -719,11 +762,14 @@ def main() -> None:
                             "ranks": f"{world} processes, one per device (torch.distributed.run)"}[mode],
                    "sharding": "pod rows per device, node tables replicated, no data-path collective",
                    "result_tables": "uint8 [pods][nodes] per plugin, resident in HBM",
+                   **({"options": args.opt} if args.opt else {}),
                    **({"pod_classes": dict(pod_classes, what="rows of pods whose records agree in everything the plugin reads are evaluated once and "
                                                               "copied (device 0's share; --no-pod-classes evaluates every row)")} if pod_classes else {})},
         "roofline": roofline,
         "kernel_evals_per_sec": n_nodes * local_pods / (kern_ms * 1e-3),
     }
+    if every_row is not None:
+        out["every_row"] = every_row
     if full_cycle is not None:
         out["full_cycle"] = full_cycle
     if gather_info is not None:
