@@ -729,6 +729,10 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *   SPX_OPT_NRT_RANK_FILTER    1 (default) = a whole-batch NRT sweep over pod classes runs its Filter launch in rank space (requests and
  *                              zone quantities as positions in the chunk's sorted request list: integer subtracts instead of float64
  *                              compares, no zone-table mutation); 0 = the float64 Filter launch.  Same status table either way
+ *   SPX_OPT_ROW_WORKGROUP      1 = the per-row kernels of a profile with Filter plugins (Allocatable's feasibility-aware NormalizeScore,
+ *                              spx_decide's argmax) give every row a whole workgroup in batch launches too; 0 (default) = four rows per
+ *                              workgroup, and the whole-workgroup mapping only when four rows' feasibility bytes would not fit the LDS
+ *                              (rows of more than about 65k nodes).  Same tables either way
  */
 #define SPX_OPT_ROW_ALIGN 0
 #define SPX_OPT_REFERENCE_KERNELS 1
@@ -742,7 +746,8 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
 #define SPX_OPT_NRT_LN_LIST_PERMILLE 9
 #define SPX_OPT_COMMIT_COOP 10
 #define SPX_OPT_NRT_RANK_FILTER 11
-#define SPX_NUM_OPTIONS 12
+#define SPX_OPT_ROW_WORKGROUP 12
+#define SPX_NUM_OPTIONS 13
 int spx_set_option(spx_engine* e, int option, int64_t value);
 int spx_get_option(const spx_engine* e, int option, int64_t* value);
 

@@ -140,17 +140,21 @@ struct RowMap {
   uint8_t* lds;
 };
 __device__ __forceinline__ RowMap row_map(const ProfileArgs& a, uint8_t* lds, size_t lds_per_row) {
-  const bool single = a.row_end - a.row_begin == 1;  // uniform
+  const bool single = a.row_end - a.row_begin == 1 || a.block_per_row;  // uniform
   const int w = threadIdx.x >> 6;
   RowMap m;
-  m.pod = single ? a.row_begin : a.row_begin + static_cast<int64_t>(blockIdx.x) * kRowsPerBlock + w;
+  m.pod = single ? a.row_begin + static_cast<int64_t>(blockIdx.x) : a.row_begin + static_cast<int64_t>(blockIdx.x) * kRowsPerBlock + w;
   m.wave = single ? w : 0;
   m.n_waves = single ? static_cast<int>(blockDim.x >> 6) : 1;
   m.lds = single ? lds : lds + static_cast<size_t>(w) * lds_per_row;
   return m;
 }
-inline unsigned row_blocks(unsigned rows) { return rows == 1 ? 1u : (rows + kRowsPerBlock - 1) / kRowsPerBlock; }
-inline unsigned row_threads(unsigned rows) { return rows == 1 ? 64u * kMaxRowWaves : 64u * kRowsPerBlock; }
+inline unsigned row_blocks(unsigned rows, bool whole = false) { return rows == 1 || whole ? rows : (rows + kRowsPerBlock - 1) / kRowsPerBlock; }
+inline unsigned row_threads(unsigned rows, bool whole = false) { return rows == 1 || whole ? 64u * kMaxRowWaves : 64u * kRowsPerBlock; }
+// kRowsPerBlock shares of dynamic LDS (plus the kernels' static arrays) must fit the 64 KiB a launch gets without opting in to more:
+// rows wider than that take the one-workgroup-per-row mapping (the layout of a single-row launch, blockIdx.x = row)
+constexpr size_t kLdsLaunchLimit = 64 * 1024 - 1024;
+inline bool whole_block_rows(unsigned rows, size_t lds_per_row) { return rows > 1 && lds_per_row * kRowsPerBlock > kLdsLaunchLimit; }
 
 __global__ __launch_bounds__(64 * kMaxRowWaves) void k_alloc_masked(ProfileArgs a, unsigned lds_per_row) {
   SPX_RESOLVE_ROWS(a);
@@ -553,7 +557,11 @@ void launch_alloc_masked(const ProfileArgs& a, hipStream_t s) {
   const size_t tiles16 = static_cast<size_t>((a.row_stride + 64 * kNplCompact - 1) / (64 * kNplCompact));
   const size_t lds = tiles4 * 64 > tiles16 * 128 ? tiles4 * 64 : tiles16 * 128;
   const unsigned rows = static_cast<unsigned>(a.row_end - a.row_begin);
-  hipLaunchKernelGGL(k_alloc_masked, dim3(row_blocks(rows)), dim3(row_threads(rows)), rows == 1 ? lds : lds * kRowsPerBlock, s, a, static_cast<unsigned>(lds));
+  ProfileArgs b = a;
+  const bool whole = rows > 1 && (a.block_per_row || whole_block_rows(rows, lds));
+  b.block_per_row = whole;
+  hipLaunchKernelGGL(k_alloc_masked, dim3(row_blocks(rows, whole)), dim3(row_threads(rows, whole)), rows == 1 || whole ? lds : lds * kRowsPerBlock, s, b,
+                     static_cast<unsigned>(lds));
 }
 
 bool decide_masked_ok(const ProfileArgs& a) {
@@ -577,7 +585,10 @@ void launch_decide_masked(const ProfileArgs& a, hipStream_t s) {
     }
   const size_t tiles16 = static_cast<size_t>((a.row_stride + 64 * kNplCompact - 1) / (64 * kNplCompact));
   const unsigned rows = static_cast<unsigned>(a.row_end - a.row_begin);
-  hipLaunchKernelGGL(k_decide_masked, dim3(row_blocks(rows)), dim3(row_threads(rows)), tiles16 * 128 * (rows == 1 ? 1 : kRowsPerBlock), s, a, f,
+  ProfileArgs b = a;
+  const bool whole = rows > 1 && (a.block_per_row || whole_block_rows(rows, tiles16 * 128));
+  b.block_per_row = whole;
+  hipLaunchKernelGGL(k_decide_masked, dim3(row_blocks(rows, whole)), dim3(row_threads(rows, whole)), tiles16 * 128 * (rows == 1 || whole ? 1 : kRowsPerBlock), s, b, f,
                      static_cast<int>(a.weight[SPX_PLUGIN_ALLOCATABLE]), static_cast<unsigned>(tiles16 * 128));
 }
 

@@ -54,7 +54,7 @@ struct spx_engine {
   int64_t row_stride = 0;
 
   // spx_set_option state (per engine; nothing is read from the environment)
-  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1};
+  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1, 0};
 
   // params
   int32_t alloc_mode = SPX_MODE_LEAST;
@@ -645,6 +645,7 @@ int spx_set_option(spx_engine* e, int option, int64_t value) {
     case SPX_OPT_PEAKS_POD_CLASSES:
     case SPX_OPT_COMMIT_COOP:
     case SPX_OPT_NRT_RANK_FILTER:
+    case SPX_OPT_ROW_WORKGROUP:
       if (value != 0 && value != 1) return fail(e, SPX_ERR_ARG, "option takes 0 or 1");
       break;
     case SPX_OPT_NRT_LN_LIST_PERMILLE:
@@ -791,6 +792,11 @@ int delta_indices(spx_engine* e, const int64_t* idx, int64_t n_rows, std::vector
     if (idx[i] < 0 || idx[i] >= e->n_nodes) return fail(e, SPX_ERR_ARG, "delta: node index out of range");
     out[static_cast<size_t>(i)] = static_cast<int32_t>(idx[i]);
   }
+  // a node listed twice would be scattered twice in no particular order — and the columns derived from the rows (the float64 images,
+  // the host copies) could end up describing different rows of the delta: refused
+  std::vector<int32_t> sorted(out);
+  std::sort(sorted.begin(), sorted.end());
+  if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return fail(e, SPX_ERR_ARG, "delta: a node index is listed twice");
   return SPX_OK;
 }
 }  // namespace
@@ -953,11 +959,9 @@ int spx_update_nrt_nodes(spx_engine* e, const int64_t* idx, const spx_nrt_nodes_
         if (!nrt_exact_f32(static_cast<double>(nrt_value_of(r == e->nrt_cpu_slot, cap)))) big |= 1u << r;
       }
     }
-    int32_t* hc = &e->h_nrt_cost[static_cast<size_t>(ix[static_cast<size_t>(i)]) * Zm * Zm];
+    const int32_t* hc = &e->h_nrt_cost[static_cast<size_t>(ix[static_cast<size_t>(i)]) * Zm * Zm];
     if (std::memcmp(hc, t->zone_cost + i * Zm * Zm, sizeof(int32_t) * Zm * Zm) != 0 || e->h_nrt_nz[static_cast<size_t>(ix[static_cast<size_t>(i)])] != t->n_zones[i]) {
-      cost_changed = true;
-      std::memcpy(hc, t->zone_cost + i * Zm * Zm, sizeof(int32_t) * Zm * Zm);
-      e->h_nrt_nz[static_cast<size_t>(ix[static_cast<size_t>(i)])] = t->n_zones[i];
+      cost_changed = true;  // (the host copies follow once the rows have shipped: a failed delta leaves them describing the device)
       for (int za = 0; za < nz && za < Zm; ++za)
         for (int zb = 0; zb < nz && zb < Zm; ++zb) {
           const int64_t c = t->zone_cost[(i * Zm + za) * Zm + zb];
@@ -990,6 +994,12 @@ int spx_update_nrt_nodes(spx_engine* e, const int64_t* idx, const spx_nrt_nodes_
   da.f_cpu = static_cast<double*>(e->d_nrt_fcpu.p), da.f_braw = static_cast<double*>(e->d_nrt_fbraw.p), da.f_rep = static_cast<uint8_t*>(e->d_nrt_frep.p);
   spx::launch_nrt_derive_rows(da, s);
   SPX_HIP(e, hipGetLastError());
+  if (cost_changed)
+    for (int64_t i = 0; i < n; ++i) {
+      const size_t node = static_cast<size_t>(ix[static_cast<size_t>(i)]);
+      std::memcpy(&e->h_nrt_cost[node * Zm * Zm], t->zone_cost + i * Zm * Zm, sizeof(int32_t) * Zm * Zm);
+      e->h_nrt_nz[node] = t->n_zones[i];
+    }
   e->nrt_fast_nodes = e->nrt_fast_nodes && ok;
   e->nrt_big_nodes |= big;
   if (cost_changed) {  // LeastNUMANodes' per-node tables are rebuilt when that strategy is next evaluated
@@ -997,7 +1007,7 @@ int spx_update_nrt_nodes(spx_engine* e, const int64_t* idx, const spx_nrt_nodes_
     e->nrt_ln_ok = e->nrt_ln_ok && ln_ok;
   }
   // (the window-local node order — perm — is a grouping hint for the sweep, not a correctness input: left as it is)
-  e->evaluated &= ~(1u << SPX_PLUGIN_NRT);
+  e->evaluated = 0;  // NRT's tables, and every table normalised over the feasible nodes its status named (Allocatable, NetworkOverhead, Peaks)
   e->best_valid = false;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
   return SPX_OK;
@@ -2147,15 +2157,32 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
       // search (k_nrt_ln_redo) — room for 3/8 of the nodes per list by default (config #3 lists 13 % of the cells, no row more than 40 %); a
       // list that overflows sends the launch back to the complete sweep
       const int64_t rows = classes ? e->nrt_n_uniq : row_end - row_begin;
-      const uint32_t per_row = static_cast<uint32_t>(spx::round_up(std::max<int64_t>(64, e->n_nodes * e->option[SPX_OPT_NRT_LN_LIST_PERMILLE] / 1000), 64));
+      // The lists are scratch: held to 1 GiB (config #3: 0.42 GB) by shortening them — a shorter list overflows sooner, and an
+      // allocation that fails leaves the launch without lists; either way the complete sweep writes the same table, slower
+      uint32_t per_row = static_cast<uint32_t>(spx::round_up(std::max<int64_t>(64, e->n_nodes * e->option[SPX_OPT_NRT_LN_LIST_PERMILLE] / 1000), 64));
+      constexpr size_t kListWords = (size_t{1} << 30) / sizeof(uint32_t);
+      if (rows > 0) {
+        const size_t room = (kListWords - 2) / (2 * static_cast<size_t>(rows));  // 1 + per_row words per list
+        if (room < 1 + static_cast<size_t>(per_row)) per_row = room > 64 ? static_cast<uint32_t>((room - 1) / 64 * 64) : 0;
+      }
       const size_t words = 2 + 2 * static_cast<size_t>(rows) * (1 + static_cast<size_t>(per_row));
-      if (rows > 0 && words < (size_t{1} << 31)) {
-        if ((rc = ensure(e, e->d_nrt_redo, words * sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(e, e->d_nrt_lnrec, static_cast<size_t>(e->n_nodes) * (SPX_NRT_MAX_ZONES * (e->nrt_n_res <= 4 ? 4 : 8) * 2 + 16) * sizeof(uint32_t)))) return rc;
-        na.redo_list = static_cast<uint32_t*>(e->d_nrt_redo.p);
-        na.ln_rec = static_cast<uint32_t*>(e->d_nrt_lnrec.p);
-        na.ln_rows = rows;
-        na.ln_per_row = per_row;
+      if (rows > 0 && per_row >= 64) {
+        std::string kept;
+        {
+          std::lock_guard<std::mutex> g(e->err_mu);
+          kept = e->err;
+        }
+        if (ensure(e, e->d_nrt_redo, words * sizeof(uint32_t)) == SPX_OK &&
+            ensure(e, e->d_nrt_lnrec, static_cast<size_t>(e->n_nodes) * (SPX_NRT_MAX_ZONES * (e->nrt_n_res <= 4 ? 4 : 8) * 2 + 16) * sizeof(uint32_t)) == SPX_OK) {
+          na.redo_list = static_cast<uint32_t*>(e->d_nrt_redo.p);
+          na.ln_rec = static_cast<uint32_t*>(e->d_nrt_lnrec.p);
+          na.ln_rows = rows;
+          na.ln_per_row = per_row;
+        } else {
+          (void)hipGetLastError();  // the failed allocation's sticky error
+          std::lock_guard<std::mutex> g(e->err_mu);
+          e->err = kept;
+        }
       }
     }
     spx::launch_nrt(na, e->stream);
@@ -2230,6 +2257,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     pa.alloc_raw = static_cast<const int64_t*>(e->d_alloc_raw.p);
     pa.alloc_rel = static_cast<const uint32_t*>(e->d_alloc_rel.p);
     pa.out_alloc = static_cast<uint8_t*>(e->score[SPX_PLUGIN_ALLOCATABLE].p);
+    pa.block_per_row = static_cast<int32_t>(e->option[SPX_OPT_ROW_WORKGROUP]);
     spx::launch_alloc_masked(pa, e->stream);
     SPX_HIP(e, hipGetLastError());
   }
@@ -3090,6 +3118,7 @@ EngineView engine_view(spx_engine* e) {
   v.row_stride = e->row_stride;
   v.best = e->d_best.p;
   v.best_valid = e->best_valid;
+  v.evaluated = e->evaluated;
   v.ev0 = e->ev0;
   v.ev1 = e->ev1;
   v.timed = e->timed;
@@ -3147,6 +3176,7 @@ int decide_masked(spx_engine* e, uint32_t eval_mask, uint32_t score_mask, int64_
   pa.best_node = reinterpret_cast<int32_t*>(pa.best_score + P);
   pa.best_ties = pa.best_node + P;
   pa.best_feasible = pa.best_ties + P;
+  pa.block_per_row = static_cast<int32_t>(e->option[SPX_OPT_ROW_WORKGROUP]);
   spx::launch_decide_masked(pa, e->stream);
   SPX_HIP(e, hipGetLastError());
   SPX_HIP(e, hipEventRecord(e->ev1, e->stream));

@@ -50,6 +50,7 @@ struct EngineView {
   int64_t n_nodes, n_pods, row_stride;
   void* best;        // decision block [score int64 P | node int32 P | ties int32 P | feasible int32 P], NULL before the first argmax
   bool best_valid;
+  uint32_t evaluated;  // bit per plugin: its tables describe the resident snapshot and pod rows
   hipEvent_t ev0, ev1;  // recorded around the last spx_eval / spx_decide
   bool timed;
 };
@@ -598,6 +599,7 @@ struct ProfileArgs {
   int64_t* best_score;
   int32_t* best_ties;
   int32_t* best_feasible;
+  int32_t block_per_row;  // set by the launchers: a whole workgroup per row in a batch launch too (rows too wide for kRowsPerBlock LDS shares)
 };
 void launch_alloc_masked(const ProfileArgs& a, hipStream_t s);
 // copies row pairs[2i+1] to row pairs[2i] in up to two uint8 tables of row_stride bytes per row (NULL = skip)

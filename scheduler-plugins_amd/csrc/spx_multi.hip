@@ -528,6 +528,13 @@ int spx_multi_allgather_table(spx_multi* m, int plugin, int which) {
   if (!m || plugin < 0 || plugin >= SPX_NUM_PLUGINS || (which != 0 && which != 1)) return SPX_ERR_ARG;
   GlobalTable& t = m->table[which][plugin];
   if (t.dptr.empty()) return mfail(m, SPX_ERR_STATE, "no global table bound for this plugin (spx_multi_bind_global_table)");
+  // a rank whose shard of the table was not written by its last evaluation (spx_multi_decide on a Filter profile folds Allocatable's
+  // normalisation into the argmax and writes no Allocatable table; a delta marks every table stale) would contribute old bytes
+  for (int r = 0; r < m->n; ++r) {
+    const spx::EngineView v = spx::engine_view(m->engine[static_cast<size_t>(r)]);
+    if (v.n_pods > 0 && !(v.evaluated & (1u << plugin)))
+      return mfail(m, SPX_ERR_STATE, "rank " + std::to_string(r) + ": this plugin's table was not written by the last evaluation (spx_multi_eval it first)");
+  }
   const int rc = all_gather_in_place(m, t.dptr, static_cast<size_t>(t.rows_per) * static_cast<size_t>(t.row_stride));
   if (rc) return rc;
   t.gathered = true;

@@ -120,11 +120,13 @@ def _full(e, hdr, n_nodes, n_pods, seed, weights):
 
 @pytest.mark.parametrize("n_nodes,n_pods,seed", [(300, 200, 1), (65, 33, 2), (17, 9, 3), (2100, 150, 4)])
 @pytest.mark.parametrize("weights", [{ALLOCATABLE: 1, TLP: 2, LVRB: 1, NRT: 3, NETOVERHEAD: 2}, {ALLOCATABLE: 7, TLP: 0, LVRB: 1, NRT: 1, NETOVERHEAD: 1}])
-def test_decide_with_filter_plugins(gpu_required, hdr, n_nodes, n_pods, seed, weights):
+@pytest.mark.parametrize("row_workgroup", [0, 1])
+def test_decide_with_filter_plugins(gpu_required, hdr, n_nodes, n_pods, seed, weights, row_workgroup):
     """the whole profile (CapacityScheduling PreFilter, NRT and NetworkOverhead Filters, five scoring plugins): Allocatable's
     feasibility-aware NormalizeScore happens inside the argmax kernel and its table is not written — same decisions"""
     from test_gpu_profile import ALL
     with Engine(0) as e:
+        e.set_option("ROW_WORKGROUP", row_workgroup)  # 1: a whole workgroup per row in batch launches (what very wide rows take)
         _full(e, hdr, n_nodes, n_pods, seed, weights)
         want, got = both(e, mask_of(*ALL))
         for name, w, g in zip(("node", "score", "ties", "feasible"), want, got):

@@ -78,6 +78,37 @@ def test_nrt_node_delta_equals_full_upload(gpu_required, hdr, strategy, kernel):
             assert np.array_equal(e.raw(NRT, r), ref.raw(NRT, r))
 
 
+def test_delta_refuses_a_node_listed_twice_and_invalidates_dependent_tables(gpu_required, hdr):
+    """a duplicated index would scatter one node's row twice in no particular order: both deltas refuse it and leave the engine as
+    it was; an accepted NRT delta marks every table stale (Allocatable normalises over the feasible nodes NRT's status names)"""
+    n_nodes, n_pods = 300, 64
+    snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=41)
+    tri = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=41)
+    params = O.nrt_params(hdr, O.Resources(), "LeastAllocated")
+    with Engine(0) as e:
+        f = e.flatten_nrt(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+        e.upload_nrt(f)
+        cols = e.flatten_trimaran_nodes(tri["nodes"], tri["metrics"], tri["assigned"])
+        e.upload_alloc_nodes(e.flatten_alloc_nodes(tri["nodes"], tri["rc"]))
+        e.upload_trimaran_nodes(cols)
+        e.upload_trimaran_pods(e.flatten_trimaran_pods(tri["pods"]))
+        e.eval(mask_of(NRT))
+        e.sync()
+        before = e.all_scores(NRT)
+        dup = np.array([5, 9, 5], dtype=np.int64)
+        with pytest.raises(Exception, match="listed twice"):
+            e.update_nrt_nodes(dup, f)
+        with pytest.raises(Exception, match="listed twice"):
+            e.update_trimaran_nodes(dup, cols)
+        assert np.array_equal(e.all_scores(NRT), before)  # refused before anything moved: the tables still stand
+        e.update_nrt_nodes(np.array([5, 9], dtype=np.int64), f)
+        with pytest.raises(Exception):
+            e.all_scores(NRT)
+        e.eval(mask_of(NRT))
+        e.sync()
+        assert np.array_equal(e.all_scores(NRT), before)  # the same rows again: the same tables
+
+
 def _grown_appgroups(hdr, ag, group, selector, node):
     """the AppGroup table with the pods (group[j], selector[j], node[j]) appended to their groups' placed lists"""
     from scheduler_plugins_amd._abi import Table

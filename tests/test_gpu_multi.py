@@ -124,5 +124,13 @@ def test_errors(gpu_required, hdr):
             m.gather_best()
         with pytest.raises(spx.SpxError, match="no global table"):
             m.allgather_table(TLP)
+        m.bind_global_table(TLP)
+        with pytest.raises(spx.SpxError, match="not written by the last evaluation"):
+            m.allgather_table(TLP)  # bound, never evaluated: a gather would publish whatever the slab held
+        m.decide(mask_of(ALLOCATABLE, TLP))  # decisions without tables
+        with pytest.raises(spx.SpxError, match="not written by the last evaluation"):
+            m.allgather_table(TLP)
+        m.eval(mask_of(ALLOCATABLE, TLP))
+        m.allgather_table(TLP)
         with pytest.raises(spx.SpxError, match="rank 0"):
             m.eval(mask_of(NRT))  # NRT tables were never uploaded: the failing rank's message comes back

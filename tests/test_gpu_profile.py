@@ -23,16 +23,19 @@ def load_all(e, hdr, snap, strategy="LeastAllocated"):
     return params
 
 
-@pytest.mark.parametrize("kernels", ["fast", "generic", "wide_allocatable_range"])
+@pytest.mark.parametrize("kernels", ["fast", "generic", "wide_allocatable_range", "row_workgroup"])
 @pytest.mark.parametrize("n_nodes,n_pods,seed", [(300, 200, 1), (65, 33, 2)])
 def test_full_profile(gpu_required, hdr, oracle, kernels, n_nodes, n_pods, seed):
     """`generic` forces the per-node NetworkOverhead sweep and the int64 NRT sweep; `wide_allocatable_range` makes
-    Allocatable's raw scores span more than 2^42, which takes the masked normalisation off its float64 path"""
+    Allocatable's raw scores span more than 2^42, which takes the masked normalisation off its float64 path; `row_workgroup`
+    gives every row of the per-row kernels a whole workgroup (the mapping rows of more than ~65k nodes take by themselves)"""
     snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=seed, pods_per_group=20, n_namespaces=20)
     weights = {ALLOCATABLE: 1, TLP: 2, LVRB: 1, NRT: 3, NETOVERHEAD: 2}
     with Engine(0) as e:
         if kernels == "generic":
             e.force_reference_kernels(NETOVERHEAD, NRT)
+        if kernels == "row_workgroup":
+            e.set_option("ROW_WORKGROUP", 1)
         if kernels == "wide_allocatable_range":
             snap["nodes"].array("alloc_mem")[:] *= 64  # up to 64 TiB: raw scores (a weighted mean) now span > 2^42
             e.set_allocatable("Least", {1: 1})
