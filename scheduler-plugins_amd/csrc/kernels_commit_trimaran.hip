@@ -82,6 +82,27 @@ __device__ __forceinline__ void tlp_cell32(const float4& rk, float pod_f, float 
   tb = static_cast<uint32_t>(__float_as_int(y)) & 0x1ffu;
 }
 
+// Two cells (a group's two nodes) at once in the packed float32 instructions: the same operations on the same values as
+// tlp_cell32 — bit-identical u, d and score byte — in 11 instead of 2 x 8.5 instructions.  Both branches of a cell come out of ONE
+// v_pk_fma_f32 ((coefficient for u > 0, for u <= 0) * (u, u) + (offsets), clamp modifier), the sign bit of u picks one; the
+// rounding and its margin are packed across the two cells.  (The builtins do not produce the clamp modifier or the operand
+// selectors on packed float32: those two instructions are written out.)
+typedef float F32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tlp_cell_pair32(const float4& ra, const float4& rb, float pod_f, const F32x2& off2, float (&u)[2], float (&d)[2],
+                                                uint32_t (&tb)[2]) {
+  const F32x2 u2 = (F32x2{pod_f, pod_f} + F32x2{ra.x, rb.x}) + F32x2{ra.y, rb.y};
+  F32x2 xa, xb;  // (value on the u > 0 branch, on the u <= 0 branch), clamped to [0, 1]
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] clamp" : "=v"(xa) : "v"(F32x2{ra.z, ra.w}), "v"(u2), "v"(off2));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] clamp" : "=v"(xb) : "v"(F32x2{rb.z, rb.w}), "v"(u2), "v"(off2));
+  const F32x2 xs{__float_as_int(u2.x) < 0 ? xa.y : xa.x, __float_as_int(u2.y) < 0 ? xb.y : xb.x};  // sign bit set: u < 0 or -0.0
+  const F32x2 y = __builtin_elementwise_fma(xs, F32x2{256.0f, 256.0f}, F32x2{kMagic, kMagic});
+  const F32x2 rr = y - F32x2{kMagic, kMagic};
+  const F32x2 dd = __builtin_elementwise_fma(xs, F32x2{256.0f, 256.0f}, -rr);
+  u[0] = u2.x, u[1] = u2.y;
+  d[0] = __builtin_fabsf(dd.x), d[1] = __builtin_fabsf(dd.y);
+  tb[0] = static_cast<uint32_t>(__float_as_int(y.x)) & 0x1ffu, tb[1] = static_cast<uint32_t>(__float_as_int(y.y)) & 0x1ffu;
+}
+
 constexpr int kChunk = 256;  // pods whose values / decisions are staged in LDS at a time
 constexpr int kGroup = 2;    // consecutive nodes per cell group (one 16-bit load of an LVRB row)
 
@@ -91,6 +112,7 @@ __global__ __launch_bounds__(T) void k_commit_trimaran_reg(CommitArgs c) {
   static_assert(K % kGroup == 0 && T % kWave == 0 && T >= kChunk, "cell groups / staging threads");
   constexpr int W = T / kWave;
   static_assert(W <= 16 && (W & (W - 1)) == 0, "the waves' keys are folded inside one 16-lane row");
+  static_assert((T & (T - 1)) == 0, "owner thread = group index mod T as a mask");
   __shared__ __align__(16) uint32_t s_key[2][W];
   __shared__ int s_tie[2];
   __shared__ int64_t s_pod[2][kChunk];       // the chunk's pod values (owner / exact path)
@@ -106,6 +128,7 @@ __global__ __launch_bounds__(T) void k_commit_trimaran_reg(CommitArgs c) {
   const double c1 = t / (100.0 - t), c2 = (100.0 - t) / t;
   const bool fast_ok = t >= 1.0 && t <= 99.0;
   const float tfs = static_cast<float>(t) * (1.0f / 256.0f);
+  const F32x2 off2{tfs, 100.0f / 256.0f};  // the two branches' offsets (scaled)
   constexpr float kHalf = 0.5f - kTol32;
   const uint32_t wt14 = Tl ? static_cast<uint32_t>(c.w_tlp) << 14 : 0u;
   const uint32_t wl14 = kHasL ? static_cast<uint32_t>(c.w_lvrb) << 14 : 0u;
@@ -138,6 +161,24 @@ __global__ __launch_bounds__(T) void k_commit_trimaran_reg(CommitArgs c) {
   };
   if (tid < kChunk) stage(0, (Tl && tid < rows) ? a.tlp_pod_milli[a.row_begin + tid] : 0);
   if (tid < 2) s_tie[tid] = 0;
+  // may the 32-bit per-cell sums of committed millicores take unchecked adds?  Yes when every pod value of the row range is a
+  // float32 integer and their total fits 31 bits (one node could receive them all) — a walk over the column, once per launch
+  __shared__ unsigned long long s_sum;
+  __shared__ int s_out_of_range;
+  if (tid == 0) s_sum = 0, s_out_of_range = 0;
+  __syncthreads();
+  {
+    unsigned long long mine = 0;
+    bool odd_value = false;
+    if (Tl)
+      for (int64_t q = tid; q < rows; q += T) {
+        const int64_t v = a.tlp_pod_milli[a.row_begin + q];
+        odd_value |= v < 0 || v >= (1 << 23);
+        mine += static_cast<unsigned long long>(v);
+      }
+    if (mine) atomicAdd(&s_sum, mine);
+    if (odd_value) atomicOr(&s_out_of_range, 1);
+  }
   uint32_t lv_next[K / kGroup];
 #pragma unroll
   for (int g = 0; g < K / kGroup; ++g) {
@@ -148,6 +189,7 @@ __global__ __launch_bounds__(T) void k_commit_trimaran_reg(CommitArgs c) {
     }
   }
   __syncthreads();
+  const bool sum_fits = __builtin_amdgcn_readfirstlane(static_cast<int>(s_out_of_range == 0 && s_sum <= 0x7fffffffull)) != 0;
 
   for (int64_t chunk0 = 0; chunk0 < rows; chunk0 += kChunk) {
     const int buf = static_cast<int>((chunk0 / kChunk) & 1);
@@ -181,19 +223,23 @@ __global__ __launch_bounds__(T) void k_commit_trimaran_reg(CommitArgs c) {
       int ties = 0;
       float worst = 0.0f, minu = 1e30f;
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        float u, d;
-        uint32_t tb;
-        tlp_cell32(r_k[k], pod_f, tfs, u, d, tb);
-        worst = __builtin_fmaxf(worst, d);
-        minu = __builtin_fminf(minu, __builtin_fabsf(u));
-        const uint32_t key = __umul24(tb, wt14) + base[k] + lv_part(k);
-        kmax = key > kmax ? key : kmax;
-        if constexpr (kTies) {
-          const uint32_t tot = key >> 14;
-          const bool real = key != 0;  // a cell past the node list carries key 0; a node's key never is (node < 16383)
-          ties = (real && tot > btot) ? 1 : ((real && tot == btot) ? ties + 1 : ties);
-          btot = (real && tot > btot) ? tot : btot;
+      for (int g = 0; g < K / kGroup; ++g) {
+        float u[2], d[2];
+        uint32_t tb[2];
+        tlp_cell_pair32(r_k[2 * g], r_k[2 * g + 1], pod_f, off2, u, d, tb);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int k = 2 * g + j;
+          worst = __builtin_fmaxf(worst, d[j]);
+          minu = __builtin_fminf(minu, __builtin_fabsf(u[j]));
+          const uint32_t key = __umul24(tb[j], wt14) + base[k] + lv_part(k);
+          kmax = key > kmax ? key : kmax;
+          if constexpr (kTies) {
+            const uint32_t tot = key >> 14;
+            const bool real = key != 0;  // a cell past the node list carries key 0; a node's key never is (node < 16383)
+            ties = (real && tot > btot) ? 1 : ((real && tot == btot) ? ties + 1 : ties);
+            btot = (real && tot > btot) ? tot : btot;
+          }
         }
       }
       const bool any = pod_bad || lane_nan || !(worst < kHalf) || !(minu > kTolU);
@@ -258,24 +304,39 @@ __global__ __launch_bounds__(T) void k_commit_trimaran_reg(CommitArgs c) {
         }
       }
       // the winner's owner advances the node: the real number b2h + b2l grows by exactly the pod's integer millicores (which
-      // tracks the float64 b within ~1e-10), and the millicores join the exact path's missing utilisation
-      if (Tl && found && ((win >> 1) % T) == tid) {
-        const int kk = ((win >> 1) / T) * kGroup + (win & 1);
-        const int64_t pod_i = s_pod[buf][p];
+      // tracks the float64 b within ~1e-10), and the millicores join the exact path's missing utilisation.  This sits on the
+      // chain — the owner's wave starts the next pod's pass after it while fifteen waves are already in theirs — so it is kept to
+      // a scalar branch into the owner's wave, a scalar pick of the cell, one select, and an LDS add that returns nothing
+      // (every gkey-derived value is the same in all lanes: made scalar where it steers a branch)
+      if (Tl && found) {
+        const int owner = (win >> 1) & (T - 1);
+        const int owner_s = __builtin_amdgcn_readfirstlane(owner);
+        if ((owner_s >> 6) == wave) {
+          const int kk = __builtin_amdgcn_readfirstlane(((win >> 1) / T) * kGroup + (win & 1));
+          const bool me = owner_s == tid;
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-          if (k == kk) {
-            const float nb = r_k[k].x + pod_f;
-            r_k[k].x = (pod_bad || !(__builtin_fabsf(nb) < 8388607.0f)) ? __builtin_nanf("") : nb;
-            lane_nan |= r_k[k].x != r_k[k].x;
-            const int64_t nd = static_cast<int64_t>(s_delta[k][tid]) + pod_i;
-            if (nd >= INT32_MIN && nd <= INT32_MAX) {
-              s_delta[k][tid] = static_cast<int32_t>(nd);
-            } else {  // (a queue of absurd pod values) fold into the column
-              c.missing[win] += nd;
-              s_delta[k][tid] = 0;
+          for (int k = 0; k < K; ++k)
+            if (k == kk) {
+              const float nb = r_k[k].x + pod_f;
+              const float nv = (pod_bad || !(__builtin_fabsf(nb) < 8388607.0f)) ? __builtin_nanf("") : nb;
+              r_k[k].x = me ? nv : r_k[k].x;
+              lane_nan |= me && nv != nv;
+            }
+          if (me) {
+            int32_t* cell = &s_delta[0][0] + kk * T + tid;
+            if (sum_fits) {  // (pod_f is the pod's value, exactly)
+              __hip_atomic_fetch_add(cell, static_cast<int32_t>(pod_f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {  // a queue whose values could overflow the 32-bit cell: checked adds, folded into the column when they would
+              const int64_t nd = static_cast<int64_t>(*cell) + s_pod[buf][p];
+              if (nd >= INT32_MIN && nd <= INT32_MAX) {
+                *cell = static_cast<int32_t>(nd);
+              } else {
+                c.missing[win] += nd;
+                *cell = 0;
+              }
             }
           }
+        }
       }
       pod_f = pod_next;
     }
