@@ -466,7 +466,11 @@ def main() -> None:
     if mode == "multi":
         snap = build_snapshot(hdr, w, n_pods_total, synth.SEED)
         target = MultiEngine(devices, RCCL if args.transport == "rccl" else PEER_COPY)
+        t_load = time.perf_counter()
         load_tables(target, w, snap)
+        host_load = {"wall_ms": (time.perf_counter() - t_load) * 1e3, "per_rank_ms": [round(x, 3) for x in target.load_ms],
+                     "what": "objects -> SoA -> HBM before the timed region: one host thread per rank flattens and uploads that rank's own pod rows "
+                             "(a view of the pod object table) and the replicated node tables; CapacityScheduling's tables are flattened once"}
         e0 = target.engines[0]
         local_pods = max(e.n_pods for e in target.engines)
     else:
@@ -772,6 +776,11 @@ def main() -> None:
         out["every_row"] = every_row
     if full_cycle is not None:
         out["full_cycle"] = full_cycle
+    if mode == "multi":
+        out["host_load"] = host_load
+    if world > 1:
+        out["n_gt_1_hardware"] = ("no figure on more than one MI355X exists for this repository: the build box has one device; lines with several ranks "
+                                  "on one device exercise the code path, not the scaling") if (len(set(devices)) == 1 or torch.cuda.device_count() < world) else "one rank per device"
     if gather_info is not None:
         out["gather"] = gather_info
     if sort_info is not None:

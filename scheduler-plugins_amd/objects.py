@@ -157,6 +157,20 @@ def build_pod_objects(hdr: Header, res: Resources, pods: Sequence[dict]) -> Tabl
     )
 
 
+def pod_rows(hdr: Header, pods: Table, begin: int, end: int) -> Table:
+    """rows [begin, end) of a pod object table as a table of its own, without copying: the per-pod columns are offset, the
+    per-container columns shared — their CSR offsets (ctr_ptr / req_ptr / lim_ptr / ovh_ptr values) are absolute.  What a rank
+    of a sharded batch hands to the flatteners (MultiEngine)."""
+    cols = {k: pods.array(k) for k in pods._keep}
+    for k in ("priority", "queue_ts", "appgroup", "selector", "ns"):
+        if k in cols:
+            cols[k] = cols[k][begin:end]
+    for k in ("ctr_ptr", "ovh_ptr"):
+        if k in cols:
+            cols[k] = cols[k][begin:end + 1]
+    return Table(hdr, "spx_pod_objects", n_pods=end - begin, **cols)
+
+
 def node(allocatable: Optional[dict] = None, capacity: Optional[dict] = None, region: int = -1, zone: int = -1) -> dict:
     """allocatable/capacity are v1.ResourceList-like dicts; capacity defaults to allocatable
     (st.MakeNode().Capacity(...) sets both in the reference's tests)."""

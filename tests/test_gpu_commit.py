@@ -68,6 +68,32 @@ def test_commit_sequential_matches_one_pod_at_a_time(gpu_required, hdr, oracle, 
     assert len(set(got_node.tolist())) > 1  # the commits moved the decision around
 
 
+@pytest.mark.parametrize("cores,n_pods", [(4000, 700), (9000, 60), (2, 300)])
+def test_commit_sequential_absurd_pod_values(gpu_required, hdr, cores, n_pods):
+    """the register-resident loop keeps the millicores it committed per node in 32-bit LDS cells: unchecked adds when the batch's
+    values are float32 integers summing below 2^31 (checked once per launch), checked adds folded into the column otherwise
+    (700 x 4000 cores = 2.8e9 millicores), and values of 2^23 millicores or more take the float64 sequence for the whole row
+    (9000 cores) — all three against the from-memory float64 kernel"""
+    rng = np.random.default_rng(cores)
+    res = O.Resources()
+    n_nodes = 50
+    nodes = [O.node({"cpu": "64", "memory": "256Gi"}, {"cpu": "64", "memory": "256Gi"}) for _ in range(n_nodes)]
+    metrics = {i: [("CPU", "AVG", float(rng.integers(5, 70))), ("CPU", "STD", 3.0)] for i in range(n_nodes)}
+    pods = [O.pod([O.container({"cpu": f"{cores + int(rng.integers(0, 3))}"})]) for _ in range(n_pods)]
+    node_t, pod_t, rc = O.build_node_objects(hdr, res, nodes), O.build_pod_objects(hdr, res, pods), res.table(hdr)
+    met_t = O.build_metrics_objects(hdr, n_nodes, metrics, window_end=WINDOW_END)
+    out = {}
+    with Engine(0) as e:
+        e.load_trimaran_objects(node_t, rc, pod_t, met_t, O.build_assigned_objects(hdr, res, n_nodes, {}))
+        for state in ("registers", "memory"):
+            e.set_option("COMMIT_FROM_MEMORY", 1 if state == "memory" else 0)
+            out[state] = e.commit_sequential(mask_of(ALLOCATABLE, TLP), want_ties=True)
+            assert e.commit_path() == 1
+    for a, b in zip(out["registers"], out["memory"]):
+        assert np.array_equal(a, b)
+    assert out["registers"][3].sum() > 0  # the committed millicores reached the missing-utilisation column
+
+
 def test_commit_sequential_rejects_unknown_plugins(gpu_required, hdr):
     from helpers import LROC
     from scheduler_plugins_amd import synth
