@@ -407,6 +407,8 @@ def main() -> None:
                     help="spx_set_option before the timed region, e.g. --opt NET_FOLD_ALLOC=0 (A/B experiments; repeatable)")
     ap.add_argument("--no-pod-classes", action="store_true", help="evaluate every pod row (SPX_OPT_NRT_POD_CLASSES / SPX_OPT_PEAKS_POD_CLASSES off): "
                     "by default a whole-batch NRT or Peaks sweep evaluates one row per class of pods with equal records and copies it")
+    ap.add_argument("--no-every-row", action="store_true", help="skip the every_row section (the sweep once more with pod classes off): profiler passes "
+                    "use it so that per-dispatch counter means describe the timed sweep only")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="ranks mode (torch.distributed.run): nccl = RCCL over xGMI (the driver's "
                     "scaling run); gloo = the same code path with the collectives on host tensors, for boxes with fewer GPUs than ranks (tests)")
     ap.add_argument("--rank-devices", default="", help="ranks mode: device of each local rank, e.g. 0,0 puts two ranks on device 0 (needs --dist-backend gloo: RCCL "
@@ -559,7 +561,7 @@ def main() -> None:
     # the same sweep with every pod row evaluated (no representative rows + copies), outside the timed region: how much of `value`
     # is the synthetic queue's repetitiveness — printed next to it in every line that uses pod classes
     every_row = None
-    if mode == "single" and not args.no_pod_classes and any(v["rows_copied"] > 0 for v in pod_classes.values()):
+    if mode == "single" and not args.no_pod_classes and not args.no_every_row and any(v["rows_copied"] > 0 for v in pod_classes.values()):
         try:
             for name in pod_classes:
                 target.set_option("NRT_POD_CLASSES" if name == "nrt" else "PEAKS_POD_CLASSES", 0)

@@ -126,8 +126,10 @@ class Parser:
             op = self.take()
             right = self.parse_unary()
             if isinstance(left, (int, float)) and isinstance(right, (int, float)):
-                left = {"*": left * right, "+": left + right, "-": left - right, "/": left // right if isinstance(left, int) else left / right,
-                        "<<": left << right, ">>": left >> right}[op]
+                both_int = isinstance(left, int) and isinstance(right, int)
+                left = {"*": lambda: left * right, "+": lambda: left + right, "-": lambda: left - right,
+                        "/": lambda: left // right if both_int else left / right,
+                        "<<": lambda: left << right, ">>": lambda: left >> right}[op]()
             else:
                 left = Call("op" + op, [left, right])
         return left

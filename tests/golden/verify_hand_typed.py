@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Checks hand-typed golden tables against the reference's Go test tables, read with goparse (no Go toolchain here, nothing is
 executed).  Runs only where /root/reference is mounted; tests/test_golden_hand_typed.py calls it and is skipped elsewhere.
-Covered so far: allocatable.py (pkg/noderesources/allocatable_test.go:114-238) — every case's pod, node sizes, resource weights,
-mode, expected list and line; the other hand-typed files are listed in README.md as not yet machine-checked."""
+Covered: allocatable.py (pkg/noderesources/allocatable_test.go:114-238) — every case's pod, node sizes, resource weights, mode,
+expected list and line; trimaran.py's COMPUTE_SCORE and MU_SIGMA; lroc.py's three Beta-distribution tables and the tolerance;
+peaks.py's power model and NormalizeScore cases.  README.md lists what is still hand-typed only."""
 from __future__ import annotations
 
 import sys
@@ -74,5 +75,145 @@ def eval_const(v, names=None):
     raise ValueError(repr(v))
 
 
+def _num(v):
+    return float(v) if isinstance(v, (int, float)) else {"true": True, "false": False}[v.name]
+
+
+def _tests(path: str, func: str, var: str = "tests := "):
+    src = (REF / path).read_text()
+    return parse_literal_after(src[src.index("func " + func):], var)
+
+
+def check_trimaran() -> int:
+    """trimaran.py: COMPUTE_SCORE (analysis_test.go:38-157, TestComputeScore) and MU_SIGMA (resourcestats_test.go:259-372,
+    TestGetMuSigma) — every number of every case, in order (names: the hand-typed table tags the reference's repeated
+    "large usedAvg" with "(dup)")"""
+    import trimaran as T
+    checked = 0
+    go = _tests("pkg/trimaran/loadvariationriskbalancing/analysis_test.go", "TestComputeScore")
+    assert len(go) == len(T.COMPUTE_SCORE)
+    for t, c in zip(go, T.COMPUTE_SCORE):
+        rs = t["rs"]
+        want = (t["margin"], t["sensitivity"], rs["Capacity"], rs["Req"], rs["UsedAvg"], rs["UsedStdev"], t["expected"])
+        assert c[0].replace(" (dup)", "") == t["name"] and tuple(c[1:]) == want, (t["name"], c, want)
+        checked += 1
+    go = _tests("pkg/trimaran/resourcestats_test.go", "TestGetMuSigma")
+    assert len(go) == len(T.MU_SIGMA)
+    for t, c in zip(go, T.MU_SIGMA):
+        rs = t["args"]["rs"]
+        want = (rs["Capacity"], rs["Req"], rs["UsedAvg"], rs["UsedStdev"], t["wantMu"], t["wantSigma"])
+        assert c[0] == t["name"] and tuple(float(x) for x in c[1:]) == tuple(float(x) for x in want), (t["name"], c, want)
+        checked += 1
+    return checked
+
+
+def check_lroc() -> int:
+    """lroc.py: MATCH_MOMENTS, DISTRIBUTION_FUNCTION, MAX_VARIANCE against beta_test.go:111-171, :236-327, :329-374"""
+    import lroc as L
+    checked = 0
+    go = _tests("pkg/trimaran/lowriskovercommitment/beta_test.go", "TestBetaDistribution_MatchMoments")
+    assert len(go) == len(L.MATCH_MOMENTS)
+    for t, c in zip(go, L.MATCH_MOMENTS):
+        f = t["fields"] or {}
+        want = (t["name"], float(t["args"]["m1"]), float(t["args"]["m2"]), _num(t["want"]),
+                float(f["alpha"]) if f else None, float(f["beta"]) if f else None)
+        got = (c[0], float(c[1]), float(c[2]), c[3], None if c[4] is None else float(c[4]), None if c[5] is None else float(c[5]))
+        assert got == want, (got, want)
+        checked += 1
+    go = _tests("pkg/trimaran/lowriskovercommitment/beta_test.go", "TestBetaDistribution_DistributionFunction")
+    assert len(go) == len(L.DISTRIBUTION_FUNCTION)
+    for t, c in zip(go, L.DISTRIBUTION_FUNCTION):
+        want = (t["name"], float(t["fields"]["alpha"]), float(t["fields"]["beta"]), float(t["args"]["x"]), float(t["want"]))
+        assert (c[0],) + tuple(float(x) for x in c[1:]) == want, (c, want)
+        checked += 1
+    go = _tests("pkg/trimaran/lowriskovercommitment/beta_test.go", "TestGetMaxVariance")
+    assert [(float(t["args"]["m1"]), float(t["want"])) for t in go] == [(float(a), float(b)) for a, b in L.MAX_VARIANCE]
+    checked += len(go)
+    src = (REF / "pkg/trimaran/lowriskovercommitment/beta_test.go").read_text()
+    tol = parse_literal_after(src, "tolerance = ") if "tolerance = " in src else None
+    assert tol is None or float(tol) == L.TOLERANCE, tol
+    return checked
+
+
+def check_lroc_compute_risk() -> int:
+    """lroc.py: the computeRisk fixtures (lowriskovercommitment_test.go:261-338: node_A's sizes, watcherData_A's metrics, nrla_A1 / nrla_A2)
+    and cases (:341-395)"""
+    import lroc as L
+    src = (REF / "pkg/trimaran/lowriskovercommitment/lowriskovercommitment_test.go").read_text()
+    res = parse_literal_after(src, "nodeResources_A map[v1.ResourceName]string = ")
+    assert {"cpu": res["v1.ResourceCPU"], "memory": res["v1.ResourceMemory"]} == L.NODE_A, res
+    wd = parse_literal_after(src, "watcherData_A watcher.Data = ")
+    metrics = next(iter(wd["NodeMetricsMap"].values()))["Metrics"]
+    typ = {"watcher.CPU": "CPU", "watcher.Memory": "Memory"}
+    op = {"watcher.Average": "AVG", "watcher.Std": "STD"}
+    assert [(typ[m["Type"].name], op[m["Operator"].name], m["Value"]) for m in metrics] == L.METRICS_A, metrics
+    key = {"NodeRequest": "req", "NodeLimit": "lim", "NodeRequestMinusPod": "req_minus_pod", "NodeLimitMinusPod": "lim_minus_pod", "Nodecapacity": "cap"}
+    fixtures = {}
+    for name, hand in (("nrla_A1", L.NRLA_A1), ("nrla_A2", L.NRLA_A2)):
+        lit = parse_literal_after(src, name + " *trimaran.NodeRequestsAndLimits = ")
+        flat = {}
+        for k, v in lit.items():
+            flat[key[k] + "_cpu"], flat[key[k] + "_mem"] = v["MilliCPU"], v["Memory"]
+        assert flat == hand, (name, flat, hand)
+        fixtures[name] = hand
+    go = parse_literal_after(src[src.index("func TestLowRiskOverCommitment_computeRisk"):], "tests := ")
+    assert len(go) == len(L.COMPUTE_RISK)
+    for t, c in zip(go, L.COMPUTE_RISK):
+        assert (t["name"], typ[t["resourceType"].name], float(t["want"])) == (c[0], c[1], float(c[3])) and fixtures[t["nodeRequestsAndLimits"].name] is c[2], (t, c)
+    return 3 + len(go)
+
+
+def check_network() -> int:
+    """network.py: TestNetworkOverheadScore's pod, raw scores and normalised scores per node (networkoverhead_test.go:572-818, 3 cases) and
+    TestNetworkOverheadFilter's pod (selector and AppGroup label: makePod's first and fourth arguments), node under test and verdict (:1055-1276, 8 cases: the "Satisfied: s Violated: v" message or nil)"""
+    import re
+    import network as N
+    src = (REF / "pkg/networkaware/networkoverhead/networkoverhead_test.go").read_text()
+    checked = 0
+    go = parse_literal_after(src[src.index("func TestNetworkOverheadScore"):], "tests := ")
+    assert len(go) == len(N.SCORE_CASES)
+    for t, c in zip(go, N.SCORE_CASES):
+        idx = lambda e: e["Name"].args[0].args[1]  # nodes[i].Name
+        for key, mine in (("wantedScoresBefore", c["before"]), ("wantedScoresAfter", c["after"])):
+            assert [idx(e) for e in t[key]] == list(range(len(mine))) and [e["Score"] for e in t[key]] == mine, (t["name"], key)
+        assert t["pod"].args[0] == c["selector"] and t["pod"].args[3] == c["appgroup"] and c["name"].split(",")[0] in t["name"], t["name"]
+        checked += 1
+    go = parse_literal_after(src[src.index("func TestNetworkOverheadFilter"):], "tests := ")
+    assert len(go) == len(N.FILTER_CASES)
+    for t, c in zip(go, N.FILTER_CASES):
+        st = t["wantStatus"]
+        want = None
+        if isinstance(st, Call):
+            m = re.search(r"Satisfied: (\d+) Violated: (\d+)", st.args[1])
+            want = (int(m.group(1)), int(m.group(2)))
+        assert (t["pod"].args[0], t["pod"].args[3], t["nodeToFilter"].args[1], want) == (c["selector"], c["appgroup"], c["node"], c["want"]), (t["name"], c)
+        checked += 1
+    return checked
+
+
+def check_peaks() -> int:
+    """peaks.py: the power model fixture (peaks_test.go:80-86) and NORMALIZE_CASES (TestPeaksNormalizeScore :426-531: the score lists
+    before and after, by their line)"""
+    import peaks as P
+    src = (REF / "pkg/trimaran/peaks/peaks_test.go").read_text()
+    model = parse_literal_after(src[src.index("var data = "):], '"node-1": ')  # (the outer map's element type is `interface{}`: the inner literal is parsed)
+    assert {k: float(v) for k, v in model.items()} == P.POWER_MODEL, model
+    score = {"fwk.MinNodeScore": 0, "fwk.MaxNodeScore": 100}
+    p = src.index("func TestPeaksNormalizeScore")
+    lists = {n: [score[e["Score"].name] for e in parse_literal_after(src[p:], n + " := ")] for n in ("nodeScoreList1", "nodeScoreList2", "nodeScoreList3")}
+    go = parse_literal_after(src[p:], "tests := ")
+    assert len(go) == len(P.NORMALIZE_CASES)
+    for t, (line, before, after) in zip(go, P.NORMALIZE_CASES):
+        at = line_of(src, '"' + t["test"] + '"', p)
+        assert abs(at - line) <= 3, (t["test"], at, line)  # (the hand-typed table cites a line inside the case)
+        assert lists[t["nodeScoreList"].name] == before and [score[e["Score"].name] for e in t["expected"]] == after, t["test"]
+    return 1 + len(go)
+
+
 if __name__ == "__main__":
     print("allocatable.py:", check_allocatable(), "cases agree with allocatable_test.go")
+    print("trimaran.py:", check_trimaran(), "rows of COMPUTE_SCORE / MU_SIGMA agree with analysis_test.go / resourcestats_test.go")
+    print("lroc.py:", check_lroc(), "rows of the three beta tables agree with beta_test.go")
+    print("lroc.py:", check_lroc_compute_risk(), "computeRisk fixtures and cases agree with lowriskovercommitment_test.go")
+    print("network.py:", check_network(), "Score / Filter cases agree with networkoverhead_test.go")
+    print("peaks.py:", check_peaks(), "fixtures agree with peaks_test.go")
