@@ -261,6 +261,89 @@ def capacity():
     return out
 
 
+_NRT_CONSTS = {"cpu": "cpu", "memory": "memory", "gpuResourceName": "vendor/gpu", "hugepages2Mi": "hugepages-2Mi",
+               "nicResourceName": "vendor/nic1", "v1.ResourceCPU": "cpu", "v1.ResourceMemory": "memory",
+               "corev1.ResourceCPU": "cpu", "corev1.ResourceMemory": "memory"}
+_NRT_ATTRS = {"nodeconfig.AttributePolicy": "topologyManagerPolicy", "nodeconfig.AttributeScope": "topologyManagerScope"}
+
+
+def _make_nrt(expr):
+    """a MakeNRT() builder chain (test/integration/nrtutils.go:159-207) as data"""
+    def rn(k):
+        return _NRT_CONSTS[k.name] if isinstance(k, Ident) else _NRT_CONSTS.get(k, k)
+    out = {"name": None, "policies": [], "attributes": {}, "zones": []}
+
+    def walk(e):
+        if e.fn == "MakeNRT":
+            return
+        walk(e.args[0])
+        if e.fn == ".Name":
+            out["name"] = e.args[1]
+        elif e.fn == ".Policy":
+            out["policies"].append(e.args[1].name.split(".")[-1])
+        elif e.fn == ".Attributes":
+            for a in e.args[1]:
+                out["attributes"][_NRT_ATTRS[a["Name"].name]] = a["Value"]
+        elif e.fn == ".Zone":
+            out["zones"].append({"name": f"node-{len(out['zones'])}", "type": "Node",
+                                 "resources": [[rn(r.args[0]), r.args[1], r.args[2]] for r in e.args[1]]})
+        elif e.fn != ".Obj":
+            raise ValueError(f"unknown NRT builder {e.fn}")
+    walk(expr)
+    return out
+
+
+def nrt_cache_integration():
+    """test/integration/noderesourcetopology_cache_test.go:111-644, TestTopologyCachePluginWithoutUpdates (6 cases): pods created one
+    after the other against two nodes whose NRT objects never change; what the second pod sees depends on the cache —
+    OverReserve (default profile; overreserve.go:170-203: a bound pod's request is charged to EVERY zone of its node, deletes are
+    ignored until a resync) or DiscardReserved (profile "discardReserved": nothing is charged once PostBind ran).  Steps are
+    recorded in order: a pod (one container per resources map; util.WithLimits = limits, which the API server copies into
+    requests; util.WithRequests = requests only) with the node it must land on ("" = stays pending, "*" = any), or a delete.
+    Nodes are created from the NRTs: capacity = the sum of the zones' capacities per resource, pods "128" (nrtutils.go:73-90,
+    :240-253).  makeTestFullyAvailableNRTs() (nrtutils.go:278-311) is read from its own literal.  The two other tests of the file
+    (resync after pod-fingerprint / attribute updates) are not transcribed."""
+    path = "test/integration/noderesourcetopology_cache_test.go"
+    src = (REF / path).read_text()
+    utils = (REF / "test/integration/nrtutils.go").read_text()
+    single = parse_literal_after(utils[utils.index("func makeTestFullyAvailableNRTSingle"):], "return ")
+    second = parse_literal_after(utils[utils.index("func makeTestFullyAvailableNRTs"):], "return ")
+    assert isinstance(second, Call) and second.fn == "append" and isinstance(second.args[0], Ident) and second.args[0].name == "nrts"
+    fully_available = [_make_nrt(n) for n in single] + [_make_nrt(n) for n in second.args[1:]]
+    p = src.index("func TestTopologyCachePluginWithoutUpdates")
+    end = src.index("func TestTopologyCachePluginWithPodFingerprintUpdates")
+    cases = []
+    cursor = p
+    for t in parse_literal_after(src[p:end], "range []testCase"):
+        cursor = src.index('"' + t["name"] + '"', cursor) + 1
+        nrts = t["nodeResourceTopologies"]
+        if isinstance(nrts, Call):
+            assert nrts.fn == "makeTestFullyAvailableNRTs", nrts.fn
+            nrts = fully_available
+        else:
+            nrts = [_make_nrt(n) for n in nrts]
+        steps, cache = [], "OverReserve"
+        for d in t["podDescs"]:
+            sched = d.get("schedulerName")
+            sched = {"discardReservedSchedulerName": "discardReserved"}.get(sched.name, sched.name) if isinstance(sched, Ident) else sched
+            if sched == "discardReserved":
+                cache = "DiscardReserved"
+            if isinstance(d.get("isDelete"), Ident) and d["isDelete"].name == "true":
+                steps.append({"delete": d["podName"]})
+                continue
+            guaranteed = d["isGuaranteed"].name == "true"
+            maps = ([d["resourcesMap"]] if d.get("resourcesMap") else []) + list(d.get("multiResourcesMap") or [])
+            ctrs = []
+            for m in maps:
+                rl = {_NRT_CONSTS.get(k, k): v for k, v in m.items()}
+                ctrs.append({"requests": dict(rl), "limits": dict(rl)} if guaranteed else {"requests": dict(rl)})
+            exp = d["expectedNode"]
+            exp = {"anyNode": "*"}[exp.name] if isinstance(exp, Ident) else exp
+            steps.append({"pod": d["podName"], "containers": ctrs, "expected_node": exp})
+        cases.append({"name": t["name"], "line": src.count("\n", 0, cursor) + 1, "cache": cache, "strategy": "LeastAllocated", "nrts": nrts, "steps": steps})
+    return {"source": path, "node_extra_capacity": {"pods": "128"}, "cases": cases}
+
+
 def nrt_integration():
     """test/integration/noderesourcetopology_test.go: the table of TestTopologyMatchPlugin (29 cases): one pod, two nodes
     with NRTs built by the MakeNRT() wrapper (test/integration/nrtutils.go:159-207), the scheduler profile (= scoring
@@ -418,7 +501,7 @@ def nrt_discard_reserved():
 
 
 FIXTURES = {"capacity.json": capacity, "nrt_filter.json": nrt_filter, "nrt_score.json": nrt_score, "nrt_least_numa.json": nrt_least_numa,
-            "nrt_integration.json": nrt_integration, "trimaran_handler.json": trimaran_handler, "nrt_discard_reserved.json": nrt_discard_reserved}
+            "nrt_integration.json": nrt_integration, "nrt_cache_integration.json": nrt_cache_integration, "trimaran_handler.json": trimaran_handler, "nrt_discard_reserved.json": nrt_discard_reserved}
 
 if __name__ == "__main__":
     for fname, fn in FIXTURES.items():
