@@ -1,11 +1,13 @@
 // parallel.hpp — chunked parallel-for over independent rows for the host flatteners.
 //
-// Round 4: a lazily created, process-wide pool of parked worker threads.  Rounds 1-3 spawned std::threads per call ("the
+// Round 4: lazily created, process-wide pools of parked worker threads.  Rounds 1-3 spawned std::threads per call ("the
 // flatteners own no thread pool"): 16 thread creations cost ~0.4 ms — at 100 000 pods the whole trimaran pod flatten is 0.1 ms of
-// work, and the spawn was most of the 0.58 ms the call took (tools/r4/time_host_cycle.py).  The pool holds one job at a time: a
-// second caller (another cgo / ctypes thread, or a nested call) finds it busy and runs its rows inline, which is always correct.
-// Rows are handed out in chunks from an atomic counter, the calling thread works too.  After a fork() the child starts a pool of
-// its own (the parent's threads do not exist there).  Never destroyed: the workers sleep on a condition variable until exit.
+// work, and the spawn was most of the 0.58 ms the call took (tools/r4/time_host_cycle.py).  A pool holds one job at a time; there
+// are up to eight of them (one per 16 hardware threads), so that concurrent callers — the ranks of a multi-device engine each
+// flattening their own pod rows, several cgo threads — each get workers; a caller that finds every pool busy (or a nested call)
+// runs its rows inline, which is always correct.  Rows are handed out in chunks from an atomic counter, the calling thread works
+// too.  After a fork() the child starts pools of its own (the parent's threads do not exist there).  Never destroyed: the workers
+// sleep on a condition variable until exit.
 #pragma once
 
 #include <unistd.h>
@@ -23,13 +25,30 @@ namespace spx_host {
 
 class RowPool {
  public:
-  static RowPool& get() {
+  static constexpr int kMaxPools = 8;
+  // the process's pools: [0, *n)
+  static RowPool* const* all(int* n) {
     static std::mutex guard;
-    static RowPool* pool = nullptr;
+    static RowPool* pools[kMaxPools] = {};
+    static int count = 0;
     static pid_t owner = 0;
     std::lock_guard<std::mutex> lk(guard);
-    if (!pool || owner != getpid()) pool = new RowPool, owner = getpid();  // (a forked child leaks the parent's object: its threads are gone)
-    return *pool;
+    if (count == 0 || owner != getpid()) {  // (a forked child leaks the parent's objects: their threads are gone)
+      const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+      count = static_cast<int>(std::min<unsigned>(kMaxPools, std::max(1u, hw / 16)));
+      for (int i = 0; i < count; ++i) pools[i] = new RowPool;
+      owner = getpid();
+    }
+    *n = count;
+    return pools;
+  }
+  // the job on the first pool that is free; false = all busy, nothing was run
+  static bool run_any(void (*fn)(void*, int64_t, int64_t), void* ctx, int64_t n, int64_t chunk, unsigned threads) {
+    int count = 0;
+    RowPool* const* pools = all(&count);
+    for (int i = 0; i < count; ++i)
+      if (pools[i]->run(fn, ctx, n, chunk, threads)) return true;
+    return false;
   }
 
   // fn(ctx, begin, end) over [0, n) in chunks of `chunk` rows on up to `threads` threads (the caller is one of them);
@@ -106,7 +125,7 @@ inline void parallel_rows(int64_t n, Fn&& fn, int64_t min_rows_per_thread = 8192
   // a few chunks per thread: the rows are not equally expensive (pods differ in container counts) and the workers wake at different times
   const int64_t chunk = std::max<int64_t>(64, (n + 4 * want - 1) / (4 * want));
   auto thunk = [](void* c, int64_t b, int64_t e) { (*static_cast<std::remove_reference_t<Fn>*>(c))(b, e); };
-  if (!RowPool::get().run(thunk, const_cast<void*>(static_cast<const void*>(&fn)), n, chunk, want)) fn(static_cast<int64_t>(0), n);
+  if (!RowPool::run_any(thunk, const_cast<void*>(static_cast<const void*>(&fn)), n, chunk, want)) fn(static_cast<int64_t>(0), n);
 }
 
 }  // namespace spx_host
