@@ -778,8 +778,16 @@ struct DeltaBlob {
       SPX_HIP(e, hipHostMalloc(&e->h_stage, bytes + 65536, hipHostMallocDefault));
       e->h_stage_bytes = bytes + 65536;
     }
-    for (size_t k = 0; k < parts.size(); ++k)
-      if (parts[k].second) std::memcpy(static_cast<char*>(e->h_stage) + offset[k], parts[k].first, parts[k].second);
+    for (size_t k = 0; k < parts.size(); ++k) {
+      char* dst = static_cast<char*>(e->h_stage) + offset[k];
+      const char* src = static_cast<const char*>(parts[k].first);
+      const int64_t blocks = static_cast<int64_t>((parts[k].second + 65535) / 65536);  // (a full node table: megabytes per column)
+      const size_t len = parts[k].second;
+      spx_host::parallel_rows(blocks, [&](int64_t b0, int64_t b1) {
+        const size_t at = static_cast<size_t>(b0) * 65536, end = std::min(len, static_cast<size_t>(b1) * 65536);
+        if (end > at) std::memcpy(dst + at, src + at, end - at);
+      }, 16);
+    }
     return upload(e, e->d_delta, e->h_stage, bytes);
   }
   const char* dev(size_t at) const { return static_cast<const char*>(e->d_delta.p) + at; }
@@ -1190,47 +1198,53 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
   if (rc) return rc;
   const int64_t n = t->n_nodes;
   constexpr int64_t Zm = SPX_NRT_MAX_ZONES;
-  if ((rc = upload(e, e->d_nrt_flags, t->flags, static_cast<size_t>(n)))) return rc;
-  if ((rc = upload(e, e->d_nrt_max_numa, t->max_numa, static_cast<size_t>(n) * 4))) return rc;
-  if ((rc = upload(e, e->d_nrt_nz, t->n_zones, static_cast<size_t>(n)))) return rc;
-  if ((rc = upload(e, e->d_nrt_np, t->node_present, static_cast<size_t>(n)))) return rc;
-  SPX_HIP(e, hipStreamSynchronize(e->stream));
-  if ((rc = upload_transposed(e, e->d_nrt_zid, t->zone_id, n, Zm))) return rc;
-  if ((rc = upload_transposed(e, e->d_nrt_zp, t->zone_present, n, Zm))) return rc;
-  if ((rc = upload_transposed(e, e->d_nrt_avail, t->zone_avail, n, Zm * t->n_res))) return rc;
-  if ((rc = upload_transposed(e, e->d_nrt_cost, t->zone_cost, n, Zm * Zm))) return rc;
-  if ((rc = upload_transposed(e, e->d_nrt_minavg, t->min_avg_dist, n, Zm))) return rc;
-  {  // float64 formulation: derived columns + precondition check
-    const int64_t R = t->n_res;
-    std::vector<double> av(static_cast<size_t>(Zm * R * n), -1.0), rcp(static_cast<size_t>(Zm * R * n), spx::kNrtNoCap), rcv(static_cast<size_t>(Zm * R * n), 1.0),
-        cpuv(static_cast<size_t>(Zm * n), 0.0), braw(static_cast<size_t>(Zm * n), spx::kNrtNoCap);
-    std::vector<uint8_t> rep(static_cast<size_t>((R > 0 ? R : 1) * n), 0);
-    std::atomic<bool> ok{true};
+  const int64_t R = t->n_res;
+  if (!t->flags || !t->max_numa || !t->n_zones || !t->zone_id || !t->zone_present || !t->zone_cost || !t->min_avg_dist || !t->node_present ||
+      (!t->zone_avail && R))
+    return fail(e, SPX_ERR_ARG, "NULL column in table");
+  // Round 4: the full upload takes the delta's road (spx_update_nrt_nodes) with every node listed — the rows as they are into ONE
+  // pinned blob, one DMA, and the device turns them into the node-major columns (k_scatter_rows) and the float64 formulation's
+  // derived columns (k_nrt_derive_rows: the expressions below used to run here, on the host, into five freshly allocated vectors
+  // that were then copied from pageable memory: 12.6 of the 24 ms a full snapshot load took at 20 000 nodes).  What stays on the host:
+  // the preconditions of the float64 formulation, the window-local node order, the host copy LeastNUMANodes' tables are built from.
+  const size_t m = static_cast<size_t>(n), cells = static_cast<size_t>(Zm * R) * m;
+  if ((rc = ensure(e, e->d_nrt_flags, m)) || (rc = ensure(e, e->d_nrt_max_numa, m * 4)) || (rc = ensure(e, e->d_nrt_nz, m)) || (rc = ensure(e, e->d_nrt_np, m)) ||
+      (rc = ensure(e, e->d_nrt_zid, m * Zm)) || (rc = ensure(e, e->d_nrt_zp, m * Zm)) || (rc = ensure(e, e->d_nrt_avail, cells * 8)) ||
+      (rc = ensure(e, e->d_nrt_cost, m * Zm * Zm * 4)) || (rc = ensure(e, e->d_nrt_minavg, m * Zm * 4)) || (rc = ensure(e, e->d_nrt_fav, cells * 8)) ||
+      (rc = ensure(e, e->d_nrt_frc, cells * 8)) || (rc = ensure(e, e->d_nrt_frcv, cells * 8)) || (rc = ensure(e, e->d_nrt_fcpu, m * Zm * 8)) ||
+      (rc = ensure(e, e->d_nrt_fbraw, m * Zm * 8)) || (rc = ensure(e, e->d_nrt_frep, static_cast<size_t>(R > 0 ? R : 1) * m)))
+    return rc;
+  {
+    std::atomic<bool> ok{true}, ln_ok{true};
     std::atomic<uint32_t> big_nodes{0};
     spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
+    bool my_ok = true, my_ln = true;
+    uint32_t my_big = 0;
     for (int64_t i = row0; i < row1; ++i) {
       const int nz = t->n_zones[i];
       for (int z = 0; z < nz && z < Zm; ++z) {
-        if (t->zone_id[i * Zm + z] != z) ok = false;  // "lowest NUMA id" must be "lowest list position"
+        if (t->zone_id[i * Zm + z] != z) my_ok = false;  // "lowest NUMA id" must be "lowest list position"
         for (int64_t r = 0; r < R; ++r) {
           if (!((t->zone_present[i * Zm + z] >> r) & 1u)) continue;
           const int64_t cap = t->zone_avail[(i * Zm + z) * R + r];
-          if (!nrt_fast_qty(cap)) ok = false;
-          const bool is_cpu = r == e->nrt_cpu_slot;
-          const double cap_v = static_cast<double>(nrt_value_of(is_cpu, cap));
-          if (!nrt_exact_f32(cap_v)) big_nodes.fetch_or(1u << r, std::memory_order_relaxed);
-          av[static_cast<size_t>((z * R + r) * n + i)] = static_cast<double>(cap);
-          rcp[static_cast<size_t>((z * R + r) * n + i)] = cap_v > 0.0 ? 100.0 / cap_v : spx::kNrtNoCap;
-          rcv[static_cast<size_t>((z * R + r) * n + i)] = cap_v > 0.0 ? 1.0 / cap_v : 1.0;
-          if (is_cpu) cpuv[static_cast<size_t>(z * n + i)] = cap_v;
-          if (is_cpu && cap > 0) braw[static_cast<size_t>(z * n + i)] = 100.0 / static_cast<double>(cap);
-          rep[static_cast<size_t>(r * n + i)] |= static_cast<uint8_t>(1u << z);
+          if (!nrt_fast_qty(cap)) my_ok = false;
+          if (!nrt_exact_f32(static_cast<double>(nrt_value_of(r == e->nrt_cpu_slot, cap)))) my_big |= 1u << r;
+        }
+        // LeastNUMANodes' tables can be built when every zone cost lies within [0, 255] (findSuitableCombination's 256 sentinel)
+        for (int zb = 0; zb < nz && zb < Zm; ++zb) {
+          const int64_t c = t->zone_cost[(i * Zm + z) * Zm + zb];
+          if (c < 0 || c > 255) my_ln = false;
         }
       }
     }
+    if (!my_ok) ok = false;
+    if (!my_ln) ln_ok = false;
+    if (my_big) big_nodes.fetch_or(my_big, std::memory_order_relaxed);
     }, 1024);
     e->nrt_fast_nodes = ok.load();
     e->nrt_big_nodes = big_nodes.load();
+    e->nrt_ln_ok = ln_ok.load();
+    e->nrt_ln_built = false;  // built when that strategy is first evaluated (build_ln_tab): more host time than everything else in this call
     // window-local node order: inside each run of 256 nodes, group the nodes by the code path their flags select
     // (not aligned / pod scope / container scope) so that wavefronts are mostly homogeneous; inside a group, by how tight the
     // node's two largest zones are (the smaller of its ranks, within the window, by the sum of the two largest zone quantities of
@@ -1274,34 +1288,39 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
       for (int k = 0; k < cnt; ++k) perm[static_cast<size_t>(w0 + k)] = static_cast<int32_t>(w0 + order[k]);
     }
     }, 16);
-    if ((rc = upload(e, e->d_nrt_perm, perm.data(), perm.size() * sizeof(int32_t)))) return rc;
-    // LeastNUMANodes' per-node tables are built when that strategy is first evaluated (build_ln_tab): they cost more host time
-    // than everything else in this call and the default strategy never reads them.  Here: the host copy they are built from,
-    // and whether they can be (every zone cost within [0, 255] — findSuitableCombination's 256 sentinel would interfere).
-    {
-      e->h_nrt_cost.assign(t->zone_cost, t->zone_cost + static_cast<size_t>(n) * Zm * Zm);
-      e->h_nrt_nz.assign(t->n_zones, t->n_zones + static_cast<size_t>(n));
-      std::atomic<bool> ln_ok{true};
-      spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
-        for (int64_t i = row0; i < row1; ++i) {
-          const int nz = std::min<int>(t->n_zones[i], static_cast<int>(Zm));
-          for (int za = 0; za < nz; ++za)
-            for (int zb = 0; zb < nz; ++zb) {
-              const int64_t c = t->zone_cost[(i * Zm + za) * Zm + zb];
-              if (c < 0 || c > 255) ln_ok = false;
-            }
-        }
-      }, 4096);
-      e->nrt_ln_ok = ln_ok.load();
-      e->nrt_ln_built = false;
-    }
-    if ((rc = upload(e, e->d_nrt_fav, av.data(), av.size() * sizeof(double)))) return rc;
-    if ((rc = upload(e, e->d_nrt_frc, rcp.data(), rcp.size() * sizeof(double)))) return rc;
-    if ((rc = upload(e, e->d_nrt_frcv, rcv.data(), rcv.size() * sizeof(double)))) return rc;
-    if ((rc = upload(e, e->d_nrt_fcpu, cpuv.data(), cpuv.size() * sizeof(double)))) return rc;
-    if ((rc = upload(e, e->d_nrt_fbraw, braw.data(), braw.size() * sizeof(double)))) return rc;
-    if ((rc = upload(e, e->d_nrt_frep, rep.data(), rep.size()))) return rc;
-    SPX_HIP(e, hipStreamSynchronize(e->stream));
+    e->h_nrt_cost.assign(t->zone_cost, t->zone_cost + m * Zm * Zm);
+    e->h_nrt_nz.assign(t->n_zones, t->n_zones + m);
+    std::vector<int32_t> all(m);
+    for (size_t i = 0; i < m; ++i) all[i] = static_cast<int32_t>(i);
+    DeltaBlob b{e};
+    const size_t o_idx = b.add(all.data(), m * 4), o_perm = b.add(perm.data(), perm.size() * sizeof(int32_t));
+    const size_t o_flags = b.add(t->flags, m), o_max = b.add(t->max_numa, m * 4), o_nz = b.add(t->n_zones, m), o_np = b.add(t->node_present, m);
+    const size_t o_zid = b.add(t->zone_id, m * Zm), o_zp = b.add(t->zone_present, m * Zm);
+    const size_t o_av = b.add(t->zone_avail, cells * 8), o_cost = b.add(t->zone_cost, m * Zm * Zm * 4);
+    const size_t o_min = b.add(t->min_avg_dist, m * Zm * 4);
+    if ((rc = ensure(e, e->d_nrt_perm, perm.size() * sizeof(int32_t)))) return rc;
+    if ((rc = b.ship())) return rc;
+    const int32_t* d_idx = reinterpret_cast<const int32_t*>(b.dev(o_idx));
+    hipStream_t st = e->stream;
+    SPX_HIP(e, hipMemcpyAsync(e->d_nrt_perm.p, b.dev(o_perm), perm.size() * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    SPX_HIP(e, hipMemcpyAsync(e->d_nrt_flags.p, b.dev(o_flags), m, hipMemcpyDeviceToDevice, st));
+    SPX_HIP(e, hipMemcpyAsync(e->d_nrt_max_numa.p, b.dev(o_max), m * 4, hipMemcpyDeviceToDevice, st));
+    SPX_HIP(e, hipMemcpyAsync(e->d_nrt_nz.p, b.dev(o_nz), m, hipMemcpyDeviceToDevice, st));
+    SPX_HIP(e, hipMemcpyAsync(e->d_nrt_np.p, b.dev(o_np), m, hipMemcpyDeviceToDevice, st));
+    spx::launch_scatter_rows(e->d_nrt_zid.p, n, static_cast<int>(Zm), d_idx, b.dev(o_zid), n, 1, st);
+    spx::launch_scatter_rows(e->d_nrt_zp.p, n, static_cast<int>(Zm), d_idx, b.dev(o_zp), n, 1, st);
+    if (R) spx::launch_scatter_rows(e->d_nrt_avail.p, n, static_cast<int>(Zm * R), d_idx, b.dev(o_av), n, 8, st);
+    spx::launch_scatter_rows(e->d_nrt_cost.p, n, static_cast<int>(Zm * Zm), d_idx, b.dev(o_cost), n, 4, st);
+    spx::launch_scatter_rows(e->d_nrt_minavg.p, n, static_cast<int>(Zm), d_idx, b.dev(o_min), n, 4, st);
+    spx::NrtDeltaArgs da{};
+    da.n_rows = n, da.n_nodes = n, da.n_res = static_cast<int32_t>(R), da.cpu_slot = e->nrt_cpu_slot;
+    da.idx = d_idx, da.n_zones = reinterpret_cast<const uint8_t*>(b.dev(o_nz)), da.zone_present = reinterpret_cast<const uint8_t*>(b.dev(o_zp));
+    da.zone_avail = reinterpret_cast<const int64_t*>(b.dev(o_av));
+    da.f_av = static_cast<double*>(e->d_nrt_fav.p), da.f_rc = static_cast<double*>(e->d_nrt_frc.p), da.f_rcv = static_cast<double*>(e->d_nrt_frcv.p);
+    da.f_cpu = static_cast<double*>(e->d_nrt_fcpu.p), da.f_braw = static_cast<double*>(e->d_nrt_fbraw.p), da.f_rep = static_cast<uint8_t*>(e->d_nrt_frep.p);
+    spx::launch_nrt_derive_rows(da, st);
+    SPX_HIP(e, hipGetLastError());
+    SPX_HIP(e, hipStreamSynchronize(st));  // the blob is reused by the next staged call
   }
   e->nrt_nodes = true;
   return SPX_OK;

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/spx.h"
+#include "parallel.hpp"
 
 namespace {
 
@@ -114,7 +115,7 @@ void build_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag,
   const size_t P = static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 0);
   k.fp = 0;  // set by the caller once the build is complete
   k.pod_key.assign(P, 0), k.topo_order.assign(P, -1);
-  k.pair_ptr.assign(1, 0), k.pair_node.clear(), k.pair_max_cost.clear(), k.key_score_equally.clear();
+  k.pair_ptr.clear(), k.pair_node.clear(), k.pair_max_cost.clear(), k.key_score_equally.clear();
   // (AppGroup, workload selector) -> key id, in order of first appearance.  A group has a handful of workloads: its keys sit in
   // a short list searched linearly (a hash map of packed pairs cost 50 ns per pod, an ordered map a tree walk)
   struct GroupKey {
@@ -142,34 +143,57 @@ void build_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag,
     k.pod_key[p] = hit->key;
     k.topo_order[p] = hit->topo;
   }
-  k.key_score_equally.resize(order.size());
-  k.pair_ptr.reserve(order.size() + 1);
-  for (std::size_t ki = 0; ki < order.size(); ++ki) {
-    const int32_t g = order[ki].first, sel = order[ki].second;
-    uint8_t flag = 1;  // scoreEqually
-    if (g >= 0) {
-      // dependencyList: Dependencies of every workload whose selector matches (util.go:203-209)
-      bool any_dep = false;
-      for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w)
-        if (ag->wl_selector[w] == sel && ag->dep_ptr[w + 1] > ag->dep_ptr[w]) any_dep = true;
-      const bool any_placed = ag->placed_ptr[g + 1] > ag->placed_ptr[g];
-      if (any_dep && any_placed) {
-        flag = 0;
-        for (int32_t s = ag->placed_ptr[g]; s < ag->placed_ptr[g + 1]; ++s)      // for each pod already allocated
-          for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w) {            //   for each dependency
-            if (ag->wl_selector[w] != sel) continue;
+  // Per key: the flag and the (host, MaxNetworkCost) pairs of the pods already placed.  The keys are independent of each other:
+  // counted on the host threads, offsets by a prefix sum, filled on the host threads (round 4; the key numbering above is the
+  // serial part).  A key's workloads — those of its group whose selector matches — are listed once, not re-found per placed pod.
+  const size_t K = order.size();
+  k.key_score_equally.assign(K, 1);  // scoreEqually
+  k.pair_ptr.assign(K + 1, 0);
+  auto walk_keys = [&](bool fill) {
+    spx_host::parallel_rows(static_cast<int64_t>(K), [&](int64_t k0, int64_t k1) {
+      std::vector<int32_t> mine;  // the key's workloads, in workload order
+      for (int64_t ki = k0; ki < k1; ++ki) {
+        const int32_t g = order[static_cast<size_t>(ki)].first, sel = order[static_cast<size_t>(ki)].second;
+        if (g < 0) continue;
+        // dependencyList: Dependencies of every workload whose selector matches (util.go:203-209)
+        mine.clear();
+        bool any_dep = false;
+        for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w)
+          if (ag->wl_selector[w] == sel) {
+            mine.push_back(w);
+            any_dep |= ag->dep_ptr[w + 1] > ag->dep_ptr[w];
+          }
+        const bool any_placed = ag->placed_ptr[g + 1] > ag->placed_ptr[g];
+        if (!(any_dep && any_placed)) continue;
+        uint8_t flag = 0;
+        int32_t at = fill ? k.pair_ptr[static_cast<size_t>(ki)] : 0;
+        for (int32_t s = ag->placed_ptr[g]; s < ag->placed_ptr[g + 1]; ++s)  // for each pod already allocated
+          for (const int32_t w : mine)                                          //   for each dependency
             for (int32_t d = ag->dep_ptr[w]; d < ag->dep_ptr[w + 1]; ++d) {
               if (ag->placed_selector[s] != ag->dep_selector[d]) continue;
               if (ag->placed_node[s] < 0) flag = 2;  // host not in the snapshot: PreFilter returns Error (:258, :274)
-              k.pair_node.push_back(ag->placed_node[s]);
-              k.pair_max_cost.push_back(ag->dep_max_cost[d]);
+              if (fill) k.pair_node[static_cast<size_t>(at)] = ag->placed_node[s], k.pair_max_cost[static_cast<size_t>(at)] = ag->dep_max_cost[d];
+              ++at;
             }
-          }
+        if (fill) k.key_score_equally[static_cast<size_t>(ki)] = flag;
+        else k.pair_ptr[static_cast<size_t>(ki) + 1] = at;  // the key's count, turned into offsets below
       }
+    }, 512);
+  };
+  walk_keys(false);
+  int64_t total = 0;
+  for (size_t ki = 0; ki < K; ++ki) {  // counts (stored one slot up) -> exclusive offsets
+    const int64_t c = k.pair_ptr[ki + 1];
+    k.pair_ptr[ki] = static_cast<int32_t>(total);
+    total += c;
+    if (total > INT32_MAX) {  // (refused by the entry point: 32-bit offsets)
+      k.pair_node.assign(static_cast<size_t>(INT32_MAX) + 1, 0);
+      return;
     }
-    k.key_score_equally[ki] = flag;
-    k.pair_ptr.push_back(static_cast<int32_t>(k.pair_node.size()));
   }
+  k.pair_ptr[K] = static_cast<int32_t>(total);
+  k.pair_node.assign(static_cast<size_t>(total), 0), k.pair_max_cost.assign(static_cast<size_t>(total), 0);
+  walk_keys(true);
 }
 }  // namespace
 
@@ -219,7 +243,7 @@ thread_local NetCommit tl_net_commit;
 void build_net_commit(const spx_pod_objects* pods, const spx_appgroup_objects* ag, NetCommit& out) {
   const size_t P = static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 0);
   out.fp = 0;
-  out.eff_ptr.assign(1, 0), out.eff_ptr.reserve(P + 1);
+  out.eff_ptr.clear();
   out.eff_key.clear(), out.eff_cost.clear();
   // key ids in order of first appearance, per group a short list (selector, key) — the numbering of spx_flatten_net_keys
   struct GroupKey {
@@ -243,33 +267,91 @@ void build_net_commit(const spx_pod_objects* pods, const spx_appgroup_objects* a
     key_of[p] = key;
   }
   // The effects of binding a pod depend only on its (AppGroup, selector), i.e. on its key: computed once per key, copied per
-  // pod (at 62.5k pods of 6.9k keys the per-pod evaluation was 21 ms per call, and the function used to run twice)
-  std::vector<std::vector<std::pair<int32_t, int64_t>>> tmpl(static_cast<size_t>(next));  // per key: (affected key, cost or -1)
-  std::vector<uint8_t> have(static_cast<size_t>(next), 0);
-  for (size_t p = 0; p < P; ++p) {
-    const int32_t g = pods->appgroup[p], sel = pods->selector[p];
-    if (g >= 0 && g < ag->n_groups) {
-      const size_t key = static_cast<size_t>(key_of[p]);
-      auto& t = tmpl[key];
-      if (!have[key]) {
-        have[key] = 1;
-        for (const GroupKey& kk : by_group[static_cast<size_t>(g)]) {
-          bool any_dep = false;
-          for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w)
-            if (ag->wl_selector[w] == kk.selector && ag->dep_ptr[w + 1] > ag->dep_ptr[w]) any_dep = true;
-          if (!any_dep) continue;
-          t.emplace_back(kk.key, int64_t{-1});
-          for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w) {
-            if (ag->wl_selector[w] != kk.selector) continue;
-            for (int32_t d = ag->dep_ptr[w]; d < ag->dep_ptr[w + 1]; ++d)
-              if (ag->dep_selector[d] == sel) t.emplace_back(kk.key, ag->dep_max_cost[d]);
+  // pod (at 62.5k pods of 6.9k keys the per-pod evaluation was 21 ms per call, and the function used to run twice).  Round 4: the
+  // keys' templates and the per-pod copies are independent of each other — both run on the host threads (the numbering above and
+  // the prefix sum between them are the only serial passes): 18.7 -> see DESIGN.md 3.16
+  const size_t K = static_cast<size_t>(next);
+  // per key a template: the (affected key, cost or -1) entries binding a pod of that key adds — flat arrays, counted first and
+  // filled second (a vector per key cost more in the allocator than the walk itself).  Per group, once: which of its keys have
+  // dependencies at all and which workloads carry each key's selector (that walk of the group's workload list per (bound key,
+  // affected key) pair was most of the function's time).
+  std::vector<int32_t> t_off(K + 1, 0);
+  std::vector<int32_t> t_key;
+  std::vector<int64_t> t_cost;
+  auto walk_groups = [&](bool fill) {
+    spx_host::parallel_rows(static_cast<int64_t>(by_group.size()), [&](int64_t g0, int64_t g1) {
+      std::vector<uint8_t> any_dep;
+      std::vector<std::vector<int32_t>> wl_of;
+      for (int64_t g = g0; g < g1; ++g) {
+        const auto& list = by_group[static_cast<size_t>(g)];
+        const size_t nk = list.size();
+        if (nk == 0) continue;
+        any_dep.assign(nk, 0);
+        wl_of.resize(std::max(wl_of.size(), nk));
+        for (size_t i = 0; i < nk; ++i) wl_of[i].clear();
+        for (int32_t w = ag->wl_ptr[g]; w < ag->wl_ptr[g + 1]; ++w)
+          for (size_t i = 0; i < nk; ++i)
+            if (list[i].selector == ag->wl_selector[w]) {
+              wl_of[i].push_back(w);
+              if (ag->dep_ptr[w + 1] > ag->dep_ptr[w]) any_dep[i] = 1;
+              break;  // (a selector sits once in the list)
+            }
+        for (const GroupKey& me : list) {  // the key of the pod being bound
+          int32_t at = fill ? t_off[static_cast<size_t>(me.key)] : 0;
+          for (size_t i = 0; i < nk; ++i) {
+            if (!any_dep[i]) continue;
+            if (fill) t_key[static_cast<size_t>(at)] = list[i].key, t_cost[static_cast<size_t>(at)] = -1;
+            ++at;
+            for (const int32_t w : wl_of[i])
+              for (int32_t d = ag->dep_ptr[w]; d < ag->dep_ptr[w + 1]; ++d)
+                if (ag->dep_selector[d] == me.selector) {
+                  if (fill) t_key[static_cast<size_t>(at)] = list[i].key, t_cost[static_cast<size_t>(at)] = ag->dep_max_cost[d];
+                  ++at;
+                }
           }
+          if (!fill) t_off[static_cast<size_t>(me.key) + 1] = at;  // the key's count, turned into offsets below
         }
       }
-      for (const auto& e : t) out.eff_key.push_back(e.first), out.eff_cost.push_back(e.second);
+    }, 64);
+  };
+  walk_groups(false);
+  int64_t t_total = 0;
+  for (size_t k = 0; k < K; ++k) {  // counts (stored one slot up) -> exclusive offsets
+    const int64_t c = t_off[k + 1];
+    t_off[k] = static_cast<int32_t>(t_total);
+    t_total += c;
+    if (t_total > INT32_MAX) {
+      out.eff_key.assign(static_cast<size_t>(INT32_MAX) + 1, 0), out.eff_ptr.assign(P + 1, 0);  // (refused by the entry point)
+      return;
     }
-    out.eff_ptr.push_back(static_cast<int32_t>(out.eff_key.size()));
   }
+  t_off[K] = static_cast<int32_t>(t_total);
+  t_key.resize(static_cast<size_t>(t_total)), t_cost.resize(static_cast<size_t>(t_total));
+  walk_groups(true);
+  out.eff_ptr.resize(P + 1);
+  int64_t total = 0;
+  for (size_t p = 0; p < P; ++p) {
+    out.eff_ptr[p] = static_cast<int32_t>(total);
+    const int32_t g = pods->appgroup[p];
+    if (g >= 0 && g < ag->n_groups) total += t_off[static_cast<size_t>(key_of[p]) + 1] - t_off[static_cast<size_t>(key_of[p])];
+    if (total > INT32_MAX) {  // (the entry point refuses such a batch: the offsets are 32-bit)
+      out.eff_key.assign(static_cast<size_t>(INT32_MAX) + 1, 0);
+      out.eff_ptr.assign(P + 1, 0);
+      return;
+    }
+  }
+  out.eff_ptr[P] = static_cast<int32_t>(total);
+  out.eff_key.resize(static_cast<size_t>(total)), out.eff_cost.resize(static_cast<size_t>(total));
+  spx_host::parallel_rows(static_cast<int64_t>(P), [&](int64_t p0, int64_t p1) {
+    for (int64_t p = p0; p < p1; ++p) {
+      const int32_t g = pods->appgroup[p];
+      if (g < 0 || g >= ag->n_groups) continue;
+      const size_t k = static_cast<size_t>(key_of[static_cast<size_t>(p)]), n_e = static_cast<size_t>(t_off[k + 1] - t_off[k]);
+      if (n_e == 0) continue;
+      std::memcpy(&out.eff_key[static_cast<size_t>(out.eff_ptr[static_cast<size_t>(p)])], &t_key[static_cast<size_t>(t_off[k])], n_e * sizeof(int32_t));
+      std::memcpy(&out.eff_cost[static_cast<size_t>(out.eff_ptr[static_cast<size_t>(p)])], &t_cost[static_cast<size_t>(t_off[k])], n_e * sizeof(int64_t));
+    }
+  }, 4096);
 }
 }  // namespace
 
