@@ -49,14 +49,32 @@ def test_config2_every_cell(gpu_required, hdr, oracle):
         osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], metrics=snap["metrics"], assigned=snap["assigned"],
                                 alloc_params=e.alloc_params, tlp_params=tlp_params(hdr), lvrb_params=lvrb_params(hdr))
         _, alloc_row = osnap.score_rows(ALLOCATABLE, 0, 1, want_raw=False)
+        # the decisions without tables (spx_decide: the fused sweep, alone and with LVRB's table folded in) — held against the ORACLE's
+        # weighted argmax of every row below, not only against the engine's own eval + best (test_config2_full_cycle_every_row)
+        weights = {ALLOCATABLE: 3, TLP: 2, LVRB: 1}
+        e.set_plugin_weights(weights)
+        decided = {}
+        for name, plugins in (("alloc+tlp", (ALLOCATABLE, TLP)), ("alloc+tlp+lvrb", (ALLOCATABLE, TLP, LVRB))):
+            e.decide(mask_of(*plugins))
+            e.sync()
+            decided[name] = (plugins, e.best())
         bad = {ALLOCATABLE: 0, TLP: 0, LVRB: 0}
+        bad_decisions = {name: 0 for name in decided}
         for r0, r1 in blocks(n_pods, n_nodes):
+            want = {}
             for p in (TLP, LVRB):  # no NormalizeScore: raw == final
-                want = osnap.score_rows(p, r0, r1, threads=THREADS, want_norm=False)[0]
-                bad[p] += count_mismatches(e.all_scores(p, r0, r1), want)[0]
+                want[p] = osnap.score_rows(p, r0, r1, threads=THREADS, want_norm=False)[0]
+                bad[p] += count_mismatches(e.all_scores(p, r0, r1), want[p])[0]
             # Allocatable ignores the pod (allocatable.go:118-126): the oracle's row 0 is every row
             bad[ALLOCATABLE] += int((e.all_scores(ALLOCATABLE, r0, r1) != alloc_row[0].astype(np.uint8)[None, :]).sum())
+            want[ALLOCATABLE] = alloc_row[0][None, :]
+            for name, (plugins, (node, score, ties, _)) in decided.items():
+                total = sum(weights[p] * np.clip(want[p], 0, 255).astype(np.int64) for p in plugins)
+                best = total.max(axis=1)
+                at_best = total == best[:, None]
+                bad_decisions[name] += int(((score[r0:r1] != best) | (node[r0:r1] != at_best.argmax(axis=1)) | (ties[r0:r1] != at_best.sum(axis=1))).sum())
         assert bad == {ALLOCATABLE: 0, TLP: 0, LVRB: 0}
+        assert bad_decisions == {name: 0 for name in decided}, bad_decisions
         # the reference-arithmetic kernel on the same snapshot leaves the same tables (spot block) and counts nothing
         e.force_reference_kernels(TLP, LVRB)
         e.stats(reset=True)
