@@ -223,6 +223,12 @@ def test_config5_share_every_cell(gpu_required, hdr, oracle):
             bad["best"] += int((~ok).sum())
         assert not any(bad.values()), bad
         assert masked_rows_differ > 0  # the feasibility sets really differ from row to row
+        # spx_decide on the same profile (Allocatable's masked normalisation folded into the argmax kernel, no Allocatable table):
+        # every field of every row equal to the decisions just held against the oracle
+        e.decide(mask_of(*allp))
+        e.sync()
+        for name, got, want_col in zip(("node", "score", "ties", "feasible"), e.best(), (node, score, ties, feas)):
+            assert np.array_equal(got, want_col), name
 
 
 def _masked(osnap, plugin, r0, r1, feasible):
