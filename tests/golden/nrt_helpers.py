@@ -91,8 +91,10 @@ CONFIG_FROM_NRT = [
 ]
 # TestConfigFromAttributes (:256-428), applied on top of the defaults: invalid values are ignored, MaxNUMANodes is capped
 CONFIG_FROM_ATTRIBUTES = [
+    (268, {}, ("none", "container", 8)),  # (:263 is the same with a nil list)
     (273, {"topologyManagerScope": "pod"}, ("none", "pod", 8)),
     (285, {"topologyManagerPolicy": "restricted"}, ("restricted", "container", 8)),
+    (297, {"topologyManagerPolicy": "restricted", "topologyManagerScope": "container"}, ("restricted", "container", 8)),
     (314, {"topologyManagerScope": "pod", "topologyManagerPolicy": "single-numa-node"}, ("single-numa-node", "pod", 8)),
     (331, {"topologyManagerScope": "Pod", "topologyManagerPolicy": "single-numa-node"}, ("single-numa-node", "container", 8)),
     (347, {"topologyManagerScope": "Container", "topologyManagerPolicy": "restricted"}, ("restricted", "container", 8)),
@@ -105,6 +107,7 @@ CONFIG_FROM_ATTRIBUTES = [
 
 # TestConfigFromPolicies (:430-498), on top of the defaults: only the first entry counts, unknown names are ignored
 CONFIG_FROM_POLICIES = [
+    (442, [], ("none", "container", 8)),  # (:437 is the same with a nil list)
     (447, ["SingleNUMANodePodLevel"], ("single-numa-node", "pod", 8)),
     (455, ["SingleNUMANodeContainerLevel"], ("single-numa-node", "container", 8)),
     (463, ["RestrictedContainerLevel"], ("restricted", "container", 8)),

@@ -191,6 +191,64 @@ def check_network() -> int:
     return checked
 
 
+def check_nrt_helpers() -> int:
+    """nrt_helpers.py: RESOURCE_CLASSES (numaresources_test.go:29-115, both tables), ONLY_NON_NUMA (pluginhelpers_test.go:53-96),
+    CONFIG_FROM_ATTRIBUTES / CONFIG_FROM_POLICIES (nodeconfig/topologymanager_test.go:256-498: every case of the Go tables, by line;
+    the Go test compares the partial config the function returns, the hand-typed rows hold it applied on the defaults
+    (none, container, 8) — topologymanager.go:47-53)"""
+    import nrt_helpers as H
+    names = {"corev1.ResourceCPU": "cpu", "corev1.ResourceMemory": "memory", "corev1.ResourceStorage": "storage",
+             "corev1.ResourceEphemeralStorage": "ephemeral-storage"}
+    rname = lambda v: names[v.name] if isinstance(v, Ident) else (v.args[0] if isinstance(v, Call) else names.get(v, v))
+    checked = 0
+    src = (REF / "pkg/noderesourcetopology/numaresources_test.go").read_text()
+    got = {}
+    for col, fn in enumerate(("TestIsHostLevelResource", "TestIsNUMAAffineResource")):
+        for t in parse_literal_after(src[src.index("func " + fn):], "testCases := "):
+            got.setdefault(rname(t["resource"]), [None, None])[col] = _num(t["expected"])
+            checked += 1
+    assert {k: tuple(v) for k, v in got.items()} == H.RESOURCE_CLASSES, got
+    src = (REF / "pkg/noderesourcetopology/pluginhelpers_test.go").read_text()
+    p = src.index("func TestOnlyNonNUMAResources")
+    go = parse_literal_after(src[p:], "testCases := ")
+    assert len(go) == len(H.ONLY_NON_NUMA)
+    for t, (line, resources, expected) in zip(go, H.ONLY_NON_NUMA):
+        want = {rname(k): v.args[0] for k, v in t["resources"].items()}
+        assert want == resources and _num(t["expected"]) == expected and abs(line_of(src, '"' + t["description"] + '"', p) - line) <= 2, (t, line)
+        checked += 1
+    src = (REF / "pkg/noderesourcetopology/nodeconfig/topologymanager_test.go").read_text()
+    policy = {"kubeletconfig.RestrictedTopologyManagerPolicy": "restricted", "kubeletconfig.SingleNumaNodeTopologyManagerPolicy": "single-numa-node",
+              "kubeletconfig.BestEffortTopologyManagerPolicy": "best-effort", "kubeletconfig.NoneTopologyManagerPolicy": "none"}
+    scope = {"kubeletconfig.PodTopologyManagerScope": "pod", "kubeletconfig.ContainerTopologyManagerScope": "container"}
+
+    def applied(exp):
+        exp = exp or {}
+        mx = exp.get("MaxNUMANodes", 8)
+        return (policy[exp["Policy"].name] if "Policy" in exp else "none", scope[exp["Scope"].name] if "Scope" in exp else "container",
+                1024 if isinstance(mx, Ident) else mx)
+
+    for fn, key, table in (("TestConfigFromAttributes", "attrs", H.CONFIG_FROM_ATTRIBUTES), ("TestConfigFromPolicies", "policies", H.CONFIG_FROM_POLICIES)):
+        p = src.index("func " + fn)
+        by_line = {row[0]: row for row in table}
+        seen = 0
+        for t in parse_literal_after(src[p:], "tests := "):
+            line = line_of(src, '"' + t["name"] + '"', p)
+            arg = t[key]
+            if isinstance(arg, Ident):  # nil: the same case as the empty list that follows it
+                assert arg.name == "nil" and applied(t["expected"]) == ("none", "container", 8)
+                continue
+            if key == "attrs":
+                arg = {a["Name"]: a["Value"] for a in arg}
+            else:
+                arg = [a.args[0].name.split(".")[-1] if isinstance(a, Call) else a for a in arg]
+            row = by_line[line]
+            assert row[1] == arg and tuple(row[2]) == applied(t["expected"]), (fn, line, row, arg, applied(t["expected"]))
+            seen += 1
+        assert seen == len(table), (fn, seen, len(table))
+        checked += seen
+    return checked
+
+
 def check_peaks() -> int:
     """peaks.py: the power model fixture (peaks_test.go:80-86) and NORMALIZE_CASES (TestPeaksNormalizeScore :426-531: the score lists
     before and after, by their line)"""
@@ -216,4 +274,5 @@ if __name__ == "__main__":
     print("lroc.py:", check_lroc(), "rows of the three beta tables agree with beta_test.go")
     print("lroc.py:", check_lroc_compute_risk(), "computeRisk fixtures and cases agree with lowriskovercommitment_test.go")
     print("network.py:", check_network(), "Score / Filter cases agree with networkoverhead_test.go")
+    print("nrt_helpers.py:", check_nrt_helpers(), "rows (resource classes, onlyNonNUMAResources, ConfigFromAttributes / ConfigFromPolicies) agree with the Go tables")
     print("peaks.py:", check_peaks(), "fixtures agree with peaks_test.go")
