@@ -107,6 +107,60 @@ def check_trimaran() -> int:
     return checked
 
 
+def check_trimaran_score_cases() -> int:
+    """trimaran.py: TLP_CASES (targetloadpacking_test.go:148-238, TestTargetLoadPackingScoring) and LVRB_CASES
+    (loadvariationriskbalancing_test.go:152-328, TestScore): per case its name and line, the pod (the empty pod or
+    getPodWithContainersAndOverhead's arguments), the watcher response's metrics (nil response = the 404 case) and the expected
+    score; the node's sizes; DefaultTargetUtilizationPercent from apis/config/v1/defaults.go"""
+    import re
+    import trimaran as T
+    target = int(re.search(r"DefaultTargetUtilizationPercent int64 = (\d+)", (REF / "apis/config/v1/defaults.go").read_text()).group(1))
+    assert target == T.TLP_PARAMS["target_utilization"]
+    consts = {"cfgv1.DefaultTargetUtilizationPercent": target, "fwk.MinNodeScore": 0, "fwk.MaxNodeScore": 100, "mega": 1024 * 1024}
+    typ = {"watcher.CPU": "CPU", "watcher.Memory": "Memory"}
+    op = {"watcher.Latest": "Latest", "watcher.Average": "AVG", "watcher.Std": "STD"}
+
+    def val(v):
+        if isinstance(v, Call) and v.fn == "float64":
+            return val(v.args[0])
+        return eval_const(v, consts)
+
+    def metrics_of(resp):
+        if not resp:  # a zero-value WatcherMetrics: the fake watcher answers 404
+            return None
+        return {0: [(typ[m["Type"].name], op[m["Operator"].name], val(m["Value"])) for m in resp["Data"]["NodeMetricsMap"]["node-1"]["Metrics"]]}
+
+    checked = 0
+    src = (REF / "pkg/trimaran/targetloadpacking/targetloadpacking_test.go").read_text()
+    p = src.index("func TestTargetLoadPackingScoring")
+    sizes = parse_literal_after(src[p:], "nodeResources := ")
+    assert {"cpu": sizes["v1.ResourceCPU"], "memory": sizes["v1.ResourceMemory"]} == T.NODE, sizes
+    go = parse_literal_after(src[p:], "tests := ")
+    assert len(go) == len(T.TLP_CASES)
+    for t, c in zip(go, T.TLP_CASES):
+        pod = t["pod"]
+        want_pod = T._pod_overhead(*[eval_const(a, consts) for a in pod.args]) if pod.fn == "getPodWithContainersAndOverhead" else {"containers": []}
+        assert (t["test"], want_pod, metrics_of(t["watcherResponse"]), [val(e["Score"]) for e in t["expected"]]) == (c["name"], c["pod"], c["metrics"], c["expected"]), t["test"]
+        assert 0 <= c["line"] - line_of(src, '"' + t["test"] + '"', p) <= 12, (t["test"], c["line"])  # (the cited line lies inside the case)
+        checked += 1
+    src = (REF / "pkg/trimaran/loadvariationriskbalancing/loadvariationriskbalancing_test.go").read_text()
+    p = src.index("func TestScore")
+    go = parse_literal_after(src[p:], "tests := ")
+    assert len(go) == len(T.LVRB_CASES)
+    for t, c in zip(go, T.LVRB_CASES):
+        pod = t["pod"]
+        if pod.fn == "getPodWithContainersAndOverhead":  # (overhead, initCpu, initMem, []cpu, []mem)
+            a = pod.args
+            assert [eval_const(x, consts) for x in a[:3]] == [0, 0, 0]
+            want_pod = T._lv_pod([eval_const(x, consts) for x in a[3]], [eval_const(x, consts) for x in a[4]])
+        else:
+            want_pod = {"containers": []}
+        assert (t["test"], want_pod, metrics_of(t["watcherResponse"]), [val(e["Score"]) for e in t["expected"]]) == (c["name"], c["pod"], c["metrics"], c["expected"]), t["test"]
+        assert 0 <= c["line"] - line_of(src, '"' + t["test"] + '"', p) <= 12, (t["test"], c["line"])
+        checked += 1
+    return checked
+
+
 def check_lroc() -> int:
     """lroc.py: MATCH_MOMENTS, DISTRIBUTION_FUNCTION, MAX_VARIANCE against beta_test.go:111-171, :236-327, :329-374"""
     import lroc as L
@@ -271,6 +325,7 @@ def check_peaks() -> int:
 if __name__ == "__main__":
     print("allocatable.py:", check_allocatable(), "cases agree with allocatable_test.go")
     print("trimaran.py:", check_trimaran(), "rows of COMPUTE_SCORE / MU_SIGMA agree with analysis_test.go / resourcestats_test.go")
+    print("trimaran.py:", check_trimaran_score_cases(), "TLP / LVRB Score cases agree with targetloadpacking_test.go / loadvariationriskbalancing_test.go")
     print("lroc.py:", check_lroc(), "rows of the three beta tables agree with beta_test.go")
     print("lroc.py:", check_lroc_compute_risk(), "computeRisk fixtures and cases agree with lowriskovercommitment_test.go")
     print("network.py:", check_network(), "Score / Filter cases agree with networkoverhead_test.go")

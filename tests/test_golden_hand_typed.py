@@ -22,6 +22,7 @@ def test_trimaran_lroc_peaks_tables_agree_with_the_go_sources():
     sys.path.insert(0, str(Path(__file__).parent / "golden"))
     import verify_hand_typed
     assert verify_hand_typed.check_trimaran() == 17
+    assert verify_hand_typed.check_trimaran_score_cases() == 10
     assert verify_hand_typed.check_lroc() == 10
     assert verify_hand_typed.check_lroc_compute_risk() == 7
     assert verify_hand_typed.check_network() == 11
