@@ -303,6 +303,57 @@ def check_nrt_helpers() -> int:
     return checked
 
 
+def check_nrt_helpers_pods() -> int:
+    """nrt_helpers.py: EFFECTIVE_REQUEST (pkg/util/resource_test.go:34-149, 8 cases: container, init-container and overhead
+    requests as makeResourceList(cpu, mem) arguments, the expected sum), INCLUDE_NON_NATIVE (resourcerequests/exclusive_test.go
+    coreTestCases :174-437, 10 cases: each container list's requests, sidecars = init containers with RestartPolicy Always,
+    expectedNonNative) and MIN_DISTANCE (least_numa_test.go:758-920: the cost maps, subset size = the combinations' length, expected)"""
+    import nrt_helpers as H
+    checked = 0
+    src = (REF / "pkg/util/resource_test.go").read_text()
+    p = src.index("func TestGetPodEffectiveRequest")
+    pair = lambda c: tuple(c.args) if isinstance(c, Call) else None
+    go = parse_literal_after(src[p:], "tests := ")
+    assert len(go) == len(H.EFFECTIVE_REQUEST)
+    for t, (line, app, init, overhead, want) in zip(go, H.EFFECTIVE_REQUEST):
+        lst = lambda v: [] if isinstance(v, Ident) or v is None else [pair(c) for c in v]
+        got = (lst(t.get("containerRequest")), lst(t.get("initContainerRequest")), pair(t.get("podOverheadRequest")), pair(t["want"]))
+        assert got == (app, init, overhead, want) and abs(line_of(src, '"' + t["name"] + '"', p) - line) <= 2, (t["name"], got, line)
+        checked += 1
+    src = (REF / "pkg/noderesourcetopology/resourcerequests/exclusive_test.go").read_text()
+    p = src.index("func coreTestCases")
+    names = {"corev1.ResourceCPU": "cpu", "corev1.ResourceMemory": "memory"}
+
+    def requests(c):
+        rl = c["Resources"].get("Requests") or {}
+        lim = c["Resources"].get("Limits") or {}
+        out = {names.get(k, k): v.args[0] for k, v in rl.items()}
+        assert {names.get(k, k): v.args[0] for k, v in lim.items()} in (out, {}) or not out, c  # limits equal the requests in every case
+        return out or {names.get(k, k): v.args[0] for k, v in lim.items()}
+
+    go = parse_literal_after(src[p:], "return ")
+    assert len(go) == len(H.INCLUDE_NON_NATIVE)
+    for t, (line, name, app, init, sidecar, want) in zip(go, H.INCLUDE_NON_NATIVE):
+        spec = (t["pod"].get("Spec") or {}) if isinstance(t["pod"], dict) else {}
+        inits = spec.get("InitContainers") or []
+        is_sidecar = lambda c: "RestartPolicy" in c
+        got = ([requests(c) for c in spec.get("Containers") or []], [requests(c) for c in inits if not is_sidecar(c)],
+               [requests(c) for c in inits if is_sidecar(c)], _num(t["expectedNonNative"]))
+        assert t["name"] == name and got == (app, init, sidecar, want) and abs(line_of(src, '"' + name + '"', p) - line) <= 2, (name, got)
+        checked += 1
+    src = (REF / "pkg/noderesourcetopology/least_numa_test.go").read_text()
+    p = src.index("func TestMinDistance")
+    costs = {z["NUMAID"]: dict(z["Costs"]) for z in parse_literal_after(src[p:], "numaNodes := ")}
+    assert costs == H.MIN_DISTANCE_COSTS, costs
+    go = parse_literal_after(src[p:], "tcases := ")
+    assert len(go) == len(H.MIN_DISTANCE)
+    for t, (line, with_costs, size, want) in zip(go, H.MIN_DISTANCE):
+        assert {len(c) for c in t["combinations"]} == {size} and (t["numaNodes"].name == "numaNodes") == with_costs and float(t["expected"]) == want, t
+        assert abs(line_of(src, '"' + t["description"] + '"', p) - line) <= 2, (t["description"], line)
+        checked += 1
+    return checked
+
+
 def check_peaks() -> int:
     """peaks.py: the power model fixture (peaks_test.go:80-86) and NORMALIZE_CASES (TestPeaksNormalizeScore :426-531: the score lists
     before and after, by their line)"""
@@ -330,4 +381,5 @@ if __name__ == "__main__":
     print("lroc.py:", check_lroc_compute_risk(), "computeRisk fixtures and cases agree with lowriskovercommitment_test.go")
     print("network.py:", check_network(), "Score / Filter cases agree with networkoverhead_test.go")
     print("nrt_helpers.py:", check_nrt_helpers(), "rows (resource classes, onlyNonNUMAResources, ConfigFromAttributes / ConfigFromPolicies) agree with the Go tables")
+    print("nrt_helpers.py:", check_nrt_helpers_pods(), "rows (GetPodEffectiveRequest, IncludeNonNative, minAvgDistanceInCombinations) agree with the Go tables")
     print("peaks.py:", check_peaks(), "fixtures agree with peaks_test.go")
