@@ -370,7 +370,36 @@ def check_peaks() -> int:
         at = line_of(src, '"' + t["test"] + '"', p)
         assert abs(at - line) <= 3, (t["test"], at, line)  # (the hand-typed table cites a line inside the case)
         assert lists[t["nodeScoreList"].name] == before and [score[e["Score"].name] for e in t["expected"]] == after, t["test"]
-    return 1 + len(go)
+    checked = 1 + len(go)
+    # TestPeaksScore (:165-423): per case the pod (by the name of its fixture), the watcher response's metrics and the expected score
+    # (scoreToUse = int64(jump(0, 100) * 1e15) is computed in the test; the hand-typed table marks it inexact)
+    p = src.index("func TestPeaksScore")
+    typ = {"watcher.CPU": "CPU", "watcher.Memory": "Memory"}
+    pods = {"testPod3": P._POD3, "testPod4": P._POD4}
+    go = parse_literal_after(src[p:], "tests := ")
+    assert len(go) == len(P.SCORE_CASES)
+    for t, c in zip(go, P.SCORE_CASES):
+        pod = t["pod"]
+        if isinstance(pod, Ident):
+            want_pod = pods[pod.name]
+        elif pod.args[0].fn == ".Container":  # testutil2.MakePod("ns", "p").Container(MakeResourceList().CPU(1).Mem(2).Obj())
+            rl = pod.args[0].args[1].args[0]
+            assert rl.fn == ".Mem" and rl.args[0].fn == ".CPU" and (rl.args[0].args[1], rl.args[1]) == (1, 2)
+            want_pod = P._REQ
+        else:
+            want_pod = {"containers": []}
+        resp = t["watcherResponse"]
+        if not resp:
+            metrics = None
+        else:
+            m = resp["Data"]["NodeMetricsMap"]
+            metrics = {0: [(typ[x["Type"].name], "Latest", x["Value"]) for x in m["node-1"]["Metrics"]]} if m else {}
+        score = t["expected"][0]["Score"]
+        want_score = P.SCORE_TO_USE if score.name == "scoreToUse" else {"fwk.MinNodeScore": 0}[score.name]
+        assert (t["test"], want_pod, metrics, want_score) == (c["name"], c["pod"], c["metrics"], c["expected"]) and c["exact"] == (score.name != "scoreToUse"), t["test"]
+        assert -2 <= c["line"] - line_of(src, '"' + t["test"] + '"', p) <= 12, (t["test"], c["line"])
+        checked += 1
+    return checked
 
 
 if __name__ == "__main__":
