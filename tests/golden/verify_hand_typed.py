@@ -354,6 +354,45 @@ def check_nrt_helpers_pods() -> int:
     return checked
 
 
+def check_nrt_helpers_numa_lists() -> int:
+    """nrt_helpers.py: SUBTRACT_NUMA (numaresources_test.go:117-373, TestSubtractResourcesFromNUMANodeList, 9 cases: the NUMA node list,
+    numaID, QoS, the container's resources, the expected list or an error) and SUBTRACT_NUMAS (:375-462, TestSubstractNUMA, 2 cases)"""
+    import nrt_helpers as H
+    names = {"corev1.ResourceCPU": "cpu", "corev1.ResourceMemory": "memory", "corev1.ResourceEphemeralStorage": "ephemeral-storage", "corev1.ResourceStorage": "storage"}
+    qos = {"corev1.PodQOSGuaranteed": "Guaranteed", "corev1.PodQOSBurstable": "Burstable", "corev1.PodQOSBestEffort": "BestEffort"}
+
+    def qty(v):  # mustParseQuantity(t, "8") / resource.MustParse("10Gi") / resource.NewQuantity(8, DecimalSI)
+        a = v.args[-1] if v.fn == "mustParseQuantity" else v.args[0]
+        return str(a)
+
+    def rl(d):
+        return {names.get(k, k.args[0] if isinstance(k, Call) else k): qty(v) for k, v in (d or {}).items()}
+
+    def zones(lst):
+        return [(z.get("NUMAID", 0), rl(z.get("Resources"))) for z in lst]
+
+    src = (REF / "pkg/noderesourcetopology/numaresources_test.go").read_text()
+    checked = 0
+    p = src.index("func TestSubtractResourcesFromNUMANodeList")
+    go = parse_literal_after(src[p:], "testCases := ")
+    assert len(go) == len(H.SUBTRACT_NUMA)
+    for t, c in zip(go, H.SUBTRACT_NUMA):
+        expected = None if "expectedError" in t else zones(t["expected"])
+        got = (t["name"], zones(t["nodes"]), t.get("numaID", 0), qos[t["qos"].name], rl(t.get("containerRes")), expected)
+        assert got == (c["name"], c["zones"], c["numa_id"], c["qos"], c["request"], c["expected"]), (got, c)
+        assert abs(line_of(src, '"' + t["name"] + '"', p) - c["line"]) <= 2, (t["name"], c["line"])
+        checked += 1
+    p = src.index("func TestSubstractNUMA")
+    go = parse_literal_after(src[p:], "tcases := ")
+    assert len(go) == len(H.SUBTRACT_NUMAS)
+    for t, c in zip(go, H.SUBTRACT_NUMAS):
+        got = (t["description"], zones(t["numaNodes"]), rl(t["resources"]), list(t["nodes"]), zones(t["expected"]))
+        assert got == (c["name"], c["zones"], c["request"], c["nodes"], c["expected"]), (got, c)
+        assert abs(line_of(src, '"' + t["description"] + '"', p) - c["line"]) <= 2
+        checked += 1
+    return checked
+
+
 def check_peaks() -> int:
     """peaks.py: the power model fixture (peaks_test.go:80-86) and NORMALIZE_CASES (TestPeaksNormalizeScore :426-531: the score lists
     before and after, by their line)"""
@@ -411,4 +450,5 @@ if __name__ == "__main__":
     print("network.py:", check_network(), "Score / Filter cases agree with networkoverhead_test.go")
     print("nrt_helpers.py:", check_nrt_helpers(), "rows (resource classes, onlyNonNUMAResources, ConfigFromAttributes / ConfigFromPolicies) agree with the Go tables")
     print("nrt_helpers.py:", check_nrt_helpers_pods(), "rows (GetPodEffectiveRequest, IncludeNonNative, minAvgDistanceInCombinations) agree with the Go tables")
+    print("nrt_helpers.py:", check_nrt_helpers_numa_lists(), "subtract cases agree with numaresources_test.go")
     print("peaks.py:", check_peaks(), "fixtures agree with peaks_test.go")

@@ -28,4 +28,5 @@ def test_trimaran_lroc_peaks_tables_agree_with_the_go_sources():
     assert verify_hand_typed.check_network() == 11
     assert verify_hand_typed.check_nrt_helpers() == 38
     assert verify_hand_typed.check_nrt_helpers_pods() == 22
+    assert verify_hand_typed.check_nrt_helpers_numa_lists() == 11
     assert verify_hand_typed.check_peaks() == 10
