@@ -88,12 +88,14 @@ __device__ __forceinline__ void tlp_cell32(const float4& rk, float pod_f, float 
 // rounding and its margin are packed across the two cells.  (The builtins do not produce the clamp modifier or the operand
 // selectors on packed float32: those two instructions are written out.)
 typedef float F32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void tlp_cell_pair32(const float4& ra, const float4& rb, float pod_f, const F32x2& off2, float (&u)[2], float (&d)[2],
-                                                uint32_t (&tb)[2]) {
-  const F32x2 u2 = (F32x2{pod_f, pod_f} + F32x2{ra.x, rb.x}) + F32x2{ra.y, rb.y};
+__device__ __forceinline__ void tlp_cell_pair32(const F32x2& bh, const F32x2& bl, const F32x2& ca, const F32x2& cb, float pod_f, const F32x2& off2,
+                                                float (&u)[2], float (&d)[2], uint32_t (&tb)[2]) {
+  const F32x2 u2 = (F32x2{pod_f, pod_f} + bh) + bl;
   F32x2 xa, xb;  // (value on the u > 0 branch, on the u <= 0 branch), clamped to [0, 1]
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] clamp" : "=v"(xa) : "v"(F32x2{ra.z, ra.w}), "v"(u2), "v"(off2));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] clamp" : "=v"(xb) : "v"(F32x2{rb.z, rb.w}), "v"(u2), "v"(off2));
+  asm("v_pk_fma_f32 %0, %2, %4, %5 op_sel_hi:[1,0,1] clamp\n\t"  // (one statement: the compiler pads every asm statement with an s_nop)
+      "v_pk_fma_f32 %1, %3, %4, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1] clamp"
+      : "=&v"(xa), "=&v"(xb)
+      : "v"(ca), "v"(cb), "v"(u2), "v"(off2));
   const F32x2 xs{__float_as_int(u2.x) < 0 ? xa.y : xa.x, __float_as_int(u2.y) < 0 ? xb.y : xb.x};  // sign bit set: u < 0 or -0.0
   const F32x2 y = __builtin_elementwise_fma(xs, F32x2{256.0f, 256.0f}, F32x2{kMagic, kMagic});
   const F32x2 rr = y - F32x2{kMagic, kMagic};
@@ -133,7 +135,10 @@ __global__ __launch_bounds__(T) void k_commit_trimaran_reg(CommitArgs c) {
   const uint32_t wt14 = Tl ? static_cast<uint32_t>(c.w_tlp) << 14 : 0u;
   const uint32_t wl14 = kHasL ? static_cast<uint32_t>(c.w_lvrb) << 14 : 0u;
 
-  float4 r_k[K];        // (b2h, b2l, coefficient for u > 0, coefficient for u <= 0 — both scaled by 1/256); NaN b2h = the cell always takes the exact path
+  // per cell (b2h, b2l, coefficient for u > 0, coefficient for u <= 0 — both scaled by 1/256); NaN b2h = the cell always takes the exact
+  // path.  Held the way the packed pass reads them — b2h and b2l of a group's two cells side by side, a cell's two coefficients side by
+  // side — so that no move stands between the registers and the v_pk instructions (a float4 per cell cost 12 v_mov per pass)
+  F32x2 b_hi[K / kGroup], b_lo[K / kGroup], coef[K];
   uint32_t base[K];     // (w_alloc * Allocatable's normalised score) << 14 | 16383 - node; 0 for a cell past the node list
   // millicores committed to the node by this loop and not yet added to c.missing[] (exact-path input): one LDS word per cell —
   // touched by the owner at a commit and by the exact path only, so it need not cost the pass K registers
@@ -144,11 +149,13 @@ __global__ __launch_bounds__(T) void k_commit_trimaran_reg(CommitArgs c) {
   for (int k = 0; k < K; ++k) {
     const int n = node_of(k);
     const bool in = n < a.n_nodes;
-    r_k[k] = (in && Tl) ? tlp_fast_consts(static_cast<double>(a.cap_cpu_milli[n]), a.tlp_cpu_util[n], static_cast<double>(c.missing[n]), a.tlp_valid[n] != 0, t, c1, c2)
+    float4 rk = (in && Tl) ? tlp_fast_consts(static_cast<double>(a.cap_cpu_milli[n]), a.tlp_cpu_util[n], static_cast<double>(c.missing[n]), a.tlp_valid[n] != 0, t, c1, c2)
                         : float4{1e30f, 0.0f, -1.0f, 0.0f};
-    if (in && Tl && !fast_ok) r_k[k].x = __builtin_nanf("");
-    r_k[k].z *= 1.0f / 256.0f, r_k[k].w *= 1.0f / 256.0f;
-    lane_nan |= r_k[k].x != r_k[k].x;
+    if (in && Tl && !fast_ok) rk.x = __builtin_nanf("");
+    lane_nan |= rk.x != rk.x;
+    if (k & 1) b_hi[k >> 1].y = rk.x, b_lo[k >> 1].y = rk.y;
+    else b_hi[k >> 1].x = rk.x, b_lo[k >> 1].x = rk.y;
+    coef[k] = F32x2{rk.z * (1.0f / 256.0f), rk.w * (1.0f / 256.0f)};
     base[k] = in ? (((A ? static_cast<uint32_t>(c.w_alloc) * a.alloc_norm[n] : 0u) << 14) | (16383u - static_cast<uint32_t>(n))) : 0u;
     s_delta[k][tid] = 0;
     if ((k & 1) == 0) gmask[k >> 1] = (in ? 0xffu : 0u) | (n + 1 < a.n_nodes ? 0xff00u : 0u);
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(T) void k_commit_trimaran_reg(CommitArgs c) {
       for (int g = 0; g < K / kGroup; ++g) {
         float u[2], d[2];
         uint32_t tb[2];
-        tlp_cell_pair32(r_k[2 * g], r_k[2 * g + 1], pod_f, off2, u, d, tb);
+        tlp_cell_pair32(b_hi[g], b_lo[g], coef[2 * g], coef[2 * g + 1], pod_f, off2, u, d, tb);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int k = 2 * g + j;
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(T) void k_commit_trimaran_reg(CommitArgs c) {
         for (int k = 0; k < K; ++k) {
           float u, d;
           uint32_t tb;
-          tlp_cell32(r_k[k], pf, tfs, u, d, tb);
+          tlp_cell32(float4{(k & 1) ? b_hi[k >> 1].y : b_hi[k >> 1].x, (k & 1) ? b_lo[k >> 1].y : b_lo[k >> 1].x, coef[k].x, coef[k].y}, pf, tfs, u, d, tb);
           const bool unknown = pod_bad || !(__builtin_fabsf(u) > kTolU);  // (NaN constant: u is NaN)
           const bool tied = !(d < kHalf);
           uint32_t key = base[k] != 0u ? __umul24(tb, wt14) + base[k] + lv_part(k) : 0u;
@@ -317,9 +324,11 @@ __global__ __launch_bounds__(T) void k_commit_trimaran_reg(CommitArgs c) {
 #pragma unroll
           for (int k = 0; k < K; ++k)
             if (k == kk) {
-              const float nb = r_k[k].x + pod_f;
+              const float bx = (k & 1) ? b_hi[k >> 1].y : b_hi[k >> 1].x;  // (vector elements are not addressable: read, then written back below)
+              const float nb = bx + pod_f;
               const float nv = (pod_bad || !(__builtin_fabsf(nb) < 8388607.0f)) ? __builtin_nanf("") : nb;
-              r_k[k].x = me ? nv : r_k[k].x;
+              if (k & 1) b_hi[k >> 1].y = me ? nv : bx;
+              else b_hi[k >> 1].x = me ? nv : bx;
               lane_nan |= me && nv != nv;
             }
           if (me) {
