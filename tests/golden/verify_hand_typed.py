@@ -247,7 +247,7 @@ def check_network() -> int:
 
 def check_nrt_helpers() -> int:
     """nrt_helpers.py: RESOURCE_CLASSES (numaresources_test.go:29-115, both tables), ONLY_NON_NUMA (pluginhelpers_test.go:53-96),
-    CONFIG_FROM_ATTRIBUTES / CONFIG_FROM_POLICIES (nodeconfig/topologymanager_test.go:256-498: every case of the Go tables, by line;
+    CONFIG_FROM_ATTRIBUTES / CONFIG_FROM_POLICIES / CONFIG_FROM_NRT (nodeconfig/topologymanager_test.go:256-607: every case of the Go tables, by line;
     the Go test compares the partial config the function returns, the hand-typed rows hold it applied on the defaults
     (none, container, 8) — topologymanager.go:47-53)"""
     import nrt_helpers as H
@@ -300,6 +300,18 @@ def check_nrt_helpers() -> int:
             seen += 1
         assert seen == len(table), (fn, seen, len(table))
         checked += seen
+    # TestConfigFromNRT (:500-607): TopologyPolicies + Attributes of one NRT object -> the complete config (defaults: TopologyManagerDefaults)
+    p = src.index("func TestConfigFromNRT")
+    go = parse_literal_after(src[p:], "tests := ")
+    assert len(go) == len(H.CONFIG_FROM_NRT)
+    for t, (line, policies, attrs, want) in zip(go, H.CONFIG_FROM_NRT):
+        nrt = t["nrt"] or {}
+        got_pol = [a.args[0].name.split(".")[-1] for a in nrt.get("TopologyPolicies", [])]
+        got_attr = {a["Name"]: a["Value"] for a in nrt.get("Attributes", [])}
+        exp = t["expected"]
+        exp_t = ("none", "container", 8) if isinstance(exp, Call) else (policy[exp["Policy"].name], scope[exp["Scope"].name], 8 if exp["MaxNUMANodes"].name == "DefaultMaxNUMANodes" else None)
+        assert (got_pol, got_attr, exp_t) == (policies, attrs, tuple(want)) and line_of(src, '"' + t["name"] + '"', p) == line, (t["name"], got_pol, got_attr, exp_t)
+        checked += 1
     return checked
 
 
@@ -448,7 +460,7 @@ if __name__ == "__main__":
     print("lroc.py:", check_lroc(), "rows of the three beta tables agree with beta_test.go")
     print("lroc.py:", check_lroc_compute_risk(), "computeRisk fixtures and cases agree with lowriskovercommitment_test.go")
     print("network.py:", check_network(), "Score / Filter cases agree with networkoverhead_test.go")
-    print("nrt_helpers.py:", check_nrt_helpers(), "rows (resource classes, onlyNonNUMAResources, ConfigFromAttributes / ConfigFromPolicies) agree with the Go tables")
+    print("nrt_helpers.py:", check_nrt_helpers(), "rows (resource classes, onlyNonNUMAResources, ConfigFromAttributes / ConfigFromPolicies / ConfigFromNRT) agree with the Go tables")
     print("nrt_helpers.py:", check_nrt_helpers_pods(), "rows (GetPodEffectiveRequest, IncludeNonNative, minAvgDistanceInCombinations) agree with the Go tables")
     print("nrt_helpers.py:", check_nrt_helpers_numa_lists(), "subtract cases agree with numaresources_test.go")
     print("peaks.py:", check_peaks(), "fixtures agree with peaks_test.go")

@@ -26,7 +26,7 @@ def test_trimaran_lroc_peaks_tables_agree_with_the_go_sources():
     assert verify_hand_typed.check_lroc() == 10
     assert verify_hand_typed.check_lroc_compute_risk() == 7
     assert verify_hand_typed.check_network() == 11
-    assert verify_hand_typed.check_nrt_helpers() == 38
+    assert verify_hand_typed.check_nrt_helpers() == 44
     assert verify_hand_typed.check_nrt_helpers_pods() == 22
     assert verify_hand_typed.check_nrt_helpers_numa_lists() == 11
     assert verify_hand_typed.check_peaks() == 10
