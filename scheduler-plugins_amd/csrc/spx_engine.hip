@@ -1196,6 +1196,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
   if (!e->nrt_slots || t->n_res != e->nrt_n_res) return fail(e, SPX_ERR_STATE, "NRT: upload the slot table first (n_res mismatch)");
   int rc = set_nodes(e, t->n_nodes);
   if (rc) return rc;
+  e->nrt_nodes = false;  // (a call that fails half-way leaves "no NRT node table", not a mix of two)
   const int64_t n = t->n_nodes;
   constexpr int64_t Zm = SPX_NRT_MAX_ZONES;
   const int64_t R = t->n_res;
@@ -1288,8 +1289,6 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
       for (int k = 0; k < cnt; ++k) perm[static_cast<size_t>(w0 + k)] = static_cast<int32_t>(w0 + order[k]);
     }
     }, 16);
-    e->h_nrt_cost.assign(t->zone_cost, t->zone_cost + m * Zm * Zm);
-    e->h_nrt_nz.assign(t->n_zones, t->n_zones + m);
     std::vector<int32_t> all(m);
     for (size_t i = 0; i < m; ++i) all[i] = static_cast<int32_t>(i);
     DeltaBlob b{e};
@@ -1300,6 +1299,8 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
     const size_t o_min = b.add(t->min_avg_dist, m * Zm * 4);
     if ((rc = ensure(e, e->d_nrt_perm, perm.size() * sizeof(int32_t)))) return rc;
     if ((rc = b.ship())) return rc;
+    e->h_nrt_cost.assign(t->zone_cost, t->zone_cost + m * Zm * Zm);  // (the host copies follow the shipped rows)
+    e->h_nrt_nz.assign(t->n_zones, t->n_zones + m);
     const int32_t* d_idx = reinterpret_cast<const int32_t*>(b.dev(o_idx));
     hipStream_t st = e->stream;
     SPX_HIP(e, hipMemcpyAsync(e->d_nrt_perm.p, b.dev(o_perm), perm.size() * sizeof(int32_t), hipMemcpyDeviceToDevice, st));

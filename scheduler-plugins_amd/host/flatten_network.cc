@@ -105,6 +105,7 @@ namespace {
 // copies it out instead of repeating the pass.
 struct NetKeys {
   uint64_t fp = 0;  // net_fingerprint of the tables the vectors were built from; 0 = nothing cached
+  bool overflow = false;  // more pairs than the 32-bit offsets hold: the entry point refuses the batch
   std::vector<int32_t> pod_key, topo_order, pair_ptr, pair_node;
   std::vector<int64_t> pair_max_cost;
   std::vector<uint8_t> key_score_equally;
@@ -114,6 +115,7 @@ thread_local NetKeys tl_net_keys;
 void build_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag, NetKeys& k) {
   const size_t P = static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 0);
   k.fp = 0;  // set by the caller once the build is complete
+  k.overflow = false;
   k.pod_key.assign(P, 0), k.topo_order.assign(P, -1);
   k.pair_ptr.clear(), k.pair_node.clear(), k.pair_max_cost.clear(), k.key_score_equally.clear();
   // (AppGroup, workload selector) -> key id, in order of first appearance.  A group has a handful of workloads: its keys sit in
@@ -186,8 +188,8 @@ void build_net_keys(const spx_pod_objects* pods, const spx_appgroup_objects* ag,
     const int64_t c = k.pair_ptr[ki + 1];
     k.pair_ptr[ki] = static_cast<int32_t>(total);
     total += c;
-    if (total > INT32_MAX) {  // (refused by the entry point: 32-bit offsets)
-      k.pair_node.assign(static_cast<size_t>(INT32_MAX) + 1, 0);
+    if (total > INT32_MAX) {
+      k.overflow = true;
       return;
     }
   }
@@ -212,7 +214,7 @@ extern "C" int spx_flatten_net_keys(const spx_pod_objects* pods, const spx_appgr
   }
   *n_keys_out = static_cast<int32_t>(k.key_score_equally.size());
   *n_pairs_out = static_cast<int64_t>(k.pair_node.size());
-  if (k.pair_node.size() > static_cast<size_t>(INT32_MAX)) return SPX_ERR_ARG;
+  if (k.overflow) return SPX_ERR_ARG;
   if (fill) {
     std::copy(k.pod_key.begin(), k.pod_key.end(), pod_key);
     std::copy(k.topo_order.begin(), k.topo_order.end(), topo_order);
@@ -235,6 +237,7 @@ namespace {
 // computed in one pass; the sizing call leaves it for the fill call that follows (as spx_flatten_net_keys does)
 struct NetCommit {
   uint64_t fp = 0;
+  bool overflow = false;  // more entries than the 32-bit offsets hold: the entry point refuses the batch
   std::vector<int32_t> eff_ptr, eff_key;
   std::vector<int64_t> eff_cost;
 };
@@ -243,6 +246,7 @@ thread_local NetCommit tl_net_commit;
 void build_net_commit(const spx_pod_objects* pods, const spx_appgroup_objects* ag, NetCommit& out) {
   const size_t P = static_cast<size_t>(pods->n_pods > 0 ? pods->n_pods : 0);
   out.fp = 0;
+  out.overflow = false;
   out.eff_ptr.clear();
   out.eff_key.clear(), out.eff_cost.clear();
   // key ids in order of first appearance, per group a short list (selector, key) — the numbering of spx_flatten_net_keys
@@ -321,7 +325,7 @@ void build_net_commit(const spx_pod_objects* pods, const spx_appgroup_objects* a
     t_off[k] = static_cast<int32_t>(t_total);
     t_total += c;
     if (t_total > INT32_MAX) {
-      out.eff_key.assign(static_cast<size_t>(INT32_MAX) + 1, 0), out.eff_ptr.assign(P + 1, 0);  // (refused by the entry point)
+      out.overflow = true;
       return;
     }
   }
@@ -334,9 +338,8 @@ void build_net_commit(const spx_pod_objects* pods, const spx_appgroup_objects* a
     out.eff_ptr[p] = static_cast<int32_t>(total);
     const int32_t g = pods->appgroup[p];
     if (g >= 0 && g < ag->n_groups) total += t_off[static_cast<size_t>(key_of[p]) + 1] - t_off[static_cast<size_t>(key_of[p])];
-    if (total > INT32_MAX) {  // (the entry point refuses such a batch: the offsets are 32-bit)
-      out.eff_key.assign(static_cast<size_t>(INT32_MAX) + 1, 0);
-      out.eff_ptr.assign(P + 1, 0);
+    if (total > INT32_MAX) {
+      out.overflow = true;
       return;
     }
   }
@@ -365,7 +368,7 @@ extern "C" int spx_flatten_net_commit(const spx_pod_objects* pods, const spx_app
     build_net_commit(pods, ag, k);
     k.fp = fp;
   }
-  if (k.eff_key.size() > static_cast<size_t>(INT32_MAX)) return SPX_ERR_ARG;
+  if (k.overflow) return SPX_ERR_ARG;
   *n_entries_out = static_cast<int64_t>(k.eff_key.size());
   if (fill) {
     std::copy(k.eff_ptr.begin(), k.eff_ptr.end(), eff_ptr);
