@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <climits>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include <atomic>
@@ -86,16 +87,38 @@ extern "C" int spx_flatten_nrt_slots(const spx_pod_objects* pods, const spx_nrt_
                                      const spx_nrt_params* p, int32_t* n_res_out, int32_t* slot_res, uint8_t* slot_flags,
                                      int64_t* slot_weight) {
   if (!pods || !nrt || !n_res_out || !slot_res || !slot_flags || !slot_weight) return SPX_ERR_ARG;
+  // the distinct resource ids of three long arrays (every container request, every overhead entry, every zone resource: ~0.8 M entries
+  // at config #5's share): scanned in pieces on the host threads, each piece's handful of ids merged under a lock
   std::vector<int32_t> ids;
-  auto add = [&](int32_t r) {
-    if (std::find(ids.begin(), ids.end(), r) == ids.end()) ids.push_back(r);
+  std::mutex ids_mu;
+  auto scan = [&](const int32_t* res, int64_t n) {
+    if (!res || n <= 0) return;
+    spx_host::parallel_rows(n, [&](int64_t b, int64_t e) {
+      int32_t mine[64];
+      int n_mine = 0;
+      bool spill = false;
+      std::vector<int32_t> more;  // (more than 64 distinct ids in one piece: the call fails below anyway, but stay correct)
+      for (int64_t i = b; i < e; ++i) {
+        const int32_t r = res[i];
+        bool seen = false;
+        for (int k = 0; k < n_mine && !seen; ++k) seen = mine[k] == r;
+        if (seen) continue;
+        if (n_mine < 64) mine[n_mine++] = r;
+        else if (std::find(more.begin(), more.end(), r) == more.end()) more.push_back(r), spill = true;
+      }
+      std::lock_guard<std::mutex> g(ids_mu);
+      for (int k = 0; k < n_mine; ++k)
+        if (std::find(ids.begin(), ids.end(), mine[k]) == ids.end()) ids.push_back(mine[k]);
+      if (spill)
+        for (const int32_t r : more)
+          if (std::find(ids.begin(), ids.end(), r) == ids.end()) ids.push_back(r);
+    }, 65536);
   };
   const int64_t n_ctr = pods->ctr_ptr[pods->n_pods];
-  for (int32_t i = 0; i < pods->req_ptr[n_ctr]; ++i) add(pods->req_res[i]);
-  if (pods->ovh_ptr)
-    for (int32_t i = 0; i < pods->ovh_ptr[pods->n_pods]; ++i) add(pods->ovh_res[i]);
+  scan(pods->req_res, pods->req_ptr[n_ctr]);
+  if (pods->ovh_ptr) scan(pods->ovh_res, pods->ovh_ptr[pods->n_pods]);
   const int32_t n_zones = nrt->zone_ptr[nrt->n_nodes];
-  for (int32_t i = 0; i < nrt->zres_ptr[n_zones]; ++i) add(nrt->zres_res[i]);
+  scan(nrt->zres_res, nrt->zres_ptr[n_zones]);
   std::sort(ids.begin(), ids.end());
   if (ids.size() > static_cast<size_t>(RM)) return SPX_ERR_ARG;  // more distinct resources than this build supports
   *n_res_out = static_cast<int32_t>(ids.size());
