@@ -216,6 +216,16 @@ def config5_leg(hdr, device, n_pods=8192):
         load_tables(e, w, snap)
         e.sync()
         out["flatten_upload_ms"] = (time.perf_counter() - t0) * 1e3
+        try:  # the same snapshot through the library's one-call loaders (spx_load_*: what a cgo caller pays — no SoA columns on its side)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                e.load_c(snap, snap["nrt_params"])
+                e.sync()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            out["load_c_ms"] = sorted(ts)[1]
+        except Exception as ex:
+            out["load_c_ms"] = {"error": repr(ex)[:200]}
         for _ in range(2):
             e.eval(mask)
         e.sync()
