@@ -200,16 +200,37 @@ int flatten_nrt_node(const spx_node_objects* nodes, const spx_nrt_objects* nrt, 
     }
     n_zones[j] = static_cast<uint8_t>(nz);
     // ---- distance matrix by list position; 255 where Costs has no entry (least_numa.go:127-132)
-    for (int a = 0; a < Z; ++a)
-      for (int b = 0; b < Z; ++b) {
-        int32_t cost = 255;
-        if (a < nz && b < nz && nrt->zcost_ptr) {
-          const int want = zone_id[j * Z + b];
-          for (int32_t k = nrt->zcost_ptr[zsrc[a]]; k < nrt->zcost_ptr[zsrc[a] + 1]; ++k)
-            if (nrt->zcost_numa_id[k] == want) cost = static_cast<int32_t>(nrt->zcost_value[k]);
-        }
-        zone_cost[(j * Z + a) * Z + b] = cost;
+    {
+      // NUMA id -> list position (ids 0..63); an id carried by two zones keeps the slow walk below (every zone with that id takes
+      // the entry).  With the map a zone's Costs list is walked once instead of once per column: the last entry for an id wins,
+      // as in the column-by-column walk.
+      int8_t pos_of[64];
+      std::memset(pos_of, -1, sizeof pos_of);
+      bool unique = true;
+      for (int b = 0; b < nz; ++b) {
+        const int id = zone_id[j * Z + b];
+        unique &= pos_of[id] < 0;
+        pos_of[id] = static_cast<int8_t>(b);
       }
+      int32_t* row = zone_cost + j * Z * Z;
+      for (int i = 0; i < Z * Z; ++i) row[i] = 255;
+      if (nrt->zcost_ptr) {
+        if (unique) {
+          for (int a = 0; a < nz; ++a)
+            for (int32_t k = nrt->zcost_ptr[zsrc[a]]; k < nrt->zcost_ptr[zsrc[a] + 1]; ++k) {
+              const int32_t id = nrt->zcost_numa_id[k];
+              if (id >= 0 && id < 64 && pos_of[id] >= 0) row[a * Z + pos_of[id]] = static_cast<int32_t>(nrt->zcost_value[k]);
+            }
+        } else {
+          for (int a = 0; a < nz; ++a)
+            for (int b = 0; b < nz; ++b) {
+              const int want = zone_id[j * Z + b];
+              for (int32_t k = nrt->zcost_ptr[zsrc[a]]; k < nrt->zcost_ptr[zsrc[a] + 1]; ++k)
+                if (nrt->zcost_numa_id[k] == want) row[a * Z + b] = static_cast<int32_t>(nrt->zcost_value[k]);
+            }
+        }
+      }
+    }
     // ---- minAvgDistanceInCombinations for every subset size (float32 exactly as the reference)
     float best[Z];
     for (int k = 0; k < Z; ++k) best[k] = 255.0f;
