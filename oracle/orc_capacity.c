@@ -128,3 +128,22 @@ int orc_capacity_prefilter(const spx_pod_objects* pods, const spx_resource_class
   if (orc_quota_cmp2(used.v, used.present, zero, min.v, min.present, 0)) return SPX_QUOTA_ST_OVER_MIN;
   return 0;
 }
+
+/* CapacityScheduling.Reserve capacity_scheduling.go:350-364 -> ElasticQuotaInfo.addPodIfNotPresent elasticquota.go:153-166 ->
+ * reserveResource :89-98, on a caller-owned Used table ([n_namespaces][SPX_QUOTA_SLOTS] + the scalar-key bits): the namespace's Used
+ * grows by computePodResourceRequest(pod); SetScalar creates a scalar key the request carries.  A namespace without an ElasticQuota
+ * reserves nothing.  (The `pods` set of addPodIfNotPresent only guards against adding one pod twice.) */
+void orc_capacity_reserve(const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_quota_objects* q, int64_t pod,
+                          int64_t* used, uint8_t* used_present) {
+  const int32_t ns = pods->ns[pod];
+  if (ns < 0 || ns >= q->n_namespaces || !q->has_quota[ns]) return;
+  fres req;
+  pod_request(pods, q, rc, pod, &req);
+  int64_t* u = used + (size_t)ns * SPX_QUOTA_SLOTS;
+  for (int s = 0; s < 4; ++s) u[s] = wadd(u[s], req.v[s]);
+  for (int s = 4; s < SPX_QUOTA_SLOTS; ++s)
+    if (req.present >> s & 1) { /* ranges over request.ScalarResources */
+      u[s] = wadd((used_present[ns] >> s & 1) ? u[s] : 0, req.v[s]);
+      used_present[ns] |= (uint8_t)(1u << s);
+    }
+}

@@ -48,8 +48,16 @@ static int dependency_list(const spx_appgroup_objects* ag, int32_t g, int32_t se
  * Error paths ("pod hostname not found"), 0 otherwise */
 int orc_net_prefilter(const spx_node_objects* nodes, const spx_pod_objects* pods, const spx_appgroup_objects* ag,
                       const spx_nettopo_objects* nt, int64_t pod, int64_t* sat, int64_t* vio, int64_t* cost) {
+  return orc_net_prefilter_range(nodes, pods, ag, nt, pod, 0, nodes->n_nodes, sat, vio, cost);
+}
+
+/* the same for the nodes [node_begin, node_end) of PreFilter's node loop (:243-280; the iterations are independent): what one
+ * worker of a chunked parallel-for computes.  The early exits do not depend on the range. */
+int orc_net_prefilter_range(const spx_node_objects* nodes, const spx_pod_objects* pods, const spx_appgroup_objects* ag,
+                            const spx_nettopo_objects* nt, int64_t pod, int64_t node_begin, int64_t node_end,
+                            int64_t* sat, int64_t* vio, int64_t* cost) {
   const int64_t n = nodes->n_nodes;
-  for (int64_t i = 0; i < n; ++i) sat[i] = vio[i] = cost[i] = 0;
+  for (int64_t i = node_begin; i < node_end; ++i) sat[i] = vio[i] = cost[i] = 0;
   int32_t g = pods->appgroup[pod];
   if (g < 0 || g >= ag->n_groups) return 1; /* "Pod does not belong to an AppGroup" :187-190 */
   int32_t dep_sel[256];
@@ -59,7 +67,7 @@ int orc_net_prefilter(const spx_node_objects* nodes, const spx_pod_objects* pods
   int32_t s0 = ag->placed_ptr[g], s1 = ag->placed_ptr[g + 1];
   if (s1 == s0) return 1; /* no pods listed / scheduled list empty :217-228 */
 
-  for (int64_t node = 0; node < n; ++node) { /* :243-280 */
+  for (int64_t node = node_begin; node < node_end; ++node) { /* :243-280 */
     int32_t region = nodes->region[node], zone = nodes->zone[node];
     int64_t satisfied = 0, violated = 0, acc = 0;
     for (int32_t s = s0; s < s1; ++s) {

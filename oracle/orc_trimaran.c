@@ -57,10 +57,36 @@ static int64_t tlp_pod_cpu(const spx_pod_objects* pods, int64_t pod, const spx_t
   return cur;
 }
 
+/* the walk of ScheduledPodsCache[nodeName] in TargetLoadPacking.Score (targetloadpacking.go:151-168) over one node's entries
+ * given as a slice: (bind time, pod index into `entry_pods`) pairs in cache order.  orc_tlp_score runs it on the snapshot's
+ * image of the cache; orc_commit.c runs it once more on the entries the one-pod-at-a-time cycle appended since
+ * (handler.go:131-139 appends to the same per-node slice, and the sum does not depend on the order). */
+int64_t orc_tlp_missing_entries(const int64_t* e_ts_unix, const int32_t* e_pod, int32_t n_entries, const spx_pod_objects* entry_pods,
+                                int64_t window_end, const spx_tlp_params* p) {
+  int64_t missing = 0;
+  for (int32_t e = 0; e < n_entries; ++e) {
+    int64_t ts = e_ts_unix[e];
+    int64_t end = window_end;
+    /* Go precedence: a || (b && c) */
+    if (ts > end || (ts <= end && (end - ts) < 60 /* metricsAgentReportingIntervalSeconds */)) {
+      missing += tlp_pod_cpu(entry_pods, e_pod[e], p);
+    }
+  }
+  return missing;
+}
+
 /* TargetLoadPacking.Score (targetloadpacking.go:107-187) */
 int64_t orc_tlp_score(const spx_node_objects* nodes, const spx_metrics_objects* metrics,
                       const spx_assigned_objects* assigned, const spx_pod_objects* pods,
                       const spx_tlp_params* p, int64_t pod, int64_t node) {
+  return orc_tlp_score_appended(nodes, metrics, assigned, pods, p, pod, node, 0, 0, 0, 0);
+}
+
+/* the same with `n_more` further cache entries of this node (appended after the snapshot's) */
+int64_t orc_tlp_score_appended(const spx_node_objects* nodes, const spx_metrics_objects* metrics,
+                               const spx_assigned_objects* assigned, const spx_pod_objects* pods,
+                               const spx_tlp_params* p, int64_t pod, int64_t node,
+                               const int64_t* more_ts_unix, const int32_t* more_pod, int32_t n_more, const spx_pod_objects* more_pods) {
   const int64_t min_node_score = 0;
   int32_t lo, hi;
   if (!orc_node_metrics(metrics, node, &lo, &hi)) return min_node_score; /* :114-120 */
@@ -84,15 +110,11 @@ int64_t orc_tlp_score(const spx_node_objects* nodes, const spx_metrics_objects* 
 
   int64_t missing = 0; /* :151-168 */
   if (assigned && assigned->e_ptr) {
-    for (int32_t e = assigned->e_ptr[node]; e < assigned->e_ptr[node + 1]; ++e) {
-      int64_t ts = assigned->e_ts_unix[e];
-      int64_t end = metrics->window_end;
-      /* Go precedence: a || (b && c) */
-      if (ts > end || (ts <= end && (end - ts) < 60 /* metricsAgentReportingIntervalSeconds */)) {
-        missing += tlp_pod_cpu(assigned->pods, assigned->e_pod[e], p);
-      }
-    }
+    const int32_t e0 = assigned->e_ptr[node];
+    missing += orc_tlp_missing_entries(assigned->e_ts_unix + e0, assigned->e_pod + e0, assigned->e_ptr[node + 1] - e0, assigned->pods,
+                                       metrics->window_end, p);
   }
+  if (n_more > 0) missing += orc_tlp_missing_entries(more_ts_unix, more_pod, n_more, more_pods, metrics->window_end, p);
 
   double predicted = 0; /* :169-173 */
   if (node_cpu_cap_millis != 0)

@@ -98,3 +98,36 @@ class Snapshot:
         if rc != 0:
             raise RuntimeError(f"orc_filter_rows failed: {rc}")
         return out
+
+
+def usable_cpus() -> int:
+    """CPUs this process can actually run on: sched_getaffinity capped by the cgroup's cpu.max (orc_usable_cpus)"""
+    return int(lib().orc_usable_cpus())
+
+
+def commit_sequential(snap: "Snapshot", plugin_mask: int, weights: Optional[dict] = None, quota: Optional[Table] = None,
+                      row_begin: int = 0, row_end: Optional[int] = None, bind_ts: int = 0, threads: int = 0):
+    """The one-pod-at-a-time cycle with its Reserve side effects (orc_commit_sequential): -> dict(node, score, ties, verdict,
+    appended).  weights: {plugin id: weight} (missing = 1); threads 0 = every usable CPU."""
+    h = header()
+    row_end = snap.n_pods if row_end is None else row_end
+    n = row_end - row_begin
+    a = h.structs["orc_commit_args"]()
+    a.s = C.pointer(snap.struct)
+    if quota is not None:
+        a.quota = C.pointer(quota.struct)
+    a.plugin_mask = plugin_mask
+    w = np.ones(h.consts["SPX_NUM_PLUGINS"], np.int64)
+    for k, v in (weights or {}).items():
+        w[k] = v
+    a.weights = w.ctypes.data_as(C.POINTER(C.c_int64))
+    a.row_begin, a.row_end, a.bind_ts = row_begin, row_end, bind_ts
+    a.threads = threads if threads > 0 else usable_cpus()
+    appended = np.zeros(snap.n_nodes, np.int32)
+    a.tlp_appended_out = appended.ctypes.data_as(C.POINTER(C.c_int32))
+    node, score, ties, verdict = np.zeros(n, np.int32), np.zeros(n, np.int64), np.zeros(n, np.int32), np.zeros(n, np.uint8)
+    rc = lib().orc_commit_sequential(C.byref(a), node.ctypes.data_as(C.POINTER(C.c_int32)), score.ctypes.data_as(C.POINTER(C.c_int64)),
+                                     ties.ctypes.data_as(C.POINTER(C.c_int32)), verdict.ctypes.data_as(C.POINTER(C.c_uint8)))
+    if rc != 0:
+        raise RuntimeError(f"orc_commit_sequential failed: {rc}")
+    return dict(node=node, score=score, ties=ties, verdict=verdict, appended=appended)

@@ -36,6 +36,14 @@ int64_t orc_tlp_score(const spx_node_objects* nodes, const spx_metrics_objects* 
                       const spx_assigned_objects* assigned, const spx_pod_objects* pods,
                       const spx_tlp_params* p, int64_t pod, int64_t node);
 
+/* the cache walk of :151-168 over one node's entries given as a slice, and Score with `n_more` entries appended to the snapshot's */
+int64_t orc_tlp_missing_entries(const int64_t* e_ts_unix, const int32_t* e_pod, int32_t n_entries, const spx_pod_objects* entry_pods,
+                                int64_t window_end, const spx_tlp_params* p);
+int64_t orc_tlp_score_appended(const spx_node_objects* nodes, const spx_metrics_objects* metrics,
+                               const spx_assigned_objects* assigned, const spx_pod_objects* pods,
+                               const spx_tlp_params* p, int64_t pod, int64_t node,
+                               const int64_t* more_ts_unix, const int32_t* more_pod, int32_t n_more, const spx_pod_objects* more_pods);
+
 /* ---- trimaran.LoadVariationRiskBalancing (.../loadvariationriskbalancing/{loadvariationriskbalancing,analysis}.go,
  *      pkg/trimaran/resourcestats.go) */
 typedef struct orc_resource_stats {
@@ -120,6 +128,9 @@ int orc_nrt_numa_nodes_required(const spx_nrt_objects* nrt, const spx_resource_c
 /* ---- networkaware NetworkOverhead + TopologicalSort (pkg/networkaware/...) */
 int orc_net_prefilter(const spx_node_objects* nodes, const spx_pod_objects* pods, const spx_appgroup_objects* ag,
                       const spx_nettopo_objects* nt, int64_t pod, int64_t* sat, int64_t* vio, int64_t* cost);
+int orc_net_prefilter_range(const spx_node_objects* nodes, const spx_pod_objects* pods, const spx_appgroup_objects* ag,
+                            const spx_nettopo_objects* nt, int64_t pod, int64_t node_begin, int64_t node_end,
+                            int64_t* sat, int64_t* vio, int64_t* cost);
 void orc_net_normalize(int64_t* scores, int64_t n);
 int32_t orc_find_pod_order(const spx_appgroup_objects* ag, int32_t g, int32_t selector);
 int orc_toposort_less(const spx_pod_objects* pods, const spx_appgroup_objects* ag, int64_t p1, int64_t p2);
@@ -129,6 +140,9 @@ int64_t orc_toposort_order_violations(const spx_pod_objects* pods, const spx_app
 /* ---- CapacityScheduling.PreFilter (pkg/capacityscheduling/{capacity_scheduling,elasticquota}.go) */
 int orc_quota_cmp2(const int64_t* x1, uint8_t x1_present, const int64_t* x2, const int64_t* y, uint8_t y_present, int64_t bound);
 int orc_capacity_prefilter(const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_quota_objects* q, int64_t pod);
+/* CapacityScheduling.Reserve -> reserveResource (capacity_scheduling.go:350-364, elasticquota.go:89-98) on a caller-owned Used table */
+void orc_capacity_reserve(const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_quota_objects* q, int64_t pod,
+                          int64_t* used, uint8_t* used_present);
 
 /* ---- batch drivers: for each pod row in [row_begin,row_end): for each node: Score(); then
  *      NormalizeScore() over that pod's node list (feasible nodes only when `mask` != NULL, as
@@ -162,6 +176,31 @@ int orc_filter_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_
 /* one pod at a time, that pod's node loop chunked over `workers` threads that join per pod, NormalizeScore serial: the
  * reference benchmark's structure (targetloadpacking_test.go:369-405, parallelism 16).  out_norm ([rows][n_nodes]) may be NULL. */
 int orc_cycle_rows(const orc_snapshot* s, int plugin, int64_t row_begin, int64_t row_end, int workers, int64_t* out_norm);
+
+/* ---- the one-pod-at-a-time cycle with its Reserve side effects (orc_commit.c): what spx_commit_sequential must reproduce.
+ * Pod rows [row_begin,row_end) in queue order; per pod: PreFilter, Filter + Score over the node list (cut into `threads`
+ * contiguous ranges joined per pod), NormalizeScore, the weighted sum (weights[plugin id]; NULL = all 1), the tie set as
+ * (lowest node index, size), then Reserve / bind on this call's private copies of the caches (NRT assumed store, trimaran
+ * ScheduledPodsCache with bind time `bind_ts`, ElasticQuota Used + nominated list, AppGroup scheduled list).  The caller's tables
+ * are not modified.  plugin_mask is a subset of {ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY}; `quota` only with CAPACITY.
+ * node_out[i] = -1 for a pod that was turned away: verdict_out[i] (may be NULL) = the CapacityScheduling PreFilter code
+ * (SPX_QUOTA_ST_*) or ORC_COMMIT_NO_FEASIBLE_NODE; score_out / ties_out may be NULL.  tlp_appended_out (may be NULL, [n_nodes]) =
+ * cache entries appended per node.  Returns 0, <0 on bad arguments / allocation failure / the reference's Error paths. */
+#define ORC_COMMIT_NO_FEASIBLE_NODE 255
+typedef struct orc_commit_args {
+  const orc_snapshot* s;
+  const spx_quota_objects* quota;
+  uint32_t plugin_mask;
+  const int64_t* weights;
+  int64_t row_begin;
+  int64_t row_end;
+  int64_t bind_ts;
+  int threads;
+  int32_t* tlp_appended_out;
+} orc_commit_args;
+int orc_commit_sequential(const orc_commit_args* a, int32_t* node_out, int64_t* score_out, int32_t* ties_out, uint8_t* verdict_out);
+/* CPUs this process may run on (sched_getaffinity) capped by the cgroup's cpu.max quota — what "all host cores" means here */
+int orc_usable_cpus(void);
 
 #ifdef __cplusplus
 }
