@@ -91,6 +91,10 @@ WORKLOADS = {
     "small_full": dict(n_nodes=2_000, n_pods=8_000, plugins=("cap", "alloc", "tlp", "lvrb", "nrt", "net"), node_row=405, pod_row=188, out=6,
                        strategy="LeastAllocated", scaling="strong",
                        desc="plumbing-sized full profile, 2k nodes x 8k pods sharded over the GPUs"),
+    # a batch no rank count divides: 8191 = 2 x 4096 - 1 = 3 x 2731 - 2 (the last rank's shard is short)
+    "small_full_ragged": dict(n_nodes=2_000, n_pods=8_191, plugins=("cap", "alloc", "tlp", "lvrb", "nrt", "net"), node_row=405, pod_row=188, out=6,
+                              strategy="LeastAllocated", scaling="strong",
+                              desc="plumbing-sized full profile, 2k nodes x 8191 pods sharded over the GPUs (ragged shards)"),
     # BASELINE.json configs[0]: noderesources.Allocatable (LeastAllocated) on 100 nodes x 1k pods — the reference's own CPU-runnable
     # case (test/integration/allocatable_test.go through hack/integration-test.sh); here the same shape through the C ABI
     "config1": dict(n_nodes=100, n_pods=1_000, plugins=("alloc",), node_row=16, pod_row=0, out=1,
@@ -334,7 +338,14 @@ def cpu_baseline(spx, snap, e, plugins, budget_s: float):
                               nrt=snap.get("nrt"), nrt_params=snap.get("nrt_params"), appgroups=snap.get("appgroups"),
                               nettopo=snap.get("nettopo"), node_pods=snap.get("node_pods"), lroc_params=getattr(e, "lroc_params", None),
                               power_models=snap.get("power_models"))
-    cores = os.cpu_count() or 1
+    # what "all host cores" is on this box: the CPUs the process may run on, capped by the cgroup's CPU quota (the round-4 line said
+    # "cores: 256" on a box whose cgroup grants 16 CPUs' worth of time — 256 runnable threads on 16 CPUs of quota)
+    cores = pyoracle.usable_cpus()
+    try:
+        cpu_max = Path("/sys/fs/cgroup/cpu.max").read_text().strip()
+    except OSError:
+        cpu_max = None
+    host_cpus = {"os_cpu_count": os.cpu_count(), "sched_getaffinity": len(os.sched_getaffinity(0)), "cgroup_cpu_max": cpu_max, "usable": cores}
     n_nodes = osnap.n_nodes
 
     def run_rows(rows: int, threads: int) -> float:
@@ -364,12 +375,13 @@ def cpu_baseline(spx, snap, e, plugins, budget_s: float):
 
     rows, t = sized(run_rows, cores, 8 * cores, 0.5)
     out = {
-        "value": rows * n_nodes / t, "unit": "evals/s", "cores": cores, "kind": "port",
+        "value": rows * n_nodes / t, "unit": "evals/s", "cores": cores, "kind": "port", "host_cpus": host_cpus,
         "sample": f"{rows} pod rows x {n_nodes} nodes of the same snapshot, {len(plugins)} plugins, {t:.2f} s wall, pod rows split over "
-                  f"{cores} threads; C restatement of the reference CPU path (oracle/), not the Go binary",
+                  f"{cores} threads (= usable CPUs: affinity capped by the cgroup quota); C restatement of the reference CPU path (oracle/), not the Go binary",
     }
     rows1, t1 = sized(run_rows, 1, 8, 0.25)
     out["single_thread"] = {"value": rows1 * n_nodes / t1, "cores": 1, "sample": f"{rows1} pod rows, {t1:.2f} s"}
+    out["scaling_efficiency"] = out["value"] / (out["single_thread"]["value"] * cores)  # all-cores rate / (one-thread rate x usable CPUs)
     if any(p not in (4, 5) for p in plugins):
         rows16, t16 = sized(run_cycle, 16, 16, 0.25)
         out["reference_structure"] = {
@@ -423,6 +435,8 @@ def main() -> None:
                     "scaling run); gloo = the same code path with the collectives on host tensors, for boxes with fewer GPUs than ranks (tests)")
     ap.add_argument("--rank-devices", default="", help="ranks mode: device of each local rank, e.g. 0,0 puts two ranks on device 0 (needs --dist-backend gloo: RCCL "
                     "refuses two ranks on one device)")
+    ap.add_argument("--verify-gather", action="store_true", help="ranks mode, strong-scaling workloads: rank 0 also evaluates the whole batch in one engine and "
+                    "compares the all-gathered decisions with it (gather.mismatches; small shapes — tests)")
     ap.add_argument("--no-config5-leg", action="store_true", help="default (config2) line only: skip the bounded full-profile leg (config5_leg)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     args = ap.parse_args()
@@ -489,8 +503,8 @@ def main() -> None:
         target = e0 = Engine(local_rank)
         if strong and world > 1:  # every rank builds the same batch and keeps its shard
             snap = build_snapshot(hdr, w, n_pods_total, synth.SEED)
-            per = -(-n_pods_total // world)
-            rows = (min(n_pods_total, rank * per), min(n_pods_total, (rank + 1) * per))
+            from scheduler_plugins_amd import shard
+            rows = shard.shard_rows(n_pods_total, world, rank)  # ceil(P/G) rows per rank: the one partition rule (= spx_multi_shard)
             load_tables(target, w, snap, rows)
         else:  # same node snapshot, an own pod batch per rank
             snap = build_snapshot(hdr, w, w["n_pods"] if not strong else n_pods_total, synth.SEED + 1000 * rank)
@@ -713,14 +727,24 @@ def main() -> None:
                 node, score, ties, feas = target.best()
                 barrier()
                 t1 = time.perf_counter()
-                if strong:  # equal shards of one batch
-                    shard.gather_best(dist, coll_dev, node, score, ties, feas, n_pods_total)
+                if strong:  # shards of one batch (ceil(P/G) rows per rank, the last one short: shard.shard_rows)
+                    gathered = shard.gather_best(dist, coll_dev, node, score, ties, feas, n_pods_total)
                 else:
-                    shard.gather_best(dist, coll_dev, node, score, ties, feas, local_pods * world)
+                    gathered = shard.gather_best(dist, coll_dev, node, score, ties, feas, local_pods * world)
                 barrier()
                 gather_info = {"best_ms": (time.perf_counter() - t1) * 1e3, "bytes_per_rank": int(local_pods) * 20,
                                "host": "one process per GPU, torch.distributed all_gather_into_tensor", "backend": args.dist_backend,
                                "note": "no N > 1 hardware figure has been measured by the builder: one-GPU boxes only (two ranks on one device run over gloo)"}
+                if args.verify_gather and strong and rank == 0:
+                    # the assembled decisions against ONE engine holding the whole batch (small shapes: tests of the partition rule)
+                    with Engine(local_rank) as whole:
+                        load_tables(whole, w, snap)
+                        whole.eval(mask)
+                        whole.eval_best(score_mask)
+                        whole.sync()
+                        want = whole.best()
+                    gather_info["verified_rows"] = int(len(want[0]))
+                    gather_info["mismatches"] = int(sum(int((np.asarray(g) != np.asarray(x)).sum()) for g, x in zip(gathered, want)))
                 if args.gather == "table":
                     p0 = plugins[-1] if plugins[-1] <= 4 else plugins[0]
                     ptr, stride, rows_t = target.score_table(p0)

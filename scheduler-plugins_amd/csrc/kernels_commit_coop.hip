@@ -874,6 +874,30 @@ size_t commit_coop_lds_bytes(const CoopArgs& c) {
   return l.total;
 }
 
+// How many workgroups of this launch the device can hold at once: every workgroup spins on every other one's granules, so the
+// launch is only valid when all n_wg of them are resident (a smaller part, a CU mask, or a device shared with another process's
+// kernels holds fewer).  <= 0: the runtime could not tell.
+int commit_coop_max_resident(const CoopArgs& c, int device) {
+  const size_t lds = commit_coop_lds_bytes(c);
+  int per_cu = 0, cus = 0;
+  if (c.nrt_sg == kSgMost)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_commit_coop<kSgMost>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  else
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_commit_coop<kSgLeast>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  hipError_t rc = c.nrt_sg == kSgMost
+                      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_commit_coop<kSgMost>), kT, lds)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_commit_coop<kSgLeast>), kT, lds);
+  if (rc != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return per_cu * cus;
+}
+
 void launch_commit_coop(const CoopArgs& c, hipStream_t s) {
   const size_t lds = commit_coop_lds_bytes(c);
   if (c.nrt_sg == kSgMost) {

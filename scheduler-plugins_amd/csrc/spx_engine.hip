@@ -166,6 +166,7 @@ struct spx_engine {
   int32_t net_n_keys = 0;
   DevBuf d_commit_save;  // backup of every table the commit loop mutates
   DevBuf d_coop_sync, d_coop_node, d_coop_max;  // cooperative commit kernel: granules + error flag, the workgroups' private pair lists
+  int coop_gave_up = 0;      // cooperative commit launches that ended with a workgroup giving up (served by the per-pod loop instead)
   int last_commit_path = 0;  // what the last spx_commit_sequential ran: 1 one-workgroup trimaran chain, 2 per-pod launches, 3 cooperative kernel
   DevBuf d_row_counter;  // int64: the row the replayed per-pod graph works on
   const int64_t* row_indirect = nullptr;  // non-NULL while that graph is captured: sweeps read their row from the device
@@ -2425,6 +2426,12 @@ int commit_coop(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t 
   SPX_HIP(e, hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, e->device));
   const size_t lds = spx::commit_coop_lds_bytes(c);
   if (lds + 4096 > static_cast<size_t>(lds_max)) return SPX_OK;  // (4 KB: the kernel's static LDS)
+  {
+    // every workgroup polls every other one's granules: all n_wg must be resident at once.  The occupancy the runtime reports for this
+    // kernel at this LDS size x the CU count is the ceiling (a smaller part, a CU mask); above it the per-pod loop runs instead.
+    const int resident = spx::commit_coop_max_resident(c, e->device);
+    if (resident > 0 && n_wg > resident) return SPX_OK;
+  }
   // ---- from here on the kernel runs
   if (Lv) {  // LVRB carries no commit state: its rows are swept once
     if ((rc = spx_eval(e, 1u << SPX_PLUGIN_LVRB, row_begin, row_end))) return rc;
@@ -2461,7 +2468,12 @@ int commit_coop(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t 
   if (n_ties) SPX_HIP(e, hipMemcpyAsync(n_ties, c.best_ties + row_begin, rows * 4, hipMemcpyDeviceToHost, e->stream));
   if (tlp_missing_out && T) SPX_HIP(e, hipMemcpyAsync(tlp_missing_out, c.missing_out, Nn * 8, hipMemcpyDeviceToHost, e->stream));
   SPX_HIP(e, hipStreamSynchronize(e->stream));
-  if (err != 0) return fail(e, SPX_ERR_HIP, "cooperative commit kernel: a workgroup gave up waiting for another one (device shared with other work?)");
+  if (err != 0) {
+    // a workgroup gave up waiting for another one (the device is shared with other work and not all workgroups became resident): the
+    // kernel mutated nothing in the engine's tables, so the per-pod loop can still serve the call
+    e->coop_gave_up += 1;
+    return SPX_OK;  // *ran is false
+  }
   if (tlp_missing_out && !T) std::memset(tlp_missing_out, 0, Nn * 8);
   e->best_valid = false;
   e->last_commit_path = 3;

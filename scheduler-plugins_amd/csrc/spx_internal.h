@@ -576,6 +576,7 @@ struct CoopArgs {
 };
 // dynamic LDS of one workgroup, 0 when the profile does not fit the kernel's staging areas (the caller then runs the per-pod loop)
 size_t commit_coop_lds_bytes(const CoopArgs& c);
+int commit_coop_max_resident(const CoopArgs& c, int device);
 void launch_commit_coop(const CoopArgs& c, hipStream_t s);
 // key k's pairs src[src_ptr[k] .. src_ptr[k+1]) -> dst[dst_ptr[k] ..): the workload pair lists re-laid with room to grow
 void launch_spread_pairs(int32_t n_keys, const int32_t* src_ptr, const int32_t* dst_ptr, const int32_t* src_node, const int64_t* src_max, int32_t* dst_node,

@@ -1,6 +1,6 @@
 """Multi-GPU sharding of the pods x nodes evaluation.
 
-Pod rows are the independent unit given a frozen snapshot: rank g owns rows [g*P/G, (g+1)*P/G), node-side tables
+Pod rows are the independent unit given a frozen snapshot: rank g owns rows [g*ceil(P/G), (g+1)*ceil(P/G)) ∩ [0, P), node-side tables
 are replicated, and the evaluation itself needs no collective.  What a consumer wants back is either
   * the per-pod decision (best node, weighted score, tie count, feasible count): 20 bytes per pod — one small
     RCCL all-gather, or
@@ -16,10 +16,12 @@ import numpy as np
 
 
 def shard_rows(n_pods: int, world: int, rank: int) -> Tuple[int, int]:
-    """Contiguous, balanced row range of `rank` (first n_pods % world ranks get one extra row)."""
-    base, extra = divmod(n_pods, world)
-    begin = rank * base + min(rank, extra)
-    return begin, begin + base + (1 if rank < extra else 0)
+    """Contiguous row range of `rank`: ceil(n_pods / world) rows per rank, the last ranks short or empty — THE partition rule of
+    this code base (spx_multi_shard in csrc/spx_multi.hip and bench.py's ranks mode use the same one: global row g lives on rank
+    g // ceil(P/G) at local row g % ceil(P/G), which is what lets equal slabs be all-gathered in place)."""
+    per = -(-n_pods // world) if world > 0 else 0
+    begin = min(n_pods, rank * per)
+    return begin, min(n_pods, begin + per)
 
 
 def shard_sizes(n_pods: int, world: int) -> List[int]:

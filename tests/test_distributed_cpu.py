@@ -26,7 +26,7 @@ WORKER = textwrap.dedent("""
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     hdr = spx.header()
-    N, P = 200, 101   # ragged: 51 + 50 rows
+    N, P = 200, int(os.environ.get('SPX_TEST_PODS', '101'))   # ragged: 51 + 50 rows (101, 2 ranks); 34 + 34 + 33 / 4 + 4 + 2 with 3
     snap = synth.trimaran_snapshot(hdr, N, P, seed=21)
     osnap = pyoracle.Snapshot(snap["nodes"], snap["pods"], metrics=snap["metrics"], assigned=snap["assigned"], tlp_params=tlp_params(hdr))
     b, e = shard.shard_rows(P, world, rank)
@@ -54,22 +54,30 @@ WORKER = textwrap.dedent("""
 
 
 def test_shard_rows_partition():
+    """one partition rule everywhere: ceil(P/G) rows per rank (shard.shard_rows = spx_multi_shard = bench.py's ranks mode)"""
     sys.path.insert(0, str(ROOT))
+    import ctypes as C
+
+    import scheduler_plugins_amd as spx
     from scheduler_plugins_amd import shard
-    for p, w in [(100000, 8), (101, 2), (7, 8), (1, 1), (0, 4)]:
+    for p, w in [(100000, 8), (101, 2), (7, 8), (1, 1), (0, 4), (10, 4), (8191, 2), (8191, 3), (500000, 8), (200000, 3)]:
         ranges = [shard.shard_rows(p, w, r) for r in range(w)]
         assert ranges[0][0] == 0 and ranges[-1][1] == p
         assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
-        sizes = [e - b for b, e in ranges]
-        assert max(sizes) - min(sizes) <= 1
+        per = -(-p // w)
+        assert all((b, e) == (min(p, r * per), min(p, (r + 1) * per)) for r, (b, e) in enumerate(ranges))
+        assert sum(shard.shard_sizes(p, w)) == p
+    assert [shard.shard_rows(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]   # not 3,3,2,2
 
 
-def test_two_rank_gloo_sharded_eval_and_gather(tmp_path):
+@pytest.mark.parametrize("world,n_pods,port", [(2, 101, 29531), (3, 10, 29533)])
+def test_gloo_sharded_eval_and_gather(tmp_path, world, n_pods, port):
+    """2 ranks x 101 rows (51 + 50) and 3 ranks x 10 rows (4 + 4 + 2: the shape on which a balanced rule and the ceil rule differ)"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", str(script), str(ROOT)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPX_TEST_PODS=str(n_pods))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), str(ROOT)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert r.stdout.count("ok") >= 2
+    assert r.stdout.count("ok") >= world

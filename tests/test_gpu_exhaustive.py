@@ -19,7 +19,9 @@ from scheduler_plugins_amd.engine import Engine, mask_of
 
 pytestmark = pytest.mark.gpu
 
-THREADS = os.cpu_count() or 1
+import pyoracle  # noqa: E402  (tests/conftest.py puts oracle/ on the path)
+
+THREADS = pyoracle.usable_cpus()  # CPUs the cgroup lets this process use (os.cpu_count() says 256 on a box that grants 16)
 
 
 def blocks(n_rows, n_nodes, cells=48_000_000):
