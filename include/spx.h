@@ -733,6 +733,10 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *                              spx_decide's argmax) give every row a whole workgroup in batch launches too; 0 (default) = four rows per
  *                              workgroup, and the whole-workgroup mapping only when four rows' feasibility bytes would not fit the LDS
  *                              (rows of more than about 65k nodes).  Same tables either way
+ *   SPX_OPT_TLP_AMB_TABLE      1 (default) = a multi-row TargetLoadPacking sweep (tables or spx_decide) first lists, per pod value and node tile,
+ *                              where a cell of the float32 formulation can be within its error bound of a rounding tie or of the branch point
+ *                              (a property of the node alone: the score is piecewise linear in the pod's integer millicores), and only the rows
+ *                              named there carry the per-cell exactness bookkeeping; 0 = every cell carries it.  Same tables either way
  */
 #define SPX_OPT_ROW_ALIGN 0
 #define SPX_OPT_REFERENCE_KERNELS 1
@@ -747,7 +751,8 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
 #define SPX_OPT_COMMIT_COOP 10
 #define SPX_OPT_NRT_RANK_FILTER 11
 #define SPX_OPT_ROW_WORKGROUP 12
-#define SPX_NUM_OPTIONS 13
+#define SPX_OPT_TLP_AMB_TABLE 13
+#define SPX_NUM_OPTIONS 14
 int spx_set_option(spx_engine* e, int option, int64_t value);
 int spx_get_option(const spx_engine* e, int option, int64_t* value);
 

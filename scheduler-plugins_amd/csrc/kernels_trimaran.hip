@@ -303,6 +303,8 @@ __device__ __forceinline__ int64_t tile_slot(int64_t n) {
 }
 
 constexpr int kLvNpl = 8, kTlpNpl = 16;  // nodes per lane of k_lvrb_fast / k_tlp_fast2
+constexpr double kAmbMargin = 1.25;          // k_tlp_amb_build lists a cell when it is within 1.25 x the tolerance of a rounding tie
+constexpr double kAmbMinSlope = 2.5 * 4e-5;  // score units per millicore below which a node is always exact (see k_tlp_amb_build)
 
 // (see k_lvrb_prepare_fast) TargetLoadPacking's per-node float32 constants: b2 = b2h + b2l and the two branch coefficients
 __global__ void k_tlp_prepare_fast(TrimaranArgs a, int64_t n_slots, double c1, double c2) {
@@ -327,8 +329,8 @@ __global__ void k_tlp_prepare_fast(TrimaranArgs a, int64_t n_slots, double c1, d
       b = (um + miss) - t * cap / 100.0;
       f1 = static_cast<float>(-c1 * k);
       f2 = static_cast<float>(c2 * k);
-      split = __builtin_fabs(b) < 8388607.0;
-      if (!split) b = __builtin_nan("");  // beyond the exact float32 integer range: always the exact path
+      split = __builtin_fabs(b) < 8388607.0 && c1 * k >= kAmbMinSlope && c2 * k >= kAmbMinSlope;
+      if (!split) b = __builtin_nan("");  // beyond the exact float32 integer range (or a slope so flat that runs of pod values are ambiguous): always the exact path
     }
   }
   // u = (pod + b2h) + b2l: the first add is exact (two integers below 2^23), the second rounds once — the same
@@ -336,6 +338,43 @@ __global__ void k_tlp_prepare_fast(TrimaranArgs a, int64_t n_slots, double c1, d
   const double bh = split ? __builtin_rint(b) : b;
   reinterpret_cast<float4*>(a.tlp_fast)[tile_slot<kTlpNpl>(n)] =
       float4{static_cast<float>(bh), split ? static_cast<float>(b - bh) : 0.0f, f1, f2};
+}
+
+// Which (pod value, node tile) pairs hold a cell the float32 sweep cannot prove (k_tlp_fast2<..., AMB>).  Per node the unrounded
+// score is x(p) = T - c1*k*u (u > 0), 100 + c2*k*u (u <= 0), u = p + b, p the pod's integer millicores: x comes within the
+// tolerance tau of a rounding tie h = 0.5, 1.5, ... 99.5 only for the integers next to the real solution p* of x(p*) = h, and only
+// when |p* - rint(p*)| * slope < tau; the branch point is ambiguous for the one integer within kTolU of -b.  One thread per (node,
+// h, branch); a hit sets bit (tile & 31) of amb[p].  Conservative by the factor kAmbMargin (a superset costs speed, not results):
+// an unflagged cell has |frac(x) - 0.5| >= 1.25 * 4e-5 > the float32 formula's error bound 1.7e-5 and |u| >= 2e-6.  A node whose
+// slope is below 2.5 * tau (more than ~10^6 millicores of capacity) could be ambiguous for runs of integers: k_tlp_prepare_fast
+// sends such nodes to the always-exact path instead.
+__global__ __launch_bounds__(256) void k_tlp_amb_build(TrimaranArgs a, double c1, double c2, int tile_nodes) {
+  const int64_t n = blockIdx.x;
+  const int j = threadIdx.x;
+  if (n >= a.n_nodes || a.tlp_valid[n] == 0 || j > 200) return;
+  const double t = a.tlp_target;
+  const double cap = static_cast<double>(a.cap_cpu_milli[n]);
+  const double um = (a.tlp_cpu_util[n] / 100.0) * cap;
+  const double miss = static_cast<double>(a.tlp_missing_milli[n]);
+  if (!(cap > 0.0) || !(um >= 0.0) || !(miss >= 0.0) || !(um < 1e15) || !(miss < 1e15)) return;  // cap == 0: x = T for every pod; the others: always exact
+  const double k = 100.0 / cap;
+  const double b = (um + miss) - t * cap / 100.0;
+  double p_star, slope;
+  if (j < 100) {  // u > 0: T - c1*k*u = h
+    slope = c1 * k;
+    p_star = (t - (j + 0.5)) / slope - b;
+  } else if (j < 200) {  // u <= 0: 100 + c2*k*u = h
+    slope = c2 * k;
+    p_star = ((j - 100 + 0.5) - 100.0) / slope - b;
+  } else {  // the branch point u = 0
+    slope = 2e-6 / (4e-5 * kAmbMargin);  // |p + b| < 2e-6 (kTolU is 1e-6)
+    p_star = -b;
+  }
+  const double pn = __builtin_rint(p_star);
+  if (!(__builtin_fabs(p_star - pn) * slope < 4e-5 * kAmbMargin)) return;
+  if (!(pn >= 0.0) || !(pn < static_cast<double>(a.tlp_amb_size))) return;
+  const uint32_t bit = 1u << (static_cast<uint32_t>(n / tile_nodes) & 31u);
+  atomicOr(a.tlp_amb + static_cast<int64_t>(pn), bit);
 }
 
 // Decisions-only mode (template flag D): nothing is written to the score tables; each wave folds the weighted sum
@@ -412,7 +451,14 @@ __device__ __forceinline__ uint32_t tlp_cell_exact(const TrimaranArgs& a, int64_
   return zero ? 0u : to_u8(x);
 }
 
-template <int NPL, bool A, bool D = false>
+// AMB (round 5): the ambiguity bookkeeping leaves the cell.  Which (node, pod value) pairs can be ambiguous is a property of the
+// node alone — the score is piecewise linear in the pod's integer millicores, so it comes within the tolerance of a rounding tie
+// only at isolated integers (k_tlp_amb_build lists them, per launch, as a bit per (pod value, node tile)).  A row whose pod value
+// has no such node in this wave's tile runs the streamlined cell: add, add, compare, fma, select, v_cvt_pk_u8_f32 (which rounds to
+// nearest even and clamps by itself: tools/micro/cvt_pk_u8.hip) — 5 instructions instead of ~9.5; the other rows (~8 % of the
+// (row, tile) pairs on continuous inputs), rows of pods outside the table and waves holding an always-exact node take the
+// checked cell exactly as before.
+template <int NPL, bool A, bool D = false, bool AMB = false>
 __global__ __launch_bounds__(kWave* kWavesPerBlock, D ? 3 : 1) void k_tlp_fast2(TrimaranArgs a, int n_tiles, double c1, double c2, DecideArgs dec) {
   SPX_RESOLVE_ROWS(a);
   static_assert(kPodsPerChunk == kWave, "one pod record per lane");
@@ -432,6 +478,10 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock, D ? 3 : 1) void k_tlp_fast2(
   const int64_t my_pod_i = (lane < n_rows) ? a.tlp_pod_milli[pod0 + lane] : 0;
   const int pod_bits = __float_as_int(static_cast<float>(my_pod_i));
   const int pod_bad = (my_pod_i < 0 || my_pod_i >= (1 << 23)) ? 1 : 0;
+  int pod_slow = 1;  // this row takes the checked cell in this tile
+  if constexpr (AMB) {
+    if (lane < n_rows && !pod_bad && my_pod_i < a.tlp_amb_size) pod_slow = static_cast<int>((a.tlp_amb[my_pod_i] >> (tile & 31)) & 1u);
+  }
 
   uint32_t alloc_w[NPL / 4];
   // b2 = b2h + b2l, b2h integer-valued with |b2h| < 2^23, |b2l| <= 0.5 — kept as pairs of nodes so that the two adds
@@ -479,6 +529,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock, D ? 3 : 1) void k_tlp_fast2(
   const float tf = static_cast<float>(t);
   constexpr float kHalf = 0.5f - kTol32;
   unsigned reevaluated = 0;  // cells this lane sent through the exact path (spx_fetch_stats), flushed once per wave
+  const bool wave_nan = AMB ? __ballot(lane_nan) != 0 : true;  // a node that always takes the exact path: every row of the wave is checked
 
   for (int r = 0; r < n_rows; ++r) {
     const int64_t row = (pod0 + r) * a.row_stride + node0;
@@ -489,8 +540,30 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock, D ? 3 : 1) void k_tlp_fast2(
     const bool row_bad = __builtin_amdgcn_readlane(pod_bad, r) != 0;
     bool any = row_bad;
     uint32_t w[NPL / 4];
+    uint32_t tb[D ? NPL : 1];  // decisions-only mode: the byte of each cell on its own (the table mode packs four per dword)
     const F32x2 pod2{pod_f, pod_f};
     const F32x2 off2{tf, 100.0f};
+    const bool row_slow = !AMB || wave_nan || __builtin_amdgcn_readlane(pod_slow, r) != 0;  // wave-uniform
+    if (!row_slow) {
+      // streamlined: no cell of this row in this tile can be ambiguous (k_tlp_amb_build), so the float32 value rounds to the
+      // reference's integer — nothing to track
+#pragma unroll
+      for (int j = 0; j < NPL / 4; ++j) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = j * 4 + q;
+          const F32x2 u2 = (pod2 + b2h[i >> 1]) + b2l[i >> 1];
+          const float u = u2[i & 1];
+          const bool gt = __float_as_int(u) > 0;
+          const F32x2 x12 = __builtin_elementwise_fma(kc[i], F32x2{u, u}, off2);
+          const float x = gt ? x12.x : x12.y;
+          if constexpr (D) tb[i] = __builtin_amdgcn_cvt_pk_u8_f32(x, 0, 0u);
+          else acc = __builtin_amdgcn_cvt_pk_u8_f32(x, q, acc);
+        }
+        w[j] = acc;
+      }
+    } else {
     // one cell: rounded float32 score and whether it is provably the reference's result
     auto cell = [&](int i, const F32x2& pod2, float* rr) -> bool {
       const F32x2 u2 = (pod2 + b2h[i >> 1]) + b2l[i >> 1];  // shared by the two cells of the pair
@@ -505,7 +578,6 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock, D ? 3 : 1) void k_tlp_fast2(
     // cell) instead of 32 compares and a chain of lane-mask ORs; NaN cells (nodes outside the float32 range) are
     // invisible to max/min and are flagged per lane by lane_nan
     float worst = 0.0f, minu = 1e30f;
-    uint32_t tb[D ? NPL : 1];  // decisions-only mode: the byte of each cell on its own (the table mode packs four per dword)
 #pragma unroll
     for (int j = 0; j < NPL / 4; ++j) {
       uint32_t acc = 0;
@@ -552,6 +624,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock, D ? 3 : 1) void k_tlp_fast2(
         }
       }
     }
+    }  // checked row
     if constexpr (!D) {
       if (active) store_bytes<NPL>(a.out_tlp + row, w);
     } else {
@@ -856,6 +929,15 @@ void launch_alloc_prepare(const AllocPrepArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_alloc_prepare, dim3(1), dim3(1024), 0, s, a);
 }
 
+// the per-launch table of k_tlp_fast2<..., AMB>: cleared and rebuilt (the node columns may have changed since the last launch: deltas,
+// commits).  Worth it for multi-row launches only; a single-row launch (the commit loop's: row_ptr) keeps the checked cell.
+static bool tlp_amb_prepare(const TrimaranArgs& a, int64_t rows, double c1, double c2, int tile_nodes, hipStream_t s) {
+  if (!a.tlp_amb || a.tlp_amb_size <= 0 || a.row_ptr || rows < 256 || (a.opts & kOptTlpNoAmbTable)) return false;
+  (void)hipMemsetAsync(a.tlp_amb, 0, static_cast<size_t>(a.tlp_amb_size) * 4, s);
+  hipLaunchKernelGGL(k_tlp_amb_build, dim3(static_cast<unsigned>(a.n_nodes)), dim3(256), 0, s, a, c1, c2, tile_nodes);
+  return true;
+}
+
 template <int NPL>
 void launch_tlp_fast(const TrimaranArgs& a, hipStream_t s) {
   const int tile_nodes = kWave * NPL;
@@ -867,6 +949,13 @@ void launch_tlp_fast(const TrimaranArgs& a, hipStream_t s) {
   const double c1 = t / (100.0 - t), c2 = (100.0 - t) / t;
   const int64_t n_slots = static_cast<int64_t>(n_tiles) * tile_nodes;
   hipLaunchKernelGGL(k_tlp_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots, c1, c2);
+  if (tlp_amb_prepare(a, rows, c1, c2, tile_nodes, s)) {
+    if (a.out_alloc)
+      hipLaunchKernelGGL((k_tlp_fast2<NPL, true, false, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, DecideArgs{});
+    else
+      hipLaunchKernelGGL((k_tlp_fast2<NPL, false, false, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, DecideArgs{});
+    return;
+  }
   if (a.out_alloc)
     hipLaunchKernelGGL((k_tlp_fast2<NPL, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, DecideArgs{});
   else
@@ -943,7 +1032,12 @@ void launch_decide_trimaran(const DecideLaunch& d, hipStream_t s) {
   dec.ties = reinterpret_cast<int32_t*>(dec.key + static_cast<int64_t>(n_tiles) * rows);
   dec.rows = rows;
   hipLaunchKernelGGL(k_tlp_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots, c1, c2);
-  if (d.use_alloc)
+  if (tlp_amb_prepare(a, rows, c1, c2, tile_nodes, s)) {
+    if (d.use_alloc)
+      hipLaunchKernelGGL((k_tlp_fast2<NPL, true, true, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, dec);
+    else
+      hipLaunchKernelGGL((k_tlp_fast2<NPL, false, true, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, dec);
+  } else if (d.use_alloc)
     hipLaunchKernelGGL((k_tlp_fast2<NPL, true, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, dec);
   else
     hipLaunchKernelGGL((k_tlp_fast2<NPL, false, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, dec);

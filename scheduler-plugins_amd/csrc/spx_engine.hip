@@ -54,7 +54,7 @@ struct spx_engine {
   int64_t row_stride = 0;
 
   // spx_set_option state (per engine; nothing is read from the environment)
-  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1, 0};
+  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1, 0, 1};
 
   // params
   int32_t alloc_mode = SPX_MODE_LEAST;
@@ -76,6 +76,7 @@ struct spx_engine {
   DevBuf d_raw_row;  // int64 [n_nodes] staging for spx_fetch_raw
   DevBuf d_lv_exact; // double [n_nodes][8] scratch of the LVRB fast kernel
   DevBuf d_lv_fast, d_tlp_fast;  // float32 per-node constants of the fast sweeps (recomputed per launch)
+  DevBuf d_tlp_amb;              // k_tlp_amb_build's table: per pod value, the node tiles holding a cell the float32 sweep cannot prove
   DevBuf d_commit;               // scratch of spx_commit_sequential
   DevBuf d_decide;               // per-tile partial decisions of spx_decide
   DevBuf d_stats;                // uint64 [SPX_NUM_PLUGINS]: cells re-evaluated by the fast sweeps' exact fallback
@@ -339,6 +340,7 @@ uint32_t launch_opts(const spx_engine* e) {
   if (e->option[SPX_OPT_COMMIT_FROM_MEMORY]) o |= spx::kOptCommitFromMemory;
   if (e->option[SPX_OPT_PEAKS_TILE] / 10 == 8) o |= spx::kOptPeaksWideA;
   if (e->option[SPX_OPT_PEAKS_TILE] % 10 == 8) o |= spx::kOptPeaksWideB;
+  if (!e->option[SPX_OPT_TLP_AMB_TABLE]) o |= spx::kOptTlpNoAmbTable;
   return o;
 }
 
@@ -582,7 +584,7 @@ int spx_destroy(spx_engine* e) {
   DevBuf* bufs[] = {&e->d_alloc,   &e->d_alloc_w,  &e->d_alloc_raw, &e->d_alloc_norm, &e->d_alloc_rel, &e->d_cap_cpu, &e->d_tlp_util,
                     &e->d_tlp_missing, &e->d_tlp_valid, &e->d_lv_acpu, &e->d_lv_amem, &e->d_lv_cavg, &e->d_lv_cstd,
                     &e->d_lv_mavg, &e->d_lv_mstd,  &e->d_lv_flags,  &e->d_tlp_pod,    &e->d_lv_rcpu, &e->d_lv_rmem,
-                    &e->d_raw_row,   &e->d_lv_exact, &e->d_lv_fast, &e->d_tlp_fast, &e->d_commit, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
+                    &e->d_raw_row,   &e->d_lv_exact, &e->d_lv_fast, &e->d_tlp_fast, &e->d_tlp_amb, &e->d_commit, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
                     &e->d_nrt_frcv, &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_ln, &e->d_nrt_fbraw, &e->d_nrt_redo,
@@ -647,6 +649,7 @@ int spx_set_option(spx_engine* e, int option, int64_t value) {
     case SPX_OPT_COMMIT_COOP:
     case SPX_OPT_NRT_RANK_FILTER:
     case SPX_OPT_ROW_WORKGROUP:
+    case SPX_OPT_TLP_AMB_TABLE:
       if (value != 0 && value != 1) return fail(e, SPX_ERR_ARG, "option takes 0 or 1");
       break;
     case SPX_OPT_NRT_LN_LIST_PERMILLE:
@@ -2105,6 +2108,9 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (T) {
     if ((rc = ensure(e, e->d_tlp_fast, static_cast<size_t>(spx::round_up(e->row_stride, 1024)) * 4 * sizeof(float)))) return rc;
     a.tlp_fast = static_cast<float*>(e->d_tlp_fast.p);
+    if ((rc = ensure(e, e->d_tlp_amb, static_cast<size_t>(spx::kTlpAmbSize) * 4))) return rc;
+    a.tlp_amb = static_cast<uint32_t*>(e->d_tlp_amb.p);
+    a.tlp_amb_size = spx::kTlpAmbSize;
   }
   if (!e->hold_ev0) SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
   if (Q) {
@@ -3310,6 +3316,9 @@ int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t r
   d.t.row_begin = row_begin;
   d.t.row_end = row_end;
   d.t.tlp_fast = static_cast<float*>(e->d_tlp_fast.p);
+  if ((rc = ensure(e, e->d_tlp_amb, static_cast<size_t>(spx::kTlpAmbSize) * 4))) return rc;
+  d.t.tlp_amb = static_cast<uint32_t*>(e->d_tlp_amb.p);
+  d.t.tlp_amb_size = spx::kTlpAmbSize;
   d.use_alloc = use_alloc;
   d.w_alloc = static_cast<int32_t>(use_alloc ? wa : 0);
   d.w_tlp = static_cast<int32_t>(wt);

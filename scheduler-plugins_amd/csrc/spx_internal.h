@@ -41,6 +41,7 @@ enum : uint32_t {
   kOptCommitFromMemory = 1u << 4,  // commit loop: node state in memory
   kOptPeaksWideA = 1u << 5,        // Peaks: 8 nodes per lane in the min/max pass
   kOptPeaksWideB = 1u << 6,        // Peaks: 8 nodes per lane in the write pass
+  kOptTlpNoAmbTable = 1u << 7,     // TLP fast sweep: per-cell exactness bookkeeping in every row (SPX_OPT_TLP_AMB_TABLE 0)
 };
 
 // what the multi-device layer (spx_multi.hip) needs to see of an engine
@@ -69,6 +70,8 @@ struct AllocPrepArgs {
   uint32_t* rel;           // [row_stride + 1] out: raw - global min as uint32, then a flag: 1 when that form is exact
 };
 void launch_alloc_prepare(const AllocPrepArgs& a, hipStream_t s);
+
+constexpr int32_t kTlpAmbSize = 1 << 16;  // pod values (millicores) k_tlp_amb_build's table covers; larger pods take the checked cell
 
 // ---------------------------------------------------------------- fused Allocatable + TLP + LVRB sweep
 struct TrimaranArgs {
@@ -102,6 +105,8 @@ struct TrimaranArgs {
   double* lv_exact;  // scratch [n_nodes][8]: per-node exact LVRB state for the fast kernel's fallback
   float* lv_fast;    // scratch [ceil(row_stride/512)*512][8]: LVRB fast constants, tile-transposed (k_lvrb_prepare_fast)
   float* tlp_fast;   // scratch [ceil(row_stride/1024)*1024][4]: TLP fast constants, tile-transposed (k_tlp_prepare_fast)
+  uint32_t* tlp_amb;     // scratch [tlp_amb_size]: per pod value, the node tiles (bit tile & 31) holding a cell the float32 sweep cannot prove (k_tlp_amb_build); NULL = checked cells everywhere
+  int32_t tlp_amb_size;  // pod values at or above it take the checked cell
   unsigned long long* stats;  // [SPX_NUM_PLUGINS][kStatSlots][kStatStride] cells the fast sweeps re-evaluated with the reference sequence (spx_fetch_stats); may be NULL
   // outputs: uint8 [n_pods][row_stride] each (NULL = plugin not evaluated)
   uint8_t* out_alloc;
