@@ -218,3 +218,52 @@ def test_config2_full_size_properties(gpu_required, hdr, oracle):
         for j in rng.integers(0, n_nodes, 200):
             col = tab[:, j]
             assert (np.diff(col[: peak[j] + 1]) >= 0).all() and (np.diff(col[peak[j]:]) <= 0).all()
+
+
+# ------------------------------------------------------------------ round 5: the ambiguity table of the TLP sweep
+@pytest.mark.parametrize("n_nodes,n_pods,round_frac,target", [(2_500, 1_000, 0.5, 40), (40_000, 600, 0.3, 40), (1_100, 5_000, 1.0, 73), (3_000, 700, 0.0, 1)])
+def test_tlp_ambiguity_table_equals_checked_cells_and_oracle(gpu_required, hdr, oracle, n_nodes, n_pods, round_frac, target):
+    """k_tlp_fast2<..., AMB> (SPX_OPT_TLP_AMB_TABLE, default on; multi-row launches of >= 256 rows) against the per-cell bookkeeping
+    (option off) and the oracle, on snapshots built to be full of exact rounding ties (integer-valued metrics on `round_frac` of the
+    nodes), with more than 32 node tiles (bit tile & 31 is shared), targets other than the default, pods at and beyond the table's
+    end (65 535 / 65 536 / 70 000 millicores), beyond float32 integers (2^23), zero and default requests, a row range that does not
+    start at 0 — tables and decisions byte for byte"""
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=11 + n_nodes, round_frac=round_frac)
+    # absurd cpu values patched into the first pods of the batch (first container carries the value, the others 0)
+    pods = snap["pods"]
+    cp, qp, lp = pods.array("ctr_ptr"), pods.array("req_ptr"), pods.array("lim_ptr")
+    for i, m in enumerate((0, 1, 65_535, 65_536, 70_000, 1 << 23, (1 << 23) - 1, 40_000, 65_534)):
+        for c in range(cp[i], cp[i + 1]):
+            for ptr, rs, qt in ((qp, pods.array("req_res"), pods.array("req_qty")), (lp, pods.array("lim_res"), pods.array("lim_qty"))):
+                for k in range(ptr[c], ptr[c + 1]):
+                    if rs[k] == 0:
+                        qt[k] = m if c == cp[i] else 0
+    got = {}
+    with Engine(0) as e:
+        e.set_tlp(target_utilization=target)
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], pods, snap["metrics"], snap["assigned"])
+        pod_milli = e.flatten_trimaran_pods(pods)["tlp_pod_milli"]
+        assert (pod_milli >= 65_536).any() and (pod_milli >= (1 << 23)).any()
+        for opt in (1, 0):
+            e.set_option("TLP_AMB_TABLE", opt)
+            e.stats(reset=True)
+            e.eval(mask_of(ALLOCATABLE, TLP))
+            e.sync()
+            t = e.all_scores(TLP)
+            n_re = int(e.stats()[TLP])
+            e.eval(mask_of(TLP), 3, n_pods)   # a range that starts inside a chunk
+            e.sync()
+            assert np.array_equal(e.all_scores(TLP), t)
+            e.decide(mask_of(ALLOCATABLE, TLP))
+            e.sync()
+            got[opt] = (t, e.best(), n_re)
+        osnap = oracle.Snapshot(snap["nodes"], pods, rc=snap["rc"], metrics=snap["metrics"], assigned=snap["assigned"], alloc_params=e.alloc_params,
+                                tlp_params=tlp_params(hdr, target_utilization=target))
+    want = osnap.score_rows(TLP, threads=oracle.usable_cpus(), want_norm=False)[0]
+    for opt in (1, 0):
+        assert np.array_equal(got[opt][0].astype(np.int64), want), opt
+    for x, y in zip(got[1][1], got[0][1]):
+        assert np.array_equal(x, y)
+    # both forms re-evaluated cells (the snapshots are tie-heavy), and the table form did not re-evaluate fewer than it had to
+    if round_frac > 0:
+        assert got[0][2] > 0 and got[1][2] > 0
