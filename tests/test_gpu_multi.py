@@ -134,3 +134,75 @@ def test_errors(gpu_required, hdr):
         m.allgather_table(TLP)
         with pytest.raises(spx.SpxError, match="rank 0"):
             m.eval(mask_of(NRT))  # NRT tables were never uploaded: the failing rank's message comes back
+
+
+# ------------------------------------------------------------------ round 5: eight ranks at the sizes BASELINE states for 8 GPUs
+def _eight():
+    g = n_gpus()
+    return (list(range(8)), RCCL, "rccl-8") if g >= 8 else ([0] * 8, PEER_COPY, "copy-8-on-dev0")
+
+
+def test_config4_eight_ranks_table_gather(gpu_required, hdr):
+    """BASELINE config #4 as stated for 8 GPUs — NetworkOverhead, 10 000 nodes x 200 000 pods, 25 000 rows per rank — through spx_multi:
+    the all-gathered decisions and EVERY byte of the all-gathered 2 GB score and status tables (as rank 0 and rank 7 hold them) equal
+    one engine evaluating the whole batch.  Eight RCCL ranks when the box has eight devices, eight ranks on device 0 over peer copies
+    otherwise (the code path, not a scaling number)."""
+    devices, transport, _ = _eight()
+    n_nodes, n_pods = 10_000, 200_000
+    snap = synth.network_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED)
+    mask = mask_of(NETOVERHEAD)
+    with Engine(0) as ref:
+        ref.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+        ref.eval(mask)
+        ref.eval_best(mask)
+        ref.sync()
+        want_best = ref.best()
+        with MultiEngine(devices, transport) as m:
+            m.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+            assert [m.shard(r) for r in range(8)] == [(r * 25_000, (r + 1) * 25_000) for r in range(8)]
+            m.bind_global_table(NETOVERHEAD)
+            m.bind_global_table(NETOVERHEAD, status=True)
+            m.eval(mask)
+            m.eval_best(mask)
+            for a, b in zip(m.gather_best(), want_best):
+                assert np.array_equal(a, b)
+            m.allgather_table(NETOVERHEAD)
+            m.allgather_table(NETOVERHEAD, status=True)
+            m.sync()
+            bad = 0
+            for r0 in range(0, n_pods, 20_000):
+                r1 = min(n_pods, r0 + 20_000)
+                want_sc, want_st = ref.all_scores(NETOVERHEAD, r0, r1), ref.all_status(NETOVERHEAD, r0, r1)
+                for rank in (0, 7):
+                    bad += int((m.global_rows(NETOVERHEAD, rank, r0, r1) != want_sc).sum())
+                    bad += int((m.global_rows(NETOVERHEAD, rank, r0, r1, status=True) != want_st).sum())
+            assert bad == 0
+            assert (want_best[3] < n_nodes).any()   # some rows lost nodes to the Filter
+
+
+def test_config5_eight_ranks_decisions(gpu_required, hdr):
+    """BASELINE config #5 as stated for 8 GPUs — the full profile, 20 000 nodes x 500 000 pods, 62 500 rows per rank (seven 1.25 GB
+    tables each) — through spx_multi with the practical exchange (per-pod decisions, 20 B per pod): all 500 000 decisions, and the
+    CapacityScheduling verdicts with the nominated pods' batch rows rebased per shard, equal ONE engine holding the whole batch (the
+    N = 1 anchor of tests/test_gpu_commit_full.py).  ~150 GB of tables on one device when the box has no eight."""
+    devices, transport, _ = _eight()
+    n_nodes, n_pods = 20_000, 500_000
+    snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED, quota_sized_for_batch=True)
+    with Engine(0) as ref:
+        load_full(ref, hdr, snap)
+        ref.set_plugin_weights(WEIGHTS)
+        ref.decide(mask_of(*ALL))
+        ref.sync()
+        want_best = ref.best()
+        want_pre = ref.prefilter(CAPACITY)
+    with MultiEngine(devices, transport) as m:
+        m.for_all(lambda e: e.set_plugin_weights(WEIGHTS))
+        load_full(m, hdr, snap)
+        assert [m.shard(r) for r in range(8)] == [(r * 62_500, (r + 1) * 62_500) for r in range(8)]
+        m.decide(mask_of(*ALL))
+        got = m.gather_best()
+        for a, b, what in zip(got, want_best, ("node", "score", "ties", "feasible")):
+            assert np.array_equal(a, b), (what, int((a != b).sum()))
+        pre = np.concatenate([e.prefilter(CAPACITY) for e in m.engines])
+        assert np.array_equal(pre, want_pre)
+        assert 0 < (want_best[0] < 0).sum() < n_pods
