@@ -814,6 +814,13 @@ def main() -> None:
         out["full_cycle"] = full_cycle
     if mode == "multi":
         out["host_load"] = host_load
+        try:  # how many ranks the exchange's communicator has, as RCCL itself reports it (0: peer copies)
+            out["collective"] = {"transport": args.transport, "rccl_ranks": target.rccl_ranks()}
+        except Exception as ex:
+            out["collective"] = {"error": repr(ex)[:200]}
+    elif mode == "ranks":
+        out["collective"] = {"backend": args.dist_backend, "ranks": int(dist.get_world_size()),
+                             "what": "torch.distributed process group the decisions / table are all-gathered on (nccl = RCCL over xGMI)"}
     if world > 1:
         out["n_gt_1_hardware"] = ("no figure on more than one MI355X exists for this repository: the build box has one device; lines with several ranks "
                                   "on one device exercise the code path, not the scaling") if (len(set(devices)) == 1 or torch.cuda.device_count() < world) else "one rank per device"

@@ -820,6 +820,9 @@ int spx_multi_destroy(spx_multi* m);
 const char* spx_multi_last_error(const spx_multi* m);
 int spx_multi_size(const spx_multi* m);
 int spx_multi_engine(spx_multi* m, int rank, spx_engine** out);
+/* ranks of the RCCL communicator the exchange runs on, as RCCL reports it (ncclCommCount of rank 0's communicator after
+ * ncclCommInitAll); 0 with the peer-copy transport.  bench.py prints it so that a scaling record shows how many ranks RCCL saw */
+int spx_multi_rccl_ranks(const spx_multi* m);
 /* rank's rows of a batch of n_pods_total pending pods: [rank * per, (rank + 1) * per) clipped to the batch, per = ceil(n / size) */
 int spx_multi_shard(const spx_multi* m, int64_t n_pods_total, int rank, int64_t* row_begin, int64_t* row_end);
 /* every rank: spx_eval / spx_eval_best / spx_decide over all of its local rows, issued concurrently, asynchronous */

@@ -167,6 +167,7 @@ struct spx_engine {
   int32_t net_n_keys = 0;
   DevBuf d_commit_save;  // backup of every table the commit loop mutates
   DevBuf d_coop_sync, d_coop_node, d_coop_max;  // cooperative commit kernel: granules + error flag, the workgroups' private pair lists
+  bool in_commit_loop = false;  // commit_with_filters' per-pod launches are running on mutated zone tables (fill_nrt)
   int coop_gave_up = 0;      // cooperative commit launches that ended with a workgroup giving up (served by the per-pod loop instead)
   int last_commit_path = 0;  // what the last spx_commit_sequential ran: 1 one-workgroup trimaran chain, 2 per-pod launches, 3 cooperative kernel
   DevBuf d_row_counter;  // int64: the row the replayed per-pod graph works on
@@ -456,6 +457,10 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   na.perm = static_cast<const int32_t*>(e->d_nrt_perm.p);
   na.stats = static_cast<unsigned long long*>(e->d_stats.p);
   na.exact32_slots = ~(e->nrt_big_nodes | e->nrt_big_pods);
+  // inside the per-pod commit loop k_commit_apply subtracts requests from the zone table: "every quantity is a float32 value" is
+  // not closed under subtraction (2^30 and 1 are, 2^30 - 1 is not) and the masks above describe the uploaded tables, so
+  // BalancedAllocation's float32 "request > capacity" test gives way to the undecided -> float64 redo route there
+  if (e->in_commit_loop) na.exact32_slots = 0;
   na.redo_list = static_cast<uint32_t*>(e->d_nrt_redo.p);
   na.redo_cap = e->nrt_redo_cap;
   na.ln_tab = (e->nrt_ln_ok && e->nrt_ln_built) ? static_cast<const uint32_t*>(e->d_nrt_ln.p) : nullptr;
@@ -920,6 +925,12 @@ int spx_update_quota_used(spx_engine* e, int64_t n_rows, const int32_t* ns, cons
   constexpr size_t S = SPX_QUOTA_SLOTS;
   for (int64_t i = 0; i < n_rows; ++i)
     if (ns[i] < 0 || ns[i] >= e->q_n_namespaces) return fail(e, SPX_ERR_ARG, "quota delta: namespace index out of range");
+  {
+    // two rows for one namespace would be scattered in unspecified order (d_q_used and d_q_usedp could end up from different rows)
+    std::vector<int32_t> seen(ns, ns + n_rows);
+    std::sort(seen.begin(), seen.end());
+    if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return fail(e, SPX_ERR_ARG, "quota delta: a namespace is listed twice");
+  }
   const size_t m = static_cast<size_t>(n_rows);
   int64_t agg[SPX_QUOTA_SLOTS + 1];
   std::memcpy(agg, agg_used, sizeof e->q_agg_used);
@@ -2534,6 +2545,11 @@ int commit_with_filters(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, 
     if (ran) return SPX_OK;
   }
   e->last_commit_path = 2;
+  struct LoopFlag {
+    spx_engine* e;
+    explicit LoopFlag(spx_engine* x) : e(x) { e->in_commit_loop = true; }
+    ~LoopFlag() { e->in_commit_loop = false; }
+  } loop_flag(e);
   // ---- save what the loop mutates
   struct Saved {
     DevBuf* buf;

@@ -37,6 +37,7 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;  // optional: only spx_multi_rccl_ranks asks
 
   bool load(std::string* why) {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -54,6 +55,7 @@ struct Rccl {
     GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
     GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    CommCount = reinterpret_cast<decltype(CommCount)>(sym("ncclCommCount"));
     if (!CommInitAll || !CommDestroy || !AllGather || !GroupStart || !GroupEnd || !GetErrorString) {
       *why = "librccl.so.1 lacks an expected symbol";
       return false;
@@ -348,6 +350,14 @@ int spx_multi_engine(spx_multi* m, int rank, spx_engine** out) {
   if (rank < 0 || rank >= m->n) return mfail(m, SPX_ERR_ARG, "rank out of range");
   *out = m->engine[static_cast<size_t>(rank)];
   return SPX_OK;
+}
+
+int spx_multi_rccl_ranks(const spx_multi* m) {
+  if (!m) return SPX_ERR_ARG;
+  if (!m->rccl_ready || m->comm.empty()) return 0;  // peer-copy transport
+  int n = static_cast<int>(m->comm.size());
+  if (m->rccl.CommCount && m->rccl.CommCount(m->comm[0], &n) != ncclSuccess) return SPX_ERR_HIP;
+  return n;
 }
 
 int spx_multi_shard(const spx_multi* m, int64_t n_pods_total, int rank, int64_t* row_begin, int64_t* row_end) {

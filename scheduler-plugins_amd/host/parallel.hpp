@@ -6,10 +6,14 @@
 // are up to eight of them (one per 16 hardware threads), so that concurrent callers — the ranks of a multi-device engine each
 // flattening their own pod rows, several cgo threads — each get workers; a caller that finds every pool busy (or a nested call)
 // runs its rows inline, which is always correct.  Rows are handed out in chunks from an atomic counter, the calling thread works
-// too.  After a fork() the child starts pools of its own (the parent's threads do not exist there).  Never destroyed: the workers
-// sleep on a condition variable until exit.
+// too.  After a fork() the child starts pools of its own (pthread_atfork: the parent's threads do not exist there, and the registry's
+// lock is not inherited mid-operation).  Never destroyed: the workers sleep on a condition variable until exit — a process that
+// dlclose()s libspx.so while they are parked would leave them in unmapped code; the library is meant to stay loaded (as cgo keeps it).
+// Round 5 (advisor): the busy flag is an atomic with an RAII release (a std::mutex try_lock'ed by its owner is undefined behaviour), a
+// thread running a pool job runs nested calls inline, a failed thread creation shrinks the job instead of escaping the extern "C" caller.
 #pragma once
 
+#include <pthread.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -17,6 +21,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -28,22 +33,19 @@ class RowPool {
   static constexpr int kMaxPools = 8;
   // the process's pools: [0, *n)
   static RowPool* const* all(int* n) {
-    static std::mutex guard;
-    static RowPool* pools[kMaxPools] = {};
-    static int count = 0;
-    static pid_t owner = 0;
-    std::lock_guard<std::mutex> lk(guard);
-    if (count == 0 || owner != getpid()) {  // (a forked child leaks the parent's objects: their threads are gone)
+    Registry& r = registry();
+    std::lock_guard<std::mutex> lk(r.guard);
+    if (r.count == 0) {
       const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-      count = static_cast<int>(std::min<unsigned>(kMaxPools, std::max(1u, hw / 16)));
-      for (int i = 0; i < count; ++i) pools[i] = new RowPool;
-      owner = getpid();
+      r.count = static_cast<int>(std::min<unsigned>(kMaxPools, std::max(1u, hw / 16)));
+      for (int i = 0; i < r.count; ++i) r.pools[i] = new RowPool;
     }
-    *n = count;
-    return pools;
+    *n = r.count;
+    return r.pools;
   }
-  // the job on the first pool that is free; false = all busy, nothing was run
+  // the job on the first pool that is free; false = all busy (or this thread is itself running a pool job), nothing was run
   static bool run_any(void (*fn)(void*, int64_t, int64_t), void* ctx, int64_t n, int64_t chunk, unsigned threads) {
+    if (inside_job()) return false;  // a nested parallel_rows runs inline: the outer job already has the workers
     int count = 0;
     RowPool* const* pools = all(&count);
     for (int i = 0; i < count; ++i)
@@ -54,12 +56,21 @@ class RowPool {
   // fn(ctx, begin, end) over [0, n) in chunks of `chunk` rows on up to `threads` threads (the caller is one of them);
   // false = the pool is busy, nothing was run
   bool run(void (*fn)(void*, int64_t, int64_t), void* ctx, int64_t n, int64_t chunk, unsigned threads) {
-    if (!busy_.try_lock()) return false;
+    if (busy_.exchange(true, std::memory_order_acquire)) return false;
+    struct Release {  // also on an exception out of fn (the flatteners are extern "C": nothing may stay locked behind them)
+      std::atomic<bool>& b;
+      ~Release() { b.store(false, std::memory_order_release); }
+    } release{busy_};
     {
       std::lock_guard<std::mutex> lk(mu_);
       while (workers_.size() + 1 < threads) {
         const unsigned id = static_cast<unsigned>(workers_.size());
-        workers_.emplace_back([this, id] { work(id); });
+        try {
+          workers_.emplace_back([this, id] { work(id); });
+        } catch (const std::system_error&) {  // no more threads to be had: this job runs with the helpers that exist
+          threads = static_cast<unsigned>(workers_.size()) + 1;
+          break;
+        }
         workers_.back().detach();
       }
       fn_ = fn, ctx_ = ctx, n_ = n, chunk_ = chunk;
@@ -69,15 +80,54 @@ class RowPool {
       ++gen_;
     }
     cv_.notify_all();
+    struct Join {  // the helpers are inside fn_ with this call's ctx: wait for them whatever happens to the caller's own share
+      RowPool* p;
+      ~Join() {
+        std::unique_lock<std::mutex> lk(p->mu_);
+        p->done_.wait(lk, [this] { return p->pending_ == 0; });
+      }
+    } join{this};
+    inside_job() = true;
+    struct Leave {
+      ~Leave() { inside_job() = false; }
+    } leave;
     drain();
-    {
-      std::unique_lock<std::mutex> lk(mu_);
-      done_.wait(lk, [this] { return pending_ == 0; });
-    }
-    busy_.unlock();
     return true;
   }
 
+ private:
+  struct Registry {
+    std::mutex guard;
+    RowPool* pools[kMaxPools] = {};
+    int count = 0;
+  };
+  // fork(): the child must not inherit `guard` locked by a thread that does not exist there, nor pools whose workers are gone —
+  // the prepare handler takes the lock (so no other thread holds it across the fork), the child forgets the parent's pools
+  // (leaked: their mutexes may be mid-operation) and starts its own on first use
+  static Registry& registry() {
+    static Registry* r = [] {
+      Registry* x = new Registry;
+      reg_ptr() = x;
+      pthread_atfork([] { reg_ptr()->guard.lock(); }, [] { reg_ptr()->guard.unlock(); },
+                     [] {
+                       Registry* c = reg_ptr();
+                       c->guard.unlock();
+                       c->count = 0;
+                       for (auto& p : c->pools) p = nullptr;
+                       inside_job() = false;
+                     });
+      return x;
+    }();
+    return *r;
+  }
+  static Registry*& reg_ptr() {
+    static Registry* p = nullptr;
+    return p;
+  }
+  static bool& inside_job() {
+    static thread_local bool in = false;
+    return in;
+  }
  private:
   void drain() {
     for (;;) {
@@ -88,6 +138,7 @@ class RowPool {
   }
   void work(unsigned id) {
     uint64_t seen = 0;
+    inside_job() = true;  // a flattener called from inside a job runs its rows inline
     for (;;) {
       {
         std::unique_lock<std::mutex> lk(mu_);
@@ -101,7 +152,8 @@ class RowPool {
     }
   }
 
-  std::mutex busy_, mu_;
+  std::atomic<bool> busy_{false};
+  std::mutex mu_;
   std::condition_variable cv_, done_;
   std::vector<std::thread> workers_;
   void (*fn_)(void*, int64_t, int64_t) = nullptr;

@@ -65,6 +65,13 @@ class MultiEngine:
         except Exception:
             pass
 
+    def rccl_ranks(self) -> int:
+        """ranks of the RCCL communicator (ncclCommCount); 0 with the peer-copy transport"""
+        n = int(self._lib.spx_multi_rccl_ranks(self._h))
+        if n < 0:
+            self._ck(n)
+        return n
+
     # ------------------------------------------------------------------ sharding
     def shard(self, rank: int, n_pods_total: Optional[int] = None):
         b, e = C.c_int64(), C.c_int64()

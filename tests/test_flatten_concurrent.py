@@ -62,3 +62,31 @@ def test_concurrent_flatteners_write_what_a_lone_call_writes(hdr, where):
                 for c, v in want_nrt.items():
                     per = len(v) // n_pods
                     assert np.array_equal(got["pods"][c], v.reshape(n_pods, per)[b:en].reshape(-1)), c
+
+
+def test_flatteners_after_fork(hdr):
+    """a child forked after the parent used the worker pools (whose threads do not exist in the child) starts pools of its own
+    (pthread_atfork in host/parallel.hpp): the flattener returns, and returns the lone call's columns — instead of waiting forever on
+    workers that are not there"""
+    import os
+    import signal
+    snap = synth.trimaran_snapshot(hdr, 50, 70_000, seed=5)
+    e = HostOnly()
+    e.tlp_params = tlp_params(hdr, 40, 1000, 1.5)
+    want = e.flatten_trimaran_pods(snap["pods"])   # parent: pools created, workers parked
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:  # child
+        ok = b"0"
+        try:
+            signal.alarm(60)   # a deadlock ends the child instead of hanging the suite
+            got = e.flatten_trimaran_pods(snap["pods"])
+            ok = b"1" if all(np.array_equal(got[c], want[c]) for c in want) else b"2"
+        finally:
+            os.write(w, ok)
+            os._exit(0)
+    os.close(w)
+    _, status = os.waitpid(pid, 0)
+    assert os.read(r, 1) == b"1" and status == 0
+    again = e.flatten_trimaran_pods(snap["pods"])   # and the parent's pools still work
+    assert all(np.array_equal(again[c], want[c]) for c in want)

@@ -172,3 +172,19 @@ def test_shim_package_uses_only_declared_identifiers():
             generic = set(re.findall(r"\[([A-Za-z_]\w*)\s", m.group(0)))  # type parameters: func cArray[T any]
             free = _free_identifiers(t[start:i + 1]) - known - _signature_names(m.group(0)) - generic
             assert not free, (f.name, m.group(0)[:70], sorted(free))
+
+
+def test_integration_md_quotes_the_shim():
+    """INTEGRATION.md section 3 shows the shim by quoting it: every ```go block tagged `<!-- verbatim: FILE -->` must be a contiguous
+    piece of FILE (round 4's hand-written excerpt had drifted from shim/go/pkg/spx/spx.go — cgo include path, Engine fields: two
+    descriptions of one uncompiled file)"""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    md = (root / "INTEGRATION.md").read_text()
+    blocks = re.findall(r"<!-- verbatim: (\S+) -->\n```go\n(.*?)```", md, re.S)
+    assert len(blocks) >= 6
+    for path, body in blocks:
+        src = (root / path).read_text()
+        assert body.rstrip("\n") in src, f"INTEGRATION.md quotes {path} but the block starting {body[:60]!r} is not in it"
+    assert {p for p, _ in blocks} == {"shim/go/pkg/spx/spx.go", "shim/go/apply_shim.py"}

@@ -62,6 +62,7 @@ def test_full_profile_sharded_equals_unsharded(gpu_required, hdr, name, devices,
         want_pre = ref.prefilter(CAPACITY)
     with MultiEngine(devices, transport) as m:
         assert m.size == len(devices)
+        assert m.rccl_ranks() == (len(devices) if transport == RCCL else 0)   # what RCCL itself counts (ncclCommCount)
         m.for_all(lambda e: e.set_plugin_weights(WEIGHTS))
         load_full(m, hdr, snap)
         # shards are equal contiguous ranges, the last ones possibly short or empty
