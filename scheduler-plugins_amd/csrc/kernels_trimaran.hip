@@ -929,12 +929,15 @@ void launch_alloc_prepare(const AllocPrepArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_alloc_prepare, dim3(1), dim3(1024), 0, s, a);
 }
 
-// the per-launch table of k_tlp_fast2<..., AMB>: cleared and rebuilt (the node columns may have changed since the last launch: deltas,
-// commits).  Worth it for multi-row launches only; a single-row launch (the commit loop's: row_ptr) keeps the checked cell.
+// the table of k_tlp_fast2<..., AMB>: cleared and rebuilt when the owner says the node columns or the target changed since it was
+// built (uploads, deltas, commits, spx_set_tlp_params: TrimaranArgs::tlp_amb_built).  Worth it for multi-row launches only; a
+// single-row launch (the commit loop's: row_ptr) keeps the checked cell.
 static bool tlp_amb_prepare(const TrimaranArgs& a, int64_t rows, double c1, double c2, int tile_nodes, hipStream_t s) {
   if (!a.tlp_amb || a.tlp_amb_size <= 0 || a.row_ptr || rows < 256 || (a.opts & kOptTlpNoAmbTable)) return false;
+  if (a.tlp_amb_built && *a.tlp_amb_built) return true;  // the table on the device still describes these node columns (16 us per sweep otherwise)
   (void)hipMemsetAsync(a.tlp_amb, 0, static_cast<size_t>(a.tlp_amb_size) * 4, s);
   hipLaunchKernelGGL(k_tlp_amb_build, dim3(static_cast<unsigned>(a.n_nodes)), dim3(256), 0, s, a, c1, c2, tile_nodes);
+  if (a.tlp_amb_built) *a.tlp_amb_built = true;
   return true;
 }
 

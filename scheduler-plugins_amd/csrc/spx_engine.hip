@@ -77,6 +77,7 @@ struct spx_engine {
   DevBuf d_lv_exact; // double [n_nodes][8] scratch of the LVRB fast kernel
   DevBuf d_lv_fast, d_tlp_fast;  // float32 per-node constants of the fast sweeps (recomputed per launch)
   DevBuf d_tlp_amb;              // k_tlp_amb_build's table: per pod value, the node tiles holding a cell the float32 sweep cannot prove
+  bool tlp_amb_built = false;    // ... and whether it still describes d_cap_cpu / d_tlp_util / d_tlp_missing / d_tlp_valid and the target (cleared by every writer of those)
   DevBuf d_commit;               // scratch of spx_commit_sequential
   DevBuf d_decide;               // per-tile partial decisions of spx_decide
   DevBuf d_stats;                // uint64 [SPX_NUM_PLUGINS]: cells re-evaluated by the fast sweeps' exact fallback
@@ -712,6 +713,7 @@ int spx_set_allocatable_params(spx_engine* e, const spx_allocatable_params* p) {
 int spx_set_tlp_params(spx_engine* e, const spx_tlp_params* p) {
   if (!e || !p) return SPX_ERR_ARG;
   e->tlp = *p;
+  e->tlp_amb_built = false;  // the table depends on the target utilisation
   return SPX_OK;
 }
 
@@ -747,6 +749,7 @@ int spx_upload_trimaran_nodes(spx_engine* e, const spx_trimaran_nodes_soa* t) {
   int rc = set_nodes(e, t->n_nodes);
   if (rc) return rc;
   const size_t n = static_cast<size_t>(t->n_nodes);
+  e->tlp_amb_built = false;  // (before the first column changes: a failed upload must not leave a table that describes the old ones)
   if ((rc = upload(e, e->d_cap_cpu, t->cap_cpu_milli, n * 8))) return rc;
   if ((rc = upload(e, e->d_tlp_util, t->tlp_cpu_util, n * 8))) return rc;
   if ((rc = upload(e, e->d_tlp_missing, t->tlp_missing_milli, n * 8))) return rc;
@@ -830,6 +833,7 @@ int spx_update_trimaran_nodes(spx_engine* e, const int64_t* idx, const spx_trima
   std::vector<int32_t> ix;
   int rc = delta_indices(e, idx, n, ix);
   if (rc) return rc;
+  e->tlp_amb_built = false;  // rows of the columns k_tlp_amb_build reads are about to change
   const size_t m = static_cast<size_t>(n);
   DeltaBlob b{e};
   const size_t o_idx = b.add(ix.data(), m * 4);
@@ -2119,9 +2123,11 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (T) {
     if ((rc = ensure(e, e->d_tlp_fast, static_cast<size_t>(spx::round_up(e->row_stride, 1024)) * 4 * sizeof(float)))) return rc;
     a.tlp_fast = static_cast<float*>(e->d_tlp_fast.p);
+    if (!e->d_tlp_amb.p) e->tlp_amb_built = false;
     if ((rc = ensure(e, e->d_tlp_amb, static_cast<size_t>(spx::kTlpAmbSize) * 4))) return rc;
     a.tlp_amb = static_cast<uint32_t*>(e->d_tlp_amb.p);
     a.tlp_amb_size = spx::kTlpAmbSize;
+    a.tlp_amb_built = &e->tlp_amb_built;
   }
   if (!e->hold_ev0) SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
   if (Q) {
@@ -2547,8 +2553,8 @@ int commit_with_filters(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, 
   e->last_commit_path = 2;
   struct LoopFlag {
     spx_engine* e;
-    explicit LoopFlag(spx_engine* x) : e(x) { e->in_commit_loop = true; }
-    ~LoopFlag() { e->in_commit_loop = false; }
+    explicit LoopFlag(spx_engine* x) : e(x) { e->in_commit_loop = true, e->tlp_amb_built = false; }  // (k_commit_apply advances d_tlp_missing)
+    ~LoopFlag() { e->in_commit_loop = false, e->tlp_amb_built = false; }
   } loop_flag(e);
   // ---- save what the loop mutates
   struct Saved {
@@ -3332,9 +3338,11 @@ int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t r
   d.t.row_begin = row_begin;
   d.t.row_end = row_end;
   d.t.tlp_fast = static_cast<float*>(e->d_tlp_fast.p);
+  if (!e->d_tlp_amb.p) e->tlp_amb_built = false;
   if ((rc = ensure(e, e->d_tlp_amb, static_cast<size_t>(spx::kTlpAmbSize) * 4))) return rc;
   d.t.tlp_amb = static_cast<uint32_t*>(e->d_tlp_amb.p);
   d.t.tlp_amb_size = spx::kTlpAmbSize;
+  d.t.tlp_amb_built = &e->tlp_amb_built;
   d.use_alloc = use_alloc;
   d.w_alloc = static_cast<int32_t>(use_alloc ? wa : 0);
   d.w_tlp = static_cast<int32_t>(wt);

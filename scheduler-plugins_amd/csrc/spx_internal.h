@@ -107,6 +107,8 @@ struct TrimaranArgs {
   float* tlp_fast;   // scratch [ceil(row_stride/1024)*1024][4]: TLP fast constants, tile-transposed (k_tlp_prepare_fast)
   uint32_t* tlp_amb;     // scratch [tlp_amb_size]: per pod value, the node tiles (bit tile & 31) holding a cell the float32 sweep cannot prove (k_tlp_amb_build); NULL = checked cells everywhere
   int32_t tlp_amb_size;  // pod values at or above it take the checked cell
+  bool* tlp_amb_built;   // host flag (may be NULL = always rebuild): true while tlp_amb describes the node columns / target in place; the launcher builds
+                         // the table when it is false and sets it; the owner clears it whenever a column k_tlp_amb_build reads, or the target, changes
   unsigned long long* stats;  // [SPX_NUM_PLUGINS][kStatSlots][kStatStride] cells the fast sweeps re-evaluated with the reference sequence (spx_fetch_stats); may be NULL
   // outputs: uint8 [n_pods][row_stride] each (NULL = plugin not evaluated)
   uint8_t* out_alloc;

@@ -204,3 +204,54 @@ def test_quota_used_delta_equals_full_upload(gpu_required, hdr):
         after = e.prefilter(CAPACITY)
         assert np.array_equal(after, ref.prefilter(CAPACITY))
         assert not np.array_equal(before, after)
+
+
+def test_tlp_ambiguity_table_follows_deltas_and_params(gpu_required, hdr):
+    """the TLP sweep's ambiguity table (k_tlp_amb_build) is kept across launches and rebuilt when a column it was built from, or
+    the target utilisation, changes: on tie-heavy snapshots (every node carries integer-valued metrics, so exact rounding ties are
+    everywhere and a stale table would leave float32-rounded bytes in them) an engine that evaluated, took a node delta, evaluated,
+    changed the target and evaluated again must hold what a fresh engine with the per-cell bookkeeping (option off) computes"""
+    n_nodes, n_pods = 2500, 1200
+    old = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=41, round_frac=1.0)
+    new = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=42, round_frac=1.0)
+    mask = mask_of(ALLOCATABLE, TLP)
+    with Engine(0) as e:
+        cols_old = e.flatten_trimaran_nodes(old["nodes"], old["metrics"], old["assigned"])
+        cols_new = e.flatten_trimaran_nodes(old["nodes"], new["metrics"], new["assigned"])
+        idx = np.random.default_rng(3).choice(n_nodes, 400, replace=False)
+        mixed = {k: v.copy() for k, v in cols_old.items()}
+        for k in mixed:
+            mixed[k][idx] = cols_new[k][idx]
+
+        def fresh(cols, target):
+            with Engine(0) as r:
+                r.set_option("TLP_AMB_TABLE", 0)
+                r.set_tlp(target_utilization=target)
+                r.upload_alloc_nodes(r.flatten_alloc_nodes(old["nodes"], old["rc"]))
+                r.upload_trimaran_nodes(cols)
+                r.upload_trimaran_pods(r.flatten_trimaran_pods(old["pods"]))
+                r.stats(reset=True)
+                r.eval(mask)
+                r.sync()
+                assert r.stats()[TLP] > 1000   # ties all over the table
+                return r.all_scores(TLP)
+
+        e.upload_alloc_nodes(e.flatten_alloc_nodes(old["nodes"], old["rc"]))
+        e.upload_trimaran_nodes(cols_old)
+        e.upload_trimaran_pods(e.flatten_trimaran_pods(old["pods"]))
+        for _ in range(2):   # the second launch reuses the table
+            e.eval(mask)
+            e.sync()
+            assert np.array_equal(e.all_scores(TLP), fresh(cols_old, 40))
+        e.update_trimaran_nodes(idx, cols_new)
+        e.eval(mask)
+        e.sync()
+        assert np.array_equal(e.all_scores(TLP), fresh(mixed, 40))
+        e.set_tlp(target_utilization=57)
+        e.eval(mask)
+        e.sync()
+        assert np.array_equal(e.all_scores(TLP), fresh(mixed, 57))
+        e.upload_trimaran_nodes(cols_new)   # a full re-upload
+        e.eval(mask)
+        e.sync()
+        assert np.array_equal(e.all_scores(TLP), fresh(cols_new, 57))
