@@ -228,6 +228,20 @@ def config5_leg(hdr, device, n_pods=8192):
                 e.sync()
                 ts.append((time.perf_counter() - t0) * 1e3)
             out["load_c_ms"] = sorted(ts)[1]
+            # per loader (one more pass, each call bracketed by a sync) and, for the NRT loader — the largest — per stage
+            per = {}
+            for name, fn in (("trimaran", lambda: e._lib.spx_load_trimaran(e._h, snap["nodes"].ref(), snap["rc"].ref(), snap["pods"].ref(), snap["metrics"].ref(), snap["assigned"].ref())),
+                             ("nrt", lambda: e._lib.spx_load_nrt(e._h, snap["nodes"].ref(), snap["nrt"].ref(), snap["rc"].ref(), snap["pods"].ref(), snap["nrt_params"].ref())),
+                             ("network", lambda: e._lib.spx_load_network(e._h, snap["nodes"].ref(), snap["pods"].ref(), snap["appgroups"].ref(), snap["nettopo"].ref())),
+                             ("quota", lambda: e._lib.spx_load_quota(e._h, snap["pods"].ref(), snap["rc"].ref(), snap["quota"].ref()))):
+                e.sync()
+                t0 = time.perf_counter()
+                if fn() != 0:
+                    raise RuntimeError(name)
+                e.sync()
+                per[name] = (time.perf_counter() - t0) * 1e3
+            out["load_c_per_loader_ms"] = per
+            out["load_c_nrt_stages_ms"] = e.last_load_nrt_ms()
         except Exception as ex:
             out["load_c_ms"] = {"error": repr(ex)[:200]}
         for _ in range(2):

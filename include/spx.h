@@ -775,6 +775,9 @@ int spx_load_trimaran(spx_engine* e, const spx_node_objects* nodes, const spx_re
 /* a new pending batch only (node tables stay): the trimaran / Allocatable pod columns flattened straight into pinned staging, one pass */
 int spx_load_trimaran_pods(spx_engine* e, const spx_pod_objects* pods);
 int spx_load_nrt(spx_engine* e, const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_resource_classes* rc, const spx_pod_objects* pods, const spx_nrt_params* params);
+/* wall time in ms of the six stages of the last spx_load_nrt on this engine: [0] spx_flatten_nrt_slots, [1] spx_flatten_nrt_nodes,
+ * [2] spx_flatten_nrt_pods, [3] parameters + slot table, [4] spx_upload_nrt_nodes, [5] spx_upload_nrt_pods (bench.py reports them) */
+int spx_last_load_nrt_ms(const spx_engine* e, double* ms6);
 int spx_load_network(spx_engine* e, const spx_node_objects* nodes, const spx_pod_objects* pods, const spx_appgroup_objects* appgroups, const spx_nettopo_objects* nettopo);
 int spx_load_quota(spx_engine* e, const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_quota_objects* quota);
 

@@ -931,10 +931,20 @@ void launch_alloc_prepare(const AllocPrepArgs& a, hipStream_t s) {
 
 // the table of k_tlp_fast2<..., AMB>: cleared and rebuilt when the owner says the node columns or the target changed since it was
 // built (uploads, deltas, commits, spx_set_tlp_params: TrimaranArgs::tlp_amb_built).  Worth it for multi-row launches only; a
-// single-row launch (the commit loop's: row_ptr) keeps the checked cell.
-static bool tlp_amb_prepare(const TrimaranArgs& a, int64_t rows, double c1, double c2, int tile_nodes, hipStream_t s) {
-  if (!a.tlp_amb || a.tlp_amb_size <= 0 || a.row_ptr || rows < 256 || (a.opts & kOptTlpNoAmbTable)) return false;
-  if (a.tlp_amb_built && *a.tlp_amb_built) return true;  // the table on the device still describes these node columns (16 us per sweep otherwise)
+// single-row launch (the commit loop's: row_ptr) and launches of fewer than 256 rows keep the checked cell.
+static bool tlp_amb_eligible(const TrimaranArgs& a, int64_t rows) {
+  return a.tlp_amb && a.tlp_amb_size > 0 && !a.row_ptr && rows >= 256 && !(a.opts & kOptTlpNoAmbTable);
+}
+// k_tlp_prepare_fast's constants (always) and, for an eligible launch, k_tlp_amb_build's table — unless the owner's flag says both
+// still describe the node columns in place (they are built together and invalidated together); true = launch the AMB variant
+static bool tlp_prepare(const TrimaranArgs& a, int64_t rows, int64_t n_slots, double c1, double c2, int tile_nodes, hipStream_t s) {
+  const bool amb = tlp_amb_eligible(a, rows);
+  if (amb && a.tlp_amb_built && *a.tlp_amb_built) return true;  // 21 us per sweep otherwise
+  hipLaunchKernelGGL(k_tlp_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots, c1, c2);
+  if (!amb) {
+    if (a.tlp_amb_built) *a.tlp_amb_built = false;  // (a single-row launch of the commit loop writes constants of its own state)
+    return false;
+  }
   (void)hipMemsetAsync(a.tlp_amb, 0, static_cast<size_t>(a.tlp_amb_size) * 4, s);
   hipLaunchKernelGGL(k_tlp_amb_build, dim3(static_cast<unsigned>(a.n_nodes)), dim3(256), 0, s, a, c1, c2, tile_nodes);
   if (a.tlp_amb_built) *a.tlp_amb_built = true;
@@ -951,8 +961,7 @@ void launch_tlp_fast(const TrimaranArgs& a, hipStream_t s) {
   const double t = a.tlp_target;
   const double c1 = t / (100.0 - t), c2 = (100.0 - t) / t;
   const int64_t n_slots = static_cast<int64_t>(n_tiles) * tile_nodes;
-  hipLaunchKernelGGL(k_tlp_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots, c1, c2);
-  if (tlp_amb_prepare(a, rows, c1, c2, tile_nodes, s)) {
+  if (tlp_prepare(a, rows, n_slots, c1, c2, tile_nodes, s)) {
     if (a.out_alloc)
       hipLaunchKernelGGL((k_tlp_fast2<NPL, true, false, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, DecideArgs{});
     else
@@ -1034,8 +1043,7 @@ void launch_decide_trimaran(const DecideLaunch& d, hipStream_t s) {
   dec.key = static_cast<uint32_t*>(d.scratch);
   dec.ties = reinterpret_cast<int32_t*>(dec.key + static_cast<int64_t>(n_tiles) * rows);
   dec.rows = rows;
-  hipLaunchKernelGGL(k_tlp_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots, c1, c2);
-  if (tlp_amb_prepare(a, rows, c1, c2, tile_nodes, s)) {
+  if (tlp_prepare(a, rows, n_slots, c1, c2, tile_nodes, s)) {
     if (d.use_alloc)
       hipLaunchKernelGGL((k_tlp_fast2<NPL, true, true, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles, c1, c2, dec);
     else

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -168,6 +169,7 @@ struct spx_engine {
   int32_t net_n_keys = 0;
   DevBuf d_commit_save;  // backup of every table the commit loop mutates
   DevBuf d_coop_sync, d_coop_node, d_coop_max;  // cooperative commit kernel: granules + error flag, the workgroups' private pair lists
+  double load_nrt_ms[6] = {0};  // stages of the last spx_load_nrt (spx_last_load_nrt_ms)
   bool in_commit_loop = false;  // commit_with_filters' per-pod launches are running on mutated zone tables (fill_nrt)
   int coop_gave_up = 0;      // cooperative commit launches that ended with a workgroup giving up (served by the per-pod loop instead)
   int last_commit_path = 0;  // what the last spx_commit_sequential ran: 1 one-workgroup trimaran chain, 2 per-pod launches, 3 cooperative kernel
@@ -2830,11 +2832,21 @@ int spx_load_trimaran_pods(spx_engine* e, const spx_pod_objects* pods) {
 int spx_load_nrt(spx_engine* e, const spx_node_objects* nodes, const spx_nrt_objects* nrt, const spx_resource_classes* rc, const spx_pod_objects* pods,
                  const spx_nrt_params* params) {
   if (!e || !nodes || !nrt || !pods || !params) return SPX_ERR_ARG;
+  using clk = std::chrono::steady_clock;
+  auto t_prev = clk::now();
+  int stage = 0;
+  auto mark = [&] {  // wall time of the stage that just ended (spx_last_load_nrt_ms)
+    const auto now = clk::now();
+    if (stage < 6) e->load_nrt_ms[stage++] = std::chrono::duration<double, std::milli>(now - t_prev).count();
+    t_prev = now;
+  };
+  for (double& x : e->load_nrt_ms) x = 0.0;
   int32_t n_res = 0, slot_res[SPX_NRT_MAX_RES] = {0};
   uint8_t slot_flags[SPX_NRT_MAX_RES] = {0};
   int64_t slot_weight[SPX_NRT_MAX_RES] = {0};
   if (spx_flatten_nrt_slots(pods, nrt, rc, params, &n_res, slot_res, slot_flags, slot_weight) != SPX_OK) return fail(e, SPX_ERR_ARG, "spx_flatten_nrt_slots failed");
   const spx_nrt_slots slots{n_res, slot_res, slot_flags, slot_weight};
+  mark();  // 0: spx_flatten_nrt_slots
   const size_t N = static_cast<size_t>(nodes->n_nodes), P = static_cast<size_t>(pods->n_pods), R = static_cast<size_t>(n_res > 0 ? n_res : 1), Z = SPX_NRT_MAX_ZONES,
                Cn = SPX_NRT_MAX_CTRS;
   std::vector<uint8_t> nflags(N), nz(N), zid(N * Z), zp(N * Z), np(N);
@@ -2844,16 +2856,28 @@ int spx_load_nrt(spx_engine* e, const spx_node_objects* nodes, const spx_nrt_obj
   if (spx_flatten_nrt_nodes(nodes, nrt, &slots, nflags.data(), max_numa.data(), nz.data(), zid.data(), zp.data(), zavail.data(), zcost.data(), minavg.data(), np.data()) !=
       SPX_OK)
     return fail(e, SPX_ERR_ARG, "spx_flatten_nrt_nodes failed");
+  mark();  // 1: node columns allocated + spx_flatten_nrt_nodes
   std::vector<uint8_t> qos(P), nn(P), nctr(P), ckind(P * Cn), cpres(P * Cn), ppres(P);
   std::vector<int64_t> creq(P * Cn * R), preq(P * R);
   if (spx_flatten_nrt_pods(pods, rc, &slots, qos.data(), nn.data(), nctr.data(), ckind.data(), cpres.data(), creq.data(), ppres.data(), preq.data()) != SPX_OK)
     return fail(e, SPX_ERR_ARG, "spx_flatten_nrt_pods failed");
+  mark();  // 2: pod columns allocated + spx_flatten_nrt_pods
   int rc_;
   if ((rc_ = spx_set_nrt_params(e, params)) || (rc_ = spx_upload_nrt_slots(e, &slots))) return rc_;
+  mark();  // 3: params + slot table
   const spx_nrt_nodes_soa ns{nodes->n_nodes, n_res, nflags.data(), max_numa.data(), nz.data(), zid.data(), zp.data(), zavail.data(), zcost.data(), minavg.data(), np.data()};
   if ((rc_ = spx_upload_nrt_nodes(e, &ns))) return rc_;
+  mark();  // 4: spx_upload_nrt_nodes (precondition checks, window-local node order, one blob, derived columns on the device)
   const spx_nrt_pods_soa ps{pods->n_pods, n_res, qos.data(), nn.data(), nctr.data(), ckind.data(), cpres.data(), creq.data(), ppres.data(), preq.data()};
-  return spx_upload_nrt_pods(e, &ps);
+  rc_ = spx_upload_nrt_pods(e, &ps);
+  mark();  // 5: spx_upload_nrt_pods (item stream, pod classes, rank stream)
+  return rc_;
+}
+
+int spx_last_load_nrt_ms(const spx_engine* e, double* ms6) {
+  if (!e || !ms6) return SPX_ERR_ARG;
+  std::memcpy(ms6, e->load_nrt_ms, sizeof e->load_nrt_ms);
+  return SPX_OK;
 }
 
 int spx_load_network(spx_engine* e, const spx_node_objects* nodes, const spx_pod_objects* pods, const spx_appgroup_objects* appgroups, const spx_nettopo_objects* nettopo) {

@@ -593,6 +593,12 @@ class Engine:
         if "nodes" in snap:
             self.n_nodes = snap["nodes"].struct.n_nodes
 
+    def last_load_nrt_ms(self) -> Dict[str, float]:
+        """wall time of the stages of the last spx_load_nrt (spx_last_load_nrt_ms)"""
+        ms = (C.c_double * 6)()
+        self._ck(self._lib.spx_last_load_nrt_ms(self._h, ms))
+        return dict(zip(("flatten_slots", "flatten_nodes", "flatten_pods", "params_slot_table", "upload_nodes", "upload_pods"), (float(x) for x in ms)))
+
     def load_trimaran_pods(self, pods: Table) -> None:
         """a new pending batch for Allocatable / TLP / LVRB: flattened straight into the engine's pinned staging (spx_load_trimaran_pods)"""
         self._ck(self._lib.spx_load_trimaran_pods(self._h, pods.ref()))
