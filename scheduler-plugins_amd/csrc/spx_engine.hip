@@ -1309,7 +1309,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
       std::stable_sort(order, order + cnt, [&](int x, int y) { return cls_of[x] != cls_of[y] ? cls_of[x] < cls_of[y] : key[x] < key[y]; });
       for (int k = 0; k < cnt; ++k) perm[static_cast<size_t>(w0 + k)] = static_cast<int32_t>(w0 + order[k]);
     }
-    }, 16);
+    }, 2);  // (three 256-key stable sorts per window, ~40 us: at 16 windows per thread config #5's 79 windows ran on 4 threads for 1 ms)
     std::vector<int32_t> all(m);
     for (size_t i = 0; i < m; ++i) all[i] = static_cast<int32_t>(i);
     DeltaBlob b{e};
