@@ -515,6 +515,9 @@ def main() -> None:
         local_pods = max(e.n_pods for e in target.engines)
     else:
         target = e0 = Engine(local_rank)
+        for kv in args.opt:  # (the row padding must be chosen before the first upload; the other options are applied below)
+            if kv.startswith("ROW_ALIGN="):
+                e0.set_option("ROW_ALIGN", int(kv.partition("=")[2]))
         if strong and world > 1:  # every rank builds the same batch and keeps its shard
             snap = build_snapshot(hdr, w, n_pods_total, synth.SEED)
             from scheduler_plugins_amd import shard
@@ -532,6 +535,8 @@ def main() -> None:
             e.set_option("PEAKS_POD_CLASSES", 0)
     for kv in args.opt:
         name, _, val = kv.partition("=")
+        if name == "ROW_ALIGN" and mode != "multi":
+            continue  # applied at engine creation
         for e in engines:
             e.set_option(name, int(val))
     pod_classes = {}

@@ -733,7 +733,7 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *                              spx_decide's argmax) give every row a whole workgroup in batch launches too; 0 (default) = four rows per
  *                              workgroup, and the whole-workgroup mapping only when four rows' feasibility bytes would not fit the LDS
  *                              (rows of more than about 65k nodes).  Same tables either way
- *   SPX_OPT_TLP_AMB_TABLE      1 (default) = a multi-row TargetLoadPacking sweep (tables or spx_decide) first lists, per pod value and node tile,
+ *   SPX_OPT_TLP_AMB_TABLE      1 (default) = a multi-row TargetLoadPacking sweep (tables or spx_decide; LoadVariationRiskBalancing's sweep likewise, per cpu / memory request) first lists, per pod value and node tile,
  *                              where a cell of the float32 formulation can be within its error bound of a rounding tie or of the branch point
  *                              (a property of the node alone: the score is piecewise linear in the pod's integer millicores), and only the rows
  *                              named there carry the per-cell exactness bookkeeping; 0 = every cell carries it.  Same tables either way

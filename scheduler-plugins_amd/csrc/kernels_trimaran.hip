@@ -303,6 +303,7 @@ __device__ __forceinline__ int64_t tile_slot(int64_t n) {
 }
 
 constexpr int kLvNpl = 8, kTlpNpl = 16;  // nodes per lane of k_lvrb_fast / k_tlp_fast2
+constexpr int kLvAmbCpu = 1 << 16, kLvAmbMem = 1 << 17;  // k_lvrb_amb_build's table: cpu millicores / memory MiB it covers
 constexpr double kAmbMargin = 1.25;          // k_tlp_amb_build lists a cell when it is within 1.25 x the tolerance of a rounding tie
 constexpr double kAmbMinSlope = 2.5 * 4e-5;  // score units per millicore below which a node is always exact (see k_tlp_amb_build)
 
@@ -753,7 +754,53 @@ __global__ void k_lvrb_prepare_fast(TrimaranArgs a, int64_t n_slots) {
   out[1] = v1;
 }
 
-template <int NPL, bool A>
+// Which (request value, node tile) pairs hold a cell k_lvrb_fast cannot prove, as k_tlp_amb_build does it for TargetLoadPacking.  Per node
+// and resource the float32 value is y_r(q) = s * (A_r - clamp(B_r * q + C_r, 0, 50)) in the pod's INTEGER request q (cpu: millicores; memory:
+// MiB — rows whose memory request is not a whole number of MiB keep the checked cell), and the cell is x = s * max(y_cpu, y_mem): it can
+// only be near a rounding tie when the maximum's argument is, so a cell neither of whose y_r is within the tolerance of k + 0.5 is provable.
+// On the linear piece y_r meets k + 0.5 at one real q*, and only the integer next to it can be within tau / B_r of it; on the clamped
+// pieces y_r is constant — a constant that is itself near a tie (integer-valued metrics make that common) makes every request beyond the
+// clamp ambiguous, and sends the node's whole tile to the checked cell (bit tile & 31 of the table's last word), as does a slope so
+// flat that more than 16 integers either side of a tie would have to be listed.  Layout: [cpu values 0 .. kLvAmbCpu) | [memory MiB 0 .. kLvAmbMem) | one word of always-checked tiles.
+// One block per node: thread j < 64 -> cpu, tie k = j; 64 <= j < 128 -> memory.
+__global__ __launch_bounds__(128) void k_lvrb_amb_build(TrimaranArgs a, int tile_nodes) {
+  const int64_t n = blockIdx.x;
+  if (n >= a.n_nodes) return;
+  const int j = threadIdx.x & 63;
+  const bool is_mem = threadIdx.x >= 64;
+  const double* o = a.lv_exact + n * 8;  // k_lvrb_prepare's exact state: {cap, usedAvg, sigma, state} x {cpu, memory}; o[7] also carries has_metrics
+  const int ms = static_cast<int>(o[7]);
+  if (!(ms & 8)) return;  // no metrics: the score is 0 for every pod
+  const double cap = is_mem ? o[4] : o[0], used = is_mem ? o[5] : o[1], sigma = is_mem ? o[6] : o[2];
+  const int state = is_mem ? (ms & 7) : static_cast<int>(o[3]);
+  if (state != 2) return;  // this resource scores 0: an integer, never near a tie
+  const uint32_t bit = 1u << (static_cast<uint32_t>(n / tile_nodes) & 31u);
+  uint32_t* const tab = a.lv_amb + (is_mem ? kLvAmbCpu : 0);
+  const int size = is_mem ? kLvAmbMem : kLvAmbCpu;
+  uint32_t* const always = a.lv_amb + kLvAmbCpu + kLvAmbMem;
+  constexpr double tau = 6e-5 * kAmbMargin;  // kTolLv with the margin
+  const double big_a = 100.0 - 50.0 * sigma, b = 50.0 / cap;
+  const double radius = tau / b;  // integers within this distance of a tie's real solution are listed (a 1 TiB node: B = 4.8e-5 per MiB, radius 1.6)
+  if (!(radius <= 16.0)) {    // flatter than that (more than ~10 TiB / 10^7 millicores, or a NaN capacity): the whole tile keeps the checked cell
+    if (j == 0) atomicOr(always, bit);
+    return;
+  }
+  if (j == 0) {  // the clamped pieces: y = A (t = 0; only q with B q + C <= 0, i.e. the linear piece's own end) and y = A - 50 (every large q)
+    const double lo = big_a - 50.0;
+    if (__builtin_fabs(lo - __builtin_floor(lo) - 0.5) < tau) atomicOr(always, bit);
+  }
+  if (j > 51) return;
+  // ties of |y| = A - t at k + 0.5 for t in [0, 50]: t = A - (k + 0.5) with k = floor(A - 0.5) - j  (the sign s only mirrors y)
+  const double k_top = __builtin_floor(big_a - 0.5);
+  const double t = big_a - (k_top - j + 0.5);
+  if (!(t >= -1e-3) || !(t <= 50.001)) return;
+  const double q_star = (t - b * used) / b;
+  const double q_lo = __builtin_ceil(q_star - radius), q_hi = __builtin_floor(q_star + radius);
+  for (double q = q_lo; q <= q_hi; q += 1.0)
+    if (q >= 0.0 && q < static_cast<double>(size)) atomicOr(tab + static_cast<int64_t>(q), bit);
+}
+
+template <int NPL, bool A, bool AMB = false>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArgs a, int n_tiles) {
   SPX_RESOLVE_ROWS(a);
   static_assert(kPodsPerChunk == kWave, "one pod record per lane");
@@ -778,6 +825,14 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
     my_cpu = static_cast<float>(rc);
     my_mem = static_cast<float>(rm);
     my_bad = (!(rc >= 0.0) || !(rm >= 0.0) || !(rc < 1e15) || !(rm < 1e15)) ? 1 : 0;
+  }
+  int my_slow = 1;  // this row takes the checked cell in this tile (k_lvrb_amb_build)
+  if constexpr (AMB) {
+    if (lane < n_rows && !my_bad) {
+      const int64_t qc = a.lv_req_cpu_milli[pod0 + lane], qm_bytes = a.lv_req_mem[pod0 + lane];
+      if (qc < kLvAmbCpu && (qm_bytes & 0xfffff) == 0 && (qm_bytes >> 20) < kLvAmbMem)
+        my_slow = static_cast<int>(((a.lv_amb[qc] | a.lv_amb[kLvAmbCpu + (qm_bytes >> 20)] | a.lv_amb[kLvAmbCpu + kLvAmbMem]) >> (tile & 31)) & 1u);
+    }
   }
   const int cpu_bits = __float_as_int(my_cpu), mem_bits = __float_as_int(my_mem);
 
@@ -826,6 +881,25 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
       return __builtin_fabsf(y - *ry);
     };
     const F32x2 req2{req_cpu, req_mem};
+    const bool row_slow = !AMB || __builtin_amdgcn_readlane(my_slow, r) != 0;  // wave-uniform
+    if (!row_slow) {
+      // streamlined: no cell of this row in this tile can be near a tie (k_lvrb_amb_build) — v_cvt_pk_u8_f32 rounds to nearest even itself
+#pragma unroll
+      for (int j = 0; j < NPL / 4; ++j) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = j * 4 + q;
+          const F32x2 t = __builtin_elementwise_fma(kb[i], req2, kc[i]);
+          const F32x2 cl{__builtin_amdgcn_fmed3f(t.x, 0.0f, 50.0f), __builtin_amdgcn_fmed3f(t.y, 0.0f, 50.0f)};
+          const F32x2 y2 = __builtin_elementwise_fma(F32x2{-ks[i], -ks[i]}, cl, ksa[i]);
+          acc = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(y2.x, y2.y) * ks[i], q, acc);
+        }
+        w[j] = acc;
+      }
+      if (active) store_bytes<NPL>(a.out_lvrb + row, w);
+      continue;
+    }
     float worst = 0.0f;  // running max of the rounding margins (v_max3_f32), as in k_tlp_fast2
 #pragma unroll
     for (int j = 0; j < NPL / 4; ++j) {
@@ -980,14 +1054,31 @@ void launch_lvrb_fast(const TrimaranArgs& a, hipStream_t s) {
   const int n_tiles = static_cast<int>((a.row_stride + tile_nodes - 1) / tile_nodes);
   const int64_t chunks = (a.row_end - a.row_begin + kPodsPerChunk - 1) / kPodsPerChunk;
   const unsigned blocks = static_cast<unsigned>((chunks * n_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
-  hipLaunchKernelGGL(k_lvrb_prepare, dim3(static_cast<unsigned>((a.n_nodes + 255) / 256)), dim3(256), 0, s, a);
   const int64_t n_slots = static_cast<int64_t>(n_tiles) * tile_nodes;
-  hipLaunchKernelGGL(k_lvrb_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots);
-  if (a.out_alloc)
+  // the per-node constants and, for a multi-row launch, the ambiguity table: built together, kept while the owner's flag says the
+  // columns they were built from (and the margin / sensitivity) are the ones in place — as launch_tlp_fast does
+  const bool amb = a.lv_amb && !a.row_ptr && a.row_end - a.row_begin >= 256 && !(a.opts & kOptTlpNoAmbTable);
+  if (!(amb && a.lv_amb_built && *a.lv_amb_built)) {
+    hipLaunchKernelGGL(k_lvrb_prepare, dim3(static_cast<unsigned>((a.n_nodes + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_lvrb_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots);
+    if (amb) {
+      (void)hipMemsetAsync(a.lv_amb, 0, static_cast<size_t>(kLvAmbCpu + kLvAmbMem + 1) * 4, s);
+      hipLaunchKernelGGL(k_lvrb_amb_build, dim3(static_cast<unsigned>(a.n_nodes)), dim3(128), 0, s, a, tile_nodes);
+    }
+    if (a.lv_amb_built) *a.lv_amb_built = amb;
+  }
+  if (amb) {
+    if (a.out_alloc)
+      hipLaunchKernelGGL((k_lvrb_fast<NPL, true, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles);
+    else
+      hipLaunchKernelGGL((k_lvrb_fast<NPL, false, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles);
+  } else if (a.out_alloc)
     hipLaunchKernelGGL((k_lvrb_fast<NPL, true>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles);
   else
     hipLaunchKernelGGL((k_lvrb_fast<NPL, false>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, s, a, n_tiles);
 }
+
+size_t lvrb_amb_bytes() { return static_cast<size_t>(kLvAmbCpu + kLvAmbMem + 1) * 4; }
 
 void launch_trimaran(const TrimaranArgs& a, hipStream_t s) {
   if (a.row_end <= a.row_begin) return;

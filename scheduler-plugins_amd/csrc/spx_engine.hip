@@ -78,6 +78,8 @@ struct spx_engine {
   DevBuf d_lv_exact; // double [n_nodes][8] scratch of the LVRB fast kernel
   DevBuf d_lv_fast, d_tlp_fast;  // float32 per-node constants of the fast sweeps (recomputed per launch)
   DevBuf d_tlp_amb;              // k_tlp_amb_build's table: per pod value, the node tiles holding a cell the float32 sweep cannot prove
+  DevBuf d_lv_amb;               // k_lvrb_amb_build's table
+  bool lv_amb_built = false;     // ... and whether d_lv_exact / d_lv_fast / d_lv_amb still describe the LVRB node columns and parameters
   bool tlp_amb_built = false;    // ... and whether it still describes d_cap_cpu / d_tlp_util / d_tlp_missing / d_tlp_valid and the target (cleared by every writer of those)
   DevBuf d_commit;               // scratch of spx_commit_sequential
   DevBuf d_decide;               // per-tile partial decisions of spx_decide
@@ -592,7 +594,7 @@ int spx_destroy(spx_engine* e) {
   DevBuf* bufs[] = {&e->d_alloc,   &e->d_alloc_w,  &e->d_alloc_raw, &e->d_alloc_norm, &e->d_alloc_rel, &e->d_cap_cpu, &e->d_tlp_util,
                     &e->d_tlp_missing, &e->d_tlp_valid, &e->d_lv_acpu, &e->d_lv_amem, &e->d_lv_cavg, &e->d_lv_cstd,
                     &e->d_lv_mavg, &e->d_lv_mstd,  &e->d_lv_flags,  &e->d_tlp_pod,    &e->d_lv_rcpu, &e->d_lv_rmem,
-                    &e->d_raw_row,   &e->d_lv_exact, &e->d_lv_fast, &e->d_tlp_fast, &e->d_tlp_amb, &e->d_commit, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
+                    &e->d_raw_row,   &e->d_lv_exact, &e->d_lv_fast, &e->d_tlp_fast, &e->d_tlp_amb, &e->d_lv_amb, &e->d_commit, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
                     &e->d_nrt_frcv, &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_ln, &e->d_nrt_fbraw, &e->d_nrt_redo,
@@ -722,6 +724,7 @@ int spx_set_tlp_params(spx_engine* e, const spx_tlp_params* p) {
 int spx_set_lvrb_params(spx_engine* e, const spx_lvrb_params* p) {
   if (!e || !p) return SPX_ERR_ARG;
   e->lvrb = *p;
+  e->lv_amb_built = false;  // sigma (margin, sensitivity) is inside the per-node constants and the table
   return SPX_OK;
 }
 
@@ -751,7 +754,7 @@ int spx_upload_trimaran_nodes(spx_engine* e, const spx_trimaran_nodes_soa* t) {
   int rc = set_nodes(e, t->n_nodes);
   if (rc) return rc;
   const size_t n = static_cast<size_t>(t->n_nodes);
-  e->tlp_amb_built = false;  // (before the first column changes: a failed upload must not leave a table that describes the old ones)
+  e->tlp_amb_built = e->lv_amb_built = false;  // (before the first column changes: a failed upload must not leave tables that describe the old ones)
   if ((rc = upload(e, e->d_cap_cpu, t->cap_cpu_milli, n * 8))) return rc;
   if ((rc = upload(e, e->d_tlp_util, t->tlp_cpu_util, n * 8))) return rc;
   if ((rc = upload(e, e->d_tlp_missing, t->tlp_missing_milli, n * 8))) return rc;
@@ -835,7 +838,7 @@ int spx_update_trimaran_nodes(spx_engine* e, const int64_t* idx, const spx_trima
   std::vector<int32_t> ix;
   int rc = delta_indices(e, idx, n, ix);
   if (rc) return rc;
-  e->tlp_amb_built = false;  // rows of the columns k_tlp_amb_build reads are about to change
+  e->tlp_amb_built = e->lv_amb_built = false;  // rows of the columns k_tlp_amb_build / k_lvrb_amb_build read are about to change
   const size_t m = static_cast<size_t>(n);
   DeltaBlob b{e};
   const size_t o_idx = b.add(ix.data(), m * 4);
@@ -2119,8 +2122,12 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (L) {
     if ((rc = ensure(e, e->d_lv_exact, static_cast<size_t>(e->n_nodes) * 8 * sizeof(double)))) return rc;
     a.lv_exact = static_cast<double*>(e->d_lv_exact.p);
+    if (!e->d_lv_exact.p || !e->d_lv_fast.p || !e->d_lv_amb.p) e->lv_amb_built = false;
     if ((rc = ensure(e, e->d_lv_fast, static_cast<size_t>(spx::round_up(e->row_stride, 512)) * 8 * sizeof(float)))) return rc;
     a.lv_fast = static_cast<float*>(e->d_lv_fast.p);
+    if ((rc = ensure(e, e->d_lv_amb, spx::lvrb_amb_bytes()))) return rc;
+    a.lv_amb = static_cast<uint32_t*>(e->d_lv_amb.p);
+    a.lv_amb_built = &e->lv_amb_built;
   }
   if (T) {
     if ((rc = ensure(e, e->d_tlp_fast, static_cast<size_t>(spx::round_up(e->row_stride, 1024)) * 4 * sizeof(float)))) return rc;

@@ -107,6 +107,8 @@ struct TrimaranArgs {
   float* tlp_fast;   // scratch [ceil(row_stride/1024)*1024][4]: TLP fast constants, tile-transposed (k_tlp_prepare_fast)
   uint32_t* tlp_amb;     // scratch [tlp_amb_size]: per pod value, the node tiles (bit tile & 31) holding a cell the float32 sweep cannot prove (k_tlp_amb_build); NULL = checked cells everywhere
   int32_t tlp_amb_size;  // pod values at or above it take the checked cell
+  uint32_t* lv_amb;      // scratch [lvrb_amb_bytes() / 4]: k_lvrb_amb_build's table (cpu millicores | memory MiB | always-checked tiles); NULL = checked cells everywhere
+  bool* lv_amb_built;    // as tlp_amb_built, for lv_exact / lv_fast / lv_amb: cleared by every writer of the LVRB node columns, margin or sensitivity
   bool* tlp_amb_built;   // host flag (may be NULL = always rebuild): true while tlp_amb describes the node columns / target in place; the launcher builds
                          // the table when it is false and sets it; the owner clears it whenever a column k_tlp_amb_build reads, or the target, changes
   unsigned long long* stats;  // [SPX_NUM_PLUGINS][kStatSlots][kStatStride] cells the fast sweeps re-evaluated with the reference sequence (spx_fetch_stats); may be NULL
@@ -117,6 +119,7 @@ struct TrimaranArgs {
 };
 // evaluates the plugins whose out_* pointer is non-NULL
 void launch_trimaran(const TrimaranArgs& a, hipStream_t s);
+size_t lvrb_amb_bytes();
 // sequential commit loop over pod rows [t.row_begin, t.row_end) for Allocatable (bit 0) / TLP (bit 1) / LVRB (bit 2)
 struct CommitArgs {
   TrimaranArgs t;       // inputs; alloc_norm must be prepared

@@ -214,7 +214,7 @@ def test_tlp_ambiguity_table_follows_deltas_and_params(gpu_required, hdr):
     n_nodes, n_pods = 2500, 1200
     old = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=41, round_frac=1.0)
     new = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=42, round_frac=1.0)
-    mask = mask_of(ALLOCATABLE, TLP)
+    mask = mask_of(ALLOCATABLE, TLP, LVRB)
     with Engine(0) as e:
         cols_old = e.flatten_trimaran_nodes(old["nodes"], old["metrics"], old["assigned"])
         cols_new = e.flatten_trimaran_nodes(old["nodes"], new["metrics"], new["assigned"])
@@ -223,18 +223,21 @@ def test_tlp_ambiguity_table_follows_deltas_and_params(gpu_required, hdr):
         for k in mixed:
             mixed[k][idx] = cols_new[k][idx]
 
-        def fresh(cols, target):
+        both = lambda eng: np.stack([eng.all_scores(TLP), eng.all_scores(LVRB)])
+
+        def fresh(cols, target, lv=(1.0, 1.0)):
             with Engine(0) as r:
                 r.set_option("TLP_AMB_TABLE", 0)
                 r.set_tlp(target_utilization=target)
+                r.set_lvrb(*lv)
                 r.upload_alloc_nodes(r.flatten_alloc_nodes(old["nodes"], old["rc"]))
                 r.upload_trimaran_nodes(cols)
                 r.upload_trimaran_pods(r.flatten_trimaran_pods(old["pods"]))
                 r.stats(reset=True)
                 r.eval(mask)
                 r.sync()
-                assert r.stats()[TLP] > 1000   # ties all over the table
-                return r.all_scores(TLP)
+                assert r.stats()[TLP] > 1000 and r.stats()[LVRB] > 1000   # ties all over the tables
+                return np.stack([r.all_scores(TLP), r.all_scores(LVRB)])
 
         e.upload_alloc_nodes(e.flatten_alloc_nodes(old["nodes"], old["rc"]))
         e.upload_trimaran_nodes(cols_old)
@@ -242,16 +245,20 @@ def test_tlp_ambiguity_table_follows_deltas_and_params(gpu_required, hdr):
         for _ in range(2):   # the second launch reuses the table
             e.eval(mask)
             e.sync()
-            assert np.array_equal(e.all_scores(TLP), fresh(cols_old, 40))
+            assert np.array_equal(both(e), fresh(cols_old, 40))
         e.update_trimaran_nodes(idx, cols_new)
         e.eval(mask)
         e.sync()
-        assert np.array_equal(e.all_scores(TLP), fresh(mixed, 40))
+        assert np.array_equal(both(e), fresh(mixed, 40))
         e.set_tlp(target_utilization=57)
         e.eval(mask)
         e.sync()
-        assert np.array_equal(e.all_scores(TLP), fresh(mixed, 57))
+        assert np.array_equal(both(e), fresh(mixed, 57))
+        e.set_lvrb(0.7, 2.0)   # another sigma: LVRB's table and constants
+        e.eval(mask)
+        e.sync()
+        assert np.array_equal(both(e), fresh(mixed, 57, (0.7, 2.0)))
         e.upload_trimaran_nodes(cols_new)   # a full re-upload
         e.eval(mask)
         e.sync()
-        assert np.array_equal(e.all_scores(TLP), fresh(cols_new, 57))
+        assert np.array_equal(both(e), fresh(cols_new, 57, (0.7, 2.0)))

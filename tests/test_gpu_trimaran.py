@@ -238,7 +238,7 @@ def test_tlp_ambiguity_table_equals_checked_cells_and_oracle(gpu_required, hdr, 
                 for k in range(ptr[c], ptr[c + 1]):
                     if rs[k] == 0:
                         qt[k] = m if c == cp[i] else 0
-    got = {}
+    got, lv = {}, {}
     with Engine(0) as e:
         e.set_tlp(target_utilization=target)
         e.load_trimaran_objects(snap["nodes"], snap["rc"], pods, snap["metrics"], snap["assigned"])
@@ -247,10 +247,12 @@ def test_tlp_ambiguity_table_equals_checked_cells_and_oracle(gpu_required, hdr, 
         for opt in (1, 0):
             e.set_option("TLP_AMB_TABLE", opt)
             e.stats(reset=True)
-            e.eval(mask_of(ALLOCATABLE, TLP))
+            e.eval(mask_of(ALLOCATABLE, TLP, LVRB))   # LVRB's sweep has the same kind of table (k_lvrb_amb_build: cpu millicores, memory MiB)
             e.sync()
             t = e.all_scores(TLP)
+            lv[opt] = e.all_scores(LVRB)
             n_re = int(e.stats()[TLP])
+            assert e.stats()[LVRB] > 0 or round_frac == 0
             e.eval(mask_of(TLP), 3, n_pods)   # a range that starts inside a chunk
             e.sync()
             assert np.array_equal(e.all_scores(TLP), t)
@@ -258,10 +260,12 @@ def test_tlp_ambiguity_table_equals_checked_cells_and_oracle(gpu_required, hdr, 
             e.sync()
             got[opt] = (t, e.best(), n_re)
         osnap = oracle.Snapshot(snap["nodes"], pods, rc=snap["rc"], metrics=snap["metrics"], assigned=snap["assigned"], alloc_params=e.alloc_params,
-                                tlp_params=tlp_params(hdr, target_utilization=target))
+                                tlp_params=tlp_params(hdr, target_utilization=target), lvrb_params=lvrb_params(hdr))
     want = osnap.score_rows(TLP, threads=oracle.usable_cpus(), want_norm=False)[0]
+    want_lv = osnap.score_rows(LVRB, threads=oracle.usable_cpus(), want_norm=False)[0]
     for opt in (1, 0):
         assert np.array_equal(got[opt][0].astype(np.int64), want), opt
+        assert np.array_equal(lv[opt].astype(np.int64), want_lv), ("LVRB", opt, int((lv[opt].astype(np.int64) != want_lv).sum()))
     for x, y in zip(got[1][1], got[0][1]):
         assert np.array_equal(x, y)
     # both forms re-evaluated cells (the snapshots are tie-heavy), and the table form did not re-evaluate fewer than it had to
