@@ -453,6 +453,254 @@ def check_peaks() -> int:
     return checked
 
 
+def check_trimaran_stats() -> int:
+    """trimaran.py: STATS_METRICS / STATS_EXPECT (resourcestats_test.go:36-161, TestCreateResourceStats): the package-level `metrics`
+    list (type, operator, value per entry), the node's capacity, the pod request and the two expected ResourceStats"""
+    import re
+    import trimaran as T
+    src = (REF / "pkg/trimaran/resourcestats_test.go").read_text()
+    typ = {"watcher.CPU": "CPU", "watcher.Memory": "Memory"}
+    op = {"watcher.Average": "AVG", "watcher.Std": "STD", "": ""}
+    go = parse_literal_after(src, "metrics = ")
+    got = [(typ[m["Type"].name], op[m["Operator"].name if isinstance(m["Operator"], Ident) else m["Operator"]], m["Value"]) for m in go]
+    assert got == [tuple(x) for x in T.STATS_METRICS], got
+    f = src[src.index("func TestCreateResourceStats"):]
+    pr = parse_literal_after(f, "pr := ")
+    assert (eval_const(pr["MilliCPU"]), eval_const(pr["Memory"])) == (100, 1024 * 1024)  # the golden comment's "podRequest {100m, 1Mi}"
+    res = parse_literal_after(src, "nodeResources = ")
+    assert {str(k): v for k, v in res.items()} == {"v1.ResourceCPU": "1000m", "v1.ResourceMemory": "1Gi"}, res
+    for var, key in (("rsExpectedCPU := ", "cpu"), ("rsExpectedMem := ", "memory")):
+        rs = parse_literal_after(f, var)
+        want = dict(capacity=float(rs["Capacity"]), req=float(rs["Req"]), used_avg=float(rs["UsedAvg"]), used_stdev=float(rs["UsedStdev"]))
+        assert T.STATS_EXPECT[key] == want, (key, want)
+    # the three sub-tests: cpu -> rsExpectedCPU, metrics[3:5] only -> (nil, false), memory -> rsExpectedMem
+    tests = parse_literal_after(f, "tests := ")
+    assert [(t["name"], t["wantIsValid"].name) for t in tests] == [("test-cpu", "true"), ("test-missing", "false"), ("test-memory", "true")]
+    return len(got) + 2 + len(tests)
+
+
+def check_nrt_helpers_zones_and_over_reserve() -> int:
+    """nrt_helpers.py: ONLY_NON_NUMA_ZONES (pluginhelpers_test.go:29-47, the NUMANodeList TestOnlyNonNUMAResources runs on) and the two
+    OVER_RESERVE flows — straight-line tests, read off with regular expressions: cache/store_test.go:998 TestResourceStoreUpdate (zones
+    by MakeTopologyResInfo(name, capacity, available), the pod's two containers, every `Available.Cmp(resource.MustParse(...))`
+    expectation and the missing device on zone 0) and cache/overreserve_test.go:292 TestGetCachedNRTCopyReserve over
+    cache_test.go:282 makeDefaultTestTopology()"""
+    import re
+    import nrt_helpers as H
+    checked = 0
+    src = (REF / "pkg/noderesourcetopology/pluginhelpers_test.go").read_text()
+    f = src[src.index("func TestOnlyNonNUMAResources"):]
+    zones = parse_literal_after(f, "numaNodes := ")
+    got = []
+    for z in zones:
+        rl = {}
+        for k, v in z["Resources"].items():
+            name = {"corev1.ResourceCPU": "cpu", "corev1.ResourceMemory": "memory"}.get(str(k.name if isinstance(k, Ident) else k), k if isinstance(k, str) else None)
+            assert name is not None, k
+            rl[name] = str(v.args[0]) if isinstance(v, Call) else v
+        got.append((z["NUMAID"], rl))
+    assert got == [(i, dict(r)) for i, r in H.ONLY_NON_NUMA_ZONES], got
+    checked += len(got)
+
+    names = {"cpu": "cpu", "memory": "memory", "nicName": "vendor.com/nic", "nicResourceName": "vendor.com/nic"}
+    # (the reference's device is "vendor_A.com/nic" in store_test.go and another constant in cache_test.go; the hand-typed table calls
+    # both "vendor.com/nic": only identity within a case matters)
+    def zones_of(text):
+        out = []
+        for zm in re.finditer(r'Name:\s*"node-(\d)".*?ResourceInfoList\{(.*?)\},\s*\},', text, re.S):
+            rl = {names[m.group(1)]: m.group(3) for m in re.finditer(r'MakeTopologyResInfo\((\w+), "([^"]+)", "([^"]+)"\)', zm.group(2))}
+            out.append((int(zm.group(1)), rl))
+        return out
+
+    st = (REF / "pkg/noderesourcetopology/cache/store_test.go").read_text()
+    f = st[st.index("func TestResourceStoreUpdate"):]
+    f = f[:f.index("\nfunc ", 10)]
+    c = H.OVER_RESERVE[0]
+    assert c["source"] == "cache/store_test.go" and c["line"] == st.count("\n", 0, st.index("func TestResourceStoreUpdate")) + 1
+    assert zones_of(f[:f.index("pod := ")]) == [(i, dict(r)) for i, r in c["zones"]]
+    ctrs = []
+    for cm in re.finditer(r'Requests: corev1\.ResourceList\{(.*?)\}', f, re.S):
+        rl = {}
+        for m in re.finditer(r'(corev1\.ResourceCPU|corev1\.ResourceMemory|corev1\.ResourceName\(nicName\)):\s*resource\.MustParse\("([^"]+)"\)', cm.group(1)):
+            rl[{"corev1.ResourceCPU": "cpu", "corev1.ResourceMemory": "memory"}.get(m.group(1), "vendor.com/nic")] = m.group(2)
+        ctrs.append(rl)
+    assert [ctrs] == c["assumed_pods"], ctrs
+    expected = {}
+    for m in re.finditer(r'(\w+) := findResourceInfo\(nrt\.Zones\[(\d)\]\.Resources, (\w+)\)(.*?)(?=\n\t\w+ := findResourceInfo|\Z)', f, re.S):
+        var, zone, res, body = m.group(1), int(m.group(2)), names[m.group(3)], m.group(4)
+        av = re.search(var + r'\.Available\.Cmp\(resource\.MustParse\("([^"]+)"\)\)', body)
+        if av:
+            expected.setdefault(zone, {})[res] = av.group(1)
+        else:
+            assert re.search(r'if ' + var + r' != nil', body), (var, "neither an availability nor an absence expectation")
+    assert sorted(expected.items()) == [(i, dict(r)) for i, r in c["expected"]], expected
+    checked += 1
+
+    ov = (REF / "pkg/noderesourcetopology/cache/overreserve_test.go").read_text()
+    c = H.OVER_RESERVE[1]
+    assert c["source"] == "cache/overreserve_test.go" and c["line"] == ov.count("\n", 0, ov.index("func TestGetCachedNRTCopyReserve(")) + 1
+    f = ov[ov.index("func TestGetCachedNRTCopyReserve("):]
+    f = f[:f.index("\nfunc ", 10)]
+    ct = (REF / "pkg/noderesourcetopology/cache/cache_test.go").read_text()
+    topo = ct[ct.index("func makeDefaultTestTopology"):]
+    topo = topo[:topo.index("\n}\n") + 3]
+    assert 'Name: "node1"' in topo and 'ReserveNodeResources("node1"' in f and 'GetCachedNRTCopy(context.Background(), "node1"' in f
+    assert zones_of(topo) == [(i, dict(r)) for i, r in c["zones"]], zones_of(topo)
+    req = re.search(r'Requests: corev1\.ResourceList\{(.*?)\}', f, re.S).group(1)
+    rl = {{"corev1.ResourceCPU": "cpu", "corev1.ResourceMemory": "memory"}[m.group(1)]: m.group(2)
+          for m in re.finditer(r'(corev1\.Resource\w+):\s*resource\.MustParse\("([^"]+)"\)', req)}
+    assert [[rl]] == c["assumed_pods"], rl
+    want = {{"corev1.ResourceCPU": "cpu", "corev1.ResourceMemory": "memory"}[m.group(1)]: m.group(2)
+            for m in re.finditer(r'case string\((corev1\.Resource\w+)\):\s*if zoneRes\.Available\.Cmp\(resource\.MustParse\("([^"]+)"\)\)', f)}
+    for i, r in c["expected"]:  # every zone: cpu and memory as the switch expects them, the device untouched
+        assert {k: v for k, v in r.items() if k != "vendor.com/nic"} == want and r["vendor.com/nic"] == dict(c["zones"])[i]["vendor.com/nic"], (i, r, want)
+    checked += 1
+    return checked
+
+
+def _run_pod_statements(body: str):
+    """A reader for the straight-line fixture code of resourcestats_test.go's two tests — `var x int64 = n`, `x := []int64{...}`,
+    reassignments, `p := getPodWithContainersAndOverhead(...)`, `p = getPodWithLimits(p, ...)` — evaluated with lroc.pod_with's
+    restatement of the two builders (:612-648).  Yields ("res", pod) at every `GetResourceLimits(p)` assignment and ("want",
+    cpu, mem) at every `resExpected` literal, in source order; returns the final environment as well."""
+    import re
+    import lroc as L
+    env, events = {}, []
+
+    def val(tok):
+        tok = tok.strip()
+        return env[tok] if tok in env else eval_const_text(tok)
+
+    def eval_const_text(t):
+        assert re.fullmatch(r"[\d\s*+]+", t), t
+        return eval(t)  # digits, * and + only
+
+    for line in body.split("\n"):
+        line = line.strip()
+        m = re.fullmatch(r"(?:var )?(\w+)(?: int64)? :?= ([\d\s*+]+)", line)
+        if m:
+            env[m.group(1)] = eval_const_text(m.group(2))
+            continue
+        m = re.fullmatch(r"(\w+) :?= \[\]int64\{([^}]*)\}", line)
+        if m:
+            env[m.group(1)] = [eval_const_text(x) for x in m.group(2).split(",") if x.strip()]
+            continue
+        m = re.fullmatch(r"(\w+) :?= getPodWithContainersAndOverhead\(([^)]*)\)", line)
+        if m:
+            a = [val(x) for x in m.group(2).split(",")]
+            assert len(a[3]) == len(a[4])
+            env[m.group(1)] = dict(ovhd=a[0], init_req=(a[1], a[2]), cont_req=list(zip(a[3], a[4])), init_lim=None, cont_lim=None)
+            continue
+        m = re.fullmatch(r"(\w+) = getPodWithLimits\((\w+), ([^)]*)\)", line)
+        if m:
+            a = [val(x) for x in m.group(3).split(",")]
+            src = dict(env[m.group(2)])
+            if len(a[2]) == len(a[3]) == len(src["cont_req"]):  # :634-636: otherwise the pod comes back unchanged
+                src["init_lim"], src["cont_lim"] = (a[0], a[1]), list(zip(a[2], a[3]))
+            env[m.group(1)] = src
+            continue
+        m = re.fullmatch(r"(\w+) :?= GetResourceLimits\((\w+)\)", line)
+        if m:
+            events.append(("res", env[m.group(2)]))
+            continue
+    for m in re.finditer(r"resExpected :?= &framework\.Resource\{\s*MilliCPU:\s*([\d\s*]+),\s*Memory:\s*([\d\s*]+),\s*\}", body):
+        events.append(("want", m.start(), eval_const_text(m.group(1)), eval_const_text(m.group(2))))
+    to_pod = lambda d: L.pod_with(d["ovhd"], d["init_req"], d["cont_req"], d["init_lim"], d["cont_lim"])
+    return env, events, to_pod
+
+
+def check_lroc_resource_tables() -> int:
+    """lroc.py: RESOURCE_LIMITS (resourcestats_test.go:203-257, TestGetResourceLimits: four pods built by two helper calls each and
+    the expected (milliCPU, memory) after each), NODE_REQUESTS_LIMITS (:374-603, TestGetNodeRequestsAndLimits: the four pods, which
+    of them sit on the node, the two nodes, and `want` — literal products for test-0 / test-1; for test-2 / test-3 the reference
+    writes min / max expressions over GetResourceRequested / GetResourceLimits and the node's capacity, evaluated here with the
+    hand-typed pod's own sums) and SCORE_CASES (lowriskovercommitment_test.go:138-243: one case)"""
+    import re
+    import lroc as L
+    src = (REF / "pkg/trimaran/resourcestats_test.go").read_text()
+    checked = 0
+    f = src[src.index("func TestGetResourceLimits"):]
+    f = f[:f.index("\nfunc ", 10)]
+    env, events, to_pod = _run_pod_statements(f)
+    pods = [to_pod(d) for k, d in [(e[0], e[1]) for e in events if e[0] == "res"]]
+    # GetResourceLimits(pod0) is assigned to `res0`: same statement shape
+    wants = [(e[2], e[3]) for e in events if e[0] == "want"]
+    assert len(pods) == len(wants) == len(L.RESOURCE_LIMITS) == 4, (len(pods), len(wants))
+    for (pod, cpu, mem), got_pod, (wc, wm) in zip(L.RESOURCE_LIMITS, pods, wants):
+        assert pod == got_pod and (cpu, mem) == (wc, wm), (cpu, mem, wc, wm)
+        checked += 1
+
+    f = src[src.index("func TestGetNodeRequestsAndLimits"):]
+    f = f[:f.index("\nfunc ", 10)]
+    env, _, to_pod = _run_pod_statements(f[:f.index("tests := ")])
+    # the statements reassign contCPULimit / contMemLimit between the pods: pod..pod2 share one shape, pod3 and pod4 differ
+    want_pods = {"pod": L.POD, "pod1": L.POD, "pod2": L.POD, "pod3": L.POD3, "pod4": L.POD4}
+    for name, want in want_pods.items():
+        assert to_pod(env[name]) == want, name
+    nodes = [m.group(1) for m in re.finditer(r"v1\.ResourceCPU:\s*\"(\w+)\"", f[:f.index("tests := ")])]
+    mems = [m.group(1) for m in re.finditer(r"v1\.ResourceMemory:\s*\"(\w+)\"", f[:f.index("tests := ")])]
+    assert ({"cpu": nodes[0], "memory": mems[0]}, {"cpu": nodes[1], "memory": mems[1]}) == (L.TEST_NODE, L.LOW_NODE)
+    node_of = {"testNode": L.TEST_NODE, "testNodeWithLowNodeCapacity": L.LOW_NODE}
+    info_of = {"podInfo1": L.POD, "podInfo2": L.POD, "podInfo3": L.POD3}
+
+    def sums(pod):  # GetResourceRequested / GetResourceLimits of a pod_with() pod: max(sum of containers, init container) + overhead
+        q = lambda d, k: int(str(d.get(k, 0)).rstrip("m")) if k == "cpu" else int(d.get(k, 0))
+        out = {}
+        for what in ("requests", "limits"):
+            for k in ("cpu", "memory"):
+                tot = sum(q(c[what], k) for c in pod["containers"])
+                tot = max(tot, max((q(c[what], k) for c in pod["init_containers"]), default=0))
+                out[(what, k)] = tot + (q(pod["overhead"], k) if k == "cpu" else 0)
+        return out
+
+    tests = parse_literal_after(f, "tests := ")
+    assert len(tests) == len(L.NODE_REQUESTS_LIMITS)
+    for t, c in zip(tests, L.NODE_REQUESTS_LIMITS):
+        a = t["args"]
+        assert t["name"] == c["name"] and [info_of[x.name] for x in a["podsOnNode"]] == c["on_node"] and node_of[a["node"].name] == c["node"], t["name"]
+        assert want_pods[a["pod"].name] == c["pod"], t["name"]
+        cap_cpu, cap_mem = int(c["node"]["cpu"].rstrip("m")), {"6Ki": 6 * 1024}[c["node"]["memory"]]
+
+        def ev(v):
+            if isinstance(v, int):
+                return v
+            if isinstance(v, Ident):
+                return {"capCpu": int(L.LOW_NODE["cpu"].rstrip("m")), "capMem": 6 * 1024}[v.name]
+            if isinstance(v, Call) and v.fn in ("op*", "op+"):
+                return eval_const(v)
+            if isinstance(v, Call) and v.fn in ("min", "max"):
+                vals = [ev(x) for x in v.args]
+                return min(vals) if v.fn == "min" else max(vals)
+            if isinstance(v, Call) and v.fn == "select":  # GetResourceRequested(pod4).MilliCPU
+                inner, field = v.args
+                s_ = sums(want_pods[inner.args[0].name])
+                return s_[({"GetResourceRequested": "requests", "GetResourceLimits": "limits"}[inner.fn], "cpu" if field == "MilliCPU" else "memory")]
+            raise ValueError(repr(v))
+
+        w = t["want"]
+        got = dict(req_cpu=ev(w["NodeRequest"]["MilliCPU"]), req_mem=ev(w["NodeRequest"]["Memory"]), lim_cpu=ev(w["NodeLimit"]["MilliCPU"]),
+                   lim_mem=ev(w["NodeLimit"]["Memory"]), req_minus_pod_cpu=ev(w["NodeRequestMinusPod"]["MilliCPU"]),
+                   req_minus_pod_mem=ev(w["NodeRequestMinusPod"]["Memory"]), lim_minus_pod_cpu=ev(w["NodeLimitMinusPod"]["MilliCPU"]),
+                   lim_minus_pod_mem=ev(w["NodeLimitMinusPod"]["Memory"]), cap_cpu=ev(w["Nodecapacity"]["MilliCPU"]), cap_mem=ev(w["Nodecapacity"]["Memory"]))
+        assert (got["cap_cpu"], got["cap_mem"]) == (cap_cpu, cap_mem), t["name"]
+        assert got == c["want"], (t["name"], got, c["want"])
+        checked += 1
+
+    src = (REF / "pkg/trimaran/lowriskovercommitment/lowriskovercommitment_test.go").read_text()
+    p0 = src.index("func TestLowRiskOverCommitment_Score")
+    tests = parse_literal_after(src[p0:], "tests := ")
+    assert len(tests) == len(L.SCORE_CASES) == 1
+    t, c = tests[0], L.SCORE_CASES[0]
+    m = t["watcherResponse"]["Data"]["NodeMetricsMap"]["node-1"]["Metrics"]
+    typ = {"watcher.CPU": "CPU", "watcher.Memory": "Memory"}
+    op = {"watcher.Average": "AVG", "watcher.Std": "STD", "watcher.Latest": "Latest"}
+    assert {0: [(typ[x["Type"].name], op[x["Operator"].name], x["Value"]) for x in m]} == c["metrics"], m
+    assert [eval_const(e["Score"], {"fwk.MinNodeScore": 0, "fwk.MaxNodeScore": 100}) for e in t["expected"]] == c["expected"]
+    assert abs(c["line"] - line_of(src, '"' + t["test"] + '"', p0)) <= 10
+    checked += 1
+    return checked
+
+
 if __name__ == "__main__":
     print("allocatable.py:", check_allocatable(), "cases agree with allocatable_test.go")
     print("trimaran.py:", check_trimaran(), "rows of COMPUTE_SCORE / MU_SIGMA agree with analysis_test.go / resourcestats_test.go")
@@ -464,3 +712,6 @@ if __name__ == "__main__":
     print("nrt_helpers.py:", check_nrt_helpers_pods(), "rows (GetPodEffectiveRequest, IncludeNonNative, minAvgDistanceInCombinations) agree with the Go tables")
     print("nrt_helpers.py:", check_nrt_helpers_numa_lists(), "subtract cases agree with numaresources_test.go")
     print("peaks.py:", check_peaks(), "fixtures agree with peaks_test.go")
+    print("lroc.py:", check_lroc_resource_tables(), "rows (GetResourceLimits, GetNodeRequestsAndLimits, the Score case) agree with resourcestats_test.go / lowriskovercommitment_test.go")
+    print("trimaran.py:", check_trimaran_stats(), "items of STATS_METRICS / STATS_EXPECT agree with resourcestats_test.go (TestCreateResourceStats)")
+    print("nrt_helpers.py:", check_nrt_helpers_zones_and_over_reserve(), "items (ONLY_NON_NUMA_ZONES, the two OVER_RESERVE flows) agree with pluginhelpers_test.go / cache/*_test.go")

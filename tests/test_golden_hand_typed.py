@@ -30,3 +30,15 @@ def test_trimaran_lroc_peaks_tables_agree_with_the_go_sources():
     assert verify_hand_typed.check_nrt_helpers_pods() == 22
     assert verify_hand_typed.check_nrt_helpers_numa_lists() == 11
     assert verify_hand_typed.check_peaks() == 10
+
+
+@pytest.mark.skipif(not REF.exists(), reason="/root/reference is not mounted here")
+def test_round5_tables_agree_with_the_go_sources():
+    """what round 4's review listed as still hand-typed only and round 5 re-read: trimaran.py's STATS_* (TestCreateResourceStats), lroc.py's
+    GetResourceLimits / GetNodeRequestsAndLimits tables and Score case (the straight-line fixture code of resourcestats_test.go read by a
+    small statement reader), nrt_helpers.py's ONLY_NON_NUMA_ZONES and the two OVER_RESERVE flows (straight-line tests, regular expressions)"""
+    sys.path.insert(0, str(Path(__file__).parent / "golden"))
+    import verify_hand_typed
+    assert verify_hand_typed.check_trimaran_stats() == 10
+    assert verify_hand_typed.check_lroc_resource_tables() == 9
+    assert verify_hand_typed.check_nrt_helpers_zones_and_over_reserve() == 4
