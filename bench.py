@@ -264,6 +264,15 @@ def config5_leg(hdr, device, n_pods=8192):
         e.sync()
         out["sweep_every_row_ms"] = (time.perf_counter() - t0) * 1e3 / 5
         e.set_option("NRT_POD_CLASSES", 1)
+        e.eval(mask)
+        e.eval_best(mask)
+        e.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            e.eval(mask)
+            e.eval_best(mask)
+        e.sync()
+        out["sweep_plus_argmax_ms"] = (time.perf_counter() - t0) * 1e3 / 5   # spx_eval + spx_eval_best: what spx_decide replaces
         e.decide(mask)
         e.sync()
         t0 = time.perf_counter()
