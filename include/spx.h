@@ -737,6 +737,13 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *                              where a cell of the float32 formulation can be within its error bound of a rounding tie or of the branch point
  *                              (a property of the node alone: the score is piecewise linear in the pod's integer millicores), and only the rows
  *                              named there carry the per-cell exactness bookkeeping; 0 = every cell carries it.  Same tables either way
+ *   SPX_OPT_NRT_PACKED_SCORE   1 (default) = NodeResourceTopologyMatch LeastAllocated's Score launch of a row range keeps the zone totals of two
+ *                              zones per register and scores in packed float32 (4 instructions per zone pair and resource instead of 6) when
+ *                              every weighted slot qualifies: capacities / 2^s <= 32768 with 2^s the power of two common to the slot's
+ *                              capacities and requests (cpu in whole cores, devices, hugepages in pages), or — one slot, memory in bytes —
+ *                              through a per-launch table of the requests for which the float32 form differs from the division (those pods
+ *                              are recomputed in float64 for the node window concerned); spx_nrt_packed_score_slots reports which;
+ *                              0 = float64 throughout.  Same tables either way
  */
 #define SPX_OPT_ROW_ALIGN 0
 #define SPX_OPT_REFERENCE_KERNELS 1
@@ -752,7 +759,8 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
 #define SPX_OPT_NRT_RANK_FILTER 11
 #define SPX_OPT_ROW_WORKGROUP 12
 #define SPX_OPT_TLP_AMB_TABLE 13
-#define SPX_NUM_OPTIONS 14
+#define SPX_OPT_NRT_PACKED_SCORE 14
+#define SPX_NUM_OPTIONS 15
 int spx_set_option(spx_engine* e, int option, int64_t value);
 int spx_get_option(const spx_engine* e, int option, int64_t* value);
 
@@ -787,6 +795,10 @@ int spx_commit_path(const spx_engine* e);
 /* Which Filter launch the last NodeResourceTopologyMatch sweep ran: 1 = float64 compares (k_nrt_fast / the reference-arithmetic
  * kernel), 2 = rank space (SPX_OPT_NRT_RANK_FILTER: whole-batch sweeps over pod classes); 0 = none yet */
 int spx_nrt_filter_path(const spx_engine* e);
+/* SPX_OPT_NRT_PACKED_SCORE with the uploaded tables and parameters: 0 = the LeastAllocated Score launch keeps float64 (other strategy,
+ * large weights, a slot that qualifies neither way, option off); else bit 24 set, bits 0..15 = the weighted slots (positions of the
+ * uploaded slot table) that are packed unconditionally, bits 16..23 = 1 + the slot that goes through the per-launch table, 0 = none */
+int spx_nrt_packed_score_slots(const spx_engine* e);
 
 /* which formulation of a plugin's sweep the uploaded tables select: 0 = generic (reference arithmetic, operation for
  * operation), 1 = fast formulation (same results; see DESIGN.md for each kernel's preconditions); <0 on error.

@@ -443,8 +443,9 @@ constexpr int nrt_waves() {
 constexpr int kLnFull = 0, kLnDefer = 1, kLnIfOverflow = 2;
 constexpr int kLnRedo = 255;  // score byte of a listed cell (scores are <= 100)
 
-template <int RM, int SG, int PH, int LNM = kLnFull>
-__global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(NrtArgs a, int n_tiles) {
+template <int RM, int SG, int PH, int LNM = kLnFull, bool PK = false>
+__global__ __launch_bounds__(256, (PK && RM == 4 ? 5 : nrt_waves<RM, SG, PH>())) void k_nrt_fast(NrtArgs a, int n_tiles) {
+  static_assert(!PK || (PH == kPhScore && SG == kSgLeast), "the packed float32 zone totals belong to LeastAllocated's Score-only launch");
   SPX_RESOLVE_ROWS(a);
   if constexpr (LNM == kLnIfOverflow) {
     if (a.redo_list[0] == 0u) return;  // block-uniform: no row's list overflowed
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
   constexpr int kRedoBuf = (SG == kSgBalanced && PH == kPhScore) ? 1024 : 1;
   __shared__ uint32_t redo_buf[kRedoBuf][2];
   __shared__ uint32_t redo_n, redo_base;
+  __shared__ uint32_t pk_flagged;  // packed LeastAllocated Score: the chunk's pods with a request k_nrt_pk_tab_build lists for this window
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // Blocks are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD has its own L2.  Each XCD
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
   FastNode<RM> ns;
   double cpu_v[kZ], braw[kZ];
   const uint32_t flags = in ? a.flags[n] : 0u;
-  load_fast_node<RM, SG>(a, n, in, ns, cpu_v, braw);
+  load_fast_node<RM, SG, PK>(a, n, in, ns, cpu_v, braw);
   // BalancedAllocation's Score launch works from float32 images of the reciprocals; the float64 tables die here
   constexpr bool kBalF32 = SG == kSgBalanced && PH == kPhScore;
   BalNode<RM> bn;
@@ -555,13 +557,28 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
         dst[i] = reinterpret_cast<const uint4*>(a.pod_items + static_cast<int64_t>(a.row_list[first + p]) * pod_words<RM>())[q];
       }
     }
-    if (threadIdx.x == 0) redo_n = 0;
+    if (threadIdx.x == 0) redo_n = 0, pk_flagged = 0;
     uint4* z = reinterpret_cast<uint4*>(&stage[0][0][0]) + threadIdx.x;  // empty slots of the window stay 0 (row padding)
 #pragma unroll
     for (int i = 0; i < static_cast<int>(sizeof(stage) / 16 / 256); ++i) z[i * 256] = uint4{0, 0, 0, 0};
   }
   __syncthreads();
-
+  if constexpr (PK) {
+    // the pods whose table-slot request (any of their items) is listed for THIS node window: recomputed in float64 after the loop
+    const int ts = a.pk_tab_slot;
+    if (ts >= 0) {  // uniform
+      for (int i = threadIdx.x; i < rows * (kItemsPerPod - 1); i += 256) {
+        const int p = i / (kItemsPerPod - 1);
+        const uint32_t* w = pod_lds + p * pod_words<RM>() + (1 + i % (kItemsPerPod - 1)) * item_words<RM>();
+        if (!((w[2 * RM] >> ts) & 1u)) continue;
+        const double k = __hiloint2double(static_cast<int>(w[2 * ts + 1]), static_cast<int>(w[2 * ts])) * a.pk_tab_inv_unit;
+        // (the engine derived unit and kmax from this very batch: k is a whole number within the table; anything else is recomputed too)
+        const bool inside = k >= 0.0 && k <= static_cast<double>(a.pk_tab_kmax) && k == __builtin_floor(k);
+        const uint32_t word = inside ? a.pk_tab[static_cast<size_t>(static_cast<uint32_t>(k)) * a.pk_tab_words + (static_cast<uint32_t>(window) >> 5)] : ~0u;
+        if ((word >> (static_cast<uint32_t>(window) & 31u)) & 1u) atomicOr(&pk_flagged, 1u << p);
+      }
+    }
+  }
   // What the wave's 64 nodes have in common (wave-uniform): a pod the launch has nothing to compute for — not filtered,
   // not Guaranteed — skips the exec-masked regions with one scalar branch.  Round 2's loop ran every pod through them
   // (48 scalar instructions for a BestEffort pod; scalar and vector instructions issue at the same rate per SIMD).
@@ -612,7 +629,7 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
             score = score_balanced_f32(bn, ns.nz, a.cpu_slot, a.exact32_slots, it, &rd);
             redo |= rd;
           } else {
-            score = score_each_fast<RM, SG>(ns, a, it, cpu_v, braw);
+            score = score_each_fast<RM, SG, PK>(ns, a, it, cpu_v, braw);
           }
         }
       }
@@ -643,7 +660,7 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
           }
         }
         if constexpr ((SG == kSgLeast || SG == kSgMost) && PH != kPhFilter) {
-          if (want_score) sum += score_each_fast<RM, SG>(ns, a, it, cpu_v, braw);
+          if (want_score) sum += score_each_fast<RM, SG, PK>(ns, a, it, cpu_v, braw);
         }
         cur = nxt;
       }
@@ -665,7 +682,7 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
               sum += score_balanced_f32(bn, ns.nz, a.cpu_slot, a.exact32_slots, it, &rd);
               redo |= rd;
             } else {
-              sum += score_each_fast<RM, SG>(ns, a, it, cpu_v, braw);
+              sum += score_each_fast<RM, SG, PK>(ns, a, it, cpu_v, braw);
             }
           }
         }
@@ -749,6 +766,47 @@ __global__ __launch_bounds__(256, (nrt_waves<RM, SG, PH>())) void k_nrt_fast(Nrt
       atomicAdd(a.stats + (SPX_PLUGIN_NRT * kStatSlots + static_cast<int>(blockIdx.x & (kStatSlots - 1))) * kStatStride, static_cast<unsigned long long>(rows) * kWindow);
   }
   __syncthreads();
+  if constexpr (PK) {
+    const uint32_t flagged = pk_flagged;  // block-uniform (every atomicOr precedes the barrier above)
+    if (flagged != 0) {
+      // second pass: the flagged pods' cells of this window with the table slot in the float64 form — its eight multipliers read
+      // again (the loop kept float32 pairs), the other slots packed as before.  Each lane rewrites its own byte of the staged dword.
+      double bt[kZ];
+#pragma unroll
+      for (int z = 0; z < kZ; ++z) {
+        const double b = in ? a.f_rc[(static_cast<int64_t>(z) * R + a.pk_tab_slot) * a.n_nodes + n] : kNrtNoCap;
+        bt[z] = b == kNrtNoCap ? __builtin_inf() : b;
+      }
+      uint32_t n_redone = 0;
+      for (uint32_t left = flagged; left != 0; left &= left - 1) {
+        const int p = __builtin_ctz(left);
+        const uint32_t* pit = pod_lds + p * pod_words<RM>();
+        const uint32_t h0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(pit[0])));
+        const uint32_t h1 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(pit[1])));
+        if ((h0 & 0xffu) != SPX_QOS_GUARANTEED) continue;  // uniform: 100 everywhere, the loop wrote it
+        ++n_redone;
+        const int n_ctr = (h0 >> 16) & 0xffu;
+        int score = 0;
+        if (aligned) {
+          if (pod_scope) {
+            score = score_each_fast<RM, SG, true, true>(ns, a, decode_item<RM, FULL>(load_item<RM, FULL>(pit, 1)), cpu_v, braw, bt);
+          } else {
+            int sum = 0;
+            for (int c = 0; c < n_ctr; ++c) sum += score_each_fast<RM, SG, true, true>(ns, a, decode_item<RM, FULL>(load_item<RM, FULL>(pit, 2 + c)), cpu_v, braw, bt);
+            score = static_cast<int>((static_cast<uint32_t>(sum) * h1) >> 16);
+          }
+        }
+        if (in) {
+          const int sh = 8 * (p & 3);
+          uint32_t& cell = stage[kScoreTab][p >> 2][pos];
+          cell = (cell & ~(0xffu << sh)) | (static_cast<uint32_t>(score) << sh);
+        }
+      }
+      if (a.stats && threadIdx.x == 0 && n_redone)  // these cells count as re-evaluated (spx_fetch_stats)
+        atomicAdd(a.stats + (SPX_PLUGIN_NRT * kStatSlots + static_cast<int>(blockIdx.x & (kStatSlots - 1))) * kStatStride, static_cast<unsigned long long>(n_redone) * kWindow);
+      __syncthreads();
+    }
+  }
   if constexpr (kBalF32) {
     const uint32_t cnt = redo_n < static_cast<uint32_t>(kRedoBuf) ? redo_n : static_cast<uint32_t>(kRedoBuf);
     if (cnt != 0) {  // block-uniform
@@ -1044,6 +1102,41 @@ __global__ __launch_bounds__(256, RM == 4 ? 2 : 1) void k_nrt_ln_redo(NrtArgs a)
 
 }  // namespace
 
+namespace {
+// The requests of the table slot for which the packed float32 LeastAllocated score differs from the integer division
+// (score_least_packed).  A difference needs x = 100 - 100 v / c within o + |e| < 1.8e-5 of an integer, i.e. v within 1.8e-7 c of
+// j c / 100 for some j = 0..100: one thread per (node, zone, j) walks the multiples of the unit inside 2.7e-7 c of that point (mostly
+// none: the unit is 2^20 for memory, 2.7e-7 c is 4.6 KB for a 16 GiB zone), REPLAYS the kernel's expression on each and compares with
+// (c - v) * 100 / c.  Bit (window & 31) of word window / 32 of the value's row.
+__global__ __launch_bounds__(256) void k_nrt_pk_tab_build(NrtArgs a) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int j = static_cast<int>(idx & 127), z = static_cast<int>((idx >> 7) % kZ);
+  const int64_t slot = idx / (128 * kZ);  // position in the window order (perm: the block that owns the node is the one that looks it up)
+  if (j > 100 || slot >= (a.n_nodes + kWindow - 1) / kWindow * kWindow || a.pk_tab_slot < 0) return;
+  const int32_t pn = a.perm[slot];
+  if (pn < 0) return;
+  const int64_t at = (static_cast<int64_t>(z) * a.n_res + a.pk_tab_slot) * a.n_nodes + pn;
+  const double c = a.f_av[at];  // available = the capacity LeastAllocated scores against; -1: not reported
+  if (!(c > 0.0)) return;       // no capacity: 0 in both forms whatever the request
+  const double b64 = a.f_rc[at];
+  const float b32 = static_cast<float>(b64 == kNrtNoCap ? __builtin_inf() : b64);
+  const double unit = 1.0 / a.pk_tab_inv_unit;
+  const double mid = static_cast<double>(j) * c / 100.0, half = 2.7e-7 * c + 1e-9 * mid;
+  double k0 = __builtin_ceil((mid - half) * a.pk_tab_inv_unit), k1 = __builtin_floor((mid + half) * a.pk_tab_inv_unit);
+  k0 = k0 < 0.0 ? 0.0 : k0;
+  k1 = k1 > static_cast<double>(a.pk_tab_kmax) ? static_cast<double>(a.pk_tab_kmax) : k1;
+  const uint32_t window = static_cast<uint32_t>(slot / kWindow);
+  const int64_t ci = static_cast<int64_t>(c);
+  for (double k = k0; k <= k1; k += 1.0) {
+    const double v = k * unit;
+    const int64_t vi = static_cast<int64_t>(v);
+    const uint32_t want = vi > ci ? 0u : static_cast<uint32_t>(((ci - vi) * 100) / ci);  // leastAllocatedScore, least_allocated.go:45-55
+    const uint32_t got = nrtdev::least_packed_one(static_cast<float>(v), b32, 99.5f + nrtdev::kPkOffsetTab);
+    if (got != want) atomicOr(a.pk_tab + static_cast<size_t>(k) * a.pk_tab_words + (window >> 5), 1u << (window & 31u));
+  }
+}
+}  // namespace
+
 bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   if (!a.fast) return false;
   if (a.strategy == SPX_NRT_LEAST_NUMA_NODES && !a.ln_tab) return false;
@@ -1071,7 +1164,15 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((k_nrt_ln_redo<RMV>), dim3(2048), dim3(256), 0, s, a); /* persistent waves */ \
         hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore, SGV == kSgLeastNuma ? kLnIfOverflow : kLnFull>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
       } else { \
-        hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
+        if (SGV == kSgLeast && a.pk_mode && a.pk_tab_slot >= 0 && !(a.pk_tab_built && *a.pk_tab_built)) { /* the table of the packed float32 Score */ \
+          (void)hipMemsetAsync(a.pk_tab, 0, (static_cast<size_t>(a.pk_tab_kmax) + 1) * a.pk_tab_words * 4, s); \
+          hipLaunchKernelGGL(k_nrt_pk_tab_build, dim3(static_cast<unsigned>(static_cast<int64_t>(n_tiles) * kWindow * kZ * 128 / 256)), dim3(256), 0, s, a); \
+          if (a.pk_tab_built) *a.pk_tab_built = true; \
+        } \
+        if (SGV == kSgLeast && a.pk_mode) \
+          hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhScore, kLnFull, true>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
+        else \
+          hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
       } \
       if (SGV == kSgBalanced) { /* ... recomputed in float64 from the list; the scan pass only acts when the list overflowed */ \
         const int64_t units = (a.row_end - a.row_begin) * (a.row_stride / 16); \

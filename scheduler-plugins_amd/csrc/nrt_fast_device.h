@@ -197,12 +197,93 @@ __device__ __forceinline__ void adjust_fast(FastNode<RM>& ns, const Item<RM>& it
   }
 }
 
+// LeastAllocated's zone totals in PACKED float32 (round 5; the Score-only launch of a whole-batch sweep, NrtArgs::pk_mode).
+// The Score launch issues one vector instruction per 4 cycles whatever its kind (VALU slots 95 % used, profiles/r04), so what counts
+// is the NUMBER of instructions: the float64 form spends 3 per (zone, resource) — v_fma_f64, v_cvt_u32_f64, v_mad_u32_u24; this one
+// 4 per zone PAIR — v_pk_fma_f32, 2 x v_cvt_pk_u8_f32, v_pk_mad_u16 — with the totals of two zones in the halves of one register.
+//   t = fma(-v, b32, 99.5 + o),  b32 = RN32(RN64(100 / c));  rs = v_cvt_pk_u8_f32(t) = RNE(t) clamped to [0, 255], NaN -> 0
+// (tools/micro/cvt_pk_u8.hip).  x = 100 - 100 v / c; t = x - 0.5 + o + e with |e| <= 5.96e-6 (b32's relative error 2^-24 on
+// 100 v / c <= 100) + 3.8e-6 (the fma's rounding below 128) < 9.8e-6.  With x = n + f: RNE(t) = n whenever 0 < f + o + e < 1.
+// The engine turns the form on only when EVERY weighted slot is of one of two kinds (nrt_packed_score, spx_engine.hip):
+//   * small: with 2^s the largest power of two dividing every zone capacity and every request of the slot, c / 2^s <= 32768 and
+//     v / 2^s < 2^24 (cpu in whole cores, devices, hugepages in pages, memory on clusters that report whole MiB): v is a float32 value
+//     and x a multiple of 2^s / c, so f is 0 or lies in [3.05e-5, 1 - 3.05e-5]; with o = 2^-16 the condition always holds;
+//   * the table slot (one at most: memory in bytes): o = 2^-17, and k_nrt_pk_tab_build REPLAYS this very formula for every request
+//     value k * unit that lands within 2.7e-5 of an integer score for some zone, against the integer division; the values it gets
+//     wrong (about 8 in 10^6 per zone) are listed per node window.  The block that stages a pod with a listed request for ITS window
+//     recomputes that pod's 256 cells in the float64 form after the sweep of the chunk (k_nrt_fast's second pass, about 3 % of the
+//     (pod, window) pairs of config #3) — the loop itself never branches on it.
+// x < 0 (request above capacity) and cells without capacity (b32 = +inf: -inf, or NaN for an explicit zero request) convert to 0 —
+// the reference's zeros.  Zone totals are u16: start at -sum(weights) mod 2^16 so that a zone whose score is 0 stays "negative" = at
+// least 2^15 and drops out of the unsigned minimum (100 * sum(weights) < 2^15: kNrtPkMaxWeightSum).  The float32 multipliers live as
+// zone pairs in ns.b[0..3][r] (load_fast_node<.., PK>); ns.b[4..7][r] are unused.
+constexpr float kPkOffsetSmall = 0x1p-16f, kPkOffsetTab = 0x1p-17f;
+
+// one resource of one zone, exactly as the packed loop computes it (k_nrt_pk_tab_build replays the table slot with it)
+__device__ __forceinline__ uint32_t least_packed_one(float v, float b32, float c0) {
+  return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(-v, b32, c0), 0, 0u) & 0xffu;
+}
+
+// MIXED (k_nrt_fast's second pass over the pods the table lists for the block's window): the table slot in the float64 form from
+// bt[zone] = RN64(100 / c) (+inf without capacity), every other slot packed as in the loop
+template <int RM, bool MIXED = false>
+__device__ __forceinline__ int score_least_packed(const FastNode<RM>& ns, const NrtArgs& a, const Item<RM>& it, const double (&value)[RM],
+                                                  const double* __restrict__ bt = nullptr) {
+  typedef float F32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned short U16x2 __attribute__((ext_vector_type(2)));
+  static_assert(kZ == 8, "four zone pairs");
+  const uint32_t wsum = it.wsum_i;
+  const unsigned short a0 = static_cast<unsigned short>(0u - wsum);
+  U16x2 accp[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) accp[k] = U16x2{a0, a0};
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    if (!((it.used >> r) & 1u)) continue;
+    SPX_KEEP_BRANCH();
+    const unsigned short w16 = static_cast<unsigned short>(a.slot_weight[r]);
+    const U16x2 wv{w16, w16};
+    if constexpr (MIXED) {
+      if (r == a.pk_tab_slot) {  // uniform
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t r0 = static_cast<uint32_t>(__builtin_fma(-value[r], bt[2 * k], 100.0 + 0x1p-43));  // (as score_each_fast's float64 form)
+          const uint32_t r1 = static_cast<uint32_t>(__builtin_fma(-value[r], bt[2 * k + 1], 100.0 + 0x1p-43));
+          const uint32_t pk = r0 | (r1 << 16);
+          U16x2 pv;
+          __builtin_memcpy(&pv, &pk, 4);
+          accp[k] = pv * wv + accp[k];
+        }
+        continue;
+      }
+    }
+    const float nvf = -static_cast<float>(value[r]);
+    const float c0f = 99.5f + (r == a.pk_tab_slot ? kPkOffsetTab : kPkOffsetSmall);  // scalar select
+    const F32x2 nv{nvf, nvf}, c0{c0f, c0f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      F32x2 bp;
+      __builtin_memcpy(&bp, &ns.b[k][r], 8);
+      const F32x2 t = __builtin_elementwise_fma(nv, bp, c0);
+      uint32_t pk = __builtin_amdgcn_cvt_pk_u8_f32(t.x, 0, 0u);
+      pk = __builtin_amdgcn_cvt_pk_u8_f32(t.y, 2, pk);
+      U16x2 pv;
+      __builtin_memcpy(&pv, &pk, 4);
+      accp[k] = pv * wv + accp[k];
+    }
+  }
+  const U16x2 mm = __builtin_elementwise_min(__builtin_elementwise_min(accp[0], accp[1]), __builtin_elementwise_min(accp[2], accp[3]));
+  const unsigned short m16 = mm.x < mm.y ? mm.x : mm.y;
+  if (m16 >= 0x8000u) return 0;  // no zone scores
+  return static_cast<int>(static_cast<double>(static_cast<unsigned short>(m16 + static_cast<unsigned short>(wsum))) * it.wrc);
+}
+
 // scoreForEachNUMANode score.go:110-124: the minimum of the non-zero zone scores, 0 when there is none (the
 // reference's running rule `min == 0 || (s != 0 && s < min)` is order-independent).  Zones past the node's
 // count hold no capacity and score 0 under Least/MostAllocated, so they drop out by themselves.
-template <int RM, int SG>
+template <int RM, int SG, bool PK = false, bool PK_MIXED = false>
 __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const NrtArgs& a, const Item<RM>& it,
-                                               const double* __restrict__ cpu_v, const double* __restrict__ braw) {
+                                               const double* __restrict__ cpu_v, const double* __restrict__ braw, const double* __restrict__ bt = nullptr) {
   const uint32_t used = it.used;
   uint32_t m = 0xffffffffu;  // min over zones of (score - 1) as unsigned: a zero score wraps to the maximum
   double value[RM];
@@ -264,6 +345,7 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
     // division per item instead of one per zone.  3 instructions per (zone, resource) + 1 per zone; the float64 form took 4 + 4.
     const uint32_t wsum = it.wsum_i;
     if (wsum == 0) return 0;  // no weighted slot requested: wave-uniform
+    if constexpr (SG == kSgLeast && PK) return score_least_packed<RM, PK_MIXED>(ns, a, it, value, bt);
     double vq[RM];  // MostAllocated: the request pre-multiplied for the "request <= capacity" product test
 #pragma unroll
     for (int r = 0; r < RM; ++r) vq[r] = SG == kSgMost ? value[r] * (1.0 + 0x1p-49) : 0.0;
@@ -313,7 +395,7 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
 }
 
 // the node's zone tables into registers (prologue of the sweep; the BalancedAllocation fix-up loads single nodes with it)
-template <int RM, int SG>
+template <int RM, int SG, bool PK = false>
 __device__ __forceinline__ void load_fast_node(const NrtArgs& a, int64_t n, bool in, FastNode<RM>& ns, double (&cpu_v)[kZ], double (&braw)[kZ]) {
   const int R = a.n_res;
   ns.nz = in ? a.n_zones[n] : 0;
@@ -342,6 +424,19 @@ __device__ __forceinline__ void load_fast_node(const NrtArgs& a, int64_t n, bool
       const double b = (SG != kSgBalanced && SG != kSgLeastNuma && in && r < R) ? ld_off(a.f_rc, i) : kNoCap;
       ns.b[z][r] = (SG == kSgLeast && b == kNoCap) ? __builtin_inf() : b;
       if constexpr (SG == kSgBalanced) ns.b[z][r] = (in && r < R) ? ld_off(a.f_rcv, i) : 1.0;  // RN(1 / Value(capacity)) for div_rn
+    }
+  }
+  if constexpr (SG == kSgLeast && PK) {
+    // packed float32 Score: every slot's multipliers as zone pairs in b[0..3][r] (score_least_packed; 1e200 "no capacity" -> +inf)
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      float f[kZ];
+#pragma unroll
+      for (int z = 0; z < kZ; ++z) f[z] = static_cast<float>(ns.b[z][r]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ns.b[k][r] = __hiloint2double(__float_as_int(f[2 * k + 1]), __float_as_int(f[2 * k]));
+#pragma unroll
+      for (int k = 4; k < kZ; ++k) ns.b[k][r] = 0.0;
     }
   }
 }

@@ -55,7 +55,7 @@ struct spx_engine {
   int64_t row_stride = 0;
 
   // spx_set_option state (per engine; nothing is read from the environment)
-  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1, 0, 1};
+  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1, 0, 1, 1};
 
   // params
   int32_t alloc_mode = SPX_MODE_LEAST;
@@ -111,6 +111,20 @@ struct spx_engine {
   DevBuf d_nrt_redo;       // BalancedAllocation: list of the cells the float32 Score launch leaves to the float64 form
   uint32_t nrt_redo_cap = 0;
   uint32_t nrt_big_nodes = ~0u, nrt_big_pods = ~0u;  // slots with a capacity / a request (Value() form) that float32 does not hold exactly
+  // per slot, Value() form: OR and maximum of the zone capacities / of the requests in place (the packed float32 LeastAllocated Score's
+  // preconditions, nrt_packed_score; delta uploads only ever add to them)
+  struct NrtQty {
+    uint64_t bits[SPX_NRT_MAX_RES] = {0};
+    int64_t most[SPX_NRT_MAX_RES] = {0};
+    void add(int r, int64_t v) { bits[r] |= static_cast<uint64_t>(v), most[r] = v > most[r] ? v : most[r]; }
+    void merge(const NrtQty& o) {
+      for (int r = 0; r < SPX_NRT_MAX_RES; ++r) bits[r] |= o.bits[r], most[r] = o.most[r] > most[r] ? o.most[r] : most[r];
+    }
+  };
+  NrtQty nrt_qty_nodes, nrt_qty_pods;
+  int32_t nrt_slot_res[SPX_NRT_MAX_RES] = {0};       // canonical resource id of each slot (the packed Score's table slot is memory's)
+  DevBuf d_nrt_pk_tab;                               // k_nrt_pk_tab_build's table ...
+  bool nrt_pk_tab_built = false;                     // ... and whether it describes the zone capacities in place
   // pod equivalence classes (spx_upload_nrt_pods): rows whose NRT records agree in everything the sweep reads
   bool nrt_creq_valid = false;   // d_nrt_creq (read by the reference-arithmetic kernel only) holds this batch's column
   void* h_stage = nullptr;       // pinned staging for the large derived tables (pod record stream): built in place, one DMA
@@ -422,6 +436,52 @@ void fill_trimaran(const spx_engine* e, spx::TrimaranArgs& a) {
   a.stats = static_cast<unsigned long long*>(e->d_stats.p);
 }
 
+// The packed float32 form of LeastAllocated's Score launch (nrt_fast_device.h, score_least_packed) needs every weighted slot to be
+// "small" — with 2^s the largest power of two dividing all its capacities and requests, capacity / 2^s <= 32768 and request / 2^s < 2^24 —
+// or, one slot at most and not cpu, to go through k_nrt_pk_tab_build's table indexed by request / unit, unit = the largest power of
+// two dividing all its requests.  false = the float64 form.
+struct NrtPacked {
+  uint32_t small_slots = 0;
+  int32_t tab_slot = -1;
+  uint32_t tab_kmax = 0, tab_words = 0;
+  double tab_inv_unit = 1.0;
+};
+constexpr int64_t kNrtSmallCap = 32768;
+bool nrt_packed_score(const spx_engine* e, NrtPacked* out) {
+  *out = NrtPacked{};
+  if (!e->option[SPX_OPT_NRT_PACKED_SCORE] || !e->nrt_nodes || !e->nrt_pods || e->in_commit_loop ||
+      e->nrt_params.strategy != SPX_NRT_LEAST_ALLOCATED)
+    return false;
+  int64_t wsum = 0;
+  for (int i = 0; i < e->nrt_n_res && i < SPX_NRT_MAX_RES; ++i) {
+    if (e->nrt_slot_weight[i] < 0) return false;
+    wsum += e->nrt_slot_weight[i];
+  }
+  if (wsum > spx::kNrtPkMaxWeightSum) return false;
+  auto low_zeros = [](uint64_t bits) { return bits ? __builtin_ctzll(bits) : 63; };
+  for (int i = 0; i < e->nrt_n_res && i < SPX_NRT_MAX_RES; ++i) {
+    if (e->nrt_slot_weight[i] == 0) continue;  // contributes 0 whatever its resource score
+    const uint64_t pod_bits = e->nrt_qty_pods.bits[i];
+    if (pod_bits == 0) {  // no request but zeros: the resource score is 100 or 0 in both forms
+      out->small_slots |= 1u << i;
+      continue;
+    }
+    const int s = low_zeros(pod_bits | e->nrt_qty_nodes.bits[i]);
+    if ((e->nrt_qty_nodes.most[i] >> s) <= kNrtSmallCap && (e->nrt_qty_pods.most[i] >> s) < (int64_t{1} << 24)) {
+      out->small_slots |= 1u << i;
+      continue;
+    }
+    const int su = low_zeros(pod_bits);
+    const int64_t kmax = e->nrt_qty_pods.most[i] >> su;
+    const size_t words = static_cast<size_t>((e->n_nodes + 255) / 256 + 31) / 32;
+    if (out->tab_slot >= 0 || i == e->nrt_cpu_slot || kmax > spx::kNrtPkTabMaxK || (static_cast<size_t>(kmax) + 1) * words * 4 > spx::kNrtPkTabMaxBytes)
+      return false;
+    out->tab_slot = i, out->tab_kmax = static_cast<uint32_t>(kmax), out->tab_words = static_cast<uint32_t>(words);
+    out->tab_inv_unit = std::ldexp(1.0, -su);
+  }
+  return true;
+}
+
 void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   na.opts = launch_opts(e);
   na.row_ptr = e->row_indirect;
@@ -462,6 +522,7 @@ void fill_nrt(const spx_engine* e, spx::NrtArgs& na) {
   na.perm = static_cast<const int32_t*>(e->d_nrt_perm.p);
   na.stats = static_cast<unsigned long long*>(e->d_stats.p);
   na.exact32_slots = ~(e->nrt_big_nodes | e->nrt_big_pods);
+  na.pk_mode = 0, na.pk_tab_slot = -1;  // (spx_eval's NRT section turns the packed Score on)
   // inside the per-pod commit loop k_commit_apply subtracts requests from the zone table: "every quantity is a float32 value" is
   // not closed under subtraction (2^30 and 1 are, 2^30 - 1 is not) and the masks above describe the uploaded tables, so
   // BalancedAllocation's float32 "request > capacity" test gives way to the undecided -> float64 redo route there
@@ -594,7 +655,7 @@ int spx_destroy(spx_engine* e) {
   DevBuf* bufs[] = {&e->d_alloc,   &e->d_alloc_w,  &e->d_alloc_raw, &e->d_alloc_norm, &e->d_alloc_rel, &e->d_cap_cpu, &e->d_tlp_util,
                     &e->d_tlp_missing, &e->d_tlp_valid, &e->d_lv_acpu, &e->d_lv_amem, &e->d_lv_cavg, &e->d_lv_cstd,
                     &e->d_lv_mavg, &e->d_lv_mstd,  &e->d_lv_flags,  &e->d_tlp_pod,    &e->d_lv_rcpu, &e->d_lv_rmem,
-                    &e->d_raw_row,   &e->d_lv_exact, &e->d_lv_fast, &e->d_tlp_fast, &e->d_tlp_amb, &e->d_lv_amb, &e->d_commit, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
+                    &e->d_raw_row,   &e->d_lv_exact, &e->d_lv_fast, &e->d_tlp_fast, &e->d_tlp_amb, &e->d_lv_amb, &e->d_nrt_pk_tab, &e->d_commit, &e->d_nrt_flags, &e->d_nrt_max_numa, &e->d_nrt_nz, &e->d_nrt_zid, &e->d_nrt_zp,
                     &e->d_nrt_avail, &e->d_nrt_cost,  &e->d_nrt_minavg, &e->d_nrt_np,    &e->d_nrt_qos, &e->d_nrt_nn,
                     &e->d_nrt_nctr,  &e->d_nrt_ckind, &e->d_nrt_cpres,  &e->d_nrt_creq,  &e->d_nrt_ppres, &e->d_nrt_preq,
                     &e->d_nrt_frcv, &e->d_nrt_fav,   &e->d_nrt_frc,   &e->d_nrt_fcpu,   &e->d_nrt_frep,  &e->d_nrt_items, &e->d_nrt_perm, &e->d_nrt_ln, &e->d_nrt_fbraw, &e->d_nrt_redo,
@@ -660,6 +721,7 @@ int spx_set_option(spx_engine* e, int option, int64_t value) {
     case SPX_OPT_NRT_RANK_FILTER:
     case SPX_OPT_ROW_WORKGROUP:
     case SPX_OPT_TLP_AMB_TABLE:
+    case SPX_OPT_NRT_PACKED_SCORE:
       if (value != 0 && value != 1) return fail(e, SPX_ERR_ARG, "option takes 0 or 1");
       break;
     case SPX_OPT_NRT_LN_LIST_PERMILLE:
@@ -980,6 +1042,7 @@ int spx_update_nrt_nodes(spx_engine* e, const int64_t* idx, const spx_nrt_nodes_
   // sends the whole table to the reference-arithmetic kernel until the next full upload
   bool ok = true, cost_changed = false, ln_ok = true;
   uint32_t big = 0;
+  spx_engine::NrtQty qty;
   for (int64_t i = 0; i < n; ++i) {
     const int nz = t->n_zones[i];
     for (int z = 0; z < nz && z < Zm; ++z) {
@@ -989,6 +1052,7 @@ int spx_update_nrt_nodes(spx_engine* e, const int64_t* idx, const spx_nrt_nodes_
         const int64_t cap = t->zone_avail[(i * Zm + z) * R + r];
         if (!nrt_fast_qty(cap)) ok = false;
         if (!nrt_exact_f32(static_cast<double>(nrt_value_of(r == e->nrt_cpu_slot, cap)))) big |= 1u << r;
+        if (cap >= 0) qty.add(static_cast<int>(r), nrt_value_of(r == e->nrt_cpu_slot, cap));
       }
     }
     const int32_t* hc = &e->h_nrt_cost[static_cast<size_t>(ix[static_cast<size_t>(i)]) * Zm * Zm];
@@ -1034,6 +1098,8 @@ int spx_update_nrt_nodes(spx_engine* e, const int64_t* idx, const spx_nrt_nodes_
     }
   e->nrt_fast_nodes = e->nrt_fast_nodes && ok;
   e->nrt_big_nodes |= big;
+  e->nrt_qty_nodes.merge(qty);
+  e->nrt_pk_tab_built = false;  // zone capacities changed
   if (cost_changed) {  // LeastNUMANodes' per-node tables are rebuilt when that strategy is next evaluated
     e->nrt_ln_built = false;
     e->nrt_ln_ok = e->nrt_ln_ok && ln_ok;
@@ -1185,6 +1251,7 @@ int spx_upload_nrt_slots(spx_engine* e, const spx_nrt_slots* t) {
   for (int i = 0; i < t->n_res; ++i) {
     e->nrt_slot_flags[i] = t->slot_flags[i];
     e->nrt_slot_weight[i] = t->slot_weight[i];
+    e->nrt_slot_res[i] = t->slot_res ? t->slot_res[i] : -1;
   }
   e->nrt_slots = true;
   e->nrt_nodes = e->nrt_pods = false;  // tables are laid out by slot count
@@ -1242,9 +1309,12 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
   {
     std::atomic<bool> ok{true}, ln_ok{true};
     std::atomic<uint32_t> big_nodes{0};
+    spx_engine::NrtQty qty_all;
+    std::mutex qty_mu;
     spx_host::parallel_rows(n, [&](int64_t row0, int64_t row1) {
     bool my_ok = true, my_ln = true;
     uint32_t my_big = 0;
+    spx_engine::NrtQty my_qty;
     for (int64_t i = row0; i < row1; ++i) {
       const int nz = t->n_zones[i];
       for (int z = 0; z < nz && z < Zm; ++z) {
@@ -1254,6 +1324,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
           const int64_t cap = t->zone_avail[(i * Zm + z) * R + r];
           if (!nrt_fast_qty(cap)) my_ok = false;
           if (!nrt_exact_f32(static_cast<double>(nrt_value_of(r == e->nrt_cpu_slot, cap)))) my_big |= 1u << r;
+          if (cap >= 0) my_qty.add(static_cast<int>(r), nrt_value_of(r == e->nrt_cpu_slot, cap));
         }
         // LeastNUMANodes' tables can be built when every zone cost lies within [0, 255] (findSuitableCombination's 256 sentinel)
         for (int zb = 0; zb < nz && zb < Zm; ++zb) {
@@ -1265,9 +1336,15 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
     if (!my_ok) ok = false;
     if (!my_ln) ln_ok = false;
     if (my_big) big_nodes.fetch_or(my_big, std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> g(qty_mu);
+      qty_all.merge(my_qty);
+    }
     }, 1024);
     e->nrt_fast_nodes = ok.load();
     e->nrt_big_nodes = big_nodes.load();
+    e->nrt_qty_nodes = qty_all;
+    e->nrt_pk_tab_built = false;
     e->nrt_ln_ok = ln_ok.load();
     e->nrt_ln_built = false;  // built when that strategy is first evaluated (build_ln_tab): more host time than everything else in this call
     // window-local node order: inside each run of 256 nodes, group the nodes by the code path their flags select
@@ -1518,7 +1595,7 @@ struct NrtCanon {
 //                 cpu request (2RM+2), sum of the weights of the requested slots (2RM+4), its biased reciprocal (2RM+6)
 // hash_out (optional): the hash of each record's canonical view, taken while the record is still in cache
 void nrt_build_items(const spx_nrt_pods_soa* t, const uint8_t* slot_flags, int cpu_slot, const std::vector<double>& wtab, uint32_t* items,
-                     bool* ok_out, uint32_t* big_out, uint64_t* hash_out) {
+                     bool* ok_out, uint32_t* big_out, uint64_t* hash_out, spx_engine::NrtQty* qty_out = nullptr) {
   const size_t p = static_cast<size_t>(t->n_pods), R = static_cast<size_t>(t->n_res);
   constexpr size_t Cm = SPX_NRT_MAX_CTRS;
   const int RMs = R <= 4 ? 4 : 8;
@@ -1530,13 +1607,15 @@ void nrt_build_items(const spx_nrt_pods_soa* t, const uint8_t* slot_flags, int c
   const bool tab_ok = ok.load();
   const NrtCanon canon{static_cast<size_t>(RMs), IW};
   // bad / big: per calling thread, merged once per chunk (the shared flags would bounce between the cores otherwise)
-  auto fill = [&](uint32_t* w, uint32_t present, const int64_t* req, bool non_g, uint32_t kind, bool& bad, uint32_t& big) {
+  std::mutex qty_mu;
+  auto fill = [&](uint32_t* w, uint32_t present, const int64_t* req, bool non_g, uint32_t kind, bool& bad, uint32_t& big, spx_engine::NrtQty& qty) {
     const uint32_t used = present & slot_mask;
     uint32_t fit = 0, always = 0;
     for (size_t r = 0; r < R; ++r) {
       if (!nrt_fast_qty(req[r])) bad = true;
       if (!nrt_exact_f32(static_cast<double>(nrt_value_of(static_cast<int>(r) == cpu_slot, req[r])))) big |= 1u << r;
       put_f64(w + 2 * r, static_cast<double>(req[r]));
+      if (((used >> r) & 1u) && req[r] > 0) qty.add(static_cast<int>(r), nrt_value_of(static_cast<int>(r) == cpu_slot, req[r]));
       if (!((used >> r) & 1u) || req[r] == 0) continue;  // "ignoring zero-qty resource request" filter.go:103-106
       if (non_g && (slot_flags[r] & SPX_NRT_SLOT_AFFINE)) always |= 1u << r;
       else fit |= 1u << r;
@@ -1553,6 +1632,7 @@ void nrt_build_items(const spx_nrt_pods_soa* t, const uint8_t* slot_flags, int c
   spx_host::parallel_rows(static_cast<int64_t>(p), [&](int64_t row0, int64_t row1) {
     bool bad = false;
     uint32_t big = 0;
+    spx_engine::NrtQty qty;
     for (size_t i = static_cast<size_t>(row0); i < static_cast<size_t>(row1); ++i) {
       uint32_t* w = &items[i * 10 * IW];
       std::memset(w, 0, 10 * IW * sizeof(uint32_t));  // the record ends with the last container: zeros after it
@@ -1568,15 +1648,19 @@ void nrt_build_items(const spx_nrt_pods_soa* t, const uint8_t* slot_flags, int c
         } else if (seen_app) {
           bad = true;  // the single-pass Filter needs init containers listed before app containers
         }
-        fill(w + (2 + c) * IW, t->ctr_present[i * Cm + c], t->ctr_req + (i * Cm + c) * R, non_g, kind, bad, big);
+        fill(w + (2 + c) * IW, t->ctr_present[i * Cm + c], t->ctr_req + (i * Cm + c) * R, non_g, kind, bad, big, qty);
       }
-      fill(w + IW, t->pod_present[i], t->pod_req + i * R, non_g, 0, bad, big);
+      fill(w + IW, t->pod_present[i], t->pod_req + i * R, non_g, 0, bad, big, qty);
       w[0] = t->qos[i] | (static_cast<uint32_t>(t->non_native[i] != 0) << 8) | (n_ctr << 16) | (last_app << 24);
       w[1] = n_ctr ? (65536u + n_ctr - 1u) / n_ctr : 0u;
       if (hash_out) hash_out[i] = canon.hash(w);
     }
     if (bad) ok = false;
     if (big) big_pods.fetch_or(big, std::memory_order_relaxed);
+    if (qty_out) {
+      std::lock_guard<std::mutex> g(qty_mu);
+      qty_out->merge(qty);
+    }
   }, 4096);
   *ok_out = ok.load();
   *big_out = big_pods.load();
@@ -1787,10 +1871,13 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
     bool ok = false;
     uint32_t big = 0;
     std::vector<uint64_t> hash(p);
-    nrt_build_items(t, e->nrt_slot_flags, e->nrt_cpu_slot, e->nrt_wtab, items, &ok, &big, hash.data());
+    spx_engine::NrtQty qty;
+    nrt_build_items(t, e->nrt_slot_flags, e->nrt_cpu_slot, e->nrt_wtab, items, &ok, &big, hash.data(), &qty);
     if ((rc = upload(e, e->d_nrt_items, items, items_bytes))) return rc;  // from pinned memory: one DMA at link speed, asynchronous
     e->nrt_fast_pods = ok;
     e->nrt_big_pods = big;
+    e->nrt_qty_pods = qty;
+    e->nrt_pk_tab_built = false;  // (the table's unit and length follow the batch)
     // the reference-arithmetic kernel's request column: shipped only when the record stream cannot stand in for it
     e->nrt_creq_valid = false;
     if (!e->nrt_fast_pods) {
@@ -2196,6 +2283,20 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     const bool classes = e->option[SPX_OPT_NRT_POD_CLASSES] && na.fast && !(na.opts & spx::kOptNrtGeneric) && !e->row_indirect &&
                          row_begin == 0 && row_end == e->n_pods && e->nrt_n_dups > 0 && e->nrt_n_dups * 32 >= e->n_pods &&
                          !(na.strategy == SPX_NRT_LEAST_NUMA_NODES && !na.ln_tab);
+    {  // LeastAllocated's Score launch in packed float32 (only the split launch of a row range acts on it: launch_nrt_fast)
+      NrtPacked pk;
+      if (na.fast && !(na.opts & spx::kOptNrtGeneric) && !e->row_indirect && nrt_packed_score(e, &pk)) {
+        if (pk.tab_slot >= 0) {
+          const size_t bytes = (static_cast<size_t>(pk.tab_kmax) + 1) * pk.tab_words * 4;
+          if (!e->d_nrt_pk_tab.p || e->d_nrt_pk_tab.bytes < bytes) e->nrt_pk_tab_built = false;
+          if ((rc = ensure(e, e->d_nrt_pk_tab, bytes))) return rc;
+        }
+        na.pk_mode = 1, na.pk_tab_slot = pk.tab_slot;
+        na.pk_tab = static_cast<uint32_t*>(e->d_nrt_pk_tab.p);
+        na.pk_tab_words = pk.tab_words, na.pk_tab_kmax = pk.tab_kmax, na.pk_tab_inv_unit = pk.tab_inv_unit;
+        na.pk_tab_built = &e->nrt_pk_tab_built;
+      }
+    }
     if (classes) {
       na.row_list = static_cast<const int32_t*>(e->d_nrt_uniq.p);
       na.n_list = e->nrt_n_uniq;
@@ -2562,8 +2663,8 @@ int commit_with_filters(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, 
   e->last_commit_path = 2;
   struct LoopFlag {
     spx_engine* e;
-    explicit LoopFlag(spx_engine* x) : e(x) { e->in_commit_loop = true, e->tlp_amb_built = false; }  // (k_commit_apply advances d_tlp_missing)
-    ~LoopFlag() { e->in_commit_loop = false, e->tlp_amb_built = false; }
+    explicit LoopFlag(spx_engine* x) : e(x) { e->in_commit_loop = true, e->tlp_amb_built = false, e->nrt_pk_tab_built = false; }  // (k_commit_apply advances d_tlp_missing and the zone tables)
+    ~LoopFlag() { e->in_commit_loop = false, e->tlp_amb_built = false, e->nrt_pk_tab_built = false; }
   } loop_flag(e);
   // ---- save what the loop mutates
   struct Saved {
@@ -2940,6 +3041,13 @@ int spx_load_quota(spx_engine* e, const spx_pod_objects* pods, const spx_resourc
 }
 
 int spx_nrt_filter_path(const spx_engine* e) { return e ? e->last_nrt_filter : 0; }
+
+int spx_nrt_packed_score_slots(const spx_engine* e) {
+  if (!e) return SPX_ERR_ARG;
+  NrtPacked pk;
+  if (!nrt_packed_score(e, &pk)) return 0;
+  return static_cast<int>(0x1000000u | pk.small_slots | (static_cast<uint32_t>(pk.tab_slot + 1) << 16));
+}
 
 int spx_commit_path(const spx_engine* e) { return e ? e->last_commit_path : SPX_ERR_ARG; }
 

@@ -289,7 +289,18 @@ struct NrtArgs {
   const uint32_t* rk_off;        // [chunks + 1] dword offsets of the chunk blocks
   uint32_t rk_max_dwords;        // largest chunk block (dynamic LDS)
   uint32_t exact32_slots;        // resource slots whose requests and capacities (Value() form) are all float32 values (below 2^24, or a multiple of a large power of two): compared exactly
+  // LeastAllocated's Score-only launch in packed float32 (nrt_fast_device.h, score_least_packed): zone PAIRS per instruction, u16 zone totals
+  uint32_t pk_mode;              // 0 = off (every other kernel / strategy / launch form)
+  int32_t pk_tab_slot;           // the slot (memory in bytes) whose requests k_nrt_pk_tab_build replays; -1: every weighted slot is "small"
+  uint32_t* pk_tab;              // [pk_tab_kmax + 1][pk_tab_words] by request / unit: bit w of the row = for some zone of node window w the packed form differs from the division
+  uint32_t pk_tab_words;         // dwords per request value: ceil(node windows / 32)
+  uint32_t pk_tab_kmax;          // largest request / unit of the pod batch
+  double pk_tab_inv_unit;        // 1 / unit; unit = the largest power of two dividing every request of the slot
+  bool* pk_tab_built;            // host flag: pk_tab describes the zone capacities and the unit in place (cleared by every writer of either)
 };
+constexpr int64_t kNrtPkTabMaxK = (int64_t{1} << 17) - 1;   // request / unit above this: the float64 form
+constexpr size_t kNrtPkTabMaxBytes = size_t{64} << 20;
+constexpr int64_t kNrtPkMaxWeightSum = 320;  // 100 * sum(weights) must stay below 2^15 for the u16 zone totals
 constexpr double kNrtNoCap = 1e200;
 // rank-space Filter: chunk rows, comparison vectors per pod (pod-level, 8 containers, 4 sums), head dwords of a pod record
 // (w0, w1, the slot sets of items 1..9, app containers a0 | a1 << 8 | a2 << 16 | count << 24, pad), largest chunk block

@@ -604,6 +604,16 @@ class Engine:
         self._ck(self._lib.spx_load_trimaran_pods(self._h, pods.ref()))
         self.n_pods = pods.struct.n_pods
 
+    def nrt_packed_score_slots(self):
+        """None when LeastAllocated's Score launch keeps float64; else (mask of the weighted NRT slots scored in packed float32
+        unconditionally, the slot scored that way through the per-launch table or -1) — spx_nrt_packed_score_slots"""
+        v = int(self._lib.spx_nrt_packed_score_slots(self._h))
+        if v < 0:
+            self._ck(v)
+        if v == 0:
+            return None
+        return v & 0xffff, ((v >> 16) & 0xff) - 1
+
     def nrt_filter_path(self) -> int:
         """which Filter launch the last NRT sweep ran: 1 float64 compares, 2 rank space"""
         return int(self._lib.spx_nrt_filter_path(self._h))

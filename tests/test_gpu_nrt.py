@@ -525,3 +525,133 @@ def test_least_numa_listed_cells_and_overflow(gpu_required, hdr, oracle, permill
         e.sync()
         assert np.array_equal(e.all_scores(NRT).astype(np.int64), want)
         assert int(e.stats(reset=True)[NRT]) == 0
+
+
+# ------------------------------------------------------------------ round 5: LeastAllocated's Score launch in packed float32
+def _packed_eval(hdr, oracle, node_t, nrt_t, res, pod_t, expect_on=True):
+    """both settings of SPX_OPT_NRT_PACKED_SCORE against the oracle, cell by cell; returns the oracle's raw scores, what
+    spx_nrt_packed_score_slots reported with the option on, and the resource id of each slot"""
+    params = O.nrt_params(hdr, res, "LeastAllocated")
+    osnap = oracle.Snapshot(node_t, pod_t, rc=res.table(hdr), nrt=nrt_t, nrt_params=params)
+    want = osnap.score_rows(NRT, threads=oracle.usable_cpus(), want_norm=False)[0]
+    want_st = osnap.filter_rows(NRT, threads=oracle.usable_cpus())
+    got = {}
+    with Engine(0) as e:
+        e.load_nrt_objects(node_t, nrt_t, res.table(hdr), pod_t, params)
+        assert e.kernel_path(NRT) == 1
+        slot_res = list(e.nrt_soa["slots"].array("slot_res"))
+        packed = e.nrt_packed_score_slots()
+        assert (packed is not None) == expect_on
+        for opt in (1, 0):
+            e.set_option("NRT_PACKED_SCORE", opt)
+            assert (e.nrt_packed_score_slots() is not None) == bool(opt and expect_on)
+            for _ in range(2):   # the second launch reuses the table
+                e.eval(mask_of(NRT))
+                e.sync()
+            got[opt] = e.all_scores(NRT).astype(np.int64)
+            assert np.array_equal(e.all_status(NRT), want_st)
+    assert np.array_equal(got[0], want)
+    assert np.array_equal(got[1], want), (np.argwhere(got[1] != want)[:5], got[1][got[1] != want][:5], want[got[1] != want][:5])
+    return want, packed, slot_res
+
+
+@pytest.mark.parametrize("big_cap", [None, 32_769, 65_536], ids=["all-small", "one-zone-32769", "one-zone-65536"])
+def test_least_allocated_packed_score_small_integer_grid(gpu_required, hdr, oracle, big_cap):
+    """SPX_OPT_NRT_PACKED_SCORE, the "small" slots: floor((c - v) * 100 / c) for whole-core / device quantities as
+    RNE(fma(-v, RN32(100 / c), 99.5 + 2^-16)).  Every (capacity, request) pair of a dense grid — c = 1..200 cores and the powers of two and
+    their neighbours up to 32 768, v = 1..210 and beyond (request above the capacity: 0; millicore requests round up to whole cores), a
+    zone without cpu, a device slot — against the oracle and against the float64 form (option off), cell by cell.  The memory request
+    is 1 % or 2 % of the zone (resource score 99 / 98), so the two pods of a cpu value together pin cpu's score to the unit; memory itself
+    is small here in units of GiB (capacities and requests share 2^30).  A single zone of 32 769 cores takes cpu out of the small
+    set, and cpu cannot be the table slot: the launch keeps float64 (spx_nrt_packed_score_slots says so)."""
+    caps = list(range(1, 201)) + [255, 256, 257, 1000, 1023, 1024, 1025, 4095, 4096, 16_383, 16_384, 32_767, 32_768]
+    if big_cap:
+        caps.append(big_cap)
+    res = O.Resources()
+    res.id("vendor.io/gpu")
+    nrts, nodes = [], []
+    for i, c in enumerate(caps):
+        rl = {"cpu": str(c), "memory": "100Gi"}
+        if i % 3 == 0:
+            rl["vendor.io/gpu"] = str(1 + i % 7)
+        zones = [{"name": "node-0", "type": "Node", "resources": rl, "costs": {"node-0": 10, "node-1": 20}},
+                 {"name": "node-1", "type": "Node", "resources": {"memory": "100Gi"} if i % 5 == 0 else {"cpu": str(max(1, c // 2)), "memory": "50Gi"},
+                  "costs": {"node-0": 20, "node-1": 10}}]
+        nrts.append(O.nrt(zones, ["SingleNUMANodePodLevel" if i % 2 else "SingleNUMANodeContainerLevel"]))
+        nodes.append(O.node_from_zones(zones))
+    pods = []
+    reqs = [f"{v}" for v in range(1, 211)] + ["1000", "4096", "32768", "40000", "1500m", "250m", "2001m", "31999m"]
+    for v in reqs:
+        for mem in ("1Gi", "2Gi"):
+            r = {"cpu": v, "memory": mem}
+            pods.append(O.pod([O.container(r, dict(r))]))
+    for g in (1, 2, 3, 7, 8):   # the device slot
+        r = {"cpu": "2", "memory": "1Gi", "vendor.io/gpu": str(g)}
+        pods.append(O.pod([O.container(r, dict(r)), O.container({"cpu": "1", "memory": "2Gi"}, {"cpu": "1", "memory": "2Gi"})]))
+    # 65 536 cores: every capacity and request of the grid would have to share a factor 2 for cpu to stay small — they do not
+    want, packed, slot_res = _packed_eval(hdr, oracle, O.build_node_objects(hdr, res, nodes), O.build_nrt_objects(hdr, res, nrts), res,
+                                          O.build_pod_objects(hdr, res, pods), expect_on=big_cap is None)
+    if big_cap is None:
+        small, tab = packed
+        assert tab == -1 and small == 0b111   # cpu, memory (GiB units), the device
+    assert len(np.unique(want)) > 50
+
+
+def _adversarial_memory(hdr, extra_pods=()):
+    """zone capacities built so that whole-MiB requests land EXACTLY on an integer resource score, within 10^-9 .. 3x10^-5 BELOW one
+    and just above one; cpu in whole cores"""
+    MiB = 1 << 20
+    ks = [64, 100, 333, 1024, 1536, 4096, 10_000, 32_768, 50_000]
+    cases = []   # (k, capacity in bytes)
+    for k in ks:
+        for s in (1, 7, 33, 50, 64, 90, 99):
+            c0 = 100 * k * MiB / (100 - s)
+            if c0 >= 2 ** 41:
+                continue   # (the float64 formulation holds quantities below 2^42)
+            for d in (0, 1, 2, 5, 20, 100, 400, 1500, 6000, 25_000, -1, -3, -40, -1000):
+                cases.append((k, int(np.floor(c0)) - d))
+    res = O.Resources()
+    nrts, nodes = [], []
+    for i in range(0, len(cases), 2):   # two zones per node, one adversarial capacity each
+        zones = []
+        for z, (k, c) in enumerate(cases[i:i + 2]):
+            zones.append({"name": f"node-{z}", "type": "Node", "resources": {"cpu": "64", "memory": c}, "costs": {"node-0": 10, "node-1": 10}})
+        nrts.append(O.nrt(zones, ["SingleNUMANodeContainerLevel" if i % 4 else "SingleNUMANodePodLevel"]))
+        nodes.append(O.node_from_zones(zones))
+    pods = []
+    for k in ks:
+        r = {"cpu": "1", "memory": k * MiB}
+        pods.append(O.pod([O.container(r, dict(r))]))
+        pods.append(O.pod([O.container(r, dict(r)), O.container({"cpu": "2", "memory": 64 * MiB}, {"cpu": "2", "memory": 64 * MiB})]))
+    for m in extra_pods:
+        r = {"cpu": "1", "memory": m}
+        pods.append(O.pod([O.container(r, dict(r))]))
+    return cases, res, O.build_node_objects(hdr, res, nodes), O.build_nrt_objects(hdr, res, nrts), O.build_pod_objects(hdr, res, pods)
+
+
+def test_least_allocated_packed_score_memory_near_integers(gpu_required, hdr, oracle):
+    """the table slot (memory in bytes, requests in whole MiB): k_nrt_pk_tab_build must list every (request, node window) whose packed
+    form differs from the division, and the block recompute those pods.  A numpy replay of the float32 formula shows that the set
+    really contains cells it gets wrong on its own — the test would fail without the table and the second pass."""
+    MiB = 1 << 20
+    cases, res, node_t, nrt_t, pod_t = _adversarial_memory(hdr)
+    want, packed, slot_res = _packed_eval(hdr, oracle, node_t, nrt_t, res, pod_t)
+    assert packed == (1 << slot_res.index(0), slot_res.index(1))   # cpu small, memory through the table
+    wrong = 0
+    for k, c in cases:
+        v = np.float32(k * MiB)
+        b32 = np.float32(np.float64(100.0) / np.float64(c))
+        t = np.float32(np.float64(-v) * np.float64(b32) + np.float64(np.float32(99.5 + 2.0 ** -17)))
+        wrong += int(np.rint(np.float64(t)) != (100 * (c - k * MiB)) // c and k * MiB <= c)
+    assert wrong > 20, wrong
+
+
+@pytest.mark.parametrize("odd,on", [(1024 * (1 << 20) + 1, False), (1024 * (1 << 20) - 4096, False), (300_000 * (1 << 20), False),
+                                    (131_071 * (1 << 20), True)],
+                         ids=["one-byte-off", "4KiB-unit", "beyond-the-table", "last-row-of-the-table"])
+def test_least_allocated_packed_score_table_unit_follows_the_batch(gpu_required, hdr, oracle, odd, on):
+    """the table's unit is the power of two common to the batch's requests and its length their maximum: one request of 1 GiB + 1 byte
+    makes the unit 1 byte, one of 1 GiB - 4 KiB makes it 4 KiB (50 000 MiB would be row 12.8 million), one of 300 000 MiB is beyond
+    the 2^17 rows — float64 for the launch each time, same tables; 131 071 MiB is the last row a table can have"""
+    cases, res, node_t, nrt_t, pod_t = _adversarial_memory(hdr, extra_pods=(odd,))
+    _packed_eval(hdr, oracle, node_t, nrt_t, res, pod_t, expect_on=on)
