@@ -564,20 +564,29 @@ __global__ __launch_bounds__(256, (PK && RM == 4 ? 5 : nrt_waves<RM, SG, PH>()))
   }
   __syncthreads();
   if constexpr (PK) {
-    // the pods whose table-slot request (any of their items) is listed for THIS node window: recomputed in float64 after the loop
+    // every staged request item into the packed loop's form, in place (PkRegs, nrt_fast_device.h): nv[r] = -float32(Value(request r));
+    // and the pods whose table-slot request (any of their items) is listed for THIS node window: recomputed after the loop
     const int ts = a.pk_tab_slot;
-    if (ts >= 0) {  // uniform
-      for (int i = threadIdx.x; i < rows * (kItemsPerPod - 1); i += 256) {
-        const int p = i / (kItemsPerPod - 1);
-        const uint32_t* w = pod_lds + p * pod_words<RM>() + (1 + i % (kItemsPerPod - 1)) * item_words<RM>();
-        if (!((w[2 * RM] >> ts) & 1u)) continue;
-        const double k = __hiloint2double(static_cast<int>(w[2 * ts + 1]), static_cast<int>(w[2 * ts])) * a.pk_tab_inv_unit;
-        // (the engine derived unit and kmax from this very batch: k is a whole number within the table; anything else is recomputed too)
-        const bool inside = k >= 0.0 && k <= static_cast<double>(a.pk_tab_kmax) && k == __builtin_floor(k);
-        const uint32_t word = inside ? a.pk_tab[static_cast<size_t>(static_cast<uint32_t>(k)) * a.pk_tab_words + (static_cast<uint32_t>(window) >> 5)] : ~0u;
-        if ((word >> (static_cast<uint32_t>(window) & 31u)) & 1u) atomicOr(&pk_flagged, 1u << p);
+    for (int i = threadIdx.x; i < rows * (kItemsPerPod - 1); i += 256) {
+      const int p = i / (kItemsPerPod - 1);
+      uint32_t* w = pod_lds + p * pod_words<RM>() + (1 + i % (kItemsPerPod - 1)) * item_words<RM>();
+      const uint32_t used = w[2 * RM] & 0xffu;
+      float nv[RM];
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        const int at = r == a.cpu_slot ? 2 * RM + 2 : 2 * r;  // Value() of the cpu request / the request as written
+        nv[r] = -static_cast<float>(__hiloint2double(static_cast<int>(w[at + 1]), static_cast<int>(w[at])));
       }
+#pragma unroll
+      for (int r = 0; r < RM; ++r) w[pk_nv_dword<RM>(r)] = __float_as_uint(nv[r]);
+      if (ts < 0 || !((used >> ts) & 1u)) continue;
+      const double k = __hiloint2double(static_cast<int>(w[2 * ts + 1]), static_cast<int>(w[2 * ts])) * a.pk_tab_inv_unit;
+      // (the engine derived unit and kmax from this very batch: k is a whole number within the table; anything else is recomputed too)
+      const bool inside = k >= 0.0 && k <= static_cast<double>(a.pk_tab_kmax) && k == __builtin_floor(k);
+      const uint32_t word = inside ? a.pk_tab[static_cast<size_t>(static_cast<uint32_t>(k)) * a.pk_tab_words + (static_cast<uint32_t>(window) >> 5)] : ~0u;
+      if ((word >> (static_cast<uint32_t>(window) & 31u)) & 1u) atomicOr(&pk_flagged, 1u << p);
     }
+    __syncthreads();
   }
   // What the wave's 64 nodes have in common (wave-uniform): a pod the launch has nothing to compute for — not filtered,
   // not Guaranteed — skips the exec-masked regions with one scalar branch.  Round 2's loop ran every pod through them
@@ -596,7 +605,12 @@ __global__ __launch_bounds__(256, (PK && RM == 4 ? 5 : nrt_waves<RM, SG, PH>()))
     hv = header(p + 1 < rows ? p + 1 : p);
     // the first container's item is requested now, ahead of the header decode (container-scope nodes nearly always need it)
     ItemRegs<RM, FULL> cur;
-    if (w_ctr) cur = load_item<RM, FULL>(pit, 2);
+    PkRegs<RM> cur_pk;
+    if constexpr (PK) {
+      if (w_ctr) cur_pk = load_item_pk<RM>(pit, 2);
+    } else {
+      if (w_ctr) cur = load_item<RM, FULL>(pit, 2);
+    }
     const int qos = hw[0] & 0xffu;
     const bool non_native = ((hw[0] >> 8) & 0xffu) != 0;
     const int n_ctr = (hw[0] >> 16) & 0xffu;
@@ -614,7 +628,19 @@ __global__ __launch_bounds__(256, (PK && RM == 4 ? 5 : nrt_waves<RM, SG, PH>()))
     const bool want_filter = u_filter && aligned;
     const bool want_score = u_score && aligned;
 
-    if (w_pod && pod_scope && aligned) {  // singleNUMAPodLevelHandler / podScopeScore
+    if constexpr (PK) {  // Score only, both scopes in the packed form
+      if (w_pod && pod_scope && aligned && want_score) score = score_least_packed<RM>(ns, a, load_item_pk<RM>(pit, 1));
+      if (w_ctr && !pod_scope && aligned) {
+        int sum = 0;
+        for (int c = 0; c < n_ctr; ++c) {
+          const PkRegs<RM> nxt = load_item_pk<RM>(pit, 2 + (c + 1 < kC ? c + 1 : c));
+          if (want_score) sum += score_least_packed<RM>(ns, a, cur_pk);
+          cur_pk = nxt;
+        }
+        if (want_score) score = static_cast<int>((static_cast<uint32_t>(sum) * inv_n) >> 16);
+      }
+    }
+    if (!PK && w_pod && pod_scope && aligned) {  // singleNUMAPodLevelHandler / podScopeScore
       const Item<RM> it = decode_item<RM, FULL>(load_item<RM, FULL>(pit, 1));
       if constexpr (PH != kPhScore) {
         if (want_filter) {
@@ -629,12 +655,12 @@ __global__ __launch_bounds__(256, (PK && RM == 4 ? 5 : nrt_waves<RM, SG, PH>()))
             score = score_balanced_f32(bn, ns.nz, a.cpu_slot, a.exact32_slots, it, &rd);
             redo |= rd;
           } else {
-            score = score_each_fast<RM, SG, PK>(ns, a, it, cpu_v, braw);
+            score = score_each_fast<RM, SG>(ns, a, it, cpu_v, braw);
           }
         }
       }
     }
-    if (w_ctr && !pod_scope && aligned) {  // singleNUMAContainerLevelHandler / containerScopeScore
+    if (!PK && w_ctr && !pod_scope && aligned) {  // singleNUMAContainerLevelHandler / containerScopeScore
       // One pass in container order (init containers come first — checked at upload): an init container must fit
       // and is never subtracted; an app container is placed on the lowest fitting zone and subtracted from it.
       // Least/MostAllocated's zone scores read only b (never the mutable table), so they score in the same pass;
@@ -660,7 +686,7 @@ __global__ __launch_bounds__(256, (PK && RM == 4 ? 5 : nrt_waves<RM, SG, PH>()))
           }
         }
         if constexpr ((SG == kSgLeast || SG == kSgMost) && PH != kPhFilter) {
-          if (want_score) sum += score_each_fast<RM, SG, PK>(ns, a, it, cpu_v, braw);
+          if (want_score) sum += score_each_fast<RM, SG>(ns, a, it, cpu_v, braw);
         }
         cur = nxt;
       }
@@ -682,7 +708,7 @@ __global__ __launch_bounds__(256, (PK && RM == 4 ? 5 : nrt_waves<RM, SG, PH>()))
               sum += score_balanced_f32(bn, ns.nz, a.cpu_slot, a.exact32_slots, it, &rd);
               redo |= rd;
             } else {
-              sum += score_each_fast<RM, SG, PK>(ns, a, it, cpu_v, braw);
+              sum += score_each_fast<RM, SG>(ns, a, it, cpu_v, braw);
             }
           }
         }
@@ -786,13 +812,17 @@ __global__ __launch_bounds__(256, (PK && RM == 4 ? 5 : nrt_waves<RM, SG, PH>()))
         if ((h0 & 0xffu) != SPX_QOS_GUARANTEED) continue;  // uniform: 100 everywhere, the loop wrote it
         ++n_redone;
         const int n_ctr = (h0 >> 16) & 0xffu;
+        auto raw_of = [&](int slot) {  // the item's table-slot request as written
+          const uint32_t* w = pit + slot * item_words<RM>() + 2 * a.pk_tab_slot;
+          return __hiloint2double(static_cast<int>(w[1]), static_cast<int>(w[0]));
+        };
         int score = 0;
         if (aligned) {
           if (pod_scope) {
-            score = score_each_fast<RM, SG, true, true>(ns, a, decode_item<RM, FULL>(load_item<RM, FULL>(pit, 1)), cpu_v, braw, bt);
+            score = score_least_packed<RM, true>(ns, a, load_item_pk<RM>(pit, 1), bt, raw_of(1));
           } else {
             int sum = 0;
-            for (int c = 0; c < n_ctr; ++c) sum += score_each_fast<RM, SG, true, true>(ns, a, decode_item<RM, FULL>(load_item<RM, FULL>(pit, 2 + c)), cpu_v, braw, bt);
+            for (int c = 0; c < n_ctr; ++c) sum += score_least_packed<RM, true>(ns, a, load_item_pk<RM>(pit, 2 + c), bt, raw_of(2 + c));
             score = static_cast<int>((static_cast<uint32_t>(sum) * h1) >> 16);
           }
         }

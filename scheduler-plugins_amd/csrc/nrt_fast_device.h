@@ -215,7 +215,8 @@ __device__ __forceinline__ void adjust_fast(FastNode<RM>& ns, const Item<RM>& it
 //     (pod, window) pairs of config #3) — the loop itself never branches on it.
 // x < 0 (request above capacity) and cells without capacity (b32 = +inf: -inf, or NaN for an explicit zero request) convert to 0 —
 // the reference's zeros.  Zone totals are u16: start at -sum(weights) mod 2^16 so that a zone whose score is 0 stays "negative" = at
-// least 2^15 and drops out of the unsigned minimum (100 * sum(weights) < 2^15: kNrtPkMaxWeightSum).  The float32 multipliers live as
+// least 2^15 (a total below sum(weights): exactly the zones whose score total / sum(weights) is 0) and drops out of the unsigned minimum
+// (100 * sum(weights) < 2^15: kNrtPkMaxWeightSum).  The float32 multipliers live as
 // zone pairs in ns.b[0..3][r] (load_fast_node<.., PK>); ns.b[4..7][r] are unused.
 constexpr float kPkOffsetSmall = 0x1p-16f, kPkOffsetTab = 0x1p-17f;
 
@@ -224,22 +225,47 @@ __device__ __forceinline__ uint32_t least_packed_one(float v, float b32, float c
   return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(-v, b32, c0), 0, 0u) & 0xffu;
 }
 
+// The request item as the packed loop reads it.  The block that staged the chunk's records rewrote every item IN PLACE
+// (k_nrt_fast): nv[r] = -float32(Value(request r)) into the dwords the float64 Score keeps Value(cpu) and the float64 weight sum in
+// (<= 4 slots: dwords 2RM+2 .. 2RM+5) or into the unused tail (8 slots: dwords 24 .. 31) — the raw float64 requests (dwords 0 .. 2RM-1)
+// stay for the second pass.  The loop fetches dwords 2RM .. : slot sets, integer weight sum, nv[], the biased reciprocal.
+template <int RM>
+struct PkRegs {
+  uint32_t w[RM == 4 ? 8 : 16];
+};
+template <int RM>
+__device__ __forceinline__ constexpr int pk_nv_dword(int r) { return RM == 4 ? 2 * RM + 2 + r : 24 + r; }
+template <int RM>
+__device__ __forceinline__ PkRegs<RM> load_item_pk(const uint32_t* pod_rec, int slot) {
+  const u32x4* p = reinterpret_cast<const u32x4*>(pod_rec + slot * item_words<RM>() + 2 * RM);
+  PkRegs<RM> r;
+#pragma unroll
+  for (int q = 0; q < (RM == 4 ? 2 : 4); ++q) {
+    const u32x4 v = p[q];
+    r.w[4 * q] = v.x, r.w[4 * q + 1] = v.y, r.w[4 * q + 2] = v.z, r.w[4 * q + 3] = v.w;
+  }
+  return r;
+}
+
 // MIXED (k_nrt_fast's second pass over the pods the table lists for the block's window): the table slot in the float64 form from
-// bt[zone] = RN64(100 / c) (+inf without capacity), every other slot packed as in the loop
+// bt[zone] = RN64(100 / c) (+inf without capacity) and the raw request, every other slot packed as in the loop
 template <int RM, bool MIXED = false>
-__device__ __forceinline__ int score_least_packed(const FastNode<RM>& ns, const NrtArgs& a, const Item<RM>& it, const double (&value)[RM],
-                                                  const double* __restrict__ bt = nullptr) {
+__device__ __forceinline__ int score_least_packed(const FastNode<RM>& ns, const NrtArgs& a, const PkRegs<RM>& g, const double* __restrict__ bt = nullptr,
+                                                  double raw_tab = 0.0) {
   typedef float F32x2 __attribute__((ext_vector_type(2)));
   typedef unsigned short U16x2 __attribute__((ext_vector_type(2)));
   static_assert(kZ == 8, "four zone pairs");
-  const uint32_t wsum = it.wsum_i;
+  const uint32_t used = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g.w[0]))) & 0xffu;
+  const uint32_t wsum = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g.w[1])));
+  if (wsum == 0) return 0;  // no weighted slot requested: wave-uniform
+  const double wrc = __hiloint2double(static_cast<int>(g.w[7]), static_cast<int>(g.w[6]));
   const unsigned short a0 = static_cast<unsigned short>(0u - wsum);
   U16x2 accp[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) accp[k] = U16x2{a0, a0};
 #pragma unroll
   for (int r = 0; r < RM; ++r) {
-    if (!((it.used >> r) & 1u)) continue;
+    if (!((used >> r) & 1u)) continue;
     SPX_KEEP_BRANCH();
     const unsigned short w16 = static_cast<unsigned short>(a.slot_weight[r]);
     const U16x2 wv{w16, w16};
@@ -247,8 +273,8 @@ __device__ __forceinline__ int score_least_packed(const FastNode<RM>& ns, const 
       if (r == a.pk_tab_slot) {  // uniform
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const uint32_t r0 = static_cast<uint32_t>(__builtin_fma(-value[r], bt[2 * k], 100.0 + 0x1p-43));  // (as score_each_fast's float64 form)
-          const uint32_t r1 = static_cast<uint32_t>(__builtin_fma(-value[r], bt[2 * k + 1], 100.0 + 0x1p-43));
+          const uint32_t r0 = static_cast<uint32_t>(__builtin_fma(-raw_tab, bt[2 * k], 100.0 + 0x1p-43));  // (as score_each_fast's float64 form)
+          const uint32_t r1 = static_cast<uint32_t>(__builtin_fma(-raw_tab, bt[2 * k + 1], 100.0 + 0x1p-43));
           const uint32_t pk = r0 | (r1 << 16);
           U16x2 pv;
           __builtin_memcpy(&pv, &pk, 4);
@@ -257,7 +283,7 @@ __device__ __forceinline__ int score_least_packed(const FastNode<RM>& ns, const 
         continue;
       }
     }
-    const float nvf = -static_cast<float>(value[r]);
+    const float nvf = __uint_as_float(g.w[pk_nv_dword<RM>(r) - 2 * RM]);
     const float c0f = 99.5f + (r == a.pk_tab_slot ? kPkOffsetTab : kPkOffsetSmall);  // scalar select
     const F32x2 nv{nvf, nvf}, c0{c0f, c0f};
 #pragma unroll
@@ -274,16 +300,16 @@ __device__ __forceinline__ int score_least_packed(const FastNode<RM>& ns, const 
   }
   const U16x2 mm = __builtin_elementwise_min(__builtin_elementwise_min(accp[0], accp[1]), __builtin_elementwise_min(accp[2], accp[3]));
   const unsigned short m16 = mm.x < mm.y ? mm.x : mm.y;
-  if (m16 >= 0x8000u) return 0;  // no zone scores
-  return static_cast<int>(static_cast<double>(static_cast<unsigned short>(m16 + static_cast<unsigned short>(wsum))) * it.wrc);
+  // (m16 >= 2^15: no zone scores — every total is below sum(weights), m16 + sum(weights) wraps to the smallest of them and the division gives 0)
+  return static_cast<int>(static_cast<double>(static_cast<unsigned short>(m16 + static_cast<unsigned short>(wsum))) * wrc);
 }
 
 // scoreForEachNUMANode score.go:110-124: the minimum of the non-zero zone scores, 0 when there is none (the
 // reference's running rule `min == 0 || (s != 0 && s < min)` is order-independent).  Zones past the node's
 // count hold no capacity and score 0 under Least/MostAllocated, so they drop out by themselves.
-template <int RM, int SG, bool PK = false, bool PK_MIXED = false>
+template <int RM, int SG>
 __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const NrtArgs& a, const Item<RM>& it,
-                                               const double* __restrict__ cpu_v, const double* __restrict__ braw, const double* __restrict__ bt = nullptr) {
+                                               const double* __restrict__ cpu_v, const double* __restrict__ braw) {
   const uint32_t used = it.used;
   uint32_t m = 0xffffffffu;  // min over zones of (score - 1) as unsigned: a zero score wraps to the maximum
   double value[RM];
@@ -345,7 +371,6 @@ __device__ __forceinline__ int score_each_fast(const FastNode<RM>& ns, const Nrt
     // division per item instead of one per zone.  3 instructions per (zone, resource) + 1 per zone; the float64 form took 4 + 4.
     const uint32_t wsum = it.wsum_i;
     if (wsum == 0) return 0;  // no weighted slot requested: wave-uniform
-    if constexpr (SG == kSgLeast && PK) return score_least_packed<RM, PK_MIXED>(ns, a, it, value, bt);
     double vq[RM];  // MostAllocated: the request pre-multiplied for the "request <= capacity" product test
 #pragma unroll
     for (int r = 0; r < RM; ++r) vq[r] = SG == kSgMost ? value[r] * (1.0 + 0x1p-49) : 0.0;
