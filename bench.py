@@ -449,7 +449,7 @@ def main() -> None:
                                                   "runs two ranks on one GPU (plumbing check of the sharded path on a one-GPU box)")
     ap.add_argument("--sweep-only", action="store_true", help="skip the full_cycle section (profiling runs: rocprofv3 counter passes crash in hipGraph capture)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
-                    help="spx_set_option before the timed region, e.g. --opt NET_FOLD_ALLOC=0 (A/B experiments; repeatable)")
+                    help="spx_set_option before the timed region, e.g. --opt NET_ALLOC_FUSED=0 (A/B experiments; repeatable)")
     ap.add_argument("--no-pod-classes", action="store_true", help="evaluate every pod row (SPX_OPT_NRT_POD_CLASSES / SPX_OPT_PEAKS_POD_CLASSES off): "
                     "by default a whole-batch NRT or Peaks sweep evaluates one row per class of pods with equal records and copies it")
     ap.add_argument("--no-every-row", action="store_true", help="skip the every_row section (the sweep once more with pod classes off): profiler passes "

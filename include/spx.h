@@ -744,6 +744,10 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *                              through a per-launch table of the requests for which the float32 form differs from the division (those pods
  *                              are recomputed in float64 for the node window concerned); spx_nrt_packed_score_slots reports which;
  *                              0 = float64 throughout.  Same tables either way
+ *   SPX_OPT_NET_ALLOC_FUSED    1 (default) = when NetworkOverhead and NodeResourcesAllocatable are evaluated together over a row range with
+ *                              Filter plugins in play, the NetworkOverhead table sweep also writes Allocatable's table (NormalizeScore over
+ *                              each pod's feasible nodes — the set that sweep already walks) instead of a separate launch that reads every
+ *                              status table again; 0 = separate launches.  Same tables either way
  */
 #define SPX_OPT_ROW_ALIGN 0
 #define SPX_OPT_REFERENCE_KERNELS 1
@@ -760,7 +764,8 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
 #define SPX_OPT_ROW_WORKGROUP 12
 #define SPX_OPT_TLP_AMB_TABLE 13
 #define SPX_OPT_NRT_PACKED_SCORE 14
-#define SPX_NUM_OPTIONS 15
+#define SPX_OPT_NET_ALLOC_FUSED 15
+#define SPX_NUM_OPTIONS 16
 int spx_set_option(spx_engine* e, int option, int64_t value);
 int spx_get_option(const spx_engine* e, int option, int64_t* value);
 

@@ -279,17 +279,84 @@ __global__ __launch_bounds__(kRowThreads) void k_net_cls(NetArgs g) {
   const int64_t n_words = (g.n_nodes + 31) / 32;
   const uint8_t* other0 = g.other_status[0] ? g.other_status[0] + pod * g.row_stride : nullptr;
   const uint8_t* other1 = g.other_status[1] ? g.other_status[1] + pod * g.row_stride : nullptr;
-  const int64_t tiles = (g.row_stride + 64 * kNpl - 1) / (64 * kNpl);
   uint8_t* out_st = g.out_status + pod * g.row_stride;
   uint8_t* out_sc = g.out_score + pod * g.row_stride;
 
-  if (flag != 0) {  // scoreEqually / PreFilter error, as in k_net
+  constexpr int kG = 16;
+  const int64_t groups = g.row_stride / kG;  // rows are padded to a multiple of 16 bytes
+  uint16_t* scored = reinterpret_cast<uint16_t*>(host_bits + n_words);  // [groups]
+  const bool fuse = g.out_alloc != nullptr && nthr == 64;  // uniform (the engine asks for it in batch launches only)
+  uint8_t* out_al = fuse ? g.out_alloc + pod * g.row_stride : nullptr;
+  auto load16 = [](const void* p) { return *reinterpret_cast<const uint4*>(p); };
+  auto byte_of = [](const uint32_t (&w)[4], int j) { return (w[j >> 2] >> (8 * (j & 3))) & 0xffu; };
+  auto half_of = [](const uint32_t (&w)[8], int j) { return (w[j >> 1] >> (16 * (j & 1))) & 0xffffu; };
+  auto rel16 = [&](int64_t n0, uint32_t (&r)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = load16(g.alloc_rel + n0 + 4 * q);
+      r[4 * q] = v.x, r[4 * q + 1] = v.y, r[4 * q + 2] = v.z, r[4 * q + 3] = v.w;
+    }
+  };
+  auto others16 = [&](int64_t n0, uint32_t (&oth)[4]) {  // non-zero byte: another Filter plugin rejected the node
+    uint4 o4 = uint4{0, 0, 0, 0};
+    if (other0) o4 = load16(other0 + n0);
+    if (other1) {
+      const uint4 v = load16(other1 + n0);
+      o4.x |= v.x, o4.y |= v.y, o4.z |= v.z, o4.w |= v.w;
+    }
+    oth[0] = o4.x, oth[1] = o4.y, oth[2] = o4.z, oth[3] = o4.w;
+  };
+  auto open16 = [&](int64_t n0, const uint32_t (&oth)[4]) {  // passed the other plugins, inside the table
+    uint32_t open = 0;
+#pragma unroll
+    for (int j = 0; j < kG; ++j) open |= (n0 + j < g.n_nodes && byte_of(oth, j) == 0u) ? 1u << j : 0u;
+    return open;
+  };
+  auto wave_range = [&](uint32_t& lo32, uint32_t& hi32) {
+    lo32 = static_cast<uint32_t>(wave_min(static_cast<int>(lo32 ^ 0x80000000u))) ^ 0x80000000u;
+    hi32 = static_cast<uint32_t>(wave_max(static_cast<int>(hi32 ^ 0x80000000u))) ^ 0x80000000u;
+  };
+  auto alloc16 = [&](int64_t n0, uint32_t ok, uint32_t alo, double ab, uint32_t (&al_w)[4]) {  // floor((rel - lo) * 100 / range); infeasible cells hold 0
+    uint32_t rel[16];
+    rel16(n0, rel);
+#pragma unroll
+    for (int j = 0; j < kG; ++j)
+      if ((ok >> j) & 1u) al_w[j >> 2] |= static_cast<uint32_t>(static_cast<double>(rel[j] - alo) * ab) << (8 * (j & 3));
+  };
+
+  if (flag != 0) {  // scoreEqually / PreFilter error, as in k_net: status 0 / 0xff everywhere, score 0
     const uint32_t st = flag == 2 ? 0xffffffffu : 0u;
-    for (int64_t q = lane; q < tiles * 64; q += nthr) {
-      const int64_t n0 = q * kNpl;
-      if (n0 >= g.row_stride) continue;
-      *reinterpret_cast<uint32_t*>(out_st + n0) = st;
-      *reinterpret_cast<uint32_t*>(out_sc + n0) = 0u;
+    uint32_t alo = 0xffffffffu, ahi = 0u;
+    const bool fz = fuse && flag != 2;  // Allocatable: scored = passed the other plugins (a PreFilter error leaves no feasible node: zeros)
+    if (fz) {
+      for (int64_t q = lane; q < groups; q += nthr) {
+        const int64_t n0 = q * kG;
+        uint32_t open = 0;
+        if (n0 < g.n_nodes) {
+          uint32_t oth[4], rel[16];
+          others16(n0, oth);
+          rel16(n0, rel);
+          open = open16(n0, oth);
+#pragma unroll
+          for (int j = 0; j < kG; ++j)
+            if ((open >> j) & 1u) alo = rel[j] < alo ? rel[j] : alo, ahi = rel[j] > ahi ? rel[j] : ahi;
+        }
+        scored[q] = static_cast<uint16_t>(open);
+      }
+      wave_range(alo, ahi);
+    }
+    const uint32_t arange = (fz && ahi >= alo) ? ahi - alo : 0u;
+    const double ab = arange ? (100.0 / static_cast<double>(arange)) * (1.0 + 0x1p-49) : 0.0;
+    for (int64_t q = lane; q < groups; q += nthr) {
+      const int64_t n0 = q * kG;
+      *reinterpret_cast<uint4*>(out_st + n0) = uint4{st, st, st, st};
+      *reinterpret_cast<uint4*>(out_sc + n0) = uint4{0u, 0u, 0u, 0u};
+      if (fuse) {
+        uint32_t al_w[4] = {0, 0, 0, 0};
+        const uint32_t ok = fz ? scored[q] : 0u;
+        if (ok != 0 && arange != 0) alloc16(n0, ok, alo, ab, al_w);
+        *reinterpret_cast<uint4*>(out_al + n0) = uint4{al_w[0], al_w[1], al_w[2], al_w[3]};
+      }
     }
     return;
   }
@@ -298,7 +365,8 @@ __global__ __launch_bounds__(kRowThreads) void k_net_cls(NetArgs g) {
   // (dynamic LDS behind the host bitmap, present only in a single-row launch: a batch launch runs one wave per row and keeps its
   // LDS footprint — its occupancy — as it was)
   constexpr int kStage = kNetStagePairs;
-  long long* sp_max = reinterpret_cast<long long*>(lds + ((3 * C + static_cast<int>(n_words) + 1) & ~1));
+  const int scored_words = static_cast<int>((g.row_stride / 16 + 1) / 2);  // the "scored" bits of phases 3-4: 16 per group of 16 nodes
+  long long* sp_max = reinterpret_cast<long long*>(lds + ((3 * C + static_cast<int>(n_words) + scored_words + 1) & ~1));
   int* sp_host = reinterpret_cast<int*>(sp_max + kStage);
   int* sp_region = sp_host + kStage;
   int* sp_zone = sp_region + kStage;
@@ -336,20 +404,24 @@ __global__ __launch_bounds__(kRowThreads) void k_net_cls(NetArgs g) {
   }
   __syncthreads();
 
-  auto other4 = [&](int64_t n0) -> uint32_t {  // non-zero byte: another Filter plugin rejected the node
-    uint32_t w = 0;
-    if (other0) w |= *reinterpret_cast<const uint32_t*>(other0 + n0);
-    if (other1) w |= *reinterpret_cast<const uint32_t*>(other1 + n0);
-    return w;
+  // ---- phases 3 and 4 walk the row in groups of 16 consecutive nodes per lane (round 5): one 16-byte load per status table, two of
+  // class ids, one 16-byte store per output table (dword accesses — 256 contiguous bytes per wave and table — reached 2.6 TB/s).
+  // The first walk leaves each group's 16 "scored" bits (passed every other Filter plugin and this one) in LDS, so the other plugins'
+  // status rows are read from HBM once.  With NetArgs::out_alloc set the same two walks also carry NodeResourcesAllocatable's
+  // feasibility-aware NormalizeScore (what k_alloc_masked's compact path computes, kernels_profile.hip: min/max of the raw-score
+  // offsets over the scored nodes, then floor((rel - lo) * 100 / range) as one float64 multiply) — the feasible set is the same, and
+  // the separate launch would read both status tables again (2.5 GB at config #5's share).
+  auto classes16 = [&](int64_t n0, uint32_t (&cw)[8]) {
+    const uint4 c0 = load16(g.node_class16 + n0), c1 = load16(g.node_class16 + n0 + 8);
+    cw[0] = c0.x, cw[1] = c0.y, cw[2] = c0.z, cw[3] = c0.w, cw[4] = c1.x, cw[5] = c1.y, cw[6] = c1.z, cw[7] = c1.w;
   };
-  auto classes4 = [&](int64_t n0) -> uint64_t {
-    const uint2 v = *reinterpret_cast<const uint2*>(g.node_class16 + n0);
-    return v.x | (static_cast<uint64_t>(v.y) << 32);
-  };
+  auto hosts16 = [&](int64_t n0) -> uint32_t { return (host_bits[n0 >> 5] >> (n0 & 31)) & 0xffffu; };  // n0 is a multiple of 16
 
   // ---- phase 3
   int mn = INT32_MAX, mx = INT32_MIN;
-  if (!other0 && !other1) {
+  uint32_t alo = 0xffffffffu, ahi = 0u;  // Allocatable: offsets of the scored nodes
+  const bool walk = other0 || other1 || fuse;
+  if (!walk) {
     for (int c = lane; c < C; c += nthr) {
       const int w = cls_word[c];
       if (w >= 0 && g.cls_size[c] - cls_hosts[c] > 0) {
@@ -365,31 +437,46 @@ __global__ __launch_bounds__(kRowThreads) void k_net_cls(NetArgs g) {
       }
     }
   } else {
-    for (int64_t q = lane; q < tiles * 64; q += nthr) {
-      const int64_t n0 = q * kNpl;
-      if (n0 >= g.n_nodes) continue;
-      const uint32_t oth = other4(n0);
-      const uint64_t cw = classes4(n0);
-      const unsigned hb = (host_bits[n0 >> 5] >> (n0 & 31)) & 0xfu;
+    for (int64_t q = lane; q < groups; q += nthr) {
+      const int64_t n0 = q * kG;
+      uint32_t ok = 0;
+      if (n0 < g.n_nodes) {
+        uint32_t oth[4], cw[8], rel[16];
+        others16(n0, oth);
+        classes16(n0, cw);
+        if (fuse) rel16(n0, rel);
+        const uint32_t hb = hosts16(n0);
+        const uint32_t open = open16(n0, oth);
 #pragma unroll
-      for (int j = 0; j < kNpl; ++j) {
-        if (n0 + j >= g.n_nodes || ((oth >> (8 * j)) & 0xffu)) continue;
-        int w;
-        if ((hb >> j) & 1u) {
-          const Acc a = direct(n0 + j);
-          w = a.cost | (a.vio > a.sat ? static_cast<int>(0x80000000u) : 0);
-        } else {
-          w = cls_word[(cw >> (16 * j)) & 0xffffu];
+        for (int j = 0; j < kG; ++j) {
+          const int w = cls_word[half_of(cw, j)];
+          if (((open & ~hb) >> j) & 1u && w >= 0) {
+            mn = w < mn ? w : mn;
+            mx = w > mx ? w : mx;
+            ok |= 1u << j;
+            if (fuse) alo = rel[j] < alo ? rel[j] : alo, ahi = rel[j] > ahi ? rel[j] : ahi;
+          }
         }
-        if (w >= 0) {
-          mn = w < mn ? w : mn;
-          mx = w > mx ? w : mx;
+        for (uint32_t hs = open & hb; hs != 0; hs &= hs - 1) {  // hosts of the pod's pairs (rare): exact
+          const int j = __builtin_ctz(hs);
+          const Acc a = direct(n0 + j);
+          if (!(a.vio > a.sat)) {
+            mn = a.cost < mn ? a.cost : mn;
+            mx = a.cost > mx ? a.cost : mx;
+            ok |= 1u << j;
+            if (fuse) {
+              const uint32_t r = g.alloc_rel[n0 + j];
+              alo = r < alo ? r : alo, ahi = r > ahi ? r : ahi;
+            }
+          }
         }
       }
+      scored[q] = static_cast<uint16_t>(ok);
     }
   }
   mn = wave_min(mn);
   mx = wave_max(mx);
+  if (fuse) wave_range(alo, ahi);
   if (nthr > 64) {
     __shared__ int s_mn[kRowThreads / 64], s_mx[kRowThreads / 64];
     if ((lane & 63) == 0) s_mn[lane >> 6] = mn, s_mx[lane >> 6] = mx;
@@ -409,53 +496,67 @@ __global__ __launch_bounds__(kRowThreads) void k_net_cls(NetArgs g) {
     cls_fin[c] = static_cast<uint32_t>(score) | (w < 0 ? static_cast<uint32_t>(SPX_NET_ST_UNSCHEDULABLE) << 8 : 0u);
   }
   __syncthreads();
+  // Allocatable's row constants (a fused launch is a batch launch: one wave per row, alo / ahi are the row's)
+  const uint32_t arange = (fuse && ahi >= alo) ? ahi - alo : 0u;
+  const double ab = arange ? (100.0 / static_cast<double>(arange)) * (1.0 + 0x1p-49) : 0.0;
 
   // ---- phase 4
-  for (int64_t q = lane; q < tiles * 64; q += nthr) {
-    const int64_t n0 = q * kNpl;
-    if (n0 >= g.row_stride) continue;
-    uint32_t st_w = 0, sc_w = 0;
+  for (int64_t q = lane; q < groups; q += nthr) {
+    const int64_t n0 = q * kG;
+    uint32_t st_w[4] = {0, 0, 0, 0}, sc_w[4] = {0, 0, 0, 0}, al_w[4] = {0, 0, 0, 0};
     if (n0 < g.n_nodes) {
-      const uint32_t oth = (other0 || other1) ? other4(n0) : 0u;
-      const uint64_t cw = classes4(n0);
-      const unsigned hb = (host_bits[n0 >> 5] >> (n0 & 31)) & 0xfu;
+      const uint32_t ok = walk ? scored[q] : 0xffffu;  // (written by this thread) rejected elsewhere: not scored
+      uint32_t cw[8];
+      classes16(n0, cw);
+      const uint32_t hb = hosts16(n0);
 #pragma unroll
-      for (int j = 0; j < kNpl; ++j) {
-        uint32_t fin = cls_fin[(cw >> (16 * j)) & 0xffffu];
-        if ((hb >> j) & 1u) {  // a host of one of the pod's pairs: exact
-          const Acc a = direct(n0 + j);
-          const bool pass = !(a.vio > a.sat);
-          int score = pass ? norm_cost(a.cost, mn, mx) : 0;
-          score = score < 0 ? 0 : (score > 255 ? 255 : score);
-          fin = static_cast<uint32_t>(score) | (pass ? 0u : static_cast<uint32_t>(SPX_NET_ST_UNSCHEDULABLE) << 8);
-        }
-        if ((oth >> (8 * j)) & 0xffu) fin &= 0xff00u;  // rejected elsewhere: not scored
+      for (int j = 0; j < kG; ++j) {
+        uint32_t fin = cls_fin[half_of(cw, j)];
         if (n0 + j >= g.n_nodes) fin = 0;
-        sc_w |= (fin & 0xffu) << (8 * j);
-        st_w |= (fin >> 8) << (8 * j);
+        st_w[j >> 2] |= (fin >> 8) << (8 * (j & 3));
+        if ((ok >> j) & 1u) sc_w[j >> 2] |= (fin & 0xffu) << (8 * (j & 3));
       }
+      for (uint32_t hs = hb; hs != 0; hs &= hs - 1) {  // a host of one of the pod's pairs: exact
+        const int j = __builtin_ctz(hs);
+        if (n0 + j >= g.n_nodes) continue;
+        const Acc a = direct(n0 + j);
+        const bool pass = !(a.vio > a.sat);
+        int score = pass ? norm_cost(a.cost, mn, mx) : 0;
+        score = score < 0 ? 0 : (score > 255 ? 255 : score);
+        const uint32_t sh = 8 * (j & 3), keep = ~(0xffu << sh);
+        st_w[j >> 2] = (st_w[j >> 2] & keep) | ((pass ? 0u : static_cast<uint32_t>(SPX_NET_ST_UNSCHEDULABLE)) << sh);
+        sc_w[j >> 2] = (sc_w[j >> 2] & keep) | ((((ok >> j) & 1u) ? static_cast<uint32_t>(score) : 0u) << sh);
+      }
+      if (fuse && ok != 0 && arange != 0) alloc16(n0, ok, alo, ab, al_w);
     }
-    *reinterpret_cast<uint32_t*>(out_st + n0) = st_w;
-    *reinterpret_cast<uint32_t*>(out_sc + n0) = sc_w;
+    *reinterpret_cast<uint4*>(out_st + n0) = uint4{st_w[0], st_w[1], st_w[2], st_w[3]};
+    *reinterpret_cast<uint4*>(out_sc + n0) = uint4{sc_w[0], sc_w[1], sc_w[2], sc_w[3]};
+    if (fuse) *reinterpret_cast<uint4*>(out_al + n0) = uint4{al_w[0], al_w[1], al_w[2], al_w[3]};
   }
 }
 
 }  // namespace
 
 size_t net_lds_bytes(int n_classes, int64_t n_nodes) {
-  return static_cast<size_t>(3 * n_classes) * sizeof(int) + static_cast<size_t>((n_nodes + 31) / 32) * sizeof(unsigned);
+  // class tables, host bitmap, the 16 "scored" bits per group of 16 nodes of the padded row
+  return static_cast<size_t>(3 * n_classes) * sizeof(int) + static_cast<size_t>((n_nodes + 31) / 32) * sizeof(unsigned) +
+         static_cast<size_t>((n_nodes + 4096) / 16 + 2) * sizeof(uint16_t);  // (row stride < n_nodes + 4096: SPX_OPT_ROW_ALIGN's limit)
 }
 
-void launch_net(const NetArgs& g, hipStream_t s) {
-  if (g.row_end <= g.row_begin) return;
+bool launch_net(const NetArgs& g, hipStream_t s) {
+  if (g.row_end <= g.row_begin) return false;
   const unsigned blocks = static_cast<unsigned>(g.row_end - g.row_begin);
   size_t lds = g.n_classes > 0 ? net_lds_bytes(g.n_classes, g.n_nodes) : 16;
   if (blocks == 1) lds = ((lds + 7) & ~static_cast<size_t>(7)) + kNetStagePairs * (sizeof(long long) + 3 * sizeof(int));  // the staged pair list
   const bool generic_only = (g.opts & kOptNetGeneric) != 0;  // SPX_OPT_REFERENCE_KERNELS
-  if (!generic_only && !g.out_raw && g.n_classes > 0 && g.n_classes <= 65535 && g.node_class16)
-    hipLaunchKernelGGL(k_net_cls, dim3(blocks), dim3(blocks == 1 ? kRowThreads : 64), lds, s, g);
-  else
-    hipLaunchKernelGGL(k_net, dim3(blocks), dim3(64), lds, s, g);
+  if (!generic_only && !g.out_raw && g.n_classes > 0 && g.n_classes <= 65535 && g.node_class16 && g.row_stride % 16 == 0) {
+    NetArgs h = g;
+    if (blocks == 1 || !h.alloc_rel) h.out_alloc = nullptr;
+    hipLaunchKernelGGL(k_net_cls, dim3(blocks), dim3(blocks == 1 ? kRowThreads : 64), lds, s, h);
+    return h.out_alloc != nullptr;
+  }
+  hipLaunchKernelGGL(k_net, dim3(blocks), dim3(64), lds, s, g);
+  return false;
 }
 
 }  // namespace spx

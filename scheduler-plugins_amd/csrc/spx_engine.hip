@@ -55,7 +55,7 @@ struct spx_engine {
   int64_t row_stride = 0;
 
   // spx_set_option state (per engine; nothing is read from the environment)
-  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1, 0, 1, 1};
+  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1, 0, 1, 1, 1};
 
   // params
   int32_t alloc_mode = SPX_MODE_LEAST;
@@ -722,6 +722,7 @@ int spx_set_option(spx_engine* e, int option, int64_t value) {
     case SPX_OPT_ROW_WORKGROUP:
     case SPX_OPT_TLP_AMB_TABLE:
     case SPX_OPT_NRT_PACKED_SCORE:
+    case SPX_OPT_NET_ALLOC_FUSED:
       if (value != 0 && value != 1) return fail(e, SPX_ERR_ARG, "option takes 0 or 1");
       break;
     case SPX_OPT_NRT_LN_LIST_PERMILLE:
@@ -1954,7 +1955,7 @@ int spx_upload_net_nodes(spx_engine* e, const spx_net_nodes_soa* t) {
   if ((rc = upload(e, e->d_net_zone, t->zone, static_cast<size_t>(n) * 4))) return rc;
   if ((rc = upload(e, e->d_net_class, cls.data(), static_cast<size_t>(n) * 4))) return rc;
   {
-    std::vector<uint16_t> c16(static_cast<size_t>(spx::round_up(n, 4)), 0);
+    std::vector<uint16_t> c16(static_cast<size_t>(spx::round_up(n, 16)), 0);  // (k_net_cls reads groups of 16)
     std::vector<int32_t> size(cr.size() ? cr.size() : 1, 0);
     e->net_class16 = cr.size() <= 65535;
     for (int64_t i = 0; i < n; ++i) {
@@ -2203,6 +2204,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
       return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
   // Allocatable's NormalizeScore runs over each pod's feasible nodes as soon as any Filter is in play
   const bool masked = N || W || e->ext_mask;
+  bool alloc_by_net = false;  // Allocatable's masked table written by the NetworkOverhead sweep (SPX_OPT_NET_ALLOC_FUSED)
   a.out_alloc = (A && !masked) ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_ALLOCATABLE].p) : nullptr;
   a.out_tlp = T ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_TLP].p) : nullptr;
   a.out_lvrb = L ? static_cast<uint8_t*>(e->score[SPX_PLUGIN_LVRB].p) : nullptr;
@@ -2357,7 +2359,13 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     g.other_status[1] = e->ext_mask ? static_cast<const uint8_t*>(e->d_ext_status.p) : nullptr;
     g.out_status = static_cast<uint8_t*>(e->status[SPX_PLUGIN_NETOVERHEAD].p);
     g.out_score = static_cast<uint8_t*>(e->score[SPX_PLUGIN_NETOVERHEAD].p);
-    spx::launch_net(g, e->stream);
+    // Allocatable's masked NormalizeScore rides on the network kernel's walks when both are evaluated over a row range (same feasible
+    // set; k_alloc_masked would read the status tables again): launch_net says whether it did
+    if (A && masked && !e->skip_alloc_masked && e->alloc_compact && !e->row_indirect && row_end - row_begin > 1 && e->option[SPX_OPT_NET_ALLOC_FUSED]) {
+      g.alloc_rel = static_cast<const uint32_t*>(e->d_alloc_rel.p);
+      g.out_alloc = static_cast<uint8_t*>(e->score[SPX_PLUGIN_ALLOCATABLE].p);
+    }
+    alloc_by_net = spx::launch_net(g, e->stream);
     SPX_HIP(e, hipGetLastError());
   }
   spx::launch_trimaran(a, e->stream);
@@ -2398,7 +2406,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
       spx::launch_rows_expand(static_cast<const int32_t*>(e->d_pk_dups.p), e->pk_n_dups, ka.out_score, nullptr, e->row_stride, e->stream);
     SPX_HIP(e, hipGetLastError());
   }
-  if (A && masked && !e->skip_alloc_masked) {
+  if (A && masked && !e->skip_alloc_masked && !alloc_by_net) {
     spx::ProfileArgs pa{};
     pa.n_nodes = e->n_nodes;
     pa.row_stride = e->row_stride;

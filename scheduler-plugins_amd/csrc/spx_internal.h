@@ -434,8 +434,13 @@ struct NetArgs {
   uint8_t* out_score;
   int64_t* out_raw;             // when set: raw row (row_begin only), no table writes
   int32_t raw_which;
+  // NodeResourcesAllocatable's feasibility-aware NormalizeScore carried by k_net_cls's two walks (batch launches; the engine sets
+  // these when the evaluation would otherwise run k_alloc_masked's compact path over the same status tables)
+  const uint32_t* alloc_rel;    // [row_stride + 1] raw scores as offsets from the global minimum (AllocPrepArgs.rel)
+  uint8_t* out_alloc;           // Allocatable's score table; NULL = not fused
 };
-void launch_net(const NetArgs& g, hipStream_t s);
+// true = the launch also wrote NetArgs::out_alloc (k_net_cls ran)
+bool launch_net(const NetArgs& g, hipStream_t s);
 size_t net_lds_bytes(int n_classes, int64_t n_nodes);
 
 // ---------------------------------------------------------------- TopologicalSort (kernels_sort.hip)

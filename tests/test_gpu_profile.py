@@ -23,12 +23,14 @@ def load_all(e, hdr, snap, strategy="LeastAllocated"):
     return params
 
 
-@pytest.mark.parametrize("kernels", ["fast", "generic", "wide_allocatable_range", "row_workgroup"])
+@pytest.mark.parametrize("kernels", ["fast", "generic", "wide_allocatable_range", "row_workgroup", "alloc_unfused"])
 @pytest.mark.parametrize("n_nodes,n_pods,seed", [(300, 200, 1), (65, 33, 2)])
 def test_full_profile(gpu_required, hdr, oracle, kernels, n_nodes, n_pods, seed):
     """`generic` forces the per-node NetworkOverhead sweep and the int64 NRT sweep; `wide_allocatable_range` makes
     Allocatable's raw scores span more than 2^42, which takes the masked normalisation off its float64 path; `row_workgroup`
-    gives every row of the per-row kernels a whole workgroup (the mapping rows of more than ~65k nodes take by themselves)"""
+    gives every row of the per-row kernels a whole workgroup (the mapping rows of more than ~65k nodes take by themselves);
+    `alloc_unfused` keeps Allocatable's masked NormalizeScore in its own launch (SPX_OPT_NET_ALLOC_FUSED = 0; `fast` lets the
+    NetworkOverhead sweep write that table)"""
     snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=seed, pods_per_group=20, n_namespaces=20)
     weights = {ALLOCATABLE: 1, TLP: 2, LVRB: 1, NRT: 3, NETOVERHEAD: 2}
     with Engine(0) as e:
@@ -36,6 +38,8 @@ def test_full_profile(gpu_required, hdr, oracle, kernels, n_nodes, n_pods, seed)
             e.force_reference_kernels(NETOVERHEAD, NRT)
         if kernels == "row_workgroup":
             e.set_option("ROW_WORKGROUP", 1)
+        if kernels == "alloc_unfused":
+            e.set_option("NET_ALLOC_FUSED", 0)
         if kernels == "wide_allocatable_range":
             snap["nodes"].array("alloc_mem")[:] *= 64  # up to 64 TiB: raw scores (a weighted mean) now span > 2^42
             e.set_allocatable("Least", {1: 1})
@@ -104,3 +108,32 @@ def test_external_mask_drives_allocatable_normalisation(gpu_required, hdr, oracl
         e.eval(mask_of(ALLOCATABLE))
         e.sync()
         assert np.array_equal(e.all_scores(ALLOCATABLE).astype(np.int64), osnap.score_rows(ALLOCATABLE)[1])
+
+
+@pytest.mark.parametrize("n_nodes", [20_011, 1_040, 17])
+def test_allocatable_written_by_the_network_sweep_equals_the_separate_launch(gpu_required, hdr, n_nodes):
+    """SPX_OPT_NET_ALLOC_FUSED: the three tables the NetworkOverhead sweep writes (its status, its score, Allocatable's masked
+    NormalizeScore) byte for byte what the separate launches write — ragged rows (node counts that are no multiple of 16), with and
+    without an external feasibility mask on top of NRT's Filter, a pod without feasible node, one with a single feasible node.
+    (Against the oracle: test_full_profile, tests/test_gpu_exhaustive.py::test_config5_share_every_cell.)"""
+    n_pods = 300
+    snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=11, pods_per_group=20, n_namespaces=20)
+    rng = np.random.default_rng(3)
+    ext = (rng.random((n_pods, n_nodes)) < 0.7).astype(np.uint8)
+    ext[7] = 0
+    ext[9] = 0
+    ext[9, n_nodes - 1] = 1
+    tables = {}
+    for fused in (1, 0):
+        with Engine(0) as e:
+            e.set_option("NET_ALLOC_FUSED", fused)
+            load_all(e, hdr, snap)
+            for with_ext in (False, True):
+                e.upload_feasible_mask(ext if with_ext else None)
+                e.eval(mask_of(ALLOCATABLE, NRT, NETOVERHEAD))
+                e.sync()
+                tables[(fused, with_ext)] = (e.all_status(NETOVERHEAD).copy(), e.all_scores(NETOVERHEAD).copy(), e.all_scores(ALLOCATABLE).copy())
+    for with_ext in (False, True):
+        for got, want, what in zip(tables[(1, with_ext)], tables[(0, with_ext)], ("status", "score", "allocatable")):
+            assert np.array_equal(got, want), (with_ext, what, np.argwhere(got != want)[:5])
+        assert tables[(1, with_ext)][2].max() == 100 and len(np.unique(tables[(1, with_ext)][2])) > 20
