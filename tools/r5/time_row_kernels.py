@@ -28,4 +28,16 @@ with Engine(0) as e:
     t_net = ms(mask_of(NRT, NETOVERHEAD))
     t_all = ms(mask_of(NRT, NETOVERHEAD, ALLOCATABLE))
     t_full = ms(mask_of(NRT, NETOVERHEAD, ALLOCATABLE, TLP, LVRB))
+    import time
+    full = 0
+    for p_ in w["plugins"]:
+        full |= 1 << bench.PID[p_]
+    for reps in (5, 100):
+        e.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            e.eval(full)
+        e.sync()
+        print(f"bench mask x{reps}: {(time.perf_counter() - t0) * 1e3 / reps:.3f} ms per eval; last_eval_ms {e.last_eval_ms():.3f}")
+    print("after the sustained run: nrt+net+alloc", round(ms(mask_of(NRT, NETOVERHEAD, ALLOCATABLE)), 3), " nrt", round(ms(mask_of(NRT)), 3))
     print(f"nrt {t_nrt:.3f}  +net {t_net - t_nrt:.3f}  +alloc_masked {t_all - t_net:.3f}  +tlp,lvrb {t_full - t_all:.3f}  total {t_full:.3f} ms")
