@@ -540,7 +540,7 @@ __global__ __launch_bounds__(kRowThreads) void k_net_cls(NetArgs g) {
 size_t net_lds_bytes(int n_classes, int64_t n_nodes) {
   // class tables, host bitmap, the 16 "scored" bits per group of 16 nodes of the padded row
   return static_cast<size_t>(3 * n_classes) * sizeof(int) + static_cast<size_t>((n_nodes + 31) / 32) * sizeof(unsigned) +
-         static_cast<size_t>((n_nodes + 4096) / 16 + 2) * sizeof(uint16_t);  // (row stride < n_nodes + 4096: SPX_OPT_ROW_ALIGN's limit)
+         static_cast<size_t>((n_nodes + 4096) / 16 + 2) * sizeof(uint16_t) + 16;  // (row stride < n_nodes + 4096: SPX_OPT_ROW_ALIGN's limit; + the roundings of the kernel's own layout)
 }
 
 bool launch_net(const NetArgs& g, hipStream_t s) {
