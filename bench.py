@@ -524,9 +524,9 @@ def main() -> None:
         local_pods = max(e.n_pods for e in target.engines)
     else:
         target = e0 = Engine(local_rank)
-        for kv in args.opt:  # (the row padding must be chosen before the first upload; the other options are applied below)
-            if kv.startswith("ROW_ALIGN="):
-                e0.set_option("ROW_ALIGN", int(kv.partition("=")[2]))
+        for kv in args.opt:  # (options read at upload time must be set before the first upload; the others are applied below)
+            if kv.startswith(("ROW_ALIGN=", "NRT_RANK_NARROW=")):
+                e0.set_option(kv.partition("=")[0], int(kv.partition("=")[2]))
         if strong and world > 1:  # every rank builds the same batch and keeps its shard
             snap = build_snapshot(hdr, w, n_pods_total, synth.SEED)
             from scheduler_plugins_amd import shard

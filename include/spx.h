@@ -748,6 +748,9 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *                              Filter plugins in play, the NetworkOverhead table sweep also writes Allocatable's table (NormalizeScore over
  *                              each pod's feasible nodes — the set that sweep already walks) instead of a separate launch that reads every
  *                              status table again; 0 = separate launches.  Same tables either way
+ *   SPX_OPT_NRT_RANK_NARROW    1 (default) = chunks of the rank-space Filter's stream (SPX_OPT_NRT_RANK_FILTER) whose lists all have at most 127
+ *                              distinct quantities keep four zones' counts per register instead of two (half the subtract / and instructions
+ *                              per comparison); 0 = two per register everywhere.  Read when pod rows are uploaded.  Same tables either way
  */
 #define SPX_OPT_ROW_ALIGN 0
 #define SPX_OPT_REFERENCE_KERNELS 1
@@ -765,7 +768,8 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
 #define SPX_OPT_TLP_AMB_TABLE 13
 #define SPX_OPT_NRT_PACKED_SCORE 14
 #define SPX_OPT_NET_ALLOC_FUSED 15
-#define SPX_NUM_OPTIONS 16
+#define SPX_OPT_NRT_RANK_NARROW 16
+#define SPX_NUM_OPTIONS 17
 int spx_set_option(spx_engine* e, int option, int64_t value);
 int spx_get_option(const spx_engine* e, int option, int64_t* value);
 

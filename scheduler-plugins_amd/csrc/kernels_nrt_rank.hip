@@ -35,23 +35,34 @@ namespace {
 
 using namespace nrtdev;
 
-constexpr uint32_t kG = 0x80008000u;  // the guard bits of a packed dword: zone j in the low half, zone j + 4 in the high half
+// Two layouts of the eight zones' counts (round 5).  WIDE: two zones per dword under guard bits 15 / 31 (zone j in the low half of dword j,
+// zone j + 4 in the high half): lists of up to 32 767 quantities.  NARROW: four zones per dword under guard bits 7 / 15 / 23 / 31 (zones 0-3 in
+// dword 0, zones 4-7 in dword 1) when every list of the chunk has at most 127 entries (the engine marks such chunks: header dword 9, and
+// replicates the thresholds into four bytes) — half the subtract / and instructions per comparison vector.  A byte (halfword) holds
+// count | guard >= 128 (32 768) and the subtrahend is at most 127 (32 767): no borrow crosses a field.
+template <bool NARROW>
+struct RkLayout {
+  static constexpr int W = NARROW ? 2 : 4;
+  static constexpr uint32_t G = NARROW ? 0x80808080u : 0x80008000u;
+  static constexpr uint32_t kOne = NARROW ? 0x01010101u : 0x00010001u;  // "count >= 1" in every field
+};
 
-// the 8 zones' verdicts for one comparison vector: guard bits of m[0..3]
-template <int RM>
-__device__ __forceinline__ void rank_mask(const uint32_t (&qa)[RM][4], const uint32_t (&fillp)[RM], uint32_t host_level, const uint32_t* thr, uint32_t fit,
-                                          uint32_t always, uint32_t (&m)[4]) {
+// the 8 zones' verdicts for one comparison vector: guard bits of m[]
+template <int RM, bool NARROW>
+__device__ __forceinline__ void rank_mask(const uint32_t (&qa)[RM][RkLayout<NARROW>::W], const uint32_t (&fillp)[RM], uint32_t host_level, const uint32_t* thr,
+                                          uint32_t fit, uint32_t always, uint32_t (&m)[RkLayout<NARROW>::W]) {
+  using L = RkLayout<NARROW>;
   const uint32_t need = fit | always;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) m[j] = kG;
+  for (int j = 0; j < L::W; ++j) m[j] = L::G;
 #pragma unroll
   for (int r = 0; r < RM; ++r) {
     if (!((need >> r) & 1u)) continue;  // uniform
     SPX_KEEP_BRANCH();
     // a non-Guaranteed pod's NUMA-affine request: any reporting zone suits (filter.go:120-129) — count >= 1
-    const uint32_t tt = ((always >> r) & 1u) ? 0x00010001u : thr[r];
+    const uint32_t tt = ((always >> r) & 1u) ? L::kOne : thr[r];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < L::W; ++j) {
       uint32_t x = qa[r][j] - tt;
       if ((host_level >> r) & 1u) x |= fillp[r];  // uniform: a host-level resource no zone reports is not checked (filter.go:110-116)
       m[j] &= x;
@@ -59,17 +70,131 @@ __device__ __forceinline__ void rank_mask(const uint32_t (&qa)[RM][4], const uin
   }
 }
 
-__device__ __forceinline__ bool any_zone(const uint32_t (&m)[4]) { return ((m[0] | m[1]) | (m[2] | m[3])) != 0u; }
+template <int W>
+__device__ __forceinline__ bool any_zone(const uint32_t (&m)[W]) {
+  uint32_t o = m[0];
+#pragma unroll
+  for (int j = 1; j < W; ++j) o |= m[j];
+  return o != 0u;
+}
 
-// the lowest zone of m as a packed one-zone set (zone z = dword z & 3, half z >> 2); 0 when m is empty
-__device__ __forceinline__ void lowest_zone(const uint32_t (&m)[4], uint32_t (&z)[4]) {
+// the lowest zone of m as a packed one-zone set (same layout as m); all zero when m is empty
+__device__ __forceinline__ void lowest_zone(const uint32_t (&m)[4], uint32_t (&z)[4]) {  // WIDE: zone z = dword z & 3, half z >> 2
   // bits 0..3 = zones 0..3, bits 16..19 = zones 4..7
   const uint32_t w = (m[0] >> 15) | (m[1] >> 14) | (m[2] >> 13) | (m[3] >> 12);
   const uint32_t m8 = (w | (w >> 12)) & 0xffu;
   const uint32_t low = m8 & (0u - m8);
   const uint32_t w2 = (low | (low << 12)) & 0x000f000fu;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) z[j] = (w2 << (15 - j)) & kG;
+  for (int j = 0; j < 4; ++j) z[j] = (w2 << (15 - j)) & 0x80008000u;
+}
+__device__ __forceinline__ void lowest_zone(const uint32_t (&m)[2], uint32_t (&z)[2]) {  // NARROW: zone z = dword z >> 2, byte z & 3
+  // guard bits 7 / 15 / 23 / 31 -> bits 28..31 of the product (2^21 + 2^14 + 2^7 + 1: the four wanted partial products land there,
+  // every other one elsewhere or outside the 32 bits, no two on one bit: no carries)
+  constexpr uint32_t kGather = 0x00204081u;
+  const uint32_t lo4 = ((m[0] & 0x80808080u) * kGather) >> 28, hi4 = ((m[1] & 0x80808080u) * kGather) >> 28;
+  const uint32_t m8 = lo4 | (hi4 << 4);
+  const uint32_t low = m8 & (0u - m8);
+  // a one-hot nibble bit k -> bit 8 k + 7: k + 7 k is one of the product's four bits k + {0, 7, 14, 21}, the only one on a byte's bit 0
+  z[0] = (((low & 0xfu) * kGather) & 0x01010101u) << 7;
+  z[1] = (((low >> 4) * kGather) & 0x01010101u) << 7;
+}
+
+// the pod loop of k_nrt_filter_rank in one of the two count layouts (chosen per chunk: block-uniform)
+template <int RM, bool NARROW>
+__device__ __forceinline__ void rank_walk(const uint32_t (&q4)[RM][4], uint32_t fill_bits, uint32_t host_level, const uint32_t* pods, int rows, int lane,
+                                          bool w_pod, bool w_ctr, bool aligned, bool pod_scope, uint32_t node_present, uint32_t st_stale, bool in, int pos,
+                                          uint32_t* stage) {
+  using L = RkLayout<NARROW>;
+  constexpr int W = L::W;
+  constexpr int PWR = kRkPodHead + kRkVectors * RM;
+  uint32_t qa[RM][W], fillp[RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) qa[r][j] = q4[r][j];
+    fillp[r] = ((fill_bits >> r) & 1u) ? L::G : 0u;
+  }
+  uint32_t acc_status = 0;
+  for (int p = 0; p < rows; ++p) {
+    const uint32_t* rec = pods + p * PWR;
+    // the head: lane l holds dword l & 15; the fields become scalars as they are needed
+    const uint32_t hv = rec[lane & 15];
+    auto head = [&](int i) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hv), i)); };
+    const uint32_t w0 = head(0);
+    const int qos = w0 & 0xffu;
+    const bool non_native = ((w0 >> 8) & 0xffu) != 0;
+    const int n_ctr = (w0 >> 16) & 0xffu;
+    const int last_app = static_cast<int>(w0 >> 24) == 0xff ? -1 : static_cast<int>(w0 >> 24);
+    const bool filtered = !(qos == SPX_QOS_BESTEFFORT && !non_native);  // filter.go:186-190
+    uint32_t status = filtered ? st_stale : 0u;
+    if (filtered) {  // uniform
+      if (w_pod && pod_scope && aligned) {  // singleNUMAPodLevelHandler
+        const uint32_t s = head(2);
+        const uint32_t fit = (s >> 8) & 0xffu, always = (s >> 16) & 0xffu;
+        uint32_t m[W];
+        rank_mask<RM, NARROW>(qa, fillp, host_level, rec + kRkPodHead, fit, always, m);
+        const bool ok = ((fit | always) & ~node_present) == 0 && any_zone(m);
+        if (!ok) status = SPX_NRT_ST_POD;
+      }
+      if (w_ctr && !pod_scope && aligned) {  // singleNUMAContainerLevelHandler, containers in order (init containers first)
+        const uint32_t apps = head(11);
+        const int a0 = apps & 0xffu, a1 = (apps >> 8) & 0xffu;
+        uint32_t z0[W], z1[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) z0[j] = z1[j] = 0u;  // the zones app containers a0 / a1 were charged to (packed one-zone sets)
+        for (int c = 0; c < n_ctr; ++c) {
+          const uint32_t s = head(3 + c);
+          const uint32_t fit = (s >> 8) & 0xffu, always = (s >> 16) & 0xffu, kind = s >> 24;
+          const uint32_t* own = rec + kRkPodHead + (1 + c) * RM;
+          uint32_t m[W];
+          rank_mask<RM, NARROW>(qa, fillp, host_level, own, fit, always, m);
+          if (kind == SPX_CTR_APP && c != a0 && fit != 0) {  // uniform: an earlier app container may have been charged to a zone
+            if (c == a1) {
+              uint32_t ms[W];
+              rank_mask<RM, NARROW>(qa, fillp, host_level, rec + kRkPodHead + 9 * RM, fit, always, ms);
+#pragma unroll
+              for (int j = 0; j < W; ++j) m[j] = (m[j] & ~z0[j]) | (ms[j] & z0[j]);
+            } else {  // the third app container: its own vector, + a0, + a1, + both
+              uint32_t m0[W], m1[W], mb[W];
+              rank_mask<RM, NARROW>(qa, fillp, host_level, rec + kRkPodHead + 10 * RM, fit, always, m0);
+              rank_mask<RM, NARROW>(qa, fillp, host_level, rec + kRkPodHead + 11 * RM, fit, always, m1);
+              rank_mask<RM, NARROW>(qa, fillp, host_level, rec + kRkPodHead + 12 * RM, fit, always, mb);
+#pragma unroll
+              for (int j = 0; j < W; ++j) {
+                const uint32_t both = z0[j] & z1[j];
+                uint32_t x = (m[j] & ~z1[j]) | (m1[j] & z1[j]);
+                x = (x & ~z0[j]) | (m0[j] & z0[j]);
+                m[j] = (x & ~both) | (mb[j] & both);
+              }
+            }
+          }
+          const bool ok = ((fit | always) & ~node_present) == 0 && any_zone(m);
+          const bool live = status == 0;
+          if (kind != SPX_CTR_APP) {
+            if (live && !ok) status = kind == SPX_CTR_SIDECAR ? SPX_NRT_ST_SIDECAR_CONTAINER : SPX_NRT_ST_INIT_CONTAINER;
+          } else {
+            if (live && !ok) status = SPX_NRT_ST_CONTAINER;
+            if (c != last_app && fit != 0) {  // uniform: the zone the container is charged to (the lowest that fits), for its successors
+              uint32_t z[W];
+              lowest_zone(m, z);
+              const bool apply = live && ok;
+#pragma unroll
+              for (int j = 0; j < W; ++j) {
+                if (c == a0) z0[j] = apply ? z[j] : 0u;
+                else z1[j] = apply ? z[j] : 0u;
+              }
+            }
+          }
+        }
+      }
+    }
+    acc_status |= status << (8 * (p & 3));
+    if ((p & 3) == 3 || p + 1 == rows) {  // uniform
+      if (in) stage[(p >> 2) * kWindow + pos] = acc_status;
+      acc_status = 0;
+    }
+  }
 }
 
 // dynamic LDS: the chunk block (header, lists, pod records), then the staged status dwords [kPodsPerUnit / 4][kWindow]
@@ -119,23 +244,24 @@ __global__ __launch_bounds__(256, 4) void k_nrt_filter_rank(NrtArgs a, int n_til
 #pragma unroll
   for (int r = 0; r < RM; ++r)
     if (r < R && (a.slot_flags[r] & SPX_NRT_SLOT_HOST_LEVEL)) host_level |= 1u << r;
-  uint32_t fillp[RM];
+  uint32_t fill_bits = 0;  // host-level resources no zone of the node reports
   const uint32_t nn = static_cast<uint32_t>(a.n_nodes), n32 = static_cast<uint32_t>(n);
 #pragma unroll
   for (int r = 0; r < RM; ++r) {
     const uint32_t rep = (in && r < R) ? ld_off(a.f_rep, static_cast<uint32_t>(r) * nn + n32) : 0u;
-    fillp[r] = (((host_level >> r) & 1u) && rep == 0) ? kG : 0u;
+    fill_bits |= (((host_level >> r) & 1u) && rep == 0) ? 1u << r : 0u;
   }
   __syncthreads();
+  const bool narrow = lds[9] != 0u;  // block-uniform: every list of the chunk has at most 127 entries (nrt_build_rank_stream)
 
   // ---- the node's cells as counts: for each resource the eight zones' quantities, ranked against the chunk's list
-  uint32_t qa[RM][4];
+  uint32_t q4[RM][4];  // WIDE: four dwords; NARROW: the first two
   const double* lists = reinterpret_cast<const double*>(lds + 16);
   uint32_t list_doubles = 0;
 #pragma unroll
   for (int r = 0; r < RM; ++r) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) qa[r][j] = kG;  // (slots past the table: never requested)
+    for (int j = 0; j < 4; ++j) q4[r][j] = narrow ? RkLayout<true>::G : RkLayout<false>::G;  // (slots past the table: never requested)
     if (r >= R) continue;  // uniform
     const uint32_t hw = lds[r];
     const int steps = static_cast<int>(hw & 0xffu);
@@ -154,12 +280,15 @@ __global__ __launch_bounds__(256, 4) void k_nrt_filter_rank(NrtArgs a, int n_til
         cnt[z] = v <= av[z] ? cnt[z] + static_cast<uint32_t>(b) : cnt[z];
       }
     }
+    if (narrow) {
+      q4[r][0] = RkLayout<true>::G | cnt[0] | (cnt[1] << 8) | (cnt[2] << 16) | (cnt[3] << 24);
+      q4[r][1] = RkLayout<true>::G | cnt[4] | (cnt[5] << 8) | (cnt[6] << 16) | (cnt[7] << 24);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) qa[r][j] = kG | cnt[j] | (cnt[j + 4] << 16);
+      for (int j = 0; j < 4; ++j) q4[r][j] = RkLayout<false>::G | cnt[j] | (cnt[j + 4] << 16);
+    }
   }
   const uint32_t* const pods = lds + 16 + 2 * list_doubles;
-  constexpr int PWR = kRkPodHead + kRkVectors * RM;
-
   const bool fresh = flags & SPX_NRT_F_FRESH;
   const bool has_nrt = flags & SPX_NRT_F_HAS_NRT;
   const bool single = flags & SPX_NRT_F_SINGLE_NUMA;
@@ -167,85 +296,8 @@ __global__ __launch_bounds__(256, 4) void k_nrt_filter_rank(NrtArgs a, int n_til
   const bool aligned = fresh && has_nrt && single;
   const bool w_pod = __ballot(aligned && pod_scope) != 0, w_ctr = __ballot(aligned && !pod_scope) != 0;
   const uint32_t st_stale = fresh ? 0u : static_cast<uint32_t>(SPX_NRT_ST_INVALID_TOPOLOGY);
-  uint32_t acc_status = 0;
-
-  for (int p = 0; p < rows; ++p) {
-    const uint32_t* rec = pods + p * PWR;
-    // the head: lane l holds dword l & 15; the fields become scalars as they are needed
-    const uint32_t hv = rec[lane & 15];
-    auto head = [&](int i) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hv), i)); };
-    const uint32_t w0 = head(0);
-    const int qos = w0 & 0xffu;
-    const bool non_native = ((w0 >> 8) & 0xffu) != 0;
-    const int n_ctr = (w0 >> 16) & 0xffu;
-    const int last_app = static_cast<int>(w0 >> 24) == 0xff ? -1 : static_cast<int>(w0 >> 24);
-    const bool filtered = !(qos == SPX_QOS_BESTEFFORT && !non_native);  // filter.go:186-190
-    uint32_t status = filtered ? st_stale : 0u;
-    if (filtered) {  // uniform
-      if (w_pod && pod_scope && aligned) {  // singleNUMAPodLevelHandler
-        const uint32_t s = head(2);
-        const uint32_t fit = (s >> 8) & 0xffu, always = (s >> 16) & 0xffu;
-        uint32_t m[4];
-        rank_mask<RM>(qa, fillp, host_level, rec + kRkPodHead, fit, always, m);
-        const bool ok = ((fit | always) & ~node_present) == 0 && any_zone(m);
-        if (!ok) status = SPX_NRT_ST_POD;
-      }
-      if (w_ctr && !pod_scope && aligned) {  // singleNUMAContainerLevelHandler, containers in order (init containers first)
-        const uint32_t apps = head(11);
-        const int a0 = apps & 0xffu, a1 = (apps >> 8) & 0xffu;
-        uint32_t z0[4] = {0, 0, 0, 0}, z1[4] = {0, 0, 0, 0};  // the zones app containers a0 / a1 were charged to (packed one-zone sets)
-        for (int c = 0; c < n_ctr; ++c) {
-          const uint32_t s = head(3 + c);
-          const uint32_t fit = (s >> 8) & 0xffu, always = (s >> 16) & 0xffu, kind = s >> 24;
-          const uint32_t* own = rec + kRkPodHead + (1 + c) * RM;
-          uint32_t m[4];
-          rank_mask<RM>(qa, fillp, host_level, own, fit, always, m);
-          if (kind == SPX_CTR_APP && c != a0 && fit != 0) {  // uniform: an earlier app container may have been charged to a zone
-            if (c == a1) {
-              uint32_t ms[4];
-              rank_mask<RM>(qa, fillp, host_level, rec + kRkPodHead + 9 * RM, fit, always, ms);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) m[j] = (m[j] & ~z0[j]) | (ms[j] & z0[j]);
-            } else {  // the third app container: its own vector, + a0, + a1, + both
-              uint32_t m0[4], m1[4], mb[4];
-              rank_mask<RM>(qa, fillp, host_level, rec + kRkPodHead + 10 * RM, fit, always, m0);
-              rank_mask<RM>(qa, fillp, host_level, rec + kRkPodHead + 11 * RM, fit, always, m1);
-              rank_mask<RM>(qa, fillp, host_level, rec + kRkPodHead + 12 * RM, fit, always, mb);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const uint32_t both = z0[j] & z1[j];
-                uint32_t x = (m[j] & ~z1[j]) | (m1[j] & z1[j]);
-                x = (x & ~z0[j]) | (m0[j] & z0[j]);
-                m[j] = (x & ~both) | (mb[j] & both);
-              }
-            }
-          }
-          const bool ok = ((fit | always) & ~node_present) == 0 && any_zone(m);
-          const bool live = status == 0;
-          if (kind != SPX_CTR_APP) {
-            if (live && !ok) status = kind == SPX_CTR_SIDECAR ? SPX_NRT_ST_SIDECAR_CONTAINER : SPX_NRT_ST_INIT_CONTAINER;
-          } else {
-            if (live && !ok) status = SPX_NRT_ST_CONTAINER;
-            if (c != last_app && fit != 0) {  // uniform: the zone the container is charged to (the lowest that fits), for its successors
-              uint32_t z[4];
-              lowest_zone(m, z);
-              const bool apply = live && ok;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                if (c == a0) z0[j] = apply ? z[j] : 0u;
-                else z1[j] = apply ? z[j] : 0u;
-              }
-            }
-          }
-        }
-      }
-    }
-    acc_status |= status << (8 * (p & 3));
-    if ((p & 3) == 3 || p + 1 == rows) {  // uniform
-      if (in) stage[(p >> 2) * kWindow + pos] = acc_status;
-      acc_status = 0;
-    }
-  }
+  if (narrow) rank_walk<RM, true>(q4, fill_bits, host_level, pods, rows, lane, w_pod, w_ctr, aligned, pod_scope, node_present, st_stale, in, pos, stage);
+  else rank_walk<RM, false>(q4, fill_bits, host_level, pods, rows, lane, w_pod, w_ctr, aligned, pod_scope, node_present, st_stale, in, pos, stage);
   __syncthreads();
   // rows leave as whole 256-byte segments (as k_nrt_fast): lane l gathers byte (row & 3) of the four dwords of nodes 4l .. 4l+3
   const int64_t col = base + lane * 4;

@@ -55,7 +55,7 @@ struct spx_engine {
   int64_t row_stride = 0;
 
   // spx_set_option state (per engine; nothing is read from the environment)
-  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1, 0, 1, 1, 1};
+  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1, 0, 1, 1, 1, 1};
 
   // params
   int32_t alloc_mode = SPX_MODE_LEAST;
@@ -723,6 +723,7 @@ int spx_set_option(spx_engine* e, int option, int64_t value) {
     case SPX_OPT_TLP_AMB_TABLE:
     case SPX_OPT_NRT_PACKED_SCORE:
     case SPX_OPT_NET_ALLOC_FUSED:
+    case SPX_OPT_NRT_RANK_NARROW:
       if (value != 0 && value != 1) return fail(e, SPX_ERR_ARG, "option takes 0 or 1");
       break;
     case SPX_OPT_NRT_LN_LIST_PERMILLE:
@@ -1710,7 +1711,7 @@ void nrt_build_classes(const uint32_t* items, const uint64_t* hash, size_t p, si
 // batch keeps the float64 Filter.  Chunk block: 16 header dwords (per slot: search steps | list offset << 8; [8] rows),
 // the lists (2^steps - 1 doubles each, padded with +inf), then per pod kRkPodHead + 13 x RM dwords.
 void nrt_build_rank_stream(const uint32_t* items, const int32_t* list, size_t n_list, size_t R, std::vector<uint32_t>& words, std::vector<uint32_t>& off,
-                           uint32_t* max_dwords_out, bool* ok_out) {
+                           uint32_t* max_dwords_out, bool* ok_out, bool narrow_ok = true) {
   const size_t RM = R <= 4 ? 4 : 8, IW = R <= 4 ? 16 : 32, PW = 10 * IW, PWR = spx::kRkPodHead + spx::kRkVectors * RM;
   const size_t n_chunks = (n_list + spx::kRkChunkRows - 1) / spx::kRkChunkRows;
   std::vector<std::vector<uint32_t>> blocks(n_chunks);
@@ -1774,6 +1775,11 @@ void nrt_build_rank_stream(const uint32_t* items, const int32_t* list, size_t n_
       b.assign(16 + 2 * list_doubles + rows * PWR, 0u);
       for (size_t r = 0; r < R; ++r) b[r] = steps[r] | (loff[r] << 8);
       b[8] = static_cast<uint32_t>(rows);
+      // every list of the chunk (leading 0 included) has at most 127 entries: positions and counts fit 7 bits, the kernel packs four zones
+      // per dword (RkLayout<true>, kernels_nrt_rank.hip) and the thresholds below are replicated into four bytes instead of two halves
+      bool narrow = narrow_ok;
+      for (size_t r = 0; r < R; ++r) narrow = narrow && vals[r].size() <= 127;
+      b[9] = narrow ? 1u : 0u;
       for (size_t r = 0; r < R; ++r) {
         double* dst = reinterpret_cast<double*>(&b[16]) + loff[r];
         const size_t n = size_t{1} << steps[r];
@@ -1787,7 +1793,7 @@ void nrt_build_rank_stream(const uint32_t* items, const int32_t* list, size_t n_
             const double q = vec[(i * spx::kRkVectors + vi) * RM + r];
             if (q != q) continue;
             const uint32_t t = static_cast<uint32_t>(std::lower_bound(vals[r].begin(), vals[r].end(), q) - vals[r].begin()) + 1u;
-            dst[spx::kRkPodHead + vi * RM + r] = t | (t << 16);
+            dst[spx::kRkPodHead + vi * RM + r] = narrow ? t * 0x01010101u : (t | (t << 16));
           }
       }
     }
@@ -1906,7 +1912,7 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
         std::vector<uint32_t> rk, rk_off;
         uint32_t rk_max = 0;
         bool rk_ok = false;
-        nrt_build_rank_stream(items, uniq.data(), uniq.size(), R, rk, rk_off, &rk_max, &rk_ok);
+        nrt_build_rank_stream(items, uniq.data(), uniq.size(), R, rk, rk_off, &rk_max, &rk_ok, e->option[SPX_OPT_NRT_RANK_NARROW] != 0);
         e->nrt_rk_max_dwords = 0;
         if (rk_ok && rk_max * sizeof(uint32_t) <= spx::kRkMaxChunkBytes) {
           if ((rc = upload(e, e->d_nrt_rk, rk.data(), rk.size() * sizeof(uint32_t)))) return rc;

@@ -307,17 +307,21 @@ def test_pod_classes_of_the_synthetic_queue(gpu_required, hdr):
         assert uniq + dups == 4000 and dups > 1200
 
 # ------------------------------------------------------------------ the Filter launch in rank space (SPX_OPT_NRT_RANK_FILTER)
+@pytest.mark.parametrize("narrow", [1, 0], ids=["narrow-chunks", "wide-only"])
 @pytest.mark.parametrize("wide", [False, True], ids=["4slots", "6slots"])
-def test_rank_filter_equals_float64_filter(gpu_required, hdr, oracle, wide):
+def test_rank_filter_equals_float64_filter(gpu_required, hdr, oracle, wide, narrow):
     """A whole-batch sweep over pod classes runs its Filter launch in rank space (kernels_nrt_rank.hip: requests and zone quantities
     as positions in the chunk's sorted request list, charged zones through request sums instead of table mutation); with the
-    option off the float64 launch runs.  Same status table, cell for cell, and the oracle's on sampled rows.  The batch holds pods
+    option off the float64 launch runs.  Same status table, cell for cell, and the oracle's on sampled rows.  `narrow` (round 5,
+    SPX_OPT_NRT_RANK_NARROW, read at upload): chunks whose lists stay below 128 entries keep four zones' counts per register — the
+    batch has chunks of both kinds; with the option off every chunk takes the two-per-register layout.  The batch holds pods
     with one to three app containers (the second and third are tested against zones their predecessors were charged to), init
     containers and sidecars, both node scopes, stale and NRT-less nodes, unreported and host-level resources."""
     n_nodes, n_pods = 1500, 2500
     snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=31, wide=wide)
     params = O.nrt_params(hdr, O.Resources(), "MostAllocated")
     with Engine(0) as e:
+        e.set_option("NRT_RANK_NARROW", narrow)
         e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
         e.eval(mask_of(NRT))
         e.sync()
