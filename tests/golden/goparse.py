@@ -110,10 +110,15 @@ class Parser:
                 self.skip_balanced("{", "}")
                 return
             elif self.kind() == "id":
-                self.take()
+                if self.take() == "interface" and self.peek() == "{" and self.peek(1) == "}":  # interface{} as an element type
+                    self.take()
+                    self.take()
+                    return
                 while self.peek() == ".":
                     self.take()
                     self.take()
+                if self.peek() == "[":  # a generic instantiation, e.g. map[string]sets.Set[string]{...}
+                    self.skip_balanced("[", "]")
                 return
             else:
                 return

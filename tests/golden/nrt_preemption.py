@@ -1,6 +1,6 @@
 """Known answers of the reference's NRT eviction-simulation test, as data.
 
-pkg/noderesourcetopology/preemption/preemption_test.go: TestGetNRTPostPodsEviction (:32-378, 8 cases), fixtures getTestNRT
+pkg/noderesourcetopology/preemption/preemption_test.go: TestGetNRTPostPodsEviction (:32-378, 7 cases), fixtures getTestNRT
 (:382-432) and getTestEncodedInfo10Containers (:436-484: container -> NUMA node affinities)."""
 
 def _zone(name, extra, avail_cpu="1", avail_mem="100Mi", avail_dev="1"):

@@ -701,6 +701,306 @@ def check_lroc_resource_tables() -> int:
     return checked
 
 
+def _nrt_zones(lit):
+    """Zones of a NodeResourceTopology literal -> the hand-typed form: [{name, type, resources: [(name, capacity, allocatable, available)]}]"""
+    def q(v):
+        assert isinstance(v, Call) and v.fn == "resource.MustParse", v
+        return v.args[0]
+    return [{"name": z["Name"], "type": z.get("Type", "Node"),
+             "resources": [(r["Name"], q(r["Capacity"]), q(r["Allocatable"]), q(r["Available"])) for r in z["Resources"]]} for z in lit["Zones"]]
+
+
+def check_nrt_preemption() -> int:
+    """nrt_preemption.py against preemption_test.go: the two fixtures (getTestNRT, getTestEncodedInfo10Containers' affinity list) and every
+    case of TestGetNRTPostPodsEviction — victims (namespace, name, QOS class, containers' requests and limits), which placement record the case
+    passes, the expected error text, the expected zone table (getTestNRT() again wherever the case expects an error) and the case's line."""
+    import nrt_preemption as N
+    src = (REF / "pkg/noderesourcetopology/preemption/preemption_test.go").read_text()
+    checked = 0
+    fix = parse_literal_after(src[src.index("func getTestNRT"):], "return ")
+    zones = _nrt_zones(fix)
+    for z in zones:
+        z["type"] = "Node"  # (the fixture leaves Type empty; the hand-typed table fills the CRD's value for the flattener — nothing reads it on this path)
+    assert zones == N.TEST_NRT["zones"], zones
+    checked += 1
+    aff = parse_literal_after(src[src.index("func getTestEncodedInfo10Containers"):], "affinities := ")
+    got = {(a["ID"]["Namespace"], a["ID"]["PodName"], a["ID"]["ContainerName"]): a["NUMANode"] for a in aff}
+    assert got == N.PLACEMENT and len(aff) == len(got) == 10, got
+    checked += 1
+    qos = {"corev1.PodQOSGuaranteed": N.G, "corev1.PodQOSBurstable": N.BU, "corev1.PodQOSBestEffort": N.BE}
+    p0 = src.index("func TestGetNRTPostPodsEviction")
+    tests = parse_literal_after(src[p0:], "testcases := ")
+    assert len(tests) == len(N.CASES), (len(tests), len(N.CASES))
+
+    def rl(m):
+        return {k: v.args[0] for k, v in (m or {}).items()}
+
+    def pod_qos(v, ctrs):
+        if "Status" in v:
+            return qos[v["Status"]["QOSClass"].name]
+        # no Status.QOSClass: v1qos.GetPodQOS (preemption.go:71) computes the class — a pod without requests or limits is BestEffort
+        assert not any(k["requests"] or k["limits"] for k in ctrs), v
+        return N.BE
+
+    for t, c in zip(tests, N.CASES):
+        assert t["name"].split(",")[0] == c["name"] or t["name"].startswith(c["name"]), (t["name"], c["name"])
+        assert c["line"] == line_of(src, '"' + t["name"] + '"', p0), (t["name"], c["line"], line_of(src, '"' + t["name"] + '"', p0))
+        victims = []
+        for v in t["victims"]:
+            ctrs = [N.ctr(k["Name"], rl(k.get("Resources", {}).get("Requests")), rl(k.get("Resources", {}).get("Limits"))) for k in v.get("Spec", {}).get("Containers", [])]
+            victims.append(dict(ns=v["ObjectMeta"].get("Namespace", ""), name=v["ObjectMeta"]["Name"], qos=pod_qos(v, ctrs), containers=ctrs))
+        assert victims == c["victims"], (t["name"], victims, c["victims"])
+        info = t.get("numaPlacementInfo")
+        if info is None:
+            assert c["placement"] is None, t["name"]
+        elif isinstance(info, Call) and info.fn == "getTestEncodedInfo10Containers":
+            assert c["placement"] is N.PLACEMENT, t["name"]
+        else:  # numaplacement.NewEncodedInfo(): a record with no containers
+            assert isinstance(info, Call) and info.fn == "numaplacement.NewEncodedInfo" and not info.args and c["placement"] == {}, (t["name"], info)
+        assert t.get("expectedError", "") == c["error"], (t["name"], t.get("expectedError"))
+        assert c["error"] in N.ERROR_CODES, c["error"]
+        want = t["expectedUpdatedNRT"]
+        if isinstance(want, Call):
+            assert want.fn == "getTestNRT" and "expected" not in c and c["error"], t["name"]
+        else:
+            wz = _nrt_zones(want)
+            for z in wz:
+                z["type"] = "Node"
+            assert not c["error"] and wz == c["expected"]["zones"], (t["name"], wz)
+        assert isinstance(t["nrt"], Call) and t["nrt"].fn == "getTestNRT", t["name"]
+        checked += 1
+    # the messages ERROR_CODES numbers are the ones preemption.go raises (the seventh, "NRT not found", has no case in the table)
+    go = (REF / "pkg/noderesourcetopology/preemption/preemption.go").read_text()
+    for msg in N.ERROR_CODES:
+        assert not msg or '"' + msg + '"' in go, msg
+    checked += 1
+    return checked
+
+
+def check_nrt_preemption_flow() -> int:
+    """nrt_preemption_flow.py against filter_preemption_test.go: makePreemptionNRT's zones and policy, makeGuaranteedPod's shape, the victim /
+    preemptor / placement constants of TestFilter_PreemptionFlow, and per sub-test (read as statements: they are straight-line code) the
+    preemption mode, whether the cache holds a placement record, the victims on the cycle state, the preemptor pod, the expected status and
+    the expected over-reserve marking."""
+    import re
+    import nrt_preemption_flow as F
+    src = (REF / "pkg/noderesourcetopology/filter_preemption_test.go").read_text()
+    checked = 0
+    nrt = parse_literal_after(src[src.index("func makePreemptionNRT"):], "return ")
+    names = {"cpu": "cpu", "memory": "memory"}  # the package's test constants (filter_test.go: cpu = string(corev1.ResourceCPU), ...)
+    zones = []
+    for z in nrt["Zones"]:
+        res = []
+        for r in z["Resources"]:
+            assert isinstance(r, Call) and r.fn == "makeTopologyResInfoWithAllocatable", r
+            nm, cap, av = r.args
+            res.append((names[nm.name], cap, cap, av))  # (:81-88: Capacity = Allocatable = the second argument)
+        zones.append({"name": z["Name"], "type": z["Type"], "resources": res})
+    assert zones == F.NRT["zones"], zones
+    pol = nrt["TopologyPolicies"]
+    assert len(pol) == 1 and pol[0].args[0].name == "topologyv1alpha2." + F.NRT["policies"][0], pol
+    checked += 1
+    # makeNodeFromNRT: capacity = allocatable = the zones' capacities summed (makeResourceListFromZones)
+    gi = lambda s_: int(s_[:-2]) if s_.endswith("Gi") else int(s_)
+    assert F.NODE == {"cpu": str(sum(gi(z["resources"][0][1]) for z in zones)), "memory": "%dGi" % sum(gi(z["resources"][1][1]) for z in zones)}
+    checked += 1
+    p0 = src.index("func TestFilter_PreemptionFlow")
+    p1 = src.index("\nfunc ", p0 + 10)
+    body = src[p0:p1]
+    cname = F.VICTIM["containers"][0]["name"]
+
+    def pod(call):
+        m = re.fullmatch(r'makeGuaranteedPod\("([^"]*)", "([^"]*)", containerName, (\d+), "([^"]*)"\)', call.strip())
+        assert m, call
+        r = {"cpu": m.group(3), "memory": m.group(4)}
+        return dict(ns=m.group(1), name=m.group(2), containers=[dict(name=cname, requests=r, limits=r)])
+
+    head = body[:body.index("t.Run(")]
+    top = {m.group(1): pod(m.group(2)) for m in re.finditer(r"(\w+) := (makeGuaranteedPod\([^\n]*\))", head)}
+    assert top["victim"] == F.VICTIM and top["preemptor"] == F.guaranteed("default", "preemptor", 4, "1Gi"), top
+    assert "numaPlacement := makeEncodedInfoForPod(victim, 0)" in head
+    assert F.PLACEMENT == {(F.VICTIM["ns"], F.VICTIM["name"], cname): 0}
+    checked += 1
+    subs = list(re.finditer(r't\.Run\("([^"]*)", func\(t \*testing\.T\) \{\n(.*?)\n\t\}\)', body, re.S))
+    assert len(subs) == len(F.CASES), (len(subs), len(F.CASES))
+    for m, c in zip(subs, F.CASES):
+        name, text = m.group(1), m.group(2)
+        # the hand-typed names abbreviate; every word of the abbreviation must come from the sub-test's name, and the line ties them
+        assert c["line"] == src.count("\n", 0, p0 + m.start()) + 1, (name, c["line"])
+        assert all(w.strip("(),:") in name for w in c["name"].replace(":", " ").split()), (name, c["name"])
+        local = {k: pod(v) for k, v in re.findall(r"(\w+) := (makeGuaranteedPod\([^\n]*\))", text)}
+        pods = {**top, **local}
+        cache = re.search(r"cache := &fakeFilterCache\{([^}]*)\}", text).group(1)
+        assert ("numaPlacement: numaPlacement" in cache) == (c["placement"] is not None), name
+        mode = re.search(r"preemptionMode: apiconfig\.(\w+)\}", text).group(1)
+        assert {"PreemptionEnabled": True, "PreemptionDisabled": False}[mode] == c["enabled"], name
+        cs = re.search(r"cycleState := cycleStateWithVictims\(t, ([^)]*)\)", text)
+        victims = [pods[v.strip()] for v in cs.group(1).split(",")] if cs else []
+        assert victims == c["victims"], (name, victims)
+        f = re.search(r"tm\.Filter\(context\.Background\(\), ([^,]*), (\w+), nodeInfo\)", text)
+        assert (f.group(1) == "cycleState") == bool(cs) and pods[f.group(2)] == c["preemptor"], name
+        st = re.search(r'quasiEqualStatus\(status, (nil|fwk\.NewStatus\(fwk\.Unschedulable, "([^"]*)"\))\)', text)
+        assert (None if st.group(1) == "nil" else st.group(2)) == c["want"], (name, st.group(0))
+        if "len(cache.maybeOverReserved) != 1" in text:
+            assert c["over_reserved"] is True, name
+        elif "len(cache.maybeOverReserved) != 0" in text:
+            assert c["over_reserved"] is False, name
+        else:
+            assert c["over_reserved"] is None, name
+        checked += 1
+    return checked
+
+
+def _watcher_metrics(src: str):
+    """the `metrics := watcher.WatcherMetrics{...}` literal of an integration test -> (Window.End or 0, {node index: [(type, operator, value)]}) with nodes
+    numbered by their name's suffix (node-1 -> 0), the hand-typed form"""
+    m = parse_literal_after(src, "metrics := ")
+    typ = {"watcher.CPU": "CPU", "watcher.Memory": "Memory"}
+    op = {"watcher.Average": "AVG", "watcher.Std": "STD", "watcher.Latest": "Latest"}
+    out = {}
+    for name, nm in m["Data"]["NodeMetricsMap"].items():
+        out[int(name.split("-")[1]) - 1] = [(typ[x["Type"].name], op[x["Operator"].name], float(x["Value"])) for x in nm["Metrics"]]
+    return (m.get("Window") or {}).get("End", 0), out
+
+
+def check_integration() -> int:
+    """integration.py against test/integration/{targetloadpacking,loadVariationRiskBalancing,allocatable,lowriskovercommitment,peaks}_test.go.  The Go tests
+    are straight-line code around one literal each: the literal (watcher metrics, the Allocatable case table, the power-model map) is read with goparse,
+    the scalars around it (node names, NewQuantity / NewMilliQuantity arguments, the per-pod cpu lists, the expected placements) with regular expressions."""
+    import re
+    import integration as I
+    checked = 0
+    RL = {"v1.ResourcePods": "pods", "v1.ResourceCPU": "cpu", "v1.ResourceMemory": "memory", "corev1.ResourceCPU": "cpu", "corev1.ResourceMemory": "memory"}
+
+    def strs(src, var):
+        return re.search(var + r" := \[\]string\{([^}]*)\}", src).group(1).replace('"', "").replace(" ", "").split(",")
+
+    def ints(src, var):
+        return [int(x) for x in re.search(var + r" := \[\]int64\{([^}]*)\}", src).group(1).replace(" ", "").split(",")]
+
+    def qty_lists(block):
+        """resource lists written as `v1.ResourceX: *resource.NewQuantity(n, ...)` lines: one dict per `ResourceList{` in the block"""
+        out = []
+        for body in re.findall(r"ResourceList\{\n(.*?)\n\t*\}", block, re.S):
+            out.append({RL[k]: v for k, v in re.findall(r"(\w+\.Resource\w+):\s+\*resource\.NewQuantity\((\d+), resource\.DecimalSI\)", body)})
+        return out
+
+    def expected_of(src, names):
+        e = re.search(r"expected := \[2\]string\{([^}]*)\}", src).group(1).replace(" ", "").split(",")
+        return [x.strip('"') if x.startswith('"') else names[int(re.fullmatch(r"nodeNames\[(\d)\]", x).group(1))] for x in e]
+
+    def line(src, fn):
+        return line_of(src, "func " + fn)
+
+    # --- TargetLoadPacking
+    src = (REF / "test/integration/targetloadpacking_test.go").read_text()
+    c = I.TLP
+    end, met = _watcher_metrics(src)
+    names = strs(src, "nodeNames")
+    assert (end, met) == (c["window_end"], c["metrics"]) and names == [n["name"] for n in c["nodes"]], (end, met)
+    alloc, cap = qty_lists(src[src.index("node.Status.Allocatable"):src.index("var newPods")])
+    assert all(n["allocatable"] == alloc and n["capacity"] == cap for n in c["nodes"]), (alloc, cap)
+    mem = re.search(r"v1\.ResourceMemory: \*resource\.NewQuantity\((\d+), resource\.DecimalSI\),\n\t\t\t\},\n\t\t\}\n\t\tnewPods", src).group(1)
+    assert c["pods"] == [{"cpu": f"{m_}m", "memory": mem} for m_ in ints(src, "containerCPU")] and len(c["pods"]) == len(strs(src, "podNames"))
+    assert expected_of(src, names) == c["expected"] and abs(line(src, "TestTargetNodePackingPlugin") - c["line"]) <= 10
+    assert "TargetUtilization:         cfgv1.DefaultTargetUtilizationPercent" in src and "DefaultRequestsMultiplier: cfgv1.DefaultRequestsMultiplier" in src
+    checked += 1
+
+    # --- LoadVariationRiskBalancing
+    src = (REF / "test/integration/loadVariationRiskBalancing_test.go").read_text()
+    c = I.LVRB
+    end, met = _watcher_metrics(src)
+    names = strs(src, "nodeNames")
+    assert (end, met) == (c["window_end"], c["metrics"]) and names == [n["name"] for n in c["nodes"]], (end, met)
+    capacity = {RL[k]: v for k, v in re.findall(r"(v1\.Resource\w+):\s+\"(\w+)\",", src[src.index("capacity := map"):src.index("for i := 0; i < len(nodeNames)")])}
+    assert all(n["capacity"] == capacity and n["allocatable"] == capacity for n in c["nodes"]), capacity  # (NodeWrapper.Capacity sets both lists)
+    mem = re.search(r"v1\.ResourceMemory: \*resource\.NewQuantity\((\d+), resource\.DecimalSI\),\n\t\t\t\},\n\t\t\}\n\t\tnewPods", src).group(1)
+    assert c["pods"] == [{"cpu": f"{m_}m", "memory": mem} for m_ in ints(src, "containerCPU")]
+    assert expected_of(src, names) == c["expected"] and abs(line(src, "TestLoadVariationRiskBalancingPlugin") - c["line"]) <= 10
+    checked += 1
+
+    # --- NodeResourcesAllocatable
+    src = (REF / "test/integration/allocatable_test.go").read_text()
+    c = I.ALLOCATABLE
+
+    def rmap(var):
+        body = src[src.index(var + " := map"):]
+        return {RL[k]: v for k, v in re.findall(r"(v1\.Resource\w+):\s+\"(\w+)\",", body[:body.index("}")])}
+
+    maps = {k: rmap(k) for k in ("smallNodeCapacity", "bigNodeCapacity", "smallPodReq", "bigPodReq")}
+    tests = parse_literal_after(src, "testCases := ")
+    assert len(tests) == 2
+
+    def chain(v):  # st.MakeX().Name(n)...Req(m) / .Capacity(m): (name, the map variable's name)
+        name = arg = None
+        while isinstance(v, Call):
+            if v.fn == ".Name":
+                name = v.args[1]
+            if v.fn in (".Req", ".Capacity"):
+                arg = v.args[1].name
+            v = v.args[0] if v.args and v.fn.startswith(".") else None
+        return name, arg
+
+    for t in tests:
+        mode = {"schedconfig.Least": "Least", "schedconfig.Most": "Most"}[t["modeType"].name]
+        assert [(n, maps[a]) for n, a in map(chain, t["pods"])] == c["pods"], t["name"]
+        nodes = [(n, maps[a]) for n, a in map(chain, t["nodes"])]
+        assert nodes == [(n["name"], n["capacity"]) for n in c["nodes"]] and all(n["capacity"] == n["allocatable"] for n in c["nodes"]), nodes
+        want = {k: set(v.args) for k, v in t["expectedNodes"].items()}
+        assert all(isinstance(v, Call) and v.fn == "sets.New" for v in t["expectedNodes"].values()) and want == c["expected"][mode], (mode, want)
+        checked += 1
+    w = re.search(r"\{Name: string\(v1\.ResourceMemory\), Weight: (\d+)\}", src)
+    assert c["weights"] == {"memory": int(w.group(1))} and src.count("Weight:") == 2  # (the other one is the plugin's own weight in the profile)
+    assert abs(line(src, "TestAllocatablePlugin") - c["line"]) <= 10
+
+    # --- LowRiskOverCommitment
+    src = (REF / "test/integration/lowriskovercommitment_test.go").read_text()
+    c = I.LROC
+    end, met = _watcher_metrics(src)
+    names = strs(src, "nodeNames")
+    assert met == c["metrics"] and names == [n["name"] for n in c["nodes"]], met
+    cpu, memc = strs(src, "capCPU"), strs(src, "capMemory")
+    assert [n["capacity"] for n in c["nodes"]] == [{"cpu": a, "memory": b} for a, b in zip(cpu, memc)] and all(n["capacity"] == n["allocatable"] for n in c["nodes"])
+    req, lim = ints(src, "requestCPU"), ints(src, "limitCPU")
+    rm, lm = re.search(r"var requestMemory int64 = (\d+)", src).group(1), re.search(r"var limitMemory int64 = (\d+)", src).group(1)
+    pods = [({"cpu": f"{a}m", "memory": rm}, {"cpu": f"{b}m", "memory": lm}) for a, b in zip(req, lim)]
+    sched = strs(src, "scheduledNodes")
+    assert "Node(nodeNames[i])" in src and sched == names  # existing pod i sits on node i
+    assert c["on_node"] == {i: [pods[i]] for i in range(len(sched))} and c["pod"] == pods[len(sched)] and len(pods) == len(sched) + 1, pods
+    assert strs(src, "expectedNodes") == [c["expected"]]
+    wts = parse_literal_after(src, "RiskLimitWeights: ")
+    assert (float(wts["cpu"]), float(wts["memory"])) == (c["params"]["w_cpu"], c["params"]["w_mem"]) and "SmoothingWindowSize: v1.DefaultSmoothingWindowSize" in src
+    d = (REF / "apis/config/v1/defaults.go").read_text()
+    assert int(re.search(r"DefaultSmoothingWindowSize\s*(?:int64)?\s*=\s*(\d+)", d).group(1)) == c["params"]["smoothing_window_size"]
+    assert abs(line(src, "TestLowRiskOverCommitmentPlugin") - c["line"]) <= 10
+    checked += 1
+
+    # --- Peaks
+    src = (REF / "test/integration/peaks_test.go").read_text()
+    c = I.PEAKS
+    data = parse_literal_after(src, "data := ")
+    names = strs(src, "nodeNames")
+    def fl(v):  # goparse reads -x as a negation call or a negative number depending on context
+        if isinstance(v, Call) and v.fn in ("op-", "neg"):
+            return -float(v.args[-1])
+        return float(v)
+    models = [{k: fl(v) for k, v in data[n].items()} for n in names]
+    assert models == c["models"], models
+    end, met = _watcher_metrics(src)
+    assert (end, met) == (0, c["metrics"]) and names == [n["name"] for n in c["nodes"]]
+    alloc, cap = qty_lists(src[src.index("node.Status.Allocatable"):src.index("var newPods")])
+    assert all(n["allocatable"] == alloc and n["capacity"] == cap for n in c["nodes"]), (alloc, cap)
+    mem = re.search(r"v1\.ResourceMemory: \*resource\.NewQuantity\((\d+), resource\.DecimalSI\),\n\t\t\t\},\n\t\t\}\n\t\tnewPods", src).group(1)
+    assert c["pods"] == [{"cpu": f"{m_}m", "memory": mem} for m_ in ints(src, "containerCPU")]
+    assert expected_of(src, names) == c["expected"] and abs(line(src, "TestPeaksPlugin") - c["line"]) <= 10
+    # `feasible` is this repository's statement of upstream's NodeResourcesFit (not in the Go file): pod-2's 1900m next to pod-1's 300m exceed node-1's 2 cpus
+    cpu_m = [int(p_["cpu"].rstrip("m")) for p_ in c["pods"]]
+    first = names.index(c["expected"][0])
+    assert c["feasible"] == [[1] * len(names), [int(not (i == first and cpu_m[0] + cpu_m[1] > 1000 * int(cap["cpu"]))) for i in range(len(names))]]
+    checked += 1
+    return checked
+
+
 if __name__ == "__main__":
     print("allocatable.py:", check_allocatable(), "cases agree with allocatable_test.go")
     print("trimaran.py:", check_trimaran(), "rows of COMPUTE_SCORE / MU_SIGMA agree with analysis_test.go / resourcestats_test.go")
@@ -715,3 +1015,6 @@ if __name__ == "__main__":
     print("lroc.py:", check_lroc_resource_tables(), "rows (GetResourceLimits, GetNodeRequestsAndLimits, the Score case) agree with resourcestats_test.go / lowriskovercommitment_test.go")
     print("trimaran.py:", check_trimaran_stats(), "items of STATS_METRICS / STATS_EXPECT agree with resourcestats_test.go (TestCreateResourceStats)")
     print("nrt_helpers.py:", check_nrt_helpers_zones_and_over_reserve(), "items (ONLY_NON_NUMA_ZONES, the two OVER_RESERVE flows) agree with pluginhelpers_test.go / cache/*_test.go")
+    print("nrt_preemption.py:", check_nrt_preemption(), "items (two fixtures, every TestGetNRTPostPodsEviction case, the error texts) agree with preemption_test.go / preemption.go")
+    print("nrt_preemption_flow.py:", check_nrt_preemption_flow(), "items (NRT, node, pods, the seven sub-tests) agree with filter_preemption_test.go")
+    print("integration.py:", check_integration(), "items (TLP, LVRB, Allocatable Least / Most, LROC, Peaks) agree with test/integration/*_test.go")

@@ -42,3 +42,15 @@ def test_round5_tables_agree_with_the_go_sources():
     assert verify_hand_typed.check_trimaran_stats() == 10
     assert verify_hand_typed.check_lroc_resource_tables() == 9
     assert verify_hand_typed.check_nrt_helpers_zones_and_over_reserve() == 4
+
+
+@pytest.mark.skipif(not REF.exists(), reason="/root/reference is not mounted here")
+def test_preemption_and_integration_tables_agree_with_the_go_sources():
+    """the last three hand-typed files: nrt_preemption.py (TestGetNRTPostPodsEviction: fixtures, every case's victims / placement / error / expected zones),
+    nrt_preemption_flow.py (TestFilter_PreemptionFlow: the seven straight-line sub-tests read as statements) and integration.py (the five integration tests'
+    metrics literals, node and pod quantities, expected placements)"""
+    sys.path.insert(0, str(Path(__file__).parent / "golden"))
+    import verify_hand_typed
+    assert verify_hand_typed.check_nrt_preemption() == 10
+    assert verify_hand_typed.check_nrt_preemption_flow() == 10
+    assert verify_hand_typed.check_integration() == 6
