@@ -579,7 +579,6 @@ __global__ __launch_bounds__(256, (PK && RM == 4 ? 5 : nrt_waves<RM, SG, PH>()))
       }
 #pragma unroll
       for (int r = 0; r < RM; ++r) w[pk_nv_dword<RM>(r)] = __float_as_uint(nv[r]);
-      w[2 * RM] = used | (w[2 * RM + 1] << 8);  // one scalar read per item in the loop: slots | weight sum (at most kNrtPkMaxWeightSum)
       if (ts < 0 || !((used >> ts) & 1u)) continue;
       const double k = __hiloint2double(static_cast<int>(w[2 * ts + 1]), static_cast<int>(w[2 * ts])) * a.pk_tab_inv_unit;
       // (the engine derived unit and kmax from this very batch: k is a whole number within the table; anything else is recomputed too)

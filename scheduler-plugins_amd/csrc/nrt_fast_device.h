@@ -228,8 +228,7 @@ __device__ __forceinline__ uint32_t least_packed_one(float v, float b32, float c
 // The request item as the packed loop reads it.  The block that staged the chunk's records rewrote every item IN PLACE
 // (k_nrt_fast): nv[r] = -float32(Value(request r)) into the dwords the float64 Score keeps Value(cpu) and the float64 weight sum in
 // (<= 4 slots: dwords 2RM+2 .. 2RM+5) or into the unused tail (8 slots: dwords 24 .. 31) — the raw float64 requests (dwords 0 .. 2RM-1)
-// stay for the second pass — and packed the requested slots with the integer weight sum (slots | sum << 8) into dword 2RM.  The loop fetches dwords
-// 2RM .. : that head, nv[], the biased reciprocal.
+// stay for the second pass.  The loop fetches dwords 2RM .. : slot sets, integer weight sum, nv[], the biased reciprocal.
 template <int RM>
 struct PkRegs {
   uint32_t w[RM == 4 ? 8 : 16];
@@ -256,8 +255,8 @@ __device__ __forceinline__ int score_least_packed(const FastNode<RM>& ns, const 
   typedef float F32x2 __attribute__((ext_vector_type(2)));
   typedef unsigned short U16x2 __attribute__((ext_vector_type(2)));
   static_assert(kZ == 8, "four zone pairs");
-  const uint32_t head = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g.w[0])));  // requested slots | sum of their weights << 8 (the staging rewrite)
-  const uint32_t used = head & 0xffu, wsum = head >> 8;
+  const uint32_t used = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g.w[0]))) & 0xffu;
+  const uint32_t wsum = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g.w[1])));
   if (wsum == 0) return 0;  // no weighted slot requested: wave-uniform
   const double wrc = __hiloint2double(static_cast<int>(g.w[7]), static_cast<int>(g.w[6]));
   const unsigned short a0 = static_cast<unsigned short>(0u - wsum);
