@@ -751,6 +751,13 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *   SPX_OPT_NRT_RANK_NARROW    1 (default) = chunks of the rank-space Filter's stream (SPX_OPT_NRT_RANK_FILTER) whose lists all have at most 127
  *                              distinct quantities keep four zones' counts per register instead of two (half the subtract / and instructions
  *                              per comparison); 0 = two per register everywhere.  Read when pod rows are uploaded.  Same tables either way
+ *   SPX_OPT_PEAKS_ESTIMATE     1 (default) = both passes of Peaks (row min / max, then NormalizeScore) first bound every cell's raw score by a
+ *                              float32 interval proven to contain the float64 value (13 float32 instructions + one v_exp_f32) and run the
+ *                              float64 sequence (division, exp) only for the cells the interval cannot decide — the candidates for a row's
+ *                              extremes, the cells next to a step of floor(100 (raw - min) / span), nodes outside the interval's
+ *                              preconditions — listed by the sweep and evaluated by a second launch with every lane busy; rows in which
+ *                              the interval decides little (a pod that requests no cpu) take the float64 sequence for the whole tile;
+ *                              8 = the same with 8 instead of 16 nodes per lane; 0 = the float64 sequence for every cell.  Same tables either way
  */
 #define SPX_OPT_ROW_ALIGN 0
 #define SPX_OPT_REFERENCE_KERNELS 1
@@ -769,7 +776,8 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
 #define SPX_OPT_NRT_PACKED_SCORE 14
 #define SPX_OPT_NET_ALLOC_FUSED 15
 #define SPX_OPT_NRT_RANK_NARROW 16
-#define SPX_NUM_OPTIONS 17
+#define SPX_OPT_PEAKS_ESTIMATE 17
+#define SPX_NUM_OPTIONS 18
 int spx_set_option(spx_engine* e, int option, int64_t value);
 int spx_get_option(const spx_engine* e, int option, int64_t* value);
 

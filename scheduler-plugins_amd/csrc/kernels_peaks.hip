@@ -194,6 +194,542 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks(PeaksArgs a, in
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Interval estimates (round 5, SPX_OPT_PEAKS_ESTIMATE, default on).
+//
+// Both passes above spend ~45 float64 instructions per cell on raw_score (a division, OCML's exp).  Neither needs the value of most
+// cells: the min/max pass needs the row's two extremes, the write pass needs floor(100 * (raw - min) / span), which a value known to
+// a few parts in 10^5 decides for all but the cells next to a step.  So both passes first compute, per cell, a float32 INTERVAL
+// [lo, hi] that is guaranteed to contain the float64 raw score the reference sequence yields — 13 full-rate float32 instructions and
+// one v_exp_f32 — and evaluate raw_score itself (the code above, node constants re-read from the tables) only where the interval
+// cannot decide:
+//   min/max pass   the cells with hi >= (largest lo of the wave's nodes) or lo <= (smallest hi): the wave's extremes are among them;
+//   write pass     the cells whose interval of 100 * (raw - min) / span straddles an integer.
+// Everything that reaches a table or the row statistic is therefore either the float64 sequence's own value or a value the interval
+// proves equal to it: the tables are byte-identical to k_peaks' (tests/test_gpu_peaks.py::test_estimate_*: every cell, both ways).
+//
+// The interval.  e^(K2 predicted) - e^(K2 util) = e_now (e^(K2 (predicted - util)) - 1) and predicted - util = 100 pod / cap, so with
+// C0 = 100 util_m / cap, C1 = 100 / cap, QL = K2 C1 log2(e), KE = 1e15 K1 e_now (float64, rounded once to float32) and u = 2^-24:
+//   y = ql * pod                          relative error 3u (ql, pod, the product)
+//   e = v_exp_f32(y)                      |e - 2^Y| <= e (2.2u |y| + 4.1u)                       (<= 3 ulp hardware exp2)
+//   est = ke * (e - 1),  B = |ke| (e + 1) (5u |y| + 12u) + sigma            (needed: 2.2u |y| + 8.2u)
+// — the difference is formed AFTER the common factor is taken out, so the interval is a few 10^-6 of the score itself even where the
+// jump is a thousandth of the two exponentials.  The float64 sequence's own roundings (of predicted, of the two exponentials, of the
+// products: below |KE| (e + 1) (1 + |K2| dmax) 2^-47) disappear in what the constants have to spare; sigma = 2 covers the truncation to an integer (0 for a node without a power model: it scores exactly 0).
+// A TAME node: cap > 0, every constant finite, |util| <= 400, |K2| log2(e) dmax <= 40 with dmax = 101 + |util|, K1 = 0 or
+// 1e7 <= |KE| <= 1e24 — conditions on the node alone: a cell with 100 pod / cap > dmax has predicted > 101, i.e. is beyond the
+// band below and scores 0 whatever its interval says (y is clamped at 41 so that nothing overflows there; |p - predicted| grows with the
+// request, but so does predicted - 100).  For the other cells |C1| pod + |C0| <= 1024 and |y| <= 40, which is what the bounds above use.
+// Replayed on the CPU against the float64 sequence with the exponential perturbed by +-3 ulp: the largest |raw - est| / B over 10^7
+// cells stays below one half (tests/test_exactness_arguments.py).
+// `predicted > 100` scores 0 (peaks.go:139-140).  p = fma(c1, pod, c0) is within 4u * 1024 of predicted; g = clamp(102400.5 - 1024 p, 0, 1)
+// is 1 below 100 - 2^-11, 0 above 100 + 2^-11 (the band is twice that bound), and in between a = g - g^2 > 0 blows the interval up to +-1e37:
+//   lo, hi = est g -+ (B g + a 1e38).
+// A node that is not tame gets the constants of a cell inside the band (c0 = 100, the rest 0): always "undecided", always evaluated
+// by raw_score.  A node without metrics (valid = 0) or with K1 = 0 has lo = hi = 0, which is its exact score; so has every cell
+// with g = 0.  Such cells take part in the row statistic as the value 0 and are never evaluated.  Columns past the table carry NaN
+// constants: v_max_f32 / v_min_f32 and every comparison ignore them.
+constexpr int kEstPods = 128;  // pod rows per chunk: the node constants (a float64 exp and division per node) are prepared once per chunk
+constexpr float kEstBeta = 5.0f * 0x1p-24f, kEstAlpha = 12.0f * 0x1p-24f;
+constexpr float kEstHuge = 1e38f;
+constexpr float kEstBpInv = 1024.0f;
+constexpr float kEstGc = 102400.5f;  // 0.5 + 100 * kEstBpInv, exact in float32
+constexpr double kEstUtilMax = 400.0, kEstYMax = 40.0, kEstMagMin = 1e7, kEstMagMax = 1e24;
+constexpr float kEstYClamp = 41.0f;
+
+struct NodeE {
+  float c0, c1, ql, ke, sigma;
+};
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Per-node tables of the launches below (k_peaks_nodetab, once per launch_peaks; S = row_stride):
+//   doubles [8][S]   cap, RN(1 / cap), (util / 100) * cap, exp(K2 * util) — load_node's own expressions — K1, K2, valid, and raw_score for a
+//                    pod that requests no cpu (every such row is this row); column-major: the tile launches read 64 consecutive nodes per load
+//   floats  [S][8]   the interval's constants (est_node), one 32-byte row per node: the sweeps read 16 consecutive nodes per lane
+constexpr int kTabCols = 8;
+__device__ __forceinline__ const float* est_tab(const PeaksArgs& a) { return reinterpret_cast<const float*>(a.node_tab + kTabCols * a.row_stride); }
+__device__ __forceinline__ NodeP load_node_tab(const PeaksArgs& a, int64_t n) {  // n < n_nodes
+  NodeP nd;
+  const double* t = a.node_tab + n;
+  const int64_t S = a.row_stride;
+  nd.cap = t[0], nd.rcap = t[S], nd.util_m = t[2 * S], nd.e_now = t[3 * S], nd.k1 = t[4 * S], nd.k2 = t[5 * S];
+  nd.valid = t[6 * S] != 0.0;
+  return nd;
+}
+
+// wave-wide max / min of a float32 (NaN lanes are ignored: v_max_f32 / v_min_f32 return the other operand); DPP steps inside the
+// 16-lane rows as wave_umax (kernels_trimaran.hip), the four rows through v_readlane.  Every lane must be live.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <bool kMax>
+__device__ __forceinline__ float wave_fminmax(float v) {
+  auto op = [](float x, float y) { return kMax ? __builtin_fmaxf(x, y) : __builtin_fminf(x, y); };
+  v = op(v, dpp_f32<0xB1>(v));
+  v = op(v, dpp_f32<0x4E>(v));
+  v = op(v, dpp_f32<0x141>(v));
+  v = op(v, dpp_f32<0x140>(v));
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return op(op(r0, r1), op(r2, r3));
+}
+
+__device__ __forceinline__ NodeE est_node_compute(const NodeP& nd, double util) {
+  NodeE ne;
+  double c0 = 0.0, c1 = 0.0;
+  if (nd.cap != 0) {
+    c0 = 100 * nd.util_m / nd.cap;
+    c1 = 100 / nd.cap;
+  }
+  const double ql = nd.k2 * c1 * 1.4426950408889634, ke = nd.k1 * 1e15 * nd.e_now;
+  // a cell that is not beyond the band has 100 pod / cap <= 101 + |util|: the preconditions need no word about the pods
+  const double dmax = 101.0 + fabs(util), ymax = fabs(nd.k2) * 1.4426950408889634 * dmax;
+  const double sigma = nd.k1 == 0 ? 0.0 : 2.0;  // the truncation to an integer (a node without a power model scores exactly 0)
+  const bool fin = __builtin_isfinite(c0) && __builtin_isfinite(c1) && __builtin_isfinite(ql) && __builtin_isfinite(ke) && __builtin_isfinite(sigma);
+  const bool mag = nd.k1 == 0 || (fabs(ke) >= kEstMagMin && fabs(ke) <= kEstMagMax);
+  const bool tame = nd.cap > 0 && fin && fabs(util) <= kEstUtilMax && ymax <= kEstYMax && mag;
+  if (!nd.valid) {  // raw_score is 0 whatever the rest says
+    ne.c0 = ne.c1 = ne.ql = ne.ke = ne.sigma = 0.0f;
+  } else if (!tame) {  // a cell inside the band: g = 1/2
+    ne.c0 = 100.0f;
+    ne.c1 = ne.ql = ne.ke = ne.sigma = 0.0f;
+  } else {
+    ne.c0 = static_cast<float>(c0), ne.c1 = static_cast<float>(c1), ne.ql = static_cast<float>(ql);
+    ne.ke = nd.k1 == 0 ? 0.0f : static_cast<float>(ke);
+    ne.sigma = static_cast<float>(sigma);
+  }
+  return ne;
+}
+
+__global__ void k_peaks_nodetab(PeaksArgs a) {
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (n >= a.n_nodes) return;
+  const NodeP nd = load_node(a, n);
+  double* t = a.node_tab + n;
+  const int64_t S = a.row_stride;
+  t[0] = nd.cap, t[S] = nd.rcap, t[2 * S] = nd.util_m, t[3 * S] = nd.e_now, t[4 * S] = nd.k1, t[5 * S] = nd.k2, t[6 * S] = nd.valid ? 1.0 : 0.0;
+  t[7 * S] = raw_score(nd, 0.0);
+  const NodeE ne = est_node_compute(nd, a.cpu_util[n]);
+  f32x4* et = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.node_tab + kTabCols * S) + n * 8);
+  et[0] = f32x4{ne.c0, ne.c1, ne.ql, ne.ke};
+  et[1] = f32x4{ne.sigma, 0.0f, 0.0f, 0.0f};
+}
+
+__device__ __forceinline__ NodeE est_node(const PeaksArgs& a, int64_t n, bool counted) {
+  NodeE ne;
+  const float q = __builtin_nanf("");
+  ne.c0 = ne.c1 = ne.ql = ne.ke = ne.sigma = q;
+  if (!counted) return ne;
+  const f32x4* et = reinterpret_cast<const f32x4*>(est_tab(a) + n * 8);
+  const f32x4 u = et[0];
+  ne.c0 = u.x, ne.c1 = u.y, ne.ql = u.z, ne.ke = u.w;
+  ne.sigma = et[1].x;
+  return ne;
+}
+
+__device__ __forceinline__ void est_interval(const NodeE& ne, float pod32, float& lo, float& hi) {
+  const float p = __builtin_fmaf(ne.c1, pod32, ne.c0);
+  const float y = __builtin_fminf(ne.ql * pod32, kEstYClamp);  // (beyond the clamp the cell is beyond the band: g = 0 below, and nothing overflows)
+  const float e = __builtin_amdgcn_exp2f(y);
+  const float est = ne.ke * (e - 1.0f);
+  const float w = __builtin_fmaf(__builtin_fabsf(ne.ke), e, __builtin_fabsf(ne.ke));
+  const float b = __builtin_fmaf(w, __builtin_fmaf(__builtin_fabsf(y), kEstBeta, kEstAlpha), ne.sigma);
+  const float g = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(p, -kEstBpInv, kEstGc), 0.0f), 1.0f);
+  const float am = __builtin_fmaf(-g, g, g);
+  const float bg = __builtin_fmaf(b, g, am * kEstHuge);
+  const float eg = est * g;
+  lo = eg - bg;
+  hi = eg + bg;
+}
+
+// The cells an estimate pass cannot decide leave it in one of two ways (per wave and pod row, wave-uniform):
+//   sparse   a handful of lanes hold one or two such cells (the usual case: the tile's largest score, the cells next to a step of the
+//            normalised score): they are APPENDED to the wave's private segment of a list — (row, node) pairs, no counter shared
+//            between waves — and a second launch (k_peaks_fix_*) runs raw_score on the listed cells with every lane busy.  Evaluating
+//            them where they are found costs a dependent table read and ~100 float64 instructions with one lane of 64 active per cell:
+//            measured, 1.7 + 1.2 ms on top of the 0.8 ms the estimates take for 10 000 x 100 000;
+//   dense    many (a pod that requests no cpu: every jump is rounding noise and the interval decides nothing; a tile of nodes outside
+//            the preconditions; a full segment): ONE entry (row, -1) names the whole tile, and the second launch runs every cell of it
+//            through raw_score, a wave per tile as k_peaks does.  The sweeps themselves hold no float64 code: 2 -> 4-5 waves per SIMD.
+constexpr int kEstSegPerPod = 3;                       // segment entries per pod row of a chunk
+constexpr int kEstSegCap = kEstSegPerPod * kEstPods;   // entries per wave: 3 KB
+constexpr int kEstSparseLanes = 12;                    // more lanes than this with undecided cells: dense
+
+struct SegEntry {
+  int32_t row, node;
+};
+typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ SegEntry seg_uload(const SegEntry* p) {  // wave-uniform read
+  const i32x2 v = uload(reinterpret_cast<const i32x2*>(p));
+  return SegEntry{v.x, v.y};
+}
+
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {  // set bits of mask below this lane
+  return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u)));
+}
+
+template <int kNpl, bool kMask>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks_minmax_est(PeaksArgs a, int n_tiles) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+  const int tile = static_cast<int>(unit % n_tiles);
+  const int64_t chunk = unit / n_tiles;
+  const int64_t n_rows = a.row_list ? a.n_list : a.row_end - a.row_begin;
+  const int64_t i0 = chunk * kEstPods;
+  if (i0 >= n_rows) return;  // wave-uniform
+  const int64_t i1 = (i0 + kEstPods < n_rows) ? i0 + kEstPods : n_rows;
+  const int64_t node0 = (static_cast<int64_t>(tile) * kWave + lane) * kNpl;
+  const bool active = node0 < a.row_stride;  // all 64 lanes stay in the loop: the reductions below run across them
+  SegEntry* const seg = reinterpret_cast<SegEntry*>(a.seg) + unit * kEstSegCap;
+  int seg_n = 0;  // wave-uniform
+
+  NodeE ne[kNpl];
+#pragma unroll
+  for (int j = 0; j < kNpl; ++j) ne[j] = est_node(a, node0 + j, active && node0 + j < a.n_nodes);
+
+  for (int64_t i = i0; i < i1; ++i) {
+    const int64_t pod = a.row_list ? static_cast<int64_t>(uload(a.row_list + i)) : a.row_begin + i;
+    const int64_t pod_i = uload(a.pod_cpu_milli + pod);
+    const float pod32 = static_cast<float>(pod_i);
+    uint32_t bad = 0;
+    if constexpr (kMask) bad = infeasible_mask<kNpl>(a, pod, node0, active);
+    float lo[kNpl], hi[kNpl];
+    float maxlo = -__builtin_inff(), minhi = __builtin_inff();
+#pragma unroll
+    for (int j = 0; j < kNpl; ++j) {
+      est_interval(ne[j], pod32, lo[j], hi[j]);
+      if constexpr (kMask) {
+        if ((bad >> j) & 1u) lo[j] = hi[j] = __builtin_nanf("");
+      }
+      maxlo = __builtin_fmaxf(maxlo, lo[j]);
+      minhi = __builtin_fminf(minhi, hi[j]);
+    }
+    maxlo = wave_fminmax<true>(maxlo);
+    minhi = wave_fminmax<false>(minhi);
+    // undecided cells: the row's extremes over this tile are among them and the cells known to score exactly 0
+    uint32_t cand = 0;
+    bool zero = false;
+#pragma unroll
+    for (int j = 0; j < kNpl; ++j) {
+      const bool c = (hi[j] >= maxlo) || (lo[j] <= minhi);
+      cand |= (c && hi[j] > lo[j]) ? (1u << j) : 0u;
+      zero = zero || (lo[j] == hi[j]);
+    }
+#if defined(SPX_PEAKS_DIAG) && (SPX_PEAKS_DIAG & 1)
+    cand = 0;  // (timing experiment: no float64 evaluations for the min/max pass — wrong tables)
+#endif
+    const unsigned long long any = __ballot(cand != 0u);
+    const int n_any = __builtin_popcountll(any);
+    const bool multi = __ballot((cand & (cand - 1u)) != 0u) != 0ull;
+    const bool zero_any = __ballot(zero) != 0ull;
+    const int left = static_cast<int>(i1 - i - 1);  // every later row of the chunk keeps room for one entry
+    if (!multi && n_any <= kEstSparseLanes && seg_n + n_any + left <= kEstSegCap) {  // uniform
+      if (cand != 0u) seg[seg_n + lanes_below(any)] = SegEntry{static_cast<int32_t>(pod), static_cast<int32_t>(node0 + __builtin_ctz(cand))};
+      seg_n += n_any;
+      if (lane == 0 && zero_any) {
+        atomicMin(reinterpret_cast<long long*>(a.row_min + pod), 0ll);
+        atomicMax(reinterpret_cast<long long*>(a.row_max + pod), 0ll);
+      }
+    } else {  // the whole tile, by k_peaks_fix_minmax
+      if (lane == 0) seg[seg_n] = SegEntry{static_cast<int32_t>(pod), -1};
+      seg_n += 1;
+    }
+  }
+  if (lane == 0) a.seg_n[unit] = seg_n;
+}
+
+// whether node `node` counts for row `pod`: inside the table and passed by every Filter status table in play
+template <bool kMask>
+__device__ __forceinline__ bool node_counts(const PeaksArgs& a, int64_t pod, int64_t node) {
+  bool c = node < a.n_nodes;
+  if constexpr (kMask) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      if (a.other_status[t] != nullptr && c) c = a.other_status[t][pod * a.row_stride + node] == 0;
+  }
+  return c;
+}
+
+// The second launch of the min/max pass, a wave per segment: the listed cells through raw_score, one lane per cell, into the row
+// statistic; a listed TILE by the whole wave — lane l takes the nodes base + 64 j + l (consecutive lanes, consecutive nodes: every table
+// column is read in whole lines), and the rows of pods that request no cpu read their raw scores from the table's last column.
+template <int kNpl, bool kMask>
+__global__ __launch_bounds__(kWave) void k_peaks_fix_minmax(PeaksArgs a, int n_tiles) {
+  const int lane = threadIdx.x;
+  const int n = uload(a.seg_n + blockIdx.x);
+  const SegEntry* seg = reinterpret_cast<const SegEntry*>(a.seg) + static_cast<int64_t>(blockIdx.x) * kEstSegCap;
+  const int tile = static_cast<int>(blockIdx.x % static_cast<unsigned>(n_tiles));
+  const int64_t base = static_cast<int64_t>(tile) * kWave * kNpl + lane;
+  const double* raw0 = a.node_tab + 7 * a.row_stride;
+  for (int k0 = 0; k0 < n; k0 += kWave) {  // uniform
+    const bool have = k0 + lane < n;
+    SegEntry e = SegEntry{0, 0};
+    if (have) e = seg[k0 + lane];
+    const bool is_tile = have && e.node < 0;
+    if (have && !is_tile) {
+      const double v = raw_score(load_node_tab(a, e.node), static_cast<double>(a.pod_cpu_milli[e.row]));
+      atomicMin(reinterpret_cast<long long*>(a.row_min + e.row), static_cast<long long>(v));
+      atomicMax(reinterpret_cast<long long*>(a.row_max + e.row), static_cast<long long>(v));
+    }
+    unsigned long long tm = __ballot(is_tile);
+    while (tm != 0ull) {  // uniform
+      const int src = __builtin_ctzll(tm);
+      tm &= tm - 1ull;
+      const int64_t pod = __builtin_amdgcn_readlane(e.row, src);
+      const int64_t pod_i = uload(a.pod_cpu_milli + pod);
+      double mn = kInf, mx = -kInf;
+      if (pod_i == 0) {  // uniform: all the loads first
+        double r[kNpl];
+        bool c[kNpl];
+#pragma unroll
+        for (int j = 0; j < kNpl; ++j) {
+          c[j] = node_counts<kMask>(a, pod, base + j * kWave);
+          r[j] = c[j] ? raw0[base + j * kWave] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < kNpl; ++j) {
+          mn = c[j] ? fmin(mn, r[j]) : mn;
+          mx = c[j] ? fmax(mx, r[j]) : mx;
+        }
+      } else {
+        const double pod_cpu = static_cast<double>(pod_i);
+#pragma unroll 2
+        for (int j = 0; j < kNpl; ++j) {
+          const int64_t node = base + j * kWave;
+          if (node_counts<kMask>(a, pod, node)) {
+            const double v = raw_score(load_node_tab(a, node), pod_cpu);
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        mn = fmin(mn, shfl_xor_f64(mn, m));
+        mx = fmax(mx, shfl_xor_f64(mx, m));
+      }
+      if (lane == 0 && mn <= mx) {
+        atomicMin(reinterpret_cast<long long*>(a.row_min + pod), static_cast<long long>(mn));
+        atomicMax(reinterpret_cast<long long*>(a.row_max + pod), static_cast<long long>(mx));
+      }
+    }
+  }
+}
+
+// per swept row, once the row statistic is complete: what the write pass needs of it in float32 — r = 100 / span, and the two
+// constants of n(x) = fma(x, r, c): c_lo / c_hi = -min * r -+ en, en covering the roundings of r, of min * r and of the fma for results in
+// [-1, 101] (outside that range both ends of a cell's interval land on the same side of every integer that matters).
+// kind: 0 = every raw score of the row is 0 (peaks.go:152-154), 1 = min == max, 2 = the general case
+__global__ void k_peaks_rowconst(PeaksArgs a) {
+  const int64_t n_rows = a.row_list ? a.n_list : a.row_end - a.row_begin;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const int64_t pod = a.row_list ? static_cast<int64_t>(a.row_list[i]) : a.row_begin + i;
+  const int64_t mni = a.row_min[pod], mxi = a.row_max[pod];
+  f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (mni == 0 && mxi == 0) {
+  } else if (mni == mxi) {
+    c.w = 1.0f;
+  } else {
+    const double mn = static_cast<double>(mni);
+    const double span = static_cast<double>(static_cast<int64_t>(static_cast<uint64_t>(mxi) - static_cast<uint64_t>(mni)));
+    const double r = 100.0 / span, mr = mn * r;
+    const float en = static_cast<float>(6.0 * 0x1p-24 * (fabs(mr) + 101.0));
+    c.x = static_cast<float>(r);
+    c.y = static_cast<float>(-mr) - en;
+    c.z = static_cast<float>(-mr) + en;
+    c.w = 2.0f;
+  }
+  reinterpret_cast<f32x4*>(a.row_c)[pod] = c;
+}
+
+template <int kNpl, bool kMask>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks_write_est(PeaksArgs a, int n_tiles) {
+  constexpr int kWords = kNpl / 4;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+  const int tile = static_cast<int>(unit % n_tiles);
+  const int64_t chunk = unit / n_tiles;
+  const int64_t n_rows = a.row_list ? a.n_list : a.row_end - a.row_begin;
+  const int64_t i0 = chunk * kEstPods;
+  if (i0 >= n_rows) return;  // wave-uniform
+  const int64_t i1 = (i0 + kEstPods < n_rows) ? i0 + kEstPods : n_rows;
+  const int64_t node0 = (static_cast<int64_t>(tile) * kWave + lane) * kNpl;
+  const bool active = node0 < a.row_stride;
+  SegEntry* const seg = reinterpret_cast<SegEntry*>(a.seg) + unit * kEstSegCap;
+  int seg_n = 0;  // wave-uniform
+
+  NodeE ne[kNpl];
+  uint32_t keep0[kWords];  // 0xff per column inside the table
+#pragma unroll
+  for (int w = 0; w < kWords; ++w) keep0[w] = 0u;
+#pragma unroll
+  for (int j = 0; j < kNpl; ++j) {
+    const bool counted = active && node0 + j < a.n_nodes;
+    ne[j] = est_node(a, node0 + j, counted);
+    keep0[j >> 2] |= counted ? (0xffu << (8 * (j & 3))) : 0u;
+  }
+
+  for (int64_t i = i0; i < i1; ++i) {
+    const int64_t pod = a.row_list ? static_cast<int64_t>(uload(a.row_list + i)) : a.row_begin + i;
+    const f32x4 rc = uload(reinterpret_cast<const f32x4*>(a.row_c) + pod);
+    uint32_t word[kWords];
+#pragma unroll
+    for (int w = 0; w < kWords; ++w) word[w] = 0u;
+    if (rc.w != 0.0f) {  // uniform
+      uint32_t keep[kWords];
+#pragma unroll
+      for (int w = 0; w < kWords; ++w) {
+        keep[w] = keep0[w];
+        if constexpr (kMask) {
+          uint32_t st = 0;
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            if (a.other_status[t] != nullptr && active) st |= *reinterpret_cast<const uint32_t*>(a.other_status[t] + pod * a.row_stride + node0 + 4 * w);
+          const uint32_t nz = (((st & 0x7f7f7f7fu) + 0x7f7f7f7fu) | st) & 0x80808080u;  // bit 7 of every non-zero byte
+          keep[w] &= ~((nz >> 7) * 0xffu);
+        }
+      }
+      if (rc.w == 1.0f) {  // min == max: every feasible node's raw score is the minimum, norm = 0
+#pragma unroll
+        for (int w = 0; w < kWords; ++w) word[w] = 0x64646464u;
+      } else {
+        const int64_t pod_i = uload(a.pod_cpu_milli + pod);
+        const float pod32 = static_cast<float>(pod_i);
+        uint32_t amb = 0;
+#pragma unroll
+        for (int j = 0; j < kNpl; ++j) {
+          float lo, hi;
+          est_interval(ne[j], pod32, lo, hi);
+          const float nlo = __builtin_fmaf(lo, rc.x, rc.y), nhi = __builtin_fmaf(hi, rc.x, rc.z);
+          const uint32_t klo = static_cast<uint32_t>(__builtin_fminf(__builtin_fmaxf(nlo, 0.0f), 1.0e6f));
+          const uint32_t khi = static_cast<uint32_t>(__builtin_fminf(__builtin_fmaxf(nhi, 0.0f), 1.0e6f));
+          amb |= (klo != khi) ? (1u << j) : 0u;
+          const uint32_t sc = 100u - (khi < 100u ? khi : 100u);
+          word[j >> 2] |= sc << (8 * (j & 3));
+        }
+        // the undecided cells of columns that count
+        uint32_t feas = 0;
+#pragma unroll
+        for (int w = 0; w < kWords; ++w) feas |= ((((keep[w] & 0x01010101u) * 0x00204081u) >> 21) & 0xfu) << (4 * w);
+        amb &= feas;
+#if defined(SPX_PEAKS_DIAG) && (SPX_PEAKS_DIAG & 2)
+        amb = 0;  // (timing experiment: no float64 evaluations for the write pass — wrong tables)
+#endif
+        unsigned long long any = __ballot(amb != 0u);
+        if (any != 0ull) {  // uniform
+          const int left = static_cast<int>(i1 - i - 1);  // every later row of the chunk keeps room for one entry
+          const int mark = seg_n;
+          bool tile_entry = __builtin_popcountll(any) > kEstSparseLanes;
+          while (!tile_entry && any != 0ull) {  // listed: the first undecided cell of every lane that has one, until none is left
+            const int n_any = __builtin_popcountll(any);
+            if (seg_n + n_any + left > kEstSegCap) {
+              tile_entry = true;
+              break;
+            }
+            if (amb != 0u) {
+              seg[seg_n + lanes_below(any)] = SegEntry{static_cast<int32_t>(pod), static_cast<int32_t>(node0 + __builtin_ctz(amb))};
+              amb &= amb - 1u;
+            }
+            seg_n += n_any;
+            any = __ballot(amb != 0u);
+          }
+          if (tile_entry) {  // the whole tile, by k_peaks_fix_write (cells listed so far for this row are dropped again)
+            seg_n = mark;
+            if (lane == 0) seg[seg_n] = SegEntry{static_cast<int32_t>(pod), -1};
+            seg_n += 1;
+          }
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < kWords; ++w) word[w] &= keep[w];
+    }
+    if (active) {
+      uint32_t* dst = reinterpret_cast<uint32_t*>(a.out_score + pod * a.row_stride + node0);
+      if constexpr (kWords == 4) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u32x4*>(dst) = u32x4{word[0], word[1], word[2], word[3]};
+      } else {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(dst) = u32x2{word[0], word[1]};
+      }
+    }
+  }
+  if (lane == 0) a.seg_n[unit] = seg_n;
+}
+
+// NormalizeScore of a raw score (k_peaks<true>'s expressions; span != 0 on this path)
+__device__ __forceinline__ uint32_t norm_byte(double raw, double mn, double span, double rspan) {
+  const double norm = div_rn(100.0 * (raw - mn), span, rspan);  // :161
+  const int sc = 100 - static_cast<int>(norm);
+  return static_cast<uint32_t>(sc < 0 ? 0 : (sc > 100 ? 100 : sc));
+}
+
+// The second launch of the write pass, a wave per segment: the listed cells through the float64 NormalizeScore, one lane per cell, one
+// byte each into the table; a listed tile by the whole wave as in k_peaks_fix_minmax, every column of the tile written (0 where the
+// node does not count).
+template <int kNpl, bool kMask>
+__global__ __launch_bounds__(kWave) void k_peaks_fix_write(PeaksArgs a, int n_tiles) {
+  const int lane = threadIdx.x;
+  const int n = uload(a.seg_n + blockIdx.x);
+  const SegEntry* seg = reinterpret_cast<const SegEntry*>(a.seg) + static_cast<int64_t>(blockIdx.x) * kEstSegCap;
+  const int tile = static_cast<int>(blockIdx.x % static_cast<unsigned>(n_tiles));
+  const int64_t base = static_cast<int64_t>(tile) * kWave * kNpl + lane;
+  const double* raw0 = a.node_tab + 7 * a.row_stride;
+  for (int k0 = 0; k0 < n; k0 += kWave) {  // uniform
+    const bool have = k0 + lane < n;
+    SegEntry e = SegEntry{0, 0};
+    if (have) e = seg[k0 + lane];
+    const bool is_tile = have && e.node < 0;
+    if (have && !is_tile) {
+      const int64_t mni = a.row_min[e.row], mxi = a.row_max[e.row];
+      const double mn = static_cast<double>(mni);
+      const double span = static_cast<double>(mxi - mni);
+      const double raw = raw_score(load_node_tab(a, e.node), static_cast<double>(a.pod_cpu_milli[e.row]));
+      a.out_score[static_cast<int64_t>(e.row) * a.row_stride + e.node] = static_cast<uint8_t>(norm_byte(raw, mn, span, 1.0 / span));
+    }
+    unsigned long long tm = __ballot(is_tile);
+    while (tm != 0ull) {  // uniform
+      const int src = __builtin_ctzll(tm);
+      tm &= tm - 1ull;
+      const int64_t pod = __builtin_amdgcn_readlane(e.row, src);
+      const int64_t pod_i = uload(a.pod_cpu_milli + pod);
+      const int64_t mni = uload(a.row_min + pod), mxi = uload(a.row_max + pod);
+      const double mn = static_cast<double>(mni);
+      const double span = static_cast<double>(mxi - mni);
+      const double rspan = 1.0 / span;
+      uint8_t* out = a.out_score + pod * a.row_stride;
+      if (pod_i == 0) {  // uniform: all the loads first
+        double r[kNpl];
+        bool c[kNpl];
+#pragma unroll
+        for (int j = 0; j < kNpl; ++j) {
+          c[j] = node_counts<kMask>(a, pod, base + j * kWave);
+          r[j] = c[j] ? raw0[base + j * kWave] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < kNpl; ++j) {
+          const int64_t node = base + j * kWave;
+          if (node < a.row_stride) out[node] = static_cast<uint8_t>(c[j] ? norm_byte(r[j], mn, span, rspan) : 0u);
+        }
+      } else {
+        const double pod_cpu = static_cast<double>(pod_i);
+#pragma unroll 2
+        for (int j = 0; j < kNpl; ++j) {
+          const int64_t node = base + j * kWave;
+          if (node >= a.row_stride) continue;
+          uint32_t b = 0;
+          if (node_counts<kMask>(a, pod, node)) b = norm_byte(raw_score(load_node_tab(a, node), pod_cpu), mn, span, rspan);
+          out[node] = static_cast<uint8_t>(b);
+        }
+      }
+    }
+  }
+}
+
 __global__ void k_peaks_raw(PeaksArgs a) {  // Score() of one pod row as int64 (spx_fetch_raw)
   const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (n >= a.n_nodes) return;
@@ -201,6 +737,15 @@ __global__ void k_peaks_raw(PeaksArgs a) {  // Score() of one pod row as int64 (
 }
 
 }  // namespace
+
+// scratch of the interval-estimate passes for a sweep of `swept` rows: one list segment and one counter per wave
+void peaks_est_scratch(uint32_t opts, int64_t row_stride, int64_t swept, size_t* seg_bytes, size_t* cnt_bytes) {
+  const int npl = (opts & kOptPeaksEst8) ? 8 : 16;
+  const int64_t nt = (row_stride + kWave * npl - 1) / (kWave * npl);
+  const int64_t waves = ((swept + kEstPods - 1) / kEstPods) * nt;
+  *seg_bytes = static_cast<size_t>(waves) * kEstSegCap * sizeof(SegEntry);
+  *cnt_bytes = static_cast<size_t>(waves) * sizeof(int32_t);
+}
 
 void launch_peaks(const PeaksArgs& a, hipStream_t s) {
   if (a.out_raw != nullptr) {
@@ -212,6 +757,45 @@ void launch_peaks(const PeaksArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_peaks_init, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0, s, a.row_min, a.row_max, a.row_begin, a.row_end);
   const int64_t swept = a.row_list ? a.n_list : rows;
   const int64_t chunks = (swept + kPodsPerChunk - 1) / kPodsPerChunk;
+  if (a.opts & kOptPeaksEstimate) {  // interval estimates; raw_score where they cannot decide
+    const bool mask = a.other_status[0] || a.other_status[1] || a.other_status[2];
+    const int npl = (a.opts & kOptPeaksEst8) ? 8 : 16;
+    const int nt = static_cast<int>((a.row_stride + kWave * npl - 1) / (kWave * npl));
+    const int64_t waves = ((swept + kEstPods - 1) / kEstPods) * nt;  // = peaks_est_waves: one list segment each
+    const dim3 g(static_cast<unsigned>((waves + kWavesPerBlock - 1) / kWavesPerBlock)), blk(kWave * kWavesPerBlock);
+    hipLaunchKernelGGL(k_peaks_nodetab, dim3(static_cast<unsigned>((a.n_nodes + 255) / 256)), dim3(256), 0, s, a);
+    if (npl == 8) {
+      if (mask) hipLaunchKernelGGL((k_peaks_minmax_est<8, true>), g, blk, 0, s, a, nt);
+      else hipLaunchKernelGGL((k_peaks_minmax_est<8, false>), g, blk, 0, s, a, nt);
+    } else {
+      if (mask) hipLaunchKernelGGL((k_peaks_minmax_est<16, true>), g, blk, 0, s, a, nt);
+      else hipLaunchKernelGGL((k_peaks_minmax_est<16, false>), g, blk, 0, s, a, nt);
+    }
+    const dim3 gf(static_cast<unsigned>(waves)), bf(kWave);
+    if (npl == 8) {
+      if (mask) hipLaunchKernelGGL((k_peaks_fix_minmax<8, true>), gf, bf, 0, s, a, nt);
+      else hipLaunchKernelGGL((k_peaks_fix_minmax<8, false>), gf, bf, 0, s, a, nt);
+    } else {
+      if (mask) hipLaunchKernelGGL((k_peaks_fix_minmax<16, true>), gf, bf, 0, s, a, nt);
+      else hipLaunchKernelGGL((k_peaks_fix_minmax<16, false>), gf, bf, 0, s, a, nt);
+    }
+    hipLaunchKernelGGL(k_peaks_rowconst, dim3(static_cast<unsigned>((swept + 255) / 256)), dim3(256), 0, s, a);
+    if (npl == 8) {
+      if (mask) hipLaunchKernelGGL((k_peaks_write_est<8, true>), g, blk, 0, s, a, nt);
+      else hipLaunchKernelGGL((k_peaks_write_est<8, false>), g, blk, 0, s, a, nt);
+    } else {
+      if (mask) hipLaunchKernelGGL((k_peaks_write_est<16, true>), g, blk, 0, s, a, nt);
+      else hipLaunchKernelGGL((k_peaks_write_est<16, false>), g, blk, 0, s, a, nt);
+    }
+    if (npl == 8) {
+      if (mask) hipLaunchKernelGGL((k_peaks_fix_write<8, true>), gf, bf, 0, s, a, nt);
+      else hipLaunchKernelGGL((k_peaks_fix_write<8, false>), gf, bf, 0, s, a, nt);
+    } else {
+      if (mask) hipLaunchKernelGGL((k_peaks_fix_write<16, true>), gf, bf, 0, s, a, nt);
+      else hipLaunchKernelGGL((k_peaks_fix_write<16, false>), gf, bf, 0, s, a, nt);
+    }
+    return;
+  }
   auto grid = [&](int npl, int* n_tiles) {
     const int tile_nodes = kWave * npl;
     *n_tiles = static_cast<int>((a.row_stride + tile_nodes - 1) / tile_nodes);

@@ -55,7 +55,7 @@ struct spx_engine {
   int64_t row_stride = 0;
 
   // spx_set_option state (per engine; nothing is read from the environment)
-  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1, 0, 1, 1, 1, 1};
+  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1, 0, 1, 1, 1, 1, 1};
 
   // params
   int32_t alloc_mode = SPX_MODE_LEAST;
@@ -92,7 +92,7 @@ struct spx_engine {
   bool lroc_nodes_exact = false, lroc_pods_exact = false, lv_alloc_exact = false;  // all values in [0, 2^52)
 
   // Peaks
-  DevBuf d_pk_cap, d_pk_util, d_pk_valid, d_pk_k1, d_pk_k2, d_pk_pod, d_pk_min, d_pk_max;
+  DevBuf d_pk_cap, d_pk_util, d_pk_valid, d_pk_k1, d_pk_k2, d_pk_pod, d_pk_min, d_pk_max, d_pk_rowc, d_pk_tab, d_pk_seg, d_pk_segn;
   bool peaks_nodes = false, peaks_pods = false;
 
   // NodeResourceTopologyMatch
@@ -361,6 +361,8 @@ uint32_t launch_opts(const spx_engine* e) {
   if (e->option[SPX_OPT_PEAKS_TILE] / 10 == 8) o |= spx::kOptPeaksWideA;
   if (e->option[SPX_OPT_PEAKS_TILE] % 10 == 8) o |= spx::kOptPeaksWideB;
   if (!e->option[SPX_OPT_TLP_AMB_TABLE]) o |= spx::kOptTlpNoAmbTable;
+  if (e->option[SPX_OPT_PEAKS_ESTIMATE]) o |= spx::kOptPeaksEstimate;
+  if (e->option[SPX_OPT_PEAKS_ESTIMATE] == 8) o |= spx::kOptPeaksEst8;
   return o;
 }
 
@@ -408,6 +410,8 @@ void fill_peaks(const spx_engine* e, spx::PeaksArgs& a) {
   a.pod_cpu_milli = static_cast<const int64_t*>(e->d_pk_pod.p);
   a.row_min = static_cast<int64_t*>(e->d_pk_min.p);
   a.row_max = static_cast<int64_t*>(e->d_pk_max.p);
+  a.row_c = static_cast<float*>(e->d_pk_rowc.p);
+  a.node_tab = static_cast<double*>(e->d_pk_tab.p);
 }
 
 void fill_trimaran(const spx_engine* e, spx::TrimaranArgs& a) {
@@ -669,7 +673,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_sort_prio, &e->d_sort_ts, &e->d_sort_group, &e->d_sort_topo, &e->d_sort_scratch,
                     &e->d_best, &e->d_stats, &e->d_decide, &e->d_lroc_nreq_c, &e->d_lroc_nreq_m, &e->d_lroc_nlim_c, &e->d_lroc_nlim_m,
                     &e->d_lroc_preq_c, &e->d_lroc_preq_m, &e->d_lroc_plim_c, &e->d_lroc_plim_m, &e->d_lroc_tab, &e->d_lroc_podf,
-                    &e->d_pk_cap, &e->d_pk_util, &e->d_pk_valid, &e->d_pk_k1, &e->d_pk_k2, &e->d_pk_pod, &e->d_pk_min, &e->d_pk_max,
+                    &e->d_pk_cap, &e->d_pk_util, &e->d_pk_valid, &e->d_pk_k1, &e->d_pk_k2, &e->d_pk_pod, &e->d_pk_min, &e->d_pk_max, &e->d_pk_rowc, &e->d_pk_tab, &e->d_pk_seg, &e->d_pk_segn,
                     &e->d_nrt_uniq, &e->d_nrt_dups, &e->d_pk_uniq, &e->d_pk_dups, &e->d_delta, &e->d_nrt_lnrec, &e->d_net_pair_node2, &e->d_net_pair_max2, &e->d_nrt_rk, &e->d_nrt_rk_off};
   for (DevBuf* b : bufs)
     if (b->p && !b->external) (void)hipFree(b->p);
@@ -728,6 +732,9 @@ int spx_set_option(spx_engine* e, int option, int64_t value) {
       break;
     case SPX_OPT_NRT_LN_LIST_PERMILLE:
       if (value < 1 || value > 1000) return fail(e, SPX_ERR_ARG, "SPX_OPT_NRT_LN_LIST_PERMILLE: 1..1000");
+      break;
+    case SPX_OPT_PEAKS_ESTIMATE:
+      if (value != 0 && value != 1 && value != 8) return fail(e, SPX_ERR_ARG, "SPX_OPT_PEAKS_ESTIMATE: 0, 1 or 8");
       break;
     case SPX_OPT_PEAKS_TILE:
       if (value != 44 && value != 84 && value != 48 && value != 88) return fail(e, SPX_ERR_ARG, "SPX_OPT_PEAKS_TILE: 44, 84, 48 or 88");
@@ -2196,7 +2203,9 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
   if (K && (rc = ensure_score_table(e, SPX_PLUGIN_PEAKS))) return rc;
   if (K && e->score_stride[SPX_PLUGIN_PEAKS] != e->row_stride)
     return fail(e, SPX_ERR_STATE, "bound score table must use the engine row stride (spx_score_table reports it)");
-  if (K && ((rc = ensure(e, e->d_pk_min, static_cast<size_t>(e->n_pods) * 8)) || (rc = ensure(e, e->d_pk_max, static_cast<size_t>(e->n_pods) * 8)))) return rc;
+  if (K && ((rc = ensure(e, e->d_pk_min, static_cast<size_t>(e->n_pods) * 8)) || (rc = ensure(e, e->d_pk_max, static_cast<size_t>(e->n_pods) * 8)) ||
+            (rc = ensure(e, e->d_pk_rowc, static_cast<size_t>(e->n_pods) * 16)) || (rc = ensure(e, e->d_pk_tab, static_cast<size_t>(e->row_stride) * 96))))
+    return rc;
   if (N && (rc = ensure_status_table(e, SPX_PLUGIN_NRT))) return rc;
   if (W && (rc = ensure_status_table(e, SPX_PLUGIN_NETOVERHEAD))) return rc;
 
@@ -2406,6 +2415,13 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     if (classes) {
       ka.row_list = static_cast<const int32_t*>(e->d_pk_uniq.p);
       ka.n_list = e->pk_n_uniq;
+    }
+    if (ka.opts & spx::kOptPeaksEstimate) {  // the undecided cells' list: sized by the rows this sweep walks
+      size_t seg_bytes = 0, cnt_bytes = 0;
+      spx::peaks_est_scratch(ka.opts, e->row_stride, classes ? ka.n_list : row_end - row_begin, &seg_bytes, &cnt_bytes);
+      if ((rc = ensure(e, e->d_pk_seg, seg_bytes)) || (rc = ensure(e, e->d_pk_segn, cnt_bytes))) return rc;
+      ka.seg = e->d_pk_seg.p;
+      ka.seg_n = static_cast<int32_t*>(e->d_pk_segn.p);
     }
     spx::launch_peaks(ka, e->stream);
     if (classes)

@@ -42,6 +42,8 @@ enum : uint32_t {
   kOptPeaksWideA = 1u << 5,        // Peaks: 8 nodes per lane in the min/max pass
   kOptPeaksWideB = 1u << 6,        // Peaks: 8 nodes per lane in the write pass
   kOptTlpNoAmbTable = 1u << 7,     // TLP fast sweep: per-cell exactness bookkeeping in every row (SPX_OPT_TLP_AMB_TABLE 0)
+  kOptPeaksEstimate = 1u << 8,     // Peaks: float32 interval estimates, raw_score only where they cannot decide (SPX_OPT_PEAKS_ESTIMATE)
+  kOptPeaksEst8 = 1u << 9,         //   8 instead of 16 nodes per lane
 };
 
 // what the multi-device layer (spx_multi.hip) needs to see of an engine
@@ -211,6 +213,10 @@ struct PeaksArgs {
   const uint8_t* other_status[3];  // Filter plugins' status tables [P][row_stride] (0 = passed), NULL = unused
   int64_t* row_min;              // [P] scratch: min / max of the raw scores over each pod's feasible nodes
   int64_t* row_max;
+  float* row_c;                  // [P][4] scratch of the interval-estimate write pass (k_peaks_rowconst)
+  double* node_tab;              // scratch of the interval-estimate passes: 96 bytes per column of a row (k_peaks_nodetab)
+  void* seg;                     // the undecided cells' list: a segment per wave (peaks_est_scratch)
+  int32_t* seg_n;                // entries per segment
   uint8_t* out_score;            // [P][row_stride]
   int64_t* out_raw;              // when set: raw int64 scores of row_begin only, no table writes
   // when set: the sweep walks these n_list rows — the first row of each distinct pod cpu request, ascending — instead of
@@ -219,6 +225,7 @@ struct PeaksArgs {
   int64_t n_list;
 };
 void launch_peaks(const PeaksArgs& a, hipStream_t s);
+void peaks_est_scratch(uint32_t opts, int64_t row_stride, int64_t swept, size_t* seg_bytes, size_t* cnt_bytes);
 
 // ---------------------------------------------------------------- NodeResourceTopologyMatch
 struct NrtArgs {

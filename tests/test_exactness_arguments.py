@@ -443,3 +443,186 @@ def test_balanced_allocation_float32_score_is_exact_outside_the_band():
     assert worst < 2.3e-4, worst
     # 2 * kBalBand of the cells, the rare fraction next to 1, and the exactly integer scores small capacities produce (all fractions 0 or equal)
     assert undecided < 5e-3 * plain_cells, (undecided, plain_cells)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# k_peaks_minmax_est / k_peaks_write_est (kernels_peaks.hip, SPX_OPT_PEAKS_ESTIMATE): the float32 interval of a cell's raw score
+# contains the value of the float64 sequence; the cells the two passes leave to raw_score are a superset of the cells that matter.
+# The replay below is the kernels' arithmetic in numpy float32 (fma through float64: the product of two float32 is exact there),
+# with v_exp_f32 modelled as the correctly rounded 2^y perturbed by up to 3 ulp either way.
+
+def _peaks_consts():
+    import re
+    from pathlib import Path
+    src = (Path(__file__).resolve().parent.parent / "scheduler-plugins_amd" / "csrc" / "kernels_peaks.hip").read_text()
+
+    def c(name):
+        return re.search(r"\b" + name + r" = ([^,;]+)[,;]", src).group(1).strip()
+
+    assert (c("kEstBeta"), c("kEstAlpha")) == ("5.0f * 0x1p-24f", "12.0f * 0x1p-24f")
+    assert (float(c("kEstHuge").rstrip("f")), float(c("kEstBpInv").rstrip("f")), float(c("kEstGc").rstrip("f"))) == (1e38, 1024.0, 102400.5)
+    assert (float(c("kEstUtilMax")), float(c("kEstYMax")), float(c("kEstMagMin")), float(c("kEstMagMax")), c("kEstYClamp")) == (400.0, 40.0, 1e7, 1e24, "41.0f")
+    f = np.float32
+    return f(5.0 * 2.0 ** -24), f(12.0 * 2.0 ** -24), f(1e38), f(1024.0), f(102400.5)
+
+
+def _peaks_fma32(a, b, c):
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+
+def _peaks_node_consts(cap, util, k1, k2, valid):
+    """est_node_compute: (c0, c1, ql, ke, sigma) per node and which nodes are outside the preconditions"""
+    cap = cap.astype(np.float64)
+    with np.errstate(all="ignore"):
+        util_m = (util / 100) * cap
+        c0 = np.where(cap != 0, 100 * util_m / np.where(cap != 0, cap, 1), 0.0)
+        c1 = np.where(cap != 0, 100 / np.where(cap != 0, cap, 1), 0.0)
+        ql = k2 * c1 * 1.4426950408889634
+        ke = k1 * 1e15 * np.exp(k2 * util)
+        dmax = 101.0 + np.abs(util)
+        ymax = np.abs(k2) * 1.4426950408889634 * dmax
+        sigma = np.where(k1 == 0, 0.0, 2.0)
+        fin = np.isfinite(c0) & np.isfinite(c1) & np.isfinite(ql) & np.isfinite(ke) & np.isfinite(sigma)
+        mag = (k1 == 0) | ((np.abs(ke) >= 1e7) & (np.abs(ke) <= 1e24))
+        tame = (cap > 0) & fin & (np.abs(util) <= 400.0) & (ymax <= 40.0) & mag
+    z = ~valid | ~tame
+    f = np.float32
+    with np.errstate(all="ignore"):
+        return (np.where(~valid, 0.0, np.where(tame, c0, 100.0)).astype(f), np.where(z, 0.0, c1).astype(f), np.where(z, 0.0, ql).astype(f),
+                np.where(z | (k1 == 0), 0.0, ke).astype(f), np.where(z, 0.0, sigma).astype(f)), valid & ~tame
+
+
+def _peaks_interval(consts, pod32, rng, ulps=3):
+    beta, alpha, huge, bpinv, gc = _peaks_consts()
+    c0, c1, ql, ke, sigma = consts
+    f = np.float32
+    p = _peaks_fma32(c1, pod32, c0)
+    with np.errstate(all="ignore"):
+        y = np.fmin((ql * pod32).astype(f), f(41.0))
+    e = np.exp2(y.astype(np.float64)).astype(f)
+    k = np.where(e > f(1e-30), rng.integers(-ulps, ulps + 1, size=e.shape), 0).astype(np.int32)  # (v_exp_f32 flushes below 2^-126: exactly 0 there)
+    e = (e.view(np.int32) + k).view(f)
+    est = (ke * (e - f(1))).astype(f)
+    w = _peaks_fma32(np.abs(ke), e, np.abs(ke))
+    b = _peaks_fma32(w, _peaks_fma32(np.abs(y), beta, alpha), sigma)
+    g = np.clip(_peaks_fma32(p, -bpinv, np.broadcast_to(gc, p.shape)), f(0), f(1)).astype(f)
+    am = _peaks_fma32(-g, g, g)
+    bg = _peaks_fma32(b, g, (am * huge).astype(f))
+    eg = (est * g).astype(f)
+    return (eg - bg).astype(f), (eg + bg).astype(f)
+
+
+def _peaks_exact(cap, util, k1, k2, valid, pod):
+    cap = cap.astype(np.float64)
+    with np.errstate(all="ignore"):
+        util_m = (util / 100) * cap
+        pred = np.where(cap != 0, 100 * (util_m + pod) / np.where(cap != 0, cap, 1), 0.0)
+        v = np.trunc(k1 * (np.exp(k2 * pred) - np.exp(k2 * util)) * 1e15)
+    return np.where(valid & ~(pred > 100), v, 0.0)
+
+
+def _peaks_snapshot(rng, n_nodes, n_pods, regime):
+    cap = rng.choice([1000, 2000, 4000, 8000, 16000, 64000, 96000, 128000, 3, 250], n_nodes).astype(np.int64)
+    util = rng.uniform(0, 100, n_nodes)
+    k1 = -rng.uniform(40, 160, n_nodes)
+    k2 = -rng.uniform(0.02, 0.12, n_nodes)
+    valid = rng.random(n_nodes) > 0.03
+    k1[rng.random(n_nodes) < 0.05] = 0.0  # nodes without a power model (peaks.go:190-196)
+    k2[k1 == 0] = 0.0
+    pod = rng.integers(0, 4000, n_pods).astype(np.int64)
+    if regime == "near100":  # predicted on / next to 100 for one of the pods
+        i = rng.integers(0, n_pods, n_nodes)
+        util = 100 - 100.0 * pod[i] / cap + rng.choice([0, 1e-9, -1e-9, 1e-6, -1e-6, 1e-4, -1e-4, 3e-4, -3e-4, 1e-3], n_nodes)
+    elif regime == "wild":
+        k1 = rng.choice([0.0, 1e-12, -1e-9, 5.0, -3000.0, 1e6, -1e12, np.nan, np.inf], n_nodes)
+        k2 = rng.choice([0.0, -0.07, 0.07, -3.0, 2.0, 1e-9, -40.0, np.nan], n_nodes)
+        util = rng.choice([0.0, 50.0, 100.0, 150.0, -20.0, 1e6, np.nan], n_nodes)
+        cap = rng.choice([0, 1, 1000, 64000, 10 ** 9], n_nodes).astype(np.int64)
+        pod = rng.choice([0, 1, 500, 10 ** 5, 10 ** 8, 3 * 10 ** 7 + 1], n_pods).astype(np.int64)
+    elif regime == "steep":  # exponents up to the precondition's limit, both signs
+        k1 = -rng.uniform(40, 160, n_nodes) * rng.choice([1, -1, 1e-3, 1e3], n_nodes)
+        k2 = rng.uniform(-0.27, 0.27, n_nodes)
+        cap = rng.choice([1000, 4000, 64000, 128000], n_nodes).astype(np.int64)
+    elif regime == "zero_cpu":
+        pod[:] = 0
+    elif regime == "identical":
+        cap[:], util[:], k1[:], k2[:] = 64000, 37.5, -91.5, -0.0718
+    return cap, util, k1, k2, valid, pod
+
+
+def test_peaks_interval_contains_the_float64_score():
+    worst = 0.0
+    for regime in ("plain", "near100", "wild", "steep", "zero_cpu", "identical"):
+        for seed in range(2):
+            rng = np.random.default_rng(100 + seed)
+            cap, util, k1, k2, valid, pod = _peaks_snapshot(rng, 2500, 500, regime)
+            consts, forced = _peaks_node_consts(cap, util, k1, k2, valid)
+            lo, hi = _peaks_interval(tuple(x[None, :] for x in consts), pod.astype(np.float32)[:, None], rng)
+            v = _peaks_exact(cap[None, :], util[None, :], k1[None, :], k2[None, :], valid[None, :], pod[:, None].astype(np.float64))
+            forced = np.broadcast_to(forced[None, :], v.shape)
+            # a node outside the preconditions is undecided in every row: the widest interval the kernel ever forms
+            assert (hi[forced] > np.float32(1e37)).all() and (lo[forced] < np.float32(-1e37)).all()
+            ok = ~forced
+            assert np.isfinite(v[ok]).all(), regime
+            assert ((lo.astype(np.float64) <= v) & (v <= hi.astype(np.float64)))[ok].all(), regime
+            known = (lo == hi) & ok
+            assert (v[known] == 0).all() and (lo[known] == 0).all(), regime  # lo == hi happens only at 0 and then IS the score
+            sel = ok & ~known & (hi < np.float32(1e30))
+            if sel.any():
+                half = (hi.astype(np.float64) - lo.astype(np.float64))[sel] / 2
+                mid = (hi.astype(np.float64) + lo.astype(np.float64))[sel] / 2
+                worst = max(worst, float((np.abs(v[sel] - mid) / half).max()))
+    assert worst < 0.5, worst  # the bound has a factor of two to spare against a 3-ulp exp2
+
+
+def test_peaks_estimate_passes_decide_what_the_float64_passes_decide():
+    """pass 1: the extremes of every (row, 1024-node tile) are among the undecided cells + the known zeros; pass 2: a cell the interval
+    decides gets the byte of the float64 NormalizeScore"""
+    f = np.float32
+    for regime in ("plain", "near100", "steep", "zero_cpu", "identical"):
+        rng = np.random.default_rng(7)
+        cap, util, k1, k2, valid, pod = _peaks_snapshot(rng, 2048, 300, regime)
+        consts, forced = _peaks_node_consts(cap, util, k1, k2, valid)
+        lo, hi = _peaks_interval(tuple(x[None, :] for x in consts), pod.astype(f)[:, None], rng)
+        v = _peaks_exact(cap[None, :], util[None, :], k1[None, :], k2[None, :], valid[None, :], pod[:, None].astype(np.float64))
+        feas = rng.random(v.shape) > (0.3 if regime != "identical" else 0.0)
+        feas[:, :5] = True
+        lo_m, hi_m = np.where(feas, lo, f(np.nan)), np.where(feas, hi, f(np.nan))
+        n_und = 0
+        for t0 in range(0, v.shape[1], 1024):
+            sl = slice(t0, t0 + 1024)
+            with np.errstate(all="ignore"):
+                maxlo = np.fmax.reduce(lo_m[:, sl], axis=1, initial=f(-np.inf))[:, None]
+                minhi = np.fmin.reduce(hi_m[:, sl], axis=1, initial=f(np.inf))[:, None]
+                und = ((hi_m[:, sl] >= maxlo) | (lo_m[:, sl] <= minhi)) & (hi_m[:, sl] > lo_m[:, sl])
+                zero = (lo_m[:, sl] == hi_m[:, sl])
+            vv = v[:, sl]
+            # (a node outside the preconditions may score NaN — exp overflow; fmin / fmax skip it in the kernels, old and new)
+            got_mn = np.fmin(np.fmin.reduce(np.where(und, vv, np.inf), axis=1), np.where(zero.any(axis=1), 0.0, np.inf))
+            got_mx = np.fmax(np.fmax.reduce(np.where(und, vv, -np.inf), axis=1), np.where(zero.any(axis=1), 0.0, -np.inf))
+            want_mn, want_mx = np.fmin.reduce(np.where(feas[:, sl], vv, np.inf), axis=1), np.fmax.reduce(np.where(feas[:, sl], vv, -np.inf), axis=1)
+            assert (got_mn == want_mn).all() and (got_mx == want_mx).all(), regime
+            n_und += int((und & ~forced[None, sl]).sum())
+        if regime == "plain":
+            assert n_und < 0.01 * feas.sum(), n_und  # a few cells per (row, tile) next to the nodes outside the preconditions, not the tile
+        # ---- pass 2
+        mn = np.fmin.reduce(np.where(feas, v, np.inf), axis=1)
+        mx = np.fmax.reduce(np.where(feas, v, -np.inf), axis=1)
+        gen = ~((mn == 0) & (mx == 0)) & (mn != mx) & (np.abs(mn) < 2.0 ** 62) & (np.abs(mx) < 2.0 ** 62)  # (the row statistic is an int64 pair)
+        span = np.where(gen, mx - mn, 1.0)
+        with np.errstate(all="ignore"):
+            want = 100 - np.trunc(100.0 * (v - mn[:, None]) / span[:, None])
+        r = 100.0 / span
+        mr = mn * r
+        en = (6.0 * 2.0 ** -24 * (np.abs(mr) + 101.0)).astype(f)
+        clo, chi = (-mr).astype(f) - en, (-mr).astype(f) + en
+        nlo = _peaks_fma32(lo, r.astype(f)[:, None], clo[:, None])
+        nhi = _peaks_fma32(hi, r.astype(f)[:, None], chi[:, None])
+        with np.errstate(all="ignore"):
+            klo = np.minimum(np.fmax(nlo, f(0)), f(1e6)).astype(np.uint32)
+            khi = np.minimum(np.fmax(nhi, f(0)), f(1e6)).astype(np.uint32)
+        decided = (klo == khi) & feas & gen[:, None]
+        got = 100 - np.minimum(khi, 100).astype(np.int64)
+        assert (got[decided] == want[decided]).all(), regime
+        if regime == "plain":
+            assert decided[:, ~forced].sum() > 0.97 * (feas & gen[:, None])[:, ~forced].sum()
