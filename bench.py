@@ -800,8 +800,9 @@ def main() -> None:
                 "traffic": counters.get("traffic") if counters else None,
                 "kernel": {"nrt": "spx::k_nrt_fast (Filter launch + Score launch, both counted)", "net": "spx::k_net_cls",
                            "lroc": "spx::k_lroc_fast (float32 quotient on exact float64 numerator/denominator, float64 fallback; VALU-bound)",
-                           "peaks": "spx::k_peaks<min/max pass> + spx::k_peaks<write pass> (VALU-bound: division + exp per cell and pass) over one row per "
-                                    "distinct pod cpu request + spx::k_rows_expand (config.pod_classes)",
+                           "peaks": "spx::k_peaks_minmax_est + k_peaks_fix_minmax + k_peaks_write_est + k_peaks_fix_write (float32 interval per cell, the float64 "
+                                    "division + exp only for the listed cells; issue-bound) over one row per distinct pod cpu request + spx::k_rows_expand "
+                                    "(config.pod_classes); SPX_OPT_PEAKS_ESTIMATE=0: spx::k_peaks<min/max pass> + spx::k_peaks<write pass>",
                            "cap": "full profile: k_quota, k_nrt_fast x2, k_net_cls, k_tlp_fast2, k_lvrb_fast, k_alloc_masked"}.get(
                     w["plugins"][0], "spx::k_tlp_fast2 (Allocatable+TLP)" + (" + spx::k_lvrb_fast" if "lvrb" in w["plugins"] else "")),
                 "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes, "frac_of_measured_copy_ceiling_6.29TBs": achieved / 6290.0,

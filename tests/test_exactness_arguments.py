@@ -467,7 +467,8 @@ def _peaks_consts():
 
 
 def _peaks_fma32(a, b, c):
-    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):  # (an interval end beyond float32 becomes inf, as on the device)
+        return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
 
 
 def _peaks_node_consts(cap, util, k1, k2, valid):
