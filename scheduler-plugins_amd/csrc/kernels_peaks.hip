@@ -229,7 +229,10 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks(PeaksArgs a, in
 // by raw_score.  A node without metrics (valid = 0) or with K1 = 0 has lo = hi = 0, which is its exact score; so has every cell
 // with g = 0.  Such cells take part in the row statistic as the value 0 and are never evaluated.  Columns past the table carry NaN
 // constants: v_max_f32 / v_min_f32 and every comparison ignore them.
-constexpr int kEstPods = 128;  // pod rows per chunk: the node constants (a float64 exp and division per node) are prepared once per chunk
+// pod rows per chunk (PeaksArgs::est_pods, a power of two in [16, 128] chosen per launch by peaks_est_plan so that the sweep has some 8 waves per
+// SIMD to offer: one row per distinct request of config #2 is 12 120 rows x 10 tiles — at 128 rows per chunk that is 950 waves for 1024 SIMDs)
+constexpr int kEstPodsMax = 128, kEstPodsMin = 16;
+constexpr int64_t kEstWavesWanted = 8192;
 constexpr float kEstBeta = 5.0f * 0x1p-24f, kEstAlpha = 12.0f * 0x1p-24f;
 constexpr float kEstHuge = 1e38f;
 constexpr float kEstBpInv = 1024.0f;
@@ -352,8 +355,7 @@ __device__ __forceinline__ void est_interval(const NodeE& ne, float pod32, float
 //   dense    many (a pod that requests no cpu: every jump is rounding noise and the interval decides nothing; a tile of nodes outside
 //            the preconditions; a full segment): ONE entry (row, -1) names the whole tile, and the second launch runs every cell of it
 //            through raw_score, a wave per tile as k_peaks does.  The sweeps themselves hold no float64 code: 2 -> 4-5 waves per SIMD.
-constexpr int kEstSegPerPod = 3;                       // segment entries per pod row of a chunk
-constexpr int kEstSegCap = kEstSegPerPod * kEstPods;   // entries per wave: 3 KB
+constexpr int kEstSegPerPod = 3;                       // segment entries per pod row of a chunk (a segment: 3 * est_pods entries)
 constexpr int kEstSparseLanes = 12;                    // more lanes than this with undecided cells: dense
 
 struct SegEntry {
@@ -377,12 +379,13 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks_minmax_est(Peak
   const int tile = static_cast<int>(unit % n_tiles);
   const int64_t chunk = unit / n_tiles;
   const int64_t n_rows = a.row_list ? a.n_list : a.row_end - a.row_begin;
-  const int64_t i0 = chunk * kEstPods;
+  const int est_pods = a.est_pods, seg_cap = kEstSegPerPod * est_pods;  // uniform
+  const int64_t i0 = chunk * est_pods;
   if (i0 >= n_rows) return;  // wave-uniform
-  const int64_t i1 = (i0 + kEstPods < n_rows) ? i0 + kEstPods : n_rows;
+  const int64_t i1 = (i0 + est_pods < n_rows) ? i0 + est_pods : n_rows;
   const int64_t node0 = (static_cast<int64_t>(tile) * kWave + lane) * kNpl;
   const bool active = node0 < a.row_stride;  // all 64 lanes stay in the loop: the reductions below run across them
-  SegEntry* const seg = reinterpret_cast<SegEntry*>(a.seg) + unit * kEstSegCap;
+  SegEntry* const seg = reinterpret_cast<SegEntry*>(a.seg) + unit * seg_cap;
   int seg_n = 0;  // wave-uniform
 
   NodeE ne[kNpl];
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks_minmax_est(Peak
     const bool multi = __ballot((cand & (cand - 1u)) != 0u) != 0ull;
     const bool zero_any = __ballot(zero) != 0ull;
     const int left = static_cast<int>(i1 - i - 1);  // every later row of the chunk keeps room for one entry
-    if (!multi && n_any <= kEstSparseLanes && seg_n + n_any + left <= kEstSegCap) {  // uniform
+    if (!multi && n_any <= kEstSparseLanes && seg_n + n_any + left <= seg_cap) {  // uniform
       if (cand != 0u) seg[seg_n + lanes_below(any)] = SegEntry{static_cast<int32_t>(pod), static_cast<int32_t>(node0 + __builtin_ctz(cand))};
       seg_n += n_any;
       if (lane == 0 && zero_any) {
@@ -459,7 +462,7 @@ template <int kNpl, bool kMask>
 __global__ __launch_bounds__(kWave) void k_peaks_fix_minmax(PeaksArgs a, int n_tiles) {
   const int lane = threadIdx.x;
   const int n = uload(a.seg_n + blockIdx.x);
-  const SegEntry* seg = reinterpret_cast<const SegEntry*>(a.seg) + static_cast<int64_t>(blockIdx.x) * kEstSegCap;
+  const SegEntry* seg = reinterpret_cast<const SegEntry*>(a.seg) + static_cast<int64_t>(blockIdx.x) * (kEstSegPerPod * a.est_pods);
   const int tile = static_cast<int>(blockIdx.x % static_cast<unsigned>(n_tiles));
   const int64_t base = static_cast<int64_t>(tile) * kWave * kNpl + lane;
   const double* raw0 = a.node_tab + 7 * a.row_stride;
@@ -554,12 +557,13 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks_write_est(Peaks
   const int tile = static_cast<int>(unit % n_tiles);
   const int64_t chunk = unit / n_tiles;
   const int64_t n_rows = a.row_list ? a.n_list : a.row_end - a.row_begin;
-  const int64_t i0 = chunk * kEstPods;
+  const int est_pods = a.est_pods, seg_cap = kEstSegPerPod * est_pods;  // uniform
+  const int64_t i0 = chunk * est_pods;
   if (i0 >= n_rows) return;  // wave-uniform
-  const int64_t i1 = (i0 + kEstPods < n_rows) ? i0 + kEstPods : n_rows;
+  const int64_t i1 = (i0 + est_pods < n_rows) ? i0 + est_pods : n_rows;
   const int64_t node0 = (static_cast<int64_t>(tile) * kWave + lane) * kNpl;
   const bool active = node0 < a.row_stride;
-  SegEntry* const seg = reinterpret_cast<SegEntry*>(a.seg) + unit * kEstSegCap;
+  SegEntry* const seg = reinterpret_cast<SegEntry*>(a.seg) + unit * seg_cap;
   int seg_n = 0;  // wave-uniform
 
   NodeE ne[kNpl];
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_peaks_write_est(Peaks
           bool tile_entry = __builtin_popcountll(any) > kEstSparseLanes;
           while (!tile_entry && any != 0ull) {  // listed: the first undecided cell of every lane that has one, until none is left
             const int n_any = __builtin_popcountll(any);
-            if (seg_n + n_any + left > kEstSegCap) {
+            if (seg_n + n_any + left > seg_cap) {
               tile_entry = true;
               break;
             }
@@ -675,7 +679,7 @@ template <int kNpl, bool kMask>
 __global__ __launch_bounds__(kWave) void k_peaks_fix_write(PeaksArgs a, int n_tiles) {
   const int lane = threadIdx.x;
   const int n = uload(a.seg_n + blockIdx.x);
-  const SegEntry* seg = reinterpret_cast<const SegEntry*>(a.seg) + static_cast<int64_t>(blockIdx.x) * kEstSegCap;
+  const SegEntry* seg = reinterpret_cast<const SegEntry*>(a.seg) + static_cast<int64_t>(blockIdx.x) * (kEstSegPerPod * a.est_pods);
   const int tile = static_cast<int>(blockIdx.x % static_cast<unsigned>(n_tiles));
   const int64_t base = static_cast<int64_t>(tile) * kWave * kNpl + lane;
   const double* raw0 = a.node_tab + 7 * a.row_stride;
@@ -738,13 +742,16 @@ __global__ void k_peaks_raw(PeaksArgs a) {  // Score() of one pod row as int64 (
 
 }  // namespace
 
-// scratch of the interval-estimate passes for a sweep of `swept` rows: one list segment and one counter per wave
-void peaks_est_scratch(uint32_t opts, int64_t row_stride, int64_t swept, size_t* seg_bytes, size_t* cnt_bytes) {
+// the interval-estimate passes for a sweep of `swept` rows: pod rows per chunk, and the scratch — one list segment and one counter per wave
+int peaks_est_plan(uint32_t opts, int64_t row_stride, int64_t swept, size_t* seg_bytes, size_t* cnt_bytes) {
   const int npl = (opts & kOptPeaksEst8) ? 8 : 16;
   const int64_t nt = (row_stride + kWave * npl - 1) / (kWave * npl);
-  const int64_t waves = ((swept + kEstPods - 1) / kEstPods) * nt;
-  *seg_bytes = static_cast<size_t>(waves) * kEstSegCap * sizeof(SegEntry);
+  int est_pods = kEstPodsMax;
+  while (est_pods > kEstPodsMin && ((swept + est_pods - 1) / est_pods) * nt < kEstWavesWanted) est_pods >>= 1;
+  const int64_t waves = ((swept + est_pods - 1) / est_pods) * nt;
+  *seg_bytes = static_cast<size_t>(waves) * kEstSegPerPod * est_pods * sizeof(SegEntry);
   *cnt_bytes = static_cast<size_t>(waves) * sizeof(int32_t);
+  return est_pods;
 }
 
 void launch_peaks(const PeaksArgs& a, hipStream_t s) {
@@ -761,7 +768,7 @@ void launch_peaks(const PeaksArgs& a, hipStream_t s) {
     const bool mask = a.other_status[0] || a.other_status[1] || a.other_status[2];
     const int npl = (a.opts & kOptPeaksEst8) ? 8 : 16;
     const int nt = static_cast<int>((a.row_stride + kWave * npl - 1) / (kWave * npl));
-    const int64_t waves = ((swept + kEstPods - 1) / kEstPods) * nt;  // = peaks_est_waves: one list segment each
+    const int64_t waves = ((swept + a.est_pods - 1) / a.est_pods) * nt;  // (est_pods: peaks_est_plan) one list segment each
     const dim3 g(static_cast<unsigned>((waves + kWavesPerBlock - 1) / kWavesPerBlock)), blk(kWave * kWavesPerBlock);
     hipLaunchKernelGGL(k_peaks_nodetab, dim3(static_cast<unsigned>((a.n_nodes + 255) / 256)), dim3(256), 0, s, a);
     if (npl == 8) {

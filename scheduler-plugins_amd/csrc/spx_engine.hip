@@ -2418,7 +2418,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     }
     if (ka.opts & spx::kOptPeaksEstimate) {  // the undecided cells' list: sized by the rows this sweep walks
       size_t seg_bytes = 0, cnt_bytes = 0;
-      spx::peaks_est_scratch(ka.opts, e->row_stride, classes ? ka.n_list : row_end - row_begin, &seg_bytes, &cnt_bytes);
+      ka.est_pods = spx::peaks_est_plan(ka.opts, e->row_stride, classes ? ka.n_list : row_end - row_begin, &seg_bytes, &cnt_bytes);
       if ((rc = ensure(e, e->d_pk_seg, seg_bytes)) || (rc = ensure(e, e->d_pk_segn, cnt_bytes))) return rc;
       ka.seg = e->d_pk_seg.p;
       ka.seg_n = static_cast<int32_t*>(e->d_pk_segn.p);

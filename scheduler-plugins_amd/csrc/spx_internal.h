@@ -217,6 +217,7 @@ struct PeaksArgs {
   double* node_tab;              // scratch of the interval-estimate passes: 96 bytes per column of a row (k_peaks_nodetab)
   void* seg;                     // the undecided cells' list: a segment per wave (peaks_est_scratch)
   int32_t* seg_n;                // entries per segment
+  int32_t est_pods;              // pod rows per chunk of the interval-estimate sweeps (peaks_est_plan)
   uint8_t* out_score;            // [P][row_stride]
   int64_t* out_raw;              // when set: raw int64 scores of row_begin only, no table writes
   // when set: the sweep walks these n_list rows — the first row of each distinct pod cpu request, ascending — instead of
@@ -225,7 +226,7 @@ struct PeaksArgs {
   int64_t n_list;
 };
 void launch_peaks(const PeaksArgs& a, hipStream_t s);
-void peaks_est_scratch(uint32_t opts, int64_t row_stride, int64_t swept, size_t* seg_bytes, size_t* cnt_bytes);
+int peaks_est_plan(uint32_t opts, int64_t row_stride, int64_t swept, size_t* seg_bytes, size_t* cnt_bytes);
 
 // ---------------------------------------------------------------- NodeResourceTopologyMatch
 struct NrtArgs {

@@ -11,10 +11,13 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+only = set(sys.argv[2:])  # optional: the workloads to collect (default: every gpurun_out/prof_* directory)
 out = ROOT / "profiles" / rnd
 out.mkdir(parents=True, exist_ok=True)
 for d in sorted((ROOT / "gpurun_out").glob("prof_*")):
     w = d.name[len("prof_"):]
+    if only and w not in only:
+        continue
     stats = d / "trace" / "t_kernel_stats.csv"
     if not stats.exists():
         continue
@@ -22,7 +25,7 @@ for d in sorted((ROOT / "gpurun_out").glob("prof_*")):
     rows = list(csv.DictReader(open(stats)))
     # the dominant SWEEP kernel: one-off kernels of the same command (the sequential commit loop, the argmax, prepare
     # steps, copies) are listed in the stats CSV but are not what bench.py's roofline line describes
-    sweep = [r for r in rows if any(k in r["Name"] for k in ("k_tlp_fast", "k_lvrb_fast", "k_trimaran<", "k_nrt", "k_net", "k_alloc_masked", "k_lroc", "k_peaks<", "k_quota", "k_rows_expand"))]
+    sweep = [r for r in rows if any(k in r["Name"] for k in ("k_tlp_fast", "k_lvrb_fast", "k_trimaran<", "k_nrt", "k_net", "k_alloc_masked", "k_lroc", "k_peaks<", "k_peaks_minmax", "k_peaks_write", "k_peaks_fix", "k_quota", "k_rows_expand"))]
     dom = max(sweep or rows, key=lambda r: float(r["TotalDurationNs"]))
     bench_line = [l for l in open(d / "trace.log") if l.startswith("{")]
     summ = {"workload": w, "dominant_kernel": dom["Name"], "rocprof_avg_ns": float(dom["AverageNs"]), "calls": int(dom["Calls"])}
