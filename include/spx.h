@@ -757,7 +757,8 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *                              extremes, the cells next to a step of floor(100 (raw - min) / span), nodes outside the interval's
  *                              preconditions — listed by the sweep and evaluated by a second launch with every lane busy; rows in which
  *                              the interval decides little (a pod that requests no cpu) take the float64 sequence for the whole tile;
- *                              8 = the same with 8 instead of 16 nodes per lane; 0 = the float64 sequence for every cell.  Same tables either way
+ *                              8 = the same with 8 instead of 16 nodes per lane; 0 = the float64 sequence for every cell.  Same tables either way.
+ *                              (The interval's bounds assume cpu requests >= 0: a batch that holds a negative one runs the float64 passes)
  */
 #define SPX_OPT_ROW_ALIGN 0
 #define SPX_OPT_REFERENCE_KERNELS 1

@@ -764,7 +764,8 @@ void launch_peaks(const PeaksArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_peaks_init, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0, s, a.row_min, a.row_max, a.row_begin, a.row_end);
   const int64_t swept = a.row_list ? a.n_list : rows;
   const int64_t chunks = (swept + kPodsPerChunk - 1) / kPodsPerChunk;
-  if (a.opts & kOptPeaksEstimate) {  // interval estimates; raw_score where they cannot decide
+  // interval estimates, raw_score where they cannot decide — when the caller planned them (peaks_est_plan) and brought the scratch
+  if ((a.opts & kOptPeaksEstimate) && a.est_pods > 0 && a.seg && a.seg_n && a.node_tab && a.row_c) {
     const bool mask = a.other_status[0] || a.other_status[1] || a.other_status[2];
     const int npl = (a.opts & kOptPeaksEst8) ? 8 : 16;
     const int nt = static_cast<int>((a.row_stride + kWave * npl - 1) / (kWave * npl));

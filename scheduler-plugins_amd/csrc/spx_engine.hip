@@ -137,6 +137,7 @@ struct spx_engine {
   int last_nrt_filter = 0;         // spx_nrt_filter_path
   DevBuf d_pk_uniq, d_pk_dups;    // the same for Peaks: classes of pods with equal cpu requests
   int64_t pk_n_uniq = 0, pk_n_dups = 0;
+  bool pk_negative = false;  // a Peaks pod row with a negative cpu request (never from a v1.Pod): the interval estimate's bounds assume >= 0
   bool nrt_ln_ok = false;  // LeastNUMANodes tables can be built: every zone cost within [0, 255]
   bool nrt_ln_built = false;
   std::vector<int32_t> h_nrt_cost;  // [N][Z][Z] host copy of the zone costs, what build_ln_tab works from
@@ -1205,6 +1206,9 @@ int spx_upload_peaks_pods(spx_engine* e, const spx_peaks_pods_soa* t) {
   // raw scores always, normalised scores when every pod's node list is the whole snapshot.  First row of each distinct value
   // (flat open-addressing table, rows in order), the others as (row, representative) pairs.
   e->pk_n_uniq = e->pk_n_dups = 0;
+  e->pk_negative = false;
+  for (int64_t i = 0; i < t->n_pods; ++i)
+    if (t->cpu_milli[i] < 0) e->pk_negative = true;
   if (t->n_pods > 1) {
     const size_t p = static_cast<size_t>(t->n_pods);
     size_t cap = 64;
@@ -2416,6 +2420,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
       ka.row_list = static_cast<const int32_t*>(e->d_pk_uniq.p);
       ka.n_list = e->pk_n_uniq;
     }
+    if (e->pk_negative) ka.opts &= ~spx::kOptPeaksEstimate;  // (the float64 passes take whatever the table holds)
     if (ka.opts & spx::kOptPeaksEstimate) {  // the undecided cells' list: sized by the rows this sweep walks
       size_t seg_bytes = 0, cnt_bytes = 0;
       ka.est_pods = spx::peaks_est_plan(ka.opts, e->row_stride, classes ? ka.n_list : row_end - row_begin, &seg_bytes, &cnt_bytes);

@@ -281,3 +281,21 @@ def test_estimate_with_awkward_nodes(gpu_required, hdr):
             e.sync()
             got = e.all_scores(PEAKS)
             assert np.array_equal(got, want), (v, int((got != want).sum()))
+
+
+def test_estimate_stands_down_for_a_negative_request(gpu_required, hdr):
+    """the interval's bounds assume cpu requests >= 0 (a v1.Pod cannot say otherwise; the C ABI can): with a negative one in the batch the
+    float64 passes run whatever the option says — same table, and k_peaks_nodetab's scratch is never needed"""
+    snap = snapshot(hdr, 900, 200, 41)
+    with Engine(0) as e:
+        f = e.flatten_peaks(snap["nodes"], snap["metrics"], snap["power_models"], snap["pods"])
+        f["pods"]["cpu_milli"][3] = -500
+        f["pods"]["cpu_milli"][77] = -1
+        e.upload_peaks(f)
+        tables = []
+        for v in (0, 1, 8):
+            e.set_option("PEAKS_ESTIMATE", v)
+            e.eval(mask_of(PEAKS))
+            e.sync()
+            tables.append(e.all_scores(PEAKS).copy())
+        assert np.array_equal(tables[0], tables[1]) and np.array_equal(tables[0], tables[2]) and tables[0].any()
