@@ -446,7 +446,7 @@ def test_balanced_allocation_float32_score_is_exact_outside_the_band():
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# k_peaks_minmax_est / k_peaks_write_est (kernels_peaks.hip, SPX_OPT_PEAKS_ESTIMATE): the float32 interval of a cell's raw score
+# k_peaks_minmax_est / k_peaks_write_est (kernels_peaks.hip + peaks_est.h, SPX_OPT_PEAKS_ESTIMATE): the float32 interval of a cell's raw score
 # contains the value of the float64 sequence; the cells the two passes leave to raw_score are a superset of the cells that matter.
 # The replay below is the kernels' arithmetic in numpy float32 (fma through float64: the product of two float32 is exact there),
 # with v_exp_f32 modelled as the correctly rounded 2^y perturbed by up to 3 ulp either way.
@@ -454,7 +454,7 @@ def test_balanced_allocation_float32_score_is_exact_outside_the_band():
 def _peaks_consts():
     import re
     from pathlib import Path
-    src = (Path(__file__).resolve().parent.parent / "scheduler-plugins_amd" / "csrc" / "kernels_peaks.hip").read_text()
+    src = (Path(__file__).resolve().parent.parent / "scheduler-plugins_amd" / "csrc" / "peaks_est.h").read_text()
 
     def c(name):
         return re.search(r"\b" + name + r" = ([^,;]+)[,;]", src).group(1).strip()
@@ -467,8 +467,24 @@ def _peaks_consts():
 
 
 def _peaks_fma32(a, b, c):
+    """fmaf on float32 arrays, correctly rounded: the product of two float32 is exact in float64; the sum is taken with its rounding error
+    (TwoSum), and where the float64 sum sits exactly half-way between two float32 the error decides the direction (the float64 -> float32
+    conversion alone would round such a tie to even, whichever side the exact value is on)"""
+    f = np.float32
     with np.errstate(over="ignore", invalid="ignore"):  # (an interval end beyond float32 becomes inf, as on the device)
-        return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+        pr = np.asarray(a, np.float64) * np.asarray(b, np.float64)
+        cc = np.broadcast_to(np.asarray(c, np.float64), pr.shape)
+        sm = pr + cc
+        bb = sm - pr
+        err = (pr - (sm - bb)) + (cc - bb)
+        r = sm.astype(f)
+        d = sm - r.astype(np.float64)
+        tie = np.isfinite(r) & (np.abs(d) * 2 == np.spacing(np.abs(r)).astype(np.float64)) & (err != 0) & np.isfinite(err)
+        if tie.any():
+            up = np.where(d > 0, np.nextafter(r, f(np.inf)), r)
+            dn = np.where(d > 0, r, np.nextafter(r, f(-np.inf)))
+            r = np.where(tie, np.where(err > 0, up, dn), r)
+        return r
 
 
 def _peaks_node_consts(cap, util, k1, k2, valid):
@@ -493,24 +509,30 @@ def _peaks_node_consts(cap, util, k1, k2, valid):
                 np.where(z | (k1 == 0), 0.0, ke).astype(f), np.where(z, 0.0, sigma).astype(f)), valid & ~tame
 
 
-def _peaks_interval(consts, pod32, rng, ulps=3):
+def _peaks_interval_from(consts, pod32, y, e):
     beta, alpha, huge, bpinv, gc = _peaks_consts()
     c0, c1, ql, ke, sigma = consts
     f = np.float32
     p = _peaks_fma32(c1, pod32, c0)
-    with np.errstate(all="ignore"):
-        y = np.fmin((ql * pod32).astype(f), f(41.0))
-    e = np.exp2(y.astype(np.float64)).astype(f)
-    k = np.where(e > f(1e-30), rng.integers(-ulps, ulps + 1, size=e.shape), 0).astype(np.int32)  # (v_exp_f32 flushes below 2^-126: exactly 0 there)
-    e = (e.view(np.int32) + k).view(f)
     est = (ke * (e - f(1))).astype(f)
     w = _peaks_fma32(np.abs(ke), e, np.abs(ke))
     b = _peaks_fma32(w, _peaks_fma32(np.abs(y), beta, alpha), sigma)
-    g = np.clip(_peaks_fma32(p, -bpinv, np.broadcast_to(gc, p.shape)), f(0), f(1)).astype(f)
+    with np.errstate(invalid="ignore"):
+        g = np.fmin(np.fmax(_peaks_fma32(p, -bpinv, np.broadcast_to(gc, p.shape)), f(0)), f(1)).astype(f)
     am = _peaks_fma32(-g, g, g)
     bg = _peaks_fma32(b, g, (am * huge).astype(f))
     eg = (est * g).astype(f)
     return (eg - bg).astype(f), (eg + bg).astype(f)
+
+
+def _peaks_interval(consts, pod32, rng, ulps=3):
+    f = np.float32
+    with np.errstate(all="ignore"):
+        y = np.fmin((consts[2] * pod32).astype(f), f(41.0))
+    e = np.exp2(y.astype(np.float64)).astype(f)
+    k = np.where(e > f(1e-30), rng.integers(-ulps, ulps + 1, size=e.shape), 0).astype(np.int32)  # (v_exp_f32 flushes below 2^-126: exactly 0 there)
+    e = (e.view(np.int32) + k).view(f)
+    return _peaks_interval_from(consts, pod32, y, e)
 
 
 def _peaks_exact(cap, util, k1, k2, valid, pod):
@@ -627,3 +649,64 @@ def test_peaks_estimate_passes_decide_what_the_float64_passes_decide():
         assert (got[decided] == want[decided]).all(), regime
         if regime == "plain":
             assert decided[:, ~forced].sum() > 0.97 * (feas & gen[:, None])[:, ~forced].sum()
+
+
+# ---- the same arithmetic from the product's own source: csrc/peaks_est.h compiled for the host (tests/cpp/peaks_est_check.cc)
+def _peaks_header_lib():
+    import ctypes as C
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    src, hdr = root / "tests" / "cpp" / "peaks_est_check.cc", root / "scheduler-plugins_amd" / "csrc" / "peaks_est.h"
+    lib = root / "tests" / "cpp" / "_build" / "libpeaks_est_check.so"
+    if not lib.exists() or lib.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+        lib.parent.mkdir(exist_ok=True)
+        subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", str(src), "-o", str(lib), "-lm"], check=True)
+    L = C.CDLL(str(lib))
+    dp, fp, bp, i64 = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_int64
+    L.peaks_est_check_nodes.argtypes = [i64, dp, dp, dp, dp, dp, bp, fp]
+    L.peaks_est_check_exponents.argtypes = [i64, i64, fp, fp, fp]
+    L.peaks_est_check_intervals.argtypes = [i64, i64, fp, fp, fp, fp, fp]
+    L.peaks_est_check_intervals_host_exp.argtypes = [i64, i64, fp, fp, fp, fp]
+    return L, (dp, fp, bp)
+
+
+def test_peaks_header_computes_what_the_replay_computes():
+    """peaks_est.h — the source the kernels are compiled from — against the numpy replay above, bit for bit: the per-node constants
+    (incl. which nodes are outside the preconditions), the exponent handed to the exponential, and the interval for a given e; so what
+    the two tests above establish for the replay holds for the device code's arithmetic, v_exp_f32's 3 ulp aside"""
+    L, (dp, fp, bp) = _peaks_header_lib()
+    f = np.float32
+    cells = 0
+    for regime in ("plain", "near100", "wild", "steep", "zero_cpu", "identical"):
+        rng = np.random.default_rng(11)
+        cap, util, k1, k2, valid, pod = _peaks_snapshot(rng, 1500, 300, regime)
+        consts, forced = _peaks_node_consts(cap, util, k1, k2, valid)
+        n, m = len(cap), len(pod)
+        with np.errstate(all="ignore"):
+            e_now = np.exp(k2 * util)
+        capd, v8 = cap.astype(np.float64), valid.astype(np.uint8)
+        got = np.zeros((n, 5), f)
+        L.peaks_est_check_nodes(n, capd.ctypes.data_as(dp), np.ascontiguousarray(util).ctypes.data_as(dp), e_now.ctypes.data_as(dp),
+                                np.ascontiguousarray(k1, np.float64).ctypes.data_as(dp), np.ascontiguousarray(k2, np.float64).ctypes.data_as(dp), v8.ctypes.data_as(bp), got.ctypes.data_as(fp))
+        want = np.stack(consts, axis=1)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (regime, np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=1))[0][:5])
+        assert np.array_equal((got[:, 0] == 100) & (got[:, 1:] == 0).all(axis=1) & valid, forced | ((want[:, 0] == 100) & (want[:, 1:] == 0).all(axis=1) & valid))
+        pod32 = pod.astype(f)
+        y = np.zeros((m, n), f)
+        L.peaks_est_check_exponents(m, n, got.ctypes.data_as(fp), pod32.ctypes.data_as(fp), y.ctypes.data_as(fp))
+        with np.errstate(all="ignore"):
+            y_want = np.fmin((consts[2][None, :] * pod32[:, None]).astype(f), f(41.0))
+        assert np.array_equal(y.view(np.uint32), y_want.view(np.uint32)), regime
+        with np.errstate(all="ignore"):
+            e = np.exp2(y.astype(np.float64)).astype(f)
+        k = np.where(e > f(1e-30), rng.integers(-3, 4, size=e.shape), 0).astype(np.int32)
+        e = (e.view(np.int32) + k).view(f)
+        lo, hi = np.zeros((m, n), f), np.zeros((m, n), f)
+        L.peaks_est_check_intervals(m, n, got.ctypes.data_as(fp), pod32.ctypes.data_as(fp), e.ctypes.data_as(fp), lo.ctypes.data_as(fp), hi.ctypes.data_as(fp))
+        lo_w, hi_w = _peaks_interval_from(tuple(x[None, :] for x in consts), pod32[:, None], y, e)
+        for a, b in ((lo, lo_w), (hi, hi_w)):
+            same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), (regime, int((~same).sum()))
+        cells += m * n
+    assert cells > 2_000_000
