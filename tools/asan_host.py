@@ -5,7 +5,7 @@ four sizes under AddressSanitizer + UBSan.  The host sources are compiled on the
         scheduler-plugins_amd/host/*.cc -o /tmp/asan/libhost_asan.so
     LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python tools/asan_host.py
 
-Last run: clean (round 2, including the decoder fuzz at the end).  The wire-format decoder is fuzzed the same way by tests/test_ingest_nrt.py::test_decoder_survives_mutated_input."""
+Last run: clean (round 5, including the decoder fuzz at the end; before that round 2).  The wire-format decoder is fuzzed the same way by tests/test_ingest_nrt.py::test_decoder_survives_mutated_input."""
 import ctypes as C, sys, numpy as np
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
 import scheduler_plugins_amd as spx
