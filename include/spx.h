@@ -715,7 +715,7 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *   SPX_OPT_DECIDE_UNFUSED     1 = spx_decide always runs spx_eval + spx_eval_best
  *   SPX_OPT_NRT_SINGLE_LAUNCH  1 = NRT Filter and Score in one launch (default: two for Least/MostAllocated)
  *   SPX_OPT_COMMIT_FROM_MEMORY 1 = spx_commit_sequential keeps node state in memory (any node count) instead of registers
- *   SPX_OPT_PEAKS_TILE         nodes per lane of Peaks' (min/max pass, write pass): 44 (default), 84, 48, 88
+ *   SPX_OPT_PEAKS_TILE         nodes per lane of Peaks' float64 (min/max pass, write pass) — SPX_OPT_PEAKS_ESTIMATE 0: 44 (default), 84, 48, 88
  *   SPX_OPT_NRT_POD_CLASSES    1 (default) = a whole-batch NRT sweep evaluates one representative row per class of pods whose
  *                              records agree in everything the sweep reads and copies it to the rest of the class; 0 = every row
  *   SPX_OPT_NRT_LN_LIST_PERMILLE  LeastNUMANodes, batch Score launch: room, in thousandths of the node count, of each per-(row, scope)
