@@ -280,11 +280,6 @@ constexpr int kEstSparseLanes = 12;                    // more lanes than this w
 struct SegEntry {
   int32_t row, node;
 };
-typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ SegEntry seg_uload(const SegEntry* p) {  // wave-uniform read
-  const i32x2 v = uload(reinterpret_cast<const i32x2*>(p));
-  return SegEntry{v.x, v.y};
-}
 
 __device__ __forceinline__ int lanes_below(unsigned long long mask) {  // set bits of mask below this lane
   return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u)));
