@@ -16,6 +16,10 @@
 // the write pass adds the normalising division.  VALU-bound, like LowRiskOverCommitment.
 // The arithmetic is the reference's, operation for operation; exp is OCML's, so raw scores can differ from a Go
 // evaluation in the last digits (relative ~1e-16) and normalised scores by 1 at an exact truncation boundary.
+//
+// Round 5 (default, SPX_OPT_PEAKS_ESTIMATE): the same two passes with a float32 interval per cell in front of that arithmetic —
+// k_peaks_nodetab, k_peaks_minmax_est + k_peaks_fix_minmax, k_peaks_rowconst, k_peaks_write_est + k_peaks_fix_write further down;
+// the float64 sequence above (raw_score) then runs only for the cells an interval cannot decide.  Same tables, byte for byte.
 #include <hip/hip_runtime.h>
 
 #include <climits>
