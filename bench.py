@@ -292,6 +292,63 @@ def config5_leg(hdr, device, n_pods=8192):
     return out
 
 
+def workload_leg(hdr, device, name, steps):
+    """One of BASELINE's other single-device workloads at its FULL size inside the default (config #2) line, so that the driver's
+    run — not only the builder's `--workload` lines under profiles/ — times it: config #3 (NRT Filter+Score, 5k x 8 x 50k), config #4
+    (NetworkOverhead, 10k x 200k), config #5's one-GPU share (full profile, 20k x 62.5k).  Tables resident, `steps` sweeps bracketed
+    by HIP events on the engine's stream, a fraction of a second of GPU time each."""
+    import torch
+    from scheduler_plugins_amd.engine import Engine
+    w = WORKLOADS[name]
+    n_nodes, n_pods = w["n_nodes"], w["n_pods"]
+    out = {"workload": w["desc"], "steps": steps}
+    t0 = time.perf_counter()
+    snap = build_snapshot(hdr, w, n_pods, synth_seed())
+    out["synth_s"] = time.perf_counter() - t0
+    mask = 0
+    for p in w["plugins"]:
+        mask |= 1 << PID[p]
+    algo = n_nodes * w["node_row"] + n_pods * w["pod_row"] + n_nodes * n_pods * w["out"]
+    stream = torch.cuda.current_stream(device)
+    with Engine(device) as e:
+        e.set_stream(stream.cuda_stream)
+        t0 = time.perf_counter()
+        load_tables(e, w, snap)
+        e.sync()
+        out["flatten_upload_ms"] = (time.perf_counter() - t0) * 1e3
+
+        def timed():
+            for _ in range(2):
+                e.eval(mask)
+            e.sync()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(stream)
+            for _ in range(steps):
+                e.eval(mask)
+            ev1.record(stream)
+            e.sync()
+            return ev0.elapsed_time(ev1) / steps
+
+        ms = timed()
+        out.update({"kernel_ms": ms, "evals_per_sec": n_nodes * n_pods / (ms * 1e-3), "algorithmic_bytes": algo,
+                    "achieved_GBs": algo / (ms * 1e-3) / 1e9, "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "kernel_source_hash": kernel_source_hash(w["plugins"])})
+        if "nrt" in w["plugins"]:
+            uniq, copies = e.nrt_pod_classes()
+            out["nrt_rows_evaluated"], out["nrt_rows_copied"] = uniq, copies
+            out["nrt_filter_path"] = e.nrt_filter_path()
+            e.set_option("NRT_POD_CLASSES", 0)
+            er = timed()
+            e.set_option("NRT_POD_CLASSES", 1)
+            out["every_row"] = {"kernel_ms": er, "frac": algo / (er * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "what": "SPX_OPT_NRT_POD_CLASSES off: every pod row evaluated, none copied"}
+        counters = profile_counters(name, w["plugins"])
+        if counters:
+            out["traffic"] = counters.get("traffic")
+            out.update({k: v for k, v in counters.items() if k != "traffic"})
+    return out
+
+
 def synth_seed():
     from scheduler_plugins_amd import synth
     return synth.SEED
@@ -461,6 +518,7 @@ def main() -> None:
     ap.add_argument("--verify-gather", action="store_true", help="ranks mode, strong-scaling workloads: rank 0 also evaluates the whole batch in one engine and "
                     "compares the all-gathered decisions with it (gather.mismatches; small shapes — tests)")
     ap.add_argument("--no-config5-leg", action="store_true", help="default (config2) line only: skip the bounded full-profile leg (config5_leg)")
+    ap.add_argument("--no-legs", action="store_true", help="default (config2) line only: skip the full-size config3 / config4 / config5_share legs")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -862,6 +920,13 @@ def main() -> None:
             out["config5_leg"] = config5_leg(hdr, local_rank)
         except Exception as ex:
             out["config5_leg"] = {"error": repr(ex)[:300]}
+    if rank == 0 and world == 1 and mode == "single" and args.workload == "config2" and not args.plugins and not args.sweep_only and not args.no_legs:
+        # BASELINE's other single-device workloads at full size, a few steps each (the driver's default run times them too)
+        for leg, name, n in (("config3_leg", "config3", 10), ("config4_leg", "config4", 5), ("config5_share_leg", "config5_share", 5)):
+            try:
+                out[leg] = workload_leg(hdr, local_rank, name, n)
+            except Exception as ex:
+                out[leg] = {"error": repr(ex)[:300]}
     if rank == 0 and args.cpu_budget > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(spx, snap, e0, plugins, args.cpu_budget)
     target.close()

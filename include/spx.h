@@ -759,6 +759,10 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *                              the interval decides little (a pod that requests no cpu) take the float64 sequence for the whole tile;
  *                              8 = the same with 8 instead of 16 nodes per lane; 0 = the float64 sequence for every cell.  Same tables either way.
  *                              (The interval's bounds assume cpu requests >= 0: a batch that holds a negative one runs the float64 passes)
+ *   SPX_OPT_NRT_FUSED          1 (default) = a whole-batch NodeResourceTopologyMatch sweep with the LeastAllocated strategy, unit weights and the
+ *                              preconditions of SPX_OPT_NRT_RANK_FILTER and SPX_OPT_NRT_PACKED_SCORE runs Filter and Score in ONE launch
+ *                              (kernels_nrt_fused.hip: rank-space Filter, float32 Score chain, pod records staged once); 0 = the Filter
+ *                              launch and the Score launch.  Same tables either way
  */
 #define SPX_OPT_ROW_ALIGN 0
 #define SPX_OPT_REFERENCE_KERNELS 1
@@ -778,7 +782,8 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
 #define SPX_OPT_NET_ALLOC_FUSED 15
 #define SPX_OPT_NRT_RANK_NARROW 16
 #define SPX_OPT_PEAKS_ESTIMATE 17
-#define SPX_NUM_OPTIONS 18
+#define SPX_OPT_NRT_FUSED 18
+#define SPX_NUM_OPTIONS 19
 int spx_set_option(spx_engine* e, int option, int64_t value);
 int spx_get_option(const spx_engine* e, int option, int64_t* value);
 
@@ -811,7 +816,8 @@ int spx_load_quota(spx_engine* e, const spx_pod_objects* pods, const spx_resourc
  * launches (replayed from a graph), 3 = the cooperative persistent kernel; 0 = none yet */
 int spx_commit_path(const spx_engine* e);
 /* Which Filter launch the last NodeResourceTopologyMatch sweep ran: 1 = float64 compares (k_nrt_fast / the reference-arithmetic
- * kernel), 2 = rank space (SPX_OPT_NRT_RANK_FILTER: whole-batch sweeps over pod classes); 0 = none yet */
+ * kernel), 2 = rank space (SPX_OPT_NRT_RANK_FILTER: whole-batch sweeps), 3 = rank space inside the fused Filter + Score launch
+ * (SPX_OPT_NRT_FUSED); 0 = none yet */
 int spx_nrt_filter_path(const spx_engine* e);
 /* SPX_OPT_NRT_PACKED_SCORE with the uploaded tables and parameters: 0 = the LeastAllocated Score launch keeps float64 (other strategy,
  * large weights, a slot that qualifies neither way, option off); else bit 24 set, bits 0..15 = the weighted slots (positions of the

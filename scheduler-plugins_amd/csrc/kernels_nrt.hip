@@ -491,10 +491,12 @@ void launch_nrt_creq_from_items(const uint32_t* pod_items, int n_res, int64_t n_
   hipLaunchKernelGGL(k_nrt_creq_from_items, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, pod_items, n_res, n_pods, ctr_req);
 }
 
-void launch_nrt(const NrtArgs& a, hipStream_t s) {
-  if (a.row_end <= a.row_begin) return;
+// true = the sweep ran as the fused Filter + Score launch (kernels_nrt_fused.hip)
+bool launch_nrt(const NrtArgs& a, hipStream_t s) {
+  if (a.row_end <= a.row_begin) return false;
   const bool generic_only = (a.opts & kOptNrtGeneric) != 0;  // SPX_OPT_REFERENCE_KERNELS
-  if (!generic_only && launch_nrt_fast(a, s)) return;
+  if (!generic_only && launch_nrt_fused(a, s)) return true;
+  if (!generic_only && launch_nrt_fast(a, s)) return false;
   const int n_tiles = static_cast<int>((a.n_nodes + 63) / 64);
   const int64_t chunks = (a.row_end - a.row_begin + kPodsPerUnit - 1) / kPodsPerUnit;
   const unsigned blocks = static_cast<unsigned>((chunks * n_tiles + 3) / 4);
@@ -502,7 +504,7 @@ void launch_nrt(const NrtArgs& a, hipStream_t s) {
 #define SPX_NRT_CASE(RMV, SGV)                                                               \
   if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                           \
     hipLaunchKernelGGL((k_nrt<RMV, SGV>), dim3(blocks), dim3(256), 0, s, a, n_tiles);       \
-    return;                                                                                  \
+    return false;                                                                            \
   }
   SPX_NRT_CASE(4, kSgAlloc)
   SPX_NRT_CASE(4, kSgBalanced)
@@ -511,6 +513,7 @@ void launch_nrt(const NrtArgs& a, hipStream_t s) {
   SPX_NRT_CASE(8, kSgBalanced)
   SPX_NRT_CASE(8, kSgLeastNuma)
 #undef SPX_NRT_CASE
+  return false;
 }
 
 }  // namespace spx

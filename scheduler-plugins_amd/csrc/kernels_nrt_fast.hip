@@ -1167,6 +1167,11 @@ __global__ __launch_bounds__(256) void k_nrt_pk_tab_build(NrtArgs a) {
 }
 }  // namespace
 
+void launch_nrt_pk_tab_build(const NrtArgs& a, int n_tiles, hipStream_t s) {
+  (void)hipMemsetAsync(a.pk_tab, 0, (static_cast<size_t>(a.pk_tab_kmax) + 1) * a.pk_tab_words * 4, s);
+  hipLaunchKernelGGL(k_nrt_pk_tab_build, dim3(static_cast<unsigned>(static_cast<int64_t>(n_tiles) * kWindow * kZ * 128 / 256)), dim3(256), 0, s, a);
+}
+
 bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   if (!a.fast) return false;
   if (a.strategy == SPX_NRT_LEAST_NUMA_NODES && !a.ln_tab) return false;
@@ -1182,7 +1187,7 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
 #define SPX_NRTF_CASE(RMV, SGV)                                                                           \
   if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                                        \
     if (split) { /* the Filter half does not depend on the strategy */ \
-      if (!launch_nrt_filter_rank(a, n_tiles, blocks, s)) /* rank space when the engine built the chunk stream (kernels_nrt_rank.hip) */ \
+      if (!launch_nrt_filter_rank(a, n_tiles, s)) /* rank space when the engine built the chunk stream (kernels_nrt_rank.hip) */ \
         hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhFilter>), dim3(blocks), dim3(256), 0, s, a, n_tiles); \
       const bool ln_lists = SGV == kSgLeastNuma && a.redo_list && a.ln_rec && a.ln_rows > 0; \
       if (SGV == kSgBalanced) (void)hipMemsetAsync(a.redo_list, 0, 8, s); /* the float32 Score launch lists the cells it could not decide */ \
@@ -1195,8 +1200,7 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore, SGV == kSgLeastNuma ? kLnIfOverflow : kLnFull>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
       } else { \
         if (SGV == kSgLeast && a.pk_mode && a.pk_tab_slot >= 0 && !(a.pk_tab_built && *a.pk_tab_built)) { /* the table of the packed float32 Score */ \
-          (void)hipMemsetAsync(a.pk_tab, 0, (static_cast<size_t>(a.pk_tab_kmax) + 1) * a.pk_tab_words * 4, s); \
-          hipLaunchKernelGGL(k_nrt_pk_tab_build, dim3(static_cast<unsigned>(static_cast<int64_t>(n_tiles) * kWindow * kZ * 128 / 256)), dim3(256), 0, s, a); \
+          launch_nrt_pk_tab_build(a, n_tiles, s); \
           if (a.pk_tab_built) *a.pk_tab_built = true; \
         } \
         if (SGV == kSgLeast && a.pk_mode) \

@@ -1,0 +1,562 @@
+// kernels_nrt_fused.hip — NodeResourceTopologyMatch Filter + LeastAllocated Score of a whole batch in ONE launch (round 6).
+//
+// Reference: pkg/noderesourcetopology/filter.go:42-245 (singleNUMAContainerLevelHandler, resourcesAvailableInAnyNUMANodes,
+// singleNUMAPodLevelHandler, Filter), numaresources.go:145-182 (subtractResourcesFromNUMANodeList), score.go:62-165 (Score,
+// scoreForEachNUMANode, podScopeScore, containerScopeScore), least_allocated.go:25-55.
+//
+// Rounds 4-5 ran two launches per sweep: the Filter in rank space (kernels_nrt_rank.hip: a zone's available quantity as the COUNT of
+// the chunk's distinct request values it reaches, so that "available >= request" is a subtraction under a guard bit) and LeastAllocated's
+// Score in packed float32 (score_least_packed, nrt_fast_device.h).  Both were instruction-issue bound, each staged and decoded the
+// same 32 pod records per block and read the node's zone table, and the Filter issued nearly as many scalar as vector instructions
+// (0.91: one scalar unit per CU serves four SIMDs).  This kernel does both for a (256-node window, 32-row chunk) block:
+//
+//  * the rank image of the zone table costs 2-4 registers per resource (8-16 for four resources), the Score's float32 multipliers 32 —
+//    together still 4 waves per SIMD, which the float64 one-launch form (128 registers of tables) never reached;
+//  * the Filter's comparison vectors are evaluated BRANCH-FREE over all resource slots: the engine writes, per vector and slot, the
+//    position of the request in the chunk's list, 1 ("any reporting zone suits") or 0 (slot not compared: every count passes), and the
+//    block start turns "host-level resource no zone reports" into an all-ones count and "not reported at node level" into count 0 —
+//    so a vector is 2 x (sub, and) per resource and layout dword with no per-resource scalar test;
+//  * what a container means for the walk (status code of a misfit, whether its verdict merges the charged-zone vectors, whether its
+//    zone is remembered) is ONE byte the engine prepared (kRkOp*, spx_internal.h) instead of a decode of kinds, positions and slot sets;
+//  * nothing tracks "the pod already failed": a misfit only sets the status of a lane whose status is still 0, and an empty verdict
+//    charges no zone by itself;
+//  * LeastAllocated's zone totals for unit weights (the reference's default: every requested resource weighs 1) are a chain of TWO
+//    full-rate float32 instructions per (zone, resource) instead of 4 per zone pair at the float64 rate:
+//        s   = clamp01(fma(-v, b32 / 128, (99.5 + o) / 128))        the packed form's t = fma(-v, b32, 99.5 + o), scaled by 2^-7 (exact) and
+//                                                                     clamped by the instruction's output modifier: t < 0, -inf, NaN -> 0
+//        acc = fma(s, -128, acc)                                      acc starts at 1.5 * 2^23: ulp 1, so this rounds t to nearest-even
+//    and acc = 1.5 * 2^23 - (sum of the resource scores), exactly what v_cvt_pk_u8_f32 + v_pk_mad_u16 produced: the same float32 t, the
+//    same rounding (ties to even — a tie can only occur in the table slot, which is chained FIRST, onto the even start value; the other
+//    slots' t are never within 1.5e-5 of a tie, nrt_fast_device.h), hence the same table of exceptions (k_nrt_pk_tab_build) and the same
+//    second pass for the pods it lists.  "total - k" (k = requested weighted slots = sum of weights) as an unsigned integer drops the
+//    zones whose score floor(total / k) is 0 out of the minimum, as before;
+//  * the per-item constants of the Score (requested weighted slots, 2^15 / k rounded up, -float32(Value(request)), the table slot's raw
+//    request) are packed by k_nrt_fused_pack into 8-12 dwords per item instead of rewritten in LDS by every block.
+//
+// The engine launches it when the sweep is a whole batch over a row list with a rank stream (pod classes, or every row), the strategy is
+// LeastAllocated with the packed Score's preconditions (nrt_packed_score) and unit weights; every other case keeps the two launches.
+// Output: the same two tables, byte for byte (tests/test_gpu_nrt.py::test_fused_sweep_equals_two_launches, the every-cell tests).
+#include <hip/hip_runtime.h>
+
+#include "spx_internal.h"
+#include "nrt_fast_device.h"
+#include "nrt_rank_device.h"
+
+namespace spx {
+
+namespace {
+
+using namespace nrtdev;
+
+constexpr float kFzMagic = 12582912.0f;          // 1.5 * 2^23: integers m with |m| < 2^22 are exact around it, bits = kFzMagicBits + m
+constexpr uint32_t kFzMagicBits = 0x4b400000u;
+constexpr int kFzItems = 1 + kC;                  // the pod-level request, then the containers
+
+// a packed Score item: nv[RM] (float32: -Value(request)); requested weighted slots | ceil(2^15 / their count k) << 8; the bits of
+// 1.5 * 2^23 minus k; the table slot's request (float64)
+template <int RM>
+constexpr int fz_item_words() { return RM + 4; }
+template <int RM>
+constexpr int fz_pod_words() { return kFzItems * fz_item_words<RM>(); }
+
+// one thread per (list position, item)
+template <int RM>
+__global__ __launch_bounds__(256) void k_nrt_fused_pack(NrtArgs a, uint32_t* __restrict__ out) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t i = idx / kFzItems;
+  const int j = static_cast<int>(idx - i * kFzItems);
+  if (i >= a.n_list) return;
+  const int64_t row = a.row_list ? a.row_list[i] : i;
+  const uint32_t* w = a.pod_items + row * pod_words<RM>() + (1 + j) * item_words<RM>();
+  uint32_t wmask = 0;
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+    if (r < a.n_res && a.slot_weight[r] != 0) wmask |= 1u << r;
+  auto f64 = [&](int at) { return __hiloint2double(static_cast<int>(w[at + 1]), static_cast<int>(w[at])); };
+  uint32_t* o = out + idx * fz_item_words<RM>();
+#pragma unroll
+  for (int r = 0; r < RM; ++r) o[r] = __float_as_uint(-static_cast<float>(f64(r == a.cpu_slot ? 2 * RM + 2 : 2 * r)));  // Value() of the cpu request
+  const uint32_t used = w[2 * RM] & 0xffu & wmask;
+  const uint32_t k = static_cast<uint32_t>(__builtin_popcount(used));
+  o[RM] = used | ((k ? (32768u + k - 1u) / k : 0u) << 8);
+  o[RM + 1] = kFzMagicBits - k;
+  const double raw = a.pk_tab_slot >= 0 ? f64(2 * a.pk_tab_slot) : 0.0;
+  o[RM + 2] = static_cast<uint32_t>(__double2loint(raw));
+  o[RM + 3] = static_cast<uint32_t>(__double2hiint(raw));
+}
+
+// a comparison vector's thresholds as fetched from LDS (one per slot, replicated into the layout's fields)
+template <int RM>
+struct FzThr {
+  uint32_t t[RM];
+};
+template <int RM>
+__device__ __forceinline__ FzThr<RM> fz_load_thr(const uint32_t* thr) {
+  FzThr<RM> g;
+  const u32x4 v = *reinterpret_cast<const u32x4*>(thr);
+  g.t[0] = v.x, g.t[1] = v.y, g.t[2] = v.z, g.t[3] = v.w;
+  if constexpr (RM == 8) {
+    const u32x4 u = *reinterpret_cast<const u32x4*>(thr + 4);
+    g.t[4] = u.x, g.t[5] = u.y, g.t[6] = u.z, g.t[7] = u.w;
+  }
+  return g;
+}
+
+// the 8 zones' verdicts for one comparison vector, all RM slots, no tests: guard bits of m[]
+template <int RM, bool NARROW>
+__device__ __forceinline__ void fz_mask(const uint32_t (&qa)[RM][RkLayout<NARROW>::W], const FzThr<RM>& g, uint32_t (&m)[RkLayout<NARROW>::W]) {
+  using L = RkLayout<NARROW>;
+#pragma unroll
+  for (int j = 0; j < L::W; ++j) {
+    uint32_t x = qa[0][j] - g.t[0];
+#pragma unroll
+    for (int r = 1; r < RM; ++r) x &= qa[r][j] - g.t[r];
+    m[j] = x & L::G;
+  }
+}
+
+// the lowest zone of m (guard bits only: zones 0-3 in dword 0, 4-7 in dword 1) as a one-zone set; all zero when m is empty.  Seven
+// full-rate instructions (lowest_zone's gather / spread multiplications are v_mul_lo_u32: quarter rate)
+__device__ __forceinline__ void fz_lowest(const uint32_t (&m)[2], uint32_t (&z)[2]) {
+  const uint32_t n0 = 0u - m[0], n1 = 0u - m[1];
+  const uint32_t any0 = static_cast<uint32_t>(static_cast<int32_t>(m[0] | n0) >> 31);  // all ones when dword 0 holds a zone
+  z[0] = m[0] & n0;
+  z[1] = m[1] & n1 & ~any0;
+}
+
+template <int W>
+__device__ __forceinline__ bool fz_none(const uint32_t (&m)[W]) {
+  uint32_t o = m[0];
+#pragma unroll
+  for (int j = 1; j < W; ++j) o |= m[j];
+  return o == 0u;
+}
+
+// s = clamp01(fma(nv, b, c0)) — the median with 0 and 1 becomes the fma's clamp output modifier (NaN -> 0: the code object runs with
+// DX10_CLAMP set) — then acc = fma(s, -128, acc): `v_fma_f32 .. clamp` + `v_fmac_f32` per zone, both at the full rate
+__device__ __forceinline__ void fz_chain(float (&acc)[kZ], float nv, const float (&b)[kZ], float c0) {
+#pragma unroll
+  for (int z = 0; z < kZ; ++z) {
+    const float s = __builtin_amdgcn_fmed3f(__builtin_fmaf(nv, b[z], c0), 0.0f, 1.0f);
+    acc[z] = __builtin_fmaf(s, -128.0f, acc[z]);
+  }
+}
+
+// an item's registers as fetched from LDS (requested at the top of a container's step, ahead of the Filter's work on it)
+template <int RM>
+struct FzItem {
+  float nv[RM];
+  uint32_t w0, w1;
+};
+template <int RM>
+__device__ __forceinline__ FzItem<RM> fz_load_item(const uint32_t* it) {
+  FzItem<RM> g;
+  const u32x4 v = *reinterpret_cast<const u32x4*>(it);
+  g.nv[0] = __uint_as_float(v.x), g.nv[1] = __uint_as_float(v.y), g.nv[2] = __uint_as_float(v.z), g.nv[3] = __uint_as_float(v.w);
+  if constexpr (RM == 8) {
+    const u32x4 u = *reinterpret_cast<const u32x4*>(it + 4);
+    g.nv[4] = __uint_as_float(u.x), g.nv[5] = __uint_as_float(u.y), g.nv[6] = __uint_as_float(u.z), g.nv[7] = __uint_as_float(u.w);
+  }
+  const u32x2 hw = *reinterpret_cast<const u32x2*>(it + RM);
+  g.w0 = hw.x, g.w1 = hw.y;
+  return g;
+}
+
+// The score of one request item on the lane's node: floor(min over the zones that score of the total / k), 0 when none does
+// (scoreForEachNUMANode score.go:110-124 over leastAllocatedScoreStrategy least_allocated.go:25-43, unit weights).  bs[r][z] =
+// RN32(RN64(100 / capacity)) / 128 (+inf without capacity), c0s[r] = (99.5 + o_r) / 128.  MIXED (second pass): the table slot's resource
+// scores come from the float64 form (bt[z] = RN64(100 / capacity), raw = the request as written), as score_least_packed<.., true>.
+template <int RM, bool MIXED, bool FIRST1>
+__device__ __forceinline__ uint32_t fz_score_item(const float (&bs)[RM][kZ], const float (&c0s)[RM], int ts, const FzItem<RM>& g, const uint32_t* it = nullptr,
+                                                  const double* __restrict__ bt = nullptr) {
+  const uint32_t w0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g.w0)));
+  const uint32_t top = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g.w1)));  // bits of 1.5 * 2^23, minus k
+  const uint32_t used = w0 & 0xffu, invk = w0 >> 8;
+  if (used == 0) return 0;  // no weighted slot requested (wave-uniform)
+  float acc[kZ];
+#pragma unroll
+  for (int z = 0; z < kZ; ++z) acc[z] = kFzMagic;
+  if (!MIXED && RM == 4 && used == 3u) {
+    // the common item — the first two slots (cpu and memory) and nothing else — without the per-slot tests; the table slot first
+    // (FIRST1: the table slot is not slot 0 — the launch's choice of instantiation)
+    fz_chain(acc, g.nv[FIRST1 ? 1 : 0], bs[FIRST1 ? 1 : 0], c0s[FIRST1 ? 1 : 0]);
+    fz_chain(acc, g.nv[FIRST1 ? 0 : 1], bs[FIRST1 ? 0 : 1], c0s[FIRST1 ? 0 : 1]);
+  } else {
+    uint32_t rest = used;
+    // the table slot first: its t may tie, and only onto the even start value does "round the sum to nearest even" equal "round t"
+    if (ts >= 0 && ((used >> ts) & 1u)) {
+      rest &= ~(1u << ts);
+      if constexpr (MIXED) {
+        const double raw = __hiloint2double(static_cast<int>(it[RM + 3]), static_cast<int>(it[RM + 2]));
+#pragma unroll
+        for (int z = 0; z < kZ; ++z) acc[z] = kFzMagic - static_cast<float>(static_cast<uint32_t>(__builtin_fma(-raw, bt[z], 100.0 + 0x1p-43)));
+      } else {
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+          if (r == ts) {  // uniform
+            SPX_KEEP_BRANCH();
+            fz_chain(acc, g.nv[r], bs[r], c0s[r]);
+          }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      if (!((rest >> r) & 1u)) continue;  // uniform
+      SPX_KEEP_BRANCH();
+      fz_chain(acc, g.nv[r], bs[r], c0s[r]);
+    }
+  }
+  // u = total - k as an unsigned integer: a zone whose total is below k (score 0) wraps to the top and leaves the minimum
+  uint32_t u[kZ];
+#pragma unroll
+  for (int z = 0; z < kZ; ++z) u[z] = top - __float_as_uint(acc[z]);
+  auto min3 = [](uint32_t x, uint32_t y, uint32_t w) { return min(min(x, y), w); };
+  const uint32_t mm = min3(min3(u[0], u[1], u[2]), min3(u[3], u[4], u[5]), min(u[6], u[7]));
+  // (no zone scores: mm + k wraps to the smallest total, below k, and the quotient is the reference's 0)
+  return __umul24(mm + (kFzMagicBits - top), invk) >> 15;  // floor(total / k): total <= 800, k <= 8, invk = ceil(2^15 / k)
+}
+
+// the pod loop.  One count layout: four zones per register (every chunk of the stream is narrow — the engine splits a chunk whose lists
+// would pass 127 entries — or the fused sweep is not launched)
+template <int RM, bool FIRST1, bool NARROW = true>
+__device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float (&bs)[RM][kZ], const float (&c0s)[RM], int ts, const uint32_t* pods,
+                                        const uint32_t* sitems, int rows, int lane, bool w_pod, bool w_ctr, bool aligned, bool pod_scope, uint32_t st_stale,
+                                        bool in, int pos, uint32_t* stage_status, uint32_t* stage_score) {
+  using L = RkLayout<NARROW>;
+  constexpr int W = L::W;
+  constexpr int PWR = kRkPodHead + kRkVectors * RM;
+  uint32_t qa[RM][W];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int j = 0; j < W; ++j) qa[r][j] = q4[r][j];
+  uint32_t acc_status = 0, acc_score = 0;
+  uint32_t hv = pods[lane & 15];  // a pod's head: lane l holds dword l & 15; the fields become scalars as they are needed
+  for (int p = 0; p < rows; ++p) {
+    const uint32_t* rec = pods + p * PWR;
+    const uint32_t* sit = sitems + p * fz_pod_words<RM>();
+    const uint32_t hcur = hv;
+    hv = pods[(p + 1 < rows ? p + 1 : p) * PWR + (lane & 15)];  // the next pod's head, requested before this pod's work
+    auto head = [&](int i) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hcur), i)); };
+    const uint32_t w0 = head(0);
+    const uint32_t qos = w0 & 0xffu;
+    const bool filtered = !(qos == SPX_QOS_BESTEFFORT && ((w0 >> 8) & 0xffu) == 0);  // filter.go:186-190
+    const bool scored = qos == SPX_QOS_GUARANTEED;                                  // score.go:72-76: every other pod scores 100
+    uint32_t status = filtered ? st_stale : 0u;
+    uint32_t score = scored ? 0u : 100u;
+    if (filtered) {  // uniform (a Guaranteed pod is always filtered)
+      if (w_pod && pod_scope && aligned) {  // singleNUMAPodLevelHandler, podScopeScore
+        const FzThr<RM> t = fz_load_thr<RM>(rec + kRkPodHead);
+        const FzItem<RM> g = fz_load_item<RM>(sit);
+        uint32_t m[W];
+        fz_mask<RM, NARROW>(qa, t, m);
+        if (fz_none(m)) status = SPX_NRT_ST_POD;
+        if (scored) score = fz_score_item<RM, false, FIRST1>(bs, c0s, ts, g);
+      }
+      if (w_ctr && !pod_scope && aligned) {  // singleNUMAContainerLevelHandler / containerScopeScore: containers in order
+        const int n_ctr = static_cast<int>((w0 >> 16) & 0xffu);
+        uint32_t ops = head(12);
+        const uint32_t ops_hi = head(13);
+        uint32_t z0[W], z1[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) z0[j] = z1[j] = 0u;  // the zones app containers a0 / a1 were charged to (packed one-zone sets)
+        uint32_t sum = 0;
+        // the next container's thresholds and Score item are in flight while this one is worked on
+        FzThr<RM> t = fz_load_thr<RM>(rec + kRkPodHead + RM);
+        FzItem<RM> g = fz_load_item<RM>(sit + fz_item_words<RM>());
+        for (int c = 0; c < n_ctr; ++c) {  // (left to the compiler: it peels the first steps, 5 % faster than `unroll 1`)
+          const uint32_t op = ops & 0xffu;
+          ops = c == 3 ? ops_hi : ops >> 8;
+          const int cn = c + 1 < kC ? c + 1 : c;
+          const FzThr<RM> tn = fz_load_thr<RM>(rec + kRkPodHead + (1 + cn) * RM);
+          const FzItem<RM> gn = fz_load_item<RM>(sit + (1 + cn) * fz_item_words<RM>());
+          uint32_t m[W];
+          fz_mask<RM, NARROW>(qa, t, m);
+          if (op & (kRkOpMerge1 | kRkOpMerge3)) {  // uniform: an earlier app container may have been charged to a zone
+            if (op & kRkOpMerge1) {
+              uint32_t ms[W];
+              fz_mask<RM, NARROW>(qa, fz_load_thr<RM>(rec + kRkPodHead + 9 * RM), ms);
+#pragma unroll
+              for (int j = 0; j < W; ++j) m[j] = (m[j] & ~z0[j]) | (ms[j] & z0[j]);
+            } else {  // the third app container: its own vector, + a0, + a1, + both
+              uint32_t m0[W], m1[W], mb[W];
+              fz_mask<RM, NARROW>(qa, fz_load_thr<RM>(rec + kRkPodHead + 10 * RM), m0);
+              fz_mask<RM, NARROW>(qa, fz_load_thr<RM>(rec + kRkPodHead + 11 * RM), m1);
+              fz_mask<RM, NARROW>(qa, fz_load_thr<RM>(rec + kRkPodHead + 12 * RM), mb);
+#pragma unroll
+              for (int j = 0; j < W; ++j) {
+                const uint32_t both = z0[j] & z1[j];
+                uint32_t x = (m[j] & ~z1[j]) | (m1[j] & z1[j]);
+                x = (x & ~z0[j]) | (m0[j] & z0[j]);
+                m[j] = (x & ~both) | (mb[j] & both);
+              }
+            }
+          }
+          // the first misfit names the status (a later one finds it set); an empty verdict has no lowest zone: nothing is charged
+          if (fz_none(m) && status == 0u) status = op & 7u;
+          if (op & (kRkOpCharge0 | kRkOpCharge1)) {  // uniform
+            uint32_t z[W];
+            fz_lowest(m, z);
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              if (op & kRkOpCharge0) z0[j] = z[j];
+              else z1[j] = z[j];
+            }
+          }
+          if (scored) sum += fz_score_item<RM, false, FIRST1>(bs, c0s, ts, g);
+          t = tn;
+          g = gn;
+        }
+        if (scored) score = (sum * head(1)) >> 16;  // int64(mean): sum / n_ctr, sum <= 800; head 1 = ceil(2^16 / n_ctr)
+      }
+    }
+    const int sh = 8 * (p & 3);
+    acc_status |= status << sh;
+    acc_score |= score << sh;
+    if ((p & 3) == 3 || p + 1 == rows) {  // uniform: one LDS write per table and four pods
+      if (in) stage_status[(p >> 2) * kWindow + pos] = acc_status, stage_score[(p >> 2) * kWindow + pos] = acc_score;
+      acc_status = acc_score = 0;
+    }
+  }
+}
+
+// dynamic LDS: the chunk block of the rank stream (header, lists, pod records), the chunk's packed Score items, then the staged
+// status and score dwords [2][kPodsPerUnit / 4][kWindow]
+template <int RM, bool FIRST1>
+__global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, const uint32_t* __restrict__ fz_items, int n_tiles) {
+  extern __shared__ __align__(16) uint32_t lds[];
+  __shared__ uint32_t pk_flagged;  // the chunk's pods with a table-slot request k_nrt_pk_tab_build lists for this window
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_windows = n_tiles;
+  int window;
+  int64_t chunk;
+  if (n_windows >= kXcdMapWindows) {  // as k_nrt_fast: every XCD walks its own node windows
+    const int wpx = (n_windows + 7) >> 3;
+    const int64_t seq = blockIdx.x >> 3;
+    window = static_cast<int>(blockIdx.x & 7u) + 8 * static_cast<int>(seq % wpx);
+    chunk = seq / wpx;
+    if (window >= n_windows) return;
+  } else {
+    window = static_cast<int>(blockIdx.x % n_windows);
+    chunk = blockIdx.x / n_windows;
+  }
+  if (chunk >= a.rk_chunks) return;
+  const int64_t first = a.rk_first[chunk];  // a chunk: up to 32 consecutive rows of the list
+  const int rows = static_cast<int>(a.rk_first[chunk + 1] - first);
+  auto row_of = [&](int p) -> int64_t { return a.row_list ? static_cast<int64_t>(uload(a.row_list + first + p)) : first + p; };
+  const int64_t base = static_cast<int64_t>(window) * kWindow;
+  const int32_t pn = a.perm[base + threadIdx.x];
+  const bool in = pn >= 0;
+  const int64_t n = in ? pn : 0;
+  const int pos = in ? static_cast<int>(n - base) : 0;
+  const int R = a.n_res;
+  const int ts = a.pk_tab_slot;
+
+  // ---- the chunk block and the chunk's Score items -> LDS (coalesced 16-byte pieces), the stage zeroed
+  const uint32_t c0 = a.rk_off[chunk], c1 = a.rk_off[chunk + 1];
+  uint32_t* const sitems = lds + a.rk_max_dwords;
+  uint32_t* const stage = sitems + kPodsPerUnit * fz_pod_words<RM>();  // [2][kPodsPerUnit / 4][kWindow]
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(a.rk_stream + c0);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    const int n_quads = static_cast<int>((c1 - c0) >> 2);
+    for (int i = threadIdx.x; i < n_quads; i += 256) dst[i] = src[i];
+    const uint4* isrc = reinterpret_cast<const uint4*>(fz_items + first * fz_pod_words<RM>());
+    uint4* idst = reinterpret_cast<uint4*>(sitems);
+    const int i_quads = rows * fz_pod_words<RM>() / 4;
+    for (int i = threadIdx.x; i < i_quads; i += 256) idst[i] = isrc[i];
+    uint4* z = reinterpret_cast<uint4*>(stage) + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2 * kPodsPerUnit / 4 * kWindow / 4 / 256; ++i) z[i * 256] = uint4{0, 0, 0, 0};
+    if (threadIdx.x == 0) pk_flagged = 0;
+  }
+  const uint32_t flags = in ? a.flags[n] : 0u;
+  const uint32_t node_present = in ? a.node_present[n] : 0u;
+  const uint32_t nn = static_cast<uint32_t>(a.n_nodes), n32 = static_cast<uint32_t>(n);
+  // host-level resources no zone of the node reports are not checked (filter.go:110-116): their counts become all ones
+  uint32_t fill_bits = 0;
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    const uint32_t rep = (in && r < R) ? ld_off(a.f_rep, static_cast<uint32_t>(r) * nn + n32) : 0u;
+    fill_bits |= (r < R && (a.slot_flags[r] & SPX_NRT_SLOT_HOST_LEVEL) && rep == 0) ? 1u << r : 0u;
+  }
+  // the Score's multipliers, float32 / 128 (the zone table's other image)
+  float bs[RM][kZ];
+  float c0s[RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    c0s[r] = (99.5f + (r == ts ? kPkOffsetTab : kPkOffsetSmall)) * 0x1p-7f;
+#pragma unroll
+    for (int z = 0; z < kZ; ++z) {
+      const double b = (in && r < R) ? ld_off(a.f_rc, (static_cast<uint32_t>(z * R + r) * nn + n32) * 8u) : kNoCap;
+      bs[r][z] = b == kNoCap ? __builtin_inff() : static_cast<float>(b) * 0x1p-7f;
+    }
+  }
+  __syncthreads();
+  // the pods whose table-slot request (any of their items) is listed for THIS node window: recomputed after the loop
+  if (ts >= 0) {
+    for (int i = threadIdx.x; i < rows * kFzItems; i += 256) {
+      const uint32_t* it = sitems + i * fz_item_words<RM>();
+      if (!((it[RM] >> ts) & 1u)) continue;
+      const double k = __hiloint2double(static_cast<int>(it[RM + 3]), static_cast<int>(it[RM + 2])) * a.pk_tab_inv_unit;
+      // (the engine derived unit and kmax from this very batch: k is a whole number within the table; anything else is recomputed too)
+      const bool inside = k >= 0.0 && k <= static_cast<double>(a.pk_tab_kmax) && k == __builtin_floor(k);
+      const uint32_t word = inside ? a.pk_tab[static_cast<size_t>(static_cast<uint32_t>(k)) * a.pk_tab_words + (static_cast<uint32_t>(window) >> 5)] : ~0u;
+      if ((word >> (static_cast<uint32_t>(window) & 31u)) & 1u) atomicOr(&pk_flagged, 1u << (i / kFzItems));
+    }
+  }
+  // ---- the node's cells as counts: for each resource the eight zones' quantities, ranked against the chunk's list
+  uint32_t q4[RM][2];
+  const double* lists = reinterpret_cast<const double*>(lds + 16);
+  uint32_t list_doubles = 0;
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    q4[r][0] = q4[r][1] = RkLayout<true>::G;  // (slots past the table: never requested)
+    if (r >= R) continue;  // uniform
+    const uint32_t hw = lds[r];
+    const int steps = static_cast<int>(hw & 0xffu);
+    const uint32_t lo = hw >> 8;
+    list_doubles = lo + (1u << steps);
+    double av[kZ];
+#pragma unroll
+    for (int z = 0; z < kZ; ++z) av[z] = in ? ld_off(a.f_av, (static_cast<uint32_t>(z * R + r) * nn + n32) * 8u) : -1.0;
+    uint32_t cnt[kZ];
+#pragma unroll
+    for (int z = 0; z < kZ; ++z) cnt[z] = 0;
+    for (int b = 1 << (steps - 1); b > 0; b >>= 1) {  // uniform trip count; the eight searches advance together
+#pragma unroll
+      for (int z = 0; z < kZ; ++z) {
+        const double v = lists[lo + cnt[z] + static_cast<uint32_t>(b) - 1u];
+        cnt[z] = v <= av[z] ? cnt[z] + static_cast<uint32_t>(b) : cnt[z];
+      }
+    }
+    // a compared resource the node does not report at node level fails whatever the zones say (filter.go:101-104): count 0 (a slot that
+    // is not compared subtracts 0 and passes); a host-level resource no zone reports passes whatever is asked: all ones
+    const bool absent = !((node_present >> r) & 1u), fill = (fill_bits >> r) & 1u;
+    const uint32_t lo4 = RkLayout<true>::G | cnt[0] | (cnt[1] << 8) | (cnt[2] << 16) | (cnt[3] << 24);
+    const uint32_t hi4 = RkLayout<true>::G | cnt[4] | (cnt[5] << 8) | (cnt[6] << 16) | (cnt[7] << 24);
+    q4[r][0] = absent ? RkLayout<true>::G : (fill ? ~0u : lo4);
+    q4[r][1] = absent ? RkLayout<true>::G : (fill ? ~0u : hi4);
+  }
+  const uint32_t* const pods = lds + 16 + 2 * list_doubles;
+  const bool fresh = flags & SPX_NRT_F_FRESH;
+  const bool has_nrt = flags & SPX_NRT_F_HAS_NRT;
+  const bool single = flags & SPX_NRT_F_SINGLE_NUMA;
+  const bool pod_scope = flags & SPX_NRT_F_POD_SCOPE;
+  const bool aligned = fresh && has_nrt && single;
+  const bool w_pod = __ballot(aligned && pod_scope) != 0, w_ctr = __ballot(aligned && !pod_scope) != 0;
+  const uint32_t st_stale = fresh ? 0u : static_cast<uint32_t>(SPX_NRT_ST_INVALID_TOPOLOGY);
+  uint32_t* const stage_status = stage;
+  uint32_t* const stage_score = stage + kPodsPerUnit / 4 * kWindow;
+  fz_walk<RM, FIRST1>(q4, bs, c0s, ts, pods, sitems, rows, lane, w_pod, w_ctr, aligned, pod_scope, st_stale, in, pos, stage_status, stage_score);
+  __syncthreads();
+  {
+    const uint32_t flagged = pk_flagged;  // block-uniform (every atomicOr precedes the barrier above)
+    if (flagged != 0) {
+      // second pass: the flagged pods' cells of this window with the table slot in the float64 form — its eight multipliers read
+      // again, the other slots chained as before.  Each lane rewrites its own byte of the staged dword.
+      double bt[kZ];
+#pragma unroll
+      for (int z = 0; z < kZ; ++z) {
+        const double b = in ? a.f_rc[(static_cast<int64_t>(z) * R + ts) * a.n_nodes + n] : kNrtNoCap;
+        bt[z] = b == kNrtNoCap ? __builtin_inf() : b;
+      }
+      constexpr int PWR = kRkPodHead + kRkVectors * RM;
+      uint32_t n_redone = 0;
+      for (uint32_t left = flagged; left != 0; left &= left - 1) {
+        const int p = __builtin_ctz(left);
+        const uint32_t* rec = pods + p * PWR;
+        const uint32_t h0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rec[0])));
+        const uint32_t h1 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rec[1])));
+        if ((h0 & 0xffu) != SPX_QOS_GUARANTEED) continue;  // uniform: 100 everywhere, the loop wrote it
+        ++n_redone;
+        const int n_ctr = (h0 >> 16) & 0xffu;
+        const uint32_t* sit = sitems + p * fz_pod_words<RM>();
+        uint32_t score = 0;
+        if (aligned) {
+          if (pod_scope) {
+            score = fz_score_item<RM, true, FIRST1>(bs, c0s, ts, fz_load_item<RM>(sit), sit, bt);
+          } else {
+            uint32_t sum = 0;
+#pragma unroll 1
+            for (int c = 0; c < n_ctr; ++c) {
+              const uint32_t* it = sit + (1 + c) * fz_item_words<RM>();
+              sum += fz_score_item<RM, true, FIRST1>(bs, c0s, ts, fz_load_item<RM>(it), it, bt);
+            }
+            score = (sum * h1) >> 16;
+          }
+        }
+        if (in) {
+          const int sh = 8 * (p & 3);
+          uint32_t& cell = stage_score[(p >> 2) * kWindow + pos];
+          cell = (cell & ~(0xffu << sh)) | (score << sh);
+        }
+      }
+      if (a.stats && threadIdx.x == 0 && n_redone)  // these cells count as re-evaluated (spx_fetch_stats)
+        atomicAdd(a.stats + (SPX_PLUGIN_NRT * kStatSlots + static_cast<int>(blockIdx.x & (kStatSlots - 1))) * kStatStride, static_cast<unsigned long long>(n_redone) * kWindow);
+      __syncthreads();
+    }
+  }
+  // rows leave as whole 256-byte segments (as k_nrt_fast): lane l gathers byte (row & 3) of the four dwords of nodes 4l .. 4l+3
+  const int64_t col = base + lane * 4;
+  if (col < a.row_stride) {
+    for (int i = wave; i < rows; i += 4) {
+      const int64_t row = row_of(i);
+      const uint32_t b = static_cast<uint32_t>(i & 3);
+      const uint32_t pick = 0x0c0c0000u | ((4u + b) << 8) | b;
+#pragma unroll
+      for (int tbl = 0; tbl < 2; ++tbl) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(&(tbl ? stage_score : stage_status)[(i >> 2) * kWindow + lane * 4]);
+        const uint32_t lo = __builtin_amdgcn_perm(w.y, w.x, pick), hi = __builtin_amdgcn_perm(w.w, w.z, pick);
+        uint8_t* out = (tbl ? a.out_score : a.out_status) + row * a.row_stride + col;
+        *reinterpret_cast<uint32_t*>(out) = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// words of scratch the packed Score items of `n_list` rows take (NrtArgs::fz_items)
+size_t nrt_fused_item_words(int n_res, int64_t n_list) {
+  return static_cast<size_t>(n_list) * static_cast<size_t>(n_res <= 4 ? fz_pod_words<4>() : fz_pod_words<8>());
+}
+
+// The whole-batch sweep in one launch; false = not launched (the caller runs the Filter and Score launches): no rank stream, a
+// strategy or weights the chain does not cover, or a chunk block that does not fit in LDS next to the items and the stage.
+bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
+  if (!a.fast || !a.fz_items || !a.rk_stream || !a.rk_off || !a.rk_first || a.rk_max_dwords == 0 || !a.out_status || !a.out_score || a.out_raw || a.row_ptr) return false;
+  if (a.strategy != SPX_NRT_LEAST_ALLOCATED || !a.pk_mode) return false;
+  for (int r = 0; r < a.n_res; ++r)
+    if (a.slot_weight[r] != 0 && a.slot_weight[r] != 1) return false;
+  const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);
+  const int64_t chunks = a.rk_chunks;
+  const int64_t per_round = n_tiles >= kXcdMapWindows ? ((n_tiles + 7) / 8) * 8 : n_tiles;
+  const unsigned blocks = static_cast<unsigned>(chunks * per_round);
+  const bool r4 = a.n_res <= 4;
+  const size_t lds = static_cast<size_t>(a.rk_max_dwords) * 4 + static_cast<size_t>(kPodsPerUnit) * (r4 ? fz_pod_words<4>() : fz_pod_words<8>()) * 4 +
+                     static_cast<size_t>(2) * (kPodsPerUnit / 4) * kWindow * 4;
+  if (lds > 64 * 1024) return false;
+  if (a.pk_tab_slot >= 0 && !(a.pk_tab_built && *a.pk_tab_built)) {  // the table of the packed float32 Score (kernels_nrt_fast.hip)
+    launch_nrt_pk_tab_build(a, n_tiles, s);
+    if (a.pk_tab_built) *a.pk_tab_built = true;
+  }
+  const unsigned pack_blocks = static_cast<unsigned>((a.n_list * kFzItems + 255) / 256);
+  // FIRST1: the two-slot fast path chains slot 1 before slot 0 — right whenever the table slot is not slot 0 (it is memory, or there is none)
+  const bool first1 = a.pk_tab_slot != 0;
+#define SPX_FZ_LAUNCH(RMV, F1V)                                                                                                            \
+  do {                                                                                                                                     \
+    hipLaunchKernelGGL((k_nrt_fused_pack<RMV>), dim3(pack_blocks), dim3(256), 0, s, a, a.fz_items);                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<RMV, F1V>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+    hipLaunchKernelGGL((k_nrt_fused<RMV, F1V>), dim3(blocks), dim3(256), lds, s, a, a.fz_items, n_tiles);                                 \
+  } while (0)
+  if (r4 && first1) SPX_FZ_LAUNCH(4, true);
+  else if (r4) SPX_FZ_LAUNCH(4, false);
+  else if (first1) SPX_FZ_LAUNCH(8, true);
+  else SPX_FZ_LAUNCH(8, false);
+#undef SPX_FZ_LAUNCH
+  return true;
+}
+
+}  // namespace spx

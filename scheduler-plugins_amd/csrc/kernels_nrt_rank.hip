@@ -28,24 +28,13 @@
 
 #include "spx_internal.h"
 #include "nrt_fast_device.h"
+#include "nrt_rank_device.h"
 
 namespace spx {
 
 namespace {
 
 using namespace nrtdev;
-
-// Two layouts of the eight zones' counts (round 5).  WIDE: two zones per dword under guard bits 15 / 31 (zone j in the low half of dword j,
-// zone j + 4 in the high half): lists of up to 32 767 quantities.  NARROW: four zones per dword under guard bits 7 / 15 / 23 / 31 (zones 0-3 in
-// dword 0, zones 4-7 in dword 1) when every list of the chunk has at most 127 entries (the engine marks such chunks: header dword 9, and
-// replicates the thresholds into four bytes) — half the subtract / and instructions per comparison vector.  A byte (halfword) holds
-// count | guard >= 128 (32 768) and the subtrahend is at most 127 (32 767): no borrow crosses a field.
-template <bool NARROW>
-struct RkLayout {
-  static constexpr int W = NARROW ? 2 : 4;
-  static constexpr uint32_t G = NARROW ? 0x80808080u : 0x80008000u;
-  static constexpr uint32_t kOne = NARROW ? 0x01010101u : 0x00010001u;  // "count >= 1" in every field
-};
 
 // the 8 zones' verdicts for one comparison vector: guard bits of m[]
 template <int RM, bool NARROW>
@@ -76,28 +65,6 @@ __device__ __forceinline__ bool any_zone(const uint32_t (&m)[W]) {
 #pragma unroll
   for (int j = 1; j < W; ++j) o |= m[j];
   return o != 0u;
-}
-
-// the lowest zone of m as a packed one-zone set (same layout as m); all zero when m is empty
-__device__ __forceinline__ void lowest_zone(const uint32_t (&m)[4], uint32_t (&z)[4]) {  // WIDE: zone z = dword z & 3, half z >> 2
-  // bits 0..3 = zones 0..3, bits 16..19 = zones 4..7
-  const uint32_t w = (m[0] >> 15) | (m[1] >> 14) | (m[2] >> 13) | (m[3] >> 12);
-  const uint32_t m8 = (w | (w >> 12)) & 0xffu;
-  const uint32_t low = m8 & (0u - m8);
-  const uint32_t w2 = (low | (low << 12)) & 0x000f000fu;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) z[j] = (w2 << (15 - j)) & 0x80008000u;
-}
-__device__ __forceinline__ void lowest_zone(const uint32_t (&m)[2], uint32_t (&z)[2]) {  // NARROW: zone z = dword z >> 2, byte z & 3
-  // guard bits 7 / 15 / 23 / 31 -> bits 28..31 of the product (2^21 + 2^14 + 2^7 + 1: the four wanted partial products land there,
-  // every other one elsewhere or outside the 32 bits, no two on one bit: no carries)
-  constexpr uint32_t kGather = 0x00204081u;
-  const uint32_t lo4 = ((m[0] & 0x80808080u) * kGather) >> 28, hi4 = ((m[1] & 0x80808080u) * kGather) >> 28;
-  const uint32_t m8 = lo4 | (hi4 << 4);
-  const uint32_t low = m8 & (0u - m8);
-  // a one-hot nibble bit k -> bit 8 k + 7: k + 7 k is one of the product's four bits k + {0, 7, 14, 21}, the only one on a byte's bit 0
-  z[0] = (((low & 0xfu) * kGather) & 0x01010101u) << 7;
-  z[1] = (((low >> 4) * kGather) & 0x01010101u) << 7;
 }
 
 // the pod loop of k_nrt_filter_rank in one of the two count layouts (chosen per chunk: block-uniform)
@@ -216,9 +183,9 @@ __global__ __launch_bounds__(256, 4) void k_nrt_filter_rank(NrtArgs a, int n_til
     window = static_cast<int>(blockIdx.x % n_windows);
     chunk = blockIdx.x / n_windows;
   }
-  const int64_t first = chunk * kPodsPerUnit;
-  if (first >= a.n_list) return;
-  const int rows = static_cast<int>(a.n_list - first < kPodsPerUnit ? a.n_list - first : kPodsPerUnit);
+  if (chunk >= a.rk_chunks) return;
+  const int64_t first = a.rk_first[chunk];  // a chunk: up to 32 consecutive rows of the list (nrt_build_rank_stream splits where the lists grow long)
+  const int rows = static_cast<int>(a.rk_first[chunk + 1] - first);
   const int64_t base = static_cast<int64_t>(window) * kWindow;
   const int32_t pn = a.perm[base + threadIdx.x];
   const bool in = pn >= 0;
@@ -316,8 +283,10 @@ __global__ __launch_bounds__(256, 4) void k_nrt_filter_rank(NrtArgs a, int n_til
 }  // namespace
 
 // the Filter launch of a whole-batch sweep over pod classes; false = not launched (no stream, or the block does not fit in LDS)
-bool launch_nrt_filter_rank(const NrtArgs& a, int n_tiles, unsigned blocks, hipStream_t s) {
-  if (!a.rk_stream || !a.rk_off || !a.row_list || a.rk_max_dwords == 0 || !a.out_status) return false;
+bool launch_nrt_filter_rank(const NrtArgs& a, int n_tiles, hipStream_t s) {
+  if (!a.rk_stream || !a.rk_off || !a.rk_first || !a.row_list || a.rk_max_dwords == 0 || !a.out_status) return false;
+  const int64_t per_round = n_tiles >= kXcdMapWindows ? ((n_tiles + 7) / 8) * 8 : n_tiles;  // the kernel's block map
+  const unsigned blocks = static_cast<unsigned>(static_cast<int64_t>(a.rk_chunks) * per_round);
   const size_t lds = static_cast<size_t>(a.rk_max_dwords) * 4 + static_cast<size_t>(kPodsPerUnit / 4) * kWindow * 4;
   if (lds > kRkMaxChunkBytes + 8192) return false;
   if (a.n_res <= 4) {

@@ -55,7 +55,7 @@ struct spx_engine {
   int64_t row_stride = 0;
 
   // spx_set_option state (per engine; nothing is read from the environment)
-  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1, 0, 1, 1, 1, 1, 1};
+  int64_t option[SPX_NUM_OPTIONS] = {spx::kRowPad, 0, 0, 0, 0, 0, 44, 1, 1, 375, 1, 1, 0, 1, 1, 1, 1, 1, 1};
 
   // params
   int32_t alloc_mode = SPX_MODE_LEAST;
@@ -134,6 +134,13 @@ struct spx_engine {
   int64_t nrt_n_uniq = 0, nrt_n_dups = 0;
   DevBuf d_nrt_rk, d_nrt_rk_off;  // rank-space Filter: the chunk stream of the listed rows (nrt_build_rank_stream) and its chunk offsets
   uint32_t nrt_rk_max_dwords = 0;  // largest chunk block; 0 = no stream (the float64 Filter runs)
+  // which rows the stream lists: 1 = the class representatives (d_nrt_uniq), 2 = every row in order (sweeps without pod classes:
+  // built when such a sweep first asks for it, nrt_rank_stream_all); 0 = none, -1 = the batch has no finite stream (> 3 app containers)
+  int nrt_rk_kind = 0;
+  DevBuf d_nrt_rk_first;          // [chunks + 1] list position of each chunk's first row (a chunk holds up to 32)
+  uint32_t nrt_rk_chunks = 0;
+  bool nrt_rk_all_narrow = false;  // every chunk keeps four zones' counts per register (the only layout the fused sweep has)
+  DevBuf d_nrt_fz;  // fused Filter + Score sweep: the packed Score items of the listed rows (k_nrt_fused_pack)
   int last_nrt_filter = 0;         // spx_nrt_filter_path
   DevBuf d_pk_uniq, d_pk_dups;    // the same for Peaks: classes of pods with equal cpu requests
   int64_t pk_n_uniq = 0, pk_n_dups = 0;
@@ -675,7 +682,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_best, &e->d_stats, &e->d_decide, &e->d_lroc_nreq_c, &e->d_lroc_nreq_m, &e->d_lroc_nlim_c, &e->d_lroc_nlim_m,
                     &e->d_lroc_preq_c, &e->d_lroc_preq_m, &e->d_lroc_plim_c, &e->d_lroc_plim_m, &e->d_lroc_tab, &e->d_lroc_podf,
                     &e->d_pk_cap, &e->d_pk_util, &e->d_pk_valid, &e->d_pk_k1, &e->d_pk_k2, &e->d_pk_pod, &e->d_pk_min, &e->d_pk_max, &e->d_pk_rowc, &e->d_pk_tab, &e->d_pk_seg, &e->d_pk_segn,
-                    &e->d_nrt_uniq, &e->d_nrt_dups, &e->d_pk_uniq, &e->d_pk_dups, &e->d_delta, &e->d_nrt_lnrec, &e->d_net_pair_node2, &e->d_net_pair_max2, &e->d_nrt_rk, &e->d_nrt_rk_off};
+                    &e->d_nrt_uniq, &e->d_nrt_dups, &e->d_pk_uniq, &e->d_pk_dups, &e->d_delta, &e->d_nrt_lnrec, &e->d_net_pair_node2, &e->d_net_pair_max2, &e->d_nrt_rk, &e->d_nrt_rk_off, &e->d_nrt_rk_first, &e->d_nrt_fz};
   for (DevBuf* b : bufs)
     if (b->p && !b->external) (void)hipFree(b->p);
   for (int i = 0; i < SPX_NUM_PLUGINS; ++i) {
@@ -729,6 +736,7 @@ int spx_set_option(spx_engine* e, int option, int64_t value) {
     case SPX_OPT_NRT_PACKED_SCORE:
     case SPX_OPT_NET_ALLOC_FUSED:
     case SPX_OPT_NRT_RANK_NARROW:
+    case SPX_OPT_NRT_FUSED:
       if (value != 0 && value != 1) return fail(e, SPX_ERR_ARG, "option takes 0 or 1");
       break;
     case SPX_OPT_NRT_LN_LIST_PERMILLE:
@@ -1719,23 +1727,28 @@ void nrt_build_classes(const uint32_t* items, const uint64_t* hash, size_t p, si
 // in integers — so the chunk's lists also hold those sums: per pod 13 comparison vectors (layout: spx::kRk*, spx_internal.h):
 // the pod-level request, the eight containers, and for the second / third app container the sums with the earlier app
 // containers a zone may carry.  Pods with more than three app containers have no such finite list: *ok_out = false and the
-// batch keeps the float64 Filter.  Chunk block: 16 header dwords (per slot: search steps | list offset << 8; [8] rows),
+// batch keeps the float64 Filter.  A chunk = up to 32 consecutive listed rows (first_out[c] .. first_out[c + 1]); chunk block: 16 header
+// dwords (per slot: search steps | list offset << 8; [8] rows; [9] narrow),
 // the lists (2^steps - 1 doubles each, padded with +inf), then per pod kRkPodHead + 13 x RM dwords.
 void nrt_build_rank_stream(const uint32_t* items, const int32_t* list, size_t n_list, size_t R, std::vector<uint32_t>& words, std::vector<uint32_t>& off,
-                           uint32_t* max_dwords_out, bool* ok_out, bool narrow_ok = true) {
+                           std::vector<uint32_t>& first_out, uint32_t* max_dwords_out, bool* ok_out, bool* all_narrow_out, bool narrow_ok = true) {
   const size_t RM = R <= 4 ? 4 : 8, IW = R <= 4 ? 16 : 32, PW = 10 * IW, PWR = spx::kRkPodHead + spx::kRkVectors * RM;
-  const size_t n_chunks = (n_list + spx::kRkChunkRows - 1) / spx::kRkChunkRows;
-  std::vector<std::vector<uint32_t>> blocks(n_chunks);
-  std::atomic<bool> ok{true};
+  const size_t n_groups = (n_list + spx::kRkChunkRows - 1) / spx::kRkChunkRows;
+  struct Block {
+    uint32_t first, rows;
+    std::vector<uint32_t> w;
+  };
+  std::vector<std::vector<Block>> groups(n_groups);  // a group = 32 consecutive listed rows = one chunk, or the chunks it was split into
+  std::atomic<bool> ok{true}, all_narrow{true};
   auto f64 = [](const uint32_t* w) { double v; std::memcpy(&v, w, sizeof v); return v; };
-  spx_host::parallel_rows(static_cast<int64_t>(n_chunks), [&](int64_t c0, int64_t c1) {
+  spx_host::parallel_rows(static_cast<int64_t>(n_groups), [&](int64_t c0, int64_t c1) {
     std::vector<double> vals[SPX_NRT_MAX_RES];
     for (int64_t c = c0; c < c1; ++c) {
       const size_t first = static_cast<size_t>(c) * spx::kRkChunkRows, rows = std::min<size_t>(spx::kRkChunkRows, n_list - first);
       // pass 1: every pod's 13 vectors (value per slot, NaN = not compared)
       std::vector<double> vec(rows * spx::kRkVectors * RM, std::numeric_limits<double>::quiet_NaN());
       std::vector<uint32_t> head(rows * spx::kRkPodHead, 0u);
-      for (size_t r = 0; r < R; ++r) vals[r].clear();
+      std::vector<uint8_t> any_always(rows * spx::kRkVectors, 0);  // per vector: the item's "any reporting zone suits" slots
       for (size_t i = 0; i < rows; ++i) {
         const uint32_t* w = items + static_cast<size_t>(list[first + i]) * PW;
         uint32_t* h = &head[i * spx::kRkPodHead];
@@ -1755,74 +1768,167 @@ void nrt_build_rank_stream(const uint32_t* items, const int32_t* list, size_t n_
         double* v = &vec[i * spx::kRkVectors * RM];
         auto put = [&](size_t vi, size_t item, std::initializer_list<uint32_t> charged) {
           const uint32_t fit = fit_of(item);
+          any_always[i * spx::kRkVectors + vi] = static_cast<uint8_t>((w[item * IW + 2 * RM] >> 16) & 0xffu);
           for (size_t r = 0; r < R; ++r) {
             if (!((fit >> r) & 1u)) continue;
             double q = raw_of(item, r);
             for (uint32_t j : charged)
               if ((fit_of(2 + j) >> r) & 1u) q += raw_of(2 + j, r);
             v[vi * RM + r] = q;
-            vals[r].push_back(q);
           }
         };
         put(0, 1, {});
         for (uint32_t ctr = 0; ctr < n_ctr && ctr < SPX_NRT_MAX_CTRS; ++ctr) put(1 + ctr, 2 + ctr, {});
         if (n_app >= 2 && n_app <= 3) put(9, 2 + app[1], {app[0]});
         if (n_app == 3) put(10, 2 + app[2], {app[0]}), put(11, 2 + app[2], {app[1]}), put(12, 2 + app[2], {app[0], app[1]});
-      }
-      // pass 2: the lists, then the thresholds
-      uint32_t steps[SPX_NRT_MAX_RES] = {0}, loff[SPX_NRT_MAX_RES] = {0};
-      size_t list_doubles = 0;
-      for (size_t r = 0; r < R; ++r) {
-        auto& a = vals[r];
-        a.push_back(0.0);
-        std::sort(a.begin(), a.end());
-        a.erase(std::unique(a.begin(), a.end()), a.end());
-        uint32_t k = 1;
-        while ((size_t{1} << k) - 1 < a.size()) ++k;
-        steps[r] = k, loff[r] = static_cast<uint32_t>(list_doubles);
-        list_doubles += (size_t{1} << k);  // 2^k - 1 entries and one pad: every list starts 16-byte aligned
-      }
-      std::vector<uint32_t>& b = blocks[static_cast<size_t>(c)];
-      b.assign(16 + 2 * list_doubles + rows * PWR, 0u);
-      for (size_t r = 0; r < R; ++r) b[r] = steps[r] | (loff[r] << 8);
-      b[8] = static_cast<uint32_t>(rows);
-      // every list of the chunk (leading 0 included) has at most 127 entries: positions and counts fit 7 bits, the kernel packs four zones
-      // per dword (RkLayout<true>, kernels_nrt_rank.hip) and the thresholds below are replicated into four bytes instead of two halves
-      bool narrow = narrow_ok;
-      for (size_t r = 0; r < R; ++r) narrow = narrow && vals[r].size() <= 127;
-      b[9] = narrow ? 1u : 0u;
-      for (size_t r = 0; r < R; ++r) {
-        double* dst = reinterpret_cast<double*>(&b[16]) + loff[r];
-        const size_t n = size_t{1} << steps[r];
-        for (size_t j = 0; j < n; ++j) dst[j] = j < vals[r].size() ? vals[r][j] : std::numeric_limits<double>::infinity();
-      }
-      for (size_t i = 0; i < rows; ++i) {
-        uint32_t* dst = &b[16 + 2 * list_doubles + i * PWR];
-        std::memcpy(dst, &head[i * spx::kRkPodHead], spx::kRkPodHead * sizeof(uint32_t));
-        for (size_t vi = 0; vi < spx::kRkVectors; ++vi)
-          for (size_t r = 0; r < R; ++r) {
-            const double q = vec[(i * spx::kRkVectors + vi) * RM + r];
-            if (q != q) continue;
-            const uint32_t t = static_cast<uint32_t>(std::lower_bound(vals[r].begin(), vals[r].end(), q) - vals[r].begin()) + 1u;
-            dst[spx::kRkPodHead + vi * RM + r] = narrow ? t * 0x01010101u : (t | (t << 16));
+        // per container one byte of what the fused sweep (kernels_nrt_fused.hip) does with it, so that its loop tests bits instead of
+        // deriving them (h[12]: containers 0-3, h[13]: 4-7): bits 0-2 the status a misfit sets, spx::kRkOp*
+        const uint32_t last_app = w[0] >> 24;
+        for (uint32_t ctr = 0; ctr < n_ctr && ctr < SPX_NRT_MAX_CTRS; ++ctr) {
+          const uint32_t kind = h[3 + ctr] >> 24, fit = fit_of(2 + ctr);
+          uint32_t op = kind == SPX_CTR_APP ? SPX_NRT_ST_CONTAINER : (kind == SPX_CTR_SIDECAR ? SPX_NRT_ST_SIDECAR_CONTAINER : SPX_NRT_ST_INIT_CONTAINER);
+          if (kind == SPX_CTR_APP && fit != 0 && n_app <= 3) {
+            if (ctr == app[1]) op |= spx::kRkOpMerge1;
+            else if (ctr == app[2]) op |= spx::kRkOpMerge3;
+            if (ctr != last_app) op |= ctr == app[0] ? spx::kRkOpCharge0 : spx::kRkOpCharge1;
           }
+          h[12 + (ctr >> 2)] |= op << (8 * (ctr & 3));
+        }
       }
+      // pass 2: the chunk [lo, hi) of the group — its lists, then the thresholds.  A chunk whose lists all have at most 127 entries (leading 0
+      // included) is "narrow": positions and counts fit 7 bits, the kernels pack four zones per dword (RkLayout<true>) and the thresholds are
+      // replicated into four bytes instead of two halves.  With narrow_ok a chunk that is not is split in halves until it is (a single pod
+      // compares at most 13 values per slot), so that every chunk of the stream is narrow — the fused sweep has no other layout.
+      std::vector<Block>& out = groups[static_cast<size_t>(c)];
+      auto emit = [&](auto&& self, size_t lo, size_t hi) -> void {
+        for (size_t r = 0; r < R; ++r) {
+          auto& a = vals[r];
+          a.clear();
+          a.push_back(0.0);
+          for (size_t i = lo; i < hi; ++i)
+            for (size_t vi = 0; vi < spx::kRkVectors; ++vi) {
+              const double q = vec[(i * spx::kRkVectors + vi) * RM + r];
+              if (q == q) a.push_back(q);
+            }
+          std::sort(a.begin(), a.end());
+          a.erase(std::unique(a.begin(), a.end()), a.end());
+        }
+        bool narrow = true;
+        for (size_t r = 0; r < R; ++r) narrow = narrow && vals[r].size() <= 127;
+        if (narrow_ok && !narrow && hi - lo > 1) {
+          const size_t mid = lo + (hi - lo) / 2;
+          self(self, lo, mid);
+          self(self, mid, hi);
+          return;
+        }
+        narrow = narrow && narrow_ok;
+        if (!narrow) all_narrow = false;
+        uint32_t steps[SPX_NRT_MAX_RES] = {0}, loff[SPX_NRT_MAX_RES] = {0};
+        size_t list_doubles = 0;
+        for (size_t r = 0; r < R; ++r) {
+          uint32_t k = 1;
+          while ((size_t{1} << k) - 1 < vals[r].size()) ++k;
+          steps[r] = k, loff[r] = static_cast<uint32_t>(list_doubles);
+          list_doubles += (size_t{1} << k);  // 2^k - 1 entries and one pad: every list starts 16-byte aligned
+        }
+        out.emplace_back();
+        Block& blk = out.back();
+        blk.first = static_cast<uint32_t>(first + lo), blk.rows = static_cast<uint32_t>(hi - lo);
+        std::vector<uint32_t>& b = blk.w;
+        b.assign(16 + 2 * list_doubles + (hi - lo) * PWR, 0u);
+        for (size_t r = 0; r < R; ++r) b[r] = steps[r] | (loff[r] << 8);
+        b[8] = static_cast<uint32_t>(hi - lo);
+        b[9] = narrow ? 1u : 0u;
+        for (size_t r = 0; r < R; ++r) {
+          double* dst = reinterpret_cast<double*>(&b[16]) + loff[r];
+          const size_t n = size_t{1} << steps[r];
+          for (size_t j = 0; j < n; ++j) dst[j] = j < vals[r].size() ? vals[r][j] : std::numeric_limits<double>::infinity();
+        }
+        for (size_t i = lo; i < hi; ++i) {
+          uint32_t* dst = &b[16 + 2 * list_doubles + (i - lo) * PWR];
+          std::memcpy(dst, &head[i * spx::kRkPodHead], spx::kRkPodHead * sizeof(uint32_t));
+          for (size_t vi = 0; vi < spx::kRkVectors; ++vi)
+            for (size_t r = 0; r < R; ++r) {
+              const double q = vec[(i * spx::kRkVectors + vi) * RM + r];
+              // a non-Guaranteed pod's NUMA-affine request: "count >= 1" (filter.go:120-129); k_nrt_filter_rank derives it from the slot
+              // sets, the fused sweep reads it here; a slot the item does not compare keeps 0 ("count >= 0": every zone passes)
+              if ((any_always[i * spx::kRkVectors + vi] >> r) & 1u) dst[spx::kRkPodHead + vi * RM + r] = narrow ? 0x01010101u : 0x00010001u;
+              if (q != q) continue;
+              const uint32_t t = static_cast<uint32_t>(std::lower_bound(vals[r].begin(), vals[r].end(), q) - vals[r].begin()) + 1u;
+              dst[spx::kRkPodHead + vi * RM + r] = narrow ? t * 0x01010101u : (t | (t << 16));
+            }
+        }
+      };
+      emit(emit, 0, rows);
     }
   }, 8);
+  size_t n_chunks = 0;
+  for (const auto& g : groups) n_chunks += g.size();
   off.assign(n_chunks + 1, 0u);
+  first_out.assign(n_chunks + 1, static_cast<uint32_t>(n_list));
+  std::vector<const Block*> flat;
+  flat.reserve(n_chunks);
+  for (const auto& g : groups)
+    for (const Block& blk : g) flat.push_back(&blk);
   uint32_t max_dwords = 0;
   for (size_t c = 0; c < n_chunks; ++c) {
-    off[c + 1] = off[c] + static_cast<uint32_t>((blocks[c].size() + 3) & ~size_t{3});
+    off[c + 1] = off[c] + static_cast<uint32_t>((flat[c]->w.size() + 3) & ~size_t{3});
+    first_out[c] = flat[c]->first;
     max_dwords = std::max<uint32_t>(max_dwords, off[c + 1] - off[c]);
   }
   words.assign(off[n_chunks], 0u);
   spx_host::parallel_rows(static_cast<int64_t>(n_chunks), [&](int64_t c0, int64_t c1) {
-    for (int64_t c = c0; c < c1; ++c) std::memcpy(&words[off[static_cast<size_t>(c)]], blocks[static_cast<size_t>(c)].data(), blocks[static_cast<size_t>(c)].size() * sizeof(uint32_t));
+    for (int64_t c = c0; c < c1; ++c) std::memcpy(&words[off[static_cast<size_t>(c)]], flat[static_cast<size_t>(c)]->w.data(), flat[static_cast<size_t>(c)]->w.size() * sizeof(uint32_t));
   }, 64);
   *max_dwords_out = max_dwords;
   *ok_out = ok.load();
+  *all_narrow_out = all_narrow.load();
 }
 }  // namespace
+
+// builds the stream of `list` and ships it; e->nrt_rk_kind = kind on success, 0 when it does not fit, -1 when the batch has none
+int nrt_rank_stream_upload(spx_engine* e, const uint32_t* items, const int32_t* list, size_t n_list, int kind) {
+  std::vector<uint32_t> rk, rk_off, rk_first;
+  uint32_t rk_max = 0;
+  bool rk_ok = false, all_narrow = false;
+  nrt_build_rank_stream(items, list, n_list, static_cast<size_t>(e->nrt_n_res), rk, rk_off, rk_first, &rk_max, &rk_ok, &all_narrow, e->option[SPX_OPT_NRT_RANK_NARROW] != 0);
+  e->nrt_rk_max_dwords = 0;
+  e->nrt_rk_kind = rk_ok ? 0 : -1;
+  if (rk_ok && rk_max * sizeof(uint32_t) <= spx::kRkMaxChunkBytes) {
+    int rc;
+    if ((rc = upload(e, e->d_nrt_rk, rk.data(), rk.size() * sizeof(uint32_t)))) return rc;
+    if ((rc = upload(e, e->d_nrt_rk_off, rk_off.data(), rk_off.size() * sizeof(uint32_t)))) return rc;
+    if ((rc = upload(e, e->d_nrt_rk_first, rk_first.data(), rk_first.size() * sizeof(uint32_t)))) return rc;
+    SPX_HIP(e, hipStreamSynchronize(e->stream));
+    e->nrt_rk_max_dwords = rk_max;
+    e->nrt_rk_chunks = static_cast<uint32_t>(rk_first.size() - 1);
+    e->nrt_rk_all_narrow = all_narrow;
+    e->nrt_rk_kind = kind;
+  }
+  return SPX_OK;
+}
+
+// The rank stream over EVERY row of the uploaded batch, in order (a whole-batch sweep without pod classes: SPX_OPT_NRT_POD_CLASSES 0,
+// or a queue with too few repeats for them): built the first time such a sweep runs after an upload — the record stream comes back
+// from the device (the host copy was staging) — and kept until the next upload or until a sweep over the classes replaces it.
+int nrt_rank_stream(spx_engine* e, int kind) {
+  if (e->nrt_rk_kind == kind) return SPX_OK;
+  if (e->nrt_rk_kind < 0 || !e->nrt_fast_pods || e->n_pods <= 0) return SPX_OK;  // no finite stream for this batch: the float64 Filter
+  if (kind == 1 && e->nrt_n_dups == 0) return SPX_OK;
+  const size_t p = static_cast<size_t>(e->n_pods), R = static_cast<size_t>(e->nrt_n_res), IW = R <= 4 ? 16 : 32;
+  std::vector<uint32_t> items(p * 10 * IW);
+  SPX_HIP(e, hipStreamSynchronize(e->stream));
+  SPX_HIP(e, hipMemcpy(items.data(), e->d_nrt_items.p, items.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  std::vector<int32_t> list;
+  if (kind == 2) {
+    list.resize(p);
+    for (size_t i = 0; i < p; ++i) list[i] = static_cast<int32_t>(i);
+  } else {
+    list.resize(static_cast<size_t>(e->nrt_n_uniq));
+    SPX_HIP(e, hipMemcpy(list.data(), e->d_nrt_uniq.p, list.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return nrt_rank_stream_upload(e, items.data(), list.data(), list.size(), kind);
+}
 
 // test hook (host only, no device): the representative row of every pod of a batch, as spx_upload_nrt_pods computes it
 // (rep_out[i] == i for a representative); *fast_ok_out = whether the batch satisfies the float64 formulation's preconditions
@@ -1904,6 +2010,7 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
     }
     e->nrt_n_uniq = e->nrt_n_dups = 0;
     e->nrt_rk_max_dwords = 0;
+    e->nrt_rk_kind = 0;
     if (e->nrt_fast_pods && p > 0) {
       std::vector<int32_t> rep(p);
       nrt_build_classes(items, hash.data(), p, R, rep.data());
@@ -1919,18 +2026,8 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
         SPX_HIP(e, hipStreamSynchronize(e->stream));
         e->nrt_n_uniq = static_cast<int64_t>(uniq.size());
         e->nrt_n_dups = static_cast<int64_t>(dups.size() / 2);
-        // the representatives' requests as ranks, per chunk of 32 (kernels_nrt_rank.hip)
-        std::vector<uint32_t> rk, rk_off;
-        uint32_t rk_max = 0;
-        bool rk_ok = false;
-        nrt_build_rank_stream(items, uniq.data(), uniq.size(), R, rk, rk_off, &rk_max, &rk_ok, e->option[SPX_OPT_NRT_RANK_NARROW] != 0);
-        e->nrt_rk_max_dwords = 0;
-        if (rk_ok && rk_max * sizeof(uint32_t) <= spx::kRkMaxChunkBytes) {
-          if ((rc = upload(e, e->d_nrt_rk, rk.data(), rk.size() * sizeof(uint32_t)))) return rc;
-          if ((rc = upload(e, e->d_nrt_rk_off, rk_off.data(), rk_off.size() * sizeof(uint32_t)))) return rc;
-          SPX_HIP(e, hipStreamSynchronize(e->stream));
-          e->nrt_rk_max_dwords = rk_max;
-        }
+        // the representatives' requests as ranks, per chunk of up to 32 (kernels_nrt_rank.hip, kernels_nrt_fused.hip)
+        if ((rc = nrt_rank_stream_upload(e, items, uniq.data(), uniq.size(), 1))) return rc;
       }
     }
   }
@@ -2318,13 +2415,31 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
         na.pk_tab_built = &e->nrt_pk_tab_built;
       }
     }
+    // the fused Filter + Score launch (kernels_nrt_fused.hip): a whole-batch LeastAllocated sweep in the packed Score's preconditions with unit
+    // weights; it walks the rank stream of the class representatives or, without classes, of every row
+    bool fused = e->option[SPX_OPT_NRT_FUSED] && e->option[SPX_OPT_NRT_RANK_FILTER] && na.pk_mode && !(na.opts & spx::kOptNrtSingleLaunch) &&
+                 row_begin == 0 && row_end == e->n_pods;
+    fused = fused && e->option[SPX_OPT_NRT_RANK_NARROW];  // (its only count layout)
+    for (int i = 0; fused && i < e->nrt_n_res; ++i) fused = e->nrt_slot_weight[i] == 0 || e->nrt_slot_weight[i] == 1;
+    if (classes || fused) {
+      if ((rc = nrt_rank_stream(e, classes ? 1 : 2))) return rc;
+    }
+    const bool stream = e->nrt_rk_max_dwords && e->nrt_rk_kind == (classes ? 1 : 2) && e->option[SPX_OPT_NRT_RANK_FILTER];
     if (classes) {
       na.row_list = static_cast<const int32_t*>(e->d_nrt_uniq.p);
       na.n_list = e->nrt_n_uniq;
-      if (e->nrt_rk_max_dwords && e->option[SPX_OPT_NRT_RANK_FILTER]) {  // the Filter launch in rank space
-        na.rk_stream = static_cast<const uint32_t*>(e->d_nrt_rk.p);
-        na.rk_off = static_cast<const uint32_t*>(e->d_nrt_rk_off.p);
-        na.rk_max_dwords = e->nrt_rk_max_dwords;
+    }
+    fused = fused && stream && e->nrt_rk_all_narrow;
+    if (stream && (classes || fused)) {  // the Filter in rank space (its own launch, or inside the fused one)
+      na.rk_stream = static_cast<const uint32_t*>(e->d_nrt_rk.p);
+      na.rk_off = static_cast<const uint32_t*>(e->d_nrt_rk_off.p);
+      na.rk_max_dwords = e->nrt_rk_max_dwords;
+      na.rk_first = static_cast<const uint32_t*>(e->d_nrt_rk_first.p);
+      na.rk_chunks = e->nrt_rk_chunks;
+      if (!classes) na.n_list = e->n_pods;
+      if (fused) {
+        if ((rc = ensure(e, e->d_nrt_fz, spx::nrt_fused_item_words(e->nrt_n_res, na.n_list) * sizeof(uint32_t)))) return rc;
+        na.fz_items = static_cast<uint32_t*>(e->d_nrt_fz.p);
       }
     }
     if (na.strategy == SPX_NRT_LEAST_NUMA_NODES && na.fast && !(na.opts & spx::kOptNrtGeneric) && !e->row_indirect) {
@@ -2360,8 +2475,8 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
         }
       }
     }
-    spx::launch_nrt(na, e->stream);
-    e->last_nrt_filter = na.rk_stream ? 2 : 1;
+    const bool ran_fused = spx::launch_nrt(na, e->stream);
+    e->last_nrt_filter = ran_fused ? 3 : (na.rk_stream ? 2 : 1);
     if (classes)
       spx::launch_rows_expand(static_cast<const int32_t*>(e->d_nrt_dups.p), e->nrt_n_dups, na.out_status, na.out_score, e->row_stride, e->stream);
     SPX_HIP(e, hipGetLastError());

@@ -296,6 +296,8 @@ struct NrtArgs {
   const uint32_t* rk_stream;
   const uint32_t* rk_off;        // [chunks + 1] dword offsets of the chunk blocks
   uint32_t rk_max_dwords;        // largest chunk block (dynamic LDS)
+  const uint32_t* rk_first;      // [rk_chunks + 1] position in the row list of each chunk's first row (a chunk holds up to 32 rows)
+  uint32_t rk_chunks;
   uint32_t exact32_slots;        // resource slots whose requests and capacities (Value() form) are all float32 values (below 2^24, or a multiple of a large power of two): compared exactly
   // LeastAllocated's Score-only launch in packed float32 (nrt_fast_device.h, score_least_packed): zone PAIRS per instruction, u16 zone totals
   uint32_t pk_mode;              // 0 = off (every other kernel / strategy / launch form)
@@ -305,6 +307,9 @@ struct NrtArgs {
   uint32_t pk_tab_kmax;          // largest request / unit of the pod batch
   double pk_tab_inv_unit;        // 1 / unit; unit = the largest power of two dividing every request of the slot
   bool* pk_tab_built;            // host flag: pk_tab describes the zone capacities and the unit in place (cleared by every writer of either)
+  // the fused Filter + Score sweep (kernels_nrt_fused.hip): scratch for the packed Score items of the listed rows
+  // (nrt_fused_item_words dwords); NULL = the Filter and Score launches
+  uint32_t* fz_items;
 };
 constexpr int64_t kNrtPkTabMaxK = (int64_t{1} << 17) - 1;   // request / unit above this: the float64 form
 constexpr size_t kNrtPkTabMaxBytes = size_t{64} << 20;
@@ -313,8 +318,16 @@ constexpr double kNrtNoCap = 1e200;
 // rank-space Filter: chunk rows, comparison vectors per pod (pod-level, 8 containers, 4 sums), head dwords of a pod record
 // (w0, w1, the slot sets of items 1..9, app containers a0 | a1 << 8 | a2 << 16 | count << 24, pad), largest chunk block
 constexpr int kRkChunkRows = 32, kRkVectors = 13, kRkPodHead = 16;
+// head dwords 12 / 13 of a pod record: one byte per container for the fused sweep — bits 0-2 the Filter status a misfit sets, then
+constexpr uint32_t kRkOpMerge1 = 8;    // the second app container: its verdict for the zone a0 was charged to comes from vector 9
+constexpr uint32_t kRkOpMerge3 = 16;   // the third: vectors 10 / 11 / 12 for the zones a0 / a1 / both were charged to
+constexpr uint32_t kRkOpCharge0 = 32;  // the lowest fitting zone is remembered as a0's
+constexpr uint32_t kRkOpCharge1 = 64;  // ... as a1's
 constexpr size_t kRkMaxChunkBytes = 56 * 1024;
-bool launch_nrt_filter_rank(const NrtArgs& a, int n_tiles, unsigned blocks, hipStream_t s);
+bool launch_nrt_filter_rank(const NrtArgs& a, int n_tiles, hipStream_t s);
+size_t nrt_fused_item_words(int n_res, int64_t n_list);
+bool launch_nrt_fused(const NrtArgs& a, hipStream_t s);
+void launch_nrt_pk_tab_build(const NrtArgs& a, int n_tiles, hipStream_t s);  // kernels_nrt_fast.hip: the packed Score's table of exceptions
 
 // combin.Combinations(8, k) for k = 1..8 as bitmasks over list positions, size-major then lexicographic — the order
 // least_numa.go:167-208 walks.  Subsets of a node with fewer zones are the entries without high positions, in the same
@@ -382,7 +395,7 @@ constexpr LnLayout make_ln_layout() {
   l.rows = kLnDwords + prow;
   return l;
 }
-void launch_nrt(const NrtArgs& a, hipStream_t s);
+bool launch_nrt(const NrtArgs& a, hipStream_t s);  // true = ran as the fused Filter + Score launch
 // the reference-arithmetic kernel's per-container request column [P][8][n_res] int64, rebuilt from the pod record stream (whose
 // quantities are exact doubles whenever the stream is valid): the engine does not ship that column — 256 bytes per pod — with every
 // pod batch, only when a launch is going to read it

@@ -338,6 +338,75 @@ def test_rank_filter_equals_float64_filter(gpu_required, hdr, oracle, wide, narr
         assert np.array_equal(ranked[r], osnap.filter_rows(NRT, r, r + 1)[0]), r
 
 
+# ------------------------------------------------------------------ Filter + Score in one launch (SPX_OPT_NRT_FUSED)
+@pytest.mark.parametrize("classes", [1, 0], ids=["pod-classes", "every-row"])
+@pytest.mark.parametrize("narrow", [1, 0], ids=["narrow-chunks", "wide-only"])
+@pytest.mark.parametrize("wide", [False, True], ids=["4slots", "6slots"])
+def test_fused_sweep_equals_two_launches(gpu_required, hdr, oracle, wide, narrow, classes):
+    """A whole-batch LeastAllocated sweep with unit weights runs Filter and Score in ONE launch (kernels_nrt_fused.hip: the rank-space
+    Filter evaluated branch-free, the Score as a chain of two float32 instructions per (zone, resource), the chunk's pod records
+    staged once); with the option off the Filter launch and the packed Score launch run.  Same two tables, cell for cell, with
+    pod classes (the stream lists the representatives) and without (the stream lists every row, built when the sweep first asks),
+    in both count layouts, for four and six resource slots; and the oracle's rows on a sample."""
+    n_nodes, n_pods = 1500, 2500
+    snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=37, wide=wide)
+    params = O.nrt_params(hdr, O.Resources(), "LeastAllocated")
+    with Engine(0) as e:
+        e.set_option("NRT_RANK_NARROW", narrow)
+        e.set_option("NRT_POD_CLASSES", classes)
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+        assert e.get_option("NRT_FUSED") == 1
+        e.eval(mask_of(NRT))
+        e.sync()
+        # (the fused sweep has the four-zones-per-register layout only: with SPX_OPT_NRT_RANK_NARROW off the two launches run)
+        fused_path = 3 if narrow else (2 if classes else 1)
+        assert e.nrt_filter_path() == fused_path
+        status, score = e.all_status(NRT), e.all_scores(NRT)
+        e.set_option("NRT_FUSED", 0)
+        e.eval(mask_of(NRT))
+        e.sync()
+        assert e.nrt_filter_path() == (2 if classes else 1)
+        assert np.array_equal(e.all_status(NRT), status) and np.array_equal(e.all_scores(NRT), score)
+        assert len(set(np.unique(status).tolist())) >= 4  # several of the Filter's verdicts occur
+        e.set_option("NRT_FUSED", 1)
+        e.set_option("NRT_POD_CLASSES", 1 - classes)  # the other row list: the stream is rebuilt for it
+        e.eval(mask_of(NRT))
+        e.sync()
+        assert e.nrt_filter_path() == (3 if narrow else (1 if classes else 2))
+        assert np.array_equal(e.all_status(NRT), status) and np.array_equal(e.all_scores(NRT), score)
+    osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
+    for r in list(range(0, n_pods, 97)) + [n_pods - 1]:
+        assert np.array_equal(status[r], osnap.filter_rows(NRT, r, r + 1)[0]), r
+        assert np.array_equal(score[r].astype(np.int64), osnap.score_rows(NRT, r, r + 1, want_norm=False)[0][0].clip(0, 255)), r
+
+
+def test_fused_sweep_steps_aside(gpu_required, hdr, oracle):
+    """weights other than 0 / 1, another strategy, or a row range: the Filter and Score launches run, same results as the oracle"""
+    n_nodes, n_pods = 700, 900
+    snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=41)
+    res = O.Resources()
+    for strategy, weights in (("LeastAllocated", {"cpu": 3, "memory": 1}), ("MostAllocated", None)):
+        params = O.nrt_params(hdr, res, strategy, weights)
+        with Engine(0) as e:
+            e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+            e.eval(mask_of(NRT))
+            e.sync()
+            assert e.nrt_filter_path() == 2
+            osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
+            for r in range(0, n_pods, 61):
+                assert np.array_equal(e.status(NRT, r), osnap.filter_rows(NRT, r, r + 1)[0]), (strategy, r)
+                assert np.array_equal(e.scores(NRT, r).astype(np.int64), osnap.score_rows(NRT, r, r + 1, want_norm=False)[0][0].clip(0, 255)), (strategy, r)
+    params = O.nrt_params(hdr, res, "LeastAllocated")
+    with Engine(0) as e:
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+        e.eval(mask_of(NRT), 0, 450)
+        e.sync()
+        assert e.nrt_filter_path() == 1
+        e.eval(mask_of(NRT))
+        e.sync()
+        assert e.nrt_filter_path() == 3
+
+
 # ------------------------------------------------------------------ full size (config #3): sampled rows + properties
 def test_config3_full_size_properties(gpu_required, hdr, oracle):
     n_nodes, n_pods = 5_000, 50_000
