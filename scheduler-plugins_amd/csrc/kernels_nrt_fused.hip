@@ -74,9 +74,12 @@ __global__ __launch_bounds__(256) void k_nrt_fused_pack(NrtArgs a, uint32_t* __r
     if (r < a.n_res && a.slot_weight[r] != 0) wmask |= 1u << r;
   auto f64 = [&](int at) { return __hiloint2double(static_cast<int>(w[at + 1]), static_cast<int>(w[at])); };
   uint32_t* o = out + idx * fz_item_words<RM>();
-#pragma unroll
-  for (int r = 0; r < RM; ++r) o[r] = __float_as_uint(-static_cast<float>(f64(r == a.cpu_slot ? 2 * RM + 2 : 2 * r)));  // Value() of the cpu request
   const uint32_t used = w[2 * RM] & 0xffu & wmask;
+  // -Value(request); -inf for a slot that is not requested or weighs nothing: its chain, run because another lane's item needs it or
+  // because the walk only knows the unweighted slot set, adds clamp01(-inf) = 0
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+    o[r] = ((used >> r) & 1u) ? __float_as_uint(-static_cast<float>(f64(r == a.cpu_slot ? 2 * RM + 2 : 2 * r))) : 0xff800000u;
   const uint32_t k = static_cast<uint32_t>(__builtin_popcount(used));
   o[RM] = used | ((k ? (32768u + k - 1u) / k : 0u) << 8);
   o[RM + 1] = kFzMagicBits - k;
@@ -167,57 +170,65 @@ __device__ __forceinline__ FzItem<RM> fz_load_item(const uint32_t* it) {
 // RN32(RN64(100 / capacity)) / 128 (+inf without capacity), c0s[r] = (99.5 + o_r) / 128.  MIXED (second pass): the table slot's resource
 // scores come from the float64 form (bt[z] = RN64(100 / capacity), raw = the request as written), as score_least_packed<.., true>.
 template <int RM, bool MIXED, bool FIRST1>
-__device__ __forceinline__ uint32_t fz_score_item(const float (&bs)[RM][kZ], const float (&c0s)[RM], int ts, const FzItem<RM>& g, const uint32_t* it = nullptr,
-                                                  const double* __restrict__ bt = nullptr) {
-  const uint32_t w0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g.w0)));
-  const uint32_t top = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g.w1)));  // bits of 1.5 * 2^23, minus k
-  const uint32_t used = w0 & 0xffu, invk = w0 >> 8;
-  if (used == 0) return 0;  // no weighted slot requested (wave-uniform)
+__device__ __forceinline__ uint32_t fz_score_item(const float (&bs)[RM][kZ], const float (&c0s)[RM], int ts, uint32_t slots, const FzItem<RM>& g,
+                                                  const uint32_t* it = nullptr, const double* __restrict__ bt = nullptr) {
+  // `slots` (wave-uniform): the chains to run — every slot some lane at work requests (a lane's item holds -inf for the others).  What
+  // depends on the item's OWN slot count k stays per lane: g.w1 = the bits of 1.5 * 2^23 minus k, g.w0 >> 8 = ceil(2^15 / k) (0: k = 0)
   float acc[kZ];
 #pragma unroll
   for (int z = 0; z < kZ; ++z) acc[z] = kFzMagic;
-  if (!MIXED && RM == 4 && used == 3u) {
-    // the common item — the first two slots (cpu and memory) and nothing else — without the per-slot tests; the table slot first
-    // (FIRST1: the table slot is not slot 0 — the launch's choice of instantiation)
-    fz_chain(acc, g.nv[FIRST1 ? 1 : 0], bs[FIRST1 ? 1 : 0], c0s[FIRST1 ? 1 : 0]);
-    fz_chain(acc, g.nv[FIRST1 ? 0 : 1], bs[FIRST1 ? 0 : 1], c0s[FIRST1 ? 0 : 1]);
-  } else {
-    uint32_t rest = used;
-    // the table slot first: its t may tie, and only onto the even start value does "round the sum to nearest even" equal "round t"
-    if (ts >= 0 && ((used >> ts) & 1u)) {
-      rest &= ~(1u << ts);
-      if constexpr (MIXED) {
+  // One chain per slot, each behind a scalar test.  The table slot first: its t may tie, and only onto the even start value does
+  // "round the sum to nearest even" equal "round t" — the table slot is slot 0 or 1 (launch_nrt_fused), and FIRST1, the launch's choice
+  // of instantiation, says which of the two is chained first (slot 1 unless the table slot is slot 0)
+  constexpr int A = FIRST1 ? 1 : 0, B = FIRST1 ? 0 : 1;
+  if ((slots >> A) & 1u) {
+    SPX_KEEP_BRANCH();
+    if constexpr (MIXED) {
+      if (ts == A) {  // uniform: the float64 form of this slot's resource scores (a lane that does not request it: raw = 0 against +inf... see below)
         const double raw = __hiloint2double(static_cast<int>(it[RM + 3]), static_cast<int>(it[RM + 2]));
+        const bool mine = __float_as_uint(g.nv[A]) != 0xff800000u;
 #pragma unroll
-        for (int z = 0; z < kZ; ++z) acc[z] = kFzMagic - static_cast<float>(static_cast<uint32_t>(__builtin_fma(-raw, bt[z], 100.0 + 0x1p-43)));
+        for (int z = 0; z < kZ; ++z)
+          acc[z] = mine ? kFzMagic - static_cast<float>(static_cast<uint32_t>(__builtin_fma(-raw, bt[z], 100.0 + 0x1p-43))) : kFzMagic;
       } else {
-#pragma unroll
-        for (int r = 0; r < RM; ++r)
-          if (r == ts) {  // uniform
-            SPX_KEEP_BRANCH();
-            fz_chain(acc, g.nv[r], bs[r], c0s[r]);
-          }
+        fz_chain(acc, g.nv[A], bs[A], c0s[A]);
       }
-    }
-#pragma unroll
-    for (int r = 0; r < RM; ++r) {
-      if (!((rest >> r) & 1u)) continue;  // uniform
-      SPX_KEEP_BRANCH();
-      fz_chain(acc, g.nv[r], bs[r], c0s[r]);
+    } else {
+      fz_chain(acc, g.nv[A], bs[A], c0s[A]);
     }
   }
+  if ((slots >> B) & 1u) {
+    SPX_KEEP_BRANCH();
+    fz_chain(acc, g.nv[B], bs[B], c0s[B]);
+  }
+#pragma unroll
+  for (int r = 2; r < RM; ++r) {
+    if (!((slots >> r) & 1u)) continue;  // uniform
+    SPX_KEEP_BRANCH();
+    fz_chain(acc, g.nv[r], bs[r], c0s[r]);
+  }
   // u = total - k as an unsigned integer: a zone whose total is below k (score 0) wraps to the top and leaves the minimum
+  const uint32_t top = g.w1;
   uint32_t u[kZ];
 #pragma unroll
   for (int z = 0; z < kZ; ++z) u[z] = top - __float_as_uint(acc[z]);
   auto min3 = [](uint32_t x, uint32_t y, uint32_t w) { return min(min(x, y), w); };
   const uint32_t mm = min3(min3(u[0], u[1], u[2]), min3(u[3], u[4], u[5]), min(u[6], u[7]));
-  // (no zone scores: mm + k wraps to the smallest total, below k, and the quotient is the reference's 0)
-  return __umul24(mm + (kFzMagicBits - top), invk) >> 15;  // floor(total / k): total <= 800, k <= 8, invk = ceil(2^15 / k)
+  // (no zone scores: mm + k wraps to the smallest total, below k, and the quotient is the reference's 0; k = 0: the multiplier is 0)
+  return __umul24(mm + (kFzMagicBits - top), g.w0 >> 8) >> 15;  // floor(total / k): total <= 800, k <= 8, ceil(2^15 / k)
 }
 
-// the pod loop.  One count layout: four zones per register (every chunk of the stream is narrow — the engine splits a chunk whose lists
-// would pass 127 entries — or the fused sweep is not launched)
+// The pod loop.  One count layout: four zones per register (every chunk of the stream is narrow — the engine splits a chunk whose lists
+// would pass 127 entries — or the fused sweep is not launched).
+//
+// One walk for both scopes: a pod-scope node (singleNUMAPodLevelHandler filter.go:165-184, podScopeScore score.go:142-150) is a
+// container-scope node whose pod has ONE container — the pod-level request (comparison vector 0, Score item 0), misfit status "cannot
+// align pod", mean over one.  Step c of the loop serves the container-scope lanes' container c and, at c = 0, the pod-scope lanes' pod-level
+// item: a lane reads ITS vector and item (two addresses per wave at most), so a wave that holds both kinds of node — one in four: the
+// engine orders a window's nodes by scope, and the boundary falls inside a wave — pays the longer path instead of the sum of the two.
+// What steers scalar branches — which slots' Score chains run — is the union of the slot sets of the items at work (from the pod's head);
+// an item holds -inf for a slot it does not request, whose chain then adds nothing, and the constants that follow from its own slot
+// count (2^15 / k, 1.5 * 2^23 - k) are read per lane.
 template <int RM, bool FIRST1, bool NARROW = true>
 __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float (&bs)[RM][kZ], const float (&c0s)[RM], int ts, const uint32_t* pods,
                                         const uint32_t* sitems, int rows, int lane, bool w_pod, bool w_ctr, bool aligned, bool pod_scope, uint32_t st_stale,
@@ -230,6 +241,8 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
   for (int r = 0; r < RM; ++r)
 #pragma unroll
     for (int j = 0; j < W; ++j) qa[r][j] = q4[r][j];
+  // a lane's first step: vector / item 0 (the pod-level request) for a pod-scope node, 1 (container 0) otherwise — byte offsets into the record
+  const uint32_t thr0 = (kRkPodHead + (pod_scope ? 0 : RM)) * 4u, item0 = (pod_scope ? 0 : fz_item_words<RM>()) * 4u;
   uint32_t acc_status = 0, acc_score = 0;
   uint32_t hv = pods[lane & 15];  // a pod's head: lane l holds dword l & 15; the fields become scalars as they are needed
   for (int p = 0; p < rows; ++p) {
@@ -244,35 +257,33 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
     const bool scored = qos == SPX_QOS_GUARANTEED;                                  // score.go:72-76: every other pod scores 100
     uint32_t status = filtered ? st_stale : 0u;
     uint32_t score = scored ? 0u : 100u;
-    if (filtered) {  // uniform (a Guaranteed pod is always filtered)
-      if (w_pod && pod_scope && aligned) {  // singleNUMAPodLevelHandler, podScopeScore
-        const FzThr<RM> t = fz_load_thr<RM>(rec + kRkPodHead);
-        const FzItem<RM> g = fz_load_item<RM>(sit);
-        uint32_t m[W];
-        fz_mask<RM, NARROW>(qa, t, m);
-        if (fz_none(m)) status = SPX_NRT_ST_POD;
-        if (scored) score = fz_score_item<RM, false, FIRST1>(bs, c0s, ts, g);
-      }
-      if (w_ctr && !pod_scope && aligned) {  // singleNUMAContainerLevelHandler / containerScopeScore: containers in order
-        const int n_ctr = static_cast<int>((w0 >> 16) & 0xffu);
-        uint32_t ops = head(12);
-        const uint32_t ops_hi = head(13);
-        uint32_t z0[W], z1[W];
+    const int n_ctr = static_cast<int>((w0 >> 16) & 0xffu);
+    const int n_steps = w_ctr && n_ctr > 0 ? n_ctr : (w_pod ? 1 : 0);
+    if (filtered && aligned && n_steps > 0) {  // (filtered, n_steps: uniform; a Guaranteed pod is always filtered)
+      uint32_t ops = head(12);
+      const uint32_t ops_hi = head(13);
+      uint32_t z0[W], z1[W];
 #pragma unroll
-        for (int j = 0; j < W; ++j) z0[j] = z1[j] = 0u;  // the zones app containers a0 / a1 were charged to (packed one-zone sets)
-        uint32_t sum = 0;
-        // the next container's thresholds and Score item are in flight while this one is worked on
-        FzThr<RM> t = fz_load_thr<RM>(rec + kRkPodHead + RM);
-        FzItem<RM> g = fz_load_item<RM>(sit + fz_item_words<RM>());
-        for (int c = 0; c < n_ctr; ++c) {  // (left to the compiler: it peels the first steps, 5 % faster than `unroll 1`)
-          const uint32_t op = ops & 0xffu;
-          ops = c == 3 ? ops_hi : ops >> 8;
-          const int cn = c + 1 < kC ? c + 1 : c;
-          const FzThr<RM> tn = fz_load_thr<RM>(rec + kRkPodHead + (1 + cn) * RM);
-          const FzItem<RM> gn = fz_load_item<RM>(sit + (1 + cn) * fz_item_words<RM>());
+      for (int j = 0; j < W; ++j) z0[j] = z1[j] = 0u;  // the zones app containers a0 / a1 were charged to (packed one-zone sets)
+      uint32_t sum = 0;
+      // the next step's thresholds and Score item are in flight while this one is worked on
+      FzThr<RM> t = fz_load_thr<RM>(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(rec) + thr0));
+      FzItem<RM> g = fz_load_item<RM>(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sit) + item0));
+      for (int c = 0; c < n_steps; ++c) {  // (left to the compiler: it peels the first steps, 5 % faster than `unroll 1`)
+        const uint32_t op = ops & 0xffu;
+        ops = c == 3 ? ops_hi : ops >> 8;
+        const int cn = c + 1 < kC ? c + 1 : c;
+        const FzThr<RM> tn = fz_load_thr<RM>(rec + kRkPodHead + (1 + cn) * RM);
+        const FzItem<RM> gn = fz_load_item<RM>(sit + (1 + cn) * fz_item_words<RM>());
+        // who takes this step: container-scope lanes while the pod has containers, pod-scope lanes the first one; the Score chains of
+        // every slot either kind of item requests (head dwords 2 / 3 + c: the items' slot sets)
+        const bool mine = pod_scope ? c == 0 : c < n_ctr;
+        uint32_t slots = (w_ctr && c < n_ctr) ? head(3 + c) & 0xffu : 0u;
+        if (w_pod && c == 0) slots |= head(2) & 0xffu;
+        if (mine) {
           uint32_t m[W];
           fz_mask<RM, NARROW>(qa, t, m);
-          if (op & (kRkOpMerge1 | kRkOpMerge3)) {  // uniform: an earlier app container may have been charged to a zone
+          if (op & (kRkOpMerge1 | kRkOpMerge3)) {  // uniform: an earlier app container may have been charged to a zone (c >= 1)
             if (op & kRkOpMerge1) {
               uint32_t ms[W];
               fz_mask<RM, NARROW>(qa, fz_load_thr<RM>(rec + kRkPodHead + 9 * RM), ms);
@@ -293,8 +304,9 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
             }
           }
           // the first misfit names the status (a later one finds it set); an empty verdict has no lowest zone: nothing is charged
-          if (fz_none(m) && status == 0u) status = op & 7u;
-          if (op & (kRkOpCharge0 | kRkOpCharge1)) {  // uniform
+          const uint32_t code = (w_pod && c == 0 && pod_scope) ? static_cast<uint32_t>(SPX_NRT_ST_POD) : (op & 7u);
+          if (fz_none(m) && status == 0u) status = code;
+          if (op & (kRkOpCharge0 | kRkOpCharge1)) {  // uniform (a pod-scope lane's copy is never read)
             uint32_t z[W];
             fz_lowest(m, z);
 #pragma unroll
@@ -303,12 +315,13 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
               else z1[j] = z[j];
             }
           }
-          if (scored) sum += fz_score_item<RM, false, FIRST1>(bs, c0s, ts, g);
-          t = tn;
-          g = gn;
+          if (scored) sum += fz_score_item<RM, false, FIRST1>(bs, c0s, ts, slots, g);
         }
-        if (scored) score = (sum * head(1)) >> 16;  // int64(mean): sum / n_ctr, sum <= 800; head 1 = ceil(2^16 / n_ctr)
+        t = tn;
+        g = gn;
       }
+      // int64(mean): sum / n_ctr, sum <= 800; head 1 = ceil(2^16 / n_ctr); a pod-scope lane's one item divides by one
+      if (scored) score = (sum * (pod_scope ? 65536u : head(1))) >> 16;
     }
     const int sh = 8 * (p & 3);
     acc_status |= status << sh;
@@ -476,13 +489,13 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
         uint32_t score = 0;
         if (aligned) {
           if (pod_scope) {
-            score = fz_score_item<RM, true, FIRST1>(bs, c0s, ts, fz_load_item<RM>(sit), sit, bt);
+            score = fz_score_item<RM, true, FIRST1>(bs, c0s, ts, sit[RM] & 0xffu, fz_load_item<RM>(sit), sit, bt);
           } else {
             uint32_t sum = 0;
 #pragma unroll 1
             for (int c = 0; c < n_ctr; ++c) {
               const uint32_t* it = sit + (1 + c) * fz_item_words<RM>();
-              sum += fz_score_item<RM, true, FIRST1>(bs, c0s, ts, fz_load_item<RM>(it), it, bt);
+              sum += fz_score_item<RM, true, FIRST1>(bs, c0s, ts, it[RM] & 0xffu, fz_load_item<RM>(it), it, bt);
             }
             score = (sum * h1) >> 16;
           }
@@ -527,7 +540,7 @@ size_t nrt_fused_item_words(int n_res, int64_t n_list) {
 // strategy or weights the chain does not cover, or a chunk block that does not fit in LDS next to the items and the stage.
 bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
   if (!a.fast || !a.fz_items || !a.rk_stream || !a.rk_off || !a.rk_first || a.rk_max_dwords == 0 || !a.out_status || !a.out_score || a.out_raw || a.row_ptr) return false;
-  if (a.strategy != SPX_NRT_LEAST_ALLOCATED || !a.pk_mode) return false;
+  if (a.strategy != SPX_NRT_LEAST_ALLOCATED || !a.pk_mode || a.pk_tab_slot > 1) return false;  // (the table slot is chained first: slot 0 or 1)
   for (int r = 0; r < a.n_res; ++r)
     if (a.slot_weight[r] != 0 && a.slot_weight[r] != 1) return false;
   const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);
