@@ -108,7 +108,7 @@ SEQ_PATH = {1: "one-workgroup chain (Filter-less profile)", 2: "per-pod single-r
 KERNEL_FILES = {
     "alloc": ("kernels_trimaran.hip",), "tlp": ("kernels_trimaran.hip",), "lvrb": ("kernels_trimaran.hip",),
     "lroc": ("kernels_lroc.hip",), "peaks": ("kernels_peaks.hip", "kernels_profile.hip"),
-    "nrt": ("kernels_nrt_fast.hip", "kernels_nrt.hip", "kernels_profile.hip"), "net": ("kernels_network.hip",),
+    "nrt": ("kernels_nrt_fused.hip", "kernels_nrt_rank.hip", "kernels_nrt_fast.hip", "kernels_nrt.hip", "kernels_profile.hip"), "net": ("kernels_network.hip",),
     "cap": ("kernels_capacity.hip", "kernels_profile.hip"),
 }
 
@@ -342,7 +342,7 @@ def workload_leg(hdr, device, name, steps):
             e.set_option("NRT_POD_CLASSES", 1)
             out["every_row"] = {"kernel_ms": er, "frac": algo / (er * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "what": "SPX_OPT_NRT_POD_CLASSES off: every pod row evaluated, none copied"}
-        counters = profile_counters(name, w["plugins"])
+        counters = profile_counters(name, w["plugins"], out.get("nrt_rows_evaluated"), n_nodes)
         if counters:
             out["traffic"] = counters.get("traffic")
             out.update({k: v for k, v in counters.items() if k != "traffic"})
@@ -471,7 +471,7 @@ def cpu_baseline(spx, snap, e, plugins, budget_s: float):
     return out
 
 
-def profile_counters(workload: str, plugins):
+def profile_counters(workload: str, plugins, rows_evaluated=None, n_nodes=None):
     """counter figures of the committed rocprofv3 PMC passes (profiles/rNN/<workload>_traffic.json: separate --pmc runs, FETCH_SIZE
     corrected x2 for gfx950) — reported only when taken with the kernel sources this run was built from"""
     cands = sorted(ROOT.glob(f"profiles/r*/{workload}_traffic.json"))
@@ -488,7 +488,15 @@ def profile_counters(workload: str, plugins):
         # kernel duration); the 1024 SIMDs issue one VALU instruction per 4 cycles each, and SQ_ACTIVE_INST_VALU counts in those
         # 4-cycle slots (it equals SQ_INSTS_VALU on these kernels): slots available = SQ_BUSY_CYCLES / 32 * 1024 / 4
         valu = pmc["SQ_ACTIVE_INST_VALU"] / (8.0 * pmc["SQ_BUSY_CYCLES"])
-    return {"traffic": d.get("traffic_bytes_per_launch"), "valu_busy_frac": valu, "source": src}
+    out = {"traffic": d.get("traffic_bytes_per_launch"), "valu_busy_frac": valu, "source": src}
+    if rows_evaluated and n_nodes and pmc.get("SQ_INSTS_VALU"):
+        # instructions per (pod row evaluated, 64 nodes) — a wavefront's share of one pod — summed over the workload's sweep kernels, and the
+        # time the vector ones alone take at one per 4 cycles per SIMD (1024 SIMDs, 2.4 GHz): progress on an issue-bound sweep counts in these
+        cells = rows_evaluated * n_nodes / 64.0
+        out["instr_per_cell"] = {"valu": pmc["SQ_INSTS_VALU"] / cells, "salu": pmc.get("SQ_INSTS_SALU", 0.0) / cells, "lds": pmc.get("SQ_INSTS_LDS", 0.0) / cells,
+                                 "cell": "one evaluated pod row x 64 nodes (a wavefront's step)", "rows_evaluated": rows_evaluated,
+                                 "valu_issue_bound_ms": pmc["SQ_INSTS_VALU"] * 4.0 / 1024.0 / 2.4e9 * 1e3}
+    return out
 
 
 def main() -> None:
@@ -853,15 +861,17 @@ def main() -> None:
     algo_bytes = n_nodes * w["node_row"] + local_pods * w["pod_row"] + n_nodes * local_pods * w["out"]
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
 
-    counters = profile_counters(args.workload, w["plugins"]) if not args.plugins else None
+    counters = profile_counters(args.workload, w["plugins"], pod_classes.get("nrt", {}).get("rows_evaluated") if pod_classes.get("nrt", {}).get("enabled") else
+                                (local_pods if "nrt" in w["plugins"] else None), n_nodes) if not args.plugins else None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": counters.get("traffic") if counters else None,
-                "kernel": {"nrt": "spx::k_nrt_fast (Filter launch + Score launch, both counted)", "net": "spx::k_net_cls",
+                "kernel": {"nrt": ("spx::k_nrt_fused (Filter + LeastAllocated Score in one launch) + k_nrt_fused_pack + k_rows_expand" if w.get("strategy") == "LeastAllocated" else
+                                   "spx::k_nrt_filter_rank (Filter launch) + spx::k_nrt_fast (Score launch), both counted, + k_rows_expand"), "net": "spx::k_net_cls",
                            "lroc": "spx::k_lroc_fast (float32 quotient on exact float64 numerator/denominator, float64 fallback; VALU-bound)",
                            "peaks": "spx::k_peaks_minmax_est + k_peaks_fix_minmax + k_peaks_write_est + k_peaks_fix_write (float32 interval per cell, the float64 "
                                     "division + exp only for the listed cells; issue-bound) over one row per distinct pod cpu request + spx::k_rows_expand "
                                     "(config.pod_classes); SPX_OPT_PEAKS_ESTIMATE=0: spx::k_peaks<min/max pass> + spx::k_peaks<write pass>",
-                           "cap": "full profile: k_quota, k_nrt_fast x2, k_net_cls, k_tlp_fast2, k_lvrb_fast, k_alloc_masked"}.get(
+                           "cap": "full profile: k_quota, k_nrt_fused, k_net_cls (+ masked Allocatable), k_tlp_fast2, k_lvrb_fast, k_rows_expand"}.get(
                     w["plugins"][0], "spx::k_tlp_fast2 (Allocatable+TLP)" + (" + spx::k_lvrb_fast" if "lvrb" in w["plugins"] else "")),
                 "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes, "frac_of_measured_copy_ceiling_6.29TBs": achieved / 6290.0,
                 "kernel_source_hash": kernel_source_hash(w["plugins"])}

@@ -560,7 +560,7 @@ bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
   const bool first1 = a.pk_tab_slot != 0;
 #define SPX_FZ_LAUNCH(RMV, F1V)                                                                                                            \
   do {                                                                                                                                     \
-    hipLaunchKernelGGL((k_nrt_fused_pack<RMV>), dim3(pack_blocks), dim3(256), 0, s, a, a.fz_items);                                      \
+    if (a.fz_pack) hipLaunchKernelGGL((k_nrt_fused_pack<RMV>), dim3(pack_blocks), dim3(256), 0, s, a, a.fz_items);                       \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<RMV, F1V>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
     hipLaunchKernelGGL((k_nrt_fused<RMV, F1V>), dim3(blocks), dim3(256), lds, s, a, a.fz_items, n_tiles);                                 \
   } while (0)

@@ -141,6 +141,15 @@ struct spx_engine {
   uint32_t nrt_rk_chunks = 0;
   bool nrt_rk_all_narrow = false;  // every chunk keeps four zones' counts per register (the only layout the fused sweep has)
   DevBuf d_nrt_fz;  // fused Filter + Score sweep: the packed Score items of the listed rows (k_nrt_fused_pack)
+  // what d_nrt_fz was packed from: generation of the pod records / slot table (bumped by their uploads), the row list's kind, the table
+  // slot, the buffer — a sweep whose key matches skips the pack launch
+  uint64_t nrt_items_gen = 1;
+  struct FzKey {
+    uint64_t gen = 0;
+    int kind = 0, tab_slot = -2;
+    const void* buf = nullptr;
+    bool operator==(const FzKey& o) const { return gen == o.gen && kind == o.kind && tab_slot == o.tab_slot && buf == o.buf; }
+  } nrt_fz_key;
   int last_nrt_filter = 0;         // spx_nrt_filter_path
   DevBuf d_pk_uniq, d_pk_dups;    // the same for Peaks: classes of pods with equal cpu requests
   int64_t pk_n_uniq = 0, pk_n_dups = 0;
@@ -1275,6 +1284,7 @@ int spx_upload_nrt_slots(spx_engine* e, const spx_nrt_slots* t) {
     e->nrt_slot_res[i] = t->slot_res ? t->slot_res[i] : -1;
   }
   e->nrt_slots = true;
+  ++e->nrt_items_gen;
   e->nrt_nodes = e->nrt_pods = false;  // tables are laid out by slot count
   // float64 formulation: weight-subset table, cpu slot, weight range
   SPX_HIP(e, hipSetDevice(e->device));
@@ -2011,6 +2021,7 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
     e->nrt_n_uniq = e->nrt_n_dups = 0;
     e->nrt_rk_max_dwords = 0;
     e->nrt_rk_kind = 0;
+    ++e->nrt_items_gen;
     if (e->nrt_fast_pods && p > 0) {
       std::vector<int32_t> rep(p);
       nrt_build_classes(items, hash.data(), p, R, rep.data());
@@ -2440,6 +2451,9 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
       if (fused) {
         if ((rc = ensure(e, e->d_nrt_fz, spx::nrt_fused_item_words(e->nrt_n_res, na.n_list) * sizeof(uint32_t)))) return rc;
         na.fz_items = static_cast<uint32_t*>(e->d_nrt_fz.p);
+        const spx_engine::FzKey key{e->nrt_items_gen, classes ? 1 : 2, na.pk_tab_slot, e->d_nrt_fz.p};
+        na.fz_pack = !(key == e->nrt_fz_key);
+        e->nrt_fz_key = key;
       }
     }
     if (na.strategy == SPX_NRT_LEAST_NUMA_NODES && na.fast && !(na.opts & spx::kOptNrtGeneric) && !e->row_indirect) {

@@ -310,6 +310,7 @@ struct NrtArgs {
   // the fused Filter + Score sweep (kernels_nrt_fused.hip): scratch for the packed Score items of the listed rows
   // (nrt_fused_item_words dwords); NULL = the Filter and Score launches
   uint32_t* fz_items;
+  bool fz_pack;                  // the items must be (re)packed before the sweep: pods, slot table, row list or table slot changed
 };
 constexpr int64_t kNrtPkTabMaxK = (int64_t{1} << 17) - 1;   // request / unit above this: the float64 form
 constexpr size_t kNrtPkTabMaxBytes = size_t{64} << 20;

@@ -123,6 +123,51 @@ def test_config3_every_cell(gpu_required, hdr, oracle, strategy):
         assert 0.01 * n_nodes * n_pods < rejected < 0.9 * n_nodes * n_pods  # both Filter verdicts are well represented
 
 
+@pytest.mark.parametrize("seed", [7, 20261004])
+def test_config2_quarter_size_other_seeds_every_cell(gpu_required, hdr, oracle, seed):
+    """Every full-size test above draws from synth.SEED; the float32 forms' failures, if any, would depend on the inputs.  Two more
+    snapshots (nodes, metrics, pods all reseeded) at a quarter of config #2's cells — 5k nodes x 50k pods — every cell of the three tables."""
+    n_nodes, n_pods = 5_000, 50_000
+    snap = synth.trimaran_snapshot(hdr, n_nodes, n_pods, seed=seed, round_frac=0.05)
+    with Engine(0) as e:
+        e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
+        assert e.kernel_path(TLP) == 1
+        e.eval(mask_of(ALLOCATABLE, TLP, LVRB))
+        e.sync()
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], metrics=snap["metrics"], assigned=snap["assigned"],
+                                alloc_params=e.alloc_params, tlp_params=tlp_params(hdr), lvrb_params=lvrb_params(hdr))
+        _, alloc_row = osnap.score_rows(ALLOCATABLE, 0, 1, want_raw=False)
+        bad = {ALLOCATABLE: 0, TLP: 0, LVRB: 0}
+        for r0, r1 in blocks(n_pods, n_nodes):
+            for p in (TLP, LVRB):
+                bad[p] += count_mismatches(e.all_scores(p, r0, r1), osnap.score_rows(p, r0, r1, threads=THREADS, want_norm=False)[0])[0]
+            bad[ALLOCATABLE] += int((e.all_scores(ALLOCATABLE, r0, r1) != alloc_row[0].astype(np.uint8)[None, :]).sum())
+        assert bad == {ALLOCATABLE: 0, TLP: 0, LVRB: 0}
+
+
+@pytest.mark.parametrize("seed", [7, 20261004])
+@pytest.mark.parametrize("strategy", ["LeastAllocated", "MostAllocated", "BalancedAllocation"])
+def test_config3_quarter_size_other_seeds_every_cell(gpu_required, hdr, oracle, strategy, seed):
+    """The same for config #3: 2 500 nodes x 25 000 pods of two other snapshots, every cell of both tables (LeastNUMANodes: its oracle
+    enumerates every NUMA subset per cell — it keeps to the full-size test and the six-slot one)."""
+    n_nodes, n_pods = 2_500, 25_000
+    snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=seed)
+    params = O.nrt_params(hdr, O.Resources(), strategy)
+    with Engine(0) as e:
+        e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
+        assert e.kernel_path(NRT) == 1
+        e.eval(mask_of(NRT))
+        e.sync()
+        if strategy == "LeastAllocated":
+            assert e.nrt_filter_path() == 3  # the fused Filter + Score launch
+        osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
+        bad_status = bad_score = 0
+        for r0, r1 in blocks(n_pods, n_nodes, cells=16_000_000):
+            bad_status += int((e.all_status(NRT, r0, r1) != osnap.filter_rows(NRT, r0, r1, threads=THREADS)).sum())
+            bad_score += count_mismatches(e.all_scores(NRT, r0, r1), osnap.score_rows(NRT, r0, r1, threads=THREADS, want_norm=False)[0])[0]
+        assert (bad_status, bad_score) == (0, 0)
+
+
 @pytest.mark.parametrize("strategy", ["LeastAllocated", "MostAllocated", "BalancedAllocation", "LeastNUMANodes"])
 def test_config3_six_slots_every_cell(gpu_required, hdr, oracle, strategy):
     """The kernels' 8-slot instantiations (5-8 NUMA-affine resources: cpu, memory, two hugepage sizes, two extended resources):
