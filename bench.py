@@ -557,6 +557,13 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
+        # every rank of the job must be in the communicator the exchange runs on — counted BY a collective, not read from the environment:
+        # a rank that did not join (a device RCCL could not open) must stop the run here, not show up as a short all-gather later
+        probe = torch.ones(1, dtype=torch.int64, device=f"cuda:{local_rank}" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(probe)
+        coll_ranks = int(probe.item())
+        if coll_ranks != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the {args.dist_backend} communicator holds {coll_ranks} rank(s) (world size {dist.get_world_size()})")
     coll_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
 
     import scheduler_plugins_amd as spx
@@ -911,12 +918,13 @@ def main() -> None:
         out["full_cycle"] = full_cycle
     if mode == "multi":
         out["host_load"] = host_load
-        try:  # how many ranks the exchange's communicator has, as RCCL itself reports it (0: peer copies)
-            out["collective"] = {"transport": args.transport, "rccl_ranks": target.rccl_ranks()}
-        except Exception as ex:
-            out["collective"] = {"error": repr(ex)[:200]}
+        # how many ranks the exchange's communicator has, as RCCL itself reports it (0: peer copies); fewer than the devices of an RCCL run is an error
+        out["collective"] = {"transport": args.transport, "rccl_ranks": target.rccl_ranks()}
+        if args.transport == "rccl" and out["collective"]["rccl_ranks"] != world:
+            raise SystemExit(f"--gpus {world} over RCCL but the communicator holds {out['collective']['rccl_ranks']} rank(s)")
     elif mode == "ranks":
-        out["collective"] = {"backend": args.dist_backend, "ranks": int(dist.get_world_size()),
+        out["collective"] = {"backend": args.dist_backend, "ranks": int(dist.get_world_size()), "rccl_ranks": coll_ranks if args.dist_backend == "nccl" else 0,
+                             "ranks_counted_by_all_reduce": coll_ranks,
                              "what": "torch.distributed process group the decisions / table are all-gathered on (nccl = RCCL over xGMI)"}
     if world > 1:
         out["n_gt_1_hardware"] = ("no figure on more than one MI355X exists for this repository: the build box has one device; lines with several ranks "

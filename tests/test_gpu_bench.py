@@ -77,6 +77,21 @@ def test_multi_device_mode(gpu_required, workload, scaling, extra):
     assert d["config"]["n_pods_slowest_rank"] == 4000
 
 
+@pytest.mark.parametrize("workload,gather", [("small_net", "table"), ("small_full", "best"), ("small_full_ragged", "best")])
+def test_multi_device_mode_eight_ranks(gpu_required, workload, gather):
+    """`--gpus 8` as one process sees it — eight ranks' engines, host threads, shards of 1 000 (the ragged batch: seven of 1 024 and one of
+    1 023) and the exchange — with all eight on device 0 over peer copies: config #4's and config #5's plugin sets at plumbing size, so
+    that the first run on eight devices is not the first run of this code with eight ranks"""
+    d = run_bench("--workload", workload, "--devices", "0,0,0,0,0,0,0,0", "--transport", "copy", "--steps", "2", "--warmup", "1", "--cpu-budget", "0", "--gather", gather)
+    check_line(d, 8, "strong")
+    assert d["config"]["host"].startswith("one process driving 8 devices")
+    total = 8191 if workload == "small_full_ragged" else 8000
+    assert d["config"]["n_pods_per_step"] == total and d["config"]["n_pods_slowest_rank"] == -(-total // 8)
+    assert d["gather"]["best_ms"] > 0 and d["collective"]["rccl_ranks"] == 0  # (peer copies: no RCCL communicator)
+    if gather == "table":
+        assert d["gather"]["table_bytes"] > 0
+
+
 @pytest.mark.skipif(n_gpus() < 2, reason="needs two GPUs")
 @pytest.mark.parametrize("workload", ["small", "small_full"])
 def test_multi_device_mode_rccl(gpu_required, workload):

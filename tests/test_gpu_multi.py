@@ -181,6 +181,34 @@ def test_config4_eight_ranks_table_gather(gpu_required, hdr):
             assert (want_best[3] < n_nodes).any()   # some rows lost nodes to the Filter
 
 
+def test_config4_slab_allgather_through_rccl_one_rank(gpu_required, hdr):
+    """The RCCL transport's group call at config #4's per-rank slab — 25 000 rows x 10 112 bytes = 253 MB, score and status — with the
+    one rank a one-device box allows: ncclCommInitAll + the grouped in-place ncclAllGather execute at the size the eight-GPU run
+    launches them with (round-5 review: one-rank RCCL had only run at toy sizes), and the table they leave is the evaluated one."""
+    n_nodes, n_pods = 10_000, 25_000
+    snap = synth.network_snapshot(hdr, n_nodes, n_pods, seed=synth.SEED)
+    mask = mask_of(NETOVERHEAD)
+    with Engine(0) as ref:
+        ref.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+        ref.eval(mask)
+        ref.sync()
+        with MultiEngine([0], RCCL) as m:
+            assert m.rccl_ranks() == 1
+            m.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
+            m.bind_global_table(NETOVERHEAD)
+            m.bind_global_table(NETOVERHEAD, status=True)
+            m.eval(mask)
+            m.allgather_table(NETOVERHEAD)
+            m.allgather_table(NETOVERHEAD, status=True)
+            m.sync()
+            assert m.last_ms()[1] >= 0
+            bad = 0
+            for r0 in range(0, n_pods, 5_000):
+                bad += int((m.global_rows(NETOVERHEAD, 0, r0, r0 + 5_000) != ref.all_scores(NETOVERHEAD, r0, r0 + 5_000)).sum())
+                bad += int((m.global_rows(NETOVERHEAD, 0, r0, r0 + 5_000, status=True) != ref.all_status(NETOVERHEAD, r0, r0 + 5_000)).sum())
+            assert bad == 0
+
+
 def test_config5_eight_ranks_decisions(gpu_required, hdr):
     """BASELINE config #5 as stated for 8 GPUs — the full profile, 20 000 nodes x 500 000 pods, 62 500 rows per rank (seven 1.25 GB
     tables each) — through spx_multi with the practical exchange (per-pod decisions, 20 B per pod): all 500 000 decisions, and the
