@@ -228,6 +228,13 @@ def config5_leg(hdr, device, n_pods=8192):
                 e.sync()
                 ts.append((time.perf_counter() - t0) * 1e3)
             out["load_c_ms"] = sorted(ts)[1]
+            ts = []
+            for _ in range(3):  # spx_load_profile: the same four loaders side by side on host threads of the library
+                t0 = time.perf_counter()
+                e.load_c(snap, snap["nrt_params"], concurrent=True)
+                e.sync()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            out["load_profile_ms"] = sorted(ts)[1]
             # per loader (one more pass, each call bracketed by a sync) and, for the NRT loader — the largest — per stage
             per = {}
             for name, fn in (("trimaran", lambda: e._lib.spx_load_trimaran(e._h, snap["nodes"].ref(), snap["rc"].ref(), snap["pods"].ref(), snap["metrics"].ref(), snap["assigned"].ref())),

@@ -811,6 +811,23 @@ int spx_load_nrt(spx_engine* e, const spx_node_objects* nodes, const spx_nrt_obj
 int spx_last_load_nrt_ms(const spx_engine* e, double* ms6);
 int spx_load_network(spx_engine* e, const spx_node_objects* nodes, const spx_pod_objects* pods, const spx_appgroup_objects* appgroups, const spx_nettopo_objects* nettopo);
 int spx_load_quota(spx_engine* e, const spx_pod_objects* pods, const spx_resource_classes* rc, const spx_quota_objects* quota);
+/* The whole profile in one call: the loaders above run side by side on host threads of the library (they fill disjoint tables and share
+ * the engine's stream; spx_load_nrt itself runs its node half and its pod half on two threads).  nodes and pods are required; a loader
+ * whose members are NULL is skipped: metrics (+ rc, assigned) = spx_load_trimaran, nrt + nrt_params = spx_load_nrt, appgroups + nettopo =
+ * spx_load_network, quota = spx_load_quota.  Returns the first failing loader's code.  No other call on the engine may run meanwhile. */
+typedef struct spx_profile_objects {
+  const spx_node_objects* nodes;
+  const spx_resource_classes* rc;
+  const spx_pod_objects* pods;
+  const spx_metrics_objects* metrics;
+  const spx_assigned_objects* assigned;
+  const spx_nrt_objects* nrt;
+  const spx_nrt_params* nrt_params;
+  const spx_appgroup_objects* appgroups;
+  const spx_nettopo_objects* nettopo;
+  const spx_quota_objects* quota;
+} spx_profile_objects;
+int spx_load_profile(spx_engine* e, const spx_profile_objects* o);
 
 /* Which form the last spx_commit_sequential ran: 1 = the one-workgroup chain of the Filter-less profile, 2 = per-pod single-row
  * launches (replayed from a graph), 3 = the cooperative persistent kernel; 0 = none yet */

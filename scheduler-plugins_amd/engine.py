@@ -576,11 +576,21 @@ class Engine:
         return int(self._lib.spx_kernel_path(self._h, plugin))
 
     # ------------------------------------------------------------------ one-call loaders (spx_load_*: flatten + upload inside the library)
-    def load_c(self, snap: dict, nrt_params: Optional[Table] = None) -> None:
+    def load_c(self, snap: dict, nrt_params: Optional[Table] = None, concurrent: bool = False) -> None:
         """the object tables of `snap` (keys as synth.full_snapshot's) through spx_load_trimaran / _nrt / _network / _quota — the calls
         the cgo shim makes — instead of this module's own flatten_* + upload_* sequences"""
         L = self._lib
         ref = lambda t: t.ref() if t is not None else None
+        if concurrent:  # spx_load_profile: the four loaders side by side inside the library
+            keys = {"nodes": "nodes", "rc": "rc", "pods": "pods", "metrics": "metrics", "assigned": "assigned", "nrt": "nrt", "appgroups": "appgroups",
+                    "nettopo": "nettopo", "quota": "quota"}
+            fields = {k: snap[v] for k, v in keys.items() if snap.get(v) is not None}
+            if "nrt" in fields:
+                fields["nrt_params"] = nrt_params
+            self._ck(L.spx_load_profile(self._h, Table(self._hdr, "spx_profile_objects", **fields).ref()))
+            self.n_pods = snap["pods"].struct.n_pods
+            self.n_nodes = snap["nodes"].struct.n_nodes
+            return
         if "metrics" in snap:
             self._ck(L.spx_load_trimaran(self._h, snap["nodes"].ref(), ref(snap.get("rc")), snap["pods"].ref(), snap["metrics"].ref(), ref(snap.get("assigned"))))
         if "nrt" in snap:

@@ -43,7 +43,11 @@ func (e *Engine) Decide(mask uint32, nPods int64) (*Decisions, error) {
 	if rc := C.spx_decide(e.h, C.uint32_t(mask), 0, C.int64_t(nPods)); rc != 0 {
 		return nil, e.err("spx_decide")
 	}
-	return e.fetchBest(nPods)
+	d, err := e.fetchBest(nPods)
+	// spx_decide may (re)write the Filter plugins' tables: rows cached before the call are not served after it
+	old := e.gen.Load()
+	e.gen.Store(&generation{nNodes: old.nNodes, nPods: old.nPods, column: old.column, podRow: old.podRow})
+	return d, err
 }
 
 // CommitSequential schedules the batch one pod after the other on the device, every pod seeing the commits of the pods before
@@ -61,6 +65,10 @@ func (e *Engine) CommitSequential(mask uint32, nPods int64) (*Decisions, error) 
 		(*C.int64_t)(unsafe.Pointer(&d.Score[0])), (*C.int32_t)(unsafe.Pointer(&d.Ties[0])), nil); rc != 0 {
 		return nil, e.err("spx_commit_sequential")
 	}
+	// the loop evaluates single rows into the plugins' tables while it runs (and restores the snapshot's tables when it ends): a fresh
+	// generation, so that no row fetched before or during the call is served after it
+	old := e.gen.Load()
+	e.gen.Store(&generation{nNodes: old.nNodes, nPods: old.nPods, column: old.column, podRow: old.podRow})
 	return d, nil
 }
 

@@ -18,10 +18,13 @@ def test_load_c_equals_python_loaders(gpu_required, hdr, strategy):
     params = O.nrt_params(hdr, O.Resources(), strategy)
     mask = mask_of(ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY)
     out = []
-    for via_c in (False, True):
+    for via_c in (False, True, "profile", "profile-again"):  # "profile": spx_load_profile, the four loaders side by side on library threads
         with Engine(0) as e:
+            if via_c == "profile-again":  # a second snapshot load into a live engine: buffers in place, nothing left from the first
+                e.load_c(snap, params, concurrent=True)
+                e.eval(mask)
             if via_c:
-                e.load_c(snap, params)
+                e.load_c(snap, params, concurrent=via_c is not True)
             else:
                 e.load_trimaran_objects(snap["nodes"], snap["rc"], snap["pods"], snap["metrics"], snap["assigned"])
                 e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
@@ -38,8 +41,9 @@ def test_load_c_equals_python_loaders(gpu_required, hdr, strategy):
             tables["commit"] = np.stack([node.astype(np.int64), score, ties.astype(np.int64)])
             tables["missing"] = missing
             out.append(tables)
-    for k in out[0]:
-        assert np.array_equal(out[0][k], out[1][k]), k
+    for other in out[1:]:
+        for k in out[0]:
+            assert np.array_equal(out[0][k], other[k]), k
     assert (out[0]["prefilter"] != 0).any() and (out[0][("status", NRT)] != 0).any()
 
 
