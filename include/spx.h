@@ -759,6 +759,10 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *                              the interval decides little (a pod that requests no cpu) take the float64 sequence for the whole tile;
  *                              8 = the same with 8 instead of 16 nodes per lane; 0 = the float64 sequence for every cell.  Same tables either way.
  *                              (The interval's bounds assume cpu requests >= 0: a batch that holds a negative one runs the float64 passes)
+ *                              Scratch, allocated by the first Peaks evaluation with the option on and kept: the undecided cells' lists, 24 bytes
+ *                              per (swept pod row, tile of 1024 nodes — 512 with the value 8) whatever the chunking — 24 MB for 100 000 rows x
+ *                              10 000 nodes, 240 MB for 500 000 x 20 000 — plus 96 bytes per node; a list that fills up falls back to one
+ *                              "whole tile" entry, so the size bounds memory, not correctness
  *   SPX_OPT_NRT_FUSED          1 (default) = a whole-batch NodeResourceTopologyMatch sweep with the LeastAllocated strategy, unit weights and the
  *                              preconditions of SPX_OPT_NRT_RANK_FILTER and SPX_OPT_NRT_PACKED_SCORE runs Filter and Score in ONE launch
  *                              (kernels_nrt_fused.hip: rank-space Filter, float32 Score chain, pod records staged once); 0 = the Filter

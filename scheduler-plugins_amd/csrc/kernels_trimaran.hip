@@ -1013,7 +1013,13 @@ static bool tlp_amb_eligible(const TrimaranArgs& a, int64_t rows) {
 // still describe the node columns in place (they are built together and invalidated together); true = launch the AMB variant
 static bool tlp_prepare(const TrimaranArgs& a, int64_t rows, int64_t n_slots, double c1, double c2, int tile_nodes, hipStream_t s) {
   const bool amb = tlp_amb_eligible(a, rows);
-  if (amb && a.tlp_amb_built && *a.tlp_amb_built) return true;  // 21 us per sweep otherwise
+  int64_t tbits;
+  static_assert(sizeof tbits == sizeof a.tlp_target, "the target's bits");
+  __builtin_memcpy(&tbits, &a.tlp_target, sizeof tbits);
+  const int64_t geom[3] = {tile_nodes, a.row_stride, tbits ^ (static_cast<int64_t>(a.tlp_amb_size) << 1)};
+  const bool same_geom = !a.tlp_amb_geom || (a.tlp_amb_geom[0] == geom[0] && a.tlp_amb_geom[1] == geom[1] && a.tlp_amb_geom[2] == geom[2]);
+  if (amb && a.tlp_amb_built && *a.tlp_amb_built && same_geom) return true;  // 21 us per sweep otherwise
+  if (a.tlp_amb_geom) a.tlp_amb_geom[0] = geom[0], a.tlp_amb_geom[1] = geom[1], a.tlp_amb_geom[2] = geom[2];
   hipLaunchKernelGGL(k_tlp_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots, c1, c2);
   if (!amb) {
     if (a.tlp_amb_built) *a.tlp_amb_built = false;  // (a single-row launch of the commit loop writes constants of its own state)
@@ -1058,7 +1064,9 @@ void launch_lvrb_fast(const TrimaranArgs& a, hipStream_t s) {
   // the per-node constants and, for a multi-row launch, the ambiguity table: built together, kept while the owner's flag says the
   // columns they were built from (and the margin / sensitivity) are the ones in place — as launch_tlp_fast does
   const bool amb = a.lv_amb && !a.row_ptr && a.row_end - a.row_begin >= 256 && !(a.opts & kOptTlpNoAmbTable);
-  if (!(amb && a.lv_amb_built && *a.lv_amb_built)) {
+  const bool lv_same_geom = !a.lv_amb_geom || (a.lv_amb_geom[0] == tile_nodes && a.lv_amb_geom[1] == a.row_stride);
+  if (a.lv_amb_geom) a.lv_amb_geom[0] = tile_nodes, a.lv_amb_geom[1] = a.row_stride;
+  if (!(amb && a.lv_amb_built && *a.lv_amb_built && lv_same_geom)) {
     hipLaunchKernelGGL(k_lvrb_prepare, dim3(static_cast<unsigned>((a.n_nodes + 255) / 256)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_lvrb_prepare_fast, dim3(static_cast<unsigned>((n_slots + 255) / 256)), dim3(256), 0, s, a, n_slots);
     if (amb) {

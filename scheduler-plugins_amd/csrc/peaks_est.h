@@ -57,6 +57,7 @@ constexpr float kEstBpInv = 1024.0f;
 constexpr float kEstGc = 102400.5f;  // 0.5 + 100 * kEstBpInv, exact in float32
 constexpr double kEstUtilMax = 400.0, kEstYMax = 40.0, kEstMagMin = 1e7, kEstMagMax = 1e24;
 constexpr float kEstYClamp = 41.0f;
+constexpr float kEstYFloor = -200.0f;
 
 struct NodeE {
   float c0, c1, ql, ke, sigma;
@@ -112,8 +113,16 @@ SPX_PK_HD void est_interval_from(const NodeE& ne, float p, float y, float e, flo
   hi = eg + bg;
 }
 
+// Clamped from above (beyond the clamp the cell is beyond the band: g = 0, and nothing overflows) and, round 6, from below: 2^y is 0 in
+// float32 from y = -150 on whatever the request, so est and the true score agree to |KE| 2^-200 there, while an unclamped |y| — a huge
+// request against a negative K2 — entered B = |KE| (e + 1) (5u |y| + 12u) and could carry it past FLT_MAX, where lo / hi turn NaN and a
+// NaN interval reads as "outside the table" instead of "undecided" (advisor, round 5).  |y| <= 200 keeps B below 2e20.  One v_med3_f32.
 SPX_PK_HD float est_exponent(const NodeE& ne, float pod32) {
-  return __builtin_fminf(ne.ql * pod32, kEstYClamp);  // (beyond the clamp the cell is beyond the band: g = 0, and nothing overflows)
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fmed3f(ne.ql * pod32, kEstYFloor, kEstYClamp);
+#else
+  return fmaxf(fminf(ne.ql * pod32, kEstYClamp), kEstYFloor);
+#endif
 }
 
 SPX_PK_HD float est_predicted(const NodeE& ne, float pod32) { return __builtin_fmaf(ne.c1, pod32, ne.c0); }

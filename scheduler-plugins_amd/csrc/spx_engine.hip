@@ -80,6 +80,7 @@ struct spx_engine {
   DevBuf d_tlp_amb;              // k_tlp_amb_build's table: per pod value, the node tiles holding a cell the float32 sweep cannot prove
   DevBuf d_lv_amb;               // k_lvrb_amb_build's table
   bool lv_amb_built = false;     // ... and whether d_lv_exact / d_lv_fast / d_lv_amb still describe the LVRB node columns and parameters
+  int64_t tlp_amb_geom[3] = {0, 0, 0}, lv_amb_geom[3] = {0, 0, 0};  // the tiling / stride / target the tables were built for (tlp_prepare compares)
   bool tlp_amb_built = false;    // ... and whether it still describes d_cap_cpu / d_tlp_util / d_tlp_missing / d_tlp_valid and the target (cleared by every writer of those)
   DevBuf d_commit;               // scratch of spx_commit_sequential
   DevBuf d_decide;               // per-tile partial decisions of spx_decide
@@ -2347,6 +2348,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     if ((rc = ensure(e, e->d_lv_amb, spx::lvrb_amb_bytes()))) return rc;
     a.lv_amb = static_cast<uint32_t*>(e->d_lv_amb.p);
     a.lv_amb_built = &e->lv_amb_built;
+    a.lv_amb_geom = e->lv_amb_geom;
   }
   if (T) {
     if ((rc = ensure(e, e->d_tlp_fast, static_cast<size_t>(spx::round_up(e->row_stride, 1024)) * 4 * sizeof(float)))) return rc;
@@ -2356,6 +2358,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     a.tlp_amb = static_cast<uint32_t*>(e->d_tlp_amb.p);
     a.tlp_amb_size = spx::kTlpAmbSize;
     a.tlp_amb_built = &e->tlp_amb_built;
+    a.tlp_amb_geom = e->tlp_amb_geom;
   }
   if (!e->hold_ev0) SPX_HIP(e, hipEventRecord(e->ev0, e->stream));
   if (Q) {
@@ -3683,6 +3686,7 @@ int spx_decide(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t r
   d.t.tlp_amb = static_cast<uint32_t*>(e->d_tlp_amb.p);
   d.t.tlp_amb_size = spx::kTlpAmbSize;
   d.t.tlp_amb_built = &e->tlp_amb_built;
+  d.t.tlp_amb_geom = e->tlp_amb_geom;
   d.use_alloc = use_alloc;
   d.w_alloc = static_cast<int32_t>(use_alloc ? wa : 0);
   d.w_tlp = static_cast<int32_t>(wt);

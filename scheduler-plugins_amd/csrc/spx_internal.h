@@ -110,6 +110,11 @@ struct TrimaranArgs {
   uint32_t* tlp_amb;     // scratch [tlp_amb_size]: per pod value, the node tiles (bit tile & 31) holding a cell the float32 sweep cannot prove (k_tlp_amb_build); NULL = checked cells everywhere
   int32_t tlp_amb_size;  // pod values at or above it take the checked cell
   uint32_t* lv_amb;      // scratch [lvrb_amb_bytes() / 4]: k_lvrb_amb_build's table (cpu millicores | memory MiB | always-checked tiles); NULL = checked cells everywhere
+  // what the two tables were built for besides the columns (host, may be NULL): {nodes per tile, row stride, bits of the target / table size};
+  // a launch whose geometry differs rebuilds them whatever the flags say (advisor, round 5: the flags alone relied on every launcher
+  // using one tiling)
+  int64_t* tlp_amb_geom;
+  int64_t* lv_amb_geom;
   bool* lv_amb_built;    // as tlp_amb_built, for lv_exact / lv_fast / lv_amb: cleared by every writer of the LVRB node columns, margin or sensitivity
   bool* tlp_amb_built;   // host flag (may be NULL = always rebuild): true while tlp_amb describes the node columns / target in place; the launcher builds
                          // the table when it is false and sets it; the owner clears it whenever a column k_tlp_amb_build reads, or the target, changes

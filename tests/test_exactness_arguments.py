@@ -528,7 +528,7 @@ def _peaks_interval_from(consts, pod32, y, e):
 def _peaks_interval(consts, pod32, rng, ulps=3):
     f = np.float32
     with np.errstate(all="ignore"):
-        y = np.fmin((consts[2] * pod32).astype(f), f(41.0))
+        y = np.fmax(np.fmin((consts[2] * pod32).astype(f), f(41.0)), f(-200.0))
     e = np.exp2(y.astype(np.float64)).astype(f)
     k = np.where(e > f(1e-30), rng.integers(-ulps, ulps + 1, size=e.shape), 0).astype(np.int32)  # (v_exp_f32 flushes below 2^-126: exactly 0 there)
     e = (e.view(np.int32) + k).view(f)
@@ -566,6 +566,10 @@ def _peaks_snapshot(rng, n_nodes, n_pods, regime):
         k1 = -rng.uniform(40, 160, n_nodes) * rng.choice([1, -1, 1e-3, 1e3], n_nodes)
         k2 = rng.uniform(-0.27, 0.27, n_nodes)
         cap = rng.choice([1000, 4000, 64000, 128000], n_nodes).astype(np.int64)
+    elif regime == "extreme_pod":  # requests up to int64's end against tame nodes: |y| unclamped would carry the bound B past FLT_MAX (advisor, round 5)
+        pod = rng.choice([0, 1, 4000, 2 ** 40, 2 ** 55, 2 ** 62, 2 ** 63 - 1], n_pods).astype(np.int64)
+        cap = rng.choice([1, 3, 1000, 64000], n_nodes).astype(np.int64)
+        k2 = rng.choice([-0.27, -0.07, 0.07, 0.27], n_nodes)
     elif regime == "zero_cpu":
         pod[:] = 0
     elif regime == "identical":
@@ -575,7 +579,7 @@ def _peaks_snapshot(rng, n_nodes, n_pods, regime):
 
 def test_peaks_interval_contains_the_float64_score():
     worst = 0.0
-    for regime in ("plain", "near100", "wild", "steep", "zero_cpu", "identical"):
+    for regime in ("plain", "near100", "wild", "steep", "zero_cpu", "identical", "extreme_pod"):
         for seed in range(2):
             rng = np.random.default_rng(100 + seed)
             cap, util, k1, k2, valid, pod = _peaks_snapshot(rng, 2500, 500, regime)
@@ -587,6 +591,7 @@ def test_peaks_interval_contains_the_float64_score():
             assert (hi[forced] > np.float32(1e37)).all() and (lo[forced] < np.float32(-1e37)).all()
             ok = ~forced
             assert np.isfinite(v[ok]).all(), regime
+            assert np.isfinite(lo[ok]).all() and np.isfinite(hi[ok]).all(), regime  # a NaN interval would read as "outside the table", not "undecided"
             assert ((lo.astype(np.float64) <= v) & (v <= hi.astype(np.float64)))[ok].all(), regime
             known = (lo == hi) & ok
             assert (v[known] == 0).all() and (lo[known] == 0).all(), regime  # lo == hi happens only at 0 and then IS the score
@@ -678,7 +683,7 @@ def test_peaks_header_computes_what_the_replay_computes():
     L, (dp, fp, bp) = _peaks_header_lib()
     f = np.float32
     cells = 0
-    for regime in ("plain", "near100", "wild", "steep", "zero_cpu", "identical"):
+    for regime in ("plain", "near100", "wild", "steep", "zero_cpu", "identical", "extreme_pod"):
         rng = np.random.default_rng(11)
         cap, util, k1, k2, valid, pod = _peaks_snapshot(rng, 1500, 300, regime)
         consts, forced = _peaks_node_consts(cap, util, k1, k2, valid)
@@ -696,7 +701,7 @@ def test_peaks_header_computes_what_the_replay_computes():
         y = np.zeros((m, n), f)
         L.peaks_est_check_exponents(m, n, got.ctypes.data_as(fp), pod32.ctypes.data_as(fp), y.ctypes.data_as(fp))
         with np.errstate(all="ignore"):
-            y_want = np.fmin((consts[2][None, :] * pod32[:, None]).astype(f), f(41.0))
+            y_want = np.fmax(np.fmin((consts[2][None, :] * pod32[:, None]).astype(f), f(41.0)), f(-200.0))
         assert np.array_equal(y.view(np.uint32), y_want.view(np.uint32)), regime
         with np.errstate(all="ignore"):
             e = np.exp2(y.astype(np.float64)).astype(f)
