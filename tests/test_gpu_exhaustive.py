@@ -355,6 +355,25 @@ def test_config2_peaks_every_cell(gpu_required, hdr, oracle):
             else:  # 100 - int64(float64(s - lo) * 100 / float64(hi - lo)): float64 as the reference, element-wise IEEE
                 norm = 100 - ((raw_g - lo).astype(np.float64) * 100.0 / float(hi - lo)).astype(np.int64)
             assert np.array_equal(e.scores(PEAKS, int(r)).astype(np.int64), norm), int(r)
+        # ... and ALL of them against the ORACLE's rows with the stated +-64 of raw noise carried through NormalizeScore: a cell's raw
+        # score s, the row's minimum and its maximum each move by at most 64, which bounds q = (s - lo) / (hi - lo) and with it the byte
+        # 100 - int64(100 q) — every byte of every such row must lie inside its bound (where the row's span is below twice the noise the
+        # bound is 0..100: that is what "rounding noise stretched over 0..100" means, and then only structure is left to check: a row
+        # whose oracle scores are all zero is all zero here)
+        outside = 0
+        for r0 in range(0, noise_rows.size, 512):
+            rows = noise_rows[r0:r0 + 512]
+            raw_w = np.stack([osnap.score_rows(PEAKS, int(r), int(r) + 1, want_norm=False)[0][0] for r in rows]).astype(np.float64)
+            got = np.stack([e.scores(PEAKS, int(r)) for r in rows]).astype(np.int64)
+            lo, hi = raw_w.min(axis=1, keepdims=True), raw_w.max(axis=1, keepdims=True)
+            flat = (lo == 0) & (hi == 0)  # no node scores at all (no metrics anywhere / no models): structural, exact
+            assert (got[flat[:, 0]] == 0).all()
+            span_min, span_max = np.maximum(hi - lo - 128.0, 0.0), hi - lo + 128.0
+            q_lo = np.where(span_min > 0, np.clip(raw_w - lo - 128.0, 0.0, None) / span_max, 0.0)
+            q_hi = np.where(span_min > 0, np.clip((raw_w - lo + 128.0) / np.where(span_min > 0, span_min, 1.0), 0.0, 1.0), 1.0)
+            b_lo, b_hi = 100 - np.floor(100.0 * q_hi) - 1, 100 - np.floor(100.0 * q_lo) + 1
+            outside += int(((got < b_lo) | (got > b_hi))[~flat[:, 0]].sum())
+        assert outside == 0, outside
 
 
 def test_config2_full_cycle_every_row(gpu_required, hdr):
