@@ -351,8 +351,12 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
     chunk = seq / wpx;
     if (window >= n_windows) return;
   } else {
-    window = static_cast<int>(blockIdx.x % n_windows);
-    chunk = blockIdx.x / n_windows;
+    // Fewer windows (the node tables fit every XCD's L2): the blocks of one chunk — all its windows — run on ONE XCD, one after the
+    // other, so that the chunk's rank block and Score items (20 KB) come into that L2 once instead of into all eight (counter traffic
+    // of config #3: 151 MB of fetch for 273 MB written before, most of it these streams eight times over)
+    const int64_t seq = blockIdx.x >> 3;
+    window = static_cast<int>(seq % n_windows);
+    chunk = (seq / n_windows) * 8 + static_cast<int64_t>(blockIdx.x & 7u);
   }
   if (chunk >= a.rk_chunks) return;
   const int64_t first = a.rk_first[chunk];  // a chunk: up to 32 consecutive rows of the list
@@ -545,8 +549,8 @@ bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
     if (a.slot_weight[r] != 0 && a.slot_weight[r] != 1) return false;
   const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);
   const int64_t chunks = a.rk_chunks;
-  const int64_t per_round = n_tiles >= kXcdMapWindows ? ((n_tiles + 7) / 8) * 8 : n_tiles;
-  const unsigned blocks = static_cast<unsigned>(chunks * per_round);
+  // the kernel's block map: 8 XCDs x their windows per chunk, or 8 chunks (one per XCD) x all windows
+  const unsigned blocks = static_cast<unsigned>(n_tiles >= kXcdMapWindows ? chunks * (((n_tiles + 7) / 8) * 8) : ((chunks + 7) / 8) * 8 * n_tiles);
   const bool r4 = a.n_res <= 4;
   const size_t lds = static_cast<size_t>(a.rk_max_dwords) * 4 + static_cast<size_t>(kPodsPerUnit) * (r4 ? fz_pod_words<4>() : fz_pod_words<8>()) * 4 +
                      static_cast<size_t>(2) * (kPodsPerUnit / 4) * kWindow * 4;
