@@ -1187,7 +1187,7 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
 #define SPX_NRTF_CASE(RMV, SGV)                                                                           \
   if ((a.n_res <= 4) == (RMV == 4) && sg == SGV) {                                                        \
     if (split) { /* the Filter half does not depend on the strategy */ \
-      if (!launch_nrt_filter_rank(a, n_tiles, s)) /* rank space when the engine built the chunk stream (kernels_nrt_rank.hip) */ \
+      if (!launch_nrt_filter_fused(a, s) && !launch_nrt_filter_rank(a, n_tiles, s)) /* rank space when the engine built the chunk stream (kernels_nrt_rank.hip) */ \
         hipLaunchKernelGGL((k_nrt_fast<RMV, kSgLeast, kPhFilter>), dim3(blocks), dim3(256), 0, s, a, n_tiles); \
       const bool ln_lists = SGV == kSgLeastNuma && a.redo_list && a.ln_rec && a.ln_rows > 0; \
       if (SGV == kSgBalanced) (void)hipMemsetAsync(a.redo_list, 0, 8, s); /* the float32 Score launch lists the cells it could not decide */ \

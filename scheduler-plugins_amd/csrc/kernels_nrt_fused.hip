@@ -229,7 +229,7 @@ __device__ __forceinline__ uint32_t fz_score_item(const float (&bs)[RM][kZ], con
 // What steers scalar branches — which slots' Score chains run — is the union of the slot sets of the items at work (from the pod's head);
 // an item holds -inf for a slot it does not request, whose chain then adds nothing, and the constants that follow from its own slot
 // count (2^15 / k, 1.5 * 2^23 - k) are read per lane.
-template <int RM, bool FIRST1, bool NARROW = true>
+template <int RM, bool FIRST1, bool SCORE, bool NARROW = true>
 __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float (&bs)[RM][kZ], const float (&c0s)[RM], int ts, const uint32_t* pods,
                                         const uint32_t* sitems, int rows, int lane, bool w_pod, bool w_ctr, bool aligned, bool pod_scope, uint32_t st_stale,
                                         bool in, int pos, uint32_t* stage_status, uint32_t* stage_score) {
@@ -268,18 +268,23 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
       uint32_t sum = 0;
       // the next step's thresholds and Score item are in flight while this one is worked on
       FzThr<RM> t = fz_load_thr<RM>(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(rec) + thr0));
-      FzItem<RM> g = fz_load_item<RM>(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sit) + item0));
+      FzItem<RM> g{};
+      if constexpr (SCORE) g = fz_load_item<RM>(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sit) + item0));
       for (int c = 0; c < n_steps; ++c) {  // (left to the compiler: it peels the first steps, 5 % faster than `unroll 1`)
         const uint32_t op = ops & 0xffu;
         ops = c == 3 ? ops_hi : ops >> 8;
         const int cn = c + 1 < kC ? c + 1 : c;
         const FzThr<RM> tn = fz_load_thr<RM>(rec + kRkPodHead + (1 + cn) * RM);
-        const FzItem<RM> gn = fz_load_item<RM>(sit + (1 + cn) * fz_item_words<RM>());
+        FzItem<RM> gn{};
+        if constexpr (SCORE) gn = fz_load_item<RM>(sit + (1 + cn) * fz_item_words<RM>());
         // who takes this step: container-scope lanes while the pod has containers, pod-scope lanes the first one; the Score chains of
         // every slot either kind of item requests (head dwords 2 / 3 + c: the items' slot sets)
         const bool mine = pod_scope ? c == 0 : c < n_ctr;
-        uint32_t slots = (w_ctr && c < n_ctr) ? head(3 + c) & 0xffu : 0u;
-        if (w_pod && c == 0) slots |= head(2) & 0xffu;
+        uint32_t slots = 0;
+        if constexpr (SCORE) {
+          slots = (w_ctr && c < n_ctr) ? head(3 + c) & 0xffu : 0u;
+          if (w_pod && c == 0) slots |= head(2) & 0xffu;
+        }
         if (mine) {
           uint32_t m[W];
           fz_mask<RM, NARROW>(qa, t, m);
@@ -315,7 +320,9 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
               else z1[j] = z[j];
             }
           }
-          if (scored) sum += fz_score_item<RM, false, FIRST1>(bs, c0s, ts, slots, g);
+          if constexpr (SCORE) {
+            if (scored) sum += fz_score_item<RM, false, FIRST1>(bs, c0s, ts, slots, g);
+          }
         }
         t = tn;
         g = gn;
@@ -327,7 +334,10 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
     acc_status |= status << sh;
     acc_score |= score << sh;
     if ((p & 3) == 3 || p + 1 == rows) {  // uniform: one LDS write per table and four pods
-      if (in) stage_status[(p >> 2) * kWindow + pos] = acc_status, stage_score[(p >> 2) * kWindow + pos] = acc_score;
+      if (in) {
+        stage_status[(p >> 2) * kWindow + pos] = acc_status;
+        if constexpr (SCORE) stage_score[(p >> 2) * kWindow + pos] = acc_score;
+      }
       acc_status = acc_score = 0;
     }
   }
@@ -335,7 +345,9 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
 
 // dynamic LDS: the chunk block of the rank stream (header, lists, pod records), the chunk's packed Score items, then the staged
 // status and score dwords [2][kPodsPerUnit / 4][kWindow]
-template <int RM, bool FIRST1>
+// SCORE = false: the Filter alone (status table only) — what the two-launch forms (another strategy, other weights) run before their Score
+// launch: the same walk without the Score's tables, items and chains
+template <int RM, bool FIRST1, bool SCORE = true>
 __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, const uint32_t* __restrict__ fz_items, int n_tiles) {
   extern __shared__ __align__(16) uint32_t lds[];
   __shared__ uint32_t pk_flagged;  // the chunk's pods with a table-slot request k_nrt_pk_tab_build lists for this window
@@ -373,19 +385,21 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
   // ---- the chunk block and the chunk's Score items -> LDS (coalesced 16-byte pieces), the stage zeroed
   const uint32_t c0 = a.rk_off[chunk], c1 = a.rk_off[chunk + 1];
   uint32_t* const sitems = lds + a.rk_max_dwords;
-  uint32_t* const stage = sitems + kPodsPerUnit * fz_pod_words<RM>();  // [2][kPodsPerUnit / 4][kWindow]
+  uint32_t* const stage = sitems + (SCORE ? kPodsPerUnit * fz_pod_words<RM>() : 0);  // [2][kPodsPerUnit / 4][kWindow] (SCORE: else one table)
   {
     const uint4* src = reinterpret_cast<const uint4*>(a.rk_stream + c0);
     uint4* dst = reinterpret_cast<uint4*>(lds);
     const int n_quads = static_cast<int>((c1 - c0) >> 2);
     for (int i = threadIdx.x; i < n_quads; i += 256) dst[i] = src[i];
-    const uint4* isrc = reinterpret_cast<const uint4*>(fz_items + first * fz_pod_words<RM>());
-    uint4* idst = reinterpret_cast<uint4*>(sitems);
-    const int i_quads = rows * fz_pod_words<RM>() / 4;
-    for (int i = threadIdx.x; i < i_quads; i += 256) idst[i] = isrc[i];
+    if constexpr (SCORE) {
+      const uint4* isrc = reinterpret_cast<const uint4*>(fz_items + first * fz_pod_words<RM>());
+      uint4* idst = reinterpret_cast<uint4*>(sitems);
+      const int i_quads = rows * fz_pod_words<RM>() / 4;
+      for (int i = threadIdx.x; i < i_quads; i += 256) idst[i] = isrc[i];
+    }
     uint4* z = reinterpret_cast<uint4*>(stage) + threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 2 * kPodsPerUnit / 4 * kWindow / 4 / 256; ++i) z[i * 256] = uint4{0, 0, 0, 0};
+    for (int i = 0; i < (SCORE ? 2 : 1) * kPodsPerUnit / 4 * kWindow / 4 / 256; ++i) z[i * 256] = uint4{0, 0, 0, 0};
     if (threadIdx.x == 0) pk_flagged = 0;
   }
   const uint32_t flags = in ? a.flags[n] : 0u;
@@ -406,13 +420,16 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
     c0s[r] = (99.5f + (r == ts ? kPkOffsetTab : kPkOffsetSmall)) * 0x1p-7f;
 #pragma unroll
     for (int z = 0; z < kZ; ++z) {
-      const double b = (in && r < R) ? ld_off(a.f_rc, (static_cast<uint32_t>(z * R + r) * nn + n32) * 8u) : kNoCap;
-      bs[r][z] = b == kNoCap ? __builtin_inff() : static_cast<float>(b) * 0x1p-7f;
+      bs[r][z] = 0.0f;
+      if constexpr (SCORE) {
+        const double b = (in && r < R) ? ld_off(a.f_rc, (static_cast<uint32_t>(z * R + r) * nn + n32) * 8u) : kNoCap;
+        bs[r][z] = b == kNoCap ? __builtin_inff() : static_cast<float>(b) * 0x1p-7f;
+      }
     }
   }
   __syncthreads();
   // the pods whose table-slot request (any of their items) is listed for THIS node window: recomputed after the loop
-  if (ts >= 0) {
+  if (SCORE && ts >= 0) {
     for (int i = threadIdx.x; i < rows * kFzItems; i += 256) {
       const uint32_t* it = sitems + i * fz_item_words<RM>();
       if (!((it[RM] >> ts) & 1u)) continue;
@@ -466,9 +483,9 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
   const uint32_t st_stale = fresh ? 0u : static_cast<uint32_t>(SPX_NRT_ST_INVALID_TOPOLOGY);
   uint32_t* const stage_status = stage;
   uint32_t* const stage_score = stage + kPodsPerUnit / 4 * kWindow;
-  fz_walk<RM, FIRST1>(q4, bs, c0s, ts, pods, sitems, rows, lane, w_pod, w_ctr, aligned, pod_scope, st_stale, in, pos, stage_status, stage_score);
+  fz_walk<RM, FIRST1, SCORE>(q4, bs, c0s, ts, pods, sitems, rows, lane, w_pod, w_ctr, aligned, pod_scope, st_stale, in, pos, stage_status, stage_score);
   __syncthreads();
-  {
+  if constexpr (SCORE) {
     const uint32_t flagged = pk_flagged;  // block-uniform (every atomicOr precedes the barrier above)
     if (flagged != 0) {
       // second pass: the flagged pods' cells of this window with the table slot in the float64 form — its eight multipliers read
@@ -523,7 +540,7 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
       const uint32_t b = static_cast<uint32_t>(i & 3);
       const uint32_t pick = 0x0c0c0000u | ((4u + b) << 8) | b;
 #pragma unroll
-      for (int tbl = 0; tbl < 2; ++tbl) {
+      for (int tbl = 0; tbl < (SCORE ? 2 : 1); ++tbl) {
         const u32x4 w = *reinterpret_cast<const u32x4*>(&(tbl ? stage_score : stage_status)[(i >> 2) * kWindow + lane * 4]);
         const uint32_t lo = __builtin_amdgcn_perm(w.y, w.x, pick), hi = __builtin_amdgcn_perm(w.w, w.z, pick);
         uint8_t* out = (tbl ? a.out_score : a.out_status) + row * a.row_stride + col;
@@ -535,6 +552,25 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
 
 }  // namespace
 
+// The Filter launch of a two-launch sweep (another strategy, weighted slots) as the fused walk without its Score: false = not launched
+// (no narrow rank stream, or the chunk block does not fit next to the stage)
+bool launch_nrt_filter_fused(const NrtArgs& a, hipStream_t s) {
+  if (!a.fast || !a.rk_all_narrow || !a.rk_stream || !a.rk_off || !a.rk_first || a.rk_max_dwords == 0 || !a.out_status || a.out_raw || a.row_ptr) return false;
+  const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);
+  const int64_t chunks = a.rk_chunks;
+  const unsigned blocks = static_cast<unsigned>(n_tiles >= kXcdMapWindows ? chunks * (((n_tiles + 7) / 8) * 8) : ((chunks + 7) / 8) * 8 * n_tiles);
+  const size_t lds = static_cast<size_t>(a.rk_max_dwords) * 4 + static_cast<size_t>(kPodsPerUnit / 4) * kWindow * 4;
+  if (lds > 64 * 1024) return false;
+  if (a.n_res <= 4) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL((k_nrt_fused<4, true, false>), dim3(blocks), dim3(256), lds, s, a, static_cast<const uint32_t*>(nullptr), n_tiles);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL((k_nrt_fused<8, true, false>), dim3(blocks), dim3(256), lds, s, a, static_cast<const uint32_t*>(nullptr), n_tiles);
+  }
+  return true;
+}
+
 // words of scratch the packed Score items of `n_list` rows take (NrtArgs::fz_items)
 size_t nrt_fused_item_words(int n_res, int64_t n_list) {
   return static_cast<size_t>(n_list) * static_cast<size_t>(n_res <= 4 ? fz_pod_words<4>() : fz_pod_words<8>());
@@ -545,14 +581,16 @@ size_t nrt_fused_item_words(int n_res, int64_t n_list) {
 bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
   if (!a.fast || !a.fz_items || !a.rk_stream || !a.rk_off || !a.rk_first || a.rk_max_dwords == 0 || !a.out_status || !a.out_score || a.out_raw || a.row_ptr) return false;
   if (a.strategy != SPX_NRT_LEAST_ALLOCATED || !a.pk_mode || a.pk_tab_slot > 1) return false;  // (the table slot is chained first: slot 0 or 1)
+  // five to eight resource slots: the Score's multipliers alone are 64 registers — 192 with the rest, two waves per SIMD, 2.25 ms for the
+  // six-slot config #3 against 1.76 for the Filter-only walk + the packed Score launch (measured): those tables take the two launches
+  if (a.n_res > 4) return false;
   for (int r = 0; r < a.n_res; ++r)
     if (a.slot_weight[r] != 0 && a.slot_weight[r] != 1) return false;
   const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);
   const int64_t chunks = a.rk_chunks;
   // the kernel's block map: 8 XCDs x their windows per chunk, or 8 chunks (one per XCD) x all windows
   const unsigned blocks = static_cast<unsigned>(n_tiles >= kXcdMapWindows ? chunks * (((n_tiles + 7) / 8) * 8) : ((chunks + 7) / 8) * 8 * n_tiles);
-  const bool r4 = a.n_res <= 4;
-  const size_t lds = static_cast<size_t>(a.rk_max_dwords) * 4 + static_cast<size_t>(kPodsPerUnit) * (r4 ? fz_pod_words<4>() : fz_pod_words<8>()) * 4 +
+  const size_t lds = static_cast<size_t>(a.rk_max_dwords) * 4 + static_cast<size_t>(kPodsPerUnit) * fz_pod_words<4>() * 4 +
                      static_cast<size_t>(2) * (kPodsPerUnit / 4) * kWindow * 4;
   if (lds > 64 * 1024) return false;
   if (a.pk_tab_slot >= 0 && !(a.pk_tab_built && *a.pk_tab_built)) {  // the table of the packed float32 Score (kernels_nrt_fast.hip)
@@ -568,10 +606,8 @@ bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<RMV, F1V>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
     hipLaunchKernelGGL((k_nrt_fused<RMV, F1V>), dim3(blocks), dim3(256), lds, s, a, a.fz_items, n_tiles);                                 \
   } while (0)
-  if (r4 && first1) SPX_FZ_LAUNCH(4, true);
-  else if (r4) SPX_FZ_LAUNCH(4, false);
-  else if (first1) SPX_FZ_LAUNCH(8, true);
-  else SPX_FZ_LAUNCH(8, false);
+  if (first1) SPX_FZ_LAUNCH(4, true);
+  else SPX_FZ_LAUNCH(4, false);
 #undef SPX_FZ_LAUNCH
   return true;
 }

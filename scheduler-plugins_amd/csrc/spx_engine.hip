@@ -2453,6 +2453,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
       na.rk_max_dwords = e->nrt_rk_max_dwords;
       na.rk_first = static_cast<const uint32_t*>(e->d_nrt_rk_first.p);
       na.rk_chunks = e->nrt_rk_chunks;
+      na.rk_all_narrow = e->nrt_rk_all_narrow && e->option[SPX_OPT_NRT_FUSED];
       if (!classes) na.n_list = e->n_pods;
       if (fused) {
         if ((rc = ensure(e, e->d_nrt_fz, spx::nrt_fused_item_words(e->nrt_n_res, na.n_list) * sizeof(uint32_t)))) return rc;

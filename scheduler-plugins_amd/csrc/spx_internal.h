@@ -303,6 +303,7 @@ struct NrtArgs {
   uint32_t rk_max_dwords;        // largest chunk block (dynamic LDS)
   const uint32_t* rk_first;      // [rk_chunks + 1] position in the row list of each chunk's first row (a chunk holds up to 32 rows)
   uint32_t rk_chunks;
+  bool rk_all_narrow;            // every chunk keeps four zones' counts per register: the fused walk (kernels_nrt_fused.hip) applies
   uint32_t exact32_slots;        // resource slots whose requests and capacities (Value() form) are all float32 values (below 2^24, or a multiple of a large power of two): compared exactly
   // LeastAllocated's Score-only launch in packed float32 (nrt_fast_device.h, score_least_packed): zone PAIRS per instruction, u16 zone totals
   uint32_t pk_mode;              // 0 = off (every other kernel / strategy / launch form)
@@ -333,6 +334,7 @@ constexpr size_t kRkMaxChunkBytes = 56 * 1024;
 bool launch_nrt_filter_rank(const NrtArgs& a, int n_tiles, hipStream_t s);
 size_t nrt_fused_item_words(int n_res, int64_t n_list);
 bool launch_nrt_fused(const NrtArgs& a, hipStream_t s);
+bool launch_nrt_filter_fused(const NrtArgs& a, hipStream_t s);  // the same walk, Filter only
 void launch_nrt_pk_tab_build(const NrtArgs& a, int n_tiles, hipStream_t s);  // kernels_nrt_fast.hip: the packed Score's table of exceptions
 
 // combin.Combinations(8, k) for k = 1..8 as bitmasks over list positions, size-major then lexicographic — the order

@@ -358,9 +358,11 @@ def test_fused_sweep_equals_two_launches(gpu_required, hdr, oracle, wide, narrow
         assert e.get_option("NRT_FUSED") == 1
         e.eval(mask_of(NRT))
         e.sync()
-        # (the fused sweep has the four-zones-per-register layout only: with SPX_OPT_NRT_RANK_NARROW off the two launches run)
-        fused_path = 3 if narrow else (2 if classes else 1)
-        assert e.nrt_filter_path() == fused_path
+        # (the fused sweep has the four-zones-per-register layout only: with SPX_OPT_NRT_RANK_NARROW off the two launches run; and with five
+        # to eight slots the one-launch form would hold two waves per SIMD: those tables run the same walk Filter-only + the packed Score launch)
+        def path(cls):
+            return (2 if wide else 3) if narrow else (2 if cls else 1)
+        assert e.nrt_filter_path() == path(classes)
         status, score = e.all_status(NRT), e.all_scores(NRT)
         e.set_option("NRT_FUSED", 0)
         e.eval(mask_of(NRT))
@@ -372,7 +374,7 @@ def test_fused_sweep_equals_two_launches(gpu_required, hdr, oracle, wide, narrow
         e.set_option("NRT_POD_CLASSES", 1 - classes)  # the other row list: the stream is rebuilt for it
         e.eval(mask_of(NRT))
         e.sync()
-        assert e.nrt_filter_path() == (3 if narrow else (1 if classes else 2))
+        assert e.nrt_filter_path() == path(1 - classes)
         assert np.array_equal(e.all_status(NRT), status) and np.array_equal(e.all_scores(NRT), score)
     osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
     for r in list(range(0, n_pods, 97)) + [n_pods - 1]:
