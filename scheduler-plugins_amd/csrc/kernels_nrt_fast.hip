@@ -1160,8 +1160,17 @@ __global__ __launch_bounds__(256) void k_nrt_pk_tab_build(NrtArgs a) {
   for (double k = k0; k <= k1; k += 1.0) {
     const double v = k * unit;
     const int64_t vi = static_cast<int64_t>(v);
-    const uint32_t want = vi > ci ? 0u : static_cast<uint32_t>(((ci - vi) * 100) / ci);  // leastAllocatedScore, least_allocated.go:45-55
-    const uint32_t got = nrtdev::least_packed_one(static_cast<float>(v), b32, 99.5f + nrtdev::kPkOffsetTab);
+    uint32_t want, got;
+    if (a.strategy == SPX_NRT_MOST_ALLOCATED) {
+      // mostAllocatedScore most_allocated.go:45-54; the fused walk's t = fma(+v, b32, -0.5 + o), taken only where the request fits (a compare
+      // of its own there: the Filter's rank bits) — so requests above the capacity need no entry
+      if (vi > ci) continue;
+      want = static_cast<uint32_t>((vi * 100) / ci);
+      got = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(static_cast<float>(v), b32, -0.5f + nrtdev::kPkOffsetTab), 0, 0u) & 0xffu;
+    } else {
+      want = vi > ci ? 0u : static_cast<uint32_t>(((ci - vi) * 100) / ci);  // leastAllocatedScore, least_allocated.go:45-55
+      got = nrtdev::least_packed_one(static_cast<float>(v), b32, 99.5f + nrtdev::kPkOffsetTab);
+    }
     if (got != want) atomicOr(a.pk_tab + static_cast<size_t>(k) * a.pk_tab_words + (window >> 5), 1u << (window & 31u));
   }
 }

@@ -48,6 +48,8 @@ namespace {
 
 using namespace nrtdev;
 
+// what a launch of the walk computes: the Filter alone, or the Filter and the Score of one of the two strategies whose zone totals chain
+constexpr int kFzFilter = 0, kFzLeast = 1, kFzMost = 2;
 constexpr float kFzMagic = 12582912.0f;          // 1.5 * 2^23: integers m with |m| < 2^22 are exact around it, bits = kFzMagicBits + m
 constexpr uint32_t kFzMagicBits = 0x4b400000u;
 constexpr int kFzItems = 1 + kC;                  // the pod-level request, then the containers
@@ -75,11 +77,13 @@ __global__ __launch_bounds__(256) void k_nrt_fused_pack(NrtArgs a, uint32_t* __r
   auto f64 = [&](int at) { return __hiloint2double(static_cast<int>(w[at + 1]), static_cast<int>(w[at])); };
   uint32_t* o = out + idx * fz_item_words<RM>();
   const uint32_t used = w[2 * RM] & 0xffu & wmask;
-  // -Value(request); -inf for a slot that is not requested or weighs nothing: its chain, run because another lane's item needs it or
-  // because the walk only knows the unweighted slot set, adds clamp01(-inf) = 0
+  // -Value(request) (LeastAllocated: t = 99.5 + o - v b) or +Value(request) (MostAllocated: t = -0.5 + o + v b); -inf for a slot that is
+  // not requested or weighs nothing: its chain, run because another lane's item needs it or because the walk only knows the unweighted
+  // slot set, adds clamp01(-inf) = 0 (b >= 0; MostAllocated's b is 0 without capacity: NaN, clamped to 0 as well)
+  const float sign = a.strategy == SPX_NRT_MOST_ALLOCATED ? 1.0f : -1.0f;
 #pragma unroll
   for (int r = 0; r < RM; ++r)
-    o[r] = ((used >> r) & 1u) ? __float_as_uint(-static_cast<float>(f64(r == a.cpu_slot ? 2 * RM + 2 : 2 * r))) : 0xff800000u;
+    o[r] = ((used >> r) & 1u) ? __float_as_uint(sign * static_cast<float>(f64(r == a.cpu_slot ? 2 * RM + 2 : 2 * r))) : 0xff800000u;
   const uint32_t k = static_cast<uint32_t>(__builtin_popcount(used));
   o[RM] = used | ((k ? (32768u + k - 1u) / k : 0u) << 8);
   o[RM + 1] = kFzMagicBits - k;
@@ -118,6 +122,21 @@ __device__ __forceinline__ void fz_mask(const uint32_t (&qa)[RM][RkLayout<NARROW
   }
 }
 
+// ... and the per-slot words with it: bit 8 (z & 3) + 7 of xs[r][z >> 2] says "zone z holds the item's request of slot r" — MostAllocated's
+// `requested.Cmp(capacity) > 0 -> 0` (most_allocated.go:49-51) read off the Filter's subtraction instead of a compare of its own
+template <int RM>
+__device__ __forceinline__ void fz_mask_slots(const uint32_t (&qa)[RM][2], const FzThr<RM>& g, uint32_t (&m)[2], uint32_t (&xs)[RM][2]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int r = 0; r < RM; ++r) xs[r][j] = qa[r][j] - g.t[r];
+    uint32_t x = xs[0][j];
+#pragma unroll
+    for (int r = 1; r < RM; ++r) x &= xs[r][j];
+    m[j] = x & RkLayout<true>::G;
+  }
+}
+
 // the lowest zone of m (guard bits only: zones 0-3 in dword 0, 4-7 in dword 1) as a one-zone set; all zero when m is empty.  Seven
 // full-rate instructions (lowest_zone's gather / spread multiplications are v_mul_lo_u32: quarter rate)
 __device__ __forceinline__ void fz_lowest(const uint32_t (&m)[2], uint32_t (&z)[2]) {
@@ -145,6 +164,17 @@ __device__ __forceinline__ void fz_chain(float (&acc)[kZ], float nv, const float
   }
 }
 
+// MostAllocated's chain: the same two instructions around a mask — the resource score counts only where the zone holds the request
+// (fit: the slot's word of fz_mask_slots; v_bfe_i32 spreads the zone's bit over a dword, v_and clears s)
+__device__ __forceinline__ void fz_chain_most(float (&acc)[kZ], float pv, const float (&b)[kZ], float c0, const uint32_t (&fit)[2]) {
+#pragma unroll
+  for (int z = 0; z < kZ; ++z) {
+    const float s = __builtin_amdgcn_fmed3f(__builtin_fmaf(pv, b[z], c0), 0.0f, 1.0f);
+    const uint32_t keep = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(fit[z >> 2]), 8 * (z & 3) + 7, 1));
+    acc[z] = __builtin_fmaf(__uint_as_float(__float_as_uint(s) & keep), -128.0f, acc[z]);
+  }
+}
+
 // an item's registers as fetched from LDS (requested at the top of a container's step, ahead of the Filter's work on it)
 template <int RM>
 struct FzItem {
@@ -169,9 +199,13 @@ __device__ __forceinline__ FzItem<RM> fz_load_item(const uint32_t* it) {
 // (scoreForEachNUMANode score.go:110-124 over leastAllocatedScoreStrategy least_allocated.go:25-43, unit weights).  bs[r][z] =
 // RN32(RN64(100 / capacity)) / 128 (+inf without capacity), c0s[r] = (99.5 + o_r) / 128.  MIXED (second pass): the table slot's resource
 // scores come from the float64 form (bt[z] = RN64(100 / capacity), raw = the request as written), as score_least_packed<.., true>.
-template <int RM, bool MIXED, bool FIRST1>
+template <int RM, bool MIXED, bool FIRST1, bool MOST>
 __device__ __forceinline__ uint32_t fz_score_item(const float (&bs)[RM][kZ], const float (&c0s)[RM], int ts, uint32_t slots, const FzItem<RM>& g,
-                                                  const uint32_t* it = nullptr, const double* __restrict__ bt = nullptr) {
+                                                  const uint32_t (&xs)[RM][2], const uint32_t* it = nullptr, const double* __restrict__ bt = nullptr) {
+  auto chain = [&](float (&acc)[kZ], int r) {
+    if constexpr (MOST) fz_chain_most(acc, g.nv[r], bs[r], c0s[r], xs[r]);
+    else fz_chain(acc, g.nv[r], bs[r], c0s[r]);
+  };
   // `slots` (wave-uniform): the chains to run — every slot some lane at work requests (a lane's item holds -inf for the others).  What
   // depends on the item's OWN slot count k stays per lane: g.w1 = the bits of 1.5 * 2^23 minus k, g.w0 >> 8 = ceil(2^15 / k) (0: k = 0)
   float acc[kZ];
@@ -188,24 +222,28 @@ __device__ __forceinline__ uint32_t fz_score_item(const float (&bs)[RM][kZ], con
         const double raw = __hiloint2double(static_cast<int>(it[RM + 3]), static_cast<int>(it[RM + 2]));
         const bool mine = __float_as_uint(g.nv[A]) != 0xff800000u;
 #pragma unroll
-        for (int z = 0; z < kZ; ++z)
-          acc[z] = mine ? kFzMagic - static_cast<float>(static_cast<uint32_t>(__builtin_fma(-raw, bt[z], 100.0 + 0x1p-43))) : kFzMagic;
+        for (int z = 0; z < kZ; ++z) {
+          uint32_t rs;  // as score_each_fast's float64 forms (nrt_fast_device.h); bt = RN64(100 / capacity), +inf (Least) or 0 (Most) without capacity
+          if constexpr (MOST) rs = ((xs[A][z >> 2] >> (8 * (z & 3) + 7)) & 1u) ? static_cast<uint32_t>((raw * (1.0 + 0x1p-49)) * bt[z]) : 0u;
+          else rs = static_cast<uint32_t>(__builtin_fma(-raw, bt[z], 100.0 + 0x1p-43));
+          acc[z] = mine ? kFzMagic - static_cast<float>(rs) : kFzMagic;
+        }
       } else {
-        fz_chain(acc, g.nv[A], bs[A], c0s[A]);
+        chain(acc, A);
       }
     } else {
-      fz_chain(acc, g.nv[A], bs[A], c0s[A]);
+      chain(acc, A);
     }
   }
   if ((slots >> B) & 1u) {
     SPX_KEEP_BRANCH();
-    fz_chain(acc, g.nv[B], bs[B], c0s[B]);
+    chain(acc, B);
   }
 #pragma unroll
   for (int r = 2; r < RM; ++r) {
     if (!((slots >> r) & 1u)) continue;  // uniform
     SPX_KEEP_BRANCH();
-    fz_chain(acc, g.nv[r], bs[r], c0s[r]);
+    chain(acc, r);
   }
   // u = total - k as an unsigned integer: a zone whose total is below k (score 0) wraps to the top and leaves the minimum
   const uint32_t top = g.w1;
@@ -229,13 +267,14 @@ __device__ __forceinline__ uint32_t fz_score_item(const float (&bs)[RM][kZ], con
 // What steers scalar branches — which slots' Score chains run — is the union of the slot sets of the items at work (from the pod's head);
 // an item holds -inf for a slot it does not request, whose chain then adds nothing, and the constants that follow from its own slot
 // count (2^15 / k, 1.5 * 2^23 - k) are read per lane.
-template <int RM, bool FIRST1, bool SCORE, bool NARROW = true>
+template <int RM, bool FIRST1, int MODE, bool NARROW = true>
 __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float (&bs)[RM][kZ], const float (&c0s)[RM], int ts, const uint32_t* pods,
                                         const uint32_t* sitems, int rows, int lane, bool w_pod, bool w_ctr, bool aligned, bool pod_scope, uint32_t st_stale,
-                                        bool in, int pos, uint32_t* stage_status, uint32_t* stage_score) {
+                                        bool in, int pos, uint32_t absent_bits, uint32_t* stage_status, uint32_t* stage_score) {
   using L = RkLayout<NARROW>;
   constexpr int W = L::W;
   constexpr int PWR = kRkPodHead + kRkVectors * RM;
+  constexpr bool SCORE = MODE != kFzFilter, MOST = MODE == kFzMost;
   uint32_t qa[RM][W];
 #pragma unroll
   for (int r = 0; r < RM; ++r)
@@ -286,8 +325,14 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
           if (w_pod && c == 0) slots |= head(2) & 0xffu;
         }
         if (mine) {
-          uint32_t m[W];
-          fz_mask<RM, NARROW>(qa, t, m);
+          uint32_t m[W], xs[RM][2];
+          if constexpr (MOST) {
+            fz_mask_slots<RM>(qa, t, m, xs);
+          } else {
+            fz_mask<RM, NARROW>(qa, t, m);
+#pragma unroll
+            for (int r = 0; r < RM; ++r) xs[r][0] = xs[r][1] = 0u;
+          }
           if (op & (kRkOpMerge1 | kRkOpMerge3)) {  // uniform: an earlier app container may have been charged to a zone (c >= 1)
             if (op & kRkOpMerge1) {
               uint32_t ms[W];
@@ -308,6 +353,14 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
               }
             }
           }
+          if constexpr (MOST) {
+            // MostAllocated reads "the zone holds the request" off the counts, so they stay the zones' own: a compared slot the node does not
+            // report at node level (filter.go:101-104: the Filter fails, the Score does not care) is tested here instead of zeroing its counts
+            const uint32_t sc = head(3 + c), sp = head(2);
+            const uint32_t need_c = ((sc >> 8) | (sc >> 16)) & 0xffu, need_p = ((sp >> 8) | (sp >> 16)) & 0xffu;
+            const uint32_t need = (w_pod && c == 0 && pod_scope) ? need_p : need_c;
+            if ((need & absent_bits) != 0u) m[0] = m[1] = 0u;
+          }
           // the first misfit names the status (a later one finds it set); an empty verdict has no lowest zone: nothing is charged
           const uint32_t code = (w_pod && c == 0 && pod_scope) ? static_cast<uint32_t>(SPX_NRT_ST_POD) : (op & 7u);
           if (fz_none(m) && status == 0u) status = code;
@@ -321,7 +374,7 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
             }
           }
           if constexpr (SCORE) {
-            if (scored) sum += fz_score_item<RM, false, FIRST1>(bs, c0s, ts, slots, g);
+            if (scored) sum += fz_score_item<RM, false, FIRST1, MOST>(bs, c0s, ts, slots, g, xs);
           }
         }
         t = tn;
@@ -347,8 +400,9 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
 // status and score dwords [2][kPodsPerUnit / 4][kWindow]
 // SCORE = false: the Filter alone (status table only) — what the two-launch forms (another strategy, other weights) run before their Score
 // launch: the same walk without the Score's tables, items and chains
-template <int RM, bool FIRST1, bool SCORE = true>
+template <int RM, bool FIRST1, int MODE>
 __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, const uint32_t* __restrict__ fz_items, int n_tiles) {
+  constexpr bool SCORE = MODE != kFzFilter, MOST = MODE == kFzMost;
   extern __shared__ __align__(16) uint32_t lds[];
   __shared__ uint32_t pk_flagged;  // the chunk's pods with a table-slot request k_nrt_pk_tab_build lists for this window
   const int lane = threadIdx.x & 63;
@@ -417,13 +471,13 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
   float c0s[RM];
 #pragma unroll
   for (int r = 0; r < RM; ++r) {
-    c0s[r] = (99.5f + (r == ts ? kPkOffsetTab : kPkOffsetSmall)) * 0x1p-7f;
+    c0s[r] = ((MOST ? -0.5f : 99.5f) + (r == ts ? kPkOffsetTab : kPkOffsetSmall)) * 0x1p-7f;
 #pragma unroll
     for (int z = 0; z < kZ; ++z) {
       bs[r][z] = 0.0f;
       if constexpr (SCORE) {
         const double b = (in && r < R) ? ld_off(a.f_rc, (static_cast<uint32_t>(z * R + r) * nn + n32) * 8u) : kNoCap;
-        bs[r][z] = b == kNoCap ? __builtin_inff() : static_cast<float>(b) * 0x1p-7f;
+        bs[r][z] = b == kNoCap ? (MOST ? 0.0f : __builtin_inff()) : static_cast<float>(b) * 0x1p-7f;  // no capacity: the resource scores 0
       }
     }
   }
@@ -467,7 +521,7 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
     }
     // a compared resource the node does not report at node level fails whatever the zones say (filter.go:101-104): count 0 (a slot that
     // is not compared subtracts 0 and passes); a host-level resource no zone reports passes whatever is asked: all ones
-    const bool absent = !((node_present >> r) & 1u), fill = (fill_bits >> r) & 1u;
+    const bool absent = !MOST && !((node_present >> r) & 1u), fill = (fill_bits >> r) & 1u;  // (MostAllocated: fz_walk tests node-level absence itself)
     const uint32_t lo4 = RkLayout<true>::G | cnt[0] | (cnt[1] << 8) | (cnt[2] << 16) | (cnt[3] << 24);
     const uint32_t hi4 = RkLayout<true>::G | cnt[4] | (cnt[5] << 8) | (cnt[6] << 16) | (cnt[7] << 24);
     q4[r][0] = absent ? RkLayout<true>::G : (fill ? ~0u : lo4);
@@ -483,7 +537,10 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
   const uint32_t st_stale = fresh ? 0u : static_cast<uint32_t>(SPX_NRT_ST_INVALID_TOPOLOGY);
   uint32_t* const stage_status = stage;
   uint32_t* const stage_score = stage + kPodsPerUnit / 4 * kWindow;
-  fz_walk<RM, FIRST1, SCORE>(q4, bs, c0s, ts, pods, sitems, rows, lane, w_pod, w_ctr, aligned, pod_scope, st_stale, in, pos, stage_status, stage_score);
+  uint32_t absent_bits = 0;  // slots the node does not report at node level
+#pragma unroll
+  for (int r = 0; r < RM; ++r) absent_bits |= (r < R && !((node_present >> r) & 1u)) ? 1u << r : 0u;
+  fz_walk<RM, FIRST1, MODE>(q4, bs, c0s, ts, pods, sitems, rows, lane, w_pod, w_ctr, aligned, pod_scope, st_stale, in, pos, absent_bits, stage_status, stage_score);
   __syncthreads();
   if constexpr (SCORE) {
     const uint32_t flagged = pk_flagged;  // block-uniform (every atomicOr precedes the barrier above)
@@ -494,7 +551,7 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
 #pragma unroll
       for (int z = 0; z < kZ; ++z) {
         const double b = in ? a.f_rc[(static_cast<int64_t>(z) * R + ts) * a.n_nodes + n] : kNrtNoCap;
-        bt[z] = b == kNrtNoCap ? __builtin_inf() : b;
+        bt[z] = b == kNrtNoCap ? (MOST ? 0.0 : __builtin_inf()) : b;
       }
       constexpr int PWR = kRkPodHead + kRkVectors * RM;
       uint32_t n_redone = 0;
@@ -507,16 +564,29 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
         ++n_redone;
         const int n_ctr = (h0 >> 16) & 0xffu;
         const uint32_t* sit = sitems + p * fz_pod_words<RM>();
+        auto fit_words = [&](int vec, uint32_t (&xs)[RM][2]) {  // MostAllocated: which zones hold the item's requests (its own comparison vector)
+          if constexpr (MOST) {
+            uint32_t m[2];
+            fz_mask_slots<RM>(q4, fz_load_thr<RM>(rec + kRkPodHead + vec * RM), m, xs);
+          } else {
+#pragma unroll
+            for (int r = 0; r < RM; ++r) xs[r][0] = xs[r][1] = 0u;
+          }
+        };
         uint32_t score = 0;
         if (aligned) {
           if (pod_scope) {
-            score = fz_score_item<RM, true, FIRST1>(bs, c0s, ts, sit[RM] & 0xffu, fz_load_item<RM>(sit), sit, bt);
+            uint32_t xs[RM][2];
+            fit_words(0, xs);
+            score = fz_score_item<RM, true, FIRST1, MOST>(bs, c0s, ts, sit[RM] & 0xffu, fz_load_item<RM>(sit), xs, sit, bt);
           } else {
             uint32_t sum = 0;
 #pragma unroll 1
             for (int c = 0; c < n_ctr; ++c) {
               const uint32_t* it = sit + (1 + c) * fz_item_words<RM>();
-              sum += fz_score_item<RM, true, FIRST1>(bs, c0s, ts, it[RM] & 0xffu, fz_load_item<RM>(it), it, bt);
+              uint32_t xs[RM][2];
+              fit_words(1 + c, xs);
+              sum += fz_score_item<RM, true, FIRST1, MOST>(bs, c0s, ts, it[RM] & 0xffu, fz_load_item<RM>(it), xs, it, bt);
             }
             score = (sum * h1) >> 16;
           }
@@ -562,11 +632,11 @@ bool launch_nrt_filter_fused(const NrtArgs& a, hipStream_t s) {
   const size_t lds = static_cast<size_t>(a.rk_max_dwords) * 4 + static_cast<size_t>(kPodsPerUnit / 4) * kWindow * 4;
   if (lds > 64 * 1024) return false;
   if (a.n_res <= 4) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    hipLaunchKernelGGL((k_nrt_fused<4, true, false>), dim3(blocks), dim3(256), lds, s, a, static_cast<const uint32_t*>(nullptr), n_tiles);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<4, true, kFzFilter>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL((k_nrt_fused<4, true, kFzFilter>), dim3(blocks), dim3(256), lds, s, a, static_cast<const uint32_t*>(nullptr), n_tiles);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    hipLaunchKernelGGL((k_nrt_fused<8, true, false>), dim3(blocks), dim3(256), lds, s, a, static_cast<const uint32_t*>(nullptr), n_tiles);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<8, true, kFzFilter>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL((k_nrt_fused<8, true, kFzFilter>), dim3(blocks), dim3(256), lds, s, a, static_cast<const uint32_t*>(nullptr), n_tiles);
   }
   return true;
 }
@@ -580,7 +650,8 @@ size_t nrt_fused_item_words(int n_res, int64_t n_list) {
 // strategy or weights the chain does not cover, or a chunk block that does not fit in LDS next to the items and the stage.
 bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
   if (!a.fast || !a.fz_items || !a.rk_stream || !a.rk_off || !a.rk_first || a.rk_max_dwords == 0 || !a.out_status || !a.out_score || a.out_raw || a.row_ptr) return false;
-  if (a.strategy != SPX_NRT_LEAST_ALLOCATED || !a.pk_mode || a.pk_tab_slot > 1) return false;  // (the table slot is chained first: slot 0 or 1)
+  const bool most = a.strategy == SPX_NRT_MOST_ALLOCATED;
+  if ((a.strategy != SPX_NRT_LEAST_ALLOCATED && !most) || !a.pk_mode || a.pk_tab_slot > 1) return false;  // (the table slot is chained first: slot 0 or 1)
   // five to eight resource slots: the Score's multipliers alone are 64 registers — 192 with the rest, two waves per SIMD, 2.25 ms for the
   // six-slot config #3 against 1.76 for the Filter-only walk + the packed Score launch (measured): those tables take the two launches
   if (a.n_res > 4) return false;
@@ -600,14 +671,19 @@ bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
   const unsigned pack_blocks = static_cast<unsigned>((a.n_list * kFzItems + 255) / 256);
   // FIRST1: the two-slot fast path chains slot 1 before slot 0 — right whenever the table slot is not slot 0 (it is memory, or there is none)
   const bool first1 = a.pk_tab_slot != 0;
-#define SPX_FZ_LAUNCH(RMV, F1V)                                                                                                            \
+#define SPX_FZ_LAUNCH(RMV, F1V, MODEV)                                                                                                     \
   do {                                                                                                                                     \
     if (a.fz_pack) hipLaunchKernelGGL((k_nrt_fused_pack<RMV>), dim3(pack_blocks), dim3(256), 0, s, a, a.fz_items);                       \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<RMV, F1V>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
-    hipLaunchKernelGGL((k_nrt_fused<RMV, F1V>), dim3(blocks), dim3(256), lds, s, a, a.fz_items, n_tiles);                                 \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<RMV, F1V, MODEV>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+    hipLaunchKernelGGL((k_nrt_fused<RMV, F1V, MODEV>), dim3(blocks), dim3(256), lds, s, a, a.fz_items, n_tiles);                          \
   } while (0)
-  if (first1) SPX_FZ_LAUNCH(4, true);
-  else SPX_FZ_LAUNCH(4, false);
+  if (most) {
+    if (first1) SPX_FZ_LAUNCH(4, true, kFzMost);
+    else SPX_FZ_LAUNCH(4, false, kFzMost);
+  } else {
+    if (first1) SPX_FZ_LAUNCH(4, true, kFzLeast);
+    else SPX_FZ_LAUNCH(4, false, kFzLeast);
+  }
 #undef SPX_FZ_LAUNCH
   return true;
 }

@@ -473,8 +473,9 @@ struct NrtPacked {
 constexpr int64_t kNrtSmallCap = 32768;
 bool nrt_packed_score(const spx_engine* e, NrtPacked* out) {
   *out = NrtPacked{};
+  // (MostAllocated: the same float32 products serve x = 100 v / c as serve 100 - x; only the fused walk consumes the answer for that strategy)
   if (!e->option[SPX_OPT_NRT_PACKED_SCORE] || !e->nrt_nodes || !e->nrt_pods || e->in_commit_loop ||
-      e->nrt_params.strategy != SPX_NRT_LEAST_ALLOCATED)
+      (e->nrt_params.strategy != SPX_NRT_LEAST_ALLOCATED && !(e->nrt_params.strategy == SPX_NRT_MOST_ALLOCATED && e->option[SPX_OPT_NRT_FUSED])))
     return false;
   int64_t wsum = 0;
   for (int i = 0; i < e->nrt_n_res && i < SPX_NRT_MAX_RES; ++i) {
@@ -1274,6 +1275,10 @@ int spx_set_nrt_params(spx_engine* e, const spx_nrt_params* p) {
   if (!e || !p) return SPX_ERR_ARG;
   if (p->strategy < SPX_NRT_MOST_ALLOCATED || p->strategy > SPX_NRT_LEAST_NUMA_NODES)
     return fail(e, SPX_ERR_ARG, "illegal scoring strategy found");  // score.go:137-139
+  if (e->nrt_params.strategy != p->strategy) {  // the packed Score's table of exceptions and the fused walk's items are per strategy
+    e->nrt_pk_tab_built = false;
+    ++e->nrt_items_gen;
+  }
   e->nrt_params.strategy = p->strategy;  // weights travel through the slot table (spx_flatten_nrt_slots)
   return SPX_OK;
 }

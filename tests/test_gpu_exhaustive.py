@@ -158,7 +158,7 @@ def test_config3_quarter_size_other_seeds_every_cell(gpu_required, hdr, oracle, 
         assert e.kernel_path(NRT) == 1
         e.eval(mask_of(NRT))
         e.sync()
-        if strategy == "LeastAllocated":
+        if strategy != "BalancedAllocation":
             assert e.nrt_filter_path() == 3  # the fused Filter + Score launch
         osnap = oracle.Snapshot(snap["nodes"], snap["pods"], rc=snap["rc"], nrt=snap["nrt"], nrt_params=params)
         bad_status = bad_score = 0

@@ -319,7 +319,7 @@ def test_rank_filter_equals_float64_filter(gpu_required, hdr, oracle, wide, narr
     containers and sidecars, both node scopes, stale and NRT-less nodes, unreported and host-level resources."""
     n_nodes, n_pods = 1500, 2500
     snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=31, wide=wide)
-    params = O.nrt_params(hdr, O.Resources(), "MostAllocated")
+    params = O.nrt_params(hdr, O.Resources(), "BalancedAllocation")  # (a strategy whose sweep keeps the Filter launch: Least / MostAllocated fuse it)
     with Engine(0) as e:
         e.set_option("NRT_RANK_NARROW", narrow)
         e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
@@ -339,18 +339,20 @@ def test_rank_filter_equals_float64_filter(gpu_required, hdr, oracle, wide, narr
 
 
 # ------------------------------------------------------------------ Filter + Score in one launch (SPX_OPT_NRT_FUSED)
+@pytest.mark.parametrize("strategy", ["LeastAllocated", "MostAllocated"])
 @pytest.mark.parametrize("classes", [1, 0], ids=["pod-classes", "every-row"])
 @pytest.mark.parametrize("narrow", [1, 0], ids=["narrow-chunks", "wide-only"])
 @pytest.mark.parametrize("wide", [False, True], ids=["4slots", "6slots"])
-def test_fused_sweep_equals_two_launches(gpu_required, hdr, oracle, wide, narrow, classes):
-    """A whole-batch LeastAllocated sweep with unit weights runs Filter and Score in ONE launch (kernels_nrt_fused.hip: the rank-space
-    Filter evaluated branch-free, the Score as a chain of two float32 instructions per (zone, resource), the chunk's pod records
-    staged once); with the option off the Filter launch and the packed Score launch run.  Same two tables, cell for cell, with
+def test_fused_sweep_equals_two_launches(gpu_required, hdr, oracle, wide, narrow, classes, strategy):
+    """A whole-batch Least- or MostAllocated sweep with unit weights runs Filter and Score in ONE launch (kernels_nrt_fused.hip: the
+    rank-space Filter evaluated branch-free, the Score as a chain of two float32 instructions per (zone, resource) — MostAllocated's
+    behind the Filter's own "request fits" bits — the chunk's pod records staged once); with the option off the Filter launch and the
+    Score launch (packed float32 for Least, float64 for Most) run.  Same two tables, cell for cell, with
     pod classes (the stream lists the representatives) and without (the stream lists every row, built when the sweep first asks),
     in both count layouts, for four and six resource slots; and the oracle's rows on a sample."""
     n_nodes, n_pods = 1500, 2500
     snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=37, wide=wide)
-    params = O.nrt_params(hdr, O.Resources(), "LeastAllocated")
+    params = O.nrt_params(hdr, O.Resources(), strategy)
     with Engine(0) as e:
         e.set_option("NRT_RANK_NARROW", narrow)
         e.set_option("NRT_POD_CLASSES", classes)
@@ -387,7 +389,7 @@ def test_fused_sweep_steps_aside(gpu_required, hdr, oracle):
     n_nodes, n_pods = 700, 900
     snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=41)
     res = O.Resources()
-    for strategy, weights in (("LeastAllocated", {"cpu": 3, "memory": 1}), ("MostAllocated", None)):
+    for strategy, weights in (("LeastAllocated", {"cpu": 3, "memory": 1}), ("MostAllocated", {"cpu": 2}), ("BalancedAllocation", None)):
         params = O.nrt_params(hdr, res, strategy, weights)
         with Engine(0) as e:
             e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
