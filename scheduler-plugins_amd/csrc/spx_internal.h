@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "../../include/spx.h"
+#include "nrt_rank_layout.h"
 
 namespace spx {
 
@@ -322,14 +323,6 @@ constexpr int64_t kNrtPkTabMaxK = (int64_t{1} << 17) - 1;   // request / unit ab
 constexpr size_t kNrtPkTabMaxBytes = size_t{64} << 20;
 constexpr int64_t kNrtPkMaxWeightSum = 320;  // 100 * sum(weights) must stay below 2^15 for the u16 zone totals
 constexpr double kNrtNoCap = 1e200;
-// rank-space Filter: chunk rows, comparison vectors per pod (pod-level, 8 containers, 4 sums), head dwords of a pod record
-// (w0, w1, the slot sets of items 1..9, app containers a0 | a1 << 8 | a2 << 16 | count << 24, pad), largest chunk block
-constexpr int kRkChunkRows = 32, kRkVectors = 13, kRkPodHead = 16;
-// head dwords 12 / 13 of a pod record: one byte per container for the fused sweep — bits 0-2 the Filter status a misfit sets, then
-constexpr uint32_t kRkOpMerge1 = 8;    // the second app container: its verdict for the zone a0 was charged to comes from vector 9
-constexpr uint32_t kRkOpMerge3 = 16;   // the third: vectors 10 / 11 / 12 for the zones a0 / a1 / both were charged to
-constexpr uint32_t kRkOpCharge0 = 32;  // the lowest fitting zone is remembered as a0's
-constexpr uint32_t kRkOpCharge1 = 64;  // ... as a1's
 constexpr size_t kRkMaxChunkBytes = 56 * 1024;
 bool launch_nrt_filter_rank(const NrtArgs& a, int n_tiles, hipStream_t s);
 size_t nrt_fused_item_words(int n_res, int64_t n_list);
