@@ -48,3 +48,17 @@ def test_committed_profiles_are_stamped_and_a_foreign_stamp_is_refused(bench_mod
     monkeypatch.setattr(bench_mod, "ROOT", tmp_path)
     got = bench_mod.profile_counters("config2", ("alloc", "tlp"))
     assert got["traffic"] is None and "stale_profile" in got and "valu_busy_frac" not in got
+
+
+def test_latest_profiles_describe_the_kernels_in_the_tree(bench_mod):
+    """Every profile of the latest round was taken with the machine code this tree builds: a kernel edit after the profiles were
+    collected fails here (round-5 review: four workloads kept round-4 stamps and DESIGN printed their times as "unchanged") — re-collect
+    with tools/prof_all.sh + tools/collect_profiles.py, or move the stale entry out of the latest round's directory."""
+    latest = sorted((ROOT / "profiles").glob("r*"))[-1]
+    stale = {}
+    for f in sorted(latest.glob("*_traffic.json")):
+        d = json.loads(f.read_text())
+        want = bench_mod.kernel_source_hash(bench_mod.WORKLOADS[d["workload"]]["plugins"])
+        if d["kernel_source_hash"] != want:
+            stale[f.name] = (d["kernel_source_hash"], want)
+    assert not stale, stale
