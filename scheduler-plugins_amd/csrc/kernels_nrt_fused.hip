@@ -92,6 +92,52 @@ __global__ __launch_bounds__(256) void k_nrt_fused_pack(NrtArgs a, uint32_t* __r
   o[RM + 3] = static_cast<uint32_t>(__double2hiint(raw));
 }
 
+// ---------------------------------------------------------------- per-window sorted cell values (the walk's block start, four slots)
+// A block of the walk needs, for each of its node's 32 cells, how many entries of the chunk's list the cell's quantity reaches.  Rounds
+// 4-6a searched the list per cell (7 dependent LDS steps x 32 cells per lane: 15 % of the walk's vector instructions).  The cells of a
+// window do not change from chunk to chunk, so their ORDER is computed once per node table: S[w][r] = the window's 2 048 quantities of
+// slot r, sorted; rank[node][z][r] = the cell's index in it.  A block then searches S once per LIST ENTRY (<= 128 per slot: two per
+// thread), drops the results into a histogram over the 2 049 positions — one dword per position, a byte per slot: a list has at most
+// 127 real entries, so no byte overflows and ONE prefix sum serves the four slots — and every cell reads its count at its rank:
+//   entry L lands at T = #{cells < L};  cell of rank i (ties in any order) has  L <= cell  <=>  T <= i;  count = prefix[i].
+constexpr int kWsCells = kWindow * kZ;  // 2 048 quantities per (window, slot)
+
+__global__ __launch_bounds__(1024) void k_nrt_window_sort(NrtArgs a, double* __restrict__ wsort, uint16_t* __restrict__ wrank) {
+  __shared__ double key[kWsCells];
+  __shared__ uint16_t idx[kWsCells];
+  const int R = a.n_res;
+  const int w = static_cast<int>(blockIdx.x) / 4, r = static_cast<int>(blockIdx.x) & 3;
+  for (int i = threadIdx.x; i < kWsCells; i += 1024) {
+    const int32_t pn = a.perm[static_cast<int64_t>(w) * kWindow + (i >> 3)];
+    // an empty slot of the window and a cell the zone does not report lie below every list entry (the lists start at 0): count 0, as before
+    key[i] = (pn >= 0 && r < R) ? a.f_av[(static_cast<int64_t>(i & 7) * R + r) * a.n_nodes + pn] : -2.0;
+    idx[i] = static_cast<uint16_t>(i);
+  }
+  __syncthreads();
+  for (int k = 2; k <= kWsCells; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < kWsCells; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k) == 0;
+          const double x = key[i], y = key[l];
+          if ((x > y) == up) {
+            key[i] = y, key[l] = x;
+            const uint16_t t = idx[i];
+            idx[i] = idx[l], idx[l] = t;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < kWsCells; i += 1024) {
+    wsort[(static_cast<int64_t>(w) * 4 + r) * kWsCells + i] = key[i];
+    const int cell = idx[i];
+    const int32_t pn = a.perm[static_cast<int64_t>(w) * kWindow + (cell >> 3)];
+    if (pn >= 0) wrank[static_cast<int64_t>(pn) * 32 + (cell & 7) * 4 + r] = static_cast<uint16_t>(i);
+  }
+}
+
 // a comparison vector's thresholds as fetched from LDS (one per slot, replicated into the layout's fields)
 template <int RM>
 struct FzThr {
@@ -498,6 +544,102 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
   uint32_t q4[RM][2];
   const double* lists = reinterpret_cast<const double*>(lds + 16);
   uint32_t list_doubles = 0;
+  bool counted = false;
+  if constexpr (RM == 4) {
+    if (a.wsort != nullptr) {  // uniform: the window's cells are sorted (k_nrt_window_sort): one search per list entry, one lookup per cell
+      counted = true;
+      uint32_t* const hist = stage;  // [kWsCells + 1] dwords, a byte per slot; the stage is not in use yet (zeroed above, and again below)
+      uint32_t lo_of[RM], len_of[RM];
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        const uint32_t hw = r < R ? lds[r] : 0u;
+        lo_of[r] = hw >> 8, len_of[r] = r < R ? 1u << (hw & 0xffu) : 0u;
+        if (r < R) list_doubles = lo_of[r] + len_of[r];
+      }
+      {  // thread t: entries (t & 63) and (t & 63) + 64 of slot t >> 6
+        const int r = static_cast<int>(threadIdx.x >> 6);
+        uint32_t lo_r = 0, len_r = 0;
+#pragma unroll
+        for (int q = 0; q < RM; ++q)
+          if (q == r) lo_r = lo_of[q], len_r = len_of[q];
+        const double* S = a.wsort + (static_cast<int64_t>(window) * 4 + r) * kWsCells;
+        const uint32_t k0 = threadIdx.x & 63u, k1 = k0 + 64u;
+        const bool on0 = k0 < len_r, on1 = k1 < len_r;
+        const double l0 = on0 ? lists[lo_r + k0] : 0.0, l1 = on1 ? lists[lo_r + k1] : 0.0;
+        // lower bound — how many of the window's quantities lie below the entry — as one binary step and five quaternary ones: six dependent
+        // round trips to the L2 instead of eleven (the block start is latency, not instructions)
+        static_assert(kWsCells == 2048, "1024 + 3 * (256 + 64 + 16 + 4 + 1) = 2047");
+        uint32_t p0 = S[1023] < l0 ? 1024u : 0u, p1 = S[1023] < l1 ? 1024u : 0u;
+#pragma unroll
+        for (uint32_t q = 256; q > 0; q >>= 2) {
+          const double a0 = S[p0 + q - 1], b0 = S[p0 + 2 * q - 1], c0v = S[p0 + 3 * q - 1];
+          const double a1 = S[p1 + q - 1], b1 = S[p1 + 2 * q - 1], c1v = S[p1 + 3 * q - 1];
+          p0 += ((a0 < l0 ? 1u : 0u) + (b0 < l0 ? 1u : 0u) + (c0v < l0 ? 1u : 0u)) * q;
+          p1 += ((a1 < l1 ? 1u : 0u) + (b1 < l1 ? 1u : 0u) + (c1v < l1 ? 1u : 0u)) * q;
+        }
+        // (the search covers 2 047 positions; one more compare for the last)
+        p0 = (p0 == kWsCells - 1 && S[kWsCells - 1] < l0) ? kWsCells : p0;
+        p1 = (p1 == kWsCells - 1 && S[kWsCells - 1] < l1) ? kWsCells : p1;
+        if (on0) atomicAdd(&hist[p0], 1u << (8 * r));
+        if (on1) atomicAdd(&hist[p1], 1u << (8 * r));
+      }
+      __syncthreads();
+      {  // inclusive prefix over the positions: eight per thread, then the threads' totals (no byte overflows: <= 127 real entries per slot)
+        u32x4 h0 = *reinterpret_cast<const u32x4*>(hist + threadIdx.x * 8), h1 = *reinterpret_cast<const u32x4*>(hist + threadIdx.x * 8 + 4);
+        h0.y += h0.x, h0.z += h0.y, h0.w += h0.z;
+        h1.x += h0.w, h1.y += h1.x, h1.z += h1.y, h1.w += h1.z;
+        uint32_t incl = h1.w;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t up = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), d));
+          incl += lane >= d ? up : 0u;
+        }
+        __shared__ uint32_t wave_sum[4];
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - h1.w;
+#pragma unroll
+        for (int wv = 0; wv < 3; ++wv) before += wv < wave ? wave_sum[wv] : 0u;
+        h0.x += before, h0.y += before, h0.z += before, h0.w += before;
+        h1.x += before, h1.y += before, h1.z += before, h1.w += before;
+        *reinterpret_cast<u32x4*>(hist + threadIdx.x * 8) = h0;
+        *reinterpret_cast<u32x4*>(hist + threadIdx.x * 8 + 4) = h1;
+      }
+      __syncthreads();
+      uint32_t cnt4[kZ];  // per zone: the four slots' counts, a byte each
+      {
+        const u32x4* rk = reinterpret_cast<const u32x4*>(a.wrank + n * 32);
+        const u32x4 r0 = in ? rk[0] : u32x4{0, 0, 0, 0}, r1 = in ? rk[1] : u32x4{0, 0, 0, 0}, r2 = in ? rk[2] : u32x4{0, 0, 0, 0},
+                    r3 = in ? rk[3] : u32x4{0, 0, 0, 0};
+        const uint32_t rw[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+#pragma unroll
+        for (int z = 0; z < kZ; ++z) {
+          // rank of (z, r): halfword z * 4 + r;  the count of slot r sits in byte r of the prefix dword at that rank
+          const uint32_t i0 = rw[2 * z] & 0xffffu, i1 = rw[2 * z] >> 16, i2 = rw[2 * z + 1] & 0xffffu, i3 = rw[2 * z + 1] >> 16;
+          const uint32_t c0v = hist[i0], c1v = hist[i1], c2v = hist[i2], c3v = hist[i3];
+          cnt4[z] = in ? (c0v & 0xffu) | (c1v & 0xff00u) | (c2v & 0xff0000u) | (c3v & 0xff000000u) : 0u;
+        }
+      }
+      __syncthreads();  // every lookup is done: the histogram's memory becomes the stage again
+      {
+        uint4* zz = reinterpret_cast<uint4*>(stage) + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < (kWsCells + 8) / 4 / 256 + 1; ++i)
+          if (i * 256 + static_cast<int>(threadIdx.x) < (SCORE ? 2 : 1) * kPodsPerUnit / 4 * kWindow / 4) zz[i * 256] = uint4{0, 0, 0, 0};
+      }
+      __syncthreads();  // (a lane's first staged dword must not meet another lane's zeroing)
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        const bool absent = !MOST && !((node_present >> r) & 1u), fill = (fill_bits >> r) & 1u;
+        uint32_t lo4 = RkLayout<true>::G, hi4 = RkLayout<true>::G;
+#pragma unroll
+        for (int z = 0; z < 4; ++z) lo4 |= ((cnt4[z] >> (8 * r)) & 0xffu) << (8 * z), hi4 |= ((cnt4[z + 4] >> (8 * r)) & 0xffu) << (8 * z);
+        q4[r][0] = (r >= R || absent) ? RkLayout<true>::G : (fill ? ~0u : lo4);
+        q4[r][1] = (r >= R || absent) ? RkLayout<true>::G : (fill ? ~0u : hi4);
+      }
+    }
+  }
+  if (!counted) {
 #pragma unroll
   for (int r = 0; r < RM; ++r) {
     q4[r][0] = q4[r][1] = RkLayout<true>::G;  // (slots past the table: never requested)
@@ -526,6 +668,7 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
     const uint32_t hi4 = RkLayout<true>::G | cnt[4] | (cnt[5] << 8) | (cnt[6] << 16) | (cnt[7] << 24);
     q4[r][0] = absent ? RkLayout<true>::G : (fill ? ~0u : lo4);
     q4[r][1] = absent ? RkLayout<true>::G : (fill ? ~0u : hi4);
+  }
   }
   const uint32_t* const pods = lds + 16 + 2 * list_doubles;
   const bool fresh = flags & SPX_NRT_F_FRESH;
@@ -629,7 +772,7 @@ bool launch_nrt_filter_fused(const NrtArgs& a, hipStream_t s) {
   const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);
   const int64_t chunks = a.rk_chunks;
   const unsigned blocks = static_cast<unsigned>(n_tiles >= kXcdMapWindows ? chunks * (((n_tiles + 7) / 8) * 8) : ((chunks + 7) / 8) * 8 * n_tiles);
-  const size_t lds = static_cast<size_t>(a.rk_max_dwords) * 4 + static_cast<size_t>(kPodsPerUnit / 4) * kWindow * 4;
+  const size_t lds = static_cast<size_t>(a.rk_max_dwords) * 4 + static_cast<size_t>(kPodsPerUnit / 4) * kWindow * 4 + 64;  // (+ the histogram's last position)
   if (lds > 64 * 1024) return false;
   if (a.n_res <= 4) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<4, true, kFzFilter>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -639,6 +782,16 @@ bool launch_nrt_filter_fused(const NrtArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_nrt_fused<8, true, kFzFilter>), dim3(blocks), dim3(256), lds, s, a, static_cast<const uint32_t*>(nullptr), n_tiles);
   }
   return true;
+}
+
+// the per-window sorted quantities and the cells' ranks (k_nrt_window_sort): wsort [windows][4][2048] doubles, wrank [nodes][32] halfwords
+size_t nrt_window_sort_bytes(int64_t n_nodes, size_t* rank_bytes) {
+  *rank_bytes = static_cast<size_t>(n_nodes) * 32 * sizeof(uint16_t);
+  return static_cast<size_t>((n_nodes + kWindow - 1) / kWindow) * 4 * kWsCells * sizeof(double);
+}
+void launch_nrt_window_sort(const NrtArgs& a, double* wsort, uint16_t* wrank, hipStream_t s) {
+  const unsigned windows = static_cast<unsigned>((a.n_nodes + kWindow - 1) / kWindow);
+  hipLaunchKernelGGL(k_nrt_window_sort, dim3(windows * 4), dim3(1024), 0, s, a, wsort, wrank);
 }
 
 // words of scratch the packed Score items of `n_list` rows take (NrtArgs::fz_items)
@@ -662,7 +815,7 @@ bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
   // the kernel's block map: 8 XCDs x their windows per chunk, or 8 chunks (one per XCD) x all windows
   const unsigned blocks = static_cast<unsigned>(n_tiles >= kXcdMapWindows ? chunks * (((n_tiles + 7) / 8) * 8) : ((chunks + 7) / 8) * 8 * n_tiles);
   const size_t lds = static_cast<size_t>(a.rk_max_dwords) * 4 + static_cast<size_t>(kPodsPerUnit) * fz_pod_words<4>() * 4 +
-                     static_cast<size_t>(2) * (kPodsPerUnit / 4) * kWindow * 4;
+                     static_cast<size_t>(2) * (kPodsPerUnit / 4) * kWindow * 4 + 64;
   if (lds > 64 * 1024) return false;
   if (a.pk_tab_slot >= 0 && !(a.pk_tab_built && *a.pk_tab_built)) {  // the table of the packed float32 Score (kernels_nrt_fast.hip)
     launch_nrt_pk_tab_build(a, n_tiles, s);

@@ -220,8 +220,8 @@ int commit_with_filters(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, 
   e->last_commit_path = 2;
   struct LoopFlag {
     spx_engine* e;
-    explicit LoopFlag(spx_engine* x) : e(x) { e->in_commit_loop = true, e->tlp_amb_built = false, e->nrt_pk_tab_built = false; }  // (k_commit_apply advances d_tlp_missing and the zone tables)
-    ~LoopFlag() { e->in_commit_loop = false, e->tlp_amb_built = false, e->nrt_pk_tab_built = false; }
+    explicit LoopFlag(spx_engine* x) : e(x) { e->in_commit_loop = true, e->tlp_amb_built = false, e->nrt_pk_tab_built = e->nrt_wsort_built = false; }  // (k_commit_apply advances d_tlp_missing and the zone tables)
+    ~LoopFlag() { e->in_commit_loop = false, e->tlp_amb_built = false, e->nrt_pk_tab_built = e->nrt_wsort_built = false; }
   } loop_flag(e);
   // ---- save what the loop mutates
   struct Saved {

@@ -141,6 +141,8 @@ struct spx_engine {
   DevBuf d_nrt_rk_first;          // [chunks + 1] list position of each chunk's first row (a chunk holds up to 32)
   uint32_t nrt_rk_chunks = 0;
   bool nrt_rk_all_narrow = false;  // every chunk keeps four zones' counts per register (the only layout the fused sweep has)
+  DevBuf d_nrt_wsort, d_nrt_wrank;  // the fused walk's per-window sorted cell quantities and the cells' ranks (k_nrt_window_sort) ...
+  bool nrt_wsort_built = false;     // ... and whether they describe the zone tables in place (cleared with nrt_pk_tab_built: every writer of the zone quantities)
   DevBuf d_nrt_fz;  // fused Filter + Score sweep: the packed Score items of the listed rows (k_nrt_fused_pack)
   // what d_nrt_fz was packed from: generation of the pod records / slot table (bumped by their uploads), the row list's kind, the table
   // slot, the buffer — a sweep whose key matches skips the pack launch

@@ -74,7 +74,7 @@ int spx_destroy(spx_engine* e) {
                     &e->d_best, &e->d_stats, &e->d_decide, &e->d_lroc_nreq_c, &e->d_lroc_nreq_m, &e->d_lroc_nlim_c, &e->d_lroc_nlim_m,
                     &e->d_lroc_preq_c, &e->d_lroc_preq_m, &e->d_lroc_plim_c, &e->d_lroc_plim_m, &e->d_lroc_tab, &e->d_lroc_podf,
                     &e->d_pk_cap, &e->d_pk_util, &e->d_pk_valid, &e->d_pk_k1, &e->d_pk_k2, &e->d_pk_pod, &e->d_pk_min, &e->d_pk_max, &e->d_pk_rowc, &e->d_pk_tab, &e->d_pk_seg, &e->d_pk_segn,
-                    &e->d_nrt_uniq, &e->d_nrt_dups, &e->d_pk_uniq, &e->d_pk_dups, &e->d_delta, &e->d_nrt_lnrec, &e->d_net_pair_node2, &e->d_net_pair_max2, &e->d_nrt_rk, &e->d_nrt_rk_off, &e->d_nrt_rk_first, &e->d_nrt_fz};
+                    &e->d_nrt_uniq, &e->d_nrt_dups, &e->d_pk_uniq, &e->d_pk_dups, &e->d_delta, &e->d_nrt_lnrec, &e->d_net_pair_node2, &e->d_net_pair_max2, &e->d_nrt_rk, &e->d_nrt_rk_off, &e->d_nrt_rk_first, &e->d_nrt_fz, &e->d_nrt_wsort, &e->d_nrt_wrank};
   for (DevBuf* b : bufs)
     if (b->p && !b->external) (void)hipFree(b->p);
   for (int i = 0; i < SPX_NUM_PLUGINS; ++i) {
@@ -424,6 +424,18 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
           e->err = kept;
         }
       }
+    }
+    if (na.rk_stream && na.rk_all_narrow && e->nrt_n_res <= 4) {  // the walk's block start reads the windows' sorted quantities: (re)built when the zone tables changed
+      size_t rank_bytes = 0;
+      const size_t sort_bytes = spx::nrt_window_sort_bytes(e->n_nodes, &rank_bytes);
+      if (!e->d_nrt_wsort.p || e->d_nrt_wsort.bytes < sort_bytes || !e->d_nrt_wrank.p || e->d_nrt_wrank.bytes < rank_bytes) e->nrt_wsort_built = false;
+      if ((rc = ensure(e, e->d_nrt_wsort, sort_bytes)) || (rc = ensure(e, e->d_nrt_wrank, rank_bytes))) return rc;
+      if (!e->nrt_wsort_built) {
+        spx::launch_nrt_window_sort(na, static_cast<double*>(e->d_nrt_wsort.p), static_cast<uint16_t*>(e->d_nrt_wrank.p), e->stream);
+        e->nrt_wsort_built = true;
+      }
+      na.wsort = static_cast<const double*>(e->d_nrt_wsort.p);
+      na.wrank = static_cast<const uint16_t*>(e->d_nrt_wrank.p);
     }
     const bool ran_fused = spx::launch_nrt(na, e->stream);
     e->last_nrt_filter = ran_fused ? 3 : (na.rk_stream ? 2 : 1);

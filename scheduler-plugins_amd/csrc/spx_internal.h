@@ -317,6 +317,10 @@ struct NrtArgs {
   // the fused Filter + Score sweep (kernels_nrt_fused.hip): scratch for the packed Score items of the listed rows
   // (nrt_fused_item_words dwords); NULL = the Filter and Score launches
   uint32_t* fz_items;
+  // the fused walk's block start for <= 4 slots: per (window, slot) the window's 2 048 cell quantities sorted, per node the cells' ranks in
+  // them (k_nrt_window_sort; NULL = the per-cell list search)
+  const double* wsort;
+  const uint16_t* wrank;
   bool fz_pack;                  // the items must be (re)packed before the sweep: pods, slot table, row list or table slot changed
 };
 constexpr int64_t kNrtPkTabMaxK = (int64_t{1} << 17) - 1;   // request / unit above this: the float64 form
@@ -328,6 +332,8 @@ bool launch_nrt_filter_rank(const NrtArgs& a, int n_tiles, hipStream_t s);
 size_t nrt_fused_item_words(int n_res, int64_t n_list);
 bool launch_nrt_fused(const NrtArgs& a, hipStream_t s);
 bool launch_nrt_filter_fused(const NrtArgs& a, hipStream_t s);  // the same walk, Filter only
+size_t nrt_window_sort_bytes(int64_t n_nodes, size_t* rank_bytes);
+void launch_nrt_window_sort(const NrtArgs& a, double* wsort, uint16_t* wrank, hipStream_t s);
 void launch_nrt_pk_tab_build(const NrtArgs& a, int n_tiles, hipStream_t s);  // kernels_nrt_fast.hip: the packed Score's table of exceptions
 
 // combin.Combinations(8, k) for k = 1..8 as bitmasks over list positions, size-major then lexicographic — the order

@@ -308,7 +308,7 @@ int spx_update_nrt_nodes(spx_engine* e, const int64_t* idx, const spx_nrt_nodes_
   e->nrt_fast_nodes = e->nrt_fast_nodes && ok;
   e->nrt_big_nodes |= big;
   e->nrt_qty_nodes.merge(qty);
-  e->nrt_pk_tab_built = false;  // zone capacities changed
+  e->nrt_pk_tab_built = e->nrt_wsort_built = false;  // zone capacities changed
   if (cost_changed) {  // LeastNUMANodes' per-node tables are rebuilt when that strategy is next evaluated
     e->nrt_ln_built = false;
     e->nrt_ln_ok = e->nrt_ln_ok && ln_ok;
@@ -453,7 +453,7 @@ int spx_set_nrt_params(spx_engine* e, const spx_nrt_params* p) {
   if (p->strategy < SPX_NRT_MOST_ALLOCATED || p->strategy > SPX_NRT_LEAST_NUMA_NODES)
     return fail(e, SPX_ERR_ARG, "illegal scoring strategy found");  // score.go:137-139
   if (e->nrt_params.strategy != p->strategy) {  // the packed Score's table of exceptions and the fused walk's items are per strategy
-    e->nrt_pk_tab_built = false;
+    e->nrt_pk_tab_built = e->nrt_wsort_built = false;
     ++e->nrt_items_gen;
   }
   e->nrt_params.strategy = p->strategy;  // weights travel through the slot table (spx_flatten_nrt_slots)
@@ -561,7 +561,7 @@ int spx_upload_nrt_nodes(spx_engine* e, const spx_nrt_nodes_soa* t) {
     e->nrt_fast_nodes = ok.load();
     e->nrt_big_nodes = big_nodes.load();
     e->nrt_qty_nodes = qty_all;
-    e->nrt_pk_tab_built = false;
+    e->nrt_pk_tab_built = e->nrt_wsort_built = false;
     e->nrt_ln_ok = ln_ok.load();
     e->nrt_ln_built = false;  // built when that strategy is first evaluated (build_ln_tab): more host time than everything else in this call
     // window-local node order: inside each run of 256 nodes, group the nodes by the code path their flags select
