@@ -692,7 +692,7 @@ __global__ void k_decide_reduce(DecideArgs dec, int n_tiles, int64_t row_begin, 
 // LoadVariationRiskBalancing fast path (bit-exact by construction, same scheme as k_tlp_fast2).
 //
 // For a resource in its regular state the reference's score is affine in the pod's request between two clamps:
-//     score_r = (1 - (mu + sigma)/2) * 100 = A - clamp(B*(usedAvg + req), 0, 50),   A = 100 - 50*sigma, B = 50/cap
+//     score_r = (1 - (mu + sigma)/2) * 100 = A - 50 * clamp01(B*(usedAvg + req)),   A = 100 - 50*sigma, B = 1/cap  (round 6: the clamp is the fma's)
 // A, B and C = B*usedAvg are per-node constants (sigma includes math.Pow / margin, evaluated once per node in
 // float64); per cell the kernel evaluates two float32 fma + v_med3, min/max, rndne and a tie test.  Non-regular
 // states (metric absent, capacity <= 0) are encoded as A = B = C = 0 (score_r = 0), and "both resources valid"
@@ -737,7 +737,9 @@ __global__ void k_lvrb_prepare_fast(TrimaranArgs a, int64_t n_slots) {
         *fa = *fb = *fc = 0.0f;
         return;
       }
-      const double b = 50.0 / r.cap;
+      // round 6: slope and offset of t / 50 = (used + request) / cap, so that the sweep clamps with the fma's output modifier (0..1)
+      // instead of a v_med3_f32 (0..50) per resource; A - 50 * clamp01(t / 50) is the same real number
+      const double b = 1.0 / r.cap;
       *fa = static_cast<float>(100.0 - 50.0 * r.sigma);
       *fb = static_cast<float>(b);
       *fc = static_cast<float>(b * r.used_avg);
@@ -841,7 +843,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
   // resources are valid (the reference takes the min of the two scores then) and +1 otherwise (max):
   //   min(xc, xm) = -max(-xc, -xm), so with y_r = s*(A_r - clamp_r) the cell is x = s*max(y_c, y_m) and rint(x) = s*rint(y)
   F32x2 kb[NPL], kc[NPL], ksa[NPL];
-  float ks[NPL];
+  float ks[NPL], k50[NPL];  // s, and -50 s (the clamp is 0..1 since round 6: y_r = s A_r - 50 s clamp01(B'_r q + C'_r))
   if constexpr (A) {
 #pragma unroll
     for (int j = 0; j < NPL / 4; ++j) alloc_w[j] = active ? reinterpret_cast<const uint32_t*>(a.alloc_norm + node0)[j] : 0u;
@@ -856,6 +858,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
       kc[j] = F32x2{v0.z, v0.w};
       ksa[j] = F32x2{v1.x, v1.y};
       ks[j] = v1.z;
+      k50[j] = -50.0f * v1.z;
     }
   }
   constexpr float kHalf = 0.5f - kTolLv;  // (no early exit: see k_tlp_fast2)
@@ -873,9 +876,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
     uint32_t w[NPL / 4];
     // one cell: y = s*x (see above), its rounding, and the distance to the rounding tie
     auto cell = [&](int i, const F32x2& req, float* ry) -> float {
-      const F32x2 t = __builtin_elementwise_fma(kb[i], req, kc[i]);
-      const F32x2 cl{__builtin_amdgcn_fmed3f(t.x, 0.0f, 50.0f), __builtin_amdgcn_fmed3f(t.y, 0.0f, 50.0f)};
-      const F32x2 y2 = __builtin_elementwise_fma(F32x2{-ks[i], -ks[i]}, cl, ksa[i]);
+      const F32x2 cl{__builtin_amdgcn_fmed3f(__builtin_fmaf(kb[i].x, req.x, kc[i].x), 0.0f, 1.0f),   // v_fma_f32 .. clamp, full rate
+                     __builtin_amdgcn_fmed3f(__builtin_fmaf(kb[i].y, req.y, kc[i].y), 0.0f, 1.0f)};
+      const F32x2 y2 = __builtin_elementwise_fma(F32x2{k50[i], k50[i]}, cl, ksa[i]);
       const float y = __builtin_fmaxf(y2.x, y2.y);
       *ry = __builtin_rintf(y);
       return __builtin_fabsf(y - *ry);
@@ -890,9 +893,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int i = j * 4 + q;
-          const F32x2 t = __builtin_elementwise_fma(kb[i], req2, kc[i]);
-          const F32x2 cl{__builtin_amdgcn_fmed3f(t.x, 0.0f, 50.0f), __builtin_amdgcn_fmed3f(t.y, 0.0f, 50.0f)};
-          const F32x2 y2 = __builtin_elementwise_fma(F32x2{-ks[i], -ks[i]}, cl, ksa[i]);
+          const F32x2 cl{__builtin_amdgcn_fmed3f(__builtin_fmaf(kb[i].x, req2.x, kc[i].x), 0.0f, 1.0f),
+                         __builtin_amdgcn_fmed3f(__builtin_fmaf(kb[i].y, req2.y, kc[i].y), 0.0f, 1.0f)};
+          const F32x2 y2 = __builtin_elementwise_fma(F32x2{k50[i], k50[i]}, cl, ksa[i]);
           acc = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(y2.x, y2.y) * ks[i], q, acc);
         }
         w[j] = acc;

@@ -150,11 +150,12 @@ def test_lvrb_float32_formula_never_disagrees_unflagged():
     want = np.clip(np.floor(xr + 0.5), 0, 255).astype(np.int64)
 
     def fast(cap, used_avg, sigma, req):
-        bq = 50.0 / cap
+        # round 6: slope and offset of t / 50, the clamp 0..1 is the fma's output modifier, then one fma with -50 (k_lvrb_prepare_fast / k_lvrb_fast)
+        bq = 1.0 / cap
         fa, fb, fc = _f32(100.0 - 50.0 * sigma), _f32(bq), _f32(bq * used_avg)
         tt = _f32(fb.astype(np.float64) * _f32(req).astype(np.float64) + fc.astype(np.float64))
-        cl = np.clip(tt, np.float32(0), np.float32(50))
-        return _f32(cl.astype(np.float64) * -1.0 * -1.0 * -1.0 + fa.astype(np.float64))  # y = s*(A - clamp) with s = -1 folded below
+        cl = np.clip(tt, np.float32(0), np.float32(1))
+        return _f32(cl.astype(np.float64) * -50.0 + fa.astype(np.float64))  # y = s*(A - 50 clamp) with s = -1 folded below
 
     # s = -1 (both valid): y_r = -(A_r - clamp_r); x = -max(y_c, y_m)
     yc = -fast(cap_c, ua_c, sg_c, req_c)
