@@ -18,14 +18,23 @@
 // column is in [0, 2^52) (checked by the engine at upload, LrocArgs::exact53) the sums and differences are exact in
 // float64 and the kernel never leaves the float64 pipe; otherwise the int64 form runs, operation for operation.
 //
-// k_lroc_fast (the default when exact53 holds) is the cheap formulation of the same sweep, in the manner of the TLP / LVRB
-// kernels: numerator and denominator of riskLimit are still formed exactly in float64 — with the per-node differences
-//   A = nodeLimit - capacity,  D = nodeLimit - nodeRequest   and per pod   d = podLimit - podRequest
-// they are  over = A + podLimit  and  den = limit - min(request, cap) = max(D + d, over)  — but the quotient, the weighted
-// sum and the final 100*(1 - max) run in float32 (v_rcp_f32, packed fma).  The float32 value s differs from the
-// reference's float64 value by less than 6e-5 (error budget in DESIGN.md 3.8; tests/test_exactness_arguments.py), so
-// whenever s is farther than kBand from a rounding boundary k + 0.5 the rounded score is provably the reference's; the
-// remaining cells (~3e-4 of those with a non-trivial score) are recomputed with the float64 form from the node table.
+// k_lroc_fast (round 6; the default when its preconditions hold: every column in [0, 2^47), no limit below its request) is the
+// float32 formulation of the same sweep.  With the per-node differences
+//   A = nodeLimit - capacity,  D = nodeLimit - nodeRequest   and per pod   d = podLimit - podRequest   (D, d >= 0)
+// the reference's  over / (limit - min(request, cap))  for over = A + podLimit > 0, else 0, is  clamp(over / (D + d), 0, 1):
+//   * over: A and podLimit each as the sum of two float32 (exact below 2^47); high parts, low parts, then both — three additions,
+//     within 3 ulp of the exact sum even when it cancels (the high sum is exact whenever it cancels, the low sum always);
+//   * both resources' quotients from ONE v_rcp_f32 of the product of the two denominators (D is held at >= 2^-30: a zero sum of
+//     whole numbers then yields quotient 1 or 0 through the clamp, never NaN);
+//   * the two resources ride the two halves of packed float32 operations (v_pk_add / v_pk_mul ... clamp / v_pk_fma);
+//   * 100 * (1 - max risk) is formed in units of 2^-16 by one fma whose sum with 2^23 rounds it to a whole number: the mantissa
+//     reads score << 16 | fraction, and "fraction within 8 units of 1/2" is one AND and one comparison whose lane mask is the
+//     answer (no per-lane flag).
+// The float32 value differs from the reference's float64 value by less than 8.7e-5 (error budget in DESIGN.md 3.8;
+// tests/test_exactness_arguments.py replays it with the reciprocal pushed one ulp either way), so a cell farther than 8 units
+// (1.22e-4) from a rounding boundary k + 0.5 has provably the reference's score; the remaining CELLS (~2.4e-4 of those with a
+// non-trivial score) — not their whole lanes: a lane's eight cells cost eight dependent trips to the node table, which was a
+// third of the round-5 kernel's time — are recomputed with the float64 form from the node table.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -43,7 +52,7 @@ constexpr int kNpl = 4;  // nodes per lane: one dword of scores per pod row
 constexpr int kNplFast = 8;           // k_lroc_fast: two dwords per lane and row
 constexpr int kTabCols = kLrocTabCols;
 constexpr double kNoOver = -1e30;     // "limit - capacity" of a node that must not contribute a riskLimit
-constexpr float kBand = 1.5e-4f;      // ambiguity band around k + 0.5 (float32 error of s < 6e-5)
+constexpr float kBand = 1.5e-4f;      // upper limit of the ambiguity band around k + 0.5 (float32 error of the score < 8.7e-5)
 typedef float F32x2 __attribute__((ext_vector_type(2)));
 
 template <typename T>
@@ -205,7 +214,7 @@ __device__ __forceinline__ uint32_t exact_cell(const LrocArgs& a, int64_t n, int
   return score_byte(has, rc, rm);
 }
 
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lroc_fast(LrocArgs a, int n_tiles) {
+__global__ __launch_bounds__(kWave* kWavesPerBlock, 4) void k_lroc_fast(LrocArgs a, int n_tiles) {
   constexpr int NPL = kNplFast;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -218,61 +227,87 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lroc_fast(LrocArgs a,
   const int64_t node0 = (static_cast<int64_t>(tile) * kWave + lane) * NPL;
   if (node0 >= a.row_stride) return;  // row_stride is a multiple of 16; no cross-lane operation below
 
-  double A_c[NPL], D_c[NPL], A_m[NPL], D_m[NPL];
-  F32x2 kl[NPL];
-  float klmax[NPL];
+  // per node: A as the sum of two float32 (exact: |A| < 2^47; its sum with the pod's limit cancels), D as the float32 it is used as —
+  // never below 2^-30, so that the reciprocal of D + d is finite: a sum of whole numbers that is 0 stands for "any excess is the whole
+  // denominator" (quotient 1)
+  // (cpu in .x, memory in .y: the two resources' chains run as packed float32 operations)
+  F32x2 Ah[NPL], Al[NPL], D[NPL], kl[NPL];
   const int64_t s = a.row_stride;
 #pragma unroll
   for (int j = 0; j < NPL; ++j) {
     const double* tab = a.node_tab + node0 + j;
-    A_c[j] = tab[8 * s], D_c[j] = tab[9 * s], A_m[j] = tab[10 * s], D_m[j] = tab[11 * s];
+    const double ac = tab[8 * s], am = tab[10 * s];
+    Ah[j] = F32x2{static_cast<float>(ac), static_cast<float>(am)};
+    Al[j] = F32x2{static_cast<float>(ac - static_cast<double>(Ah[j].x)), static_cast<float>(am - static_cast<double>(Ah[j].y))};
+    D[j] = F32x2{__builtin_fmaxf(static_cast<float>(tab[9 * s]), 0x1p-30f), __builtin_fmaxf(static_cast<float>(tab[11 * s]), 0x1p-30f)};
     kl[j] = F32x2{static_cast<float>(tab[12 * s]), static_cast<float>(tab[13 * s])};
-    klmax[j] = __builtin_fmaxf(kl[j].x, kl[j].y);
   }
   const F32x2 w2{static_cast<float>(a.w_cpu), static_cast<float>(a.w_mem)};
   const int64_t np = a.n_pods_total;
-  constexpr float kHalf = 0.5f - kBand;
+  constexpr float kMagic = 8388608.0f;   // 2^23: a sum in [2^23, 2^24) is a whole number, and the mantissa bits are that number - 2^23
+  constexpr float kScale = 6553600.0f;   // 100 * 2^16
+  constexpr float kBandUnits = 8.0f;     // the band around k + 1/2 in units of 2^-16: 1.22e-4 (float32 error of the score < 8.7e-5)
+  static_assert(kBandUnits * 0x1p-16f < kBand && kBandUnits == 8.0f, "the mask below clears log2(2 * kBandUnits) bits");
 
   unsigned redone = 0;
+  // per pod (host-prepared, one 32-byte scalar load): podLimit as two float32 and podLimit - podRequest for cpu, memory; the seventh
+  // word marks a pod without requests or limits (MinNodeScore, lowriskovercommitment.go:124-128).  The next pod's is asked for
+  // before this one's cells.
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  const f32x8* recs = reinterpret_cast<const f32x8*>(a.pod_f32);
+  f32x8 next = uload(recs + pod0);
   for (int64_t pod = pod0; pod < pod1; ++pod) {
-    // per pod (host-prepared float64, scalar loads): podLimit and podLimit - podRequest for cpu, memory; NaN marks a
-    // pod without requests or limits (MinNodeScore, lowriskovercommitment.go:124-128)
-    const double plc = uload(a.pod_f64 + pod), dc = uload(a.pod_f64 + np + pod);
-    const double plm = uload(a.pod_f64 + 2 * np + pod), dm = uload(a.pod_f64 + 3 * np + pod);
+    const f32x8 rec = next;
+    next = uload(recs + (pod + 1 < pod1 ? pod + 1 : pod));
+    const F32x2 plh{rec[0], rec[1]}, pll{rec[2], rec[3]}, df{rec[4], rec[5]};
     uint32_t w[NPL / 4] = {};
-    if (plc == plc) {  // wave-uniform
-      float worst = 0.0f;
+    if (rec[6] == 0.0f) {  // wave-uniform
+      unsigned long long near[NPL];  // per cell: the lanes whose value is within the band of a rounding boundary
 #pragma unroll
       for (int j = 0; j < NPL / 4; ++j) {
-        uint32_t acc = 0;
+        uint32_t kb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int i = j * 4 + q;
-          const double over_c = A_c[i] + plc, over_m = A_m[i] + plm;        // limit - capacity, exact
-          const double den_c = fmax(D_c[i] + dc, over_c), den_m = fmax(D_m[i] + dm, over_m);  // limit - request, exact
-          const F32x2 ov{static_cast<float>(over_c), static_cast<float>(over_m)};
-          const F32x2 rc{__builtin_amdgcn_rcpf(static_cast<float>(den_c)), __builtin_amdgcn_rcpf(static_cast<float>(den_m))};
-          // w * max(over/den, 0) + kl  ==  max(fma(w, over/den, kl), kl): a negative, infinite or NaN quotient (over <= 0,
-          // possibly with den == 0) is absorbed by the max, which returns its non-NaN operand
-          const F32x2 t2 = __builtin_elementwise_fma(w2, ov * rc, kl[i]);
-          const float m = __builtin_fmaxf(__builtin_fmaxf(t2.x, t2.y), klmax[i]);
-          const float sc = __builtin_fmaf(-100.0f, m, 100.0f);            // 100 * (1 - max risk)
-          const float rr = __builtin_rintf(sc);
-          worst = __builtin_fmaxf(worst, __builtin_fabsf(sc - rr));
-          acc = __builtin_amdgcn_cvt_pk_u8_f32(rr, q, acc);
+          // riskLimit = over / max(D + d, over) for over > 0, else 0  ==  clamp(over / (D + d), 0, 1): over exact, then float32
+          // (high parts, low parts, then both: the high sum is exact whenever it cancels, the low sum always — within 3 ulp of A + limit)
+          const F32x2 ov = (Ah[i] + plh) + (Al[i] + pll);
+          const F32x2 dd = D[i] + df;
+          const float rr = __builtin_amdgcn_rcpf(dd.x * dd.y);  // one reciprocal for both quotients
+          const F32x2 x = ov * __builtin_shufflevector(dd, dd, 1, 0);
+          F32x2 qq, r2;
+          r2.x = rr;  // (.y is not read: op_sel_hi takes the low half for both products)
+          // (inline: the compiler has no packed clamp pattern; s_nop: the wait state a transcendental's consumer needs, which the
+          // hazard pass cannot add inside an asm statement)
+          asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] clamp" : "=v"(qq) : "v"(x), "v"(r2));  // both quotients, clamped to [0, 1] (NaN cannot occur: rr and x are finite or x is an infinity)
+          const F32x2 t2 = __builtin_elementwise_fma(w2, qq, kl[i]);
+          const float t_c = t2.x, t_m = t2.y;
+          const float m = __builtin_amdgcn_fmed3f(__builtin_fmaxf(t_c, t_m), 0.0f, 1.0f);  // totalRisk's clamp (:252), after the max
+          // 100 * (1 - max risk) in units of 2^-16, + 1/2 + the band, rounded to a whole number by the sum with 2^23 (the fma rounds once):
+          // the mantissa then reads  score << 16 | fraction,  and a fraction below 2 * kBandUnits means "within the band of k + 1/2"
+          const float k = __builtin_fmaf(m, -kScale, kMagic + kScale + 32768.0f + kBandUnits);
+          kb[q] = __float_as_uint(k);
+          near[i] = __ballot((kb[q] & (0xffffu & ~(2u * static_cast<uint32_t>(kBandUnits) - 1u))) == 0u);  // (the comparison's lane mask: no vector work)
         }
-        w[j] = acc;
+        const uint32_t lo = __builtin_amdgcn_perm(kb[1], kb[0], 0x0c0c0602u), hi = __builtin_amdgcn_perm(kb[3], kb[2], 0x0c0c0602u);  // the scores: byte 2
+        w[j] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
       }
-      if (__builtin_expect(!(worst < kHalf), 0)) {  // rare: some cell of this lane is within the band of a rounding boundary
+      unsigned long long any = 0;
 #pragma unroll
-        for (int j = 0; j < NPL / 4; ++j) {
-#pragma unroll 1
-          for (int q = 0; q < 4; ++q) {  // not unrolled: the slow path must not cost the sweep its registers
-            const uint32_t b = exact_cell(a, node0 + j * 4 + q, pod);
-            w[j] = (w[j] & ~(0xffu << (8 * q))) | (b << (8 * q));
-          }
+      for (int i = 0; i < NPL; ++i) any |= near[i];
+      if (__builtin_expect(any != 0ull, 0)) {  // rare (uniform): some cell of some lane is within the band — those cells in float64
+        uint32_t amb = 0;  // this lane's cells: cell i -> bit NPL - 1 - i
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) amb |= ((near[i] >> lane) & 1ull) ? 1u << (NPL - 1 - i) : 0u;
+        while (amb != 0u) {
+          const int i = NPL - 1 - (31 - __builtin_clz(amb));  // (per lane)
+          amb &= ~(1u << (NPL - 1 - i));
+          const uint32_t b = exact_cell(a, node0 + i, pod);
+          const uint32_t keep = ~(0xffu << (8 * (i & 3))), put = b << (8 * (i & 3));
+#pragma unroll
+          for (int j = 0; j < NPL / 4; ++j) w[j] = (i >> 2) == j ? (w[j] & keep) | put : w[j];
+          ++redone;  // spx_fetch_stats: cells re-evaluated
         }
-        ++redone;  // spx_fetch_stats: the whole lane (NPL cells) is redone, not only the cells inside the band
       }
     }
     uint32_t* dst = reinterpret_cast<uint32_t*>(a.out_score + pod * a.row_stride + node0);
@@ -281,8 +316,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lroc_fast(LrocArgs a,
   }
   // one atomic per lane that met a band, each lane on its own counter line (lanes past the row have left: no wave reduction)
   if (redone && a.stats) {
-    const int64_t cells = min<int64_t>(NPL, max<int64_t>(a.n_nodes - node0, 0));
-    atomicAdd(a.stats + (SPX_PLUGIN_LROC * kStatSlots + lane) * kStatStride, static_cast<unsigned long long>(redone) * static_cast<unsigned long long>(cells));
+    atomicAdd(a.stats + (SPX_PLUGIN_LROC * kStatSlots + lane) * kStatStride, static_cast<unsigned long long>(redone));
   }
 }
 
@@ -301,7 +335,7 @@ void launch_lroc(const LrocArgs& a, hipStream_t s) {
   const int64_t chunks = (rows + kPodsPerChunk - 1) / kPodsPerChunk;
   const int64_t units = chunks * n_tiles;
   const unsigned blocks = static_cast<unsigned>((units + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (a.exact53 && a.pod_f64 != nullptr) {
+  if (a.exact53 && a.pod_f32 != nullptr) {
     const int tn = kWave * kNplFast;
     const int nt = static_cast<int>((a.row_stride + tn - 1) / tn);
     const unsigned nb = static_cast<unsigned>((chunks * nt + kWavesPerBlock - 1) / kWavesPerBlock);

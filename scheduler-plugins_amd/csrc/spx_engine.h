@@ -96,6 +96,8 @@ struct spx_engine {
   DevBuf d_lroc_nreq_c, d_lroc_nreq_m, d_lroc_nlim_c, d_lroc_nlim_m, d_lroc_preq_c, d_lroc_preq_m, d_lroc_plim_c, d_lroc_plim_m, d_lroc_tab, d_lroc_podf;
   bool lroc_nodes = false, lroc_pods = false, lroc_tab_ready = false;
   bool lroc_nodes_exact = false, lroc_pods_exact = false, lv_alloc_exact = false;  // all values in [0, 2^52)
+  // the float32 sweep's preconditions (kernels_lroc.hip): all values in [0, 2^47), limits not below requests
+  bool lroc_nodes_f32 = false, lroc_pods_f32 = false, lv_alloc_f32 = false;
 
   // Peaks
   DevBuf d_pk_cap, d_pk_util, d_pk_valid, d_pk_k1, d_pk_k2, d_pk_pod, d_pk_min, d_pk_max, d_pk_rowc, d_pk_tab, d_pk_seg, d_pk_segn;
@@ -278,6 +280,17 @@ bool all_below_2p52(const int64_t* v, size_t n) {
   for (size_t i = 0; i < n; ++i) acc |= static_cast<uint64_t>(v[i]);
   return (acc >> 52) == 0;
 }
+// every value in [0, 2^47): such a value, and the difference of two, is the sum of two float32 exactly (k_lroc_fast)
+bool all_below_2p47(const int64_t* v, size_t n) {
+  uint64_t acc = 0;
+  for (size_t i = 0; i < n; ++i) acc |= static_cast<uint64_t>(v[i]);
+  return (acc >> 47) == 0;
+}
+bool none_below(const int64_t* hi, const int64_t* lo, size_t n) {
+  bool ok = true;
+  for (size_t i = 0; i < n; ++i) ok = ok && hi[i] >= lo[i];
+  return ok;
+}
 
 int set_nodes(spx_engine* e, int64_t n) {
   if (n <= 0) return fail(e, SPX_ERR_ARG, "n_nodes must be positive");
@@ -384,6 +397,10 @@ uint32_t launch_opts(const spx_engine* e) {
 bool lroc_exact53(const spx_engine* e) {
   return e->lroc_nodes_exact && e->lroc_pods_exact && e->lv_alloc_exact && !forced_reference(e, SPX_PLUGIN_LROC);
 }
+// the float32 sweep (k_lroc_fast) may run: exact columns, below 2^47, every limit at least its request (SetMaxLimits, resourcestats.go:227-231)
+bool lroc_f32_ok(const spx_engine* e) {
+  return lroc_exact53(e) && e->lroc_nodes_f32 && e->lroc_pods_f32 && e->lv_alloc_f32 && !e->option[SPX_OPT_LROC_FLOAT64];
+}
 
 void fill_lroc(const spx_engine* e, spx::LrocArgs& a) {
   a.n_nodes = e->n_nodes;
@@ -408,7 +425,7 @@ void fill_lroc(const spx_engine* e, spx::LrocArgs& a) {
   a.w_mem = e->lroc.risk_limit_weight_mem;
   a.node_tab = static_cast<double*>(e->d_lroc_tab.p);
   a.exact53 = lroc_exact53(e) ? 1 : 0;
-  a.pod_f64 = (a.exact53 && !e->option[SPX_OPT_LROC_FLOAT64]) ? static_cast<const double*>(e->d_lroc_podf.p) : nullptr;
+  a.pod_f32 = lroc_f32_ok(e) ? static_cast<const float*>(e->d_lroc_podf.p) : nullptr;
   a.n_pods_total = e->n_pods;
   a.stats = static_cast<unsigned long long*>(e->d_stats.p);
 }

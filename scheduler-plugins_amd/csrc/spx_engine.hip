@@ -576,7 +576,7 @@ int spx_kernel_path(const spx_engine* e, int plugin) {
     return (e->nrt_fast_slots && e->nrt_fast_nodes && e->nrt_fast_pods && !forced_reference(e, SPX_PLUGIN_NRT) &&
             (e->nrt_params.strategy != SPX_NRT_LEAST_NUMA_NODES || e->nrt_ln_ok)) ? 1 : 0;
   if (plugin == SPX_PLUGIN_NETOVERHEAD) return (e->net_nodes && e->net_class16 && e->net_n_classes > 0 && !forced_reference(e, SPX_PLUGIN_NETOVERHEAD)) ? 1 : 0;
-  if (plugin == SPX_PLUGIN_LROC) return (lroc_exact53(e) && !e->option[SPX_OPT_LROC_FLOAT64]) ? 1 : 0;
+  if (plugin == SPX_PLUGIN_LROC) return lroc_f32_ok(e) ? 1 : 0;
   if (plugin == SPX_PLUGIN_TLP) return (e->tlp.target_utilization >= 1 && e->tlp.target_utilization <= 99 && !(launch_opts(e) & spx::kOptTrimaranExact)) ? 1 : 0;
   return 0;
 }

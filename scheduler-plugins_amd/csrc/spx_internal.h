@@ -192,9 +192,10 @@ struct LrocArgs {
   //   2..7: float64 images of requested / limits / capacity for cpu, then memory;
   //   8..13: the fast form's constants (limits - capacity, limits - requested per resource; the two riskLoad terms as float32)
   double* node_tab;
-  // fast form only: [4][n_pods_total] float64 = pod limit and (limit - request) for cpu, then memory, prepared by the engine at
-  // upload when the pod columns are exact; NaN in the first column marks a pod without requests and limits.  NULL = not available
-  const double* pod_f64;
+  // float32 sweep only: [n_pods_total][8] float32 = pod limit as the sum of two float32 (high parts: cpu, memory; low parts: cpu, memory), limit - request
+  // (cpu, memory), 1 for a pod without requests and limits, 0 — prepared by the engine at upload when its preconditions hold
+  // (columns below 2^47, limits not below requests).  NULL = not available: the float64 / int64 sweep runs
+  const float* pod_f32;
   int64_t n_pods_total;
   int32_t exact53;      // every integer the sweep touches is in [0, 2^52): float64 sums and differences are exact
   unsigned long long* stats;  // as TrimaranArgs::stats

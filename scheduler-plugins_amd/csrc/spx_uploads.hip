@@ -38,6 +38,7 @@ int spx_upload_trimaran_nodes(spx_engine* e, const spx_trimaran_nodes_soa* t) {
   if ((rc = upload(e, e->d_lv_mstd, t->lv_mem_std, n * 8))) return rc;
   if ((rc = upload(e, e->d_lv_flags, t->lv_flags, n))) return rc;
   e->lv_alloc_exact = all_below_2p52(t->lv_alloc_cpu_milli, n) && all_below_2p52(t->lv_alloc_mem, n);
+  e->lv_alloc_f32 = all_below_2p47(t->lv_alloc_cpu_milli, n) && all_below_2p47(t->lv_alloc_mem, n);
   e->lroc_tab_ready = false;
   e->tri_nodes = true;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
@@ -125,6 +126,7 @@ int spx_update_trimaran_nodes(spx_engine* e, const int64_t* idx, const spx_trima
   SPX_HIP(e, hipGetLastError());
   // the aggregate property stays conservative: rows may only take it away (a full upload re-establishes it)
   e->lv_alloc_exact = e->lv_alloc_exact && all_below_2p52(t->lv_alloc_cpu_milli, m) && all_below_2p52(t->lv_alloc_mem, m);
+  e->lv_alloc_f32 = e->lv_alloc_f32 && all_below_2p47(t->lv_alloc_cpu_milli, m) && all_below_2p47(t->lv_alloc_mem, m);
   e->lroc_tab_ready = false;
   e->evaluated = 0;  // every table computed from the old rows is stale
   e->best_valid = false;
@@ -344,6 +346,8 @@ int spx_upload_lroc_nodes(spx_engine* e, const spx_lroc_nodes_soa* t) {
   if ((rc = upload(e, e->d_lroc_nlim_m, t->lim_mem, n * 8))) return rc;
   e->lroc_nodes_exact = all_below_2p52(t->req_cpu_milli, n) && all_below_2p52(t->req_mem, n) && all_below_2p52(t->lim_cpu_milli, n) &&
                         all_below_2p52(t->lim_mem, n);
+  e->lroc_nodes_f32 = all_below_2p47(t->req_cpu_milli, n) && all_below_2p47(t->req_mem, n) && all_below_2p47(t->lim_cpu_milli, n) && all_below_2p47(t->lim_mem, n) &&
+                      none_below(t->lim_cpu_milli, t->req_cpu_milli, n) && none_below(t->lim_mem, t->req_mem, n);
   e->lroc_nodes = true;
   e->lroc_tab_ready = false;
   SPX_HIP(e, hipStreamSynchronize(e->stream));
@@ -362,16 +366,23 @@ int spx_upload_lroc_pods(spx_engine* e, const spx_lroc_pods_soa* t) {
   if ((rc = upload(e, e->d_lroc_plim_m, t->lim_mem, p * 8))) return rc;
   e->lroc_pods_exact = all_below_2p52(t->req_cpu_milli, p) && all_below_2p52(t->req_mem, p) && all_below_2p52(t->lim_cpu_milli, p) &&
                        all_below_2p52(t->lim_mem, p);
-  if (e->lroc_pods_exact) {  // float64 pod records of the fast sweep: limit and limit - request per resource (exact below 2^52)
-    std::vector<double> f(4 * p);
+  e->lroc_pods_f32 = e->lroc_pods_exact && all_below_2p47(t->req_cpu_milli, p) && all_below_2p47(t->req_mem, p) && all_below_2p47(t->lim_cpu_milli, p) &&
+                     all_below_2p47(t->lim_mem, p) && none_below(t->lim_cpu_milli, t->req_cpu_milli, p) && none_below(t->lim_mem, t->req_mem, p);
+  if (e->lroc_pods_f32) {
+    // the float32 sweep's pod records, 32 bytes each (one scalar load): the limits' high float32 parts (cpu, memory), their low parts (exact below
+    // 2^47), limit - request as the float32 it is used as, and a marker for the pod without requests and limits
+    std::vector<float> f(8 * p);
     for (size_t i = 0; i < p; ++i) {
+      float* r = &f[8 * i];
       const bool none = t->req_cpu_milli[i] == 0 && t->req_mem[i] == 0 && t->lim_cpu_milli[i] == 0 && t->lim_mem[i] == 0;
-      f[i] = none ? std::nan("") : static_cast<double>(t->lim_cpu_milli[i]);
-      f[p + i] = static_cast<double>(t->lim_cpu_milli[i] - t->req_cpu_milli[i]);
-      f[2 * p + i] = static_cast<double>(t->lim_mem[i]);
-      f[3 * p + i] = static_cast<double>(t->lim_mem[i] - t->req_mem[i]);
+      const double lc = static_cast<double>(t->lim_cpu_milli[i]), lm = static_cast<double>(t->lim_mem[i]);
+      r[0] = static_cast<float>(lc), r[2] = static_cast<float>(lc - static_cast<double>(r[0]));
+      r[1] = static_cast<float>(lm), r[3] = static_cast<float>(lm - static_cast<double>(r[1]));
+      r[4] = static_cast<float>(static_cast<double>(t->lim_cpu_milli[i] - t->req_cpu_milli[i]));
+      r[5] = static_cast<float>(static_cast<double>(t->lim_mem[i] - t->req_mem[i]));
+      r[6] = none ? 1.0f : 0.0f, r[7] = 0.0f;
     }
-    if ((rc = upload(e, e->d_lroc_podf, f.data(), f.size() * sizeof(double)))) return rc;
+    if ((rc = upload(e, e->d_lroc_podf, f.data(), f.size() * sizeof(float)))) return rc;
     SPX_HIP(e, hipStreamSynchronize(e->stream));  // f goes out of scope
   }
   e->lroc_pods = true;

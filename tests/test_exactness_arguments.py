@@ -243,13 +243,15 @@ def test_commit_loop_incremental_constant_tracks_the_float64_value():
 
 
 def test_lroc_float32_quotient_is_exact_outside_the_ambiguity_band():
-    """k_lroc_fast (kernels_lroc.hip): over = A + podLimit and den = max(D + d, over) are formed exactly in float64; the
-    quotient, w*q + (1-w)*riskLoad and 100*(1 - max) run in float32 with a 1-ulp reciprocal.  Claim: the float32 value s is
-    within 6e-5 of the reference's float64 value, so a cell whose s is farther than 1.5e-4 from every k + 0.5 rounds to the
-    reference's score.  The reciprocal is emulated pessimistically: correctly rounded, then pushed one ulp either way."""
+    """k_lroc_fast (kernels_lroc.hip), round 6: riskLimit = clamp(over / (D + d), 0, 1) with over = A + podLimit formed from the
+    two-float32 images of A and podLimit (exact below 2^47; high parts, low parts, then both), D + d in float32, ONE 1-ulp
+    reciprocal of the two denominators' product for both resources, w*q + (1-w)*riskLoad as one fma, and 100*(1 - max) in units
+    of 2^-16 rounded by the sum with 2^23.  Claim: that value is within 8.7e-5 of the reference's float64 value, so a cell
+    whose fraction is farther than 8 units (1.22e-4) from k + 0.5 rounds to the reference's score.  The reciprocal is emulated
+    pessimistically: correctly rounded, then pushed one ulp either way."""
     rng = np.random.default_rng(12)
     n = 400_000
-    f32 = np.float32
+    f32, f64 = np.float32, np.float64
     cap_c = rng.choice(np.array([8, 16, 64, 128], dtype=np.int64), n) * 1000 - rng.integers(500, 2001, n)
     cap_m = rng.choice(np.array([32, 128, 512, 1024], dtype=np.int64), n) * (1 << 30)
     nreq_c = (rng.uniform(0, 1.5, n) * cap_c).astype(np.int64)
@@ -260,44 +262,66 @@ def test_lroc_float32_quotient_is_exact_outside_the_ambiguity_band():
     plim_c = preq_c + rng.integers(0, 9000, n) * (rng.random(n) < 0.5)
     preq_m = rng.integers(0, 64 << 30, n)
     plim_m = preq_m + rng.integers(0, 32 << 30, n) * (rng.random(n) < 0.5)
-    # adversarial slice: limits that exceed the capacity by a hair (tiny numerators) and denominators of 1
+    # adversarial slices: limits that exceed the capacity by a hair (tiny numerators: the sum A + podLimit cancels), denominators of
+    # 0 and 1 (Guaranteed pods on nodes of Guaranteed pods), and the same for memory with odd byte counts near 2^46
     k = n // 20
     nlim_c[:k] = cap_c[:k] - plim_c[:k] + rng.integers(-3, 4, k)
     nreq_c[:k] = np.minimum(nreq_c[:k], nlim_c[:k].clip(0))
     nlim_c[:k] = np.maximum(nlim_c[:k], nreq_c[:k])
+    cap_m[k:2 * k] = (1 << 46) + rng.integers(-(1 << 30), 1 << 30, k) * 2 + 1
+    plim_m[k:2 * k] = rng.integers(1, 1 << 36, k) * 2 + 1
+    preq_m[k:2 * k] = plim_m[k:2 * k] - rng.integers(0, 3, k)
+    nlim_m[k:2 * k] = cap_m[k:2 * k] - plim_m[k:2 * k] + rng.integers(-3, 4, k)
+    nreq_m[k:2 * k] = nlim_m[k:2 * k] - rng.integers(0, 3, k)
     load_c = rng.choice([0.0, 1.0, 0.5], n, p=[0.3, 0.2, 0.5]) * np.where(rng.random(n) < 0.5, 1.0, rng.random(n))
     load_m = rng.choice([0.0, 1.0, 0.5], n, p=[0.3, 0.2, 0.5]) * np.where(rng.random(n) < 0.5, 1.0, rng.random(n))
+
+    def two(v):  # an integer column as the sum of two float32
+        hi = v.astype(f64).astype(f32)
+        lo = (v.astype(f64) - hi.astype(f64)).astype(f32)
+        assert np.array_equal(hi.astype(f64) + lo.astype(f64), v.astype(f64))  # below 2^47: exact
+        return hi, lo
+
     for w_c, w_m in [(0.5, 0.5), (0.9, 0.2), (0.0, 1.0), (1.0, 0.0), (0.37, 0.63)]:
         kl_c, kl_m = (1 - w_c) * load_c, (1 - w_m) * load_m
 
         def ref(w, kl, nreq, nlim, cap, preq, plim):  # lowriskovercommitment.go:205-208, :250-253 in float64 / int64
             limit = nlim + plim
             request = np.minimum(nreq + preq, cap)
-            rl = np.where(limit > cap, (limit - cap).astype(np.float64) / np.maximum(limit - request, 1).astype(np.float64), 0.0)
+            rl = np.where(limit > cap, (limit - cap).astype(f64) / np.maximum(limit - request, 1).astype(f64), 0.0)
             return np.clip(w * rl + kl, 0.0, 1.0)
 
         s64 = (1 - np.maximum(ref(w_c, kl_c, nreq_c, nlim_c, cap_c, preq_c, plim_c), ref(w_m, kl_m, nreq_m, nlim_m, cap_m, preq_m, plim_m))) * 100.0
         want = np.floor(s64 + 0.5).astype(np.int64)  # math.Round on a non-negative value
 
-        for bump in (0, 1, -1):
-            def fast(w, kl, nreq, nlim, cap, preq, plim):
-                A, D, d = (nlim - cap).astype(np.float64), (nlim - nreq).astype(np.float64), (plim - preq).astype(np.float64)
-                over = A + plim.astype(np.float64)
-                den = np.maximum(D + d, over)
-                with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
-                    rc = f32(1.0) / den.astype(f32)
-                    if bump:
-                        rc = np.nextafter(rc, f32(np.inf) * f32(bump))
-                    q = over.astype(f32) * rc
-                    t = (f32(w) * q.astype(np.float64) + f32(kl).astype(np.float64)).astype(f32)  # one fma: single rounding
-                return np.fmax(t, f32(kl))  # max(fma, kl) == fma(w, max(q, 0), kl); NaN-absorbing like v_max_f32
+        def parts(nreq, nlim, cap, preq, plim):
+            ah, al = two(nlim - cap)
+            ph, pl = two(plim)
+            ov = (ah + ph) + (al + pl)                                   # three float32 additions
+            dd = np.maximum((nlim - nreq).astype(f64).astype(f32), f32(2.0 ** -30)) + (plim - preq).astype(f64).astype(f32)
+            return ov, dd
 
-            m = np.fmax(fast(w_c, kl_c, nreq_c, nlim_c, cap_c, preq_c, plim_c), fast(w_m, kl_m, nreq_m, nlim_m, cap_m, preq_m, plim_m))
-            s32 = (f32(-100.0) * m.astype(np.float64) + 100.0).astype(f32)
-            assert np.abs(s32.astype(np.float64) - s64).max() < 6e-5
-            rr = np.rint(s32)
-            amb = ~(np.abs(s32 - rr) < f32(0.5) - f32(1.5e-4))
-            bad = (~amb) & (rr.astype(np.int64) != want)
+        ov_c, dd_c = parts(nreq_c, nlim_c, cap_c, preq_c, plim_c)
+        ov_m, dd_m = parts(nreq_m, nlim_m, cap_m, preq_m, plim_m)
+        assert ov_c.dtype == f32 and dd_m.dtype == f32
+        for bump in (0, 1, -1):
+            with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+                rr = f32(1.0) / (dd_c * dd_m)
+                if bump:
+                    rr = np.nextafter(rr, f32(np.inf) * f32(bump))
+                q_c = np.clip((ov_c * dd_m) * rr, f32(0), f32(1))
+                q_m = np.clip((ov_m * dd_c) * rr, f32(0), f32(1))
+            assert not np.isnan(q_c).any() and not np.isnan(q_m).any()
+            t_c = (f32(w_c).astype(f64) * q_c.astype(f64) + kl_c.astype(f32).astype(f64)).astype(f32)  # one fma: single rounding
+            t_m = (f32(w_m).astype(f64) * q_m.astype(f64) + kl_m.astype(f32).astype(f64)).astype(f32)
+            m = np.clip(np.maximum(t_c, t_m), f32(0), f32(1))
+            kk = (m.astype(f64) * -6553600.0 + 14974984.0).astype(f32)     # fma(m, -100 * 2^16, 2^23 + 100 * 2^16 + 2^15 + 8)
+            nn = kk.astype(np.int64) - (1 << 23)
+            assert (nn >= 0).all() and (nn < (1 << 23)).all()
+            s32 = (nn - 32776) / 65536.0
+            assert np.abs(s32 - s64).max() < 8.7e-5, float(np.abs(s32 - s64).max())
+            amb = (nn & 0xfff0) == 0
+            bad = (~amb) & ((nn >> 16) != want)
             assert not bad.any(), (w_c, w_m, bump, int(bad.sum()))
             generic = np.abs(s64 - np.floor(s64) - 0.5) > 1e-9   # cells that do not sit on a boundary by construction (e.g. 0.63 * 0.5)
             assert amb[generic].mean() < 5e-3, (w_c, w_m, bump, float(amb[generic].mean()))

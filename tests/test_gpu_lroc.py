@@ -97,6 +97,70 @@ def test_wide_values_take_the_int64_form(gpu_required, hdr, oracle):
     assert np.abs(got - want).max() <= 1
 
 
+def _two_node_snapshot(hdr, cap, on_lim, pod_specs):
+    res = O.Resources()
+    nodes = O.build_node_objects(hdr, res, [O.node({"cpu": "64000m", "memory": cap}), O.node({"cpu": "8000m", "memory": cap // 3})])
+    pods = O.build_pod_objects(hdr, res, [{"containers": [O.container(rq, lm)]} for rq, lm in pod_specs])
+    on = {0: [{"containers": [O.container({"cpu": "1000m", "memory": on_lim - 3}, {"cpu": "2000m", "memory": on_lim})]}]}
+    return dict(nodes=nodes, pods=pods, metrics=O.build_metrics_objects(hdr, 2, {0: [("CPU", "AVG", 30), ("CPU", "STD", 4), ("Memory", "AVG", 55), ("Memory", "STD", 9)],
+                                                                                 1: [("CPU", "AVG", 70), ("Memory", "Latest", 20)]}),
+                node_pods=O.build_node_pods_objects(hdr, res, 2, on))
+
+
+def test_values_from_2_47_take_the_float64_form(gpu_required, hdr, oracle):
+    """the float32 sweep holds a quantity as the sum of two float32, exact below 2^47: at or above, the float64 sweep runs"""
+    big = 1 << 49
+    snap = _two_node_snapshot(hdr, big, big - 77, [({"cpu": "500m", "memory": big // 7}, {"cpu": "9000m", "memory": big // 2 + 12345}),
+                                                   ({"cpu": "100m", "memory": 1 << 20}, {})])
+    want = oracle_scores(oracle, hdr, snap)
+    with Engine(0) as e:
+        load(e, snap)
+        assert e.kernel_path(LROC) == 0
+        e.eval(mask_of(LROC))
+        e.sync()
+        got = e.all_scores(LROC).astype(np.int64)
+    assert np.abs(got - want).max() <= 1
+
+
+def test_float32_sweep_on_sums_that_cancel_near_2_46(gpu_required, hdr, oracle):
+    """limit - capacity and the pod's limit cancel to a few bytes at 2^46 (odd byte counts: both need their low float32 part), with
+    denominators of 0 .. 3: the float32 sweep (kernel path 1) must read the sign and the size of the excess right"""
+    cap = (1 << 46) + 12345
+    on_lim = cap - (1 << 30) - 7
+    specs = []
+    for excess in (-2, -1, 0, 1, 2, 3, 1000):
+        for d in (0, 1, 3):
+            lim = (1 << 30) + 7 + excess
+            specs.append(({"cpu": "100m", "memory": lim - d}, {"cpu": "200m", "memory": lim}))
+    snap = _two_node_snapshot(hdr, cap, on_lim, specs)
+    params = dict(w_cpu=1.0, w_mem=1.0)  # (riskLimit alone: the measured load would otherwise hold every score at 50)
+    want = oracle_scores(oracle, hdr, snap, **params)
+    with Engine(0) as e:
+        load(e, snap, **params)
+        assert e.kernel_path(LROC) == 1
+        e.eval(mask_of(LROC))
+        e.sync()
+        got = e.all_scores(LROC).astype(np.int64)
+    assert np.abs(got - want).max() <= 1
+    assert len(np.unique(want[:, 0])) > 3  # the excess does move node 0's score
+
+
+def test_float32_sweep_steps_aside_when_a_limit_is_below_its_request(gpu_required, hdr):
+    """the clamp form of riskLimit needs limit - request >= 0 (upstream raises limits to requests: SetMaxLimits, resourcestats.go:227-231);
+    columns that break it — only a caller of the column-level ABI can produce them — get the float64 sweep"""
+    snap = synth.trimaran_snapshot(hdr, 64, 16, seed=5, with_node_pods=True)
+    with Engine(0) as e:
+        load(e, snap)
+        assert e.kernel_path(LROC) == 1
+        cols = e.flatten_lroc_pods(snap["pods"])
+        cols["lim_mem"] = cols["lim_mem"].copy()
+        cols["lim_mem"][3] = cols["req_mem"][3] - 1
+        e.upload_lroc_pods(cols)
+        assert e.kernel_path(LROC) == 0
+        e.eval(mask_of(LROC))
+        e.sync()
+
+
 def test_profile_argmax_with_lroc(gpu_required, hdr, oracle):
     """LROC's table takes part in the weighted argmax like any other score plugin"""
     snap = synth.trimaran_snapshot(hdr, 400, 50, seed=9, with_node_pods=True)
