@@ -1181,6 +1181,18 @@ void launch_nrt_pk_tab_build(const NrtArgs& a, int n_tiles, hipStream_t s) {
   hipLaunchKernelGGL(k_nrt_pk_tab_build, dim3(static_cast<unsigned>(static_cast<int64_t>(n_tiles) * kWindow * kZ * 128 / 256)), dim3(256), 0, s, a);
 }
 
+// BalancedAllocation's fix-up launches: the scan pass only acts when the list overflowed (it then finds the marks in the table)
+void launch_nrt_bal_fixups(const NrtArgs& a, hipStream_t s) {
+  const int64_t units = (a.row_end - a.row_begin) * (a.row_stride / 16);
+  if (a.n_res <= 4) {
+    hipLaunchKernelGGL((k_nrt_bal_scan<4>), dim3(static_cast<unsigned>((units + scan_threads<4>() - 1) / scan_threads<4>())), dim3(scan_threads<4>()), 0, s, a);
+    hipLaunchKernelGGL((k_nrt_bal_redo<4>), dim3((a.redo_cap + 255) / 256), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((k_nrt_bal_scan<8>), dim3(static_cast<unsigned>((units + scan_threads<8>() - 1) / scan_threads<8>())), dim3(scan_threads<8>()), 0, s, a);
+    hipLaunchKernelGGL((k_nrt_bal_redo<8>), dim3((a.redo_cap + 255) / 256), dim3(256), 0, s, a);
+  }
+}
+
 bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
   if (!a.fast) return false;
   if (a.strategy == SPX_NRT_LEAST_NUMA_NODES && !a.ln_tab) return false;
@@ -1217,11 +1229,7 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
         else \
           hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
       } \
-      if (SGV == kSgBalanced) { /* ... recomputed in float64 from the list; the scan pass only acts when the list overflowed */ \
-        const int64_t units = (a.row_end - a.row_begin) * (a.row_stride / 16); \
-        hipLaunchKernelGGL((k_nrt_bal_scan<RMV>), dim3(static_cast<unsigned>((units + scan_threads<RMV>() - 1) / scan_threads<RMV>())), dim3(scan_threads<RMV>()), 0, s, a); \
-        hipLaunchKernelGGL((k_nrt_bal_redo<RMV>), dim3((a.redo_cap + 255) / 256), dim3(256), 0, s, a); \
-      } \
+      if (SGV == kSgBalanced) launch_nrt_bal_fixups(a, s); /* ... recomputed in float64 from the list */ \
     } else {                                                                                              \
       hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhBoth>), dim3(blocks), dim3(256), 0, s, a, n_tiles);     \
     }                                                                                                     \

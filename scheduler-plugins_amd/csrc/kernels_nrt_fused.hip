@@ -49,10 +49,12 @@ namespace {
 using namespace nrtdev;
 
 // what a launch of the walk computes: the Filter alone, or the Filter and the Score of one of the two strategies whose zone totals chain
-constexpr int kFzFilter = 0, kFzLeast = 1, kFzMost = 2;
+constexpr int kFzFilter = 0, kFzLeast = 1, kFzMost = 2, kFzBalanced = 3;
 constexpr float kFzMagic = 12582912.0f;          // 1.5 * 2^23: integers m with |m| < 2^22 are exact around it, bits = kFzMagicBits + m
 constexpr uint32_t kFzMagicBits = 0x4b400000u;
 constexpr int kFzItems = 1 + kC;                  // the pod-level request, then the containers
+constexpr float kFzBalBand = 3e-4f;               // BalancedAllocation: |float32 minimum - float64 value| < 2.3e-4 (kBalBand, kernels_nrt_fast.hip)
+constexpr uint32_t kFzBalRedo = 255u;             // score byte of a cell k_nrt_bal_redo recomputes (kBalRedo)
 
 // a packed Score item: nv[RM] (float32: -Value(request)); requested weighted slots | ceil(2^15 / their count k) << 8; the bits of
 // 1.5 * 2^23 minus k; the table slot's request (float64)
@@ -76,15 +78,30 @@ __global__ __launch_bounds__(256) void k_nrt_fused_pack(NrtArgs a, uint32_t* __r
     if (r < a.n_res && a.slot_weight[r] != 0) wmask |= 1u << r;
   auto f64 = [&](int at) { return __hiloint2double(static_cast<int>(w[at + 1]), static_cast<int>(w[at])); };
   uint32_t* o = out + idx * fz_item_words<RM>();
-  const uint32_t used = w[2 * RM] & 0xffu & wmask;
-  // -Value(request) (LeastAllocated: t = 99.5 + o - v b) or +Value(request) (MostAllocated: t = -0.5 + o + v b); -inf for a slot that is
+  const bool balanced = a.strategy == SPX_NRT_BALANCED_ALLOCATION;  // (weights do not enter: balanced_allocation.go:27-46 iterates the requested resources)
+  const uint32_t used = w[2 * RM] & 0xffu & (balanced ? 0xffu : wmask);
+  // -Value(request) (LeastAllocated: t = 99.5 + o - v b) or +Value(request) (MostAllocated: t = -0.5 + o + v b; BalancedAllocation: the fraction v / c); -inf for a slot that is
   // not requested or weighs nothing: its chain, run because another lane's item needs it or because the walk only knows the unweighted
   // slot set, adds clamp01(-inf) = 0 (b >= 0; MostAllocated's b is 0 without capacity: NaN, clamped to 0 as well)
-  const float sign = a.strategy == SPX_NRT_MOST_ALLOCATED ? 1.0f : -1.0f;
+  const float sign = a.strategy == SPX_NRT_LEAST_ALLOCATED ? -1.0f : 1.0f;
 #pragma unroll
   for (int r = 0; r < RM; ++r)
     o[r] = ((used >> r) & 1u) ? __float_as_uint(sign * static_cast<float>(f64(r == a.cpu_slot ? 2 * RM + 2 : 2 * r))) : 0xff800000u;
   const uint32_t k = static_cast<uint32_t>(__builtin_popcount(used));
+  if (balanced) {
+    // 1 / n and 100 / (n - 1) (as RN32(100 * RN32(1 / (n - 1)))) for the variance over the item's n fractions; fewer than two: the
+    // reference's variance is NaN and every zone scores 0 — NaN here, which leaves every zone out of the minimum.  A requested slot
+    // whose Value() is 0 travels as 1e-30: its fraction is 0 on a zone with capacity (1e-30 * rcp, lost in every sum) and 1 on a zone
+    // without (1e-30 * inf under the clamp; 0 * inf would be NaN)
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+      if (((used >> r) & 1u) && f64(r == a.cpu_slot ? 2 * RM + 2 : 2 * r) == 0.0) o[r] = __float_as_uint(1e-30f);
+    const float c100rm = k >= 2 ? 100.0f * (1.0f / static_cast<float>(k - 1)) : __builtin_nanf("");
+    o[RM] = __float_as_uint(k ? 1.0f / static_cast<float>(k) : 0.0f);
+    o[RM + 1] = __float_as_uint(c100rm);
+    o[RM + 2] = o[RM + 3] = 0u;
+    return;
+  }
   o[RM] = used | ((k ? (32768u + k - 1u) / k : 0u) << 8);
   o[RM + 1] = kFzMagicBits - k;
   const double raw = a.pk_tab_slot >= 0 ? f64(2 * a.pk_tab_slot) : 0.0;
@@ -302,6 +319,69 @@ __device__ __forceinline__ uint32_t fz_score_item(const float (&bs)[RM][kZ], con
   return __umul24(mm + (kFzMagicBits - top), g.w0 >> 8) >> 15;  // floor(total / k): total <= 800, k <= 8, ceil(2^15 / k)
 }
 
+// BalancedAllocation's per-node constants next to the reciprocals (bs), four registers:
+//   qc   the cpu slot's counts once more, of 1000 x Value(capacity) — "request > capacity" is decided on rounded-up cores for cpu
+//        (fractionOfCapacity divides Value() by Value()), and ceil(request / 1000) <= cores  <=>  request <= 1000 cores: the same
+//        subtraction of the request's rank, on another count.  All ones where the capacity is not positive (fraction 1, never
+//        exceeded), 0 past the node's zones;
+//   zc   the node's zones whose capacity of slot r is not positive (fraction 1: the zone stays in whatever is asked): bit 7 - r of the
+//        zone's byte in the count layout, so that `zc << r` lines slot r's bits up with the guard bits.
+struct FzBal {
+  uint32_t qc[2];
+  uint32_t zc[2];
+  int cpu_slot;
+};
+
+// BalancedAllocation (balanced_allocation.go:27-54; gonum stat.Variance) of one request item on the lane's node, as score_balanced_f32
+// (kernels_nrt_fast.hip) computes it — the same float32 operations on the fractions and the variance, hence the same error bound
+// (2.3e-4 against the band of 3e-4; tests/test_exactness_arguments.py) — except for what decides "request > capacity":
+//   * every slot but cpu: Value() is the quantity itself, so fraction > 1 is the Filter's own comparison — the guard bit of the item's
+//     subtraction (xs, as MostAllocated reads it), exact, where the float32 form had to leave near-equal byte counts undecided;
+//   * cpu: the same subtraction on the counts of 1000 x whole cores (FzBal::qc; the walk puts it in xs[cpu slot]).
+// A zone without capacity for a slot contributes fraction 1 (rcp = +inf under the clamp; zc keeps the zone) and the fraction of a
+// request that fits is clamped to 1 (RN32(v) * RN32(1 / c) can exceed it by an ulp when v == c).  Returns the truncated minimum over the
+// zones that score (0: none); *redo |= the minimum is within the band of an integer.
+template <int RM>
+__device__ __forceinline__ uint32_t fz_score_item_bal(const float (&rcp)[RM][kZ], const FzBal& bal, uint32_t slots, const FzItem<RM>& g,
+                                                      const uint32_t (&xs)[RM][2], uint32_t* redo) {
+  float sum[kZ], sq[kZ];
+#pragma unroll
+  for (int z = 0; z < kZ; ++z) sum[z] = 0.0f, sq[z] = 0.0f;
+  uint32_t ok[2] = {~0u, ~0u};  // (only the guard bits are read)
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    if (!((slots >> r) & 1u)) continue;  // uniform: a slot some lane at work requests (the others hold -inf: fraction 0)
+    SPX_KEEP_BRANCH();
+#pragma unroll
+    for (int z = 0; z < kZ; ++z) {
+      const float f = __builtin_amdgcn_fmed3f(g.nv[r] * rcp[r][z], 0.0f, 1.0f);
+      sum[z] += f;
+      sq[z] = __builtin_fmaf(f, f, sq[z]);
+    }
+    ok[0] &= xs[r][0] | (bal.zc[0] << r);
+    ok[1] &= xs[r][1] | (bal.zc[1] << r);
+  }
+  // 100 (1 - var), var = (sq - sum^2 / n) / (n - 1): g.w0 = 1 / n, g.w1 = 100 / (n - 1) (NaN for n < 2: no zone scores)
+  const float rn = __uint_as_float(g.w0), c100rm = -__uint_as_float(g.w1);
+  const uint32_t out[2] = {~ok[0], ~ok[1]};
+  // The minimum over the zones that are in, on the values' bit patterns: a zone's score is in [50, 100] (a positive float32 orders as
+  // its bits), a zone that is out — some slot's guard bit cleared — becomes all ones, and a NaN
+  // (n < 2) lies above +inf either way: v_min3_u32, no canonicalisation of NaN operands as the float minimum needs
+  uint32_t u[kZ];
+#pragma unroll
+  for (int z = 0; z < kZ; ++z) {
+    const float sc = __builtin_fmaf(__builtin_fmaf(-(sum[z] * sum[z]), rn, sq[z]), c100rm, 100.0f);
+    u[z] = __float_as_uint(sc) | static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(out[z >> 2]), 8 * (z & 3) + 7, 1));
+  }
+  auto min3 = [](uint32_t x, uint32_t y, uint32_t w) { return min(min(x, y), w); };
+  const uint32_t bu = min3(min3(u[0], u[1], u[2]), min3(u[3], u[4], u[5]), min(u[6], u[7]));
+  const bool has = bu < 0x7f800000u;
+  const float best = __uint_as_float(bu);
+  const float fl = __builtin_floorf(best), frac = best - fl;
+  *redo |= (has && (frac < kFzBalBand || frac > 1.0f - kFzBalBand)) ? 1u : 0u;
+  return has ? static_cast<uint32_t>(static_cast<int>(fl)) : 0u;
+}
+
 // The pod loop.  One count layout: four zones per register (every chunk of the stream is narrow — the engine splits a chunk whose lists
 // would pass 127 entries — or the fused sweep is not launched).
 //
@@ -316,11 +396,12 @@ __device__ __forceinline__ uint32_t fz_score_item(const float (&bs)[RM][kZ], con
 template <int RM, bool FIRST1, int MODE, bool NARROW = true>
 __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float (&bs)[RM][kZ], const float (&c0s)[RM], int ts, const uint32_t* pods,
                                         const uint32_t* sitems, int rows, int lane, bool w_pod, bool w_ctr, bool aligned, bool pod_scope, uint32_t st_stale,
-                                        bool in, int pos, uint32_t absent_bits, uint32_t* stage_status, uint32_t* stage_score) {
+                                        bool in, int pos, uint32_t absent_bits, uint32_t* stage_status, uint32_t* stage_score, const FzBal& bal) {
   using L = RkLayout<NARROW>;
   constexpr int W = L::W;
   constexpr int PWR = kRkPodHead + kRkVectors * RM;
-  constexpr bool SCORE = MODE != kFzFilter, MOST = MODE == kFzMost;
+  constexpr bool SCORE = MODE != kFzFilter, MOST = MODE == kFzMost, BAL = MODE == kFzBalanced;
+  constexpr bool FITS = MOST || BAL;  // the Score reads per-slot fit bits off the Filter's subtractions
   uint32_t qa[RM][W];
 #pragma unroll
   for (int r = 0; r < RM; ++r)
@@ -350,7 +431,7 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
       uint32_t z0[W], z1[W];
 #pragma unroll
       for (int j = 0; j < W; ++j) z0[j] = z1[j] = 0u;  // the zones app containers a0 / a1 were charged to (packed one-zone sets)
-      uint32_t sum = 0;
+      uint32_t sum = 0, redo = 0;  // (redo, BalancedAllocation: some item's minimum is too close to an integer for float32)
       // the next step's thresholds and Score item are in flight while this one is worked on
       FzThr<RM> t = fz_load_thr<RM>(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(rec) + thr0));
       FzItem<RM> g{};
@@ -372,8 +453,13 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
         }
         if (mine) {
           uint32_t m[W], xs[RM][2];
-          if constexpr (MOST) {
+          if constexpr (FITS) {
             fz_mask_slots<RM>(qa, t, m, xs);
+            if constexpr (BAL) {  // the Score's cpu comparison is on whole cores (FzBal::qc); the Filter's verdict m keeps the quantities'
+#pragma unroll
+              for (int r = 0; r < RM; ++r)
+                if (r == bal.cpu_slot) xs[r][0] = bal.qc[0] - t.t[r], xs[r][1] = bal.qc[1] - t.t[r];  // uniform
+            }
           } else {
             fz_mask<RM, NARROW>(qa, t, m);
 #pragma unroll
@@ -399,8 +485,8 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
               }
             }
           }
-          if constexpr (MOST) {
-            // MostAllocated reads "the zone holds the request" off the counts, so they stay the zones' own: a compared slot the node does not
+          if constexpr (FITS) {
+            // MostAllocated / BalancedAllocation read "the zone holds the request" off the counts, so they stay the zones' own: a compared slot the node does not
             // report at node level (filter.go:101-104: the Filter fails, the Score does not care) is tested here instead of zeroing its counts
             const uint32_t sc = head(3 + c), sp = head(2);
             const uint32_t need_c = ((sc >> 8) | (sc >> 16)) & 0xffu, need_p = ((sp >> 8) | (sp >> 16)) & 0xffu;
@@ -419,7 +505,9 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
               else z1[j] = z[j];
             }
           }
-          if constexpr (SCORE) {
+          if constexpr (BAL) {
+            if (scored) sum += fz_score_item_bal<RM>(bs, bal, slots, g, xs, &redo);
+          } else if constexpr (SCORE) {
             if (scored) sum += fz_score_item<RM, false, FIRST1, MOST>(bs, c0s, ts, slots, g, xs);
           }
         }
@@ -428,6 +516,7 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
       }
       // int64(mean): sum / n_ctr, sum <= 800; head 1 = ceil(2^16 / n_ctr); a pod-scope lane's one item divides by one
       if (scored) score = (sum * (pod_scope ? 65536u : head(1))) >> 16;
+      if constexpr (BAL) score = (scored && redo) ? kFzBalRedo : score;  // k_nrt_bal_redo recomputes the cell in float64
     }
     const int sh = 8 * (p & 3);
     acc_status |= status << sh;
@@ -448,7 +537,7 @@ __device__ __forceinline__ void fz_walk(const uint32_t (&q4)[RM][2], const float
 // launch: the same walk without the Score's tables, items and chains
 template <int RM, bool FIRST1, int MODE>
 __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, const uint32_t* __restrict__ fz_items, int n_tiles) {
-  constexpr bool SCORE = MODE != kFzFilter, MOST = MODE == kFzMost;
+  constexpr bool SCORE = MODE != kFzFilter, MOST = MODE == kFzMost, BAL = MODE == kFzBalanced, FITS = MOST || BAL;
   extern __shared__ __align__(16) uint32_t lds[];
   __shared__ uint32_t pk_flagged;  // the chunk's pods with a table-slot request k_nrt_pk_tab_build lists for this window
   const int lane = threadIdx.x & 63;
@@ -521,9 +610,35 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
 #pragma unroll
     for (int z = 0; z < kZ; ++z) {
       bs[r][z] = 0.0f;
-      if constexpr (SCORE) {
+      if constexpr (BAL) {
+        // RN32(RN64(1 / Value(capacity))); +inf where the capacity is not positive: the clamped fraction of any request is then 1
+        const uint32_t at = (static_cast<uint32_t>(z * R + r) * nn + n32) * 8u;
+        const bool cap = in && r < R && ld_off(a.f_av, at) > 0.0;
+        bs[r][z] = cap ? static_cast<float>(ld_off(a.f_rcv, at)) : __builtin_inff();
+      } else if constexpr (SCORE) {
         const double b = (in && r < R) ? ld_off(a.f_rc, (static_cast<uint32_t>(z * R + r) * nn + n32) * 8u) : kNoCap;
         bs[r][z] = b == kNoCap ? (MOST ? 0.0f : __builtin_inff()) : static_cast<float>(b) * 0x1p-7f;  // no capacity: the resource scores 0
+      }
+    }
+  }
+  FzBal bal{};
+  bal.cpu_slot = a.cpu_slot;
+  double cpu_q[kZ];  // BalancedAllocation: 1000 x Value() of the zones' cpu capacity (1e300: not positive; -1: past the node's zones)
+  if constexpr (BAL) {
+    const int nz = in ? a.n_zones[n] : 0;
+    const uint32_t cs = static_cast<uint32_t>(a.cpu_slot >= 0 ? a.cpu_slot : 0);
+#pragma unroll
+    for (int z = 0; z < kZ; ++z) {
+      const bool cap = in && a.cpu_slot >= 0 && ld_off(a.f_av, (static_cast<uint32_t>(z * R) + cs) * nn * 8u + n32 * 8u) > 0.0;
+      cpu_q[z] = z < nz ? (cap ? 1000.0 * ld_off(a.f_cpu, (static_cast<uint32_t>(z) * nn + n32) * 8u) : 1e300) : -1.0;  // (1e300: above every entry, below the lists' +inf padding)
+    }
+    bal.zc[0] = bal.zc[1] = 0u;
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+#pragma unroll
+      for (int z = 0; z < kZ; ++z) {
+        const bool none = in && r < R && r != a.cpu_slot && z < nz && !(ld_off(a.f_av, (static_cast<uint32_t>(z * R + r) * nn + n32) * 8u) > 0.0);
+        bal.zc[z >> 2] |= none ? 0x80u >> r << (8 * (z & 3)) : 0u;
       }
     }
   }
@@ -630,7 +745,7 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
       __syncthreads();  // (a lane's first staged dword must not meet another lane's zeroing)
 #pragma unroll
       for (int r = 0; r < RM; ++r) {
-        const bool absent = !MOST && !((node_present >> r) & 1u), fill = (fill_bits >> r) & 1u;
+        const bool absent = !FITS && !((node_present >> r) & 1u), fill = (fill_bits >> r) & 1u;
         uint32_t lo4 = RkLayout<true>::G, hi4 = RkLayout<true>::G;
 #pragma unroll
         for (int z = 0; z < 4; ++z) lo4 |= ((cnt4[z] >> (8 * r)) & 0xffu) << (8 * z), hi4 |= ((cnt4[z + 4] >> (8 * r)) & 0xffu) << (8 * z);
@@ -663,12 +778,32 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
     }
     // a compared resource the node does not report at node level fails whatever the zones say (filter.go:101-104): count 0 (a slot that
     // is not compared subtracts 0 and passes); a host-level resource no zone reports passes whatever is asked: all ones
-    const bool absent = !MOST && !((node_present >> r) & 1u), fill = (fill_bits >> r) & 1u;  // (MostAllocated: fz_walk tests node-level absence itself)
+    const bool absent = !FITS && !((node_present >> r) & 1u), fill = (fill_bits >> r) & 1u;  // (Most / BalancedAllocation: fz_walk tests node-level absence itself)
     const uint32_t lo4 = RkLayout<true>::G | cnt[0] | (cnt[1] << 8) | (cnt[2] << 16) | (cnt[3] << 24);
     const uint32_t hi4 = RkLayout<true>::G | cnt[4] | (cnt[5] << 8) | (cnt[6] << 16) | (cnt[7] << 24);
     q4[r][0] = absent ? RkLayout<true>::G : (fill ? ~0u : lo4);
     q4[r][1] = absent ? RkLayout<true>::G : (fill ? ~0u : hi4);
   }
+  }
+  if constexpr (BAL) {
+    bal.qc[0] = bal.qc[1] = ~0u;  // (no cpu slot: nothing is subtracted from it)
+    if (a.cpu_slot >= 0) {  // uniform: the eight quantities ranked against the chunk's cpu list, as the block start without sorted windows does
+      const uint32_t hw = lds[a.cpu_slot];
+      const int steps = static_cast<int>(hw & 0xffu);
+      const uint32_t lo = hw >> 8;
+      uint32_t cnt[kZ];
+#pragma unroll
+      for (int z = 0; z < kZ; ++z) cnt[z] = 0;
+      for (int b = 1 << (steps - 1); b > 0; b >>= 1) {
+#pragma unroll
+        for (int z = 0; z < kZ; ++z) {
+          const double v = lists[lo + cnt[z] + static_cast<uint32_t>(b) - 1u];
+          cnt[z] = v <= cpu_q[z] ? cnt[z] + static_cast<uint32_t>(b) : cnt[z];
+        }
+      }
+      bal.qc[0] = RkLayout<true>::G | cnt[0] | (cnt[1] << 8) | (cnt[2] << 16) | (cnt[3] << 24);
+      bal.qc[1] = RkLayout<true>::G | cnt[4] | (cnt[5] << 8) | (cnt[6] << 16) | (cnt[7] << 24);
+    }
   }
   const uint32_t* const pods = lds + 16 + 2 * list_doubles;
   const bool fresh = flags & SPX_NRT_F_FRESH;
@@ -683,9 +818,41 @@ __global__ __launch_bounds__(256, RM == 4 ? 4 : 2) void k_nrt_fused(NrtArgs a, c
   uint32_t absent_bits = 0;  // slots the node does not report at node level
 #pragma unroll
   for (int r = 0; r < RM; ++r) absent_bits |= (r < R && !((node_present >> r) & 1u)) ? 1u << r : 0u;
-  fz_walk<RM, FIRST1, MODE>(q4, bs, c0s, ts, pods, sitems, rows, lane, w_pod, w_ctr, aligned, pod_scope, st_stale, in, pos, absent_bits, stage_status, stage_score);
+  fz_walk<RM, FIRST1, MODE>(q4, bs, c0s, ts, pods, sitems, rows, lane, w_pod, w_ctr, aligned, pod_scope, st_stale, in, pos, absent_bits, stage_status, stage_score, bal);
   __syncthreads();
-  if constexpr (SCORE) {
+  if constexpr (BAL) {
+    // the cells left to the float64 form (score byte 255), listed for k_nrt_bal_redo: ~1 % of config #3's cells.  A thread counts the
+    // marks of its node's staged dwords, the block takes ONE range of the global list (an atomic per marked cell on the one counter
+    // made the launch 9.7 ms); past the list's capacity the count says so and k_nrt_bal_scan finds the marks in the table
+    __shared__ uint32_t redo_n, redo_base;
+    if (threadIdx.x == 0) redo_n = 0;
+    __syncthreads();
+    const int quads = (rows + 3) >> 2;
+    uint32_t mine = 0;
+    if (in)
+      for (int q = 0; q < quads; ++q) {
+        const uint32_t w4 = stage_score[q * kWindow + pos];
+        // bytes equal to 0xff (scores are <= 100: only the mark has bit 7 set)
+        mine += static_cast<uint32_t>(__builtin_popcount(w4 & 0x80808080u));
+      }
+    uint32_t at = mine ? atomicAdd(&redo_n, mine) : 0u;
+    __syncthreads();
+    if (redo_n != 0u) {  // block-uniform
+      if (threadIdx.x == 0) redo_base = atomicAdd(a.redo_list, redo_n);
+      __syncthreads();
+      at += redo_base;
+      if (mine)
+        for (int q = 0; q < quads; ++q) {
+          uint32_t w4 = stage_score[q * kWindow + pos] & 0x80808080u;
+          for (; w4 != 0u; w4 &= w4 - 1u, ++at) {
+            if (at >= a.redo_cap) continue;
+            a.redo_list[2 + 2 * static_cast<size_t>(at)] = static_cast<uint32_t>(row_of(4 * q + (__builtin_ctz(w4) >> 3)));
+            a.redo_list[3 + 2 * static_cast<size_t>(at)] = n32;
+          }
+        }
+    }
+  }
+  if constexpr (SCORE && !BAL) {
     const uint32_t flagged = pk_flagged;  // block-uniform (every atomicOr precedes the barrier above)
     if (flagged != 0) {
       // second pass: the flagged pods' cells of this window with the table slot in the float64 form — its eight multipliers read
@@ -803,12 +970,17 @@ size_t nrt_fused_item_words(int n_res, int64_t n_list) {
 // strategy or weights the chain does not cover, or a chunk block that does not fit in LDS next to the items and the stage.
 bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
   if (!a.fast || !a.fz_items || !a.rk_stream || !a.rk_off || !a.rk_first || a.rk_max_dwords == 0 || !a.out_status || !a.out_score || a.out_raw || a.row_ptr) return false;
-  const bool most = a.strategy == SPX_NRT_MOST_ALLOCATED;
-  if ((a.strategy != SPX_NRT_LEAST_ALLOCATED && !most) || !a.pk_mode || a.pk_tab_slot > 1) return false;  // (the table slot is chained first: slot 0 or 1)
+  const bool most = a.strategy == SPX_NRT_MOST_ALLOCATED, balanced = a.strategy == SPX_NRT_BALANCED_ALLOCATION;
+  if (balanced) {
+    // the float32 form needs the cpu slot's whole cores exact in float32 and somewhere to list the cells it leaves to float64
+    if (!a.redo_list || a.redo_cap == 0 || !a.f_rcv || !a.f_cpu || (a.cpu_slot >= 0 && !((a.exact32_slots >> a.cpu_slot) & 1u))) return false;
+  } else if ((a.strategy != SPX_NRT_LEAST_ALLOCATED && !most) || !a.pk_mode || a.pk_tab_slot > 1) {
+    return false;  // (the table slot is chained first: slot 0 or 1)
+  }
   // five to eight resource slots: the Score's multipliers alone are 64 registers — 192 with the rest, two waves per SIMD, 2.25 ms for the
   // six-slot config #3 against 1.76 for the Filter-only walk + the packed Score launch (measured): those tables take the two launches
   if (a.n_res > 4) return false;
-  for (int r = 0; r < a.n_res; ++r)
+  for (int r = 0; r < a.n_res && !balanced; ++r)
     if (a.slot_weight[r] != 0 && a.slot_weight[r] != 1) return false;
   const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);
   const int64_t chunks = a.rk_chunks;
@@ -817,7 +989,7 @@ bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
   const size_t lds = static_cast<size_t>(a.rk_max_dwords) * 4 + static_cast<size_t>(kPodsPerUnit) * fz_pod_words<4>() * 4 +
                      static_cast<size_t>(2) * (kPodsPerUnit / 4) * kWindow * 4 + 64;
   if (lds > 64 * 1024) return false;
-  if (a.pk_tab_slot >= 0 && !(a.pk_tab_built && *a.pk_tab_built)) {  // the table of the packed float32 Score (kernels_nrt_fast.hip)
+  if (!balanced && a.pk_tab_slot >= 0 && !(a.pk_tab_built && *a.pk_tab_built)) {  // the table of the packed float32 Score (kernels_nrt_fast.hip)
     launch_nrt_pk_tab_build(a, n_tiles, s);
     if (a.pk_tab_built) *a.pk_tab_built = true;
   }
@@ -830,7 +1002,15 @@ bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<RMV, F1V, MODEV>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
     hipLaunchKernelGGL((k_nrt_fused<RMV, F1V, MODEV>), dim3(blocks), dim3(256), lds, s, a, a.fz_items, n_tiles);                          \
   } while (0)
-  if (most) {
+  if (balanced) {
+    NrtArgs b = a;
+    b.pk_tab_slot = -1;  // (no table slot: the walk's second pass and its flags stay idle)
+    (void)hipMemsetAsync(a.redo_list, 0, 8, s);
+    if (a.fz_pack) hipLaunchKernelGGL((k_nrt_fused_pack<4>), dim3(pack_blocks), dim3(256), 0, s, b, a.fz_items);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<4, true, kFzBalanced>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL((k_nrt_fused<4, true, kFzBalanced>), dim3(blocks), dim3(256), lds, s, b, a.fz_items, n_tiles);
+    launch_nrt_bal_fixups(a, s);  // the listed cells in float64 (kernels_nrt_fast.hip)
+  } else if (most) {
     if (first1) SPX_FZ_LAUNCH(4, true, kFzMost);
     else SPX_FZ_LAUNCH(4, false, kFzMost);
   } else {

@@ -363,10 +363,12 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     }
     // the fused Filter + Score launch (kernels_nrt_fused.hip): a whole-batch LeastAllocated sweep in the packed Score's preconditions with unit
     // weights; it walks the rank stream of the class representatives or, without classes, of every row
-    bool fused = e->option[SPX_OPT_NRT_FUSED] && e->option[SPX_OPT_NRT_RANK_FILTER] && na.pk_mode && !(na.opts & spx::kOptNrtSingleLaunch) &&
+    // (BalancedAllocation, round 6b: the walk carries its float32 Score too — no packed-Score preconditions, its own list of cells for float64)
+    const bool fz_balanced = na.strategy == SPX_NRT_BALANCED_ALLOCATION && na.fast && !(na.opts & spx::kOptNrtGeneric) && !e->row_indirect && e->nrt_n_res <= 4;
+    bool fused = e->option[SPX_OPT_NRT_FUSED] && e->option[SPX_OPT_NRT_RANK_FILTER] && (na.pk_mode || fz_balanced) && !(na.opts & spx::kOptNrtSingleLaunch) &&
                  row_begin == 0 && row_end == e->n_pods;
     fused = fused && e->option[SPX_OPT_NRT_RANK_NARROW];  // (its only count layout)
-    for (int i = 0; fused && i < e->nrt_n_res; ++i) fused = e->nrt_slot_weight[i] == 0 || e->nrt_slot_weight[i] == 1;
+    for (int i = 0; fused && !fz_balanced && i < e->nrt_n_res; ++i) fused = e->nrt_slot_weight[i] == 0 || e->nrt_slot_weight[i] == 1;
     if (classes || fused) {
       if ((rc = nrt_rank_stream(e, classes ? 1 : 2))) return rc;
     }

@@ -659,6 +659,8 @@ struct ProfileArgs {
 };
 void launch_alloc_masked(const ProfileArgs& a, hipStream_t s);
 // copies row pairs[2i+1] to row pairs[2i] in up to two uint8 tables of row_stride bytes per row (NULL = skip)
+// BalancedAllocation: the cells a float32 Score launch listed in NrtArgs::redo_list, recomputed in float64 (k_nrt_bal_scan + k_nrt_bal_redo, kernels_nrt_fast.hip)
+void launch_nrt_bal_fixups(const NrtArgs& a, hipStream_t s);
 void launch_rows_expand(const int32_t* pairs, int64_t n_pairs, uint8_t* t0, uint8_t* t1, int64_t row_stride, hipStream_t s);
 void launch_best(const ProfileArgs& a, hipStream_t s);
 // spx_decide with Filter plugins in the mask: Allocatable's feasibility-aware normalisation and the weighted argmax in one kernel

@@ -406,7 +406,7 @@ def test_balanced_allocation_float32_score_is_exact_outside_the_band():
     rng = np.random.default_rng(21)
     cells = 400_000
     band = np.float32(3e-4)
-    worst = 0.0
+    worst = worst_walk = 0.0
     undecided = plain_cells = 0
     for n in range(2, 9):
         mag = rng.integers(1, 41, (cells, n))
@@ -465,7 +465,30 @@ def test_balanced_allocation_float32_score_is_exact_outside_the_band():
         worst = max(worst, float(np.abs(sc[both].astype(np.float64) - score64[both]).max()))
         undecided += int((redo & plain).sum())
         plain_cells += int(plain.sum())
+        # ---- the walk's form (fz_score_item_bal, kernels_nrt_fused.hip): the fraction as a clamped product (+inf for "no capacity"),
+        # "request > capacity" exact (the Filter's rank-space bits; whole cores for cpu), the variance's last two steps as one fma with
+        # RN32(-100 / (n - 1))
+        reqz = np.where(req == 0, np.float32(1e-30), _f32(req)).astype(np.float32)  # (a zero request travels as 1e-30: 0 * inf would be NaN)
+        fz = np.clip(reqz * np.where(nocap, np.float32(np.inf), _f32(1.0 / cap)).astype(np.float32), np.float32(0), np.float32(1))
+        assert not np.isnan(fz).any()
+        sm = np.zeros(cells, np.float32)
+        sq = np.zeros(cells, np.float32)
+        for i in range(n):
+            sm = (sm + fz[:, i]).astype(np.float32)
+            sq = _f32(fz[:, i].astype(np.float64) * fz[:, i].astype(np.float64) + sq.astype(np.float64))
+        m100rm = np.float32(-100.0) * rm_
+        t2 = _f32(-((sm * sm).astype(np.float32).astype(np.float64)) * np.float64(rn_) + sq.astype(np.float64))
+        scz = _f32(t2.astype(np.float64) * np.float64(m100rm) + 100.0)
+        flz = np.floor(scz)
+        fracz = scz - flz
+        redoz = ~over & ((fracz < band) | (fracz > np.float32(1) - band))
+        gotz = np.where(~over, flz, 0).astype(np.int64)
+        okz = ~redoz
+        assert (gotz[okz] == want[okz]).all(), (n, np.flatnonzero(okz & (gotz != want))[:5])
+        sel = ~over
+        worst_walk = max(worst_walk, float(np.abs(scz[sel].astype(np.float64) - score64[sel]).max()))
     assert worst < 2.3e-4, worst
+    assert worst_walk < 2.3e-4, worst_walk
     # 2 * kBalBand of the cells, the rare fraction next to 1, and the exactly integer scores small capacities produce (all fractions 0 or equal)
     assert undecided < 5e-3 * plain_cells, (undecided, plain_cells)
 

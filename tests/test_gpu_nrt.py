@@ -307,9 +307,10 @@ def test_pod_classes_of_the_synthetic_queue(gpu_required, hdr):
         assert uniq + dups == 4000 and dups > 1200
 
 # ------------------------------------------------------------------ the Filter launch in rank space (SPX_OPT_NRT_RANK_FILTER)
+@pytest.mark.parametrize("fused", [0, 1], ids=["rank-kernel", "walk"])
 @pytest.mark.parametrize("narrow", [1, 0], ids=["narrow-chunks", "wide-only"])
 @pytest.mark.parametrize("wide", [False, True], ids=["4slots", "6slots"])
-def test_rank_filter_equals_float64_filter(gpu_required, hdr, oracle, wide, narrow):
+def test_rank_filter_equals_float64_filter(gpu_required, hdr, oracle, wide, narrow, fused):
     """A whole-batch sweep over pod classes runs its Filter launch in rank space (kernels_nrt_rank.hip: requests and zone quantities
     as positions in the chunk's sorted request list, charged zones through request sums instead of table mutation); with the
     option off the float64 launch runs.  Same status table, cell for cell, and the oracle's on sampled rows.  `narrow` (round 5,
@@ -319,13 +320,16 @@ def test_rank_filter_equals_float64_filter(gpu_required, hdr, oracle, wide, narr
     containers and sidecars, both node scopes, stale and NRT-less nodes, unreported and host-level resources."""
     n_nodes, n_pods = 1500, 2500
     snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=31, wide=wide)
-    params = O.nrt_params(hdr, O.Resources(), "BalancedAllocation")  # (a strategy whose sweep keeps the Filter launch: Least / MostAllocated fuse it)
+    # `fused` (SPX_OPT_NRT_FUSED): off, the Filter launch is k_nrt_filter_rank; on, the walk of kernels_nrt_fused.hip — Filter-only
+    # before the six-slot Score launch, or (four slots, narrow chunks) with BalancedAllocation's Score in the same launch (path 3)
+    params = O.nrt_params(hdr, O.Resources(), "BalancedAllocation")
     with Engine(0) as e:
         e.set_option("NRT_RANK_NARROW", narrow)
+        e.set_option("NRT_FUSED", fused)
         e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
         e.eval(mask_of(NRT))
         e.sync()
-        assert e.nrt_filter_path() == 2
+        assert e.nrt_filter_path() == (3 if fused and narrow and not wide else 2)
         ranked, score = e.all_status(NRT), e.all_scores(NRT)
         e.set_option("NRT_RANK_FILTER", 0)
         e.eval(mask_of(NRT))
@@ -339,15 +343,16 @@ def test_rank_filter_equals_float64_filter(gpu_required, hdr, oracle, wide, narr
 
 
 # ------------------------------------------------------------------ Filter + Score in one launch (SPX_OPT_NRT_FUSED)
-@pytest.mark.parametrize("strategy", ["LeastAllocated", "MostAllocated"])
+@pytest.mark.parametrize("strategy", ["LeastAllocated", "MostAllocated", "BalancedAllocation"])
 @pytest.mark.parametrize("classes", [1, 0], ids=["pod-classes", "every-row"])
 @pytest.mark.parametrize("narrow", [1, 0], ids=["narrow-chunks", "wide-only"])
 @pytest.mark.parametrize("wide", [False, True], ids=["4slots", "6slots"])
 def test_fused_sweep_equals_two_launches(gpu_required, hdr, oracle, wide, narrow, classes, strategy):
-    """A whole-batch Least- or MostAllocated sweep with unit weights runs Filter and Score in ONE launch (kernels_nrt_fused.hip: the
-    rank-space Filter evaluated branch-free, the Score as a chain of two float32 instructions per (zone, resource) — MostAllocated's
-    behind the Filter's own "request fits" bits — the chunk's pod records staged once); with the option off the Filter launch and the
-    Score launch (packed float32 for Least, float64 for Most) run.  Same two tables, cell for cell, with
+    """A whole-batch Least- or MostAllocated sweep with unit weights, or a BalancedAllocation sweep, runs Filter and Score in ONE launch
+    (kernels_nrt_fused.hip: the rank-space Filter evaluated branch-free, the Score as a chain of two float32 instructions per (zone,
+    resource) — MostAllocated's behind the Filter's own "request fits" bits, BalancedAllocation's float32 variance behind them too, its
+    undecided cells listed for the float64 fix-up — the chunk's pod records staged once); with the option off the Filter launch and the
+    Score launch (packed float32 for Least, float64 for Most, float32 + fix-up for Balanced) run.  Same two tables, cell for cell, with
     pod classes (the stream lists the representatives) and without (the stream lists every row, built when the sweep first asks),
     in both count layouts, for four and six resource slots; and the oracle's rows on a sample."""
     n_nodes, n_pods = 1500, 2500
@@ -363,6 +368,8 @@ def test_fused_sweep_equals_two_launches(gpu_required, hdr, oracle, wide, narrow
         # (the fused sweep has the four-zones-per-register layout only: with SPX_OPT_NRT_RANK_NARROW off the two launches run; and with five
         # to eight slots the one-launch form would hold two waves per SIMD: those tables run the same walk Filter-only + the packed Score launch)
         def path(cls):
+            if strategy == "BalancedAllocation" and wide:  # (no one-launch form for six slots, and no packed Score either: nothing asks for the every-row stream)
+                return 2 if cls else 1
             return (2 if wide else 3) if narrow else (2 if cls else 1)
         assert e.nrt_filter_path() == path(classes)
         status, score = e.all_status(NRT), e.all_scores(NRT)
@@ -389,7 +396,7 @@ def test_fused_sweep_steps_aside(gpu_required, hdr, oracle):
     n_nodes, n_pods = 700, 900
     snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=41)
     res = O.Resources()
-    for strategy, weights in (("LeastAllocated", {"cpu": 3, "memory": 1}), ("MostAllocated", {"cpu": 2}), ("BalancedAllocation", None)):
+    for strategy, weights in (("LeastAllocated", {"cpu": 3, "memory": 1}), ("MostAllocated", {"cpu": 2}), ("LeastNUMANodes", None)):
         params = O.nrt_params(hdr, res, strategy, weights)
         with Engine(0) as e:
             e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
