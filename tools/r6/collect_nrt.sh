@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 cd /root/repo
-for batch in "config3 config3_most config3_balanced" "config3_leastnuma config3_r8 config3_r8_balanced" "config5_share"; do
+for batch in "config3 config3_most config3_balanced" "config3_leastnuma config3_r8 config3_r8_balanced" "config5_share config2_lroc"; do
   rm -rf gpurun_out/prof_*
   /usr/local/graft/bin/gpurun --timeout 1500 -- "bash tools/prof_all.sh $batch 2>&1 | tail -4" 2>&1 | grep -E "status=" | tail -2
   python tools/collect_profiles.py r06 $batch 2>&1 | tail -4
