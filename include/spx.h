@@ -711,7 +711,8 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *   SPX_OPT_ROW_ALIGN          row padding of the result tables in bytes (multiple of 16; default 128)
  *   SPX_OPT_REFERENCE_KERNELS  bit mask of plugin ids whose sweep runs the reference-arithmetic ("generic") kernel instead of
  *                              the fast formulation: TLP and LVRB (one switch for both), NRT, NETOVERHEAD, LROC (int64 form)
- *   SPX_OPT_LROC_FLOAT64       1 = LowRiskOverCommitment in the float64 form (no float32 quotient)
+ *   SPX_OPT_LROC_FLOAT64       1 = LowRiskOverCommitment in the float64 form (no float32 quotient; that form also runs, whatever the
+ *                              option says, when a column holds a value from 2^47 or a limit below its request)
  *   SPX_OPT_DECIDE_UNFUSED     1 = spx_decide always runs spx_eval + spx_eval_best
  *   SPX_OPT_NRT_SINGLE_LAUNCH  1 = NRT Filter and Score in one launch (default: two for Least/MostAllocated)
  *   SPX_OPT_COMMIT_FROM_MEMORY 1 = spx_commit_sequential keeps node state in memory (any node count) instead of registers
@@ -763,10 +764,11 @@ int spx_last_eval_ms(spx_engine* e, float* ms);
  *                              per (swept pod row, tile of 1024 nodes — 512 with the value 8) whatever the chunking — 24 MB for 100 000 rows x
  *                              10 000 nodes, 240 MB for 500 000 x 20 000 — plus 96 bytes per node; a list that fills up falls back to one
  *                              "whole tile" entry, so the size bounds memory, not correctness
- *   SPX_OPT_NRT_FUSED          1 (default) = a whole-batch NodeResourceTopologyMatch sweep with the LeastAllocated strategy, unit weights and the
- *                              preconditions of SPX_OPT_NRT_RANK_FILTER and SPX_OPT_NRT_PACKED_SCORE runs Filter and Score in ONE launch
- *                              (kernels_nrt_fused.hip: rank-space Filter, float32 Score chain, pod records staged once); 0 = the Filter
- *                              launch and the Score launch.  Same tables either way
+ *   SPX_OPT_NRT_FUSED          1 (default) = a whole-batch NodeResourceTopologyMatch sweep runs Filter and Score in ONE launch
+ *                              (kernels_nrt_fused.hip: rank-space Filter, float32 Score, pod records staged once) for the Least- and
+ *                              MostAllocated strategies with unit weights under the preconditions of SPX_OPT_NRT_RANK_FILTER and
+ *                              SPX_OPT_NRT_PACKED_SCORE, and for BalancedAllocation with up to four resource slots (its undecided cells are
+ *                              recomputed in float64 by a second launch); 0 = the Filter launch and the Score launch.  Same tables either way
  */
 #define SPX_OPT_ROW_ALIGN 0
 #define SPX_OPT_REFERENCE_KERNELS 1
