@@ -979,14 +979,16 @@ bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
   }
   // five to eight resource slots: the Score's multipliers alone are 64 registers — 192 with the rest, two waves per SIMD, 2.25 ms for the
   // six-slot config #3 against 1.76 for the Filter-only walk + the packed Score launch (measured): those tables take the two launches
-  if (a.n_res > 4) return false;
+  // (BalancedAllocation's six-slot Score launch is the slow one — 6.6 ms at two waves per SIMD —: there the one-launch form at two waves wins)
+  if (a.n_res > 4 && !balanced) return false;
+  const bool wide = a.n_res > 4;
   for (int r = 0; r < a.n_res && !balanced; ++r)
     if (a.slot_weight[r] != 0 && a.slot_weight[r] != 1) return false;
   const int n_tiles = static_cast<int>((a.n_nodes + kWindow - 1) / kWindow);
   const int64_t chunks = a.rk_chunks;
   // the kernel's block map: 8 XCDs x their windows per chunk, or 8 chunks (one per XCD) x all windows
   const unsigned blocks = static_cast<unsigned>(n_tiles >= kXcdMapWindows ? chunks * (((n_tiles + 7) / 8) * 8) : ((chunks + 7) / 8) * 8 * n_tiles);
-  const size_t lds = static_cast<size_t>(a.rk_max_dwords) * 4 + static_cast<size_t>(kPodsPerUnit) * fz_pod_words<4>() * 4 +
+  const size_t lds = static_cast<size_t>(a.rk_max_dwords) * 4 + static_cast<size_t>(kPodsPerUnit) * (wide ? fz_pod_words<8>() : fz_pod_words<4>()) * 4 +
                      static_cast<size_t>(2) * (kPodsPerUnit / 4) * kWindow * 4 + 64;
   if (lds > 64 * 1024) return false;
   if (!balanced && a.pk_tab_slot >= 0 && !(a.pk_tab_built && *a.pk_tab_built)) {  // the table of the packed float32 Score (kernels_nrt_fast.hip)
@@ -1006,9 +1008,15 @@ bool launch_nrt_fused(const NrtArgs& a, hipStream_t s) {
     NrtArgs b = a;
     b.pk_tab_slot = -1;  // (no table slot: the walk's second pass and its flags stay idle)
     (void)hipMemsetAsync(a.redo_list, 0, 8, s);
-    if (a.fz_pack) hipLaunchKernelGGL((k_nrt_fused_pack<4>), dim3(pack_blocks), dim3(256), 0, s, b, a.fz_items);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<4, true, kFzBalanced>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    hipLaunchKernelGGL((k_nrt_fused<4, true, kFzBalanced>), dim3(blocks), dim3(256), lds, s, b, a.fz_items, n_tiles);
+    if (wide) {
+      if (a.fz_pack) hipLaunchKernelGGL((k_nrt_fused_pack<8>), dim3(pack_blocks), dim3(256), 0, s, b, a.fz_items);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<8, true, kFzBalanced>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      hipLaunchKernelGGL((k_nrt_fused<8, true, kFzBalanced>), dim3(blocks), dim3(256), lds, s, b, a.fz_items, n_tiles);
+    } else {
+      if (a.fz_pack) hipLaunchKernelGGL((k_nrt_fused_pack<4>), dim3(pack_blocks), dim3(256), 0, s, b, a.fz_items);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nrt_fused<4, true, kFzBalanced>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      hipLaunchKernelGGL((k_nrt_fused<4, true, kFzBalanced>), dim3(blocks), dim3(256), lds, s, b, a.fz_items, n_tiles);
+    }
     launch_nrt_bal_fixups(a, s);  // the listed cells in float64 (kernels_nrt_fast.hip)
   } else if (most) {
     if (first1) SPX_FZ_LAUNCH(4, true, kFzMost);

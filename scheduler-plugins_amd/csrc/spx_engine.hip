@@ -364,7 +364,7 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     // the fused Filter + Score launch (kernels_nrt_fused.hip): a whole-batch LeastAllocated sweep in the packed Score's preconditions with unit
     // weights; it walks the rank stream of the class representatives or, without classes, of every row
     // (BalancedAllocation, round 6b: the walk carries its float32 Score too — no packed-Score preconditions, its own list of cells for float64)
-    const bool fz_balanced = na.strategy == SPX_NRT_BALANCED_ALLOCATION && na.fast && !(na.opts & spx::kOptNrtGeneric) && !e->row_indirect && e->nrt_n_res <= 4;
+    const bool fz_balanced = na.strategy == SPX_NRT_BALANCED_ALLOCATION && na.fast && !(na.opts & spx::kOptNrtGeneric) && !e->row_indirect;
     bool fused = e->option[SPX_OPT_NRT_FUSED] && e->option[SPX_OPT_NRT_RANK_FILTER] && (na.pk_mode || fz_balanced) && !(na.opts & spx::kOptNrtSingleLaunch) &&
                  row_begin == 0 && row_end == e->n_pods;
     fused = fused && e->option[SPX_OPT_NRT_RANK_NARROW];  // (its only count layout)

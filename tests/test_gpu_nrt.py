@@ -321,7 +321,7 @@ def test_rank_filter_equals_float64_filter(gpu_required, hdr, oracle, wide, narr
     n_nodes, n_pods = 1500, 2500
     snap = synth.nrt_snapshot(hdr, n_nodes, n_pods, seed=31, wide=wide)
     # `fused` (SPX_OPT_NRT_FUSED): off, the Filter launch is k_nrt_filter_rank; on, the walk of kernels_nrt_fused.hip — Filter-only
-    # before the six-slot Score launch, or (four slots, narrow chunks) with BalancedAllocation's Score in the same launch (path 3)
+    # with BalancedAllocation's Score in the same launch (narrow chunks: path 3), or Filter-only before the Score launch
     params = O.nrt_params(hdr, O.Resources(), "BalancedAllocation")
     with Engine(0) as e:
         e.set_option("NRT_RANK_NARROW", narrow)
@@ -329,7 +329,7 @@ def test_rank_filter_equals_float64_filter(gpu_required, hdr, oracle, wide, narr
         e.load_nrt_objects(snap["nodes"], snap["nrt"], snap["rc"], snap["pods"], params)
         e.eval(mask_of(NRT))
         e.sync()
-        assert e.nrt_filter_path() == (3 if fused and narrow and not wide else 2)
+        assert e.nrt_filter_path() == (3 if fused and narrow else 2)
         ranked, score = e.all_status(NRT), e.all_scores(NRT)
         e.set_option("NRT_RANK_FILTER", 0)
         e.eval(mask_of(NRT))
@@ -368,8 +368,8 @@ def test_fused_sweep_equals_two_launches(gpu_required, hdr, oracle, wide, narrow
         # (the fused sweep has the four-zones-per-register layout only: with SPX_OPT_NRT_RANK_NARROW off the two launches run; and with five
         # to eight slots the one-launch form would hold two waves per SIMD: those tables run the same walk Filter-only + the packed Score launch)
         def path(cls):
-            if strategy == "BalancedAllocation" and wide:  # (no one-launch form for six slots, and no packed Score either: nothing asks for the every-row stream)
-                return 2 if cls else 1
+            if strategy == "BalancedAllocation":  # (one launch for six slots too: its two-launch Score is the slow one)
+                return 3 if narrow else (2 if cls else 1)
             return (2 if wide else 3) if narrow else (2 if cls else 1)
         assert e.nrt_filter_path() == path(classes)
         status, score = e.all_status(NRT), e.all_scores(NRT)
