@@ -531,22 +531,35 @@ __global__ __launch_bounds__(64 * kMaxRowWaves) void k_best(ProfileArgs a) {
   }
 }
 
-// Pod equivalence classes: the sweep evaluated one representative row per class; every other member's row is a copy.  One
-// workgroup per copied row and table, 16 bytes per lane; the representatives' rows are few and stay in L2.
-__global__ __launch_bounds__(256) void k_rows_expand(const int32_t* __restrict__ pairs, uint8_t* t0, uint8_t* t1, int64_t row_stride) {
-  const int64_t dst = pairs[2 * static_cast<int64_t>(blockIdx.x)], src = pairs[2 * static_cast<int64_t>(blockIdx.x) + 1];
+// Pod equivalence classes: the sweep evaluated one representative row per class; every other member's row is a copy.  A workgroup takes a
+// TASK — up to kExpandFan copies of one representative (the engine sorts the (row, representative) pairs by representative and cuts the runs:
+// expand_tasks, spx_engine.h) — reads the representative's row once, 16 bytes per lane and step, and writes it to each copy.  (Round 5 had a
+// workgroup per copied row: Peaks' 88 000 copies read their 12 000 representatives' 121 MB seven times over — 0.26 ms for 0.88 GB of copies.)
+constexpr int kExpandFan = kRowsExpandFan;
+__global__ __launch_bounds__(256) void k_rows_expand(const int32_t* __restrict__ pairs, const int32_t* __restrict__ tasks, uint8_t* t0, uint8_t* t1,
+                                                     int64_t row_stride) {
+  const int64_t first = tasks[2 * static_cast<int64_t>(blockIdx.x)];
+  const int count = tasks[2 * static_cast<int64_t>(blockIdx.x) + 1];
   uint8_t* t = blockIdx.y ? t1 : t0;
+  const int64_t src = pairs[2 * first + 1];
   const uint4* from = reinterpret_cast<const uint4*>(t + src * row_stride);
-  uint4* to = reinterpret_cast<uint4*>(t + dst * row_stride);
-  for (int64_t i = threadIdx.x; i < row_stride / 16; i += 256) to[i] = from[i];
+  uint4* to[kExpandFan];
+#pragma unroll
+  for (int j = 0; j < kExpandFan; ++j) to[j] = reinterpret_cast<uint4*>(t + static_cast<int64_t>(pairs[2 * (first + (j < count ? j : 0))]) * row_stride);
+  for (int64_t i = threadIdx.x; i < row_stride / 16; i += 256) {
+    const uint4 v = from[i];
+#pragma unroll
+    for (int j = 0; j < kExpandFan; ++j)
+      if (j < count) to[j][i] = v;  // block-uniform
+  }
 }
 
 }  // namespace
 
-void launch_rows_expand(const int32_t* pairs, int64_t n_pairs, uint8_t* t0, uint8_t* t1, int64_t row_stride, hipStream_t s) {
-  if (n_pairs <= 0 || (!t0 && !t1)) return;
+void launch_rows_expand(const int32_t* pairs, const int32_t* tasks, int64_t n_tasks, uint8_t* t0, uint8_t* t1, int64_t row_stride, hipStream_t s) {
+  if (n_tasks <= 0 || (!t0 && !t1)) return;
   if (!t0) t0 = t1, t1 = nullptr;
-  hipLaunchKernelGGL(k_rows_expand, dim3(static_cast<unsigned>(n_pairs), t1 ? 2 : 1), dim3(256), 0, s, pairs, t0, t1, row_stride);
+  hipLaunchKernelGGL(k_rows_expand, dim3(static_cast<unsigned>(n_tasks), t1 ? 2 : 1), dim3(256), 0, s, pairs, tasks, t0, t1, row_stride);
 }
 
 void launch_alloc_masked(const ProfileArgs& a, hipStream_t s) {

@@ -134,7 +134,7 @@ struct spx_engine {
   size_t h_items_bytes = 0;
   DevBuf d_delta;                // staged rows of a node-table delta (spx_update_*_nodes)
   DevBuf d_nrt_uniq, d_nrt_dups;  // int32 [n_uniq] representative rows, ascending; int32 [n_dups][2] (row, its representative)
-  int64_t nrt_n_uniq = 0, nrt_n_dups = 0;
+  int64_t nrt_n_uniq = 0, nrt_n_dups = 0, nrt_n_tasks = 0;  // (d_nrt_dups: the pairs sorted by representative, then the copy tasks — expand_tasks)
   DevBuf d_nrt_rk, d_nrt_rk_off;  // rank-space Filter: the chunk stream of the listed rows (nrt_build_rank_stream) and its chunk offsets
   uint32_t nrt_rk_max_dwords = 0;  // largest chunk block; 0 = no stream (the float64 Filter runs)
   // which rows the stream lists: 1 = the class representatives (d_nrt_uniq), 2 = every row in order (sweeps without pod classes:
@@ -157,7 +157,7 @@ struct spx_engine {
   } nrt_fz_key;
   int last_nrt_filter = 0;         // spx_nrt_filter_path
   DevBuf d_pk_uniq, d_pk_dups;    // the same for Peaks: classes of pods with equal cpu requests
-  int64_t pk_n_uniq = 0, pk_n_dups = 0;
+  int64_t pk_n_uniq = 0, pk_n_dups = 0, pk_n_tasks = 0;
   bool pk_negative = false;  // a Peaks pod row with a negative cpu request (never from a v1.Pod): the interval estimate's bounds assume >= 0
   bool nrt_ln_ok = false;  // LeastNUMANodes tables can be built: every zone cost within [0, 255]
   bool nrt_ln_built = false;
@@ -637,6 +637,26 @@ int upload_transposed(spx_engine* e, DevBuf& b, const T* src, int64_t n, int64_t
   if (rc) return rc;
   SPX_HIP(e, hipStreamSynchronize(e->stream));  // tmp dies at scope exit
   return SPX_OK;
+}
+
+// The (row, representative) pairs of a pod batch's equivalence classes as launch_rows_expand reads them: sorted by representative (then row), and
+// behind them the copy tasks — (first pair, count <= kRowsExpandFan) per run of pairs with one representative — so that a workgroup reads a
+// representative's row once for up to eight copies.  Returns the task count; `dups` = [pairs | tasks].
+inline int64_t expand_tasks(std::vector<int32_t>& dups) {
+  const size_t n = dups.size() / 2;
+  std::vector<int64_t> key(n);
+  for (size_t i = 0; i < n; ++i) key[i] = (static_cast<int64_t>(dups[2 * i + 1]) << 32) | static_cast<uint32_t>(dups[2 * i]);
+  std::sort(key.begin(), key.end());
+  for (size_t i = 0; i < n; ++i) dups[2 * i] = static_cast<int32_t>(key[i] & 0xffffffff), dups[2 * i + 1] = static_cast<int32_t>(key[i] >> 32);
+  int64_t tasks = 0;
+  for (size_t i = 0; i < n;) {
+    size_t j = i;
+    while (j < n && j - i < static_cast<size_t>(spx::kRowsExpandFan) && dups[2 * j + 1] == dups[2 * i + 1]) ++j;
+    dups.push_back(static_cast<int32_t>(i)), dups.push_back(static_cast<int32_t>(j - i));
+    ++tasks;
+    i = j;
+  }
+  return tasks;
 }
 
 }  // namespace

@@ -442,7 +442,8 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     const bool ran_fused = spx::launch_nrt(na, e->stream);
     e->last_nrt_filter = ran_fused ? 3 : (na.rk_stream ? 2 : 1);
     if (classes)
-      spx::launch_rows_expand(static_cast<const int32_t*>(e->d_nrt_dups.p), e->nrt_n_dups, na.out_status, na.out_score, e->row_stride, e->stream);
+      spx::launch_rows_expand(static_cast<const int32_t*>(e->d_nrt_dups.p), static_cast<const int32_t*>(e->d_nrt_dups.p) + 2 * e->nrt_n_dups, e->nrt_n_tasks, na.out_status, na.out_score,
+                              e->row_stride, e->stream);
     SPX_HIP(e, hipGetLastError());
   }
   if (W) {
@@ -509,7 +510,8 @@ int spx_eval(spx_engine* e, uint32_t plugin_mask, int64_t row_begin, int64_t row
     }
     spx::launch_peaks(ka, e->stream);
     if (classes)
-      spx::launch_rows_expand(static_cast<const int32_t*>(e->d_pk_dups.p), e->pk_n_dups, ka.out_score, nullptr, e->row_stride, e->stream);
+      spx::launch_rows_expand(static_cast<const int32_t*>(e->d_pk_dups.p), static_cast<const int32_t*>(e->d_pk_dups.p) + 2 * e->pk_n_dups, e->pk_n_tasks, ka.out_score, nullptr,
+                              e->row_stride, e->stream);
     SPX_HIP(e, hipGetLastError());
   }
   if (A && masked && !e->skip_alloc_masked && !alloc_by_net) {

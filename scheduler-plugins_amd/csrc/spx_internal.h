@@ -658,10 +658,12 @@ struct ProfileArgs {
   int32_t block_per_row;  // set by the launchers: a whole workgroup per row in a batch launch too (rows too wide for kRowsPerBlock LDS shares)
 };
 void launch_alloc_masked(const ProfileArgs& a, hipStream_t s);
-// copies row pairs[2i+1] to row pairs[2i] in up to two uint8 tables of row_stride bytes per row (NULL = skip)
+// copies row pairs[2i+1] to row pairs[2i] in up to two uint8 tables of row_stride bytes per row (NULL = skip); tasks[2k], tasks[2k+1] = first pair and
+// number of pairs (<= kRowsExpandFan) of a run of pairs that share their source row (expand_tasks, spx_engine.h)
 // BalancedAllocation: the cells a float32 Score launch listed in NrtArgs::redo_list, recomputed in float64 (k_nrt_bal_scan + k_nrt_bal_redo, kernels_nrt_fast.hip)
 void launch_nrt_bal_fixups(const NrtArgs& a, hipStream_t s);
-void launch_rows_expand(const int32_t* pairs, int64_t n_pairs, uint8_t* t0, uint8_t* t1, int64_t row_stride, hipStream_t s);
+constexpr int kRowsExpandFan = 8;
+void launch_rows_expand(const int32_t* pairs, const int32_t* tasks, int64_t n_tasks, uint8_t* t0, uint8_t* t1, int64_t row_stride, hipStream_t s);
 void launch_best(const ProfileArgs& a, hipStream_t s);
 // spx_decide with Filter plugins in the mask: Allocatable's feasibility-aware normalisation and the weighted argmax in one kernel
 // (no Allocatable table).  decide_masked_ok: weights fit the 32-bit totals and the rows the 16-byte tiles; the caller also needs

@@ -433,11 +433,13 @@ int spx_upload_peaks_pods(spx_engine* e, const spx_peaks_pods_soa* t) {
       else dups.push_back(static_cast<int32_t>(i)), dups.push_back(tab[k]);
     }
     if (!dups.empty()) {
+      const int64_t n_dups = static_cast<int64_t>(dups.size() / 2), n_tasks = expand_tasks(dups);
       if ((rc = upload(e, e->d_pk_uniq, uniq.data(), uniq.size() * sizeof(int32_t)))) return rc;
       if ((rc = upload(e, e->d_pk_dups, dups.data(), dups.size() * sizeof(int32_t)))) return rc;
       SPX_HIP(e, hipStreamSynchronize(e->stream));  // the vectors go out of scope
       e->pk_n_uniq = static_cast<int64_t>(uniq.size());
-      e->pk_n_dups = static_cast<int64_t>(dups.size() / 2);
+      e->pk_n_dups = n_dups;
+      e->pk_n_tasks = n_tasks;
     }
   }
   e->peaks_pods = true;
@@ -888,11 +890,13 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
         else dups.push_back(static_cast<int32_t>(i)), dups.push_back(rep[i]);
       }
       if (!dups.empty()) {
+        const int64_t n_dups = static_cast<int64_t>(dups.size() / 2), n_tasks = expand_tasks(dups);
         if ((rc = upload(e, e->d_nrt_uniq, uniq.data(), uniq.size() * sizeof(int32_t)))) return rc;
         if ((rc = upload(e, e->d_nrt_dups, dups.data(), dups.size() * sizeof(int32_t)))) return rc;
         SPX_HIP(e, hipStreamSynchronize(e->stream));
         e->nrt_n_uniq = static_cast<int64_t>(uniq.size());
-        e->nrt_n_dups = static_cast<int64_t>(dups.size() / 2);
+        e->nrt_n_dups = n_dups;
+        e->nrt_n_tasks = n_tasks;
         // the representatives' requests as ranks, per chunk of up to 32 (kernels_nrt_rank.hip, kernels_nrt_fused.hip)
         if ((rc = nrt_rank_stream_upload(e, items, uniq.data(), uniq.size(), 1))) return rc;
       }
