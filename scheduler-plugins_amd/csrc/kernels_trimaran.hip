@@ -723,7 +723,7 @@ __global__ void k_lvrb_prepare(TrimaranArgs a) {
 __global__ void k_lvrb_prepare_fast(TrimaranArgs a, int64_t n_slots) {
   const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (n >= n_slots) return;
-  float4 v0{0.0f, 0.0f, 0.0f, 0.0f}, v1{0.0f, 0.0f, 1.0f, 0.0f};
+  float4 v0{0.0f, 0.0f, 0.0f, 0.0f}, v1{0.0f, 0.0f, __builtin_inff(), 0.0f};
   if (n < a.n_nodes) {
     const uint8_t f = a.lv_flags[n];
     const bool has = (f & SPX_LV_HAS_METRICS) != 0;
@@ -747,9 +747,11 @@ __global__ void k_lvrb_prepare_fast(TrimaranArgs a, int64_t n_slots) {
     float ca, cb, cc, ma, mb, mc;
     consts(c, &ca, &cb, &cc);
     consts(m, &ma, &mb, &mc);
-    const float sgn = (has && c.state != 0 && m.state != 0) ? -1.0f : 1.0f;
+    // both resources valid: the reference takes the min of the two scores, else the max (loadvariationriskbalancing.go:112-116) — the
+    // sweep's v_med3_f32(x_cpu, x_mem, L) with L = -inf / +inf (round 6b; before: a per-node sign on A and on the result)
+    const float pick = (has && c.state != 0 && m.state != 0) ? -__builtin_inff() : __builtin_inff();
     v0 = float4{cb, mb, cc, mc};
-    v1 = float4{sgn * ca, sgn * ma, sgn, 0.0f};
+    v1 = float4{ca, ma, pick, 0.0f};
   }
   float4* out = reinterpret_cast<float4*>(a.lv_fast) + tile_slot<kLvNpl>(n) * 2;
   out[0] = v0;
@@ -839,11 +841,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
   const int cpu_bits = __float_as_int(my_cpu), mem_bits = __float_as_int(my_mem);
 
   uint32_t alloc_w[NPL / 4];
-  // per node, (cpu, memory) pairs for v_pk_fma_f32: slope B, offset C = B*usedAvg, and s*A with s = -1 when both
-  // resources are valid (the reference takes the min of the two scores then) and +1 otherwise (max):
-  //   min(xc, xm) = -max(-xc, -xm), so with y_r = s*(A_r - clamp_r) the cell is x = s*max(y_c, y_m) and rint(x) = s*rint(y)
-  F32x2 kb[NPL], kc[NPL], ksa[NPL];
-  float ks[NPL], k50[NPL];  // s, and -50 s (the clamp is 0..1 since round 6: y_r = s A_r - 50 s clamp01(B'_r q + C'_r))
+  // per node, (cpu, memory) pairs for v_pk_fma_f32: slope B, offset C = B*usedAvg (of t / 50: the clamp is the fma's 0..1), A; and L = -inf
+  // when both resources are valid (the reference takes the min of the two scores then), +inf otherwise (max):
+  //   x_r = A_r - 50 clamp01(B_r q + C_r),  x = v_med3_f32(x_cpu, x_mem, L)   — one instruction and one register per node fewer than the
+  //   per-node sign of rounds 2-6a (y_r = s x_r, x = s max(y_cpu, y_mem)); the same float32 values: an fma is odd in its sign
+  F32x2 kb[NPL], kc[NPL], ka[NPL];
+  float kl[NPL];
   if constexpr (A) {
 #pragma unroll
     for (int j = 0; j < NPL / 4; ++j) alloc_w[j] = active ? reinterpret_cast<const uint32_t*>(a.alloc_norm + node0)[j] : 0u;
@@ -856,9 +859,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
       const float4 v0 = tab[static_cast<int64_t>(j) * kWave * 2], v1 = tab[static_cast<int64_t>(j) * kWave * 2 + 1];
       kb[j] = F32x2{v0.x, v0.y};
       kc[j] = F32x2{v0.z, v0.w};
-      ksa[j] = F32x2{v1.x, v1.y};
-      ks[j] = v1.z;
-      k50[j] = -50.0f * v1.z;
+      ka[j] = F32x2{v1.x, v1.y};
+      kl[j] = v1.z;
     }
   }
   constexpr float kHalf = 0.5f - kTolLv;  // (no early exit: see k_tlp_fast2)
@@ -874,14 +876,15 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
     const bool row_bad = __builtin_amdgcn_readlane(my_bad, r) != 0;
     bool any = row_bad;
     uint32_t w[NPL / 4];
-    // one cell: y = s*x (see above), its rounding, and the distance to the rounding tie
-    auto cell = [&](int i, const F32x2& req, float* ry) -> float {
+    // one cell: x, its rounding, and the distance to the rounding tie
+    const F32x2 m50{-50.0f, -50.0f};
+    auto cell = [&](int i, const F32x2& req, float* rx) -> float {
       const F32x2 cl{__builtin_amdgcn_fmed3f(__builtin_fmaf(kb[i].x, req.x, kc[i].x), 0.0f, 1.0f),   // v_fma_f32 .. clamp, full rate
                      __builtin_amdgcn_fmed3f(__builtin_fmaf(kb[i].y, req.y, kc[i].y), 0.0f, 1.0f)};
-      const F32x2 y2 = __builtin_elementwise_fma(F32x2{k50[i], k50[i]}, cl, ksa[i]);
-      const float y = __builtin_fmaxf(y2.x, y2.y);
-      *ry = __builtin_rintf(y);
-      return __builtin_fabsf(y - *ry);
+      const F32x2 x2 = __builtin_elementwise_fma(m50, cl, ka[i]);
+      const float x = __builtin_amdgcn_fmed3f(x2.x, x2.y, kl[i]);
+      *rx = __builtin_rintf(x);
+      return __builtin_fabsf(x - *rx);
     };
     const F32x2 req2{req_cpu, req_mem};
     const bool row_slow = !AMB || __builtin_amdgcn_readlane(my_slow, r) != 0;  // wave-uniform
@@ -895,8 +898,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
           const int i = j * 4 + q;
           const F32x2 cl{__builtin_amdgcn_fmed3f(__builtin_fmaf(kb[i].x, req2.x, kc[i].x), 0.0f, 1.0f),
                          __builtin_amdgcn_fmed3f(__builtin_fmaf(kb[i].y, req2.y, kc[i].y), 0.0f, 1.0f)};
-          const F32x2 y2 = __builtin_elementwise_fma(F32x2{k50[i], k50[i]}, cl, ksa[i]);
-          acc = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(y2.x, y2.y) * ks[i], q, acc);
+          const F32x2 x2 = __builtin_elementwise_fma(m50, cl, ka[i]);
+          acc = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(x2.x, x2.y, kl[i]), q, acc);
         }
         w[j] = acc;
       }
@@ -910,9 +913,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_lvrb_fast(TrimaranArg
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = j * 4 + q;
-        float ry;
-        worst = __builtin_fmaxf(worst, cell(i, req2, &ry));
-        acc = __builtin_amdgcn_cvt_pk_u8_f32(ry * ks[i], q, acc);
+        float rx;
+        worst = __builtin_fmaxf(worst, cell(i, req2, &rx));
+        acc = __builtin_amdgcn_cvt_pk_u8_f32(rx, q, acc);
       }
       w[j] = acc;
     }
