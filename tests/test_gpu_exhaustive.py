@@ -194,9 +194,11 @@ def test_config3_six_slots_every_cell(gpu_required, hdr, oracle, strategy):
         assert 0.01 * n_nodes * n_pods < rejected < 0.9 * n_nodes * n_pods
 
 
-def test_config4_every_cell(gpu_required, hdr, oracle):
-    n_nodes, n_pods = 10_000, 200_000
-    snap = synth.network_snapshot(hdr, n_nodes, n_pods)
+@pytest.mark.parametrize("n_nodes,n_pods,seed", [(10_000, 200_000, synth.SEED), (5_000, 100_000, 7), (5_000, 100_000, 20261004)],
+                         ids=["full", "quarter-seed7", "quarter-seed20261004"])
+def test_config4_every_cell(gpu_required, hdr, oracle, n_nodes, n_pods, seed):
+    """config #4 at its full size, and two other snapshots (nodes, AppGroups, topology, pods all reseeded) at a quarter of its cells"""
+    snap = synth.network_snapshot(hdr, n_nodes, n_pods, seed=seed)
     with Engine(0) as e:
         e.load_network_objects(snap["nodes"], snap["pods"], snap["appgroups"], snap["nettopo"])
         assert e.kernel_path(NETOVERHEAD) == 1
@@ -214,12 +216,14 @@ def test_config4_every_cell(gpu_required, hdr, oracle):
         assert rejected > 0
 
 
-def test_config5_share_every_cell(gpu_required, hdr, oracle):
+@pytest.mark.parametrize("n_nodes,n_pods,seed", [(20_000, 62_500, synth.SEED), (10_000, 31_250, 7), (10_000, 31_250, 20261004)],
+                         ids=["share", "quarter-seed7", "quarter-seed20261004"])
+def test_config5_share_every_cell(gpu_required, hdr, oracle, n_nodes, n_pods, seed):
     """the one-GPU share of config #5 (20k nodes x 62.5k of the 500k pods), full plugin set: Filter tables, the
     non-normalising scores, NetworkOverhead normalised over the nodes that passed NRT, Allocatable normalised over the nodes
-    that passed both Filters, CapacityScheduling.PreFilter, and the per-pod weighted argmax with its tie set"""
-    n_nodes, n_pods = 20_000, 62_500
-    snap = synth.full_snapshot(hdr, n_nodes, n_pods)
+    that passed both Filters, CapacityScheduling.PreFilter, and the per-pod weighted argmax with its tie set.  Round 6: the same on
+    two other snapshots (every table of the profile reseeded) at a quarter of the share's cells"""
+    snap = synth.full_snapshot(hdr, n_nodes, n_pods, seed=seed)
     params = O.nrt_params(hdr, O.Resources(), "LeastAllocated")
     weights = {ALLOCATABLE: 1, TLP: 2, LVRB: 1, NRT: 3, NETOVERHEAD: 2}
     allp = (ALLOCATABLE, TLP, LVRB, NRT, NETOVERHEAD, CAPACITY)
