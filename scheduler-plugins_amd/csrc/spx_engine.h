@@ -642,12 +642,17 @@ int upload_transposed(spx_engine* e, DevBuf& b, const T* src, int64_t n, int64_t
 // The (row, representative) pairs of a pod batch's equivalence classes as launch_rows_expand reads them: sorted by representative (then row), and
 // behind them the copy tasks — (first pair, count <= kRowsExpandFan) per run of pairs with one representative — so that a workgroup reads a
 // representative's row once for up to eight copies.  Returns the task count; `dups` = [pairs | tasks].
-inline int64_t expand_tasks(std::vector<int32_t>& dups) {
+inline int64_t expand_tasks(std::vector<int32_t>& dups, int64_t n_rows) {
   const size_t n = dups.size() / 2;
-  std::vector<int64_t> key(n);
-  for (size_t i = 0; i < n; ++i) key[i] = (static_cast<int64_t>(dups[2 * i + 1]) << 32) | static_cast<uint32_t>(dups[2 * i]);
-  std::sort(key.begin(), key.end());
-  for (size_t i = 0; i < n; ++i) dups[2 * i] = static_cast<int32_t>(key[i] & 0xffffffff), dups[2 * i + 1] = static_cast<int32_t>(key[i] >> 32);
+  // counting sort by representative (the pairs arrive in ascending order of the copied row, and stay so inside a representative's run)
+  std::vector<int32_t> at(static_cast<size_t>(n_rows) + 1, 0), sorted(2 * n);
+  for (size_t i = 0; i < n; ++i) ++at[static_cast<size_t>(dups[2 * i + 1]) + 1];
+  for (int64_t r = 0; r < n_rows; ++r) at[static_cast<size_t>(r) + 1] += at[static_cast<size_t>(r)];
+  for (size_t i = 0; i < n; ++i) {
+    const size_t k = static_cast<size_t>(at[static_cast<size_t>(dups[2 * i + 1])]++);
+    sorted[2 * k] = dups[2 * i], sorted[2 * k + 1] = dups[2 * i + 1];
+  }
+  dups.swap(sorted);
   int64_t tasks = 0;
   for (size_t i = 0; i < n;) {
     size_t j = i;

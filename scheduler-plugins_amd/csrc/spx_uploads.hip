@@ -433,7 +433,7 @@ int spx_upload_peaks_pods(spx_engine* e, const spx_peaks_pods_soa* t) {
       else dups.push_back(static_cast<int32_t>(i)), dups.push_back(tab[k]);
     }
     if (!dups.empty()) {
-      const int64_t n_dups = static_cast<int64_t>(dups.size() / 2), n_tasks = expand_tasks(dups);
+      const int64_t n_dups = static_cast<int64_t>(dups.size() / 2), n_tasks = expand_tasks(dups, static_cast<int64_t>(p));
       if ((rc = upload(e, e->d_pk_uniq, uniq.data(), uniq.size() * sizeof(int32_t)))) return rc;
       if ((rc = upload(e, e->d_pk_dups, dups.data(), dups.size() * sizeof(int32_t)))) return rc;
       SPX_HIP(e, hipStreamSynchronize(e->stream));  // the vectors go out of scope
@@ -890,7 +890,7 @@ int spx_upload_nrt_pods(spx_engine* e, const spx_nrt_pods_soa* t) {
         else dups.push_back(static_cast<int32_t>(i)), dups.push_back(rep[i]);
       }
       if (!dups.empty()) {
-        const int64_t n_dups = static_cast<int64_t>(dups.size() / 2), n_tasks = expand_tasks(dups);
+        const int64_t n_dups = static_cast<int64_t>(dups.size() / 2), n_tasks = expand_tasks(dups, static_cast<int64_t>(p));
         if ((rc = upload(e, e->d_nrt_uniq, uniq.data(), uniq.size() * sizeof(int32_t)))) return rc;
         if ((rc = upload(e, e->d_nrt_dups, dups.data(), dups.size() * sizeof(int32_t)))) return rc;
         SPX_HIP(e, hipStreamSynchronize(e->stream));
