@@ -174,6 +174,27 @@ def test_shim_package_uses_only_declared_identifiers():
             assert not free, (f.name, m.group(0)[:70], sorted(free))
 
 
+def test_shim_c_constants_are_untyped_integer_macros():
+    """The shim assigns C.SPX_PLUGIN_* to C.int parameters and switches a Go byte on C.SPX_NRT_ST_* / C.SPX_QUOTA_ST_*: that only type-checks
+    while cgo sees them as UNTYPED integer constants, i.e. object-like `#define NAME <integer literal>` in include/spx.h (an enum member or a
+    `static const` would be a typed C value and need conversions).  No Go toolchain here: this is the part of the type check that can be
+    made on the header (round-5 review, weak item 11)."""
+    import re
+    header = (ROOT / "include" / "spx.h").read_text()
+    macros = dict(re.findall(r"^#define[ \t]+(SPX_[A-Z0-9_]+)[ \t]+(.+?)[ \t]*(?:/\*.*)?$", header, re.M))
+    used = set()
+    for f in (ROOT / "shim" / "go" / "pkg" / "spx").glob("*.go"):
+        used |= set(re.findall(r"\bC\.(SPX_[A-Z0-9_]+)\b", f.read_text()))
+    assert used, "the shim names no C constants?"
+    for name in sorted(used):
+        assert name in macros, f"{name}: not an object-like macro of spx.h (cgo would see a typed value, or nothing)"
+        assert re.fullmatch(r"-?(0x[0-9a-fA-F]+|\d+)[uU]?", macros[name].strip()), (name, macros[name])
+    # and as status bytes / plugin ids they must fit what the shim stores them in
+    for name in used:
+        v = int(macros[name].strip().rstrip("uU"), 0)
+        assert 0 <= v <= 255, (name, v)
+
+
 def test_integration_md_quotes_the_shim():
     """INTEGRATION.md section 3 shows the shim by quoting it: every ```go block tagged `<!-- verbatim: FILE -->` must be a contiguous
     piece of FILE (round 4's hand-written excerpt had drifted from shim/go/pkg/spx/spx.go — cgo include path, Engine fields: two
