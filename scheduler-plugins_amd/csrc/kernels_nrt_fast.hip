@@ -1044,7 +1044,8 @@ __global__ __launch_bounds__(1024) void k_nrt_ln_longest(NrtArgs a) {
 }
 
 template <int RM>
-__global__ __launch_bounds__(256, RM == 4 ? 2 : 1) void k_nrt_ln_redo(NrtArgs a) {
+// (round 6: bounded to three waves per SIMD for <= 4 slots — 168 VGPRs, 18 of 196 spilled outside the search —: 3.32 -> 3.16 ms at config #3)
+__global__ __launch_bounds__(256, RM == 4 ? 3 : 1) void k_nrt_ln_redo(NrtArgs a) {
   SPX_RESOLVE_ROWS(a);
   __shared__ __align__(4) uint8_t ln_subset[kLnDwords * 32];
   __shared__ uint32_t ln_allow[256 * kLnDwords];
@@ -1217,7 +1218,7 @@ bool launch_nrt_fast(const NrtArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore, SGV == kSgLeastNuma ? kLnDefer : kLnFull>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
         hipLaunchKernelGGL(k_nrt_ln_longest, dim3(1), dim3(1024), 0, s, a); \
         hipLaunchKernelGGL((k_nrt_ln_pack<RMV>), dim3(static_cast<unsigned>((a.n_nodes + 255) / 256)), dim3(256), 0, s, a); \
-        hipLaunchKernelGGL((k_nrt_ln_redo<RMV>), dim3(2048), dim3(256), 0, s, a); /* persistent waves */ \
+        hipLaunchKernelGGL((k_nrt_ln_redo<RMV>), dim3(RMV == 4 ? 8192 : 2048), dim3(256), 0, s, a); /* persistent waves; the units' costs differ by the pod: 768 / 2048 / 6144 / 12288 / 49152 workgroups 3.52 / 3.17 / 2.92 / 2.93 / 3.24 ms */ \
         hipLaunchKernelGGL((k_nrt_fast<RMV, SGV, kPhScore, SGV == kSgLeastNuma ? kLnIfOverflow : kLnFull>), dim3(blocks), dim3(256), 0, s, a, n_tiles);  \
       } else { \
         if (SGV == kSgLeast && a.pk_mode && a.pk_tab_slot >= 0 && !(a.pk_tab_built && *a.pk_tab_built)) { /* the table of the packed float32 Score */ \
